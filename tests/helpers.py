@@ -1,0 +1,46 @@
+"""Shared test helpers (fixture loading, parity metric)."""
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+def sd_from(npz, prefix="sd/"):
+    return {k[len(prefix):]: torch.from_numpy(npz[k].copy()) for k in npz.files if k.startswith(prefix)}
+
+
+def grads_from(npz, prefix="grad/"):
+    return {k[len(prefix):]: torch.from_numpy(npz[k].copy()) for k in npz.files if k.startswith(prefix)}
+
+
+def rel_inf(a, b):
+    """SURVEY.md §8d parity metric: ||a-b||_inf / ||b||_inf (never per-element relative error)."""
+    a = torch.as_tensor(a, dtype=torch.float64).reshape(-1)
+    b = torch.as_tensor(b, dtype=torch.float64).reshape(-1)
+    denom = b.abs().max().item()
+    return (a - b).abs().max().item() / (denom if denom > 0 else 1.0)
+
+
+def flat_grads(named, keys):
+    return torch.cat([named[k].reshape(-1).double() for k in keys])
+
+
+def density_inputs(npz):
+    """Rebuild the symmetrised, (row,col)-sorted density graph from the stored u<v pairs."""
+    und = npz["und_pairs"].astype(np.int64)
+    n = int(npz["n_node"])
+    ei = np.concatenate([und, und[::-1]], axis=1)
+    order = np.argsort(ei[0] * n + ei[1], kind="stable")
+    ei = torch.from_numpy(ei[:, order].copy())
+    ew = torch.ones(ei.shape[1])
+    x = torch.from_numpy(npz["x"].astype(np.int64)).reshape(n, 1, 1)
+    pos = torch.from_numpy(npz["pos"].astype(np.int64))
+    y = torch.from_numpy(npz["y"].astype(np.int64))
+    z = torch.from_numpy(npz["z"].astype(np.int64))
+    return n, ei, ew, x, pos, y, z
