@@ -1,0 +1,81 @@
+"""ctypes binding of libglass_hip.so (the C ABI declared in include/glass_hip.h).
+
+The library is built in-tree by `make -C glass_amd/csrc` (or `__graft_entry__.build()`); the
+`.so` sits next to this file so it travels to the GPU box with the repo snapshot.  There is no
+fallback: if the library is missing, or a call fails, a GlassHipError is raised.
+"""
+import ctypes
+import os
+
+# torch MUST be imported before libglass_hip.so is opened: torch bundles its own HIP runtime with
+# the same SONAME (libamdhip64.so.7) as /opt/rocm's.  Loaded first, it is the one runtime both torch
+# and this library use (one set of streams and device pointers); loaded second, the process would
+# hold two runtimes and every launch here would fail with "no ROCm-capable device".
+import torch  # noqa: F401
+from ctypes import c_void_p, c_int, c_int64, c_uint64, c_float, c_double, c_char_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libglass_hip.so")
+
+POOL_MODES = {"sum": 0, "mean": 1, "max": 2, "size": 3}
+AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
+ACT_NONE, ACT_ELU = 0, 1
+PLAN_HEADER_WORDS = 16
+ABI_VERSION = 1
+
+
+class GlassHipError(RuntimeError):
+    pass
+
+
+_P = c_void_p
+_I = c_int64
+# name -> (restype, argtypes); mirrors include/glass_hip.h one to one
+SIGNATURES = {
+    "glass_version": (c_int, []),
+    "glass_last_error_string": (c_char_p, []),
+    "glass_spmm_plan_build": (c_int, [_P, _I, _P, POINTER(c_int64)]),
+    "glass_spmm_ws_bytes": (c_int64, [_P, _I]),
+    "glass_spmm_csr_f32": (c_int, [_P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P]),
+    "glass_adj_values_f32": (c_int, [_P, _P, _P, _I, c_int, _P, _P, _P]),
+    "glass_maxzoz_i64": (c_int, [_P, _I, _P, _I, _P]),
+    "glass_embed_label_f32": (c_int, [_P, _P, _I, _P, _P, _I, _P, _I, _P, _I, _I, _P]),
+    "glass_mix_fwd_f32": (c_int, [_P, _I, _P, c_double, c_int, _P, _I, _I, _I, _P]),
+    "glass_mix_bwd_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _I, _I, _P]),
+    "glass_graphnorm_ws_bytes": (c_int64, [_I, _I]),
+    "glass_graphnorm_fwd_f32": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P, c_float, _P, c_int, c_float, _P, c_uint64,
+                                        _P, _P]),
+    "glass_graphnorm_bwd_f32": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, c_int, c_float, _P,
+                                        c_uint64, _P, _P]),
+    "glass_rng_advance": (c_int, [_P, _P]),
+    "glass_segment_pool_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _I, _P, _I, _I, _P]),
+    "glass_segment_pool_bwd_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _P, _I, _I, _I, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GlassHipError(f"{LIB_PATH} not found: build it with `make -C glass_amd/csrc` "
+                            "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.glass_version()
+    if v != ABI_VERSION:
+        raise GlassHipError(f"libglass_hip ABI version {v}, expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().glass_last_error_string().decode(errors="replace")
+        raise GlassHipError(f"{what} failed (rc={rc}): {msg}")

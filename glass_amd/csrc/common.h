@@ -1,0 +1,80 @@
+// Shared host/device helpers for libglass_hip (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/glass_hip.h"
+
+namespace glass {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;  // 4 waves: one per SIMD of a CU
+
+void set_error(const char* fmt, ...);
+
+// Every launch function ends with this: report a launch failure without synchronising.
+inline int launch_status(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}
+
+#define GLASS_REQUIRE(cond, ...)        \
+    do {                                \
+        if (!(cond)) {                  \
+            glass::set_error(__VA_ARGS__); \
+            return GLASS_E_ARG;         \
+        }                               \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Smallest power of two >= v (v >= 1), capped at `cap`.
+inline int pow2_ceil_cap(int64_t v, int cap) {
+    int p = 1;
+    while (p < v && p < cap) p <<= 1;
+    return p;
+}
+
+// ---- device helpers ------------------------------------------------------------------------
+__device__ __forceinline__ float elu_f(float h) { return h > 0.f ? h : expm1f(h); }
+__device__ __forceinline__ float elu_grad_f(float h) { return h > 0.f ? 1.f : __expf(h); }
+
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so the backward regenerates the forward's
+// dropout mask from (seed, step, call_id, element) instead of storing it.
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+    uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+    uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+    uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+// Four uniform 32-bit words for 128-bit counter (idx, call_id) under key (seed ^ step mix).
+__device__ __forceinline__ void philox4(uint64_t seed, uint64_t step, uint64_t call_id, uint64_t idx,
+                                        uint32_t (&out)[4]) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)call_id, (uint32_t)step};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(step >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+}
+
+// keep-scale of element (row, 4-column group): 4 consecutive columns share one Philox call.
+__device__ __forceinline__ float keep_scale(uint32_t word, float p_drop, float inv_keep) {
+    // uniform in [0,1) from the top 24 bits
+    float u = (float)(word >> 8) * (1.0f / 16777216.0f);
+    return u >= p_drop ? inv_keep : 0.f;
+}
+
+}  // namespace glass

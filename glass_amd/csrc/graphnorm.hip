@@ -1,0 +1,497 @@
+// K6: whole-graph GraphNorm (+ optional ELU + inverted dropout) forward and backward.
+// Replaces PyG GraphNorm(batch=None) as called at reference impl/models.py:165,249,257,266,271
+// and the F.dropout / activation that follow it (impl/models.py:166,251,258-259).
+//
+// HBM-bound column reductions + elementwise passes over a row-major [N,C] matrix:
+//   forward : 1 read (fp64 sum / sum-of-squares per column) + 1 read + 1 write
+//   backward: 2 reads (dy, x) for the two column sums + 2 reads + 1 write
+// Thread layout: TC lanes x 16 B cover a row (coalesced), 256/TC rows per workgroup step,
+// 4 rows in flight per thread.  Column sums are fp64, combined across row slots through LDS and
+// across workgroups by a second tiny kernel in fixed order -> bitwise repeatable.
+#include "common.h"
+
+namespace glass {
+
+constexpr int kUnroll = 4;
+constexpr int kMaxStatBlocks = 1024;
+
+struct Tiling {
+    int vw;       // floats per access (4 if everything is 16-B aligned, else 1)
+    int cw;       // column words = ceil(C / vw)
+    int tc;       // lanes across columns (power of two <= 256)
+    int tc_log2;
+    int rpb;      // rows per workgroup step = 256 / tc
+    int ctiles;   // grid.y
+};
+
+static Tiling make_tiling(int64_t C, bool vec_ok) {
+    Tiling t;
+    t.vw = vec_ok ? 4 : 1;
+    t.cw = (int)ceil_div(C, t.vw);
+    t.tc = pow2_ceil_cap(t.cw, kBlock);
+    t.tc_log2 = 0;
+    while ((1 << t.tc_log2) < t.tc) ++t.tc_log2;
+    t.rpb = kBlock / t.tc;
+    t.ctiles = (int)ceil_div(t.cw, t.tc);
+    return t;
+}
+
+static int stat_blocks(int64_t n_rows, const Tiling& t) {
+    int64_t b = ceil_div(n_rows, (int64_t)t.rpb * kUnroll * 2);
+    if (b < 1) b = 1;
+    if (b > kMaxStatBlocks) b = kMaxStatBlocks;
+    return (int)b;
+}
+
+// scratch: [kMaxStatBlocks][2][C] doubles (column partials) + [4][C] floats (backward coefficients)
+static int64_t ws_partials_bytes(int64_t C) { return (int64_t)kMaxStatBlocks * 2 * C * (int64_t)sizeof(double); }
+
+template <int VW> struct F;
+template <> struct F<4> {
+    float a[4];
+    __device__ __forceinline__ void load(const float* p) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        a[0] = v.x; a[1] = v.y; a[2] = v.z; a[3] = v.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<float4*>(p) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+};
+template <> struct F<1> {
+    float a[1];
+    __device__ __forceinline__ void load(const float* p) { a[0] = *p; }
+    __device__ __forceinline__ void store(float* p) const { *p = a[0]; }
+};
+
+// Load per-column parameters for this thread's column word (zeros past C).
+template <int VW>
+__device__ __forceinline__ void load_cols(float (&dst)[VW], const float* src, int c0, int C) {
+#pragma unroll
+    for (int k = 0; k < VW; ++k) dst[k] = (c0 + k < C) ? src[c0 + k] : 0.f;
+}
+
+struct Drop {
+    float p, inv_keep;
+    uint64_t seed, step, call_id;
+    int cw4;  // ceil(C/4): Philox counter = row*cw4 + col/4, word = col%4 (independent of VW / ld)
+};
+
+template <int VW>
+__device__ __forceinline__ void drop_scales(const Drop& d, int64_t row, int c0, float (&s)[VW]) {
+    if (VW == 4) {
+        uint32_t w[4];
+        philox4(d.seed, d.step, d.call_id, (uint64_t)row * d.cw4 + (c0 >> 2), w);
+#pragma unroll
+        for (int k = 0; k < VW; ++k) s[k] = keep_scale(w[k], d.p, d.inv_keep);
+    } else {
+        uint32_t w[4];
+        philox4(d.seed, d.step, d.call_id, (uint64_t)row * d.cw4 + (c0 >> 2), w);
+        s[0] = keep_scale(w[c0 & 3], d.p, d.inv_keep);
+    }
+}
+
+// Reduce this thread's 2*VW fp64 accumulators over the row slots of the workgroup (fixed order)
+// and let row slot 0 write them to partial[blk][which][c].
+template <int VW>
+__device__ __forceinline__ void block_reduce_store(double (&s0)[VW], double (&s1)[VW], double* lds, int tc, int tr,
+                                                   int TC, int rpb, double* partial, int c0, int C) {
+    double* mine = lds + (size_t)threadIdx.x * 2 * VW;
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+        mine[k] = s0[k];
+        mine[VW + k] = s1[k];
+    }
+    __syncthreads();
+    if (tr == 0) {
+        for (int r = 1; r < rpb; ++r) {
+            const double* o = lds + (size_t)(r * TC + tc) * 2 * VW;
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                s0[k] += o[k];
+                s1[k] += o[VW + k];
+            }
+        }
+        double* p = partial + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int k = 0; k < VW; ++k)
+            if (c0 + k < C) {
+                p[c0 + k] = s0[k];
+                p[C + c0 + k] = s1[k];
+            }
+    }
+}
+
+// ---- forward statistics: per-column sum(x), sum(x^2) ------------------------------------------
+template <int VW>
+__global__ __launch_bounds__(kBlock) void gn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int C,
+                                                          int tc_log2, double* __restrict__ partial) {
+    __shared__ double lds[kBlock * 2 * VW];
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = (blockIdx.y * TC + tc) * VW;
+    const bool ok = c0 < C;
+    double s[VW], q[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) s[k] = q[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * kUnroll) {
+        F<VW> v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+#pragma unroll
+            for (int k = 0; k < VW; ++k) v[u].a[k] = 0.f;
+            if (ok && rr < N) v[u].load(x + rr * ldx + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                const double d = (double)v[u].a[k];
+                s[k] += d;
+                q[k] += d * d;
+            }
+    }
+    block_reduce_store<VW>(s, q, lds, tc, tr, TC, rpb, partial, c0, C);
+}
+
+// ---- finalize: sum workgroup partials in order; derive mean / rstd / scale / shift -------------
+// 16 columns x 16 partial slots per workgroup.
+__global__ __launch_bounds__(kBlock) void gn_finalize_fwd_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                                 int64_t N, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 const float* __restrict__ alpha, float eps,
+                                                                 float* __restrict__ saved) {
+    __shared__ double lds[kBlock * 2];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int b = tr; b < nblk; b += 16) {
+            s += partial[(size_t)b * 2 * C + c];
+            q += partial[(size_t)b * 2 * C + C + c];
+        }
+    lds[threadIdx.x * 2] = s;
+    lds[threadIdx.x * 2 + 1] = q;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) {
+            s += lds[(r * 16 + tc) * 2];
+            q += lds[(r * 16 + tc) * 2 + 1];
+        }
+        const double a = (double)alpha[c];
+        const double mu = s / (double)N;
+        // mean((x - a*mu)^2) = E[x^2] - mu^2 * (2a - a^2)   (exact in fp64 for fp32 data)
+        double var = q / (double)N - mu * mu * (2.0 * a - a * a);
+        if (var < 0.0) var = 0.0;
+        const double rstd = 1.0 / sqrt(var + (double)eps);
+        const double scale = (double)gamma[c] * rstd;
+        saved[c] = (float)mu;
+        saved[C + c] = (float)rstd;
+        saved[2 * C + c] = (float)scale;
+        saved[3 * C + c] = (float)((double)beta[c] - scale * a * mu);
+    }
+}
+
+// ---- forward apply: y = dropout(act(x*scale + shift)) ------------------------------------------
+template <int VW>
+__global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restrict__ x, int64_t ldx,
+                                                          float* __restrict__ y, int64_t ldy, int64_t N, int C,
+                                                          int tc_log2, const float* __restrict__ saved, int act,
+                                                          Drop drop, const uint64_t* __restrict__ rng_state) {
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = (blockIdx.y * TC + tc) * VW;
+    if (c0 >= C) return;
+    float scale[VW], shift[VW];
+    load_cols<VW>(scale, saved + 2 * C, c0, C);
+    load_cols<VW>(shift, saved + 3 * C, c0, C);
+    if (drop.p > 0.f) {
+        drop.seed = rng_state[0];
+        drop.step = rng_state[1];
+    }
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * kUnroll) {
+        F<VW> v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr < N) v[u].load(x + rr * ldx + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr >= N) continue;
+            float ds[VW];
+#pragma unroll
+            for (int k = 0; k < VW; ++k) ds[k] = 1.f;
+            if (drop.p > 0.f) drop_scales<VW>(drop, rr, c0, ds);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                float h = fmaf(v[u].a[k], scale[k], shift[k]);
+                if (act == GLASS_ACT_ELU) h = elu_f(h);
+                v[u].a[k] = h * ds[k];
+            }
+            v[u].store(y + rr * ldy + c0);
+        }
+    }
+}
+
+// ---- backward statistics: S1 = sum(g), S2 = sum(g * xhat), g = dy * dropmask * act'(h) ---------
+template <int VW>
+__device__ __forceinline__ void bwd_g(float (&g)[VW], const float (&xv)[VW], const float (&scale)[VW],
+                                      const float (&shift)[VW], int act, const Drop& drop, int64_t row, int c0) {
+    if (drop.p > 0.f) {
+        float ds[VW];
+        drop_scales<VW>(drop, row, c0, ds);
+#pragma unroll
+        for (int k = 0; k < VW; ++k) g[k] *= ds[k];
+    }
+    if (act == GLASS_ACT_ELU) {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) g[k] *= elu_grad_f(fmaf(xv[k], scale[k], shift[k]));
+    }
+}
+
+template <int VW>
+__global__ __launch_bounds__(kBlock) void gn_bwd_stats_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                              const float* __restrict__ x, int64_t ldx, int64_t N,
+                                                              int C, int tc_log2, const float* __restrict__ saved,
+                                                              const float* __restrict__ alpha, int act, Drop drop,
+                                                              const uint64_t* __restrict__ rng_state,
+                                                              double* __restrict__ partial) {
+    __shared__ double lds[kBlock * 2 * VW];
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = (blockIdx.y * TC + tc) * VW;
+    const bool ok = c0 < C;
+    float mu[VW], rstd[VW], scale[VW], shift[VW], al[VW];
+    load_cols<VW>(mu, saved, c0, C);
+    load_cols<VW>(rstd, saved + C, c0, C);
+    load_cols<VW>(scale, saved + 2 * C, c0, C);
+    load_cols<VW>(shift, saved + 3 * C, c0, C);
+    load_cols<VW>(al, alpha, c0, C);
+    if (drop.p > 0.f) {
+        drop.seed = rng_state[0];
+        drop.step = rng_state[1];
+    }
+    double s1[VW], s2[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) s1[k] = s2[k] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * kUnroll) {
+        F<VW> g[kUnroll], xv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+#pragma unroll
+            for (int k = 0; k < VW; ++k) g[u].a[k] = xv[u].a[k] = 0.f;
+            if (ok && rr < N) {
+                g[u].load(dy + rr * lddy + c0);
+                xv[u].load(x + rr * ldx + c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (!ok || rr >= N) continue;
+            bwd_g<VW>(g[u].a, xv[u].a, scale, shift, act, drop, rr, c0);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                const float xhat = (xv[u].a[k] - al[k] * mu[k]) * rstd[k];
+                s1[k] += (double)g[u].a[k];
+                s2[k] += (double)g[u].a[k] * (double)xhat;
+            }
+        }
+    }
+    block_reduce_store<VW>(s1, s2, lds, tc, tr, TC, rpb, partial, c0, C);
+}
+
+// finalize backward: parameter grads + coefficients of dx = A*g + Bx*x + K
+__global__ __launch_bounds__(kBlock) void gn_finalize_bwd_kernel(const double* __restrict__ partial, int nblk, int C,
+                                                                 int64_t N, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ alpha,
+                                                                 const float* __restrict__ saved,
+                                                                 float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                 float* __restrict__ dalpha, float* __restrict__ coef) {
+    __shared__ double lds[kBlock * 2];
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + tc;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = tr; b < nblk; b += 16) {
+            s1 += partial[(size_t)b * 2 * C + c];
+            s2 += partial[(size_t)b * 2 * C + C + c];
+        }
+    lds[threadIdx.x * 2] = s1;
+    lds[threadIdx.x * 2 + 1] = s2;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) {
+            s1 += lds[(r * 16 + tc) * 2];
+            s2 += lds[(r * 16 + tc) * 2 + 1];
+        }
+        const double n = (double)N, g = (double)gamma[c], a = (double)alpha[c];
+        const double mu = (double)saved[c], r = (double)saved[C + c];
+        const double m2 = s2 / n;
+        const double sum_xhat = r * n * mu * (1.0 - a);          // sum_n (x_n - a*mu) * r
+        const double sum_do = g * r * (s1 - sum_xhat * m2);       // sum_n d o_n
+        if (dgamma) dgamma[c] = (float)s2;
+        if (dbeta) dbeta[c] = (float)s1;
+        if (dalpha) dalpha[c] = (float)(-mu * sum_do);
+        // dx = do - a*mean(do),  do = g*r*(gr - xhat*m2),  xhat = (x - a*mu)*r
+        const double A = g * r;
+        const double Bx = -g * r * r * m2;
+        const double K = g * r * r * m2 * a * mu - a * (sum_do / n);
+        coef[c] = (float)A;
+        coef[C + c] = (float)Bx;
+        coef[2 * C + c] = (float)K;
+    }
+}
+
+template <int VW>
+__global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                              const float* __restrict__ x, int64_t ldx,
+                                                              float* __restrict__ dx, int64_t lddx, int64_t N, int C,
+                                                              int tc_log2, const float* __restrict__ saved,
+                                                              const float* __restrict__ coef, int act, Drop drop,
+                                                              const uint64_t* __restrict__ rng_state) {
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = (blockIdx.y * TC + tc) * VW;
+    if (c0 >= C) return;
+    float scale[VW], shift[VW], A[VW], Bx[VW], K[VW];
+    load_cols<VW>(scale, saved + 2 * C, c0, C);
+    load_cols<VW>(shift, saved + 3 * C, c0, C);
+    load_cols<VW>(A, coef, c0, C);
+    load_cols<VW>(Bx, coef + C, c0, C);
+    load_cols<VW>(K, coef + 2 * C, c0, C);
+    if (drop.p > 0.f) {
+        drop.seed = rng_state[0];
+        drop.step = rng_state[1];
+    }
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * kUnroll) {
+        F<VW> g[kUnroll], xv[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr < N) {
+                g[u].load(dy + rr * lddy + c0);
+                xv[u].load(x + rr * ldx + c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr >= N) continue;
+            bwd_g<VW>(g[u].a, xv[u].a, scale, shift, act, drop, rr, c0);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) g[u].a[k] = fmaf(A[k], g[u].a[k], fmaf(Bx[k], xv[u].a[k], K[k]));
+            g[u].store(dx + rr * lddx + c0);
+        }
+    }
+}
+
+__global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
+
+static unsigned apply_blocks(int64_t n_rows, const Tiling& t) {
+    int64_t b = ceil_div(n_rows, (int64_t)t.rpb * kUnroll);
+    if (b < 1) b = 1;
+    if (b > 4096) b = 4096;
+    return (unsigned)b;
+}
+
+static Drop make_drop(float p, uint64_t call_id, int64_t C) {
+    Drop d;
+    d.p = p;
+    d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    d.seed = d.step = 0;
+    d.call_id = call_id;
+    d.cw4 = (int)ceil_div(C, 4);
+    return d;
+}
+
+}  // namespace glass
+
+using namespace glass;
+
+extern "C" int64_t glass_graphnorm_ws_bytes(int64_t n_rows, int64_t C) {
+    (void)n_rows;
+    return ws_partials_bytes(C) + 4 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int64_t C,
+                                       const float* gamma, const float* beta, const float* alpha, float eps,
+                                       float* saved, int act, float p_drop, const uint64_t* rng_state,
+                                       uint64_t call_id, void* ws, void* stream) {
+    GLASS_REQUIRE(x && y && gamma && beta && alpha && saved && ws, "graphnorm_fwd: null pointer");
+    GLASS_REQUIRE(n_rows > 0 && C > 0 && ldx >= C && ldy >= C, "graphnorm_fwd: bad sizes N=%lld C=%lld",
+                  (long long)n_rows, (long long)C);
+    GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_fwd: bad dropout args");
+    GLASS_REQUIRE(act == GLASS_ACT_NONE || act == GLASS_ACT_ELU, "graphnorm_fwd: bad act %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y);
+    const Tiling t = make_tiling(C, vec);
+    const int nblk = stat_blocks(n_rows, t);
+    double* partial = (double*)ws;
+    const Drop drop = make_drop(p_drop, call_id, C);
+    dim3 gs(nblk, t.ctiles), ga(apply_blocks(n_rows, t), t.ctiles);
+    if (vec) {
+        hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+    }
+    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
+                       (int)C, n_rows, gamma, beta, alpha, eps, saved);
+    if (vec) {
+        hipLaunchKernelGGL(gn_apply_kernel<4>, ga, dim3(kBlock), 0, st, x, ldx, y, ldy, n_rows, (int)C, t.tc_log2,
+                           saved, act, drop, rng_state);
+    } else {
+        hipLaunchKernelGGL(gn_apply_kernel<1>, ga, dim3(kBlock), 0, st, x, ldx, y, ldy, n_rows, (int)C, t.tc_log2,
+                           saved, act, drop, rng_state);
+    }
+    return launch_status("glass_graphnorm_fwd_f32");
+}
+
+extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx,
+                                       int64_t lddx, int64_t n_rows, int64_t C, const float* gamma,
+                                       const float* alpha, const float* saved, float* dgamma, float* dbeta,
+                                       float* dalpha, int act, float p_drop, const uint64_t* rng_state,
+                                       uint64_t call_id, void* ws, void* stream) {
+    GLASS_REQUIRE(dy && x && dx && gamma && alpha && saved && ws, "graphnorm_bwd: null pointer");
+    GLASS_REQUIRE(n_rows > 0 && C > 0 && lddy >= C && ldx >= C && lddx >= C, "graphnorm_bwd: bad sizes");
+    GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd: bad dropout args");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && aligned16(dy) && aligned16(x) &&
+                     aligned16(dx);
+    const Tiling t = make_tiling(C, vec);
+    const int nblk = stat_blocks(n_rows, t);
+    double* partial = (double*)ws;
+    float* coef = (float*)((char*)ws + ws_partials_bytes(C));
+    const Drop drop = make_drop(p_drop, call_id, C);
+    dim3 gs(nblk, t.ctiles), ga(apply_blocks(n_rows, t), t.ctiles);
+    if (vec) {
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<4>, gs, dim3(kBlock), 0, st, dy, lddy, x, ldx, n_rows, (int)C,
+                           t.tc_log2, saved, alpha, act, drop, rng_state, partial);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_stats_kernel<1>, gs, dim3(kBlock), 0, st, dy, lddy, x, ldx, n_rows, (int)C,
+                           t.tc_log2, saved, alpha, act, drop, rng_state, partial);
+    }
+    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
+                       (int)C, n_rows, gamma, alpha, saved, dgamma, dbeta, dalpha, coef);
+    if (vec) {
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, n_rows, (int)C,
+                           t.tc_log2, saved, coef, act, drop, rng_state);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, n_rows, (int)C,
+                           t.tc_log2, saved, coef, act, drop, rng_state);
+    }
+    return launch_status("glass_graphnorm_bwd_f32");
+}
+
+extern "C" int glass_rng_advance(uint64_t* rng_state, void* stream) {
+    GLASS_REQUIRE(rng_state, "rng_advance: null pointer");
+    hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
+    return launch_status("glass_rng_advance");
+}

@@ -1,0 +1,322 @@
+// K1: CSR aggregation Y = A @ X for gfx950.   Replaces `self.adj @ x` (reference
+// impl/models.py:164) and, on the CSR of A^T, its autograd backward.
+//
+// Shape of the work: per edge one gather of a 4H-byte feature row (256 B at H=64) — HBM/L2
+// bound, no matrix-core work.  Layout per wave64: a feature row is covered by LPR lanes x 16 B
+// (LPR=16 at H=64), so one wave-instruction gathers G = 64/LPR neighbour rows = 1 KiB, fully
+// coalesced per row.  A wave first reads up to 64 (col,val) pairs of its row coalesced, then
+// hands them to the lane groups with ds_bpermute (__shfl) — one dependent latency per 64 edges —
+// and keeps U gathers in flight.  Partial sums of the G groups are combined with __shfl_xor;
+// rows long enough to need a whole workgroup are combined through LDS; rows longer than one
+// chunk go through per-chunk partial rows summed in fixed order (no float atomics).
+#include "common.h"
+
+#include <vector>
+
+namespace glass {
+
+constexpr int32_t kPlanMagic = 0x474C5350;  // 'GLSP'
+constexpr int32_t kPlanVersion = 1;
+// header word indices
+enum { H_MAGIC, H_VER, H_NROWS, H_NNZ, H_NSWEEP, H_NLONG, H_NREDUCE, H_NSLOTS, H_LONG_THR, H_LONG_CHUNK,
+       H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RSV0, H_RSV1, H_RSV2 };
+
+// ---- vector helpers --------------------------------------------------------------------------
+template <int VW> struct Vec;
+template <> struct Vec<4> {
+    float4 v;
+    __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
+    __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
+    __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ void fma(float a, const Vec& x) {
+        v.x = fmaf(a, x.v.x, v.x); v.y = fmaf(a, x.v.y, v.y); v.z = fmaf(a, x.v.z, v.z); v.w = fmaf(a, x.v.w, v.w);
+    }
+    __device__ __forceinline__ void add(const Vec& x) { v.x += x.v.x; v.y += x.v.y; v.z += x.v.z; v.w += x.v.w; }
+    __device__ __forceinline__ void xor_add(int s) {
+        v.x += __shfl_xor(v.x, s); v.y += __shfl_xor(v.y, s); v.z += __shfl_xor(v.z, s); v.w += __shfl_xor(v.w, s);
+    }
+};
+template <> struct Vec<1> {
+    float v;
+    __device__ __forceinline__ void zero() { v = 0.f; }
+    __device__ __forceinline__ void load(const float* p) { v = *p; }
+    __device__ __forceinline__ void store(float* p) const { *p = v; }
+    __device__ __forceinline__ void fma(float a, const Vec& x) { v = fmaf(a, x.v, v); }
+    __device__ __forceinline__ void add(const Vec& x) { v += x.v; }
+    __device__ __forceinline__ void xor_add(int s) { v += __shfl_xor(v, s); }
+};
+
+// Accumulate edges [e0,e1) of one row into `acc` (per lane-group partial sums).
+// All 64 lanes execute this together; e0/e1 are wave-uniform.
+template <int VW, int LPR, int U>
+__device__ __forceinline__ void gather_edges(Vec<VW>& acc, const int32_t* __restrict__ col,
+                                             const float* __restrict__ val, const float* __restrict__ Xc, int64_t ldx,
+                                             int e0, int e1, int lane, int grp, bool col_ok) {
+    constexpr int G = kWave / LPR;
+    for (int eb = e0; eb < e1; eb += kWave) {
+        const int cnt = min(kWave, e1 - eb);
+        int my_c = 0;
+        float my_v = 0.f;
+        if (lane < cnt) {
+            my_c = col[eb + lane];
+            my_v = val[eb + lane];
+        }
+        for (int j = 0; j < cnt; j += U * G) {
+            Vec<VW> x[U];
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = j + u * G + grp;          // < 64 + U*G: shfl wraps mod 64, masked by `ok`
+                const int c = __shfl(my_c, idx);
+                v[u] = __shfl(my_v, idx);
+                const bool ok = col_ok && idx < cnt;
+                x[u].zero();
+                if (ok) x[u].load(Xc + (int64_t)c * ldx);
+                if (!ok) v[u] = 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc.fma(v[u], x[u]);
+        }
+    }
+}
+
+template <int VW, int LPR>
+__device__ __forceinline__ void reduce_groups(Vec<VW>& acc) {
+#pragma unroll
+    for (int s = LPR; s < kWave; s <<= 1) acc.xor_add(s);
+}
+
+// ---- sweep kernel: one wave per contiguous, edge-balanced row range --------------------------
+template <int VW, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col,
+                                                            const float* __restrict__ val,
+                                                            const float* __restrict__ X, int64_t ldx,
+                                                            float* __restrict__ Y, int64_t ldy, int H,
+                                                            const int32_t* __restrict__ wave_rows, int n_waves,
+                                                            int long_thr) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (wave >= n_waves) return;
+    const int grp = lane / LPR, sub = lane % LPR;
+    const int coff = (blockIdx.y * LPR + sub) * VW;
+    const bool col_ok = coff < H;
+    const float* Xc = X + coff;
+    const int r0 = __builtin_amdgcn_readfirstlane(wave_rows[wave]);
+    const int r1 = __builtin_amdgcn_readfirstlane(wave_rows[wave + 1]);
+    int e0 = __builtin_amdgcn_readfirstlane(rowptr[r0]);
+    for (int r = r0; r < r1; ++r) {
+        const int e1 = __builtin_amdgcn_readfirstlane(rowptr[r + 1]);
+        if (e1 - e0 < long_thr) {
+            Vec<VW> acc;
+            acc.zero();
+            gather_edges<VW, LPR, U>(acc, col, val, Xc, ldx, e0, e1, lane, grp, col_ok);
+            reduce_groups<VW, LPR>(acc);
+            if (grp == 0 && col_ok) acc.store(Y + (int64_t)r * ldy + coff);
+        }
+        e0 = e1;
+    }
+}
+
+// ---- long-row kernel: one workgroup per (row, chunk); 4 waves combine through LDS ------------
+template <int VW, int LPR, int U>
+__global__ __launch_bounds__(kBlock) void spmm_long_kernel(const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float* __restrict__ X, int64_t ldx,
+                                                           float* __restrict__ Y, int64_t ldy,
+                                                           float* __restrict__ partials, int H,
+                                                           const int32_t* __restrict__ items) {
+    __shared__ float lds[(kBlock / kWave) * LPR * VW];
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int grp = lane / LPR, sub = lane % LPR;
+    const int coff = (blockIdx.y * LPR + sub) * VW;
+    const bool col_ok = coff < H;
+    const int32_t* it = items + 4 * (int64_t)blockIdx.x;
+    const int row = it[0], eb = it[1], ee = it[2], slot = it[3];
+    // wave w takes the w-th quarter of the chunk, rounded to whole 64-edge batches
+    const int per = ((ee - eb + 4 * kWave - 1) / (4 * kWave)) * kWave;
+    const int e0 = min(eb + w * per, ee), e1 = min(e0 + per, ee);
+    Vec<VW> acc;
+    acc.zero();
+    gather_edges<VW, LPR, U>(acc, col, val, X + coff, ldx, e0, e1, lane, grp, col_ok);
+    reduce_groups<VW, LPR>(acc);
+    if (grp == 0) acc.store(&lds[(w * LPR + sub) * VW]);
+    __syncthreads();
+    if (w == 0 && grp == 0 && col_ok) {
+        Vec<VW> s, t;
+        s.load(&lds[sub * VW]);
+#pragma unroll
+        for (int k = 1; k < kBlock / kWave; ++k) {
+            t.load(&lds[(k * LPR + sub) * VW]);
+            s.add(t);
+        }
+        float* dst = slot < 0 ? Y + (int64_t)row * ldy : partials + (int64_t)slot * H;
+        s.store(dst + coff);
+    }
+}
+
+// ---- reduce kernel: rows cut into several chunks: sum their partial rows in slot order --------
+__global__ __launch_bounds__(kBlock) void spmm_reduce_kernel(const float* __restrict__ partials, float* __restrict__ Y,
+                                                             int64_t ldy, int H, const int32_t* __restrict__ rrows) {
+    const int32_t* rr = rrows + 3 * (int64_t)blockIdx.x;
+    const int row = rr[0], first = rr[1], n = rr[2];
+    for (int c = threadIdx.x; c < H; c += kBlock) {
+        float s = 0.f;
+        for (int k = 0; k < n; ++k) s += partials[(int64_t)(first + k) * H + c];
+        Y[(int64_t)row * ldy + c] = s;
+    }
+}
+
+template <int VW, int LPR>
+static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, int64_t ldx,
+                       float* Y, int64_t ldy, int64_t H, const int32_t* hdr, const int32_t* plan, float* ws,
+                       hipStream_t st) {
+    constexpr int U = (LPR >= 32) ? 4 : 4;
+    const int n_ctiles = (int)ceil_div(H, (int64_t)LPR * VW);
+    const int n_waves = hdr[H_NSWEEP];
+    if (n_waves > 0) {
+        dim3 grid((unsigned)ceil_div(n_waves, kBlock / kWave), n_ctiles);
+        hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx, Y,
+                           ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_LONG_THR]);
+    }
+    if (hdr[H_NLONG] > 0) {
+        dim3 grid((unsigned)hdr[H_NLONG], n_ctiles);
+        hipLaunchKernelGGL((spmm_long_kernel<VW, LPR, U>), grid, dim3(kBlock), 0, st, col, val, X, ldx, Y, ldy, ws,
+                           (int)H, plan + hdr[H_OFF_LONG]);
+    }
+    if (hdr[H_NREDUCE] > 0) {
+        hipLaunchKernelGGL(spmm_reduce_kernel, dim3((unsigned)hdr[H_NREDUCE]), dim3(kBlock), 0, st, ws, Y, ldy, (int)H,
+                           plan + hdr[H_OFF_REDUCE]);
+    }
+    return launch_status("glass_spmm_csr_f32");
+}
+
+}  // namespace glass
+
+using namespace glass;
+
+// Plan policy (host).  Rows with >= kLongThr edges are given to whole workgroups in chunks of
+// kLongChunk edges; the rest are swept by waves holding ~edges_per_wave edges each.
+static constexpr int kLongThr = 256;
+static constexpr int kLongChunk = 2048;
+static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
+static constexpr int kTargetWaves = 32768;  // ~4 rounds of 256 CUs x 32 waves
+
+extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int32_t* plan, int64_t* plan_words) {
+    GLASS_REQUIRE(rowptr && plan_words && n_rows >= 0 && n_rows < (1ll << 31), "plan_build: bad arguments");
+    const int64_t nnz = rowptr[n_rows];
+    GLASS_REQUIRE(rowptr[0] == 0 && nnz >= 0, "plan_build: rowptr[0] must be 0 and nnz < 2^31");
+    std::vector<int32_t> sweep, longs, reduces;
+    int64_t cost_total = 0;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
+        GLASS_REQUIRE(d >= 0, "plan_build: rowptr not monotone at row %lld", (long long)r);
+        cost_total += kRowCost + (d < kLongThr ? d : 0);
+    }
+    int64_t budget = cost_total / kTargetWaves;
+    if (budget < 32) budget = 32;
+    if (budget > 1024) budget = 1024;
+    int64_t acc = 0;
+    int32_t n_slots = 0;
+    sweep.push_back(0);
+    for (int64_t r = 0; r < n_rows; ++r) {
+        const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
+        const int64_t c = kRowCost + (d < kLongThr ? d : 0);
+        if (acc > 0 && acc + c > budget) {
+            sweep.push_back((int32_t)r);
+            acc = 0;
+        }
+        acc += c;
+        if (d >= kLongThr) {
+            const int64_t n_chunks = ceil_div(d, kLongChunk);
+            const int64_t per = ceil_div(ceil_div(d, n_chunks), kWave) * kWave;  // even chunks, whole batches
+            if (n_chunks > 1) {
+                reduces.push_back((int32_t)r);
+                reduces.push_back(n_slots);
+                reduces.push_back((int32_t)n_chunks);
+            }
+            for (int64_t k = 0; k < n_chunks; ++k) {
+                const int64_t b = rowptr[r] + k * per;
+                const int64_t e = (b + per < rowptr[r + 1]) ? b + per : rowptr[r + 1];
+                longs.push_back((int32_t)r);
+                longs.push_back((int32_t)b);
+                longs.push_back((int32_t)e);
+                longs.push_back(n_chunks > 1 ? n_slots++ : -1);
+            }
+        }
+    }
+    if (n_rows > 0) sweep.push_back((int32_t)n_rows);
+    const int64_t n_sweep = n_rows > 0 ? (int64_t)sweep.size() - 1 : 0;
+    const int64_t off_sweep = GLASS_PLAN_HEADER_WORDS;
+    const int64_t off_long = off_sweep + (int64_t)sweep.size();
+    const int64_t off_reduce = off_long + (int64_t)longs.size();
+    const int64_t total = off_reduce + (int64_t)reduces.size();
+    *plan_words = total;
+    if (!plan) return 0;
+    for (int i = 0; i < GLASS_PLAN_HEADER_WORDS; ++i) plan[i] = 0;
+    plan[H_MAGIC] = kPlanMagic;
+    plan[H_VER] = kPlanVersion;
+    plan[H_NROWS] = (int32_t)n_rows;
+    plan[H_NNZ] = (int32_t)nnz;
+    plan[H_NSWEEP] = (int32_t)n_sweep;
+    plan[H_NLONG] = (int32_t)(longs.size() / 4);
+    plan[H_NREDUCE] = (int32_t)(reduces.size() / 3);
+    plan[H_NSLOTS] = n_slots;
+    plan[H_LONG_THR] = kLongThr;
+    plan[H_LONG_CHUNK] = kLongChunk;
+    plan[H_OFF_SWEEP] = (int32_t)off_sweep;
+    plan[H_OFF_LONG] = (int32_t)off_long;
+    plan[H_OFF_REDUCE] = (int32_t)off_reduce;
+    for (size_t i = 0; i < sweep.size(); ++i) plan[off_sweep + i] = sweep[i];
+    for (size_t i = 0; i < longs.size(); ++i) plan[off_long + i] = longs[i];
+    for (size_t i = 0; i < reduces.size(); ++i) plan[off_reduce + i] = reduces[i];
+    return 0;
+}
+
+extern "C" int64_t glass_spmm_ws_bytes(const int32_t* hdr, int64_t H) {
+    if (!hdr || hdr[H_MAGIC] != kPlanMagic) return GLASS_E_PLAN;
+    return (int64_t)hdr[H_NSLOTS] * H * (int64_t)sizeof(float);
+}
+
+extern "C" int glass_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, const float* X,
+                                  int64_t ldx, float* Y, int64_t ldy, int64_t n_rows, int64_t H, const int32_t* hdr,
+                                  const int32_t* plan_dev, void* ws, void* stream) {
+    GLASS_REQUIRE(rowptr && X && Y && hdr && plan_dev, "spmm: null pointer");
+    GLASS_REQUIRE(H > 0 && ldx >= H && ldy >= H, "spmm: need H>0, ldx>=H, ldy>=H (H=%lld ldx=%lld ldy=%lld)",
+                  (long long)H, (long long)ldx, (long long)ldy);
+    if (hdr[H_MAGIC] != kPlanMagic || hdr[H_VER] != kPlanVersion || hdr[H_NROWS] != n_rows) {
+        set_error("spmm: plan does not match (magic %x, rows %d vs %lld)", hdr[H_MAGIC], hdr[H_NROWS],
+                  (long long)n_rows);
+        return GLASS_E_PLAN;
+    }
+    GLASS_REQUIRE(hdr[H_NNZ] == 0 || (col && val), "spmm: null col/val");
+    GLASS_REQUIRE(hdr[H_NSLOTS] == 0 || ws, "spmm: plan needs %d partial rows but ws is null", hdr[H_NSLOTS]);
+    if (n_rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+    const bool vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && aligned16(X) && aligned16(Y) &&
+                     (hdr[H_NSLOTS] == 0 || aligned16(ws));
+#define GLASS_SPMM_CASE(VW, LPR) \
+    return launch_spmm<VW, LPR>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan_dev, wsf, st)
+    if (vec) {
+        switch (pow2_ceil_cap(H / 4, 64)) {
+            case 1: GLASS_SPMM_CASE(4, 1);
+            case 2: GLASS_SPMM_CASE(4, 2);
+            case 4: GLASS_SPMM_CASE(4, 4);
+            case 8: GLASS_SPMM_CASE(4, 8);
+            case 16: GLASS_SPMM_CASE(4, 16);
+            case 32: GLASS_SPMM_CASE(4, 32);
+            default: GLASS_SPMM_CASE(4, 64);
+        }
+    }
+    switch (pow2_ceil_cap(H, 64)) {
+        case 1: GLASS_SPMM_CASE(1, 1);
+        case 2: GLASS_SPMM_CASE(1, 2);
+        case 4: GLASS_SPMM_CASE(1, 4);
+        case 8: GLASS_SPMM_CASE(1, 8);
+        case 16: GLASS_SPMM_CASE(1, 16);
+        case 32: GLASS_SPMM_CASE(1, 32);
+        default: GLASS_SPMM_CASE(1, 64);
+    }
+#undef GLASS_SPMM_CASE
+}

@@ -1,0 +1,289 @@
+"""GLASS model stack on the MI355X HIP kernels — the host-side mirror of the reference's
+`impl/models.py` surface (same class names, constructor arguments, forward signatures,
+state_dict keys and error types), so `GLASSTest.py`-style drivers are drop-in
+callers.  The arithmetic runs in libglass_hip (ops.py); dense Linears stay on rocBLAS through
+torch; there is no CPU path.
+
+Reference map (file:line under /root/reference):
+  Seq 10-24 · MLP 27-80 · buildAdj 83-111 · GLASSConv 114-174 · EmbZGConv 177-272 ·
+  PoolModule/AddPool/MaxPool/MeanPool/SizePool 275-319 · GLASS 322-355   (impl/models.py)
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .graph import CSRAdj, Selection
+from .ops import ACT_ELU, ACT_NONE
+from .utils import batch2pad
+
+
+# ---------------------------------------------------------------------------------------------
+class GraphNorm(nn.Module):
+    """Whole-graph GraphNorm (PyG 1.7.2 semantics with batch=None): parameters `weight`, `bias`,
+    `mean_scale` initialised to 1, 0, 1.  `forward` optionally fuses the ELU and the inverted
+    dropout that follow every GraphNorm in the reference (models.py:166,251,258-259)."""
+    def __init__(self, in_channels, eps=1e-5):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = nn.Parameter(torch.ones(in_channels))
+        self.bias = nn.Parameter(torch.zeros(in_channels))
+        self.mean_scale = nn.Parameter(torch.ones(in_channels))
+
+    def reset_parameters(self):
+        nn.init.ones_(self.weight)
+        nn.init.zeros_(self.bias)
+        nn.init.ones_(self.mean_scale)
+
+    def forward(self, x, batch=None, act=ACT_NONE, p_drop=0.0, call_id=0):
+        if batch is not None:
+            raise NotImplementedError("GLASS only uses whole-graph GraphNorm (batch=None)")
+        return ops.graphnorm(x, self.weight, self.bias, self.mean_scale, self.eps, act, p_drop, call_id)
+
+
+def _act_code(activation):
+    """ELU(alpha=1) is fused into the kernels; any other module runs as a torch GPU op."""
+    if isinstance(activation, nn.ELU) and activation.alpha == 1.0:
+        return ACT_ELU
+    return None
+
+
+class Seq(nn.Module):
+    """nn.Sequential whose first module also receives the extra positional / keyword arguments."""
+    def __init__(self, modlist):
+        super().__init__()
+        self.modlist = nn.ModuleList(modlist)
+
+    def forward(self, *args, **kwargs):
+        it = iter(self.modlist)
+        out = next(it)(*args, **kwargs)
+        for m in it:
+            out = m(out)
+        return out
+
+
+class MLP(nn.Module):
+    """Linear / GraphNorm / Dropout / activation stack with the reference's layer ordering
+    (only GNNEmb / GNNSeg use it; GLASSTest's head is a bare nn.Linear)."""
+    def __init__(self, input_channels, hidden_channels, output_channels, num_layers, dropout=0, tail_activation=False,
+                 activation=nn.ReLU(inplace=True), gn=False):
+        super().__init__()
+
+        def tail(width):
+            mods = [GraphNorm(width)] if gn else []
+            if dropout > 0:
+                mods.append(nn.Dropout(p=dropout, inplace=True))
+            return mods + [activation]
+
+        dims = [input_channels] + [hidden_channels] * (num_layers - 1) + [output_channels]
+        mods = []
+        for i in range(num_layers):
+            mods.append(nn.Linear(dims[i], dims[i + 1]))
+            if i + 1 < num_layers or tail_activation:
+                mods += tail(dims[i + 1])
+        self.seq = Seq(mods)
+
+    def forward(self, x):
+        return self.seq(x)
+
+
+# ---------------------------------------------------------------------------------------------
+_adj_cache = []  # [(edge_index, edge_weight, n, aggr, CSRAdj)] — tensors are held so pointers stay valid
+
+
+def buildAdj(edge_index, edge_weight, n_node: int, aggr: str):
+    """Normalised adjacency for aggr in {mean,sum,gcn} as a device CSR (graph.CSRAdj) instead of the
+    reference's COO.  One instance is shared by every layer asking for the same (graph, aggr) —
+    the reference builds an identical copy per layer (models.py:154-156)."""
+    if aggr not in ("mean", "sum", "gcn"):
+        raise NotImplementedError
+    for ei, ew, n, a, adj in _adj_cache:
+        if ei is edge_index and ew is edge_weight and n == int(n_node) and a == aggr:
+            return adj
+    adj = CSRAdj(edge_index, edge_weight, n_node, aggr)
+    _adj_cache.append((edge_index, edge_weight, int(n_node), aggr, adj))
+    del _adj_cache[:-8]
+    return adj
+
+
+class GLASSConv(nn.Module):
+    """Labeled message-passing layer: two weight sets (index 1 = labeled, 0 = unlabeled) mixed by
+    z_ratio before and after the neighbour aggregation."""
+    def __init__(self, in_channels: int, out_channels: int, activation=nn.ReLU(inplace=True), aggr="mean",
+                 z_ratio=0.8, dropout=0.2):
+        super().__init__()
+        self.trans_fns = nn.ModuleList([nn.Linear(in_channels, out_channels), nn.Linear(in_channels, out_channels)])
+        self.comb_fns = nn.ModuleList([nn.Linear(in_channels + out_channels, out_channels),
+                                       nn.Linear(in_channels + out_channels, out_channels)])
+        self.adj = None
+        self.activation = activation
+        self.aggr = aggr
+        self.gn = GraphNorm(out_channels)
+        self.z_ratio = z_ratio
+        self.dropout = dropout
+        self.call_base = 0  # set by EmbZGConv: distinguishes dropout streams of different layers
+
+    def reset_parameters(self):
+        for lin in list(self.trans_fns) + list(self.comb_fns):
+            lin.reset_parameters()
+        self.gn.reset_parameters()
+
+    def forward(self, x_, edge_index, edge_weight, mask):
+        if self.adj is None:
+            self.adj = buildAdj(edge_index, edge_weight, x_.shape[0], self.aggr)
+        if mask.dtype != torch.uint8:
+            mask = mask.reshape(-1).to(torch.uint8)
+        p = self.dropout if self.training else 0.0
+        code = _act_code(self.activation)
+        # both weight sets in one GEMM: T = [f1 | f0]
+        T = F.linear(x_, torch.cat((self.trans_fns[1].weight, self.trans_fns[0].weight)),
+                     torch.cat((self.trans_fns[1].bias, self.trans_fns[0].bias)))
+        if code is None:
+            T = self.activation(T)
+        m = ops.mix(T, mask, self.z_ratio, ACT_NONE if code is None else code)
+        a = ops.spmm(self.adj, m)
+        g = self.gn(a, p_drop=p, call_id=self.call_base)
+        c = torch.cat((g, x_), dim=-1)
+        C = F.linear(c, torch.cat((self.comb_fns[1].weight, self.comb_fns[0].weight)),
+                     torch.cat((self.comb_fns[1].bias, self.comb_fns[0].bias)))
+        return ops.mix(C, mask, self.z_ratio, ACT_NONE)
+
+
+class EmbZGConv(nn.Module):
+    """Embedding of the integer node feature + label mask, then `num_layers` GLASSConv layers
+    with GraphNorm / activation / dropout between them and optional JK concatenation."""
+    def __init__(self, hidden_channels, output_channels, num_layers, max_deg, dropout=0, activation=nn.ReLU(),
+                 conv=GLASSConv, gn=True, jk=False, **kwargs):
+        super().__init__()
+        self.input_emb = nn.Embedding(int(max_deg) + 1, hidden_channels, scale_grad_by_freq=False)
+        self.emb_gn = GraphNorm(hidden_channels)
+        self.convs = nn.ModuleList()
+        self.jk = jk
+        widths = [hidden_channels] * (num_layers - 1) + [output_channels]
+        for l, w in enumerate(widths):
+            layer = conv(in_channels=hidden_channels, out_channels=w, activation=activation, **kwargs)
+            layer.call_base = 16 * (l + 1)
+            self.convs.append(layer)
+        self.activation = activation
+        self.dropout = dropout
+        if gn:
+            self.gns = nn.ModuleList([GraphNorm(hidden_channels) for _ in range(num_layers - 1)])
+            self.gns.append(GraphNorm(output_channels + (num_layers - 1) * hidden_channels if jk else output_channels))
+        else:
+            self.gns = None
+        self._sel = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        self.input_emb.reset_parameters()
+        self.emb_gn.reset_parameters()
+        for conv in self.convs:
+            conv.reset_parameters()
+        if self.gns is not None:
+            for gn in self.gns:
+                gn.reset_parameters()
+
+    def _selection(self, x_flat):
+        V = self.input_emb.weight.shape[0]
+        if self._sel is None or self._sel[0] is not x_flat or self._sel[1] != V:
+            self._sel = (x_flat, V, Selection(x_flat, V))
+        return self._sel[2]
+
+    def forward(self, x, edge_index, edge_weight, z=None):
+        n = x.shape[0]
+        if x.numel() != n:
+            raise NotImplementedError("one integer feature per node (x of shape [N,1])")
+        x_flat = x if x.dim() == 1 else x.view(n)
+        p = self.dropout if self.training else 0.0
+        if self.training and (p > 0 or any(c.dropout > 0 for c in self.convs)):
+            ops.rng_advance(x.device)  # new dropout masks for this forward/backward pair
+        code = _act_code(self.activation)
+        h, mask = ops.embed_label(self.input_emb.weight, x_flat, z, self._selection(x_flat))
+        h = self.emb_gn(h, p_drop=p, call_id=1)
+        xs = []
+        for layer, conv in enumerate(self.convs):
+            h = conv(h, edge_index, edge_weight, mask)
+            xs.append(h)
+            if layer + 1 == len(self.convs):
+                break
+            if self.gns is not None:
+                if code is not None:
+                    h = self.gns[layer](h, act=code, p_drop=p, call_id=conv.call_base + 1)
+                    continue
+                h = self.gns[layer](h)
+            h = self.activation(h)
+            h = F.dropout(h, p=self.dropout, training=self.training)
+        h = torch.cat(xs, dim=-1) if self.jk else xs[-1]
+        if self.gns is not None:
+            h = self.gns[-1](h)
+        return h
+
+
+# ---------------------------------------------------------------------------------------------
+class PoolModule(nn.Module):
+    """Subgraph readout.  `forward(x, batch)` keeps the reference's gathered-rows + batch-vector
+    calling convention; GLASS.Pool uses the fused padded-matrix kernel directly."""
+    mode = None
+
+    def __init__(self, pool_fn=None, trans_fn=None):
+        super().__init__()
+        self.pool_fn = pool_fn
+        self.trans_fn = trans_fn
+
+    def forward(self, x, batch):
+        if self.trans_fn is not None:
+            x = self.trans_fn(x)
+        return ops.segment_pool(x, batch2pad(batch), self.mode)
+
+
+class AddPool(PoolModule):
+    mode = "sum"
+
+    def __init__(self, trans_fn=None):
+        super().__init__(None, trans_fn)
+
+
+class MaxPool(PoolModule):
+    mode = "max"
+
+    def __init__(self, trans_fn=None):
+        super().__init__(None, trans_fn)
+
+
+class MeanPool(PoolModule):
+    mode = "mean"
+
+    def __init__(self, trans_fn=None):
+        super().__init__(None, trans_fn)
+
+
+class SizePool(AddPool):
+    mode = "size"
+
+
+class GLASS(nn.Module):
+    """EmbZGConv + per-target pooling and prediction heads (`preds[id]`, `pools[id]`)."""
+    def __init__(self, conv: EmbZGConv, preds: nn.ModuleList, pools: nn.ModuleList):
+        super().__init__()
+        self.conv = conv
+        self.preds = preds
+        self.pools = pools
+
+    def NodeEmb(self, x, edge_index, edge_weight, z=None):
+        embs = [self.conv(x[:, c, :].reshape(x.shape[0], x.shape[-1]), edge_index, edge_weight, z)
+                for c in range(x.shape[1])]
+        if len(embs) == 1:
+            return embs[0]  # mean over a single feature channel is the identity
+        return torch.stack(embs, dim=1).mean(dim=1)
+
+    def Pool(self, emb, subG_node, pool):
+        if isinstance(pool, PoolModule) and pool.trans_fn is None and pool.mode is not None:
+            return ops.segment_pool(emb, subG_node, pool.mode)
+        from .utils import pad2batch
+        batch, pos = pad2batch(subG_node)
+        return pool(emb[pos], batch)
+
+    def forward(self, x, edge_index, edge_weight, subG_node, z=None, id=0):
+        emb = self.NodeEmb(x, edge_index, edge_weight, z)
+        emb = self.Pool(emb, subG_node, self.pools[id])
+        return self.preds[id](emb)

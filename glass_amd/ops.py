@@ -1,0 +1,256 @@
+"""torch.autograd bindings of the HIP kernels (host side of the C ABI in include/glass_hip.h).
+
+Every op here enqueues hand-written gfx950 kernels on torch's current HIP stream through ctypes;
+torch only supplies device memory, streams and the autograd tape.  There is no CPU path: a CPU
+tensor raises GlassHipError (the CPU restatement lives in oracle/ and is a checker only).
+"""
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, ACT_ELU, POOL_MODES, GlassHipError
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise GlassHipError(f"glass_amd op got a {t.device} tensor: the HIP path is the only path (no CPU fallback)")
+
+
+def _rows(t):
+    """Row-major 2-D fp32 view -> (tensor, leading dimension)."""
+    if t.dim() != 2 or t.dtype != torch.float32:
+        raise GlassHipError(f"expected a 2-D float32 tensor, got {tuple(t.shape)} {t.dtype}")
+    if t.stride(1) != 1 or (t.shape[0] > 1 and t.stride(0) < t.shape[1]):
+        t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+# ---------------------------------------------------------------------------------------------
+# dropout RNG state: uint64[2] = (seed, step) in DEVICE memory, so captured graphs get fresh masks
+# ---------------------------------------------------------------------------------------------
+_rng = {}
+
+
+def rng_state(device):
+    st = _rng.get(device)
+    if st is None:
+        st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        _rng[device] = st
+    return st
+
+
+def rng_seed(seed, device):
+    _rng[device] = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+
+
+def rng_advance(device):
+    _lib.check(_lib.load().glass_rng_advance(rng_state(device).data_ptr(), _stream()), "glass_rng_advance")
+
+
+# ---------------------------------------------------------------------------------------------
+# K4  MaxZOZ
+# ---------------------------------------------------------------------------------------------
+def maxzoz(n_nodes, pos):
+    """z[n] = 1 iff n occurs in pos (int64, -1 = padding).  reference impl/utils.py:32-45"""
+    _need_gpu(pos)
+    pos = pos.contiguous()
+    if pos.dtype != torch.int64:
+        pos = pos.to(torch.int64)
+    z = torch.empty(n_nodes, dtype=torch.int64, device=pos.device)
+    _lib.check(_lib.load().glass_maxzoz_i64(pos.data_ptr(), pos.numel(), z.data_ptr(), n_nodes, _stream()),
+               "glass_maxzoz_i64")
+    return z
+
+
+# ---------------------------------------------------------------------------------------------
+# K1  aggregation
+# ---------------------------------------------------------------------------------------------
+class SpMMFn(torch.autograd.Function):
+    """y = A @ x with A a graph.CSRAdj; backward dx = A^T @ dy (A carries no gradient:
+    edge weights never require grad in the reference, datasets.py:126,226)."""
+    @staticmethod
+    def forward(ctx, adj, x):
+        _need_gpu(x)
+        x, _ = _rows(x)
+        ctx.adj = adj
+        return adj.fwd.spmm(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy, _ = _rows(dy)
+        return None, ctx.adj.bwd.spmm(dy)
+
+
+def spmm(adj, x):
+    return SpMMFn.apply(adj, x)
+
+
+# ---------------------------------------------------------------------------------------------
+# K3+K4  label + embedding
+# ---------------------------------------------------------------------------------------------
+class EmbedLabelFn(torch.autograd.Function):
+    """(h, mask) = (W[x], label byte).  Backward dW = S^T @ dh on K1 via graph.Selection."""
+    @staticmethod
+    def forward(ctx, weight, x_flat, z, selection):
+        _need_gpu(weight, x_flat, z)
+        n, (V, H) = x_flat.shape[0], weight.shape
+        w = weight.contiguous()
+        out = torch.empty((n, H), dtype=torch.float32, device=w.device)
+        mask = torch.empty(n, dtype=torch.uint8, device=w.device)
+        zp = 0 if z is None else z.data_ptr()
+        rc = _lib.load().glass_embed_label_f32(x_flat.data_ptr(), w.data_ptr(), V, zp, 0, 0, out.data_ptr(), H,
+                                               mask.data_ptr(), n, H, _stream())
+        _lib.check(rc, "glass_embed_label_f32")
+        ctx.selection = selection
+        ctx.mark_non_differentiable(mask)
+        return out, mask
+
+    @staticmethod
+    def backward(ctx, dout, _dmask):
+        dout, _ = _rows(dout)
+        return ctx.selection.op.spmm(dout), None, None, None
+
+
+def embed_label(weight, x_flat, z, selection):
+    return EmbedLabelFn.apply(weight, x_flat, z, selection)
+
+
+# ---------------------------------------------------------------------------------------------
+# mix
+# ---------------------------------------------------------------------------------------------
+class MixFn(torch.autograd.Function):
+    """out = mask ? zr*a1+(1-zr)*a0 : zr*a0+(1-zr)*a1 with a = act(T), T = [T1 | T0]  [N,2H]."""
+    @staticmethod
+    def forward(ctx, T, mask, z_ratio, act):
+        _need_gpu(T, mask)
+        T, ldt = _rows(T)
+        n, H = T.shape[0], T.shape[1] // 2
+        out = torch.empty((n, H), dtype=torch.float32, device=T.device)
+        rc = _lib.load().glass_mix_fwd_f32(T.data_ptr(), ldt, mask.data_ptr(), float(z_ratio), act, out.data_ptr(), H,
+                                           n, H, _stream())
+        _lib.check(rc, "glass_mix_fwd_f32")
+        ctx.save_for_backward(T if act != ACT_NONE else None, mask)
+        ctx.z_ratio, ctx.act, ctx.shape = float(z_ratio), act, (n, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        T, mask = ctx.saved_tensors
+        n, H = ctx.shape
+        dout, ldd = _rows(dout)
+        dT = torch.empty((n, 2 * H), dtype=torch.float32, device=dout.device)
+        tp, ldt = (0, 0) if T is None else (T.data_ptr(), T.stride(0))
+        rc = _lib.load().glass_mix_bwd_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), ctx.z_ratio, ctx.act,
+                                           dT.data_ptr(), 2 * H, n, H, _stream())
+        _lib.check(rc, "glass_mix_bwd_f32")
+        return dT, None, None, None
+
+
+def mix(T, mask, z_ratio, act):
+    return MixFn.apply(T, mask, z_ratio, act)
+
+
+# ---------------------------------------------------------------------------------------------
+# K6  GraphNorm (+ELU +dropout)
+# ---------------------------------------------------------------------------------------------
+_gn_ws = {}
+
+
+def _graphnorm_ws(device, n_rows, C):
+    key = (device, C)
+    ws = _gn_ws.get(key)
+    if ws is None:
+        nbytes = _lib.load().glass_graphnorm_ws_bytes(n_rows, C)
+        ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=device)
+        _gn_ws[key] = ws
+    return ws
+
+
+class GraphNormFn(torch.autograd.Function):
+    """y = dropout(act(GraphNorm(x))) over the whole graph (PyG GraphNorm with batch=None)."""
+    @staticmethod
+    def forward(ctx, x, gamma, beta, alpha, eps, act, p_drop, call_id):
+        _need_gpu(x, gamma)
+        x, ldx = _rows(x)
+        n, C = x.shape
+        y = torch.empty((n, C), dtype=torch.float32, device=x.device)
+        saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        ws = _graphnorm_ws(x.device, n, C)
+        rng = rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        g, b, a = gamma.contiguous(), beta.contiguous(), alpha.contiguous()
+        rc = _lib.load().glass_graphnorm_fwd_f32(x.data_ptr(), ldx, y.data_ptr(), C, n, C, g.data_ptr(), b.data_ptr(),
+                                                 a.data_ptr(), eps, saved.data_ptr(), act, p_drop, rng, call_id,
+                                                 ws.data_ptr(), _stream())
+        _lib.check(rc, "glass_graphnorm_fwd_f32")
+        ctx.save_for_backward(x, g, a, saved)
+        ctx.cfg = (act, p_drop, call_id)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, a, saved = ctx.saved_tensors
+        act, p_drop, call_id = ctx.cfg
+        n, C = x.shape
+        dy, lddy = _rows(dy)
+        dx = torch.empty((n, C), dtype=torch.float32, device=x.device)
+        dparams = torch.empty((3, C), dtype=torch.float32, device=x.device)
+        ws = _graphnorm_ws(x.device, n, C)
+        rng = rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), lddy, x.data_ptr(), x.stride(0), dx.data_ptr(), C, n,
+                                                 C, g.data_ptr(), a.data_ptr(), saved.data_ptr(),
+                                                 dparams[0].data_ptr(), dparams[1].data_ptr(), dparams[2].data_ptr(),
+                                                 act, p_drop, rng, call_id, ws.data_ptr(), _stream())
+        _lib.check(rc, "glass_graphnorm_bwd_f32")
+        return dx, dparams[0], dparams[1], dparams[2], None, None, None, None
+
+
+def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id=0):
+    return GraphNormFn.apply(x, gamma, beta, alpha, float(eps), int(act), float(p_drop), int(call_id))
+
+
+# ---------------------------------------------------------------------------------------------
+# K7  subgraph pooling
+# ---------------------------------------------------------------------------------------------
+class SegmentPoolFn(torch.autograd.Function):
+    """out[b] = reduce over the non-padding nodes of pos[b] of emb[node]  (sum|mean|max|size)."""
+    @staticmethod
+    def forward(ctx, emb, pos, mode):
+        _need_gpu(emb, pos)
+        if mode not in POOL_MODES:
+            raise NotImplementedError  # reference: GLASSTest.py:168-171
+        emb, lde = _rows(emb)
+        pos = pos.contiguous()
+        if pos.dtype != torch.int64:
+            pos = pos.to(torch.int64)
+        n, C = emb.shape
+        B, Smax = pos.shape
+        out = torch.empty((B, C), dtype=torch.float32, device=emb.device)
+        argmax = torch.empty((B, C), dtype=torch.int32, device=emb.device) if mode == "max" else None
+        rc = _lib.load().glass_segment_pool_f32(emb.data_ptr(), lde, pos.data_ptr(), B, Smax, POOL_MODES[mode],
+                                                out.data_ptr(), C, 0 if argmax is None else argmax.data_ptr(), n, C,
+                                                _stream())
+        _lib.check(rc, "glass_segment_pool_f32")
+        ctx.save_for_backward(pos, argmax)
+        ctx.cfg = (mode, n, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pos, argmax = ctx.saved_tensors
+        mode, n, C = ctx.cfg
+        dout, ldd = _rows(dout)
+        B, Smax = pos.shape
+        demb = torch.zeros((n, C), dtype=torch.float32, device=dout.device)
+        rc = _lib.load().glass_segment_pool_bwd_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, Smax, POOL_MODES[mode],
+                                                    0 if argmax is None else argmax.data_ptr(), demb.data_ptr(), C, n,
+                                                    C, _stream())
+        _lib.check(rc, "glass_segment_pool_bwd_f32")
+        return demb, None, None
+
+
+def segment_pool(emb, pos, mode):
+    return SegmentPoolFn.apply(emb, pos, mode)

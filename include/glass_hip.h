@@ -1,0 +1,156 @@
+/* glass_hip.h — C ABI of libglass_hip.so: the MI355X (gfx950) kernels behind GLASS's labeled
+ * message-passing hot path.
+ *
+ * This is the LOWER drop-in boundary of SURVEY.md §8(b): the entry points a binding of the
+ * reference would call in place of the third-party kernels its Python dispatches to today
+ * (ATen sparse addmm, nn.Embedding, index_put, PyG GraphNorm / global_*_pool → torch_scatter).
+ * Each function cites the reference call site (file:line under /root/reference) it replaces.
+ *
+ * Conventions
+ *  - plain C: raw DEVICE pointers owned by the caller, sizes as int64_t, `stream` is a
+ *    hipStream_t passed as void* (NULL = default stream). No torch types, no exceptions.
+ *  - every function returns 0 on success, a positive hipError_t, or a negative GLASS_E_* code;
+ *    glass_last_error_string() describes the last failure on the calling thread.
+ *  - functions only ENQUEUE work on `stream`: no allocation, no host synchronisation, no global
+ *    state (hipGraph-capturable). Scratch is caller-provided; its size comes from a *_ws_bytes()
+ *    query that is pure host arithmetic.
+ *  - all floating data is fp32, row-major, with an explicit leading dimension (`ld*`, in
+ *    elements) so outputs can land inside wider buffers (the [g || x_] concat, the JK concat).
+ *  - results are deterministic (bitwise repeatable run to run) unless a function says otherwise.
+ */
+#ifndef GLASS_HIP_H
+#define GLASS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLASS_ABI_VERSION 1
+
+#define GLASS_E_ARG (-1)       /* bad argument (null pointer, negative size, misaligned ld) */
+#define GLASS_E_PLAN (-2)      /* plan blob does not match the call (magic / sizes) */
+#define GLASS_E_UNSUPPORTED (-3)
+
+/* pool modes: AddPool / MeanPool / MaxPool / SizePool (impl/models.py:294-319) */
+#define GLASS_POOL_SUM 0
+#define GLASS_POOL_MEAN 1
+#define GLASS_POOL_MAX 2
+#define GLASS_POOL_SIZE 3
+
+/* activation fused into a kernel: none, or ELU(alpha=1) (GLASSTest.py:143) */
+#define GLASS_ACT_NONE 0
+#define GLASS_ACT_ELU 1
+
+int glass_version(void);
+const char* glass_last_error_string(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  CSR aggregation  Y = A @ X         replaces `self.adj @ x` (impl/models.py:164) and its
+ *     autograd backward `adj^T @ g` (call it again with the CSR of A^T).
+ *
+ * The launch schedule ("plan") depends only on the row pointer: rows are dealt to wavefronts
+ * in edge-balanced contiguous ranges; rows longer than a threshold are cut into chunks that a
+ * whole workgroup reduces through LDS, and rows longer than one chunk are summed from
+ * per-chunk partial rows in a fixed order (no float atomics -> bitwise repeatable).
+ *
+ *   glass_spmm_plan_build: HOST function. `rowptr_host` = int32[n_rows+1] in host memory.
+ *     Writes the plan into `plan_host` (int32 words; pass NULL to only query) and returns the
+ *     number of int32 words needed in *plan_words. The caller copies the blob to the device.
+ *     The first GLASS_PLAN_HEADER_WORDS words are the header the launch reads on the host.
+ *   glass_spmm_ws_bytes: scratch bytes needed by glass_spmm_csr_f32 for feature width H.
+ * ---------------------------------------------------------------------------------------- */
+#define GLASS_PLAN_HEADER_WORDS 16
+int glass_spmm_plan_build(const int32_t* rowptr_host, int64_t n_rows, int32_t* plan_host, int64_t* plan_words);
+int64_t glass_spmm_ws_bytes(const int32_t* plan_header_host, int64_t H);
+int glass_spmm_csr_f32(const int32_t* rowptr, const int32_t* col, const float* val, /* CSR of A, device */
+                       const float* X, int64_t ldx,                                 /* [n_cols, H] */
+                       float* Y, int64_t ldy,                                       /* [n_rows, H] */
+                       int64_t n_rows, int64_t H,
+                       const int32_t* plan_header_host, const int32_t* plan_dev, void* ws, void* stream);
+
+/* K2  normalised edge values of buildAdj (impl/models.py:83-111) on an (row,col)-sorted COO:
+ *     deg = segment-sum of w per row, deg<0.5 -> +1; aggr 0=mean w/deg[row], 1=sum w,
+ *     2=gcn deg[row]^-1/2 * w * deg[col]^-1/2.  Duplicate (row,col) entries stay separate CSR
+ *     entries (they act additively in the product, as in the reference's uncoalesced COO).
+ *     Unknown aggr -> GLASS_E_UNSUPPORTED (the reference raises NotImplementedError). */
+int glass_adj_values_f32(const int32_t* rowptr, const int32_t* col, const float* w, int64_t n_rows, int aggr,
+                         float* deg_ws /*[n_rows], receives deg*/, float* val, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K4  max-zero-one label   replaces utils.MaxZOZ (impl/utils.py:32-45):  z[n]=0; z[pos>=0]=1
+ * ---------------------------------------------------------------------------------------- */
+int glass_maxzoz_i64(const int64_t* pos, int64_t n_pos /* B*Smax, -1 = padding */, int64_t* z, int64_t n_nodes,
+                     void* stream);
+
+/* K3+K4 fused label + embedding   replaces `mask=(z>0.5)` and `input_emb(x)`
+ *     (impl/models.py:242-248):  out[n,:] = W[x[n],:],  mask[n] = label of node n.
+ *     The label comes from `z` (int64[N], as MaxZOZ produced it) when z != NULL, else from
+ *     `pos` (int64[n_pos], -1 pad) scattered here; both NULL -> every node labeled
+ *     (impl/models.py:243-244). An index of x outside [0,V) yields a zero row here; callers
+ *     validate x once per dataset (nn.Embedding would raise IndexError). */
+int glass_embed_label_f32(const int64_t* x, const float* W, int64_t V, const int64_t* z, const int64_t* pos,
+                          int64_t n_pos, float* out, int64_t ldo, uint8_t* mask, int64_t n_nodes, int64_t H,
+                          void* stream);
+/*     backward of the embedding gather (ATen embedding_dense_backward, a scatter-add):
+ *     dW[v,:] = sum_{n: x[n]=v} dout[n,:]  is  dW = S^T @ dout with S the [N,V] one-hot selection
+ *     matrix, so it runs on K1: call glass_spmm_csr_f32 with the CSR of S^T (rows = table rows,
+ *     cols = node ids in ascending order, val = 1), built once per dataset because x is static.
+ *     That keeps the scatter-add atomic-free and bitwise repeatable, and a hot table row
+ *     (use_one: every node -> row 1) is split over workgroups by the K1 plan. */
+
+/* ------------------------------------------------------------------------------------------
+ * K5' label-conditioned mix (impl/models.py:158-162 and 169-173)
+ *     T = [T1 | T0] is the [N, 2H] output of the two stacked Linears (f1 then f0).
+ *     a = act(T);  out = mask ? zr*a1 + (1-zr)*a0 : zr*a0 + (1-zr)*a1
+ *     backward: dT1 = dout * (mask ? zr : 1-zr) * act'(T1), dT0 likewise with the roles swapped.
+ *     z_ratio is a double so that 1 - z_ratio is formed as the reference forms it (Python float)
+ *     before both factors are rounded to fp32.
+ * ---------------------------------------------------------------------------------------- */
+int glass_mix_fwd_f32(const float* T, int64_t ldt, const uint8_t* mask, double z_ratio, int act, float* out,
+                      int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
+int glass_mix_bwd_f32(const float* dout, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, double z_ratio,
+                      int act, float* dT, int64_t lddt, int64_t n_nodes, int64_t H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K6  whole-graph GraphNorm (PyG GraphNorm with batch=None; impl/models.py:165,249,257,266,271)
+ *     mu = mean_rows(x); o = x - alpha*mu; y = gamma*o*rsqrt(mean_rows(o^2)+eps) + beta
+ *     optionally followed by ELU and by inverted dropout (the reference applies F.dropout right
+ *     after every GraphNorm(+act): impl/models.py:166,251,259).
+ *     Column sums are accumulated in fp64 (one pass: sum and sum of squares), reduced in a fixed
+ *     order. `saved` = float[4*C]: mean, rstd, scale, shift (needed by the backward).
+ *     Dropout: keep-mask from Philox4x32-10 keyed by (rng_state[0]=seed, rng_state[1]=step,
+ *     call_id, element index); rng_state is DEVICE memory so captured graphs see new masks each
+ *     replay once glass_rng_advance has run. p_drop = 0 disables it (rng_state may be NULL).
+ * ---------------------------------------------------------------------------------------- */
+int64_t glass_graphnorm_ws_bytes(int64_t n_rows, int64_t C);
+int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int64_t C,
+                            const float* gamma, const float* beta, const float* alpha, float eps, float* saved,
+                            int act, float p_drop, const uint64_t* rng_state, uint64_t call_id, void* ws,
+                            void* stream);
+int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                            int64_t n_rows, int64_t C, const float* gamma, const float* alpha, const float* saved,
+                            float* dgamma, float* dbeta, float* dalpha, int act, float p_drop,
+                            const uint64_t* rng_state, uint64_t call_id, void* ws, void* stream);
+int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 */
+
+/* ------------------------------------------------------------------------------------------
+ * K7  subgraph pooling   replaces pad2batch + emb[pos] + global_{add,mean,max}_pool /
+ *     GraphSizeNorm (impl/models.py:346-350, 294-319; impl/utils.py:18-29)
+ *     out[b,:] = reduce_{j: pos[b,j]>=0} emb[pos[b,j],:]   (sum | mean | max | sum * n_b^-1/2)
+ *     argmax (int32 [B,C], only for max, may be NULL otherwise) records the contributing node.
+ *     An all-padding row gives 0 (torch_scatter semantics).
+ *     Backward scatters into demb (must be ZEROED by the caller): a node shared by several
+ *     subgraphs accumulates with float atomics — order-dependent only beyond two sharers.
+ * ---------------------------------------------------------------------------------------- */
+int glass_segment_pool_f32(const float* emb, int64_t lde, const int64_t* pos, int64_t B, int64_t Smax, int mode,
+                           float* out, int64_t ldo, int32_t* argmax, int64_t n_nodes, int64_t C, void* stream);
+int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode,
+                               const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLASS_HIP_H */

@@ -1,0 +1,303 @@
+"""Kernel-level parity: every HIP kernel (through the C ABI, via glass_amd.ops) against the CPU
+oracle on the same seeded inputs.  Tolerance: rel-inf <= 1e-5 (north_star), written per test;
+integer / index outputs must be exact."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, rel_inf
+from oracle import glass_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda:0"
+
+
+def _graph(n, n_pairs, seed, weighted=False, powerlaw=0.0):
+    from glass_amd import synth
+    ei, ew = synth.make_graph(n, n_pairs, seed, powerlaw)
+    if weighted:
+        rng = np.random.default_rng(seed + 100)
+        ew = rng.uniform(0.25, 2.0, ew.shape[0]).astype(np.float32)
+    return torch.from_numpy(ei), torch.from_numpy(ew)
+
+
+# ---------------------------------------------------------------------------------- K2 + K1
+@pytest.mark.parametrize("aggr", ["mean", "sum", "gcn"])
+def test_adj_values_g1(aggr):
+    """buildAdj on the golden 12-node graph: isolated node, duplicate edge, self-loop, weights."""
+    from glass_amd.graph import CSRAdj
+    g = load("g1_buildadj.npz")
+    ei, ew = torch.from_numpy(g["edge_index"]).to(DEV), torch.from_numpy(g["edge_weight"]).to(DEV)
+    adj = CSRAdj(ei, ew, int(g["n_node"]), aggr)
+    assert rel_inf(adj.to_dense().cpu(), g["A_" + aggr]) < 1e-6
+    # transpose operand really is A^T
+    n = adj.n_node
+    x = torch.eye(n, device=DEV)
+    assert rel_inf(adj.bwd.spmm(x).cpu(), g["A_" + aggr].T) < 1e-6
+    assert rel_inf(adj.fwd.spmm(x).cpu(), g["A_" + aggr]) < 1e-6
+
+
+def test_adj_unknown_aggr_raises():
+    from glass_amd.models import buildAdj
+    ei, ew = _graph(20, 30, 0)
+    with pytest.raises(NotImplementedError):
+        buildAdj(ei.to(DEV), ew.to(DEV), 20, "median")
+
+
+@pytest.mark.parametrize("H", [1, 4, 8, 17, 20, 64, 100, 128, 256, 260, 512])
+@pytest.mark.parametrize("aggr", ["mean", "gcn"])
+def test_spmm_widths(H, aggr):
+    """All feature widths: float4 path (H%4==0), scalar path (17), column tiling (>256)."""
+    from glass_amd.graph import CSRAdj
+    from glass_amd import ops
+    n = 700
+    ei, ew = _graph(n, 6000, 3, weighted=True)
+    x = torch.randn(n, H, generator=torch.Generator().manual_seed(H))
+    ref = O.build_adj(ei, ew, n, aggr).to(torch.float64) @ x.double()
+    adj = CSRAdj(ei.to(DEV), ew.to(DEV), n, aggr)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.spmm(adj, xg)
+    assert rel_inf(y.detach().cpu(), ref) < TOL
+    gout = torch.randn(n, H, generator=torch.Generator().manual_seed(H + 1))
+    y.backward(gout.to(DEV))
+    ref_g = O.build_adj(ei, ew, n, aggr).to(torch.float64).t() @ gout.double()
+    assert rel_inf(xg.grad.cpu(), ref_g) < TOL
+
+
+def test_spmm_long_rows_and_repeatable():
+    """Power-law graph: rows >= 256 edges (workgroup path) and > 2048 (chunked partials)."""
+    from glass_amd.graph import CSRAdj
+    n = 20000
+    ei, ew = _graph(n, 400000, 5, weighted=True, powerlaw=0.9)
+    deg = torch.bincount(ei[0], minlength=n)
+    assert int((deg >= 256).sum()) > 0 and int(deg.max()) > 2048
+    x = torch.randn(n, 64, generator=torch.Generator().manual_seed(1))
+    ref = O.build_adj(ei, ew, n, "mean").to(torch.float64) @ x.double()
+    adj = CSRAdj(ei.to(DEV), ew.to(DEV), n, "mean")
+    assert adj.fwd.header[5] > 0 and adj.fwd.header[6] > 0  # long items and multi-chunk rows exist
+    xg = x.to(DEV)
+    y1 = adj.fwd.spmm(xg)
+    y2 = adj.fwd.spmm(xg)
+    assert rel_inf(y1.cpu(), ref) < TOL
+    assert torch.equal(y1, y2)  # bitwise repeatable: no float atomics
+    yt = adj.bwd.spmm(xg)
+    ref_t = O.build_adj(ei, ew, n, "mean").to(torch.float64).t() @ x.double()
+    assert rel_inf(yt.cpu(), ref_t) < TOL
+
+
+def test_spmm_empty_rows_and_strided():
+    from glass_amd.graph import CSRAdj
+    n = 50
+    ei = torch.tensor([[0, 1, 1, 49], [1, 0, 49, 1]])
+    ew = torch.ones(4)
+    adj = CSRAdj(ei.to(DEV), ew.to(DEV), n, "sum")
+    wide = torch.randn(n, 96, device=DEV)
+    x = wide[:, 32:64]  # ld = 96
+    out = torch.full((n, 80), 7.0, device=DEV)
+    adj.fwd.spmm(x, out=out[:, 16:48])
+    ref = O.build_adj(ei, ew, n, "sum") @ x.cpu()
+    assert rel_inf(out[:, 16:48].cpu(), ref) < 1e-6
+    assert float(out[:, :16].min()) == 7.0 and float(out[:, 48:].min()) == 7.0  # neighbours untouched
+    assert float(out[5, 16:48].abs().max()) == 0.0  # isolated row written as zeros
+
+
+# ---------------------------------------------------------------------------------- K4, K3
+def test_maxzoz_g6_and_random():
+    from glass_amd import utils
+    g = load("g6_utils.npz")
+    x = torch.zeros(int(g["mz_n"]), 1, 1, dtype=torch.int64, device=DEV)
+    z = utils.MaxZOZ(x, torch.from_numpy(g["mz_pos"]).to(DEV))
+    assert z.dtype == torch.int64 and np.array_equal(z.cpu().numpy(), g["mz_z"])
+    rng = np.random.default_rng(0)
+    pos = rng.integers(-1, 5000, (80, 37))
+    zr = O.max_zero_one(torch.zeros(5000, 1), torch.from_numpy(pos))
+    zg = utils.MaxZOZ(torch.zeros(5000, 1, device=DEV), torch.from_numpy(pos).to(DEV))
+    assert torch.equal(zg.cpu(), zr)
+
+
+def test_pad2batch_batch2pad_docstrings():
+    from glass_amd import utils
+    pad = utils.batch2pad(torch.tensor([0, 1, 0, 0, 1, 1, 2, 2], device=DEV))
+    assert pad.cpu().tolist() == [[0, 2, 3], [1, 4, 5], [6, 7, -1]]
+    b, p = utils.pad2batch(pad)
+    assert b.cpu().tolist() == [0, 0, 0, 1, 1, 1, 2, 2] and p.cpu().tolist() == [0, 2, 3, 1, 4, 5, 6, 7]
+
+
+@pytest.mark.parametrize("H,V", [(64, 40), (17, 3), (8, 2)])
+def test_embed_label(H, V):
+    from glass_amd import ops
+    from glass_amd.graph import Selection
+    n = 3000
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randint(0, V, (n, ), generator=gen)
+    if V == 2:
+        x[:] = 1  # use_one: every node -> row 1 (a single hot table row)
+    w = torch.randn(V, H, generator=gen)
+    z = (torch.rand(n, generator=gen) < 0.1).to(torch.int64)
+    wg = w.to(DEV).requires_grad_(True)
+    xg = x.to(DEV)
+    h, mask = ops.embed_label(wg, xg, z.to(DEV), Selection(xg, V))
+    assert torch.equal(h.detach().cpu(), w[x])  # gather is exact
+    assert torch.equal(mask.cpu().bool(), z > 0)
+    gout = torch.randn(n, H, generator=gen)
+    h.backward(gout.to(DEV))
+    ref = torch.zeros(V, H, dtype=torch.float64).index_add_(0, x, gout.double())
+    assert rel_inf(wg.grad.cpu(), ref) < TOL
+    _, mask_all = ops.embed_label(wg, xg, None, Selection(xg, V))
+    assert bool(mask_all.bool().all())  # z=None -> every node labeled (models.py:243-244)
+
+
+def test_embed_index_out_of_range_raises():
+    from glass_amd.graph import Selection
+    with pytest.raises(IndexError):
+        Selection(torch.tensor([0, 5, 2], device=DEV), 5)
+
+
+# ---------------------------------------------------------------------------------- mix
+@pytest.mark.parametrize("H", [8, 17, 64])
+@pytest.mark.parametrize("act", [0, 1])
+def test_mix(H, act):
+    from glass_amd import ops
+    n = 1234
+    gen = torch.Generator().manual_seed(11)
+    T = torch.randn(n, 2 * H, generator=gen)
+    mask = torch.rand(n, generator=gen) < 0.3
+    gout = torch.randn(n, H, generator=gen)
+    zr = 0.85
+    Tc = T.double().requires_grad_(True)
+    a = torch.nn.functional.elu(Tc) if act else Tc
+    ref = O._mix(mask.reshape(-1, 1), zr, a[:, :H], a[:, H:])
+    ref.backward(gout.double())
+    Tg = T.to(DEV).requires_grad_(True)
+    out = ops.mix(Tg, mask.to(DEV).to(torch.uint8), zr, act)
+    out.backward(gout.to(DEV))
+    assert rel_inf(out.detach().cpu(), ref.detach()) < 1e-6
+    assert rel_inf(Tg.grad.cpu(), Tc.grad) < 1e-6
+
+
+# ---------------------------------------------------------------------------------- K6
+@pytest.mark.parametrize("n,C", [(4998, 64), (1000, 17), (333, 8), (20000, 128), (513, 300)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_graphnorm(n, C, act):
+    from glass_amd import ops
+    gen = torch.Generator().manual_seed(n + C)
+    x = torch.randn(n, C, generator=gen) * 2.0 + 5.0  # mean 5 / std 2: the hard case for one-pass variance
+    gamma = 1 + 0.3 * torch.randn(C, generator=gen)
+    beta = 0.2 * torch.randn(C, generator=gen)
+    alpha = 1 + 0.3 * torch.randn(C, generator=gen)
+    gout = torch.randn(n, C, generator=gen)
+    gn = O.GraphNorm(C).double()
+    with torch.no_grad():
+        gn.weight.copy_(gamma), gn.bias.copy_(beta), gn.mean_scale.copy_(alpha)
+    xc = x.double().requires_grad_(True)
+    ref = gn(xc)
+    if act:
+        ref = torch.nn.functional.elu(ref)
+    ref.backward(gout.double())
+    xg = x.to(DEV).requires_grad_(True)
+    params = [t.to(DEV).requires_grad_(True) for t in (gamma, beta, alpha)]
+    y = ops.graphnorm(xg, *params, 1e-5, act)
+    y.backward(gout.to(DEV))
+    assert rel_inf(y.detach().cpu(), ref.detach()) < TOL
+    assert rel_inf(xg.grad.cpu(), xc.grad) < TOL
+    for mine, theirs in zip(params, (gn.weight, gn.bias, gn.mean_scale)):
+        assert rel_inf(mine.grad.cpu(), theirs.grad) < TOL
+
+
+def test_graphnorm_strided_input_and_repeatable():
+    from glass_amd import ops
+    n, C = 5000, 64
+    wide = torch.randn(n, 3 * C, device=DEV)
+    x = wide[:, C:2 * C]
+    ones, zeros = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    y1 = ops.graphnorm(x, ones, zeros, ones)
+    y2 = ops.graphnorm(x.contiguous(), ones, zeros, ones)
+    assert torch.equal(y1, y2)
+    ref = O.GraphNorm(C)(x.cpu())
+    assert rel_inf(y1.cpu(), ref.detach()) < TOL
+
+
+def test_graphnorm_dropout_statistics():
+    """Inverted dropout fused after GraphNorm: keep-rate, scaling, and the backward reuses the
+    forward's mask (regenerated from the Philox counter, not stored)."""
+    from glass_amd import ops
+    n, C, p = 20000, 64, 0.5
+    x = torch.randn(n, C, device=DEV).requires_grad_(True)
+    ones, zeros = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.rng_seed(123, x.device)
+    ops.rng_advance(x.device)
+    y0 = ops.graphnorm(x, ones, zeros, ones)
+    y = ops.graphnorm(x, ones, zeros, ones, p_drop=p, call_id=5)
+    kept = y != 0
+    rate = kept.float().mean().item()
+    assert abs(rate - (1 - p)) < 0.01
+    assert rel_inf(y[kept].cpu(), (y0[kept] / (1 - p)).cpu()) < 1e-6
+    # same (seed, step, call_id) -> same mask; other call_id or next step -> different mask
+    y_same = ops.graphnorm(x, ones, zeros, ones, p_drop=p, call_id=5)
+    assert torch.equal(y_same, y)
+    assert not torch.equal(ops.graphnorm(x, ones, zeros, ones, p_drop=p, call_id=6) != 0, kept)
+    # backward: gradient flows only through kept elements.  d/dx of sum(y*w) through GraphNorm is
+    # dense, so check the mask by linearity: grad(p) computed with upstream w must equal
+    # grad(no-dropout) computed with upstream w * keepmask / (1-p).
+    w = torch.randn(n, C, device=DEV)
+    (g_drop, ) = torch.autograd.grad(y, x, w)
+    (g_ref, ) = torch.autograd.grad(y0, x, w * kept / (1 - p))
+    assert rel_inf(g_drop.cpu(), g_ref.cpu()) < 1e-5
+    ops.rng_advance(x.device)
+    assert not torch.equal(ops.graphnorm(x, ones, zeros, ones, p_drop=p, call_id=5) != 0, kept)
+
+
+# ---------------------------------------------------------------------------------- K7
+@pytest.mark.parametrize("mode", ["sum", "mean", "max", "size"])
+def test_pool_g4(mode):
+    from glass_amd import ops
+    g = load("g4_pool.npz")
+    e = torch.from_numpy(g["emb"]).to(DEV).requires_grad_(True)
+    y = ops.segment_pool(e, torch.from_numpy(g["pos"]).to(DEV), mode)
+    y.backward(torch.from_numpy(g["gout"]).to(DEV))
+    assert rel_inf(y.detach().cpu(), g["y_" + mode]) < 1e-6
+    assert rel_inf(e.grad.cpu(), g["grad_" + mode]) < 1e-6
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean", "max", "size"])
+@pytest.mark.parametrize("C", [128, 17, 512])
+def test_pool_ragged(mode, C):
+    from glass_amd import ops
+    n, B, S = 5000, 99, 40
+    rng = np.random.default_rng(C)
+    pos = np.full((B, S), -1, dtype=np.int64)
+    for b in range(B):
+        k = rng.integers(1, S + 1)
+        pos[b, :k] = rng.choice(n, k, replace=False)
+    pos[3, :] = -1  # an all-padding row pools to 0 (torch_scatter semantics for an empty segment)
+    pos[4, :5] = pos[5, :5]  # nodes shared between subgraphs
+    emb = torch.randn(n, C, generator=torch.Generator().manual_seed(C))
+    gout = torch.randn(B, C, generator=torch.Generator().manual_seed(C + 1))
+    post = torch.from_numpy(pos)
+    ec = emb.double().requires_grad_(True)
+    batch, p = O.pad_to_batch(post)
+    ref = O.segment_pool(ec[p], batch, B, mode)
+    ref.backward(gout.double())
+    eg = emb.to(DEV).requires_grad_(True)
+    y = ops.segment_pool(eg, post.to(DEV), mode)
+    y.backward(gout.to(DEV))
+    assert rel_inf(y.detach().cpu(), ref.detach()) < 1e-6
+    assert float(y[3].abs().max()) == 0.0
+    assert rel_inf(eg.grad.cpu(), ec.grad) < 1e-6
+
+
+def test_pool_unknown_mode_raises():
+    from glass_amd import ops
+    with pytest.raises(NotImplementedError):
+        ops.segment_pool(torch.randn(4, 4, device=DEV), torch.zeros(1, 2, dtype=torch.int64, device=DEV), "median")
+
+
+def test_cpu_tensor_fails_loudly():
+    """No CPU fallback: the product path refuses CPU tensors instead of computing on the host."""
+    from glass_amd import ops
+    from glass_amd._lib import GlassHipError
+    with pytest.raises(GlassHipError):
+        ops.graphnorm(torch.randn(8, 4), torch.ones(4), torch.zeros(4), torch.ones(4))
+    with pytest.raises(GlassHipError):
+        ops.maxzoz(10, torch.zeros(2, 2, dtype=torch.int64))
