@@ -184,16 +184,20 @@ class EmbZGConv(nn.Module):
                 gn.reset_parameters()
 
     def _selection(self, x_flat):
-        V = self.input_emb.weight.shape[0]
-        if self._sel is None or self._sel[0] is not x_flat or self._sel[1] != V:
-            self._sel = (x_flat, V, Selection(x_flat, V))
+        # x is static per dataset: key the cached selection on the storage it views (the tensor is
+        # kept alive in the cache entry so the pointer cannot be recycled underneath us)
+        key = (x_flat.data_ptr(), x_flat.shape[0], self.input_emb.weight.shape[0])
+        if self._sel is None or self._sel[0] != key:
+            self._sel = (key, x_flat, Selection(x_flat, key[2]))
         return self._sel[2]
 
     def forward(self, x, edge_index, edge_weight, z=None):
         n = x.shape[0]
         if x.numel() != n:
             raise NotImplementedError("one integer feature per node (x of shape [N,1])")
-        x_flat = x if x.dim() == 1 else x.view(n)
+        x_flat = x.reshape(n)
+        if x_flat.dtype != torch.int64:
+            x_flat = x_flat.to(torch.int64)
         p = self.dropout if self.training else 0.0
         if self.training and (p > 0 or any(c.dropout > 0 for c in self.convs)):
             ops.rng_advance(x.device)  # new dropout masks for this forward/backward pair

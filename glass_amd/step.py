@@ -1,0 +1,85 @@
+"""One training step of the hot loop (reference impl/train.py:10-16 + ZGDataloader), optionally
+replayed from a captured hipGraph.
+
+The step is ~100 short kernels on small graphs (ppi_bp-shape: the aggregation itself is ~35 us),
+so eager launches are host-bound; every kernel in libglass_hip only enqueues work on the caller's
+stream (no allocation, no sync), which makes the whole step capturable: MaxZOZ -> zero grads ->
+forward -> loss -> backward -> [all-reduce] -> Adam.  Dropout masks still change every replay
+because the Philox (seed, step) pair lives in device memory and is advanced by a captured kernel.
+With more than one rank the collective stays outside the graphs (forward/backward graph, eager
+all-reduce on the same stream, optimizer graph)."""
+import torch
+
+from . import dist as gdist
+from . import utils
+
+
+class TrainStep:
+    def __init__(self, model, optimizer, loss_fn, x, edge_index, edge_weight, bucket=None, use_graph=True,
+                 warmup_iters=3):
+        self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
+        self.x, self.ei, self.ew = x, edge_index, edge_weight
+        self.bucket = bucket if bucket is not None else gdist.bucket_for(model)
+        self.use_graph = use_graph
+        self.warmup_iters = warmup_iters
+        self.graphed = False
+        self._pos = self._y = None
+        self._loss = torch.zeros((), device=x.device)
+        self._g_fb = self._g_opt = None
+
+    # -- the step body, split at the collective ---------------------------------------------------
+    def _fwd_bwd(self):
+        z = utils.MaxZOZ(self.x, self._pos)
+        self.bucket.zero()
+        pred = self.model(self.x, self.ei, self.ew, self._pos, z, id=0)
+        loss = self.loss_fn(pred, self._y)
+        loss.backward()
+        self._loss.copy_(loss.detach())
+
+    def _capture(self):
+        dist_on = gdist.is_distributed()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # warm-up: builds CSR / plans / workspaces outside the capture
+            for _ in range(self.warmup_iters):
+                self._fwd_bwd()
+                self.bucket.all_reduce_mean()
+                self.opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._g_fb = torch.cuda.CUDAGraph()
+        if not dist_on:
+            with torch.cuda.graph(self._g_fb):
+                self._fwd_bwd()
+                self.opt.step()
+        else:
+            with torch.cuda.graph(self._g_fb):
+                self._fwd_bwd()
+            self._g_opt = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
+                self.opt.step()
+        self.graphed = True
+
+    def __call__(self, pos, y):
+        if self._pos is None:
+            self._pos, self._y = pos.clone(), y.clone()
+            if self.use_graph:
+                self._capture()
+        if pos.shape != self._pos.shape:
+            raise ValueError("TrainStep needs a fixed batch shape (drop_last=True): "
+                             f"{tuple(pos.shape)} vs {tuple(self._pos.shape)}")
+        self._pos.copy_(pos)
+        self._y.copy_(y)
+        if self.graphed:
+            self._g_fb.replay()
+            if self._g_opt is not None:
+                self.bucket.all_reduce_mean()
+                self._g_opt.replay()
+        else:
+            self._fwd_bwd()
+            self.bucket.all_reduce_mean()
+            self.opt.step()
+        return self._loss
+
+    def last_loss(self):
+        return float(self._loss.item())

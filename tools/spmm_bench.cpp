@@ -1,0 +1,189 @@
+// Stand-alone micro-benchmark of K1 (glass_spmm_csr_f32) — no torch, links libglass_hip.so only.
+// Generates a synthetic symmetric graph on the host, times the kernel with HIP events on its own
+// stream, prints algorithmic GB/s against the HBM roofline, and spot-checks rows in fp64.
+// Also the program to put after `rocprofv3 ... --` for per-kernel traces and PMC counters.
+//
+//   spmm_bench <shape> [H] [iters] [--transpose]
+//   shape: ppi_bp | hpo_neuro | em_user | powerlaw | density-like | N:PAIRS[:zipf]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <random>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../include/glass_hip.h"
+
+#define HIP_OK(x)                                                                        \
+    do {                                                                                 \
+        hipError_t e_ = (x);                                                             \
+        if (e_ != hipSuccess) {                                                          \
+            fprintf(stderr, "%s:%d %s: %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+            exit(2);                                                                     \
+        }                                                                                \
+    } while (0)
+
+struct Graph {
+    int64_t n = 0;
+    std::vector<int32_t> rowptr, col;
+    std::vector<float> val;
+};
+
+// distinct undirected pairs, symmetrised, sorted by (row, col); val = 1/deg[row] ("mean")
+static Graph make_graph(int64_t n, int64_t pairs, double zipf, uint64_t seed) {
+    std::mt19937_64 rng(seed);
+    std::vector<double> cdf;
+    if (zipf > 0) {
+        cdf.resize(n);
+        double s = 0;
+        for (int64_t i = 0; i < n; ++i) cdf[i] = (s += pow((double)(i + 1), -zipf));
+        for (auto& c : cdf) c /= s;
+    }
+    std::uniform_real_distribution<double> U(0.0, 1.0);
+    auto draw = [&]() -> int64_t {
+        if (zipf > 0) {
+            int64_t k = std::lower_bound(cdf.begin(), cdf.end(), U(rng)) - cdf.begin();
+            return std::min<int64_t>(k, n - 1);
+        }
+        return (int64_t)(rng() % (uint64_t)n);
+    };
+    std::unordered_set<uint64_t> seen;
+    seen.reserve((size_t)pairs * 2);
+    std::vector<int32_t> deg(n, 0);
+    const int32_t max_deg = 50000;
+    std::vector<std::pair<int32_t, int32_t>> und;
+    und.reserve(pairs);
+    while ((int64_t)und.size() < pairs) {
+        int64_t u = draw(), v = draw();
+        if (u == v) continue;
+        if (u > v) std::swap(u, v);
+        if (deg[u] >= max_deg || deg[v] >= max_deg) continue;
+        if (!seen.insert((uint64_t)u * (uint64_t)n + (uint64_t)v).second) continue;
+        und.emplace_back((int32_t)u, (int32_t)v);
+        ++deg[u];
+        ++deg[v];
+    }
+    Graph g;
+    g.n = n;
+    g.rowptr.assign(n + 1, 0);
+    for (int64_t i = 0; i < n; ++i) g.rowptr[i + 1] = g.rowptr[i] + deg[i];
+    g.col.resize(2 * pairs);
+    std::vector<int32_t> fill(g.rowptr.begin(), g.rowptr.end() - 1);
+    for (auto& p : und) {
+        g.col[fill[p.first]++] = p.second;
+        g.col[fill[p.second]++] = p.first;
+    }
+    for (int64_t i = 0; i < n; ++i) std::sort(g.col.begin() + g.rowptr[i], g.col.begin() + g.rowptr[i + 1]);
+    g.val.resize(2 * pairs);
+    for (int64_t i = 0; i < n; ++i)
+        for (int32_t e = g.rowptr[i]; e < g.rowptr[i + 1]; ++e) g.val[e] = 1.0f / (float)std::max(deg[i], 1);
+    return g;
+}
+
+int main(int argc, char** argv) {
+    std::string shape = argc > 1 ? argv[1] : "ppi_bp";
+    int64_t H = argc > 2 ? atoll(argv[2]) : 64;
+    int iters = argc > 3 ? atoi(argv[3]) : 50;
+    int64_t n, pairs;
+    double zipf = 0;
+    if (shape == "ppi_bp") n = 17080, pairs = 316951;
+    else if (shape == "hpo_neuro") n = 14587, pairs = 3238174;
+    else if (shape == "em_user") n = 50000, pairs = 500000;
+    else if (shape == "powerlaw") n = 1000000, pairs = 10000000, zipf = 0.8;
+    else if (shape == "density-like") n = 4998, pairs = 29962;
+    else {
+        double z = 0;
+        long long a = 0, b = 0;
+        int k = sscanf(shape.c_str(), "%lld:%lld:%lf", &a, &b, &z);
+        if (k < 2) {
+            fprintf(stderr, "bad shape %s\n", shape.c_str());
+            return 1;
+        }
+        n = a, pairs = b, zipf = z;
+    }
+    Graph g = make_graph(n, pairs, zipf, 0);
+    const int64_t nnz = (int64_t)g.col.size();
+    int32_t maxdeg = 0;
+    for (int64_t i = 0; i < n; ++i) maxdeg = std::max(maxdeg, g.rowptr[i + 1] - g.rowptr[i]);
+
+    int64_t words = 0;
+    if (glass_spmm_plan_build(g.rowptr.data(), n, nullptr, &words)) return 3;
+    std::vector<int32_t> plan(words);
+    if (glass_spmm_plan_build(g.rowptr.data(), n, plan.data(), &words)) return 3;
+    const int64_t ws_bytes = glass_spmm_ws_bytes(plan.data(), H);
+
+    std::vector<float> X((size_t)n * H);
+    std::mt19937 r32(1);
+    std::normal_distribution<float> N01(0.f, 1.f);
+    for (auto& v : X) v = N01(r32);
+
+    int32_t *d_rowptr, *d_col, *d_plan;
+    float *d_val, *d_X, *d_Y;
+    void* d_ws = nullptr;
+    HIP_OK(hipMalloc(&d_rowptr, (n + 1) * 4));
+    HIP_OK(hipMalloc(&d_col, nnz * 4));
+    HIP_OK(hipMalloc(&d_val, nnz * 4));
+    HIP_OK(hipMalloc(&d_plan, words * 4));
+    HIP_OK(hipMalloc(&d_X, (size_t)n * H * 4));
+    HIP_OK(hipMalloc(&d_Y, (size_t)n * H * 4));
+    if (ws_bytes > 0) HIP_OK(hipMalloc(&d_ws, ws_bytes));
+    HIP_OK(hipMemcpy(d_rowptr, g.rowptr.data(), (n + 1) * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_col, g.col.data(), nnz * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_val, g.val.data(), nnz * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_plan, plan.data(), words * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_X, X.data(), (size_t)n * H * 4, hipMemcpyHostToDevice));
+
+    hipStream_t st;
+    HIP_OK(hipStreamCreate(&st));
+    auto run = [&]() {
+        int rc = glass_spmm_csr_f32(d_rowptr, d_col, d_val, d_X, H, d_Y, H, n, H, plan.data(), d_plan, d_ws, st);
+        if (rc) {
+            fprintf(stderr, "spmm rc=%d: %s\n", rc, glass_last_error_string());
+            exit(4);
+        }
+    };
+    for (int i = 0; i < 5; ++i) run();
+    HIP_OK(hipStreamSynchronize(st));
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) run();
+    HIP_OK(hipEventRecord(e1, st));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    const double t = ms * 1e-3 / iters;
+    // algorithmic bytes per pass: nnz*(4H+8) + N*(4H+4)
+    const double bytes = (double)nnz * (4.0 * H + 8) + (double)n * (4.0 * H + 4);
+
+    // spot check 64 rows in fp64
+    std::vector<float> Y((size_t)n * H);
+    HIP_OK(hipMemcpy(Y.data(), d_Y, (size_t)n * H * 4, hipMemcpyDeviceToHost));
+    double max_err = 0, max_ref = 0;
+    for (int k = 0; k < 64; ++k) {
+        int64_t r = (k < 8) ? k : (int64_t)((uint64_t)(k * 2654435761u) % (uint64_t)n);
+        if (k == 8) {  // the longest row
+            for (int64_t i = 0; i < n; ++i)
+                if (g.rowptr[i + 1] - g.rowptr[i] == maxdeg) r = i;
+        }
+        for (int64_t c = 0; c < H; ++c) {
+            double s = 0;
+            for (int32_t e = g.rowptr[r]; e < g.rowptr[r + 1]; ++e) s += (double)g.val[e] * X[(size_t)g.col[e] * H + c];
+            max_err = std::max(max_err, fabs(s - (double)Y[(size_t)r * H + c]));
+            max_ref = std::max(max_ref, fabs(s));
+        }
+    }
+    printf("{\"shape\": \"%s\", \"N\": %lld, \"nnz\": %lld, \"max_deg\": %d, \"H\": %lld, \"sweep_waves\": %d, "
+           "\"long_items\": %d, \"reduce_rows\": %d, \"us_per_pass\": %.2f, \"edges_per_s\": %.4g, \"alg_GBps\": %.1f, "
+           "\"frac_of_8TBps\": %.3f, \"spot_rel_err\": %.2e}\n",
+           shape.c_str(), (long long)n, (long long)nnz, maxdeg, (long long)H, plan[4], plan[5], plan[6], t * 1e6,
+           nnz / t, bytes / t / 1e9, bytes / t / 8e12, max_err / (max_ref > 0 ? max_ref : 1));
+    return max_err / (max_ref > 0 ? max_ref : 1) < 1e-5 ? 0 : 5;
+}
