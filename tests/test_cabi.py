@@ -1,0 +1,128 @@
+"""CPU-side checks of the C ABI: the library loads, exports every symbol include/glass_hip.h
+declares, the ctypes table mirrors the header, the host-side plan builder is correct, and argument
+validation returns error codes (no exceptions across the ABI).  No GPU compute is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "glass_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(glass_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from glass_amd import _lib
+    lib = _lib.load()
+    names = declared_functions()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in glass_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
+    assert lib.glass_version() == _lib.ABI_VERSION == 1
+
+
+def test_header_cites_reference_lines():
+    text = open(os.path.join(ROOT, "include", "glass_hip.h")).read()
+    for cite in ("impl/models.py:164", "impl/models.py:83-111", "impl/utils.py:32-45", "impl/models.py:346-350"):
+        assert cite in text
+
+
+def _plan(rowptr):
+    from glass_amd import _lib
+    lib = _lib.load()
+    rp = np.asarray(rowptr, dtype=np.int32)
+    n = rp.shape[0] - 1
+    words = ctypes.c_int64(0)
+    assert lib.glass_spmm_plan_build(rp.ctypes.data, n, None, ctypes.byref(words)) == 0
+    plan = np.zeros(words.value, dtype=np.int32)
+    assert lib.glass_spmm_plan_build(rp.ctypes.data, n, plan.ctypes.data, ctypes.byref(words)) == 0
+    return plan
+
+
+def _check_plan(rowptr):
+    rp = np.asarray(rowptr, dtype=np.int64)
+    n = rp.shape[0] - 1
+    plan = _plan(rowptr)
+    hdr = plan[:16]
+    assert hdr[0] == 0x474C5350 and hdr[2] == n and hdr[3] == rp[-1]
+    n_sweep, n_long, n_red, n_slots, thr, chunk = hdr[4:10]
+    sweep = plan[hdr[10]:hdr[10] + n_sweep + 1]
+    longs = plan[hdr[11]:hdr[11] + 4 * n_long].reshape(-1, 4)
+    reds = plan[hdr[12]:hdr[12] + 3 * n_red].reshape(-1, 3)
+    deg = rp[1:] - rp[:-1]
+    # sweep ranges tile [0, n) in order
+    if n:
+        assert sweep[0] == 0 and sweep[-1] == n and np.all(np.diff(sweep) > 0)
+    # every long row (deg >= thr) is covered exactly by its chunks, in order, whole 64-edge batches
+    long_rows = np.nonzero(deg >= thr)[0]
+    assert sorted(set(longs[:, 0].tolist())) == long_rows.tolist()
+    slots = []
+    for r in long_rows:
+        it = longs[longs[:, 0] == r]
+        assert it[0, 1] == rp[r] and it[-1, 2] == rp[r + 1]
+        assert np.all(it[1:, 1] == it[:-1, 2])
+        assert np.all((it[:, 2] - it[:, 1]) <= chunk) and np.all((it[:-1, 2] - it[:-1, 1]) % 64 == 0)
+        if len(it) == 1:
+            assert it[0, 3] == -1
+        else:
+            slots += it[:, 3].tolist()
+            (rr, ) = reds[reds[:, 0] == r]
+            assert rr[1] == it[0, 3] and rr[2] == len(it)
+    assert slots == list(range(n_slots))
+    return hdr
+
+
+def test_plan_builder_shapes():
+    rng = np.random.default_rng(0)
+    _check_plan([0])  # empty matrix
+    _check_plan([0, 0, 0, 0])  # only empty rows
+    _check_plan(np.concatenate([[0], np.cumsum(rng.integers(0, 60, 5000))]))
+    hdr = _check_plan(np.concatenate([[0], np.cumsum(rng.choice([0, 3, 255, 256, 257, 2048, 2049, 50000], 300))]))
+    assert hdr[5] > 0 and hdr[6] > 0 and hdr[7] > 0
+    hdr = _check_plan(np.concatenate([[0], np.cumsum(np.full(20000, 37))]))
+    assert hdr[5] == 0 and hdr[4] == 20000  # ppi_bp-like: one row per wave
+
+
+def test_plan_builder_rejects_bad_rowptr():
+    from glass_amd import _lib
+    lib = _lib.load()
+    words = ctypes.c_int64(0)
+    bad = np.array([0, 5, 3], dtype=np.int32)
+    assert lib.glass_spmm_plan_build(bad.ctypes.data, 2, None, ctypes.byref(words)) == -1
+    assert b"monotone" in lib.glass_last_error_string()
+    assert lib.glass_spmm_plan_build(None, 2, None, ctypes.byref(words)) == -1
+
+
+def test_argument_validation_returns_codes_not_exceptions():
+    """Validation runs before any HIP call, so these work without a GPU."""
+    from glass_amd import _lib
+    lib = _lib.load()
+    assert lib.glass_spmm_csr_f32(None, None, None, None, 0, None, 0, 4, 8, None, None, None, None) == -1
+    plan = _plan([0, 1, 2])
+    x = np.zeros(16, dtype=np.float32)
+    # plan built for 2 rows used with n_rows=3 -> GLASS_E_PLAN
+    rc = lib.glass_spmm_csr_f32(plan.ctypes.data, plan.ctypes.data, x.ctypes.data, x.ctypes.data, 8, x.ctypes.data, 8,
+                                3, 8, plan.ctypes.data, plan.ctypes.data, None, None)
+    assert rc == -2 and b"plan does not match" in lib.glass_last_error_string()
+    assert lib.glass_adj_values_f32(plan.ctypes.data, None, None, 2, 7, x.ctypes.data, None, None) == -3  # bad aggr
+    assert lib.glass_segment_pool_f32(x.ctypes.data, 4, x.ctypes.data, 1, 1, 9, x.ctypes.data, 4, None, 4, 4,
+                                      None) == -3  # bad pool mode
+    assert lib.glass_graphnorm_fwd_f32(None, 0, None, 0, 0, 0, None, None, None, 1e-5, None, 0, 0.0, None, 0, None,
+                                       None) == -1
+    assert lib.glass_mix_fwd_f32(x.ctypes.data, 4, x.ctypes.data, 0.5, 0, x.ctypes.data, 4, 2, 4, None) == -1  # ldt<2H
+    assert lib.glass_spmm_ws_bytes(x.ctypes.data, 64) == -2  # not a plan header
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from glass_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libglass_hip.so"))
+    with pytest.raises(_lib.GlassHipError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,164 @@
+"""CPU tests of the host-side mirror of the reference interface (no GPU compute): module surface,
+index helpers, loaders, metrics, config, synthetic generators, gradient bucket."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import load, build_glass
+
+
+def test_drop_in_surface():
+    """`from impl import models, SubGDataset, train, metrics, utils, config` (GLASSTest.py:1) and every
+    name a driver touches."""
+    from impl import models, SubGDataset, train, metrics, utils, config
+    for name in ("Seq", "MLP", "buildAdj", "GLASSConv", "EmbZGConv", "PoolModule", "AddPool", "MaxPool", "MeanPool",
+                 "SizePool", "GLASS"):
+        assert hasattr(models, name)
+    for name in ("MaxZOZ", "pad2batch", "batch2pad"):
+        assert hasattr(utils, name)
+    for name in ("GDataset", "GDataloader", "ZGDataloader"):
+        assert hasattr(SubGDataset, name)
+    assert callable(train.train) and callable(train.test)
+    assert callable(metrics.binaryf1) and callable(metrics.microf1) and callable(metrics.auroc)
+    config.set_device(-1)
+    assert config.device == torch.device("cpu")
+    config.set_device("cpu")
+    assert config.device == torch.device("cpu")
+    config.set_device(0)
+    assert config.device.type in ("cuda", "cpu")
+
+
+def test_state_dict_keys_match_reference():
+    g = load("g9_keys.npz")
+    model = build_glass(64, 2, 1, 3, "mean", "sum", 0.8)
+    sd = model.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert [str(list(v.shape)) for v in sd.values()] == [str(s) for s in g["shapes"]]
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
+
+
+def test_constructor_contract():
+    """max_deg may be a 0-dim tensor (GLASSTest.py:99,142); input_emb is re-assignable (GLASSTest.py:157);
+    GLASSConv works under functools.partial; unknown pool raises NotImplementedError in buildModel style."""
+    import functools
+    from impl import models
+    conv = models.EmbZGConv(8, 8, 2, max_deg=torch.tensor(5), activation=nn.ELU(inplace=True), jk=True, dropout=0.1,
+                            conv=functools.partial(models.GLASSConv, aggr="gcn", z_ratio=0.7, dropout=0.1), gn=True)
+    assert conv.input_emb.weight.shape == (6, 8)
+    conv.input_emb = nn.Embedding.from_pretrained(torch.randn(11, 8), freeze=False)
+    assert conv.state_dict()["input_emb.weight"].shape == (11, 8)
+    assert conv.gns[-1].weight.shape == (16, )  # JK: H * L channels
+    assert conv.convs[0].comb_fns[0].weight.shape == (8, 16)  # input order [aggregated || x_]
+    nojk = models.EmbZGConv(8, 4, 3, max_deg=2, jk=False)
+    assert nojk.gns[-1].weight.shape == (4, ) and len(nojk.gns) == 3
+
+
+def test_mlp_and_seq_structure():
+    from impl import models
+    m = models.MLP(4, 8, 2, 3, dropout=0.5, tail_activation=False, gn=False)
+    kinds = [type(x).__name__ for x in m.seq.modlist]
+    assert kinds == ["Linear", "Dropout", "ReLU", "Linear", "Dropout", "ReLU", "Linear"]
+    m1 = models.MLP(4, 8, 2, 1, tail_activation=True, gn=True)
+    assert [type(x).__name__ for x in m1.seq.modlist] == ["Linear", "GraphNorm", "ReLU"]
+    y = models.MLP(4, 8, 2, 2)(torch.randn(5, 4))  # plain torch modules: runs anywhere
+    assert y.shape == (5, 2)
+    s = models.Seq([nn.Linear(3, 3), nn.ReLU()])
+    assert s(torch.randn(2, 3)).shape == (2, 3)
+
+
+def test_product_model_refuses_cpu_tensors():
+    """No CPU fallback in the product path: the HIP path is the only path."""
+    from glass_amd._lib import GlassHipError
+    model = build_glass(8, 1, 3, 2, "mean", "sum", 0.8)
+    x = torch.zeros(6, 1, 1, dtype=torch.int64)
+    ei = torch.tensor([[0, 1], [1, 0]])
+    with pytest.raises(GlassHipError):
+        model(x, ei, torch.ones(2), torch.tensor([[0, 1]]), torch.zeros(6, dtype=torch.int64))
+
+
+def test_pad2batch_batch2pad_docstring_examples():
+    from impl import utils
+    pad = utils.batch2pad(torch.tensor([0, 1, 0, 0, 1, 1, 2, 2]))  # impl/utils.py:9
+    assert pad.tolist() == [[0, 2, 3], [1, 4, 5], [6, 7, -1]]
+    b, p = utils.pad2batch(pad)  # impl/utils.py:21 (row-major order)
+    assert b.tolist() == [0, 0, 0, 1, 1, 1, 2, 2] and p.tolist() == [0, 2, 3, 1, 4, 5, 6, 7]
+    g = load("g6_utils.npz")
+    assert np.array_equal(utils.batch2pad(torch.from_numpy(g["batch"])).numpy(), g["pad"])
+    b, p = utils.pad2batch(torch.from_numpy(g["pad"]))
+    assert np.array_equal(b.numpy(), g["p2b_batch"]) and np.array_equal(p.numpy(), g["p2b_pos"])
+    # negative batch entries are dropped, empty rows impossible, ragged widths padded
+    pad = utils.batch2pad(torch.tensor([3, -1, 3, 7, 7, 7]))
+    assert pad.tolist() == [[0, 2, -1], [3, 4, 5]]
+
+
+def test_metrics_golden():
+    from impl import metrics
+    g = load("g7_metrics.npz")
+    assert metrics.binaryf1(g["pred_b"], g["lab_b"]) == pytest.approx(float(g["f1_b"]), abs=1e-12)
+    assert metrics.microf1(g["pred_m"], g["lab_m"]) == pytest.approx(float(g["f1_m"]), abs=1e-12)
+    assert 0.0 <= metrics.auroc(np.array([0.1, 0.9, 0.4, 0.8]), np.array([0, 1, 0, 1])) <= 1.0
+
+
+def _dataset(n_sub=23, n=50):
+    from impl import SubGDataset
+    g = torch.Generator().manual_seed(0)
+    x = torch.zeros(n, 1, 1, dtype=torch.int64)
+    ei = torch.randint(0, n, (2, 100), generator=g)
+    pos = torch.randint(-1, n, (n_sub, 5), generator=g)
+    return SubGDataset.GDataset(x, ei, torch.ones(100), pos, torch.arange(n_sub))
+
+
+def test_loader_tuple_layout_and_batching():
+    from impl import SubGDataset
+    ds = _dataset()
+    assert len(ds) == 23 and ds.num_nodes == 50 and ds[3][1].item() == 3
+    ld = SubGDataset.GDataloader(ds, batch_size=5, shuffle=False, drop_last=True)
+    batches = list(ld)
+    assert len(batches) == len(ld) == 4
+    x, ei, ea, pos, y = batches[0]
+    assert x is ds.x and ei is ds.edge_index and ea is ds.edge_attr
+    assert pos.shape == (5, 5) and y.tolist() == [0, 1, 2, 3, 4]
+    ld = SubGDataset.GDataloader(ds, batch_size=5, shuffle=True, drop_last=False)
+    ys = torch.cat([b[-1] for b in ld])
+    assert sorted(ys.tolist()) == list(range(23))  # a permutation, last partial batch kept
+    seen = {}
+    zl = SubGDataset.ZGDataloader(ds, 4, shuffle=False, drop_last=False, z_fn=lambda x, p: seen.setdefault("p", p))
+    b = next(iter(zl))
+    assert len(b) == 6 and b[4] is seen["p"] and torch.equal(b[3], ds.pos[:4])  # (x, ei, ea, pos, z, y)
+    default = SubGDataset.ZGDataloader(ds, 4, shuffle=False)
+    assert next(iter(default))[4].shape == (50, 1)  # default z_fn: zeros [N, x.shape[1]]
+
+
+def test_synthetic_generators_are_seeded_and_well_formed():
+    from glass_amd import synth
+    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=0, n_batches=2)
+    w2, ei2, *_ = synth.make_workload("tiny", seed=0, n_batches=2)
+    assert np.array_equal(ei, ei2)
+    assert ei.shape == (2, 2 * w.n_pairs) and np.all(ei[0] != ei[1])
+    key = ei[0] * w.n_node + ei[1]
+    assert np.all(np.diff(key) > 0)  # sorted by (row, col), no duplicates
+    assert set(map(tuple, ei.T)) == set(map(tuple, ei[::-1].T))  # symmetric
+    assert x.shape == (w.n_node, 1, 1) and pos.shape == (2 * w.batch, w.sub_size)
+    for row in pos:
+        assert len(set(row.tolist())) == w.sub_size  # without replacement
+    ei_p, _ = synth.make_graph(3000, 20000, seed=1, powerlaw=0.9)
+    deg = np.bincount(ei_p[0], minlength=3000)
+    assert deg.max() > 20 * np.median(deg[deg > 0])  # skewed
+
+
+def test_flat_grad_bucket_aliases_grads():
+    from glass_amd.dist import FlatGradBucket
+    lin = nn.Sequential(nn.Linear(4, 3), nn.Linear(3, 2))
+    b = FlatGradBucket(list(lin.parameters()))
+    assert b.flat.numel() == sum(p.numel() for p in lin.parameters()) and b.attached()
+    lin(torch.randn(5, 4)).sum().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in lin.parameters()])
+    assert torch.equal(ref, b.flat) and b.flat.abs().sum() > 0  # autograd accumulated INTO the bucket
+    b.zero()
+    assert all(float(p.grad.abs().sum()) == 0 for p in lin.parameters())
+    for p in lin.parameters():
+        p.grad = None
+    assert not b.attached()
+    b.zero()  # re-attaches
+    assert b.attached()

@@ -4,7 +4,9 @@
 // Also the program to put after `rocprofv3 ... --` for per-kernel traces and PMC counters.
 //
 //   spmm_bench <shape> [H] [iters] [--transpose]
-//   shape: ppi_bp | hpo_neuro | em_user | powerlaw | density-like | N:PAIRS[:zipf]
+//   shape: ppi_bp | hpo_neuro | em_user | powerlaw | density-like | N:PAIRS[:zipf] | calib:N
+//   calib:N = random permutation matrix (one edge per row, every X row read exactly once): a known
+//   byte count in K1's own access pattern, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -97,6 +99,7 @@ int main(int argc, char** argv) {
     else if (shape == "em_user") n = 50000, pairs = 500000;
     else if (shape == "powerlaw") n = 1000000, pairs = 10000000, zipf = 0.8;
     else if (shape == "density-like") n = 4998, pairs = 29962;
+    else if (shape.rfind("calib:", 0) == 0) n = atoll(shape.c_str() + 6), pairs = -1;
     else {
         double z = 0;
         long long a = 0, b = 0;
@@ -107,7 +110,19 @@ int main(int argc, char** argv) {
         }
         n = a, pairs = b, zipf = z;
     }
-    Graph g = make_graph(n, pairs, zipf, 0);
+    Graph g;
+    if (pairs < 0) {  // permutation matrix
+        g.n = n;
+        g.rowptr.resize(n + 1);
+        g.col.resize(n);
+        g.val.assign(n, 1.0f);
+        for (int64_t i = 0; i <= n; ++i) g.rowptr[i] = (int32_t)i;
+        for (int64_t i = 0; i < n; ++i) g.col[i] = (int32_t)i;
+        std::mt19937_64 prng(7);
+        std::shuffle(g.col.begin(), g.col.end(), prng);
+    } else {
+        g = make_graph(n, pairs, zipf, 0);
+    }
     const int64_t nnz = (int64_t)g.col.size();
     int32_t maxdeg = 0;
     for (int64_t i = 0; i < n; ++i) maxdeg = std::max(maxdeg, g.rowptr[i + 1] - g.rowptr[i]);
