@@ -111,13 +111,15 @@ def main():
     torch.manual_seed(0)
     model = build_glass(H, L, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=w.dropout).to(dev)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=w.lr, capturable=True)
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    bucket = ParamArena(model)  # flat params + grads: stacked weight views, fused Adam, one all-reduce
+    opt = FlatAdam(bucket, lr=w.lr)
     loss_fn = loss_fn_for(w)
     xg, eig, ewg = x.to(dev), ei.to(dev), ew.to(dev)
     # this rank's batches: rank r owns batches r, r+world, ...  (disjoint subgraphs; weak scaling)
     pos_g = pos.to(dev).reshape(n_batches * world, w.batch, -1)[rank::world].contiguous()
     y_g = y.to(dev).reshape(n_batches * world, w.batch, *y.shape[1:])[rank::world].contiguous()
-    bucket = gdist.FlatGradBucket(list(model.parameters()))
     ops.rng_seed(1234 + rank, dev)
 
     from glass_amd.step import TrainStep

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_bwd_kernel(const double* _
                                                                  const float* __restrict__ alpha,
                                                                  const float* __restrict__ saved,
                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                                 float* __restrict__ dalpha, float* __restrict__ coef) {
+                                                                 float* __restrict__ dalpha, int accumulate,
+                                                                 float* __restrict__ coef) {
     __shared__ double lds[kBlock * 2];
     const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + tc;
@@ -336,9 +337,9 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_bwd_kernel(const double* _
         const double m2 = s2 / n;
         const double sum_xhat = r * n * mu * (1.0 - a);          // sum_n (x_n - a*mu) * r
         const double sum_do = g * r * (s1 - sum_xhat * m2);       // sum_n d o_n
-        if (dgamma) dgamma[c] = (float)s2;
-        if (dbeta) dbeta[c] = (float)s1;
-        if (dalpha) dalpha[c] = (float)(-mu * sum_do);
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+        if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + (float)(-mu * sum_do);
         // dx = do - a*mean(do),  do = g*r*(gr - xhat*m2),  xhat = (x - a*mu)*r
         const double A = g * r;
         const double Bx = -g * r * r * m2;
@@ -457,8 +458,8 @@ extern "C" int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, in
 extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx,
                                        int64_t lddx, int64_t n_rows, int64_t C, const float* gamma,
                                        const float* alpha, const float* saved, float* dgamma, float* dbeta,
-                                       float* dalpha, int act, float p_drop, const uint64_t* rng_state,
-                                       uint64_t call_id, void* ws, void* stream) {
+                                       float* dalpha, int accumulate, int act, float p_drop,
+                                       const uint64_t* rng_state, uint64_t call_id, void* ws, void* stream) {
     GLASS_REQUIRE(dy && x && dx && gamma && alpha && saved && ws, "graphnorm_bwd: null pointer");
     GLASS_REQUIRE(n_rows > 0 && C > 0 && lddy >= C && ldx >= C && lddx >= C, "graphnorm_bwd: bad sizes");
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd: bad dropout args");
@@ -479,7 +480,7 @@ extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const floa
                            t.tc_log2, saved, alpha, act, drop, rng_state, partial);
     }
     hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
-                       (int)C, n_rows, gamma, alpha, saved, dgamma, dbeta, dalpha, coef);
+                       (int)C, n_rows, gamma, alpha, saved, dgamma, dbeta, dalpha, accumulate, coef);
     if (vec) {
         hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, n_rows, (int)C,
                            t.tc_log2, saved, coef, act, drop, rng_state);

@@ -1,0 +1,238 @@
+// Weight/bias gradient of the stacked Linears of GLASSConv:  dW[o,i] (+)= sum_n G[n,o] * X[n,i],
+// db[o] (+)= sum_n G[n,o]   (autograd backward of nn.Linear at reference impl/models.py:158-159,
+// 169-170; G = gradient of the [N,2H] Linear output, X = its [N,H] or [N,2H] input).
+//
+// This is the one genuinely dense contraction on the path that the vendor GEMM serves badly: the
+// output is tiny (128x64 .. 128x128) and the reduction dimension is the node count (17 080 .. 1 M),
+// so hipBLASLt launches 8-28 workgroups and takes 80-95 us at ppi_bp-shape (profiles/r01_*).  Here
+// the reduction is split over up to 256 workgroups ("split-K" over rows) on the fp32 matrix cores:
+//   v_mfma_f32_32x32x2_f32, A = G^T tile (32 outputs x 2 rows), B = X tile (2 rows x 32 inputs).
+// Loads are whole-row and vectorised: lane (c = l&31, h = l>>5) reads float4 G[n+h][4c..4c+3] and
+// float2 X[n+h][2c..2c+1]; component t of the float4 feeds output tile t, whose 32 rows are the
+// STRIDED set o = 4r+t (likewise inputs i = 2c+u) — the MFMA does not care which 32 outputs form a
+// tile, so no shuffle or LDS transpose is needed.  One wave accumulates a full 128x64 block in 128
+// accumulator registers; the 4 waves of a workgroup take interleaved row pairs and are combined
+// through LDS; workgroup partials are summed in fixed order by a second kernel (deterministic).
+// fp32 MFMA is an exact k-ordered fmaf chain, so numerics equal a plain fp32 reduction.
+#include "common.h"
+
+namespace glass {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kOT = 128;            // outputs per workgroup (4 tiles of 32, strided by 4)
+constexpr int kIT = 64;             // inputs per workgroup  (2 tiles of 32, strided by 2)
+constexpr int kTile = kOT * kIT;    // 8192 accumulators per workgroup
+constexpr int kMaxSlabs = 256;
+
+// idx of accumulator (t,u,reg,lane) in the permuted partial layout
+__device__ __forceinline__ int acc_index(int t, int u, int reg, int lane) { return ((t * 2 + u) * 16 + reg) * 64 + lane; }
+
+__global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* __restrict__ G, int64_t ldg,
+                                                                  const float* __restrict__ X, int64_t ldx,
+                                                                  int64_t N, int O, int I, int rows_per_slab,
+                                                                  float* __restrict__ part_w,
+                                                                  float* __restrict__ part_b) {
+    __shared__ float lds[2 * kTile];       // 64 KiB: two wave-sized accumulator images
+    __shared__ float lds_b[8 * kOT];       // bias partials: [wave*2 + h][o]
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int o0 = blockIdx.z * kOT + 4 * c;   // this lane's 4 outputs
+    const int i0 = blockIdx.y * kIT + 2 * c;   // this lane's 2 inputs
+    const bool o_ok = o0 < O, i_ok = i0 < I;   // O % 4 == 0 and I % 2 == 0 (checked on the host)
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+    const int64_t r1 = min(N, r0 + rows_per_slab);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // wave w takes row pairs p = w, w+4, ...; two pairs in flight
+    for (int64_t nb = r0 + 2 * w; nb < r1; nb += 16) {  // wave-uniform trip count (MFMA needs all lanes)
+        const int64_t n = nb + h;
+        float4 g[2];
+        float2 x[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t nn = n + 8 * s;
+            g[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            x[s] = make_float2(0.f, 0.f);
+            if (nn < r1) {
+                if (o_ok) g[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
+                if (i_ok) x[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float gv[4] = {g[s].x, g[s].y, g[s].z, g[s].w};
+            const float xv[2] = {x[s].x, x[s].y};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
+            bsum.x += g[s].x; bsum.y += g[s].y; bsum.z += g[s].z; bsum.w += g[s].w;
+        }
+    }
+
+    // ---- combine the 4 waves through LDS: waves 0,1 store; waves 2,3 add; everyone sums the pair ----
+    if (w < 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index(t, u, k, lane)] = acc[t][u][k];
+    }
+    *reinterpret_cast<float4*>(&lds_b[(w * 2 + h) * kOT + 4 * c]) = bsum;
+    __syncthreads();
+    if (w >= 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index(t, u, k, lane)] += acc[t][u][k];
+    }
+    __syncthreads();
+    const int64_t tile_id = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* pw = part_w + tile_id * kTile;
+    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(&lds[k]);
+        const float4 b = *reinterpret_cast<const float4*>(&lds[kTile + k]);
+        *reinterpret_cast<float4*>(pw + k) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    if (blockIdx.y == 0 && part_b && threadIdx.x < kOT) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds_b[k * kOT + threadIdx.x];
+        part_b[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * kOT + threadIdx.x] = s;
+    }
+}
+
+// Sum the slab partials in slab order and scatter to dW[o,i] / db[o].
+__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part_w,
+                                                              const float* __restrict__ part_b, int n_slabs, int ny,
+                                                              int O, int I, float* __restrict__ dW, int64_t lddw,
+                                                              float* __restrict__ db, int accumulate) {
+    const int chunk = blockIdx.y;  // (z * ny + y)
+    const int z = chunk / ny, y = chunk % ny;
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < kTile) {
+        const float* p = part_w + (int64_t)chunk * n_slabs * kTile + k;
+        float s = 0.f;
+        for (int b = 0; b < n_slabs; ++b) s += p[(int64_t)b * kTile];
+        // decode k = ((t*2+u)*16 + reg)*64 + lane  ->  (o, i)
+        const int lane = k & 63, reg = (k >> 6) & 15, tu = k >> 10;
+        const int t = tu >> 1, u = tu & 1;
+        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), cc = lane & 31;
+        const int o = z * kOT + 4 * r + t, i = y * kIT + 2 * cc + u;
+        if (o < O && i < I) {
+            float* d = dW + (int64_t)o * lddw + i;
+            *d = accumulate ? *d + s : s;
+        }
+    } else if (db && y == 0 && k < kTile + kOT) {
+        const int oo = k - kTile;
+        const float* p = part_b + (int64_t)z * n_slabs * kOT + oo;
+        float s = 0.f;
+        for (int b = 0; b < n_slabs; ++b) s += p[(int64_t)b * kOT];
+        const int o = z * kOT + oo;
+        if (o < O) db[o] = accumulate ? db[o] + s : s;
+    }
+}
+
+struct WgradGeom {
+    int n_slabs, rows_per_slab, ny, nz;
+    int64_t part_w_floats, part_b_floats;
+};
+
+static WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
+    WgradGeom g;
+    int64_t rows = ceil_div(N, kMaxSlabs);
+    if (rows < 64) rows = 64;
+    rows = ceil_div(rows, 8) * 8;  // whole row pairs for each of the 4 waves
+    g.rows_per_slab = (int)rows;
+    g.n_slabs = (int)ceil_div(N, rows);
+    g.ny = (int)ceil_div(I, kIT);
+    g.nz = (int)ceil_div(O, kOT);
+    g.part_w_floats = (int64_t)g.n_slabs * g.ny * g.nz * kTile;
+    g.part_b_floats = (int64_t)g.n_slabs * g.nz * kOT;
+    return g;
+}
+
+// ---- fused Adam over the flat parameter arena --------------------------------------------------
+// torch.optim.Adam (single-tensor formulation, amsgrad=False, maximize=False):
+//   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void adam_step_count_kernel(int64_t* step) { step[0] += 1; }
+
+__global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                      const float* __restrict__ lr_dev, float beta1, float beta2,
+                                                      float eps, float weight_decay,
+                                                      const int64_t* __restrict__ step_dev) {
+    const double t = (double)step_dev[0];
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    const float step_size = (float)((double)lr_dev[0] / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
+        float gk = g[k];
+        const float pk = p[k];
+        if (weight_decay != 0.f) gk = fmaf(weight_decay, pk, gk);
+        const float mk = m[k] + w1 * (gk - m[k]);
+        const float vk = v[k] * beta2 + w2 * gk * gk;
+        m[k] = mk;
+        v[k] = vk;
+        const float denom = sqrtf(vk) / bc2_sqrt + eps;
+        p[k] = pk - step_size * (mk / denom);
+    }
+}
+
+}  // namespace glass
+
+using namespace glass;
+
+extern "C" int64_t glass_linear_wgrad_ws_bytes(int64_t N, int64_t O, int64_t I) {
+    if (N <= 0 || O <= 0 || I <= 0) return GLASS_E_ARG;
+    const WgradGeom g = wgrad_geom(N, O, I);
+    return (g.part_w_floats + g.part_b_floats) * (int64_t)sizeof(float);
+}
+
+extern "C" int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t N, int64_t O,
+                                      int64_t I, float* dW, int64_t lddw, float* db, int accumulate, void* ws,
+                                      void* stream) {
+    GLASS_REQUIRE(G && X && dW && ws, "linear_wgrad: null pointer");
+    GLASS_REQUIRE(N > 0 && O > 0 && I > 0 && ldg >= O && ldx >= I && lddw >= I, "linear_wgrad: bad sizes");
+    if (O % 4 || I % 2 || ldg % 4 || ldx % 2 || !aligned16(G) || (reinterpret_cast<uintptr_t>(X) & 7u)) {
+        set_error("linear_wgrad: needs O%%4==0, I%%2==0, ldg%%4==0, ldx%%2==0 and 16-B/8-B aligned G/X "
+                  "(O=%lld I=%lld ldg=%lld ldx=%lld)", (long long)O, (long long)I, (long long)ldg, (long long)ldx);
+        return GLASS_E_UNSUPPORTED;  // caller falls back to a library GEMM for odd shapes
+    }
+    const WgradGeom g = wgrad_geom(N, O, I);
+    float* part_w = (float*)ws;
+    float* part_b = part_w + g.part_w_floats;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, G, ldg, X, ldx, N, (int)O,
+                       (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT + kBlock - 1) / kBlock, g.ny * g.nz), dim3(kBlock), 0, st,
+                       part_w, part_b, g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
+    return launch_status("glass_linear_wgrad_f32");
+}
+
+extern "C" int glass_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                   const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                                   int64_t* step_dev, void* stream) {
+    GLASS_REQUIRE(param && grad && exp_avg && exp_avg_sq && lr_dev && step_dev && n > 0, "adam_step: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(adam_step_count_kernel, dim3(1), dim3(1), 0, st, step_dev);
+    int64_t blocks = ceil_div(n, kBlock);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, param, grad, exp_avg, exp_avg_sq, n,
+                       lr_dev, (float)beta1, (float)beta2, (float)eps, (float)weight_decay, step_dev);
+    return launch_status("glass_adam_step_f32");
+}

@@ -38,7 +38,8 @@ class GraphNorm(nn.Module):
     def forward(self, x, batch=None, act=ACT_NONE, p_drop=0.0, call_id=0):
         if batch is not None:
             raise NotImplementedError("GLASS only uses whole-graph GraphNorm (batch=None)")
-        return ops.graphnorm(x, self.weight, self.bias, self.mean_scale, self.eps, act, p_drop, call_id)
+        return ops.graphnorm(x, self.weight, self.bias, self.mean_scale, self.eps, act, p_drop, call_id,
+                             getattr(self, "_direct_grad", False))
 
 
 def _act_code(activation):
@@ -135,17 +136,16 @@ class GLASSConv(nn.Module):
             mask = mask.reshape(-1).to(torch.uint8)
         p = self.dropout if self.training else 0.0
         code = _act_code(self.activation)
+        stack = getattr(self, "_stack", {})  # set by arena.ParamArena: stacked weight views
         # both weight sets in one GEMM: T = [f1 | f0]
-        T = F.linear(x_, torch.cat((self.trans_fns[1].weight, self.trans_fns[0].weight)),
-                     torch.cat((self.trans_fns[1].bias, self.trans_fns[0].bias)))
+        T = ops.stacked_linear(x_, self.trans_fns[1], self.trans_fns[0], stack.get("trans"))
         if code is None:
             T = self.activation(T)
         m = ops.mix(T, mask, self.z_ratio, ACT_NONE if code is None else code)
         a = ops.spmm(self.adj, m)
         g = self.gn(a, p_drop=p, call_id=self.call_base)
         c = torch.cat((g, x_), dim=-1)
-        C = F.linear(c, torch.cat((self.comb_fns[1].weight, self.comb_fns[0].weight)),
-                     torch.cat((self.comb_fns[1].bias, self.comb_fns[0].bias)))
+        C = ops.stacked_linear(c, self.comb_fns[1], self.comb_fns[0], stack.get("comb"))
         return ops.mix(C, mask, self.z_ratio, ACT_NONE)
 
 

@@ -155,6 +155,73 @@ def mix(T, mask, z_ratio, act):
 
 
 # ---------------------------------------------------------------------------------------------
+# K5  the two Linears of a weight-set pair as one GEMM; weight gradient on the fp32 matrix cores
+# ---------------------------------------------------------------------------------------------
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(device, N, O, I):
+    nbytes = _lib.load().glass_linear_wgrad_ws_bytes(N, O, I)
+    ws = _wgrad_ws.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4 + 16, dtype=torch.float32, device=device)
+        _wgrad_ws[device] = ws
+    return ws
+
+
+def linear_wgrad(G, X, dW, db, accumulate):
+    """dW (+)= G^T @ X, db (+)= colsum(G) with glass_linear_wgrad_f32; False if the shape is unsupported."""
+    G, ldg = _rows(G)
+    X, ldx = _rows(X)
+    N, O = G.shape
+    I = X.shape[1]
+    if O % 4 or I % 2 or ldg % 4 or ldx % 2 or G.data_ptr() % 16 or X.data_ptr() % 8 or dW.stride(1) != 1:
+        return False
+    ws = _wgrad_workspace(G.device, N, O, I)
+    rc = _lib.load().glass_linear_wgrad_f32(G.data_ptr(), ldg, X.data_ptr(), ldx, N, O, I, dW.data_ptr(), dW.stride(0),
+                                            0 if db is None else db.data_ptr(), int(accumulate), ws.data_ptr(),
+                                            _stream())
+    _lib.check(rc, "glass_linear_wgrad_f32")
+    return True
+
+
+class StackedLinearFn(torch.autograd.Function):
+    """T = x @ [W1; W0]^T + [b1 | b0]  — both weight sets of a GLASSConv Linear pair in one GEMM
+    (rocBLAS/hipBLASLt through torch).  With a ParamArena the stacked weight is a view (no cat) and
+    the backward accumulates dW / db straight into the gradient arena with the split-K MFMA kernel."""
+    @staticmethod
+    def forward(ctx, x, w1, w0, b1, b0, stack):
+        _need_gpu(x, w1)
+        if stack is not None:
+            W, b = stack[0], stack[1]
+        else:
+            W, b = torch.cat((w1, w0)), torch.cat((b1, b0))
+        ctx.save_for_backward(x, W)
+        ctx.stack = stack
+        ctx.split = w1.shape[0]
+        return torch.addmm(b, x, W.t())
+
+    @staticmethod
+    def backward(ctx, dT):
+        x, W = ctx.saved_tensors
+        dT, _ = _rows(dT)
+        dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
+        if ctx.stack is not None and linear_wgrad(dT, x, ctx.stack[2], ctx.stack[3], True):
+            return dx, None, None, None, None, None
+        dW = torch.empty_like(W)
+        db = torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
+        if not linear_wgrad(dT, x, dW, db, False):
+            dW = torch.mm(dT.t(), x)
+            db = dT.sum(0)
+        k = ctx.split
+        return dx, dW[:k], dW[k:], db[:k], db[k:], None
+
+
+def stacked_linear(x, lin1, lin0, stack=None):
+    return StackedLinearFn.apply(x, lin1.weight, lin0.weight, lin1.bias, lin0.bias, stack)
+
+
+# ---------------------------------------------------------------------------------------------
 # K6  GraphNorm (+ELU +dropout)
 # ---------------------------------------------------------------------------------------------
 _gn_ws = {}
@@ -173,7 +240,7 @@ def _graphnorm_ws(device, n_rows, C):
 class GraphNormFn(torch.autograd.Function):
     """y = dropout(act(GraphNorm(x))) over the whole graph (PyG GraphNorm with batch=None)."""
     @staticmethod
-    def forward(ctx, x, gamma, beta, alpha, eps, act, p_drop, call_id):
+    def forward(ctx, x, gamma, beta, alpha, eps, act, p_drop, call_id, direct=False):
         _need_gpu(x, gamma)
         x, ldx = _rows(x)
         n, C = x.shape
@@ -188,6 +255,8 @@ class GraphNormFn(torch.autograd.Function):
         _lib.check(rc, "glass_graphnorm_fwd_f32")
         ctx.save_for_backward(x, g, a, saved)
         ctx.cfg = (act, p_drop, call_id)
+        # direct: parameter gradients are accumulated straight into the flat gradient arena
+        ctx.direct = (gamma, beta, alpha) if (direct and all(t.grad is not None for t in (gamma, beta, alpha))) else None
         return y
 
     @staticmethod
@@ -197,19 +266,27 @@ class GraphNormFn(torch.autograd.Function):
         n, C = x.shape
         dy, lddy = _rows(dy)
         dx = torch.empty((n, C), dtype=torch.float32, device=x.device)
-        dparams = torch.empty((3, C), dtype=torch.float32, device=x.device)
+        if ctx.direct is not None:
+            dg, db, da = (t.grad for t in ctx.direct)
+            accumulate = 1
+        else:
+            dparams = torch.empty((3, C), dtype=torch.float32, device=x.device)
+            dg, db, da = dparams[0], dparams[1], dparams[2]
+            accumulate = 0
         ws = _graphnorm_ws(x.device, n, C)
         rng = rng_state(x.device).data_ptr() if p_drop > 0 else 0
         rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), lddy, x.data_ptr(), x.stride(0), dx.data_ptr(), C, n,
-                                                 C, g.data_ptr(), a.data_ptr(), saved.data_ptr(),
-                                                 dparams[0].data_ptr(), dparams[1].data_ptr(), dparams[2].data_ptr(),
-                                                 act, p_drop, rng, call_id, ws.data_ptr(), _stream())
+                                                 C, g.data_ptr(), a.data_ptr(), saved.data_ptr(), dg.data_ptr(),
+                                                 db.data_ptr(), da.data_ptr(), accumulate, act, p_drop, rng, call_id,
+                                                 ws.data_ptr(), _stream())
         _lib.check(rc, "glass_graphnorm_bwd_f32")
-        return dx, dparams[0], dparams[1], dparams[2], None, None, None, None
+        if ctx.direct is not None:
+            return dx, None, None, None, None, None, None, None, None
+        return dx, dg, db, da, None, None, None, None, None
 
 
-def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id=0):
-    return GraphNormFn.apply(x, gamma, beta, alpha, float(eps), int(act), float(p_drop), int(call_id))
+def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id=0, direct=False):
+    return GraphNormFn.apply(x, gamma, beta, alpha, float(eps), int(act), float(p_drop), int(call_id), bool(direct))
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,0 +1,42 @@
+"""Adam over a ParamArena in one kernel launch (glass_adam_step_f32), with torch.optim.Adam's
+update rule (GLASSTest.py:213 uses Adam(lr) with defaults) and enough of the Optimizer interface
+for `lr_scheduler.ReduceLROnPlateau` (GLASSTest.py:214-216, 225): the learning rate lives in
+`param_groups[0]['lr']`; it is mirrored into device memory so a captured step follows it."""
+import torch
+
+from . import _lib
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        self.arena = arena
+        super().__init__(arena.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        dev = arena.flat.device
+        self.exp_avg = torch.zeros_like(arena.flat)
+        self.exp_avg_sq = torch.zeros_like(arena.flat)
+        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.lr_dev = torch.full((1, ), float(lr), dtype=torch.float32, device=dev)
+        self._lr_host = float(lr)
+
+    def sync_lr(self):
+        """Mirror a scheduler's change of param_groups[0]['lr'] into device memory (call outside a
+        graph replay; cheap host compare otherwise)."""
+        lr = float(self.param_groups[0]["lr"])
+        if lr != self._lr_host:
+            self.lr_dev.fill_(lr)
+            self._lr_host = lr
+
+    def zero_grad(self, set_to_none=False):
+        self.arena.zero()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        g = self.param_groups[0]
+        if not torch.cuda.is_current_stream_capturing():
+            self.sync_lr()
+        a = self.arena
+        rc = _lib.load().glass_adam_step_f32(a.flat_param.data_ptr(), a.flat.data_ptr(), self.exp_avg.data_ptr(),
+                                             self.exp_avg_sq.data_ptr(), a.flat.numel(), self.lr_dev.data_ptr(),
+                                             g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
+                                             self.step_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "glass_adam_step_f32")

@@ -36,17 +36,22 @@ class TrainStep:
         loss.backward()
         self._loss.copy_(loss.detach())
 
-    def _capture(self):
-        dist_on = gdist.is_distributed()
+    def _warmup(self):
+        """Real training steps on the first batch, on a side stream: builds the CSR / plans /
+        workspaces / BLAS handles outside any capture.  Runs in eager mode too, so both modes follow
+        the same trajectory."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):  # warm-up: builds CSR / plans / workspaces outside the capture
+        with torch.cuda.stream(side):
             for _ in range(self.warmup_iters):
                 self._fwd_bwd()
                 self.bucket.all_reduce_mean()
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+
+    def _capture(self):
+        dist_on = gdist.is_distributed()
         self._g_fb = torch.cuda.CUDAGraph()
         if not dist_on:
             with torch.cuda.graph(self._g_fb):
@@ -63,6 +68,7 @@ class TrainStep:
     def __call__(self, pos, y):
         if self._pos is None:
             self._pos, self._y = pos.clone(), y.clone()
+            self._warmup()
             if self.use_graph:
                 self._capture()
         if pos.shape != self._pos.shape:
@@ -70,6 +76,8 @@ class TrainStep:
                              f"{tuple(pos.shape)} vs {tuple(self._pos.shape)}")
         self._pos.copy_(pos)
         self._y.copy_(y)
+        if hasattr(self.opt, "sync_lr"):
+            self.opt.sync_lr()  # a scheduler may have changed the learning rate since the capture
         if self.graphed:
             self._g_fb.replay()
             if self._g_opt is not None:

@@ -131,8 +131,9 @@ int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, int64_t ldy, 
                             void* stream);
 int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx,
                             int64_t n_rows, int64_t C, const float* gamma, const float* alpha, const float* saved,
-                            float* dgamma, float* dbeta, float* dalpha, int act, float p_drop,
-                            const uint64_t* rng_state, uint64_t call_id, void* ws, void* stream);
+                            float* dgamma, float* dbeta, float* dalpha, int accumulate /* != 0: add into d* */,
+                            int act, float p_drop, const uint64_t* rng_state, uint64_t call_id, void* ws,
+                            void* stream);
 int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 */
 
 /* ------------------------------------------------------------------------------------------
@@ -149,6 +150,27 @@ int glass_segment_pool_f32(const float* emb, int64_t lde, const int64_t* pos, in
 int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode,
                                const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C,
                                void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K5w weight / bias gradient of the stacked Linears   (autograd backward of nn.Linear at
+ *     impl/models.py:158-159,169-170 — the measured dominant dense contraction of the step)
+ *     dW[o,i] (+)= sum_n G[n,o] * X[n,i]      db[o] (+)= sum_n G[n,o]      (db may be NULL)
+ *     Split over the node dimension on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), slab
+ *     partials summed in fixed order (deterministic; exact fp32 fma-chain numerics).
+ *     accumulate != 0 adds into dW / db (the flat gradient arena), else overwrites.
+ *     Needs O%4==0, I%2==0, ldg%4==0, ldx%2==0, G 16-B and X 8-B aligned; otherwise returns
+ *     GLASS_E_UNSUPPORTED and the caller uses a library GEMM.
+ * ---------------------------------------------------------------------------------------- */
+int64_t glass_linear_wgrad_ws_bytes(int64_t N, int64_t O, int64_t I);
+int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t N, int64_t O, int64_t I,
+                           float* dW, int64_t lddw, float* db, int accumulate, void* ws, void* stream);
+
+/* K9  Adam over a flat parameter arena (torch.optim.Adam as used at GLASSTest.py:213; amsgrad
+ *     off): one launch for all parameters.  lr and the step counter live in DEVICE memory so a
+ *     captured graph follows ReduceLROnPlateau and advances its own bias correction. */
+int glass_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                        int64_t* step_dev, void* stream);
 
 #ifdef __cplusplus
 }

@@ -116,6 +116,8 @@ def test_argument_validation_returns_codes_not_exceptions():
                                       None) == -3  # bad pool mode
     assert lib.glass_graphnorm_fwd_f32(None, 0, None, 0, 0, 0, None, None, None, 1e-5, None, 0, 0.0, None, 0, None,
                                        None) == -1
+    assert lib.glass_linear_wgrad_f32(x.ctypes.data, 6, x.ctypes.data, 4, 2, 6, 4, x.ctypes.data, 4, None, 0,
+                                      x.ctypes.data, None) == -3  # O % 4 != 0 -> caller uses a library GEMM
     assert lib.glass_mix_fwd_f32(x.ctypes.data, 4, x.ctypes.data, 0.5, 0, x.ctypes.data, 4, 2, 4, None) == -1  # ldt<2H
     assert lib.glass_spmm_ws_bytes(x.ctypes.data, 64) == -2  # not a plan header
 

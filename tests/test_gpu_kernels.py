@@ -301,3 +301,84 @@ def test_cpu_tensor_fails_loudly():
         ops.graphnorm(torch.randn(8, 4), torch.ones(4), torch.zeros(4), torch.ones(4))
     with pytest.raises(GlassHipError):
         ops.maxzoz(10, torch.zeros(2, 2, dtype=torch.int64))
+
+
+# ---------------------------------------------------------------------------------- K5w, K9
+@pytest.mark.parametrize("N,O,I", [(17080, 128, 64), (17080, 128, 128), (1000, 16, 8), (333, 40, 20), (70000, 256, 128),
+                                   (5, 128, 64)])
+def test_linear_wgrad(N, O, I):
+    """Split-K fp32-MFMA weight/bias gradient vs an fp64 GEMM; overwrite and accumulate modes;
+    strided operands (X as the right half of a wider buffer); bitwise repeatable."""
+    from glass_amd import ops
+    gen = torch.Generator().manual_seed(N + O)
+    G = torch.randn(N, O, generator=gen)
+    wide = torch.randn(N, 2 * I, generator=gen)
+    Gg, wg = G.to(DEV), wide.to(DEV)
+    X = wg[:, I:]
+    ref_w = G.double().t() @ wide[:, I:].double()
+    ref_b = G.double().sum(0)
+    dW = torch.full((O, I), 3.0, device=DEV)
+    db = torch.full((O, ), -2.0, device=DEV)
+    assert ops.linear_wgrad(Gg, X, dW, db, False)
+    assert rel_inf(dW.cpu(), ref_w) < TOL and rel_inf(db.cpu(), ref_b) < TOL
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    ops.linear_wgrad(Gg, X, dW2, db2, False)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    ops.linear_wgrad(Gg, X, dW2, db2, True)  # accumulate on top
+    assert rel_inf(dW2.cpu(), 2 * ref_w) < TOL and rel_inf(db2.cpu(), 2 * ref_b) < TOL
+
+
+def test_linear_wgrad_unsupported_shape_falls_back_to_library_gemm():
+    from glass_amd import ops
+    G, X = torch.randn(50, 17, device=DEV), torch.randn(50, 17, device=DEV)
+    assert ops.linear_wgrad(G, X, torch.empty(17, 17, device=DEV), None, False) is False
+
+
+def test_stacked_linear_matches_two_linears():
+    from glass_amd import ops
+    import torch.nn as nn
+    torch.manual_seed(0)
+    l1, l0 = nn.Linear(64, 64).to(DEV), nn.Linear(64, 64).to(DEV)
+    x = torch.randn(3000, 64, device=DEV, requires_grad=True)
+    gout = torch.randn(3000, 128, device=DEV)
+    T = ops.stacked_linear(x, l1, l0)
+    T.backward(gout)
+    got = [x.grad.clone(), l1.weight.grad.clone(), l0.weight.grad.clone(), l1.bias.grad.clone(), l0.bias.grad.clone()]
+    x.grad = None
+    for p in list(l1.parameters()) + list(l0.parameters()):
+        p.grad = None
+    xd = x.detach().double().requires_grad_(True)
+    l1d, l0d = nn.Linear(64, 64).double().to(DEV), nn.Linear(64, 64).double().to(DEV)
+    l1d.load_state_dict({k: v.double() for k, v in l1.state_dict().items()})
+    l0d.load_state_dict({k: v.double() for k, v in l0.state_dict().items()})
+    Td = torch.cat((l1d(xd), l0d(xd)), -1)
+    Td.backward(gout.double())
+    want = [xd.grad, l1d.weight.grad, l0d.weight.grad, l1d.bias.grad, l0d.bias.grad]
+    assert rel_inf(T.detach().cpu(), Td.detach().cpu()) < TOL
+    for a, b in zip(got, want):
+        assert rel_inf(a.cpu(), b.cpu()) < TOL
+
+
+def test_flat_adam_matches_torch_adam():
+    """glass_adam_step_f32 over a ParamArena == torch.optim.Adam, 5 steps, incl. a learning-rate change
+    made the way ReduceLROnPlateau makes it (param_groups[0]['lr'])."""
+    import copy
+    import torch.nn as nn
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    torch.manual_seed(0)
+    a = nn.Sequential(nn.Linear(20, 33), nn.ELU(), nn.Linear(33, 7)).to(DEV)
+    b = copy.deepcopy(a)
+    arena = ParamArena(a)
+    oa, ob = FlatAdam(arena, lr=1e-2), torch.optim.Adam(b.parameters(), lr=1e-2)
+    for step in range(5):
+        x = torch.randn(64, 20, device=DEV)
+        if step == 3:
+            oa.param_groups[0]["lr"] = ob.param_groups[0]["lr"] = 2e-3
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(x).pow(2).mean().backward()
+            o.step()
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert rel_inf(pa.detach().cpu(), pb.detach().cpu()) < 1e-6
+    assert arena.attached()

@@ -116,6 +116,87 @@ def test_g8_adam_three_steps():
     assert np.allclose(losses, g["losses"], rtol=1e-5, atol=0)
 
 
+@pytest.mark.parametrize("aggr", ["mean"])
+def test_g5_density_with_param_arena(aggr):
+    """Same fixture through the flat parameter/gradient arena: stacked weight VIEWS (no cat), weight and
+    GraphNorm gradients accumulated straight into the arena by the kernels."""
+    from impl import utils
+    from glass_amd.arena import ParamArena
+    g = load(f"g5_density_{aggr}.npz")
+    n, ei, ew, x, pos, y, z = density_inputs(g)
+    model = build_glass(int(g["hidden"]), int(g["layers"]), int(g["max_deg"]), 3, aggr, str(g["pool"]),
+                        float(g["z_ratio"]))
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    model.load_state_dict(sd_from(g))  # in-place copy: keeps the aliasing
+    assert arena.attached() and "trans" in model.conv.convs[0]._stack and "comb" in model.conv.convs[1]._stack
+    W = model.conv.convs[0]._stack["trans"][0]
+    assert torch.equal(W[:64], model.conv.convs[0].trans_fns[1].weight) and torch.equal(
+        W[64:], model.conv.convs[0].trans_fns[0].weight)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    for _ in range(2):  # twice: gradients must not leak across arena.zero()
+        arena.zero()
+        pred = model(xg, eig, ewg, posg, utils.MaxZOZ(xg, posg))
+        loss = nn.CrossEntropyLoss()(pred, yg)
+        loss.backward()
+    keys = [str(k) for k in g["gnorm64_keys"]]
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    assert rel_inf(pred.detach().cpu(), g["pred64"]) < TOL
+    assert rel_inf(flat_grads(mine, keys), flat_grads(grads_from(g, "grad64/"), keys)) < TOL
+    assert list(model.state_dict().keys()) == [k[3:] for k in g.files if k.startswith("sd/")]
+
+
+def test_g8_adam_three_steps_arena_flat_adam():
+    from impl import utils
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    g = load("g8_adam.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    ei, ew = torch.from_numpy(g["edge_index"]).to(DEV), torch.from_numpy(g["edge_weight"]).to(DEV)
+    pos_all, y_all = torch.from_numpy(g["pos"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    model = build_glass(int(g["hidden"]), int(g["layers"]), int(x.max()), 3, str(g["aggr"]), str(g["pool"]),
+                        float(g["z_ratio"])).to(DEV).train()
+    arena = ParamArena(model)
+    model.load_state_dict(sd_from(g))
+    opt = FlatAdam(arena, lr=float(g["lr"]))
+    losses = []
+    for step in range(3):
+        sel = torch.arange(step * 4, step * 4 + 4, device=DEV)
+        p = pos_all[sel]
+        opt.zero_grad()
+        loss = nn.CrossEntropyLoss()(model(x, ei, ew, p, utils.MaxZOZ(x, p), id=0), y_all[sel])
+        loss.backward()
+        losses.append(loss.item())
+        opt.step()
+    assert np.allclose(losses, g["losses"], rtol=1e-5, atol=0)
+    end = sd_from(g, "sd_end/")
+    keys = sorted(end)
+    mine = {k: v.cpu() for k, v in model.state_dict().items()}
+    assert rel_inf(flat_grads(mine, keys), flat_grads(end, keys)) < 1e-4
+
+
+def test_train_step_graph_replay_matches_eager():
+    """The hipGraph-replayed step (TrainStep) follows the eager step: same losses over 6 steps (dropout 0)."""
+    from glass_amd import synth
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    from glass_amd.step import TrainStep
+    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=2, n_batches=6)
+    ei, ew, x, pos, y = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x, pos, y))
+    pos, y = pos.reshape(6, w.batch, -1), y.reshape(6, w.batch)
+    curves = []
+    for use_graph in (False, True):
+        torch.manual_seed(0)
+        model = build_glass(w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio).to(DEV).train()
+        arena = ParamArena(model)
+        opt = FlatAdam(arena, lr=5e-3)
+        step = TrainStep(model, opt, nn.CrossEntropyLoss(), x, ei, ew, arena, use_graph=use_graph, warmup_iters=2)
+        curves.append([float(step(pos[i], y[i]).item()) for i in range(6)])
+        assert step.graphed == use_graph
+    assert np.allclose(curves[0], curves[1], rtol=1e-5, atol=0)
+    assert curves[0][-1] != curves[0][0]
+
+
 def test_g9_state_dict_keys():
     g = load("g9_keys.npz")
     model = build_glass(64, 2, 1, 3, "mean", "sum", 0.8)
