@@ -52,31 +52,43 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
             for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // wave w takes row pairs p = w, w+4, ...; two pairs in flight
-    for (int64_t nb = r0 + 2 * w; nb < r1; nb += 16) {  // wave-uniform trip count (MFMA needs all lanes)
-        const int64_t n = nb + h;
-        float4 g[2];
-        float2 x[2];
+    // Wave w takes row pairs p = w, w+4, ...  One pipeline stage = two row pairs (16 MFMAs = 1024
+    // cycles of matrix work); kStages stages are kept in flight because a stage's loads take about
+    // one loaded-memory latency (~2 us) — with a single stage of prefetch the loop ran 4x slower
+    // than the MFMA rate at N = 1 M (profiles/r01: 6.9 ms vs 1.7 ms of matrix time).
+    constexpr int kStages = 4;
+    float4 g[kStages][2];
+    float2 x[kStages][2];
+    auto load_stage = [&](int64_t nb, float4 (&gs)[2], float2 (&xs)[2]) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int64_t nn = n + 8 * s;
-            g[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            x[s] = make_float2(0.f, 0.f);
-            if (nn < r1) {
-                if (o_ok) g[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
-                if (i_ok) x[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
+            const int64_t nn = nb + h + 8 * s;
+            gs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xs[s] = make_float2(0.f, 0.f);
+            if (nn < r1) {  // rows past the slab load nothing and contribute zeros
+                if (o_ok) gs[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
+                if (i_ok) xs[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
             }
         }
+    };
+    const int64_t nb0 = r0 + 2 * w;  // wave-uniform (MFMA needs every lane in the loop)
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float gv[4] = {g[s].x, g[s].y, g[s].z, g[s].w};
-            const float xv[2] = {x[s].x, x[s].y};
+    for (int st = 0; st < kStages; ++st) load_stage(nb0 + 16 * st, g[st], x[st]);
+    for (int64_t nb = nb0; nb < r1; nb += 16 * kStages) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+        for (int st = 0; st < kStages; ++st) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
-            bsum.x += g[s].x; bsum.y += g[s].y; bsum.z += g[s].z; bsum.w += g[s].w;
+            for (int s = 0; s < 2; ++s) {
+                const float gv[4] = {g[st][s].x, g[st][s].y, g[st][s].z, g[st][s].w};
+                const float xv[2] = {x[st][s].x, x[st][s].y};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
+                bsum.x += g[st][s].x; bsum.y += g[st][s].y; bsum.z += g[st][s].z; bsum.w += g[st][s].w;
+            }
+            load_stage(nb + 16 * (st + kStages), g[st], x[st]);  // refill this stage, kStages ahead
         }
     }
 
@@ -115,34 +127,66 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
     }
 }
 
-// Sum the slab partials in slab order and scatter to dW[o,i] / db[o].
+// Sum the slab partials and scatter to dW[o,i] / db[o].  A [n_slabs x 8192(+128)] column reduction:
+// 16 lanes x float4 cover 64 columns, 16 row slots walk the slabs (4 loads in flight each) and are
+// combined through LDS in slot order -> fixed summation order.
 __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part_w,
                                                               const float* __restrict__ part_b, int n_slabs, int ny,
                                                               int O, int I, float* __restrict__ dW, int64_t lddw,
                                                               float* __restrict__ db, int accumulate) {
+    __shared__ float4 lds[kBlock];
     const int chunk = blockIdx.y;  // (z * ny + y)
     const int z = chunk / ny, y = chunk % ny;
-    const int k = blockIdx.x * kBlock + threadIdx.x;
-    if (k < kTile) {
-        const float* p = part_w + (int64_t)chunk * n_slabs * kTile + k;
-        float s = 0.f;
-        for (int b = 0; b < n_slabs; ++b) s += p[(int64_t)b * kTile];
-        // decode k = ((t*2+u)*16 + reg)*64 + lane  ->  (o, i)
-        const int lane = k & 63, reg = (k >> 6) & 15, tu = k >> 10;
-        const int t = tu >> 1, u = tu & 1;
-        const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), cc = lane & 31;
-        const int o = z * kOT + 4 * r + t, i = y * kIT + 2 * cc + u;
-        if (o < O && i < I) {
-            float* d = dW + (int64_t)o * lddw + i;
-            *d = accumulate ? *d + s : s;
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int k0 = blockIdx.x * 64 + tc * 4;       // first of this thread's 4 columns
+    const bool is_bias = k0 >= kTile;
+    if (is_bias && (y != 0 || db == nullptr)) return;  // whole workgroup: blockIdx.x is uniform
+    const float* p;
+    int64_t stride;
+    if (!is_bias) {
+        p = part_w + (int64_t)chunk * n_slabs * kTile + k0;
+        stride = kTile;
+    } else {
+        p = part_b + (int64_t)z * n_slabs * kOT + (k0 - kTile);
+        stride = kOT;
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = tr; b < n_slabs; b += 64) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int bb = b + 16 * u;
+            v[u] = bb < n_slabs ? *reinterpret_cast<const float4*>(p + (int64_t)bb * stride)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-    } else if (db && y == 0 && k < kTile + kOT) {
-        const int oo = k - kTile;
-        const float* p = part_b + (int64_t)z * n_slabs * kOT + oo;
-        float s = 0.f;
-        for (int b = 0; b < n_slabs; ++b) s += p[(int64_t)b * kOT];
-        const int o = z * kOT + oo;
-        if (o < O) db[o] = accumulate ? db[o] + s : s;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    if (tr != 0) return;
+    for (int r = 1; r < 16; ++r) {
+        const float4 o = lds[r * 16 + tc];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = k0 + q;
+        if (!is_bias) {
+            // decode k = ((t*2+u)*16 + reg)*64 + lane  ->  (o, i)
+            const int lane = k & 63, reg = (k >> 6) & 15, tu = k >> 10;
+            const int t = tu >> 1, u = tu & 1;
+            const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), cc = lane & 31;
+            const int o = z * kOT + 4 * r + t, i = y * kIT + 2 * cc + u;
+            if (o < O && i < I) {
+                float* d = dW + (int64_t)o * lddw + i;
+                *d = accumulate ? *d + sv[q] : sv[q];
+            }
+        } else {
+            const int o = z * kOT + (k - kTile);
+            if (o < O) db[o] = accumulate ? db[o] + sv[q] : sv[q];
+        }
     }
 }
 
@@ -219,7 +263,7 @@ extern "C" int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* 
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wgrad_partial_kernel, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, G, ldg, X, ldx, N, (int)O,
                        (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT + kBlock - 1) / kBlock, g.ny * g.nz), dim3(kBlock), 0, st,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st,
                        part_w, part_b, g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
     return launch_status("glass_linear_wgrad_f32");
 }
