@@ -91,11 +91,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
+    n_dev = torch.cuda.device_count()
+    backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")  # "gloo": smoke-test the N>1 path on a 1-GPU box
+    if backend == "gloo":
+        local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as td
-        td.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        if backend == "nccl":
+            td.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+        else:
+            td.init_process_group(backend)
 
     from glass_amd import synth, ops, graph as ggraph, dist as gdist
     from impl import utils
@@ -133,7 +140,7 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as td
-            td.barrier(device_ids=[local_rank])
+            td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()
         torch.cuda.synchronize()
 
     run(args.warmup, 0)
