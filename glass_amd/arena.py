@@ -54,6 +54,7 @@ class ParamArena(FlatGradBucket):
                 off += b.numel()
         total = (off + 3) // 4 * 4
         self.model = model
+        model._glass_grad_bucket = self  # dist.bucket_for(model) -> the arena (train.train's all-reduce hook)
         self.params = params
         self.flat_param = torch.zeros(total, dtype=dtype, device=dev)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)  # gradients (FlatGradBucket API)

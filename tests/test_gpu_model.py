@@ -299,3 +299,16 @@ def test_train_and_test_loops():
     score, loss = train.test(model, SubGDataset.ZGDataloader(ds, w.batch, z_fn=utils.MaxZOZ, shuffle=True,
                                                              drop_last=False), metrics.microf1, nn.CrossEntropyLoss())
     assert 0.0 <= score <= 1.0 and torch.isfinite(loss)
+
+
+def test_driver_density_learns(capsys):
+    """GLASSTest.py-compatible driver end to end on the shipped density set with the README recipe
+    (--use_one --use_seed --use_maxzeroone; config/density.yml: H=8, L=1, batch 2): log format and a
+    test micro-F1 well above chance (3 classes) within 40 epochs (the reference reaches 0.95+ at ~41)."""
+    import GLASSTest
+    outs = GLASSTest.main(["--use_one", "--use_seed", "--use_maxzeroone", "--repeat", "1", "--device", "0",
+                           "--dataset", "density", "--max_epoch", "40"])
+    text = capsys.readouterr().out
+    assert "params {" in text and "repeat 0" in text and "end: epoch" in text and "average " in text
+    assert any(line.startswith("iter ") and " val " in line and " tst " in line for line in text.splitlines())
+    assert outs[0] > 0.8

@@ -162,3 +162,47 @@ def test_flat_grad_bucket_aliases_grads():
     assert not b.attached()
     b.zero()  # re-attaches
     assert b.attached()
+
+
+def test_datasets_loader_reproduces_reference_density():
+    """datasets.load_dataset('density') (plain-array file, no pickle / networkx / PyG) vs the graph the
+    REFERENCE's loader produced when fixture g5 was generated: same symmetrised edges, same degree feature,
+    same padded subgraphs; split mask sizes 50/25/25 %."""
+    import datasets
+    g5 = load("g5_density_mean.npz")
+    torch.manual_seed(0)
+    g = datasets.load_dataset("density")
+    g.setDegreeFeature()
+    n = int(g5["n_node"])
+    und = g5["und_pairs"].astype(np.int64)
+    ref_keys = np.sort(np.concatenate([und[0] * n + und[1], und[1] * n + und[0]]))
+    mine = (g.edge_index[0] * n + g.edge_index[1]).numpy()
+    assert np.array_equal(mine, ref_keys)  # (row,col)-sorted, symmetric, coalesced
+    assert torch.all(g.edge_attr == 1) and g.x.shape == (n, 1, 1)
+    assert np.array_equal(g.x.reshape(-1).numpy(), g5["x"].astype(np.int64))
+    sel = [0, 5, 9, 200, 249, 31, 77, 123]  # the subgraphs of the g5 'mean' variant
+    assert np.array_equal(g.pos[sel].numpy(), g5["pos"].astype(np.int64))
+    assert np.array_equal(g.y[sel].numpy(), g5["y"])
+    assert g.mask.bincount().tolist() == [125, 62, 63]
+    x, ei, ea, pos, y = g.get_split("valid")
+    assert pos.shape == (62, 20) and y.shape == (62, )
+
+
+def test_datasets_other_sources():
+    import datasets
+    for name, n, e2 in (("cut_ratio", 5000, 2 * 84295), ("coreness", 5000, 2 * 119205), ("component", 17260, 2 * 91619)):
+        g = datasets.load_dataset(name)
+        assert g.num_nodes == n and g.edge_index.shape == (2, e2)
+    g = datasets.load_dataset("synthetic:tiny")
+    g.setOneFeature()
+    assert g.x.unique().tolist() == [1] and g.edge_index.shape[1] == 3000
+    g.setNodeIdFeature()
+    assert g.x.reshape(-1).tolist() == list(range(g.num_nodes))
+    with pytest.raises(FileNotFoundError):
+        datasets.load_dataset("ppi_bp")  # real-world sets are not shipped
+    with pytest.raises(NotImplementedError):
+        datasets.load_dataset("no_such_dataset")
+    # to_undirected: directed input with a duplicate -> symmetrised, duplicate weights add
+    bg = datasets.BaseGraph(torch.empty(4, 1, 0), torch.tensor([[0, 0, 2], [1, 1, 3]]), torch.tensor([1.0, 2.0, 1.0]),
+                            torch.tensor([[0, 1]]), torch.tensor([0]), torch.tensor([0]))
+    assert bg.edge_index.tolist() == [[0, 1, 2, 3], [1, 0, 3, 2]] and bg.edge_attr.tolist() == [3.0, 3.0, 1.0, 1.0]
