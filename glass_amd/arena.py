@@ -89,7 +89,14 @@ class ParamArena(FlatGradBucket):
         return all(p.data.untyped_storage().data_ptr() == base_p and p.grad is not None
                    and p.grad.untyped_storage().data_ptr() == base_g for p in self.params)
 
+    def all_reduce_mean(self):
+        from .ops import join_side_streams
+        join_side_streams()  # the side-stream weight gradients must have landed in the arena
+        super().all_reduce_mean()
+
     def zero(self):
+        from .ops import join_side_streams
+        join_side_streams()
         if not self.attached():
             raise RuntimeError("ParamArena detached (model.to()/zero_grad(set_to_none=True) after flattening?)")
         self.flat.zero_()

@@ -157,32 +157,79 @@ def mix(T, mask, z_ratio, act):
 # ---------------------------------------------------------------------------------------------
 # K5  the two Linears of a weight-set pair as one GEMM; weight gradient on the fp32 matrix cores
 # ---------------------------------------------------------------------------------------------
+import os as _os
+
+# Off by default — measured on MI355X (ppi_bp-shape, hipGraph replay, 3 interleaved A/B rounds): 0.765 ms/step
+# with the weight gradients forked onto a side stream vs 0.678 ms/step on one stream: the fork/join
+# dependencies cost more than the overlap of these 10-20 us kernels buys.
+USE_SIDE_STREAM = _os.environ.get("GLASS_SIDE_STREAM", "0") == "1"
 _wgrad_ws = {}
+_side = {}
 
 
-def _wgrad_workspace(device, N, O, I):
+def _wgrad_workspace(device, N, O, I, slot=0):
     nbytes = _lib.load().glass_linear_wgrad_ws_bytes(N, O, I)
-    ws = _wgrad_ws.get(device)
+    ws = _wgrad_ws.get((device, slot))
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty(nbytes // 4 + 16, dtype=torch.float32, device=device)
-        _wgrad_ws[device] = ws
+        _wgrad_ws[(device, slot)] = ws
     return ws
 
 
-def linear_wgrad(G, X, dW, db, accumulate):
-    """dW (+)= G^T @ X, db (+)= colsum(G) with glass_linear_wgrad_f32; False if the shape is unsupported."""
+class SideStream:
+    """Weight gradients do not feed the rest of the backward pass, so they run on a second HIP stream
+    beside the dgrad -> GraphNorm -> aggregation chain (most kernels of a small graph fill only part of
+    the 256 CUs).  fork() orders the side stream after everything enqueued so far on the current
+    stream; join() makes the current stream wait for the side work (call before the optimizer).
+    Under hipGraph capture this becomes a fork/join in the graph."""
+    def __init__(self, device):
+        self.stream = torch.cuda.Stream(device=device)
+        self.pending = False
+
+    def fork(self):
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self.pending = True
+        return torch.cuda.stream(self.stream)
+
+    def join(self):
+        if self.pending:
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.pending = False
+
+
+def side_stream(device):
+    s = _side.get(device)
+    if s is None:
+        s = _side[device] = SideStream(device)
+    return s
+
+
+def join_side_streams():
+    for s in _side.values():
+        s.join()
+
+
+def linear_wgrad(G, X, dW, db, accumulate, slot=0):
+    """dW (+)= G^T @ X, db (+)= colsum(G) with glass_linear_wgrad_f32; False if the shape is unsupported.
+    `slot` selects a scratch buffer (calls that may overlap on different streams need different ones)."""
     G, ldg = _rows(G)
     X, ldx = _rows(X)
     N, O = G.shape
     I = X.shape[1]
     if O % 4 or I % 2 or ldg % 4 or ldx % 2 or G.data_ptr() % 16 or X.data_ptr() % 8 or dW.stride(1) != 1:
         return False
-    ws = _wgrad_workspace(G.device, N, O, I)
+    ws = _wgrad_workspace(G.device, N, O, I, slot)
     rc = _lib.load().glass_linear_wgrad_f32(G.data_ptr(), ldg, X.data_ptr(), ldx, N, O, I, dW.data_ptr(), dW.stride(0),
                                             0 if db is None else db.data_ptr(), int(accumulate), ws.data_ptr(),
                                             _stream())
     _lib.check(rc, "glass_linear_wgrad_f32")
     return True
+
+
+def _wgrad_supported(G, X, dW):
+    O, I = G.shape[1], X.shape[1]
+    return not (O % 4 or I % 2 or G.stride(0) % 4 or X.stride(0) % 2 or G.data_ptr() % 16 or X.data_ptr() % 8 or
+                G.stride(1) != 1 or X.stride(1) != 1 or dW.stride(1) != 1)
 
 
 class StackedLinearFn(torch.autograd.Function):
@@ -205,9 +252,19 @@ class StackedLinearFn(torch.autograd.Function):
     def backward(ctx, dT):
         x, W = ctx.saved_tensors
         dT, _ = _rows(dT)
-        dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
-        if ctx.stack is not None and linear_wgrad(dT, x, ctx.stack[2], ctx.stack[3], True):
+        if ctx.stack is not None and _wgrad_supported(dT, x, ctx.stack[2]) and USE_SIDE_STREAM:
+            # accumulate straight into the gradient arena, on the side stream (joined before Adam).
+            # The side stream uses its own scratch; successive wgrads on it are stream-ordered.
+            side = side_stream(dT.device)
+            if not side.pending:  # re-join at the end of this backward pass, whoever called it
+                torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
+            with side.fork():
+                linear_wgrad(dT, x, ctx.stack[2], ctx.stack[3], True, slot=1)
+                dT.record_stream(side.stream)
+                x.record_stream(side.stream)
+            dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
             return dx, None, None, None, None, None
+        dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(W)
         db = torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
         if not linear_wgrad(dT, x, dW, db, False):

@@ -31,6 +31,8 @@ class FlatAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        from .ops import join_side_streams
+        join_side_streams()  # weight gradients accumulate on a side stream
         g = self.param_groups[0]
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
