@@ -52,6 +52,12 @@ SIGNATURES = {
     "glass_segment_pool_bwd_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _P, _I, _I, _I, _P]),
     "glass_linear_wgrad_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, c_int, _P, _P]),
+    "glass_dual_linear_supported": (c_int, [_I]),
+    "glass_dual_linear_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P]),
+    "glass_dual_linear_dgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
+    "glass_dual_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, _I, _P,
+                                            c_int, _P, _P]),
+    "glass_transpose_batch_f32": (c_int, [_P, _P, _P, _P, _I, _P]),
     "glass_adam_step_f32": (c_int, [_P, _P, _P, _P, _I, _P, c_double, c_double, c_double, c_double, _P, _P]),
 }
 

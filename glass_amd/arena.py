@@ -79,10 +79,37 @@ class ParamArena(FlatGradBucket):
             shape = (2 * a.shape[0], ) + tuple(a.shape[1:])
             stacks.setdefault((id(mod), kind), [mod, kind]).append(
                 (self.flat_param[o:o + n2].view(shape), self.flat[o:o + n2].view(shape)))
+        self._transposes = []
         for (_, kind), (mod, _k, *views) in stacks.items():
             if len(views) == 2:  # weight and bias both stackable
                 (W, dW), (b, db) = views
-                mod._stack[kind] = (W, b, dW, db)
+                WT = torch.empty((W.shape[1], W.shape[0]), dtype=dtype, device=dev)  # refreshed once per step
+                mod._stack[kind] = (W, b, dW, db, WT)
+                self._transposes.append((W, WT))
+        import numpy as np
+        k = len(self._transposes)
+        self._tp_args = (np.array([w.data_ptr() for w, _ in self._transposes], dtype=np.uint64),
+                         np.array([t.data_ptr() for _, t in self._transposes], dtype=np.uint64),
+                         np.array([w.shape[0] for w, _ in self._transposes], dtype=np.int64),
+                         np.array([w.shape[1] for w, _ in self._transposes], dtype=np.int64), k)
+        from .models import EmbZGConv
+        for mod in model.modules():
+            if isinstance(mod, EmbZGConv):
+                mod._glass_arena = self  # EmbZGConv.forward refreshes the transposes once per training forward
+        self.refresh_transposes()
+
+    def refresh_transposes(self):
+        """W^T of every stacked weight (operand layout of the fused data-gradient kernel): one launch for the
+        whole model, called once per training forward because Adam changes the weights in between."""
+        src, dst, rows, cols, k = self._tp_args
+        if k == 0:
+            return
+        from . import _lib
+        for i in range(0, k, 16):
+            n = min(16, k - i)
+            rc = _lib.load().glass_transpose_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, rows[i:].ctypes.data,
+                                                       cols[i:].ctypes.data, n, torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "glass_transpose_batch_f32")
 
     def attached(self):
         base_p, base_g = self.flat_param.untyped_storage().data_ptr(), self.flat.untyped_storage().data_ptr()

@@ -1,0 +1,277 @@
+// K5: the dense half of GLASSConv fused with its label-conditioned mix, on the fp32 matrix cores.
+//
+//   forward  (reference impl/models.py:158-162 and 167-173)
+//     trans: T = x_ @ [W1;W0]^T + [b1|b0];  m = mix(ELU(T1), ELU(T0))        writes T (kept for backward) and m
+//     comb : y = mix(C1, C0),  C = [g || x_] @ [Wc1;Wc0]^T + [bc1|bc0]        reads g and x_ in place (no cat),
+//                                                                              never materialises C
+//   backward data gradient:  dIN = dZ @ Wstack, with dZ = mix'(dsrc) (* ELU'(T)) synthesised on the fly
+//   (the [N,2H] gradient of the stacked Linear output is never written).
+//
+// Why here and not in the vendor GEMM: at hidden=64 these GEMMs are tiny in two dimensions
+// ([N,64..128] x [64..128,128]); hipBLASLt takes 12-18 us each and the mix/ELU/cat around them are 5-7
+// separate elementwise launches of ~5 us (profiles/r01_bench_*): launch-bound, not FLOP-bound.
+//
+// Mapping (v_mfma_f32_16x16x4_f32; exact fp32 fma chain): a wave owns 16 rows and ALL output columns.
+// Lane (i = l&15, q = l>>4) holds the contiguous K-chunk [q*KT/4, (q+1)*KT/4) of row i of A and, per
+// 16-column output tile, the same chunk of row (16t+i) of the [out][in] weight — both are plain 16-B
+// loads of consecutive floats; MFMA step s multiplies element s of the four chunks (the matrix core
+// sums over k in any order, so no transposes, shuffles or LDS staging are needed).  Weights come
+// from L1/L2 (32-64 KiB per layer); the next tile's weight chunk is loaded while the current tile's
+// MFMAs issue.  Supported hidden sizes: multiples of 64 up to 256; other sizes use the library GEMM +
+// the stand-alone mix kernels.
+#include "common.h"
+
+namespace glass {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kKC = 16;  // K elements per lane per pass (64 per wave-step group)
+
+__device__ __forceinline__ void load16(float (&dst)[kKC], const float* p, bool ok) {
+#pragma unroll
+    for (int v = 0; v < kKC / 4; ++v) {
+        float4 t = ok ? *reinterpret_cast<const float4*>(p + 4 * v) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dst[4 * v] = t.x; dst[4 * v + 1] = t.y; dst[4 * v + 2] = t.z; dst[4 * v + 3] = t.w;
+    }
+}
+
+// acc[t] += A_chunk . W_tile_chunk for every 16-column tile t; `wrow(t)` = pointer to this lane's
+// kKC consecutive weights of tile t.  Double-buffered weight loads.
+template <int NTILES, typename WPtr>
+__device__ __forceinline__ void mfma_pass(f32x4 (&acc)[NTILES], const float (&a)[kKC], WPtr wrow) {
+    float b[2][kKC];
+    load16(b[0], wrow(0), true);
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) {
+        if (t + 1 < NTILES) load16(b[(t + 1) & 1], wrow(t + 1), true);
+#pragma unroll
+        for (int s = 0; s < kKC; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t & 1][s], acc[t], 0, 0, 0);
+    }
+}
+
+// ---- forward ----------------------------------------------------------------------------------
+template <int H, bool COMB>
+__global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restrict__ xa, int64_t lda,
+                                                          const float* __restrict__ xb, int64_t ldb,
+                                                          const float* __restrict__ W, const float* __restrict__ bias,
+                                                          const uint8_t* __restrict__ mask, float zr, float omz, int act,
+                                                          float* __restrict__ T, int64_t ldt, float* __restrict__ out,
+                                                          int64_t ldo, int64_t N) {
+    constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H, NTILES = NT / 16, HT = H / 16;
+    static_assert(KQ % kKC == 0, "hidden size must be a multiple of 64");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + w) * 16;
+    const int64_t row = row0 + i;
+    const bool row_ok = row < N;
+    // this lane's K-chunk of its A row: q*KQ .. (q+1)*KQ of [xa || xb]
+    const float* arow;
+    if (!COMB) {
+        arow = xa + row * lda + q * KQ;
+    } else {
+        arow = (q < 2) ? xa + row * lda + q * KQ : xb + row * ldb + (q - 2) * KQ;  // KQ = H/2
+    }
+    f32x4 acc[NTILES];
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KQ / kKC; ++kc) {
+        float a[kKC];
+        load16(a, arow + kc * kKC, row_ok);
+        const float* wbase = W + (int64_t)i * KT + q * KQ + kc * kKC;
+        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)t * 16 * KT; });
+    }
+    // epilogue: acc[t][reg] is row row0 + 4q + reg, column 16t + i
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = row0 + 4 * q + reg;
+        if (r >= N) continue;
+        const float w1 = mask[r] ? zr : omz, w0 = mask[r] ? omz : zr;
+#pragma unroll
+        for (int t = 0; t < HT; ++t) {
+            const int c = 16 * t + i;
+            float v1 = acc[t][reg] + bias[c];
+            float v0 = acc[t + HT][reg] + bias[H + c];
+            if (T) {
+                T[r * ldt + c] = v1;
+                T[r * ldt + H + c] = v0;
+            }
+            if (act == GLASS_ACT_ELU) {
+                v1 = elu_f(v1);
+                v0 = elu_f(v0);
+            }
+            out[r * ldo + c] = w1 * v1 + w0 * v0;
+        }
+    }
+}
+
+// ---- backward data gradient ---------------------------------------------------------------------
+// out[N, NT] = dZ[N, 2H] @ Wstack[2H, NT] (+ addend), dZ[n, o] = coef(n, o<H) * dsrc[n, o mod H] * act'(T[n, o]);
+// WT = Wstack^T stored [NT][2H] so that weight chunks are contiguous (refreshed once per step).
+template <int H, int NT>
+__global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
+                                                            const float* __restrict__ T, int64_t ldt,
+                                                            const uint8_t* __restrict__ mask, float zr, float omz,
+                                                            int act, const float* __restrict__ WT,
+                                                            const float* __restrict__ addend, int64_t ldadd,
+                                                            float* __restrict__ out, int64_t ldo, int64_t N) {
+    constexpr int KT = 2 * H, KQ = KT / 4, NTILES = NT / 16;
+    static_assert(KQ % kKC == 0, "hidden size must be a multiple of 32");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + w) * 16;
+    const int64_t row = row0 + i;
+    const bool row_ok = row < N;
+    const bool first = q < 2;  // lanes q=0,1 hold the f1 half (o < H), q=2,3 the f0 half
+    float coef = 0.f;
+    if (row_ok) coef = (mask[row] != 0) == first ? zr : omz;
+    const float* drow = dsrc + row * ldd + (q & 1) * KQ;   // o mod H
+    const float* trow = T ? T + row * ldt + q * KQ : nullptr;
+    f32x4 acc[NTILES];
+#pragma unroll
+    for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KQ / kKC; ++kc) {
+        float a[kKC];
+        load16(a, drow + kc * kKC, row_ok);
+        if (act == GLASS_ACT_ELU) {
+            float tv[kKC];
+            load16(tv, trow + kc * kKC, row_ok);
+#pragma unroll
+            for (int s = 0; s < kKC; ++s) a[s] *= elu_grad_f(tv[s]);
+        }
+#pragma unroll
+        for (int s = 0; s < kKC; ++s) a[s] *= coef;
+        const float* wbase = WT + (int64_t)i * KT + q * KQ + kc * kKC;
+        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)t * 16 * KT; });
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int64_t r = row0 + 4 * q + reg;
+        if (r >= N) continue;
+#pragma unroll
+        for (int t = 0; t < NTILES; ++t) {
+            const int c = 16 * t + i;
+            float v = acc[t][reg];
+            if (addend) v += addend[r * ldadd + c];
+            out[r * ldo + c] = v;
+        }
+    }
+}
+
+// ---- transposes of the stacked weights (one launch for the whole model) --------------------------
+struct TransposeJob {
+    const float* src;  // [rows][cols]
+    float* dst;        // [cols][rows]
+    int rows, cols;
+};
+constexpr int kMaxTransposeJobs = 16;
+struct TransposeBatch {
+    TransposeJob job[kMaxTransposeJobs];
+    int n;
+};
+
+__global__ __launch_bounds__(kBlock) void transpose_batch_kernel(TransposeBatch batch) {
+    __shared__ float tile[32][33];
+    const TransposeJob j = batch.job[blockIdx.z];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    if (c0 >= j.cols || r0 >= j.rows) return;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < j.rows && c < j.cols) ? j.src[(int64_t)r * j.cols + c] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < j.cols && r < j.rows) j.dst[(int64_t)c * j.rows + r] = tile[tx][k];
+    }
+}
+
+}  // namespace glass
+
+using namespace glass;
+
+static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128 || H == 192 || H == 256; }
+
+extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
+
+extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
+                                         const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
+                                         int64_t ldt, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
+                                         void* stream) {
+    GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
+    if (!dense_shape_ok(H)) {
+        set_error("dual_linear_fwd: hidden size %lld not supported (64,128,192,256)", (long long)H);
+        return GLASS_E_UNSUPPORTED;
+    }
+    const bool comb = xb != nullptr;
+    GLASS_REQUIRE(lda >= H && lda % 4 == 0 && aligned16(xa) && (!comb || (ldb >= H && ldb % 4 == 0 && aligned16(xb))) &&
+                      aligned16(W) && ldo >= H && (!T || ldt >= 2 * H),
+                  "dual_linear_fwd: operands must be 16-B aligned with ld %% 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div(n_nodes, 64));
+    const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
+#define GLASS_FWD(HH)                                                                                              \
+    if (H == HH) {                                                                                                 \
+        if (comb)                                                                                                  \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, true>), grid, dim3(kBlock), 0, st, xa, lda, xb, ldb, W, bias, mask, \
+                               zr, omz, act, T, ldt, out, ldo, n_nodes);                                           \
+        else                                                                                                       \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, false>), grid, dim3(kBlock), 0, st, xa, lda, xb, ldb, W, bias, mask, \
+                               zr, omz, act, T, ldt, out, ldo, n_nodes);                                           \
+    }
+    GLASS_FWD(64) GLASS_FWD(128) GLASS_FWD(192) GLASS_FWD(256)
+#undef GLASS_FWD
+    return launch_status("glass_dual_linear_fwd_f32");
+}
+
+extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt,
+                                           const uint8_t* mask, double z_ratio, int act, const float* WT,
+                                           int64_t n_out, const float* addend, int64_t ldadd, float* out, int64_t ldo,
+                                           int64_t n_nodes, int64_t H, void* stream) {
+    GLASS_REQUIRE(dsrc && mask && WT && out && n_nodes > 0, "dual_linear_dgrad: null pointer");
+    if (!dense_shape_ok(H) || (n_out != H && n_out != 2 * H)) {
+        set_error("dual_linear_dgrad: unsupported shape H=%lld n_out=%lld", (long long)H, (long long)n_out);
+        return GLASS_E_UNSUPPORTED;
+    }
+    GLASS_REQUIRE(ldd >= H && ldd % 4 == 0 && aligned16(dsrc) && aligned16(WT) && ldo >= n_out &&
+                      (act == GLASS_ACT_NONE || (T && ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))) &&
+                      (!addend || ldadd >= n_out),
+                  "dual_linear_dgrad: operands must be 16-B aligned with ld %% 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)ceil_div(n_nodes, 64));
+    const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
+    const float* Tp = act == GLASS_ACT_ELU ? T : nullptr;
+#define GLASS_DG(HH)                                                                                               \
+    if (H == HH) {                                                                                                 \
+        if (n_out == H)                                                                                            \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH>), grid, dim3(kBlock), 0, st, dsrc, ldd, Tp, ldt, mask, zr, omz, \
+                               act, WT, addend, ldadd, out, ldo, n_nodes);                                         \
+        else                                                                                                       \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH>), grid, dim3(kBlock), 0, st, dsrc, ldd, Tp, ldt, mask, zr, \
+                               omz, act, WT, addend, ldadd, out, ldo, n_nodes);                                    \
+    }
+    GLASS_DG(64) GLASS_DG(128) GLASS_DG(192) GLASS_DG(256)
+#undef GLASS_DG
+    return launch_status("glass_dual_linear_dgrad_f32");
+}
+
+extern "C" int glass_transpose_batch_f32(const float* const* src, float* const* dst, const int64_t* rows,
+                                         const int64_t* cols, int64_t n_jobs, void* stream) {
+    GLASS_REQUIRE(src && dst && rows && cols && n_jobs >= 0 && n_jobs <= kMaxTransposeJobs,
+                  "transpose_batch: bad arguments (at most %d matrices per call)", kMaxTransposeJobs);
+    if (n_jobs == 0) return 0;
+    TransposeBatch b;
+    b.n = (int)n_jobs;
+    int64_t mr = 0, mc = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        GLASS_REQUIRE(src[k] && dst[k] && rows[k] > 0 && cols[k] > 0, "transpose_batch: bad job %d", k);
+        b.job[k] = TransposeJob{src[k], dst[k], (int)rows[k], (int)cols[k]};
+        mr = rows[k] > mr ? rows[k] : mr;
+        mc = cols[k] > mc ? cols[k] : mc;
+    }
+    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)ceil_div(mc, 32), (unsigned)ceil_div(mr, 32), (unsigned)n_jobs),
+                       dim3(kBlock), 0, (hipStream_t)stream, b);
+    return launch_status("glass_transpose_batch_f32");
+}

@@ -28,11 +28,27 @@ constexpr int kMaxSlabs = 256;
 // idx of accumulator (t,u,reg,lane) in the permuted partial layout
 __device__ __forceinline__ int acc_index(int t, int u, int reg, int lane) { return ((t * 2 + u) * 16 + reg) * 64 + lane; }
 
+// SYNTH: G is not read but synthesised from the gradient of the mixed output (glass_dual_linear_wgrad_f32):
+//   G[n,o] = coef(mask[n], o<H) * dsrc[n, o mod H] * (act ? ELU'(T[n,o]) : 1),  O = 2H,
+// and X may be the virtual concatenation [X | X2] (each H wide) of the comb Linear's two inputs.
+struct WgradSynth {
+    const float* dsrc;   // [N,H]
+    int64_t ldd;
+    const float* T;      // [N,2H] pre-activations (act != 0)
+    int64_t ldt;
+    const uint8_t* mask;
+    float zr, omz;
+    int act, H;
+    const float* X2;     // second input half (may be null)
+    int64_t ldx2;
+};
+
+template <bool SYNTH>
 __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* __restrict__ G, int64_t ldg,
                                                                   const float* __restrict__ X, int64_t ldx,
                                                                   int64_t N, int O, int I, int rows_per_slab,
                                                                   float* __restrict__ part_w,
-                                                                  float* __restrict__ part_b) {
+                                                                  float* __restrict__ part_b, WgradSynth sy) {
     __shared__ float lds[2 * kTile];       // 64 KiB: two wave-sized accumulator images
     __shared__ float lds_b[8 * kOT];       // bias partials: [wave*2 + h][o]
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -66,8 +82,26 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
             gs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             xs[s] = make_float2(0.f, 0.f);
             if (nn < r1) {  // rows past the slab load nothing and contribute zeros
-                if (o_ok) gs[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
-                if (i_ok) xs[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
+                if (!SYNTH) {
+                    if (o_ok) gs[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
+                    if (i_ok) xs[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
+                } else {
+                    if (o_ok) {
+                        const bool first = o0 < sy.H;
+                        float4 d = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (first ? o0 : o0 - sy.H));
+                        const float cf = ((sy.mask[nn] != 0) == first) ? sy.zr : sy.omz;
+                        d.x *= cf; d.y *= cf; d.z *= cf; d.w *= cf;
+                        if (sy.act == GLASS_ACT_ELU) {
+                            const float4 t = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
+                            d.x *= elu_grad_f(t.x); d.y *= elu_grad_f(t.y); d.z *= elu_grad_f(t.z); d.w *= elu_grad_f(t.w);
+                        }
+                        gs[s] = d;
+                    }
+                    if (i_ok)
+                        xs[s] = (i0 < sy.H || sy.X2 == nullptr)
+                                    ? *reinterpret_cast<const float2*>(X + nn * ldx + i0)
+                                    : *reinterpret_cast<const float2*>(sy.X2 + nn * sy.ldx2 + (i0 - sy.H));
+                }
             }
         }
     };
@@ -261,11 +295,37 @@ extern "C" int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* 
     float* part_w = (float*)ws;
     float* part_b = part_w + g.part_w_floats;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wgrad_partial_kernel, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, G, ldg, X, ldx, N, (int)O,
-                       (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr);
+    hipLaunchKernelGGL(wgrad_partial_kernel<false>, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, G, ldg, X, ldx, N,
+                       (int)O, (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr, WgradSynth{});
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st,
                        part_w, part_b, g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
     return launch_status("glass_linear_wgrad_f32");
+}
+
+extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt,
+                                           const uint8_t* mask, double z_ratio, int act, const float* X, int64_t ldx,
+                                           const float* X2, int64_t ldx2, int64_t N, int64_t H, float* dW,
+                                           int64_t lddw, float* db, int accumulate, void* ws, void* stream) {
+    GLASS_REQUIRE(dsrc && mask && X && dW && ws && N > 0 && H > 0, "dual_linear_wgrad: null pointer");
+    const int64_t O = 2 * H, I = X2 ? 2 * H : H;
+    GLASS_REQUIRE(ldd >= H && ldx >= H && lddw >= I && (!X2 || ldx2 >= H) && (act == GLASS_ACT_NONE || (T && ldt >= O)),
+                  "dual_linear_wgrad: bad sizes");
+    if (H % 64 || ldd % 4 || ldx % 2 || (X2 && ldx2 % 2) || !aligned16(dsrc) || (reinterpret_cast<uintptr_t>(X) & 7u) ||
+        (X2 && (reinterpret_cast<uintptr_t>(X2) & 7u)) || (act != GLASS_ACT_NONE && (ldt % 4 || !aligned16(T)))) {
+        set_error("dual_linear_wgrad: needs H%%64==0 and aligned operands (H=%lld)", (long long)H);
+        return GLASS_E_UNSUPPORTED;
+    }
+    const WgradGeom g = wgrad_geom(N, O, I);
+    float* part_w = (float*)ws;
+    float* part_b = part_w + g.part_w_floats;
+    hipStream_t st = (hipStream_t)stream;
+    const WgradSynth sy{dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
+                        act, (int)H, X2, ldx2};
+    hipLaunchKernelGGL(wgrad_partial_kernel<true>, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X, ldx,
+                       N, (int)O, (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr, sy);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st, part_w, part_b,
+                       g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
+    return launch_status("glass_dual_linear_wgrad_f32");
 }
 
 extern "C" int glass_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -137,6 +137,16 @@ class GLASSConv(nn.Module):
         p = self.dropout if self.training else 0.0
         code = _act_code(self.activation)
         stack = getattr(self, "_stack", {})  # set by arena.ParamArena: stacked weight views
+        H = x_.shape[1]
+        if (code is not None and "trans" in stack and "comb" in stack and len(stack["trans"]) == 5 and
+                self.trans_fns[0].weight.shape == (H, H) and ops.dual_linear_supported(H) and ops.USE_FUSED_DENSE):
+            # fused dense path: Linear pair + ELU + mix in one MFMA kernel each; no cat, no [N,2H] round trips
+            m = ops.dual_linear_mix(x_, None, self.trans_fns[1], self.trans_fns[0], mask, self.z_ratio, code,
+                                    stack["trans"])
+            a = ops.spmm(self.adj, m)
+            g = self.gn(a, p_drop=p, call_id=self.call_base)
+            return ops.dual_linear_mix(g, x_, self.comb_fns[1], self.comb_fns[0], mask, self.z_ratio, ACT_NONE,
+                                       stack["comb"])
         # both weight sets in one GEMM: T = [f1 | f0]
         T = ops.stacked_linear(x_, self.trans_fns[1], self.trans_fns[0], stack.get("trans"))
         if code is None:
@@ -201,6 +211,9 @@ class EmbZGConv(nn.Module):
         p = self.dropout if self.training else 0.0
         if self.training and (p > 0 or any(c.dropout > 0 for c in self.convs)):
             ops.rng_advance(x.device)  # new dropout masks for this forward/backward pair
+        arena = getattr(self, "_glass_arena", None)
+        if arena is not None and torch.is_grad_enabled():
+            arena.refresh_transposes()  # W^T operands of the fused data-gradient kernels
         code = _act_code(self.activation)
         h, mask = ops.embed_label(self.input_emb.weight, x_flat, z, self._selection(x_flat))
         h = self.emb_gn(h, p_drop=p, call_id=1)

@@ -163,6 +163,7 @@ import os as _os
 # with the weight gradients forked onto a side stream vs 0.678 ms/step on one stream: the fork/join
 # dependencies cost more than the overlap of these 10-20 us kernels buys.
 USE_SIDE_STREAM = _os.environ.get("GLASS_SIDE_STREAM", "0") == "1"
+USE_FUSED_DENSE = _os.environ.get("GLASS_FUSED_DENSE", "1") != "0"  # A/B switch: fused MFMA dense path
 _wgrad_ws = {}
 _side = {}
 
@@ -276,6 +277,66 @@ class StackedLinearFn(torch.autograd.Function):
 
 def stacked_linear(x, lin1, lin0, stack=None):
     return StackedLinearFn.apply(x, lin1.weight, lin0.weight, lin1.bias, lin0.bias, stack)
+
+
+def dual_linear_supported(H):
+    return bool(_lib.load().glass_dual_linear_supported(int(H)))
+
+
+class DualLinearMixFn(torch.autograd.Function):
+    """out = mix(act(Z1), act(Z0)) with Z = [xa || xb] @ [W1;W0]^T + [b1|b0] in ONE kernel on the fp32 matrix
+    cores (glass_dual_linear_fwd_f32); xb=None for the trans pair (ELU, Z kept for the backward), xb=x_ for
+    the comb pair (no activation, no cat, Z never materialised).  Backward: one fused data-gradient kernel
+    and the split-K weight-gradient kernel, both synthesising dZ from `dout` on the fly; weight / bias
+    gradients are accumulated straight into the gradient arena (stack = arena views W, b, dW, db, W^T)."""
+    @staticmethod
+    def forward(ctx, xa, xb, w1, w0, b1, b0, mask, z_ratio, act, stack, out):
+        _need_gpu(xa, mask)
+        xa, lda = _rows(xa)
+        n, H = xa.shape
+        if xb is not None:
+            xb, ldb = _rows(xb)
+        W, b = stack[0], stack[1]
+        T = torch.empty((n, 2 * H), dtype=torch.float32, device=xa.device) if act != ACT_NONE else None
+        if out is None:
+            out = torch.empty((n, H), dtype=torch.float32, device=xa.device)
+        rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), lda, 0 if xb is None else xb.data_ptr(),
+                                                   0 if xb is None else ldb, W.data_ptr(), b.data_ptr(),
+                                                   mask.data_ptr(), float(z_ratio), act, 0 if T is None else T.data_ptr(),
+                                                   2 * H, out.data_ptr(), out.stride(0), n, H, _stream())
+        _lib.check(rc, "glass_dual_linear_fwd_f32")
+        ctx.save_for_backward(xa, xb, T, mask)
+        ctx.cfg = (float(z_ratio), act, stack, n, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        xa, xb, T, mask = ctx.saved_tensors
+        z_ratio, act, stack, n, H = ctx.cfg
+        dout, ldd = _rows(dout)
+        n_out = H if xb is None else 2 * H
+        lib = _lib.load()
+        tp, ldt = (0, 0) if T is None else (T.data_ptr(), T.stride(0))
+        din = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            din = torch.empty((n, n_out), dtype=torch.float32, device=dout.device)
+            rc = lib.glass_dual_linear_dgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act,
+                                                 stack[4].data_ptr(), n_out, 0, 0, din.data_ptr(), n_out, n, H, _stream())
+            _lib.check(rc, "glass_dual_linear_dgrad_f32")
+        I = n_out
+        ws = _wgrad_workspace(dout.device, n, 2 * H, I)
+        rc = lib.glass_dual_linear_wgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act, xa.data_ptr(),
+                                             xa.stride(0), 0 if xb is None else xb.data_ptr(),
+                                             0 if xb is None else xb.stride(0), n, H, stack[2].data_ptr(),
+                                             stack[2].stride(0), stack[3].data_ptr(), 1, ws.data_ptr(), _stream())
+        _lib.check(rc, "glass_dual_linear_wgrad_f32")
+        da = din if xb is None else (None if din is None else din[:, :H])
+        db_ = None if (xb is None or din is None) else din[:, H:]
+        return da, db_, None, None, None, None, None, None, None, None, None
+
+
+def dual_linear_mix(xa, xb, lin1, lin0, mask, z_ratio, act, stack, out=None):
+    return DualLinearMixFn.apply(xa, xb, lin1.weight, lin0.weight, lin1.bias, lin0.bias, mask, z_ratio, act, stack, out)
 
 
 # ---------------------------------------------------------------------------------------------

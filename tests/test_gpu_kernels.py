@@ -422,3 +422,66 @@ def test_graphnorm_scratch_reuse_stress():
         (d, ) = torch.autograd.grad(ops.graphnorm(x, ones, zeros, ones, 1e-5, 1), x, g)
         bad += int(not torch.equal(d, d0))
     assert bad == 0
+
+
+# ---------------------------------------------------------------------------------- K5 fused dense
+@pytest.mark.parametrize("H,N", [(64, 17080), (64, 77), (128, 5000), (256, 1030)])
+@pytest.mark.parametrize("comb", [False, True])
+def test_dual_linear_mix_fused(H, N, comb):
+    """Fused (Linear pair + ELU + mix) MFMA kernels vs an fp64 composition of nn.Linear, ELU and the mix:
+    forward, data gradient (both inputs for the comb pair) and weight / bias gradients accumulated into the
+    arena.  Inputs are strided views (the comb pair reads [g || x_] in place)."""
+    import torch.nn as nn
+    from glass_amd import ops
+    gen = torch.Generator().manual_seed(H + N)
+    K = 2 * H if comb else H
+    act = 0 if comb else 1
+    zr = 0.85
+    W = torch.randn(2 * H, K, generator=gen) / K**0.5
+    b = torch.randn(2 * H, generator=gen) * 0.1
+    wide_a, wide_b = torch.randn(N, H + 4, generator=gen), torch.randn(N, 2 * H, generator=gen)
+    mask = torch.rand(N, generator=gen) < 0.3
+    gout = torch.randn(N, H, generator=gen)
+    # fp64 reference
+    xa64 = wide_a[:, :H].double().requires_grad_(True)
+    xb64 = wide_b[:, H:].double().requires_grad_(True)
+    W64, b64 = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    xin = torch.cat((xa64, xb64), -1) if comb else xa64
+    Z = xin @ W64.t() + b64
+    A = torch.nn.functional.elu(Z) if act else Z
+    ref = O._mix(mask.reshape(-1, 1), zr, A[:, :H], A[:, H:])
+    ref.backward(gout.double())
+    # HIP
+    Wg, bg = W.to(DEV), b.to(DEV)
+    dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
+    WT = Wg.t().contiguous()
+    lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)  # carriers for the autograd edges only
+    xa = wide_a.to(DEV)[:, :H].requires_grad_(True)
+    xb = wide_b.to(DEV)[:, H:].requires_grad_(True) if comb else None
+    out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, WT))
+    out.backward(gout.to(DEV))
+    assert rel_inf(out.detach().cpu(), ref.detach()) < TOL
+    assert rel_inf(xa.grad.cpu(), xa64.grad) < TOL
+    if comb:
+        assert rel_inf(xb.grad.cpu(), xb64.grad) < TOL
+    assert rel_inf(dW.cpu(), W64.grad) < TOL
+    assert rel_inf(db.cpu(), b64.grad) < TOL
+    out2 = ops.dual_linear_mix(xa.detach(), None if xb is None else xb.detach(), lin1, lin0,
+                               mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, WT))
+    assert torch.equal(out2, out.detach())
+
+
+def test_transpose_batch():
+    import ctypes
+    from glass_amd import _lib
+    mats = [torch.randn(r, c, device=DEV) for r, c in ((128, 64), (128, 128), (40, 7), (1, 33))]
+    outs = [torch.empty(m.shape[1], m.shape[0], device=DEV) for m in mats]
+    src = np.array([m.data_ptr() for m in mats], dtype=np.uint64)
+    dst = np.array([m.data_ptr() for m in outs], dtype=np.uint64)
+    rows = np.array([m.shape[0] for m in mats], dtype=np.int64)
+    cols = np.array([m.shape[1] for m in mats], dtype=np.int64)
+    rc = _lib.load().glass_transpose_batch_f32(src.ctypes.data, dst.ctypes.data, rows.ctypes.data, cols.ctypes.data, 4,
+                                               torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    for m, o in zip(mats, outs):
+        assert torch.equal(o, m.t())
