@@ -35,17 +35,36 @@ __device__ __forceinline__ void load16(float (&dst)[kKC], const float* p, bool o
     }
 }
 
-// acc[t] += A_chunk . W_tile_chunk for every 16-column tile t; `wrow(t)` = pointer to this lane's
-// kKC consecutive weights of tile t.  Double-buffered weight loads.
+// Output-column permutation: tile t = 4*grp + k holds, in lane j, output column 64*grp + 4*j + k, so the four
+// tiles of a group give every lane FOUR CONSECUTIVE columns of a row -> 16-B stores / loads in the epilogue
+// (the MFMA does not care which 16 weight rows form a tile).
+__device__ __forceinline__ int tile_col(int t, int j) { return 64 * (t >> 2) + 4 * j + (t & 3); }
+
+// acc[t] += A_chunk . W_tile_chunk for every 16-column tile t; `wrow(t)` = pointer to this lane's kKC
+// consecutive weights of tile t.  Tiles go in pairs (two independent accumulators hide the 40-cycle
+// dependent-MFMA latency); the next pair's weight chunks are loaded while the current pair's MFMAs issue.
 template <int NTILES, typename WPtr>
 __device__ __forceinline__ void mfma_pass(f32x4 (&acc)[NTILES], const float (&a)[kKC], WPtr wrow) {
-    float b[2][kKC];
-    load16(b[0], wrow(0), true);
+    static_assert(NTILES % 2 == 0, "tiles are processed in pairs");
+    float b[2][2][kKC];
+    load16(b[0][0], wrow(0), true);
+    load16(b[0][1], wrow(1), true);
 #pragma unroll
-    for (int t = 0; t < NTILES; ++t) {
-        if (t + 1 < NTILES) load16(b[(t + 1) & 1], wrow(t + 1), true);
+    for (int t = 0; t < NTILES; t += 2) {
+        const int cur = (t >> 1) & 1;
+        if (t + 2 < NTILES) {
+            load16(b[cur ^ 1][0], wrow(t + 2), true);
+            load16(b[cur ^ 1][1], wrow(t + 3), true);
+        }
+        // hipcc otherwise sinks each weight load to just before its first use (one 16-B load per four
+        // MFMAs, vmcnt(1)): the whole kernel then runs at L2 latency, 18-22 us instead of ~5 (measured).
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < kKC; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[t & 1][s], acc[t], 0, 0, 0);
+        for (int s = 0; s < kKC; ++s) {
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[cur][0][s], acc[t], 0, 0, 0);
+            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[cur][1][s], acc[t + 1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -57,7 +76,7 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
                                                           const uint8_t* __restrict__ mask, float zr, float omz, int act,
                                                           float* __restrict__ T, int64_t ldt, float* __restrict__ out,
                                                           int64_t ldo, int64_t N) {
-    constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H, NTILES = NT / 16, HT = H / 16;
+    constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H, NTILES = NT / 16;
     static_assert(KQ % kKC == 0, "hidden size must be a multiple of 64");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
@@ -78,29 +97,45 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
     for (int kc = 0; kc < KQ / kKC; ++kc) {
         float a[kKC];
         load16(a, arow + kc * kKC, row_ok);
-        const float* wbase = W + (int64_t)i * KT + q * KQ + kc * kKC;
-        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)t * 16 * KT; });
+        const float* wbase = W + q * KQ + kc * kKC;
+        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)tile_col(t, i) * KT; });
     }
-    // epilogue: acc[t][reg] is row row0 + 4q + reg, column 16t + i
+    // epilogue: acc[4g+k][reg] is row row0 + 4q + reg, column 64g + 4i + k  ->  float4 per (row, group)
+    constexpr int NG = H / 64;  // 64-column groups per half
+    float4 bv[2 * NG];
+#pragma unroll
+    for (int g = 0; g < 2 * NG; ++g) bv[g] = *reinterpret_cast<const float4*>(bias + 64 * g + 4 * i);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = row0 + 4 * q + reg;
         if (r >= N) continue;
         const float w1 = mask[r] ? zr : omz, w0 = mask[r] ? omz : zr;
 #pragma unroll
-        for (int t = 0; t < HT; ++t) {
-            const int c = 16 * t + i;
-            float v1 = acc[t][reg] + bias[c];
-            float v0 = acc[t + HT][reg] + bias[H + c];
+        for (int g = 0; g < NG; ++g) {
+            const int c = 64 * g + 4 * i;
+            float v1[4], v0[4];
+            const float b1[4] = {bv[g].x, bv[g].y, bv[g].z, bv[g].w};
+            const float b0[4] = {bv[NG + g].x, bv[NG + g].y, bv[NG + g].z, bv[NG + g].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v1[k] = acc[4 * g + k][reg] + b1[k];
+                v0[k] = acc[4 * (NG + g) + k][reg] + b0[k];
+            }
             if (T) {
-                T[r * ldt + c] = v1;
-                T[r * ldt + H + c] = v0;
+                *reinterpret_cast<float4*>(T + r * ldt + c) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+                *reinterpret_cast<float4*>(T + r * ldt + H + c) = make_float4(v0[0], v0[1], v0[2], v0[3]);
             }
-            if (act == GLASS_ACT_ELU) {
-                v1 = elu_f(v1);
-                v0 = elu_f(v0);
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a1 = v1[k], a0 = v0[k];
+                if (act == GLASS_ACT_ELU) {
+                    a1 = elu_f(a1);
+                    a0 = elu_f(a0);
+                }
+                o[k] = w1 * a1 + w0 * a0;
             }
-            out[r * ldo + c] = w1 * v1 + w0 * v0;
+            *reinterpret_cast<float4*>(out + r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
 }
@@ -142,19 +177,22 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
         }
 #pragma unroll
         for (int s = 0; s < kKC; ++s) a[s] *= coef;
-        const float* wbase = WT + (int64_t)i * KT + q * KQ + kc * kKC;
-        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)t * 16 * KT; });
+        const float* wbase = WT + q * KQ + kc * kKC;
+        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)tile_col(t, i) * KT; });
     }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = row0 + 4 * q + reg;
         if (r >= N) continue;
 #pragma unroll
-        for (int t = 0; t < NTILES; ++t) {
-            const int c = 16 * t + i;
-            float v = acc[t][reg];
-            if (addend) v += addend[r * ldadd + c];
-            out[r * ldo + c] = v;
+        for (int g = 0; g < NTILES / 4; ++g) {
+            const int c = 64 * g + 4 * i;
+            float4 v = make_float4(acc[4 * g][reg], acc[4 * g + 1][reg], acc[4 * g + 2][reg], acc[4 * g + 3][reg]);
+            if (addend) {
+                const float4 ad = *reinterpret_cast<const float4*>(addend + r * ldadd + c);
+                v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+            }
+            *reinterpret_cast<float4*>(out + r * ldo + c) = v;
         }
     }
 }
@@ -207,7 +245,8 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     }
     const bool comb = xb != nullptr;
     GLASS_REQUIRE(lda >= H && lda % 4 == 0 && aligned16(xa) && (!comb || (ldb >= H && ldb % 4 == 0 && aligned16(xb))) &&
-                      aligned16(W) && ldo >= H && (!T || ldt >= 2 * H),
+                      aligned16(W) && aligned16(bias) && ldo >= H && ldo % 4 == 0 && aligned16(out) &&
+                      (!T || (ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))),
                   "dual_linear_fwd: operands must be 16-B aligned with ld %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(n_nodes, 64));
@@ -235,9 +274,9 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
         set_error("dual_linear_dgrad: unsupported shape H=%lld n_out=%lld", (long long)H, (long long)n_out);
         return GLASS_E_UNSUPPORTED;
     }
-    GLASS_REQUIRE(ldd >= H && ldd % 4 == 0 && aligned16(dsrc) && aligned16(WT) && ldo >= n_out &&
-                      (act == GLASS_ACT_NONE || (T && ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))) &&
-                      (!addend || ldadd >= n_out),
+    GLASS_REQUIRE(ldd >= H && ldd % 4 == 0 && aligned16(dsrc) && aligned16(WT) && ldo >= n_out && ldo % 4 == 0 &&
+                      aligned16(out) && (act == GLASS_ACT_NONE || (T && ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))) &&
+                      (!addend || (ldadd >= n_out && ldadd % 4 == 0 && aligned16(addend))),
                   "dual_linear_dgrad: operands must be 16-B aligned with ld %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(n_nodes, 64));

@@ -73,56 +73,68 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
     // one loaded-memory latency (~2 us) — with a single stage of prefetch the loop ran 4x slower
     // than the MFMA rate at N = 1 M (profiles/r01: 6.9 ms vs 1.7 ms of matrix time).
     constexpr int kStages = 4;
-    float4 g[kStages][2];
-    float2 x[kStages][2];
-    auto load_stage = [&](int64_t nb, float4 (&gs)[2], float2 (&xs)[2]) {
+    // A stage holds RAW loads only (rows past the slab are clamped to its last row and zeroed at use),
+    // so that no load has to be waited for when it is issued; the mix / ELU' synthesis of G happens
+    // right before the MFMAs.  (Synthesising at load time put an s_waitcnt vmcnt(0) into every stage.)
+    struct Stage {
+        float4 g[2], t[2];
+        float2 x[2];
+        int mk[2];
+        bool live[2];
+    };
+    Stage st[kStages];
+    const bool first = o0 < sy.H;  // SYNTH: this lane's four outputs lie in the f1 half
+    auto load_stage = [&](int64_t nb, Stage& S) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int64_t nn = nb + h + 8 * s;
-            gs[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xs[s] = make_float2(0.f, 0.f);
-            if (nn < r1) {  // rows past the slab load nothing and contribute zeros
-                if (!SYNTH) {
-                    if (o_ok) gs[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
-                    if (i_ok) xs[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
-                } else {
-                    if (o_ok) {
-                        const bool first = o0 < sy.H;
-                        float4 d = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (first ? o0 : o0 - sy.H));
-                        const float cf = ((sy.mask[nn] != 0) == first) ? sy.zr : sy.omz;
-                        d.x *= cf; d.y *= cf; d.z *= cf; d.w *= cf;
-                        if (sy.act == GLASS_ACT_ELU) {
-                            const float4 t = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
-                            d.x *= elu_grad_f(t.x); d.y *= elu_grad_f(t.y); d.z *= elu_grad_f(t.z); d.w *= elu_grad_f(t.w);
-                        }
-                        gs[s] = d;
-                    }
-                    if (i_ok)
-                        xs[s] = (i0 < sy.H || sy.X2 == nullptr)
-                                    ? *reinterpret_cast<const float2*>(X + nn * ldx + i0)
-                                    : *reinterpret_cast<const float2*>(sy.X2 + nn * sy.ldx2 + (i0 - sy.H));
-                }
+            const int64_t want = nb + h + 8 * s;
+            const int64_t nn = want < r1 ? want : r1 - 1;
+            S.live[s] = want < r1;
+            S.g[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            S.x[s] = make_float2(0.f, 0.f);
+            if (!SYNTH) {
+                if (o_ok) S.g[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
+                if (i_ok) S.x[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
+            } else {  // O = 2H and I are multiples of the tile sizes: every lane is in range
+                S.g[s] = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (first ? o0 : o0 - sy.H));
+                if (sy.act == GLASS_ACT_ELU) S.t[s] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
+                S.mk[s] = sy.mask[nn];
+                S.x[s] = (i0 < sy.H || sy.X2 == nullptr)
+                             ? *reinterpret_cast<const float2*>(X + nn * ldx + i0)
+                             : *reinterpret_cast<const float2*>(sy.X2 + nn * sy.ldx2 + (i0 - sy.H));
             }
         }
     };
     const int64_t nb0 = r0 + 2 * w;  // wave-uniform (MFMA needs every lane in the loop)
 #pragma unroll
-    for (int st = 0; st < kStages; ++st) load_stage(nb0 + 16 * st, g[st], x[st]);
+    for (int k = 0; k < kStages; ++k) load_stage(nb0 + 16 * k, st[k]);
     for (int64_t nb = nb0; nb < r1; nb += 16 * kStages) {
 #pragma unroll
-        for (int st = 0; st < kStages; ++st) {
+        for (int k = 0; k < kStages; ++k) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const float gv[4] = {g[st][s].x, g[st][s].y, g[st][s].z, g[st][s].w};
-                const float xv[2] = {x[st][s].x, x[st][s].y};
+                float4 g = st[k].g[s];
+                if (SYNTH) {
+                    const float cf = ((st[k].mk[s] != 0) == first) ? sy.zr : sy.omz;
+                    g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
+                    if (sy.act == GLASS_ACT_ELU) {
+                        const float4 t = st[k].t[s];
+                        g.x *= elu_grad_f(t.x); g.y *= elu_grad_f(t.y); g.z *= elu_grad_f(t.z); g.w *= elu_grad_f(t.w);
+                    }
+                }
+                if (!st[k].live[s]) g = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float gv[4] = {g.x, g.y, g.z, g.w};
+                const float xv[2] = {st[k].x[s].x, st[k].x[s].y};
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
                         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
-                bsum.x += g[st][s].x; bsum.y += g[st][s].y; bsum.z += g[st][s].z; bsum.w += g[st][s].w;
+                bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
             }
-            load_stage(nb + 16 * (st + kStages), g[st], x[st]);  // refill this stage, kStages ahead
+            __builtin_amdgcn_sched_barrier(0);  // keep the refill below from being sunk into later stages
+            load_stage(nb + 16 * (k + kStages), st[k]);  // refill this stage, kStages ahead
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
