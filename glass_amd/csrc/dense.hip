@@ -15,10 +15,9 @@
 // Lane (i = l&15, q = l>>4) holds the contiguous K-chunk [q*KT/4, (q+1)*KT/4) of row i of A and, per
 // 16-column output tile, the same chunk of row (16t+i) of the [out][in] weight — both are plain 16-B
 // loads of consecutive floats; MFMA step s multiplies element s of the four chunks (the matrix core
-// sums over k in any order, so no transposes, shuffles or LDS staging are needed).  Weights come
-// from L1/L2 (32-64 KiB per layer); the next tile's weight chunk is loaded while the current tile's
-// MFMAs issue.  Supported hidden sizes: multiples of 64 up to 256; other sizes use the library GEMM +
-// the stand-alone mix kernels.
+// sums over k in any order, so no transposes or shuffles are needed).  The weight slice of a K-pass is
+// staged once per workgroup in LDS, pre-permuted into consumption order (see WStage).  Supported hidden
+// sizes: 64, 128, 192 (256: weight images exceed the LDS budget -> library GEMM + stand-alone mix).
 #include "common.h"
 
 namespace glass {
@@ -40,31 +39,100 @@ __device__ __forceinline__ void load16(float (&dst)[kKC], const float* p, bool o
 // (the MFMA does not care which 16 weight rows form a tile).
 __device__ __forceinline__ int tile_col(int t, int j) { return 64 * (t >> 2) + 4 * j + (t & 3); }
 
-// acc[t] += A_chunk . W_tile_chunk for every 16-column tile t; `wrow(t)` = pointer to this lane's kKC
-// consecutive weights of tile t.  Tiles go in pairs (two independent accumulators hide the 40-cycle
-// dependent-MFMA latency); the next pair's weight chunks are loaded while the current pair's MFMAs issue.
-template <int NTILES, typename WPtr>
-__device__ __forceinline__ void mfma_pass(f32x4 (&acc)[NTILES], const float (&a)[kKC], WPtr wrow) {
+// ---- weights through LDS --------------------------------------------------------------------------
+// Every wave needs the whole [NT x KT] weight; read straight from L2 that is 1000+ waves pulling the
+// same 32-64 KiB in the same order (hot L2 lines: the first version ran at 18-22 us per launch for
+// 3-4 us of MFMA work).  Instead the workgroup copies the weight slice of one K-pass into LDS once,
+// already permuted into the order the lanes consume it:  image[(t*4 + v)*64 + lane] (float4) holds
+// elements 4v..4v+3 of lane (j,q)'s 16-float chunk of weight row tile_col(t, j)  ->  every wave-level
+// ds_read_b128 is one contiguous KiB (no bank conflicts) and the L2 sees one fetch per workgroup.
+template <int NT>
+struct WStage {
+    static constexpr int NTILES = NT / 16;
+    static constexpr int kVecs = NTILES * 4 * 64;          // float4 per pass image
+    static constexpr int kPerThread = kVecs / kBlock;      // staging float4 per thread
+    float4 r[kPerThread];
+    // global -> registers: slice kc of the [NT][KT] row-major weight
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, int KT, int kc) {
+        const int KQ = KT / 4;
+#pragma unroll
+        for (int n = 0; n < kPerThread; ++n) {
+            const int l = threadIdx.x + kBlock * n;
+            const int lane = l & 63, v = (l >> 6) & 3, t = l >> 8;
+            const int j = lane & 15, q = lane >> 4;
+            r[n] = *reinterpret_cast<const float4*>(W + (int64_t)tile_col(t, j) * KT + q * KQ + kc * kKC + 4 * v);
+        }
+    }
+    // registers -> LDS image (consecutive threads write consecutive float4)
+    __device__ __forceinline__ void commit(float4* __restrict__ image) const {
+#pragma unroll
+        for (int n = 0; n < kPerThread; ++n) image[threadIdx.x + kBlock * n] = r[n];
+    }
+};
+
+// acc[t] += A_chunk . W_tile_chunk for every 16-column tile t, weights from the LDS image of this pass.
+// Tiles go in pairs (two independent accumulators hide the 40-cycle dependent-MFMA latency); the next
+// pair's chunks are read from LDS while the current pair's MFMAs issue.
+template <int NTILES>
+__device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float (&a)[kKC], const float4* image,
+                                              int lane) {
     static_assert(NTILES % 2 == 0, "tiles are processed in pairs");
-    float b[2][2][kKC];
-    load16(b[0][0], wrow(0), true);
-    load16(b[0][1], wrow(1), true);
+    float4 b[2][2][4];
+    auto read_tile = [&](int t, float4 (&dst)[4]) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) dst[v] = image[(t * 4 + v) * 64 + lane];
+    };
+    read_tile(0, b[0][0]);
+    read_tile(1, b[0][1]);
 #pragma unroll
     for (int t = 0; t < NTILES; t += 2) {
         const int cur = (t >> 1) & 1;
         if (t + 2 < NTILES) {
-            load16(b[cur ^ 1][0], wrow(t + 2), true);
-            load16(b[cur ^ 1][1], wrow(t + 3), true);
+            read_tile(t + 2, b[cur ^ 1][0]);
+            read_tile(t + 3, b[cur ^ 1][1]);
         }
-        // hipcc otherwise sinks each weight load to just before its first use (one 16-B load per four
-        // MFMAs, vmcnt(1)): the whole kernel then runs at L2 latency, 18-22 us instead of ~5 (measured).
-        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above ahead of the MFMAs below
 #pragma unroll
-        for (int s = 0; s < kKC; ++s) {
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[cur][0][s], acc[t], 0, 0, 0);
-            acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[cur][1][s], acc[t + 1], 0, 0, 0);
+        for (int v = 0; v < 4; ++v) {
+            const float b0[4] = {b[cur][0][v].x, b[cur][0][v].y, b[cur][0][v].z, b[cur][0][v].w};
+            const float b1[4] = {b[cur][1][v].x, b[cur][1][v].y, b[cur][1][v].z, b[cur][1][v].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * v + e], b0[e], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * v + e], b1[e], acc[t + 1], 0, 0, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Whole product for one wave's 16 rows: passes over K in chunks of 64 (16 per lane), weight slices
+// double-buffered through LDS.  `load_a(kc, a)` fills this lane's A chunk of pass kc.
+template <int NT, int KT, typename LoadA>
+__device__ __forceinline__ void staged_product(f32x4 (&acc)[NT / 16], const float* __restrict__ W, float4* lds,
+                                               int lane, LoadA load_a) {
+    constexpr int NKC = KT / 4 / kKC;
+    constexpr int kVecs = WStage<NT>::kVecs;
+    WStage<NT> ws;
+    ws.fetch(W, KT, 0);
+    float a[kKC];
+    load_a(0, a);
+    ws.commit(lds);
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+        float an[kKC];
+        if (kc + 1 < NKC) {
+            ws.fetch(W, KT, kc + 1);
+            load_a(kc + 1, an);
+        }
+        mfma_pass_lds<NT / 16>(acc, a, lds + (kc & 1) * kVecs, lane);
+        if (kc + 1 < NKC) {
+            ws.commit(lds + ((kc + 1) & 1) * kVecs);
+#pragma unroll
+            for (int s = 0; s < kKC; ++s) a[s] = an[s];
+            __syncthreads();
+        }
     }
 }
 
@@ -90,16 +158,11 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
     } else {
         arow = (q < 2) ? xa + row * lda + q * KQ : xb + row * ldb + (q - 2) * KQ;  // KQ = H/2
     }
+    extern __shared__ float4 lds_w[];
     f32x4 acc[NTILES];
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < KQ / kKC; ++kc) {
-        float a[kKC];
-        load16(a, arow + kc * kKC, row_ok);
-        const float* wbase = W + q * KQ + kc * kKC;
-        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)tile_col(t, i) * KT; });
-    }
+    staged_product<NT, KT>(acc, W, lds_w, lane, [&](int kc, float (&a)[kKC]) { load16(a, arow + kc * kKC, row_ok); });
     // epilogue: acc[4g+k][reg] is row row0 + 4q + reg, column 64g + 4i + k  ->  float4 per (row, group)
     constexpr int NG = H / 64;  // 64-column groups per half
     float4 bv[2 * NG];
@@ -162,12 +225,11 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
     if (row_ok) coef = (mask[row] != 0) == first ? zr : omz;
     const float* drow = dsrc + row * ldd + (q & 1) * KQ;   // o mod H
     const float* trow = T ? T + row * ldt + q * KQ : nullptr;
+    extern __shared__ float4 lds_w[];
     f32x4 acc[NTILES];
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kc = 0; kc < KQ / kKC; ++kc) {
-        float a[kKC];
+    staged_product<NT, KT>(acc, WT, lds_w, lane, [&](int kc, float (&a)[kKC]) {
         load16(a, drow + kc * kKC, row_ok);
         if (act == GLASS_ACT_ELU) {
             float tv[kKC];
@@ -177,9 +239,7 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
         }
 #pragma unroll
         for (int s = 0; s < kKC; ++s) a[s] *= coef;
-        const float* wbase = WT + q * KQ + kc * kKC;
-        mfma_pass<NTILES>(acc, a, [&](int t) { return wbase + (int64_t)tile_col(t, i) * KT; });
-    }
+    });
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = row0 + 4 * q + reg;
@@ -230,9 +290,18 @@ __global__ __launch_bounds__(kBlock) void transpose_batch_kernel(TransposeBatch 
 
 using namespace glass;
 
-static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128 || H == 192 || H == 256; }
+// Dynamic LDS above 64 KiB must be allowed per kernel once.
+template <typename K>
+static void allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
 
-extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
+static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128; }
+
+// Policy: the kernels are correct for H = 64 and 128 (both tested), but measured on MI355X the fused path
+// only beats hipBLASLt + the stand-alone mix kernels at H = 64 (ppi_bp-shape step 0.600 vs 0.689 ms);
+// at H = 128 (em_user-shape) it loses (1.38 vs 1.18 ms), so callers are steered to the library there.
+extern "C" int glass_dual_linear_supported(int64_t H) { return H == 64 ? 1 : 0; }
 
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
@@ -240,7 +309,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
                                          void* stream) {
     GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
     if (!dense_shape_ok(H)) {
-        set_error("dual_linear_fwd: hidden size %lld not supported (64,128,192,256)", (long long)H);
+        set_error("dual_linear_fwd: hidden size %lld not supported (64, 128)", (long long)H);
         return GLASS_E_UNSUPPORTED;
     }
     const bool comb = xb != nullptr;
@@ -251,16 +320,20 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(n_nodes, 64));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
+    // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs >1 pass)
+    const size_t image = (size_t)2 * H * 256;
 #define GLASS_FWD(HH)                                                                                              \
     if (H == HH) {                                                                                                 \
+        allow_lds(dual_fwd_kernel<HH, true>, 2 * image);                                                           \
+        allow_lds(dual_fwd_kernel<HH, false>, 2 * image);                                                          \
         if (comb)                                                                                                  \
-            hipLaunchKernelGGL((dual_fwd_kernel<HH, true>), grid, dim3(kBlock), 0, st, xa, lda, xb, ldb, W, bias, mask, \
-                               zr, omz, act, T, ldt, out, ldo, n_nodes);                                           \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, true>), grid, dim3(kBlock), 2 * image, st, xa, lda, xb, ldb, W, bias, \
+                               mask, zr, omz, act, T, ldt, out, ldo, n_nodes);                                     \
         else                                                                                                       \
-            hipLaunchKernelGGL((dual_fwd_kernel<HH, false>), grid, dim3(kBlock), 0, st, xa, lda, xb, ldb, W, bias, mask, \
-                               zr, omz, act, T, ldt, out, ldo, n_nodes);                                           \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, false>), grid, dim3(kBlock), (HH > 64 ? 2 : 1) * image, st, xa, lda, \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes);                   \
     }
-    GLASS_FWD(64) GLASS_FWD(128) GLASS_FWD(192) GLASS_FWD(256)
+    GLASS_FWD(64) GLASS_FWD(128)
 #undef GLASS_FWD
     return launch_status("glass_dual_linear_fwd_f32");
 }
@@ -282,16 +355,19 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
     const dim3 grid((unsigned)ceil_div(n_nodes, 64));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     const float* Tp = act == GLASS_ACT_ELU ? T : nullptr;
+    const size_t image = (size_t)n_out * 256;  // K = 2H always needs >= 2 passes
 #define GLASS_DG(HH)                                                                                               \
     if (H == HH) {                                                                                                 \
+        allow_lds(dual_dgrad_kernel<HH, HH>, 2 * image);                                                           \
+        allow_lds(dual_dgrad_kernel<HH, 2 * HH>, 2 * image);                                                       \
         if (n_out == H)                                                                                            \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH>), grid, dim3(kBlock), 0, st, dsrc, ldd, Tp, ldt, mask, zr, omz, \
-                               act, WT, addend, ldadd, out, ldo, n_nodes);                                         \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, mask, \
+                               zr, omz, act, WT, addend, ldadd, out, ldo, n_nodes);                                \
         else                                                                                                       \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH>), grid, dim3(kBlock), 0, st, dsrc, ldd, Tp, ldt, mask, zr, \
-                               omz, act, WT, addend, ldadd, out, ldo, n_nodes);                                    \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, \
+                               mask, zr, omz, act, WT, addend, ldadd, out, ldo, n_nodes);                          \
     }
-    GLASS_DG(64) GLASS_DG(128) GLASS_DG(192) GLASS_DG(256)
+    GLASS_DG(64) GLASS_DG(128)
 #undef GLASS_DG
     return launch_status("glass_dual_linear_dgrad_f32");
 }
