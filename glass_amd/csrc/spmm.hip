@@ -197,8 +197,12 @@ using namespace glass;
 
 // Plan policy (host).  Rows with >= kLongThr edges are given to whole workgroups in chunks of
 // kLongChunk edges; the rest are swept by waves holding ~edges_per_wave edges each.
-static constexpr int kLongThr = 256;
-static constexpr int kLongChunk = 2048;
+// Matrices with few, long rows (the transposed one-hot selection matrix of the embedding backward:
+// V ~ 50 rows holding N entries) would keep most of the chip idle under that policy (47 workgroups,
+// 26 us at ppi_bp-shape), so when the whole matrix yields fewer than ~1024 chunks the threshold and
+// the chunk shrink until it does (never below one 64-edge batch per wave).
+static constexpr int kLongThrMax = 256;
+static constexpr int kLongChunkMax = 2048;
 static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
 static constexpr int kTargetWaves = 32768;  // ~4 rounds of 256 CUs x 32 waves
 
@@ -207,6 +211,17 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     const int64_t nnz = rowptr[n_rows];
     GLASS_REQUIRE(rowptr[0] == 0 && nnz >= 0, "plan_build: rowptr[0] must be 0 and nnz < 2^31");
     std::vector<int32_t> sweep, longs, reduces;
+    int kLongThr = kLongThrMax, kLongChunk = kLongChunkMax;
+    while (kLongChunk > 256) {
+        int64_t items = 0;
+        for (int64_t r = 0; r < n_rows; ++r) {
+            const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
+            if (d >= kLongThr) items += ceil_div(d, kLongChunk);
+        }
+        if (items + n_rows >= 1024) break;  // enough independent work items
+        kLongChunk /= 2;
+        if (kLongThr > 64) kLongThr /= 2;
+    }
     int64_t cost_total = 0;
     for (int64_t r = 0; r < n_rows; ++r) {
         const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
