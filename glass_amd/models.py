@@ -129,7 +129,8 @@ class GLASSConv(nn.Module):
             lin.reset_parameters()
         self.gn.reset_parameters()
 
-    def forward(self, x_, edge_index, edge_weight, mask):
+    def forward(self, x_, edge_index, edge_weight, mask, out=None):
+        """`out` (optional, fused path only): a preallocated [N,H] view (a slice of the JK buffer) to write into."""
         if self.adj is None:
             self.adj = buildAdj(edge_index, edge_weight, x_.shape[0], self.aggr)
         if mask.dtype != torch.uint8:
@@ -146,7 +147,7 @@ class GLASSConv(nn.Module):
             a = ops.spmm(self.adj, m)
             g = self.gn(a, p_drop=p, call_id=self.call_base)
             return ops.dual_linear_mix(g, x_, self.comb_fns[1], self.comb_fns[0], mask, self.z_ratio, ACT_NONE,
-                                       stack["comb"])
+                                       stack["comb"], out)
         # both weight sets in one GEMM: T = [f1 | f0]
         T = ops.stacked_linear(x_, self.trans_fns[1], self.trans_fns[0], stack.get("trans"))
         if code is None:
@@ -218,8 +219,19 @@ class EmbZGConv(nn.Module):
         h, mask = ops.embed_label(self.input_emb.weight, x_flat, z, self._selection(x_flat))
         h = self.emb_gn(h, p_drop=p, call_id=1)
         xs = []
+        # JK buffer written in place by the fused layers (no torch.cat) when every layer takes that path
+        widths = [c.trans_fns[0].weight.shape[0] for c in self.convs if isinstance(c, GLASSConv)]
+        jk_buf = None
+        if (self.jk and len(widths) == len(self.convs) and len(set(widths)) == 1 and widths[0] == h.shape[1] and
+                code is not None and all("comb" in getattr(c, "_stack", {}) and len(c._stack["comb"]) == 5
+                                         for c in self.convs) and ops.dual_linear_supported(h.shape[1]) and
+                ops.USE_FUSED_DENSE):
+            jk_buf = torch.empty((n, sum(widths)), dtype=torch.float32, device=h.device)
         for layer, conv in enumerate(self.convs):
-            h = conv(h, edge_index, edge_weight, mask)
+            if jk_buf is not None:
+                h = conv(h, edge_index, edge_weight, mask, out=jk_buf[:, layer * widths[0]:(layer + 1) * widths[0]])
+            else:
+                h = conv(h, edge_index, edge_weight, mask)
             xs.append(h)
             if layer + 1 == len(self.convs):
                 break
@@ -230,7 +242,10 @@ class EmbZGConv(nn.Module):
                 h = self.gns[layer](h)
             h = self.activation(h)
             h = F.dropout(h, p=self.dropout, training=self.training)
-        h = torch.cat(xs, dim=-1) if self.jk else xs[-1]
+        if jk_buf is not None:
+            h = ops.join_cols(jk_buf, xs)
+        else:
+            h = torch.cat(xs, dim=-1) if self.jk else xs[-1]
         if self.gns is not None:
             h = self.gns[-1](h)
         return h

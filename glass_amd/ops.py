@@ -279,6 +279,33 @@ def stacked_linear(x, lin1, lin0, stack=None):
     return StackedLinearFn.apply(x, lin1.weight, lin0.weight, lin1.bias, lin0.bias, stack)
 
 
+class JoinColsFn(torch.autograd.Function):
+    """`buf` already holds the column blocks `parts` (each op wrote its output straight into its slice of
+    the JK buffer); this only tells autograd that buf depends on them — no copy in either direction
+    (replaces torch.cat((xs...), -1) of reference impl/models.py:263)."""
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        off = 0
+        for p in parts:
+            if p.data_ptr() != buf.data_ptr() + 4 * off or p.stride(0) != buf.stride(0) or p.shape[0] != buf.shape[0]:
+                raise GlassHipError("JoinColsFn: parts must be consecutive column slices of buf")
+            off += p.shape[1]
+        ctx.widths = [p.shape[1] for p in parts]
+        return buf.view_as(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for w in ctx.widths:
+            outs.append(g[:, off:off + w])
+            off += w
+        return (None, *outs)
+
+
+def join_cols(buf, parts):
+    return JoinColsFn.apply(buf, *parts)
+
+
 def dual_linear_supported(H):
     return bool(_lib.load().glass_dual_linear_supported(int(H)))
 
