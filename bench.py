@@ -45,9 +45,10 @@ def parse():
 
 
 def loss_fn_for(w):
-    if w.multilabel:
-        return lambda p, t: nn.BCEWithLogitsLoss()(p.flatten(), t.flatten())
-    return nn.CrossEntropyLoss()
+    """The driver's losses (GLASSTest.py:57-58, 69); glass_amd.losses' versions compute the same values and
+    let TrainStep fuse them with the Linear head."""
+    from glass_amd import losses
+    return losses.BCEWithLogits() if w.multilabel else losses.CrossEntropy()
 
 
 def cpu_baseline(w, ei, ew, x, pos, y, steps):
@@ -58,7 +59,7 @@ def cpu_baseline(w, ei, ew, x, pos, y, steps):
                           dropout=w.dropout)
     model.train()
     opt = torch.optim.Adam(model.parameters(), lr=w.lr)
-    loss_fn = loss_fn_for(w)
+    loss_fn = (lambda p, t: nn.BCEWithLogitsLoss()(p.flatten(), t.flatten())) if w.multilabel else nn.CrossEntropyLoss()
     nb = pos.shape[0] // w.batch
 
     def step(i):

@@ -1,0 +1,73 @@
+"""Losses the training step can fuse with the prediction head.
+
+`CrossEntropy()` / `BCEWithLogits()` behave exactly like the losses the reference driver builds
+(GLASSTest.py:57-58, 69) when called as `loss_fn(pred, y)`; in addition `glass_amd.step.TrainStep`
+recognises them and, when the model's head is a bare nn.Linear (GLASSTest.py:159-160), runs
+head + loss + their backward as two kernels (`glass_head_loss_fwd/bwd_f32`) instead of ~12 launches."""
+import torch
+import torch.nn as nn
+
+from . import _lib, ops
+
+
+class CrossEntropy(nn.Module):
+    mode = 0
+
+    def forward(self, pred, y):
+        return nn.functional.cross_entropy(pred, y)
+
+
+class BCEWithLogits(nn.Module):
+    """Binary / multi-label: BCEWithLogitsLoss()(pred.flatten(), y.flatten())."""
+    mode = 1
+
+    def forward(self, pred, y):
+        return nn.functional.binary_cross_entropy_with_logits(pred.flatten(), y.flatten())
+
+
+class HeadLossFn(torch.autograd.Function):
+    """loss = L(pooled @ W^T + b, target) — forward in one launch, backward in one launch."""
+    @staticmethod
+    def forward(ctx, pooled, weight, bias, target, mode, direct):
+        ops._need_gpu(pooled, weight, target)
+        pooled, ldp = ops._rows(pooled)
+        B, C = pooled.shape
+        K = weight.shape[0]
+        w, b = weight.contiguous(), bias.contiguous()
+        tgt = target.contiguous().to(torch.int64 if mode == 0 else torch.float32)
+        logits = torch.empty((B, K), dtype=torch.float32, device=pooled.device)
+        prob = torch.empty(B * K + B, dtype=torch.float32, device=pooled.device)  # probabilities + per-row loss terms
+        loss = torch.empty((), dtype=torch.float32, device=pooled.device)
+        rc = _lib.load().glass_head_loss_fwd_f32(pooled.data_ptr(), ldp, w.data_ptr(), b.data_ptr(), tgt.data_ptr(), mode,
+                                                 B, C, K, logits.data_ptr(), prob.data_ptr(), loss.data_ptr(),
+                                                 ops._stream())
+        _lib.check(rc, "glass_head_loss_fwd_f32")
+        ctx.save_for_backward(pooled, w, prob, tgt)
+        ctx.cfg = (mode, B, C, K)
+        # direct: accumulate dW / db straight into the flat gradient arena (weight.grad / bias.grad views)
+        ctx.direct = (weight, bias) if (direct and weight.grad is not None and bias.grad is not None) else None
+        ctx.mark_non_differentiable(logits)
+        return loss, logits
+
+    @staticmethod
+    def backward(ctx, gl, _glogits):
+        pooled, w, prob, tgt = ctx.saved_tensors
+        mode, B, C, K = ctx.cfg
+        gl = gl.contiguous().reshape(1).to(torch.float32)
+        dpooled = torch.empty((B, C), dtype=torch.float32, device=pooled.device)
+        if ctx.direct is not None:
+            dW, db, acc = ctx.direct[0].grad, ctx.direct[1].grad, 1
+        else:
+            dW, db, acc = torch.empty_like(w), torch.empty(K, dtype=torch.float32, device=w.device), 0
+        rc = _lib.load().glass_head_loss_bwd_f32(pooled.data_ptr(), pooled.stride(0), w.data_ptr(), prob.data_ptr(),
+                                                 tgt.data_ptr(), mode, gl.data_ptr(), B, C, K, dpooled.data_ptr(), C,
+                                                 dW.data_ptr(), db.data_ptr(), acc, ops._stream())
+        _lib.check(rc, "glass_head_loss_bwd_f32")
+        if ctx.direct is not None:
+            return dpooled, None, None, None, None, None
+        return dpooled, dW, db, None, None, None
+
+
+def head_loss(pooled, linear, target, mode, direct=False):
+    """-> (loss, logits) for an nn.Linear head; mode 0 = cross-entropy, 1 = BCE-with-logits."""
+    return HeadLossFn.apply(pooled, linear.weight, linear.bias, target, mode, direct)

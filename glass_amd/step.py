@@ -28,11 +28,26 @@ class TrainStep:
         self._g_fb = self._g_opt = None
 
     # -- the step body, split at the collective ---------------------------------------------------
+    def _fused_head(self):
+        """Head + loss fusable: a bare nn.Linear head and one of glass_amd.losses' marker losses."""
+        import torch.nn as nn
+        from . import losses
+        head = self.model.preds[0]
+        return (isinstance(self.loss_fn, (losses.CrossEntropy, losses.BCEWithLogits)) and type(head) is nn.Linear and
+                head.bias is not None)
+
     def _fwd_bwd(self):
         z = utils.MaxZOZ(self.x, self._pos)
         self.bucket.zero()
-        pred = self.model(self.x, self.ei, self.ew, self._pos, z, id=0)
-        loss = self.loss_fn(pred, self._y)
+        if self._fused_head():
+            from . import losses
+            emb = self.model.NodeEmb(self.x, self.ei, self.ew, z)
+            pooled = self.model.Pool(emb, self._pos, self.model.pools[0])
+            loss, _logits = losses.head_loss(pooled, self.model.preds[0], self._y, self.loss_fn.mode,
+                                             direct=hasattr(self.bucket, "flat_param"))
+        else:
+            pred = self.model(self.x, self.ei, self.ew, self._pos, z, id=0)
+            loss = self.loss_fn(pred, self._y)
         loss.backward()
         self._loss.copy_(loss.detach())
 

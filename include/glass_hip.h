@@ -195,6 +195,19 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
 int glass_transpose_batch_f32(const float* const* src, float* const* dst, const int64_t* rows, const int64_t* cols,
                               int64_t n_jobs, void* stream);
 
+/* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
+ *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened
+ *     logits, GLASSTest.py:57-58, mode 1, target float[B,K]; mean reduction) in one launch, and their
+ *     whole backward in one launch.  fwd writes logits [B,K], prob (float[B*K + B]: softmax / sigmoid
+ *     kept for the backward, then B per-subgraph loss terms) and loss[0] (their mean, summed in order).  bwd: dlogits = grad_loss[0] * (prob - target) / (B or B*K);
+ *     dpooled = dlogits @ W; dW (+)= dlogits^T @ pooled; db (+)= colsum(dlogits); fixed summation order. */
+int glass_head_loss_fwd_f32(const float* pooled, int64_t ldp, const float* W, const float* bias, const void* target,
+                            int mode, int64_t B, int64_t C, int64_t K, float* logits, float* prob, float* loss,
+                            void* stream);
+int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const float* W, const float* prob, const void* target,
+                            int mode, const float* grad_loss, int64_t B, int64_t C, int64_t K, float* dpooled,
+                            int64_t lddp, float* dW, float* db, int accumulate, void* stream);
+
 /* K9  Adam over a flat parameter arena (torch.optim.Adam as used at GLASSTest.py:213; amsgrad
  *     off): one launch for all parameters.  lr and the step counter live in DEVICE memory so a
  *     captured graph follows ReduceLROnPlateau and advances its own bias correction. */

@@ -485,3 +485,35 @@ def test_transpose_batch():
     assert rc == 0
     for m, o in zip(mats, outs):
         assert torch.equal(o, m.t())
+
+
+# ---------------------------------------------------------------------------------- K8 head + loss
+@pytest.mark.parametrize("mode,B,C,K", [(0, 80, 128, 6), (0, 7, 17, 3), (1, 99, 128, 10), (1, 5, 64, 1)])
+def test_head_loss_fused(mode, B, C, K):
+    """Linear head + CrossEntropy / BCE-with-logits fused (2 launches) vs torch in fp64."""
+    import torch.nn as nn
+    from glass_amd import losses
+    gen = torch.Generator().manual_seed(B + K)
+    pooled = torch.randn(B, C, generator=gen)
+    lin = nn.Linear(C, K)
+    y = torch.randint(0, K, (B, ), generator=gen) if mode == 0 else (torch.rand(B, K, generator=gen) < 0.4).float()
+    p64 = pooled.double().requires_grad_(True)
+    l64 = nn.Linear(C, K).double()
+    l64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    z = l64(p64)
+    ref = nn.functional.cross_entropy(z, y) if mode == 0 else nn.functional.binary_cross_entropy_with_logits(
+        z.flatten(), y.double().flatten())
+    (ref * 1.7).backward()
+    ling = nn.Linear(C, K).to(DEV)
+    ling.load_state_dict(lin.state_dict())
+    pg = pooled.to(DEV).requires_grad_(True)
+    loss, logits = losses.head_loss(pg, ling, y.to(DEV), mode)
+    (loss * 1.7).backward()
+    assert abs(loss.item() - ref.item()) < TOL * abs(ref.item())
+    assert rel_inf(logits.cpu(), z.detach()) < TOL
+    assert rel_inf(pg.grad.cpu(), p64.grad) < TOL
+    assert rel_inf(ling.weight.grad.cpu(), l64.weight.grad) < TOL
+    assert rel_inf(ling.bias.grad.cpu(), l64.bias.grad) < TOL
+    # the marker modules are ordinary losses too
+    m = losses.CrossEntropy() if mode == 0 else losses.BCEWithLogits()
+    assert abs(m(logits, y.to(DEV)).item() - ref.item()) < TOL * abs(ref.item())
