@@ -517,3 +517,66 @@ def test_head_loss_fused(mode, B, C, K):
     # the marker modules are ordinary losses too
     m = losses.CrossEntropy() if mode == 0 else losses.BCEWithLogits()
     assert abs(m(logits, y.to(DEV)).item() - ref.item()) < TOL * abs(ref.item())
+
+
+# ---------------------------------------------------------------------------------- degenerate inputs
+def test_spmm_graph_without_edges_and_single_node():
+    from glass_amd.graph import CSRAdj
+    ei = torch.zeros((2, 0), dtype=torch.int64, device=DEV)
+    adj = CSRAdj(ei, torch.zeros(0, device=DEV), 7, "mean")
+    y = adj.fwd.spmm(torch.randn(7, 64, device=DEV))
+    assert y.shape == (7, 64) and float(y.abs().max()) == 0.0
+    assert float(adj.deg.min()) == 1.0  # isolated rows get degree 1 (models.py:93-94)
+    one = CSRAdj(torch.tensor([[0], [0]], device=DEV), torch.tensor([2.0], device=DEV), 1, "gcn")  # one self-loop
+    x = torch.randn(1, 8, device=DEV)
+    assert rel_inf(one.fwd.spmm(x).cpu(), x.cpu()) < 1e-6  # 2 / sqrt(2) / sqrt(2) = 1
+
+
+def test_model_on_degenerate_batches():
+    """B = 1, Smax = 1, an all-padding subgraph row, a graph with isolated nodes only around the batch."""
+    from helpers import build_glass
+    from impl import utils
+    from glass_amd import synth
+    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=5, n_batches=1)
+    ei, ew, x = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x))
+    torch.manual_seed(0)
+    model = build_glass(16, 2, int(x.max()), 3, "gcn", "mean", 0.75).to(DEV).train()
+    for p in (torch.tensor([[5]]), torch.tensor([[5, -1, -1], [-1, -1, -1]]), torch.tensor([[0, 1, 2, 3]])):
+        p = p.to(DEV)
+        out = model(x, ei, ew, p, utils.MaxZOZ(x, p))
+        assert out.shape == (p.shape[0], 3) and bool(torch.isfinite(out).all())
+        out.sum().backward()
+    assert all(bool(torch.isfinite(q.grad).all()) for q in model.parameters())
+
+
+@pytest.mark.parametrize("shape", ["em_user", "powerlaw"])
+def test_spmm_full_size_properties(shape):
+    """BASELINE-size graphs (C4: N=50 000 / nnz=1 M; C5: N=1 M / nnz=20 M power-law with 50 000-edge hubs), too big
+    for the CPU oracle in a test: size-independent properties instead.
+      linearity        A(ax + by) = a Ax + b Ay
+      row sums         A 1 = 1 on non-isolated rows for aggr=mean (every row of A sums to 1)
+      adjointness      <A x, y> = <x, A^T y>: the backward operand really is the transpose of the forward one
+      repeatability    bitwise equal across launches (no float atomics, also through the chunked-row path)"""
+    from glass_amd import synth
+    from glass_amd.graph import CSRAdj
+    w = synth.WORKLOADS[shape]
+    ei, ew = synth.make_graph(w.n_node, w.n_pairs, 0, w.powerlaw)
+    n, H = w.n_node, 32
+    adj = CSRAdj(torch.from_numpy(ei).to(DEV), torch.from_numpy(ew).to(DEV), n, "mean")
+    assert adj.nnz == 2 * w.n_pairs
+    gen = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn(n, H, device=DEV, generator=gen)
+    y = torch.randn(n, H, device=DEV, generator=gen)
+    ax, ay = adj.fwd.spmm(x), adj.fwd.spmm(y)
+    lin = adj.fwd.spmm(0.3 * x - 1.7 * y)
+    assert rel_inf(lin.cpu(), (0.3 * ax - 1.7 * ay).cpu()) < TOL
+    ones = adj.fwd.spmm(torch.ones(n, 4, device=DEV))
+    deg = torch.bincount(torch.from_numpy(ei[0]), minlength=n).to(DEV)
+    assert rel_inf(ones[deg > 0].cpu(), torch.ones_like(ones[deg > 0]).cpu()) < 1e-5
+    assert float(ones[deg == 0].abs().max() if bool((deg == 0).any()) else 0.0) == 0.0
+    lhs = (ax.double() * y.double()).sum().item()
+    rhs = (x.double() * adj.bwd.spmm(y).double()).sum().item()
+    assert abs(lhs - rhs) < 1e-6 * max(abs(lhs), (ax.double().norm() * y.double().norm()).item())
+    assert torch.equal(adj.fwd.spmm(x), ax)
+    if shape == "powerlaw":
+        assert adj.fwd.header[6] > 0 and int(deg.max()) == 50000  # chunked rows present
