@@ -16,6 +16,8 @@
 // fp32 MFMA is an exact k-ordered fmaf chain, so numerics equal a plain fp32 reduction.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace glass {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -243,7 +245,14 @@ struct WgradGeom {
 
 static WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     WgradGeom g;
-    int64_t rows = ceil_div(N, kMaxSlabs);
+    // Slab count: about one workgroup per CU over all (slab, input-chunk, output-chunk) triples, at most 128
+    // slabs (measured on MI355X, us for 128/64 slabs vs 256: N=17 080 O=128 I=128 22 vs 31; N=50 000 O=256 I=128
+    // 52 vs 80 — fewer, longer slabs amortise the pipeline fill and halve the partial traffic).
+    const int64_t tiles = ceil_div(I, kIT) * ceil_div(O, kOT);
+    int64_t max_slabs = kMaxSlabs / tiles;
+    if (max_slabs > 128) max_slabs = 128;
+    if (max_slabs < 32) max_slabs = 32;
+    int64_t rows = ceil_div(N, max_slabs);
     if (rows < 64) rows = 64;
     rows = ceil_div(rows, 8) * 8;  // whole row pairs for each of the 4 waves
     g.rows_per_slab = (int)rows;

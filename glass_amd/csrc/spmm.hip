@@ -11,6 +11,7 @@
 // chunk go through per-chunk partial rows summed in fixed order (no float atomics).
 #include "common.h"
 
+#include <stdlib.h>
 #include <vector>
 
 namespace glass {
@@ -167,11 +168,10 @@ __global__ __launch_bounds__(kBlock) void spmm_reduce_kernel(const float* __rest
     }
 }
 
-template <int VW, int LPR>
-static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, int64_t ldx,
+template <int VW, int LPR, int U>
+static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, int64_t ldx,
                        float* Y, int64_t ldy, int64_t H, const int32_t* hdr, const int32_t* plan, float* ws,
                        hipStream_t st) {
-    constexpr int U = (LPR >= 32) ? 4 : 4;
     const int n_ctiles = (int)ceil_div(H, (int64_t)LPR * VW);
     const int n_waves = hdr[H_NSWEEP];
     if (n_waves > 0) {
@@ -189,6 +189,15 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* v
                            plan + hdr[H_OFF_REDUCE]);
     }
     return launch_status("glass_spmm_csr_f32");
+}
+
+template <int VW, int LPR>
+static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, int64_t ldx,
+                       float* Y, int64_t ldy, int64_t H, const int32_t* hdr, const int32_t* plan, float* ws,
+                       hipStream_t st) {
+    // gathers in flight per lane group: measured us/launch for U = 2 / 4 / 8 on MI355X — ppi_bp-shape
+    // 14.9 / 13.2 / 12.7, hpo_neuro-shape 87.8 / 83.4 / 81.0, power-law H=256 2638 / 2600 / 2597.
+    return launch_spmm_u<VW, LPR, 8>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
 }
 
 }  // namespace glass
