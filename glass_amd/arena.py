@@ -79,37 +79,44 @@ class ParamArena(FlatGradBucket):
             shape = (2 * a.shape[0], ) + tuple(a.shape[1:])
             stacks.setdefault((id(mod), kind), [mod, kind]).append(
                 (self.flat_param[o:o + n2].view(shape), self.flat[o:o + n2].view(shape)))
-        self._transposes = []
+        self._packs = []  # (src weight view, dst image, NT, KT, transposed)
+        from . import _lib
         for (_, kind), (mod, _k, *views) in stacks.items():
             if len(views) == 2:  # weight and bias both stackable
                 (W, dW), (b, db) = views
-                WT = torch.empty((W.shape[1], W.shape[0]), dtype=dtype, device=dev)  # refreshed once per step
-                mod._stack[kind] = (W, b, dW, db, WT)
-                self._transposes.append((W, WT))
+                O, K = W.shape  # [2H, K]
+                if O % 64 == 0 and K % 64 == 0 and _lib.load().glass_dual_linear_supported(O // 2):
+                    # MFMA images of W (forward operand, [NT=2H][KT=K]) and of W^T (data-gradient operand,
+                    # [NT=K][KT=2H]); refreshed by ONE launch per training forward (Adam changes W in between)
+                    Wimg, WTimg = torch.empty_like(W).reshape(-1), torch.empty_like(W).reshape(-1)
+                    self._packs.append((W, Wimg, O, K, 0))
+                    self._packs.append((W, WTimg, K, O, 1))
+                    mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)
+                else:
+                    mod._stack[kind] = (W, b, dW, db)
         import numpy as np
-        k = len(self._transposes)
-        self._tp_args = (np.array([w.data_ptr() for w, _ in self._transposes], dtype=np.uint64),
-                         np.array([t.data_ptr() for _, t in self._transposes], dtype=np.uint64),
-                         np.array([w.shape[0] for w, _ in self._transposes], dtype=np.int64),
-                         np.array([w.shape[1] for w, _ in self._transposes], dtype=np.int64), k)
+        self._pack_args = (np.array([w.data_ptr() for w, *_ in self._packs], dtype=np.uint64),
+                           np.array([p[1].data_ptr() for p in self._packs], dtype=np.uint64),
+                           np.array([p[2] for p in self._packs], dtype=np.int64),
+                           np.array([p[3] for p in self._packs], dtype=np.int64),
+                           np.array([p[4] for p in self._packs], dtype=np.int32), len(self._packs))
         from .models import EmbZGConv
         for mod in model.modules():
             if isinstance(mod, EmbZGConv):
-                mod._glass_arena = self  # EmbZGConv.forward refreshes the transposes once per training forward
+                mod._glass_arena = self  # EmbZGConv.forward refreshes the images once per training forward
         self.refresh_transposes()
 
     def refresh_transposes(self):
-        """W^T of every stacked weight (operand layout of the fused data-gradient kernel): one launch for the
-        whole model, called once per training forward because Adam changes the weights in between."""
-        src, dst, rows, cols, k = self._tp_args
-        if k == 0:
-            return
+        """Re-pack every stacked weight into the operand images of the fused dense kernels (forward: W,
+        data gradient: W^T): one launch for the whole model."""
+        src, dst, nt, kt, tr, k = self._pack_args
         from . import _lib
         for i in range(0, k, 16):
             n = min(16, k - i)
-            rc = _lib.load().glass_transpose_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, rows[i:].ctypes.data,
-                                                       cols[i:].ctypes.data, n, torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, "glass_transpose_batch_f32")
+            rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
+                                                        kt[i:].ctypes.data, tr[i:].ctypes.data, n,
+                                                        torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "glass_dense_pack_batch_f32")
 
     def attached(self):
         base_p, base_g = self.flat_param.untyped_storage().data_ptr(), self.flat.untyped_storage().data_ptr()

@@ -46,22 +46,20 @@ __device__ __forceinline__ int tile_col(int t, int j) { return 64 * (t >> 2) + 4
 // already permuted into the order the lanes consume it:  image[(t*4 + v)*64 + lane] (float4) holds
 // elements 4v..4v+3 of lane (j,q)'s 16-float chunk of weight row tile_col(t, j)  ->  every wave-level
 // ds_read_b128 is one contiguous KiB (no bank conflicts) and the L2 sees one fetch per workgroup.
+// The permutation itself is done once per training step for all weights by pack_batch_kernel.
 template <int NT>
 struct WStage {
     static constexpr int NTILES = NT / 16;
     static constexpr int kVecs = NTILES * 4 * 64;          // float4 per pass image
     static constexpr int kPerThread = kVecs / kBlock;      // staging float4 per thread
     float4 r[kPerThread];
-    // global -> registers: slice kc of the [NT][KT] row-major weight
-    __device__ __forceinline__ void fetch(const float* __restrict__ W, int KT, int kc) {
-        const int KQ = KT / 4;
+    // global -> registers: pass kc of the PACKED weight (glass_dense_pack_batch_f32 wrote it in image
+    // order once per step), so this is a fully coalesced 16-B-per-lane copy.  (Gathering the image from
+    // the row-major weight here cost ~4 us per pass: 64 scattered 16-B reads per wave-instruction.)
+    __device__ __forceinline__ void fetch(const float* __restrict__ Wimg, int /*KT*/, int kc) {
+        const float4* src = reinterpret_cast<const float4*>(Wimg) + (int64_t)kc * kVecs;
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) {
-            const int l = threadIdx.x + kBlock * n;
-            const int lane = l & 63, v = (l >> 6) & 3, t = l >> 8;
-            const int j = lane & 15, q = lane >> 4;
-            r[n] = *reinterpret_cast<const float4*>(W + (int64_t)tile_col(t, j) * KT + q * KQ + kc * kKC + 4 * v);
-        }
+        for (int n = 0; n < kPerThread; ++n) r[n] = src[threadIdx.x + kBlock * n];
     }
     // registers -> LDS image (consecutive threads write consecutive float4)
     __device__ __forceinline__ void commit(float4* __restrict__ image) const {
@@ -193,8 +191,8 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
             for (int k = 0; k < 4; ++k) {
                 float a1 = v1[k], a0 = v0[k];
                 if (act == GLASS_ACT_ELU) {
-                    a1 = elu_f(a1);
-                    a0 = elu_f(a0);
+                    a1 = elu_fast_f(a1);
+                    a0 = elu_fast_f(a0);
                 }
                 o[k] = w1 * a1 + w0 * a0;
             }
@@ -257,32 +255,37 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
     }
 }
 
-// ---- transposes of the stacked weights (one launch for the whole model) --------------------------
-struct TransposeJob {
-    const float* src;  // [rows][cols]
-    float* dst;        // [cols][rows]
-    int rows, cols;
+// ---- packing of the stacked weights into MFMA images (one launch for the whole model, once per step) ------
+// job: logical operand B[NT][KT] (row = output column of the product, col = k).  transposed == 0: B = src
+// ([NT][KT] row-major, the forward weight [2H][K]); transposed == 1: B[n][k] = src[k][n] with src [KT][NT]
+// row-major (the data-gradient operand W^T of a weight stored [2H][n_out]).
+// dst[((kc*NTILES + t)*4 + v)*64 + lane] (float4) = B[tile_col(t, j)][q*KT/4 + kc*16 + 4v .. +3], lane = j + 16q.
+struct PackJob {
+    const float* src;
+    float* dst;
+    int NT, KT, transposed;
 };
-constexpr int kMaxTransposeJobs = 16;
-struct TransposeBatch {
-    TransposeJob job[kMaxTransposeJobs];
-    int n;
+constexpr int kMaxPackJobs = 16;
+struct PackBatch {
+    PackJob job[kMaxPackJobs];
 };
 
-__global__ __launch_bounds__(kBlock) void transpose_batch_kernel(TransposeBatch batch) {
-    __shared__ float tile[32][33];
-    const TransposeJob j = batch.job[blockIdx.z];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-    if (c0 >= j.cols || r0 >= j.rows) return;
-    for (int k = ty; k < 32; k += 8) {
-        const int r = r0 + k, c = c0 + tx;
-        tile[k][tx] = (r < j.rows && c < j.cols) ? j.src[(int64_t)r * j.cols + c] : 0.f;
-    }
-    __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
-        const int c = c0 + k, r = r0 + tx;
-        if (c < j.cols && r < j.rows) j.dst[(int64_t)c * j.rows + r] = tile[tx][k];
+__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch) {
+    const PackJob j = batch.job[blockIdx.y];
+    const int KQ = j.KT / 4, NTILES = j.NT / 16, NKC = KQ / kKC;
+    const int total = NKC * NTILES * 4 * 64;  // float4 elements
+    for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
+        const int lane = l & 63, v = (l >> 6) & 3, t = (l >> 8) % NTILES, kc = (l >> 8) / NTILES;
+        const int jj = lane & 15, q = lane >> 4;
+        const int n = tile_col(t, jj), k = q * KQ + kc * kKC + 4 * v;
+        float4 o;
+        if (!j.transposed) {
+            o = *reinterpret_cast<const float4*>(j.src + (int64_t)n * j.KT + k);
+        } else {
+            o = make_float4(j.src[(int64_t)k * j.NT + n], j.src[(int64_t)(k + 1) * j.NT + n],
+                            j.src[(int64_t)(k + 2) * j.NT + n], j.src[(int64_t)(k + 3) * j.NT + n]);
+        }
+        reinterpret_cast<float4*>(j.dst)[l] = o;
     }
 }
 
@@ -372,21 +375,19 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
     return launch_status("glass_dual_linear_dgrad_f32");
 }
 
-extern "C" int glass_transpose_batch_f32(const float* const* src, float* const* dst, const int64_t* rows,
-                                         const int64_t* cols, int64_t n_jobs, void* stream) {
-    GLASS_REQUIRE(src && dst && rows && cols && n_jobs >= 0 && n_jobs <= kMaxTransposeJobs,
-                  "transpose_batch: bad arguments (at most %d matrices per call)", kMaxTransposeJobs);
+extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,
+                                          const int64_t* KT, const int32_t* transposed, int64_t n_jobs, void* stream) {
+    GLASS_REQUIRE(src && dst && NT && KT && transposed && n_jobs >= 0 && n_jobs <= kMaxPackJobs,
+                  "dense_pack_batch: bad arguments (at most %d matrices per call)", kMaxPackJobs);
     if (n_jobs == 0) return 0;
-    TransposeBatch b;
-    b.n = (int)n_jobs;
-    int64_t mr = 0, mc = 0;
+    PackBatch b;
+    for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0};
     for (int k = 0; k < n_jobs; ++k) {
-        GLASS_REQUIRE(src[k] && dst[k] && rows[k] > 0 && cols[k] > 0, "transpose_batch: bad job %d", k);
-        b.job[k] = TransposeJob{src[k], dst[k], (int)rows[k], (int)cols[k]};
-        mr = rows[k] > mr ? rows[k] : mr;
-        mc = cols[k] > mc ? cols[k] : mc;
+        GLASS_REQUIRE(src[k] && dst[k] && NT[k] > 0 && NT[k] % 64 == 0 && KT[k] > 0 && KT[k] % 64 == 0 && aligned16(src[k]) &&
+                          aligned16(dst[k]),
+                      "dense_pack_batch: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", k);
+        b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k]};
     }
-    hipLaunchKernelGGL(transpose_batch_kernel, dim3((unsigned)ceil_div(mc, 32), (unsigned)ceil_div(mr, 32), (unsigned)n_jobs),
-                       dim3(kBlock), 0, (hipStream_t)stream, b);
-    return launch_status("glass_transpose_batch_f32");
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(32, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream, b);
+    return launch_status("glass_dense_pack_batch_f32");
 }

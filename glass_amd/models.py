@@ -139,7 +139,7 @@ class GLASSConv(nn.Module):
         code = _act_code(self.activation)
         stack = getattr(self, "_stack", {})  # set by arena.ParamArena: stacked weight views
         H = x_.shape[1]
-        if (code is not None and "trans" in stack and "comb" in stack and len(stack["trans"]) == 5 and
+        if (code is not None and "trans" in stack and "comb" in stack and len(stack["trans"]) == 6 and
                 self.trans_fns[0].weight.shape == (H, H) and ops.dual_linear_supported(H) and ops.USE_FUSED_DENSE):
             # fused dense path: Linear pair + ELU + mix in one MFMA kernel each; no cat, no [N,2H] round trips
             m = ops.dual_linear_mix(x_, None, self.trans_fns[1], self.trans_fns[0], mask, self.z_ratio, code,
@@ -223,7 +223,7 @@ class EmbZGConv(nn.Module):
         widths = [c.trans_fns[0].weight.shape[0] for c in self.convs if isinstance(c, GLASSConv)]
         jk_buf = None
         if (self.jk and len(widths) == len(self.convs) and len(set(widths)) == 1 and widths[0] == h.shape[1] and
-                code is not None and all("comb" in getattr(c, "_stack", {}) and len(c._stack["comb"]) == 5
+                code is not None and all("comb" in getattr(c, "_stack", {}) and len(c._stack["comb"]) == 6
                                          for c in self.convs) and ops.dual_linear_supported(h.shape[1]) and
                 ops.USE_FUSED_DENSE):
             jk_buf = torch.empty((n, sum(widths)), dtype=torch.float32, device=h.device)

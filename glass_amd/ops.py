@@ -315,7 +315,8 @@ class DualLinearMixFn(torch.autograd.Function):
     cores (glass_dual_linear_fwd_f32); xb=None for the trans pair (ELU, Z kept for the backward), xb=x_ for
     the comb pair (no activation, no cat, Z never materialised).  Backward: one fused data-gradient kernel
     and the split-K weight-gradient kernel, both synthesising dZ from `dout` on the fly; weight / bias
-    gradients are accumulated straight into the gradient arena (stack = arena views W, b, dW, db, W^T)."""
+    gradients are accumulated straight into the gradient arena (stack = arena views W, b, dW, db + the packed
+    operand images of W and W^T)."""
     @staticmethod
     def forward(ctx, xa, xb, w1, w0, b1, b0, mask, z_ratio, act, stack, out):
         _need_gpu(xa, mask)
@@ -323,12 +324,12 @@ class DualLinearMixFn(torch.autograd.Function):
         n, H = xa.shape
         if xb is not None:
             xb, ldb = _rows(xb)
-        W, b = stack[0], stack[1]
+        Wimg, b = stack[4], stack[1]
         T = torch.empty((n, 2 * H), dtype=torch.float32, device=xa.device) if act != ACT_NONE else None
         if out is None:
             out = torch.empty((n, H), dtype=torch.float32, device=xa.device)
         rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), lda, 0 if xb is None else xb.data_ptr(),
-                                                   0 if xb is None else ldb, W.data_ptr(), b.data_ptr(),
+                                                   0 if xb is None else ldb, Wimg.data_ptr(), b.data_ptr(),
                                                    mask.data_ptr(), float(z_ratio), act, 0 if T is None else T.data_ptr(),
                                                    2 * H, out.data_ptr(), out.stride(0), n, H, _stream())
         _lib.check(rc, "glass_dual_linear_fwd_f32")
@@ -348,7 +349,7 @@ class DualLinearMixFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             din = torch.empty((n, n_out), dtype=torch.float32, device=dout.device)
             rc = lib.glass_dual_linear_dgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act,
-                                                 stack[4].data_ptr(), n_out, 0, 0, din.data_ptr(), n_out, n, H, _stream())
+                                                 stack[5].data_ptr(), n_out, 0, 0, din.data_ptr(), n_out, n, H, _stream())
             _lib.check(rc, "glass_dual_linear_dgrad_f32")
         I = n_out
         ws = _wgrad_workspace(dout.device, n, 2 * H, I)

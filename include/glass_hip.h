@@ -169,31 +169,35 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  * K5  stacked Linear pair fused with the label-conditioned mix, on the fp32 matrix cores
  *     (impl/models.py:158-162 trans_fns + ELU + mix; 167-173 cat + comb_fns + mix).
  *     W = [W1; W0] ([2H, K] row-major, K = H or 2H), bias = [b1 | b0].
+ *     The kernels consume the weight as a PACKED image (fragment order of v_mfma_f32_16x16x4_f32, one
+ *     contiguous KiB per wave-level read), produced by glass_dense_pack_batch_f32 once per step:
+ *     Wimg from W itself (forward), WTimg from W with transposed = 1 (data gradient).
  *   fwd : xb == NULL (trans): T = xa @ W^T + bias is written to T (kept for the backward),
  *                             out = mix(act(T1), act(T0)).
  *         xb != NULL (comb) : the input is the virtual concatenation [xa || xb] (no cat copy),
  *                             out = mix(C1, C0); T may be NULL (C is never materialised).
  *   dgrad: out[N, n_out] = dZ @ W (+ addend), dZ[n,o] = coef(mask[n], o<H) * dsrc[n, o mod H] * act'(T[n,o])
- *          synthesised on the fly; WT = W^T stored [n_out][2H] (glass_transpose_batch_f32, once per step).
+ *          synthesised on the fly; WTimg = packed image of W^T ([n_out] x [2H]).
  *   wgrad: dW[2H, K] (+)= dZ^T @ [X || X2], db (+)= colsum(dZ), same synthesis, split-K MFMA as K5w.
  *   Hidden sizes 64/128/192/256 (glass_dual_linear_supported); otherwise GLASS_E_UNSUPPORTED and the
  *   caller composes the library GEMM with glass_mix_*.
  * ---------------------------------------------------------------------------------------- */
 int glass_dual_linear_supported(int64_t H);
-int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
+int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg,
                               const float* bias, const uint8_t* mask, double z_ratio, int act, float* T, int64_t ldt,
                               float* out, int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
 int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
-                                double z_ratio, int act, const float* WT, int64_t n_out, const float* addend,
+                                double z_ratio, int act, const float* WTimg, int64_t n_out, const float* addend,
                                 int64_t ldadd, float* out, int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
 int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
                                 int64_t N, int64_t H, float* dW, int64_t lddw, float* db, int accumulate, void* ws,
                                 void* stream);
-/*     dst[k] ([cols,rows]) = transpose of src[k] ([rows,cols]) for up to 16 matrices in one launch;
- *     the pointer arrays are HOST arrays of device pointers. */
-int glass_transpose_batch_f32(const float* const* src, float* const* dst, const int64_t* rows, const int64_t* cols,
-                              int64_t n_jobs, void* stream);
+/*     Pack up to 16 weight operands B[NT][KT] (NT, KT multiples of 64) into MFMA image order in one launch.
+ *     transposed[k] == 0: B = src[k] ([NT][KT] row-major); 1: B[n][k] = src[k][k][n] (src is [KT][NT]).
+ *     dst[k] holds NT*KT floats.  The pointer / size arrays are HOST arrays. */
+int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
+                               const int32_t* transposed, int64_t n_jobs, void* stream);
 
 /* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
  *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened

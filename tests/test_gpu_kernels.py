@@ -454,11 +454,11 @@ def test_dual_linear_mix_fused(H, N, comb):
     # HIP
     Wg, bg = W.to(DEV), b.to(DEV)
     dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
-    WT = Wg.t().contiguous()
+    Wimg, WTimg = _pack(Wg, False), _pack(Wg, True)
     lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)  # carriers for the autograd edges only
     xa = wide_a.to(DEV)[:, :H].requires_grad_(True)
     xb = wide_b.to(DEV)[:, H:].requires_grad_(True) if comb else None
-    out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, WT))
+    out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, Wimg, WTimg))
     out.backward(gout.to(DEV))
     assert rel_inf(out.detach().cpu(), ref.detach()) < TOL
     assert rel_inf(xa.grad.cpu(), xa64.grad) < TOL
@@ -467,24 +467,38 @@ def test_dual_linear_mix_fused(H, N, comb):
     assert rel_inf(dW.cpu(), W64.grad) < TOL
     assert rel_inf(db.cpu(), b64.grad) < TOL
     out2 = ops.dual_linear_mix(xa.detach(), None if xb is None else xb.detach(), lin1, lin0,
-                               mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, WT))
+                               mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, Wimg, WTimg))
     assert torch.equal(out2, out.detach())
 
 
-def test_transpose_batch():
-    import ctypes
+def _pack(W, transposed):
+    """glass_dense_pack_batch_f32 on one matrix: operand image of W ([NT][KT]) or of W^T."""
     from glass_amd import _lib
-    mats = [torch.randn(r, c, device=DEV) for r, c in ((128, 64), (128, 128), (40, 7), (1, 33))]
-    outs = [torch.empty(m.shape[1], m.shape[0], device=DEV) for m in mats]
-    src = np.array([m.data_ptr() for m in mats], dtype=np.uint64)
-    dst = np.array([m.data_ptr() for m in outs], dtype=np.uint64)
-    rows = np.array([m.shape[0] for m in mats], dtype=np.int64)
-    cols = np.array([m.shape[1] for m in mats], dtype=np.int64)
-    rc = _lib.load().glass_transpose_batch_f32(src.ctypes.data, dst.ctypes.data, rows.ctypes.data, cols.ctypes.data, 4,
-                                               torch.cuda.current_stream().cuda_stream)
+    img = torch.empty(W.numel(), device=DEV)
+    nt, kt = (W.shape[1], W.shape[0]) if transposed else W.shape
+    src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
+    nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
+    trs = np.array([int(transposed)], dtype=np.int32)
+    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+                                                trs.ctypes.data, 1, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
-    for m, o in zip(mats, outs):
-        assert torch.equal(o, m.t())
+    return img
+
+
+def test_dense_pack_is_a_permutation():
+    """The packed image holds exactly the elements of the operand, in the documented fragment order."""
+    W = torch.arange(128 * 64, dtype=torch.float32, device=DEV).reshape(128, 64)
+    for transposed in (False, True):
+        img = _pack(W, transposed).cpu()
+        assert sorted(img.tolist()) == W.reshape(-1).cpu().tolist()
+        B = (W.t() if transposed else W).cpu()  # logical operand [NT][KT]
+        NT, KT = B.shape
+        KQ = KT // 4
+        for (kc, t, v, lane) in ((0, 0, 0, 0), (0, min(5, NT // 16 - 1), 3, 37), (KQ // 16 - 1, NT // 16 - 1, 2, 63)):
+            j, q = lane & 15, lane >> 4
+            n, k = 64 * (t >> 2) + 4 * j + (t & 3), q * KQ + kc * 16 + 4 * v
+            off = (((kc * (NT // 16) + t) * 4 + v) * 64 + lane) * 4
+            assert img[off:off + 4].tolist() == B[n, k:k + 4].tolist()
 
 
 # ---------------------------------------------------------------------------------- K8 head + loss

@@ -54,9 +54,33 @@ def bench_gn():
         print(f"  N={N:8d} C={C:4d}  fwd {t_f:9.1f} us ({3*by/t_f/1e6:5.2f} TB/s)   bwd {t_b:9.1f} us ({5*by/t_b/1e6:5.2f} TB/s)")
 
 
+def bench_dual():
+    import torch.nn as nn
+    print("dual linear (fused Linear pair + mix): fwd / dgrad")
+    for N, H in [(17080, 64)]:
+        for comb in (False, True):
+            K = 2 * H if comb else H
+            W = torch.randn(2 * H, K, device=DEV) / K**0.5
+            b = torch.randn(2 * H, device=DEV)
+            dW, db, WT = torch.zeros_like(W), torch.zeros_like(b), W.t().contiguous()
+            lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)
+            xa = torch.randn(N, H, device=DEV, requires_grad=True)
+            xb = torch.randn(N, H, device=DEV, requires_grad=True) if comb else None
+            mask = (torch.rand(N, device=DEV) < 0.05).to(torch.uint8)
+            act = 0 if comb else 1
+            stack = (W, b, dW, db, WT)
+            t_f = timeit(lambda: ops.dual_linear_mix(xa.detach(), None if xb is None else xb.detach(), lin1, lin0, mask, 0.9, act, stack))
+            out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask, 0.9, act, stack)
+            g = torch.randn_like(out)
+            t_b = timeit(lambda: torch.autograd.grad(out, xa, g, retain_graph=True))
+            print(f"  N={N} H={H} comb={comb}: fwd {t_f:.1f} us, bwd (dgrad+wgrad) {t_b:.1f} us")
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what in ("wgrad", "all"):
         bench_wgrad()
     if what in ("gn", "all"):
         bench_gn()
+    if what in ("dual", "all"):
+        bench_dual()
