@@ -20,6 +20,8 @@
 // sizes: 64, 128, 192 (256: weight images exceed the LDS budget -> library GEMM + stand-alone mix).
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace glass {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -304,7 +306,10 @@ static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128; }
 // Policy: the kernels are correct for H = 64 and 128 (both tested), but measured on MI355X the fused path
 // only beats hipBLASLt + the stand-alone mix kernels at H = 64 (ppi_bp-shape step 0.600 vs 0.689 ms);
 // at H = 128 (em_user-shape) it loses (1.38 vs 1.18 ms), so callers are steered to the library there.
-extern "C" int glass_dual_linear_supported(int64_t H) { return H == 64 ? 1 : 0; }
+extern "C" int glass_dual_linear_supported(int64_t H) {
+    static const bool h128 = getenv("GLASS_DENSE_H128") && atoi(getenv("GLASS_DENSE_H128")) == 1;  // A/B switch
+    return (H == 64 || (h128 && H == 128)) ? 1 : 0;
+}
 
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,

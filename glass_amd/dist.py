@@ -73,8 +73,11 @@ class FlatGradBucket:
     def all_reduce_mean(self):
         if not is_distributed():
             return
-        td.all_reduce(self.flat, op=td.ReduceOp.SUM)
-        self.flat.div_(td.get_world_size())
+        if td.get_backend() == "nccl":
+            td.all_reduce(self.flat, op=td.ReduceOp.AVG)  # RCCL averages in the collective: no extra kernel
+        else:
+            td.all_reduce(self.flat, op=td.ReduceOp.SUM)
+            self.flat.div_(td.get_world_size())
 
 
 def bucket_for(model):

@@ -26,6 +26,7 @@ class TrainStep:
         self._pos = self._y = None
         self._loss = torch.zeros((), device=x.device)
         self._g_fb = self._g_opt = None
+        self._split = False
 
     # -- the step body, split at the collective ---------------------------------------------------
     def _fused_head(self):
@@ -73,11 +74,12 @@ class TrainStep:
                 self._fwd_bwd()
                 self.opt.step()
         else:
+            # the collective stays outside the graph; the optimizer is two launches, cheaper eager than a
+            # second graph replay
             with torch.cuda.graph(self._g_fb):
                 self._fwd_bwd()
-            self._g_opt = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g_opt, pool=self._g_fb.pool()):
-                self.opt.step()
+            self._g_opt = None
+        self._split = dist_on
         self.graphed = True
 
     def __call__(self, pos, y):
@@ -95,9 +97,9 @@ class TrainStep:
             self.opt.sync_lr()  # a scheduler may have changed the learning rate since the capture
         if self.graphed:
             self._g_fb.replay()
-            if self._g_opt is not None:
+            if self._split:
                 self.bucket.all_reduce_mean()
-                self._g_opt.replay()
+                self.opt.step()
         else:
             self._fwd_bwd()
             self.bucket.all_reduce_mean()
