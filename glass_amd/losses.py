@@ -47,6 +47,7 @@ class HeadLossFn(torch.autograd.Function):
         # direct: accumulate dW / db straight into the flat gradient arena (weight.grad / bias.grad views)
         ctx.direct = (weight, bias) if (direct and weight.grad is not None and bias.grad is not None) else None
         ctx.mark_non_differentiable(logits)
+        ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the logits output
         return loss, logits
 
     @staticmethod

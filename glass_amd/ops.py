@@ -107,6 +107,7 @@ class EmbedLabelFn(torch.autograd.Function):
         _lib.check(rc, "glass_embed_label_f32")
         ctx.selection = selection
         ctx.mark_non_differentiable(mask)
+        ctx.set_materialize_grads(False)  # no zero-filled gradient tensor for the mask output
         return out, mask
 
     @staticmethod

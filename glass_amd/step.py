@@ -25,6 +25,7 @@ class TrainStep:
         self.graphed = False
         self._pos = self._y = None
         self._loss = torch.zeros((), device=x.device)
+        self._one = torch.ones((), device=x.device)
         self._g_fb = self._g_opt = None
         self._split = False
 
@@ -49,8 +50,10 @@ class TrainStep:
         else:
             pred = self.model(self.x, self.ei, self.ew, self._pos, z, id=0)
             loss = self.loss_fn(pred, self._y)
-        loss.backward()
-        self._loss.copy_(loss.detach())
+        loss.backward(gradient=self._one)  # persistent seed gradient: no ones_like fill per step
+        # Under capture `loss` lives at a fixed address of the graph's private pool, so keeping the
+        # reference replaces a copy kernel; in eager mode it is simply the latest loss tensor.
+        self._loss = loss.detach()
 
     def _warmup(self):
         """Real training steps on the first batch, on a side stream: builds the CSR / plans /
