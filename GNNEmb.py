@@ -1,0 +1,141 @@
+"""Self-supervised pre-training of node embeddings by link prediction on the MI355X path — the workload of
+the reference's GNNEmb.py (EdgeGNN = EmbGConv(MyGCNConv) + 2-layer MLP, BCE on edge / non-edge pairs,
+`work()` 108-163, search space `obj()` 169-192), with the same flags and log lines.
+
+Optuna is not available here, so the hyper-parameter search is a seeded random search over the same space
+(conv_layer 2..5, dropout 0..0.5 step 0.1, aggr sum/mean/gcn; hidden 64, lr 1e-3, batch 131072, jk off); the
+best trial's embeddings go to `<path><name>_64.pt`, the file `GLASSTest.py --use_nodeid` loads.
+
+    python GNNEmb.py --use_nodeid --device 0 --dataset density --name density --optruns 3
+"""
+import argparse
+import functools
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import BCEWithLogitsLoss
+from torch.optim import Adam, lr_scheduler
+
+import datasets
+from impl import SubGDataset, config, metrics, models, train
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="")
+    p.add_argument("--dataset", type=str, default="ppi_bp")
+    p.add_argument("--use_deg", action="store_true")
+    p.add_argument("--use_one", action="store_true")
+    p.add_argument("--use_nodeid", action="store_true")
+    p.add_argument("--repeat", type=int, default=1)
+    p.add_argument("--test", action="store_true")
+    p.add_argument("--abl", action="store_true")
+    p.add_argument("--optruns", type=int, default=100)
+    p.add_argument("--path", type=str, default="Emb/")
+    p.add_argument("--name", type=str, default="opt")
+    p.add_argument("--device", type=int, default=0)
+    p.add_argument("--use_seed", action="store_true")
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--max_epoch", type=int, default=100, help="(extension) cap on epochs per trial")
+    return p.parse_args(argv)
+
+
+class Pretrain:
+    def __init__(self, args):
+        self.args = args
+        g = datasets.load_dataset(args.dataset)
+        if args.use_deg:
+            g.setDegreeFeature()
+        elif args.use_one:
+            g.setOneFeature()
+        elif args.use_nodeid:
+            g.setNodeIdFeature()
+        else:
+            raise NotImplementedError
+        self.max_deg = torch.max(g.x)
+        g.to(config.device)
+        x, ei, ea, pos, y = g.get_LPdataset()
+        idx = torch.randperm(pos.shape[0], device=pos.device)
+        cut = int(0.95 * idx.shape[0])
+        self.trn = SubGDataset.GDataset(x, ei, ea, pos[idx[:cut]], y[idx[:cut]])
+        self.val = SubGDataset.GDataset(x, ei, ea, pos[idx[cut:]], y[idx[cut:]])
+
+    def build_model(self, hidden_dim, conv_layer, dropout, jk, aggr):
+        conv = models.EmbGConv(hidden_dim, hidden_dim, hidden_dim, conv_layer, max_deg=self.max_deg,
+                               activation=nn.ReLU(inplace=True), jk=jk, dropout=dropout,
+                               conv=functools.partial(models.MyGCNConv, aggr=aggr), gn=True)
+        head = models.MLP(hidden_dim * conv_layer if jk else hidden_dim, hidden_dim, 1, 2, dropout=dropout,
+                          activation=nn.ReLU(inplace=True))
+        return models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()])).to(config.device)
+
+    def work(self, hidden_dim, conv_layer, dropout, jk, lr, batch_size, aggr):
+        a = self.args
+        trn_loader = SubGDataset.GDataloader(self.trn, batch_size)
+        val_loader = SubGDataset.GDataloader(self.val, self.val.y.shape[0], shuffle=False)
+        loss_fn = lambda p, t: BCEWithLogitsLoss()(p.flatten(), t.flatten())  # noqa: E731
+        outs, emb = [], None
+        for _ in range(a.repeat):
+            gnn = self.build_model(hidden_dim, conv_layer, dropout, jk, aggr)
+            with torch.no_grad():
+                emb = gnn.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr).detach().cpu()
+            optimizer = Adam(gnn.parameters(), lr=lr)
+            scd = lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.7, min_lr=5e-5, patience=50)
+            best_score, early_stop = 0.0, 0
+            for i in range(a.max_epoch):
+                gnn.train()
+                losss = []
+                for ib, batch in enumerate(trn_loader):
+                    optimizer.zero_grad()
+                    node_emb = gnn.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr)
+                    loss = loss_fn(gnn.preds[0](gnn.Pool(node_emb, batch[-2], None)), batch[-1])
+                    loss.backward()
+                    scd.step(loss)
+                    losss.append(loss.item())
+                    optimizer.step()
+                    if ib >= 9:
+                        break
+                if i % 5 == 0:
+                    score, _ = train.test(gnn, val_loader, metrics.binaryf1, loss_fn)
+                    print(f"iter {i} loss {np.average(losss)} score {score}", flush=True)
+                    early_stop += 1
+                    if score > best_score:
+                        with torch.no_grad():
+                            emb = gnn.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr).detach().cpu()
+                        best_score, early_stop = score, 0
+                    if early_stop >= 3:
+                        break
+                else:
+                    print(f"iter {i} loss {np.average(losss)}", flush=True)
+            outs.append(best_score)
+        return np.average(outs) - np.std(outs), emb
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    config.set_device(args.device)
+    if config.device.type != "cuda":
+        raise SystemExit("this driver runs the MI355X HIP path only")
+    if args.use_seed:
+        random.seed(args.seed)
+        np.random.seed(args.seed)
+        torch.manual_seed(args.seed)
+    run = Pretrain(args)
+    print(args)
+    rng = random.Random(args.seed)
+    best_score, best_params = 0.0, None
+    for trial in range(args.optruns):
+        params = dict(conv_layer=rng.randint(2, 5), dropout=rng.choice([0.0, 0.1, 0.2, 0.3, 0.4, 0.5]),
+                      aggr=rng.choice(["sum", "mean", "gcn"]))
+        score, emb = run.work(64, params["conv_layer"], params["dropout"], False, 1e-3, 131072, params["aggr"])
+        print(f"trial {trial} params {params} score {score}", flush=True)
+        if score > best_score:
+            torch.save(emb, f"{args.path}{args.name}_64.pt")
+            best_score, best_params = score, params
+    print("best params ", best_params)
+    print("best valf1 ", best_score)
+    return best_score, best_params
+
+
+if __name__ == "__main__":
+    main()

@@ -71,10 +71,46 @@ class BaseGraph:
         both = torch.cat((ei, ei.flip(0)), dim=1)
         self.edge_index, self.edge_attr = _coalesce_add(both, torch.cat((ea, ea)), n)
 
+    def get_LPdataset(self, use_loop=False):
+        """Link-prediction dataset for SSL pre-training (reference datasets.py:73-91): every edge is a positive
+        pair, an equal number of uniformly sampled non-edges are negatives; with use_loop one extra sample per node
+        asks whether it has a self-loop.  -> (x, edge_index, edge_attr, pos [M,2], y [M])."""
+        n = self.x.shape[0]
+        ei = self.edge_index
+        neg = negative_sampling(ei, n)
+        pos = torch.cat((ei, neg), dim=1).t()
+        y = torch.cat((torch.ones(ei.shape[1]), torch.zeros(neg.shape[1]))).to(ei.device)
+        if use_loop:
+            loops = ei[0][ei[0] == ei[1]]
+            all_loops = torch.arange(n, device=ei.device).reshape(-1, 1)[:, [0, 0]]
+            y_loop = torch.zeros(n, device=y.device)
+            y_loop[loops] = 1
+            pos = torch.cat((pos, all_loops), dim=0)
+            y = torch.cat((y, y_loop), dim=0)
+        return self.x, ei, self.edge_attr, pos, y
+
     def to(self, device):
         for name in ("x", "edge_index", "edge_attr", "pos", "y", "mask"):
             setattr(self, name, getattr(self, name).to(device))
         return self
+
+
+def negative_sampling(edge_index, num_nodes, num_neg_samples=None):
+    """Uniformly random node pairs that are NOT edges (PyG `negative_sampling`, sparse method): about as many
+    as there are edges; may return slightly fewer on very dense graphs."""
+    want = edge_index.shape[1] if num_neg_samples is None else num_neg_samples
+    dev = edge_index.device
+    existing = torch.unique(edge_index[0] * num_nodes + edge_index[1])
+    out = torch.empty(0, dtype=torch.int64, device=dev)
+    for _ in range(4):
+        cand = torch.randint(0, num_nodes * num_nodes, (int(1.2 * (want - out.shape[0])) + 16, ), device=dev)
+        hit = torch.searchsorted(existing, cand).clamp_(max=existing.shape[0] - 1)
+        cand = cand[existing[hit] != cand]
+        out = torch.unique(torch.cat((out, cand)))
+        if out.shape[0] >= want:
+            break
+    out = out[torch.randperm(out.shape[0], device=dev)[:want]]
+    return torch.stack((torch.div(out, num_nodes, rounding_mode="floor"), out % num_nodes))
 
 
 def _split_mask(cnt):

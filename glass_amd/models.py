@@ -319,3 +319,97 @@ class GLASS(nn.Module):
         emb = self.NodeEmb(x, edge_index, edge_weight, z)
         emb = self.Pool(emb, subG_node, self.pools[id])
         return self.preds[id](emb)
+
+
+# ---------------------------------------------------------------------------------------------
+# SSL pre-training models (link prediction) — reference impl/models.py:361-509.  Same kernels:
+# K1 for the aggregation, K6 GraphNorm, K3 embedding gather (+ K1 backward), K7 for the pair readout.
+# ---------------------------------------------------------------------------------------------
+class MyGCNConv(nn.Module):
+    """Unlabeled message-passing layer: comb_fn([GraphNorm(adj @ act(trans_fn(x_))) || x_])."""
+    def __init__(self, in_channels: int, out_channels: int, activation=nn.ReLU(inplace=True), aggr="mean"):
+        super().__init__()
+        self.trans_fn = nn.Linear(in_channels, out_channels)
+        self.comb_fn = nn.Linear(in_channels + out_channels, out_channels)
+        self.adj = None
+        self.activation = activation
+        self.aggr = aggr
+        self.gn = GraphNorm(out_channels)
+
+    def reset_parameters(self):
+        self.trans_fn.reset_parameters()
+        self.comb_fn.reset_parameters()
+        self.gn.reset_parameters()
+
+    def forward(self, x_, edge_index, edge_weight):
+        if self.adj is None:
+            self.adj = buildAdj(edge_index, edge_weight, x_.shape[0], self.aggr)
+        x = self.activation(self.trans_fn(x_))
+        x = self.gn(ops.spmm(self.adj, x))
+        return self.comb_fn(torch.cat((x, x_), dim=-1))
+
+
+class EmbGConv(nn.Module):
+    """Embedding + `num_layers` unlabeled conv layers (GraphNorm / activation / dropout between them)."""
+    def __init__(self, input_channels: int, hidden_channels: int, output_channels: int, num_layers: int, max_deg: int,
+                 dropout=0, activation=nn.ReLU(inplace=True), conv=MyGCNConv, gn=True, jk=False, **kwargs):
+        super().__init__()
+        self.input_emb = nn.Embedding(int(max_deg) + 1, hidden_channels)
+        self.jk = jk
+        dims = [input_channels] + [hidden_channels] * (num_layers - 1) + [output_channels]
+        self.convs = nn.ModuleList([conv(in_channels=dims[i], out_channels=dims[i + 1], **kwargs)
+                                    for i in range(num_layers)])
+        self.activation = activation
+        self.dropout = dropout
+        self.gns = nn.ModuleList([GraphNorm(hidden_channels) for _ in range(num_layers - 1)]) if gn else None
+        self._sel = None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for conv in self.convs:
+            conv.reset_parameters()
+        if self.gns is not None:
+            for gn in self.gns:
+                gn.reset_parameters()
+
+    _selection = EmbZGConv._selection
+
+    def forward(self, x, edge_index, edge_weight, z=None):
+        x_flat = x.reshape(-1)
+        if x_flat.dtype != torch.int64:
+            x_flat = x_flat.to(torch.int64)
+        h, _mask = ops.embed_label(self.input_emb.weight, x_flat, None, self._selection(x_flat))
+        h = F.dropout(h, p=self.dropout, training=self.training)
+        # The reference appends the GraphNorm output and then applies the activation to that very tensor; with
+        # the driver's nn.ReLU(inplace=True) (GNNEmb.py:90) the appended tensor is therefore the ACTIVATED one.
+        inplace = bool(getattr(self.activation, "inplace", False))
+        xs = []
+        for layer, conv in enumerate(self.convs[:-1]):
+            h = conv(h, edge_index, edge_weight)
+            if self.gns is not None:
+                h = self.gns[layer](h)
+            pre = h
+            h = self.activation(h)
+            xs.append(h if inplace else pre)
+            h = F.dropout(h, p=self.dropout, training=self.training)
+        xs.append(self.convs[-1](h, edge_index, edge_weight))
+        return torch.cat(xs, dim=-1) if self.jk else xs[-1]
+
+
+class EdgeGNN(nn.Module):
+    """Link-prediction wrapper: node embeddings -> mean over each node pair -> preds[id]."""
+    def __init__(self, conv, preds: nn.ModuleList, pools: nn.ModuleList):
+        super().__init__()
+        self.conv = conv
+        self.preds = preds
+        self.pools = pools
+
+    NodeEmb = GLASS.NodeEmb
+
+    def Pool(self, emb, subG_node, pool):
+        return ops.segment_pool(emb, subG_node, "mean")  # emb[subG_node].mean(dim=1); pairs carry no padding
+
+    def forward(self, x, edge_index, edge_weight, subG_node, z=None, id=0):
+        emb = self.NodeEmb(x, edge_index, edge_weight, z)
+        emb = self.Pool(emb, subG_node, self.pools[id])
+        return self.preds[id](emb)

@@ -224,3 +224,83 @@ def train_step(model, optimizer, loss_fn, x, edge_index, edge_weight, pos, y):
     val = loss.detach().item()
     optimizer.step()
     return val
+
+
+# ----------------------------------------------------------------------------------------
+# SSL pre-training path (link prediction)              (reference impl/models.py:361-509)
+# ----------------------------------------------------------------------------------------
+class OracleGCNConv(nn.Module):
+    """`MyGCNConv` (models.py:361-397): one weight set, no labels:
+    comb_fn([GraphNorm(adj @ act(trans_fn(x_))) || x_])."""
+    def __init__(self, cin, cout, aggr):
+        super().__init__()
+        self.trans_fn = nn.Linear(cin, cout)
+        self.comb_fn = nn.Linear(cin + cout, cout)
+        self.gn = GraphNorm(cout)
+        self.aggr = aggr
+        self.adj = None
+
+    def forward(self, x_in, edge_index, edge_weight, act):
+        if self.adj is None:
+            self.adj = build_adj(edge_index, edge_weight.to(x_in.dtype), x_in.shape[0], self.aggr)
+        h = self.gn(self.adj @ act(self.trans_fn(x_in)))
+        return self.comb_fn(torch.cat((h, x_in), dim=-1))
+
+
+class OracleEmbGConv(nn.Module):
+    """`EmbGConv` (models.py:400-473): embedding (+dropout), then per non-last layer conv -> GraphNorm -> save ->
+    act -> dropout; the last conv output is saved raw; JK concatenates the saved tensors.
+    Quirk kept on purpose: the driver's activation is nn.ReLU(inplace=True) (GNNEmb.py:90) and the reference
+    applies it to the very tensor it has just appended (models.py:461-463), so the tensors JK sees are the
+    ACTIVATED ones.  (GNNEmb.py always runs jk=False, where only the raw last output matters.)"""
+    def __init__(self, cin, hidden, out, n_layers, max_deg, dropout, aggr, jk=False):
+        super().__init__()
+        self.input_emb = nn.Embedding(int(max_deg) + 1, hidden)
+        dims = [cin] + [hidden] * (n_layers - 1) + [out]
+        self.convs = nn.ModuleList([OracleGCNConv(dims[i], dims[i + 1], aggr) for i in range(n_layers)])
+        self.gns = nn.ModuleList([GraphNorm(hidden) for _ in range(n_layers - 1)])
+        self.jk, self.dropout = jk, dropout
+
+    def forward(self, x, edge_index, edge_weight, z=None):
+        act = F.relu  # GNNEmb.py:90 nn.ReLU(inplace=True)
+        h = F.dropout(self.input_emb(x.reshape(-1)), p=self.dropout, training=self.training)
+        saved = []
+        for l, conv in enumerate(self.convs[:-1]):
+            h = act(self.gns[l](conv(h, edge_index, edge_weight, act)))  # in-place ReLU aliases the saved tensor
+            saved.append(h)
+            h = F.dropout(h, p=self.dropout, training=self.training)
+        saved.append(self.convs[-1](h, edge_index, edge_weight, act))
+        return torch.cat(saved, dim=-1) if self.jk else saved[-1]
+
+
+class OracleEdgeGNN(nn.Module):
+    """`EdgeGNN` (models.py:476-509) with the 2-layer MLP head of GNNEmb.py:94-99 (Linear, [dropout], ReLU,
+    Linear); Pool = mean over the node pair (models.py:501-504)."""
+    def __init__(self, hidden, n_layers, max_deg, aggr="mean", dropout=0.0, jk=False):
+        super().__init__()
+        self.conv = OracleEmbGConv(hidden, hidden, hidden, n_layers, max_deg, dropout, aggr, jk)
+        width = hidden * n_layers if jk else hidden
+
+        class _Seq(nn.Module):  # key layout preds.0.seq.modlist.{i} of the reference's MLP/Seq
+            def __init__(self, mods):
+                super().__init__()
+                self.modlist = nn.ModuleList(mods)
+
+        class _MLP(nn.Module):
+            def __init__(self):
+                super().__init__()
+                mods = [nn.Linear(width, hidden)] + ([nn.Dropout(dropout)] if dropout > 0 else []) + \
+                       [nn.ReLU(), nn.Linear(hidden, 1)]
+                self.seq = _Seq(mods)
+
+            def forward(self, x):
+                for m in self.seq.modlist:
+                    x = m(x)
+                return x
+
+        self.preds = nn.ModuleList([_MLP()])
+
+    def forward(self, x, edge_index, edge_weight, pairs, z=None, id=0):
+        assert x.shape[1] == 1
+        emb = self.conv(x[:, 0, :].reshape(x.shape[0], -1), edge_index, edge_weight, z)
+        return self.preds[id](emb[pairs].mean(dim=1))

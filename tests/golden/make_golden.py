@@ -298,6 +298,51 @@ def g9():
          n_params=sum(p.numel() for p in model.parameters()))
 
 
+def main():
+    fns = {"g1": g1, "g2": g2, "g3": g3, "g4": g4, "g5": g5, "g6": g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
+    only = [a for a in sys.argv[1:] if a in fns]
+    for name, fn in fns.items():
+        if not only or name in only:
+            fn()
+
+
+def g10():
+    """SSL pre-training path: EdgeGNN = EmbGConv(MyGCNConv layers) + MLP head, link prediction
+    with Pool = mean of the two endpoint embeddings (reference impl/models.py:361-509, GNNEmb.py:76-105)."""
+    rng = np.random.default_rng(10)
+    n, h = 40, 8
+    ei, ew = small_graph(rng, n, 90)
+    deg = np.bincount(ei[0], minlength=n)
+    xfeat = np.unique(deg, return_inverse=True)[1].reshape(n, 1, 1).astype(np.int64)
+    pairs = rng.integers(0, n, (24, 2)).astype(np.int64)
+    y = (rng.random(24) < 0.5).astype(np.float32)
+    for layers, jk, aggr in ((2, 0, "mean"), (3, 1, "gcn"), (1, 0, "sum")):
+        torch.manual_seed(100 + layers)
+        gen = torch.Generator().manual_seed(101)
+
+        def build():
+            conv = models.EmbGConv(h, h, h, layers, max_deg=int(xfeat.max()), activation=nn.ReLU(inplace=True),
+                                   jk=bool(jk), dropout=0.0,
+                                   conv=functools.partial(models.MyGCNConv, aggr=aggr), gn=True)
+            head = models.MLP(h * layers if jk else h, h, 1, 2, dropout=0.0, activation=nn.ReLU(inplace=True))
+            return models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()]))
+
+        m32 = build()
+        randomize_(m32, gen)
+        m64 = build().double()
+        m64.load_state_dict({k: v.double() for k, v in m32.state_dict().items()})
+        outs = {}
+        for tag, m, dt in (("", m32, torch.float32), ("64", m64, torch.float64)):
+            m.train()
+            pred = m(torch.from_numpy(xfeat), torch.from_numpy(ei), torch.from_numpy(ew).to(dt), torch.from_numpy(pairs))
+            loss = nn.BCEWithLogitsLoss()(pred.flatten(), torch.from_numpy(y).to(dt))
+            loss.backward()
+            outs["pred" + tag] = pred.detach().numpy()
+            outs["loss" + tag] = loss.item()
+            outs.update(grad_arrays(m, "grad" + tag + "/"))
+        save(f"g10_edgegnn_L{layers}_jk{jk}_{aggr}.npz", edge_index=ei, edge_weight=ew, x=xfeat, pairs=pairs, y=y,
+             layers=layers, jk=jk, aggr=aggr, hidden=h, **sd_arrays(m32), **outs)
+
+
 if __name__ == "__main__":
-    for fn in (g1, g2, g3, g4, g5, g6, g7, g8, g9):
-        fn()
+    main()

@@ -315,3 +315,46 @@ def test_driver_density_learns(capsys):
     assert "params {" in text and "repeat 0" in text and "end: epoch" in text and "average " in text
     assert any(line.startswith("iter ") and " val " in line and " tst " in line for line in text.splitlines())
     assert outs[0] > 0.8
+
+
+@pytest.mark.parametrize("name", ["L2_jk0_mean", "L3_jk1_gcn", "L1_jk0_sum"])
+def test_g10_edgegnn_ssl_path(name):
+    """SSL pre-training path: EdgeGNN / EmbGConv / MyGCNConv on the HIP kernels vs the reference
+    (fp64 and fp32 runs), incl. the in-place-ReLU JK quirk."""
+    import functools
+    from impl import models
+    g = load(f"g10_edgegnn_{name}.npz")
+    h, layers, jk = int(g["hidden"]), int(g["layers"]), bool(g["jk"])
+    x = torch.from_numpy(g["x"])
+    conv = models.EmbGConv(h, h, h, layers, max_deg=int(x.max()), activation=nn.ReLU(inplace=True), jk=jk, dropout=0.0,
+                           conv=functools.partial(models.MyGCNConv, aggr=str(g["aggr"])), gn=True)
+    head = models.MLP(h * layers if jk else h, h, 1, 2, dropout=0.0, activation=nn.ReLU(inplace=True))
+    model = models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()]))
+    model.load_state_dict(sd_from(g))
+    model.to(DEV).train()
+    pred = model(x.to(DEV), torch.from_numpy(g["edge_index"]).to(DEV), torch.from_numpy(g["edge_weight"]).to(DEV),
+                 torch.from_numpy(g["pairs"]).to(DEV))
+    loss = nn.BCEWithLogitsLoss()(pred.flatten(), torch.from_numpy(g["y"]).to(DEV))
+    loss.backward()
+    ref64, ref32 = grads_from(g, "grad64/"), grads_from(g, "grad/")
+    keys = sorted(ref64)
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    assert sorted(mine) == keys
+    assert rel_inf(pred.detach().cpu(), g["pred64"]) < TOL and rel_inf(pred.detach().cpu(), g["pred"]) < TOL
+    assert abs(loss.item() - float(g["loss64"])) < TOL * abs(float(g["loss64"]))
+    assert rel_inf(flat_grads(mine, keys), flat_grads(ref64, keys)) < TOL
+    assert rel_inf(flat_grads(mine, keys), flat_grads(ref32, keys)) < TOL
+
+
+def test_pretraining_driver_learns_links(tmp_path, capsys):
+    """GNNEmb.py-compatible driver: one trial of link-prediction pre-training on the shipped density graph
+    learns to separate edges from sampled non-edges and writes the [N,64] embedding file GLASSTest.py
+    --use_nodeid consumes."""
+    import GNNEmb
+    score, params = GNNEmb.main(["--use_nodeid", "--use_seed", "--device", "0", "--dataset", "density", "--name",
+                                 "density", "--path", str(tmp_path) + "/", "--optruns", "1", "--max_epoch", "16"])
+    text = capsys.readouterr().out
+    assert "iter 0 loss" in text and "best valf1" in text
+    emb = torch.load(str(tmp_path / "density_64.pt"))
+    assert emb.shape == (4998, 64) and bool(torch.isfinite(emb).all())
+    assert score > 0.6  # binary F1 on a balanced edge / non-edge set: well above the 0.5 of an untrained model

@@ -206,3 +206,20 @@ def test_datasets_other_sources():
     bg = datasets.BaseGraph(torch.empty(4, 1, 0), torch.tensor([[0, 0, 2], [1, 1, 3]]), torch.tensor([1.0, 2.0, 1.0]),
                             torch.tensor([[0, 1]]), torch.tensor([0]), torch.tensor([0]))
     assert bg.edge_index.tolist() == [[0, 1, 2, 3], [1, 0, 3, 2]] and bg.edge_attr.tolist() == [3.0, 3.0, 1.0, 1.0]
+
+
+def test_link_prediction_dataset():
+    """get_LPdataset (SSL pre-training): positives = all edges, negatives = sampled non-edges, optional loop probes."""
+    import datasets
+    torch.manual_seed(0)
+    g = datasets.load_dataset("synthetic:tiny")
+    g.setDegreeFeature()
+    x, ei, ea, pos, y = g.get_LPdataset()
+    nnz, n = ei.shape[1], g.num_nodes
+    assert pos.shape == (2 * nnz, 2) and y.shape == (2 * nnz, ) and y[:nnz].min() == 1 and y[nnz:].max() == 0
+    assert torch.equal(pos[:nnz], ei.t())
+    edges = set((ei[0] * n + ei[1]).tolist())
+    assert not edges & set((pos[nnz:, 0] * n + pos[nnz:, 1]).tolist())  # negatives are non-edges
+    assert len(set((pos[nnz:, 0] * n + pos[nnz:, 1]).tolist())) == nnz  # distinct
+    x, ei, ea, pos2, y2 = g.get_LPdataset(use_loop=True)
+    assert pos2.shape[0] == 2 * nnz + n and torch.equal(pos2[-n:, 0], pos2[-n:, 1]) and y2[-n:].sum() == 0

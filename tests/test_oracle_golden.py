@@ -195,3 +195,25 @@ def test_oracle_fp64_mode():
     y = conv(torch.from_numpy(g["x"]).double(), torch.from_numpy(g["edge_index"]),
              torch.from_numpy(g["edge_weight"]), torch.from_numpy(g["mask"]).reshape(-1, 1), torch.nn.functional.elu)
     assert y.dtype == torch.float64 and rel_inf(y.detach(), g["y"]) < TOL
+
+
+@pytest.mark.parametrize("name", ["L2_jk0_mean", "L3_jk1_gcn", "L1_jk0_sum"])
+def test_g10_edgegnn_ssl_path(name):
+    """SSL pre-training path (EdgeGNN / EmbGConv / MyGCNConv): oracle vs the reference in fp64 (math pin) and fp32."""
+    g = load(f"g10_edgegnn_{name}.npz")
+    x, ei, ew = torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_weight"])
+    pairs, y = torch.from_numpy(g["pairs"]), torch.from_numpy(g["y"])
+    for dt, tag, tol in ((torch.float64, "64", 1e-11), (torch.float32, "", TOL)):
+        m = O.OracleEdgeGNN(int(g["hidden"]), int(g["layers"]), int(x.max()), aggr=str(g["aggr"]), jk=bool(g["jk"]))
+        m.load_state_dict(sd_from(g))
+        m = m.to(dt).train()
+        pred = m(x, ei, ew.to(dt), pairs)
+        loss = nn.BCEWithLogitsLoss()(pred.flatten(), y.to(dt))
+        loss.backward()
+        ref = grads_from(g, "grad" + tag + "/")
+        keys = sorted(ref)
+        mine = {k: p.grad for k, p in m.named_parameters()}
+        assert sorted(mine) == keys
+        assert rel_inf(pred.detach(), g["pred" + tag]) < tol
+        assert abs(loss.item() - float(g["loss" + tag])) < tol * abs(float(g["loss" + tag]))
+        assert rel_inf(flat_grads(mine, keys), flat_grads(ref, keys)) < tol
