@@ -16,12 +16,16 @@ from . import utils
 
 class TrainStep:
     def __init__(self, model, optimizer, loss_fn, x, edge_index, edge_weight, bucket=None, use_graph=True,
-                 warmup_iters=3):
+                 warmup_iters=3, preserve_state=False):
+        """preserve_state: the warm-up steps are run for their side effects only (CSR / plan / workspace / BLAS
+        handle creation) and parameters, optimizer state and dropout stream are restored afterwards, so the
+        training trajectory is exactly the one of a loop without warm-up (used by impl.train.train)."""
         self.model, self.opt, self.loss_fn = model, optimizer, loss_fn
         self.x, self.ei, self.ew = x, edge_index, edge_weight
         self.bucket = bucket if bucket is not None else gdist.bucket_for(model)
         self.use_graph = use_graph
         self.warmup_iters = warmup_iters
+        self.preserve_state = preserve_state
         self.graphed = False
         self._pos = self._y = None
         self._loss = torch.zeros((), device=x.device)
@@ -59,6 +63,13 @@ class TrainStep:
         """Real training steps on the first batch, on a side stream: builds the CSR / plans /
         workspaces / BLAS handles outside any capture.  Runs in eager mode too, so both modes follow
         the same trajectory."""
+        import copy
+        from . import ops
+        snap = None
+        if self.preserve_state and self.warmup_iters > 0:
+            snap = (copy.deepcopy(self.model.state_dict()), copy.deepcopy(self.opt.state_dict()),
+                    {k: getattr(self.opt, k).clone() for k in ("exp_avg", "exp_avg_sq", "step_dev") if hasattr(self.opt, k)},
+                    ops.rng_state(self.x.device).clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -68,6 +79,13 @@ class TrainStep:
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if snap is not None:
+            self.model.load_state_dict(snap[0])          # in-place copies: arena aliasing is kept
+            self.opt.load_state_dict(snap[1])
+            for k, v in snap[2].items():
+                getattr(self.opt, k).copy_(v)
+            ops.rng_state(self.x.device).copy_(snap[3])
+            torch.cuda.synchronize()
 
     def _capture(self):
         dist_on = gdist.is_distributed()

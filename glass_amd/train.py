@@ -1,14 +1,53 @@
 """Epoch loops with the reference's interface (/root/reference/impl/train.py:4-34), plus the
 data-parallel hook: when torch.distributed is initialised, gradients are averaged across ranks
 through one flat bucket (glass_amd.dist) between backward() and optimizer.step()."""
+import os
+
 import torch
 
 from . import dist as gdist
+
+USE_GRAPH = os.environ.get("GLASS_TRAIN_GRAPH", "1") != "0"
+
+
+def _graph_step(optimizer, model, dataloader, loss_fn):
+    """A hipGraph-replayed step (glass_amd.step.TrainStep) when the epoch is graph-safe: a GLASS model on the GPU,
+    ZGDataloader with z_fn = MaxZOZ and drop_last (fixed batch shape), and an optimizer whose step is capturable
+    (FlatAdam, or a torch optimizer built with capturable=True).  Cached on the model.  None -> eager loop."""
+    from . import utils
+    from .SubGDataset import ZGDataloader
+    from .models import GLASS
+    from .optim import FlatAdam
+    if not (USE_GRAPH and isinstance(model, GLASS) and isinstance(dataloader, ZGDataloader) and
+            dataloader.z_fn is utils.MaxZOZ and dataloader.drop_last and dataloader.Gdataset.x.is_cuda and
+            len(dataloader) > 0):
+        return None
+    if not (isinstance(optimizer, FlatAdam) or all(g.get("capturable", False) for g in optimizer.param_groups)):
+        return None
+    ds = dataloader.Gdataset
+    key = (id(optimizer), id(loss_fn), id(ds.x), id(ds.edge_index), dataloader.batch_size, gdist.world_size())
+    cache = model.__dict__.setdefault("_glass_train_steps", {})
+    step = cache.get(key)
+    if step is None:
+        from .step import TrainStep
+        step = TrainStep(model, optimizer, loss_fn, ds.x, ds.edge_index, ds.edge_attr, gdist.bucket_for(model),
+                         use_graph=True, warmup_iters=2, preserve_state=True)
+        cache.clear()  # one live graph per model
+        cache[key] = step
+    return step
 
 
 def train(optimizer, model, dataloader, loss_fn):
     """One epoch; returns the mean per-step loss.  batch = (x, ei, ea, pos, [z,] y)."""
     model.train()
+    step = _graph_step(optimizer, model, dataloader, loss_fn)
+    if step is not None:
+        total, n = None, 0
+        for batch in dataloader:
+            loss = step(batch[3], batch[-1])  # z is recomputed inside the captured step (MaxZOZ kernel)
+            total = loss.clone() if total is None else total.add_(loss)
+            n += 1
+        return (total / n).item()
     total_loss = []
     bucket = gdist.bucket_for(model) if gdist.is_distributed() else None
     for batch in dataloader:

@@ -358,3 +358,30 @@ def test_pretraining_driver_learns_links(tmp_path, capsys):
     emb = torch.load(str(tmp_path / "density_64.pt"))
     assert emb.shape == (4998, 64) and bool(torch.isfinite(emb).all())
     assert score > 0.6  # binary F1 on a balanced edge / non-edge set: well above the 0.5 of an untrained model
+
+
+def test_train_epoch_graph_path_matches_eager_path():
+    """impl.train.train replays the step from a hipGraph when the epoch is graph-safe (FlatAdam, ZGDataloader with
+    MaxZOZ, drop_last).  The state-preserving warm-up must leave the trajectory untouched: epoch losses and final
+    weights equal the eager loop's (dropout 0, same shuffles)."""
+    from glass_amd import synth
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    from impl import SubGDataset, train, utils
+    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=4, n_batches=6)
+    ds = SubGDataset.GDataset(*(torch.from_numpy(a) for a in (x, ei, ew, pos, y))).to(DEV)
+    results = []
+    for use_graph in (False, True):
+        train.USE_GRAPH = use_graph
+        torch.manual_seed(0)
+        model = build_glass(w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio).to(DEV)
+        opt = FlatAdam(ParamArena(model), lr=5e-3)
+        loader = SubGDataset.ZGDataloader(ds, w.batch, z_fn=utils.MaxZOZ, shuffle=True, drop_last=True)
+        loader.generator = torch.Generator().manual_seed(7)
+        losses = [train.train(opt, model, loader, nn.CrossEntropyLoss()) for _ in range(4)]
+        results.append((losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()))
+        assert ("_glass_train_steps" in model.__dict__) == use_graph
+    train.USE_GRAPH = True
+    assert np.allclose(results[0][0], results[1][0], rtol=2e-5, atol=0)
+    assert rel_inf(results[1][1], results[0][1]) < 1e-4
+    assert results[0][0][-1] < results[0][0][0]
