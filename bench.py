@@ -28,7 +28,6 @@ import torch.nn as nn
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def parse():
@@ -107,7 +106,7 @@ def main():
 
     from glass_amd import synth, ops, graph as ggraph, dist as gdist
     from impl import utils
-    from helpers import build_glass
+    from glass_amd.factory import build_glass
 
     n_batches = 16
     w, ei_np, ew_np, x_np, pos_np, y_np = synth.make_workload(args.workload, seed=0, n_batches=n_batches * world)

@@ -46,16 +46,7 @@ def density_inputs(npz):
     return n, ei, ew, x, pos, y, z
 
 
-def build_glass(hidden, layers, max_deg, out_ch, aggr, pool, z_ratio, dropout=0.0, jk=True):
-    """The product model, constructed exactly as GLASSTest.py:129-175 (buildModel) constructs the
-    reference one — through the drop-in `impl.models` surface."""
-    import functools
-    import torch.nn as nn
-    from impl import models
-    conv = models.EmbZGConv(hidden, hidden, layers, max_deg=max_deg, activation=nn.ELU(inplace=True), jk=jk,
-                            dropout=dropout,
-                            conv=functools.partial(models.GLASSConv, aggr=aggr, z_ratio=z_ratio, dropout=dropout),
-                            gn=True)
-    mlp = nn.Linear(hidden * layers if jk else hidden, out_ch)
-    pool_fn = {"mean": models.MeanPool, "max": models.MaxPool, "sum": models.AddPool, "size": models.SizePool}[pool]()
-    return models.GLASS(conv, nn.ModuleList([mlp]), nn.ModuleList([pool_fn]))
+def build_glass(*args, **kwargs):
+    """The product model, constructed exactly as GLASSTest.py:129-175 (buildModel) constructs the reference one."""
+    from glass_amd.factory import build_glass as _build
+    return _build(*args, **kwargs)

@@ -128,3 +128,19 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "libglass_hip.so"))
     with pytest.raises(_lib.GlassHipError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_plan_builder_property_based():
+    """hypothesis: for arbitrary degree sequences the plan tiles every row exactly once (sweep ranges in order,
+    long rows covered by contiguous whole-batch chunks, partial slots numbered consecutively)."""
+    from hypothesis import given, settings, strategies as st
+
+    degrees = st.lists(st.one_of(st.integers(0, 40), st.integers(0, 600), st.sampled_from([255, 256, 2047, 2048, 2049, 9000])),
+                       min_size=0, max_size=300)
+
+    @settings(max_examples=60, deadline=None)
+    @given(degrees)
+    def check(degs):
+        _check_plan(np.concatenate([[0], np.cumsum(np.asarray(degs, dtype=np.int64))]))
+
+    check()
