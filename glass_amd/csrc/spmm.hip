@@ -106,6 +106,64 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
     const int r0 = __builtin_amdgcn_readfirstlane(wave_rows[wave]);
     const int r1 = __builtin_amdgcn_readfirstlane(wave_rows[wave + 1]);
     int e0 = __builtin_amdgcn_readfirstlane(rowptr[r0]);
+    constexpr int G = kWave / LPR;
+    if (G > 1) {
+        // Row-parallel mode for very short rows (mean degree of this wave's range <= G): splitting one row's
+        // edges over the G lane groups leaves most groups idle and exposes one gather latency per ROW (0.23 of
+        // the HBM roofline on a degree-1 pattern).  Here every lane group takes its OWN row, G rows per step:
+        // G x more bytes in flight per wave and no cross-group reduction.  The mode is a pure function of the plan
+        // and H (wave-uniform test below), so results stay bitwise repeatable; a row is summed in plain edge order.
+        const int e_last = __builtin_amdgcn_readfirstlane(rowptr[r1]);
+        if (e_last - e0 <= G * (r1 - r0)) {
+            constexpr int NB = 2;  // row batches in flight: two independent rowptr -> (col,val) -> X chains
+            for (int rb = r0; rb < r1; rb += NB * G) {
+                int re0[NB], deg[NB];
+                bool store_ok[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const int r = rb + b * G + grp;
+                    const bool valid = r < r1;
+                    re0[b] = valid ? rowptr[r] : 0;
+                    deg[b] = valid ? rowptr[r + 1] - re0[b] : 0;
+                    const bool is_long = deg[b] >= long_thr;  // left to the long-row kernel
+                    if (is_long) deg[b] = 0;
+                    store_ok[b] = valid && !is_long && col_ok;
+                }
+                Vec<VW> acc[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) acc[b].zero();
+                for (int k = 0; __any(k < deg[0] || k < deg[1]); k += U / NB) {
+                    constexpr int UU = U / NB;  // gathers per batch per step (U in flight per lane group overall)
+                    int c[NB][UU];
+                    float v[NB][UU];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int u = 0; u < UU; ++u) {
+                            const bool ok = k + u < deg[b];
+                            c[b][u] = ok ? col[re0[b] + k + u] : 0;
+                            v[b][u] = ok ? val[re0[b] + k + u] : 0.f;
+                        }
+                    Vec<VW> x[NB][UU];
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int u = 0; u < UU; ++u) {
+                            x[b][u].zero();
+                            if (col_ok && k + u < deg[b]) x[b][u].load(Xc + (int64_t)c[b][u] * ldx);
+                        }
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+#pragma unroll
+                        for (int u = 0; u < UU; ++u) acc[b].fma(v[b][u], x[b][u]);
+                }
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if (store_ok[b]) acc[b].store(Y + (int64_t)(rb + b * G + grp) * ldy + coff);
+            }
+            return;
+        }
+    }
     for (int r = r0; r < r1; ++r) {
         const int e1 = __builtin_amdgcn_readfirstlane(rowptr[r + 1]);
         if (e1 - e0 < long_thr) {

@@ -594,3 +594,27 @@ def test_spmm_full_size_properties(shape):
     assert torch.equal(adj.fwd.spmm(x), ax)
     if shape == "powerlaw":
         assert adj.fwd.header[6] > 0 and int(deg.max()) == 50000  # chunked rows present
+
+
+@pytest.mark.parametrize("H", [8, 64, 128, 17])
+def test_spmm_row_parallel_mode_for_short_rows(H):
+    """Mean degree <= G (= 64 / lanes-per-row): the sweep kernel gives every lane group its own row.  Degrees 0-3
+    with a few long rows (>= 256 edges, which that mode must leave to the workgroup kernel) mixed into the range."""
+    from glass_amd.graph import CSRAdj
+    rng = np.random.default_rng(H)
+    n = 6000
+    rows = np.repeat(np.arange(n), rng.integers(0, 4, n))
+    cols = rng.integers(0, n, rows.shape[0])
+    hub = np.array([17, 3000])
+    rows = np.concatenate([rows, np.repeat(hub, 300)])
+    cols = np.concatenate([cols, rng.integers(0, n, 600)])
+    ei = torch.from_numpy(np.stack([rows, cols]))
+    ew = torch.from_numpy(rng.uniform(0.5, 2.0, rows.shape[0]).astype(np.float32))
+    x = torch.randn(n, H, generator=torch.Generator().manual_seed(H))
+    ref = O.build_adj(ei, ew, n, "sum").to(torch.float64) @ x.double()
+    adj = CSRAdj(ei.to(DEV), ew.to(DEV), n, "sum")
+    y = adj.fwd.spmm(x.to(DEV))
+    assert rel_inf(y.cpu(), ref) < TOL
+    assert torch.equal(adj.fwd.spmm(x.to(DEV)), y)
+    yt = adj.bwd.spmm(x.to(DEV))
+    assert rel_inf(yt.cpu(), O.build_adj(ei, ew, n, "sum").to(torch.float64).t() @ x.double()) < TOL
