@@ -18,9 +18,10 @@ namespace glass {
 
 constexpr int32_t kPlanMagic = 0x474C5350;  // 'GLSP'
 constexpr int32_t kPlanVersion = 1;
+constexpr int64_t kRowParallelWideWaves = 8192;
 // header word indices
 enum { H_MAGIC, H_VER, H_NROWS, H_NNZ, H_NSWEEP, H_NLONG, H_NREDUCE, H_NSLOTS, H_LONG_THR, H_LONG_CHUNK,
-       H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RSV0, H_RSV1, H_RSV2 };
+       H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RP_FACTOR, H_RSV1, H_RSV2 };
 
 // ---- vector helpers --------------------------------------------------------------------------
 template <int VW> struct Vec;
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
                                                             const float* __restrict__ X, int64_t ldx,
                                                             float* __restrict__ Y, int64_t ldy, int H,
                                                             const int32_t* __restrict__ wave_rows, int n_waves,
-                                                            int long_thr) {
+                                                            int long_thr, int rp_factor) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
     if (wave >= n_waves) return;
@@ -108,13 +109,13 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
     int e0 = __builtin_amdgcn_readfirstlane(rowptr[r0]);
     constexpr int G = kWave / LPR;
     if (G > 1) {
-        // Row-parallel mode for very short rows (mean degree of this wave's range <= G): splitting one row's
+        // Row-parallel mode for very short rows (mean degree of this wave's range <= rp_factor * G, plan header): splitting one row's
         // edges over the G lane groups leaves most groups idle and exposes one gather latency per ROW (0.23 of
         // the HBM roofline on a degree-1 pattern).  Here every lane group takes its OWN row, G rows per step:
         // G x more bytes in flight per wave and no cross-group reduction.  The mode is a pure function of the plan
         // and H (wave-uniform test below), so results stay bitwise repeatable; a row is summed in plain edge order.
         const int e_last = __builtin_amdgcn_readfirstlane(rowptr[r1]);
-        if (e_last - e0 <= G * (r1 - r0)) {
+        if (e_last - e0 <= rp_factor * G * (r1 - r0)) {
             constexpr int NB = 2;  // row batches in flight: two independent rowptr -> (col,val) -> X chains
             for (int rb = r0; rb < r1; rb += NB * G) {
                 int re0[NB], deg[NB];
@@ -235,7 +236,8 @@ static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float*
     if (n_waves > 0) {
         dim3 grid((unsigned)ceil_div(n_waves, kBlock / kWave), n_ctiles);
         hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx, Y,
-                           ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_LONG_THR]);
+                           ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_LONG_THR],
+                           hdr[H_RP_FACTOR] > 0 ? hdr[H_RP_FACTOR] : 1);
     }
     if (hdr[H_NLONG] > 0) {
         dim3 grid((unsigned)hdr[H_NLONG], n_ctiles);
@@ -346,6 +348,10 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     plan[H_NSLOTS] = n_slots;
     plan[H_LONG_THR] = kLongThr;
     plan[H_LONG_CHUNK] = kLongChunk;
+    // Row-parallel threshold (mean degree of a wave's rows <= factor * G): 2 once the sweep is throughput-bound
+    // (degree-6 uniform graph: 0.66 -> 0.72 of the HBM roofline), 1 on small graphs where the serial per-row edge
+    // loop would lengthen the latency-bound critical path (density-shape: 5.0 -> 5.35 us with factor 2).
+    plan[H_RP_FACTOR] = n_sweep >= kRowParallelWideWaves ? 2 : 1;
     plan[H_OFF_SWEEP] = (int32_t)off_sweep;
     plan[H_OFF_LONG] = (int32_t)off_long;
     plan[H_OFF_REDUCE] = (int32_t)off_reduce;

@@ -618,3 +618,23 @@ def test_spmm_row_parallel_mode_for_short_rows(H):
     assert torch.equal(adj.fwd.spmm(x.to(DEV)), y)
     yt = adj.bwd.spmm(x.to(DEV))
     assert rel_inf(yt.cpu(), O.build_adj(ei, ew, n, "sum").to(torch.float64).t() @ x.double()) < TOL
+
+
+@pytest.mark.gpu
+def test_spmm_row_parallel_wide_threshold_on_large_graphs():
+    """Plans with >= 8192 sweep waves double the row-parallel threshold (header word 13): degrees 0-8 at H=64 then
+    run row-parallel (mean 4 < 2 * G = 8).  Checked against a float64 CSR product built with scipy."""
+    import scipy.sparse as sp
+    from glass_amd.graph import CSRAdj
+    rng = np.random.default_rng(5)
+    n, H = 600_000, 64
+    rows = np.repeat(np.arange(n), rng.integers(0, 9, n))
+    cols = rng.integers(0, n, rows.shape[0])
+    w = rng.uniform(0.5, 2.0, rows.shape[0]).astype(np.float32)
+    x = torch.randn(n, H, generator=torch.Generator().manual_seed(5))
+    adj = CSRAdj(torch.from_numpy(np.stack([rows, cols])).to(DEV), torch.from_numpy(w).to(DEV), n, "sum")
+    assert int(adj.fwd.header[13]) == 2
+    y = adj.fwd.spmm(x.to(DEV))
+    ref = sp.csr_matrix((w.astype(np.float64), (rows, cols)), shape=(n, n)) @ x.double().numpy()
+    assert rel_inf(y.cpu(), torch.from_numpy(ref)) < TOL
+    assert torch.equal(adj.fwd.spmm(x.to(DEV)), y)
