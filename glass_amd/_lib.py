@@ -45,7 +45,7 @@ SIGNATURES = {
     "glass_graphnorm_ws_bytes": (c_int64, [_I, _I]),
     "glass_graphnorm_fwd_f32": (c_int, [_P, _I, _P, _I, _I, _I, _P, _P, _P, c_float, _P, c_int, c_float, _P, c_uint64,
                                         _P, _P]),
-    "glass_graphnorm_bwd_f32": (c_int, [_P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float,
+    "glass_graphnorm_bwd_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float,
                                         _P, c_uint64, _P, _P]),
     "glass_rng_advance": (c_int, [_P, _P]),
     "glass_segment_pool_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _I, _P, _I, _I, _P]),

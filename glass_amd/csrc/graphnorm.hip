@@ -353,8 +353,10 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_bwd_kernel(const double* _
 template <int VW>
 __global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __restrict__ dy, int64_t lddy,
                                                               const float* __restrict__ x, int64_t ldx,
-                                                              float* __restrict__ dx, int64_t lddx, int64_t N, int C,
-                                                              int tc_log2, const float* __restrict__ saved,
+                                                              float* __restrict__ dx, int64_t lddx,
+                                                              const float* __restrict__ addend, int64_t ldadd,
+                                                              int64_t N, int C, int tc_log2,
+                                                              const float* __restrict__ saved,
                                                               const float* __restrict__ coef, int act, Drop drop,
                                                               const uint64_t* __restrict__ rng_state) {
     const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
@@ -373,13 +375,14 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __res
     }
     const int64_t stride = (int64_t)gridDim.x * rpb;
     for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * kUnroll) {
-        F<VW> g[kUnroll], xv[kUnroll];
+        F<VW> g[kUnroll], xv[kUnroll], ad[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int64_t rr = r + u * stride;
             if (rr < N) {
                 g[u].load(dy + rr * lddy + c0);
                 xv[u].load(x + rr * ldx + c0);
+                if (addend) ad[u].load(addend + rr * ldadd + c0);
             }
         }
 #pragma unroll
@@ -388,7 +391,10 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __res
             if (rr >= N) continue;
             bwd_g<VW>(g[u].a, xv[u].a, scale, shift, act, drop, rr, c0);
 #pragma unroll
-            for (int k = 0; k < VW; ++k) g[u].a[k] = fmaf(A[k], g[u].a[k], fmaf(Bx[k], xv[u].a[k], K[k]));
+            for (int k = 0; k < VW; ++k) {
+                g[u].a[k] = fmaf(A[k], g[u].a[k], fmaf(Bx[k], xv[u].a[k], K[k]));
+                if (addend) g[u].a[k] += ad[u].a[k];
+            }
             g[u].store(dx + rr * lddx + c0);
         }
     }
@@ -456,16 +462,18 @@ extern "C" int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, in
 }
 
 extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx,
-                                       int64_t lddx, int64_t n_rows, int64_t C, const float* gamma,
+                                       int64_t lddx, const float* addend, int64_t ldadd, int64_t n_rows, int64_t C,
+                                       const float* gamma,
                                        const float* alpha, const float* saved, float* dgamma, float* dbeta,
                                        float* dalpha, int accumulate, int act, float p_drop,
                                        const uint64_t* rng_state, uint64_t call_id, void* ws, void* stream) {
     GLASS_REQUIRE(dy && x && dx && gamma && alpha && saved && ws, "graphnorm_bwd: null pointer");
-    GLASS_REQUIRE(n_rows > 0 && C > 0 && lddy >= C && ldx >= C && lddx >= C, "graphnorm_bwd: bad sizes");
+    GLASS_REQUIRE(n_rows > 0 && C > 0 && lddy >= C && ldx >= C && lddx >= C && (!addend || ldadd >= C),
+                  "graphnorm_bwd: bad sizes");
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd: bad dropout args");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && aligned16(dy) && aligned16(x) &&
-                     aligned16(dx);
+                     aligned16(dx) && (!addend || (ldadd % 4 == 0 && aligned16(addend)));
     const Tiling t = make_tiling(C, vec);
     const int nblk = stat_blocks(n_rows, t);
     double* partial = (double*)ws;
@@ -482,11 +490,11 @@ extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const floa
     hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
                        (int)C, n_rows, gamma, alpha, saved, dgamma, dbeta, dalpha, accumulate, coef);
     if (vec) {
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, n_rows, (int)C,
-                           t.tc_log2, saved, coef, act, drop, rng_state);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, addend, ldadd,
+                           n_rows, (int)C, t.tc_log2, saved, coef, act, drop, rng_state);
     } else {
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, n_rows, (int)C,
-                           t.tc_log2, saved, coef, act, drop, rng_state);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, addend, ldadd,
+                           n_rows, (int)C, t.tc_log2, saved, coef, act, drop, rng_state);
     }
     return launch_status("glass_graphnorm_bwd_f32");
 }

@@ -12,10 +12,15 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import ops
+import os
+
+from . import ops, stack
 from .graph import CSRAdj, Selection
 from .ops import ACT_ELU, ACT_NONE
 from .utils import batch2pad
+
+
+USE_STACK = os.environ.get("GLASS_STACK", "1") != "0"  # A/B switch: whole-stack program vs per-op autograd nodes
 
 
 # ---------------------------------------------------------------------------------------------
@@ -209,12 +214,15 @@ class EmbZGConv(nn.Module):
         x_flat = x.reshape(n)
         if x_flat.dtype != torch.int64:
             x_flat = x_flat.to(torch.int64)
+        if USE_STACK and stack.StackProgram.supported(self):
+            # the whole stack as one autograd node (explicit forward / backward program, glass_amd/stack.py)
+            return stack.run(self, x_flat, z, edge_index, edge_weight)
         p = self.dropout if self.training else 0.0
         if self.training and (p > 0 or any(c.dropout > 0 for c in self.convs)):
             ops.rng_advance(x.device)  # new dropout masks for this forward/backward pair
         arena = getattr(self, "_glass_arena", None)
-        if arena is not None and torch.is_grad_enabled():
-            arena.refresh_transposes()  # W^T operands of the fused data-gradient kernels
+        if arena is not None:
+            arena.refresh_transposes()  # operand images (W, W^T) of the fused dense kernels follow the weights
         code = _act_code(self.activation)
         h, mask = ops.embed_label(self.input_emb.weight, x_flat, z, self._selection(x_flat))
         h = self.emb_gn(h, p_drop=p, call_id=1)

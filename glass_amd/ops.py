@@ -422,8 +422,8 @@ class GraphNormFn(torch.autograd.Function):
             accumulate = 0
         ws = _graphnorm_ws(x.device, n, C)
         rng = rng_state(x.device).data_ptr() if p_drop > 0 else 0
-        rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), lddy, x.data_ptr(), x.stride(0), dx.data_ptr(), C, n,
-                                                 C, g.data_ptr(), a.data_ptr(), saved.data_ptr(), dg.data_ptr(),
+        rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), lddy, x.data_ptr(), x.stride(0), dx.data_ptr(), C, 0, 0,
+                                                 n, C, g.data_ptr(), a.data_ptr(), saved.data_ptr(), dg.data_ptr(),
                                                  db.data_ptr(), da.data_ptr(), accumulate, act, p_drop, rng, call_id,
                                                  ws.data_ptr(), _stream())
         _lib.check(rc, "glass_graphnorm_bwd_f32")

@@ -1,0 +1,226 @@
+"""The EmbZGConv stack as ONE explicit forward / backward program over the C ABI.
+
+`models.EmbZGConv.forward` (reference impl/models.py:241-272, layers 158-173) normally records one autograd node
+per kernel group (ops.py).  On the small graphs of the BASELINE configs the step is a chain of ~70 dependent
+4-15 us kernels, and the tape costs real launches: every tensor with two consumers (the layer input feeds the
+trans pair and the comb pair; with jumping knowledge a conv output feeds the next GraphNorm and the final one)
+gets its two gradients from two nodes and autograd adds them with an elementwise kernel.  Here the whole stack is
+a single autograd node whose backward walks the layers itself, so those sums ride along as the `addend` operand
+of the kernel that produces the other summand, and parameter gradients go straight into the gradient arena.
+
+Used when every layer takes the fused dense path (ParamArena present, GLASSConv layers of equal width that
+glass_dual_linear_supported() accepts, ELU, GraphNorm on); anything else keeps the per-op path.  Same kernels,
+same Philox call ids -> same dropout masks as the per-op path.
+"""
+import torch
+
+from . import _lib, ops
+from .ops import ACT_ELU, ACT_NONE, _stream
+
+
+def _check(rc, what):
+    _lib.check(rc, what)
+
+
+class _GN:
+    """Launch helpers for one GraphNorm module (weights read in place; gradients accumulated in place)."""
+    def __init__(self, mod):
+        self.mod = mod
+
+    def fwd(self, x, y, act, p_drop, call_id):
+        m = self.mod
+        n, C = x.shape
+        saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        ws = ops._graphnorm_ws(x.device, n, C)
+        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rc = _lib.load().glass_graphnorm_fwd_f32(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), n, C,
+                                                 m.weight.data_ptr(), m.bias.data_ptr(), m.mean_scale.data_ptr(),
+                                                 float(m.eps), saved.data_ptr(), act, float(p_drop), rng, call_id,
+                                                 ws.data_ptr(), _stream())
+        _check(rc, "glass_graphnorm_fwd_f32")
+        return saved
+
+    def bwd(self, dy, x, saved, dx, act, p_drop, call_id, addend=None):
+        m = self.mod
+        n, C = x.shape
+        ws = ops._graphnorm_ws(x.device, n, C)
+        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        ap, lda = (0, 0) if addend is None else (addend.data_ptr(), addend.stride(0))
+        rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dx.data_ptr(),
+                                                 dx.stride(0), ap, lda, n, C, m.weight.data_ptr(),
+                                                 m.mean_scale.data_ptr(), saved.data_ptr(), m.weight.grad.data_ptr(),
+                                                 m.bias.grad.data_ptr(), m.mean_scale.grad.data_ptr(), 1, act,
+                                                 float(p_drop), rng, call_id, ws.data_ptr(), _stream())
+        _check(rc, "glass_graphnorm_bwd_f32")
+
+
+def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out):
+    n, H = xa.shape
+    rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
+                                               0 if xb is None else xb.stride(0), stack[4].data_ptr(),
+                                               stack[1].data_ptr(), mask.data_ptr(), float(z_ratio), act,
+                                               0 if T is None else T.data_ptr(), 0 if T is None else T.stride(0),
+                                               out.data_ptr(), out.stride(0), n, H, _stream())
+    _check(rc, "glass_dual_linear_fwd_f32")
+
+
+def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out):
+    n, H = dsrc.shape
+    rc = _lib.load().glass_dual_linear_dgrad_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
+                                                 0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
+                                                 stack[5].data_ptr(), n_out, 0 if addend is None else addend.data_ptr(),
+                                                 0 if addend is None else addend.stride(0), out.data_ptr(),
+                                                 out.stride(0), n, H, _stream())
+    _check(rc, "glass_dual_linear_dgrad_f32")
+
+
+def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb):
+    n, H = dout.shape
+    ws = ops._wgrad_workspace(dout.device, n, 2 * H, H if xb is None else 2 * H)
+    rc = _lib.load().glass_dual_linear_wgrad_f32(dout.data_ptr(), dout.stride(0), 0 if T is None else T.data_ptr(),
+                                                 0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
+                                                 xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
+                                                 0 if xb is None else xb.stride(0), n, H, stack[2].data_ptr(),
+                                                 stack[2].stride(0), stack[3].data_ptr(), 1, ws.data_ptr(), _stream())
+    _check(rc, "glass_dual_linear_wgrad_f32")
+
+
+class StackProgram:
+    """Forward / backward of one EmbZGConv over preselected kernels.  `supported(emb)` is the gate."""
+    def __init__(self, emb):
+        self.emb = emb
+
+    @staticmethod
+    def supported(emb):
+        from .models import GLASSConv, _act_code
+        if not ops.USE_FUSED_DENSE or getattr(emb, "_glass_arena", None) is None or emb.gns is None:
+            return False
+        if _act_code(emb.activation) != ACT_ELU or not len(emb.convs):
+            return False
+        H = emb.input_emb.weight.shape[1]
+        if not ops.dual_linear_supported(H):
+            return False
+        for c in emb.convs:
+            st = getattr(c, "_stack", {})
+            if not (isinstance(c, GLASSConv) and _act_code(c.activation) == ACT_ELU and
+                    len(st.get("trans", ())) == 6 and len(st.get("comb", ())) == 6 and
+                    c.trans_fns[0].weight.shape == (H, H) and c.comb_fns[0].weight.shape == (H, 2 * H)):
+                return False
+        mods = [emb.emb_gn] + [c.gn for c in emb.convs] + list(emb.gns)
+        return all(getattr(m, "_direct_grad", False) and m.weight.grad is not None for m in mods) and \
+            emb.input_emb.weight.grad is not None
+
+    # ---------------------------------------------------------------------------------------------
+    def forward(self, x_flat, z, edge_index, edge_weight, keep):
+        """Returns (out, state).  keep=False (no gradient wanted): intermediates are dropped as soon as possible."""
+        from .models import buildAdj
+        emb, lib = self.emb, _lib.load()
+        dev = x_flat.device
+        n = x_flat.shape[0]
+        W = emb.input_emb.weight
+        V, H = W.shape
+        L = len(emb.convs)
+        train = emb.training
+        p = float(emb.dropout) if train else 0.0
+        f32 = dict(dtype=torch.float32, device=dev)
+        if train and (p > 0 or any(c.dropout > 0 for c in emb.convs)):
+            ops.rng_advance(dev)
+        emb._glass_arena.refresh_transposes()  # operand images of the current weights (one launch)
+        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat}
+        # K3+K4: embedding gather + label byte
+        h0 = torch.empty((n, H), **f32)
+        mask = torch.empty(n, dtype=torch.uint8, device=dev)
+        _check(lib.glass_embed_label_f32(x_flat.data_ptr(), W.data_ptr(), V, 0 if z is None else z.data_ptr(), 0, 0,
+                                         h0.data_ptr(), H, mask.data_ptr(), n, H, _stream()), "glass_embed_label_f32")
+        h = torch.empty((n, H), **f32)
+        st["h0"], st["mask"] = h0, mask
+        st["emb_saved"] = _GN(emb.emb_gn).fwd(h0, h, ACT_NONE, p, 1)
+        C_out = H * L if emb.jk else H
+        jk = torch.empty((n, C_out), **f32)
+        layers = []
+        for l, conv in enumerate(emb.convs):
+            if conv.adj is None:
+                conv.adj = buildAdj(edge_index, edge_weight, n, conv.aggr)
+            pc = float(conv.dropout) if train else 0.0
+            T = torch.empty((n, 2 * H), **f32)
+            m = torch.empty((n, H), **f32)
+            _dual_fwd(h, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m)
+            a = conv.adj.fwd.spmm(m)
+            g = torch.empty((n, H), **f32)
+            gsaved = _GN(conv.gn).fwd(a, g, ACT_NONE, pc, conv.call_base)
+            last = l + 1 == L
+            c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
+            _dual_fwd(g, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c)
+            rec = {"h": h, "T": T, "a": a, "g": g, "gsaved": gsaved, "c": c, "pc": pc}
+            if not last:
+                h = torch.empty((n, H), **f32)
+                rec["nsaved"] = _GN(emb.gns[l]).fwd(c, h, ACT_ELU, p, conv.call_base + 1)
+            layers.append(rec if keep else None)
+        out = torch.empty((n, C_out), **f32)
+        st["final_saved"] = _GN(emb.gns[-1]).fwd(jk, out, ACT_NONE, 0.0, 0)
+        st["jk"], st["layers"] = jk, layers
+        return out, (st if keep else None)
+
+    # ---------------------------------------------------------------------------------------------
+    def backward(self, st, dout):
+        emb = self.emb
+        n, H, L, p = st["n"], st["H"], st["L"], st["p"]
+        dev = dout.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        mask, jk = st["mask"], st["jk"]
+        djk = torch.empty_like(jk)
+        _GN(emb.gns[-1]).bwd(dout, jk, st["final_saved"], djk, ACT_NONE, 0.0, 0)
+        dh_next = None   # gradient w.r.t. the input of layer l+1 (= output of gns[l])
+        for l in range(L - 1, -1, -1):
+            conv, rec = emb.convs[l], st["layers"][l]
+            last = l + 1 == L
+            # gradient w.r.t. the raw conv output c_l
+            if last:
+                dc = djk[:, l * H:(l + 1) * H] if emb.jk else djk
+            else:
+                dc = torch.empty((n, H), **f32)
+                _GN(emb.gns[l]).bwd(dh_next, rec["c"], rec["nsaved"], dc, ACT_ELU, p, conv.call_base + 1,
+                                    addend=djk[:, l * H:(l + 1) * H] if emb.jk else None)
+            din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
+            _dual_dgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din)
+            _dual_wgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, rec["g"], rec["h"])
+            da = torch.empty((n, H), **f32)
+            _GN(conv.gn).bwd(din[:, :H], rec["a"], rec["gsaved"], da, ACT_NONE, rec["pc"], conv.call_base)
+            dm = conv.adj.bwd.spmm(da)
+            dh = torch.empty((n, H), **f32)
+            _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh)
+            _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None)
+            dh_next = dh
+            st["layers"][l] = None  # release this layer's activations
+        dh0 = torch.empty((n, H), **f32)
+        _GN(emb.emb_gn).bwd(dh_next, st["h0"], st["emb_saved"], dh0, ACT_NONE, p, 1)
+        # embedding backward: dW += S^T @ dh0 on K1
+        emb.input_emb.weight.grad.add_(emb._selection(st["x_flat"]).op.spmm(dh0))
+
+
+class StackFn(torch.autograd.Function):
+    """autograd node of a whole EmbZGConv.  The parameters are listed as inputs only so that the node is
+    differentiable; their gradients are accumulated in place (arena) and None is returned for them."""
+    @staticmethod
+    def forward(ctx, prog, x_flat, z, edge_index, edge_weight, *params):
+        keep = any(ctx.needs_input_grad)
+        out, st = prog.forward(x_flat, z, edge_index, edge_weight, keep)
+        ctx.prog, ctx.st, ctx.n_in = prog, st, 5 + len(params)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        st, ctx.st = ctx.st, None
+        if st is None:
+            raise RuntimeError("StackFn: backward called twice (activations are released after the first pass)")
+        dout, _ = ops._rows(dout)
+        ctx.prog.backward(st, dout)
+        return (None, ) * ctx.n_in
+
+
+def run(emb, x_flat, z, edge_index, edge_weight):
+    prog = emb.__dict__.get("_glass_stack_prog")
+    if prog is None:
+        prog = emb.__dict__["_glass_stack_prog"] = StackProgram(emb)
+    params = [p for p in emb.parameters() if p.requires_grad]
+    return StackFn.apply(prog, x_flat, z, edge_index, edge_weight, *params)

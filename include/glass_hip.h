@@ -129,7 +129,10 @@ int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, int64_t ldy, 
                             const float* gamma, const float* beta, const float* alpha, float eps, float* saved,
                             int act, float p_drop, const uint64_t* rng_state, uint64_t call_id, void* ws,
                             void* stream);
+/* backward: dx = dGraphNorm(dy) (+ addend when addend != NULL: a second gradient flowing into the same tensor,
+ * e.g. the jumping-knowledge slice next to the next layer's input gradient — saves an elementwise launch). */
 int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx, int64_t lddx,
+                            const float* addend, int64_t ldadd,
                             int64_t n_rows, int64_t C, const float* gamma, const float* alpha, const float* saved,
                             float* dgamma, float* dbeta, float* dalpha, int accumulate /* != 0: add into d* */,
                             int act, float p_drop, const uint64_t* rng_state, uint64_t call_id, void* ws,

@@ -177,9 +177,10 @@ def test_mix(H, act):
 
 
 # ---------------------------------------------------------------------------------- K6
-@pytest.mark.parametrize("n,C", [(4998, 64), (1000, 17), (333, 8), (20000, 128), (513, 300)])
+@pytest.mark.parametrize("n,C", [(4998, 64), (1000, 17), (333, 8), (20000, 128), (513, 300), (70000, 64), (3, 4)])
 @pytest.mark.parametrize("act", [0, 1])
 def test_graphnorm(n, C, act):
+    """(70000, 64): every statistics workgroup loops more than once; (3, 4): fewer rows than row slots."""
     from glass_amd import ops
     gen = torch.Generator().manual_seed(n + C)
     x = torch.randn(n, C, generator=gen) * 2.0 + 5.0  # mean 5 / std 2: the hard case for one-pass variance

@@ -385,3 +385,107 @@ def test_train_epoch_graph_path_matches_eager_path():
     assert np.allclose(results[0][0], results[1][0], rtol=2e-5, atol=0)
     assert rel_inf(results[1][1], results[0][1]) < 1e-4
     assert results[0][0][-1] < results[0][0][0]
+
+
+# ---------------------------------------------------------------------------------- whole-stack program
+def _emb_pair(layers, jk, aggr, z_ratio, dropout, seed, n=700, n_pairs=4000, V=9):
+    """(product EmbZGConv with arena on the GPU, oracle twin with the same weights, inputs)."""
+    import functools
+    from glass_amd import synth
+    from glass_amd.arena import ParamArena
+    from impl import models
+    H = 64
+    torch.manual_seed(seed)
+    emb = models.EmbZGConv(H, H, layers, max_deg=V - 1, activation=nn.ELU(inplace=True), jk=bool(jk), dropout=dropout,
+                           conv=functools.partial(models.GLASSConv, aggr=aggr, z_ratio=z_ratio, dropout=dropout),
+                           gn=True)
+    with torch.no_grad():  # non-trivial GraphNorm parameters
+        for m in emb.modules():
+            if isinstance(m, models.GraphNorm):
+                m.weight.add_(0.2 * torch.randn_like(m.weight))
+                m.bias.add_(0.2 * torch.randn_like(m.bias))
+                m.mean_scale.add_(0.2 * torch.randn_like(m.mean_scale))
+    sd = {k: v.clone() for k, v in emb.state_dict().items()}
+    ei, ew = synth.make_graph(n, n_pairs, seed, 0.0)
+    rng = np.random.default_rng(seed)
+    x = torch.from_numpy(rng.integers(0, V, n)).reshape(n, 1)
+    z = torch.from_numpy((rng.random(n) < 0.1).astype(np.int64))
+    gout = torch.randn(n, H * layers if jk else H, generator=torch.Generator().manual_seed(seed))
+    orc = O.OracleEmbZGConv(H, H, layers, V - 1, dropout, aggr, z_ratio, jk=bool(jk))
+    orc.load_state_dict(sd)
+    emb.to(DEV)
+    arena = ParamArena(emb)
+    return emb, arena, orc, (x, torch.from_numpy(ei), torch.from_numpy(ew), z), gout
+
+
+@pytest.mark.parametrize("layers,jk,aggr", [(1, 1, "mean"), (2, 1, "gcn"), (3, 1, "sum"), (2, 0, "mean"), (3, 0, "gcn")])
+def test_stack_program_vs_oracle(layers, jk, aggr):
+    """EmbZGConv as one forward/backward program (glass_amd/stack.py), hidden 64, against the fp64 oracle:
+    output, every parameter gradient (accumulated in place in the arena), and eval mode."""
+    from glass_amd import stack
+    emb, arena, orc, (x, ei, ew, z), gout = _emb_pair(layers, jk, aggr, 0.85, 0.0, seed=layers * 2 + jk)
+    assert stack.StackProgram.supported(emb)
+    emb.train()
+    args = [t.to(DEV) for t in (x, ei, ew, z)]
+    for _ in range(2):  # twice: activations of the first pass must not leak into the second
+        arena.zero()
+        y = emb(*args)
+        assert isinstance(y.grad_fn, stack.StackFn._backward_cls)
+        y.backward(gout.to(DEV))
+    orc = orc.double().train()
+    yo = orc(x.reshape(-1), ei, ew.double(), z)
+    yo.backward(gout.double())
+    assert rel_inf(y.detach().cpu(), yo.detach()) < TOL
+    mine = {k: p.grad.cpu() for k, p in emb.named_parameters()}
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    keys = sorted(mine)
+    assert rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys)) < TOL
+    for k in keys:  # no tensor may hide behind a larger one in the flat norm
+        assert rel_inf(mine[k], theirs[k]) < 5 * TOL, k
+    emb.eval()
+    with torch.no_grad():
+        ye = emb(*args[:3], None)
+    assert rel_inf(ye.cpu(), orc.eval()(x.reshape(-1), ei, ew.double(), None).detach()) < TOL
+
+
+def test_stack_program_matches_per_op_path_with_dropout(monkeypatch):
+    """Same kernels, same Philox call ids: with dropout 0.5 the program and the per-op autograd path must draw the
+    same masks, so outputs and gradients agree to rounding (the gradient sums are merely associated differently)."""
+    from glass_amd import models as gm, ops
+    emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.95, 0.5, seed=11)
+    emb.train()
+    args = [t.to(DEV) for t in (x, ei, ew, z)]
+    res = []
+    for use in (True, False):
+        monkeypatch.setattr(gm, "USE_STACK", use)
+        ops.rng_seed(1234, torch.device(DEV))
+        arena.zero()
+        y = emb(*args)
+        y.backward(gout.to(DEV))
+        res.append((y.detach().clone(), arena.flat.clone()))
+    assert float((res[0][0] == 0).float().mean()) < 0.01  # final GraphNorm output: dropout acts upstream only
+    assert rel_inf(res[0][0].cpu(), res[1][0].cpu()) < 1e-6
+    assert rel_inf(res[0][1].cpu(), res[1][1].cpu()) < 1e-6
+
+
+def test_eval_after_optimizer_step_uses_current_weights():
+    """The fused dense kernels read packed operand images of the weights; they must be re-packed whenever the
+    weights may have changed, also for a no-grad evaluation right after an optimizer step."""
+    from glass_amd.optim import FlatAdam
+    emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.9, 0.0, seed=3)
+    args = [t.to(DEV) for t in (x, ei, ew, z)]
+    opt = FlatAdam(arena, lr=0.05)
+    emb.train()
+    arena.zero()
+    emb(*args).backward(gout.to(DEV))
+    opt.step()
+    emb.eval()
+    with torch.no_grad():
+        y1 = emb(*args)
+    arena.refresh_transposes()
+    with torch.no_grad():
+        y2 = emb(*args)
+    assert torch.equal(y1, y2)
+    sd = {k: v.detach().cpu().clone() for k, v in emb.state_dict().items()}
+    _orc.load_state_dict(sd)
+    assert rel_inf(y1.cpu(), _orc.double().eval()(x.reshape(-1), ei, ew.double(), z).detach()) < TOL
