@@ -48,6 +48,7 @@ SIGNATURES = {
     "glass_graphnorm_bwd_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float,
                                         _P, c_uint64, _P, _P]),
     "glass_rng_advance": (c_int, [_P, _P]),
+    "glass_linear_wgrad_reduce_batch_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "glass_segment_pool_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _I, _P, _I, _I, _P]),
     "glass_segment_pool_bwd_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _P, _I, _I, _I, _P]),
     "glass_linear_wgrad_ws_bytes": (c_int64, [_I, _I, _I]),
@@ -57,7 +58,7 @@ SIGNATURES = {
     "glass_dual_linear_dgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, _P, _I, _I, _I, _P]),
     "glass_dual_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, _I, _P,
                                             c_int, _P, _P]),
-    "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _I, _P]),
+    "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _I, _P, _P]),
     "glass_head_loss_fwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _I, _I, _I, _P, _P, _P, _P]),
     "glass_head_loss_bwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _P, _I, _I, _I, _P, _I, _P, _P, c_int, _P]),
     "glass_adam_step_f32": (c_int, [_P, _P, _P, _P, _I, _P, c_double, c_double, c_double, c_double, _P, _P]),

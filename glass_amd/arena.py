@@ -106,15 +106,19 @@ class ParamArena(FlatGradBucket):
                 mod._glass_arena = self  # EmbZGConv.forward refreshes the images once per training forward
         self.refresh_transposes()
 
-    def refresh_transposes(self):
+    def refresh_transposes(self, rng_state=None):
         """Re-pack every stacked weight into the operand images of the fused dense kernels (forward: W,
-        data gradient: W^T): one launch for the whole model."""
+        data gradient: W^T): one launch for the whole model.  rng_state (the device-resident dropout counter,
+        ops.rng_state): advanced by the same launch — the two once-per-step prologue jobs share it."""
         src, dst, nt, kt, tr, k = self._pack_args
-        from . import _lib
+        from . import _lib, ops
+        if k == 0 and rng_state is not None:
+            ops.rng_advance(rng_state.device)
         for i in range(0, k, 16):
             n = min(16, k - i)
             rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
                                                         kt[i:].ctypes.data, tr[i:].ctypes.data, n,
+                                                        rng_state.data_ptr() if (rng_state is not None and i == 0) else 0,
                                                         torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "glass_dense_pack_batch_f32")
 

@@ -272,7 +272,8 @@ struct PackBatch {
     PackJob job[kMaxPackJobs];
 };
 
-__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch) {
+__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state) {
+    if (rng_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rng_state[1] += 1;  // see glass_rng_advance
     const PackJob j = batch.job[blockIdx.y];
     const int KQ = j.KT / 4, NTILES = j.NT / 16, NKC = KQ / kKC;
     const int total = NKC * NTILES * 4 * 64;  // float4 elements
@@ -381,10 +382,11 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
 }
 
 extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,
-                                          const int64_t* KT, const int32_t* transposed, int64_t n_jobs, void* stream) {
+                                          const int64_t* KT, const int32_t* transposed, int64_t n_jobs,
+                                          uint64_t* rng_state, void* stream) {
     GLASS_REQUIRE(src && dst && NT && KT && transposed && n_jobs >= 0 && n_jobs <= kMaxPackJobs,
                   "dense_pack_batch: bad arguments (at most %d matrices per call)", kMaxPackJobs);
-    if (n_jobs == 0) return 0;
+    if (n_jobs == 0) return rng_state ? glass_rng_advance(rng_state, stream) : 0;
     PackBatch b;
     for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0};
     for (int k = 0; k < n_jobs; ++k) {
@@ -393,6 +395,7 @@ extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const*
                       "dense_pack_batch: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", k);
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k]};
     }
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(32, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(32, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream, b,
+                       rng_state);
     return launch_status("glass_dense_pack_batch_f32");
 }

@@ -178,12 +178,10 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
 // Sum the slab partials and scatter to dW[o,i] / db[o].  A [n_slabs x 8192(+128)] column reduction:
 // 16 lanes x float4 cover 64 columns, 16 row slots walk the slabs (4 loads in flight each) and are
 // combined through LDS in slot order -> fixed summation order.
-__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part_w,
-                                                              const float* __restrict__ part_b, int n_slabs, int ny,
-                                                              int O, int I, float* __restrict__ dW, int64_t lddw,
-                                                              float* __restrict__ db, int accumulate) {
-    __shared__ float4 lds[kBlock];
-    const int chunk = blockIdx.y;  // (z * ny + y)
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part_w, const float* __restrict__ part_b,
+                                                  int n_slabs, int ny, int O, int I, float* __restrict__ dW,
+                                                  int64_t lddw, float* __restrict__ db, int accumulate, float4* lds,
+                                                  int chunk /* z * ny + y */) {
     const int z = chunk / ny, y = chunk % ny;
     const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
     const int k0 = blockIdx.x * 64 + tc * 4;       // first of this thread's 4 columns
@@ -238,6 +236,35 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __res
     }
 }
 
+__global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part_w,
+                                                              const float* __restrict__ part_b, int n_slabs, int ny,
+                                                              int O, int I, float* __restrict__ dW, int64_t lddw,
+                                                              float* __restrict__ db, int accumulate) {
+    __shared__ float4 lds[kBlock];
+    wgrad_reduce_body(part_w, part_b, n_slabs, ny, O, I, dW, lddw, db, accumulate, lds, blockIdx.y);
+}
+
+// Several weight gradients reduced by ONE launch (blockIdx.z = job): the partial kernels of a backward pass write to
+// separate scratch buffers and their reductions are deferred to the end of the pass (glass_linear_wgrad_reduce_batch_f32).
+struct ReduceJob {
+    const float *part_w, *part_b;
+    int n_slabs, ny, nz, O, I, accumulate;
+    float* dW;
+    int64_t lddw;
+    float* db;
+};
+constexpr int kMaxReduceJobs = 8;
+struct ReduceBatch {
+    ReduceJob job[kMaxReduceJobs];
+};
+
+__global__ __launch_bounds__(kBlock) void wgrad_reduce_batch_kernel(ReduceBatch batch) {
+    __shared__ float4 lds[kBlock];
+    const ReduceJob& j = batch.job[blockIdx.z];
+    if ((int)blockIdx.y >= j.ny * j.nz) return;
+    wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
+}
+
 struct WgradGeom {
     int n_slabs, rows_per_slab, ny, nz;
     int64_t part_w_floats, part_b_floats;
@@ -267,14 +294,16 @@ static WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
 // ---- fused Adam over the flat parameter arena --------------------------------------------------
 // torch.optim.Adam (single-tensor formulation, amsgrad=False, maximize=False):
 //   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
-__global__ void adam_step_count_kernel(int64_t* step) { step[0] += 1; }
-
+// step_dev = int64[2]: (steps completed, ticket).  Every workgroup reads the count first and takes a ticket last;
+// the workgroup that takes the last ticket publishes count + 1 and clears the ticket — the bias correction needs
+// no counter kernel of its own (a dependent launch of ~4 us on a ~500 us step).
 __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                       float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                       const float* __restrict__ lr_dev, float beta1, float beta2,
                                                       float eps, float weight_decay,
-                                                      const int64_t* __restrict__ step_dev) {
-    const double t = (double)step_dev[0];
+                                                      int64_t* __restrict__ step_dev) {
+    const int64_t step_now = step_dev[0] + 1;
+    const double t = (double)step_now;
     const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
     const float step_size = (float)((double)lr_dev[0] / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
@@ -289,6 +318,14 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, con
         v[k] = vk;
         const float denom = sqrtf(vk) / bc2_sqrt + eps;
         p[k] = pk - step_size * (mk / denom);
+    }
+    __syncthreads();  // every thread of this workgroup has read step_dev[0]
+    if (threadIdx.x == 0) {
+        const unsigned long long taken = atomicAdd(reinterpret_cast<unsigned long long*>(step_dev + 1), 1ull) + 1ull;
+        if (taken == gridDim.x) {
+            step_dev[1] = 0;
+            step_dev[0] = step_now;
+        }
     }
 }
 
@@ -327,9 +364,9 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
                                            const uint8_t* mask, double z_ratio, int act, const float* X, int64_t ldx,
                                            const float* X2, int64_t ldx2, int64_t N, int64_t H, float* dW,
                                            int64_t lddw, float* db, int accumulate, void* ws, void* stream) {
-    GLASS_REQUIRE(dsrc && mask && X && dW && ws && N > 0 && H > 0, "dual_linear_wgrad: null pointer");
+    GLASS_REQUIRE(dsrc && mask && X && ws && N > 0 && H > 0, "dual_linear_wgrad: null pointer");
     const int64_t O = 2 * H, I = X2 ? 2 * H : H;
-    GLASS_REQUIRE(ldd >= H && ldx >= H && lddw >= I && (!X2 || ldx2 >= H) && (act == GLASS_ACT_NONE || (T && ldt >= O)),
+    GLASS_REQUIRE(ldd >= H && ldx >= H && (!dW || lddw >= I) && (!X2 || ldx2 >= H) && (act == GLASS_ACT_NONE || (T && ldt >= O)),
                   "dual_linear_wgrad: bad sizes");
     if (H % 64 || ldd % 4 || ldx % 2 || (X2 && ldx2 % 2) || !aligned16(dsrc) || (reinterpret_cast<uintptr_t>(X) & 7u) ||
         (X2 && (reinterpret_cast<uintptr_t>(X2) & 7u)) || (act != GLASS_ACT_NONE && (ldt % 4 || !aligned16(T)))) {
@@ -343,10 +380,38 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     const WgradSynth sy{dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
                         act, (int)H, X2, ldx2};
     hipLaunchKernelGGL(wgrad_partial_kernel<true>, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X, ldx,
-                       N, (int)O, (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr, sy);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st, part_w, part_b,
-                       g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
+                       N, (int)O, (int)I, g.rows_per_slab, part_w, (db || !dW) ? part_b : nullptr, sy);
+    if (dW)  // dW == NULL: partial sums only; the caller reduces later with glass_linear_wgrad_reduce_batch_f32
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st, part_w,
+                           part_b, g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
     return launch_status("glass_dual_linear_wgrad_f32");
+}
+
+extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, const int64_t* N,
+                                                   const int64_t* O, const int64_t* I, float* const* dW,
+                                                   const int64_t* lddw, float* const* db, const int32_t* accumulate,
+                                                   void* stream) {
+    GLASS_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (ws && N && O && I && dW && lddw && db && accumulate)),
+                  "wgrad_reduce_batch: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    for (int64_t j0 = 0; j0 < n_jobs; j0 += kMaxReduceJobs) {
+        const int nj = (int)(n_jobs - j0 < kMaxReduceJobs ? n_jobs - j0 : kMaxReduceJobs);
+        ReduceBatch b;
+        int max_chunks = 0;
+        for (int k = 0; k < kMaxReduceJobs; ++k) b.job[k] = ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
+        for (int k = 0; k < nj; ++k) {
+            const int64_t j = j0 + k;
+            GLASS_REQUIRE(ws[j] && dW[j] && N[j] > 0 && O[j] > 0 && I[j] > 0 && lddw[j] >= I[j],
+                          "wgrad_reduce_batch: bad job %lld", (long long)j);
+            const WgradGeom g = wgrad_geom(N[j], O[j], I[j]);
+            const float* part_w = (const float*)ws[j];
+            b.job[k] = ReduceJob{part_w, part_w + g.part_w_floats, g.n_slabs, g.ny, g.nz, (int)O[j], (int)I[j],
+                                 accumulate[j], dW[j], lddw[j], db[j]};
+            if (g.ny * g.nz > max_chunks) max_chunks = g.ny * g.nz;
+        }
+        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((kTile + kOT) / 64, max_chunks, nj), dim3(kBlock), 0, st, b);
+    }
+    return launch_status("glass_linear_wgrad_reduce_batch_f32");
 }
 
 extern "C" int glass_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
@@ -354,7 +419,6 @@ extern "C" int glass_adam_step_f32(float* param, const float* grad, float* exp_a
                                    int64_t* step_dev, void* stream) {
     GLASS_REQUIRE(param && grad && exp_avg && exp_avg_sq && lr_dev && step_dev && n > 0, "adam_step: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(adam_step_count_kernel, dim3(1), dim3(1), 0, st, step_dev);
     int64_t blocks = ceil_div(n, kBlock);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, param, grad, exp_avg, exp_avg_sq, n,

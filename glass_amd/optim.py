@@ -14,7 +14,7 @@ class FlatAdam(torch.optim.Optimizer):
         dev = arena.flat.device
         self.exp_avg = torch.zeros_like(arena.flat)
         self.exp_avg_sq = torch.zeros_like(arena.flat)
-        self.step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.step_dev = torch.zeros(2, dtype=torch.int64, device=dev)  # (steps completed, kernel ticket)
         self.lr_dev = torch.full((1, ), float(lr), dtype=torch.float32, device=dev)
         self._lr_host = float(lr)
 

@@ -12,6 +12,7 @@ Used when every layer takes the fused dense path (ParamArena present, GLASSConv 
 glass_dual_linear_supported() accepts, ELU, GraphNorm on); anything else keeps the per-op path.  Same kernels,
 same Philox call ids -> same dropout masks as the per-op path.
 """
+import numpy as np
 import torch
 
 from . import _lib, ops
@@ -74,15 +75,33 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out):
     _check(rc, "glass_dual_linear_dgrad_f32")
 
 
-def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb):
+def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending):
+    """Per-slab partial sums of dW / db into a scratch buffer of their own; the reduction into the gradient arena
+    is deferred to ONE launch at the end of the backward pass (`_reduce_pending`)."""
     n, H = dout.shape
-    ws = ops._wgrad_workspace(dout.device, n, 2 * H, H if xb is None else 2 * H)
+    I = H if xb is None else 2 * H
+    ws = ops._wgrad_workspace(dout.device, n, 2 * H, I, slot=("stack", len(pending)))
     rc = _lib.load().glass_dual_linear_wgrad_f32(dout.data_ptr(), dout.stride(0), 0 if T is None else T.data_ptr(),
                                                  0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
                                                  xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
-                                                 0 if xb is None else xb.stride(0), n, H, stack[2].data_ptr(),
-                                                 stack[2].stride(0), stack[3].data_ptr(), 1, ws.data_ptr(), _stream())
+                                                 0 if xb is None else xb.stride(0), n, H, 0, 0, 0, 1, ws.data_ptr(),
+                                                 _stream())
     _check(rc, "glass_dual_linear_wgrad_f32")
+    pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), 1))
+
+
+def _reduce_pending(pending):
+    if not pending:
+        return
+    cols = list(zip(*pending))
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    i64 = lambda v: np.array(v, dtype=np.int64)
+    ws, N, O, I, dW, ld, db = u64(cols[0]), i64(cols[1]), i64(cols[2]), i64(cols[3]), u64(cols[4]), i64(cols[5]), u64(cols[6])
+    acc = np.array(cols[7], dtype=np.int32)
+    rc = _lib.load().glass_linear_wgrad_reduce_batch_f32(len(pending), ws.ctypes.data, N.ctypes.data, O.ctypes.data,
+                                                         I.ctypes.data, dW.ctypes.data, ld.ctypes.data, db.ctypes.data,
+                                                         acc.ctypes.data, _stream())
+    _check(rc, "glass_linear_wgrad_reduce_batch_f32")
 
 
 class StackProgram:
@@ -123,9 +142,9 @@ class StackProgram:
         train = emb.training
         p = float(emb.dropout) if train else 0.0
         f32 = dict(dtype=torch.float32, device=dev)
-        if train and (p > 0 or any(c.dropout > 0 for c in emb.convs)):
-            ops.rng_advance(dev)
-        emb._glass_arena.refresh_transposes()  # operand images of the current weights (one launch)
+        # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
+        advance = train and (p > 0 or any(c.dropout > 0 for c in emb.convs))
+        emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
         st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat}
         # K3+K4: embedding gather + label byte
         h0 = torch.empty((n, H), **f32)
@@ -171,6 +190,7 @@ class StackProgram:
         djk = torch.empty_like(jk)
         _GN(emb.gns[-1]).bwd(dout, jk, st["final_saved"], djk, ACT_NONE, 0.0, 0)
         dh_next = None   # gradient w.r.t. the input of layer l+1 (= output of gns[l])
+        pending = []     # weight gradients whose partial sums are written but not yet reduced
         for l in range(L - 1, -1, -1):
             conv, rec = emb.convs[l], st["layers"][l]
             last = l + 1 == L
@@ -183,15 +203,16 @@ class StackProgram:
                                     addend=djk[:, l * H:(l + 1) * H] if emb.jk else None)
             din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
             _dual_dgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din)
-            _dual_wgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, rec["g"], rec["h"])
+            _dual_wgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, rec["g"], rec["h"], pending)
             da = torch.empty((n, H), **f32)
             _GN(conv.gn).bwd(din[:, :H], rec["a"], rec["gsaved"], da, ACT_NONE, rec["pc"], conv.call_base)
             dm = conv.adj.bwd.spmm(da)
             dh = torch.empty((n, H), **f32)
             _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh)
-            _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None)
+            _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None, pending)
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations
+        _reduce_pending(pending)
         dh0 = torch.empty((n, H), **f32)
         _GN(emb.emb_gn).bwd(dh_next, st["h0"], st["emb_saved"], dh0, ACT_NONE, p, 1)
         # embedding backward: dW += S^T @ dh0 on K1

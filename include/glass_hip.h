@@ -196,11 +196,20 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
                                 double z_ratio, int act, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
                                 int64_t N, int64_t H, float* dW, int64_t lddw, float* db, int accumulate, void* ws,
                                 void* stream);
+/*     Deferred reduction: glass_dual_linear_wgrad_f32 with dW == NULL only writes the per-slab partial sums
+ *     into `ws` (one scratch buffer per pending gradient); this call then reduces n_jobs of them — job j is
+ *     the gradient of a [O[j], I[j]] weight over N[j] rows — into dW[j] / db[j] (db[j] may be NULL) with ONE
+ *     launch.  All array arguments are HOST arrays. */
+int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, const int64_t* N, const int64_t* O,
+                                        const int64_t* I, float* const* dW, const int64_t* lddw, float* const* db,
+                                        const int32_t* accumulate, void* stream);
 /*     Pack up to 16 weight operands B[NT][KT] (NT, KT multiples of 64) into MFMA image order in one launch.
  *     transposed[k] == 0: B = src[k] ([NT][KT] row-major); 1: B[n][k] = src[k][k][n] (src is [KT][NT]).
  *     dst[k] holds NT*KT floats.  The pointer / size arrays are HOST arrays. */
+/*     rng_state (may be NULL): the same launch also advances the dropout stream, rng_state[1] += 1 (both are
+ *     once-per-step prologue work; equivalent to a following glass_rng_advance). */
 int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
-                               const int32_t* transposed, int64_t n_jobs, void* stream);
+                               const int32_t* transposed, int64_t n_jobs, uint64_t* rng_state, void* stream);
 
 /* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
  *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened
@@ -217,7 +226,9 @@ int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const float* W, co
 
 /* K9  Adam over a flat parameter arena (torch.optim.Adam as used at GLASSTest.py:213; amsgrad
  *     off): one launch for all parameters.  lr and the step counter live in DEVICE memory so a
- *     captured graph follows ReduceLROnPlateau and advances its own bias correction. */
+ *     captured graph follows ReduceLROnPlateau and advances its own bias correction.
+ *     step_dev = int64[2]: [0] = steps completed (the launch uses [0]+1 and stores it back), [1] = scratch
+ *     ticket counter, zero between launches. */
 int glass_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
                         int64_t* step_dev, void* stream);

@@ -383,6 +383,26 @@ def test_flat_adam_matches_torch_adam():
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert rel_inf(pa.detach().cpu(), pb.detach().cpu()) < 1e-6
     assert arena.attached()
+    assert oa.step_dev.tolist() == [5, 0]  # (steps completed, ticket back at zero): counted inside the Adam launch
+
+
+def test_pack_launch_advances_dropout_stream():
+    """glass_dense_pack_batch_f32(rng_state) == pack + glass_rng_advance in one launch."""
+    from glass_amd import _lib, ops
+    dev = torch.device(DEV)
+    ops.rng_seed(77, dev)
+    st = ops.rng_state(dev)
+    W = torch.randn(128, 64, device=DEV)
+    img = torch.empty(W.numel(), device=DEV)
+    src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
+    nts, kts, trs = np.array([128], dtype=np.int64), np.array([64], dtype=np.int64), np.array([0], dtype=np.int32)
+    for expect in (1, 2):
+        rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+                                                    trs.ctypes.data, 1, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0 and st.tolist() == [77, expect]
+    assert torch.equal(img, _pack(W, False))
+    rc = _lib.load().glass_dense_pack_batch_f32(0, 0, 0, 0, 0, 0, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc != 0  # null arrays are rejected even for zero jobs
 
 
 def test_graphnorm_scratch_reuse_stress():
@@ -481,7 +501,7 @@ def _pack(W, transposed):
     nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
     trs = np.array([int(transposed)], dtype=np.int32)
     rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
-                                                trs.ctypes.data, 1, torch.cuda.current_stream().cuda_stream)
+                                                trs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     return img
 
