@@ -80,4 +80,34 @@ __device__ __forceinline__ float keep_scale(uint32_t word, float p_drop, float i
     return u >= p_drop ? inv_keep : 0.f;
 }
 
+// Inverted-dropout configuration shared by every kernel that draws or re-draws a mask: the mask of element
+// (row, col) is word col%4 of Philox(seed, step, call_id, row*cw4 + col/4), independent of vector width / ld.
+struct Drop {
+    float p, inv_keep;
+    uint64_t seed, step, call_id;
+    int cw4;  // ceil(C/4)
+};
+
+inline Drop make_drop(float p, uint64_t call_id, int64_t C) {
+    Drop d;
+    d.p = p;
+    d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    d.seed = d.step = 0;
+    d.call_id = call_id;
+    d.cw4 = (int)ceil_div(C, 4);
+    return d;
+}
+
+template <int VW>
+__device__ __forceinline__ void drop_scales(const Drop& d, int64_t row, int c0, float (&s)[VW]) {
+    uint32_t w[4];
+    philox4(d.seed, d.step, d.call_id, (uint64_t)row * d.cw4 + (c0 >> 2), w);
+    if (VW == 4) {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) s[k] = keep_scale(w[k], d.p, d.inv_keep);
+    } else {
+        s[0] = keep_scale(w[c0 & 3], d.p, d.inv_keep);
+    }
+}
+
 }  // namespace glass

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
                                                             const uint8_t* __restrict__ mask, float zr, float omz,
                                                             int act, const float* __restrict__ WT,
                                                             const float* __restrict__ addend, int64_t ldadd,
+                                                            Drop drop, const uint64_t* __restrict__ rng_state,
                                                             float* __restrict__ out, int64_t ldo, int64_t N) {
     constexpr int KT = 2 * H, KQ = KT / 4, NTILES = NT / 16;
     static_assert(KQ % kKC == 0, "hidden size must be a multiple of 32");
@@ -240,6 +241,10 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
 #pragma unroll
         for (int s = 0; s < kKC; ++s) a[s] *= coef;
     });
+    if (drop.p > 0.f) {
+        drop.seed = rng_state[0];
+        drop.step = rng_state[1];
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = row0 + 4 * q + reg;
@@ -251,6 +256,11 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
             if (addend) {
                 const float4 ad = *reinterpret_cast<const float4*>(addend + r * ldadd + c);
                 v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+            }
+            if (drop.p > 0.f) {  // gradient w.r.t. the pre-dropout tensor: same mask as the forward drew
+                float ds[4];
+                drop_scales<4>(drop, r, c, ds);
+                v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
             }
             *reinterpret_cast<float4*>(out + r * ldo + c) = v;
         }
@@ -349,9 +359,12 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
 
 extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt,
                                            const uint8_t* mask, double z_ratio, int act, const float* WT,
-                                           int64_t n_out, const float* addend, int64_t ldadd, float* out, int64_t ldo,
+                                           int64_t n_out, const float* addend, int64_t ldadd, float p_drop,
+                                           const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo,
                                            int64_t n_nodes, int64_t H, void* stream) {
     GLASS_REQUIRE(dsrc && mask && WT && out && n_nodes > 0, "dual_linear_dgrad: null pointer");
+    GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (rng_state && n_out == H)),
+                  "dual_linear_dgrad: bad dropout args (the masked output must be the [N,H] layer input)");
     if (!dense_shape_ok(H) || (n_out != H && n_out != 2 * H)) {
         set_error("dual_linear_dgrad: unsupported shape H=%lld n_out=%lld", (long long)H, (long long)n_out);
         return GLASS_E_UNSUPPORTED;
@@ -365,16 +378,17 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     const float* Tp = act == GLASS_ACT_ELU ? T : nullptr;
     const size_t image = (size_t)n_out * 256;  // K = 2H always needs >= 2 passes
+    const Drop drop = make_drop(p_drop, call_id, n_out);
 #define GLASS_DG(HH)                                                                                               \
     if (H == HH) {                                                                                                 \
         allow_lds(dual_dgrad_kernel<HH, HH>, 2 * image);                                                           \
         allow_lds(dual_dgrad_kernel<HH, 2 * HH>, 2 * image);                                                       \
         if (n_out == H)                                                                                            \
             hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, mask, \
-                               zr, omz, act, WT, addend, ldadd, out, ldo, n_nodes);                                \
+                               zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes);               \
         else                                                                                                       \
             hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, \
-                               mask, zr, omz, act, WT, addend, ldadd, out, ldo, n_nodes);                          \
+                               mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes);         \
     }
     GLASS_DG(64) GLASS_DG(128)
 #undef GLASS_DG

@@ -9,6 +9,7 @@
 // 4 rows in flight per thread.  Column sums are fp64, combined across row slots through LDS and
 // across workgroups by a second tiny kernel in fixed order -> bitwise repeatable.
 #include "common.h"
+#include "gn_math.h"
 
 namespace glass {
 
@@ -68,26 +69,6 @@ template <int VW>
 __device__ __forceinline__ void load_cols(float (&dst)[VW], const float* src, int c0, int C) {
 #pragma unroll
     for (int k = 0; k < VW; ++k) dst[k] = (c0 + k < C) ? src[c0 + k] : 0.f;
-}
-
-struct Drop {
-    float p, inv_keep;
-    uint64_t seed, step, call_id;
-    int cw4;  // ceil(C/4): Philox counter = row*cw4 + col/4, word = col%4 (independent of VW / ld)
-};
-
-template <int VW>
-__device__ __forceinline__ void drop_scales(const Drop& d, int64_t row, int c0, float (&s)[VW]) {
-    if (VW == 4) {
-        uint32_t w[4];
-        philox4(d.seed, d.step, d.call_id, (uint64_t)row * d.cw4 + (c0 >> 2), w);
-#pragma unroll
-        for (int k = 0; k < VW; ++k) s[k] = keep_scale(w[k], d.p, d.inv_keep);
-    } else {
-        uint32_t w[4];
-        philox4(d.seed, d.step, d.call_id, (uint64_t)row * d.cw4 + (c0 >> 2), w);
-        s[0] = keep_scale(w[c0 & 3], d.p, d.inv_keep);
-    }
 }
 
 // Reduce this thread's 2*VW fp64 accumulators over the row slots of the workgroup (fixed order)
@@ -179,17 +160,8 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_fwd_kernel(const double* _
             s += lds[(r * 16 + tc) * 2];
             q += lds[(r * 16 + tc) * 2 + 1];
         }
-        const double a = (double)alpha[c];
-        const double mu = s / (double)N;
-        // mean((x - a*mu)^2) = E[x^2] - mu^2 * (2a - a^2)   (exact in fp64 for fp32 data)
-        double var = q / (double)N - mu * mu * (2.0 * a - a * a);
-        if (var < 0.0) var = 0.0;
-        const double rstd = 1.0 / sqrt(var + (double)eps);
-        const double scale = (double)gamma[c] * rstd;
-        saved[c] = (float)mu;
-        saved[C + c] = (float)rstd;
-        saved[2 * C + c] = (float)scale;
-        saved[3 * C + c] = (float)((double)beta[c] - scale * a * mu);
+        gn_fwd_coeffs(s, q, (double)N, gamma[c], beta[c], alpha[c], eps, saved[c], saved[C + c], saved[2 * C + c],
+                      saved[3 * C + c]);
     }
 }
 
@@ -332,21 +304,12 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_bwd_kernel(const double* _
             s1 += lds[(r * 16 + tc) * 2];
             s2 += lds[(r * 16 + tc) * 2 + 1];
         }
-        const double n = (double)N, g = (double)gamma[c], a = (double)alpha[c];
-        const double mu = (double)saved[c], r = (double)saved[C + c];
-        const double m2 = s2 / n;
-        const double sum_xhat = r * n * mu * (1.0 - a);          // sum_n (x_n - a*mu) * r
-        const double sum_do = g * r * (s1 - sum_xhat * m2);       // sum_n d o_n
+        float da;
+        gn_bwd_coeffs(s1, s2, (double)N, gamma[c], alpha[c], saved[c], saved[C + c], coef[c], coef[C + c],
+                      coef[2 * C + c], da);
         if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
         if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-        if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + (float)(-mu * sum_do);
-        // dx = do - a*mean(do),  do = g*r*(gr - xhat*m2),  xhat = (x - a*mu)*r
-        const double A = g * r;
-        const double Bx = -g * r * r * m2;
-        const double K = g * r * r * m2 * a * mu - a * (sum_do / n);
-        coef[c] = (float)A;
-        coef[C + c] = (float)Bx;
-        coef[2 * C + c] = (float)K;
+        if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + da;
     }
 }
 
@@ -407,16 +370,6 @@ static unsigned apply_blocks(int64_t n_rows, const Tiling& t) {
     if (b < 1) b = 1;
     if (b > 4096) b = 4096;
     return (unsigned)b;
-}
-
-static Drop make_drop(float p, uint64_t call_id, int64_t C) {
-    Drop d;
-    d.p = p;
-    d.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
-    d.seed = d.step = 0;
-    d.call_id = call_id;
-    d.cw4 = (int)ceil_div(C, 4);
-    return d;
 }
 
 }  // namespace glass

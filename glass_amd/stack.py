@@ -19,6 +19,11 @@ from . import _lib, ops
 from .ops import ACT_ELU, ACT_NONE, _stream
 
 
+import os
+
+USE_EMBED_TABLE = os.environ.get("GLASS_EMBED_TABLE", "1") != "0"  # A/B switch: lookup + emb_gn through the table
+
+
 def _check(rc, what):
     _lib.check(rc, what)
 
@@ -65,13 +70,16 @@ def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out):
     _check(rc, "glass_dual_linear_fwd_f32")
 
 
-def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out):
+def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=None):
+    """drop = (p, call_id): also multiply by that dropout's mask (gradient w.r.t. the pre-dropout layer input)."""
     n, H = dsrc.shape
+    p_drop, call_id = drop if drop is not None else (0.0, 0)
+    rng = ops.rng_state(dsrc.device).data_ptr() if p_drop > 0 else 0
     rc = _lib.load().glass_dual_linear_dgrad_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
                                                  0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
                                                  stack[5].data_ptr(), n_out, 0 if addend is None else addend.data_ptr(),
-                                                 0 if addend is None else addend.stride(0), out.data_ptr(),
-                                                 out.stride(0), n, H, _stream())
+                                                 0 if addend is None else addend.stride(0), float(p_drop), rng, call_id,
+                                                 out.data_ptr(), out.stride(0), n, H, _stream())
     _check(rc, "glass_dual_linear_dgrad_f32")
 
 
@@ -146,14 +154,30 @@ class StackProgram:
         advance = train and (p > 0 or any(c.dropout > 0 for c in emb.convs))
         emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
         st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat}
-        # K3+K4: embedding gather + label byte
-        h0 = torch.empty((n, H), **f32)
         mask = torch.empty(n, dtype=torch.uint8, device=dev)
-        _check(lib.glass_embed_label_f32(x_flat.data_ptr(), W.data_ptr(), V, 0 if z is None else z.data_ptr(), 0, 0,
-                                         h0.data_ptr(), H, mask.data_ptr(), n, H, _stream()), "glass_embed_label_f32")
         h = torch.empty((n, H), **f32)
-        st["h0"], st["mask"] = h0, mask
-        st["emb_saved"] = _GN(emb.emb_gn).fwd(h0, h, ACT_NONE, p, 1)
+        st["mask"] = mask
+        gn0 = emb.emb_gn
+        if V <= _lib.EMBED_NORM_MAX_ROWS and USE_EMBED_TABLE:
+            # K3n: lookup + emb_gn + dropout through the V-row table (statistics are count-weighted sums over W)
+            sel = emb._selection(x_flat)
+            saved = torch.empty(4 * H, **f32)
+            table = torch.empty((V, H), **f32)
+            rng = ops.rng_state(dev).data_ptr() if p > 0 else 0
+            _check(lib.glass_embed_norm_fwd_f32(x_flat.data_ptr(), W.data_ptr(), V, sel.op.rowptr.data_ptr(),
+                                                gn0.weight.data_ptr(), gn0.bias.data_ptr(), gn0.mean_scale.data_ptr(),
+                                                float(gn0.eps), saved.data_ptr(), table.data_ptr(),
+                                                0 if z is None else z.data_ptr(), 0, 0, p, rng, 1, h.data_ptr(), H,
+                                                mask.data_ptr(), n, H, _stream()), "glass_embed_norm_fwd_f32")
+            st["emb_table"], st["emb_saved"] = sel, saved
+        else:
+            # K3+K4: embedding gather + label byte, then the whole-graph GraphNorm
+            h0 = torch.empty((n, H), **f32)
+            _check(lib.glass_embed_label_f32(x_flat.data_ptr(), W.data_ptr(), V, 0 if z is None else z.data_ptr(), 0,
+                                             0, h0.data_ptr(), H, mask.data_ptr(), n, H, _stream()),
+                   "glass_embed_label_f32")
+            st["h0"] = h0
+            st["emb_saved"] = _GN(gn0).fwd(h0, h, ACT_NONE, p, 1)
         C_out = H * L if emb.jk else H
         jk = torch.empty((n, C_out), **f32)
         layers = []
@@ -208,15 +232,28 @@ class StackProgram:
             _GN(conv.gn).bwd(din[:, :H], rec["a"], rec["gsaved"], da, ACT_NONE, rec["pc"], conv.call_base)
             dm = conv.adj.bwd.spmm(da)
             dh = torch.empty((n, H), **f32)
-            _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh)
+            # layer 0 on the table path: the epilogue applies emb_gn's dropout mask (call id 1)
+            drop = (p, 1) if (l == 0 and "emb_table" in st) else None
+            _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, drop)
             _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None, pending)
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations
         _reduce_pending(pending)
+        W, gn0 = emb.input_emb.weight, emb.emb_gn
+        if "emb_table" in st:
+            sel = st["emb_table"]
+            G = sel.op.spmm(dh_next)  # [V,H]: per table row, the sum of its nodes' (masked) gradients, on K1
+            _check(_lib.load().glass_embed_norm_bwd_f32(G.data_ptr(), W.data_ptr(), W.shape[0], sel.op.rowptr.data_ptr(),
+                                                        gn0.weight.data_ptr(), gn0.mean_scale.data_ptr(),
+                                                        st["emb_saved"].data_ptr(), W.grad.data_ptr(), 1,
+                                                        gn0.weight.grad.data_ptr(), gn0.bias.grad.data_ptr(),
+                                                        gn0.mean_scale.grad.data_ptr(), 1, H, _stream()),
+                   "glass_embed_norm_bwd_f32")
+            return
         dh0 = torch.empty((n, H), **f32)
-        _GN(emb.emb_gn).bwd(dh_next, st["h0"], st["emb_saved"], dh0, ACT_NONE, p, 1)
+        _GN(gn0).bwd(dh_next, st["h0"], st["emb_saved"], dh0, ACT_NONE, p, 1)
         # embedding backward: dW += S^T @ dh0 on K1
-        emb.input_emb.weight.grad.add_(emb._selection(st["x_flat"]).op.spmm(dh0))
+        W.grad.add_(emb._selection(st["x_flat"]).op.spmm(dh0))
 
 
 class StackFn(torch.autograd.Function):

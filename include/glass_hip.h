@@ -140,6 +140,29 @@ int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64
 int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 */
 
 /* ------------------------------------------------------------------------------------------
+ * K3n  embedding lookup + emb_gn + dropout through the embedding TABLE   (replaces the chain
+ *      input_emb -> emb_gn -> dropout at impl/models.py:246-251 when the table is small)
+ *     h0 = W[x] has only V distinct rows, so the whole-graph GraphNorm statistics are count-weighted sums
+ *     over W (class_rowptr = int32[V+1], row lengths = nodes per table row, class_rowptr[V] = N: the row
+ *     pointer of the selection CSR whose product on K1 is the embedding backward).
+ *   fwd: saved[4H] = mean, rstd, scale, shift; table[V,H] (scratch) = W*scale + shift;
+ *        out[n] = dropout(table[x[n]]); mask[n] as glass_embed_label_f32.  Two launches instead of
+ *        gather + statistics + finalize + apply over [N,H].
+ *   bwd: G[V,H] = sum over the nodes of each table row of the (dropout-masked) gradient of `out`
+ *        (glass_spmm_csr_f32 with the selection CSR).  dW (+)= GraphNorm-and-gather backward,
+ *        dgamma/dbeta/dalpha (+)=.  One launch instead of backward statistics + finalize + apply over [N,H].
+ * ---------------------------------------------------------------------------------------- */
+#define GLASS_EMBED_NORM_MAX_ROWS 1024
+int glass_embed_norm_fwd_f32(const int64_t* x, const float* W, int64_t V, const int32_t* class_rowptr,
+                             const float* gamma, const float* beta, const float* alpha, float eps, float* saved,
+                             float* table, const int64_t* z, const int64_t* pos, int64_t n_pos, float p_drop,
+                             const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo, uint8_t* mask,
+                             int64_t n_nodes, int64_t H, void* stream);
+int glass_embed_norm_bwd_f32(const float* G, const float* W, int64_t V, const int32_t* class_rowptr,
+                             const float* gamma, const float* alpha, const float* saved, float* dW, int accumulate_w,
+                             float* dgamma, float* dbeta, float* dalpha, int accumulate, int64_t H, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * K7  subgraph pooling   replaces pad2batch + emb[pos] + global_{add,mean,max}_pool /
  *     GraphSizeNorm (impl/models.py:346-350, 294-319; impl/utils.py:18-29)
  *     out[b,:] = reduce_{j: pos[b,j]>=0} emb[pos[b,j],:]   (sum | mean | max | sum * n_b^-1/2)
@@ -189,9 +212,13 @@ int glass_dual_linear_supported(int64_t H);
 int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg,
                               const float* bias, const uint8_t* mask, double z_ratio, int act, float* T, int64_t ldt,
                               float* out, int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
+/*   dgrad epilogue: out = (dZ @ W + addend) * dropmask(p_drop, rng_state, call_id) — the mask of the dropout that
+ *   produced this layer's input (same Philox layout as glass_graphnorm_fwd_f32), so the consumer receives the
+ *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL). */
 int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* WTimg, int64_t n_out, const float* addend,
-                                int64_t ldadd, float* out, int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
+                                int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* out,
+                                int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
 int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
                                 int64_t N, int64_t H, float* dW, int64_t lddw, float* db, int accumulate, void* ws,

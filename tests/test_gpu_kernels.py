@@ -659,3 +659,80 @@ def test_spmm_row_parallel_wide_threshold_on_large_graphs():
     ref = sp.csr_matrix((w.astype(np.float64), (rows, cols)), shape=(n, n)) @ x.double().numpy()
     assert rel_inf(y.cpu(), torch.from_numpy(ref)) < TOL
     assert torch.equal(adj.fwd.spmm(x.to(DEV)), y)
+
+
+# ---------------------------------------------------------------------------------- K3n embedding table path
+@pytest.mark.parametrize("H,V,n", [(64, 40, 3000), (17, 3, 500), (128, 1024, 5000), (8, 3, 100)])
+def test_embed_norm_table_path(H, V, n):
+    """glass_embed_norm_fwd/bwd (lookup + emb_gn through the V-row table) against torch fp64 autograd of
+    GraphNorm(Embedding(x)) on the node matrix; some table rows unused (count 0)."""
+    from glass_amd import _lib
+    from glass_amd.graph import Selection
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(H + V)
+    x = torch.randint(0, max(V - 1, 1), (n, ), generator=gen)  # last row never used when V > 1
+    W = torch.randn(V, H, generator=gen) * 1.5 + 0.7
+    gamma, beta, alpha = (1 + 0.3 * torch.randn(H, generator=gen), 0.2 * torch.randn(H, generator=gen),
+                          1 + 0.3 * torch.randn(H, generator=gen))
+    z = (torch.rand(n, generator=gen) < 0.2).to(torch.int64)
+    gout = torch.randn(n, H, generator=gen)
+    # reference
+    Wd = W.double().requires_grad_(True)
+    gn = O.GraphNorm(H).double()
+    with torch.no_grad():
+        gn.weight.copy_(gamma), gn.bias.copy_(beta), gn.mean_scale.copy_(alpha)
+    ref = gn(Wd[x])
+    ref.backward(gout.double())
+    # HIP
+    xg, Wg, zg = x.to(DEV), W.to(DEV), z.to(DEV)
+    g, b, a = gamma.to(DEV), beta.to(DEV), alpha.to(DEV)
+    sel = Selection(xg, V)
+    saved, table = torch.empty(4 * H, device=DEV), torch.empty(V, H, device=DEV)
+    out, mask = torch.empty(n, H, device=DEV), torch.empty(n, dtype=torch.uint8, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.glass_embed_norm_fwd_f32(xg.data_ptr(), Wg.data_ptr(), V, sel.op.rowptr.data_ptr(), g.data_ptr(), b.data_ptr(),
+                                      a.data_ptr(), 1e-5, saved.data_ptr(), table.data_ptr(), zg.data_ptr(), 0, 0, 0.0, 0, 1,
+                                      out.data_ptr(), H, mask.data_ptr(), n, H, st)
+    assert rc == 0
+    assert rel_inf(out.cpu(), ref.detach()) < TOL
+    assert torch.equal(mask.cpu().bool(), z > 0)
+    G = sel.op.spmm(gout.to(DEV))
+    dW = torch.full((V, H), 0.5, device=DEV)       # accumulate_w = 1: adds to what is there
+    dg, db, da = (torch.zeros(H, device=DEV) for _ in range(3))
+    rc = lib.glass_embed_norm_bwd_f32(G.data_ptr(), Wg.data_ptr(), V, sel.op.rowptr.data_ptr(), g.data_ptr(), a.data_ptr(),
+                                      saved.data_ptr(), dW.data_ptr(), 1, dg.data_ptr(), db.data_ptr(), da.data_ptr(), 0, H, st)
+    assert rc == 0
+    assert rel_inf((dW - 0.5).cpu(), Wd.grad) < TOL
+    assert rel_inf(dg.cpu(), gn.weight.grad) < TOL and rel_inf(db.cpu(), gn.bias.grad) < TOL
+    assert rel_inf(da.cpu(), gn.mean_scale.grad) < TOL
+    if V > 1:
+        assert float((dW[V - 1] - 0.5).abs().max()) == 0.0  # unused row: no gradient
+    # more rows than the table path takes -> rejected (callers keep the whole-graph kernels)
+    assert lib.glass_embed_norm_fwd_f32(xg.data_ptr(), Wg.data_ptr(), 1025, sel.op.rowptr.data_ptr(), g.data_ptr(),
+                                        b.data_ptr(), a.data_ptr(), 1e-5, saved.data_ptr(), table.data_ptr(), 0, 0, 0, 0.0,
+                                        0, 1, out.data_ptr(), H, mask.data_ptr(), n, H, st) != 0
+
+
+def test_dgrad_dropout_epilogue_matches_graphnorm_mask():
+    """The data-gradient kernel's dropout epilogue draws the same mask as glass_graphnorm_fwd_f32 with the same
+    (p, call id): masking there == masking in the GraphNorm backward."""
+    from glass_amd import _lib, ops
+    from glass_amd.arena import ParamArena
+    import torch.nn as nn
+    from impl import models
+    dev = torch.device(DEV)
+    n, H, p, call = 1000, 64, 0.5, 1
+    ops.rng_seed(99, dev)
+    ones, zeros = torch.ones(H, device=DEV), torch.zeros(H, device=DEV)
+    x = torch.randn(n, H, device=DEV)
+    kept = ops.graphnorm(x, ones, zeros, ones, p_drop=p, call_id=call) != 0
+    conv = models.GLASSConv(H, H, activation=nn.ELU(), aggr="mean", z_ratio=0.9, dropout=0.0).to(DEV)
+    ParamArena(conv)
+    st = conv._stack["trans"]
+    from glass_amd.stack import _dual_dgrad
+    mask = (torch.rand(n, device=DEV) < 0.3).to(torch.uint8)
+    dsrc, T = torch.randn(n, H, device=DEV), torch.randn(n, 2 * H, device=DEV)
+    plain, dropped = torch.empty(n, H, device=DEV), torch.empty(n, H, device=DEV)
+    _dual_dgrad(dsrc, T, st, mask, 0.9, 1, H, None, plain)
+    _dual_dgrad(dsrc, T, st, mask, 0.9, 1, H, None, dropped, drop=(p, call))
+    assert torch.equal(dropped, torch.where(kept, plain / (1 - p), torch.zeros_like(plain)))

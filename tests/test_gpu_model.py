@@ -489,3 +489,21 @@ def test_eval_after_optimizer_step_uses_current_weights():
     sd = {k: v.detach().cpu().clone() for k, v in emb.state_dict().items()}
     _orc.load_state_dict(sd)
     assert rel_inf(y1.cpu(), _orc.double().eval()(x.reshape(-1), ei, ew.double(), z).detach()) < TOL
+
+
+def test_stack_program_large_table_keeps_whole_graph_kernels():
+    """More than 1024 embedding rows (node-id style features): lookup + emb_gn stay on the [N,H] kernels."""
+    emb, arena, orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.8, 0.0, seed=5, V=1500)
+    emb.train()
+    args = [t.to(DEV) for t in (x, ei, ew, z)]
+    arena.zero()
+    y = emb(*args)
+    y.backward(gout.to(DEV))
+    orc = orc.double().train()
+    yo = orc(x.reshape(-1), ei, ew.double(), z)
+    yo.backward(gout.double())
+    assert rel_inf(y.detach().cpu(), yo.detach()) < TOL
+    mine = {k: p.grad.cpu() for k, p in emb.named_parameters()}
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    keys = sorted(mine)
+    assert rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys)) < TOL
