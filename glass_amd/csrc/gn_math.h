@@ -39,4 +39,38 @@ __device__ __forceinline__ void gn_bwd_coeffs(double s1, double s2, double N, fl
     dalpha_f = (float)(-mu * sum_do);
 }
 
+// One workgroup (256 threads = 16 columns x 16 partial slots) of the backward finalize: sums partial[b][2][C]
+// over b in slot order, derives the coefficients (coef[3C] = A, Bx, K) and the parameter gradients of columns
+// 16*blk .. 16*blk+15.  lds: kBlock*2 doubles.
+__device__ __forceinline__ void gn_finalize_bwd_block(int blk, const double* __restrict__ partial, int nblk, int C,
+                                                      int64_t N, const float* __restrict__ gamma,
+                                                      const float* __restrict__ alpha, const float* __restrict__ saved,
+                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                      float* __restrict__ dalpha, int accumulate,
+                                                      float* __restrict__ coef, double* lds) {
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int c = blk * 16 + tc;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = tr; b < nblk; b += 16) {
+            s1 += partial[(size_t)b * 2 * C + c];
+            s2 += partial[(size_t)b * 2 * C + C + c];
+        }
+    lds[threadIdx.x * 2] = s1;
+    lds[threadIdx.x * 2 + 1] = s2;
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        for (int r = 1; r < 16; ++r) {
+            s1 += lds[(r * 16 + tc) * 2];
+            s2 += lds[(r * 16 + tc) * 2 + 1];
+        }
+        float da;
+        gn_bwd_coeffs(s1, s2, (double)N, gamma[c], alpha[c], saved[c], saved[C + c], coef[c], coef[C + c],
+                      coef[2 * C + c], da);
+        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+        if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + da;
+    }
+}
+
 }  // namespace glass

@@ -288,29 +288,8 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_bwd_kernel(const double* _
                                                                  float* __restrict__ dalpha, int accumulate,
                                                                  float* __restrict__ coef) {
     __shared__ double lds[kBlock * 2];
-    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + tc;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = tr; b < nblk; b += 16) {
-            s1 += partial[(size_t)b * 2 * C + c];
-            s2 += partial[(size_t)b * 2 * C + C + c];
-        }
-    lds[threadIdx.x * 2] = s1;
-    lds[threadIdx.x * 2 + 1] = s2;
-    __syncthreads();
-    if (tr == 0 && c < C) {
-        for (int r = 1; r < 16; ++r) {
-            s1 += lds[(r * 16 + tc) * 2];
-            s2 += lds[(r * 16 + tc) * 2 + 1];
-        }
-        float da;
-        gn_bwd_coeffs(s1, s2, (double)N, gamma[c], alpha[c], saved[c], saved[C + c], coef[c], coef[C + c],
-                      coef[2 * C + c], da);
-        if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-        if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-        if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + da;
-    }
+    gn_finalize_bwd_block(blockIdx.x, partial, nblk, C, N, gamma, alpha, saved, dgamma, dbeta, dalpha, accumulate, coef,
+                          lds);
 }
 
 template <int VW>
@@ -412,6 +391,27 @@ extern "C" int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, in
                            saved, act, drop, rng_state);
     }
     return launch_status("glass_graphnorm_fwd_f32");
+}
+
+extern "C" int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, const float* gamma,
+                                         const float* beta, const float* alpha, float eps, float* saved, void* ws,
+                                         void* stream) {
+    GLASS_REQUIRE(x && gamma && beta && alpha && saved && ws, "graphnorm_stats: null pointer");
+    GLASS_REQUIRE(n_rows > 0 && C > 0 && ldx >= C, "graphnorm_stats: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = C % 4 == 0 && ldx % 4 == 0 && aligned16(x);
+    const Tiling t = make_tiling(C, vec);
+    const int nblk = stat_blocks(n_rows, t);
+    double* partial = (double*)ws;
+    dim3 gs(nblk, t.ctiles);
+    if (vec) {
+        hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+    }
+    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
+                       (int)C, n_rows, gamma, beta, alpha, eps, saved);
+    return launch_status("glass_graphnorm_stats_f32");
 }
 
 extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx,

@@ -1,0 +1,344 @@
+// Training-step readout: final GraphNorm (apply) -> subgraph pooling -> Linear head -> loss, and the whole
+// backward down to the gradient of the jumping-knowledge buffer, in four launches.
+// reference: impl/models.py:266/271 (gns[-1]), 346-350 (Pool), GLASSTest.py:159-160 (head), :57-58/:69 (loss).
+//
+// Unfused this is 12 dependent launches (GraphNorm apply; pool; logits; loss mean; head backward; zero-fill of
+// the [N,C] embedding gradient; pool scatter; GraphNorm backward statistics / finalize / apply), five of them
+// full passes over [N,C] although only the P = sum of subgraph sizes pooled rows carry a gradient.  Here:
+//   R1  one workgroup per subgraph: gathers its raw rows, applies the GraphNorm affine on the fly, pools, computes
+//       its logits, its loss term, d logits, d pooled — and, because the gradient of the GraphNorm OUTPUT is nonzero
+//       only on pooled rows, the subgraph's share of the two backward column sums
+//       S1 = sum_n g[n], S2 = sum_n g[n]*xhat[n]   (g[n] = sum over the subgraphs holding n of scale_b * dpooled[b]).
+//   R2  head weight/bias gradient rows, the mean loss, and the GraphNorm backward finalize (independent roles of one
+//       launch).
+//   R3  dense part of the GraphNorm backward over all nodes: d jk = Bx*x + K.
+//   R4  sparse part: d jk[n] += A * g[n] on the pooled rows (float atomics, like glass_segment_pool_bwd_f32).
+#include "common.h"
+#include "gn_math.h"
+
+namespace glass {
+
+constexpr int kReadoutMaxK = 256;
+constexpr int kLossCE = 0, kLossBCE = 1;
+
+struct ReadoutWs {
+    double* partial;   // [B][2][C]
+    float* coef;       // [3C]  A, Bx, K
+    float* dys;        // [B][C]  gradient of every pooled row of subgraph b (already scaled by the pool scale)
+    float* dlogits;    // [B][K]
+    float* loss_rows;  // [B]
+};
+
+static ReadoutWs carve_ws(void* ws, int64_t B, int64_t C, int64_t K) {
+    ReadoutWs w;
+    char* p = (char*)ws;
+    w.partial = (double*)p;
+    p += sizeof(double) * 2 * B * C;
+    w.coef = (float*)p;
+    p += sizeof(float) * 4 * C;
+    w.dys = (float*)p;
+    p += sizeof(float) * B * C;
+    w.dlogits = (float*)p;
+    p += sizeof(float) * B * K;
+    w.loss_rows = (float*)p;
+    return w;
+}
+
+__device__ __forceinline__ int valid_count(const int64_t* __restrict__ prow, int Smax, int64_t n_nodes) {
+    int cnt = 0;
+    for (int j0 = 0; j0 < Smax; j0 += kBlock) {
+        const int j = j0 + threadIdx.x;
+        cnt += __syncthreads_count(j < Smax && prow[j] >= 0 && prow[j] < n_nodes);
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ float readout_pool_scale(int mode, int cnt) {
+    if (mode == GLASS_POOL_MEAN) return 1.0f / (float)(cnt > 0 ? cnt : 1);
+    if (mode == GLASS_POOL_SIZE) return cnt > 0 ? 1.0f / sqrtf((float)cnt) : 0.f;
+    return 1.0f;
+}
+
+struct R1Args {
+    const float* jk; int64_t ldj;
+    const float *saved, *alpha;
+    const int64_t* pos; int Smax, mode;
+    const float *Wh, *bh; const void* target; int loss_mode, B, C, K;
+    const float* gl;
+    float *pooled, *logits;
+    ReadoutWs ws;
+    int64_t n_nodes;
+    int tc_log2;
+};
+
+// dynamic LDS (floats): pooled_s[C] | xh_s[C] | red[kBlock*8] | zs[kReadoutMaxK] | dl[kReadoutMaxK]
+__global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
+    extern __shared__ float sm[];
+    const int C = a.C, K = a.K;
+    float* pooled_s = sm;
+    float* xh_s = sm + C;
+    float* red = sm + 2 * C;
+    float* zs = red + kBlock * 8;
+    float* dl = zs + kReadoutMaxK;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t* prow = a.pos + (int64_t)b * a.Smax;
+    const int cnt = valid_count(prow, a.Smax, a.n_nodes);
+    const float sc = readout_pool_scale(a.mode, cnt);
+    // ---- pool the normalised rows; also sum xhat over the subgraph's rows ----
+    const int TC = 1 << a.tc_log2, rpb = kBlock >> a.tc_log2;
+    const int tc = tid & (TC - 1), tr = tid >> a.tc_log2;
+    const int c0 = tc * 4;
+    const bool ok = c0 < C;
+    float accy[4] = {0.f, 0.f, 0.f, 0.f}, acch[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        float mu[4], rstd[4], scale[4], shift[4], al[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mu[k] = a.saved[c0 + k];
+            rstd[k] = a.saved[C + c0 + k];
+            scale[k] = a.saved[2 * C + c0 + k];
+            shift[k] = a.saved[3 * C + c0 + k];
+            al[k] = a.alpha[c0 + k];
+        }
+        for (int j = tr; j < a.Smax; j += rpb) {
+            const int64_t node = prow[j];
+            if (node < 0 || node >= a.n_nodes) continue;
+            const float4 v = *reinterpret_cast<const float4*>(a.jk + node * a.ldj + c0);
+            const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                accy[k] += fmaf(x[k], scale[k], shift[k]);
+                acch[k] += (x[k] - al[k] * mu[k]) * rstd[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        red[tid * 8 + k] = accy[k];
+        red[tid * 8 + 4 + k] = acch[k];
+    }
+    __syncthreads();
+    if (tr == 0 && ok) {
+        for (int r = 1; r < rpb; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                accy[k] += red[(r * TC + tc) * 8 + k];
+                acch[k] += red[(r * TC + tc) * 8 + 4 + k];
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pooled_s[c0 + k] = accy[k] * sc;
+            xh_s[c0 + k] = acch[k];
+        }
+        *reinterpret_cast<float4*>(a.pooled + (int64_t)b * C + c0) =
+            make_float4(accy[0] * sc, accy[1] * sc, accy[2] * sc, accy[3] * sc);
+    }
+    __syncthreads();
+    // ---- logits: wave w takes classes w, w+4, ... ----
+    const int lane = tid & 63, w = tid >> 6;
+    for (int k = w; k < K; k += kBlock / kWave) {
+        const float* wr = a.Wh + (int64_t)k * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += kWave) s = fmaf(pooled_s[c], wr[c], s);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) zs[k] = s + a.bh[k];
+    }
+    __syncthreads();
+    // ---- loss term and d logits (mean reduction over B rows, or B*K elements for BCE) ----
+    if (tid == 0) {
+        const float gscale = a.gl[0] / (a.loss_mode == kLossCE ? (float)a.B : (float)a.B * (float)K);
+        float term = 0.f;
+        if (a.loss_mode == kLossCE) {
+            float m = zs[0];
+            for (int k = 1; k < K; ++k) m = fmaxf(m, zs[k]);
+            float se = 0.f;
+            for (int k = 0; k < K; ++k) se += expf(zs[k] - m);
+            const float lse = m + logf(se);
+            const int64_t t = ((const int64_t*)a.target)[b];
+            for (int k = 0; k < K; ++k) dl[k] = gscale * (expf(zs[k] - lse) - (t == k ? 1.f : 0.f));
+            term = (t >= 0 && t < K) ? lse - zs[t] : 0.f;
+        } else {
+            const float* y = (const float*)a.target + (int64_t)b * K;
+            for (int k = 0; k < K; ++k) {
+                const float z = zs[k];
+                dl[k] = gscale * (1.f / (1.f + expf(-z)) - y[k]);
+                term += fmaxf(z, 0.f) - z * y[k] + log1pf(expf(-fabsf(z)));  // torch's stable BCE-with-logits
+            }
+        }
+        a.ws.loss_rows[b] = term;
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += kBlock) {
+        a.logits[(int64_t)b * K + k] = zs[k];
+        a.ws.dlogits[(int64_t)b * K + k] = dl[k];
+    }
+    // ---- d pooled -> gradient of each pooled row, and this subgraph's share of the GraphNorm column sums ----
+    double* part = a.ws.partial + (size_t)b * 2 * C;
+    for (int c = tid; c < C; c += kBlock) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) s = fmaf(dl[k], a.Wh[(int64_t)k * C + c], s);
+        const float dy = sc * s;
+        a.ws.dys[(int64_t)b * C + c] = dy;
+        part[c] = (double)cnt * (double)dy;
+        part[C + c] = (double)dy * (double)xh_s[c];
+    }
+}
+
+struct R2Args {
+    const float* pooled; ReadoutWs ws; int B, C, K, loss_mode;
+    float *dWh, *dbh; int acc_head;
+    float* loss;
+    int64_t n_nodes;
+    const float *gamma, *alpha, *saved;
+    float *dgamma, *dbeta, *dalpha; int acc_gn;
+};
+
+// blocks [0,K): head gradient row k;  block K: mean loss;  blocks (K, K + ceil(C/16)]: GraphNorm backward finalize.
+// dynamic LDS: max(B floats, kBlock*2 doubles)
+__global__ __launch_bounds__(kBlock) void readout_reduce_kernel(R2Args a) {
+    extern __shared__ double smd[];
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk < a.K) {
+        float* dl = reinterpret_cast<float*>(smd);
+        for (int b = tid; b < a.B; b += kBlock) dl[b] = a.ws.dlogits[(int64_t)b * a.K + blk];
+        __syncthreads();
+        for (int c = tid; c < a.C; c += kBlock) {
+            float s = 0.f;
+#pragma unroll 8
+            for (int b = 0; b < a.B; ++b) s = fmaf(dl[b], a.pooled[(int64_t)b * a.C + c], s);
+            float* d = a.dWh + (int64_t)blk * a.C + c;
+            *d = a.acc_head ? *d + s : s;
+        }
+        if (tid == 0) {
+            float s = 0.f;
+            for (int b = 0; b < a.B; ++b) s += dl[b];
+            a.dbh[blk] = a.acc_head ? a.dbh[blk] + s : s;
+        }
+        return;
+    }
+    if (blk == a.K) {
+        double part = 0.0;
+        for (int b = tid; b < a.B; b += kBlock) part += (double)a.ws.loss_rows[b];
+        smd[tid] = part;
+        __syncthreads();
+        for (int s = kBlock / 2; s > 0; s >>= 1) {
+            if (tid < s) smd[tid] += smd[tid + s];
+            __syncthreads();
+        }
+        if (tid == 0)
+            a.loss[0] = (float)(smd[0] / (a.loss_mode == kLossCE ? (double)a.B : (double)a.B * (double)a.K));
+        return;
+    }
+    gn_finalize_bwd_block(blk - a.K - 1, a.ws.partial, a.B, a.C, a.n_nodes, a.gamma, a.alpha, a.saved, a.dgamma, a.dbeta,
+                          a.dalpha, a.acc_gn, a.ws.coef, smd);
+}
+
+// R3: d jk = Bx*x + K over all nodes (the part of the GraphNorm backward that does not depend on the row's own g)
+__global__ __launch_bounds__(kBlock) void readout_dense_kernel(const float* __restrict__ x, int64_t ldx,
+                                                               float* __restrict__ dx, int64_t lddx, int64_t N, int C,
+                                                               int tc_log2, const float* __restrict__ coef) {
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = tc * 4;
+    if (c0 >= C) return;
+    const float4 Bx = *reinterpret_cast<const float4*>(coef + C + c0);
+    const float4 K = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr < N) v[u] = *reinterpret_cast<const float4*>(x + rr * ldx + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr >= N) continue;
+            *reinterpret_cast<float4*>(dx + rr * lddx + c0) =
+                make_float4(fmaf(Bx.x, v[u].x, K.x), fmaf(Bx.y, v[u].y, K.y), fmaf(Bx.z, v[u].z, K.z),
+                            fmaf(Bx.w, v[u].w, K.w));
+        }
+    }
+}
+
+// R4: d jk[n] += A * g on the pooled rows
+__global__ __launch_bounds__(kBlock) void readout_scatter_kernel(const int64_t* __restrict__ pos, int Smax,
+                                                                 const float* __restrict__ dys,
+                                                                 const float* __restrict__ coef, float* __restrict__ dx,
+                                                                 int64_t lddx, int64_t n_nodes, int C, int tc_log2) {
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = tc * 4, b = blockIdx.x;
+    if (c0 >= C) return;
+    const float4 A = *reinterpret_cast<const float4*>(coef + c0);
+    const float4 g = *reinterpret_cast<const float4*>(dys + (int64_t)b * C + c0);
+    const float add[4] = {A.x * g.x, A.y * g.y, A.z * g.z, A.w * g.w};
+    const int64_t* prow = pos + (int64_t)b * Smax;
+    for (int j = tr; j < Smax; j += rpb) {
+        const int64_t node = prow[j];
+        if (node < 0 || node >= n_nodes) continue;
+        float* dst = dx + node * lddx + c0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(dst + k, add[k]);
+    }
+}
+
+}  // namespace glass
+
+using namespace glass;
+
+extern "C" int glass_readout_supported(int64_t C, int64_t K, int pool_mode) {
+    return (C > 0 && C % 4 == 0 && C <= 4 * kBlock && K > 0 && K <= kReadoutMaxK &&
+            (pool_mode == GLASS_POOL_SUM || pool_mode == GLASS_POOL_MEAN || pool_mode == GLASS_POOL_SIZE)) ? 1 : 0;
+}
+
+extern "C" int64_t glass_readout_ws_bytes(int64_t B, int64_t C, int64_t K) {
+    if (B <= 0 || C <= 0 || K <= 0) return GLASS_E_ARG;
+    return (int64_t)sizeof(double) * 2 * B * C + (int64_t)sizeof(float) * (4 * C + B * C + B * K + B) + 64;
+}
+
+extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved, const float* gamma,
+                                       const float* alpha, const int64_t* pos, int64_t B, int64_t Smax, int pool_mode,
+                                       const float* Wh, const float* bh, const void* target, int loss_mode, int64_t K,
+                                       const float* grad_loss, float* pooled, float* logits, float* loss, float* djk,
+                                       int64_t lddj, float* dWh, float* dbh, int acc_head, float* dgamma, float* dbeta,
+                                       float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C, void* stream) {
+    GLASS_REQUIRE(jk && gn_saved && gamma && alpha && pos && Wh && bh && target && grad_loss && pooled && logits && loss &&
+                      djk && dWh && dbh && ws,
+                  "readout_train: null pointer");
+    GLASS_REQUIRE(B > 0 && Smax > 0 && Smax < (1ll << 31) && n_nodes > 0 && ldj >= C && lddj >= C && B * K < (1ll << 30),
+                  "readout_train: bad sizes");
+    if (!glass_readout_supported(C, K, pool_mode) || (loss_mode != kLossCE && loss_mode != kLossBCE)) {
+        set_error("readout_train: unsupported shape/mode (C=%lld K=%lld pool=%d loss=%d): C %% 4 == 0, C <= 1024, "
+                  "K <= 256, pool sum|mean|size", (long long)C, (long long)K, pool_mode, loss_mode);
+        return GLASS_E_UNSUPPORTED;
+    }
+    GLASS_REQUIRE(ldj % 4 == 0 && lddj % 4 == 0 && aligned16(jk) && aligned16(djk) && aligned16(pooled) && aligned16(ws),
+                  "readout_train: operands must be 16-B aligned with ld %% 4 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    const ReadoutWs w = carve_ws(ws, B, C, K);
+    const int tc = pow2_ceil_cap(C / 4, kBlock);
+    int tc_log2 = 0;
+    while ((1 << tc_log2) < tc) ++tc_log2;
+    R1Args a1{jk, ldj, gn_saved, alpha, pos, (int)Smax, pool_mode, Wh, bh, target, loss_mode, (int)B, (int)C, (int)K,
+              grad_loss, pooled, logits, w, n_nodes, tc_log2};
+    const size_t lds1 = sizeof(float) * (size_t)(2 * C + kBlock * 8 + 2 * kReadoutMaxK);
+    hipLaunchKernelGGL(readout_subgraph_kernel, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
+    R2Args a2{pooled, w, (int)B, (int)C, (int)K, loss_mode, dWh, dbh, acc_head, loss, n_nodes, gamma, alpha, gn_saved,
+              dgamma, dbeta, dalpha, acc_gn};
+    size_t lds2 = sizeof(double) * kBlock * 2;
+    if (sizeof(float) * (size_t)B > lds2) lds2 = sizeof(float) * (size_t)B;
+    GLASS_REQUIRE(lds2 <= 64 * 1024, "readout_train: batch too large for the LDS staging");
+    hipLaunchKernelGGL(readout_reduce_kernel, dim3((unsigned)(K + 1 + ceil_div(C, 16))), dim3(kBlock), lds2, st, a2);
+    const int rpb = kBlock / tc;
+    int64_t blocks = ceil_div(n_nodes, (int64_t)rpb * 4);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(readout_dense_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, jk, ldj, djk, lddj, n_nodes, (int)C,
+                       tc_log2, w.coef);
+    hipLaunchKernelGGL(readout_scatter_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, pos, (int)Smax, w.dys, w.coef, djk,
+                       lddj, n_nodes, (int)C, tc_log2);
+    return launch_status("glass_readout_train_f32");
+}

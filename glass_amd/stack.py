@@ -22,6 +22,7 @@ from .ops import ACT_ELU, ACT_NONE, _stream
 import os
 
 USE_EMBED_TABLE = os.environ.get("GLASS_EMBED_TABLE", "1") != "0"  # A/B switch: lookup + emb_gn through the table
+USE_READOUT = os.environ.get("GLASS_READOUT", "1") != "0"          # A/B switch: fused training readout (K8r)
 
 
 def _check(rc, what):
@@ -138,8 +139,10 @@ class StackProgram:
             emb.input_emb.weight.grad is not None
 
     # ---------------------------------------------------------------------------------------------
-    def forward(self, x_flat, z, edge_index, edge_weight, keep):
-        """Returns (out, state).  keep=False (no gradient wanted): intermediates are dropped as soon as possible."""
+    def forward(self, x_flat, z, edge_index, edge_weight, keep, readout=None):
+        """Returns (out, state).  keep=False (no gradient wanted): intermediates are dropped as soon as possible.
+        readout = (pos, pool_mode, head Linear, target, loss_mode): instead of the final GraphNorm apply, run the
+        fused training readout (K8r) — out = (loss, logits) and state carries the gradient of the JK buffer."""
         from .models import buildAdj
         emb, lib = self.emb, _lib.load()
         dev = x_flat.device
@@ -199,20 +202,52 @@ class StackProgram:
                 h = torch.empty((n, H), **f32)
                 rec["nsaved"] = _GN(emb.gns[l]).fwd(c, h, ACT_ELU, p, conv.call_base + 1)
             layers.append(rec if keep else None)
+        st["jk"], st["layers"] = jk, layers
+        if readout is not None:
+            return self._readout(st, jk, *readout), st
         out = torch.empty((n, C_out), **f32)
         st["final_saved"] = _GN(emb.gns[-1]).fwd(jk, out, ACT_NONE, 0.0, 0)
-        st["jk"], st["layers"] = jk, layers
         return out, (st if keep else None)
+
+    def _readout(self, st, jk, pos, pool_mode, head, target, loss_mode):
+        lib, gn = _lib.load(), self.emb.gns[-1]
+        n, C = jk.shape
+        B, Smax = pos.shape
+        K = head.weight.shape[0]
+        dev = jk.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        saved = torch.empty(4 * C, **f32)
+        _check(lib.glass_graphnorm_stats_f32(jk.data_ptr(), jk.stride(0), n, C, gn.weight.data_ptr(), gn.bias.data_ptr(),
+                                             gn.mean_scale.data_ptr(), float(gn.eps), saved.data_ptr(),
+                                             ops._graphnorm_ws(dev, n, C).data_ptr(), _stream()),
+               "glass_graphnorm_stats_f32")
+        ws = torch.empty(lib.glass_readout_ws_bytes(B, C, K) // 8 + 1, dtype=torch.float64, device=dev)
+        pooled, logits = torch.empty((B, C), **f32), torch.empty((B, K), **f32)
+        loss, djk = torch.empty((), **f32), torch.empty((n, C), **f32)
+        tgt = target.contiguous().to(torch.int64 if loss_mode == 0 else torch.float32)
+        _check(lib.glass_readout_train_f32(jk.data_ptr(), jk.stride(0), saved.data_ptr(), gn.weight.data_ptr(),
+                                           gn.mean_scale.data_ptr(), pos.data_ptr(), B, Smax, _lib.POOL_MODES[pool_mode],
+                                           head.weight.data_ptr(), head.bias.data_ptr(), tgt.data_ptr(), loss_mode, K,
+                                           _one(dev).data_ptr(), pooled.data_ptr(), logits.data_ptr(), loss.data_ptr(),
+                                           djk.data_ptr(), djk.stride(0), head.weight.grad.data_ptr(),
+                                           head.bias.grad.data_ptr(), 1, gn.weight.grad.data_ptr(),
+                                           gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), 1, ws.data_ptr(), n, C,
+                                           _stream()), "glass_readout_train_f32")
+        st["djk"] = djk
+        return loss, logits
 
     # ---------------------------------------------------------------------------------------------
     def backward(self, st, dout):
         emb = self.emb
         n, H, L, p = st["n"], st["H"], st["L"], st["p"]
-        dev = dout.device
+        dev = st["mask"].device
         f32 = dict(dtype=torch.float32, device=dev)
         mask, jk = st["mask"], st["jk"]
-        djk = torch.empty_like(jk)
-        _GN(emb.gns[-1]).bwd(dout, jk, st["final_saved"], djk, ACT_NONE, 0.0, 0)
+        if "djk" in st:  # the fused readout already went through the final GraphNorm
+            djk = st["djk"]
+        else:
+            djk = torch.empty_like(jk)
+            _GN(emb.gns[-1]).bwd(dout, jk, st["final_saved"], djk, ACT_NONE, 0.0, 0)
         dh_next = None   # gradient w.r.t. the input of layer l+1 (= output of gns[l])
         pending = []     # weight gradients whose partial sums are written but not yet reduced
         for l in range(L - 1, -1, -1):
@@ -254,6 +289,66 @@ class StackProgram:
         _GN(gn0).bwd(dh_next, st["h0"], st["emb_saved"], dh0, ACT_NONE, p, 1)
         # embedding backward: dW += S^T @ dh0 on K1
         W.grad.add_(emb._selection(st["x_flat"]).op.spmm(dh0))
+
+
+    # ---------------------------------------------------------------------------------------------
+    def loss_and_grads(self, x_flat, z, edge_index, edge_weight, pos, pool_mode, head, target, loss_mode):
+        """One training pass WITHOUT the autograd tape: forward, fused readout, backward; every parameter gradient
+        (stack, final GraphNorm, head) is accumulated into the gradient arena.  Returns (loss, logits)."""
+        with torch.no_grad():
+            (loss, logits), st = self.forward(x_flat, z, edge_index, edge_weight, True,
+                                              readout=(pos, pool_mode, head, target, loss_mode))
+            self.backward(st, None)
+        return loss, logits
+
+
+_ones = {}
+
+
+def _one(device):
+    t = _ones.get(device)
+    if t is None:
+        t = _ones[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def step_supported(model, loss_fn):
+    """True when `model` (models.GLASS) + loss can run as StackProgram.loss_and_grads: one feature channel, the stack
+    program's own conditions, pooling sum|mean|size straight from the padded node matrix, a bare Linear head whose
+    gradients live in the arena, a fusable loss."""
+    import torch.nn as nn
+    from . import losses
+    from .models import EmbZGConv, PoolModule
+    emb = getattr(model, "conv", None)
+    if not (USE_READOUT and isinstance(emb, EmbZGConv) and StackProgram.supported(emb) and emb.training):
+        return False
+    pool, head = model.pools[0], model.preds[0]
+    if not (isinstance(pool, PoolModule) and pool.trans_fn is None and pool.mode in ("sum", "mean", "size")):
+        return False
+    if not (type(head) is nn.Linear and head.bias is not None and head.weight.grad is not None and
+            head.bias.grad is not None and isinstance(loss_fn, (losses.CrossEntropy, losses.BCEWithLogits))):
+        return False
+    C = emb.gns[-1].weight.shape[0]
+    return head.weight.shape[1] == C and bool(_lib.load().glass_readout_supported(C, head.weight.shape[0],
+                                                                                  _lib.POOL_MODES[pool.mode]))
+
+
+def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target):
+    """(loss, logits) of model(x, ..., pos, z) under loss_fn, gradients accumulated in place (see step_supported)."""
+    emb = model.conv
+    if x.dim() != 3 or x.shape[1] != 1 or x.shape[2] != 1:
+        raise NotImplementedError("one integer feature per node (x of shape [N,1,1])")
+    x_flat = x.reshape(x.shape[0])
+    if x_flat.dtype != torch.int64:
+        x_flat = x_flat.to(torch.int64)
+    prog = emb.__dict__.get("_glass_stack_prog")
+    if prog is None:
+        prog = emb.__dict__["_glass_stack_prog"] = StackProgram(emb)
+    pos = pos.contiguous()
+    if pos.dtype != torch.int64:
+        pos = pos.to(torch.int64)
+    return prog.loss_and_grads(x_flat, z, edge_index, edge_weight, pos, model.pools[0].mode, model.preds[0], target,
+                               loss_fn.mode)
 
 
 class StackFn(torch.autograd.Function):

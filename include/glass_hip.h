@@ -251,6 +251,26 @@ int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const float* W, co
                             int mode, const float* grad_loss, int64_t B, int64_t C, int64_t K, float* dpooled,
                             int64_t lddp, float* dW, float* db, int accumulate, void* stream);
 
+/* K8r  training-step readout: final GraphNorm apply -> subgraph pooling -> Linear head -> loss AND the whole
+ *      backward down to the gradient of the GraphNorm INPUT, in four launches (impl/models.py:266/271, 346-350;
+ *      GLASSTest.py:159-160, 57-58/69).  Only pooled rows carry a gradient into the GraphNorm output, so its two
+ *      backward column sums are accumulated per subgraph; the [N,C] normalised embedding and its gradient are
+ *      never materialised.  jk = GraphNorm input [N,C] (the jumping-knowledge buffer); gn_saved from
+ *      glass_graphnorm_stats_f32 (statistics + finalize without the apply pass); pos [B,Smax] (-1 padding);
+ *      pool_mode sum|mean|size; loss_mode 0 = cross-entropy (target int64[B]), 1 = BCE-with-logits (float[B,K]);
+ *      grad_loss = device scalar seed.  Outputs: pooled [B,C], logits [B,K], loss [1], djk [N,C] (overwritten);
+ *      dWh/dbh and dgamma/dbeta/dalpha are accumulated when acc_* != 0. */
+int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, const float* gamma,
+                              const float* beta, const float* alpha, float eps, float* saved, void* ws, void* stream);
+int glass_readout_supported(int64_t C, int64_t K, int pool_mode);
+int64_t glass_readout_ws_bytes(int64_t B, int64_t C, int64_t K);
+int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved, const float* gamma, const float* alpha,
+                            const int64_t* pos, int64_t B, int64_t Smax, int pool_mode, const float* Wh, const float* bh,
+                            const void* target, int loss_mode, int64_t K, const float* grad_loss, float* pooled,
+                            float* logits, float* loss, float* djk, int64_t lddj, float* dWh, float* dbh, int acc_head,
+                            float* dgamma, float* dbeta, float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
+                            void* stream);
+
 /* K9  Adam over a flat parameter arena (torch.optim.Adam as used at GLASSTest.py:213; amsgrad
  *     off): one launch for all parameters.  lr and the step counter live in DEVICE memory so a
  *     captured graph follows ReduceLROnPlateau and advances its own bias correction.

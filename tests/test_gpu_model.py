@@ -507,3 +507,54 @@ def test_stack_program_large_table_keeps_whole_graph_kernels():
     theirs = {k: p.grad for k, p in orc.named_parameters()}
     keys = sorted(mine)
     assert rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys)) < TOL
+
+
+@pytest.mark.parametrize("pool,multilabel", [("sum", False), ("mean", False), ("size", True)])
+def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel):
+    """stack.loss_and_grads (no tape; final GraphNorm apply + pool + head + loss and their backward as K8r) against
+    (a) the autograd path of the same model and (b) the fp64 oracle: loss, logits, every gradient.  The subgraphs
+    share nodes and are ragged (padding -1)."""
+    from glass_amd import stack, losses
+    from glass_amd.arena import ParamArena
+    from impl import utils
+    from glass_amd import synth
+    n, H, L, K, B, S = 900, 64, 2, 5, 12, 9
+    torch.manual_seed(21)
+    model = build_glass(H, L, 7, K, "mean", pool, 0.9)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ei, ew = synth.make_graph(n, 5000, 4, 0.0)
+    rng = np.random.default_rng(4)
+    x = torch.from_numpy(rng.integers(0, 8, n)).reshape(n, 1, 1)
+    pos = rng.integers(0, 40, (B, S))          # drawn from 40 nodes: heavy sharing between subgraphs
+    pos[:, -3:][rng.random((B, 3)) < 0.5] = -1
+    pos[0, 1:] = -1                            # a single-node subgraph
+    pos = torch.from_numpy(pos)
+    y = torch.from_numpy((rng.random((B, K)) < 0.4).astype(np.float32)) if multilabel else torch.from_numpy(rng.integers(0, K, B))
+    loss_fn = losses.BCEWithLogits() if multilabel else losses.CrossEntropy()
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    xg, eig, ewg, posg, yg = x.to(DEV), torch.from_numpy(ei).to(DEV), torch.from_numpy(ew).to(DEV), pos.to(DEV), y.to(DEV)
+    z = utils.MaxZOZ(xg, posg)
+    assert stack.step_supported(model, loss_fn)
+    arena.zero()
+    loss_a, logits_a = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, z, yg)
+    grads_a = arena.flat.clone()
+    arena.zero()
+    pred = model(xg, eig, ewg, posg, z)
+    loss_b = loss_fn(pred, yg)
+    loss_b.backward()
+    assert rel_inf(logits_a.cpu(), pred.detach().cpu()) < 1e-6
+    assert abs(loss_a.item() - loss_b.item()) < 1e-6 * abs(loss_b.item())
+    assert rel_inf(grads_a.cpu(), arena.flat.cpu()) < 2e-6
+    orc = O.OracleGLASS(H, L, 7, K, aggr="mean", pool=pool, z_ratio=0.9)
+    orc.load_state_dict(sd)
+    orc = orc.double().train()
+    po = orc(x, torch.from_numpy(ei), torch.from_numpy(ew).double(), pos, O.max_zero_one(x, pos))
+    lo = loss_fn(po, y.double() if multilabel else y)
+    lo.backward()
+    assert rel_inf(logits_a.cpu(), po.detach()) < TOL and abs(loss_a.item() - lo.item()) < TOL * abs(lo.item())
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    keys = sorted(mine)
+    arena.flat.copy_(grads_a)
+    assert rel_inf(flat_grads({k: p.grad.cpu() for k, p in model.named_parameters()}, keys), flat_grads(theirs, keys)) < TOL
