@@ -47,7 +47,7 @@ class _GN:
         _check(rc, "glass_graphnorm_fwd_f32")
         return saved
 
-    def bwd(self, dy, x, saved, dx, act, p_drop, call_id, addend=None):
+    def bwd(self, dy, x, saved, dx, act, p_drop, call_id, addend=None, acc=1):
         m = self.mod
         n, C = x.shape
         ws = ops._graphnorm_ws(x.device, n, C)
@@ -56,7 +56,7 @@ class _GN:
         rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dx.data_ptr(),
                                                  dx.stride(0), ap, lda, n, C, m.weight.data_ptr(),
                                                  m.mean_scale.data_ptr(), saved.data_ptr(), m.weight.grad.data_ptr(),
-                                                 m.bias.grad.data_ptr(), m.mean_scale.grad.data_ptr(), 1, act,
+                                                 m.bias.grad.data_ptr(), m.mean_scale.grad.data_ptr(), acc, act,
                                                  float(p_drop), rng, call_id, ws.data_ptr(), _stream())
         _check(rc, "glass_graphnorm_bwd_f32")
 
@@ -84,7 +84,7 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=Non
     _check(rc, "glass_dual_linear_dgrad_f32")
 
 
-def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending):
+def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending, acc=1):
     """Per-slab partial sums of dW / db into a scratch buffer of their own; the reduction into the gradient arena
     is deferred to ONE launch at the end of the backward pass (`_reduce_pending`)."""
     n, H = dout.shape
@@ -96,7 +96,7 @@ def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending):
                                                  0 if xb is None else xb.stride(0), n, H, 0, 0, 0, 1, ws.data_ptr(),
                                                  _stream())
     _check(rc, "glass_dual_linear_wgrad_f32")
-    pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), 1))
+    pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
 
 
 def _reduce_pending(pending):
@@ -139,7 +139,7 @@ class StackProgram:
             emb.input_emb.weight.grad is not None
 
     # ---------------------------------------------------------------------------------------------
-    def forward(self, x_flat, z, edge_index, edge_weight, keep, readout=None):
+    def forward(self, x_flat, z, edge_index, edge_weight, keep, readout=None, acc=1):
         """Returns (out, state).  keep=False (no gradient wanted): intermediates are dropped as soon as possible.
         readout = (pos, pool_mode, head Linear, target, loss_mode): instead of the final GraphNorm apply, run the
         fused training readout (K8r) — out = (loss, logits) and state carries the gradient of the JK buffer."""
@@ -156,7 +156,13 @@ class StackProgram:
         # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
         advance = train and (p > 0 or any(c.dropout > 0 for c in emb.convs))
         emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
-        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat}
+        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc)}
+        # labels: z (int64 [N], > 0 = labeled), None (all labeled), or ("pos", pos): labeled = the nodes listed in the
+        # padded subgraph matrix — utils.MaxZOZ without materialising z (a byte memset + scatter inside the gather)
+        if isinstance(z, tuple):
+            zp, pp, npos = 0, z[1].data_ptr(), z[1].numel()
+        else:
+            zp, pp, npos = (0 if z is None else z.data_ptr()), 0, 0
         mask = torch.empty(n, dtype=torch.uint8, device=dev)
         h = torch.empty((n, H), **f32)
         st["mask"] = mask
@@ -170,14 +176,14 @@ class StackProgram:
             _check(lib.glass_embed_norm_fwd_f32(x_flat.data_ptr(), W.data_ptr(), V, sel.op.rowptr.data_ptr(),
                                                 gn0.weight.data_ptr(), gn0.bias.data_ptr(), gn0.mean_scale.data_ptr(),
                                                 float(gn0.eps), saved.data_ptr(), table.data_ptr(),
-                                                0 if z is None else z.data_ptr(), 0, 0, p, rng, 1, h.data_ptr(), H,
+                                                zp, pp, npos, p, rng, 1, h.data_ptr(), H,
                                                 mask.data_ptr(), n, H, _stream()), "glass_embed_norm_fwd_f32")
             st["emb_table"], st["emb_saved"] = sel, saved
         else:
             # K3+K4: embedding gather + label byte, then the whole-graph GraphNorm
             h0 = torch.empty((n, H), **f32)
-            _check(lib.glass_embed_label_f32(x_flat.data_ptr(), W.data_ptr(), V, 0 if z is None else z.data_ptr(), 0,
-                                             0, h0.data_ptr(), H, mask.data_ptr(), n, H, _stream()),
+            _check(lib.glass_embed_label_f32(x_flat.data_ptr(), W.data_ptr(), V, zp, pp, npos, h0.data_ptr(), H,
+                                             mask.data_ptr(), n, H, _stream()),
                    "glass_embed_label_f32")
             st["h0"] = h0
             st["emb_saved"] = _GN(gn0).fwd(h0, h, ACT_NONE, p, 1)
@@ -230,8 +236,9 @@ class StackProgram:
                                            head.weight.data_ptr(), head.bias.data_ptr(), tgt.data_ptr(), loss_mode, K,
                                            _one(dev).data_ptr(), pooled.data_ptr(), logits.data_ptr(), loss.data_ptr(),
                                            djk.data_ptr(), djk.stride(0), head.weight.grad.data_ptr(),
-                                           head.bias.grad.data_ptr(), 1, gn.weight.grad.data_ptr(),
-                                           gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), 1, ws.data_ptr(), n, C,
+                                           head.bias.grad.data_ptr(), st["acc"], gn.weight.grad.data_ptr(),
+                                           gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), st["acc"], ws.data_ptr(),
+                                           n, C,
                                            _stream()), "glass_readout_train_f32")
         st["djk"] = djk
         return loss, logits
@@ -243,11 +250,12 @@ class StackProgram:
         dev = st["mask"].device
         f32 = dict(dtype=torch.float32, device=dev)
         mask, jk = st["mask"], st["jk"]
+        acc = st["acc"]  # 1: add into the gradient arena; 0: overwrite (every gradient is written exactly once)
         if "djk" in st:  # the fused readout already went through the final GraphNorm
             djk = st["djk"]
         else:
             djk = torch.empty_like(jk)
-            _GN(emb.gns[-1]).bwd(dout, jk, st["final_saved"], djk, ACT_NONE, 0.0, 0)
+            _GN(emb.gns[-1]).bwd(dout, jk, st["final_saved"], djk, ACT_NONE, 0.0, 0, acc=acc)
         dh_next = None   # gradient w.r.t. the input of layer l+1 (= output of gns[l])
         pending = []     # weight gradients whose partial sums are written but not yet reduced
         for l in range(L - 1, -1, -1):
@@ -259,18 +267,18 @@ class StackProgram:
             else:
                 dc = torch.empty((n, H), **f32)
                 _GN(emb.gns[l]).bwd(dh_next, rec["c"], rec["nsaved"], dc, ACT_ELU, p, conv.call_base + 1,
-                                    addend=djk[:, l * H:(l + 1) * H] if emb.jk else None)
+                                    addend=djk[:, l * H:(l + 1) * H] if emb.jk else None, acc=acc)
             din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
             _dual_dgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din)
-            _dual_wgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, rec["g"], rec["h"], pending)
+            _dual_wgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, rec["g"], rec["h"], pending, acc)
             da = torch.empty((n, H), **f32)
-            _GN(conv.gn).bwd(din[:, :H], rec["a"], rec["gsaved"], da, ACT_NONE, rec["pc"], conv.call_base)
+            _GN(conv.gn).bwd(din[:, :H], rec["a"], rec["gsaved"], da, ACT_NONE, rec["pc"], conv.call_base, acc=acc)
             dm = conv.adj.bwd.spmm(da)
             dh = torch.empty((n, H), **f32)
             # layer 0 on the table path: the epilogue applies emb_gn's dropout mask (call id 1)
             drop = (p, 1) if (l == 0 and "emb_table" in st) else None
             _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, drop)
-            _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None, pending)
+            _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None, pending, acc)
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations
         _reduce_pending(pending)
@@ -280,24 +288,39 @@ class StackProgram:
             G = sel.op.spmm(dh_next)  # [V,H]: per table row, the sum of its nodes' (masked) gradients, on K1
             _check(_lib.load().glass_embed_norm_bwd_f32(G.data_ptr(), W.data_ptr(), W.shape[0], sel.op.rowptr.data_ptr(),
                                                         gn0.weight.data_ptr(), gn0.mean_scale.data_ptr(),
-                                                        st["emb_saved"].data_ptr(), W.grad.data_ptr(), 1,
+                                                        st["emb_saved"].data_ptr(), W.grad.data_ptr(), acc,
                                                         gn0.weight.grad.data_ptr(), gn0.bias.grad.data_ptr(),
-                                                        gn0.mean_scale.grad.data_ptr(), 1, H, _stream()),
+                                                        gn0.mean_scale.grad.data_ptr(), acc, H, _stream()),
                    "glass_embed_norm_bwd_f32")
             return
         dh0 = torch.empty((n, H), **f32)
-        _GN(gn0).bwd(dh_next, st["h0"], st["emb_saved"], dh0, ACT_NONE, p, 1)
-        # embedding backward: dW += S^T @ dh0 on K1
-        W.grad.add_(emb._selection(st["x_flat"]).op.spmm(dh0))
+        _GN(gn0).bwd(dh_next, st["h0"], st["emb_saved"], dh0, ACT_NONE, p, 1, acc=acc)
+        # embedding backward: dW (+)= S^T @ dh0 on K1
+        if acc:
+            W.grad.add_(emb._selection(st["x_flat"]).op.spmm(dh0))
+        else:
+            emb._selection(st["x_flat"]).op.spmm(dh0, out=W.grad)
 
 
     # ---------------------------------------------------------------------------------------------
-    def loss_and_grads(self, x_flat, z, edge_index, edge_weight, pos, pool_mode, head, target, loss_mode):
+    def written_params(self, head):
+        """Every parameter whose gradient loss_and_grads writes (exactly once per call)."""
+        emb = self.emb
+        out = [emb.input_emb.weight, head.weight, head.bias]
+        for gn in [emb.emb_gn] + [c.gn for c in emb.convs] + list(emb.gns):
+            out += [gn.weight, gn.bias, gn.mean_scale]
+        for c in emb.convs:
+            for lin in list(c.trans_fns) + list(c.comb_fns):
+                out += [lin.weight, lin.bias]
+        return out
+
+    def loss_and_grads(self, x_flat, z, edge_index, edge_weight, pos, pool_mode, head, target, loss_mode, overwrite=False):
         """One training pass WITHOUT the autograd tape: forward, fused readout, backward; every parameter gradient
-        (stack, final GraphNorm, head) is accumulated into the gradient arena.  Returns (loss, logits)."""
+        (stack, final GraphNorm, head) is accumulated into the gradient arena — or, with overwrite=True, stored over
+        whatever is there (no zero-fill of the arena needed when written_params() covers it).  Returns (loss, logits)."""
         with torch.no_grad():
             (loss, logits), st = self.forward(x_flat, z, edge_index, edge_weight, True,
-                                              readout=(pos, pool_mode, head, target, loss_mode))
+                                              readout=(pos, pool_mode, head, target, loss_mode), acc=0 if overwrite else 1)
             self.backward(st, None)
         return loss, logits
 
@@ -333,22 +356,38 @@ def step_supported(model, loss_fn):
                                                                                   _lib.POOL_MODES[pool.mode]))
 
 
-def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target):
-    """(loss, logits) of model(x, ..., pos, z) under loss_fn, gradients accumulated in place (see step_supported)."""
+def covers_arena(model, arena):
+    """loss_and_grads writes the gradient of every parameter in the arena -> overwrite mode needs no zero-fill."""
+    prog = _program(model.conv)
+    return {id(p) for p in arena.params} <= {id(p) for p in prog.written_params(model.preds[0])}
+
+
+def _program(emb):
+    prog = emb.__dict__.get("_glass_stack_prog")
+    if prog is None:
+        prog = emb.__dict__["_glass_stack_prog"] = StackProgram(emb)
+    return prog
+
+
+def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, overwrite=False):
+    """(loss, logits) of model(x, ..., pos, z) under loss_fn, gradients accumulated in place (see step_supported).
+    z = "pos": label the nodes listed in pos (what utils.MaxZOZ(x, pos) would mark) without materialising z."""
     emb = model.conv
     if x.dim() != 3 or x.shape[1] != 1 or x.shape[2] != 1:
         raise NotImplementedError("one integer feature per node (x of shape [N,1,1])")
     x_flat = x.reshape(x.shape[0])
     if x_flat.dtype != torch.int64:
         x_flat = x_flat.to(torch.int64)
-    prog = emb.__dict__.get("_glass_stack_prog")
-    if prog is None:
-        prog = emb.__dict__["_glass_stack_prog"] = StackProgram(emb)
+    prog = _program(emb)
     pos = pos.contiguous()
     if pos.dtype != torch.int64:
         pos = pos.to(torch.int64)
+    if isinstance(z, str):
+        if z != "pos":
+            raise ValueError("z must be a tensor, None or 'pos'")
+        z = ("pos", pos)
     return prog.loss_and_grads(x_flat, z, edge_index, edge_weight, pos, model.pools[0].mode, model.preds[0], target,
-                               loss_fn.mode)
+                               loss_fn.mode, overwrite)
 
 
 class StackFn(torch.autograd.Function):
@@ -372,8 +411,6 @@ class StackFn(torch.autograd.Function):
 
 
 def run(emb, x_flat, z, edge_index, edge_weight):
-    prog = emb.__dict__.get("_glass_stack_prog")
-    if prog is None:
-        prog = emb.__dict__["_glass_stack_prog"] = StackProgram(emb)
+    prog = _program(emb)
     params = [p for p in emb.parameters() if p.requires_grad]
     return StackFn.apply(prog, x_flat, z, edge_index, edge_weight, *params)

@@ -43,16 +43,20 @@ class TrainStep:
                 head.bias is not None)
 
     def _fwd_bwd(self):
-        z = utils.MaxZOZ(self.x, self._pos)
-        self.bucket.zero()
         from . import stack
         if (self._fused_head() and hasattr(self.bucket, "flat_param") and self.x.dim() == 3 and
                 self.x.shape[1:] == (1, 1) and stack.step_supported(self.model, self.loss_fn)):
-            # whole step as one explicit program: no autograd tape, fused readout (glass_amd/stack.py)
-            loss, _logits = stack.loss_and_grads(self.model, self.loss_fn, self.x, self.ei, self.ew, self._pos, z,
-                                                 self._y)
+            # whole step as one explicit program: no autograd tape, fused readout, labels straight from pos, and
+            # — when the program writes every gradient of the arena — no zero-fill (glass_amd/stack.py)
+            overwrite = stack.covers_arena(self.model, self.bucket)
+            if not overwrite:
+                self.bucket.zero()
+            loss, _logits = stack.loss_and_grads(self.model, self.loss_fn, self.x, self.ei, self.ew, self._pos, "pos",
+                                                 self._y, overwrite)
             self._loss = loss
             return
+        z = utils.MaxZOZ(self.x, self._pos)
+        self.bucket.zero()
         if self._fused_head():
             from . import losses
             emb = self.model.NodeEmb(self.x, self.ei, self.ew, z)

@@ -539,6 +539,16 @@ def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel):
     arena.zero()
     loss_a, logits_a = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, z, yg)
     grads_a = arena.flat.clone()
+    # overwrite mode + labels straight from pos: no zero-fill needed, garbage in the arena must not survive
+    assert stack.covers_arena(model, arena)
+    arena.flat.fill_(7.0)
+    loss_o, _ = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg, overwrite=True)
+    assert abs(loss_o.item() - loss_a.item()) < 1e-6 * abs(loss_a.item())
+    used = torch.zeros_like(arena.flat, dtype=torch.bool)
+    for p_ in arena.params:
+        o = arena._offsets[id(p_)]
+        used[o:o + p_.numel()] = True
+    assert rel_inf(arena.flat[used].cpu(), grads_a[used].cpu()) < 1e-6
     arena.zero()
     pred = model(xg, eig, ewg, posg, z)
     loss_b = loss_fn(pred, yg)
