@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           const uint8_t* __restrict__ mask, float zr, float omz, int act,
                                                           float* __restrict__ T, int64_t ldt, float* __restrict__ out,
-                                                          int64_t ldo, int64_t N) {
+                                                          int64_t ldo, int64_t N, double* __restrict__ stats) {
     constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H, NTILES = NT / 16;
     static_assert(KQ % kKC == 0, "hidden size must be a multiple of 64");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -165,6 +165,11 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
     staged_product<NT, KT>(acc, W, lds_w, lane, [&](int kc, float (&a)[kKC]) { load16(a, arow + kc * kKC, row_ok); });
     // epilogue: acc[4g+k][reg] is row row0 + 4q + reg, column 64g + 4i + k  ->  float4 per (row, group)
     constexpr int NG = H / 64;  // 64-column groups per half
+    float ssum[NG][4], ssq[NG][4];  // this lane's column sums over its (up to) 4 rows, for the GraphNorm that follows
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ssum[g][k] = ssq[g][k] = 0.f;
     float4 bv[2 * NG];
 #pragma unroll
     for (int g = 0; g < 2 * NG; ++g) bv[g] = *reinterpret_cast<const float4*>(bias + 64 * g + 4 * i);
@@ -197,9 +202,41 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
                     a0 = elu_fast_f(a0);
                 }
                 o[k] = w1 * a1 + w0 * a0;
+                ssum[g][k] += o[k];
+                ssq[g][k] = fmaf(o[k], o[k], ssq[g][k]);
             }
             *reinterpret_cast<float4*>(out + r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
         }
+    }
+    if (stats == nullptr) return;
+    // Column statistics of `out` for the GraphNorm that consumes it (its statistics pass is skipped):
+    // stats[blockIdx.x][2][H] = per-workgroup sum / sum of squares over its 64 rows, in fp64 from here on.
+    __syncthreads();  // every wave is done with the weight images in LDS
+    double* red = reinterpret_cast<double*>(lds_w);  // [4 waves][H][2]
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double s = (double)ssum[g][k], q2 = (double)ssq[g][k];
+            s += __shfl_xor(s, 16);
+            q2 += __shfl_xor(q2, 16);
+            s += __shfl_xor(s, 32);
+            q2 += __shfl_xor(q2, 32);
+            if (q == 0) {
+                red[(w * H + 64 * g + 4 * i + k) * 2] = s;
+                red[(w * H + 64 * g + 4 * i + k) * 2 + 1] = q2;
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += kBlock) {
+        double s = 0.0, q2 = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < kBlock / kWave; ++ww) {
+            s += red[(ww * H + c) * 2];
+            q2 += red[(ww * H + c) * 2 + 1];
+        }
+        stats[((size_t)blockIdx.x * 2) * H + c] = s;
+        stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
     }
 }
 
@@ -325,7 +362,7 @@ extern "C" int glass_dual_linear_supported(int64_t H) {
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
                                          int64_t ldt, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
-                                         void* stream) {
+                                         double* stats, void* stream) {
     GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
     if (!dense_shape_ok(H)) {
         set_error("dual_linear_fwd: hidden size %lld not supported (64, 128)", (long long)H);
@@ -347,10 +384,10 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
         allow_lds(dual_fwd_kernel<HH, false>, 2 * image);                                                          \
         if (comb)                                                                                                  \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, true>), grid, dim3(kBlock), 2 * image, st, xa, lda, xb, ldb, W, bias, \
-                               mask, zr, omz, act, T, ldt, out, ldo, n_nodes);                                     \
+                               mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats);                              \
         else                                                                                                       \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, false>), grid, dim3(kBlock), (HH > 64 ? 2 : 1) * image, st, xa, lda, \
-                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes);                   \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats);            \
     }
     GLASS_FWD(64) GLASS_FWD(128)
 #undef GLASS_FWD

@@ -165,6 +165,71 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_fwd_kernel(const double* _
     }
 }
 
+// finalize from statistics written by OTHER kernels' epilogues: up to 8 partial buffers [nblk][2][C_each], source k
+// covering columns k*C_each .. (k+1)*C_each - 1.  Four independent accumulator pairs per thread keep the loads
+// of the (longer: one partial per 64 rows) slot loop in flight.
+constexpr int kMaxStatSrc = 8;
+struct StatSrc {
+    const double* p[kMaxStatSrc];
+};
+
+__global__ __launch_bounds__(kBlock) void gn_finalize_src_kernel(StatSrc src, int nblk, int C_each, int C, int64_t N,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 const float* __restrict__ alpha, float eps,
+                                                                 float* __restrict__ saved) {
+    // 4 columns x 64 partial slots per workgroup, 8 partials per thread in flight: up to 512 partials (32 768 rows)
+    // cost ONE memory round trip — the partials were written by other XCDs, so every load is an L2 miss.
+    constexpr int kCols = 4, kSlots = kBlock / kCols, kFly = 8;
+    __shared__ double lds[kBlock * 2];
+    const int tc = threadIdx.x & (kCols - 1), tr = threadIdx.x / kCols;
+    const int c = blockIdx.x * kCols + tc;
+    double ss = 0.0, qq = 0.0;
+    if (c < C) {
+        const double* part = src.p[c / C_each];
+        const int cl = c % C_each;
+        for (int b = tr; b < nblk; b += kSlots * kFly) {
+            double s[kFly], q[kFly];
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) {
+                const int bb = b + kSlots * u;
+                s[u] = bb < nblk ? part[((size_t)bb * 2) * C_each + cl] : 0.0;
+                q[u] = bb < nblk ? part[((size_t)bb * 2 + 1) * C_each + cl] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kFly; ++u) {
+                ss += s[u];
+                qq += q[u];
+            }
+        }
+    }
+    lds[threadIdx.x * 2] = ss;
+    lds[threadIdx.x * 2 + 1] = qq;
+    __syncthreads();
+    // fold the 64 slots: 8 threads per column each fold 8 slots, then slot 0 folds those 8 (fixed order)
+    double a = 0.0, b2 = 0.0;
+    if (tr < 8)
+        for (int r = tr; r < kSlots; r += 8) {
+            a += lds[(r * kCols + tc) * 2];
+            b2 += lds[(r * kCols + tc) * 2 + 1];
+        }
+    __syncthreads();
+    if (tr < 8) {
+        lds[threadIdx.x * 2] = a;
+        lds[threadIdx.x * 2 + 1] = b2;
+    }
+    __syncthreads();
+    if (tr == 0 && c < C) {
+        ss = 0.0, qq = 0.0;
+        for (int r = 0; r < 8; ++r) {
+            ss += lds[(r * kCols + tc) * 2];
+            qq += lds[(r * kCols + tc) * 2 + 1];
+        }
+        gn_fwd_coeffs(ss, qq, (double)N, gamma[c], beta[c], alpha[c], eps, saved[c], saved[C + c], saved[2 * C + c],
+                      saved[3 * C + c]);
+    }
+}
+
 // ---- forward apply: y = dropout(act(x*scale + shift)) ------------------------------------------
 template <int VW>
 __global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restrict__ x, int64_t ldx,
@@ -412,6 +477,43 @@ extern "C" int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_
     hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
                        (int)C, n_rows, gamma, beta, alpha, eps, saved);
     return launch_status("glass_graphnorm_stats_f32");
+}
+
+extern "C" int glass_graphnorm_finalize_f32(const double* const* partials, int64_t n_src, int64_t nblk, int64_t C_each,
+                                            int64_t n_rows, const float* gamma, const float* beta, const float* alpha,
+                                            float eps, float* saved, void* stream) {
+    GLASS_REQUIRE(partials && gamma && beta && alpha && saved, "graphnorm_finalize: null pointer");
+    GLASS_REQUIRE(n_src > 0 && n_src <= kMaxStatSrc && nblk > 0 && nblk < (1ll << 31) && C_each > 0 && n_rows > 0,
+                  "graphnorm_finalize: bad sizes (at most %d sources)", kMaxStatSrc);
+    StatSrc src;
+    for (int k = 0; k < kMaxStatSrc; ++k) src.p[k] = k < n_src ? partials[k] : nullptr;
+    for (int k = 0; k < n_src; ++k) GLASS_REQUIRE(src.p[k], "graphnorm_finalize: null source %d", k);
+    const int64_t C = n_src * C_each;
+    hipLaunchKernelGGL(gn_finalize_src_kernel, dim3((unsigned)ceil_div(C, 4)), dim3(kBlock), 0, (hipStream_t)stream, src,
+                       (int)nblk, (int)C_each, (int)C, n_rows, gamma, beta, alpha, eps, saved);
+    return launch_status("glass_graphnorm_finalize_f32");
+}
+
+extern "C" int glass_graphnorm_apply_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int64_t C,
+                                         const float* saved, int act, float p_drop, const uint64_t* rng_state,
+                                         uint64_t call_id, void* stream) {
+    GLASS_REQUIRE(x && y && saved, "graphnorm_apply: null pointer");
+    GLASS_REQUIRE(n_rows > 0 && C > 0 && ldx >= C && ldy >= C, "graphnorm_apply: bad sizes");
+    GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_apply: bad dropout args");
+    GLASS_REQUIRE(act == GLASS_ACT_NONE || act == GLASS_ACT_ELU, "graphnorm_apply: bad act %d", act);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y);
+    const Tiling t = make_tiling(C, vec);
+    const Drop drop = make_drop(p_drop, call_id, C);
+    dim3 ga(apply_blocks(n_rows, t), t.ctiles);
+    if (vec) {
+        hipLaunchKernelGGL(gn_apply_kernel<4>, ga, dim3(kBlock), 0, st, x, ldx, y, ldy, n_rows, (int)C, t.tc_log2, saved,
+                           act, drop, rng_state);
+    } else {
+        hipLaunchKernelGGL(gn_apply_kernel<1>, ga, dim3(kBlock), 0, st, x, ldx, y, ldy, n_rows, (int)C, t.tc_log2, saved,
+                           act, drop, rng_state);
+    }
+    return launch_status("glass_graphnorm_apply_f32");
 }
 
 extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx,

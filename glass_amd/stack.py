@@ -47,6 +47,26 @@ class _GN:
         _check(rc, "glass_graphnorm_fwd_f32")
         return saved
 
+    def finalize(self, stats, n_rows):
+        """saved[4C] from statistics the producers' epilogues wrote (list of [nblk, 2, C_each] float64 buffers)."""
+        m = self.mod
+        C_each, nblk = stats[0].shape[2], stats[0].shape[0]
+        C = C_each * len(stats)
+        saved = torch.empty(4 * C, dtype=torch.float32, device=stats[0].device)
+        ptrs = np.array([t.data_ptr() for t in stats], dtype=np.uint64)
+        rc = _lib.load().glass_graphnorm_finalize_f32(ptrs.ctypes.data, len(stats), nblk, C_each, n_rows,
+                                                      m.weight.data_ptr(), m.bias.data_ptr(), m.mean_scale.data_ptr(),
+                                                      float(m.eps), saved.data_ptr(), _stream())
+        _check(rc, "glass_graphnorm_finalize_f32")
+        return saved
+
+    def apply(self, x, y, saved, act, p_drop, call_id):
+        n, C = x.shape
+        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rc = _lib.load().glass_graphnorm_apply_f32(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), n, C,
+                                                   saved.data_ptr(), act, float(p_drop), rng, call_id, _stream())
+        _check(rc, "glass_graphnorm_apply_f32")
+
     def bwd(self, dy, x, saved, dx, act, p_drop, call_id, addend=None, acc=1):
         m = self.mod
         n, C = x.shape
@@ -61,13 +81,15 @@ class _GN:
         _check(rc, "glass_graphnorm_bwd_f32")
 
 
-def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out):
+def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None):
+    """stats: [ceil(n/64), 2, H] float64 — per-workgroup column sums of `out` for the GraphNorm that follows."""
     n, H = xa.shape
     rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                                0 if xb is None else xb.stride(0), stack[4].data_ptr(),
                                                stack[1].data_ptr(), mask.data_ptr(), float(z_ratio), act,
                                                0 if T is None else T.data_ptr(), 0 if T is None else T.stride(0),
-                                               out.data_ptr(), out.stride(0), n, H, _stream())
+                                               out.data_ptr(), out.stride(0), n, H,
+                                               0 if stats is None else stats.data_ptr(), _stream())
     _check(rc, "glass_dual_linear_fwd_f32")
 
 
@@ -189,7 +211,7 @@ class StackProgram:
             st["emb_saved"] = _GN(gn0).fwd(h0, h, ACT_NONE, p, 1)
         C_out = H * L if emb.jk else H
         jk = torch.empty((n, C_out), **f32)
-        layers = []
+        layers, cstats = [], []
         for l, conv in enumerate(emb.convs):
             if conv.adj is None:
                 conv.adj = buildAdj(edge_index, edge_weight, n, conv.aggr)
@@ -202,17 +224,24 @@ class StackProgram:
             gsaved = _GN(conv.gn).fwd(a, g, ACT_NONE, pc, conv.call_base)
             last = l + 1 == L
             c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
-            _dual_fwd(g, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c)
+            # the comb kernel's epilogue also leaves the column statistics of c for the GraphNorm(s) that read it
+            cstat = torch.empty(((n + 63) // 64, 2, H), dtype=torch.float64, device=dev)
+            _dual_fwd(g, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c, cstat)
+            cstats.append(cstat)
             rec = {"h": h, "T": T, "a": a, "g": g, "gsaved": gsaved, "c": c, "pc": pc}
             if not last:
                 h = torch.empty((n, H), **f32)
-                rec["nsaved"] = _GN(emb.gns[l]).fwd(c, h, ACT_ELU, p, conv.call_base + 1)
+                gnl = _GN(emb.gns[l])
+                rec["nsaved"] = gnl.finalize([cstat], n)
+                gnl.apply(c, h, rec["nsaved"], ACT_ELU, p, conv.call_base + 1)
             layers.append(rec if keep else None)
         st["jk"], st["layers"] = jk, layers
+        gnf = _GN(emb.gns[-1])
+        st["final_saved"] = gnf.finalize(cstats if emb.jk else cstats[-1:], n)
         if readout is not None:
             return self._readout(st, jk, *readout), st
         out = torch.empty((n, C_out), **f32)
-        st["final_saved"] = _GN(emb.gns[-1]).fwd(jk, out, ACT_NONE, 0.0, 0)
+        gnf.apply(jk, out, st["final_saved"], ACT_NONE, 0.0, 0)
         return out, (st if keep else None)
 
     def _readout(self, st, jk, pos, pool_mode, head, target, loss_mode):
@@ -222,11 +251,7 @@ class StackProgram:
         K = head.weight.shape[0]
         dev = jk.device
         f32 = dict(dtype=torch.float32, device=dev)
-        saved = torch.empty(4 * C, **f32)
-        _check(lib.glass_graphnorm_stats_f32(jk.data_ptr(), jk.stride(0), n, C, gn.weight.data_ptr(), gn.bias.data_ptr(),
-                                             gn.mean_scale.data_ptr(), float(gn.eps), saved.data_ptr(),
-                                             ops._graphnorm_ws(dev, n, C).data_ptr(), _stream()),
-               "glass_graphnorm_stats_f32")
+        saved = st["final_saved"]
         ws = torch.empty(lib.glass_readout_ws_bytes(B, C, K) // 8 + 1, dtype=torch.float64, device=dev)
         pooled, logits = torch.empty((B, C), **f32), torch.empty((B, K), **f32)
         loss, djk = torch.empty((), **f32), torch.empty((n, C), **f32)

@@ -137,6 +137,16 @@ int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const float* x, int64
                             float* dgamma, float* dbeta, float* dalpha, int accumulate /* != 0: add into d* */,
                             int act, float p_drop, const uint64_t* rng_state, uint64_t call_id, void* ws,
                             void* stream);
+/*     GraphNorm in pieces, for statistics produced elsewhere (the epilogue of the kernel that wrote x):
+ *     finalize: saved[4*C] from n_src partial buffers (HOST array of device pointers), each [nblk][2][C_each]
+ *     doubles, covering consecutive column blocks (C = n_src * C_each; several sources = the jumping-knowledge
+ *     concatenation);  apply: y = dropout(act(x*scale + shift)) from saved. */
+int glass_graphnorm_finalize_f32(const double* const* partials, int64_t n_src, int64_t nblk, int64_t C_each,
+                                 int64_t n_rows, const float* gamma, const float* beta, const float* alpha, float eps,
+                                 float* saved, void* stream);
+int glass_graphnorm_apply_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int64_t C,
+                              const float* saved, int act, float p_drop, const uint64_t* rng_state, uint64_t call_id,
+                              void* stream);
 int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 */
 
 /* ------------------------------------------------------------------------------------------
@@ -209,9 +219,12 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  *   caller composes the library GEMM with glass_mix_*.
  * ---------------------------------------------------------------------------------------- */
 int glass_dual_linear_supported(int64_t H);
+/*   fwd, stats != NULL: the epilogue also writes the column statistics of `out` for the GraphNorm that consumes
+ *   it — stats[ceil(n_nodes/64)][2][H] doubles (per 64-row workgroup: sum, sum of squares) — so that GraphNorm
+ *   needs no statistics pass of its own: glass_graphnorm_finalize_f32 + glass_graphnorm_apply_f32. */
 int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg,
                               const float* bias, const uint8_t* mask, double z_ratio, int act, float* T, int64_t ldt,
-                              float* out, int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
+                              float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* stats, void* stream);
 /*   dgrad epilogue: out = (dZ @ W + addend) * dropmask(p_drop, rng_state, call_id) — the mask of the dropout that
  *   produced this layer's input (same Philox layout as glass_graphnorm_fwd_f32), so the consumer receives the
  *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL). */
