@@ -39,31 +39,65 @@ __device__ __forceinline__ void gn_bwd_coeffs(double s1, double s2, double N, fl
     dalpha_f = (float)(-mu * sum_do);
 }
 
-// One workgroup (256 threads = 16 columns x 16 partial slots) of the backward finalize: sums partial[b][2][C]
-// over b in slot order, derives the coefficients (coef[3C] = A, Bx, K) and the parameter gradients of columns
-// 16*blk .. 16*blk+15.  lds: kBlock*2 doubles.
+// Sum partial[b][2][C] (doubles, written by other workgroups — every load is an L2 miss) over b for 4 columns per
+// workgroup: 64 partial slots x 8 partials per thread in flight, so up to 512 partials cost ONE memory round trip;
+// slots folded through LDS in fixed order.  Result valid in the threads with slot 0 (tr == 0).  lds: kBlock*2 doubles.
+constexpr int kFinCols = 4, kFinSlots = kBlock / kFinCols, kFinFly = 8;
+
+__device__ __forceinline__ void gn_sum_partials(const double* __restrict__ part, int nblk, int C_part, int cl, bool ok,
+                                                int tc, int tr, double* lds, double& ss, double& qq) {
+    ss = 0.0, qq = 0.0;
+    if (ok)
+        for (int b = tr; b < nblk; b += kFinSlots * kFinFly) {
+            double s[kFinFly], q[kFinFly];
+#pragma unroll
+            for (int u = 0; u < kFinFly; ++u) {
+                const int bb = b + kFinSlots * u;
+                s[u] = bb < nblk ? part[((size_t)bb * 2) * C_part + cl] : 0.0;
+                q[u] = bb < nblk ? part[((size_t)bb * 2 + 1) * C_part + cl] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kFinFly; ++u) {
+                ss += s[u];
+                qq += q[u];
+            }
+        }
+    lds[threadIdx.x * 2] = ss;
+    lds[threadIdx.x * 2 + 1] = qq;
+    __syncthreads();
+    double a = 0.0, b2 = 0.0;
+    if (tr < 8)
+        for (int r = tr; r < kFinSlots; r += 8) {
+            a += lds[(r * kFinCols + tc) * 2];
+            b2 += lds[(r * kFinCols + tc) * 2 + 1];
+        }
+    __syncthreads();
+    if (tr < 8) {
+        lds[threadIdx.x * 2] = a;
+        lds[threadIdx.x * 2 + 1] = b2;
+    }
+    __syncthreads();
+    ss = 0.0, qq = 0.0;
+    if (tr == 0)
+        for (int r = 0; r < 8; ++r) {
+            ss += lds[(r * kFinCols + tc) * 2];
+            qq += lds[(r * kFinCols + tc) * 2 + 1];
+        }
+}
+
+// One workgroup of the backward finalize (columns 4*blk .. 4*blk+3): coefficients coef[3C] = A, Bx, K and the
+// parameter gradients from the partial sums.
 __device__ __forceinline__ void gn_finalize_bwd_block(int blk, const double* __restrict__ partial, int nblk, int C,
                                                       int64_t N, const float* __restrict__ gamma,
                                                       const float* __restrict__ alpha, const float* __restrict__ saved,
                                                       float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                       float* __restrict__ dalpha, int accumulate,
                                                       float* __restrict__ coef, double* lds) {
-    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
-    const int c = blk * 16 + tc;
-    double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = tr; b < nblk; b += 16) {
-            s1 += partial[(size_t)b * 2 * C + c];
-            s2 += partial[(size_t)b * 2 * C + C + c];
-        }
-    lds[threadIdx.x * 2] = s1;
-    lds[threadIdx.x * 2 + 1] = s2;
-    __syncthreads();
+    const int tc = threadIdx.x & (kFinCols - 1), tr = threadIdx.x / kFinCols;
+    const int c = blk * kFinCols + tc;
+    double s1, s2;
+    gn_sum_partials(partial, nblk, C, c, c < C, tc, tr, lds, s1, s2);
     if (tr == 0 && c < C) {
-        for (int r = 1; r < 16; ++r) {
-            s1 += lds[(r * 16 + tc) * 2];
-            s2 += lds[(r * 16 + tc) * 2 + 1];
-        }
         float da;
         gn_bwd_coeffs(s1, s2, (double)N, gamma[c], alpha[c], saved[c], saved[C + c], coef[c], coef[C + c],
                       coef[2 * C + c], da);

@@ -136,38 +136,10 @@ __global__ __launch_bounds__(kBlock) void gn_stats_kernel(const float* __restric
     block_reduce_store<VW>(s, q, lds, tc, tr, TC, rpb, partial, c0, C);
 }
 
-// ---- finalize: sum workgroup partials in order; derive mean / rstd / scale / shift -------------
-// 16 columns x 16 partial slots per workgroup.
-__global__ __launch_bounds__(kBlock) void gn_finalize_fwd_kernel(const double* __restrict__ partial, int nblk, int C,
-                                                                 int64_t N, const float* __restrict__ gamma,
-                                                                 const float* __restrict__ beta,
-                                                                 const float* __restrict__ alpha, float eps,
-                                                                 float* __restrict__ saved) {
-    __shared__ double lds[kBlock * 2];
-    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + tc;
-    double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int b = tr; b < nblk; b += 16) {
-            s += partial[(size_t)b * 2 * C + c];
-            q += partial[(size_t)b * 2 * C + C + c];
-        }
-    lds[threadIdx.x * 2] = s;
-    lds[threadIdx.x * 2 + 1] = q;
-    __syncthreads();
-    if (tr == 0 && c < C) {
-        for (int r = 1; r < 16; ++r) {
-            s += lds[(r * 16 + tc) * 2];
-            q += lds[(r * 16 + tc) * 2 + 1];
-        }
-        gn_fwd_coeffs(s, q, (double)N, gamma[c], beta[c], alpha[c], eps, saved[c], saved[C + c], saved[2 * C + c],
-                      saved[3 * C + c]);
-    }
-}
-
-// finalize from statistics written by OTHER kernels' epilogues: up to 8 partial buffers [nblk][2][C_each], source k
-// covering columns k*C_each .. (k+1)*C_each - 1.  Four independent accumulator pairs per thread keep the loads
-// of the (longer: one partial per 64 rows) slot loop in flight.
+// ---- finalize: sum the workgroup partials in fixed order; derive mean / rstd / scale / shift ----
+// Up to 8 partial buffers [nblk][2][C_each], source k covering columns k*C_each .. (k+1)*C_each - 1 (one source for
+// the statistics kernel above; several when the statistics come from the epilogues of the kernels that wrote the
+// column blocks of a jumping-knowledge buffer).
 constexpr int kMaxStatSrc = 8;
 struct StatSrc {
     const double* p[kMaxStatSrc];
@@ -178,56 +150,15 @@ __global__ __launch_bounds__(kBlock) void gn_finalize_src_kernel(StatSrc src, in
                                                                  const float* __restrict__ beta,
                                                                  const float* __restrict__ alpha, float eps,
                                                                  float* __restrict__ saved) {
-    // 4 columns x 64 partial slots per workgroup, 8 partials per thread in flight: up to 512 partials (32 768 rows)
-    // cost ONE memory round trip — the partials were written by other XCDs, so every load is an L2 miss.
-    constexpr int kCols = 4, kSlots = kBlock / kCols, kFly = 8;
     __shared__ double lds[kBlock * 2];
-    const int tc = threadIdx.x & (kCols - 1), tr = threadIdx.x / kCols;
-    const int c = blockIdx.x * kCols + tc;
-    double ss = 0.0, qq = 0.0;
-    if (c < C) {
-        const double* part = src.p[c / C_each];
-        const int cl = c % C_each;
-        for (int b = tr; b < nblk; b += kSlots * kFly) {
-            double s[kFly], q[kFly];
-#pragma unroll
-            for (int u = 0; u < kFly; ++u) {
-                const int bb = b + kSlots * u;
-                s[u] = bb < nblk ? part[((size_t)bb * 2) * C_each + cl] : 0.0;
-                q[u] = bb < nblk ? part[((size_t)bb * 2 + 1) * C_each + cl] : 0.0;
-            }
-#pragma unroll
-            for (int u = 0; u < kFly; ++u) {
-                ss += s[u];
-                qq += q[u];
-            }
-        }
-    }
-    lds[threadIdx.x * 2] = ss;
-    lds[threadIdx.x * 2 + 1] = qq;
-    __syncthreads();
-    // fold the 64 slots: 8 threads per column each fold 8 slots, then slot 0 folds those 8 (fixed order)
-    double a = 0.0, b2 = 0.0;
-    if (tr < 8)
-        for (int r = tr; r < kSlots; r += 8) {
-            a += lds[(r * kCols + tc) * 2];
-            b2 += lds[(r * kCols + tc) * 2 + 1];
-        }
-    __syncthreads();
-    if (tr < 8) {
-        lds[threadIdx.x * 2] = a;
-        lds[threadIdx.x * 2 + 1] = b2;
-    }
-    __syncthreads();
-    if (tr == 0 && c < C) {
-        ss = 0.0, qq = 0.0;
-        for (int r = 0; r < 8; ++r) {
-            ss += lds[(r * kCols + tc) * 2];
-            qq += lds[(r * kCols + tc) * 2 + 1];
-        }
+    const int tc = threadIdx.x & (kFinCols - 1), tr = threadIdx.x / kFinCols;
+    const int c = blockIdx.x * kFinCols + tc;
+    const bool ok = c < C;
+    double ss, qq;
+    gn_sum_partials(ok ? src.p[c / C_each] : nullptr, nblk, C_each, ok ? c % C_each : 0, ok, tc, tr, lds, ss, qq);
+    if (tr == 0 && ok)
         gn_fwd_coeffs(ss, qq, (double)N, gamma[c], beta[c], alpha[c], eps, saved[c], saved[C + c], saved[2 * C + c],
                       saved[3 * C + c]);
-    }
 }
 
 // ---- forward apply: y = dropout(act(x*scale + shift)) ------------------------------------------
@@ -446,8 +377,8 @@ extern "C" int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, in
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
     }
-    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
-                       (int)C, n_rows, gamma, beta, alpha, eps, saved);
+    hipLaunchKernelGGL(gn_finalize_src_kernel, dim3((unsigned)ceil_div(C, kFinCols)), dim3(kBlock), 0, st,
+                       StatSrc{{partial}}, nblk, (int)C, (int)C, n_rows, gamma, beta, alpha, eps, saved);
     if (vec) {
         hipLaunchKernelGGL(gn_apply_kernel<4>, ga, dim3(kBlock), 0, st, x, ldx, y, ldy, n_rows, (int)C, t.tc_log2,
                            saved, act, drop, rng_state);
@@ -474,8 +405,8 @@ extern "C" int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
     }
-    hipLaunchKernelGGL(gn_finalize_fwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
-                       (int)C, n_rows, gamma, beta, alpha, eps, saved);
+    hipLaunchKernelGGL(gn_finalize_src_kernel, dim3((unsigned)ceil_div(C, kFinCols)), dim3(kBlock), 0, st,
+                       StatSrc{{partial}}, nblk, (int)C, (int)C, n_rows, gamma, beta, alpha, eps, saved);
     return launch_status("glass_graphnorm_stats_f32");
 }
 
@@ -489,7 +420,7 @@ extern "C" int glass_graphnorm_finalize_f32(const double* const* partials, int64
     for (int k = 0; k < kMaxStatSrc; ++k) src.p[k] = k < n_src ? partials[k] : nullptr;
     for (int k = 0; k < n_src; ++k) GLASS_REQUIRE(src.p[k], "graphnorm_finalize: null source %d", k);
     const int64_t C = n_src * C_each;
-    hipLaunchKernelGGL(gn_finalize_src_kernel, dim3((unsigned)ceil_div(C, 4)), dim3(kBlock), 0, (hipStream_t)stream, src,
+    hipLaunchKernelGGL(gn_finalize_src_kernel, dim3((unsigned)ceil_div(C, kFinCols)), dim3(kBlock), 0, (hipStream_t)stream, src,
                        (int)nblk, (int)C_each, (int)C, n_rows, gamma, beta, alpha, eps, saved);
     return launch_status("glass_graphnorm_finalize_f32");
 }
@@ -542,7 +473,7 @@ extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const floa
         hipLaunchKernelGGL(gn_bwd_stats_kernel<1>, gs, dim3(kBlock), 0, st, dy, lddy, x, ldx, n_rows, (int)C,
                            t.tc_log2, saved, alpha, act, drop, rng_state, partial);
     }
-    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((unsigned)ceil_div(C, 16)), dim3(kBlock), 0, st, partial, nblk,
+    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((unsigned)ceil_div(C, kFinCols)), dim3(kBlock), 0, st, partial, nblk,
                        (int)C, n_rows, gamma, alpha, saved, dgamma, dbeta, dalpha, accumulate, coef);
     if (vec) {
         hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, addend, ldadd,

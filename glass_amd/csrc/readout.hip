@@ -195,7 +195,7 @@ struct R2Args {
     float *dgamma, *dbeta, *dalpha; int acc_gn;
 };
 
-// blocks [0,K): head gradient row k;  block K: mean loss;  blocks (K, K + ceil(C/16)]: GraphNorm backward finalize.
+// blocks [0,K): head gradient row k;  block K: mean loss;  blocks (K, K + ceil(C/4)]: GraphNorm backward finalize.
 // dynamic LDS: max(B floats, kBlock*2 doubles)
 __global__ __launch_bounds__(kBlock) void readout_reduce_kernel(R2Args a) {
     extern __shared__ double smd[];
@@ -332,7 +332,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     size_t lds2 = sizeof(double) * kBlock * 2;
     if (sizeof(float) * (size_t)B > lds2) lds2 = sizeof(float) * (size_t)B;
     GLASS_REQUIRE(lds2 <= 64 * 1024, "readout_train: batch too large for the LDS staging");
-    hipLaunchKernelGGL(readout_reduce_kernel, dim3((unsigned)(K + 1 + ceil_div(C, 16))), dim3(kBlock), lds2, st, a2);
+    hipLaunchKernelGGL(readout_reduce_kernel, dim3((unsigned)(K + 1 + ceil_div(C, kFinCols))), dim3(kBlock), lds2, st, a2);
     const int rpb = kBlock / tc;
     int64_t blocks = ceil_div(n_nodes, (int64_t)rpb * 4);
     if (blocks > 4096) blocks = 4096;
