@@ -107,43 +107,84 @@ __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float 
 }
 
 // Whole product for one wave's 16 rows: passes over K in chunks of 64 (16 per lane), weight slices
-// double-buffered through LDS.  `load_a(kc, a)` fills this lane's A chunk of pass kc.
-template <int NT, int KT, typename LoadA>
+// double-buffered through LDS.  The A operand of pass kc is produced in two steps so that the loads of pass kc+1
+// stay in flight across the MFMAs of pass kc: `issue(kc, raw)` only starts the global loads into `raw`;
+// `finish(kc, raw, a)` (run after the current pass) turns them into the operand chunk (prologue arithmetic).
+template <int NT, int KT, typename Raw, typename Issue, typename Finish>
 __device__ __forceinline__ void staged_product(f32x4 (&acc)[NT / 16], const float* __restrict__ W, float4* lds,
-                                               int lane, LoadA load_a) {
+                                               int lane, Issue issue, Finish finish) {
     constexpr int NKC = KT / 4 / kKC;
     constexpr int kVecs = WStage<NT>::kVecs;
     WStage<NT> ws;
     ws.fetch(W, KT, 0);
-    float a[kKC];
-    load_a(0, a);
+    Raw raw;
+    issue(0, raw);
     ws.commit(lds);
+    float a[kKC];
+    finish(0, raw, a);
     __syncthreads();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
-        float an[kKC];
         if (kc + 1 < NKC) {
             ws.fetch(W, KT, kc + 1);
-            load_a(kc + 1, an);
+            issue(kc + 1, raw);
         }
+        __builtin_amdgcn_sched_barrier(0);  // the loads above are issued before the MFMAs below
         mfma_pass_lds<NT / 16>(acc, a, lds + (kc & 1) * kVecs, lane);
         if (kc + 1 < NKC) {
             ws.commit(lds + ((kc + 1) & 1) * kVecs);
-#pragma unroll
-            for (int s = 0; s < kKC; ++s) a[s] = an[s];
+            finish(kc + 1, raw, a);
             __syncthreads();
         }
     }
 }
 
 // ---- forward ----------------------------------------------------------------------------------
+// Optional GraphNorm prologue on the xa operand: xa is the INPUT of a GraphNorm whose statistics are already final
+// (saved[4C] = mean, rstd, scale, shift); the lanes normalise (+ ELU + dropout) their chunk while loading it, use
+// it as the MFMA operand and write it to `side` (the layer's backward and, for the trans pair, the comb pair of the
+// same layer read it) — the GraphNorm apply launch and its read of xa disappear.
+struct GnPrologue {
+    const float* saved;  // nullptr: no prologue
+    int C, act;
+    Drop drop;
+    const uint64_t* rng_state;
+    float* side;
+    int64_t lds;
+};
+
+struct FwdRaw {
+    float x[kKC];
+    float4 sc[kKC / 4], sh[kKC / 4];  // GraphNorm scale / shift of this chunk's columns (prologue lanes only)
+};
+
+__device__ __forceinline__ void gn_prologue16(float (&a)[kKC], const FwdRaw& raw, const GnPrologue& pro,
+                                              const Drop& drop, int64_t row, int col0) {
+#pragma unroll
+    for (int v = 0; v < kKC / 4; ++v) {
+        const float4 s4 = raw.sc[v], h4 = raw.sh[v];
+        const float scale[4] = {s4.x, s4.y, s4.z, s4.w}, shift[4] = {h4.x, h4.y, h4.z, h4.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop.p > 0.f) drop_scales<4>(drop, row, col0 + 4 * v, ds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float h = fmaf(a[4 * v + k], scale[k], shift[k]);
+            if (pro.act == GLASS_ACT_ELU) h = elu_f(h);
+            a[4 * v + k] = h * ds[k];
+        }
+        *reinterpret_cast<float4*>(pro.side + row * pro.lds + col0 + 4 * v) =
+            make_float4(a[4 * v], a[4 * v + 1], a[4 * v + 2], a[4 * v + 3]);
+    }
+}
+
 template <int H, bool COMB>
 __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                           const float* __restrict__ xb, int64_t ldb,
                                                           const float* __restrict__ W, const float* __restrict__ bias,
                                                           const uint8_t* __restrict__ mask, float zr, float omz, int act,
                                                           float* __restrict__ T, int64_t ldt, float* __restrict__ out,
-                                                          int64_t ldo, int64_t N, double* __restrict__ stats) {
+                                                          int64_t ldo, int64_t N, double* __restrict__ stats,
+                                                          GnPrologue pro) {
     constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H, NTILES = NT / 16;
     static_assert(KQ % kKC == 0, "hidden size must be a multiple of 64");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -162,7 +203,30 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
     f32x4 acc[NTILES];
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    staged_product<NT, KT>(acc, W, lds_w, lane, [&](int kc, float (&a)[kKC]) { load16(a, arow + kc * kKC, row_ok); });
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    const bool pro_lane = pro.saved != nullptr && row_ok && (!COMB || q < 2);  // lanes whose chunk belongs to xa
+    staged_product<NT, KT, FwdRaw>(
+        acc, W, lds_w, lane,
+        [&](int kc, FwdRaw& raw) {
+            load16(raw.x, arow + kc * kKC, row_ok);
+            if (pro_lane) {
+                const int col0 = q * KQ + kc * kKC;
+#pragma unroll
+                for (int v = 0; v < kKC / 4; ++v) {
+                    raw.sc[v] = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + col0 + 4 * v);
+                    raw.sh[v] = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + col0 + 4 * v);
+                }
+            }
+        },
+        [&](int kc, const FwdRaw& raw, float (&a)[kKC]) {
+#pragma unroll
+            for (int s2 = 0; s2 < kKC; ++s2) a[s2] = raw.x[s2];
+            if (pro_lane) gn_prologue16(a, raw, pro, drop, row, q * KQ + kc * kKC);
+        });
     // epilogue: acc[4g+k][reg] is row row0 + 4q + reg, column 64g + 4i + k  ->  float4 per (row, group)
     constexpr int NG = H / 64;  // 64-column groups per half
     float ssum[NG][4], ssq[NG][4];  // this lane's column sums over its (up to) 4 rows, for the GraphNorm that follows
@@ -240,6 +304,10 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
     }
 }
 
+struct DgradRaw {
+    float d[kKC], t[kKC];
+};
+
 // ---- backward data gradient ---------------------------------------------------------------------
 // out[N, NT] = dZ[N, 2H] @ Wstack[2H, NT] (+ addend), dZ[n, o] = coef(n, o<H) * dsrc[n, o mod H] * act'(T[n, o]);
 // WT = Wstack^T stored [NT][2H] so that weight chunks are contiguous (refreshed once per step).
@@ -267,17 +335,20 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
     f32x4 acc[NTILES];
 #pragma unroll
     for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    staged_product<NT, KT>(acc, WT, lds_w, lane, [&](int kc, float (&a)[kKC]) {
-        load16(a, drow + kc * kKC, row_ok);
-        if (act == GLASS_ACT_ELU) {
-            float tv[kKC];
-            load16(tv, trow + kc * kKC, row_ok);
+    staged_product<NT, KT, DgradRaw>(
+        acc, WT, lds_w, lane,
+        [&](int kc, DgradRaw& raw) {
+            load16(raw.d, drow + kc * kKC, row_ok);
+            if (act == GLASS_ACT_ELU) load16(raw.t, trow + kc * kKC, row_ok);
+        },
+        [&](int, const DgradRaw& raw, float (&a)[kKC]) {
 #pragma unroll
-            for (int s = 0; s < kKC; ++s) a[s] *= elu_grad_f(tv[s]);
-        }
-#pragma unroll
-        for (int s = 0; s < kKC; ++s) a[s] *= coef;
-    });
+            for (int s = 0; s < kKC; ++s) {
+                float v = raw.d[s] * coef;
+                if (act == GLASS_ACT_ELU) v *= elu_grad_f(raw.t[s]);
+                a[s] = v;
+            }
+        });
     if (drop.p > 0.f) {
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
@@ -362,8 +433,14 @@ extern "C" int glass_dual_linear_supported(int64_t H) {
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
                                          int64_t ldt, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
-                                         double* stats, void* stream) {
+                                         double* stats, const float* gn_saved, int gn_act, float p_drop,
+                                         const uint64_t* rng_state, uint64_t call_id, float* xa_out, int64_t ldxo,
+                                         void* stream) {
     GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
+    GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved) &&
+                                p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
+                                (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                  "dual_linear_fwd: bad GraphNorm prologue arguments");
     if (!dense_shape_ok(H)) {
         set_error("dual_linear_fwd: hidden size %lld not supported (64, 128)", (long long)H);
         return GLASS_E_UNSUPPORTED;
@@ -378,16 +455,17 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs >1 pass)
     const size_t image = (size_t)2 * H * 256;
+    const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
 #define GLASS_FWD(HH)                                                                                              \
     if (H == HH) {                                                                                                 \
         allow_lds(dual_fwd_kernel<HH, true>, 2 * image);                                                           \
         allow_lds(dual_fwd_kernel<HH, false>, 2 * image);                                                          \
         if (comb)                                                                                                  \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, true>), grid, dim3(kBlock), 2 * image, st, xa, lda, xb, ldb, W, bias, \
-                               mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats);                              \
+                               mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);                         \
         else                                                                                                       \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, false>), grid, dim3(kBlock), (HH > 64 ? 2 : 1) * image, st, xa, lda, \
-                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats);            \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
     }
     GLASS_FWD(64) GLASS_FWD(128)
 #undef GLASS_FWD

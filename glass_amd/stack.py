@@ -10,7 +10,7 @@ of the kernel that produces the other summand, and parameter gradients go straig
 
 Used when every layer takes the fused dense path (ParamArena present, GLASSConv layers of equal width that
 glass_dual_linear_supported() accepts, ELU, GraphNorm on); anything else keeps the per-op path.  Same kernels,
-same Philox call ids -> same dropout masks as the per-op path.
+same dropout call ids -> same dropout masks as the per-op path.
 """
 import numpy as np
 import torch
@@ -47,6 +47,17 @@ class _GN:
         _check(rc, "glass_graphnorm_fwd_f32")
         return saved
 
+    def stats(self, x):
+        """saved[4C] (statistics + finalize, no apply pass): the consumer normalises while loading."""
+        m = self.mod
+        n, C = x.shape
+        saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        rc = _lib.load().glass_graphnorm_stats_f32(x.data_ptr(), x.stride(0), n, C, m.weight.data_ptr(), m.bias.data_ptr(),
+                                                   m.mean_scale.data_ptr(), float(m.eps), saved.data_ptr(),
+                                                   ops._graphnorm_ws(x.device, n, C).data_ptr(), _stream())
+        _check(rc, "glass_graphnorm_stats_f32")
+        return saved
+
     def finalize(self, stats, n_rows):
         """saved[4C] from statistics the producers' epilogues wrote (list of [nblk, 2, C_each] float64 buffers)."""
         m = self.mod
@@ -81,15 +92,23 @@ class _GN:
         _check(rc, "glass_graphnorm_bwd_f32")
 
 
-def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None):
-    """stats: [ceil(n/64), 2, H] float64 — per-workgroup column sums of `out` for the GraphNorm that follows."""
+def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None, gn=None):
+    """stats: [ceil(n/64), 2, H] float64 — per-workgroup column sums of `out` for the GraphNorm that follows.
+    gn = (saved, act, p_drop, call_id, xa_out): xa is the raw input of a GraphNorm with final statistics `saved`; the
+    kernel normalises (+act +dropout) while loading and writes the normalised operand to xa_out."""
     n, H = xa.shape
+    if gn is not None:
+        saved, gact, gp, gcall, xa_out = gn
+        grng = ops.rng_state(xa.device).data_ptr() if gp > 0 else 0
+        gargs = (saved.data_ptr(), gact, float(gp), grng, gcall, xa_out.data_ptr(), xa_out.stride(0))
+    else:
+        gargs = (0, 0, 0.0, 0, 0, 0, 0)
     rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                                0 if xb is None else xb.stride(0), stack[4].data_ptr(),
                                                stack[1].data_ptr(), mask.data_ptr(), float(z_ratio), act,
                                                0 if T is None else T.data_ptr(), 0 if T is None else T.stride(0),
                                                out.data_ptr(), out.stride(0), n, H,
-                                               0 if stats is None else stats.data_ptr(), _stream())
+                                               0 if stats is None else stats.data_ptr(), *gargs, _stream())
     _check(rc, "glass_dual_linear_fwd_f32")
 
 
@@ -212,28 +231,35 @@ class StackProgram:
         C_out = H * L if emb.jk else H
         jk = torch.empty((n, C_out), **f32)
         layers, cstats = [], []
+        pending_gn = None  # (saved, act, p, call_id) of the GraphNorm between the previous layer and this one
+        c_prev = None
         for l, conv in enumerate(emb.convs):
             if conv.adj is None:
                 conv.adj = buildAdj(edge_index, edge_weight, n, conv.aggr)
             pc = float(conv.dropout) if train else 0.0
             T = torch.empty((n, 2 * H), **f32)
             m = torch.empty((n, H), **f32)
-            _dual_fwd(h, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m)
+            if pending_gn is None:
+                _dual_fwd(h, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m)
+            else:
+                # gns[l-1] (+ELU +dropout) is applied by the trans kernel while it loads c_{l-1}; h = its side output
+                h = torch.empty((n, H), **f32)
+                _dual_fwd(c_prev, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m, gn=(*pending_gn, h))
             a = conv.adj.fwd.spmm(m)
+            # conv.gn: statistics + finalize here, the apply (+dropout) rides in the comb kernel's operand load
             g = torch.empty((n, H), **f32)
-            gsaved = _GN(conv.gn).fwd(a, g, ACT_NONE, pc, conv.call_base)
+            gsaved = _GN(conv.gn).stats(a)
             last = l + 1 == L
             c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
             # the comb kernel's epilogue also leaves the column statistics of c for the GraphNorm(s) that read it
             cstat = torch.empty(((n + 63) // 64, 2, H), dtype=torch.float64, device=dev)
-            _dual_fwd(g, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c, cstat)
+            _dual_fwd(a, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c, cstat,
+                      gn=(gsaved, ACT_NONE, pc, conv.call_base, g))
             cstats.append(cstat)
             rec = {"h": h, "T": T, "a": a, "g": g, "gsaved": gsaved, "c": c, "pc": pc}
             if not last:
-                h = torch.empty((n, H), **f32)
-                gnl = _GN(emb.gns[l])
-                rec["nsaved"] = gnl.finalize([cstat], n)
-                gnl.apply(c, h, rec["nsaved"], ACT_ELU, p, conv.call_base + 1)
+                rec["nsaved"] = _GN(emb.gns[l]).finalize([cstat], n)
+                pending_gn, c_prev = (rec["nsaved"], ACT_ELU, p, conv.call_base + 1), c
             layers.append(rec if keep else None)
         st["jk"], st["layers"] = jk, layers
         gnf = _GN(emb.gns[-1])

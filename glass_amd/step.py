@@ -5,7 +5,7 @@ The step is ~100 short kernels on small graphs (ppi_bp-shape: the aggregation it
 so eager launches are host-bound; every kernel in libglass_hip only enqueues work on the caller's
 stream (no allocation, no sync), which makes the whole step capturable: MaxZOZ -> zero grads ->
 forward -> loss -> backward -> [all-reduce] -> Adam.  Dropout masks still change every replay
-because the Philox (seed, step) pair lives in device memory and is advanced by a captured kernel.
+because the dropout (seed, step) pair lives in device memory and is advanced by a captured kernel.
 With more than one rank the collective stays outside the graphs (forward/backward graph, eager
 all-reduce on the same stream, optimizer graph)."""
 import torch

@@ -120,7 +120,7 @@ int glass_mix_bwd_f32(const float* dout, int64_t ldd, const float* T, int64_t ld
  *     after every GraphNorm(+act): impl/models.py:166,251,259).
  *     Column sums are accumulated in fp64 (one pass: sum and sum of squares), reduced in a fixed
  *     order. `saved` = float[4*C]: mean, rstd, scale, shift (needed by the backward).
- *     Dropout: keep-mask from Philox4x32-10 keyed by (rng_state[0]=seed, rng_state[1]=step,
+ *     Dropout: keep-mask from a counter-based hash keyed by (rng_state[0]=seed, rng_state[1]=step,
  *     call_id, element index); rng_state is DEVICE memory so captured graphs see new masks each
  *     replay once glass_rng_advance has run. p_drop = 0 disables it (rng_state may be NULL).
  * ---------------------------------------------------------------------------------------- */
@@ -221,12 +221,18 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
 int glass_dual_linear_supported(int64_t H);
 /*   fwd, stats != NULL: the epilogue also writes the column statistics of `out` for the GraphNorm that consumes
  *   it — stats[ceil(n_nodes/64)][2][H] doubles (per 64-row workgroup: sum, sum of squares) — so that GraphNorm
- *   needs no statistics pass of its own: glass_graphnorm_finalize_f32 + glass_graphnorm_apply_f32. */
+ *   needs no statistics pass of its own: glass_graphnorm_finalize_f32 + glass_graphnorm_apply_f32.
+ *   fwd, gn_saved != NULL: xa is the INPUT of a GraphNorm whose statistics are final (gn_saved[4H] from
+ *   glass_graphnorm_finalize_f32 / _stats_f32); the kernel computes dropout(act(xa*scale + shift)) while loading
+ *   (gn_act, p_drop, rng_state, call_id as in glass_graphnorm_fwd_f32), multiplies THAT, and writes it to xa_out
+ *   [n_nodes, H] for the backward — no separate GraphNorm apply launch. */
 int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg,
                               const float* bias, const uint8_t* mask, double z_ratio, int act, float* T, int64_t ldt,
-                              float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* stats, void* stream);
+                              float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* stats, const float* gn_saved,
+                              int gn_act, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
+                              int64_t ldxo, void* stream);
 /*   dgrad epilogue: out = (dZ @ W + addend) * dropmask(p_drop, rng_state, call_id) — the mask of the dropout that
- *   produced this layer's input (same Philox layout as glass_graphnorm_fwd_f32), so the consumer receives the
+ *   produced this layer's input (same mask layout as glass_graphnorm_fwd_f32), so the consumer receives the
  *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL). */
 int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* WTimg, int64_t n_out, const float* addend,

@@ -221,7 +221,7 @@ def test_graphnorm_strided_input_and_repeatable():
 
 def test_graphnorm_dropout_statistics():
     """Inverted dropout fused after GraphNorm: keep-rate, scaling, and the backward reuses the
-    forward's mask (regenerated from the Philox counter, not stored)."""
+    forward's mask (regenerated from the counter, not stored)."""
     from glass_amd import ops
     n, C, p = 20000, 64, 0.5
     x = torch.randn(n, C, device=DEV).requires_grad_(True)

@@ -449,7 +449,7 @@ def test_stack_program_vs_oracle(layers, jk, aggr):
 
 
 def test_stack_program_matches_per_op_path_with_dropout(monkeypatch):
-    """Same kernels, same Philox call ids: with dropout 0.5 the program and the per-op autograd path must draw the
+    """Same kernels, same dropout call ids: with dropout 0.5 the program and the per-op autograd path must draw the
     same masks, so outputs and gradients agree to rounding (the gradient sums are merely associated differently)."""
     from glass_amd import models as gm, ops
     emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.95, 0.5, seed=11)
