@@ -227,6 +227,27 @@ __global__ __launch_bounds__(kBlock) void mix_bwd_kernel(const float* __restrict
     }
 }
 
+// Plain fill kernels instead of hipMemsetAsync: inside a captured hipGraph a memset NODE followed by the scatter
+// kernel was observed to leave stale labels behind after other work had run between replays (z of the same pos
+// differed between replays; found by hashing every intermediate of a replayed step) — kernels order reliably.
+__global__ __launch_bounds__(kBlock) void fill_i64_kernel(int64_t* __restrict__ p, int64_t n, int64_t v) {
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) p[k] = v;
+}
+
+__global__ __launch_bounds__(kBlock) void fill_u8_kernel(uint8_t* __restrict__ p, int64_t n, uint8_t v) {
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) p[k] = v;
+}
+
+// two small device-to-device copies in one launch (the batch's pos and target into the captured step's buffers)
+__global__ __launch_bounds__(kBlock) void copy_pair_kernel(uint32_t* __restrict__ d0, const uint32_t* __restrict__ s0,
+                                                           int64_t w0, uint32_t* __restrict__ d1,
+                                                           const uint32_t* __restrict__ s1, int64_t w1) {
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < w0 + w1; k += (int64_t)gridDim.x * kBlock) {
+        if (k < w0) d0[k] = s0[k];
+        else d1[k - w0] = s1[k - w0];
+    }
+}
+
 }  // namespace glass
 
 using namespace glass;
@@ -252,11 +273,9 @@ extern "C" int glass_maxzoz_i64(const int64_t* pos, int64_t n_pos, int64_t* z, i
     GLASS_REQUIRE(z && n_nodes >= 0 && n_pos >= 0 && (pos || n_pos == 0), "maxzoz: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     if (n_nodes == 0) return 0;
-    hipError_t e = hipMemsetAsync(z, 0, (size_t)n_nodes * sizeof(int64_t), st);
-    if (e != hipSuccess) {
-        set_error("maxzoz: memset: %s", hipGetErrorString(e));
-        return (int)e;
-    }
+    int64_t fb = ceil_div(n_nodes, kBlock);
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((unsigned)fb), dim3(kBlock), 0, st, z, n_nodes, (int64_t)0);
     if (n_pos > 0) {
         int64_t b = ceil_div(n_pos, 256);
         if (b > 1024) b = 1024;
@@ -271,12 +290,10 @@ extern "C" int glass_embed_label_f32(const int64_t* x, const float* W, int64_t V
     GLASS_REQUIRE(x && W && out && mask, "embed_label: null pointer");
     GLASS_REQUIRE(n_nodes > 0 && H > 0 && V > 0 && ldo >= H, "embed_label: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    if (!z) {
-        hipError_t e = hipMemsetAsync(mask, pos ? 0 : 1, (size_t)n_nodes, st);  // no z, no pos: all labeled
-        if (e != hipSuccess) {
-            set_error("embed_label: memset: %s", hipGetErrorString(e));
-            return (int)e;
-        }
+    if (!z) {  // no z, no pos: all labeled
+        int64_t fb = ceil_div(n_nodes, kBlock);
+        if (fb > 2048) fb = 2048;
+        hipLaunchKernelGGL(fill_u8_kernel, dim3((unsigned)fb), dim3(kBlock), 0, st, mask, n_nodes, (uint8_t)(pos ? 0 : 1));
     }
     const bool vec = H % 4 == 0 && ldo % 4 == 0 && aligned16(W) && aligned16(out);
     const RowTiling t = row_tiling(H, vec);
@@ -325,4 +342,17 @@ extern "C" int glass_mix_bwd_f32(const float* dout, int64_t ldd, const float* T,
         hipLaunchKernelGGL(mix_bwd_kernel<1>, grid, dim3(kBlock), 0, st, dout, ldd, T, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio), act, dT,
                            lddt, n_nodes, (int)H, t.tc_log2);
     return launch_status("glass_mix_bwd_f32");
+}
+
+extern "C" int glass_copy_pair(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1,
+                               int64_t bytes1, void* stream) {
+    GLASS_REQUIRE(dst0 && src0 && dst1 && src1 && bytes0 > 0 && bytes1 > 0, "copy_pair: null pointer / empty copy");
+    GLASS_REQUIRE(bytes0 % 4 == 0 && bytes1 % 4 == 0 && ((uintptr_t)dst0 | (uintptr_t)src0 | (uintptr_t)dst1 | (uintptr_t)src1) % 4 == 0,
+                  "copy_pair: 4-byte granularity");
+    const int64_t words = (bytes0 + bytes1) / 4;
+    int64_t blocks = ceil_div(words, kBlock);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(copy_pair_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, (uint32_t*)dst0,
+                       (const uint32_t*)src0, bytes0 / 4, (uint32_t*)dst1, (const uint32_t*)src1, bytes1 / 4);
+    return launch_status("glass_copy_pair");
 }

@@ -36,9 +36,16 @@ __global__ __launch_bounds__(kBlock) void emb_table_fwd_kernel(const float* __re
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ alpha, float eps,
-                                                               float* __restrict__ saved, float* __restrict__ table) {
+                                                               float* __restrict__ saved, float* __restrict__ table,
+                                                               uint8_t* __restrict__ mask_fill, int fill_value,
+                                                               int64_t n_nodes) {
     __shared__ double lds[kBlock * 2];
     __shared__ float coef[2 * kTabCols];
+    // label bytes initialised here (0 before the gather kernel scatters pos, 1 = everything labeled) instead of by a
+    // memset launch (two fill launches for a byte count that is not a multiple of 4)
+    if (mask_fill)
+        for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n_nodes; n += (int64_t)gridDim.x * kBlock)
+            mask_fill[n] = (uint8_t)fill_value;
     const int tc = threadIdx.x & (kTabCols - 1), tr = threadIdx.x / kTabCols;
     const int c = blockIdx.x * kTabCols + tc;
     const bool ok = c < H;
@@ -204,15 +211,9 @@ extern "C" int glass_embed_norm_fwd_f32(const int64_t* x, const float* W, int64_
                   "embed_norm_fwd: bad sizes (V=%lld, at most %d table rows)", (long long)V, GLASS_EMBED_NORM_MAX_ROWS);
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "embed_norm_fwd: bad dropout args");
     hipStream_t st = (hipStream_t)stream;
-    if (!z) {
-        hipError_t e = hipMemsetAsync(mask, pos ? 0 : 1, (size_t)n_nodes, st);  // no z, no pos: all labeled
-        if (e != hipSuccess) {
-            set_error("embed_norm_fwd: memset: %s", hipGetErrorString(e));
-            return (int)e;
-        }
-    }
+    // no z: the table kernel fills the label bytes (0 when pos will be scattered by the gather kernel, else all 1)
     hipLaunchKernelGGL(emb_table_fwd_kernel, dim3((unsigned)ceil_div(H, kTabCols)), dim3(kBlock), 0, st, W, (int)V, (int)H,
-                       class_rowptr, gamma, beta, alpha, eps, saved, table);
+                       class_rowptr, gamma, beta, alpha, eps, saved, table, z ? nullptr : mask, pos ? 0 : 1, n_nodes);
     const bool vec = H % 4 == 0 && ldo % 4 == 0 && aligned16(table) && aligned16(out);
     const int vw = vec ? 4 : 1;
     const int cw = (int)ceil_div(H, vw);

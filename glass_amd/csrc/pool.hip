@@ -154,6 +154,60 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_kernel(const float* __restric
     }
 }
 
+// Ordered, atomic-free backward for sum / mean / size pooling (demb zero-filled by the caller): the whole pos
+// matrix is staged in LDS as int32 node ids together with every subgraph's scale; one wave per entry: if an EARLIER
+// entry names the same node the wave skips (that entry owns the node), otherwise it adds up every occurrence in
+// (b, s) order (64 entries per ballot) and stores the row.  Bitwise repeatable however many subgraphs share a node.
+__global__ __launch_bounds__(kBlock) void pool_bwd_ordered_kernel(const float* __restrict__ dout, int64_t ldd,
+                                                                  const int64_t* __restrict__ pos, int Smax, int B,
+                                                                  int mode, float* __restrict__ demb, int64_t lde,
+                                                                  int64_t n_nodes, int C) {
+    extern __shared__ int32_t sm_i[];
+    int32_t* nodes = sm_i;                                         // [B*Smax]
+    float* scale = reinterpret_cast<float*>(sm_i + (size_t)B * Smax);  // [B]
+    const int n_pos = B * Smax;
+    for (int j = threadIdx.x; j < n_pos; j += kBlock) {
+        const int64_t p = pos[j];
+        nodes[j] = (p >= 0 && p < n_nodes) ? (int32_t)p : -1;
+    }
+    __syncthreads();
+    for (int bb = threadIdx.x; bb < B; bb += kBlock) {
+        int cnt = 0;
+        for (int s = 0; s < Smax; ++s) cnt += nodes[bb * Smax + s] >= 0;
+        scale[bb] = pool_scale(mode, cnt);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
+    for (int s = w; s < Smax; s += kBlock / kWave) {
+        const int j = b * Smax + s;
+        const int node = nodes[j];
+        if (node < 0) continue;  // wave-uniform
+        bool owned = false;      // an earlier entry names this node
+        for (int j0 = 0; j0 < j && !owned; j0 += kWave) {
+            const int jj = j0 + lane;
+            owned = __any(jj < j && nodes[jj] == node);
+        }
+        if (owned) continue;
+        for (int c0 = 0; c0 < C; c0 += kWave) {  // 64 columns per pass, one per lane (any C, any alignment)
+            const int c = c0 + lane;
+            float acc = 0.f;
+            for (int j0 = j; j0 < n_pos; j0 += kWave) {
+                const int jj = j0 + lane;
+                unsigned long long hits = __ballot(jj < n_pos && nodes[jj] == node);
+                while (hits) {
+                    const int bit = __ffsll((long long)hits) - 1;
+                    hits &= hits - 1;
+                    const int bb = (j0 + bit) / Smax;
+                    if (c < C) acc = fmaf(dout[(int64_t)bb * ldd + c], scale[bb], acc);
+                }
+            }
+            if (c < C) demb[(int64_t)node * lde + c] = acc;
+        }
+    }
+}
+
+constexpr int64_t kPoolOrderedMax = 12288;  // pos entries (+ B scales) staged in LDS: <= 64 KiB
+
 }  // namespace glass
 
 using namespace glass;
@@ -204,6 +258,12 @@ extern "C" int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const 
     while ((1 << tc_log2) < tc) ++tc_log2;
     dim3 grid((unsigned)B, (unsigned)ceil_div(cw, tc));
     hipStream_t st = (hipStream_t)stream;
+    if (mode != GLASS_POOL_MAX && B * Smax + B <= kPoolOrderedMax) {
+        // atomic-free and bitwise repeatable (demb is zero-filled by the caller; untouched rows stay zero)
+        hipLaunchKernelGGL(pool_bwd_ordered_kernel, dim3((unsigned)B), dim3(kBlock), sizeof(int32_t) * (size_t)(B * Smax + B), st,
+                           dout, ldd, pos, (int)Smax, (int)B, mode, demb, lde, n_nodes, (int)C);
+        return launch_status("glass_segment_pool_bwd_f32");
+    }
     if (vec)
         hipLaunchKernelGGL(pool_bwd_kernel<4>, grid, dim3(kBlock), 0, st, dout, ldd, pos, (int)Smax, mode, argmax, demb,
                            lde, n_nodes, (int)C, tc_log2);

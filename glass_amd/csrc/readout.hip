@@ -12,13 +12,16 @@
 //   R2  head weight/bias gradient rows, the mean loss, and the GraphNorm backward finalize (independent roles of one
 //       launch).
 //   R3  dense part of the GraphNorm backward over all nodes: d jk = Bx*x + K.
-//   R4  sparse part: d jk[n] += A * g[n] on the pooled rows (float atomics, like glass_segment_pool_bwd_f32).
+//   R4  sparse part: d jk[n] += A * g[n] on the pooled rows: an ordered, atomic-free scatter (bitwise repeatable) while
+//       pos fits LDS (B*Smax <= 16 384); beyond that float atomics (order-dependent in the last bits when subgraphs
+//       share nodes, because the row already holds the dense part).
 #include "common.h"
 #include "gn_math.h"
 
 namespace glass {
 
 constexpr int kReadoutMaxK = 256;
+constexpr int64_t kReadoutOrderedMax = 16384;  // pos entries staged in LDS by the atomic-free scatter (64 KiB)
 constexpr int kLossCE = 0, kLossBCE = 1;
 
 struct ReadoutWs {
@@ -264,6 +267,71 @@ __global__ __launch_bounds__(kBlock) void readout_dense_kernel(const float* __re
     }
 }
 
+// R4 (ordered): d jk[n] += A * sum of g over the subgraphs holding n, WITHOUT atomics.  The whole pos matrix is staged
+// in LDS (int32 node ids); one wave per entry: if an EARLIER entry names the same node the wave skips (that entry
+// owns the node), otherwise it adds up every occurrence in (b, s) order (64 entries per ballot) and does the single
+// read-modify-write of that row.  Bitwise repeatable however many subgraphs share a node; B*Smax <= 16 384.
+__global__ __launch_bounds__(kBlock) void readout_scatter_ordered_kernel(const int64_t* __restrict__ pos, int Smax,
+                                                                         int n_pos, const float* __restrict__ dys,
+                                                                         const float* __restrict__ coef,
+                                                                         float* __restrict__ dx, int64_t lddx,
+                                                                         int64_t n_nodes, int C) {
+    extern __shared__ int32_t nodes[];
+    for (int j = threadIdx.x; j < n_pos; j += kBlock) {
+        const int64_t p = pos[j];
+        nodes[j] = (p >= 0 && p < n_nodes) ? (int32_t)p : -1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
+    for (int s = w; s < Smax; s += kBlock / kWave) {
+        const int j = b * Smax + s;
+        const int node = nodes[j];
+        if (node < 0) continue;  // wave-uniform
+        bool owned = false;      // an earlier entry names this node
+        for (int j0 = 0; j0 < j && !owned; j0 += kWave) {
+            const int jj = j0 + lane;
+            owned = __any(jj < j && nodes[jj] == node);
+        }
+        if (owned) continue;
+        // every lane takes part in the ballots (entries are spread over all 64 lanes); a lane owns the columns
+        // lane*4 + 256*t, t < 4 (C <= 1024)
+        float4 acc[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j0 = j; j0 < n_pos; j0 += kWave) {
+            const int jj = j0 + lane;
+            unsigned long long hits = __ballot(jj < n_pos && nodes[jj] == node);
+            while (hits) {
+                const int bit = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const float* grow = dys + (int64_t)((j0 + bit) / Smax) * C;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int c = lane * 4 + kWave * 4 * t;
+                    if (c < C) {
+                        const float4 A = *reinterpret_cast<const float4*>(coef + c);
+                        const float4 g = *reinterpret_cast<const float4*>(grow + c);
+                        acc[t].x = fmaf(A.x, g.x, acc[t].x);
+                        acc[t].y = fmaf(A.y, g.y, acc[t].y);
+                        acc[t].z = fmaf(A.z, g.z, acc[t].z);
+                        acc[t].w = fmaf(A.w, g.w, acc[t].w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int c = lane * 4 + kWave * 4 * t;
+            if (c < C) {
+                float4* dst = reinterpret_cast<float4*>(dx + (int64_t)node * lddx + c);
+                float4 o = *dst;
+                o.x += acc[t].x; o.y += acc[t].y; o.z += acc[t].z; o.w += acc[t].w;
+                *dst = o;
+            }
+        }
+    }
+}
+
 // R4: d jk[n] += A * g on the pooled rows
 __global__ __launch_bounds__(kBlock) void readout_scatter_kernel(const int64_t* __restrict__ pos, int Smax,
                                                                  const float* __restrict__ dys,
@@ -338,7 +406,12 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(readout_dense_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, jk, ldj, djk, lddj, n_nodes, (int)C,
                        tc_log2, w.coef);
-    hipLaunchKernelGGL(readout_scatter_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, pos, (int)Smax, w.dys, w.coef, djk,
-                       lddj, n_nodes, (int)C, tc_log2);
+    if (B * Smax <= kReadoutOrderedMax) {
+        hipLaunchKernelGGL(readout_scatter_ordered_kernel, dim3((unsigned)B), dim3(kBlock), sizeof(int32_t) * (size_t)(B * Smax),
+                           st, pos, (int)Smax, (int)(B * Smax), w.dys, w.coef, djk, lddj, n_nodes, (int)C);
+    } else {
+        hipLaunchKernelGGL(readout_scatter_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, pos, (int)Smax, w.dys, w.coef,
+                           djk, lddj, n_nodes, (int)C, tc_log2);
+    }
     return launch_status("glass_readout_train_f32");
 }

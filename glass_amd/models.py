@@ -187,7 +187,6 @@ class EmbZGConv(nn.Module):
             self.gns.append(GraphNorm(output_channels + (num_layers - 1) * hidden_channels if jk else output_channels))
         else:
             self.gns = None
-        self._sel = None
         self.reset_parameters()
 
     def reset_parameters(self):
@@ -200,12 +199,20 @@ class EmbZGConv(nn.Module):
                 gn.reset_parameters()
 
     def _selection(self, x_flat):
-        # x is static per dataset: key the cached selection on the storage it views (the tensor is
-        # kept alive in the cache entry so the pointer cannot be recycled underneath us)
+        # x is static per dataset: the selection CSR is cached per feature tensor, keyed on the storage it views (the
+        # tensor is kept alive in the entry so the pointer cannot be recycled underneath us).  SEVERAL entries are kept:
+        # train / validation / test sets hold their own copies of x, and a captured training step (hipGraph) keeps
+        # launching K1 with the raw pointers of ITS entry — evicting that entry when an evaluation comes by with another
+        # x would leave the graph reading freed memory.
         key = (x_flat.data_ptr(), x_flat.shape[0], self.input_emb.weight.shape[0])
-        if self._sel is None or self._sel[0] != key:
-            self._sel = (key, x_flat, Selection(x_flat, key[2]))
-        return self._sel[2]
+        cache = self.__dict__.setdefault("_sel_cache", {})
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 16:
+                raise RuntimeError("EmbZGConv: more than 16 distinct node-feature tensors seen by one model; the selection "
+                                   "cache keeps them alive for captured graphs — reuse the dataset tensors")
+            hit = cache[key] = (x_flat, Selection(x_flat, key[2]))
+        return hit[1]
 
     def forward(self, x, edge_index, edge_weight, z=None):
         n = x.shape[0]
@@ -370,7 +377,6 @@ class EmbGConv(nn.Module):
         self.activation = activation
         self.dropout = dropout
         self.gns = nn.ModuleList([GraphNorm(hidden_channels) for _ in range(num_layers - 1)]) if gn else None
-        self._sel = None
         self.reset_parameters()
 
     def reset_parameters(self):

@@ -44,7 +44,13 @@ def rng_state(device):
 
 
 def rng_seed(seed, device):
-    _rng[device] = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+    """(Re)seed the dropout stream IN PLACE: captured graphs keep reading the same device words."""
+    st = _rng.get(device)
+    new = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64)
+    if st is None:
+        _rng[device] = new.to(device)
+    else:
+        st.copy_(new)
 
 
 def rng_advance(device):
@@ -166,6 +172,7 @@ import os as _os
 USE_SIDE_STREAM = _os.environ.get("GLASS_SIDE_STREAM", "0") == "1"
 USE_FUSED_DENSE = _os.environ.get("GLASS_FUSED_DENSE", "1") != "0"  # A/B switch: fused MFMA dense path
 _wgrad_ws = {}
+_retired_ws = []
 _side = {}
 
 
@@ -173,6 +180,8 @@ def _wgrad_workspace(device, N, O, I, slot=0):
     nbytes = _lib.load().glass_linear_wgrad_ws_bytes(N, O, I)
     ws = _wgrad_ws.get((device, slot))
     if ws is None or ws.numel() * 4 < nbytes:
+        if ws is not None:
+            _retired_ws.append(ws)  # a captured graph may still launch with this pointer: never hand it back
         ws = torch.empty(nbytes // 4 + 16, dtype=torch.float32, device=device)
         _wgrad_ws[(device, slot)] = ws
     return ws

@@ -124,8 +124,7 @@ class TrainStep:
         if pos.shape != self._pos.shape:
             raise ValueError("TrainStep needs a fixed batch shape (drop_last=True): "
                              f"{tuple(pos.shape)} vs {tuple(self._pos.shape)}")
-        self._pos.copy_(pos)
-        self._y.copy_(y)
+        self._load_batch(pos, y)
         if hasattr(self.opt, "sync_lr"):
             self.opt.sync_lr()  # a scheduler may have changed the learning rate since the capture
         if self.graphed:
@@ -138,6 +137,20 @@ class TrainStep:
             self.bucket.all_reduce_mean()
             self.opt.step()
         return self._loss
+
+    def _load_batch(self, pos, y):
+        """The batch into the step's fixed buffers: one launch for both tensors when they are plain device tensors."""
+        if (pos.is_cuda and y.is_cuda and pos.is_contiguous() and y.is_contiguous() and pos.dtype == self._pos.dtype and
+                y.dtype == self._y.dtype and y.shape == self._y.shape and pos.numel() and y.numel() and
+                (pos.element_size() * pos.numel()) % 4 == 0 and (y.element_size() * y.numel()) % 4 == 0):
+            from . import _lib
+            rc = _lib.load().glass_copy_pair(self._pos.data_ptr(), pos.data_ptr(), pos.numel() * pos.element_size(),
+                                             self._y.data_ptr(), y.data_ptr(), y.numel() * y.element_size(),
+                                             torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "glass_copy_pair")
+            return
+        self._pos.copy_(pos)
+        self._y.copy_(y)
 
     def last_loss(self):
         return float(self._loss.item())

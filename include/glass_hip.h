@@ -178,8 +178,10 @@ int glass_embed_norm_bwd_f32(const float* G, const float* W, int64_t V, const in
  *     out[b,:] = reduce_{j: pos[b,j]>=0} emb[pos[b,j],:]   (sum | mean | max | sum * n_b^-1/2)
  *     argmax (int32 [B,C], only for max, may be NULL otherwise) records the contributing node.
  *     An all-padding row gives 0 (torch_scatter semantics).
- *     Backward scatters into demb (must be ZEROED by the caller): a node shared by several
- *     subgraphs accumulates with float atomics — order-dependent only beyond two sharers.
+ *     Backward scatters into demb (must be ZEROED by the caller).  sum / mean / size with B*Smax + B <= 12 288:
+ *     ordered and atomic-free (pos staged in LDS; the first entry naming a node sums all its occurrences in
+ *     (b, s) order) -> bitwise repeatable.  Larger batches and max pooling: float atomics, order-dependent only
+ *     beyond two sharers of a node.
  * ---------------------------------------------------------------------------------------- */
 int glass_segment_pool_f32(const float* emb, int64_t lde, const int64_t* pos, int64_t B, int64_t Smax, int mode,
                            float* out, int64_t ldo, int32_t* argmax, int64_t n_nodes, int64_t C, void* stream);
@@ -278,7 +280,9 @@ int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const float* W, co
  *      glass_graphnorm_stats_f32 (statistics + finalize without the apply pass); pos [B,Smax] (-1 padding);
  *      pool_mode sum|mean|size; loss_mode 0 = cross-entropy (target int64[B]), 1 = BCE-with-logits (float[B,K]);
  *      grad_loss = device scalar seed.  Outputs: pooled [B,C], logits [B,K], loss [1], djk [N,C] (overwritten);
- *      dWh/dbh and dgamma/dbeta/dalpha are accumulated when acc_* != 0. */
+ *      dWh/dbh and dgamma/dbeta/dalpha are accumulated when acc_* != 0.
+ *      Bitwise repeatable while B*Smax <= 16 384 (ordered, atomic-free scatter of the sparse part); beyond that the
+ *      scatter uses float atomics. */
 int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, const float* gamma,
                               const float* beta, const float* alpha, float eps, float* saved, void* ws, void* stream);
 int glass_readout_supported(int64_t C, int64_t K, int pool_mode);
@@ -289,6 +293,11 @@ int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved,
                             float* logits, float* loss, float* djk, int64_t lddj, float* dWh, float* dbh, int acc_head,
                             float* dgamma, float* dbeta, float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
                             void* stream);
+
+/*     Two small device-to-device copies in one launch (4-byte granularity): a training step that is replayed from a
+ *     captured graph reads its batch (pos, target) from fixed buffers; this fills both per step. */
+int glass_copy_pair(void* dst0, const void* src0, int64_t bytes0, void* dst1, const void* src1, int64_t bytes1,
+                    void* stream);
 
 /* K9  Adam over a flat parameter arena (torch.optim.Adam as used at GLASSTest.py:213; amsgrad
  *     off): one launch for all parameters.  lr and the step counter live in DEVICE memory so a

@@ -736,3 +736,15 @@ def test_dgrad_dropout_epilogue_matches_graphnorm_mask():
     _dual_dgrad(dsrc, T, st, mask, 0.9, 1, H, None, plain)
     _dual_dgrad(dsrc, T, st, mask, 0.9, 1, H, None, dropped, drop=(p, call))
     assert torch.equal(dropped, torch.where(kept, plain / (1 - p), torch.zeros_like(plain)))
+
+
+def test_copy_pair():
+    from glass_amd import _lib
+    a = torch.randint(-5, 1000, (80, 11), device=DEV)
+    b = torch.rand(80, 6, device=DEV)
+    da, db = torch.empty_like(a), torch.full_like(b, -1.0)
+    rc = _lib.load().glass_copy_pair(da.data_ptr(), a.data_ptr(), a.numel() * 8, db.data_ptr(), b.data_ptr(), b.numel() * 4,
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0 and torch.equal(da, a) and torch.equal(db, b)
+    assert _lib.load().glass_copy_pair(da.data_ptr(), a.data_ptr(), 6, db.data_ptr(), b.data_ptr(), 4,
+                                       torch.cuda.current_stream().cuda_stream) != 0  # 4-byte granularity

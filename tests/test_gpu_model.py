@@ -306,15 +306,15 @@ def test_train_and_test_loops():
 
 def test_driver_density_learns(capsys):
     """GLASSTest.py-compatible driver end to end on the shipped density set with the README recipe
-    (--use_one --use_seed --use_maxzeroone; config/density.yml: H=8, L=1, batch 2): log format and a
-    test micro-F1 well above chance (3 classes) within 40 epochs (the reference reaches 0.95+ at ~41)."""
+    (--use_one --use_seed --use_maxzeroone; config/density.yml: H=8, L=1, batch 2): log format and the test
+    micro-F1 after 40 epochs (0.968 — what the reference itself reaches on this set, SURVEY.md §8c — reproducibly)."""
     import GLASSTest
     outs = GLASSTest.main(["--use_one", "--use_seed", "--use_maxzeroone", "--repeat", "1", "--device", "0",
                            "--dataset", "density", "--max_epoch", "40"])
     text = capsys.readouterr().out
     assert "params {" in text and "repeat 0" in text and "end: epoch" in text and "average " in text
     assert any(line.startswith("iter ") and " val " in line and " tst " in line for line in text.splitlines())
-    assert outs[0] > 0.8
+    assert outs[0] > 0.9
 
 
 @pytest.mark.parametrize("name", ["L2_jk0_mean", "L3_jk1_gcn", "L1_jk0_sum"])
@@ -568,3 +568,73 @@ def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel):
     keys = sorted(mine)
     arena.flat.copy_(grads_a)
     assert rel_inf(flat_grads({k: p.grad.cpu() for k, p in model.named_parameters()}, keys), flat_grads(theirs, keys)) < TOL
+
+
+# ---------------------------------------------------------------------------------- repeatability / graph safety
+def _train_probe(name, hidden, dropout, steps, use_graph=True):
+    from glass_amd import synth, losses, ops
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    from glass_amd.step import TrainStep
+    dev = torch.device(DEV)
+    w, ei, ew, x, pos, y = synth.make_workload(name, seed=0, n_batches=4)
+    ei, ew, x, pos, y = (torch.from_numpy(a).to(dev) for a in (ei, ew, x, pos, y))
+    pos[:, 0] = pos[0, 0]  # one node shared by EVERY subgraph of a batch: order-dependent if summed with atomics
+    torch.manual_seed(0)
+    ops.rng_seed(321, dev)
+    model = build_glass(hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=dropout).to(dev).train()
+    arena = ParamArena(model)
+    opt = FlatAdam(arena, lr=1e-2)
+    step = TrainStep(model, opt, losses.CrossEntropy(), x, ei, ew, arena, use_graph=use_graph, warmup_iters=2,
+                     preserve_state=True)
+    B = w.batch
+    for k in range(steps):
+        b = k % 4
+        step(pos[b * B:(b + 1) * B], y[b * B:(b + 1) * B])
+    torch.cuda.synchronize()
+    return arena.flat_param.clone()
+
+
+@pytest.mark.parametrize("hidden", [16, 64])
+def test_training_is_bitwise_repeatable(hidden):
+    """The same seeded training twice -> bit-identical parameters, on the per-op path (hidden 16) and on the step
+    program (hidden 64: fused readout with its ordered, atomic-free scatter), with dropout and with a node shared by
+    all subgraphs of every batch; and the hipGraph replay equals the eager execution of the same step bit for bit."""
+    a = _train_probe("tiny", hidden, 0.5, 40)
+    b = _train_probe("tiny", hidden, 0.5, 40)
+    c = _train_probe("tiny", hidden, 0.5, 40, use_graph=False)
+    assert torch.equal(a, b)
+    assert torch.equal(a, c)
+
+
+def test_graph_epochs_with_evaluation_between_match_eager_loop(monkeypatch):
+    """impl.train.train replays a captured step; evaluations (eager kernels on other tensors: the validation set's own
+    copies of x / edge_index, its own label vectors) run between the epochs.  The captured graph must not depend on
+    anything those touch: parameters after 3 epochs equal the plain eager loop's.  (Regression: a hipMemsetAsync NODE
+    in the captured MaxZOZ left stale labels behind after such interleaving; an evicted selection CSR would dangle.)"""
+    import GLASSTest
+    from impl import config, train
+    from glass_amd import train as gtrain
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    config.set_device(0)
+    args = GLASSTest.parse_args(["--use_one", "--use_seed", "--use_maxzeroone", "--device", "0", "--dataset", "density"])
+    outs = []
+    for use_graph in (True, False):
+        monkeypatch.setattr(gtrain, "USE_GRAPH", use_graph)
+        GLASSTest.set_seed(0)
+        run = GLASSTest.Run(args)
+        run.split()
+        GLASSTest.set_seed(0)
+        gnn = run.build_model(8, 1, 0.0, 1, "size", 1.0, "sum")
+        arena = ParamArena(gnn)
+        opt = FlatAdam(arena, lr=1e-3)
+        trn, val = run.loader(run.trn, 2, True), run.loader(run.val, 2, False)
+        scores = []
+        for _ in range(3):
+            train.train(opt, gnn, trn, run.loss_fn)
+            scores.append(train.test(gnn, val, run.score_fn, loss_fn=run.loss_fn)[0])
+        torch.cuda.synchronize()
+        outs.append((arena.flat_param.clone(), scores))
+    assert outs[0][1] == outs[1][1]
+    assert rel_inf(outs[0][0].cpu(), outs[1][0].cpu()) < 1e-6
