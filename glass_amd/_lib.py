@@ -66,7 +66,9 @@ SIGNATURES = {
     "glass_graphnorm_finalize_f32": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, c_float, _P, _P]),
     "glass_graphnorm_apply_f32": (c_int, [_P, _I, _P, _I, _I, _I, _P, c_int, c_float, _P, c_uint64, _P]),
     "glass_dual_linear_dgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, c_float, _P, c_uint64, _P, _I,
-                                            _I, _I, _P]),
+                                            _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, _P]),
+    "glass_graphnorm_bwd_from_stats_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P,
+                                                   c_int, c_int, c_float, _P, c_uint64, _P, _P]),
     "glass_embed_norm_fwd_f32": (c_int, [_P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _I, c_float, _P, c_uint64, _P,
                                          _I, _P, _I, _I, _P]),
     "glass_embed_norm_bwd_f32": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _I, _P]),

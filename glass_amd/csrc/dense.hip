@@ -308,6 +308,19 @@ struct DgradRaw {
     float d[kKC], t[kKC];
 };
 
+// Optional epilogue of the data-gradient kernel: its first H output columns are the gradient dy of a GraphNorm
+// OUTPUT (conv.gn's for the comb pair, gns[l]'s for the next layer's trans pair), so the two backward column sums of
+// that GraphNorm — S1 = sum g, S2 = sum g*xhat with g = dy * dropmask * act'(x*scale + shift) — are accumulated here
+// from the tile in registers plus one read of the GraphNorm input x, instead of by a statistics launch re-reading
+// dy and x.  partial[blockIdx.x][2][H] doubles, consumed by glass_graphnorm_bwd_from_stats_f32.
+struct GnBwdStats {
+    double* partial;  // nullptr: off
+    const float* x; int64_t ldx;
+    const float *saved, *alpha;
+    int act;
+    Drop drop;
+};
+
 // ---- backward data gradient ---------------------------------------------------------------------
 // out[N, NT] = dZ[N, 2H] @ Wstack[2H, NT] (+ addend), dZ[n, o] = coef(n, o<H) * dsrc[n, o mod H] * act'(T[n, o]);
 // WT = Wstack^T stored [NT][2H] so that weight chunks are contiguous (refreshed once per step).
@@ -318,7 +331,8 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
                                                             int act, const float* __restrict__ WT,
                                                             const float* __restrict__ addend, int64_t ldadd,
                                                             Drop drop, const uint64_t* __restrict__ rng_state,
-                                                            float* __restrict__ out, int64_t ldo, int64_t N) {
+                                                            float* __restrict__ out, int64_t ldo, int64_t N,
+                                                            GnBwdStats gs) {
     constexpr int KT = 2 * H, KQ = KT / 4, NTILES = NT / 16;
     static_assert(KQ % kKC == 0, "hidden size must be a multiple of 32");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -353,6 +367,26 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
     }
+    constexpr int NGS = H / 64;  // 64-column groups of the GraphNorm half
+    float s1[NGS][4], s2[NGS][4];
+    float4 g_mu[NGS], g_rstd[NGS], g_scale[NGS], g_shift[NGS], g_al[NGS];
+    if (gs.partial) {
+        if (gs.drop.p > 0.f) {
+            gs.drop.seed = rng_state[0];
+            gs.drop.step = rng_state[1];
+        }
+#pragma unroll
+        for (int g = 0; g < NGS; ++g) {
+            const int c = 64 * g + 4 * i;
+            g_mu[g] = *reinterpret_cast<const float4*>(gs.saved + c);
+            g_rstd[g] = *reinterpret_cast<const float4*>(gs.saved + H + c);
+            g_scale[g] = *reinterpret_cast<const float4*>(gs.saved + 2 * H + c);
+            g_shift[g] = *reinterpret_cast<const float4*>(gs.saved + 3 * H + c);
+            g_al[g] = *reinterpret_cast<const float4*>(gs.alpha + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s1[g][k] = s2[g][k] = 0.f;
+        }
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = row0 + 4 * q + reg;
@@ -371,7 +405,54 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
                 v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
             }
             *reinterpret_cast<float4*>(out + r * ldo + c) = v;
+            if (g < NGS && gs.partial) {
+                const float4 x4 = *reinterpret_cast<const float4*>(gs.x + r * gs.ldx + c);
+                const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, dy[4] = {v.x, v.y, v.z, v.w};
+                const float mu[4] = {g_mu[g].x, g_mu[g].y, g_mu[g].z, g_mu[g].w};
+                const float rs[4] = {g_rstd[g].x, g_rstd[g].y, g_rstd[g].z, g_rstd[g].w};
+                const float sc[4] = {g_scale[g].x, g_scale[g].y, g_scale[g].z, g_scale[g].w};
+                const float sh[4] = {g_shift[g].x, g_shift[g].y, g_shift[g].z, g_shift[g].w};
+                const float al[4] = {g_al[g].x, g_al[g].y, g_al[g].z, g_al[g].w};
+                float ds[4] = {1.f, 1.f, 1.f, 1.f};
+                if (gs.drop.p > 0.f) drop_scales<4>(gs.drop, r, c, ds);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float gp = dy[k] * ds[k];
+                    if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv[k], sc[k], sh[k]));
+                    const float xhat = (xv[k] - al[k] * mu[k]) * rs[k];
+                    s1[g < NGS ? g : 0][k] += gp;
+                    s2[g < NGS ? g : 0][k] = fmaf(gp, xhat, s2[g < NGS ? g : 0][k]);
+                }
+            }
         }
+    }
+    if (gs.partial == nullptr) return;
+    __syncthreads();  // every wave is done with the weight images in LDS
+    double* red = reinterpret_cast<double*>(lds_w);  // [4 waves][H][2]
+#pragma unroll
+    for (int g = 0; g < NGS; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double a = (double)s1[g][k], b2 = (double)s2[g][k];
+            a += __shfl_xor(a, 16);
+            b2 += __shfl_xor(b2, 16);
+            a += __shfl_xor(a, 32);
+            b2 += __shfl_xor(b2, 32);
+            if (q == 0) {
+                red[(w * H + 64 * g + 4 * i + k) * 2] = a;
+                red[(w * H + 64 * g + 4 * i + k) * 2 + 1] = b2;
+            }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += kBlock) {
+        double a = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < kBlock / kWave; ++ww) {
+            a += red[(ww * H + c) * 2];
+            b2 += red[(ww * H + c) * 2 + 1];
+        }
+        gs.partial[((size_t)blockIdx.x * 2) * H + c] = a;
+        gs.partial[((size_t)blockIdx.x * 2 + 1) * H + c] = b2;
     }
 }
 
@@ -476,7 +557,9 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                                            const uint8_t* mask, double z_ratio, int act, const float* WT,
                                            int64_t n_out, const float* addend, int64_t ldadd, float p_drop,
                                            const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo,
-                                           int64_t n_nodes, int64_t H, void* stream) {
+                                           int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
+                                           int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act,
+                                           float gn_p_drop, uint64_t gn_call_id, void* stream) {
     GLASS_REQUIRE(dsrc && mask && WT && out && n_nodes > 0, "dual_linear_dgrad: null pointer");
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (rng_state && n_out == H)),
                   "dual_linear_dgrad: bad dropout args (the masked output must be the [N,H] layer input)");
@@ -494,16 +577,22 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
     const float* Tp = act == GLASS_ACT_ELU ? T : nullptr;
     const size_t image = (size_t)n_out * 256;  // K = 2H always needs >= 2 passes
     const Drop drop = make_drop(p_drop, call_id, n_out);
+    GLASS_REQUIRE(!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && gn_ldx % 4 == 0 && aligned16(gn_x) &&
+                                  aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
+                                  (gn_p_drop == 0.f || rng_state) && (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                  "dual_linear_dgrad: bad GraphNorm statistics arguments");
+    const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
+                        make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
 #define GLASS_DG(HH)                                                                                               \
     if (H == HH) {                                                                                                 \
         allow_lds(dual_dgrad_kernel<HH, HH>, 2 * image);                                                           \
         allow_lds(dual_dgrad_kernel<HH, 2 * HH>, 2 * image);                                                       \
         if (n_out == H)                                                                                            \
             hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, mask, \
-                               zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes);               \
+                               zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs);           \
         else                                                                                                       \
             hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, \
-                               mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes);         \
+                               mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs);     \
     }
     GLASS_DG(64) GLASS_DG(128)
 #undef GLASS_DG

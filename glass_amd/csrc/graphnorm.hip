@@ -485,6 +485,36 @@ extern "C" int glass_graphnorm_bwd_f32(const float* dy, int64_t lddy, const floa
     return launch_status("glass_graphnorm_bwd_f32");
 }
 
+extern "C" int glass_graphnorm_bwd_from_stats_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx,
+                                                  int64_t lddx, const float* addend, int64_t ldadd, int64_t n_rows,
+                                                  int64_t C, const float* gamma, const float* alpha, const float* saved,
+                                                  const double* partial, int64_t nblk, float* dgamma, float* dbeta,
+                                                  float* dalpha, int accumulate, int act, float p_drop,
+                                                  const uint64_t* rng_state, uint64_t call_id, void* ws, void* stream) {
+    GLASS_REQUIRE(dy && x && dx && gamma && alpha && saved && partial && ws, "graphnorm_bwd_from_stats: null pointer");
+    GLASS_REQUIRE(n_rows > 0 && C > 0 && nblk > 0 && nblk < (1ll << 31) && lddy >= C && ldx >= C && lddx >= C &&
+                      (!addend || ldadd >= C),
+                  "graphnorm_bwd_from_stats: bad sizes");
+    GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd_from_stats: bad dropout args");
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && aligned16(dy) && aligned16(x) &&
+                     aligned16(dx) && (!addend || (ldadd % 4 == 0 && aligned16(addend)));
+    const Tiling t = make_tiling(C, vec);
+    float* coef = (float*)((char*)ws + ws_partials_bytes(C));
+    const Drop drop = make_drop(p_drop, call_id, C);
+    dim3 ga(apply_blocks(n_rows, t), t.ctiles);
+    hipLaunchKernelGGL(gn_finalize_bwd_kernel, dim3((unsigned)ceil_div(C, kFinCols)), dim3(kBlock), 0, st, partial, (int)nblk,
+                       (int)C, n_rows, gamma, alpha, saved, dgamma, dbeta, dalpha, accumulate, coef);
+    if (vec) {
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<4>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, addend, ldadd,
+                           n_rows, (int)C, t.tc_log2, saved, coef, act, drop, rng_state);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<1>, ga, dim3(kBlock), 0, st, dy, lddy, x, ldx, dx, lddx, addend, ldadd,
+                           n_rows, (int)C, t.tc_log2, saved, coef, act, drop, rng_state);
+    }
+    return launch_status("glass_graphnorm_bwd_from_stats_f32");
+}
+
 extern "C" int glass_rng_advance(uint64_t* rng_state, void* stream) {
     GLASS_REQUIRE(rng_state, "rng_advance: null pointer");
     hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);

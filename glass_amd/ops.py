@@ -361,7 +361,7 @@ class DualLinearMixFn(torch.autograd.Function):
             din = torch.empty((n, n_out), dtype=torch.float32, device=dout.device)
             rc = lib.glass_dual_linear_dgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act,
                                                  stack[5].data_ptr(), n_out, 0, 0, 0.0, 0, 0, din.data_ptr(), n_out, n, H,
-                                                 _stream())
+                                                 0, 0, 0, 0, 0, 0, 0.0, 0, _stream())
             _lib.check(rc, "glass_dual_linear_dgrad_f32")
         I = n_out
         ws = _wgrad_workspace(dout.device, n, 2 * H, I)

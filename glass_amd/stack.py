@@ -78,6 +78,22 @@ class _GN:
                                                    saved.data_ptr(), act, float(p_drop), rng, call_id, _stream())
         _check(rc, "glass_graphnorm_apply_f32")
 
+    def bwd_from_stats(self, dy, x, saved, dx, partial, act, p_drop, call_id, addend=None, acc=1):
+        """Backward with the two column sums already accumulated (data-gradient epilogue): finalize + apply."""
+        m = self.mod
+        n, C = x.shape
+        ws = ops._graphnorm_ws(x.device, n, C)
+        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        ap, lda = (0, 0) if addend is None else (addend.data_ptr(), addend.stride(0))
+        rc = _lib.load().glass_graphnorm_bwd_from_stats_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0),
+                                                            dx.data_ptr(), dx.stride(0), ap, lda, n, C,
+                                                            m.weight.data_ptr(), m.mean_scale.data_ptr(), saved.data_ptr(),
+                                                            partial.data_ptr(), partial.shape[0],
+                                                            m.weight.grad.data_ptr(), m.bias.grad.data_ptr(),
+                                                            m.mean_scale.grad.data_ptr(), acc, act, float(p_drop), rng,
+                                                            call_id, ws.data_ptr(), _stream())
+        _check(rc, "glass_graphnorm_bwd_from_stats_f32")
+
     def bwd(self, dy, x, saved, dx, act, p_drop, call_id, addend=None, acc=1):
         m = self.mod
         n, C = x.shape
@@ -112,16 +128,23 @@ def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None, gn=None):
     _check(rc, "glass_dual_linear_fwd_f32")
 
 
-def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=None):
-    """drop = (p, call_id): also multiply by that dropout's mask (gradient w.r.t. the pre-dropout layer input)."""
+def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=None, gn=None):
+    """drop = (p, call_id): also multiply by that dropout's mask (gradient w.r.t. the pre-dropout layer input).
+    gn = (partial, x, saved, alpha, act, p, call_id): the first H output columns are the gradient of that GraphNorm's
+    output; its backward column sums are accumulated into `partial` [ceil(n/64), 2, H] float64 by the epilogue."""
     n, H = dsrc.shape
     p_drop, call_id = drop if drop is not None else (0.0, 0)
-    rng = ops.rng_state(dsrc.device).data_ptr() if p_drop > 0 else 0
+    if gn is not None:
+        gpart, gx, gsaved, galpha, gact, gp, gcall = gn
+        gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall)
+    else:
+        gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0)
+    rng = ops.rng_state(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
     rc = _lib.load().glass_dual_linear_dgrad_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
                                                  0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
                                                  stack[5].data_ptr(), n_out, 0 if addend is None else addend.data_ptr(),
                                                  0 if addend is None else addend.stride(0), float(p_drop), rng, call_id,
-                                                 out.data_ptr(), out.stride(0), n, H, _stream())
+                                                 out.data_ptr(), out.stride(0), n, H, *gargs, _stream())
     _check(rc, "glass_dual_linear_dgrad_f32")
 
 
@@ -308,7 +331,10 @@ class StackProgram:
             djk = torch.empty_like(jk)
             _GN(emb.gns[-1]).bwd(dout, jk, st["final_saved"], djk, ACT_NONE, 0.0, 0, acc=acc)
         dh_next = None   # gradient w.r.t. the input of layer l+1 (= output of gns[l])
+        npart = None     # backward column sums of gns[l], accumulated by layer l+1's trans data-gradient epilogue
         pending = []     # weight gradients whose partial sums are written but not yet reduced
+        nblk = (n + 63) // 64
+        f64 = dict(dtype=torch.float64, device=dev)
         for l in range(L - 1, -1, -1):
             conv, rec = emb.convs[l], st["layers"][l]
             last = l + 1 == L
@@ -317,18 +343,27 @@ class StackProgram:
                 dc = djk[:, l * H:(l + 1) * H] if emb.jk else djk
             else:
                 dc = torch.empty((n, H), **f32)
-                _GN(emb.gns[l]).bwd(dh_next, rec["c"], rec["nsaved"], dc, ACT_ELU, p, conv.call_base + 1,
-                                    addend=djk[:, l * H:(l + 1) * H] if emb.jk else None, acc=acc)
+                _GN(emb.gns[l]).bwd_from_stats(dh_next, rec["c"], rec["nsaved"], dc, npart, ACT_ELU, p, conv.call_base + 1,
+                                               addend=djk[:, l * H:(l + 1) * H] if emb.jk else None, acc=acc)
             din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
-            _dual_dgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din)
+            gpart = torch.empty((nblk, 2, H), **f64)  # conv.gn's backward column sums, from this kernel's epilogue
+            _dual_dgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din,
+                        gn=(gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base))
             _dual_wgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, rec["g"], rec["h"], pending, acc)
             da = torch.empty((n, H), **f32)
-            _GN(conv.gn).bwd(din[:, :H], rec["a"], rec["gsaved"], da, ACT_NONE, rec["pc"], conv.call_base, acc=acc)
+            _GN(conv.gn).bwd_from_stats(din[:, :H], rec["a"], rec["gsaved"], da, gpart, ACT_NONE, rec["pc"], conv.call_base,
+                                        acc=acc)
             dm = conv.adj.bwd.spmm(da)
             dh = torch.empty((n, H), **f32)
-            # layer 0 on the table path: the epilogue applies emb_gn's dropout mask (call id 1)
+            # layer 0 on the table path: the epilogue applies emb_gn's dropout mask (call id 1); layers above: the
+            # epilogue accumulates the backward column sums of gns[l-1], whose output this gradient belongs to
             drop = (p, 1) if (l == 0 and "emb_table" in st) else None
-            _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, drop)
+            gn = None
+            if l > 0:
+                below, cb = st["layers"][l - 1], emb.convs[l - 1]
+                npart = torch.empty((nblk, 2, H), **f64)
+                gn = (npart, below["c"], below["nsaved"], emb.gns[l - 1].mean_scale, ACT_ELU, p, cb.call_base + 1)
+            _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, drop, gn)
             _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None, pending, acc)
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations

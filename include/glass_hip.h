@@ -147,6 +147,14 @@ int glass_graphnorm_finalize_f32(const double* const* partials, int64_t n_src, i
 int glass_graphnorm_apply_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int64_t n_rows, int64_t C,
                               const float* saved, int act, float p_drop, const uint64_t* rng_state, uint64_t call_id,
                               void* stream);
+/*     backward from partial sums produced elsewhere (glass_dual_linear_dgrad_f32 with gn_partial): finalize
+ *     (parameter gradients, coefficients) + apply; ws as glass_graphnorm_ws_bytes. */
+int glass_graphnorm_bwd_from_stats_f32(const float* dy, int64_t lddy, const float* x, int64_t ldx, float* dx,
+                                       int64_t lddx, const float* addend, int64_t ldadd, int64_t n_rows, int64_t C,
+                                       const float* gamma, const float* alpha, const float* saved,
+                                       const double* partial, int64_t nblk, float* dgamma, float* dbeta,
+                                       float* dalpha, int accumulate, int act, float p_drop, const uint64_t* rng_state,
+                                       uint64_t call_id, void* ws, void* stream);
 int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 */
 
 /* ------------------------------------------------------------------------------------------
@@ -235,11 +243,17 @@ int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int
                               int64_t ldxo, void* stream);
 /*   dgrad epilogue: out = (dZ @ W + addend) * dropmask(p_drop, rng_state, call_id) — the mask of the dropout that
  *   produced this layer's input (same mask layout as glass_graphnorm_fwd_f32), so the consumer receives the
- *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL). */
+ *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL).
+ *   dgrad, gn_partial != NULL: the first H output columns are the gradient dy of a GraphNorm OUTPUT (input gn_x,
+ *   forward statistics gn_saved, mean scale gn_alpha, activation / dropout gn_act, gn_p_drop, gn_call_id of that
+ *   GraphNorm); the epilogue accumulates its two backward column sums into gn_partial[ceil(n_nodes/64)][2][H]
+ *   doubles, for glass_graphnorm_bwd_from_stats_f32 — no backward statistics launch. */
 int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* WTimg, int64_t n_out, const float* addend,
                                 int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* out,
-                                int64_t ldo, int64_t n_nodes, int64_t H, void* stream);
+                                int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
+                                int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
+                                uint64_t gn_call_id, void* stream);
 int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
                                 int64_t N, int64_t H, float* dW, int64_t lddw, float* db, int accumulate, void* ws,
