@@ -393,6 +393,7 @@ extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* c
                                                    void* stream) {
     GLASS_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (ws && N && O && I && dW && lddw && db && accumulate)),
                   "wgrad_reduce_batch: null pointer");
+    if (n_jobs == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     for (int64_t j0 = 0; j0 < n_jobs; j0 += kMaxReduceJobs) {
         const int nj = (int)(n_jobs - j0 < kMaxReduceJobs ? n_jobs - j0 : kMaxReduceJobs);

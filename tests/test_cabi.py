@@ -122,6 +122,43 @@ def test_argument_validation_returns_codes_not_exceptions():
     assert lib.glass_spmm_ws_bytes(x.ctypes.data, 64) == -2  # not a plan header
 
 
+def test_step_program_entry_points_validate_on_the_host():
+    """The entry points of the step program (table embedding, GraphNorm in pieces, fused readout, deferred weight
+    gradient reduction, batch copy): host-side answers and argument checks, no GPU."""
+    from glass_amd import _lib
+    lib = _lib.load()
+    x = np.zeros(64, dtype=np.float32)
+    p = x.ctypes.data
+    # readout support matrix: C multiple of 4 and <= 1024, K <= 256, pooling sum(0) | mean(1) | size(3)
+    assert lib.glass_readout_supported(128, 6, 0) == 1 and lib.glass_readout_supported(128, 6, 3) == 1
+    assert lib.glass_readout_supported(128, 6, 2) == 0 and lib.glass_readout_supported(130, 6, 0) == 0
+    assert lib.glass_readout_supported(2048, 6, 0) == 0 and lib.glass_readout_supported(128, 300, 0) == 0
+    assert lib.glass_readout_ws_bytes(80, 128, 6) >= 8 * 2 * 80 * 128 + 4 * (4 * 128 + 80 * 128 + 80 * 6 + 80)
+    assert lib.glass_readout_ws_bytes(0, 128, 6) == -1
+    args = [p, 128, p, p, p, p, 80, 10, 2, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 1000, 128, None]
+    assert lib.glass_readout_train_f32(*args) == -3  # max pooling is not fusable
+    # table path: more rows than GLASS_EMBED_NORM_MAX_ROWS
+    assert lib.glass_embed_norm_fwd_f32(p, p, 5000, p, p, p, p, 1e-5, p, p, None, None, 0, 0.0, None, 1, p, 64, p, 10, 64,
+                                        None) == -1
+    assert b"1024" in lib.glass_last_error_string()
+    assert lib.glass_embed_norm_bwd_f32(None, p, 4, p, p, p, p, p, 1, p, p, p, 1, 64, None) == -1
+    # GraphNorm pieces
+    ptrs = np.array([p] * 9, dtype=np.uint64)
+    assert lib.glass_graphnorm_finalize_f32(ptrs.ctypes.data, 9, 4, 64, 100, p, p, p, 1e-5, p, None) == -1  # > 8 sources
+    assert lib.glass_graphnorm_apply_f32(p, 2, p, 4, 4, 4, p, 0, 0.0, None, 0, None) == -1                # ldx < C
+    assert lib.glass_graphnorm_apply_f32(p, 4, p, 4, 4, 4, p, 0, 0.5, None, 0, None) == -1                # dropout w/o state
+    assert lib.glass_graphnorm_stats_f32(None, 4, 4, 4, p, p, p, 1e-5, p, p, None) == -1
+    assert lib.glass_graphnorm_bwd_from_stats_f32(p, 4, p, 4, p, 4, None, 0, 4, 4, p, p, p, None, 3, p, p, p, 1, 0, 0.0, None,
+                                                  0, p, None) == -1
+    # deferred reduction and batch copy
+    assert lib.glass_linear_wgrad_reduce_batch_f32(0, None, None, None, None, None, None, None, None, None) == 0
+    assert lib.glass_linear_wgrad_reduce_batch_f32(1, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.glass_copy_pair(p, p, 6, p, p, 4, None) == -1 and lib.glass_copy_pair(None, p, 4, p, p, 4, None) == -1
+    # fused dense forward: GraphNorm prologue without a side output is rejected before any launch
+    assert lib.glass_dual_linear_fwd_f32(p, 64, None, 0, p, p, p, 0.9, 1, p, 128, p, 64, 16, 64, None, p, 0, 0.0, None, 0,
+                                         None, 0, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from glass_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)
