@@ -638,3 +638,39 @@ def test_graph_epochs_with_evaluation_between_match_eager_loop(monkeypatch):
         outs.append((arena.flat_param.clone(), scores))
     assert outs[0][1] == outs[1][1]
     assert rel_inf(outs[0][0].cpu(), outs[1][0].cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["ppi_bp", "hpo_neuro"])
+def test_step_program_full_size_vs_oracle(name):
+    """The benchmarked path itself — ParamArena + stack.loss_and_grads (table embedding, fused dense + GraphNorm
+    fusion, fused readout, labels from pos, gradients overwritten) — at the full BASELINE shapes (C2 ppi_bp-shaped
+    N=17 080 nnz=633 902 mean/sum CE; C3 hpo_neuro-shaped gcn multilabel BCE), dropout 0, against the fp64 oracle:
+    logits, loss, every gradient."""
+    from glass_amd import synth, stack, losses
+    from glass_amd.arena import ParamArena
+    w, ei, ew, x, pos, y = synth.make_workload(name, seed=0, n_batches=1)
+    ei, ew, x, pos, y = (torch.from_numpy(a) for a in (ei, ew, x, pos, y))
+    torch.manual_seed(0)
+    model = build_glass(w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    loss_fn = losses.BCEWithLogits() if w.multilabel else losses.CrossEntropy()
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    assert stack.step_supported(model, loss_fn) and stack.covers_arena(model, arena)
+    arena.flat.fill_(3.0)  # overwrite mode: stale contents must not survive
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg, overwrite=True)
+    orc = O.OracleGLASS(w.hidden, w.layers, int(x.max()), w.n_class, aggr=w.aggr, pool=w.pool, z_ratio=w.z_ratio)
+    orc.load_state_dict(sd)
+    orc = orc.double().train()
+    po = orc(x, ei, ew.double(), pos, O.max_zero_one(x, pos))
+    lo = loss_fn(po, y.double() if w.multilabel else y)
+    lo.backward()
+    assert rel_inf(logits.cpu(), po.detach()) < TOL
+    assert abs(loss.item() - lo.item()) < TOL * abs(lo.item())
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    keys = sorted(mine)
+    err = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
+    print(f"{name}: step program vs fp64 oracle: logits {rel_inf(logits.cpu(), po.detach()):.2e} grad {err:.2e}")
+    assert err < (TOL if name == "ppi_bp" else 3 * TOL)  # hpo_neuro: SpMM re-ordering alone costs ~1e-5 (Appendix B.3)
