@@ -46,6 +46,7 @@ __global__ __launch_bounds__(kBlock) void emb_table_fwd_kernel(const float* __re
     if (mask_fill)
         for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n_nodes; n += (int64_t)gridDim.x * kBlock)
             mask_fill[n] = (uint8_t)fill_value;
+    if ((int)blockIdx.x >= (H + kTabCols - 1) / kTabCols) return;  // extra workgroups only help with the fill
     const int tc = threadIdx.x & (kTabCols - 1), tr = threadIdx.x / kTabCols;
     const int c = blockIdx.x * kTabCols + tc;
     const bool ok = c < H;
@@ -212,7 +213,13 @@ extern "C" int glass_embed_norm_fwd_f32(const int64_t* x, const float* W, int64_
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "embed_norm_fwd: bad dropout args");
     hipStream_t st = (hipStream_t)stream;
     // no z: the table kernel fills the label bytes (0 when pos will be scattered by the gather kernel, else all 1)
-    hipLaunchKernelGGL(emb_table_fwd_kernel, dim3((unsigned)ceil_div(H, kTabCols)), dim3(kBlock), 0, st, W, (int)V, (int)H,
+    int64_t tab_blocks = ceil_div(H, kTabCols);
+    if (!z) {  // a few more workgroups share the byte fill
+        int64_t fill_blocks = ceil_div(n_nodes, (int64_t)kBlock * 16);
+        if (fill_blocks > 64) fill_blocks = 64;
+        if (fill_blocks > tab_blocks) tab_blocks = fill_blocks;
+    }
+    hipLaunchKernelGGL(emb_table_fwd_kernel, dim3((unsigned)tab_blocks), dim3(kBlock), 0, st, W, (int)V, (int)H,
                        class_rowptr, gamma, beta, alpha, eps, saved, table, z ? nullptr : mask, pos ? 0 : 1, n_nodes);
     const bool vec = H % 4 == 0 && ldo % 4 == 0 && aligned16(table) && aligned16(out);
     const int vw = vec ? 4 : 1;

@@ -271,19 +271,21 @@ __global__ __launch_bounds__(kBlock) void readout_dense_kernel(const float* __re
 // in LDS (int32 node ids); one wave per entry: if an EARLIER entry names the same node the wave skips (that entry
 // owns the node), otherwise it adds up every occurrence in (b, s) order (64 entries per ballot) and does the single
 // read-modify-write of that row.  Bitwise repeatable however many subgraphs share a node; B*Smax <= 16 384.
-__global__ __launch_bounds__(kBlock) void readout_scatter_ordered_kernel(const int64_t* __restrict__ pos, int Smax,
+constexpr int kOrdBlock = 1024;  // 16 waves: one entry per wave for Smax <= 16, so the per-entry latency chains overlap
+
+__global__ __launch_bounds__(kOrdBlock) void readout_scatter_ordered_kernel(const int64_t* __restrict__ pos, int Smax,
                                                                          int n_pos, const float* __restrict__ dys,
                                                                          const float* __restrict__ coef,
                                                                          float* __restrict__ dx, int64_t lddx,
                                                                          int64_t n_nodes, int C) {
     extern __shared__ int32_t nodes[];
-    for (int j = threadIdx.x; j < n_pos; j += kBlock) {
+    for (int j = threadIdx.x; j < n_pos; j += kOrdBlock) {
         const int64_t p = pos[j];
         nodes[j] = (p >= 0 && p < n_nodes) ? (int32_t)p : -1;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
-    for (int s = w; s < Smax; s += kBlock / kWave) {
+    for (int s = w; s < Smax; s += kOrdBlock / kWave) {
         const int j = b * Smax + s;
         const int node = nodes[j];
         if (node < 0) continue;  // wave-uniform
@@ -407,7 +409,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     hipLaunchKernelGGL(readout_dense_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, jk, ldj, djk, lddj, n_nodes, (int)C,
                        tc_log2, w.coef);
     if (B * Smax <= kReadoutOrderedMax) {
-        hipLaunchKernelGGL(readout_scatter_ordered_kernel, dim3((unsigned)B), dim3(kBlock), sizeof(int32_t) * (size_t)(B * Smax),
+        hipLaunchKernelGGL(readout_scatter_ordered_kernel, dim3((unsigned)B), dim3(kOrdBlock), sizeof(int32_t) * (size_t)(B * Smax),
                            st, pos, (int)Smax, (int)(B * Smax), w.dys, w.coef, djk, lddj, n_nodes, (int)C);
     } else {
         hipLaunchKernelGGL(readout_scatter_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, pos, (int)Smax, w.dys, w.coef,
