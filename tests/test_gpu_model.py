@@ -674,3 +674,49 @@ def test_step_program_full_size_vs_oracle(name):
     err = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
     print(f"{name}: step program vs fp64 oracle: logits {rel_inf(logits.cpu(), po.detach()):.2e} grad {err:.2e}")
     assert err < (TOL if name == "ppi_bp" else 3 * TOL)  # hpo_neuro: SpMM re-ordering alone costs ~1e-5 (Appendix B.3)
+
+
+def test_large_batches_fall_back_to_atomic_scatters():
+    """pos matrices beyond the LDS staging of the ordered scatters (readout: B*Smax > 16 384, pool backward:
+    > 12 288) take the float-atomic kernels: same results within tolerance (not bitwise repeatable)."""
+    from glass_amd import stack, losses, ops, synth
+    from glass_amd.arena import ParamArena
+    n, H, L, K, B, S = 3000, 64, 1, 4, 132, 128          # B*S = 16 896
+    torch.manual_seed(3)
+    model = build_glass(H, L, 5, K, "mean", "sum", 0.8)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ei, ew = synth.make_graph(n, 9000, 2, 0.0)
+    rng = np.random.default_rng(2)
+    x = torch.from_numpy(rng.integers(0, 6, n)).reshape(n, 1, 1)
+    pos = np.stack([rng.choice(n, S, replace=False) for _ in range(B)])
+    pos[:, -40:][rng.random((B, 40)) < 0.5] = -1
+    pos = torch.from_numpy(pos)
+    y = torch.from_numpy(rng.integers(0, K, B))
+    loss_fn = losses.CrossEntropy()
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    xg, eig, ewg, posg, yg = x.to(DEV), torch.from_numpy(ei).to(DEV), torch.from_numpy(ew).to(DEV), pos.to(DEV), y.to(DEV)
+    arena.zero()
+    loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg)
+    orc = O.OracleGLASS(H, L, 5, K, aggr="mean", pool="sum", z_ratio=0.8)
+    orc.load_state_dict(sd)
+    orc = orc.double().train()
+    po = orc(x, torch.from_numpy(ei), torch.from_numpy(ew).double(), pos, O.max_zero_one(x, pos))
+    lo = loss_fn(po, y)
+    lo.backward()
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    keys = sorted(mine)
+    assert rel_inf(logits.cpu(), po.detach()) < TOL
+    assert rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys)) < TOL
+    # pool backward beyond its staging limit, through the per-op op
+    emb = torch.randn(n, 32, device=DEV, requires_grad=True)
+    out = ops.segment_pool(emb, posg, "mean")
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    e64 = emb.detach().cpu().double().requires_grad_(True)
+    valid = (pos >= 0)
+    rows = e64[pos.clamp(min=0)] * valid.unsqueeze(-1)                       # [B, S, C]
+    r = rows.sum(1) / valid.sum(1).clamp(min=1).unsqueeze(-1)
+    r.backward(gout.cpu().double())
+    assert rel_inf(out.detach().cpu(), r.detach()) < TOL and rel_inf(emb.grad.cpu(), e64.grad) < TOL
