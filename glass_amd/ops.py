@@ -276,6 +276,10 @@ class StackedLinearFn(torch.autograd.Function):
             dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
             return dx, None, None, None, None, None
         dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
+        if ctx.stack is not None and _wgrad_supported(dT, x, ctx.stack[2]) and ctx.stack[2].is_contiguous():
+            # arena views: dW / db accumulate straight into the gradient arena (no temporaries, no autograd add kernels)
+            if linear_wgrad(dT, x, ctx.stack[2], ctx.stack[3], True):
+                return dx, None, None, None, None, None
         dW = torch.empty_like(W)
         db = torch.empty(W.shape[0], dtype=W.dtype, device=W.device)
         if not linear_wgrad(dT, x, dW, db, False):
