@@ -201,6 +201,11 @@ def main():
                 roofline["traffic"] = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
+    if roofline["traffic"]:
+        # frac above counts ALGORITHMIC bytes (X is L2 / Infinity-Cache resident on the small BASELINE graphs, so it can
+        # exceed 1); this is the same launch priced with the L2-miss traffic the PMC counters saw
+        roofline["traffic_frac"] = roofline["traffic"] / k1_avg / 8e12
+        roofline["traffic_source"] = "profiles/r01_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
