@@ -148,17 +148,35 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=Non
     _check(rc, "glass_dual_linear_dgrad_f32")
 
 
+# A/B switch, off: weight-gradient partial kernels forked onto a second stream inside the captured step (4 forks, one join
+# before the batched reduction).  Measured on MI355X at C2, two interleaved rounds: 0.441 vs 0.386 ms/step — as with the
+# per-op path earlier (0.765 vs 0.678), the fork/join edges of the replayed graph cost more than overlapping these
+# 16 us kernels with the 12-20 us kernels of the main chain buys.
+USE_WGRAD_STREAM = os.environ.get("GLASS_WGRAD_STREAM", "0") == "1"
+_wgrad_streams = {}
+_wgrad_keep = []  # operands of side-stream launches stay referenced until the join
+
+
 def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending, acc=1):
     """Per-slab partial sums of dW / db into a scratch buffer of their own; the reduction into the gradient arena
     is deferred to ONE launch at the end of the backward pass (`_reduce_pending`)."""
     n, H = dout.shape
     I = H if xb is None else 2 * H
     ws = ops._wgrad_workspace(dout.device, n, 2 * H, I, slot=("stack", len(pending)))
+    stream = None
+    if USE_WGRAD_STREAM:
+        # nothing downstream of the backward chain reads these partial sums before the final reduction: run them beside
+        # the chain (fork here, one join before `_reduce_pending`)
+        stream = _wgrad_streams.get(dout.device)
+        if stream is None:
+            stream = _wgrad_streams[dout.device] = torch.cuda.Stream(device=dout.device)
+        stream.wait_stream(torch.cuda.current_stream())
+        _wgrad_keep.append((dout, T, mask, xa, xb))
     rc = _lib.load().glass_dual_linear_wgrad_f32(dout.data_ptr(), dout.stride(0), 0 if T is None else T.data_ptr(),
                                                  0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
                                                  xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                                  0 if xb is None else xb.stride(0), n, H, 0, 0, 0, 1, ws.data_ptr(),
-                                                 _stream())
+                                                 stream.cuda_stream if stream is not None else _stream())
     _check(rc, "glass_dual_linear_wgrad_f32")
     pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
 
@@ -166,6 +184,10 @@ def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending, acc=1):
 def _reduce_pending(pending):
     if not pending:
         return
+    if USE_WGRAD_STREAM and _wgrad_keep:
+        dev = _wgrad_keep[0][0].device
+        torch.cuda.current_stream().wait_stream(_wgrad_streams[dev])
+        _wgrad_keep.clear()
     cols = list(zip(*pending))
     u64 = lambda v: np.array(v, dtype=np.uint64)
     i64 = lambda v: np.array(v, dtype=np.int64)
