@@ -269,7 +269,9 @@ using namespace glass;
 // Matrices with few, long rows (the transposed one-hot selection matrix of the embedding backward:
 // V ~ 50 rows holding N entries) would keep most of the chip idle under that policy (47 workgroups,
 // 26 us at ppi_bp-shape), so when the whole matrix yields fewer than ~1024 chunks the threshold and
-// the chunk shrink until it does (never below one 64-edge batch per wave).
+// the chunk shrink until it does (never below one 64-edge batch per wave).  Such matrices (<= 1024 rows averaging
+// >= 64 entries) also skip the sweep kernel altogether: EVERY row becomes workgroup items (an empty row one empty
+// item that stores zeros), so the product is two launches (items + reduce) instead of three.
 static constexpr int kLongThrMax = 256;
 static constexpr int kLongChunkMax = 2048;
 static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
@@ -291,6 +293,8 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
         kLongChunk /= 2;
         if (kLongThr > 64) kLongThr /= 2;
     }
+    const bool all_long = n_rows > 0 && n_rows <= 1024 && nnz >= 64 * n_rows;
+    if (all_long) kLongThr = 0;
     int64_t cost_total = 0;
     for (int64_t r = 0; r < n_rows; ++r) {
         const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
@@ -306,13 +310,13 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     for (int64_t r = 0; r < n_rows; ++r) {
         const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
         const int64_t c = kRowCost + (d < kLongThr ? d : 0);
-        if (acc > 0 && acc + c > budget) {
+        if (!all_long && acc > 0 && acc + c > budget) {
             sweep.push_back((int32_t)r);
             acc = 0;
         }
         acc += c;
         if (d >= kLongThr) {
-            const int64_t n_chunks = ceil_div(d, kLongChunk);
+            const int64_t n_chunks = d > 0 ? ceil_div(d, kLongChunk) : 1;
             const int64_t per = ceil_div(ceil_div(d, n_chunks), kWave) * kWave;  // even chunks, whole batches
             if (n_chunks > 1) {
                 reduces.push_back((int32_t)r);
@@ -330,7 +334,7 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
         }
     }
     if (n_rows > 0) sweep.push_back((int32_t)n_rows);
-    const int64_t n_sweep = n_rows > 0 ? (int64_t)sweep.size() - 1 : 0;
+    const int64_t n_sweep = (n_rows > 0 && !all_long) ? (int64_t)sweep.size() - 1 : 0;
     const int64_t off_sweep = GLASS_PLAN_HEADER_WORDS;
     const int64_t off_long = off_sweep + (int64_t)sweep.size();
     const int64_t off_reduce = off_long + (int64_t)longs.size();

@@ -58,7 +58,9 @@ def _check_plan(rowptr):
     reds = plan[hdr[12]:hdr[12] + 3 * n_red].reshape(-1, 3)
     deg = rp[1:] - rp[:-1]
     # sweep ranges tile [0, n) in order
-    if n:
+    all_long = 0 < n <= 1024 and rp[-1] >= 64 * n  # few rows, many entries: no sweep, every row is workgroup items
+    assert (thr == 0 and n_sweep == 0) if all_long else thr > 0
+    if n and not all_long:
         assert sweep[0] == 0 and sweep[-1] == n and np.all(np.diff(sweep) > 0)
     # every long row (deg >= thr) is covered exactly by its chunks, in order, whole 64-edge batches
     long_rows = np.nonzero(deg >= thr)[0]
@@ -88,6 +90,8 @@ def test_plan_builder_shapes():
     assert hdr[5] > 0 and hdr[6] > 0 and hdr[7] > 0
     hdr = _check_plan(np.concatenate([[0], np.cumsum(np.full(20000, 37))]))
     assert hdr[5] == 0 and hdr[4] == 20000  # ppi_bp-like: one row per wave
+    hdr = _check_plan(np.concatenate([[0], np.cumsum(rng.choice([0, 0, 40, 300, 5000], 60))]))  # selection-matrix-like
+    assert hdr[4] == 0 and hdr[5] >= 60 and hdr[8] == 0
 
 
 def test_plan_builder_rejects_bad_rowptr():
