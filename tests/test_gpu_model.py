@@ -720,3 +720,29 @@ def test_large_batches_fall_back_to_atomic_scatters():
     r = rows.sum(1) / valid.sum(1).clamp(min=1).unsqueeze(-1)
     r.backward(gout.cpu().double())
     assert rel_inf(out.detach().cpu(), r.detach()) < TOL and rel_inf(emb.grad.cpu(), e64.grad) < TOL
+
+
+@pytest.mark.parametrize("aggr", ["sum", "mean", "gcn"])
+def test_g5_density_step_program_vs_reference_fixture(aggr):
+    """Golden fixture g5 (the REFERENCE itself run on the real density graph, fp64: loss, logits, every gradient)
+    against the benchmarked form of the step — stack.loss_and_grads with the fused readout, labels from pos,
+    gradients overwritten."""
+    from glass_amd import stack, losses
+    from glass_amd.arena import ParamArena
+    g = load(f"g5_density_{aggr}.npz")
+    n, ei, ew, x, pos, y, z = density_inputs(g)
+    model = build_glass(int(g["hidden"]), int(g["layers"]), int(g["max_deg"]), 3, aggr, str(g["pool"]), float(g["z_ratio"]))
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    model.load_state_dict(sd_from(g))
+    loss_fn = losses.CrossEntropy()
+    assert stack.step_supported(model, loss_fn) and stack.covers_arena(model, arena)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    assert torch.equal(O.max_zero_one(x, pos), z)  # the fixture's labels are the max-zero-one labels of pos
+    arena.flat.fill_(-2.0)
+    loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg, overwrite=True)
+    keys = [str(k) for k in g["gnorm64_keys"]]
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    assert rel_inf(logits.cpu(), g["pred64"]) < TOL
+    assert abs(loss.item() - float(g["loss64"])) < TOL * abs(float(g["loss64"]))
+    assert rel_inf(flat_grads(mine, keys), flat_grads(grads_from(g, "grad64/"), keys)) < TOL
