@@ -746,3 +746,32 @@ def test_g5_density_step_program_vs_reference_fixture(aggr):
     assert rel_inf(logits.cpu(), g["pred64"]) < TOL
     assert abs(loss.item() - float(g["loss64"])) < TOL * abs(float(g["loss64"]))
     assert rel_inf(flat_grads(mine, keys), flat_grads(grads_from(g, "grad64/"), keys)) < TOL
+
+
+def test_g8_adam_three_steps_through_captured_step_program():
+    """Fixture g8 (the reference's losses over three Adam steps and its final weights) against the captured
+    training step: TrainStep -> hipGraph replay of stack.loss_and_grads + FlatAdam, warm-up with state restore."""
+    from glass_amd import losses as gl
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    from glass_amd.step import TrainStep
+    g = load("g8_adam.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    ei, ew = torch.from_numpy(g["edge_index"]).to(DEV), torch.from_numpy(g["edge_weight"]).to(DEV)
+    pos_all, y_all = torch.from_numpy(g["pos"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    model = build_glass(int(g["hidden"]), int(g["layers"]), int(x.max()), 3, str(g["aggr"]), str(g["pool"]),
+                        float(g["z_ratio"])).to(DEV).train()
+    arena = ParamArena(model)
+    model.load_state_dict(sd_from(g))
+    opt = FlatAdam(arena, lr=float(g["lr"]))
+    step = TrainStep(model, opt, gl.CrossEntropy(), x, ei, ew, arena, use_graph=True, warmup_iters=2, preserve_state=True)
+    got = []
+    for k in range(3):
+        sel = torch.arange(k * 4, k * 4 + 4, device=DEV)
+        got.append(float(step(pos_all[sel].contiguous(), y_all[sel].contiguous()).item()))
+    assert step.graphed
+    assert np.allclose(got, g["losses"], rtol=1e-5, atol=0)
+    end = sd_from(g, "sd_end/")
+    keys = sorted(end)
+    mine = {k: v.cpu() for k, v in model.state_dict().items()}
+    assert rel_inf(flat_grads(mine, keys), flat_grads(end, keys)) < 1e-4
