@@ -775,3 +775,38 @@ def test_g8_adam_three_steps_through_captured_step_program():
     keys = sorted(end)
     mine = {k: v.cpu() for k, v in model.state_dict().items()}
     assert rel_inf(flat_grads(mine, keys), flat_grads(end, keys)) < 1e-4
+
+
+def test_step_program_at_c5_scale_matches_per_op_path(monkeypatch):
+    """N = 1 M nodes, nnz = 20 M (power-law, long rows -> all three K1 kernels), hidden 64: the step program (stats from
+    15 625 producer workgroups, fused readout) against the per-op autograd path of the same model on the GPU — loss,
+    logits and the flat gradient; and bitwise repeatable.  (Size-independent property check; the CPU oracle is not
+    run at this size.)"""
+    from glass_amd import synth, stack, losses, models as gm
+    from glass_amd.arena import ParamArena
+    from impl import utils
+    w = synth.WORKLOADS["powerlaw"]
+    ei, ew = synth.make_graph(w.n_node, w.n_pairs, 0, w.powerlaw)
+    x = synth.degree_feature(ei, w.n_node)
+    pos, y = synth.make_subgraphs(w.n_node, 64, 32, 6, 1, False)
+    ei, ew, x, pos, y = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x, pos, y))
+    torch.manual_seed(0)
+    V = int(x.max()) + 1
+    model = build_glass(64, 2, V - 1, 6, "mean", "sum", 0.9).to(DEV).train()
+    arena = ParamArena(model)
+    loss_fn = losses.CrossEntropy()
+    assert stack.step_supported(model, loss_fn)
+    arena.zero()
+    loss_a, logits_a = stack.loss_and_grads(model, loss_fn, x, ei, ew, pos, "pos", y)
+    ga = arena.flat.clone()
+    arena.zero()
+    loss_a2, _ = stack.loss_and_grads(model, loss_fn, x, ei, ew, pos, "pos", y)
+    assert torch.equal(arena.flat, ga) and torch.equal(loss_a, loss_a2)
+    monkeypatch.setattr(gm, "USE_STACK", False)
+    arena.zero()
+    pred = model(x, ei, ew, pos, utils.MaxZOZ(x, pos))
+    loss_b = loss_fn(pred, y)
+    loss_b.backward()
+    assert torch.isfinite(loss_a) and rel_inf(logits_a.cpu(), pred.detach().cpu()) < TOL
+    assert abs(loss_a.item() - loss_b.item()) < TOL * abs(loss_b.item())
+    assert rel_inf(ga.cpu(), arena.flat.cpu()) < 2 * TOL
