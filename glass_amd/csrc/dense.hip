@@ -49,11 +49,11 @@ __device__ __forceinline__ int tile_col(int t, int j) { return 64 * (t >> 2) + 4
 // elements 4v..4v+3 of lane (j,q)'s 16-float chunk of weight row tile_col(t, j)  ->  every wave-level
 // ds_read_b128 is one contiguous KiB (no bank conflicts) and the L2 sees one fetch per workgroup.
 // The permutation itself is done once per training step for all weights by pack_batch_kernel.
-template <int NT>
+template <int NT, int THREADS>
 struct WStage {
     static constexpr int NTILES = NT / 16;
     static constexpr int kVecs = NTILES * 4 * 64;          // float4 per pass image
-    static constexpr int kPerThread = kVecs / kBlock;      // staging float4 per thread
+    static constexpr int kPerThread = kVecs / THREADS;     // staging float4 per thread
     float4 r[kPerThread];
     // global -> registers: pass kc of the PACKED weight (glass_dense_pack_batch_f32 wrote it in image
     // order once per step), so this is a fully coalesced 16-B-per-lane copy.  (Gathering the image from
@@ -61,24 +61,28 @@ struct WStage {
     __device__ __forceinline__ void fetch(const float* __restrict__ Wimg, int /*KT*/, int kc) {
         const float4* src = reinterpret_cast<const float4*>(Wimg) + (int64_t)kc * kVecs;
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) r[n] = src[threadIdx.x + kBlock * n];
+        for (int n = 0; n < kPerThread; ++n) r[n] = src[threadIdx.x + THREADS * n];
     }
     // registers -> LDS image (consecutive threads write consecutive float4)
     __device__ __forceinline__ void commit(float4* __restrict__ image) const {
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) image[threadIdx.x + kBlock * n] = r[n];
+        for (int n = 0; n < kPerThread; ++n) image[threadIdx.x + THREADS * n] = r[n];
     }
 };
 
 // acc[t] += A_chunk . W_tile_chunk for every 16-column tile t, weights from the LDS image of this pass.
 // Tiles go in pairs (two independent accumulators hide the 40-cycle dependent-MFMA latency); the next
 // pair's chunks are read from LDS while the current pair's MFMAs issue.
-template <int NTILES>
+// A wave may own only part of the output columns (column split, hidden 128: two wave groups per 16 rows): its
+// NTILES local tiles are the image tiles base0 .. base0+HALF-1 followed by base1 .. (two runs: the f1 and f0
+// halves of a Linear pair; HALF == NTILES: one run).
+template <int NTILES, int HALF>
 __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float (&a)[kKC], const float4* image,
-                                              int lane) {
+                                              int lane, int base0, int base1) {
     static_assert(NTILES % 2 == 0, "tiles are processed in pairs");
     float4 b[2][2][4];
-    auto read_tile = [&](int t, float4 (&dst)[4]) {
+    auto read_tile = [&](int tl, float4 (&dst)[4]) {
+        const int t = tl < HALF ? base0 + tl : base1 + (tl - HALF);
 #pragma unroll
         for (int v = 0; v < 4; ++v) dst[v] = image[(t * 4 + v) * 64 + lane];
     };
@@ -110,12 +114,12 @@ __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float 
 // double-buffered through LDS.  The A operand of pass kc is produced in two steps so that the loads of pass kc+1
 // stay in flight across the MFMAs of pass kc: `issue(kc, raw)` only starts the global loads into `raw`;
 // `finish(kc, raw, a)` (run after the current pass) turns them into the operand chunk (prologue arithmetic).
-template <int NT, int KT, typename Raw, typename Issue, typename Finish>
-__device__ __forceinline__ void staged_product(f32x4 (&acc)[NT / 16], const float* __restrict__ W, float4* lds,
-                                               int lane, Issue issue, Finish finish) {
+template <int NT, int KT, int NLOC, int HALF, int THREADS, typename Raw, typename Issue, typename Finish>
+__device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* __restrict__ W, float4* lds, int lane,
+                                               int base0, int base1, Issue issue, Finish finish) {
     constexpr int NKC = KT / 4 / kKC;
-    constexpr int kVecs = WStage<NT>::kVecs;
-    WStage<NT> ws;
+    constexpr int kVecs = WStage<NT, THREADS>::kVecs;
+    WStage<NT, THREADS> ws;
     ws.fetch(W, KT, 0);
     Raw raw;
     issue(0, raw);
@@ -130,7 +134,7 @@ __device__ __forceinline__ void staged_product(f32x4 (&acc)[NT / 16], const floa
             issue(kc + 1, raw);
         }
         __builtin_amdgcn_sched_barrier(0);  // the loads above are issued before the MFMAs below
-        mfma_pass_lds<NT / 16>(acc, a, lds + (kc & 1) * kVecs, lane);
+        mfma_pass_lds<NLOC, HALF>(acc, a, lds + (kc & 1) * kVecs, lane, base0, base1);
         if (kc + 1 < NKC) {
             ws.commit(lds + ((kc + 1) & 1) * kVecs);
             finish(kc + 1, raw, a);
@@ -172,24 +176,34 @@ __device__ __forceinline__ void gn_prologue16(float (&a)[kKC], const FwdRaw& raw
             if (pro.act == GLASS_ACT_ELU) h = elu_f(h);
             a[4 * v + k] = h * ds[k];
         }
-        *reinterpret_cast<float4*>(pro.side + row * pro.lds + col0 + 4 * v) =
-            make_float4(a[4 * v], a[4 * v + 1], a[4 * v + 2], a[4 * v + 3]);
+        if (pro.side)
+            *reinterpret_cast<float4*>(pro.side + row * pro.lds + col0 + 4 * v) =
+                make_float4(a[4 * v], a[4 * v + 1], a[4 * v + 2], a[4 * v + 3]);
     }
 }
 
-template <int H, bool COMB>
-__global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restrict__ xa, int64_t lda,
-                                                          const float* __restrict__ xb, int64_t ldb,
-                                                          const float* __restrict__ W, const float* __restrict__ bias,
-                                                          const uint8_t* __restrict__ mask, float zr, float omz, int act,
-                                                          float* __restrict__ T, int64_t ldt, float* __restrict__ out,
-                                                          int64_t ldo, int64_t N, double* __restrict__ stats,
-                                                          GnPrologue pro) {
-    constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H, NTILES = NT / 16;
-    static_assert(KQ % kKC == 0, "hidden size must be a multiple of 64");
+// CS = column split: CS wave groups of 4 waves share the same 64 rows, each owning 1/CS of the 64-column output
+// groups (hidden 64: CS = 1, a wave holds all 8 tiles; hidden 128: CS = 2, 8 of the 16 tiles per wave -> the
+// accumulators, staging registers and operand chunks fit the register file without spills).
+template <int H, bool COMB, int CS>
+__global__ __launch_bounds__(kBlock * CS) void dual_fwd_kernel(const float* __restrict__ xa, int64_t lda,
+                                                               const float* __restrict__ xb, int64_t ldb,
+                                                               const float* __restrict__ W,
+                                                               const float* __restrict__ bias,
+                                                               const uint8_t* __restrict__ mask, float zr, float omz,
+                                                               int act, float* __restrict__ T, int64_t ldt,
+                                                               float* __restrict__ out, int64_t ldo, int64_t N,
+                                                               double* __restrict__ stats, GnPrologue pro) {
+    constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H;
+    constexpr int THREADS = kBlock * CS;
+    constexpr int NG = H / 64;       // 64-column groups per half
+    constexpr int NGL = NG / CS;     // ... owned by one wave
+    constexpr int NLOC = 8 * NGL;    // local tiles: 4*NGL of the f1 half, then 4*NGL of the f0 half
+    static_assert(KQ % kKC == 0 && NG % CS == 0, "hidden size must be a multiple of 64 * CS");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rw = w & 3, cg = w >> 2;  // row wave, column group
     const int i = lane & 15, q = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + w) * 16;
+    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + rw) * 16;
     const int64_t row = row0 + i;
     const bool row_ok = row < N;
     // this lane's K-chunk of its A row: q*KQ .. (q+1)*KQ of [xa || xb]
@@ -200,17 +214,19 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
         arow = (q < 2) ? xa + row * lda + q * KQ : xb + row * ldb + (q - 2) * KQ;  // KQ = H/2
     }
     extern __shared__ float4 lds_w[];
-    f32x4 acc[NTILES];
+    f32x4 acc[NLOC];
 #pragma unroll
-    for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NLOC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     Drop drop = pro.drop;
     if (pro.saved && drop.p > 0.f) {
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
     const bool pro_lane = pro.saved != nullptr && row_ok && (!COMB || q < 2);  // lanes whose chunk belongs to xa
-    staged_product<NT, KT, FwdRaw>(
-        acc, W, lds_w, lane,
+    GnPrologue pro_w = pro;
+    if (cg != 0) pro_w.side = nullptr;  // the wave groups of a row tile compute the same operand; one writes it
+    staged_product<NT, KT, NLOC, 4 * NGL, THREADS, FwdRaw>(
+        acc, W, lds_w, lane, 4 * NGL * cg, 4 * (NG + NGL * cg),
         [&](int kc, FwdRaw& raw) {
             load16(raw.x, arow + kc * kKC, row_ok);
             if (pro_lane) {
@@ -225,33 +241,35 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
         [&](int kc, const FwdRaw& raw, float (&a)[kKC]) {
 #pragma unroll
             for (int s2 = 0; s2 < kKC; ++s2) a[s2] = raw.x[s2];
-            if (pro_lane) gn_prologue16(a, raw, pro, drop, row, q * KQ + kc * kKC);
+            if (pro_lane) gn_prologue16(a, raw, pro_w, drop, row, q * KQ + kc * kKC);
         });
-    // epilogue: acc[4g+k][reg] is row row0 + 4q + reg, column 64g + 4i + k  ->  float4 per (row, group)
-    constexpr int NG = H / 64;  // 64-column groups per half
-    float ssum[NG][4], ssq[NG][4];  // this lane's column sums over its (up to) 4 rows, for the GraphNorm that follows
+    // epilogue: acc[4gl+k][reg] is row row0 + 4q + reg, column 64g + 4i + k (g = NGL*cg + gl) -> float4 per (row, group)
+    float ssum[NGL][4], ssq[NGL][4];  // this lane's column sums over its (up to) 4 rows, for the GraphNorm that follows
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int g = 0; g < NGL; ++g)
 #pragma unroll
         for (int k = 0; k < 4; ++k) ssum[g][k] = ssq[g][k] = 0.f;
-    float4 bv[2 * NG];
+    float4 bv[2 * NGL];
 #pragma unroll
-    for (int g = 0; g < 2 * NG; ++g) bv[g] = *reinterpret_cast<const float4*>(bias + 64 * g + 4 * i);
+    for (int gl = 0; gl < NGL; ++gl) {
+        bv[gl] = *reinterpret_cast<const float4*>(bias + 64 * (NGL * cg + gl) + 4 * i);
+        bv[NGL + gl] = *reinterpret_cast<const float4*>(bias + H + 64 * (NGL * cg + gl) + 4 * i);
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
         const int64_t r = row0 + 4 * q + reg;
         if (r >= N) continue;
         const float w1 = mask[r] ? zr : omz, w0 = mask[r] ? omz : zr;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int c = 64 * g + 4 * i;
+        for (int gl = 0; gl < NGL; ++gl) {
+            const int c = 64 * (NGL * cg + gl) + 4 * i;
             float v1[4], v0[4];
-            const float b1[4] = {bv[g].x, bv[g].y, bv[g].z, bv[g].w};
-            const float b0[4] = {bv[NG + g].x, bv[NG + g].y, bv[NG + g].z, bv[NG + g].w};
+            const float b1[4] = {bv[gl].x, bv[gl].y, bv[gl].z, bv[gl].w};
+            const float b0[4] = {bv[NGL + gl].x, bv[NGL + gl].y, bv[NGL + gl].z, bv[NGL + gl].w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v1[k] = acc[4 * g + k][reg] + b1[k];
-                v0[k] = acc[4 * (NG + g) + k][reg] + b0[k];
+                v1[k] = acc[4 * gl + k][reg] + b1[k];
+                v0[k] = acc[4 * (NGL + gl) + k][reg] + b0[k];
             }
             if (T) {
                 *reinterpret_cast<float4*>(T + r * ldt + c) = make_float4(v1[0], v1[1], v1[2], v1[3]);
@@ -266,8 +284,8 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
                     a0 = elu_fast_f(a0);
                 }
                 o[k] = w1 * a1 + w0 * a0;
-                ssum[g][k] += o[k];
-                ssq[g][k] = fmaf(o[k], o[k], ssq[g][k]);
+                ssum[gl][k] += o[k];
+                ssq[gl][k] = fmaf(o[k], o[k], ssq[gl][k]);
             }
             *reinterpret_cast<float4*>(out + r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -276,23 +294,24 @@ __global__ __launch_bounds__(kBlock) void dual_fwd_kernel(const float* __restric
     // Column statistics of `out` for the GraphNorm that consumes it (its statistics pass is skipped):
     // stats[blockIdx.x][2][H] = per-workgroup sum / sum of squares over its 64 rows, in fp64 from here on.
     __syncthreads();  // every wave is done with the weight images in LDS
-    double* red = reinterpret_cast<double*>(lds_w);  // [4 waves][H][2]
+    double* red = reinterpret_cast<double*>(lds_w);  // [4 row waves][H][2]
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int gl = 0; gl < NGL; ++gl)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            double s = (double)ssum[g][k], q2 = (double)ssq[g][k];
+            double s = (double)ssum[gl][k], q2 = (double)ssq[gl][k];
             s += __shfl_xor(s, 16);
             q2 += __shfl_xor(q2, 16);
             s += __shfl_xor(s, 32);
             q2 += __shfl_xor(q2, 32);
             if (q == 0) {
-                red[(w * H + 64 * g + 4 * i + k) * 2] = s;
-                red[(w * H + 64 * g + 4 * i + k) * 2 + 1] = q2;
+                const int c = 64 * (NGL * cg + gl) + 4 * i + k;
+                red[(rw * H + c) * 2] = s;
+                red[(rw * H + c) * 2 + 1] = q2;
             }
         }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += kBlock) {
+    for (int c = threadIdx.x; c < H; c += THREADS) {
         double s = 0.0, q2 = 0.0;
 #pragma unroll
         for (int ww = 0; ww < kBlock / kWave; ++ww) {
@@ -324,20 +343,25 @@ struct GnBwdStats {
 // ---- backward data gradient ---------------------------------------------------------------------
 // out[N, NT] = dZ[N, 2H] @ Wstack[2H, NT] (+ addend), dZ[n, o] = coef(n, o<H) * dsrc[n, o mod H] * act'(T[n, o]);
 // WT = Wstack^T stored [NT][2H] so that weight chunks are contiguous (refreshed once per step).
-template <int H, int NT>
-__global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
-                                                            const float* __restrict__ T, int64_t ldt,
-                                                            const uint8_t* __restrict__ mask, float zr, float omz,
-                                                            int act, const float* __restrict__ WT,
-                                                            const float* __restrict__ addend, int64_t ldadd,
-                                                            Drop drop, const uint64_t* __restrict__ rng_state,
-                                                            float* __restrict__ out, int64_t ldo, int64_t N,
-                                                            GnBwdStats gs) {
-    constexpr int KT = 2 * H, KQ = KT / 4, NTILES = NT / 16;
-    static_assert(KQ % kKC == 0, "hidden size must be a multiple of 32");
+template <int H, int NT, int CS>
+__global__ __launch_bounds__(kBlock * CS) void dual_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
+                                                                 const float* __restrict__ T, int64_t ldt,
+                                                                 const uint8_t* __restrict__ mask, float zr, float omz,
+                                                                 int act, const float* __restrict__ WT,
+                                                                 const float* __restrict__ addend, int64_t ldadd,
+                                                                 Drop drop, const uint64_t* __restrict__ rng_state,
+                                                                 float* __restrict__ out, int64_t ldo, int64_t N,
+                                                                 GnBwdStats gs) {
+    constexpr int KT = 2 * H, KQ = KT / 4;
+    constexpr int THREADS = kBlock * CS;
+    constexpr int NGO = NT / 64;      // 64-column output groups
+    constexpr int NGL = NGO / CS;     // ... owned by one wave (one contiguous run of 4*NGL tiles)
+    constexpr int NLOC = 4 * NGL;
+    static_assert(KQ % kKC == 0 && NGO % CS == 0 && NLOC % 2 == 0, "unsupported shape");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int rw = w & 3, cg = w >> 2;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + w) * 16;
+    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + rw) * 16;
     const int64_t row = row0 + i;
     const bool row_ok = row < N;
     const bool first = q < 2;  // lanes q=0,1 hold the f1 half (o < H), q=2,3 the f0 half
@@ -346,11 +370,11 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
     const float* drow = dsrc + row * ldd + (q & 1) * KQ;   // o mod H
     const float* trow = T ? T + row * ldt + q * KQ : nullptr;
     extern __shared__ float4 lds_w[];
-    f32x4 acc[NTILES];
+    f32x4 acc[NLOC];
 #pragma unroll
-    for (int t = 0; t < NTILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    staged_product<NT, KT, DgradRaw>(
-        acc, WT, lds_w, lane,
+    for (int t = 0; t < NLOC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    staged_product<NT, KT, NLOC, NLOC, THREADS, DgradRaw>(
+        acc, WT, lds_w, lane, NLOC * cg, 0,
         [&](int kc, DgradRaw& raw) {
             load16(raw.d, drow + kc * kKC, row_ok);
             if (act == GLASS_ACT_ELU) load16(raw.t, trow + kc * kKC, row_ok);
@@ -367,24 +391,25 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
     }
-    constexpr int NGS = H / 64;  // 64-column groups of the GraphNorm half
-    float s1[NGS][4], s2[NGS][4];
-    float4 g_mu[NGS], g_rstd[NGS], g_scale[NGS], g_shift[NGS], g_al[NGS];
+    constexpr int NGS = H / 64;  // 64-column groups of the GraphNorm half (global groups 0 .. NGS-1)
+    float s1[NGL][4], s2[NGL][4];
+    float4 g_mu[NGL], g_rstd[NGL], g_scale[NGL], g_shift[NGL], g_al[NGL];
     if (gs.partial) {
         if (gs.drop.p > 0.f) {
             gs.drop.seed = rng_state[0];
             gs.drop.step = rng_state[1];
         }
 #pragma unroll
-        for (int g = 0; g < NGS; ++g) {
-            const int c = 64 * g + 4 * i;
-            g_mu[g] = *reinterpret_cast<const float4*>(gs.saved + c);
-            g_rstd[g] = *reinterpret_cast<const float4*>(gs.saved + H + c);
-            g_scale[g] = *reinterpret_cast<const float4*>(gs.saved + 2 * H + c);
-            g_shift[g] = *reinterpret_cast<const float4*>(gs.saved + 3 * H + c);
-            g_al[g] = *reinterpret_cast<const float4*>(gs.alpha + c);
+        for (int gl = 0; gl < NGL; ++gl) {
+            const int g = NGL * cg + gl;
+            const int c = 64 * (g < NGS ? g : 0) + 4 * i;
+            g_mu[gl] = *reinterpret_cast<const float4*>(gs.saved + c);
+            g_rstd[gl] = *reinterpret_cast<const float4*>(gs.saved + H + c);
+            g_scale[gl] = *reinterpret_cast<const float4*>(gs.saved + 2 * H + c);
+            g_shift[gl] = *reinterpret_cast<const float4*>(gs.saved + 3 * H + c);
+            g_al[gl] = *reinterpret_cast<const float4*>(gs.alpha + c);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) s1[g][k] = s2[g][k] = 0.f;
+            for (int k = 0; k < 4; ++k) s1[gl][k] = s2[gl][k] = 0.f;
         }
     }
 #pragma unroll
@@ -392,9 +417,10 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
         const int64_t r = row0 + 4 * q + reg;
         if (r >= N) continue;
 #pragma unroll
-        for (int g = 0; g < NTILES / 4; ++g) {
+        for (int gl = 0; gl < NGL; ++gl) {
+            const int g = NGL * cg + gl;
             const int c = 64 * g + 4 * i;
-            float4 v = make_float4(acc[4 * g][reg], acc[4 * g + 1][reg], acc[4 * g + 2][reg], acc[4 * g + 3][reg]);
+            float4 v = make_float4(acc[4 * gl][reg], acc[4 * gl + 1][reg], acc[4 * gl + 2][reg], acc[4 * gl + 3][reg]);
             if (addend) {
                 const float4 ad = *reinterpret_cast<const float4*>(addend + r * ldadd + c);
                 v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
@@ -405,14 +431,14 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
                 v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
             }
             *reinterpret_cast<float4*>(out + r * ldo + c) = v;
-            if (g < NGS && gs.partial) {
+            if (gs.partial && g < NGS) {
                 const float4 x4 = *reinterpret_cast<const float4*>(gs.x + r * gs.ldx + c);
                 const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, dy[4] = {v.x, v.y, v.z, v.w};
-                const float mu[4] = {g_mu[g].x, g_mu[g].y, g_mu[g].z, g_mu[g].w};
-                const float rs[4] = {g_rstd[g].x, g_rstd[g].y, g_rstd[g].z, g_rstd[g].w};
-                const float sc[4] = {g_scale[g].x, g_scale[g].y, g_scale[g].z, g_scale[g].w};
-                const float sh[4] = {g_shift[g].x, g_shift[g].y, g_shift[g].z, g_shift[g].w};
-                const float al[4] = {g_al[g].x, g_al[g].y, g_al[g].z, g_al[g].w};
+                const float mu[4] = {g_mu[gl].x, g_mu[gl].y, g_mu[gl].z, g_mu[gl].w};
+                const float rs[4] = {g_rstd[gl].x, g_rstd[gl].y, g_rstd[gl].z, g_rstd[gl].w};
+                const float sc[4] = {g_scale[gl].x, g_scale[gl].y, g_scale[gl].z, g_scale[gl].w};
+                const float sh[4] = {g_shift[gl].x, g_shift[gl].y, g_shift[gl].z, g_shift[gl].w};
+                const float al[4] = {g_al[gl].x, g_al[gl].y, g_al[gl].z, g_al[gl].w};
                 float ds[4] = {1.f, 1.f, 1.f, 1.f};
                 if (gs.drop.p > 0.f) drop_scales<4>(gs.drop, r, c, ds);
 #pragma unroll
@@ -420,31 +446,34 @@ __global__ __launch_bounds__(kBlock) void dual_dgrad_kernel(const float* __restr
                     float gp = dy[k] * ds[k];
                     if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv[k], sc[k], sh[k]));
                     const float xhat = (xv[k] - al[k] * mu[k]) * rs[k];
-                    s1[g < NGS ? g : 0][k] += gp;
-                    s2[g < NGS ? g : 0][k] = fmaf(gp, xhat, s2[g < NGS ? g : 0][k]);
+                    s1[gl][k] += gp;
+                    s2[gl][k] = fmaf(gp, xhat, s2[gl][k]);
                 }
             }
         }
     }
     if (gs.partial == nullptr) return;
     __syncthreads();  // every wave is done with the weight images in LDS
-    double* red = reinterpret_cast<double*>(lds_w);  // [4 waves][H][2]
+    double* red = reinterpret_cast<double*>(lds_w);  // [4 row waves][H][2]
 #pragma unroll
-    for (int g = 0; g < NGS; ++g)
+    for (int gl = 0; gl < NGL; ++gl) {
+        const int g = NGL * cg + gl;
+        if (g >= NGS) continue;  // wave-uniform
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            double a = (double)s1[g][k], b2 = (double)s2[g][k];
+            double a = (double)s1[gl][k], b2 = (double)s2[gl][k];
             a += __shfl_xor(a, 16);
             b2 += __shfl_xor(b2, 16);
             a += __shfl_xor(a, 32);
             b2 += __shfl_xor(b2, 32);
             if (q == 0) {
-                red[(w * H + 64 * g + 4 * i + k) * 2] = a;
-                red[(w * H + 64 * g + 4 * i + k) * 2 + 1] = b2;
+                red[(rw * H + 64 * g + 4 * i + k) * 2] = a;
+                red[(rw * H + 64 * g + 4 * i + k) * 2 + 1] = b2;
             }
         }
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < H; c += kBlock) {
+    for (int c = threadIdx.x; c < H; c += THREADS) {
         double a = 0.0, b2 = 0.0;
 #pragma unroll
         for (int ww = 0; ww < kBlock / kWave; ++ww) {
@@ -503,11 +532,12 @@ static void allow_lds(K kernel, size_t bytes) {
 
 static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128; }
 
-// Policy: the kernels are correct for H = 64 and 128 (both tested), but measured on MI355X the fused path
-// only beats hipBLASLt + the stand-alone mix kernels at H = 64 (ppi_bp-shape step 0.600 vs 0.689 ms);
-// at H = 128 (em_user-shape) it loses (1.38 vs 1.18 ms), so callers are steered to the library there.
+// Policy: hidden 64 (one wave group per 64 rows) and hidden 128 (two wave groups splitting the output columns, 512
+// threads: without the split the 16 accumulator tiles + staging spilled and the path lost to hipBLASLt + the
+// stand-alone mix kernels, 1.38 vs 1.18 ms on em_user-shape; with it the step program takes that shape from 1.04 to
+// 0.85 ms).  GLASS_DENSE_H128=0 turns hidden 128 off for A/B runs.
 extern "C" int glass_dual_linear_supported(int64_t H) {
-    static const bool h128 = getenv("GLASS_DENSE_H128") && atoi(getenv("GLASS_DENSE_H128")) == 1;  // A/B switch
+    static const bool h128 = !(getenv("GLASS_DENSE_H128") && atoi(getenv("GLASS_DENSE_H128")) == 0);
     return (H == 64 || (h128 && H == 128)) ? 1 : 0;
 }
 
@@ -537,18 +567,18 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs >1 pass)
     const size_t image = (size_t)2 * H * 256;
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
-#define GLASS_FWD(HH)                                                                                              \
+#define GLASS_FWD(HH, CS)                                                                                          \
     if (H == HH) {                                                                                                 \
-        allow_lds(dual_fwd_kernel<HH, true>, 2 * image);                                                           \
-        allow_lds(dual_fwd_kernel<HH, false>, 2 * image);                                                          \
+        allow_lds(dual_fwd_kernel<HH, true, CS>, 2 * image);                                                       \
+        allow_lds(dual_fwd_kernel<HH, false, CS>, 2 * image);                                                      \
         if (comb)                                                                                                  \
-            hipLaunchKernelGGL((dual_fwd_kernel<HH, true>), grid, dim3(kBlock), 2 * image, st, xa, lda, xb, ldb, W, bias, \
-                               mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);                         \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, true, CS>), grid, dim3(kBlock * CS), 2 * image, st, xa, lda, xb, ldb, \
+                               W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);                \
         else                                                                                                       \
-            hipLaunchKernelGGL((dual_fwd_kernel<HH, false>), grid, dim3(kBlock), (HH > 64 ? 2 : 1) * image, st, xa, lda, \
-                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS>), grid, dim3(kBlock * CS), (HH > 64 ? 2 : 1) * image, st, \
+                               xa, lda, xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro); \
     }
-    GLASS_FWD(64) GLASS_FWD(128)
+    GLASS_FWD(64, 1) GLASS_FWD(128, 2)
 #undef GLASS_FWD
     return launch_status("glass_dual_linear_fwd_f32");
 }
@@ -583,18 +613,19 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                   "dual_linear_dgrad: bad GraphNorm statistics arguments");
     const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                         make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
-#define GLASS_DG(HH)                                                                                               \
+#define GLASS_DG(HH, CS)                                                                                           \
     if (H == HH) {                                                                                                 \
-        allow_lds(dual_dgrad_kernel<HH, HH>, 2 * image);                                                           \
-        allow_lds(dual_dgrad_kernel<HH, 2 * HH>, 2 * image);                                                       \
+        allow_lds(dual_dgrad_kernel<HH, HH, CS>, 2 * image);                                                       \
+        allow_lds(dual_dgrad_kernel<HH, 2 * HH, CS>, 2 * image);                                                   \
         if (n_out == H)                                                                                            \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, mask, \
-                               zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs);           \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH, CS>), grid, dim3(kBlock * CS), 2 * image, st, dsrc, ldd, Tp, \
+                               ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs); \
         else                                                                                                       \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH>), grid, dim3(kBlock), 2 * image, st, dsrc, ldd, Tp, ldt, \
-                               mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs);     \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH, CS>), grid, dim3(kBlock * CS), 2 * image, st, dsrc, ldd, \
+                               Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, \
+                               gs);                                                                                \
     }
-    GLASS_DG(64) GLASS_DG(128)
+    GLASS_DG(64, 1) GLASS_DG(128, 2)
 #undef GLASS_DG
     return launch_status("glass_dual_linear_dgrad_f32");
 }

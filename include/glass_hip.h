@@ -225,7 +225,7 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  *   dgrad: out[N, n_out] = dZ @ W (+ addend), dZ[n,o] = coef(mask[n], o<H) * dsrc[n, o mod H] * act'(T[n,o])
  *          synthesised on the fly; WTimg = packed image of W^T ([n_out] x [2H]).
  *   wgrad: dW[2H, K] (+)= dZ^T @ [X || X2], db (+)= colsum(dZ), same synthesis, split-K MFMA as K5w.
- *   Hidden sizes 64/128/192/256 (glass_dual_linear_supported); otherwise GLASS_E_UNSUPPORTED and the
+ *   Hidden sizes 64 and 128 (glass_dual_linear_supported); otherwise GLASS_E_UNSUPPORTED and the
  *   caller composes the library GEMM with glass_mix_*.
  * ---------------------------------------------------------------------------------------- */
 int glass_dual_linear_supported(int64_t H);
