@@ -49,24 +49,29 @@ __device__ __forceinline__ int tile_col(int t, int j) { return 64 * (t >> 2) + 4
 // elements 4v..4v+3 of lane (j,q)'s 16-float chunk of weight row tile_col(t, j)  ->  every wave-level
 // ds_read_b128 is one contiguous KiB (no bank conflicts) and the L2 sees one fetch per workgroup.
 // The permutation itself is done once per training step for all weights by pack_batch_kernel.
-template <int NT, int THREADS>
+// One staging object holds at most 8 float4 per thread (32 registers): the compiler only promotes private arrays of
+// up to 32 registers to VGPRs, a 16-float4 array (hidden 256: 128 KiB image / 512 threads) went to scratch (272 B
+// per lane).  Larger images use two objects (PART 0 and 1).
+template <int NT, int THREADS, int PART>
 struct WStage {
     static constexpr int NTILES = NT / 16;
     static constexpr int kVecs = NTILES * 4 * 64;          // float4 per pass image
-    static constexpr int kPerThread = kVecs / THREADS;     // staging float4 per thread
-    float4 r[kPerThread];
+    static constexpr int kPerThread = kVecs / THREADS;     // staging float4 per thread, all parts
+    static constexpr int kFirst = PART * 8;
+    static constexpr int kMine = kPerThread - kFirst < 8 ? (kPerThread - kFirst > 0 ? kPerThread - kFirst : 0) : 8;
+    float4 r[kMine > 0 ? kMine : 1];
     // global -> registers: pass kc of the PACKED weight (glass_dense_pack_batch_f32 wrote it in image
     // order once per step), so this is a fully coalesced 16-B-per-lane copy.  (Gathering the image from
     // the row-major weight here cost ~4 us per pass: 64 scattered 16-B reads per wave-instruction.)
     __device__ __forceinline__ void fetch(const float* __restrict__ Wimg, int /*KT*/, int kc) {
         const float4* src = reinterpret_cast<const float4*>(Wimg) + (int64_t)kc * kVecs;
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) r[n] = src[threadIdx.x + THREADS * n];
+        for (int n = 0; n < kMine; ++n) r[n] = src[threadIdx.x + THREADS * (kFirst + n)];
     }
     // registers -> LDS image (consecutive threads write consecutive float4)
     __device__ __forceinline__ void commit(float4* __restrict__ image) const {
 #pragma unroll
-        for (int n = 0; n < kPerThread; ++n) image[threadIdx.x + THREADS * n] = r[n];
+        for (int n = 0; n < kMine; ++n) image[threadIdx.x + THREADS * (kFirst + n)] = r[n];
     }
 };
 
@@ -76,16 +81,40 @@ struct WStage {
 // A wave may own only part of the output columns (column split, hidden 128: two wave groups per 16 rows): its
 // NTILES local tiles are the image tiles base0 .. base0+HALF-1 followed by base1 .. (two runs: the f1 and f0
 // halves of a Linear pair; HALF == NTILES: one run).
-template <int NTILES, int HALF>
+template <int NTILES, int HALF, bool LEAN>
 __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float (&a)[kKC], const float4* image,
                                               int lane, int base0, int base1) {
     static_assert(NTILES % 2 == 0, "tiles are processed in pairs");
-    float4 b[2][2][4];
-    auto read_tile = [&](int tl, float4 (&dst)[4]) {
+    auto read_tile = [&](int tl, float4 (&dst)[4]) __attribute__((always_inline)) {
         const int t = tl < HALF ? base0 + tl : base1 + (tl - HALF);
 #pragma unroll
         for (int v = 0; v < 4; ++v) dst[v] = image[(t * 4 + v) * 64 + lane];
     };
+    auto mfma_pair = [&](int t, const float4 (&b0v)[4], const float4 (&b1v)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float b0[4] = {b0v[v].x, b0v[v].y, b0v[v].z, b0v[v].w};
+            const float b1[4] = {b1v[v].x, b1v[v].y, b1v[v].z, b1v[v].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * v + e], b0[e], acc[t], 0, 0, 0);
+                acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * v + e], b1[e], acc[t + 1], 0, 0, 0);
+            }
+        }
+    };
+    if (LEAN) {
+        // hidden 256: 64 registers per lane hold the next 128 KiB weight image across this pass, so the operand pair
+        // of the next tiles is not prefetched (32 registers less; otherwise the compiler spills the staging to scratch)
+#pragma unroll
+        for (int t = 0; t < NTILES; t += 2) {
+            float4 b0v[4], b1v[4];
+            read_tile(t, b0v);
+            read_tile(t + 1, b1v);
+            mfma_pair(t, b0v, b1v);
+        }
+        return;
+    }
+    float4 b[2][2][4];
     read_tile(0, b[0][0]);
     read_tile(1, b[0][1]);
 #pragma unroll
@@ -96,16 +125,7 @@ __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float 
             read_tile(t + 3, b[cur ^ 1][1]);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above ahead of the MFMAs below
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float b0[4] = {b[cur][0][v].x, b[cur][0][v].y, b[cur][0][v].z, b[cur][0][v].w};
-            const float b1[4] = {b[cur][1][v].x, b[cur][1][v].y, b[cur][1][v].z, b[cur][1][v].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * v + e], b0[e], acc[t], 0, 0, 0);
-                acc[t + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * v + e], b1[e], acc[t + 1], 0, 0, 0);
-            }
-        }
+        mfma_pair(t, b[cur][0], b[cur][1]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -114,16 +134,27 @@ __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float 
 // double-buffered through LDS.  The A operand of pass kc is produced in two steps so that the loads of pass kc+1
 // stay in flight across the MFMAs of pass kc: `issue(kc, raw)` only starts the global loads into `raw`;
 // `finish(kc, raw, a)` (run after the current pass) turns them into the operand chunk (prologue arithmetic).
+// LDS budget per workgroup for the weight images (160 KiB per CU; headroom for the runtime)
+constexpr int kLdsBudget = 152 * 1024;
+template <int NT> struct WBuf {
+    static constexpr bool kDouble = 2 * NT * 256 <= kLdsBudget;  // NT*256 B per pass image
+};
+
 template <int NT, int KT, int NLOC, int HALF, int THREADS, typename Raw, typename Issue, typename Finish>
 __device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* __restrict__ W, float4* lds, int lane,
                                                int base0, int base1, Issue issue, Finish finish) {
     constexpr int NKC = KT / 4 / kKC;
-    constexpr int kVecs = WStage<NT, THREADS>::kVecs;
-    WStage<NT, THREADS> ws;
+    constexpr int kVecs = WStage<NT, THREADS, 0>::kVecs;
+    static_assert(WStage<NT, THREADS, 0>::kPerThread <= 16, "weight image too large for two staging parts");
+    constexpr bool kDouble = WBuf<NT>::kDouble;  // hidden 256: one image at a time (two barriers per pass)
+    WStage<NT, THREADS, 0> ws;
+    WStage<NT, THREADS, 1> ws1;
     ws.fetch(W, KT, 0);
+    ws1.fetch(W, KT, 0);
     Raw raw;
     issue(0, raw);
     ws.commit(lds);
+    ws1.commit(lds);
     float a[kKC];
     finish(0, raw, a);
     __syncthreads();
@@ -131,12 +162,17 @@ __device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* 
     for (int kc = 0; kc < NKC; ++kc) {
         if (kc + 1 < NKC) {
             ws.fetch(W, KT, kc + 1);
+            ws1.fetch(W, KT, kc + 1);
             issue(kc + 1, raw);
         }
         __builtin_amdgcn_sched_barrier(0);  // the loads above are issued before the MFMAs below
-        mfma_pass_lds<NLOC, HALF>(acc, a, lds + (kc & 1) * kVecs, lane, base0, base1);
+        // LEAN when the staging registers of a 128 KiB image (16 float4 per thread) are alive across the pass
+        mfma_pass_lds<NLOC, HALF, (WStage<NT, THREADS, 0>::kPerThread > 8)>(acc, a, lds + (kDouble ? (kc & 1) * kVecs : 0), lane,
+                                                                          base0, base1);
         if (kc + 1 < NKC) {
-            ws.commit(lds + ((kc + 1) & 1) * kVecs);
+            if (!kDouble) __syncthreads();  // every wave has read this pass's image before it is overwritten
+            ws.commit(lds + (kDouble ? ((kc + 1) & 1) * kVecs : 0));
+            ws1.commit(lds + (kDouble ? ((kc + 1) & 1) * kVecs : 0));
             finish(kc + 1, raw, a);
             __syncthreads();
         }
@@ -185,8 +221,8 @@ __device__ __forceinline__ void gn_prologue16(float (&a)[kKC], const FwdRaw& raw
 // CS = column split: CS wave groups of 4 waves share the same 64 rows, each owning 1/CS of the 64-column output
 // groups (hidden 64: CS = 1, a wave holds all 8 tiles; hidden 128: CS = 2, 8 of the 16 tiles per wave -> the
 // accumulators, staging registers and operand chunks fit the register file without spills).
-template <int H, bool COMB, int CS>
-__global__ __launch_bounds__(kBlock * CS) void dual_fwd_kernel(const float* __restrict__ xa, int64_t lda,
+template <int H, bool COMB, int CS, int RW>
+__global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
                                                                const float* __restrict__ W,
                                                                const float* __restrict__ bias,
@@ -195,15 +231,15 @@ __global__ __launch_bounds__(kBlock * CS) void dual_fwd_kernel(const float* __re
                                                                float* __restrict__ out, int64_t ldo, int64_t N,
                                                                double* __restrict__ stats, GnPrologue pro) {
     constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H;
-    constexpr int THREADS = kBlock * CS;
+    constexpr int THREADS = kWave * RW * CS;  // RW row waves (16 rows each) x CS column groups
     constexpr int NG = H / 64;       // 64-column groups per half
     constexpr int NGL = NG / CS;     // ... owned by one wave
     constexpr int NLOC = 8 * NGL;    // local tiles: 4*NGL of the f1 half, then 4*NGL of the f0 half
     static_assert(KQ % kKC == 0 && NG % CS == 0, "hidden size must be a multiple of 64 * CS");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int rw = w & 3, cg = w >> 2;  // row wave, column group
+    const int rw = w % RW, cg = w / RW;  // row wave, column group
     const int i = lane & 15, q = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + rw) * 16;
+    const int64_t row0 = ((int64_t)blockIdx.x * RW + rw) * 16;
     const int64_t row = row0 + i;
     const bool row_ok = row < N;
     // this lane's K-chunk of its A row: q*KQ .. (q+1)*KQ of [xa || xb]
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(kBlock * CS) void dual_fwd_kernel(const float* __re
     if (cg != 0) pro_w.side = nullptr;  // the wave groups of a row tile compute the same operand; one writes it
     staged_product<NT, KT, NLOC, 4 * NGL, THREADS, FwdRaw>(
         acc, W, lds_w, lane, 4 * NGL * cg, 4 * (NG + NGL * cg),
-        [&](int kc, FwdRaw& raw) {
+        [&](int kc, FwdRaw& raw) __attribute__((always_inline)) {
             load16(raw.x, arow + kc * kKC, row_ok);
             if (pro_lane) {
                 const int col0 = q * KQ + kc * kKC;
@@ -238,7 +274,7 @@ __global__ __launch_bounds__(kBlock * CS) void dual_fwd_kernel(const float* __re
                 }
             }
         },
-        [&](int kc, const FwdRaw& raw, float (&a)[kKC]) {
+        [&](int kc, const FwdRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s2 = 0; s2 < kKC; ++s2) a[s2] = raw.x[s2];
             if (pro_lane) gn_prologue16(a, raw, pro_w, drop, row, q * KQ + kc * kKC);
@@ -292,9 +328,9 @@ __global__ __launch_bounds__(kBlock * CS) void dual_fwd_kernel(const float* __re
     }
     if (stats == nullptr) return;
     // Column statistics of `out` for the GraphNorm that consumes it (its statistics pass is skipped):
-    // stats[blockIdx.x][2][H] = per-workgroup sum / sum of squares over its 64 rows, in fp64 from here on.
+    // stats[blockIdx.x][2][H] = per-workgroup sum / sum of squares over its 16*RW rows, in fp64 from here on.
     __syncthreads();  // every wave is done with the weight images in LDS
-    double* red = reinterpret_cast<double*>(lds_w);  // [4 row waves][H][2]
+    double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
 #pragma unroll
     for (int gl = 0; gl < NGL; ++gl)
 #pragma unroll
@@ -314,7 +350,7 @@ __global__ __launch_bounds__(kBlock * CS) void dual_fwd_kernel(const float* __re
     for (int c = threadIdx.x; c < H; c += THREADS) {
         double s = 0.0, q2 = 0.0;
 #pragma unroll
-        for (int ww = 0; ww < kBlock / kWave; ++ww) {
+        for (int ww = 0; ww < RW; ++ww) {
             s += red[(ww * H + c) * 2];
             q2 += red[(ww * H + c) * 2 + 1];
         }
@@ -343,8 +379,8 @@ struct GnBwdStats {
 // ---- backward data gradient ---------------------------------------------------------------------
 // out[N, NT] = dZ[N, 2H] @ Wstack[2H, NT] (+ addend), dZ[n, o] = coef(n, o<H) * dsrc[n, o mod H] * act'(T[n, o]);
 // WT = Wstack^T stored [NT][2H] so that weight chunks are contiguous (refreshed once per step).
-template <int H, int NT, int CS>
-__global__ __launch_bounds__(kBlock * CS) void dual_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
+template <int H, int NT, int CS, int RW>
+__global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                  const float* __restrict__ T, int64_t ldt,
                                                                  const uint8_t* __restrict__ mask, float zr, float omz,
                                                                  int act, const float* __restrict__ WT,
@@ -353,15 +389,15 @@ __global__ __launch_bounds__(kBlock * CS) void dual_dgrad_kernel(const float* __
                                                                  float* __restrict__ out, int64_t ldo, int64_t N,
                                                                  GnBwdStats gs) {
     constexpr int KT = 2 * H, KQ = KT / 4;
-    constexpr int THREADS = kBlock * CS;
+    constexpr int THREADS = kWave * RW * CS;
     constexpr int NGO = NT / 64;      // 64-column output groups
     constexpr int NGL = NGO / CS;     // ... owned by one wave (one contiguous run of 4*NGL tiles)
     constexpr int NLOC = 4 * NGL;
     static_assert(KQ % kKC == 0 && NGO % CS == 0 && NLOC % 2 == 0, "unsupported shape");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int rw = w & 3, cg = w >> 2;
+    const int rw = w % RW, cg = w / RW;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * (kBlock / kWave) + rw) * 16;
+    const int64_t row0 = ((int64_t)blockIdx.x * RW + rw) * 16;
     const int64_t row = row0 + i;
     const bool row_ok = row < N;
     const bool first = q < 2;  // lanes q=0,1 hold the f1 half (o < H), q=2,3 the f0 half
@@ -375,11 +411,11 @@ __global__ __launch_bounds__(kBlock * CS) void dual_dgrad_kernel(const float* __
     for (int t = 0; t < NLOC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     staged_product<NT, KT, NLOC, NLOC, THREADS, DgradRaw>(
         acc, WT, lds_w, lane, NLOC * cg, 0,
-        [&](int kc, DgradRaw& raw) {
+        [&](int kc, DgradRaw& raw) __attribute__((always_inline)) {
             load16(raw.d, drow + kc * kKC, row_ok);
             if (act == GLASS_ACT_ELU) load16(raw.t, trow + kc * kKC, row_ok);
         },
-        [&](int, const DgradRaw& raw, float (&a)[kKC]) {
+        [&](int, const DgradRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < kKC; ++s) {
                 float v = raw.d[s] * coef;
@@ -454,7 +490,7 @@ __global__ __launch_bounds__(kBlock * CS) void dual_dgrad_kernel(const float* __
     }
     if (gs.partial == nullptr) return;
     __syncthreads();  // every wave is done with the weight images in LDS
-    double* red = reinterpret_cast<double*>(lds_w);  // [4 row waves][H][2]
+    double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
 #pragma unroll
     for (int gl = 0; gl < NGL; ++gl) {
         const int g = NGL * cg + gl;
@@ -476,7 +512,7 @@ __global__ __launch_bounds__(kBlock * CS) void dual_dgrad_kernel(const float* __
     for (int c = threadIdx.x; c < H; c += THREADS) {
         double a = 0.0, b2 = 0.0;
 #pragma unroll
-        for (int ww = 0; ww < kBlock / kWave; ++ww) {
+        for (int ww = 0; ww < RW; ++ww) {
             a += red[(ww * H + c) * 2];
             b2 += red[(ww * H + c) * 2 + 1];
         }
@@ -530,16 +566,29 @@ static void allow_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128; }
+static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128 || H == 256; }
+static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at once (see WBuf)
+    const size_t image = (size_t)NT * 256;
+    return (n_pass > 1 && 2 * image <= (size_t)kLdsBudget) ? 2 * image : image;
+}
 
 // Policy: hidden 64 (one wave group per 64 rows) and hidden 128 (two wave groups splitting the output columns, 512
 // threads: without the split the 16 accumulator tiles + staging spilled and the path lost to hipBLASLt + the
 // stand-alone mix kernels, 1.38 vs 1.18 ms on em_user-shape; with it the step program takes that shape from 1.04 to
 // 0.85 ms).  GLASS_DENSE_H128=0 turns hidden 128 off for A/B runs.
+// Hidden 256 is built and parity-tested (2 row waves x 4 column groups, one 128 KiB weight image in LDS at a time)
+// but OFF: the compiler keeps the 64 staging registers of the next image in scratch across the MFMA pass, and at
+// C5 (N = 1 M) the step takes 121 ms against 74 ms on the library-GEMM path.  GLASS_DENSE_H256=1 enables it; it
+// needs a K-pass of 32 (64 KiB images, double-buffered, 8 staging registers) to be worth it.
 extern "C" int glass_dual_linear_supported(int64_t H) {
     static const bool h128 = !(getenv("GLASS_DENSE_H128") && atoi(getenv("GLASS_DENSE_H128")) == 0);
-    return (H == 64 || (h128 && H == 128)) ? 1 : 0;
+    static const bool h256 = getenv("GLASS_DENSE_H256") && atoi(getenv("GLASS_DENSE_H256")) == 1;
+    return (H == 64 || (h128 && H == 128) || (h256 && H == 256)) ? 1 : 0;
 }
+
+// rows per workgroup = rows per epilogue statistics partial: 64 (hidden 64 / 128), 32 (hidden 256: 2 row waves x 4
+// column groups, 512 threads, so that a wave may use more than 128 registers)
+extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return H == 256 ? 32 : 64; }
 
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
@@ -553,7 +602,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
                                 (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
                   "dual_linear_fwd: bad GraphNorm prologue arguments");
     if (!dense_shape_ok(H)) {
-        set_error("dual_linear_fwd: hidden size %lld not supported (64, 128)", (long long)H);
+        set_error("dual_linear_fwd: hidden size %lld not supported (64, 128, 256)", (long long)H);
         return GLASS_E_UNSUPPORTED;
     }
     const bool comb = xb != nullptr;
@@ -562,23 +611,23 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
                       (!T || (ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))),
                   "dual_linear_fwd: operands must be 16-B aligned with ld %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)ceil_div(n_nodes, 64));
+    const dim3 grid((unsigned)ceil_div(n_nodes, glass_dual_linear_stat_rows(H)));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
-    // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs >1 pass)
-    const size_t image = (size_t)2 * H * 256;
+    // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs > 1 pass and both fit)
+    const size_t lds_comb = lds_bytes(2 * H, (int)(2 * H / 64)), lds_trans = lds_bytes(2 * H, (int)(H / 64));
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
-#define GLASS_FWD(HH, CS)                                                                                          \
+#define GLASS_FWD(HH, CS, RW)                                                                                      \
     if (H == HH) {                                                                                                 \
-        allow_lds(dual_fwd_kernel<HH, true, CS>, 2 * image);                                                       \
-        allow_lds(dual_fwd_kernel<HH, false, CS>, 2 * image);                                                      \
+        allow_lds(dual_fwd_kernel<HH, true, CS, RW>, lds_comb);                                                    \
+        allow_lds(dual_fwd_kernel<HH, false, CS, RW>, lds_trans);                                                  \
         if (comb)                                                                                                  \
-            hipLaunchKernelGGL((dual_fwd_kernel<HH, true, CS>), grid, dim3(kBlock * CS), 2 * image, st, xa, lda, xb, ldb, \
-                               W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);                \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, true, CS, RW>), grid, dim3(kWave * RW * CS), lds_comb, st, xa, lda,  \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
         else                                                                                                       \
-            hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS>), grid, dim3(kBlock * CS), (HH > 64 ? 2 : 1) * image, st, \
-                               xa, lda, xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro); \
+            hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS, RW>), grid, dim3(kWave * RW * CS), lds_trans, st, xa, lda, \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
     }
-    GLASS_FWD(64, 1) GLASS_FWD(128, 2)
+    GLASS_FWD(64, 1, 4) GLASS_FWD(128, 2, 4) GLASS_FWD(256, 4, 2)
 #undef GLASS_FWD
     return launch_status("glass_dual_linear_fwd_f32");
 }
@@ -602,10 +651,10 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                       (!addend || (ldadd >= n_out && ldadd % 4 == 0 && aligned16(addend))),
                   "dual_linear_dgrad: operands must be 16-B aligned with ld %% 4 == 0");
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)ceil_div(n_nodes, 64));
+    const dim3 grid((unsigned)ceil_div(n_nodes, glass_dual_linear_stat_rows(H)));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     const float* Tp = act == GLASS_ACT_ELU ? T : nullptr;
-    const size_t image = (size_t)n_out * 256;  // K = 2H always needs >= 2 passes
+    const size_t lds_dg = lds_bytes(n_out, 2);  // K = 2H always needs >= 2 passes
     const Drop drop = make_drop(p_drop, call_id, n_out);
     GLASS_REQUIRE(!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && gn_ldx % 4 == 0 && aligned16(gn_x) &&
                                   aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
@@ -613,19 +662,20 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                   "dual_linear_dgrad: bad GraphNorm statistics arguments");
     const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                         make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
-#define GLASS_DG(HH, CS)                                                                                           \
+#define GLASS_DG(HH, CS, RW)                                                                                       \
     if (H == HH) {                                                                                                 \
-        allow_lds(dual_dgrad_kernel<HH, HH, CS>, 2 * image);                                                       \
-        allow_lds(dual_dgrad_kernel<HH, 2 * HH, CS>, 2 * image);                                                   \
+        allow_lds(dual_dgrad_kernel<HH, HH, CS, RW>, lds_dg);                                                      \
+        allow_lds(dual_dgrad_kernel<HH, 2 * HH, CS, RW>, lds_dg);                                                  \
         if (n_out == H)                                                                                            \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH, CS>), grid, dim3(kBlock * CS), 2 * image, st, dsrc, ldd, Tp, \
-                               ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs); \
-        else                                                                                                       \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH, CS>), grid, dim3(kBlock * CS), 2 * image, st, dsrc, ldd, \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH, CS, RW>), grid, dim3(kWave * RW * CS), lds_dg, st, dsrc, ldd,  \
                                Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, \
                                gs);                                                                                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH, CS, RW>), grid, dim3(kWave * RW * CS), lds_dg, st, dsrc,   \
+                               ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo,     \
+                               n_nodes, gs);                                                                       \
     }
-    GLASS_DG(64, 1) GLASS_DG(128, 2)
+    GLASS_DG(64, 1, 4) GLASS_DG(128, 2, 4) GLASS_DG(256, 4, 2)
 #undef GLASS_DG
     return launch_status("glass_dual_linear_dgrad_f32");
 }

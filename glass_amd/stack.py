@@ -242,7 +242,8 @@ class StackProgram:
         # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
         advance = train and (p > 0 or any(c.dropout > 0 for c in emb.convs))
         emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
-        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc)}
+        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc),
+              "stat_rows": int(lib.glass_dual_linear_stat_rows(H))}  # rows per workgroup of the fused dense kernels
         # labels: z (int64 [N], > 0 = labeled), None (all labeled), or ("pos", pos): labeled = the nodes listed in the
         # padded subgraph matrix — utils.MaxZOZ without materialising z (a byte memset + scatter inside the gather)
         if isinstance(z, tuple):
@@ -297,7 +298,7 @@ class StackProgram:
             last = l + 1 == L
             c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
             # the comb kernel's epilogue also leaves the column statistics of c for the GraphNorm(s) that read it
-            cstat = torch.empty(((n + 63) // 64, 2, H), dtype=torch.float64, device=dev)
+            cstat = torch.empty((-(-n // st["stat_rows"]), 2, H), dtype=torch.float64, device=dev)
             _dual_fwd(a, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c, cstat,
                       gn=(gsaved, ACT_NONE, pc, conv.call_base, g))
             cstats.append(cstat)
@@ -355,7 +356,7 @@ class StackProgram:
         dh_next = None   # gradient w.r.t. the input of layer l+1 (= output of gns[l])
         npart = None     # backward column sums of gns[l], accumulated by layer l+1's trans data-gradient epilogue
         pending = []     # weight gradients whose partial sums are written but not yet reduced
-        nblk = (n + 63) // 64
+        nblk = -(-n // st["stat_rows"])
         f64 = dict(dtype=torch.float64, device=dev)
         for l in range(L - 1, -1, -1):
             conv, rec = emb.convs[l], st["layers"][l]

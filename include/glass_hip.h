@@ -225,12 +225,14 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  *   dgrad: out[N, n_out] = dZ @ W (+ addend), dZ[n,o] = coef(mask[n], o<H) * dsrc[n, o mod H] * act'(T[n,o])
  *          synthesised on the fly; WTimg = packed image of W^T ([n_out] x [2H]).
  *   wgrad: dW[2H, K] (+)= dZ^T @ [X || X2], db (+)= colsum(dZ), same synthesis, split-K MFMA as K5w.
- *   Hidden sizes 64 and 128 (glass_dual_linear_supported); otherwise GLASS_E_UNSUPPORTED and the
+ *   Hidden sizes 64 and 128 (glass_dual_linear_supported; 256 is built but slower than the library path and off); otherwise GLASS_E_UNSUPPORTED and the
  *   caller composes the library GEMM with glass_mix_*.
  * ---------------------------------------------------------------------------------------- */
 int glass_dual_linear_supported(int64_t H);
+/* rows covered by one workgroup of the fused kernels at hidden H = rows per `stats` / `gn_partial` entry */
+int64_t glass_dual_linear_stat_rows(int64_t H);
 /*   fwd, stats != NULL: the epilogue also writes the column statistics of `out` for the GraphNorm that consumes
- *   it — stats[ceil(n_nodes/64)][2][H] doubles (per 64-row workgroup: sum, sum of squares) — so that GraphNorm
+ *   it — stats[ceil(n_nodes/R)][2][H] doubles, R = glass_dual_linear_stat_rows(H) (per workgroup: sum, sum of squares) — so that GraphNorm
  *   needs no statistics pass of its own: glass_graphnorm_finalize_f32 + glass_graphnorm_apply_f32.
  *   fwd, gn_saved != NULL: xa is the INPUT of a GraphNorm whose statistics are final (gn_saved[4H] from
  *   glass_graphnorm_finalize_f32 / _stats_f32); the kernel computes dropout(act(xa*scale + shift)) while loading
@@ -246,7 +248,7 @@ int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int
  *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL).
  *   dgrad, gn_partial != NULL: the first H output columns are the gradient dy of a GraphNorm OUTPUT (input gn_x,
  *   forward statistics gn_saved, mean scale gn_alpha, activation / dropout gn_act, gn_p_drop, gn_call_id of that
- *   GraphNorm); the epilogue accumulates its two backward column sums into gn_partial[ceil(n_nodes/64)][2][H]
+ *   GraphNorm); the epilogue accumulates its two backward column sums into gn_partial[ceil(n_nodes/R)][2][H]
  *   doubles, for glass_graphnorm_bwd_from_stats_f32 — no backward statistics launch. */
 int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* WTimg, int64_t n_out, const float* addend,
