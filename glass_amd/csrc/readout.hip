@@ -284,8 +284,12 @@ __global__ __launch_bounds__(kOrdBlock) void readout_scatter_ordered_kernel(cons
         nodes[j] = (p >= 0 && p < n_nodes) ? (int32_t)p : -1;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, b = blockIdx.x;
-    for (int s = w; s < Smax; s += kOrdBlock / kWave) {
+    // grid = B * ceil(Smax / 16): workgroup (b, part) takes entries part*16 .. part*16+15 of subgraph b, one per wave
+    constexpr int kWaves = kOrdBlock / kWave;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int parts = (Smax + kWaves - 1) / kWaves;
+    const int b = blockIdx.x / parts;
+    for (int s = (blockIdx.x % parts) * kWaves + w; s < Smax; s += Smax) {  // at most one entry per wave
         const int j = b * Smax + s;
         const int node = nodes[j];
         if (node < 0) continue;  // wave-uniform
@@ -409,7 +413,8 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     hipLaunchKernelGGL(readout_dense_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, st, jk, ldj, djk, lddj, n_nodes, (int)C,
                        tc_log2, w.coef);
     if (B * Smax <= kReadoutOrderedMax) {
-        hipLaunchKernelGGL(readout_scatter_ordered_kernel, dim3((unsigned)B), dim3(kOrdBlock), sizeof(int32_t) * (size_t)(B * Smax),
+        const int64_t parts = ceil_div(Smax, (int64_t)(kOrdBlock / kWave));
+        hipLaunchKernelGGL(readout_scatter_ordered_kernel, dim3((unsigned)(B * parts)), dim3(kOrdBlock), sizeof(int32_t) * (size_t)(B * Smax),
                            st, pos, (int)Smax, (int)(B * Smax), w.dys, w.coef, djk, lddj, n_nodes, (int)C);
     } else {
         hipLaunchKernelGGL(readout_scatter_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, pos, (int)Smax, w.dys, w.coef,
