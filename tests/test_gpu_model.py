@@ -388,13 +388,12 @@ def test_train_epoch_graph_path_matches_eager_path():
 
 
 # ---------------------------------------------------------------------------------- whole-stack program
-def _emb_pair(layers, jk, aggr, z_ratio, dropout, seed, n=700, n_pairs=4000, V=9):
+def _emb_pair(layers, jk, aggr, z_ratio, dropout, seed, n=700, n_pairs=4000, V=9, H=64):
     """(product EmbZGConv with arena on the GPU, oracle twin with the same weights, inputs)."""
     import functools
     from glass_amd import synth
     from glass_amd.arena import ParamArena
     from impl import models
-    H = 64
     torch.manual_seed(seed)
     emb = models.EmbZGConv(H, H, layers, max_deg=V - 1, activation=nn.ELU(inplace=True), jk=bool(jk), dropout=dropout,
                            conv=functools.partial(models.GLASSConv, aggr=aggr, z_ratio=z_ratio, dropout=dropout),
@@ -418,12 +417,13 @@ def _emb_pair(layers, jk, aggr, z_ratio, dropout, seed, n=700, n_pairs=4000, V=9
     return emb, arena, orc, (x, torch.from_numpy(ei), torch.from_numpy(ew), z), gout
 
 
-@pytest.mark.parametrize("layers,jk,aggr", [(1, 1, "mean"), (2, 1, "gcn"), (3, 1, "sum"), (2, 0, "mean"), (3, 0, "gcn")])
-def test_stack_program_vs_oracle(layers, jk, aggr):
-    """EmbZGConv as one forward/backward program (glass_amd/stack.py), hidden 64, against the fp64 oracle:
-    output, every parameter gradient (accumulated in place in the arena), and eval mode."""
+@pytest.mark.parametrize("layers,jk,aggr,hidden", [(1, 1, "mean", 64), (2, 1, "gcn", 64), (3, 1, "sum", 64), (2, 0, "mean", 64),
+                                                   (3, 0, "gcn", 64), (2, 1, "mean", 128), (3, 0, "sum", 128)])
+def test_stack_program_vs_oracle(layers, jk, aggr, hidden):
+    """EmbZGConv as one forward/backward program (glass_amd/stack.py), hidden 64 and 128 (column-split dense kernels),
+    against the fp64 oracle: output, every parameter gradient (accumulated in place in the arena), and eval mode."""
     from glass_amd import stack
-    emb, arena, orc, (x, ei, ew, z), gout = _emb_pair(layers, jk, aggr, 0.85, 0.0, seed=layers * 2 + jk)
+    emb, arena, orc, (x, ei, ew, z), gout = _emb_pair(layers, jk, aggr, 0.85, 0.0, seed=layers * 2 + jk, H=hidden)
     assert stack.StackProgram.supported(emb)
     emb.train()
     args = [t.to(DEV) for t in (x, ei, ew, z)]
@@ -452,7 +452,7 @@ def test_stack_program_matches_per_op_path_with_dropout(monkeypatch):
     """Same kernels, same dropout call ids: with dropout 0.5 the program and the per-op autograd path must draw the
     same masks, so outputs and gradients agree to rounding (the gradient sums are merely associated differently)."""
     from glass_amd import models as gm, ops
-    emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.95, 0.5, seed=11)
+    emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.95, 0.5, seed=11, H=64)
     emb.train()
     args = [t.to(DEV) for t in (x, ei, ew, z)]
     res = []
