@@ -1,25 +1,32 @@
 """The EmbZGConv stack as ONE explicit forward / backward program over the C ABI.
 
 `models.EmbZGConv.forward` (reference impl/models.py:241-272, layers 158-173) normally records one autograd node
-per kernel group (ops.py).  On the small graphs of the BASELINE configs the step is a chain of ~70 dependent
-4-15 us kernels, and the tape costs real launches: every tensor with two consumers (the layer input feeds the
-trans pair and the comb pair; with jumping knowledge a conv output feeds the next GraphNorm and the final one)
-gets its two gradients from two nodes and autograd adds them with an elementwise kernel.  Here the whole stack is
-a single autograd node whose backward walks the layers itself, so those sums ride along as the `addend` operand
-of the kernel that produces the other summand, and parameter gradients go straight into the gradient arena.
+per kernel group (ops.py).  On the small graphs of the BASELINE configs the step is a chain of dependent 4-15 us
+kernels, and both the tape and the op granularity cost real launches.  Here the whole stack is a single autograd
+node (`StackFn`) — or no tape at all (`loss_and_grads`, used by step.TrainStep) — whose forward and backward walk
+the layers themselves:
+
+  * gradient sums of tensors with two consumers ride as the `addend` operand of the kernel producing the other
+    summand; parameter gradients go straight into the gradient arena (accumulated, or overwritten so that the arena
+    needs no zero-fill);
+  * embedding lookup + emb_gn + dropout run through the V-row table (K3n) when the table is small;
+  * GraphNorm statistics come from the epilogue of the kernel that produced the tensor, the apply rides in the
+    operand load of the consuming fused dense kernel, backward column sums come from the data-gradient epilogues;
+  * the weight-gradient partial sums of all layers are reduced by one launch at the end of the backward pass;
+  * with a fusable readout (`step_supported`): final GraphNorm apply + pooling + Linear head + loss and their
+    backward are the four launches of K8r, and the labels are scattered straight from `pos`.
 
 Used when every layer takes the fused dense path (ParamArena present, GLASSConv layers of equal width that
-glass_dual_linear_supported() accepts, ELU, GraphNorm on); anything else keeps the per-op path.  Same kernels,
-same dropout call ids -> same dropout masks as the per-op path.
+glass_dual_linear_supported() accepts — hidden 64 / 128 —, ELU, GraphNorm on); anything else keeps the per-op path.
+Same kernels, same dropout call ids -> same dropout masks as the per-op path; no float atomics -> bitwise repeatable.
 """
+import os
+
 import numpy as np
 import torch
 
 from . import _lib, ops
 from .ops import ACT_ELU, ACT_NONE, _stream
-
-
-import os
 
 USE_EMBED_TABLE = os.environ.get("GLASS_EMBED_TABLE", "1") != "0"  # A/B switch: lookup + emb_gn through the table
 USE_READOUT = os.environ.get("GLASS_READOUT", "1") != "0"          # A/B switch: fused training readout (K8r)
