@@ -221,6 +221,15 @@ class EmbZGConv(nn.Module):
         x_flat = x.reshape(n)
         if x_flat.dtype != torch.int64:
             x_flat = x_flat.to(torch.int64)
+        if z is not None:
+            # reference: mask = (z > 0.5) for whatever z holds (impl/models.py:243-248); the kernels read int64
+            if z.numel() != n:
+                raise ValueError(f"z must hold one label per node ({n}), got {tuple(z.shape)}")
+            z = z.reshape(n)
+            if z.dtype != torch.int64:
+                z = (z > 0.5).to(torch.int64)
+            elif not z.is_contiguous():
+                z = z.contiguous()
         if USE_STACK and stack.StackProgram.supported(self):
             # the whole stack as one autograd node (explicit forward / backward program, glass_amd/stack.py)
             return stack.run(self, x_flat, z, edge_index, edge_weight)

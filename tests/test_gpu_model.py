@@ -810,3 +810,18 @@ def test_step_program_at_c5_scale_matches_per_op_path(monkeypatch):
     assert torch.isfinite(loss_a) and rel_inf(logits_a.cpu(), pred.detach().cpu()) < TOL
     assert abs(loss_a.item() - loss_b.item()) < TOL * abs(loss_b.item())
     assert rel_inf(ga.cpu(), arena.flat.cpu()) < 2 * TOL
+
+
+def test_label_vector_dtypes_and_shapes():
+    """z may arrive as int64 [N] (MaxZOZ), but also as a float / bool / [N,1] tensor: the reference thresholds it at
+    0.5 whatever it is (impl/models.py:243-248)."""
+    emb, arena, _orc, (x, ei, ew, z), _g = _emb_pair(1, 1, "mean", 0.8, 0.0, seed=2)
+    emb.eval()
+    args = [t.to(DEV) for t in (x, ei, ew)]
+    zg = z.to(DEV)
+    with torch.no_grad():
+        ref = emb(*args, zg)
+        for variant in (zg.to(torch.float32) * 0.9, zg.bool(), zg.reshape(-1, 1), zg.to(torch.int32), zg.double() + 0.3 * (1 - zg.double())):
+            assert torch.equal(emb(*args, variant), ref)
+        with pytest.raises(ValueError):
+            emb(*args, zg[:-1])
