@@ -825,3 +825,17 @@ def test_label_vector_dtypes_and_shapes():
             assert torch.equal(emb(*args, variant), ref)
         with pytest.raises(ValueError):
             emb(*args, zg[:-1])
+
+
+def test_split_step_with_rccl_allreduce_on_one_rank():
+    """The N>1 form of the step (captured forward/backward + eager RCCL all-reduce(AVG) of the flat gradient arena +
+    eager fused Adam) on a 1-rank RCCL group, in a subprocess: bit-identical parameters to the single-process form."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29578", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_step_probe.py")], capture_output=True, text=True,
+                         timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "EQUAL" in out.stdout, out.stdout[-500:]

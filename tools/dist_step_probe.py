@@ -1,0 +1,48 @@
+"""The N>1 form of the training step on ONE GPU: a 1-rank RCCL group with glass_amd.dist told to treat it as
+distributed, so TrainStep takes its split form (captured forward/backward, eager RCCL all-reduce of the flat gradient
+arena with ReduceOp.AVG, eager fused Adam).  Prints the parameter hash after 20 steps next to the single-process
+form's: with one rank the average is the identity, so they must be equal.  Used by tests/test_gpu_model.py."""
+import hashlib
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as td
+
+
+def run(dist_mode):
+    from glass_amd import synth, losses, ops, dist as gdist
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    from glass_amd.step import TrainStep
+    from glass_amd.factory import build_glass
+    dev = torch.device("cuda", 0)
+    if dist_mode:
+        gdist.is_distributed = lambda: True  # a 1-rank group: world_size() == 1, rank() == 0
+    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=0, n_batches=4)
+    ei, ew, x, pos, y = (torch.from_numpy(a).to(dev) for a in (ei, ew, x, pos, y))
+    torch.manual_seed(0)
+    ops.rng_seed(7, dev)
+    model = build_glass(64, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=0.5).to(dev).train()
+    arena = ParamArena(model)
+    opt = FlatAdam(arena, lr=1e-2)
+    step = TrainStep(model, opt, losses.CrossEntropy(), x, ei, ew, arena, use_graph=True, warmup_iters=2, preserve_state=True)
+    B = w.batch
+    for k in range(20):
+        b = k % 4
+        step(pos[b * B:(b + 1) * B], y[b * B:(b + 1) * B])
+    torch.cuda.synchronize()
+    assert step.graphed and step._split == bool(dist_mode)
+    return hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest()
+
+
+if __name__ == "__main__":
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    single = run(False)
+    td.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    split = run(True)
+    td.barrier(device_ids=[0])
+    td.destroy_process_group()
+    print("single", single, "split", split, "EQUAL" if single == split else "DIFFERENT")
