@@ -16,8 +16,8 @@
 
 namespace glass {
 
-constexpr int kTabCols = 64;                    // columns per workgroup
-constexpr int kTabSlots = kBlock / kTabCols;    // row slots per workgroup (4)
+constexpr int kTabCols = 16;                    // columns per workgroup (one per lane of a 16-lane group)
+constexpr int kTabSlots = kBlock / kTabCols;    // row slots per workgroup (16): V ~ 60 rows -> 4 sequential loads each
 
 // Sum the two fp64 accumulators of this thread's column over the row slots (fixed order); result valid in slot 0.
 __device__ __forceinline__ void slot_reduce(double& a, double& b, double* lds, int tc, int tr) {
