@@ -1,7 +1,7 @@
 """Flat parameter / gradient arena for a GLASS model.
 
 All parameters become views into ONE contiguous fp32 buffer and all gradients views into a second
-one (what DDP/FSDP call flattening).  That buys, on a path whose step is ~100 short kernels:
+one (what DDP/FSDP call flattening).  That buys, on a path whose step is a chain of short dependent kernels:
   * one fused Adam launch over the whole model (glass_amd.optim.FlatAdam),
   * one memset to zero the gradients, one all-reduce for data parallelism (dist.FlatGradBucket),
   * the two weight sets of a GLASSConv Linear pair laid out back to back ([W1; W0], [b1 | b0]), so
