@@ -6,8 +6,8 @@ form, ~0.38 ms of GPU time), so eager launches are host-bound; every kernel in l
 caller's stream (no allocation, no sync, no memset / memcpy nodes), which makes the whole step capturable:
 labels -> forward -> loss -> backward -> [all-reduce] -> Adam.  Dropout masks still change every replay
 because the dropout (seed, step) pair lives in device memory and is advanced by a captured kernel.
-With more than one rank the collective stays outside the graphs (forward/backward graph, eager
-all-reduce on the same stream, optimizer graph)."""
+With more than one rank the collective stays outside the graph (captured forward/backward, eager RCCL
+all-reduce of the flat gradient arena on the same stream, eager fused Adam launch)."""
 import torch
 
 from . import dist as gdist
