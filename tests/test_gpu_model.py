@@ -839,3 +839,16 @@ def test_split_step_with_rccl_allreduce_on_one_rank():
                          timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "EQUAL" in out.stdout, out.stdout[-500:]
+
+
+def test_step_program_randomised_configurations():
+    """tools/fuzz_step_program.py: 12 random configurations (hidden 64 / 128, 1-3 layers, all aggregations and fusable
+    pools, CE / BCE, uniform and power-law graphs with random edge weights, ragged subgraphs with repeated nodes) of the
+    step program against the fp64 oracle, rel-inf <= 1e-5 on logits, loss and the flat gradient."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_step_program.py"), "12", "2024"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]

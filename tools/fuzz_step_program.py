@@ -1,0 +1,64 @@
+"""Randomised parity fuzz of the benchmarked step program (stack.loss_and_grads) against the fp64 oracle: random hidden
+size (64 / 128), depth, aggregation, pooling, loss, graph (uniform / power-law, random per-direction edge weights), feature
+table, ragged subgraph matrices WITH repeated nodes.  usage (GPU box): python tools/fuzz_step_program.py [n_cases] [seed]"""
+import sys, os
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch, torch.nn as nn
+from helpers import rel_inf, flat_grads, build_glass
+from oracle import glass_oracle as O
+from glass_amd import synth, stack, losses
+from glass_amd.arena import ParamArena
+DEV = "cuda:0"
+N_CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+worst = 0.0
+for it in range(N_CASES):
+    H = int(rng.choice([64, 128]))
+    L = int(rng.integers(1, 4))
+    aggr = str(rng.choice(["mean", "sum", "gcn"]))
+    pool = str(rng.choice(["sum", "mean", "size"]))
+    multilabel = bool(rng.integers(0, 2))
+    K = int(rng.integers(1 if multilabel else 2, 9))
+    n = int(rng.integers(80, 3000))
+    n_pairs = int(rng.integers(n, 6 * n))
+    V = int(rng.integers(3, 40))  # two distinct feature rows make emb_gn ill-conditioned
+    B = int(rng.integers(1, 30))
+    S = int(rng.integers(1, 25))
+    zr = float(rng.uniform(0.5, 1.0))
+    torch.manual_seed(it)
+    model = build_glass(H, L, V - 1, K, aggr, pool, zr)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    ei, ew = synth.make_graph(n, min(n_pairs, n * (n - 1) // 4), it, float(rng.choice([0.0, 0.7])))
+    ew = rng.uniform(0.3, 2.0, ew.shape[0]).astype(np.float32) if rng.integers(0, 2) else ew
+    # symmetric weights are not required by the kernels; keep what make_graph gave or random per-direction weights
+    x = torch.from_numpy(rng.integers(0, V, n)).reshape(n, 1, 1)
+    pos = rng.integers(0, n, (B, S))
+    pos[rng.random((B, S)) < 0.25] = -1
+    pos[:, 0] = rng.integers(0, n, B)  # at least one node per subgraph
+    pos = torch.from_numpy(pos)
+    y = torch.from_numpy((rng.random((B, K)) < 0.4).astype(np.float32)) if multilabel else torch.from_numpy(rng.integers(0, K, B))
+    loss_fn = losses.BCEWithLogits() if multilabel else losses.CrossEntropy()
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    if not stack.step_supported(model, loss_fn):
+        print(it, "unsupported", H, L, pool); continue
+    tg = lambda t: t.to(DEV)
+    eit, ewt = torch.from_numpy(ei), torch.from_numpy(ew)
+    arena.flat.fill_(9.0)
+    loss, logits = stack.loss_and_grads(model, loss_fn, tg(x), tg(eit), tg(ewt), tg(pos), "pos", tg(y), overwrite=True)
+    orc = O.OracleGLASS(H, L, V - 1, K, aggr=aggr, pool=pool, z_ratio=zr)
+    orc.load_state_dict(sd)
+    orc = orc.double().train()
+    po = orc(x, eit, ewt.double(), pos, O.max_zero_one(x, pos))
+    lo = loss_fn(po, y.double() if multilabel else y)
+    lo.backward()
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    keys = sorted(mine)
+    e1, e2 = rel_inf(logits.cpu(), po.detach()), rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
+    e3 = abs(loss.item() - lo.item()) / max(abs(lo.item()), 1e-12)
+    worst = max(worst, e1, e2, e3)
+    flag = "" if max(e1, e2, e3) < 1e-5 else "  <-- FAIL"
+    print(f"{it:2d} H={H} L={L} {aggr:4s} {pool:4s} ml={int(multilabel)} K={K} n={n} nnz={ei.shape[1]} V={V} B={B} S={S}: logits {e1:.1e} grad {e2:.1e} loss {e3:.1e}{flag}")
+print("worst", worst)
+sys.exit(0 if worst < 1e-5 else 1)
