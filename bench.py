@@ -1,6 +1,11 @@
 """Headline benchmark: aggregated edges/sec of the GLASS labeled message-passing step.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+With --gpus N > 1 and no WORLD_SIZE in the environment, this process starts N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, before anything here
+touches a GPU), forwards rank 0's JSON line and exits with the children's return code.  Launched by
+torch.distributed.run directly (RANK / LOCAL_RANK / WORLD_SIZE set) it is one rank of that job.
 
 A step = MaxZOZ + GLASS.forward + loss + backward + (gradient all-reduce) + Adam.step on one batch
 of subgraphs per rank, over the WHOLE graph (the reference propagates over the full graph every
@@ -8,18 +13,27 @@ step, /root/reference/impl/train.py:10-16).  metric = nnz * L * steps * world / 
 (SURVEY.md §8d), inputs resident in HBM before the timed region.  At N=1 the workload is BASELINE
 config[1]: the ppi_bp-shaped synthetic graph, hidden=64 (config/ppi_bp.yml hyper-parameters incl.
 dropout 0.5).  Multi-GPU = subgraph-batch data parallelism: replicated graph, per-rank batch fixed
-("weak"), one flat-bucket RCCL all-reduce per step.
+("weak"), gradient all-reduce per step (--features nodeid: bucketed, see glass_amd/dist.py).
 
 The JSON line also carries
-  roofline     : the CSR aggregation kernel (K1) — algorithmic bytes nnz*(4H+8)+N*(4H+4) per launch
-                 divided by its average duration, measured with HIP events on the launch stream in a
-                 second, instrumented pass of the same step loop — against the 8 TB/s HBM peak.
-  cpu_baseline : the oracle (CPU restatement of the reference path, torch ops on host cores) timed
-                 on a bounded sample of the same workload on rank 0 at N=1.
+  roofline       : the CSR aggregation kernel (K1) inside the step — algorithmic bytes
+                   nnz*(4H+8)+N*(4H+4) per launch / its average duration.  Durations come from HIP events
+                   recorded on the launch stream around every K1 launch of an instrumented pass, minus the
+                   bracket's own cost, which is CALIBRATED in the same process on the same kernel and shape
+                   (bracketed average - back-to-back average of a 50-launch hipGraph).  The bound is the
+                   level X is served from: "l2" (34.5 TB/s aggregate) while X <= 32 MiB, "hbm" (8 TB/s) beyond.
+  roofline_hbm   : K1 alone, same process, on shapes whose X cannot be cache-resident (N = 4 M permutation
+                   = no reuse at all; N = 2 M uniform, mean degree 6), hidden 64, against the 8 TB/s HBM peak.
+  step_breakdown : device time per C-ABI entry point per step (same bracket method), and the MFMA
+                   fraction of the largest one when it is a dense kernel.
+  cpu_baseline   : the oracle (CPU restatement of the reference path, torch ops on host cores) timed
+                   on a bounded sample of the same workload on rank 0 at N=1.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,18 +43,46 @@ import torch.nn as nn
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md §L2: aggregate of the 8 XCD L2s
+HBM_PEAK_GBPS = 8000.0   # spec (6.29 TB/s measured achievable copy)
+MFMA_F32_TFLOPS = 157.3  # dense fp32 matrix-core peak
+L2_TOTAL_BYTES = 32 << 20
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="ppi_bp", help="ppi_bp | hpo_neuro | em_user | powerlaw | tiny")
+    ap.add_argument("--features", default="deg", choices=["deg", "nodeid"],
+                    help="deg: use_deg-style small table (default); nodeid: V = N embedding table (dense [N,H] "
+                         "gradient -> the bucketed collective matters)")
     ap.add_argument("--dropout", type=float, default=None, help="override the workload's YAML dropout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline-hbm", action="store_true", help="skip the stand-alone HBM-bound K1 measurements")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline steps (0 = size to ~15 s)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a captured hipGraph when possible")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / process-group plumbing only (no GPU work; value is null) — CPU-box smoke")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(args):
+    """--gpus N without a torchrun environment: start the N ranks as a child job.  Nothing in this process has
+    touched the GPU yet (no torch.cuda call, libglass_hip not loaded); the child processes are fresh interpreters."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
 
 
 def loss_fn_for(w):
@@ -84,11 +126,150 @@ def cpu_baseline(w, ei, ew, x, pos, y, steps):
             "ms_per_step": dt / steps * 1e3}
 
 
+# ---- device-time instrumentation -----------------------------------------------------------------------------
+class _BracketLib:
+    """Stand-in for the ctypes library during an instrumented pass: every C-ABI call that takes a stream is bracketed
+    by two HIP events recorded on the launch stream (torch's current stream is the stream every launch here uses)."""
+    def __init__(self, lib, sink):
+        self._lib, self._sink = lib, sink
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.endswith("_f32") and name not in ("glass_maxzoz_i64", "glass_copy_pair", "glass_rng_advance"):
+            return fn
+        sink = self._sink
+
+        def call(*a):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*a)
+            e1.record()
+            sink.append((name, e0, e1, a))
+            return rc
+        return call
+
+
+def _k1_alg_bytes(nnz, n_rows, H):
+    return nnz * (4 * H + 8) + n_rows * (4 * H + 4)
+
+
+def k1_back_to_back(op, H, launches=50, replays=5):
+    """Average duration of one K1 launch when `launches` of them run back to back from a hipGraph (no host gaps,
+    no event between launches): what rocprofv3's kernel trace reports per dispatch, up to the launch boundary."""
+    dev = op.rowptr.device
+    x = torch.randn(op.n_cols, H, device=dev)
+    y = torch.empty(op.n_rows, H, device=dev)
+    for _ in range(3):
+        op.spmm(x, out=y)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            for _ in range(launches):
+                op.spmm(x, out=y)
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / (launches * replays), (x, y)
+
+
+def k1_bracketed(op, x, y, launches=50):
+    """The same launch measured the way the in-step launches are: one event pair around each, the stream kept fed
+    (each batch queued behind a GPU-side spin so that the host runs ahead)."""
+    evs = []
+    torch.cuda._sleep(int(3e-3 * 2.4e9))
+    for _ in range(launches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        op.spmm(x, out=y)
+        e1.record()
+        evs.append((e0, e1))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2] * 1e-3
+
+
+def roofline_hbm_entries(dev):
+    """K1 alone on shapes where X (and Y) cannot be cache-resident: the regime the >= 0.60 target is about."""
+    import numpy as np
+    from glass_amd import graph as ggraph, synth
+    out = []
+    H = 64
+    # (a) permutation matrix, N = 4 M: every X row read exactly once, no reuse anywhere (X = Y = 1.02 GB)
+    n = 4_000_000
+    rng = np.random.Generator(np.random.PCG64(7))
+    col = torch.from_numpy(rng.permutation(n).astype(np.int32)).to(dev)
+    rowptr = torch.arange(n + 1, dtype=torch.int32, device=dev)
+    op = ggraph.CSROperand(rowptr, col, torch.ones(n, device=dev), n, n)
+    t, keep = k1_back_to_back(op, H, launches=10, replays=3)
+    b = _k1_alg_bytes(n, n, H)
+    out.append({"shape": "permutation N=4000000 (degree 1, no reuse)", "H": H, "bound": "hbm", "avg_launch_us": t * 1e6,
+                "alg_bytes_per_launch": b, "achieved": b / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": b / t / 1e9 / HBM_PEAK_GBPS})
+    del op, keep, col, rowptr
+    # (b) uniform random graph, N = 2 M, 6 M undirected pairs (mean degree 6): X = 512 MB > Infinity Cache
+    n, pairs = 2_000_000, 6_000_000
+    rng = np.random.Generator(np.random.PCG64(11))
+    u, v = rng.integers(0, n, pairs), rng.integers(0, n, pairs)   # duplicates / self-loops are harmless for a timing shape
+    row = torch.from_numpy(np.concatenate([u, v])).to(dev)
+    colt = torch.from_numpy(np.concatenate([v, u])).to(dev)
+    order = torch.argsort(row * n + colt)
+    row, colt = row[order], colt[order]
+    rowptr = ggraph._csr_from_sorted(row, n)
+    op = ggraph.CSROperand(rowptr, colt.to(torch.int32).contiguous(),
+                           torch.full((2 * pairs, ), 1.0 / 6.0, device=dev), n, n)
+    t, keep = k1_back_to_back(op, H, launches=10, replays=3)
+    b = _k1_alg_bytes(2 * pairs, n, H)
+    out.append({"shape": "uniform N=2000000 nnz=12000000 (mean degree 6)", "H": H, "bound": "hbm", "avg_launch_us": t * 1e6,
+                "alg_bytes_per_launch": b, "achieved": b / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": b / t / 1e9 / HBM_PEAK_GBPS})
+    del op, keep
+    torch.cuda.empty_cache()
+    return out
+
+
+def dry_run(args, world, rank):
+    """Process-group plumbing without a GPU (gloo): the same barrier / max-over-ranks / rank-0-prints protocol."""
+    import torch.distributed as td
+    if world > 1:
+        td.init_process_group("gloo")
+    if world > 1:
+        td.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        pass
+    if world > 1:
+        td.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        td.all_reduce(dt, op=td.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "aggregated edges/sec (GLASSConv fwd+bwd)", "value": None, "unit": "edges/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                          "data": "synthetic", "dry_run": True,
+                          "config": {"workload": args.workload, "parallelism": f"subgraph-batch dp{world}"}}), flush=True)
+    if world > 1:
+        td.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
     n_dev = torch.cuda.device_count()
@@ -104,14 +285,16 @@ def main():
         else:
             td.init_process_group(backend)
 
-    from glass_amd import synth, ops, graph as ggraph, dist as gdist
-    from impl import utils
+    from glass_amd import synth, ops, graph as ggraph, _lib
     from glass_amd.factory import build_glass
 
     n_batches = 16
     w, ei_np, ew_np, x_np, pos_np, y_np = synth.make_workload(args.workload, seed=0, n_batches=n_batches * world)
     if args.dropout is not None:
         w.dropout = args.dropout
+    if args.features == "nodeid":
+        import numpy as np
+        x_np = np.arange(w.n_node, dtype=np.int64).reshape(-1, 1, 1)  # use_nodeid: identity gather, V = N
     ei, ew, x, pos, y = (torch.from_numpy(a) for a in (ei_np, ew_np, x_np, pos_np, y_np))
     nnz, N, H, L = ei.shape[1], w.n_node, w.hidden, w.layers
 
@@ -120,7 +303,7 @@ def main():
     model.train()
     from glass_amd.arena import ParamArena
     from glass_amd.optim import FlatAdam
-    bucket = ParamArena(model)  # flat params + grads: stacked weight views, fused Adam, one all-reduce
+    bucket = ParamArena(model)  # flat params + grads: stacked weight views, fused Adam, bucketed all-reduce
     opt = FlatAdam(bucket, lr=w.lr)
     loss_fn = loss_fn_for(w)
     xg, eig, ewg = x.to(dev), ei.to(dev), ew.to(dev)
@@ -155,15 +338,19 @@ def main():
         td.all_reduce(t, op=td.ReduceOp.MAX)
         dt = t.item()
     last_loss = stepper.last_loss()
+    collective = stepper.collective_share() if hasattr(stepper, "collective_share") else None
 
-    # ---- roofline of the dominant kernel (K1), measured in the same step loop with HIP events ----
-    # A second, instrumented pass of the same steps: every K1 launch is bracketed by HIP events recorded
-    # on the launch stream (graph.K1_EVENT_HOOK).  The pass is eager (events cannot sit inside the replayed
-    # graph), and an eager step is host-bound here (~2.5 ms of launches for ~0.6 ms of GPU work), which would
-    # count host starvation between the two records as kernel time; so each step is queued behind a GPU-side
-    # spin long enough for the host to run ahead — the commands then execute back to back, as in the graph.
-    k1_steps = min(args.steps, 50)
-    events = []
+    # ---- device time per C-ABI call inside the step, K1 roofline (rank 0 reports; every rank runs the same code) ----
+    # A second, instrumented pass of the same steps, eager (events cannot sit inside the replayed graph).  An eager
+    # step is host-bound here, which would count host starvation between two records as kernel time, so each step
+    # is queued behind a GPU-side spin long enough for the host to run ahead.
+    adj = model.conv.convs[0].adj.fwd
+    t_b2b, (kx, ky) = k1_back_to_back(adj, H)
+    t_brk = k1_bracketed(adj, kx, ky)
+    bracket_cost = max(t_brk - t_b2b, 0.0)  # what one event pair adds to the reading of this kernel on this box
+    del kx, ky
+    k1_steps = min(args.steps, 50 if N < 200000 else 10)
+    calls = []
     eager = TrainStep(model, opt, loss_fn, xg, eig, ewg, bucket, use_graph=False)
     eager(pos_g[0], y_g[0])
     torch.cuda.synchronize()
@@ -171,30 +358,41 @@ def main():
     eager(pos_g[0], y_g[0])  # host time of one eager step (no sync inside)
     t_host = time.perf_counter() - t_host
     torch.cuda.synchronize()
-    spin_cycles = int(max(t_host * 1.5, 2e-3) * 2.4e9)
-    ggraph.K1_EVENT_HOOK = events
-    null_pairs = []  # two back-to-back records with nothing between them: the bracket's own cost
-    for i in range(k1_steps):
-        torch.cuda._sleep(spin_cycles)
-        eager(pos_g[i % n_batches], y_g[i % n_batches])
-        n0, n1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n0.record()
-        n1.record()
-        null_pairs.append((n0, n1))
-        torch.cuda.synchronize()
-    ggraph.K1_EVENT_HOOK = None
-    torch.cuda.synchronize()
-    bracket_ms = sorted(a.elapsed_time(b) for a, b in null_pairs)[len(null_pairs) // 2]
-    # adjacency launches only (the embedding backward also runs on K1, with its own tiny matrix)
-    k1_ms = [a.elapsed_time(b) for a, b, _nr, nz, _h in events if nz == nnz]
-    k1_raw = sum(k1_ms) / len(k1_ms) * 1e-3
-    k1_avg = max(k1_raw - bracket_ms * 1e-3, 1e-7)  # launch duration = bracket reading - empty-bracket reading
-    alg_bytes = nnz * (4 * H + 8) + N * (4 * H + 4)
-    roofline = {"bound": "hbm", "achieved": alg_bytes / k1_avg / 1e9, "peak": 8000.0, "unit": "GB/s",
-                "frac": alg_bytes / k1_avg / 8e12, "traffic": None, "kernel": "glass_spmm_csr_f32 (spmm_sweep_kernel)",
-                "alg_bytes_per_launch": alg_bytes, "avg_launch_us": k1_avg * 1e6, "launches_timed": len(k1_ms),
-                "event_bracket_raw_us": k1_raw * 1e6, "empty_bracket_us": bracket_ms * 1e3}
-    prof = os.path.join(ROOT, "profiles", "r01_k1_traffic.json")
+    spin_cycles = int(max(t_host * 2.0, 2e-3) * 2.4e9)
+    real_lib = _lib.load()
+    _lib._lib = _BracketLib(real_lib, calls)
+    try:
+        for i in range(k1_steps):
+            torch.cuda._sleep(spin_cycles)
+            eager(pos_g[i % n_batches], y_g[i % n_batches])
+            torch.cuda.synchronize()
+    finally:
+        _lib._lib = real_lib
+    per_call = {}
+    k1_us = []
+    for name, e0, e1, a in calls:
+        t_us = max(e0.elapsed_time(e1) * 1e3 - bracket_cost * 1e6, 0.0)
+        per_call.setdefault(name, []).append(t_us)
+        if name == "glass_spmm_csr_f32" and a[7] == N and a[8] == H:  # adjacency launches (n_rows, H), not the selection product
+            k1_us.append(t_us)
+    k1_avg = sum(k1_us) / len(k1_us) * 1e-6
+    alg_bytes = _k1_alg_bytes(nnz, N, H)
+    x_bytes = N * H * 4
+    cache_resident = x_bytes <= L2_TOTAL_BYTES
+    peak = L2_PEAK_GBPS if cache_resident else HBM_PEAK_GBPS
+    roofline = {"bound": "l2" if cache_resident else "hbm", "achieved": alg_bytes / k1_avg / 1e9, "peak": peak,
+                "unit": "GB/s", "frac": alg_bytes / k1_avg / 1e9 / peak, "traffic": None,
+                "kernel": "glass_spmm_csr_f32 (spmm_sweep_kernel) inside the training step",
+                "regime": (f"X = {x_bytes / 2**20:.1f} MiB <= 32 MiB of L2: gathers are served by the XCD L2s / Infinity "
+                           "Cache, so the bound is the aggregate L2 rate (34.5 TB/s)") if cache_resident else
+                          f"X = {x_bytes / 2**20:.0f} MiB: gathers go to HBM (8 TB/s spec)",
+                "frac_of_hbm_peak": alg_bytes / k1_avg / 1e9 / HBM_PEAK_GBPS,
+                "alg_bytes_per_launch": alg_bytes, "avg_launch_us": k1_avg * 1e6, "launches_timed": len(k1_us),
+                "back_to_back_us": t_b2b * 1e6, "bracketed_standalone_us": t_brk * 1e6,
+                "bracket_cost_us": bracket_cost * 1e6,
+                "timing": "HIP events on the launch stream around each in-step launch, minus the bracket cost calibrated "
+                          "on the same kernel/shape (bracketed - back-to-back hipGraph average)"}
+    prof = os.path.join(ROOT, "profiles", "r02_k1_traffic.json")
     if os.path.exists(prof):
         try:
             with open(prof) as f:
@@ -202,10 +400,34 @@ def main():
         except Exception:
             pass
     if roofline["traffic"]:
-        # frac above counts ALGORITHMIC bytes (X is L2 / Infinity-Cache resident on the small BASELINE graphs, so it can
-        # exceed 1); this is the same launch priced with the L2-miss traffic the PMC counters saw
-        roofline["traffic_frac"] = roofline["traffic"] / k1_avg / 8e12
-        roofline["traffic_source"] = "profiles/r01_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        roofline["traffic_source"] = "profiles/r02_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+
+    n_prof = max(k1_steps, 1)
+    breakdown = sorted(((name, sum(v) / n_prof, len(v) / n_prof) for name, v in per_call.items()), key=lambda r: -r[1])
+    step_breakdown = {"unit": "us per step (device time, calibrated event brackets, eager instrumented pass)",
+                      "calls": {name: {"us": round(us, 2), "launch_groups": round(cnt, 2)} for name, us, cnt in breakdown},
+                      "total_us": round(sum(us for _, us, _ in breakdown), 1)}
+    dense_flops = {"glass_dual_linear_fwd_f32": 2.0 * N * (3 * H) * (2 * H) * L,       # trans K=H + comb K=2H, 2H outputs
+                   "glass_dual_linear_dgrad_f32": 2.0 * N * (2 * H) * (3 * H) * L,     # comb -> 2H, trans -> H outputs
+                   "glass_dual_linear_wgrad_f32": 2.0 * N * (2 * H) * (3 * H) * L}
+    top = breakdown[0]
+    dominant = {"kernel": top[0], "us_per_step": round(top[1], 2), "share_of_step": round(top[1] / step_breakdown["total_us"], 3)}
+    if top[0] in dense_flops:
+        tf = dense_flops[top[0]] / (top[1] * 1e-6) / 1e12
+        dominant.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_TFLOPS})
+    elif top[0] == "glass_spmm_csr_f32":
+        dominant.update({"bound": roofline["bound"], "frac": roofline["frac"]})
+    step_breakdown["dominant"] = dominant
+    dense_us = sum(us for name, us, _ in breakdown if name in dense_flops)
+    if dense_us > 0:
+        tf = sum(dense_flops.values()) / (dense_us * 1e-6) / 1e12
+        step_breakdown["dense_mfma"] = {"us_per_step": round(dense_us, 1), "achieved": tf, "peak": MFMA_F32_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": tf / MFMA_F32_TFLOPS}
+
+    hbm = None
+    if rank == 0 and world == 1 and not args.no_roofline_hbm:
+        del eager
+        hbm = roofline_hbm_entries(dev)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -219,12 +441,15 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{w.name}-shaped synthetic graph (BASELINE config[1] family): N={N}, nnz={nnz}, "
                                    f"hidden={H}, layers={L}, aggr={w.aggr}, pool={w.pool}, z_ratio={w.z_ratio}, "
-                                   f"dropout={w.dropout}, batch={w.batch}x{w.sub_size} per rank, use_deg features, Adam",
-                       "parallelism": f"subgraph-batch dp{world}, replicated graph, one flat all-reduce/step",
+                                   f"dropout={w.dropout}, batch={w.batch}x{w.sub_size} per rank, "
+                                   f"{'use_nodeid (V=N)' if args.features == 'nodeid' else 'use_deg'} features, Adam",
+                       "parallelism": f"subgraph-batch dp{world}, replicated graph, bucketed gradient all-reduce per step",
                        "step": "MaxZOZ+fwd+loss+bwd+allreduce+Adam", "hip_graph": bool(stepper.graphed),
                        "final_loss": last_loss},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_hbm": hbm, "step_breakdown": step_breakdown, "cpu_baseline": cpu,
         }
+        if collective is not None:
+            out["collective"] = collective
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as td

@@ -17,8 +17,19 @@
 namespace glass {
 
 constexpr int32_t kPlanMagic = 0x474C5350;  // 'GLSP'
-constexpr int32_t kPlanVersion = 1;
-constexpr int64_t kRowParallelWideWaves = 8192;
+constexpr int32_t kPlanVersion = 2;
+
+// Cache policy of the once-read streams (rowptr / col / val in, Y out): GLASS_K1_NT=1 marks them non-temporal so that
+// they do not displace X rows, the only data of this kernel that is re-read, from the XCD's L2.
+#ifndef GLASS_K1_NT
+#define GLASS_K1_NT 1
+#endif
+#if GLASS_K1_NT
+#define K1_LOAD_IDX(p) __builtin_nontemporal_load(p)
+#else
+#define K1_LOAD_IDX(p) (*(p))
+#endif
+typedef float k1_f32x4 __attribute__((ext_vector_type(4)));
 // header word indices
 enum { H_MAGIC, H_VER, H_NROWS, H_NNZ, H_NSWEEP, H_NLONG, H_NREDUCE, H_NSLOTS, H_LONG_THR, H_LONG_CHUNK,
        H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RP_FACTOR, H_RSV1, H_RSV2 };
@@ -30,6 +41,13 @@ template <> struct Vec<4> {
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    __device__ __forceinline__ void store_out(float* p) const {  // a row of Y: written once, not read by this kernel
+#if GLASS_K1_NT
+        __builtin_nontemporal_store((k1_f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<k1_f32x4*>(p));
+#else
+        store(p);
+#endif
+    }
     __device__ __forceinline__ void fma(float a, const Vec& x) {
         v.x = fmaf(a, x.v.x, v.x); v.y = fmaf(a, x.v.y, v.y); v.z = fmaf(a, x.v.z, v.z); v.w = fmaf(a, x.v.w, v.w);
     }
@@ -43,6 +61,13 @@ template <> struct Vec<1> {
     __device__ __forceinline__ void zero() { v = 0.f; }
     __device__ __forceinline__ void load(const float* p) { v = *p; }
     __device__ __forceinline__ void store(float* p) const { *p = v; }
+    __device__ __forceinline__ void store_out(float* p) const {
+#if GLASS_K1_NT
+        __builtin_nontemporal_store(v, p);
+#else
+        store(p);
+#endif
+    }
     __device__ __forceinline__ void fma(float a, const Vec& x) { v = fmaf(a, x.v, v); }
     __device__ __forceinline__ void add(const Vec& x) { v += x.v; }
     __device__ __forceinline__ void xor_add(int s) { v += __shfl_xor(v, s); }
@@ -60,8 +85,8 @@ __device__ __forceinline__ void gather_edges(Vec<VW>& acc, const int32_t* __rest
         int my_c = 0;
         float my_v = 0.f;
         if (lane < cnt) {
-            my_c = col[eb + lane];
-            my_v = val[eb + lane];
+            my_c = K1_LOAD_IDX(col + eb + lane);
+            my_v = K1_LOAD_IDX(val + eb + lane);
         }
         for (int j = 0; j < cnt; j += U * G) {
             Vec<VW> x[U];
@@ -88,93 +113,139 @@ __device__ __forceinline__ void reduce_groups(Vec<VW>& acc) {
     for (int s = LPR; s < kWave; s <<= 1) acc.xor_add(s);
 }
 
-// ---- sweep kernel: one wave per contiguous, edge-balanced row range --------------------------
+// ---- sweep kernel: one wave per plan item (r0, r1, e0, e1): <= 64 consecutive short rows holding <= 256 edges ----
+// The item carries its edge range, so the index loads (row pointers, col, val) depend on ONE scalar load of the plan
+// and not on a chain plan -> rowptr -> col: plan -> {rowptr chunk, col/val} -> X rows -> store.
+//
+// Two modes, chosen per wave from the item alone (wave-uniform, a pure function of the plan and H, so results are
+// bitwise repeatable):
+//  * row mode (mean degree > rp_factor * G): one row at a time, its edges split over the G lane groups, partial sums
+//    combined with __shfl_xor;
+//  * flat mode (short rows): the item's col/val/rowptr are staged once in LDS with coalesced loads; each lane group
+//    owns an edge-balanced run of whole rows and walks ITS edges as one flat stream, U gathers in flight whatever
+//    the row lengths (a row boundary only flushes the accumulator), rows summed in plain edge order, no cross-group
+//    reduction.  On a degree-1 pattern that is U*G independent 4H-byte gathers in flight per wave behind a single
+//    index round trip (the previous form had 2 per group behind three dependent round trips: 0.55 of the HBM roofline).
+constexpr int kItemRows = 64;    // rows per sweep item (one coalesced rowptr load per wave)
+constexpr int kItemEdges = 256;  // edges per sweep item (LDS staging: 2 KiB of (col,val) per wave)
+
 template <int VW, int LPR, int U>
 __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
                                                             const float* __restrict__ X, int64_t ldx,
                                                             float* __restrict__ Y, int64_t ldy, int H,
-                                                            const int32_t* __restrict__ wave_rows, int n_waves,
-                                                            int long_thr, int rp_factor) {
+                                                            const int32_t* __restrict__ items, int n_waves,
+                                                            int rp_factor) {
+    constexpr int G = kWave / LPR;
+    constexpr int kWaves = kBlock / kWave;
+    __shared__ int32_t s_rp[G > 1 ? kWaves : 1][kItemRows + 1];
+    __shared__ int32_t s_col[G > 1 ? kWaves : 1][kItemEdges];
+    __shared__ float s_val[G > 1 ? kWaves : 1][kItemEdges];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * kWaves + w;
     if (wave >= n_waves) return;
     const int grp = lane / LPR, sub = lane % LPR;
     const int coff = (blockIdx.y * LPR + sub) * VW;
     const bool col_ok = coff < H;
     const float* Xc = X + coff;
-    const int r0 = __builtin_amdgcn_readfirstlane(wave_rows[wave]);
-    const int r1 = __builtin_amdgcn_readfirstlane(wave_rows[wave + 1]);
-    int e0 = __builtin_amdgcn_readfirstlane(rowptr[r0]);
-    constexpr int G = kWave / LPR;
-    if (G > 1) {
-        // Row-parallel mode for very short rows (mean degree of this wave's range <= rp_factor * G, plan header): splitting one row's
-        // edges over the G lane groups leaves most groups idle and exposes one gather latency per ROW (0.23 of
-        // the HBM roofline on a degree-1 pattern).  Here every lane group takes its OWN row, G rows per step:
-        // G x more bytes in flight per wave and no cross-group reduction.  The mode is a pure function of the plan
-        // and H (wave-uniform test below), so results stay bitwise repeatable; a row is summed in plain edge order.
-        const int e_last = __builtin_amdgcn_readfirstlane(rowptr[r1]);
-        if (e_last - e0 <= rp_factor * G * (r1 - r0)) {
-            constexpr int NB = 2;  // row batches in flight: two independent rowptr -> (col,val) -> X chains
-            for (int rb = r0; rb < r1; rb += NB * G) {
-                int re0[NB], deg[NB];
-                bool store_ok[NB];
+    const int4 it = reinterpret_cast<const int4*>(items)[wave];
+    const int r0 = __builtin_amdgcn_readfirstlane(it.x), r1 = __builtin_amdgcn_readfirstlane(it.y);
+    const int e0 = __builtin_amdgcn_readfirstlane(it.z), e1 = __builtin_amdgcn_readfirstlane(it.w);
+    const int nrows = r1 - r0, ne = e1 - e0;
+    // start edge of row r0 + lane (lanes past the item hold e1, so "end of row i" is always lane i + 1's value or e1)
+    const int rp_reg = (lane < nrows) ? K1_LOAD_IDX(rowptr + r0 + lane) : e1;
+    if (G > 1 && ne <= rp_factor * G * nrows) {
+        // ---- flat mode ----
+        int32_t* rp_s = s_rp[G > 1 ? w : 0];
+        int32_t* col_s = s_col[G > 1 ? w : 0];
+        float* val_s = s_val[G > 1 ? w : 0];
+        int cr[kItemEdges / kWave];
+        float vr[kItemEdges / kWave];
 #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const int r = rb + b * G + grp;
-                    const bool valid = r < r1;
-                    re0[b] = valid ? rowptr[r] : 0;
-                    deg[b] = valid ? rowptr[r + 1] - re0[b] : 0;
-                    const bool is_long = deg[b] >= long_thr;  // left to the long-row kernel
-                    if (is_long) deg[b] = 0;
-                    store_ok[b] = valid && !is_long && col_ok;
-                }
-                Vec<VW> acc[NB];
-#pragma unroll
-                for (int b = 0; b < NB; ++b) acc[b].zero();
-                for (int k = 0; __any(k < deg[0] || k < deg[1]); k += U / NB) {
-                    constexpr int UU = U / NB;  // gathers per batch per step (U in flight per lane group overall)
-                    int c[NB][UU];
-                    float v[NB][UU];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-#pragma unroll
-                        for (int u = 0; u < UU; ++u) {
-                            const bool ok = k + u < deg[b];
-                            c[b][u] = ok ? col[re0[b] + k + u] : 0;
-                            v[b][u] = ok ? val[re0[b] + k + u] : 0.f;
-                        }
-                    Vec<VW> x[NB][UU];
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-#pragma unroll
-                        for (int u = 0; u < UU; ++u) {
-                            x[b][u].zero();
-                            if (col_ok && k + u < deg[b]) x[b][u].load(Xc + (int64_t)c[b][u] * ldx);
-                        }
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-#pragma unroll
-                        for (int u = 0; u < UU; ++u) acc[b].fma(v[b][u], x[b][u]);
-                }
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    if (store_ok[b]) acc[b].store(Y + (int64_t)(rb + b * G + grp) * ldy + coff);
+        for (int k = 0; k < kItemEdges / kWave; ++k) {
+            const int idx = k * kWave + lane;
+            cr[k] = 0;
+            vr[k] = 0.f;
+            if (idx < ne) {
+                cr[k] = K1_LOAD_IDX(col + e0 + idx);
+                vr[k] = K1_LOAD_IDX(val + e0 + idx);
             }
-            return;
         }
-    }
-    for (int r = r0; r < r1; ++r) {
-        const int e1 = __builtin_amdgcn_readfirstlane(rowptr[r + 1]);
-        if (e1 - e0 < long_thr) {
-            Vec<VW> acc;
+        rp_s[lane] = rp_reg - e0;
+        if (lane == 0) rp_s[kItemRows] = ne;
+#pragma unroll
+        for (int k = 0; k < kItemEdges / kWave; ++k) {
+            col_s[k * kWave + lane] = cr[k];
+            val_s[k * kWave + lane] = vr[k];
+        }
+        // this lane group's rows [rbeg, rend): edge-balanced cut points (row granularity) when G is small, equal row
+        // counts otherwise
+        int rbeg, rend;
+        if (G <= 8) {
+            rbeg = 0;
+            rend = nrows;
+#pragma unroll
+            for (int g = 1; g < G; ++g) {
+                const int tgt = e0 + (int)(((int64_t)ne * g) / G);
+                const int cnt = __popcll(__ballot(lane < nrows && rp_reg < tgt));
+                if (grp == g) rbeg = cnt;
+                if (grp == g - 1) rend = cnt;
+            }
+        } else {
+            const int per = (nrows + G - 1) / G;
+            rbeg = min(grp * per, nrows);
+            rend = min(rbeg + per, nrows);
+        }
+        // (the LDS image was written by this wave only; ds operations of one wave complete in order)
+        int r = rbeg;
+        int e = rbeg < nrows ? rp_s[rbeg] : ne;
+        const int ge = rend < nrows ? rp_s[rend] : ne;
+        int row_end = rp_s[r + 1];  // entries past the item's rows hold ne
+        Vec<VW> acc;
+        acc.zero();
+        while (e < ge) {
+            Vec<VW> x[U];
+            float v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool ok = e + u < ge;
+                const int c = ok ? col_s[e + u] : 0;
+                v[u] = ok ? val_s[e + u] : 0.f;
+                x[u].zero();
+                if (ok && col_ok) x[u].load(Xc + (int64_t)c * ldx);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (e + u < ge) {
+                    while (e + u >= row_end) {  // row r is complete (possibly empty): flush
+                        if (col_ok) acc.store_out(Y + (int64_t)(r0 + r) * ldy + coff);
+                        acc.zero();
+                        ++r;
+                        row_end = rp_s[r + 1];
+                    }
+                    acc.fma(v[u], x[u]);
+                }
+            }
+            e += U;
+        }
+        for (; r < rend; ++r) {  // the row in progress, then trailing empty rows
+            if (col_ok) acc.store_out(Y + (int64_t)(r0 + r) * ldy + coff);
             acc.zero();
-            gather_edges<VW, LPR, U>(acc, col, val, Xc, ldx, e0, e1, lane, grp, col_ok);
-            reduce_groups<VW, LPR>(acc);
-            if (grp == 0 && col_ok) acc.store(Y + (int64_t)r * ldy + coff);
         }
-        e0 = e1;
+        return;
+    }
+    // ---- row mode ----
+    int es = e0;
+    for (int i = 0; i < nrows; ++i) {
+        const int ee = (i + 1 < nrows) ? __builtin_amdgcn_readlane(rp_reg, i + 1) : e1;
+        Vec<VW> acc;
+        acc.zero();
+        gather_edges<VW, LPR, U>(acc, col, val, Xc, ldx, es, ee, lane, grp, col_ok);
+        reduce_groups<VW, LPR>(acc);
+        if (grp == 0 && col_ok) acc.store_out(Y + (int64_t)(r0 + i) * ldy + coff);
+        es = ee;
     }
 }
 
@@ -236,8 +307,7 @@ static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float*
     if (n_waves > 0) {
         dim3 grid((unsigned)ceil_div(n_waves, kBlock / kWave), n_ctiles);
         hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx, Y,
-                           ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_LONG_THR],
-                           hdr[H_RP_FACTOR] > 0 ? hdr[H_RP_FACTOR] : 1);
+                           ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_RP_FACTOR]);
     }
     if (hdr[H_NLONG] > 0) {
         dim3 grid((unsigned)hdr[H_NLONG], n_ctiles);
@@ -276,6 +346,7 @@ static constexpr int kLongThrMax = 256;
 static constexpr int kLongChunkMax = 2048;
 static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
 static constexpr int kTargetWaves = 32768;  // ~4 rounds of 256 CUs x 32 waves
+static constexpr int kFlatFactor = 2;       // see spmm_sweep_kernel: flat mode up to a mean degree of 2 G
 
 extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int32_t* plan, int64_t* plan_words) {
     GLASS_REQUIRE(rowptr && plan_words && n_rows >= 0 && n_rows < (1ll << 31), "plan_build: bad arguments");
@@ -304,18 +375,34 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     int64_t budget = cost_total / kTargetWaves;
     if (budget < 32) budget = 32;
     if (budget > 1024) budget = 1024;
-    int64_t acc = 0;
+    // Sweep items (r0, r1, e0, e1): maximal runs of consecutive SHORT rows under three caps — the cost budget (balance),
+    // kItemRows rows and kItemEdges edges (what the kernel stages per wave).  Long rows belong to the workgroup kernel
+    // and end the current item, so an item never contains one.
+    int64_t acc = 0, it_r0 = 0, it_edges = 0;
     int32_t n_slots = 0;
-    sweep.push_back(0);
+    bool open = false;
+    auto close_item = [&](int64_t r_end) {
+        if (!open) return;
+        sweep.push_back((int32_t)it_r0);
+        sweep.push_back((int32_t)r_end);
+        sweep.push_back(rowptr[it_r0]);
+        sweep.push_back(rowptr[r_end]);
+        open = false;
+    };
     for (int64_t r = 0; r < n_rows; ++r) {
         const int64_t d = (int64_t)rowptr[r + 1] - rowptr[r];
-        const int64_t c = kRowCost + (d < kLongThr ? d : 0);
-        if (!all_long && acc > 0 && acc + c > budget) {
-            sweep.push_back((int32_t)r);
-            acc = 0;
-        }
-        acc += c;
-        if (d >= kLongThr) {
+        if (d < kLongThr) {
+            const int64_t c = kRowCost + d;
+            if (open && (acc + c > budget || r - it_r0 >= kItemRows || it_edges + d > kItemEdges)) close_item(r);
+            if (!open) {
+                open = true;
+                it_r0 = r;
+                acc = it_edges = 0;
+            }
+            acc += c;
+            it_edges += d;
+        } else {
+            close_item(r);
             const int64_t n_chunks = d > 0 ? ceil_div(d, kLongChunk) : 1;
             const int64_t per = ceil_div(ceil_div(d, n_chunks), kWave) * kWave;  // even chunks, whole batches
             if (n_chunks > 1) {
@@ -333,8 +420,8 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
             }
         }
     }
-    if (n_rows > 0) sweep.push_back((int32_t)n_rows);
-    const int64_t n_sweep = (n_rows > 0 && !all_long) ? (int64_t)sweep.size() - 1 : 0;
+    close_item(n_rows);
+    const int64_t n_sweep = (int64_t)sweep.size() / 4;
     const int64_t off_sweep = GLASS_PLAN_HEADER_WORDS;
     const int64_t off_long = off_sweep + (int64_t)sweep.size();
     const int64_t off_reduce = off_long + (int64_t)longs.size();
@@ -352,10 +439,8 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     plan[H_NSLOTS] = n_slots;
     plan[H_LONG_THR] = kLongThr;
     plan[H_LONG_CHUNK] = kLongChunk;
-    // Row-parallel threshold (mean degree of a wave's rows <= factor * G): 2 once the sweep is throughput-bound
-    // (degree-6 uniform graph: 0.66 -> 0.72 of the HBM roofline), 1 on small graphs where the serial per-row edge
-    // loop would lengthen the latency-bound critical path (density-shape: 5.0 -> 5.35 us with factor 2).
-    plan[H_RP_FACTOR] = n_sweep >= kRowParallelWideWaves ? 2 : 1;
+    // Flat-mode threshold (mean degree of an item's rows <= factor * G, G = lane groups per wave at the launch's H).
+    plan[H_RP_FACTOR] = kFlatFactor;
     plan[H_OFF_SWEEP] = (int32_t)off_sweep;
     plan[H_OFF_LONG] = (int32_t)off_long;
     plan[H_OFF_REDUCE] = (int32_t)off_reduce;

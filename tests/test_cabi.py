@@ -53,15 +53,19 @@ def _check_plan(rowptr):
     hdr = plan[:16]
     assert hdr[0] == 0x474C5350 and hdr[2] == n and hdr[3] == rp[-1]
     n_sweep, n_long, n_red, n_slots, thr, chunk = hdr[4:10]
-    sweep = plan[hdr[10]:hdr[10] + n_sweep + 1]
+    sweep = plan[hdr[10]:hdr[10] + 4 * n_sweep].reshape(-1, 4)  # items (r0, r1, e0, e1)
+    deg = rp[1:] - rp[:-1]
     longs = plan[hdr[11]:hdr[11] + 4 * n_long].reshape(-1, 4)
     reds = plan[hdr[12]:hdr[12] + 3 * n_red].reshape(-1, 3)
-    deg = rp[1:] - rp[:-1]
-    # sweep ranges tile [0, n) in order
+    # sweep items: consecutive runs of short rows, in order, covering every short row exactly once, each within the
+    # kernel's staging caps (64 rows, 256 edges), carrying their own edge range
     all_long = 0 < n <= 1024 and rp[-1] >= 64 * n  # few rows, many entries: no sweep, every row is workgroup items
     assert (thr == 0 and n_sweep == 0) if all_long else thr > 0
-    if n and not all_long:
-        assert sweep[0] == 0 and sweep[-1] == n and np.all(np.diff(sweep) > 0)
+    covered = []
+    for r0, r1, e0, e1 in sweep.tolist():
+        assert 0 <= r0 < r1 <= n and r1 - r0 <= 64 and e0 == rp[r0] and e1 == rp[r1] and e1 - e0 <= 256
+        covered += list(range(r0, r1))
+    assert covered == np.nonzero(deg < thr)[0].tolist()
     # every long row (deg >= thr) is covered exactly by its chunks, in order, whole 64-edge batches
     long_rows = np.nonzero(deg >= thr)[0]
     assert sorted(set(longs[:, 0].tolist())) == long_rows.tolist()

@@ -3,7 +3,8 @@
 // stream, prints algorithmic GB/s against the HBM roofline, and spot-checks rows in fp64.
 // Also the program to put after `rocprofv3 ... --` for per-kernel traces and PMC counters.
 //
-//   spmm_bench <shape> [H] [iters] [--transpose]
+//   spmm_bench <shape> [H] [iters] [--rp K] [--full]
+//   --rp K : override the plan's flat-mode factor (header word 13) for A/B runs; --full : check EVERY row in fp64
 //   shape: ppi_bp | hpo_neuro | em_user | powerlaw | density-like | N:PAIRS[:zipf] | calib:N
 //   calib:N = random permutation matrix (one edge per row, every X row read exactly once): a known
 //   byte count in K1's own access pattern, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE.
@@ -89,9 +90,17 @@ static Graph make_graph(int64_t n, int64_t pairs, double zipf, uint64_t seed) {
 }
 
 int main(int argc, char** argv) {
-    std::string shape = argc > 1 ? argv[1] : "ppi_bp";
-    int64_t H = argc > 2 ? atoll(argv[2]) : 64;
-    int iters = argc > 3 ? atoi(argv[3]) : 50;
+    int rp_override = -1;
+    bool full = false;
+    std::vector<char*> pos_args;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--rp") && i + 1 < argc) rp_override = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--full")) full = true;
+        else pos_args.push_back(argv[i]);
+    }
+    std::string shape = pos_args.size() > 0 ? pos_args[0] : "ppi_bp";
+    int64_t H = pos_args.size() > 1 ? atoll(pos_args[1]) : 64;
+    int iters = pos_args.size() > 2 ? atoi(pos_args[2]) : 50;
     int64_t n, pairs;
     double zipf = 0;
     if (shape == "ppi_bp") n = 17080, pairs = 316951;
@@ -131,6 +140,7 @@ int main(int argc, char** argv) {
     if (glass_spmm_plan_build(g.rowptr.data(), n, nullptr, &words)) return 3;
     std::vector<int32_t> plan(words);
     if (glass_spmm_plan_build(g.rowptr.data(), n, plan.data(), &words)) return 3;
+    if (rp_override >= 0) plan[13] = rp_override;
     const int64_t ws_bytes = glass_spmm_ws_bytes(plan.data(), H);
 
     std::vector<float> X((size_t)n * H);
@@ -182,9 +192,10 @@ int main(int argc, char** argv) {
     std::vector<float> Y((size_t)n * H);
     HIP_OK(hipMemcpy(Y.data(), d_Y, (size_t)n * H * 4, hipMemcpyDeviceToHost));
     double max_err = 0, max_ref = 0;
-    for (int k = 0; k < 64; ++k) {
-        int64_t r = (k < 8) ? k : (int64_t)((uint64_t)(k * 2654435761u) % (uint64_t)n);
-        if (k == 8) {  // the longest row
+    const int64_t n_check = full ? n : 64;
+    for (int64_t k = 0; k < n_check; ++k) {
+        int64_t r = (full || k < 8) ? k : (int64_t)((uint64_t)(k * 2654435761u) % (uint64_t)n);
+        if (!full && k == 8) {  // the longest row
             for (int64_t i = 0; i < n; ++i)
                 if (g.rowptr[i + 1] - g.rowptr[i] == maxdeg) r = i;
         }
@@ -195,10 +206,10 @@ int main(int argc, char** argv) {
             max_ref = std::max(max_ref, fabs(s));
         }
     }
-    printf("{\"shape\": \"%s\", \"N\": %lld, \"nnz\": %lld, \"max_deg\": %d, \"H\": %lld, \"sweep_waves\": %d, "
+    printf("{\"shape\": \"%s\", \"rp\": %d, \"rows_checked\": %lld, \"N\": %lld, \"nnz\": %lld, \"max_deg\": %d, \"H\": %lld, \"sweep_waves\": %d, "
            "\"long_items\": %d, \"reduce_rows\": %d, \"us_per_pass\": %.2f, \"edges_per_s\": %.4g, \"alg_GBps\": %.1f, "
            "\"frac_of_8TBps\": %.3f, \"spot_rel_err\": %.2e}\n",
-           shape.c_str(), (long long)n, (long long)nnz, maxdeg, (long long)H, plan[4], plan[5], plan[6], t * 1e6,
+           shape.c_str(), plan[13], (long long)n_check, (long long)n, (long long)nnz, maxdeg, (long long)H, plan[4], plan[5], plan[6], t * 1e6,
            nnz / t, bytes / t / 1e9, bytes / t / 8e12, max_err / (max_ref > 0 ? max_ref : 1));
     return max_err / (max_ref > 0 ? max_ref : 1) < 1e-5 ? 0 : 5;
 }
