@@ -1,9 +1,11 @@
 """Dataset / loader classes with the reference's interface (/root/reference/impl/SubGDataset.py).
 
 A loader yields whole-graph tensors plus the padded node matrix and targets of a batch of
-subgraphs: (x, edge_index, edge_attr, pos[perm], [z,] y[perm]).  Data-parallel runs shard every
-batch: rank r keeps perm[r::world], so ranks label and pool disjoint subgraphs of
-the same replicated graph."""
+subgraphs: (x, edge_index, edge_attr, pos[perm], [z,] y[perm]).  Data-parallel TRAINING loaders are
+built with shard=True: rank r keeps perm[r::world] of every batch, so ranks label and
+pool disjoint subgraphs of the same replicated graph.  Loaders without the flag (validation / test) yield
+the full batches on every rank, so that scores, scheduler steps and early-stop decisions are identical
+everywhere."""
 import torch
 
 from . import dist as gdist
@@ -30,8 +32,9 @@ class GDataset:
 class GDataloader:
     """Iterates index batches over the subgraphs (shuffle / drop_last as torch's DataLoader) and
     returns the tuple the training loop expects."""
-    def __init__(self, Gdataset, batch_size=64, shuffle=True, drop_last=False):
+    def __init__(self, Gdataset, batch_size=64, shuffle=True, drop_last=False, shard=False):
         self.Gdataset, self.batch_size, self.shuffle, self.drop_last = Gdataset, batch_size, shuffle, drop_last
+        self.shard = bool(shard)  # data-parallel training loader: this rank's slice of every batch
         self.generator = None  # optional torch.Generator (CPU) for reproducible shuffles
 
     def get_x(self):
@@ -60,8 +63,14 @@ class GDataloader:
             order = gdist.broadcast_cpu(order)  # identical permutation on every rank
         order = order.to(self.Gdataset.pos.device)
         stop = n - n % self.batch_size if self.drop_last else n
+        sharded = self.shard and gdist.is_distributed()
         for s in range(0, stop, self.batch_size):
-            yield gdist.shard(order[s:s + self.batch_size])
+            batch = order[s:s + self.batch_size]
+            if sharded:
+                if batch.shape[0] < gdist.world_size():
+                    continue  # a tail smaller than the world would leave a rank without subgraphs: skipped on EVERY rank
+                batch = gdist.shard(batch)
+            yield batch
 
     def __iter__(self):
         self.iter = self._batches()
@@ -78,8 +87,8 @@ class GDataloader:
 class ZGDataloader(GDataloader):
     """Adds the node labels z = z_fn(x, pos) of the batch before the targets."""
     def __init__(self, Gdataset, batch_size=64, shuffle=True, drop_last=False,
-                 z_fn=lambda x, y: torch.zeros((x.shape[0], x.shape[1]), dtype=torch.int64)):
-        super().__init__(Gdataset, batch_size, shuffle, drop_last)
+                 z_fn=lambda x, y: torch.zeros((x.shape[0], x.shape[1]), dtype=torch.int64), shard=False):
+        super().__init__(Gdataset, batch_size, shuffle, drop_last, shard)
         self.z_fn = z_fn
 
     def __next__(self):

@@ -121,6 +121,8 @@ class ParamArena(FlatGradBucket):
                                                         rng_state.data_ptr() if (rng_state is not None and i == 0) else 0,
                                                         torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "glass_dense_pack_batch_f32")
+            if rng_state is not None and i == 0:
+                ops.note_rng_advance(rng_state.device)
 
     def attached(self):
         base_p, base_g = self.flat_param.untyped_storage().data_ptr(), self.flat.untyped_storage().data_ptr()

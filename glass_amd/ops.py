@@ -53,8 +53,33 @@ def rng_seed(seed, device):
         st.copy_(new)
 
 
+# Host-side count of advances of the device-resident stream.  The backward of a dropout regenerates the forward's
+# mask from the LIVE (seed, step) words, so a second training forward (which advances them) between a forward and its
+# backward would silently pair the gradient with the wrong mask (gradient accumulation, GLASS.NodeEmb over several
+# feature channels, two model calls before loss.backward()).  Every autograd node that drew a mask remembers the
+# epoch of its forward and refuses to run its backward under another one.  (Replays of a captured step do not touch
+# the host counter; there forward and backward sit in the same graph.)
+_rng_epoch = {}
+
+
+def note_rng_advance(device):
+    _rng_epoch[device] = _rng_epoch.get(device, 0) + 1
+
+
+def rng_epoch(device):
+    return _rng_epoch.get(device, 0)
+
+
+def check_rng_epoch(device, epoch, what):
+    if epoch != rng_epoch(device):
+        raise RuntimeError(f"{what}: the dropout stream was advanced by another training forward between this "
+                           "forward and its backward; its mask can no longer be regenerated (run backward() before "
+                           "the next training forward, or use dropout 0)")
+
+
 def rng_advance(device):
     _lib.check(_lib.load().glass_rng_advance(rng_state(device).data_ptr(), _stream()), "glass_rng_advance")
+    note_rng_advance(device)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -243,6 +268,14 @@ def _wgrad_supported(G, X, dW):
                 G.stride(1) != 1 or X.stride(1) != 1 or dW.stride(1) != 1)
 
 
+def _arena_grads_live(stack, params):
+    """The in-place gradient path writes into the arena views stack[2] / stack[3] and hands autograd None.  That is only
+    correct while every parameter's .grad still IS its arena view: optimizer.zero_grad(set_to_none=True) (torch's
+    default) detaches them, after which gradients written to the arena would never reach the optimizer."""
+    base = stack[2].untyped_storage().data_ptr()
+    return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in params)
+
+
 class StackedLinearFn(torch.autograd.Function):
     """T = x @ [W1; W0]^T + [b1 | b0]  — both weight sets of a GLASSConv Linear pair in one GEMM
     (rocBLAS/hipBLASLt through torch).  With a ParamArena the stacked weight is a view (no cat) and
@@ -256,6 +289,7 @@ class StackedLinearFn(torch.autograd.Function):
             W, b = torch.cat((w1, w0)), torch.cat((b1, b0))
         ctx.save_for_backward(x, W)
         ctx.stack = stack
+        ctx.params = (w1, w0, b1, b0)
         ctx.split = w1.shape[0]
         return torch.addmm(b, x, W.t())
 
@@ -263,6 +297,8 @@ class StackedLinearFn(torch.autograd.Function):
     def backward(ctx, dT):
         x, W = ctx.saved_tensors
         dT, _ = _rows(dT)
+        if ctx.stack is not None and not _arena_grads_live(ctx.stack, ctx.params):
+            ctx.stack = None  # .grad no longer aliases the arena: gradients go back through autograd
         if ctx.stack is not None and _wgrad_supported(dT, x, ctx.stack[2]) and USE_SIDE_STREAM:
             # accumulate straight into the gradient arena, on the side stream (joined before Adam).
             # The side stream uses its own scratch; successive wgrads on it are stream-ordered.
@@ -350,6 +386,7 @@ class DualLinearMixFn(torch.autograd.Function):
         _lib.check(rc, "glass_dual_linear_fwd_f32")
         ctx.save_for_backward(xa, xb, T, mask)
         ctx.cfg = (float(z_ratio), act, stack, n, H)
+        ctx.params = (w1, w0, b1, b0)
         return out
 
     @staticmethod
@@ -369,14 +406,23 @@ class DualLinearMixFn(torch.autograd.Function):
             _lib.check(rc, "glass_dual_linear_dgrad_f32")
         I = n_out
         ws = _wgrad_workspace(dout.device, n, 2 * H, I)
+        live = _arena_grads_live(stack, ctx.params)
+        if live:   # accumulate straight into the gradient arena
+            dW, dbias, accumulate = stack[2], stack[3], 1
+        else:      # .grad was detached from the arena (zero_grad(set_to_none=True)): hand the gradients to autograd
+            dW = torch.empty((2 * H, I), dtype=torch.float32, device=dout.device)
+            dbias = torch.empty(2 * H, dtype=torch.float32, device=dout.device)
+            accumulate = 0
         rc = lib.glass_dual_linear_wgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act, xa.data_ptr(),
                                              xa.stride(0), 0 if xb is None else xb.data_ptr(),
-                                             0 if xb is None else xb.stride(0), n, H, stack[2].data_ptr(),
-                                             stack[2].stride(0), stack[3].data_ptr(), 1, ws.data_ptr(), _stream())
+                                             0 if xb is None else xb.stride(0), n, H, dW.data_ptr(),
+                                             dW.stride(0), dbias.data_ptr(), accumulate, ws.data_ptr(), _stream())
         _lib.check(rc, "glass_dual_linear_wgrad_f32")
         da = din if xb is None else (None if din is None else din[:, :H])
         db_ = None if (xb is None or din is None) else din[:, H:]
-        return da, db_, None, None, None, None, None, None, None, None, None
+        if live:
+            return da, db_, None, None, None, None, None, None, None, None, None
+        return da, db_, dW[:H], dW[H:], dbias[:H], dbias[H:], None, None, None, None, None
 
 
 def dual_linear_mix(xa, xb, lin1, lin0, mask, z_ratio, act, stack, out=None):
@@ -417,6 +463,7 @@ class GraphNormFn(torch.autograd.Function):
         _lib.check(rc, "glass_graphnorm_fwd_f32")
         ctx.save_for_backward(x, g, a, saved)
         ctx.cfg = (act, p_drop, call_id)
+        ctx.rng_epoch = rng_epoch(x.device)
         # direct: parameter gradients are accumulated straight into the flat gradient arena
         ctx.direct = (gamma, beta, alpha) if (direct and all(t.grad is not None for t in (gamma, beta, alpha))) else None
         return y
@@ -436,6 +483,8 @@ class GraphNormFn(torch.autograd.Function):
             dg, db, da = dparams[0], dparams[1], dparams[2]
             accumulate = 0
         ws = _graphnorm_ws(x.device, n, C)
+        if p_drop > 0:
+            check_rng_epoch(x.device, ctx.rng_epoch, "GraphNormFn.backward")
         rng = rng_state(x.device).data_ptr() if p_drop > 0 else 0
         rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), lddy, x.data_ptr(), x.stride(0), dx.data_ptr(), C, 0, 0,
                                                  n, C, g.data_ptr(), a.data_ptr(), saved.data_ptr(), dg.data_ptr(),

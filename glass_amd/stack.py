@@ -249,7 +249,7 @@ class StackProgram:
         # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
         advance = train and (p > 0 or any(c.dropout > 0 for c in emb.convs))
         emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
-        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc),
+        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc), "rng_epoch": ops.rng_epoch(dev),
               "stat_rows": int(lib.glass_dual_linear_stat_rows(H))}  # rows per workgroup of the fused dense kernels
         # labels: z (int64 [N], > 0 = labeled), None (all labeled), or ("pos", pos): labeled = the nodes listed in the
         # padded subgraph matrix — utils.MaxZOZ without materialising z (a byte memset + scatter inside the gather)
@@ -354,6 +354,8 @@ class StackProgram:
         dev = st["mask"].device
         f32 = dict(dtype=torch.float32, device=dev)
         mask, jk = st["mask"], st["jk"]
+        if p > 0 or any(rec is not None and rec["pc"] > 0 for rec in st["layers"]):
+            ops.check_rng_epoch(dev, st["rng_epoch"], "StackProgram.backward")
         acc = st["acc"]  # 1: add into the gradient arena; 0: overwrite (every gradient is written exactly once)
         if "djk" in st:  # the fused readout already went through the final GraphNorm
             djk = st["djk"]

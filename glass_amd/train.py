@@ -13,7 +13,7 @@ USE_GRAPH = os.environ.get("GLASS_TRAIN_GRAPH", "1") != "0"
 def _graph_step(optimizer, model, dataloader, loss_fn):
     """A hipGraph-replayed step (glass_amd.step.TrainStep) when the epoch is graph-safe: a GLASS model on the GPU,
     ZGDataloader with z_fn = MaxZOZ and drop_last (fixed batch shape), and an optimizer whose step is capturable
-    (FlatAdam, or a torch optimizer built with capturable=True).  Cached on the model.  None -> eager loop."""
+    (FlatAdam: its learning rate lives in device memory, so schedulers keep working under replay).  Cached on the model.  None -> eager loop."""
     from . import utils
     from .SubGDataset import ZGDataloader
     from .models import GLASS
@@ -22,7 +22,9 @@ def _graph_step(optimizer, model, dataloader, loss_fn):
             dataloader.z_fn is utils.MaxZOZ and dataloader.drop_last and dataloader.Gdataset.x.is_cuda and
             len(dataloader) > 0):
         return None
-    if not (isinstance(optimizer, FlatAdam) or all(g.get("capturable", False) for g in optimizer.param_groups)):
+    if not isinstance(optimizer, FlatAdam):
+        # FlatAdam mirrors param_groups[...]["lr"] into device memory before every replay (sync_lr); a torch optimizer's
+        # Python-float lr would be baked into the captured graph and a scheduler's changes silently ignored
         return None
     ds = dataloader.Gdataset
     key = (id(optimizer), id(loss_fn), id(ds.x), id(ds.edge_index), dataloader.batch_size, gdist.world_size())
@@ -37,6 +39,17 @@ def _graph_step(optimizer, model, dataloader, loss_fn):
     return step
 
 
+def _epoch_loss(mean_loss, dataloader):
+    """The value train() returns: with a sharded (data-parallel) loader the mean over ranks, so that the scheduler
+    and the early-stop logic of the driver see the same number on every rank."""
+    if gdist.is_distributed() and getattr(dataloader, "shard", False):
+        import torch.distributed as td
+        t = mean_loss.detach().clone().reshape(1)
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+        mean_loss = t[0] / gdist.world_size()
+    return mean_loss.item()
+
+
 def train(optimizer, model, dataloader, loss_fn):
     """One epoch; returns the mean per-step loss.  batch = (x, ei, ea, pos, [z,] y)."""
     model.train()
@@ -47,7 +60,7 @@ def train(optimizer, model, dataloader, loss_fn):
             loss = step(batch[3], batch[-1])  # z is recomputed inside the captured step (MaxZOZ kernel)
             total = loss.clone() if total is None else total.add_(loss)
             n += 1
-        return (total / n).item()
+        return _epoch_loss(total / n, dataloader)
     total_loss = []
     bucket = gdist.bucket_for(model) if gdist.is_distributed() else None
     for batch in dataloader:
@@ -63,7 +76,7 @@ def train(optimizer, model, dataloader, loss_fn):
         total_loss.append(loss.detach())
         optimizer.step()
     # one host sync per epoch instead of the reference's .item() per step (train.py:15)
-    return torch.stack(total_loss).mean().item()
+    return _epoch_loss(torch.stack(total_loss).mean(), dataloader)
 
 
 @torch.no_grad()

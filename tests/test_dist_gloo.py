@@ -71,8 +71,15 @@ def _worker(rank, port, out_dir):
     # --- loader: same permutation everywhere (rank 0's), disjoint strided shards --------------------
     torch.manual_seed(100 + rank)  # different local RNG per rank on purpose
     ds = GDataset(x, ei, ew, pos, torch.arange(pos.shape[0]))
-    loader = ZGDataloader(ds, batch_size=8, shuffle=True, drop_last=True, z_fn=O.max_zero_one)
+    loader = ZGDataloader(ds, batch_size=8, shuffle=True, drop_last=True, z_fn=O.max_zero_one, shard=True)
     shards = [b[-1].clone() for b in loader]
+    # evaluation loaders are NOT sharded: every rank sees the full batches (same scores / early stop everywhere);
+    # a sharded loader skips, on every rank, a tail batch smaller than the world
+    full = [b[-1].tolist() for b in ZGDataloader(ds, batch_size=8, shuffle=False, z_fn=O.max_zero_one)]
+    assert full == [list(range(0, 8)), list(range(8, 16))]
+    ds17 = GDataset(x, ei, ew, pos[:1].repeat(17, 1), torch.arange(17))
+    tail = [b[-1].tolist() for b in ZGDataloader(ds17, batch_size=8, shuffle=False, z_fn=O.max_zero_one, shard=True)]
+    assert [len(t) for t in tail] == [4, 4] and all(len(t) > 0 for t in tail)
     gathered = [None] * WORLD
     td.all_gather_object(gathered, [s.tolist() for s in shards])
     # --- one data-parallel step through the flat bucket -------------------------------------------
