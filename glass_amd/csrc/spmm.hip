@@ -19,16 +19,16 @@ namespace glass {
 constexpr int32_t kPlanMagic = 0x474C5350;  // 'GLSP'
 constexpr int32_t kPlanVersion = 2;
 
-// Cache policy of the once-read streams (rowptr / col / val in, Y out): GLASS_K1_NT=1 marks them non-temporal so that
-// they do not displace X rows, the only data of this kernel that is re-read, from the XCD's L2.
-#ifndef GLASS_K1_NT
-#define GLASS_K1_NT 1
-#endif
-#if GLASS_K1_NT
-#define K1_LOAD_IDX(p) __builtin_nontemporal_load(p)
-#else
-#define K1_LOAD_IDX(p) (*(p))
-#endif
+// Cache policy of the once-read streams (rowptr / col / val in, Y out), template parameter NT of the kernels: non-temporal
+// when the launch streams more than the Infinity Cache can hold (they would only displace X rows, the one operand that
+// is re-read: permutation N = 4 M 413 -> 395 us, uniform degree 3 at N = 2 M 311 -> 292 us), default policy otherwise
+// — on the BASELINE graphs col/val/Y of one launch ARE re-read by the next launch from L2 / Infinity Cache, and
+// marking them non-temporal costs 13.4 -> 15.7 us at ppi_bp-shape and 75 -> 89 us at hpo_neuro-shape.
+template <bool NT, typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+    if (NT) return __builtin_nontemporal_load(p);
+    return *p;
+}
 typedef float k1_f32x4 __attribute__((ext_vector_type(4)));
 // header word indices
 enum { H_MAGIC, H_VER, H_NROWS, H_NNZ, H_NSWEEP, H_NLONG, H_NREDUCE, H_NSLOTS, H_LONG_THR, H_LONG_CHUNK,
@@ -41,12 +41,10 @@ template <> struct Vec<4> {
     __device__ __forceinline__ void zero() { v = make_float4(0.f, 0.f, 0.f, 0.f); }
     __device__ __forceinline__ void load(const float* p) { v = *reinterpret_cast<const float4*>(p); }
     __device__ __forceinline__ void store(float* p) const { *reinterpret_cast<float4*>(p) = v; }
+    template <bool NT>
     __device__ __forceinline__ void store_out(float* p) const {  // a row of Y: written once, not read by this kernel
-#if GLASS_K1_NT
-        __builtin_nontemporal_store((k1_f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<k1_f32x4*>(p));
-#else
-        store(p);
-#endif
+        if (NT) __builtin_nontemporal_store((k1_f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<k1_f32x4*>(p));
+        else store(p);
     }
     __device__ __forceinline__ void fma(float a, const Vec& x) {
         v.x = fmaf(a, x.v.x, v.x); v.y = fmaf(a, x.v.y, v.y); v.z = fmaf(a, x.v.z, v.z); v.w = fmaf(a, x.v.w, v.w);
@@ -61,12 +59,10 @@ template <> struct Vec<1> {
     __device__ __forceinline__ void zero() { v = 0.f; }
     __device__ __forceinline__ void load(const float* p) { v = *p; }
     __device__ __forceinline__ void store(float* p) const { *p = v; }
+    template <bool NT>
     __device__ __forceinline__ void store_out(float* p) const {
-#if GLASS_K1_NT
-        __builtin_nontemporal_store(v, p);
-#else
-        store(p);
-#endif
+        if (NT) __builtin_nontemporal_store(v, p);
+        else store(p);
     }
     __device__ __forceinline__ void fma(float a, const Vec& x) { v = fmaf(a, x.v, v); }
     __device__ __forceinline__ void add(const Vec& x) { v += x.v; }
@@ -75,7 +71,7 @@ template <> struct Vec<1> {
 
 // Accumulate edges [e0,e1) of one row into `acc` (per lane-group partial sums).
 // All 64 lanes execute this together; e0/e1 are wave-uniform.
-template <int VW, int LPR, int U>
+template <int VW, int LPR, int U, bool NT>
 __device__ __forceinline__ void gather_edges(Vec<VW>& acc, const int32_t* __restrict__ col,
                                              const float* __restrict__ val, const float* __restrict__ Xc, int64_t ldx,
                                              int e0, int e1, int lane, int grp, bool col_ok) {
@@ -85,8 +81,8 @@ __device__ __forceinline__ void gather_edges(Vec<VW>& acc, const int32_t* __rest
         int my_c = 0;
         float my_v = 0.f;
         if (lane < cnt) {
-            my_c = K1_LOAD_IDX(col + eb + lane);
-            my_v = K1_LOAD_IDX(val + eb + lane);
+            my_c = ld_stream<NT>(col + eb + lane);
+            my_v = ld_stream<NT>(val + eb + lane);
         }
         for (int j = 0; j < cnt; j += U * G) {
             Vec<VW> x[U];
@@ -126,10 +122,11 @@ __device__ __forceinline__ void reduce_groups(Vec<VW>& acc) {
 //    the row lengths (a row boundary only flushes the accumulator), rows summed in plain edge order, no cross-group
 //    reduction.  On a degree-1 pattern that is U*G independent 4H-byte gathers in flight per wave behind a single
 //    index round trip (the previous form had 2 per group behind three dependent round trips: 0.55 of the HBM roofline).
+constexpr int64_t kStreamNtBytes = 256ll << 20;  // Infinity Cache size
 constexpr int kItemRows = 64;    // rows per sweep item (one coalesced rowptr load per wave)
 constexpr int kItemEdges = 256;  // edges per sweep item (LDS staging: 2 KiB of (col,val) per wave)
 
-template <int VW, int LPR, int U>
+template <int VW, int LPR, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
@@ -155,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
     const int e0 = __builtin_amdgcn_readfirstlane(it.z), e1 = __builtin_amdgcn_readfirstlane(it.w);
     const int nrows = r1 - r0, ne = e1 - e0;
     // start edge of row r0 + lane (lanes past the item hold e1, so "end of row i" is always lane i + 1's value or e1)
-    const int rp_reg = (lane < nrows) ? K1_LOAD_IDX(rowptr + r0 + lane) : e1;
+    const int rp_reg = (lane < nrows) ? ld_stream<NT>(rowptr + r0 + lane) : e1;
     if (G > 1 && ne <= rp_factor * G * nrows) {
         // ---- flat mode ----
         int32_t* rp_s = s_rp[G > 1 ? w : 0];
@@ -169,8 +166,8 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
             cr[k] = 0;
             vr[k] = 0.f;
             if (idx < ne) {
-                cr[k] = K1_LOAD_IDX(col + e0 + idx);
-                vr[k] = K1_LOAD_IDX(val + e0 + idx);
+                cr[k] = ld_stream<NT>(col + e0 + idx);
+                vr[k] = ld_stream<NT>(val + e0 + idx);
             }
         }
         rp_s[lane] = rp_reg - e0;
@@ -220,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
             for (int u = 0; u < U; ++u) {
                 if (e + u < ge) {
                     while (e + u >= row_end) {  // row r is complete (possibly empty): flush
-                        if (col_ok) acc.store_out(Y + (int64_t)(r0 + r) * ldy + coff);
+                        if (col_ok) acc.template store_out<NT>(Y + (int64_t)(r0 + r) * ldy + coff);
                         acc.zero();
                         ++r;
                         row_end = rp_s[r + 1];
@@ -231,7 +228,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
             e += U;
         }
         for (; r < rend; ++r) {  // the row in progress, then trailing empty rows
-            if (col_ok) acc.store_out(Y + (int64_t)(r0 + r) * ldy + coff);
+            if (col_ok) acc.template store_out<NT>(Y + (int64_t)(r0 + r) * ldy + coff);
             acc.zero();
         }
         return;
@@ -242,15 +239,15 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
         const int ee = (i + 1 < nrows) ? __builtin_amdgcn_readlane(rp_reg, i + 1) : e1;
         Vec<VW> acc;
         acc.zero();
-        gather_edges<VW, LPR, U>(acc, col, val, Xc, ldx, es, ee, lane, grp, col_ok);
+        gather_edges<VW, LPR, U, NT>(acc, col, val, Xc, ldx, es, ee, lane, grp, col_ok);
         reduce_groups<VW, LPR>(acc);
-        if (grp == 0 && col_ok) acc.store_out(Y + (int64_t)(r0 + i) * ldy + coff);
+        if (grp == 0 && col_ok) acc.template store_out<NT>(Y + (int64_t)(r0 + i) * ldy + coff);
         es = ee;
     }
 }
 
 // ---- long-row kernel: one workgroup per (row, chunk); 4 waves combine through LDS ------------
-template <int VW, int LPR, int U>
+template <int VW, int LPR, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void spmm_long_kernel(const int32_t* __restrict__ col,
                                                            const float* __restrict__ val,
                                                            const float* __restrict__ X, int64_t ldx,
@@ -269,7 +266,7 @@ __global__ __launch_bounds__(kBlock) void spmm_long_kernel(const int32_t* __rest
     const int e0 = min(eb + w * per, ee), e1 = min(e0 + per, ee);
     Vec<VW> acc;
     acc.zero();
-    gather_edges<VW, LPR, U>(acc, col, val, X + coff, ldx, e0, e1, lane, grp, col_ok);
+    gather_edges<VW, LPR, U, NT>(acc, col, val, X + coff, ldx, e0, e1, lane, grp, col_ok);
     reduce_groups<VW, LPR>(acc);
     if (grp == 0) acc.store(&lds[(w * LPR + sub) * VW]);
     __syncthreads();
@@ -298,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void spmm_reduce_kernel(const float* __rest
     }
 }
 
-template <int VW, int LPR, int U>
+template <int VW, int LPR, int U, bool NT>
 static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float* val, const float* X, int64_t ldx,
                        float* Y, int64_t ldy, int64_t H, const int32_t* hdr, const int32_t* plan, float* ws,
                        hipStream_t st) {
@@ -306,12 +303,12 @@ static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float*
     const int n_waves = hdr[H_NSWEEP];
     if (n_waves > 0) {
         dim3 grid((unsigned)ceil_div(n_waves, kBlock / kWave), n_ctiles);
-        hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx, Y,
+        hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U, NT>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx, Y,
                            ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_RP_FACTOR]);
     }
     if (hdr[H_NLONG] > 0) {
         dim3 grid((unsigned)hdr[H_NLONG], n_ctiles);
-        hipLaunchKernelGGL((spmm_long_kernel<VW, LPR, U>), grid, dim3(kBlock), 0, st, col, val, X, ldx, Y, ldy, ws,
+        hipLaunchKernelGGL((spmm_long_kernel<VW, LPR, U, NT>), grid, dim3(kBlock), 0, st, col, val, X, ldx, Y, ldy, ws,
                            (int)H, plan + hdr[H_OFF_LONG]);
     }
     if (hdr[H_NREDUCE] > 0) {
@@ -327,7 +324,10 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* v
                        hipStream_t st) {
     // gathers in flight per lane group: measured us/launch for U = 2 / 4 / 8 on MI355X — ppi_bp-shape
     // 14.9 / 13.2 / 12.7, hpo_neuro-shape 87.8 / 83.4 / 81.0, power-law H=256 2638 / 2600 / 2597.
-    return launch_spmm_u<VW, LPR, 8>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
+    // streamed bytes of this launch (indices in, Y out) beyond what the Infinity Cache holds -> non-temporal streams
+    const int64_t streamed = (int64_t)hdr[H_NNZ] * 8 + (int64_t)hdr[H_NROWS] * (4 * H + 4);
+    if (streamed > kStreamNtBytes) return launch_spmm_u<VW, LPR, 8, true>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
+    return launch_spmm_u<VW, LPR, 8, false>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
 }
 
 }  // namespace glass
@@ -346,7 +346,7 @@ static constexpr int kLongThrMax = 256;
 static constexpr int kLongChunkMax = 2048;
 static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
 static constexpr int kTargetWaves = 32768;  // ~4 rounds of 256 CUs x 32 waves
-static constexpr int kFlatFactor = 2;       // see spmm_sweep_kernel: flat mode up to a mean degree of 2 G
+static constexpr int kFlatFactor = 4;       // flat mode up to a mean degree of 4 G (uniform degree 12 at H = 64: 988 -> 931 us; degree 37: row mode)
 
 extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int32_t* plan, int64_t* plan_words) {
     GLASS_REQUIRE(rowptr && plan_words && n_rows >= 0 && n_rows < (1ll << 31), "plan_build: bad arguments");
