@@ -84,10 +84,15 @@ class Run:
         self.val = SubGDataset.GDataset(*g.get_split("valid"))
         self.tst = SubGDataset.GDataset(*g.get_split("test"))
 
-    def loader(self, ds, bs, drop_last):
+    def loaders(self, batch_size):
+        """(train, valid, test) loaders.  With --use_maxzeroone every batch is labeled by utils.MaxZOZ and the training
+        loader drops the last partial batch; without it plain loaders are used and nothing is dropped.  All shuffle."""
         if self.args.use_maxzeroone:
-            return SubGDataset.ZGDataloader(ds, bs, z_fn=utils.MaxZOZ, shuffle=True, drop_last=drop_last)
-        return SubGDataset.GDataloader(ds, bs, shuffle=True, drop_last=drop_last if drop_last else False)
+            make = functools.partial(SubGDataset.ZGDataloader, z_fn=utils.MaxZOZ, shuffle=True)
+            return (make(self.trn, batch_size, drop_last=True), make(self.val, batch_size, drop_last=False),
+                    make(self.tst, batch_size, drop_last=False))
+        return tuple(SubGDataset.GDataloader(ds, batch_size, shuffle=True, drop_last=False)
+                     for ds in (self.trn, self.val, self.tst))
 
     def build_model(self, hidden_dim, conv_layer, dropout, jk, pool, z_ratio, aggr):
         a = self.args
@@ -104,60 +109,90 @@ class Run:
             raise NotImplementedError
         return models.GLASS(conv, nn.ModuleList([mlp]), nn.ModuleList([POOLS[pool]()])).to(config.device)
 
+    def evaluate(self, model, loader):
+        """Score of the task metric on one split."""
+        return train.test(model, loader, self.score_fn, loss_fn=self.loss_fn)[0]
+
+    def fit_once(self, model, optimizer, scheduler, loaders, warmup_epochs, patience):
+        """One training run.  Validation starts after `warmup_epochs`; the test score is the one measured at the best
+        validation score (ties within 1e-5 keep the larger test score).  Returns (epochs, seconds, val, test)."""
+        trn_loader, val_loader, tst_loader = loaders
+        policy = Patience(patience)
+        seconds = 0.0
+        epoch = 0
+        for epoch in range(self.args.max_epoch):
+            start = time.time()
+            loss = train.train(optimizer, model, trn_loader, self.loss_fn)
+            seconds += time.time() - start
+            scheduler.step(loss)
+            if epoch >= warmup_epochs:
+                val = self.evaluate(model, val_loader)
+                verdict = policy.judge(val)
+                if verdict == "better":
+                    policy.test_at_best = self.evaluate(model, tst_loader)
+                    print(f"iter {epoch} loss {loss:.4f} val {policy.best_val:.4f} tst {policy.test_at_best:.4f}", flush=True)
+                elif verdict == "tie":
+                    tst = self.evaluate(model, tst_loader)
+                    policy.test_at_best = max(tst, policy.test_at_best)
+                    print(f"iter {epoch} loss {loss:.4f} val {policy.best_val:.4f} tst {tst:.4f}", flush=True)
+                elif epoch % 10 == 0:  # worse: a progress line every tenth epoch only
+                    print(f"iter {epoch} loss {loss:.4f} val {val:.4f} tst {self.evaluate(model, tst_loader):.4f}", flush=True)
+            if policy.saturated():
+                policy.strikes += 1
+            if policy.exhausted():
+                break
+        return epoch + 1, seconds, policy.best_val, policy.test_at_best
+
     def test(self, pool="size", aggr="mean", hidden_dim=64, conv_layer=8, dropout=0.3, jk=1, lr=1e-3, z_ratio=0.8,
              batch_size=None, resi=0.7):
-        """Train `repeat` times with one hyper-parameter set; prints the reference's log lines."""
+        """Train `repeat` times with one hyper-parameter set (the YAML keys); prints the reference's log lines."""
         from glass_amd.arena import ParamArena
         from glass_amd.optim import FlatAdam
-        a = self.args
-        num_div = self.tst.y.shape[0] / batch_size
-        if a.dataset in SYNTHETIC_SETS:
-            num_div /= 5
-        outs = []
-        for repeat in range(a.repeat):
+        # evaluation cadence: both the warm-up and the patience are 100 test-set batches' worth of epochs (synthetic
+        # sets: a fifth of that)
+        batches_in_test = self.tst.y.shape[0] / batch_size
+        if self.args.dataset in SYNTHETIC_SETS:
+            batches_in_test /= 5
+        horizon = 100 / batches_in_test
+        results = []
+        for repeat in range(self.args.repeat):
             set_seed((1 << repeat) - 1)
             print(f"repeat {repeat}")
             self.split()
-            gnn = self.build_model(hidden_dim, conv_layer, dropout, jk, pool, z_ratio, aggr)
-            trn_loader = self.loader(self.trn, batch_size, True)
-            val_loader = self.loader(self.val, batch_size, False)
-            tst_loader = self.loader(self.tst, batch_size, False)
-            optimizer = FlatAdam(ParamArena(gnn), lr=lr)  # torch.optim.Adam(lr) semantics, one launch
-            scd = lr_scheduler.ReduceLROnPlateau(optimizer, factor=resi, min_lr=5e-5)
-            val_score = tst_score = 0
-            early_stop = 0
-            trn_time = []
-            i = 0
-            for i in range(a.max_epoch):
-                t1 = time.time()
-                loss = train.train(optimizer, gnn, trn_loader, self.loss_fn)
-                trn_time.append(time.time() - t1)
-                scd.step(loss)
-                if i >= 100 / num_div:
-                    score, _ = train.test(gnn, val_loader, self.score_fn, loss_fn=self.loss_fn)
-                    if score > val_score:
-                        early_stop = 0
-                        val_score = score
-                        tst_score, _ = train.test(gnn, tst_loader, self.score_fn, loss_fn=self.loss_fn)
-                        print(f"iter {i} loss {loss:.4f} val {val_score:.4f} tst {tst_score:.4f}", flush=True)
-                    elif score >= val_score - 1e-5:
-                        score, _ = train.test(gnn, tst_loader, self.score_fn, loss_fn=self.loss_fn)
-                        tst_score = max(score, tst_score)
-                        print(f"iter {i} loss {loss:.4f} val {val_score:.4f} tst {score:.4f}", flush=True)
-                    else:
-                        early_stop += 1
-                        if i % 10 == 0:
-                            s = train.test(gnn, tst_loader, self.score_fn, loss_fn=self.loss_fn)[0]
-                            print(f"iter {i} loss {loss:.4f} val {score:.4f} tst {s:.4f}", flush=True)
-                if val_score >= 1 - 1e-5:
-                    early_stop += 1
-                if early_stop > 100 / num_div:
-                    break
-            print(f"end: epoch {i+1}, train time {sum(trn_time):.2f} s, val {val_score:.3f}, tst {tst_score:.3f}",
-                  flush=True)
-            outs.append(tst_score)
-        print(f"average {np.average(outs):.3f} error {np.std(outs) / np.sqrt(len(outs)):.3f}")
-        return outs
+            model = self.build_model(hidden_dim, conv_layer, dropout, jk, pool, z_ratio, aggr)
+            optimizer = FlatAdam(ParamArena(model), lr=lr)  # torch.optim.Adam(lr) semantics, one launch
+            scheduler = lr_scheduler.ReduceLROnPlateau(optimizer, factor=resi, min_lr=5e-5)
+            epochs, seconds, val, tst = self.fit_once(model, optimizer, scheduler, self.loaders(batch_size), horizon, horizon)
+            print(f"end: epoch {epochs}, train time {seconds:.2f} s, val {val:.3f}, tst {tst:.3f}", flush=True)
+            results.append(tst)
+        print(f"average {np.average(results):.3f} error {np.std(results) / np.sqrt(len(results)):.3f}")
+        return results
+
+
+class Patience:
+    """Early-stop bookkeeping of the driver: an epoch is `better` (new best validation score), a `tie` (within 1e-5
+    below the best) or `worse` (one strike).  A saturated validation score (>= 1 - 1e-5) also costs a strike per
+    epoch.  More strikes than `limit` end the run; a better epoch clears them."""
+    def __init__(self, limit):
+        self.limit = limit
+        self.best_val = 0
+        self.test_at_best = 0
+        self.strikes = 0
+
+    def judge(self, val):
+        if val > self.best_val:
+            self.best_val, self.strikes = val, 0
+            return "better"
+        if val >= self.best_val - 1e-5:
+            return "tie"
+        self.strikes += 1
+        return "worse"
+
+    def saturated(self):
+        return self.best_val >= 1 - 1e-5
+
+    def exhausted(self):
+        return self.strikes > self.limit
 
 
 def main(argv=None):

@@ -10,6 +10,7 @@ best trial's embeddings go to `<path><name>_64.pt`, the file `GLASSTest.py --use
 """
 import argparse
 import functools
+import itertools
 import random
 
 import numpy as np
@@ -69,46 +70,58 @@ class Pretrain:
                           activation=nn.ReLU(inplace=True))
         return models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()])).to(config.device)
 
+    def node_embeddings(self, model):
+        with torch.no_grad():
+            return model.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr).detach().cpu()
+
+    def train_epoch(self, model, optimizer, scheduler, loader, loss_fn, max_batches=10):
+        """At most `max_batches` link-prediction batches (the whole graph is re-embedded for each); the plateau scheduler
+        is stepped per batch, before the optimizer.  Returns the mean batch loss."""
+        model.train()
+        seen = []
+        for batch in itertools.islice(loader, max_batches):
+            pairs, target = batch[-2], batch[-1]
+            optimizer.zero_grad()
+            emb = model.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr)
+            loss = loss_fn(model.preds[0](model.Pool(emb, pairs, None)), target)
+            loss.backward()
+            scheduler.step(loss)
+            seen.append(loss.item())
+            optimizer.step()
+        return np.average(seen)
+
     def work(self, hidden_dim, conv_layer, dropout, jk, lr, batch_size, aggr):
-        a = self.args
+        """Score one hyper-parameter set: `repeat` runs of up to max_epoch epochs, validated every 5th epoch, stopped
+        after 3 validations without improvement.  Returns (mean - std of the best validation F1, embeddings of the
+        last run's best checkpoint)."""
         trn_loader = SubGDataset.GDataloader(self.trn, batch_size)
         val_loader = SubGDataset.GDataloader(self.val, self.val.y.shape[0], shuffle=False)
-        loss_fn = lambda p, t: BCEWithLogitsLoss()(p.flatten(), t.flatten())  # noqa: E731
-        outs, emb = [], None
-        for _ in range(a.repeat):
-            gnn = self.build_model(hidden_dim, conv_layer, dropout, jk, aggr)
-            with torch.no_grad():
-                emb = gnn.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr).detach().cpu()
-            optimizer = Adam(gnn.parameters(), lr=lr)
-            scd = lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.7, min_lr=5e-5, patience=50)
-            best_score, early_stop = 0.0, 0
-            for i in range(a.max_epoch):
-                gnn.train()
-                losss = []
-                for ib, batch in enumerate(trn_loader):
-                    optimizer.zero_grad()
-                    node_emb = gnn.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr)
-                    loss = loss_fn(gnn.preds[0](gnn.Pool(node_emb, batch[-2], None)), batch[-1])
-                    loss.backward()
-                    scd.step(loss)
-                    losss.append(loss.item())
-                    optimizer.step()
-                    if ib >= 9:
-                        break
-                if i % 5 == 0:
-                    score, _ = train.test(gnn, val_loader, metrics.binaryf1, loss_fn)
-                    print(f"iter {i} loss {np.average(losss)} score {score}", flush=True)
-                    early_stop += 1
-                    if score > best_score:
-                        with torch.no_grad():
-                            emb = gnn.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr).detach().cpu()
-                        best_score, early_stop = score, 0
-                    if early_stop >= 3:
-                        break
+
+        def loss_fn(pred, target):
+            return BCEWithLogitsLoss()(pred.flatten(), target.flatten())
+
+        scores, emb = [], None
+        for _ in range(self.args.repeat):
+            model = self.build_model(hidden_dim, conv_layer, dropout, jk, aggr)
+            emb = self.node_embeddings(model)
+            optimizer = Adam(model.parameters(), lr=lr)
+            scheduler = lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.7, min_lr=5e-5, patience=50)
+            best, stale = 0.0, 0
+            for epoch in range(self.args.max_epoch):
+                mean_loss = self.train_epoch(model, optimizer, scheduler, trn_loader, loss_fn)
+                if epoch % 5:
+                    print(f"iter {epoch} loss {mean_loss}", flush=True)
+                    continue
+                score, _ = train.test(model, val_loader, metrics.binaryf1, loss_fn)
+                print(f"iter {epoch} loss {mean_loss} score {score}", flush=True)
+                if score > best:
+                    best, stale, emb = score, 0, self.node_embeddings(model)
                 else:
-                    print(f"iter {i} loss {np.average(losss)}", flush=True)
-            outs.append(best_score)
-        return np.average(outs) - np.std(outs), emb
+                    stale += 1
+                    if stale >= 3:
+                        break
+            scores.append(best)
+        return np.average(scores) - np.std(scores), emb
 
 
 def main(argv=None):

@@ -314,6 +314,7 @@ def main():
 
     from glass_amd.step import TrainStep
     stepper = TrainStep(model, opt, loss_fn, xg, eig, ewg, bucket, use_graph=bool(args.graph))
+    stepper.time_collective = world > 1  # HIP events around the exchange / optimizer part of every step
 
     def run(k, offset):
         for i in range(k):

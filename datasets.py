@@ -168,6 +168,11 @@ def _load_subgnn_text(name):
     mask = torch.cat((torch.zeros(len(rows["train"]), dtype=torch.int64), torch.ones(len(rows["val"]), dtype=torch.int64),
                       2 * torch.ones(len(rows["test"]), dtype=torch.int64)))
     edges = np.loadtxt(edge_f, dtype=np.int64).reshape(-1, 2)
+    # the reference reads the file through networkx.read_edgelist into an undirected simple Graph: a repeated line and
+    # a reversed duplicate ("u v" and "v u") are ONE edge (they must not coalesce to weight 2 in to_undirected)
+    lo, hi = edges.min(1), edges.max(1)
+    _, first = np.unique(lo * (int(hi.max()) + 1 if edges.size else 1) + hi, return_index=True)
+    edges = edges[np.sort(first)]
     edge_index = torch.from_numpy(edges).t().contiguous()
     n = int(max(pos.max(), edge_index.max())) + 1
     return BaseGraph(torch.empty((n, 1, 0)), edge_index, torch.ones(edge_index.shape[1]), pos, label.to(torch.float),

@@ -62,6 +62,7 @@ SIGNATURES = {
     "glass_linear_wgrad_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, c_int, _P, _P]),
     "glass_dual_linear_supported": (c_int, [_I]),
+    "glass_dual_linear_layout": (c_int, [_I]),
     "glass_dual_linear_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, _P, c_int,
                                           c_float, _P, c_uint64, _P, _I, _P]),
     "glass_graphnorm_finalize_f32": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, c_float, _P, _P]),

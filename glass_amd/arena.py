@@ -26,13 +26,30 @@ def _pairs(model):
     return out
 
 
+BIG_PARAM_ELEMS = 1 << 18  # parameters from 1 MB up (the use_nodeid embedding table) form the "big" bucket
+
+
 class ParamArena(FlatGradBucket):
-    def __init__(self, model):
+    def __init__(self, model, big_elems=BIG_PARAM_ELEMS):
         from .models import GraphNorm, GLASSConv
         params = [p for p in model.parameters() if p.requires_grad]
         if not params:
             raise ValueError("model has no trainable parameters")
         dev, dtype = params[0].device, params[0].dtype
+        # layout: [layer / head parameters][embedding-sized parameters].  The second group is the "big" bucket of the
+        # data-parallel exchange (dist.GradExchange): reduce-scatter + sharded Adam + all-gather instead of all-reduce.
+        # The big bucket starts with the parameters of the GraphNorm right behind such an embedding (emb_gn): in the
+        # backward pass their gradients are written together with the table's, after every layer / head gradient is
+        # final — so the small bucket can be all-reduced while that tail of the backward still runs (step.TrainStep).
+        from .models import EmbZGConv
+        emb_w = {id(m.weight) for m in model.modules() if isinstance(m, torch.nn.Embedding)}
+        big = [p for p in params if id(p) in emb_w and p.numel() >= big_elems]
+        tail = []
+        for m in model.modules():
+            if isinstance(m, EmbZGConv) and any(m.input_emb.weight is q for q in big) and getattr(m, "emb_gn", None) is not None:
+                tail += [p for p in m.emb_gn.parameters() if p.requires_grad]
+        big = tail + big if big else []
+        params = [p for p in params if not any(p is q for q in big)] + big
         order, seen, groups = [], set(), []
         for mod, kind, l1, l0 in _pairs(model):
             for a, b in ((l1.weight, l0.weight), (l1.bias, l0.bias)):
@@ -52,7 +69,16 @@ class ParamArena(FlatGradBucket):
                 b = grouped[id(p)][1]
                 offsets[id(b)] = off  # exactly adjacent: [a; b] is one stacked tensor
                 off += b.numel()
-        total = (off + 3) // 4 * 4
+        from . import dist as gdist
+        self.big_start = None
+        if big:
+            self.big_start = offsets[id(big[0])]
+            quantum = 4 * gdist.world_size()  # every rank's shard of the big bucket: whole float4s
+            total = self.big_start + -(-(off - self.big_start) // quantum) * quantum
+        else:
+            total = (off + 3) // 4 * 4
+            self.big_start = total
+        self._exchange = None
         self.model = model
         model._glass_grad_bucket = self  # dist.bucket_for(model) -> the arena (train.train's all-reduce hook)
         self.params = params
@@ -85,12 +111,16 @@ class ParamArena(FlatGradBucket):
             if len(views) == 2:  # weight and bias both stackable
                 (W, dW), (b, db) = views
                 O, K = W.shape  # [2H, K]
-                if O % 64 == 0 and K % 64 == 0 and _lib.load().glass_dual_linear_supported(O // 2):
+                from . import ops
+                if O % 64 == 0 and K % 64 == 0 and ops.dual_linear_supported(O // 2):
                     # MFMA images of W (forward operand, [NT=2H][KT=K]) and of W^T (data-gradient operand,
-                    # [NT=K][KT=2H]); refreshed by ONE launch per training forward (Adam changes W in between)
+                    # [NT=K][KT=2H]); refreshed by ONE launch per training forward (Adam changes W in between).
+                    # flags = transposed | layout << 1 (layout 0: wave16 images; tiled kernels: forward operand
+                    # paired = 1, data-gradient operand plain = 2)
+                    tiled = _lib.load().glass_dual_linear_layout(O // 2) == 1
                     Wimg, WTimg = torch.empty_like(W).reshape(-1), torch.empty_like(W).reshape(-1)
-                    self._packs.append((W, Wimg, O, K, 0))
-                    self._packs.append((W, WTimg, K, O, 1))
+                    self._packs.append((W, Wimg, O, K, 0 | ((1 << 1) if tiled else 0)))
+                    self._packs.append((W, WTimg, K, O, 1 | ((2 << 1) if tiled else 0)))
                     mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)
                 else:
                     mod._stack[kind] = (W, b, dW, db)
@@ -129,10 +159,28 @@ class ParamArena(FlatGradBucket):
         return all(p.data.untyped_storage().data_ptr() == base_p and p.grad is not None
                    and p.grad.untyped_storage().data_ptr() == base_g for p in self.params)
 
+    @property
+    def exchange(self):
+        """dist.GradExchange over this arena (built on first use, once a process group with > 1 rank exists)."""
+        from . import dist as gdist
+        if self._exchange is None and gdist.is_distributed():
+            self._exchange = gdist.GradExchange(self.flat, self.flat_param, self.big_start)
+        return self._exchange
+
+    def sharded(self):
+        """True when the big bucket is exchanged by reduce-scatter: the optimizer must then update the small bucket
+        and this rank's shard only, and call exchange.gather_params()."""
+        ex = self.exchange
+        return ex is not None and ex.has_big
+
     def all_reduce_mean(self):
         from .ops import join_side_streams
         join_side_streams()  # the side-stream weight gradients must have landed in the arena
-        super().all_reduce_mean()
+        ex = self.exchange
+        if ex is None:
+            return
+        ex.reduce_small()
+        ex.reduce_big()
 
     def zero(self):
         from .ops import join_side_streams

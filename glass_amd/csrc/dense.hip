@@ -19,6 +19,7 @@
 // staged once per workgroup in LDS, pre-permuted into consumption order (see WStage).  Supported hidden
 // sizes: 64, 128, 192 (256: weight images exceed the LDS budget -> library GEMM + stand-alone mix).
 #include "common.h"
+#include "dense_common.h"
 
 #include <stdlib.h>
 
@@ -184,15 +185,6 @@ __device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* 
 // (saved[4C] = mean, rstd, scale, shift); the lanes normalise (+ ELU + dropout) their chunk while loading it, use
 // it as the MFMA operand and write it to `side` (the layer's backward and, for the trans pair, the comb pair of the
 // same layer read it) — the GraphNorm apply launch and its read of xa disappear.
-struct GnPrologue {
-    const float* saved;  // nullptr: no prologue
-    int C, act;
-    Drop drop;
-    const uint64_t* rng_state;
-    float* side;
-    int64_t lds;
-};
-
 struct FwdRaw {
     float x[kKC];
     float4 sc[kKC / 4], sh[kKC / 4];  // GraphNorm scale / shift of this chunk's columns (prologue lanes only)
@@ -368,14 +360,6 @@ struct DgradRaw {
 // that GraphNorm — S1 = sum g, S2 = sum g*xhat with g = dy * dropmask * act'(x*scale + shift) — are accumulated here
 // from the tile in registers plus one read of the GraphNorm input x, instead of by a statistics launch re-reading
 // dy and x.  partial[blockIdx.x][2][H] doubles, consumed by glass_graphnorm_bwd_from_stats_f32.
-struct GnBwdStats {
-    double* partial;  // nullptr: off
-    const float* x; int64_t ldx;
-    const float *saved, *alpha;
-    int act;
-    Drop drop;
-};
-
 // ---- backward data gradient ---------------------------------------------------------------------
 // out[N, NT] = dZ[N, 2H] @ Wstack[2H, NT] (+ addend), dZ[n, o] = coef(n, o<H) * dsrc[n, o mod H] * act'(T[n, o]);
 // WT = Wstack^T stored [NT][2H] so that weight chunks are contiguous (refreshed once per step).
@@ -529,30 +513,38 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(const float
 struct PackJob {
     const float* src;
     float* dst;
-    int NT, KT, transposed;
+    int NT, KT, transposed, layout;
 };
 constexpr int kMaxPackJobs = 16;
 struct PackBatch {
     PackJob job[kMaxPackJobs];
 };
 
+__device__ __forceinline__ float4 pack_fetch(const PackJob& j, int n, int k) {
+    if (!j.transposed) return *reinterpret_cast<const float4*>(j.src + (int64_t)n * j.KT + k);
+    return make_float4(j.src[(int64_t)k * j.NT + n], j.src[(int64_t)(k + 1) * j.NT + n], j.src[(int64_t)(k + 2) * j.NT + n],
+                       j.src[(int64_t)(k + 3) * j.NT + n]);
+}
+
 __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state) {
     if (rng_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rng_state[1] += 1;  // see glass_rng_advance
     const PackJob j = batch.job[blockIdx.y];
-    const int KQ = j.KT / 4, NTILES = j.NT / 16, NKC = KQ / kKC;
-    const int total = NKC * NTILES * 4 * 64;  // float4 elements
-    for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
-        const int lane = l & 63, v = (l >> 6) & 3, t = (l >> 8) % NTILES, kc = (l >> 8) / NTILES;
-        const int jj = lane & 15, q = lane >> 4;
-        const int n = tile_col(t, jj), k = q * KQ + kc * kKC + 4 * v;
-        float4 o;
-        if (!j.transposed) {
-            o = *reinterpret_cast<const float4*>(j.src + (int64_t)n * j.KT + k);
-        } else {
-            o = make_float4(j.src[(int64_t)k * j.NT + n], j.src[(int64_t)(k + 1) * j.NT + n],
-                            j.src[(int64_t)(k + 2) * j.NT + n], j.src[(int64_t)(k + 3) * j.NT + n]);
+    const int total = j.NT * j.KT / 4;  // float4 elements
+    if (j.layout == kLayoutWave16) {
+        const int KQ = j.KT / 4, NTILES = j.NT / 16;
+        for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
+            const int lane = l & 63, v = (l >> 6) & 3, t = (l >> 8) % NTILES, kc = (l >> 8) / NTILES;
+            const int jj = lane & 15, q = lane >> 4;
+            reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tile_col(t, jj), q * KQ + kc * kKC + 4 * v);
         }
-        reinterpret_cast<float4*>(j.dst)[l] = o;
+        return;
+    }
+    // tiled layouts (dense_tiled.hip): dst[((ct * NKS + ks) * 4 + q) * 256 + nl] (float4) = B[tiled_col(ct, nl)][16 ks + 4 q ..+3]
+    const int NKS = j.KT / 16, H = j.NT / 2;  // H only meaningful for the paired layout (NT = 2H)
+    for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
+        const int nl = l & 255, q = (l >> 8) & 3, tile = l >> 10;
+        const int ct = tile / NKS, ks = tile % NKS;
+        reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tiled_col(j.layout, ct, nl, H), 16 * ks + 4 * q);
     }
 }
 
@@ -566,29 +558,24 @@ static void allow_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-static bool dense_shape_ok(int64_t H) { return H == 64 || H == 128 || H == 256; }
+static bool wave16_shape_ok(int64_t H) { return H == 64 || H == 128; }
+static bool dense_shape_ok(int64_t H) { return wave16_shape_ok(H) || tiled_shape_ok(H); }
 static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at once (see WBuf)
     const size_t image = (size_t)NT * 256;
     return (n_pass > 1 && 2 * image <= (size_t)kLdsBudget) ? 2 * image : image;
 }
 
 // Policy: hidden 64 (one wave group per 64 rows) and hidden 128 (two wave groups splitting the output columns, 512
-// threads: without the split the 16 accumulator tiles + staging spilled and the path lost to hipBLASLt + the
-// stand-alone mix kernels, 1.38 vs 1.18 ms on em_user-shape; with it the step program takes that shape from 1.04 to
-// 0.85 ms).  GLASS_DENSE_H128=0 turns hidden 128 off for A/B runs.
-// Hidden 256 is built and parity-tested (2 row waves x 4 column groups, one 128 KiB weight image in LDS at a time)
-// but OFF: the compiler keeps the 64 staging registers of the next image in scratch across the MFMA pass, and at
-// C5 (N = 1 M) the step takes 121 ms against 74 ms on the library-GEMM path.  GLASS_DENSE_H256=1 enables it; it
-// needs a K-pass of 32 (64 KiB images, double-buffered, 8 staging registers) to be worth it.
-extern "C" int glass_dual_linear_supported(int64_t H) {
-    static const bool h128 = !(getenv("GLASS_DENSE_H128") && atoi(getenv("GLASS_DENSE_H128")) == 0);
-    static const bool h256 = getenv("GLASS_DENSE_H256") && atoi(getenv("GLASS_DENSE_H256")) == 1;
-    return (H == 64 || (h128 && H == 128) || (h256 && H == 256)) ? 1 : 0;
-}
+// threads) on the wave-owns-16-rows kernels of this file; hidden 256 / 512 on the LDS-tiled kernels of dense_tiled.hip.
+// (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
+extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
 
-// rows per workgroup = rows per epilogue statistics partial: 64 (hidden 64 / 128), 32 (hidden 256: 2 row waves x 4
-// column groups, 512 threads, so that a wave may use more than 128 registers)
-extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return H == 256 ? 32 : 64; }
+// Operand-image layout glass_dense_pack_batch_f32 must produce for hidden size H: 0 = wave16 images (forward and data
+// gradient alike), 1 = tiled (forward operand: paired layout; data-gradient operand: plain layout)
+extern "C" int glass_dual_linear_layout(int64_t H) { return tiled_shape_ok(H) ? 1 : 0; }
+
+// rows per workgroup = rows per epilogue statistics partial
+extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return tiled_shape_ok(H) ? kTiledRows : 64; }
 
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
@@ -602,7 +589,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
                                 (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
                   "dual_linear_fwd: bad GraphNorm prologue arguments");
     if (!dense_shape_ok(H)) {
-        set_error("dual_linear_fwd: hidden size %lld not supported (64, 128, 256)", (long long)H);
+        set_error("dual_linear_fwd: hidden size %lld not supported (64, 128, 256, 512)", (long long)H);
         return GLASS_E_UNSUPPORTED;
     }
     const bool comb = xb != nullptr;
@@ -616,6 +603,8 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs > 1 pass and both fit)
     const size_t lds_comb = lds_bytes(2 * H, (int)(2 * H / 64)), lds_trans = lds_bytes(2 * H, (int)(H / 64));
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
+    if (tiled_shape_ok(H))
+        return launch_tiled_fwd(xa, lda, xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, H, stats, pro, st);
 #define GLASS_FWD(HH, CS, RW)                                                                                      \
     if (H == HH) {                                                                                                 \
         allow_lds(dual_fwd_kernel<HH, true, CS, RW>, lds_comb);                                                    \
@@ -627,7 +616,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
             hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS, RW>), grid, dim3(kWave * RW * CS), lds_trans, st, xa, lda, \
                                xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
     }
-    GLASS_FWD(64, 1, 4) GLASS_FWD(128, 2, 4) GLASS_FWD(256, 4, 2)
+    GLASS_FWD(64, 1, 4) GLASS_FWD(128, 2, 4)
 #undef GLASS_FWD
     return launch_status("glass_dual_linear_fwd_f32");
 }
@@ -662,6 +651,9 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                   "dual_linear_dgrad: bad GraphNorm statistics arguments");
     const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                         make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
+    if (tiled_shape_ok(H))
+        return launch_tiled_dgrad(dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, n_out, addend, ldadd, drop, rng_state, out,
+                                  ldo, n_nodes, H, gs, st);
 #define GLASS_DG(HH, CS, RW)                                                                                       \
     if (H == HH) {                                                                                                 \
         allow_lds(dual_dgrad_kernel<HH, HH, CS, RW>, lds_dg);                                                      \
@@ -675,7 +667,7 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                                ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo,     \
                                n_nodes, gs);                                                                       \
     }
-    GLASS_DG(64, 1, 4) GLASS_DG(128, 2, 4) GLASS_DG(256, 4, 2)
+    GLASS_DG(64, 1, 4) GLASS_DG(128, 2, 4)
 #undef GLASS_DG
     return launch_status("glass_dual_linear_dgrad_f32");
 }
@@ -687,12 +679,15 @@ extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const*
                   "dense_pack_batch: bad arguments (at most %d matrices per call)", kMaxPackJobs);
     if (n_jobs == 0) return rng_state ? glass_rng_advance(rng_state, stream) : 0;
     PackBatch b;
-    for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0};
+    for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0, 0};
     for (int k = 0; k < n_jobs; ++k) {
         GLASS_REQUIRE(src[k] && dst[k] && NT[k] > 0 && NT[k] % 64 == 0 && KT[k] > 0 && KT[k] % 64 == 0 && aligned16(src[k]) &&
                           aligned16(dst[k]),
                       "dense_pack_batch: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", k);
-        b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k]};
+        const int layout = transposed[k] >> 1;
+        GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0),
+                      "dense_pack_batch: job %d: unknown layout %d or NT not a multiple of 256 for a tiled layout", k, layout);
+        b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout};
     }
     hipLaunchKernelGGL(pack_batch_kernel, dim3(32, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream, b,
                        rng_state);

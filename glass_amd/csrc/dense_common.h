@@ -1,0 +1,61 @@
+// Pieces shared by the two families of fused dense kernels: dense.hip (16x16x4 MFMA, a wave owns 16 rows and all
+// output columns: small graphs, hidden 64 / 128) and dense_tiled.hip (LDS-tiled 32x32x2 MFMA GEMM: hidden 256 / 512).
+#pragma once
+#include "common.h"
+
+namespace glass {
+
+// Optional GraphNorm prologue on the xa operand of the forward kernels: xa is the INPUT of a GraphNorm whose statistics
+// are already final (saved[4C] = mean, rstd, scale, shift); the kernel normalises (+ ELU + dropout) its operand while
+// staging it, uses it as the MFMA operand and writes it to `side` (the layer's backward and, for the trans pair, the
+// comb pair of the same layer read it) — the GraphNorm apply launch and its read of xa disappear.
+struct GnPrologue {
+    const float* saved;  // nullptr: no prologue
+    int C, act;
+    Drop drop;
+    const uint64_t* rng_state;
+    float* side;
+    int64_t lds;
+};
+
+// Optional epilogue of the data-gradient kernels: their first H output columns are the gradient dy of a GraphNorm
+// OUTPUT (conv.gn's for the comb pair, gns[l]'s for the next layer's trans pair), so the two backward column sums of
+// that GraphNorm — S1 = sum g, S2 = sum g*xhat with g = dy * dropmask * act'(x*scale + shift) — are accumulated here
+// from the tile in registers plus one read of the GraphNorm input x, instead of by a statistics launch re-reading
+// dy and x.  partial[row tile][2][H] doubles, consumed by glass_graphnorm_bwd_from_stats_f32.
+struct GnBwdStats {
+    double* partial;  // nullptr: off
+    const float* x; int64_t ldx;
+    const float *saved, *alpha;
+    int act;
+    Drop drop;
+};
+
+// Operand-image layouts written by glass_dense_pack_batch_f32 (bits 1.. of its per-job flags; bit 0 = transposed source)
+enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2 };
+
+// dense_tiled.hip
+bool tiled_shape_ok(int64_t H);
+constexpr int kTiledRows = 128;  // rows per workgroup = rows per statistics partial of the tiled kernels
+int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
+                     const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,
+                     int64_t N, int64_t H, double* stats, const GnPrologue& pro, hipStream_t st);
+int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, float zr,
+                       float omz, int act, const float* WTimg, int64_t n_out, const float* addend, int64_t ldadd,
+                       const Drop& drop, const uint64_t* rng_state, float* out, int64_t ldo, int64_t N, int64_t H,
+                       const GnBwdStats& gs, hipStream_t st);
+// image element source of the tiled layouts (used by the pack kernel): output column of image slot nl of column tile ct
+__host__ __device__ inline int tiled_col(int layout, int ct, int nl, int H) {
+    const int wn = nl >> 7, cb = (nl >> 5) & 3, j = nl & 31;
+    if (layout == kLayoutTiledPaired) {
+        // a wave's 128 slots = 64 columns of the f1 half (cb 0,1) + the SAME 64 columns of the f0 half (cb 2,3), so the
+        // label mix of the forward epilogue is register-local; slot (cb, j) <-> column 2j + (cb & 1): a lane holds two
+        // consecutive columns -> 8-byte stores, 256 contiguous bytes per row and half-wave
+        const int c = ct * 128 + wn * 64 + 2 * j + (cb & 1);
+        return (cb >> 1) ? H + c : c;
+    }
+    // plain: slot (cb, j) <-> column 4j + cb: a lane holds four consecutive columns -> 16-byte stores
+    return ct * 256 + wn * 128 + 4 * j + cb;
+}
+
+}  // namespace glass

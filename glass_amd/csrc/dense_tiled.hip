@@ -1,0 +1,435 @@
+// K5t: the dense half of GLASSConv for WIDE layers on LARGE graphs (hidden 256 / 512: BASELINE config 5, N = 1 M):
+// the Linear pair + bias + ELU + label mix (forward, reference impl/models.py:158-162, 167-173) and its data
+// gradient as LDS-tiled GEMMs on the fp32 matrix cores, with the same fusions as dense.hip (GraphNorm apply + ELU +
+// dropout in the operand staging, GraphNorm statistics in the epilogue, dZ synthesised on the fly, no cat, no [N,2H]
+// gradient) — so config 5 runs the step program instead of library GEMMs + stand-alone mix / cat / GraphNorm passes.
+//
+// Why a second kernel family: dense.hip gives a wave 16 rows and ALL output columns (right where the graph is
+// small and every CU gets one row tile); at hidden 256 that is 32 accumulator tiles per wave and a 128 KiB weight
+// image per 64-deep K pass, restreamed for every 32 rows — it spilled and lost to hipBLASLt (121 vs 74 ms/step).
+// Here: workgroup tile 128 rows x 256 output columns, K step 16, v_mfma_f32_32x32x2_f32; 4 waves as 2 (rows) x 2
+// (columns), each 64 x 128 = 2 x 4 MFMA tiles = 128 accumulator registers; both operands go through LDS (double
+// buffered, 24 KiB per stage), so a weight byte is fetched once per 128 rows and an activation byte once per 256
+// output columns; 64 MFMAs (4 096 cycles per wave) per K step against 6 staging loads and 12 ds_read_b128.
+//
+// K assignment: the matrix core sums over k in any order, so lane (j = l & 31, h = l >> 5) feeds k = 16 ks + 8 h + s
+// at MFMA step s: its 8 values per K step are two contiguous 16-B groups of both operands (plane q = 2h + s/4 of the
+// LDS images) -> ds_read_b128 only, conflict-free.  Column assignment: which output column sits in which MFMA column
+// slot is a permutation chosen by the weight packing (tiled_col, dense_common.h): the forward pairs the f1 / f0
+// halves inside a wave, both kernels give a lane consecutive columns -> wide stores.
+#include "dense_common.h"
+
+namespace glass {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kTM = kTiledRows, kTN = 256, kTK = 16, kTThreads = 256;
+constexpr int kAPlane = kTM + 2;  // float4 per k-quad plane of the A image (+2: the 4 lanes that stage one row's 64 B
+                                  // land in 4 different bank groups; reads are per-row consecutive either way)
+constexpr int kBPlane = kTN;
+constexpr int kAImg = 4 * kAPlane, kBImg = 4 * kBPlane;  // float4 per stage
+constexpr int kStageVecs = kAImg + kBImg;                // 1 544 float4 = 24 704 B
+constexpr size_t kTiledLds = 2 * (size_t)kStageVecs * sizeof(float4);
+
+bool tiled_shape_ok(int64_t H) { return H == 256 || H == 512; }
+
+__device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
+
+// acc[rb][cb] += A(rows wm*64 + rb*32 ..) . B(slots wn*128 + cb*32 ..) over the 16 k of one stage
+__device__ __forceinline__ void tile_mma(f32x16 (&acc)[2][4], const float4* __restrict__ A, const float4* __restrict__ B,
+                                         int j, int h, int wm, int wn) {
+#pragma unroll
+    for (int sq = 0; sq < 2; ++sq) {
+        const int q = h * 2 + sq;
+        float4 a[2], b[4];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) a[rb] = A[q * kAPlane + wm * 64 + rb * 32 + j];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) b[cb] = B[q * kBPlane + wn * 128 + cb * 32 + j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[rb], e), f4e(b[cb], e), acc[rb][cb], 0, 0, 0);
+    }
+}
+
+// Workgroup -> (row tile, column tile).  Blocks are dealt round-robin over the 8 XCDs, so blocks b and b + 8 share an
+// L2: the NCT column tiles of one row tile are given ids 8 apart — the second one finds the activation rows in its
+// XCD's L2.  (Speed only; any placement is correct.)
+__device__ __forceinline__ bool tile_of_block(int nct, int n_rowtiles, int& rt, int& ct) {
+    const int b = blockIdx.x, grp = 8 * nct, r = b % grp;
+    ct = r / 8;
+    rt = (b / grp) * 8 + (r % 8);
+    return rt < n_rowtiles;
+}
+
+static inline unsigned tiled_grid(int64_t n_rowtiles, int nct) { return (unsigned)(ceil_div(n_rowtiles, 8) * 8 * nct); }
+
+// The weight stage: 1 024 float4, already in LDS order in the packed image
+struct BStage {
+    float4 v[4];
+    __device__ __forceinline__ void issue(const float4* __restrict__ img) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = img[threadIdx.x + kTThreads * i];
+    }
+    __device__ __forceinline__ void commit(float4* __restrict__ B) const {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) B[threadIdx.x + kTThreads * i] = v[i];
+    }
+};
+
+// ---- forward ----------------------------------------------------------------------------------------------------
+template <int H, bool COMB>
+__global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
+                                                                const float* __restrict__ xb, int64_t ldb,
+                                                                const float* __restrict__ Wimg,
+                                                                const float* __restrict__ bias,
+                                                                const uint8_t* __restrict__ mask, float zr, float omz,
+                                                                int act, float* __restrict__ T, int64_t ldt,
+                                                                float* __restrict__ out, int64_t ldo, int64_t N,
+                                                                double* __restrict__ stats, GnPrologue pro,
+                                                                int n_rowtiles) {
+    constexpr int KT = COMB ? 2 * H : H, NKS = KT / kTK, NCT = H / 128;
+    extern __shared__ float4 smem[];
+    int rt, ct;
+    if (!tile_of_block(NCT, n_rowtiles, rt, ct)) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)rt * kTM;
+    // staging assignment: float4 f = tid + 256 i of the A tile: row f >> 2, k-quad f & 3 (4 lanes cover one row's 64 B)
+    int srow[2], skq[2];
+    bool sok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + kTThreads * i;
+        srow[i] = f >> 2;
+        skq[i] = f & 3;
+        sok[i] = row0 + srow[i] < N;
+    }
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    const bool side_writer = pro.side != nullptr && ct == 0;  // every column tile computes the operand; one writes it
+    const float4* wimg = reinterpret_cast<const float4*>(Wimg) + (int64_t)ct * NKS * kBImg;
+
+    float4 av[2], asc[2], ash[2];
+    BStage bs;
+    auto issue = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = ks * kTK + 4 * skq[i];
+            const int64_t r = row0 + srow[i];
+            const float* src = (!COMB || k < H) ? xa + r * lda + k : xb + r * ldb + (k - H);
+            av[i] = sok[i] ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pro.saved && (!COMB || k < H)) {
+                asc[i] = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + k);
+                ash[i] = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + k);
+            }
+        }
+        bs.issue(wimg + (int64_t)ks * kBImg);
+    };
+    auto commit = [&](int ks, float4* stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = ks * kTK + 4 * skq[i];
+            float4 v = av[i];
+            if (pro.saved && (!COMB || k < H) && sok[i]) {
+                const int64_t r = row0 + srow[i];
+                float ds[4] = {1.f, 1.f, 1.f, 1.f};
+                if (drop.p > 0.f) drop_scales<4>(drop, r, k, ds);
+                float o[4] = {fmaf(v.x, asc[i].x, ash[i].x), fmaf(v.y, asc[i].y, ash[i].y), fmaf(v.z, asc[i].z, ash[i].z),
+                              fmaf(v.w, asc[i].w, ash[i].w)};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (pro.act == GLASS_ACT_ELU) o[e] = elu_f(o[e]);
+                    o[e] *= ds[e];
+                }
+                v = make_float4(o[0], o[1], o[2], o[3]);
+                if (side_writer) *reinterpret_cast<float4*>(pro.side + r * pro.lds + k) = v;
+            }
+            stage[skq[i] * kAPlane + srow[i]] = v;
+        }
+        bs.commit(stage + kAImg);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+    issue(0);
+    commit(0, smem);
+    __syncthreads();
+    for (int ks = 0; ks < NKS; ++ks) {
+        float4* cur = smem + (ks & 1) * kStageVecs;
+        float4* nxt = smem + ((ks + 1) & 1) * kStageVecs;
+        if (ks + 1 < NKS) issue(ks + 1);  // in flight across this stage's MFMAs
+        tile_mma(acc, cur, cur + kAImg, j, h, wm, wn);
+        if (ks + 1 < NKS) commit(ks + 1, nxt);  // the other buffer: last read in stage ks - 1, before the previous barrier
+        __syncthreads();
+    }
+
+    // epilogue: acc[rb][cb][i] = row rt*128 + wm*64 + rb*32 + 8(i>>2) + 4h + (i&3); cb 0,1: f1 columns colp, colp+1;
+    // cb 2,3: the same two columns of the f0 half
+    const int colp = ct * 128 + wn * 64 + 2 * j;
+    const float2 b1 = *reinterpret_cast<const float2*>(bias + colp);
+    const float2 b0 = *reinterpret_cast<const float2*>(bias + H + colp);
+    double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;  // column sums of `out` over this lane's rows (GraphNorm that follows)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t r = row0 + wm * 64 + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            if (r < N) {
+                const bool lab = mask[r] != 0;
+                const float w1 = lab ? zr : omz, w0 = lab ? omz : zr;
+                const float v1x = acc[rb][0][i] + b1.x, v1y = acc[rb][1][i] + b1.y;
+                const float v0x = acc[rb][2][i] + b0.x, v0y = acc[rb][3][i] + b0.y;
+                if (T) {
+                    *reinterpret_cast<float2*>(T + r * ldt + colp) = make_float2(v1x, v1y);
+                    *reinterpret_cast<float2*>(T + r * ldt + H + colp) = make_float2(v0x, v0y);
+                }
+                float a1x = v1x, a1y = v1y, a0x = v0x, a0y = v0y;
+                if (act == GLASS_ACT_ELU) {
+                    a1x = elu_fast_f(a1x); a1y = elu_fast_f(a1y); a0x = elu_fast_f(a0x); a0y = elu_fast_f(a0y);
+                }
+                const float ox = w1 * a1x + w0 * a0x, oy = w1 * a1y + w0 * a0y;
+                *reinterpret_cast<float2*>(out + r * ldo + colp) = make_float2(ox, oy);
+                s0 += (double)ox; q0 += (double)ox * (double)ox;
+                s1 += (double)oy; q1 += (double)oy * (double)oy;
+            }
+        }
+    if (stats == nullptr) return;
+    // stats[rt][2][H]: sum / sum of squares of this row tile, columns of this column tile (fp64 from the first add)
+    s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+    double* red = reinterpret_cast<double*>(smem);  // [wm][128 columns][2]; the last barrier of the loop freed the stages
+    if (h == 0) {
+        const int c = wn * 64 + 2 * j;
+        red[(wm * 128 + c) * 2] = s0; red[(wm * 128 + c) * 2 + 1] = q0;
+        red[(wm * 128 + c + 1) * 2] = s1; red[(wm * 128 + c + 1) * 2 + 1] = q1;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        const double s = red[tid * 2] + red[(128 + tid) * 2], q = red[tid * 2 + 1] + red[(128 + tid) * 2 + 1];
+        stats[((size_t)rt * 2) * H + ct * 128 + tid] = s;
+        stats[((size_t)rt * 2 + 1) * H + ct * 128 + tid] = q;
+    }
+}
+
+// ---- backward data gradient ---------------------------------------------------------------------------------------
+// out[N, NOUT] = dZ[N, 2H] @ Wstack[2H, NOUT] (+ addend)(* dropout mask), dZ[n, o] = coef(n, o < H) * dsrc[n, o mod H]
+// * act'(T[n, o]) synthesised while staging; WTimg = Wstack^T packed plain-tiled.
+template <int H, int NOUT>
+__global__ __launch_bounds__(kTThreads, 2) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
+                                                                  const float* __restrict__ T, int64_t ldt,
+                                                                  const uint8_t* __restrict__ mask, float zr, float omz,
+                                                                  int act, const float* __restrict__ WTimg,
+                                                                  const float* __restrict__ addend, int64_t ldadd,
+                                                                  Drop drop, const uint64_t* __restrict__ rng_state,
+                                                                  float* __restrict__ out, int64_t ldo, int64_t N,
+                                                                  GnBwdStats gs, int n_rowtiles) {
+    constexpr int KT = 2 * H, NKS = KT / kTK, NCT = NOUT / kTN;
+    static_assert(NOUT % kTN == 0, "output width must be a multiple of the column tile");
+    extern __shared__ float4 smem[];
+    int rt, ct;
+    if (!tile_of_block(NCT, n_rowtiles, rt, ct)) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
+    const int64_t row0 = (int64_t)rt * kTM;
+    int srow[2], skq[2];
+    bool sok[2], slab[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = tid + kTThreads * i;
+        srow[i] = f >> 2;
+        skq[i] = f & 3;
+        sok[i] = row0 + srow[i] < N;
+        slab[i] = sok[i] && mask[row0 + srow[i]] != 0;
+    }
+    const float4* wimg = reinterpret_cast<const float4*>(WTimg) + (int64_t)ct * NKS * kBImg;
+    float4 dv[2], tv[2];
+    BStage bs;
+    auto issue = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = ks * kTK + 4 * skq[i];  // column of dZ
+            const int64_t r = row0 + srow[i];
+            dv[i] = sok[i] ? *reinterpret_cast<const float4*>(dsrc + r * ldd + (o < H ? o : o - H)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (act == GLASS_ACT_ELU)
+                tv[i] = sok[i] ? *reinterpret_cast<const float4*>(T + r * ldt + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        bs.issue(wimg + (int64_t)ks * kBImg);
+    };
+    auto commit = [&](int ks, float4* stage) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int o = ks * kTK + 4 * skq[i];
+            const float coef = sok[i] ? ((slab[i] == (o < H)) ? zr : omz) : 0.f;
+            float4 v = make_float4(dv[i].x * coef, dv[i].y * coef, dv[i].z * coef, dv[i].w * coef);
+            if (act == GLASS_ACT_ELU) {
+                v.x *= elu_grad_f(tv[i].x); v.y *= elu_grad_f(tv[i].y); v.z *= elu_grad_f(tv[i].z); v.w *= elu_grad_f(tv[i].w);
+            }
+            stage[skq[i] * kAPlane + srow[i]] = v;
+        }
+        bs.commit(stage + kAImg);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
+
+    issue(0);
+    commit(0, smem);
+    __syncthreads();
+    for (int ks = 0; ks < NKS; ++ks) {
+        float4* cur = smem + (ks & 1) * kStageVecs;
+        float4* nxt = smem + ((ks + 1) & 1) * kStageVecs;
+        if (ks + 1 < NKS) issue(ks + 1);
+        tile_mma(acc, cur, cur + kAImg, j, h, wm, wn);
+        if (ks + 1 < NKS) commit(ks + 1, nxt);
+        __syncthreads();
+    }
+
+    // epilogue: this lane's four consecutive output columns col4 .. col4 + 3 (cb = 0..3) of 32 rows
+    const int col4 = ct * kTN + wn * 128 + 4 * j;
+    if (drop.p > 0.f) {
+        drop.seed = rng_state[0];
+        drop.step = rng_state[1];
+    }
+    const bool gn_half = gs.partial != nullptr && col4 < H;  // wave-uniform (H is a multiple of 128)
+    float4 g_mu, g_rstd, g_scale, g_shift, g_al;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (gn_half) {
+        if (gs.drop.p > 0.f) {
+            gs.drop.seed = rng_state[0];
+            gs.drop.step = rng_state[1];
+        }
+        g_mu = *reinterpret_cast<const float4*>(gs.saved + col4);
+        g_rstd = *reinterpret_cast<const float4*>(gs.saved + H + col4);
+        g_scale = *reinterpret_cast<const float4*>(gs.saved + 2 * H + col4);
+        g_shift = *reinterpret_cast<const float4*>(gs.saved + 3 * H + col4);
+        g_al = *reinterpret_cast<const float4*>(gs.alpha + col4);
+    }
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int64_t r = row0 + wm * 64 + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            if (r < N) {
+                float4 v = make_float4(acc[rb][0][i], acc[rb][1][i], acc[rb][2][i], acc[rb][3][i]);
+                if (addend) {
+                    const float4 ad = *reinterpret_cast<const float4*>(addend + r * ldadd + col4);
+                    v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                }
+                if (drop.p > 0.f) {  // gradient w.r.t. the pre-dropout tensor: same mask as the forward drew
+                    float ds[4];
+                    drop_scales<4>(drop, r, col4, ds);
+                    v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
+                }
+                *reinterpret_cast<float4*>(out + r * ldo + col4) = v;
+                if (gn_half) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(gs.x + r * gs.ldx + col4);
+                    float ds[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (gs.drop.p > 0.f) drop_scales<4>(gs.drop, r, col4, ds);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float gp = f4e(v, e) * ds[e];
+                        if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(f4e(x4, e), f4e(g_scale, e), f4e(g_shift, e)));
+                        const float xhat = (f4e(x4, e) - f4e(g_al, e) * f4e(g_mu, e)) * f4e(g_rstd, e);
+                        s1[e] += (double)gp;
+                        s2[e] += (double)gp * (double)xhat;
+                    }
+                }
+            }
+        }
+    if (gs.partial == nullptr) return;
+    // partial[rt][2][H] over this row tile: lanes h = 0/1, then the two row waves through LDS
+    double* red = reinterpret_cast<double*>(smem);  // [wm][256 columns][2]
+    if (gn_half) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            s1[e] += __shfl_xor(s1[e], 32);
+            s2[e] += __shfl_xor(s2[e], 32);
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = wn * 128 + 4 * j + e;
+                red[(wm * 256 + c) * 2] = s1[e];
+                red[(wm * 256 + c) * 2 + 1] = s2[e];
+            }
+        }
+    }
+    __syncthreads();
+    const int c = ct * kTN + tid;  // 256 threads <-> the 256 columns of this tile
+    if (c < H) {
+        gs.partial[((size_t)rt * 2) * H + c] = red[tid * 2] + red[(256 + tid) * 2];
+        gs.partial[((size_t)rt * 2 + 1) * H + c] = red[tid * 2 + 1] + red[(256 + tid) * 2 + 1];
+    }
+}
+
+template <typename K>
+static void allow_tiled_lds(K kernel) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTiledLds);
+}
+
+int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
+                     const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,
+                     int64_t N, int64_t H, double* stats, const GnPrologue& pro, hipStream_t st) {
+    const int64_t n_rt = ceil_div(N, kTM);
+    const bool comb = xb != nullptr;
+#define GLASS_TFWD(HH)                                                                                               \
+    if (H == HH) {                                                                                                   \
+        const dim3 grid(tiled_grid(n_rt, HH / 128));                                                                 \
+        if (comb) {                                                                                                  \
+            allow_tiled_lds(tiled_fwd_kernel<HH, true>);                                                             \
+            hipLaunchKernelGGL((tiled_fwd_kernel<HH, true>), grid, dim3(kTThreads), kTiledLds, st, xa, lda, xb, ldb, Wimg, \
+                               bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
+        } else {                                                                                                     \
+            allow_tiled_lds(tiled_fwd_kernel<HH, false>);                                                            \
+            hipLaunchKernelGGL((tiled_fwd_kernel<HH, false>), grid, dim3(kTThreads), kTiledLds, st, xa, lda, xb, ldb, Wimg, \
+                               bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
+        }                                                                                                            \
+    }
+    GLASS_TFWD(256) GLASS_TFWD(512)
+#undef GLASS_TFWD
+    return launch_status("glass_dual_linear_fwd_f32 (tiled)");
+}
+
+int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, float zr,
+                       float omz, int act, const float* WTimg, int64_t n_out, const float* addend, int64_t ldadd,
+                       const Drop& drop, const uint64_t* rng_state, float* out, int64_t ldo, int64_t N, int64_t H,
+                       const GnBwdStats& gs, hipStream_t st) {
+    const int64_t n_rt = ceil_div(N, kTM);
+#define GLASS_TDG(HH)                                                                                                \
+    if (H == HH) {                                                                                                   \
+        if (n_out == H) {                                                                                            \
+            allow_tiled_lds(tiled_dgrad_kernel<HH, HH>);                                                             \
+            hipLaunchKernelGGL((tiled_dgrad_kernel<HH, HH>), dim3(tiled_grid(n_rt, HH / kTN)), dim3(kTThreads), kTiledLds, \
+                               st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, \
+                               N, gs, (int)n_rt);                                                                    \
+        } else {                                                                                                     \
+            allow_tiled_lds(tiled_dgrad_kernel<HH, 2 * HH>);                                                         \
+            hipLaunchKernelGGL((tiled_dgrad_kernel<HH, 2 * HH>), dim3(tiled_grid(n_rt, 2 * HH / kTN)), dim3(kTThreads),  \
+                               kTiledLds, st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop,     \
+                               rng_state, out, ldo, N, gs, (int)n_rt);                                               \
+        }                                                                                                            \
+    }
+    GLASS_TDG(256) GLASS_TDG(512)
+#undef GLASS_TDG
+    return launch_status("glass_dual_linear_dgrad_f32 (tiled)");
+}
+
+}  // namespace glass

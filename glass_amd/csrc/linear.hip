@@ -15,6 +15,7 @@
 // through LDS; workgroup partials are summed in fixed order by a second kernel (deterministic).
 // fp32 MFMA is an exact k-ordered fmaf chain, so numerics equal a plain fp32 reduction.
 #include "common.h"
+#include "wgrad_common.h"
 
 #include <stdlib.h>
 
@@ -29,21 +30,6 @@ constexpr int kMaxSlabs = 256;
 
 // idx of accumulator (t,u,reg,lane) in the permuted partial layout
 __device__ __forceinline__ int acc_index(int t, int u, int reg, int lane) { return ((t * 2 + u) * 16 + reg) * 64 + lane; }
-
-// SYNTH: G is not read but synthesised from the gradient of the mixed output (glass_dual_linear_wgrad_f32):
-//   G[n,o] = coef(mask[n], o<H) * dsrc[n, o mod H] * (act ? ELU'(T[n,o]) : 1),  O = 2H,
-// and X may be the virtual concatenation [X | X2] (each H wide) of the comb Linear's two inputs.
-struct WgradSynth {
-    const float* dsrc;   // [N,H]
-    int64_t ldd;
-    const float* T;      // [N,2H] pre-activations (act != 0)
-    int64_t ldt;
-    const uint8_t* mask;
-    float zr, omz;
-    int act, H;
-    const float* X2;     // second input half (may be null)
-    int64_t ldx2;
-};
 
 template <bool SYNTH>
 __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* __restrict__ G, int64_t ldg,
@@ -336,7 +322,12 @@ using namespace glass;
 extern "C" int64_t glass_linear_wgrad_ws_bytes(int64_t N, int64_t O, int64_t I) {
     if (N <= 0 || O <= 0 || I <= 0) return GLASS_E_ARG;
     const WgradGeom g = wgrad_geom(N, O, I);
-    return (g.part_w_floats + g.part_b_floats) * (int64_t)sizeof(float);
+    int64_t floats = g.part_w_floats + g.part_b_floats;
+    if (wgrad_tiled_shape(N, O, I)) {  // glass_dual_linear_wgrad_f32 takes the tiled kernel there: room for either geometry
+        const TiledWgradGeom t = wgrad_tiled_geom(N, O, I);
+        if (t.part_w_floats + t.part_b_floats > floats) floats = t.part_w_floats + t.part_b_floats;
+    }
+    return floats * (int64_t)sizeof(float);
 }
 
 extern "C" int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t ldx, int64_t N, int64_t O,
@@ -349,10 +340,10 @@ extern "C" int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* 
                   "(O=%lld I=%lld ldg=%lld ldx=%lld)", (long long)O, (long long)I, (long long)ldg, (long long)ldx);
         return GLASS_E_UNSUPPORTED;  // caller falls back to a library GEMM for odd shapes
     }
+    hipStream_t st = (hipStream_t)stream;
     const WgradGeom g = wgrad_geom(N, O, I);
     float* part_w = (float*)ws;
     float* part_b = part_w + g.part_w_floats;
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wgrad_partial_kernel<false>, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, G, ldg, X, ldx, N,
                        (int)O, (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr, WgradSynth{});
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st,
@@ -373,12 +364,23 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
         set_error("dual_linear_wgrad: needs H%%64==0 and aligned operands (H=%lld)", (long long)H);
         return GLASS_E_UNSUPPORTED;
     }
-    const WgradGeom g = wgrad_geom(N, O, I);
-    float* part_w = (float*)ws;
-    float* part_b = part_w + g.part_w_floats;
     hipStream_t st = (hipStream_t)stream;
     const WgradSynth sy{dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
                         act, (int)H, X2, ldx2};
+    if (wgrad_tiled_shape(N, O, I)) {  // wide layer on a large graph: LDS-tiled kernel (wgrad_tiled.hip)
+        if (ldx % 4 || !aligned16(X) || (X2 && (ldx2 % 4 || !aligned16(X2)))) {
+            set_error("dual_linear_wgrad: the tiled kernel needs ld %% 4 == 0 and 16-B aligned inputs");
+            return GLASS_E_UNSUPPORTED;
+        }
+        const TiledWgradGeom t = wgrad_tiled_geom(N, O, I);
+        float* pw = (float*)ws;
+        launch_tiled_wgrad_partial(X, ldx, N, O, I, sy, pw, (db || !dW) ? pw + t.part_w_floats : nullptr, st);
+        if (dW) launch_tiled_wgrad_reduce(pw, pw + t.part_w_floats, N, O, I, dW, lddw, db, accumulate, st);
+        return launch_status("glass_dual_linear_wgrad_f32 (tiled)");
+    }
+    const WgradGeom g = wgrad_geom(N, O, I);
+    float* part_w = (float*)ws;
+    float* part_b = part_w + g.part_w_floats;
     hipLaunchKernelGGL(wgrad_partial_kernel<true>, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X, ldx,
                        N, (int)O, (int)I, g.rows_per_slab, part_w, (db || !dW) ? part_b : nullptr, sy);
     if (dW)  // dW == NULL: partial sums only; the caller reduces later with glass_linear_wgrad_reduce_batch_f32
@@ -404,13 +406,21 @@ extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* c
             const int64_t j = j0 + k;
             GLASS_REQUIRE(ws[j] && dW[j] && N[j] > 0 && O[j] > 0 && I[j] > 0 && lddw[j] >= I[j],
                           "wgrad_reduce_batch: bad job %lld", (long long)j);
+            if (wgrad_tiled_shape(N[j], O[j], I[j])) {  // partials of the tiled kernel (what glass_dual_linear_wgrad_f32
+                                                        // writes at this shape): their own reduce launch
+                const TiledWgradGeom t = wgrad_tiled_geom(N[j], O[j], I[j]);
+                const float* pw = (const float*)ws[j];
+                launch_tiled_wgrad_reduce(pw, pw + t.part_w_floats, N[j], O[j], I[j], dW[j], lddw[j], db[j], accumulate[j], st);
+                continue;  // b.job[k] stays empty (ny * nz = 0: its blocks return at once)
+            }
             const WgradGeom g = wgrad_geom(N[j], O[j], I[j]);
             const float* part_w = (const float*)ws[j];
             b.job[k] = ReduceJob{part_w, part_w + g.part_w_floats, g.n_slabs, g.ny, g.nz, (int)O[j], (int)I[j],
                                  accumulate[j], dW[j], lddw[j], db[j]};
             if (g.ny * g.nz > max_chunks) max_chunks = g.ny * g.nz;
         }
-        hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((kTile + kOT) / 64, max_chunks, nj), dim3(kBlock), 0, st, b);
+        if (max_chunks > 0)
+            hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((kTile + kOT) / 64, max_chunks, nj), dim3(kBlock), 0, st, b);
     }
     return launch_status("glass_linear_wgrad_reduce_batch_f32");
 }

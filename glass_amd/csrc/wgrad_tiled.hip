@@ -1,0 +1,241 @@
+// K5w-t: weight / bias gradient of a stacked Linear pair for WIDE layers on LARGE graphs (hidden >= 256, BASELINE
+// config 5):  dW[o,i] (+)= sum_n G[n,o] * X[n,i],  db[o] (+)= sum_n G[n,o]   (autograd backward of nn.Linear at
+// reference impl/models.py:158-159, 169-170).
+//
+// linear.hip's kernel feeds the MFMAs straight from global memory with a 128 x 64 output tile per workgroup; at
+// O = I = 512 every G row is then re-read by 8 input tiles and every X row by 4 output tiles — 24.6 GB per launch at
+// N = 1 M, HBM-bound at 5.1 ms for 3.5 ms of matrix work (profiles/r02: 83 - 103 TF/s).  Here both operands go through
+// LDS: workgroup tile 128 outputs x 256 inputs (4 waves as 2 x 2, 128 accumulator registers each), 16 rows of the node
+// dimension per stage, double buffered: 12 GB per launch, and a stage's 64 MFMAs (4 096 cycles per wave) cover its
+// loads.  The LDS images are the plain row-major [16 rows][128 | 256] tiles (the node index IS the MFMA k index, so
+// staging is a straight 16-B copy and an MFMA operand is one ds_read_b32, consecutive lanes consecutive words).
+// Split over row slabs; slab partials are plain [128][256] tiles summed in slab order by the reduce kernel
+// (deterministic).  fp32 MFMA = exact k-ordered fmaf chain.
+#include "wgrad_common.h"
+
+namespace glass {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWO = 128, kWI = 256, kWK = 16, kWThreads = 256;
+constexpr int kWStage = kWK * (kWO + kWI);  // floats per stage: 6 144 = 24 KiB
+constexpr int kWTile = kWO * kWI;
+
+bool wgrad_tiled_shape(int64_t N, int64_t O, int64_t I) { return O >= 512 && O % kWO == 0 && I % kWI == 0 && N >= 65536; }
+
+TiledWgradGeom wgrad_tiled_geom(int64_t N, int64_t O, int64_t I) {
+    TiledWgradGeom g;
+    g.ny = (int)(I / kWI);
+    g.nz = (int)(O / kWO);
+    // about two resident workgroups per CU over all (slab, tile) pairs, slabs of whole 16-row stages, at most 256 slabs
+    int64_t slabs = ceil_div(512, (int64_t)g.ny * g.nz);
+    if (slabs > 256) slabs = 256;
+    int64_t rows = ceil_div(ceil_div(N, slabs), kWK) * kWK;
+    g.rows_per_slab = (int)rows;
+    g.n_slabs = (int)ceil_div(N, rows);
+    g.part_w_floats = (int64_t)g.n_slabs * g.ny * g.nz * kWTile;
+    g.part_b_floats = (int64_t)g.n_slabs * g.nz * kWO;
+    return g;
+}
+
+// One stage of raw loads in registers (issued a whole stage of MFMAs before they are needed) and their commit to LDS.
+struct StageCtx {
+    const float* G; int64_t ldg;
+    const float* xsrc; int64_t xld; int xcol;
+    int a_col; bool a_first;
+    int64_t r0, r1;
+    int tid;
+};
+
+template <bool SYNTH>
+struct WStageRegs {
+    float4 ga[2], ta[2], xb[4];
+    int mk[2];
+    bool alive[2];
+    __device__ __forceinline__ void issue(const StageCtx& c, const WgradSynth& sy, int step) {
+        const int64_t base = c.r0 + (int64_t)step * kWK;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int64_t n = base + ((c.tid + kWThreads * a) >> 5);
+            alive[a] = n < c.r1;
+            const int64_t nn = alive[a] ? n : c.r1 - 1;  // clamped: loads never wait on a predicate, zeroed at use
+            if (!SYNTH) {
+                ga[a] = *reinterpret_cast<const float4*>(c.G + nn * c.ldg + c.a_col);
+            } else {
+                ga[a] = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (c.a_first ? c.a_col : c.a_col - sy.H));
+                if (sy.act == GLASS_ACT_ELU) ta[a] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + c.a_col);
+                mk[a] = sy.mask[nn];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t n = base + ((c.tid + kWThreads * b) >> 6);
+            const int64_t nn = n < c.r1 ? n : c.r1 - 1;  // rows past the slab: the A operand is zero there
+            xb[b] = *reinterpret_cast<const float4*>(c.xsrc + nn * c.xld + c.xcol);
+        }
+    }
+    __device__ __forceinline__ void commit(const StageCtx& c, const WgradSynth& sy, float* stage, float4& bsum) const {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            float4 g = ga[a];
+            if (SYNTH) {
+                const float cf = ((mk[a] != 0) == c.a_first) ? sy.zr : sy.omz;
+                g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
+                if (sy.act == GLASS_ACT_ELU) {
+                    g.x *= elu_grad_f(ta[a].x); g.y *= elu_grad_f(ta[a].y); g.z *= elu_grad_f(ta[a].z); g.w *= elu_grad_f(ta[a].w);
+                }
+            }
+            if (!alive[a]) g = make_float4(0.f, 0.f, 0.f, 0.f);
+            bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+            reinterpret_cast<float4*>(stage)[c.tid + kWThreads * a] = g;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) reinterpret_cast<float4*>(stage + kWK * kWO)[c.tid + kWThreads * b] = xb[b];
+    }
+};
+
+template <bool SYNTH>
+__global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* __restrict__ G, int64_t ldg,
+                                                                  const float* __restrict__ X, int64_t ldx, int64_t N,
+                                                                  int rows_per_slab, float* __restrict__ part_w,
+                                                                  float* __restrict__ part_b, WgradSynth sy) {
+    extern __shared__ float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
+    const int o0 = blockIdx.z * kWO, i0 = blockIdx.y * kWI;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
+    const int64_t r1 = min(N, r0 + rows_per_slab);
+    const int n_steps = (int)((r1 - r0 + kWK - 1) / kWK);
+    // staging assignment.  A tile [16][128]: float4 f = tid + 256 a: row f >> 5, column quad f & 31 (a = 0, 1);
+    // B tile [16][256]: float4 f = tid + 256 b: row f >> 6, column quad f & 63 (b = 0..3).  The column quads are the
+    // same for every stage, so the bias partial of this thread's four outputs accumulates in registers.
+    const int a_col = o0 + 4 * (tid & 31);          // global output column of this thread's A quad
+    const bool a_first = a_col < sy.H;              // SYNTH: f1 half
+    const int b_col = i0 + 4 * (tid & 63);
+    const float* xsrc = X;
+    int64_t xld = ldx;
+    int xcol = b_col;
+    if (SYNTH && sy.X2 != nullptr && b_col >= sy.H) {  // second half of the virtual concatenation [X | X2]
+        xsrc = sy.X2;
+        xld = sy.ldx2;
+        xcol = b_col - sy.H;
+    }
+    WStageRegs<SYNTH> sr;
+    const StageCtx cx{G, ldg, xsrc, xld, xcol, a_col, a_first, r0, r1, tid};
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[rb][cb][k] = 0.f;
+
+    sr.issue(cx, sy, 0);
+    sr.commit(cx, sy, wsm, bsum);
+    __syncthreads();
+    for (int step = 0; step < n_steps; ++step) {
+        const float* cur = wsm + (step & 1) * kWStage;
+        float* nxt = wsm + ((step + 1) & 1) * kWStage;
+        if (step + 1 < n_steps) sr.issue(cx, sy, step + 1);
+        const float* A = cur + wm * 64 + j;
+        const float* B = cur + kWK * kWO + wn * 128 + j;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int k = 8 * h + s;  // node row of this stage fed by this lane half at MFMA step s
+            float av[2], bv[4];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) av[rb] = A[k * kWO + rb * 32];
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) bv[cb] = B[k * kWI + cb * 32];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb], bv[cb], acc[rb][cb], 0, 0, 0);
+        }
+        if (step + 1 < n_steps) sr.commit(cx, sy, nxt, bsum);
+        __syncthreads();
+    }
+
+    // partial tile, plain [128][256]: acc[rb][cb][k] = output wm*64 + rb*32 + 8(k>>2) + 4h + (k&3), input wn*128 + cb*32 + j
+    const int64_t tile_id = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    float* pw = part_w + tile_id * kWTile;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int o = wm * 64 + rb * 32 + 8 * (k >> 2) + 4 * h + (k & 3);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) pw[o * kWI + wn * 128 + cb * 32 + j] = acc[rb][cb][k];
+        }
+    if (blockIdx.y == 0 && part_b) {
+        // 8 threads (tid & 31 equal) hold partial bias sums of the same 4 outputs: combine through LDS in thread order
+        float4* red = reinterpret_cast<float4*>(wsm);  // the loop's last barrier freed the stages
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float4 s = red[tid];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                const float4 o = red[tid + 32 * r];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            *reinterpret_cast<float4*>(part_b + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * kWO + 4 * tid) = s;
+        }
+    }
+}
+
+// dW[o0 + r][i0 + c] (+)= sum over slabs, in slab order; one thread per 4 consecutive inputs.  grid (kWTile / 4 / 256 +
+// 1, ny * nz): the last x-block of an input-tile-0 chunk reduces the bias partials.
+__global__ __launch_bounds__(kWThreads) void tiled_wgrad_reduce_kernel(const float* __restrict__ part_w,
+                                                                      const float* __restrict__ part_b, int n_slabs,
+                                                                      int ny, float* __restrict__ dW, int64_t lddw,
+                                                                      float* __restrict__ db, int accumulate) {
+    const int chunk = blockIdx.y, z = chunk / ny, y = chunk % ny;
+    if (blockIdx.x == kWTile / 4 / kWThreads) {  // bias block
+        if (y != 0 || db == nullptr || threadIdx.x >= kWO) return;
+        const float* p = part_b + (int64_t)z * n_slabs * kWO + threadIdx.x;
+        float s = 0.f;
+        for (int b = 0; b < n_slabs; ++b) s += p[(int64_t)b * kWO];
+        float* d = db + z * kWO + threadIdx.x;
+        *d = accumulate ? *d + s : s;
+        return;
+    }
+    const int e = (blockIdx.x * kWThreads + threadIdx.x) * 4;  // element of the [128][256] tile
+    const float* p = part_w + (int64_t)chunk * n_slabs * kWTile + e;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < n_slabs; b += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = b + u < n_slabs ? *reinterpret_cast<const float4*>(p + (int64_t)(b + u) * kWTile) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    float* d = dW + (int64_t)(z * kWO + e / kWI) * lddw + y * kWI + e % kWI;
+    if (accumulate) {
+        d[0] += s.x; d[1] += s.y; d[2] += s.z; d[3] += s.w;
+    } else {
+        d[0] = s.x; d[1] = s.y; d[2] = s.z; d[3] = s.w;
+    }
+}
+
+void launch_tiled_wgrad_partial(const float* X, int64_t ldx, int64_t N, int64_t O, int64_t I, const WgradSynth& sy,
+                                float* part_w, float* part_b, hipStream_t st) {
+    const TiledWgradGeom g = wgrad_tiled_geom(N, O, I);
+    const size_t lds = 2 * (size_t)kWStage * sizeof(float);
+    const dim3 grid(g.n_slabs, g.ny, g.nz);
+    hipLaunchKernelGGL(tiled_wgrad_kernel<true>, grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N, g.rows_per_slab, part_w,
+                       part_b, sy);
+}
+
+void launch_tiled_wgrad_reduce(const float* part_w, const float* part_b, int64_t N, int64_t O, int64_t I, float* dW,
+                               int64_t lddw, float* db, int accumulate, hipStream_t st) {
+    const TiledWgradGeom g = wgrad_tiled_geom(N, O, I);
+    hipLaunchKernelGGL(tiled_wgrad_reduce_kernel, dim3(kWTile / 4 / kWThreads + 1, g.ny * g.nz), dim3(kWThreads), 0, st,
+                       part_w, part_b, g.n_slabs, g.ny, dW, lddw, db, accumulate);
+}
+
+}  // namespace glass

@@ -80,6 +80,79 @@ class FlatGradBucket:
             self.flat.div_(td.get_world_size())
 
 
+class GradExchange:
+    """The step's collective over a flat gradient buffer cut in two buckets:
+
+      small = flat[0:big_start]       layer / head parameters (0.2 - 3 MB): all-reduce(mean) — latency-bound
+      big   = flat[big_start:total]   embedding-sized gradients (`--use_nodeid`: the [N,H] table of
+                                      GLASSTest.py:153-157 — 25.6 MB at C4, 1 GB at C5): reduce-scatter(mean) ->
+                                      the optimizer updates only THIS rank's 1/world shard of the table -> all-gather
+                                      of the updated parameter shards.  Against a full all-reduce that is the same
+                                      bytes on each xGMI link for the gradient (reduce-scatter is its first half),
+                                      half of them replaced by parameters, and 1/world of the Adam work and state.
+
+    Works on any backend torch.distributed offers (RCCL in the product, gloo in the CPU tests).  `big` must be a multiple
+    of the world size (ParamArena pads).  Elementwise optimizers (Adam) do not care that a shard cuts through a row."""
+    def __init__(self, flat_grad, flat_param, big_start):
+        self.grad, self.param = flat_grad, flat_param
+        self.total = flat_grad.numel()
+        self.big_start = int(big_start)
+        self.world, self.rank = world_size(), rank()
+        big = self.total - self.big_start
+        if big % self.world:
+            raise ValueError(f"big bucket ({big} elements) must be a multiple of the world size {self.world}")
+        self.shard_len = big // self.world
+        self.shard_lo = self.big_start + self.rank * self.shard_len
+        self.shard_grad = torch.empty(self.shard_len, dtype=flat_grad.dtype, device=flat_grad.device) if big else None
+        self._inplace = td.get_backend() == "nccl"  # RCCL supports output = slice of input; gloo gets a staging copy
+
+    @property
+    def has_big(self):
+        return self.total > self.big_start
+
+    def _mean(self, t):
+        if td.get_backend() == "nccl":
+            return td.ReduceOp.AVG, None
+        return td.ReduceOp.SUM, self.world
+
+    def reduce_small(self):
+        if self.big_start == 0:
+            return
+        small = self.grad[:self.big_start]
+        op, div = self._mean(small)
+        td.all_reduce(small, op=op)
+        if div:
+            small.div_(div)
+
+    def reduce_big(self):
+        """-> shard_grad: this rank's slice of the mean gradient of the big bucket."""
+        if not self.has_big:
+            return None
+        big = self.grad[self.big_start:]
+        op, div = self._mean(big)
+        td.reduce_scatter_tensor(self.shard_grad, big, op=op)
+        if div:
+            self.shard_grad.div_(div)
+        return self.shard_grad
+
+    def shard_views(self, *flats):
+        """This rank's shard of other flat buffers laid out like the arena (parameters, optimizer state)."""
+        return tuple(f[self.shard_lo:self.shard_lo + self.shard_len] for f in flats)
+
+    def gather_params(self):
+        """After the optimizer has updated this rank's parameter shard: every rank receives every shard."""
+        if not self.has_big:
+            return
+        big = self.param[self.big_start:]
+        mine = self.param[self.shard_lo:self.shard_lo + self.shard_len]
+        td.all_gather_into_tensor(big, mine if self._inplace else mine.clone())
+
+    def payload_bytes(self):
+        es = self.grad.element_size()
+        return {"small_allreduce": self.big_start * es, "big_reduce_scatter": (self.total - self.big_start) * es,
+                "big_all_gather": (self.total - self.big_start) * es}
+
+
 def bucket_for(model):
     b = getattr(model, "_glass_grad_bucket", None)
     if b is None:

@@ -4,6 +4,8 @@ Every op here enqueues hand-written gfx950 kernels on torch's current HIP stream
 torch only supplies device memory, streams and the autograd tape.  There is no CPU path: a CPU
 tensor raises GlassHipError (the CPU restatement lives in oracle/ and is a checker only).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -356,8 +358,13 @@ def join_cols(buf, parts):
     return JoinColsFn.apply(buf, *parts)
 
 
+# A/B switches of the fused dense path per hidden size (the library itself keeps no state): GLASS_DENSE_H128=0 /
+# GLASS_DENSE_H256=0 send that width back to library GEMMs + stand-alone mix kernels.
+_DENSE_OFF = {h for h in (128, 256, 512) if os.environ.get(f"GLASS_DENSE_H{h}", "1") == "0"}
+
+
 def dual_linear_supported(H):
-    return bool(_lib.load().glass_dual_linear_supported(int(H)))
+    return int(H) not in _DENSE_OFF and bool(_lib.load().glass_dual_linear_supported(int(H)))
 
 
 class DualLinearMixFn(torch.autograd.Function):

@@ -15,6 +15,7 @@ class FlatAdam(torch.optim.Optimizer):
         self.exp_avg = torch.zeros_like(arena.flat)
         self.exp_avg_sq = torch.zeros_like(arena.flat)
         self.step_dev = torch.zeros(2, dtype=torch.int64, device=dev)  # (steps completed, kernel ticket)
+        self.step_dev_shard = torch.zeros(2, dtype=torch.int64, device=dev)  # the same for the sharded big bucket
         self.lr_dev = torch.full((1, ), float(lr), dtype=torch.float32, device=dev)
         self._lr_host = float(lr)
 
@@ -37,8 +38,25 @@ class FlatAdam(torch.optim.Optimizer):
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         a = self.arena
-        rc = _lib.load().glass_adam_step_f32(a.flat_param.data_ptr(), a.flat.data_ptr(), self.exp_avg.data_ptr(),
-                                             self.exp_avg_sq.data_ptr(), a.flat.numel(), self.lr_dev.data_ptr(),
-                                             g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"],
-                                             self.step_dev.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(rc, "glass_adam_step_f32")
+
+        def launch(param, grad, m, v, counter):
+            if param.numel() == 0:
+                return
+            rc = _lib.load().glass_adam_step_f32(param.data_ptr(), grad.data_ptr(), m.data_ptr(), v.data_ptr(), param.numel(),
+                                                 self.lr_dev.data_ptr(), g["betas"][0], g["betas"][1], g["eps"],
+                                                 g["weight_decay"], counter.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream)
+            _lib.check(rc, "glass_adam_step_f32")
+
+        if not a.sharded():
+            launch(a.flat_param, a.flat, self.exp_avg, self.exp_avg_sq, self.step_dev)
+            return
+        # data-parallel run with an embedding-sized bucket (dist.GradExchange): the small bucket holds the all-reduced
+        # mean gradient; of the big bucket this rank owns one shard (mean gradient in ex.shard_grad) — update both,
+        # then every rank receives every updated parameter shard.  Each region counts its own steps.
+        ex = a.exchange
+        s = a.big_start
+        launch(a.flat_param[:s], a.flat[:s], self.exp_avg[:s], self.exp_avg_sq[:s], self.step_dev)
+        p_sh, m_sh, v_sh = ex.shard_views(a.flat_param, self.exp_avg, self.exp_avg_sq)
+        launch(p_sh, ex.shard_grad, m_sh, v_sh, self.step_dev_shard)
+        ex.gather_params()

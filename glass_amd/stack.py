@@ -348,7 +348,9 @@ class StackProgram:
         return loss, logits
 
     # ---------------------------------------------------------------------------------------------
-    def backward(self, st, dout):
+    def backward(self, st, dout, tail_hook=None):
+        """tail_hook: called once every gradient except the embedding's and emb_gn's has been written (the data-parallel
+        step starts the all-reduce of the small gradient bucket there, beside the rest of this backward pass)."""
         emb = self.emb
         n, H, L, p = st["n"], st["H"], st["L"], st["p"]
         dev = st["mask"].device
@@ -400,6 +402,8 @@ class StackProgram:
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations
         _reduce_pending(pending)
+        if tail_hook is not None:
+            tail_hook()
         W, gn0 = emb.input_emb.weight, emb.emb_gn
         if "emb_table" in st:
             sel = st["emb_table"]
@@ -432,14 +436,15 @@ class StackProgram:
                 out += [lin.weight, lin.bias]
         return out
 
-    def loss_and_grads(self, x_flat, z, edge_index, edge_weight, pos, pool_mode, head, target, loss_mode, overwrite=False):
+    def loss_and_grads(self, x_flat, z, edge_index, edge_weight, pos, pool_mode, head, target, loss_mode, overwrite=False,
+                       tail_hook=None):
         """One training pass WITHOUT the autograd tape: forward, fused readout, backward; every parameter gradient
         (stack, final GraphNorm, head) is accumulated into the gradient arena — or, with overwrite=True, stored over
         whatever is there (no zero-fill of the arena needed when written_params() covers it).  Returns (loss, logits)."""
         with torch.no_grad():
             (loss, logits), st = self.forward(x_flat, z, edge_index, edge_weight, True,
                                               readout=(pos, pool_mode, head, target, loss_mode), acc=0 if overwrite else 1)
-            self.backward(st, None)
+            self.backward(st, None, tail_hook)
         return loss, logits
 
 
@@ -487,7 +492,7 @@ def _program(emb):
     return prog
 
 
-def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, overwrite=False):
+def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, overwrite=False, tail_hook=None):
     """(loss, logits) of model(x, ..., pos, z) under loss_fn, gradients accumulated in place (see step_supported).
     z = "pos": label the nodes listed in pos (what utils.MaxZOZ(x, pos) would mark) without materialising z."""
     emb = model.conv
@@ -505,7 +510,7 @@ def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, o
             raise ValueError("z must be a tensor, None or 'pos'")
         z = ("pos", pos)
     return prog.loss_and_grads(x_flat, z, edge_index, edge_weight, pos, model.pools[0].mode, model.preds[0], target,
-                               loss_fn.mode, overwrite)
+                               loss_fn.mode, overwrite, tail_hook)
 
 
 class StackFn(torch.autograd.Function):

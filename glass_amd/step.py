@@ -6,8 +6,12 @@ form, ~0.38 ms of GPU time), so eager launches are host-bound; every kernel in l
 caller's stream (no allocation, no sync, no memset / memcpy nodes), which makes the whole step capturable:
 labels -> forward -> loss -> backward -> [all-reduce] -> Adam.  Dropout masks still change every replay
 because the dropout (seed, step) pair lives in device memory and is advanced by a captured kernel.
-With more than one rank the collective stays outside the graph (captured forward/backward, eager RCCL
-all-reduce of the flat gradient arena on the same stream, eager fused Adam launch)."""
+With more than one rank the collectives stay outside the graph (captured forward/backward, eager RCCL exchange of
+the gradient arena, eager fused Adam launches).  The exchange is bucketed (dist.GradExchange): the small bucket
+(layer / head parameters) is all-reduced; an embedding-sized bucket (`--use_nodeid`) is reduce-scattered, Adam updates
+this rank's shard, and the updated parameter shards are all-gathered.  With such a bucket the backward pass is captured
+as TWO graphs cut where the small bucket becomes final, and its all-reduce runs on a second stream beside the rest of
+the backward (emb_gn + embedding gradient) and beside the big bucket's reduce-scatter."""
 import torch
 
 from . import dist as gdist
@@ -30,8 +34,11 @@ class TrainStep:
         self._pos = self._y = None
         self._loss = torch.zeros((), device=x.device)
         self._one = torch.ones((), device=x.device)
-        self._g_fb = self._g_opt = None
+        self._g_fb = self._g_tail = None
         self._split = False
+        self._comm_stream = None
+        self.time_collective = False   # bench.py: record HIP events around the exchange of the last steps
+        self._coll_events = []
 
     # -- the step body, split at the collective ---------------------------------------------------
     def _fused_head(self):
@@ -42,19 +49,25 @@ class TrainStep:
         return (isinstance(self.loss_fn, (losses.CrossEntropy, losses.BCEWithLogits)) and type(head) is nn.Linear and
                 head.bias is not None)
 
-    def _fwd_bwd(self):
+    def _program_step(self):
         from . import stack
-        if (self._fused_head() and hasattr(self.bucket, "flat_param") and self.x.dim() == 3 and
-                self.x.shape[1:] == (1, 1) and stack.step_supported(self.model, self.loss_fn)):
+        return (self._fused_head() and hasattr(self.bucket, "flat_param") and self.x.dim() == 3 and
+                self.x.shape[1:] == (1, 1) and stack.step_supported(self.model, self.loss_fn))
+
+    def _fwd_bwd(self, tail_hook=None):
+        from . import stack
+        if self._program_step():
             # whole step as one explicit program: no autograd tape, fused readout, labels straight from pos, and
             # — when the program writes every gradient of the arena — no zero-fill (glass_amd/stack.py)
             overwrite = stack.covers_arena(self.model, self.bucket)
             if not overwrite:
                 self.bucket.zero()
             loss, _logits = stack.loss_and_grads(self.model, self.loss_fn, self.x, self.ei, self.ew, self._pos, "pos",
-                                                 self._y, overwrite)
+                                                 self._y, overwrite, tail_hook)
             self._loss = loss
             return
+        if tail_hook is not None:
+            raise RuntimeError("tail_hook needs the step program")
         z = utils.MaxZOZ(self.x, self._pos)
         self.bucket.zero()
         if self._fused_head():
@@ -80,7 +93,7 @@ class TrainStep:
         snap = None
         if self.preserve_state and self.warmup_iters > 0:
             snap = (copy.deepcopy(self.model.state_dict()), copy.deepcopy(self.opt.state_dict()),
-                    {k: getattr(self.opt, k).clone() for k in ("exp_avg", "exp_avg_sq", "step_dev") if hasattr(self.opt, k)},
+                    {k: getattr(self.opt, k).clone() for k in ("exp_avg", "exp_avg_sq", "step_dev", "step_dev_shard") if hasattr(self.opt, k)},
                     ops.rng_state(self.x.device).clone())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -99,6 +112,12 @@ class TrainStep:
             ops.rng_state(self.x.device).copy_(snap[3])
             torch.cuda.synchronize()
 
+    def _overlap_small_bucket(self):
+        """The data-parallel step with an embedding-sized gradient bucket, on the step program: worth cutting the
+        backward where the small bucket is final."""
+        return (gdist.is_distributed() and hasattr(self.bucket, "sharded") and self.bucket.sharded() and
+                self._program_step())
+
     def _capture(self):
         dist_on = gdist.is_distributed()
         self._g_fb = torch.cuda.CUDAGraph()
@@ -106,14 +125,69 @@ class TrainStep:
             with torch.cuda.graph(self._g_fb):
                 self._fwd_bwd()
                 self.opt.step()
-        else:
+        elif not self._overlap_small_bucket():
             # the collective stays outside the graph; the optimizer is two launches, cheaper eager than a
             # second graph replay
             with torch.cuda.graph(self._g_fb):
                 self._fwd_bwd()
-            self._g_opt = None
+        else:
+            # two graphs sharing one memory pool, cut by the program's tail hook: [forward + backward down to the last
+            # layer / head gradient] | [emb_gn + embedding gradient]
+            self._g_tail = torch.cuda.CUDAGraph()
+            self._comm_stream = torch.cuda.Stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._g_fb.capture_begin()
+
+                def cut():
+                    self._g_fb.capture_end()
+                    self._g_tail.capture_begin(pool=self._g_fb.pool())
+                self._fwd_bwd(tail_hook=cut)
+                self._g_tail.capture_end()
+            torch.cuda.current_stream().wait_stream(side)
         self._split = dist_on
         self.graphed = True
+
+    def _exchange_and_update(self):
+        """Eager part of the data-parallel step, after the (first) graph: collectives + Adam."""
+        ev = None
+        if self.time_collective:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            ev[0].record()
+        if self._g_tail is not None:
+            main, comm = torch.cuda.current_stream(), self._comm_stream
+            ex = self.bucket.exchange
+            comm.wait_stream(main)             # the small bucket is final here
+            with torch.cuda.stream(comm):
+                ex.reduce_small()              # beside the tail of the backward pass ...
+            self._g_tail.replay()
+            ex.reduce_big()                    # ... and beside the big bucket's reduce-scatter
+            main.wait_stream(comm)
+        else:
+            self.bucket.all_reduce_mean()
+        if ev:
+            ev[1].record()
+        self.opt.step()
+        if ev:
+            ev[2].record()
+            self._coll_events = (self._coll_events + [ev])[-64:]
+
+    def collective_share(self):
+        """Mean device time of the exchange and of the optimizer part (Adam launches + parameter all-gather) over the
+        recorded steps, with the payload per step (bench.py --features nodeid)."""
+        if not self._coll_events:
+            return None
+        torch.cuda.synchronize()
+        red = [a.elapsed_time(b) * 1e3 for a, b, _ in self._coll_events]
+        upd = [b.elapsed_time(c) * 1e3 for _, b, c in self._coll_events]
+        out = {"exchange_us": sum(red) / len(red), "adam_and_gather_us": sum(upd) / len(upd), "steps_timed": len(red),
+               "overlapped_small_bucket": self._g_tail is not None}
+        ex = getattr(self.bucket, "exchange", None)
+        if ex is not None:
+            out["payload_bytes"] = ex.payload_bytes()
+            out["world"] = ex.world
+        return out
 
     def __call__(self, pos, y):
         if self._pos is None:
@@ -130,12 +204,13 @@ class TrainStep:
         if self.graphed:
             self._g_fb.replay()
             if self._split:
-                self.bucket.all_reduce_mean()
-                self.opt.step()
+                self._exchange_and_update()
         else:
             self._fwd_bwd()
-            self.bucket.all_reduce_mean()
-            self.opt.step()
+            if gdist.is_distributed():
+                self._exchange_and_update()
+            else:
+                self.opt.step()
         return self._loss
 
     def _load_batch(self, pos, y):

@@ -50,10 +50,15 @@ const char* glass_last_error_string(void);
  * K1  CSR aggregation  Y = A @ X         replaces `self.adj @ x` (impl/models.py:164) and its
  *     autograd backward `adj^T @ g` (call it again with the CSR of A^T).
  *
- * The launch schedule ("plan") depends only on the row pointer: rows are dealt to wavefronts
- * in edge-balanced contiguous ranges; rows longer than a threshold are cut into chunks that a
- * whole workgroup reduces through LDS, and rows longer than one chunk are summed from
- * per-chunk partial rows in a fixed order (no float atomics -> bitwise repeatable).
+ * The launch schedule ("plan") depends only on the row pointer: short rows are dealt to wavefronts as
+ * items (r0, r1, e0, e1) — runs of <= 64 consecutive rows holding <= 256 edges, edge-balanced, each
+ * carrying its own edge range so that the kernel's index loads hang off one plan read; rows longer
+ * than a threshold are cut into chunks that a whole workgroup reduces through LDS, and rows longer
+ * than one chunk are summed from per-chunk partial rows in a fixed order (no float atomics ->
+ * bitwise repeatable).  Header words: magic, version (2), n_rows, nnz, #items, #long chunks,
+ * #reduce rows, #partial slots, long threshold, long chunk, offsets of the three sections, and the
+ * flat-mode factor (an item whose mean degree is <= factor * lane-groups-per-wave is walked as one
+ * flat edge stream per lane group instead of row by row).
  *
  *   glass_spmm_plan_build: HOST function. `rowptr_host` = int32[n_rows+1] in host memory.
  *     Writes the plan into `plan_host` (int32 words; pass NULL to only query) and returns the
@@ -215,9 +220,12 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  * K5  stacked Linear pair fused with the label-conditioned mix, on the fp32 matrix cores
  *     (impl/models.py:158-162 trans_fns + ELU + mix; 167-173 cat + comb_fns + mix).
  *     W = [W1; W0] ([2H, K] row-major, K = H or 2H), bias = [b1 | b0].
- *     The kernels consume the weight as a PACKED image (fragment order of v_mfma_f32_16x16x4_f32, one
- *     contiguous KiB per wave-level read), produced by glass_dense_pack_batch_f32 once per step:
- *     Wimg from W itself (forward), WTimg from W with transposed = 1 (data gradient).
+ *     The kernels consume the weight as a PACKED image produced by glass_dense_pack_batch_f32 once per step:
+ *     Wimg from W itself (forward), WTimg from W with the transposed flag (data gradient).  Two kernel families,
+ *     chosen by the hidden size: H = 64 / 128 — a wave owns 16 rows and all output columns, v_mfma_f32_16x16x4_f32,
+ *     images in that fragment order (layout 0); H = 256 / 512 — LDS-tiled GEMM, workgroup tile 128 rows x 256
+ *     columns, v_mfma_f32_32x32x2_f32, images in LDS-stage order (forward: layout 1 "paired", the f1 / f0 halves of
+ *     a column side by side in a wave; data gradient: layout 2 "plain").  glass_dual_linear_layout(H) tells which.
  *   fwd : xb == NULL (trans): T = xa @ W^T + bias is written to T (kept for the backward),
  *                             out = mix(act(T1), act(T0)).
  *         xb != NULL (comb) : the input is the virtual concatenation [xa || xb] (no cat copy),
@@ -225,10 +233,13 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  *   dgrad: out[N, n_out] = dZ @ W (+ addend), dZ[n,o] = coef(mask[n], o<H) * dsrc[n, o mod H] * act'(T[n,o])
  *          synthesised on the fly; WTimg = packed image of W^T ([n_out] x [2H]).
  *   wgrad: dW[2H, K] (+)= dZ^T @ [X || X2], db (+)= colsum(dZ), same synthesis, split-K MFMA as K5w.
- *   Hidden sizes 64 and 128 (glass_dual_linear_supported; 256 is built but slower than the library path and off); otherwise GLASS_E_UNSUPPORTED and the
+ *   Hidden sizes 64, 128, 256, 512 (glass_dual_linear_supported); otherwise GLASS_E_UNSUPPORTED and the
  *   caller composes the library GEMM with glass_mix_*.
  * ---------------------------------------------------------------------------------------- */
 int glass_dual_linear_supported(int64_t H);
+/* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
+ * operand layout 2) */
+int glass_dual_linear_layout(int64_t H);
 /* rows covered by one workgroup of the fused kernels at hidden H = rows per `stats` / `gn_partial` entry */
 int64_t glass_dual_linear_stat_rows(int64_t H);
 /*   fwd, stats != NULL: the epilogue also writes the column statistics of `out` for the GraphNorm that consumes
@@ -268,12 +279,13 @@ int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, c
                                         const int64_t* I, float* const* dW, const int64_t* lddw, float* const* db,
                                         const int32_t* accumulate, void* stream);
 /*     Pack up to 16 weight operands B[NT][KT] (NT, KT multiples of 64) into MFMA image order in one launch.
- *     transposed[k] == 0: B = src[k] ([NT][KT] row-major); 1: B[n][k] = src[k][k][n] (src is [KT][NT]).
+ *     flags[k] bit 0 = transposed: 0: B = src[k] ([NT][KT] row-major); 1: B[n][k] = src[k][k][n] (src is [KT][NT]).
+ *     flags[k] >> 1 = layout: 0 wave16, 1 tiled paired (NT = 2H), 2 tiled plain (tiled: NT a multiple of 256).
  *     dst[k] holds NT*KT floats.  The pointer / size arrays are HOST arrays. */
 /*     rng_state (may be NULL): the same launch also advances the dropout stream, rng_state[1] += 1 (both are
  *     once-per-step prologue work; equivalent to a following glass_rng_advance). */
 int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
-                               const int32_t* transposed, int64_t n_jobs, uint64_t* rng_state, void* stream);
+                               const int32_t* flags, int64_t n_jobs, uint64_t* rng_state, void* stream);
 
 /* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
  *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened

@@ -446,12 +446,13 @@ def test_graphnorm_scratch_reuse_stress():
 
 
 # ---------------------------------------------------------------------------------- K5 fused dense
-@pytest.mark.parametrize("H,N", [(64, 17080), (64, 77), (128, 5000), (128, 1030), (256, 2100), (256, 33)])
+@pytest.mark.parametrize("H,N", [(64, 17080), (64, 77), (128, 5000), (128, 1030), (256, 2100), (256, 33), (256, 70001)])
 @pytest.mark.parametrize("comb", [False, True])
 def test_dual_linear_mix_fused(H, N, comb):
     """Fused (Linear pair + ELU + mix) MFMA kernels vs an fp64 composition of nn.Linear, ELU and the mix:
     forward, data gradient (both inputs for the comb pair) and weight / bias gradients accumulated into the
-    arena.  Inputs are strided views (the comb pair reads [g || x_] in place)."""
+    arena.  Inputs are strided views (the comb pair reads [g || x_] in place).  Hidden 256: the LDS-tiled kernels
+    (row counts off their 128-row tile); N = 70 001 also takes the tiled weight-gradient kernel (N >= 65 536)."""
     import torch.nn as nn
     from glass_amd import ops
     gen = torch.Generator().manual_seed(H + N)
@@ -475,8 +476,11 @@ def test_dual_linear_mix_fused(H, N, comb):
     # HIP
     Wg, bg = W.to(DEV), b.to(DEV)
     dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
-    Wimg, WTimg = _pack(Wg, False), _pack(Wg, True)
+    Wimg, WTimg = _pack(Wg, False, H), _pack(Wg, True, H)
     lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)  # carriers for the autograd edges only
+    # as under a ParamArena: the parameters' .grad ARE views of the stacked gradient buffers (the in-place path is only
+    # taken while that holds: ops._arena_grads_live)
+    lin1.weight.grad, lin0.weight.grad, lin1.bias.grad, lin0.bias.grad = dW[:H], dW[H:], db[:H], db[H:]
     xa = wide_a.to(DEV)[:, :H].requires_grad_(True)
     xb = wide_b.to(DEV)[:, H:].requires_grad_(True) if comb else None
     out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, Wimg, WTimg))
@@ -492,14 +496,16 @@ def test_dual_linear_mix_fused(H, N, comb):
     assert torch.equal(out2, out.detach())
 
 
-def _pack(W, transposed):
-    """glass_dense_pack_batch_f32 on one matrix: operand image of W ([NT][KT]) or of W^T."""
+def _pack(W, transposed, H=64):
+    """glass_dense_pack_batch_f32 on one matrix: operand image of W ([NT][KT]) or of W^T, in the layout the fused dense
+    kernels of hidden size H read (flags = transposed | layout << 1: forward operand paired, data-gradient plain)."""
     from glass_amd import _lib
     img = torch.empty(W.numel(), device=DEV)
     nt, kt = (W.shape[1], W.shape[0]) if transposed else W.shape
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
-    trs = np.array([int(transposed)], dtype=np.int32)
+    layout = (2 if transposed else 1) if _lib.load().glass_dual_linear_layout(H) == 1 else 0
+    trs = np.array([int(transposed) | (layout << 1)], dtype=np.int32)
     rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                 trs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
@@ -520,6 +526,28 @@ def test_dense_pack_is_a_permutation():
             n, k = 64 * (t >> 2) + 4 * j + (t & 3), q * KQ + kc * 16 + 4 * v
             off = (((kc * (NT // 16) + t) * 4 + v) * 64 + lane) * 4
             assert img[off:off + 4].tolist() == B[n, k:k + 4].tolist()
+
+
+def test_dense_pack_tiled_layouts():
+    """Operand images of the LDS-tiled kernels (hidden 256): a permutation of the operand, element order as documented
+    in dense_common.h::tiled_col — image[((ct*NKS + ks)*4 + q)*256 + nl] = B[col(ct, nl)][16 ks + 4 q .. +3]."""
+    H = 256
+    W = torch.arange(2 * H * H, dtype=torch.float32, device=DEV).reshape(2 * H, H)  # trans pair weight [2H][H]
+    for transposed in (False, True):
+        img = _pack(W, transposed, H).cpu()
+        assert sorted(img.tolist()) == W.reshape(-1).cpu().tolist()
+        B = (W.t() if transposed else W).cpu()
+        NT, KT = B.shape
+        NKS = KT // 16
+        for (ct, ks, q, nl) in ((0, 0, 0, 0), (NT // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (NT // 256 - 1, 5, 1, 200)):
+            wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
+            if not transposed:  # paired: cb 0,1 -> f1 columns 2j + cb ; cb 2,3 -> the same columns of the f0 half
+                c = ct * 128 + wn * 64 + 2 * j + (cb & 1)
+                n = H + c if cb >= 2 else c
+            else:               # plain: four consecutive columns per lane
+                n = ct * 256 + wn * 128 + 4 * j + cb
+            off = ((((ct * NKS + ks) * 4 + q) * 256) + nl) * 4
+            assert img[off:off + 4].tolist() == B[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4].tolist()
 
 
 # ---------------------------------------------------------------------------------- K8 head + loss
@@ -619,8 +647,9 @@ def test_spmm_full_size_properties(shape):
 
 @pytest.mark.parametrize("H", [8, 64, 128, 17])
 def test_spmm_row_parallel_mode_for_short_rows(H):
-    """Mean degree <= G (= 64 / lanes-per-row): the sweep kernel gives every lane group its own row.  Degrees 0-3
-    with a few long rows (>= 256 edges, which that mode must leave to the workgroup kernel) mixed into the range."""
+    """Short rows (mean degree <= 4 G, G = 64 / lanes-per-row): the sweep kernel's flat mode — indices staged in LDS,
+    every lane group walks its own run of rows as one edge stream.  Degrees 0-3 with a few long rows (>= 256 edges,
+    which belong to the workgroup kernel and cut the sweep items) mixed in."""
     from glass_amd.graph import CSRAdj
     rng = np.random.default_rng(H)
     n = 6000
@@ -643,18 +672,19 @@ def test_spmm_row_parallel_mode_for_short_rows(H):
 
 @pytest.mark.gpu
 def test_spmm_row_parallel_wide_threshold_on_large_graphs():
-    """Plans with >= 8192 sweep waves double the row-parallel threshold (header word 13): degrees 0-8 at H=64 then
-    run row-parallel (mean 4 < 2 * G = 8).  Checked against a float64 CSR product built with scipy."""
+    """Flat-mode factor 4 (header word 13): degrees 0-8 at H=64 (mean 4 <= 4 * G = 16) run in flat mode on a graph
+    large enough for the non-temporal index / output streams (n_rows * 260 B + nnz * 8 B > 256 MiB).  Checked against a
+    float64 CSR product built with scipy."""
     import scipy.sparse as sp
     from glass_amd.graph import CSRAdj
     rng = np.random.default_rng(5)
-    n, H = 600_000, 64
+    n, H = 1_100_000, 64
     rows = np.repeat(np.arange(n), rng.integers(0, 9, n))
     cols = rng.integers(0, n, rows.shape[0])
     w = rng.uniform(0.5, 2.0, rows.shape[0]).astype(np.float32)
     x = torch.randn(n, H, generator=torch.Generator().manual_seed(5))
     adj = CSRAdj(torch.from_numpy(np.stack([rows, cols])).to(DEV), torch.from_numpy(w).to(DEV), n, "sum")
-    assert int(adj.fwd.header[13]) == 2
+    assert int(adj.fwd.header[13]) == 4 and n * (4 * H + 4) + rows.shape[0] * 8 > (256 << 20)
     y = adj.fwd.spmm(x.to(DEV))
     ref = sp.csr_matrix((w.astype(np.float64), (rows, cols)), shape=(n, n)) @ x.double().numpy()
     assert rel_inf(y.cpu(), torch.from_numpy(ref)) < TOL

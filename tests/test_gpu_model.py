@@ -424,10 +424,11 @@ def _emb_pair(layers, jk, aggr, z_ratio, dropout, seed, n=700, n_pairs=4000, V=9
 
 
 @pytest.mark.parametrize("layers,jk,aggr,hidden", [(1, 1, "mean", 64), (2, 1, "gcn", 64), (3, 1, "sum", 64), (2, 0, "mean", 64),
-                                                   (3, 0, "gcn", 64), (2, 1, "mean", 128), (3, 0, "sum", 128)])
+                                                   (3, 0, "gcn", 64), (2, 1, "mean", 128), (3, 0, "sum", 128),
+                                                   (2, 1, "mean", 256), (1, 0, "gcn", 256)])
 def test_stack_program_vs_oracle(layers, jk, aggr, hidden):
-    """EmbZGConv as one forward/backward program (glass_amd/stack.py), hidden 64 and 128 (column-split dense kernels),
-    against the fp64 oracle: output, every parameter gradient (accumulated in place in the arena), and eval mode."""
+    """EmbZGConv as one forward/backward program (glass_amd/stack.py), hidden 64, 128 (column-split dense kernels) and
+    256 (LDS-tiled dense kernels; n = 700 is not a multiple of their 128-row tile), against the fp64 oracle: output, every parameter gradient (accumulated in place in the arena), and eval mode."""
     from glass_amd import stack
     emb, arena, orc, (x, ei, ew, z), gout = _emb_pair(layers, jk, aggr, 0.85, 0.0, seed=layers * 2 + jk, H=hidden)
     assert stack.StackProgram.supported(emb)
@@ -454,11 +455,13 @@ def test_stack_program_vs_oracle(layers, jk, aggr, hidden):
     assert rel_inf(ye.cpu(), orc.eval()(x.reshape(-1), ei, ew.double(), None).detach()) < TOL
 
 
-def test_stack_program_matches_per_op_path_with_dropout(monkeypatch):
+@pytest.mark.parametrize("hidden", [64, 256])
+def test_stack_program_matches_per_op_path_with_dropout(monkeypatch, hidden):
     """Same kernels, same dropout call ids: with dropout 0.5 the program and the per-op autograd path must draw the
-    same masks, so outputs and gradients agree to rounding (the gradient sums are merely associated differently)."""
+    same masks, so outputs and gradients agree to rounding (the gradient sums are merely associated differently).
+    hidden 256: the masks drawn in the tiled kernels' operand staging / epilogues against the stand-alone GraphNorm's."""
     from glass_amd import models as gm, ops
-    emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.95, 0.5, seed=11, H=64)
+    emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.95, 0.5, seed=11, H=hidden)
     emb.train()
     args = [t.to(DEV) for t in (x, ei, ew, z)]
     res = []
@@ -1005,8 +1008,10 @@ def test_label_vector_dtypes_and_shapes():
 
 
 def test_split_step_with_rccl_allreduce_on_one_rank():
-    """The N>1 form of the step (captured forward/backward + eager RCCL all-reduce(AVG) of the flat gradient arena +
-    eager fused Adam) on a 1-rank RCCL group, in a subprocess: bit-identical parameters to the single-process form."""
+    """The N>1 forms of the step on a 1-rank RCCL group, in a subprocess: (a) captured forward/backward + eager RCCL
+    all-reduce(AVG) of the gradient arena + eager fused Adam; (b) with an embedding-sized bucket: two graphs cut where
+    the small bucket is final, its all-reduce on a second stream beside the tail of the backward, reduce-scatter +
+    sharded Adam + all-gather for the table.  Both bit-identical in parameters to the single-process form."""
     import os
     import subprocess
     import sys
@@ -1015,7 +1020,7 @@ def test_split_step_with_rccl_allreduce_on_one_rank():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_step_probe.py")], capture_output=True, text=True,
                          timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert "EQUAL" in out.stdout, out.stdout[-500:]
+    assert "ALL EQUAL" in out.stdout and "DIFFERENT" not in out.stdout, out.stdout[-500:]
 
 
 def test_step_program_randomised_configurations():

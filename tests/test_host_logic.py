@@ -223,3 +223,21 @@ def test_link_prediction_dataset():
     assert len(set((pos[nnz:, 0] * n + pos[nnz:, 1]).tolist())) == nnz  # distinct
     x, ei, ea, pos2, y2 = g.get_LPdataset(use_loop=True)
     assert pos2.shape[0] == 2 * nnz + n and torch.equal(pos2[-n:, 0], pos2[-n:, 1]) and y2[-n:].sum() == 0
+
+
+def test_subgnn_text_loader_deduplicates_undirected_edges(tmp_path, monkeypatch):
+    """Real-world format (reference datasets.py:131-227 reads edge_list.txt through networkx.read_edgelist into an
+    undirected simple graph): repeated and reversed lines are one edge; valid / test are swapped so valid is larger."""
+    import datasets
+    root = tmp_path / "dataset" / "toy"
+    root.mkdir(parents=True)
+    (root / "edge_list.txt").write_text("0 1\n1 0\n1 2\n1 2\n2 3\n3 3\n")
+    (root / "subgraphs.pth").write_text("0-1\tA\ttrain\n1-2-3\tB\ttrain\n2-3\tA\tval\n0\tB\ttest\n3\tA\ttest\n")
+    monkeypatch.chdir(tmp_path)
+    g = datasets._load_subgnn_text("toy")
+    # BaseGraph symmetrises on construction (coalesce with add): every undirected edge once per direction with weight 1
+    # (2 would mean a duplicate line survived); the self-loop meets itself and gets 2, as in the reference
+    got = {tuple(p): w for p, w in zip(g.edge_index.t().tolist(), g.edge_attr.tolist())}
+    assert got == {(0, 1): 1.0, (1, 0): 1.0, (1, 2): 1.0, (2, 1): 1.0, (2, 3): 1.0, (3, 2): 1.0, (3, 3): 2.0}
+    assert g.pos.shape == (5, 3)
+    assert g.mask.tolist() == [0, 0, 1, 1, 2]  # the larger of val / test becomes valid

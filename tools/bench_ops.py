@@ -54,26 +54,46 @@ def bench_gn():
         print(f"  N={N:8d} C={C:4d}  fwd {t_f:9.1f} us ({3*by/t_f/1e6:5.2f} TB/s)   bwd {t_b:9.1f} us ({5*by/t_b/1e6:5.2f} TB/s)")
 
 
-def bench_dual():
-    import torch.nn as nn
-    print("dual linear (fused Linear pair + mix): fwd / dgrad")
-    for N, H in [(17080, 64)]:
-        for comb in (False, True):
-            K = 2 * H if comb else H
-            W = torch.randn(2 * H, K, device=DEV) / K**0.5
-            b = torch.randn(2 * H, device=DEV)
-            dW, db, WT = torch.zeros_like(W), torch.zeros_like(b), W.t().contiguous()
-            lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)
-            xa = torch.randn(N, H, device=DEV, requires_grad=True)
-            xb = torch.randn(N, H, device=DEV, requires_grad=True) if comb else None
-            mask = (torch.rand(N, device=DEV) < 0.05).to(torch.uint8)
-            act = 0 if comb else 1
-            stack = (W, b, dW, db, WT)
-            t_f = timeit(lambda: ops.dual_linear_mix(xa.detach(), None if xb is None else xb.detach(), lin1, lin0, mask, 0.9, act, stack))
-            out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask, 0.9, act, stack)
-            g = torch.randn_like(out)
-            t_b = timeit(lambda: torch.autograd.grad(out, xa, g, retain_graph=True))
-            print(f"  N={N} H={H} comb={comb}: fwd {t_f:.1f} us, bwd (dgrad+wgrad) {t_b:.1f} us")
+def bench_dual(shapes=((17080, 64), (50000, 128), (1000000, 256))):
+    """The fused Linear-pair kernels (forward with stats, data gradient, weight gradient) as the step program calls
+    them, per pair, against the library GEMM of the same FLOPs."""
+    from glass_amd import stack
+    from glass_amd.arena import ParamArena
+    from glass_amd.factory import build_glass
+    print("fused Linear pair (glass_dual_linear_{fwd,dgrad,wgrad}_f32) vs library GEMM of the same shape")
+    for N, H in shapes:
+        model = build_glass(H, 1, 5, 3, "mean", "sum", 0.9).to(DEV).train()
+        ParamArena(model)
+        conv = model.conv.convs[0]
+        mask = (torch.rand(N, device=DEV) < 0.05).to(torch.uint8)
+        f32 = dict(dtype=torch.float32, device=DEV)
+        h, a = torch.randn(N, H, **f32), torch.randn(N, H, **f32)
+        T, m, c = torch.empty(N, 2 * H, **f32), torch.empty(N, H, **f32), torch.empty(N, H, **f32)
+        nblk = -(-N // int(stack._lib.load().glass_dual_linear_stat_rows(H)))
+        cstat = torch.empty(nblk, 2, H, dtype=torch.float64, device=DEV)
+        dc, dm = torch.randn(N, H, **f32), torch.randn(N, H, **f32)
+        din, dh = torch.empty(N, 2 * H, **f32), torch.empty(N, H, **f32)
+        rows = []
+        for kind, K, n_out in (("trans", H, H), ("comb", 2 * H, 2 * H)):
+            st = conv._stack[kind]
+            if kind == "trans":
+                fwd = lambda: stack._dual_fwd(h, None, st, mask, 0.9, 1, T, m)
+                dg = lambda: stack._dual_dgrad(dm, T, st, mask, 0.9, 1, H, None, dh)
+                wg = lambda: stack._dual_wgrad(dm, T, st, mask, 0.9, 1, h, None, [])
+            else:
+                fwd = lambda: stack._dual_fwd(a, h, st, mask, 0.9, 0, None, c, cstat)
+                dg = lambda: stack._dual_dgrad(dc, None, st, mask, 0.9, 0, 2 * H, None, din)
+                wg = lambda: stack._dual_wgrad(dc, None, st, mask, 0.9, 0, a, h, [])
+            A = torch.randn(N, K, **f32)
+            W = torch.randn(2 * H, K, **f32)
+            lib = lambda: torch.mm(A, W.t())
+            fl = 2.0 * N * K * 2 * H
+            iters = 5 if N >= 500000 else 30
+            t = [timeit(f, iters=iters, warm=2) for f in (fwd, dg, wg, lib)]
+            rows.append((kind, fl, t))
+            print(f"  N={N:8d} H={H:4d} {kind:5s}: fwd {t[0]:9.1f} us ({fl/t[0]/1e6:6.1f} TF)  dgrad {t[1]:9.1f} us ({fl/t[1]/1e6:6.1f} TF)  "
+                  f"wgrad {t[2]:9.1f} us ({fl/t[2]/1e6:6.1f} TF)  | library GEMM {t[3]:9.1f} us ({fl/t[3]/1e6:6.1f} TF)")
+        del model
 
 
 if __name__ == "__main__":

@@ -1,7 +1,10 @@
 """The N>1 form of the training step on ONE GPU: a 1-rank RCCL group with glass_amd.dist told to treat it as
-distributed, so TrainStep takes its split form (captured forward/backward, eager RCCL all-reduce of the flat gradient
-arena with ReduceOp.AVG, eager fused Adam).  Prints the parameter hash after 20 steps next to the single-process
-form's: with one rank the average is the identity, so they must be equal.  Used by tests/test_gpu_model.py."""
+distributed, so TrainStep takes its split form (captured forward/backward, eager RCCL exchange of the gradient arena
+with ReduceOp.AVG, eager fused Adam).  Two scenarios: use_deg-style features (one small bucket: all-reduce) and
+use_nodeid-style features with the embedding table forced into the big bucket (two graphs cut at the tail hook, small
+all-reduce on the communication stream beside the tail, reduce-scatter + sharded Adam + all-gather for the table).
+Prints the parameter hash after 20 steps next to the single-process form's: with one rank the average is the identity
+and the shard is the whole bucket, so they must be equal.  Used by tests/test_gpu_model.py."""
 import hashlib
 import os
 import sys
@@ -11,7 +14,7 @@ import torch
 import torch.distributed as td
 
 
-def run(dist_mode):
+def run(dist_mode, nodeid=False):
     from glass_amd import synth, losses, ops, dist as gdist
     from glass_amd.arena import ParamArena
     from glass_amd.optim import FlatAdam
@@ -22,10 +25,13 @@ def run(dist_mode):
         gdist.is_distributed = lambda: True  # a 1-rank group: world_size() == 1, rank() == 0
     w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=0, n_batches=4)
     ei, ew, x, pos, y = (torch.from_numpy(a).to(dev) for a in (ei, ew, x, pos, y))
+    if nodeid:
+        x = torch.arange(x.shape[0], device=dev).reshape(-1, 1, 1)  # use_nodeid: V = N, identity gather
     torch.manual_seed(0)
     ops.rng_seed(7, dev)
     model = build_glass(64, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=0.5).to(dev).train()
-    arena = ParamArena(model)
+    arena = ParamArena(model, big_elems=4096 if nodeid else 1 << 18)  # 300 x 64 table -> the big bucket
+    assert (arena.big_start < arena.flat.numel()) == nodeid
     opt = FlatAdam(arena, lr=1e-2)
     step = TrainStep(model, opt, losses.CrossEntropy(), x, ei, ew, arena, use_graph=True, warmup_iters=2, preserve_state=True)
     B = w.batch
@@ -34,15 +40,21 @@ def run(dist_mode):
         step(pos[b * B:(b + 1) * B], y[b * B:(b + 1) * B])
     torch.cuda.synchronize()
     assert step.graphed and step._split == bool(dist_mode)
+    assert (step._g_tail is not None) == bool(dist_mode and nodeid)  # two graphs + overlapped small all-reduce
     return hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest()
 
 
 if __name__ == "__main__":
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), RANK="0", WORLD_SIZE="1")
     torch.cuda.set_device(0)
-    single = run(False)
+    single = {nid: run(False, nid) for nid in (False, True)}
     td.init_process_group("nccl", device_id=torch.device("cuda", 0))
-    split = run(True)
+    split = {nid: run(True, nid) for nid in (False, True)}
     td.barrier(device_ids=[0])
     td.destroy_process_group()
-    print("single", single, "split", split, "EQUAL" if single == split else "DIFFERENT")
+    ok = True
+    for nid in (False, True):
+        same = single[nid] == split[nid]
+        ok = ok and same
+        print("nodeid" if nid else "deg", "single", single[nid], "split", split[nid], "same" if same else "DIFFERENT")
+    print("ALL EQUAL" if ok else "MISMATCH")

@@ -13,7 +13,7 @@ N_CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 worst = 0.0
 for it in range(N_CASES):
-    H = int(rng.choice([64, 128]))
+    H = int(rng.choice([64, 128, 256]))
     L = int(rng.integers(1, 4))
     aggr = str(rng.choice(["mean", "sum", "gcn"]))
     pool = str(rng.choice(["sum", "mean", "size"]))
