@@ -410,7 +410,8 @@ def main():
                       "total_us": round(sum(us for _, us, _ in breakdown), 1)}
     dense_flops = {"glass_dual_linear_fwd_f32": 2.0 * N * (3 * H) * (2 * H) * L,       # trans K=H + comb K=2H, 2H outputs
                    "glass_dual_linear_dgrad_f32": 2.0 * N * (2 * H) * (3 * H) * L,     # comb -> 2H, trans -> H outputs
-                   "glass_dual_linear_wgrad_f32": 2.0 * N * (2 * H) * (3 * H) * L}
+                   "glass_dual_linear_wgrad_f32": 2.0 * N * (2 * H) * (3 * H) * L,
+                   "glass_dual_linear_bwd_f32": 4.0 * N * (2 * H) * (3 * H) * L}   # data + weight gradient in one call
     top = breakdown[0]
     dominant = {"kernel": top[0], "us_per_step": round(top[1], 2), "share_of_step": round(top[1] / step_breakdown["total_us"], 3)}
     if top[0] in dense_flops:
@@ -421,7 +422,7 @@ def main():
     step_breakdown["dominant"] = dominant
     dense_us = sum(us for name, us, _ in breakdown if name in dense_flops)
     if dense_us > 0:
-        tf = sum(dense_flops.values()) / (dense_us * 1e-6) / 1e12
+        tf = sum(fl for name, fl in dense_flops.items() if name in per_call) / (dense_us * 1e-6) / 1e12
         step_breakdown["dense_mfma"] = {"us_per_step": round(dense_us, 1), "achieved": tf, "peak": MFMA_F32_TFLOPS,
                                         "unit": "TFLOP/s", "frac": tf / MFMA_F32_TFLOPS}
 

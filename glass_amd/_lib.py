@@ -21,7 +21,7 @@ POOL_MODES = {"sum": 0, "mean": 1, "max": 2, "size": 3}
 AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
 ACT_NONE, ACT_ELU = 0, 1
 PLAN_HEADER_WORDS = 16
-EMBED_NORM_MAX_ROWS = 1024  # GLASS_EMBED_NORM_MAX_ROWS
+EMBED_NORM_MAX_ROWS = 8192  # GLASS_EMBED_NORM_MAX_ROWS
 ABI_VERSION = 1
 
 
@@ -69,6 +69,8 @@ SIGNATURES = {
     "glass_graphnorm_apply_f32": (c_int, [_P, _I, _P, _I, _I, _I, _P, c_int, c_float, _P, c_uint64, _P]),
     "glass_dual_linear_dgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, c_float, _P, c_uint64, _P, _I,
                                             _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, _P]),
+    "glass_dual_linear_bwd_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, c_float, _P, c_uint64, _P, _I,
+                                          _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, _P, _I, _P, _I, _P, _P]),
     "glass_graphnorm_bwd_from_stats_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P,
                                                    c_int, c_int, c_float, _P, c_uint64, _P, _P]),
     "glass_embed_norm_fwd_f32": (c_int, [_P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _I, c_float, _P, c_uint64, _P,

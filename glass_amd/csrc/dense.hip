@@ -20,6 +20,7 @@
 // sizes: 64, 128, 192 (256: weight images exceed the LDS budget -> library GEMM + stand-alone mix).
 #include "common.h"
 #include "dense_common.h"
+#include "wgrad_common.h"
 
 #include <stdlib.h>
 
@@ -50,29 +51,34 @@ __device__ __forceinline__ int tile_col(int t, int j) { return 64 * (t >> 2) + 4
 // elements 4v..4v+3 of lane (j,q)'s 16-float chunk of weight row tile_col(t, j)  ->  every wave-level
 // ds_read_b128 is one contiguous KiB (no bank conflicts) and the L2 sees one fetch per workgroup.
 // The permutation itself is done once per training step for all weights by pack_batch_kernel.
-// One staging object holds at most 8 float4 per thread (32 registers): the compiler only promotes private arrays of
-// up to 32 registers to VGPRs, a 16-float4 array (hidden 256: 128 KiB image / 512 threads) went to scratch (272 B
-// per lane).  Larger images use two objects (PART 0 and 1).
-template <int NT, int THREADS, int PART>
+template <int NT, int THREADS>
 struct WStage {
     static constexpr int NTILES = NT / 16;
     static constexpr int kVecs = NTILES * 4 * 64;          // float4 per pass image
-    static constexpr int kPerThread = kVecs / THREADS;     // staging float4 per thread, all parts
-    static constexpr int kFirst = PART * 8;
-    static constexpr int kMine = kPerThread - kFirst < 8 ? (kPerThread - kFirst > 0 ? kPerThread - kFirst : 0) : 8;
-    float4 r[kMine > 0 ? kMine : 1];
+    static constexpr int kPerThread = kVecs / THREADS;     // staging float4 per thread (4 or 8 at hidden 64 and 128)
+    static constexpr int kHalf = kPerThread / 2;
+    static_assert(kPerThread % 2 == 0, "staging is held as two half arrays");
+    // two arrays of <= 16 registers: a single 32-register array sits exactly at the compiler's promotion limit and went
+    // to scratch memory inside the fused backward kernel
+    float4 ra[kHalf], rb[kHalf];
     // global -> registers: pass kc of the PACKED weight (glass_dense_pack_batch_f32 wrote it in image
     // order once per step), so this is a fully coalesced 16-B-per-lane copy.  (Gathering the image from
     // the row-major weight here cost ~4 us per pass: 64 scattered 16-B reads per wave-instruction.)
-    __device__ __forceinline__ void fetch(const float* __restrict__ Wimg, int /*KT*/, int kc) {
+    __device__ __forceinline__ void fetch(const float* __restrict__ Wimg, int kc) {
         const float4* src = reinterpret_cast<const float4*>(Wimg) + (int64_t)kc * kVecs;
 #pragma unroll
-        for (int n = 0; n < kMine; ++n) r[n] = src[threadIdx.x + THREADS * (kFirst + n)];
+        for (int n = 0; n < kHalf; ++n) {
+            ra[n] = src[threadIdx.x + THREADS * n];
+            rb[n] = src[threadIdx.x + THREADS * (kHalf + n)];
+        }
     }
     // registers -> LDS image (consecutive threads write consecutive float4)
     __device__ __forceinline__ void commit(float4* __restrict__ image) const {
 #pragma unroll
-        for (int n = 0; n < kMine; ++n) image[threadIdx.x + THREADS * (kFirst + n)] = r[n];
+        for (int n = 0; n < kHalf; ++n) {
+            image[threadIdx.x + THREADS * n] = ra[n];
+            image[threadIdx.x + THREADS * (kHalf + n)] = rb[n];
+        }
     }
 };
 
@@ -82,7 +88,7 @@ struct WStage {
 // A wave may own only part of the output columns (column split, hidden 128: two wave groups per 16 rows): its
 // NTILES local tiles are the image tiles base0 .. base0+HALF-1 followed by base1 .. (two runs: the f1 and f0
 // halves of a Linear pair; HALF == NTILES: one run).
-template <int NTILES, int HALF, bool LEAN>
+template <int NTILES, int HALF>
 __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float (&a)[kKC], const float4* image,
                                               int lane, int base0, int base1) {
     static_assert(NTILES % 2 == 0, "tiles are processed in pairs");
@@ -103,18 +109,6 @@ __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float 
             }
         }
     };
-    if (LEAN) {
-        // hidden 256: 64 registers per lane hold the next 128 KiB weight image across this pass, so the operand pair
-        // of the next tiles is not prefetched (32 registers less; otherwise the compiler spills the staging to scratch)
-#pragma unroll
-        for (int t = 0; t < NTILES; t += 2) {
-            float4 b0v[4], b1v[4];
-            read_tile(t, b0v);
-            read_tile(t + 1, b1v);
-            mfma_pair(t, b0v, b1v);
-        }
-        return;
-    }
     float4 b[2][2][4];
     read_tile(0, b[0][0]);
     read_tile(1, b[0][1]);
@@ -135,45 +129,30 @@ __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float 
 // double-buffered through LDS.  The A operand of pass kc is produced in two steps so that the loads of pass kc+1
 // stay in flight across the MFMAs of pass kc: `issue(kc, raw)` only starts the global loads into `raw`;
 // `finish(kc, raw, a)` (run after the current pass) turns them into the operand chunk (prologue arithmetic).
-// LDS budget per workgroup for the weight images (160 KiB per CU; headroom for the runtime)
-constexpr int kLdsBudget = 152 * 1024;
-template <int NT> struct WBuf {
-    static constexpr bool kDouble = 2 * NT * 256 <= kLdsBudget;  // NT*256 B per pass image
-};
-
 template <int NT, int KT, int NLOC, int HALF, int THREADS, typename Raw, typename Issue, typename Finish>
 __device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* __restrict__ W, float4* lds, int lane,
                                                int base0, int base1, Issue issue, Finish finish) {
     constexpr int NKC = KT / 4 / kKC;
-    constexpr int kVecs = WStage<NT, THREADS, 0>::kVecs;
-    static_assert(WStage<NT, THREADS, 0>::kPerThread <= 16, "weight image too large for two staging parts");
-    constexpr bool kDouble = WBuf<NT>::kDouble;  // hidden 256: one image at a time (two barriers per pass)
-    WStage<NT, THREADS, 0> ws;
-    WStage<NT, THREADS, 1> ws1;
-    ws.fetch(W, KT, 0);
-    ws1.fetch(W, KT, 0);
+    constexpr int kVecs = WStage<NT, THREADS>::kVecs;
+    static_assert(WStage<NT, THREADS>::kPerThread <= 8, "weight image too large for one staging object");
+    WStage<NT, THREADS> ws;
+    ws.fetch(W, 0);
     Raw raw;
     issue(0, raw);
     ws.commit(lds);
-    ws1.commit(lds);
     float a[kKC];
     finish(0, raw, a);
     __syncthreads();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
         if (kc + 1 < NKC) {
-            ws.fetch(W, KT, kc + 1);
-            ws1.fetch(W, KT, kc + 1);
+            ws.fetch(W, kc + 1);
             issue(kc + 1, raw);
         }
         __builtin_amdgcn_sched_barrier(0);  // the loads above are issued before the MFMAs below
-        // LEAN when the staging registers of a 128 KiB image (16 float4 per thread) are alive across the pass
-        mfma_pass_lds<NLOC, HALF, (WStage<NT, THREADS, 0>::kPerThread > 8)>(acc, a, lds + (kDouble ? (kc & 1) * kVecs : 0), lane,
-                                                                          base0, base1);
+        mfma_pass_lds<NLOC, HALF>(acc, a, lds + (kc & 1) * kVecs, lane, base0, base1);
         if (kc + 1 < NKC) {
-            if (!kDouble) __syncthreads();  // every wave has read this pass's image before it is overwritten
-            ws.commit(lds + (kDouble ? ((kc + 1) & 1) * kVecs : 0));
-            ws1.commit(lds + (kDouble ? ((kc + 1) & 1) * kVecs : 0));
+            ws.commit(lds + ((kc + 1) & 1) * kVecs);  // the other image: last read in pass kc - 1, before the previous barrier
             finish(kc + 1, raw, a);
             __syncthreads();
         }
@@ -351,8 +330,26 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
     }
 }
 
+// 16 consecutive floats of a row as four named float4 (NOT an array: the two 16-float arrays of the raw-load stage sat at
+// the compiler's alloca-promotion limit and were kept in scratch memory across the MFMA pass)
+struct F16 {
+    float4 q0, q1, q2, q3;
+    __device__ __forceinline__ void load(const float* p, bool ok) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        q0 = ok ? *reinterpret_cast<const float4*>(p) : z;
+        q1 = ok ? *reinterpret_cast<const float4*>(p + 4) : z;
+        q2 = ok ? *reinterpret_cast<const float4*>(p + 8) : z;
+        q3 = ok ? *reinterpret_cast<const float4*>(p + 12) : z;
+    }
+    __device__ __forceinline__ float at(int s) const {  // s is a compile-time constant at every call site (unrolled)
+        const float4& q = s < 4 ? q0 : s < 8 ? q1 : s < 12 ? q2 : q3;
+        const int e = s & 3;
+        return e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w;
+    }
+};
+
 struct DgradRaw {
-    float d[kKC], t[kKC];
+    F16 d, t;
 };
 
 // Optional epilogue of the data-gradient kernel: its first H output columns are the gradient dy of a GraphNorm
@@ -363,15 +360,31 @@ struct DgradRaw {
 // ---- backward data gradient ---------------------------------------------------------------------
 // out[N, NT] = dZ[N, 2H] @ Wstack[2H, NT] (+ addend), dZ[n, o] = coef(n, o<H) * dsrc[n, o mod H] * act'(T[n, o]);
 // WT = Wstack^T stored [NT][2H] so that weight chunks are contiguous (refreshed once per step).
+struct DgradArgs {
+    const float* dsrc; int64_t ldd;
+    const float* T; int64_t ldt;
+    const uint8_t* mask; float zr, omz;
+    int act;
+    const float* WT;
+    const float* addend; int64_t ldadd;
+    Drop drop;
+    const uint64_t* rng_state;
+    float* out; int64_t ldo;
+    int64_t N;
+    GnBwdStats gs;
+};
+
+// One row tile (`block`) of the data gradient; lds_w = the workgroup's dynamic LDS (weight images, then the statistics
+// reduction).  A device function so that it can also be one branch of the fused backward launch (dual_bwd_kernel).
+// Plain by-value arguments: with the argument struct passed by reference the compiler kept the weight staging registers
+// of the wider variants in scratch memory.
 template <int H, int NT, int CS, int RW>
-__global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
-                                                                 const float* __restrict__ T, int64_t ldt,
-                                                                 const uint8_t* __restrict__ mask, float zr, float omz,
-                                                                 int act, const float* __restrict__ WT,
-                                                                 const float* __restrict__ addend, int64_t ldadd,
-                                                                 Drop drop, const uint64_t* __restrict__ rng_state,
-                                                                 float* __restrict__ out, int64_t ldo, int64_t N,
-                                                                 GnBwdStats gs) {
+__device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, int64_t ldd, const float* __restrict__ T,
+                                                int64_t ldt, const uint8_t* __restrict__ mask, float zr, float omz, int act,
+                                                const float* __restrict__ WT, const float* __restrict__ addend,
+                                                int64_t ldadd, Drop drop, const uint64_t* __restrict__ rng_state,
+                                                float* __restrict__ out, int64_t ldo, int64_t N, GnBwdStats gs, int block,
+                                                float4* lds_w) {
     constexpr int KT = 2 * H, KQ = KT / 4;
     constexpr int THREADS = kWave * RW * CS;
     constexpr int NGO = NT / 64;      // 64-column output groups
@@ -381,7 +394,7 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(const float
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rw = w % RW, cg = w / RW;
     const int i = lane & 15, q = lane >> 4;
-    const int64_t row0 = ((int64_t)blockIdx.x * RW + rw) * 16;
+    const int64_t row0 = ((int64_t)block * RW + rw) * 16;
     const int64_t row = row0 + i;
     const bool row_ok = row < N;
     const bool first = q < 2;  // lanes q=0,1 hold the f1 half (o < H), q=2,3 the f0 half
@@ -389,21 +402,20 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(const float
     if (row_ok) coef = (mask[row] != 0) == first ? zr : omz;
     const float* drow = dsrc + row * ldd + (q & 1) * KQ;   // o mod H
     const float* trow = T ? T + row * ldt + q * KQ : nullptr;
-    extern __shared__ float4 lds_w[];
     f32x4 acc[NLOC];
 #pragma unroll
     for (int t = 0; t < NLOC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     staged_product<NT, KT, NLOC, NLOC, THREADS, DgradRaw>(
         acc, WT, lds_w, lane, NLOC * cg, 0,
         [&](int kc, DgradRaw& raw) __attribute__((always_inline)) {
-            load16(raw.d, drow + kc * kKC, row_ok);
-            if (act == GLASS_ACT_ELU) load16(raw.t, trow + kc * kKC, row_ok);
+            raw.d.load(drow + kc * kKC, row_ok);
+            if (act == GLASS_ACT_ELU) raw.t.load(trow + kc * kKC, row_ok);
         },
         [&](int, const DgradRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < kKC; ++s) {
-                float v = raw.d[s] * coef;
-                if (act == GLASS_ACT_ELU) v *= elu_grad_f(raw.t[s]);
+                float v = raw.d.at(s) * coef;
+                if (act == GLASS_ACT_ELU) v *= elu_grad_f(raw.t.at(s));
                 a[s] = v;
             }
         });
@@ -500,9 +512,40 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(const float
             a += red[(ww * H + c) * 2];
             b2 += red[(ww * H + c) * 2 + 1];
         }
-        gs.partial[((size_t)blockIdx.x * 2) * H + c] = a;
-        gs.partial[((size_t)blockIdx.x * 2 + 1) * H + c] = b2;
+        gs.partial[((size_t)block * 2) * H + c] = a;
+        gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
     }
+}
+
+template <int H, int NT, int CS, int RW>
+__global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(DgradArgs A) {
+    extern __shared__ float4 lds_w[];
+    dual_dgrad_body<H, NT, CS, RW>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
+                                   A.rng_state, A.out, A.ldo, A.N, A.gs, blockIdx.x, lds_w);
+}
+
+// Fused backward launch of one Linear pair on SMALL graphs (hidden 64): the data gradient (row tiles) and the
+// weight-gradient partial sums (row slabs) are independent — both only read the pair's output gradient — and at
+// ppi_bp-shape each is a 12-17 us launch that leaves the chip half idle (one wave per SIMD, latency-bound).  As two
+// branches of ONE launch their workgroups share the CUs (two per CU: <= 256 registers, 68 KiB LDS) and the pair costs
+// about the longer of the two instead of their sum, with one launch boundary less.  (The same overlap through a
+// second stream inside the captured step cost more in graph edges than it saved: DESIGN.md §5.)
+template <int H, int NT>
+__global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_dgrad_blocks, const float* __restrict__ X,
+                                                            int64_t ldx, int O, int I, int rows_per_slab, int gx, int gy,
+                                                            float* __restrict__ part_w, float* __restrict__ part_b,
+                                                            WgradSynth sy) {
+    extern __shared__ float4 lds_w[];
+    const int b = blockIdx.x;
+    if (b < n_dgrad_blocks) {
+        dual_dgrad_body<H, NT, 1, 4>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
+                                     A.rng_state, A.out, A.ldo, A.N, A.gs, b, lds_w);
+        return;
+    }
+    const int t = b - n_dgrad_blocks;  // slab fastest, then input tile, then output tile (as the 3-D grid of the stand-alone launch)
+    float* lds = reinterpret_cast<float*>(lds_w);
+    wgrad_partial_body<true, 2>(nullptr, 0, X, ldx, A.N, O, I, rows_per_slab, part_w, part_b, sy, t % gx, (t / gx) % gy,
+                                t / (gx * gy), gx, gy, lds, lds + 2 * kTile);
 }
 
 // ---- packing of the stacked weights into MFMA images (one launch for the whole model, once per step) ------
@@ -559,10 +602,13 @@ static void allow_lds(K kernel, size_t bytes) {
 }
 
 static bool wave16_shape_ok(int64_t H) { return H == 64 || H == 128; }
+// Above this many rows the two halves of the backward of a pair fill the chip on their own (one launch each, the
+// weight gradient with its 4-stage pipeline); below, they run as two branches of one launch (dual_bwd_kernel).
+static constexpr int64_t kFusedBwdMaxRows = 100000;
 static bool dense_shape_ok(int64_t H) { return wave16_shape_ok(H) || tiled_shape_ok(H); }
-static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at once (see WBuf)
+static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at once: two when K needs more than one pass
     const size_t image = (size_t)NT * 256;
-    return (n_pass > 1 && 2 * image <= (size_t)kLdsBudget) ? 2 * image : image;
+    return n_pass > 1 ? 2 * image : image;
 }
 
 // Policy: hidden 64 (one wave group per 64 rows) and hidden 128 (two wave groups splitting the output columns, 512
@@ -621,13 +667,19 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     return launch_status("glass_dual_linear_fwd_f32");
 }
 
-extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt,
-                                           const uint8_t* mask, double z_ratio, int act, const float* WT,
-                                           int64_t n_out, const float* addend, int64_t ldadd, float p_drop,
-                                           const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo,
-                                           int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
-                                           int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act,
-                                           float gn_p_drop, uint64_t gn_call_id, void* stream) {
+// The weight-gradient half of glass_dual_linear_bwd_f32 (inputs of the pair + scratch for the partial sums)
+struct BwdWgrad {
+    const float* X; int64_t ldx;
+    const float* X2; int64_t ldx2;
+    void* ws;
+};
+
+static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, double z_ratio,
+                        int act, const float* WT, int64_t n_out, const float* addend, int64_t ldadd, float p_drop,
+                        const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
+                        double* gn_partial, const float* gn_x, int64_t gn_ldx, const float* gn_saved,
+                        const float* gn_alpha, int gn_act, float gn_p_drop, uint64_t gn_call_id, const BwdWgrad* wg,
+                        void* stream) {
     GLASS_REQUIRE(dsrc && mask && WT && out && n_nodes > 0, "dual_linear_dgrad: null pointer");
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (rng_state && n_out == H)),
                   "dual_linear_dgrad: bad dropout args (the masked output must be the [N,H] layer input)");
@@ -651,25 +703,79 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                   "dual_linear_dgrad: bad GraphNorm statistics arguments");
     const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                         make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
-    if (tiled_shape_ok(H))
-        return launch_tiled_dgrad(dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, n_out, addend, ldadd, drop, rng_state, out,
-                                  ldo, n_nodes, H, gs, st);
+    // the weight-gradient partials of the same pair, as a second launch (large graphs / wide layers) ...
+    auto wgrad_after = [&]() -> int {
+        if (!wg) return 0;
+        return glass_dual_linear_wgrad_f32(dsrc, ldd, T, ldt, mask, z_ratio, act, wg->X, wg->ldx, wg->X2, wg->ldx2, n_nodes, H,
+                                           nullptr, 0, nullptr, 0, wg->ws, stream);
+    };
+    if (tiled_shape_ok(H)) {
+        const int rc = launch_tiled_dgrad(dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, n_out, addend, ldadd, drop, rng_state,
+                                          out, ldo, n_nodes, H, gs, st);
+        return rc ? rc : wgrad_after();
+    }
+    const DgradArgs dargs{dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs};
+    // ... or, at hidden 64 on a graph small enough to be latency-bound, as the second branch of the SAME launch
+    const int64_t O = 2 * H, I = wg && wg->X2 ? 2 * H : H;
+    if (wg && H == 64 && n_nodes <= kFusedBwdMaxRows && !wgrad_tiled_shape(n_nodes, O, I)) {
+        GLASS_REQUIRE(wg->X && wg->ws && wg->ldx >= H && wg->ldx % 2 == 0 && (reinterpret_cast<uintptr_t>(wg->X) & 7u) == 0 &&
+                          (!wg->X2 || (wg->ldx2 >= H && wg->ldx2 % 2 == 0 && (reinterpret_cast<uintptr_t>(wg->X2) & 7u) == 0)),
+                      "dual_linear_bwd: the pair's inputs must be 8-B aligned with even leading dimensions");
+        const WgradGeom g = wgrad_geom(n_nodes, O, I);
+        float* part_w = (float*)wg->ws;
+        const WgradSynth sy{dsrc, ldd, Tp, ldt, mask, zr, omz, act, (int)H, wg->X2, wg->ldx2};
+        const size_t lds_wg = (size_t)(2 * kTile + 8 * kOT) * sizeof(float);
+        const size_t lds_fused = lds_dg > lds_wg ? lds_dg : lds_wg;
+        const unsigned blocks = grid.x + (unsigned)(g.n_slabs * g.ny * g.nz);
+        if (n_out == H) {
+            allow_lds(dual_bwd_kernel<64, 64>, lds_fused);
+            hipLaunchKernelGGL((dual_bwd_kernel<64, 64>), dim3(blocks), dim3(kBlock), lds_fused, st, dargs, (int)grid.x, wg->X,
+                               wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats, sy);
+        } else {
+            allow_lds(dual_bwd_kernel<64, 128>, lds_fused);
+            hipLaunchKernelGGL((dual_bwd_kernel<64, 128>), dim3(blocks), dim3(kBlock), lds_fused, st, dargs, (int)grid.x, wg->X,
+                               wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats, sy);
+        }
+        return launch_status("glass_dual_linear_bwd_f32");
+    }
 #define GLASS_DG(HH, CS, RW)                                                                                       \
     if (H == HH) {                                                                                                 \
         allow_lds(dual_dgrad_kernel<HH, HH, CS, RW>, lds_dg);                                                      \
         allow_lds(dual_dgrad_kernel<HH, 2 * HH, CS, RW>, lds_dg);                                                  \
         if (n_out == H)                                                                                            \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH, CS, RW>), grid, dim3(kWave * RW * CS), lds_dg, st, dsrc, ldd,  \
-                               Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, \
-                               gs);                                                                                \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, HH, CS, RW>), grid, dim3(kWave * RW * CS), lds_dg, st, dargs); \
         else                                                                                                       \
-            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH, CS, RW>), grid, dim3(kWave * RW * CS), lds_dg, st, dsrc,   \
-                               ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo,     \
-                               n_nodes, gs);                                                                       \
+            hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH, CS, RW>), grid, dim3(kWave * RW * CS), lds_dg, st, dargs); \
     }
     GLASS_DG(64, 1, 4) GLASS_DG(128, 2, 4)
 #undef GLASS_DG
-    return launch_status("glass_dual_linear_dgrad_f32");
+    const int rc = launch_status("glass_dual_linear_dgrad_f32");
+    return rc ? rc : wgrad_after();
+}
+
+extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt,
+                                           const uint8_t* mask, double z_ratio, int act, const float* WT,
+                                           int64_t n_out, const float* addend, int64_t ldadd, float p_drop,
+                                           const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo,
+                                           int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
+                                           int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act,
+                                           float gn_p_drop, uint64_t gn_call_id, void* stream) {
+    return dgrad_launch(dsrc, ldd, T, ldt, mask, z_ratio, act, WT, n_out, addend, ldadd, p_drop, rng_state, call_id, out, ldo,
+                        n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, nullptr,
+                        stream);
+}
+
+extern "C" int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
+                                         double z_ratio, int act, const float* WT, int64_t n_out, const float* addend,
+                                         int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id,
+                                         float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial,
+                                         const float* gn_x, int64_t gn_ldx, const float* gn_saved, const float* gn_alpha,
+                                         int gn_act, float gn_p_drop, uint64_t gn_call_id, const float* X, int64_t ldx,
+                                         const float* X2, int64_t ldx2, void* ws, void* stream) {
+    GLASS_REQUIRE(X && ws, "dual_linear_bwd: null pointer");
+    const BwdWgrad wg{X, ldx, X2, ldx2, ws};
+    return dgrad_launch(dsrc, ldd, T, ldt, mask, z_ratio, act, WT, n_out, addend, ldadd, p_drop, rng_state, call_id, out, ldo,
+                        n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, &wg, stream);
 }
 
 extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,

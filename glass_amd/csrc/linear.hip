@@ -21,144 +21,17 @@
 
 namespace glass {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kOT = 128;            // outputs per workgroup (4 tiles of 32, strided by 4)
-constexpr int kIT = 64;             // inputs per workgroup  (2 tiles of 32, strided by 2)
-constexpr int kTile = kOT * kIT;    // 8192 accumulators per workgroup
-constexpr int kMaxSlabs = 256;
-
-// idx of accumulator (t,u,reg,lane) in the permuted partial layout
-__device__ __forceinline__ int acc_index(int t, int u, int reg, int lane) { return ((t * 2 + u) * 16 + reg) * 64 + lane; }
-
+// The partial-sum kernel body lives in wgrad_common.h (wgrad_partial_body): it is also one branch of the fused
+// backward launch of dense.hip.
 template <bool SYNTH>
 __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* __restrict__ G, int64_t ldg,
                                                                   const float* __restrict__ X, int64_t ldx,
                                                                   int64_t N, int O, int I, int rows_per_slab,
                                                                   float* __restrict__ part_w,
                                                                   float* __restrict__ part_b, WgradSynth sy) {
-    __shared__ float lds[2 * kTile];       // 64 KiB: two wave-sized accumulator images
-    __shared__ float lds_b[8 * kOT];       // bias partials: [wave*2 + h][o]
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int c = lane & 31, h = lane >> 5;
-    const int o0 = blockIdx.z * kOT + 4 * c;   // this lane's 4 outputs
-    const int i0 = blockIdx.y * kIT + 2 * c;   // this lane's 2 inputs
-    const bool o_ok = o0 < O, i_ok = i0 < I;   // O % 4 == 0 and I % 2 == 0 (checked on the host)
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
-    const int64_t r1 = min(N, r0 + rows_per_slab);
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-
-    // Wave w takes row pairs p = w, w+4, ...  One pipeline stage = two row pairs (16 MFMAs = 1024
-    // cycles of matrix work); kStages stages are kept in flight because a stage's loads take about
-    // one loaded-memory latency (~2 us) — with a single stage of prefetch the loop ran 4x slower
-    // than the MFMA rate at N = 1 M (profiles/r01: 6.9 ms vs 1.7 ms of matrix time).
-    constexpr int kStages = 4;
-    // A stage holds RAW loads only (rows past the slab are clamped to its last row and zeroed at use),
-    // so that no load has to be waited for when it is issued; the mix / ELU' synthesis of G happens
-    // right before the MFMAs.  (Synthesising at load time put an s_waitcnt vmcnt(0) into every stage.)
-    struct Stage {
-        float4 g[2], t[2];
-        float2 x[2];
-        int mk[2];
-        bool live[2];
-    };
-    Stage st[kStages];
-    const bool first = o0 < sy.H;  // SYNTH: this lane's four outputs lie in the f1 half
-    auto load_stage = [&](int64_t nb, Stage& S) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int64_t want = nb + h + 8 * s;
-            const int64_t nn = want < r1 ? want : r1 - 1;
-            S.live[s] = want < r1;
-            S.g[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            S.x[s] = make_float2(0.f, 0.f);
-            if (!SYNTH) {
-                if (o_ok) S.g[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
-                if (i_ok) S.x[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
-            } else {  // O = 2H and I are multiples of the tile sizes: every lane is in range
-                S.g[s] = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (first ? o0 : o0 - sy.H));
-                if (sy.act == GLASS_ACT_ELU) S.t[s] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
-                S.mk[s] = sy.mask[nn];
-                S.x[s] = (i0 < sy.H || sy.X2 == nullptr)
-                             ? *reinterpret_cast<const float2*>(X + nn * ldx + i0)
-                             : *reinterpret_cast<const float2*>(sy.X2 + nn * sy.ldx2 + (i0 - sy.H));
-            }
-        }
-    };
-    const int64_t nb0 = r0 + 2 * w;  // wave-uniform (MFMA needs every lane in the loop)
-#pragma unroll
-    for (int k = 0; k < kStages; ++k) load_stage(nb0 + 16 * k, st[k]);
-    for (int64_t nb = nb0; nb < r1; nb += 16 * kStages) {
-#pragma unroll
-        for (int k = 0; k < kStages; ++k) {
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                float4 g = st[k].g[s];
-                if (SYNTH) {
-                    const float cf = ((st[k].mk[s] != 0) == first) ? sy.zr : sy.omz;
-                    g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
-                    if (sy.act == GLASS_ACT_ELU) {
-                        const float4 t = st[k].t[s];
-                        g.x *= elu_grad_f(t.x); g.y *= elu_grad_f(t.y); g.z *= elu_grad_f(t.z); g.w *= elu_grad_f(t.w);
-                    }
-                }
-                if (!st[k].live[s]) g = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float gv[4] = {g.x, g.y, g.z, g.w};
-                const float xv[2] = {st[k].x[s].x, st[k].x[s].y};
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u)
-                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
-                bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
-            }
-            __builtin_amdgcn_sched_barrier(0);  // keep the refill below from being sunk into later stages
-            load_stage(nb + 16 * (k + kStages), st[k]);  // refill this stage, kStages ahead
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---- combine the 4 waves through LDS: waves 0,1 store; waves 2,3 add; everyone sums the pair ----
-    if (w < 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index(t, u, k, lane)] = acc[t][u][k];
-    }
-    *reinterpret_cast<float4*>(&lds_b[(w * 2 + h) * kOT + 4 * c]) = bsum;
-    __syncthreads();
-    if (w >= 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index(t, u, k, lane)] += acc[t][u][k];
-    }
-    __syncthreads();
-    const int64_t tile_id = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    float* pw = part_w + tile_id * kTile;
-    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
-        const float4 a = *reinterpret_cast<const float4*>(&lds[k]);
-        const float4 b = *reinterpret_cast<const float4*>(&lds[kTile + k]);
-        *reinterpret_cast<float4*>(pw + k) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    }
-    if (blockIdx.y == 0 && part_b && threadIdx.x < kOT) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += lds_b[k * kOT + threadIdx.x];
-        part_b[((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * kOT + threadIdx.x] = s;
-    }
+    __shared__ float lds[2 * kTile + 8 * kOT];  // 64 KiB: two wave-sized accumulator images; + bias partials [wave*2 + h][o]
+    wgrad_partial_body<SYNTH, 4>(G, ldg, X, ldx, N, O, I, rows_per_slab, part_w, part_b, sy, blockIdx.x, blockIdx.y,
+                                 blockIdx.z, gridDim.x, gridDim.y, lds, lds + 2 * kTile);
 }
 
 // Sum the slab partials and scatter to dW[o,i] / db[o].  A [n_slabs x 8192(+128)] column reduction:
@@ -251,12 +124,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_batch_kernel(ReduceBatch 
     wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
 }
 
-struct WgradGeom {
-    int n_slabs, rows_per_slab, ny, nz;
-    int64_t part_w_floats, part_b_floats;
-};
-
-static WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
+WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     WgradGeom g;
     // Slab count: about one workgroup per CU over all (slab, input-chunk, output-chunk) triples, at most 128
     // slabs (measured on MI355X, us for 128/64 slabs vs 256: N=17 080 O=128 I=128 22 vs 31; N=50 000 O=256 I=128

@@ -20,6 +20,153 @@ struct WgradSynth {
     int64_t ldx2;
 };
 
+struct WgradGeom {
+    int n_slabs, rows_per_slab, ny, nz;
+    int64_t part_w_floats, part_b_floats;
+};
+WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I);  // linear.hip
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kOT = 128;            // outputs per workgroup (4 tiles of 32, strided by 4)
+constexpr int kIT = 64;             // inputs per workgroup  (2 tiles of 32, strided by 2)
+constexpr int kTile = kOT * kIT;    // 8192 accumulators per workgroup
+constexpr int kMaxSlabs = 256;
+
+// idx of accumulator (t,u,reg,lane) in the permuted partial layout
+__device__ __forceinline__ int acc_index(int t, int u, int reg, int lane) { return ((t * 2 + u) * 16 + reg) * 64 + lane; }
+
+// Partial sums of one (slab bx, input tile by, output tile bz) of a gx x gy x gz launch, by one 256-thread workgroup.
+// lds: 2 * kTile floats (two wave-sized accumulator images), lds_b: 8 * kOT floats (bias partials [wave*2 + h][o]).
+// kStages: pipeline stages of raw loads kept in flight (4 on large graphs; 2 in the fused backward launch of small
+// graphs, where a slab holds only a few stages and registers decide whether two workgroups share a CU).
+template <bool SYNTH, int kStages>
+__device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, int64_t ldg,
+                                                   const float* __restrict__ X, int64_t ldx, int64_t N, int O, int I,
+                                                   int rows_per_slab, float* __restrict__ part_w,
+                                                   float* __restrict__ part_b, const WgradSynth& sy, int bx, int by, int bz,
+                                                   int gx, int gy, float* lds, float* lds_b) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int o0 = bz * kOT + 4 * c;   // this lane's 4 outputs
+    const int i0 = by * kIT + 2 * c;   // this lane's 2 inputs
+    const bool o_ok = o0 < O, i_ok = i0 < I;   // O % 4 == 0 and I % 2 == 0 (checked on the host)
+    const int64_t r0 = (int64_t)bx * rows_per_slab;
+    const int64_t r1 = min(N, r0 + rows_per_slab);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // Wave w takes row pairs p = w, w+4, ...  One pipeline stage = two row pairs (16 MFMAs = 1024
+    // cycles of matrix work); kStages stages are kept in flight because a stage's loads take about
+    // one loaded-memory latency (~2 us) — with a single stage of prefetch the loop ran 4x slower
+    // than the MFMA rate at N = 1 M (profiles/r01: 6.9 ms vs 1.7 ms of matrix time).
+    // A stage holds RAW loads only (rows past the slab are clamped to its last row and zeroed at use),
+    // so that no load has to be waited for when it is issued; the mix / ELU' synthesis of G happens
+    // right before the MFMAs.  (Synthesising at load time put an s_waitcnt vmcnt(0) into every stage.)
+    struct Stage {
+        float4 g[2], t[2];
+        float2 x[2];
+        int mk[2];
+        bool live[2];
+    };
+    Stage st[kStages];
+    const bool first = o0 < sy.H;  // SYNTH: this lane's four outputs lie in the f1 half
+    auto load_stage = [&](int64_t nb, Stage& S) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t want = nb + h + 8 * s;
+            const int64_t nn = want < r1 ? want : r1 - 1;
+            S.live[s] = want < r1;
+            S.g[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            S.x[s] = make_float2(0.f, 0.f);
+            if (!SYNTH) {
+                if (o_ok) S.g[s] = *reinterpret_cast<const float4*>(G + nn * ldg + o0);
+                if (i_ok) S.x[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
+            } else {  // O = 2H and I are multiples of the tile sizes: every lane is in range
+                S.g[s] = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (first ? o0 : o0 - sy.H));
+                if (sy.act == GLASS_ACT_ELU) S.t[s] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
+                S.mk[s] = sy.mask[nn];
+                S.x[s] = (i0 < sy.H || sy.X2 == nullptr)
+                             ? *reinterpret_cast<const float2*>(X + nn * ldx + i0)
+                             : *reinterpret_cast<const float2*>(sy.X2 + nn * sy.ldx2 + (i0 - sy.H));
+            }
+        }
+    };
+    const int64_t nb0 = r0 + 2 * w;  // wave-uniform (MFMA needs every lane in the loop)
+#pragma unroll
+    for (int k = 0; k < kStages; ++k) load_stage(nb0 + 16 * k, st[k]);
+    for (int64_t nb = nb0; nb < r1; nb += 16 * kStages) {
+#pragma unroll
+        for (int k = 0; k < kStages; ++k) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float4 g = st[k].g[s];
+                if (SYNTH) {
+                    const float cf = ((st[k].mk[s] != 0) == first) ? sy.zr : sy.omz;
+                    g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
+                    if (sy.act == GLASS_ACT_ELU) {
+                        const float4 t = st[k].t[s];
+                        g.x *= elu_grad_f(t.x); g.y *= elu_grad_f(t.y); g.z *= elu_grad_f(t.z); g.w *= elu_grad_f(t.w);
+                    }
+                }
+                if (!st[k].live[s]) g = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float gv[4] = {g.x, g.y, g.z, g.w};
+                const float xv[2] = {st[k].x[s].x, st[k].x[s].y};
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
+                bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the refill below from being sunk into later stages
+            load_stage(nb + 16 * (k + kStages), st[k]);  // refill this stage, kStages ahead
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- combine the 4 waves through LDS: waves 0,1 store; waves 2,3 add; everyone sums the pair ----
+    if (w < 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index(t, u, k, lane)] = acc[t][u][k];
+    }
+    *reinterpret_cast<float4*>(&lds_b[(w * 2 + h) * kOT + 4 * c]) = bsum;
+    __syncthreads();
+    if (w >= 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index(t, u, k, lane)] += acc[t][u][k];
+    }
+    __syncthreads();
+    const int64_t tile_id = ((int64_t)bz * gy + by) * gx + bx;
+    float* pw = part_w + tile_id * kTile;
+    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(&lds[k]);
+        const float4 b = *reinterpret_cast<const float4*>(&lds[kTile + k]);
+        *reinterpret_cast<float4*>(pw + k) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    if (by == 0 && part_b && threadIdx.x < kOT) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds_b[k * kOT + threadIdx.x];
+        part_b[((int64_t)bz * gx + bx) * kOT + threadIdx.x] = s;
+    }
+}
+
 // wgrad_tiled.hip: used by glass_dual_linear_wgrad_f32 (and the deferred reduction of its partials) when
 // wgrad_tiled_shape(N, O, I) — the partial kernel writes plain [slab][tile][128][256] partial
 // sums (+ [slab][o-tile][128] bias partials), the reduce kernel sums the slabs in order into dW / db.

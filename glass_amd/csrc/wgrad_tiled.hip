@@ -15,7 +15,7 @@
 
 namespace glass {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+
 
 constexpr int kWO = 128, kWI = 256, kWK = 16, kWThreads = 256;
 constexpr int kWStage = kWK * (kWO + kWI);  // floats per stage: 6 144 = 24 KiB

@@ -155,6 +155,37 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=Non
     _check(rc, "glass_dual_linear_dgrad_f32")
 
 
+USE_FUSED_BWD = os.environ.get("GLASS_FUSED_BWD", "1") != "0"  # A/B switch: data + weight gradient of a pair as one launch
+
+
+def _dual_bwd(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, xa, xb, pending, acc, drop=None, gn=None):
+    """Backward of one Linear pair: _dual_dgrad + _dual_wgrad through glass_dual_linear_bwd_f32 (ONE launch at hidden 64 on
+    small graphs, where the two are independent latency-bound kernels; two launches inside the library otherwise)."""
+    if not USE_FUSED_BWD or USE_WGRAD_STREAM:
+        _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop, gn)
+        _dual_wgrad(dsrc, T, stack, mask, z_ratio, act, xa, xb, pending, acc)
+        return
+    n, H = dsrc.shape
+    I = H if xb is None else 2 * H
+    p_drop, call_id = drop if drop is not None else (0.0, 0)
+    if gn is not None:
+        gpart, gx, gsaved, galpha, gact, gp, gcall = gn
+        gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall)
+    else:
+        gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0)
+    rng = ops.rng_state(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
+    ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, I, slot=("stack", len(pending)))
+    rc = _lib.load().glass_dual_linear_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
+                                               0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
+                                               stack[5].data_ptr(), n_out, 0 if addend is None else addend.data_ptr(),
+                                               0 if addend is None else addend.stride(0), float(p_drop), rng, call_id,
+                                               out.data_ptr(), out.stride(0), n, H, *gargs, xa.data_ptr(), xa.stride(0),
+                                               0 if xb is None else xb.data_ptr(), 0 if xb is None else xb.stride(0),
+                                               ws.data_ptr(), _stream())
+    _check(rc, "glass_dual_linear_bwd_f32")
+    pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
+
+
 # A/B switch, off: weight-gradient partial kernels forked onto a second stream inside the captured step (4 forks, one join
 # before the batched reduction).  Measured on MI355X at C2, two interleaved rounds: 0.441 vs 0.386 ms/step — as with the
 # per-op path earlier (0.765 vs 0.678), the fork/join edges of the replayed graph cost more than overlapping these
@@ -381,9 +412,8 @@ class StackProgram:
                                                addend=djk[:, l * H:(l + 1) * H] if emb.jk else None, acc=acc)
             din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
             gpart = torch.empty((nblk, 2, H), **f64)  # conv.gn's backward column sums, from this kernel's epilogue
-            _dual_dgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din,
-                        gn=(gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base))
-            _dual_wgrad(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, rec["g"], rec["h"], pending, acc)
+            _dual_bwd(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din, rec["g"], rec["h"], pending,
+                      acc, gn=(gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base))
             da = torch.empty((n, H), **f32)
             _GN(conv.gn).bwd_from_stats(din[:, :H], rec["a"], rec["gsaved"], da, gpart, ACT_NONE, rec["pc"], conv.call_base,
                                         acc=acc)
@@ -397,8 +427,8 @@ class StackProgram:
                 below, cb = st["layers"][l - 1], emb.convs[l - 1]
                 npart = torch.empty((nblk, 2, H), **f64)
                 gn = (npart, below["c"], below["nsaved"], emb.gns[l - 1].mean_scale, ACT_ELU, p, cb.call_base + 1)
-            _dual_dgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, drop, gn)
-            _dual_wgrad(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, rec["h"], None, pending, acc)
+            _dual_bwd(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, rec["h"], None, pending,
+                      acc, drop, gn)
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations
         _reduce_pending(pending)

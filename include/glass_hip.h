@@ -175,7 +175,7 @@ int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 *
  *        (glass_spmm_csr_f32 with the selection CSR).  dW (+)= GraphNorm-and-gather backward,
  *        dgamma/dbeta/dalpha (+)=.  One launch instead of backward statistics + finalize + apply over [N,H].
  * ---------------------------------------------------------------------------------------- */
-#define GLASS_EMBED_NORM_MAX_ROWS 1024
+#define GLASS_EMBED_NORM_MAX_ROWS 8192
 int glass_embed_norm_fwd_f32(const int64_t* x, const float* W, int64_t V, const int32_t* class_rowptr,
                              const float* gamma, const float* beta, const float* alpha, float eps, float* saved,
                              float* table, const int64_t* z, const int64_t* pos, int64_t n_pos, float p_drop,
@@ -267,6 +267,18 @@ int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
                                 int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
                                 int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
                                 uint64_t gn_call_id, void* stream);
+/*   bwd: the whole backward of one pair for the step program — exactly glass_dual_linear_dgrad_f32 (same arguments)
+ *   followed by glass_dual_linear_wgrad_f32 with dW == NULL (partial sums of dW / db into `ws`, reduced later by
+ *   glass_linear_wgrad_reduce_batch_f32; X / X2 = the pair's inputs).  At hidden 64 on graphs of up to 100 000 nodes
+ *   the two are independent, latency-bound 12-17 us kernels: there they run as two branches of ONE launch (their
+ *   workgroups share the CUs); otherwise as the two launches. */
+int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
+                              double z_ratio, int act, const float* WTimg, int64_t n_out, const float* addend,
+                              int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* out,
+                              int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
+                              int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
+                              uint64_t gn_call_id, const float* X, int64_t ldx, const float* X2, int64_t ldx2, void* ws,
+                              void* stream);
 int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
                                 int64_t N, int64_t H, float* dW, int64_t lddw, float* db, int accumulate, void* ws,

@@ -1,0 +1,47 @@
+"""Compile-time guard (no GPU needed): no kernel of libglass_hip may use scratch memory.  Twice this round a refactor
+silently sent staging registers of a latency-bound kernel to scratch (private arrays at the compiler's promotion limit);
+hipcc reports it per kernel with -Rpass-analysis=kernel-resource-usage."""
+import concurrent.futures
+import glob
+import os
+import re
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "glass_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _usage(src):
+    cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=on",
+           "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", os.devnull]
+    out = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    kernels, name = {}, None
+    for line in out.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            kernels[name] = {}
+        m = re.search(r"(ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill): (\d+)", line)
+        if m and name:
+            kernels[name][m.group(1)] = int(m.group(2))
+    return kernels
+
+
+def test_no_kernel_uses_scratch_or_spills():
+    if not os.path.exists(HIPCC):
+        import pytest
+        pytest.skip("hipcc not available")
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    assert len(srcs) >= 10
+    with concurrent.futures.ThreadPoolExecutor(max_workers=4) as pool:
+        results = list(pool.map(_usage, srcs))
+    seen, bad = 0, []
+    for src, kernels in zip(srcs, results):
+        for k, u in kernels.items():
+            seen += 1
+            if u.get("ScratchSize [bytes/lane]", 0) or u.get("VGPRs Spill", 0):
+                bad.append((os.path.basename(src), k, u))
+    assert seen > 40
+    assert not bad, bad

@@ -146,9 +146,9 @@ def test_step_program_entry_points_validate_on_the_host():
     args = [p, 128, p, p, p, p, 80, 10, 2, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 1000, 128, None]
     assert lib.glass_readout_train_f32(*args) == -3  # max pooling is not fusable
     # table path: more rows than GLASS_EMBED_NORM_MAX_ROWS
-    assert lib.glass_embed_norm_fwd_f32(p, p, 5000, p, p, p, p, 1e-5, p, p, None, None, 0, 0.0, None, 1, p, 64, p, 10, 64,
+    assert lib.glass_embed_norm_fwd_f32(p, p, 10000, p, p, p, p, 1e-5, p, p, None, None, 0, 0.0, None, 1, p, 64, p, 10, 64,
                                         None) == -1
-    assert b"1024" in lib.glass_last_error_string()
+    assert b"8192" in lib.glass_last_error_string()
     assert lib.glass_embed_norm_bwd_f32(None, p, 4, p, p, p, p, p, 1, p, p, p, 1, 64, None) == -1
     # GraphNorm pieces
     ptrs = np.array([p] * 9, dtype=np.uint64)

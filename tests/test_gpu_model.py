@@ -500,9 +500,12 @@ def test_eval_after_optimizer_step_uses_current_weights():
     assert rel_inf(y1.cpu(), _orc.double().eval()(x.reshape(-1), ei, ew.double(), z).detach()) < TOL
 
 
-def test_stack_program_large_table_keeps_whole_graph_kernels():
-    """More than 1024 embedding rows (node-id style features): lookup + emb_gn stay on the [N,H] kernels."""
-    emb, arena, orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.8, 0.0, seed=5, V=1500)
+@pytest.mark.parametrize("V,n", [(1500, 700), (9000, 9500)])
+def test_stack_program_large_tables(V, n):
+    """Large embedding tables: up to GLASS_EMBED_NORM_MAX_ROWS = 8 192 rows (the degree feature of the 1 M-node power-law
+    graph has 1 814) the lookup + emb_gn still run through the table; beyond (node-id style features) they stay on
+    the [N,H] kernels.  Both against the fp64 oracle."""
+    emb, arena, orc, (x, ei, ew, z), gout = _emb_pair(2, 1, "mean", 0.8, 0.0, seed=5, V=V, n=n, n_pairs=6 * n)
     emb.train()
     args = [t.to(DEV) for t in (x, ei, ew, z)]
     arena.zero()
