@@ -330,26 +330,8 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
     }
 }
 
-// 16 consecutive floats of a row as four named float4 (NOT an array: the two 16-float arrays of the raw-load stage sat at
-// the compiler's alloca-promotion limit and were kept in scratch memory across the MFMA pass)
-struct F16 {
-    float4 q0, q1, q2, q3;
-    __device__ __forceinline__ void load(const float* p, bool ok) {
-        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-        q0 = ok ? *reinterpret_cast<const float4*>(p) : z;
-        q1 = ok ? *reinterpret_cast<const float4*>(p + 4) : z;
-        q2 = ok ? *reinterpret_cast<const float4*>(p + 8) : z;
-        q3 = ok ? *reinterpret_cast<const float4*>(p + 12) : z;
-    }
-    __device__ __forceinline__ float at(int s) const {  // s is a compile-time constant at every call site (unrolled)
-        const float4& q = s < 4 ? q0 : s < 8 ? q1 : s < 12 ? q2 : q3;
-        const int e = s & 3;
-        return e == 0 ? q.x : e == 1 ? q.y : e == 2 ? q.z : q.w;
-    }
-};
-
 struct DgradRaw {
-    F16 d, t;
+    float d[kKC], t[kKC];
 };
 
 // Optional epilogue of the data-gradient kernel: its first H output columns are the gradient dy of a GraphNorm
@@ -408,14 +390,14 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
     staged_product<NT, KT, NLOC, NLOC, THREADS, DgradRaw>(
         acc, WT, lds_w, lane, NLOC * cg, 0,
         [&](int kc, DgradRaw& raw) __attribute__((always_inline)) {
-            raw.d.load(drow + kc * kKC, row_ok);
-            if (act == GLASS_ACT_ELU) raw.t.load(trow + kc * kKC, row_ok);
+            load16(raw.d, drow + kc * kKC, row_ok);
+            if (act == GLASS_ACT_ELU) load16(raw.t, trow + kc * kKC, row_ok);
         },
         [&](int, const DgradRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < kKC; ++s) {
-                float v = raw.d.at(s) * coef;
-                if (act == GLASS_ACT_ELU) v *= elu_grad_f(raw.t.at(s));
+                float v = raw.d[s] * coef;
+                if (act == GLASS_ACT_ELU) v *= elu_grad_f(raw.t[s]);
                 a[s] = v;
             }
         });

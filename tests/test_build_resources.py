@@ -45,3 +45,27 @@ def test_no_kernel_uses_scratch_or_spills():
                 bad.append((os.path.basename(src), k, u))
     assert seen > 40
     assert not bad, bad
+
+
+def test_dense_kernels_keep_vector_loads():
+    """The fused dense kernels load their operands as 16-byte vectors.  (A helper that selected per element between a
+    load and zero made hipcc emit 64 branch-guarded dword loads per lane and doubled the data-gradient kernels' time.)"""
+    if not os.path.exists(HIPCC):
+        import pytest
+        pytest.skip("hipcc not available")
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        dst = os.path.join(tmp, "dense.s")
+        cmd = [HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=on", "-S", "--cuda-device-only",
+               "dense.hip", "-o", dst]
+        out = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        asm = open(dst).read()
+    found = 0
+    for m in re.finditer(r"^(_ZN5glass\d+dual_(?:fwd|dgrad|bwd)_kernel[^:\s]*):", asm, re.M):
+        body = asm[m.end():asm.index(".Lfunc_end", m.end())]
+        scalar = len(re.findall(r"^\s*global_load_dword\s", body, re.M))
+        vector = len(re.findall(r"global_load_dwordx4", body))
+        assert scalar == 0 and vector >= 10, (m.group(1), scalar, vector)
+        found += 1
+    assert found >= 8

@@ -738,7 +738,7 @@ def test_embed_norm_table_path(H, V, n):
     if V > 1:
         assert float((dW[V - 1] - 0.5).abs().max()) == 0.0  # unused row: no gradient
     # more rows than the table path takes -> rejected (callers keep the whole-graph kernels)
-    assert lib.glass_embed_norm_fwd_f32(xg.data_ptr(), Wg.data_ptr(), 1025, sel.op.rowptr.data_ptr(), g.data_ptr(),
+    assert lib.glass_embed_norm_fwd_f32(xg.data_ptr(), Wg.data_ptr(), _lib.EMBED_NORM_MAX_ROWS + 1, sel.op.rowptr.data_ptr(), g.data_ptr(),
                                         b.data_ptr(), a.data_ptr(), 1e-5, saved.data_ptr(), table.data_ptr(), 0, 0, 0, 0.0,
                                         0, 1, out.data_ptr(), H, mask.data_ptr(), n, H, st) != 0
 

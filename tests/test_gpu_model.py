@@ -641,7 +641,7 @@ def test_graph_epochs_with_evaluation_between_match_eager_loop(monkeypatch):
         gnn = run.build_model(8, 1, 0.0, 1, "size", 1.0, "sum")
         arena = ParamArena(gnn)
         opt = FlatAdam(arena, lr=1e-3)
-        trn, val = run.loader(run.trn, 2, True), run.loader(run.val, 2, False)
+        trn, val, _tst = run.loaders(2)
         scores = []
         for _ in range(3):
             train.train(opt, gnn, trn, run.loss_fn)
