@@ -123,8 +123,17 @@ __device__ __forceinline__ void reduce_groups(Vec<VW>& acc) {
 //    reduction.  On a degree-1 pattern that is U*G independent 4H-byte gathers in flight per wave behind a single
 //    index round trip (the previous form had 2 per group behind three dependent round trips: 0.55 of the HBM roofline).
 constexpr int64_t kStreamNtBytes = 256ll << 20;  // Infinity Cache size
-constexpr int kItemRows = 64;    // rows per sweep item (one coalesced rowptr load per wave)
-constexpr int kItemEdges = 256;  // edges per sweep item (LDS staging: 2 KiB of (col,val) per wave)
+// Tunables (overridable only by the laboratory build, tools/Makefile `lab`): gathers in flight per lane group and the
+// sweep item caps
+#ifndef GLASS_K1_U
+#define GLASS_K1_U 8
+#endif
+#ifndef GLASS_K1_ITEM_EDGES
+#define GLASS_K1_ITEM_EDGES 256
+#endif
+constexpr int kGathers = GLASS_K1_U;
+constexpr int kItemRows = 64;                    // rows per sweep item (one coalesced rowptr load per wave)
+constexpr int kItemEdges = GLASS_K1_ITEM_EDGES;  // edges per sweep item (LDS staging: 2 KiB of (col,val) per wave at 256)
 
 template <int VW, int LPR, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
@@ -326,8 +335,8 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* v
     // 14.9 / 13.2 / 12.7, hpo_neuro-shape 87.8 / 83.4 / 81.0, power-law H=256 2638 / 2600 / 2597.
     // streamed bytes of this launch (indices in, Y out) beyond what the Infinity Cache holds -> non-temporal streams
     const int64_t streamed = (int64_t)hdr[H_NNZ] * 8 + (int64_t)hdr[H_NROWS] * (4 * H + 4);
-    if (streamed > kStreamNtBytes) return launch_spmm_u<VW, LPR, 8, true>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
-    return launch_spmm_u<VW, LPR, 8, false>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
+    if (streamed > kStreamNtBytes) return launch_spmm_u<VW, LPR, kGathers, true>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
+    return launch_spmm_u<VW, LPR, kGathers, false>(rowptr, col, val, X, ldx, Y, ldy, H, hdr, plan, ws, st);
 }
 
 }  // namespace glass

@@ -11,3 +11,5 @@ python bench.py --steps 200 --warmup 20 > $out/bench_c2.json 2> $out/bench_c2.er
 tail -3 $out/bench_c2.err; cat $out/bench_c2.json
 python bench.py --workload powerlaw --steps 20 --warmup 3 --no-cpu-baseline --no-roofline-hbm > $out/bench_c5.json 2> $out/bench_c5.err; echo "bench c5 rc=$?"
 tail -3 $out/bench_c5.err; cat $out/bench_c5.json
+GLASS_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 50 --warmup 5 --workload em_user --features nodeid --no-cpu-baseline --no-roofline-hbm > $out/bench_gloo2_nodeid.json 2> $out/bench_gloo2_nodeid.err; echo "bench gloo2 nodeid rc=$?"
+tail -3 $out/bench_gloo2_nodeid.err; cat $out/bench_gloo2_nodeid.json | cut -c1-1200
