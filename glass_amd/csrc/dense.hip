@@ -16,8 +16,8 @@
 // 16-column output tile, the same chunk of row (16t+i) of the [out][in] weight — both are plain 16-B
 // loads of consecutive floats; MFMA step s multiplies element s of the four chunks (the matrix core
 // sums over k in any order, so no transposes or shuffles are needed).  The weight slice of a K-pass is
-// staged once per workgroup in LDS, pre-permuted into consumption order (see WStage).  Supported hidden
-// sizes: 64, 128, 192 (256: weight images exceed the LDS budget -> library GEMM + stand-alone mix).
+// staged once per workgroup in LDS, pre-permuted into consumption order (see WStage).  Hidden sizes 64 and 128
+// (128: two wave groups split the output columns); 256 / 512 take the LDS-tiled kernels of dense_tiled.hip.
 #include "common.h"
 #include "dense_common.h"
 #include "wgrad_common.h"
