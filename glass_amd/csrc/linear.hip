@@ -132,6 +132,13 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     const int64_t tiles = ceil_div(I, kIT) * ceil_div(O, kOT);
     int64_t max_slabs = kMaxSlabs / tiles;
     if (max_slabs > 128) max_slabs = 128;
+    // Small graphs: this kernel shares ONE launch with the data gradient of the same pair (dual_bwd_kernel: N/64 row
+    // tiles + these slabs, two workgroups per CU).  Keep the sum within the 512 resident workgroups of the chip — a
+    // handful of surplus workgroups would wait for a free slot and run as a second round (28 vs ~21 us at ppi_bp-shape).
+    if (N <= 100000) {
+        const int64_t room = (2 * 256 - 4 - ceil_div(N, 64)) / tiles;
+        if (room >= 32 && room < max_slabs) max_slabs = room;
+    }
     if (max_slabs < 32) max_slabs = 32;
     int64_t rows = ceil_div(N, max_slabs);
     if (rows < 64) rows = 64;

@@ -11,6 +11,7 @@
 // chunk go through per-chunk partial rows summed in fixed order (no float atomics).
 #include "common.h"
 
+#include <stdint.h>
 #include <stdlib.h>
 #include <vector>
 
@@ -32,7 +33,7 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 typedef float k1_f32x4 __attribute__((ext_vector_type(4)));
 // header word indices
 enum { H_MAGIC, H_VER, H_NROWS, H_NNZ, H_NSWEEP, H_NLONG, H_NREDUCE, H_NSLOTS, H_LONG_THR, H_LONG_CHUNK,
-       H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RP_FACTOR, H_RSV1, H_RSV2 };
+       H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RP_FACTOR, H_MIN_ITEM_DEG, H_RSV2 };
 
 // ---- vector helpers --------------------------------------------------------------------------
 template <int VW> struct Vec;
@@ -135,7 +136,11 @@ constexpr int kGathers = GLASS_K1_U;
 constexpr int kItemRows = 64;                    // rows per sweep item (one coalesced rowptr load per wave)
 constexpr int kItemEdges = GLASS_K1_ITEM_EDGES;  // edges per sweep item (LDS staging: 2 KiB of (col,val) per wave at 256)
 
-template <int VW, int LPR, int U, bool NT>
+// FLAT = false: the plan holds no item short enough for flat mode at this H (header word H_MIN_ITEM_DEG; e.g. every
+// BASELINE graph: mean degree 12-444) -> a specialisation without the flat branch, its LDS staging and its registers
+// (the kernel is latency x occupancy bound on cache-resident graphs: 17 080 one-row waves at ppi_bp-shape are 2-3
+// rounds of the chip, and a wave more per SIMD is a round less).
+template <int VW, int LPR, int U, bool NT, bool FLAT>
 __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
@@ -145,9 +150,10 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
                                                             int rp_factor) {
     constexpr int G = kWave / LPR;
     constexpr int kWaves = kBlock / kWave;
-    __shared__ int32_t s_rp[G > 1 ? kWaves : 1][kItemRows + 1];
-    __shared__ int32_t s_col[G > 1 ? kWaves : 1][kItemEdges];
-    __shared__ float s_val[G > 1 ? kWaves : 1][kItemEdges];
+    constexpr bool kFlat = FLAT && G > 1;
+    __shared__ int32_t s_rp[kFlat ? kWaves : 1][kFlat ? kItemRows + 1 : 1];
+    __shared__ int32_t s_col[kFlat ? kWaves : 1][kFlat ? kItemEdges : 1];
+    __shared__ float s_val[kFlat ? kWaves : 1][kFlat ? kItemEdges : 1];
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * kWaves + w;
@@ -162,11 +168,11 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
     const int nrows = r1 - r0, ne = e1 - e0;
     // start edge of row r0 + lane (lanes past the item hold e1, so "end of row i" is always lane i + 1's value or e1)
     const int rp_reg = (lane < nrows) ? ld_stream<NT>(rowptr + r0 + lane) : e1;
-    if (G > 1 && ne <= rp_factor * G * nrows) {
+    if (kFlat && ne <= rp_factor * G * nrows) {
         // ---- flat mode ----
-        int32_t* rp_s = s_rp[G > 1 ? w : 0];
-        int32_t* col_s = s_col[G > 1 ? w : 0];
-        float* val_s = s_val[G > 1 ? w : 0];
+        int32_t* rp_s = s_rp[kFlat ? w : 0];
+        int32_t* col_s = s_col[kFlat ? w : 0];
+        float* val_s = s_val[kFlat ? w : 0];
         int cr[kItemEdges / kWave];
         float vr[kItemEdges / kWave];
 #pragma unroll
@@ -312,8 +318,13 @@ static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float*
     const int n_waves = hdr[H_NSWEEP];
     if (n_waves > 0) {
         dim3 grid((unsigned)ceil_div(n_waves, kBlock / kWave), n_ctiles);
-        hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U, NT>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx, Y,
-                           ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_RP_FACTOR]);
+        constexpr int G = kWave / LPR;
+        if (G > 1 && hdr[H_MIN_ITEM_DEG] <= hdr[H_RP_FACTOR] * G)  // some item is short enough for flat mode at this H
+            hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U, NT, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx,
+                               Y, ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_RP_FACTOR]);
+        else
+            hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U, NT, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx,
+                               Y, ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, 0);
     }
     if (hdr[H_NLONG] > 0) {
         dim3 grid((unsigned)hdr[H_NLONG], n_ctiles);
@@ -390,8 +401,12 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     int64_t acc = 0, it_r0 = 0, it_edges = 0;
     int32_t n_slots = 0;
     bool open = false;
+    int64_t min_item_deg = INT32_MAX;  // min over sweep items of ceil(edges / rows): decides whether flat mode can occur
     auto close_item = [&](int64_t r_end) {
         if (!open) return;
+        const int64_t e = (int64_t)rowptr[r_end] - rowptr[it_r0];
+        const int64_t md = ceil_div(e, r_end - it_r0);
+        if (md < min_item_deg) min_item_deg = md;
         sweep.push_back((int32_t)it_r0);
         sweep.push_back((int32_t)r_end);
         sweep.push_back(rowptr[it_r0]);
@@ -450,6 +465,7 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     plan[H_LONG_CHUNK] = kLongChunk;
     // Flat-mode threshold (mean degree of an item's rows <= factor * G, G = lane groups per wave at the launch's H).
     plan[H_RP_FACTOR] = kFlatFactor;
+    plan[H_MIN_ITEM_DEG] = (int32_t)min_item_deg;
     plan[H_OFF_SWEEP] = (int32_t)off_sweep;
     plan[H_OFF_LONG] = (int32_t)off_long;
     plan[H_OFF_REDUCE] = (int32_t)off_reduce;

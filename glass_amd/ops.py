@@ -510,6 +510,23 @@ def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id
 # ---------------------------------------------------------------------------------------------
 # K7  subgraph pooling
 # ---------------------------------------------------------------------------------------------
+# Largest padded node matrices (B * Smax entries) the ORDERED, atomic-free scatters stage in LDS (pool.hip kPoolOrderedMax,
+# readout.hip kReadoutOrderedMax).  Beyond them — and for max pooling — the library falls back to float atomics: same
+# values within rounding, but no longer bitwise repeatable from run to run.  Said once, loudly, instead of silently.
+POOL_ORDERED_MAX, READOUT_ORDERED_MAX = 12288, 16384
+_atomic_warned = set()
+
+
+def warn_atomic_fallback(what, entries, limit):
+    if what in _atomic_warned:
+        return
+    _atomic_warned.add(what)
+    import warnings
+    warnings.warn(f"{what}: {entries} padded subgraph entries exceed the {limit} the ordered (atomic-free) scatter stages in "
+                  "LDS (or max pooling is used); falling back to float atomics — results stay within rounding but are not "
+                  "bitwise repeatable between runs", RuntimeWarning, stacklevel=3)
+
+
 class SegmentPoolFn(torch.autograd.Function):
     """out[b] = reduce over the non-padding nodes of pos[b] of emb[node]  (sum|mean|max|size)."""
     @staticmethod
@@ -539,6 +556,8 @@ class SegmentPoolFn(torch.autograd.Function):
         mode, n, C = ctx.cfg
         dout, ldd = _rows(dout)
         B, Smax = pos.shape
+        if mode == "max" or B * Smax > POOL_ORDERED_MAX:
+            warn_atomic_fallback("segment pool backward", B * Smax, POOL_ORDERED_MAX)
         demb = torch.zeros((n, C), dtype=torch.float32, device=dout.device)
         rc = _lib.load().glass_segment_pool_bwd_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, Smax, POOL_MODES[mode],
                                                     0 if argmax is None else argmax.data_ptr(), demb.data_ptr(), C, n,

@@ -358,6 +358,8 @@ class StackProgram:
         lib, gn = _lib.load(), self.emb.gns[-1]
         n, C = jk.shape
         B, Smax = pos.shape
+        if B * Smax > ops.READOUT_ORDERED_MAX:
+            ops.warn_atomic_fallback("fused readout", B * Smax, ops.READOUT_ORDERED_MAX)
         K = head.weight.shape[0]
         dev = jk.device
         f32 = dict(dtype=torch.float32, device=dev)

@@ -66,6 +66,10 @@ def _check_plan(rowptr):
         assert 0 <= r0 < r1 <= n and r1 - r0 <= 64 and e0 == rp[r0] and e1 == rp[r1] and e1 - e0 <= 256
         covered += list(range(r0, r1))
     assert covered == np.nonzero(deg < thr)[0].tolist()
+    # header word 14: the smallest mean degree (rounded up) of any sweep item — the launch picks the kernel without the
+    # flat-mode branch when no item can qualify at its feature width
+    if n_sweep:
+        assert hdr[14] == min(-(-(e1 - e0) // (r1 - r0)) for r0, r1, e0, e1 in sweep.tolist())
     # every long row (deg >= thr) is covered exactly by its chunks, in order, whole 64-edge batches
     long_rows = np.nonzero(deg >= thr)[0]
     assert sorted(set(longs[:, 0].tolist())) == long_rows.tolist()

@@ -717,7 +717,9 @@ def test_large_batches_fall_back_to_atomic_scatters():
     arena = ParamArena(model)
     xg, eig, ewg, posg, yg = x.to(DEV), torch.from_numpy(ei).to(DEV), torch.from_numpy(ew).to(DEV), pos.to(DEV), y.to(DEV)
     arena.zero()
-    loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg)
+    ops._atomic_warned.clear()
+    with pytest.warns(RuntimeWarning, match="not bitwise repeatable"):  # the fallback announces itself (once per kind)
+        loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg)
     orc = O.OracleGLASS(H, L, 5, K, aggr="mean", pool="sum", z_ratio=0.8)
     orc.load_state_dict(sd)
     orc = orc.double().train()
