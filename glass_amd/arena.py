@@ -120,7 +120,10 @@ class ParamArena(FlatGradBucket):
                     tiled = _lib.load().glass_dual_linear_layout(O // 2) == 1
                     Wimg, WTimg = torch.empty_like(W).reshape(-1), torch.empty_like(W).reshape(-1)
                     self._packs.append((W, Wimg, O, K, 0 | ((1 << 1) if tiled else 0)))
-                    self._packs.append((W, WTimg, K, O, 1 | ((2 << 1) if tiled else 0)))
+                    # data-gradient operand: NT = K output columns in 256-column tiles; a 128-wide output (hidden 128,
+                    # trans pair) keeps the wave16 kernel and its image
+                    plain = 2 if K % 256 == 0 else 0
+                    self._packs.append((W, WTimg, K, O, 1 | ((plain << 1) if tiled else 0)))
                     mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)
                 else:
                     mod._stack[kind] = (W, b, dW, db)

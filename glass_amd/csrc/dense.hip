@@ -583,10 +583,14 @@ static void allow_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-static bool wave16_shape_ok(int64_t H) { return H == 64 || H == 128; }
+#ifndef GLASS_H128_TILED
+#define GLASS_H128_TILED 1  // hidden 128 on the LDS-tiled kernels (64-row tiles) instead of the two-wave-group wave16 kernels
+#endif
+static bool wave16_shape_ok(int64_t H) { return H == 64 || (H == 128 && !GLASS_H128_TILED); }
 // Above this many rows the two halves of the backward of a pair fill the chip on their own (one launch each, the
 // weight gradient with its 4-stage pipeline); below, they run as two branches of one launch (dual_bwd_kernel).
 static constexpr int64_t kFusedBwdMaxRows = 100000;
+static bool tiled_here(int64_t H) { return tiled_shape_ok(H) && !wave16_shape_ok(H); }
 static bool dense_shape_ok(int64_t H) { return wave16_shape_ok(H) || tiled_shape_ok(H); }
 static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at once: two when K needs more than one pass
     const size_t image = (size_t)NT * 256;
@@ -600,10 +604,10 @@ extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H)
 
 // Operand-image layout glass_dense_pack_batch_f32 must produce for hidden size H: 0 = wave16 images (forward and data
 // gradient alike), 1 = tiled (forward operand: paired layout; data-gradient operand: plain layout)
-extern "C" int glass_dual_linear_layout(int64_t H) { return tiled_shape_ok(H) ? 1 : 0; }
+extern "C" int glass_dual_linear_layout(int64_t H) { return tiled_here(H) ? 1 : 0; }
 
 // rows per workgroup = rows per epilogue statistics partial
-extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return tiled_shape_ok(H) ? kTiledRows : 64; }
+extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return tiled_here(H) ? tiled_rows(H) : 64; }
 
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
@@ -631,7 +635,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs > 1 pass and both fit)
     const size_t lds_comb = lds_bytes(2 * H, (int)(2 * H / 64)), lds_trans = lds_bytes(2 * H, (int)(H / 64));
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
-    if (tiled_shape_ok(H))
+    if (tiled_here(H))
         return launch_tiled_fwd(xa, lda, xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, H, stats, pro, st);
 #define GLASS_FWD(HH, CS, RW)                                                                                      \
     if (H == HH) {                                                                                                 \
@@ -691,7 +695,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         return glass_dual_linear_wgrad_f32(dsrc, ldd, T, ldt, mask, z_ratio, act, wg->X, wg->ldx, wg->X2, wg->ldx2, n_nodes, H,
                                            nullptr, 0, nullptr, 0, wg->ws, stream);
     };
-    if (tiled_shape_ok(H)) {
+    if (tiled_here(H) && !(H == 128 && n_out == H)) {  // (hidden 128, 128-wide output: wave16 kernel below, wave16 image)
         const int rc = launch_tiled_dgrad(dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, n_out, addend, ldadd, drop, rng_state,
                                           out, ldo, n_nodes, H, gs, st);
         return rc ? rc : wgrad_after();

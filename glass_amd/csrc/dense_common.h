@@ -36,7 +36,7 @@ enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2 };
 
 // dense_tiled.hip
 bool tiled_shape_ok(int64_t H);
-constexpr int kTiledRows = 128;  // rows per workgroup = rows per statistics partial of the tiled kernels
+int tiled_rows(int64_t H);  // rows per workgroup = rows per statistics partial of the tiled kernels (64 at hidden 128, else 128)
 int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
                      const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,
                      int64_t N, int64_t H, double* stats, const GnPrologue& pro, hipStream_t st);

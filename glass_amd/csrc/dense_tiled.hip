@@ -23,35 +23,47 @@ namespace glass {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kTM = kTiledRows, kTN = 256, kTK = 16, kTThreads = 256;
-constexpr int kAPlane = kTM + 2;  // float4 per k-quad plane of the A image (+2: the 4 lanes that stage one row's 64 B
-                                  // land in 4 different bank groups; reads are per-row consecutive either way)
-constexpr int kBPlane = kTN;
-constexpr int kAImg = 4 * kAPlane, kBImg = 4 * kBPlane;  // float4 per stage
-constexpr int kStageVecs = kAImg + kBImg;                // 1 544 float4 = 24 704 B
-constexpr size_t kTiledLds = 2 * (size_t)kStageVecs * sizeof(float4);
+constexpr int kTK = 16, kTThreads = 256;
+// Tile geometry.  BM rows x BN column slots per workgroup; 4 waves as 2 (rows) x 2 (columns), each BM/2 x BN/2 =
+// RB x CB MFMA tiles.  BM = 128 on large graphs (hidden 256 / 512: a weight byte fetched once per 128 rows); BM = 64 at
+// hidden 128 (config 4, N = 50 000: 782 instead of 391 workgroups for 256 CUs, three per CU instead of a ragged 1-2).
+// BN = 256 everywhere except the data gradient with a 128-wide output (hidden 128, trans pair).
+template <int BM, int BN>
+struct Tile {
+    static constexpr int RB = BM / 64, CB = BN / 64;
+    static constexpr int kAPlane = BM + 2;  // float4 per k-quad plane of the A image (+2: the 4 lanes that stage one row's
+                                            // 64 B land in 4 different bank groups; reads are per-row consecutive either way)
+    static constexpr int kBPlane = BN;
+    static constexpr int kAImg = 4 * kAPlane, kBImg = 4 * kBPlane;  // float4 per stage
+    static constexpr int kStageVecs = kAImg + kBImg;                // 128 x 256: 1 544 float4 = 24 704 B
+    static constexpr size_t kLds = 2 * (size_t)kStageVecs * sizeof(float4);
+    static constexpr int kAPer = BM * 4 / kTThreads, kBPer = BN * 4 / kTThreads;  // staging float4 per thread
+};
 
-bool tiled_shape_ok(int64_t H) { return H == 256 || H == 512; }
+bool tiled_shape_ok(int64_t H) { return H == 128 || H == 256 || H == 512; }
+int tiled_rows(int64_t H) { return H == 128 ? 64 : 128; }
 
 __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
-// acc[rb][cb] += A(rows wm*64 + rb*32 ..) . B(slots wn*128 + cb*32 ..) over the 16 k of one stage
-__device__ __forceinline__ void tile_mma(f32x16 (&acc)[2][4], const float4* __restrict__ A, const float4* __restrict__ B,
-                                         int j, int h, int wm, int wn) {
+// acc[rb][cb] += A(rows wm*BM/2 + rb*32 ..) . B(slots wn*BN/2 + cb*32 ..) over the 16 k of one stage
+template <int BM, int BN>
+__device__ __forceinline__ void tile_mma(f32x16 (&acc)[BM / 64][BN / 64], const float4* __restrict__ A,
+                                         const float4* __restrict__ B, int j, int h, int wm, int wn) {
+    using TL = Tile<BM, BN>;
 #pragma unroll
     for (int sq = 0; sq < 2; ++sq) {
         const int q = h * 2 + sq;
-        float4 a[2], b[4];
+        float4 a[TL::RB], b[TL::CB];
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) a[rb] = A[q * kAPlane + wm * 64 + rb * 32 + j];
+        for (int rb = 0; rb < TL::RB; ++rb) a[rb] = A[q * TL::kAPlane + wm * (BM / 2) + rb * 32 + j];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) b[cb] = B[q * kBPlane + wn * 128 + cb * 32 + j];
+        for (int cb = 0; cb < TL::CB; ++cb) b[cb] = B[q * TL::kBPlane + wn * (BN / 2) + cb * 32 + j];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < TL::RB; ++rb)
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
+                for (int cb = 0; cb < TL::CB; ++cb)
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[rb], e), f4e(b[cb], e), acc[rb][cb], 0, 0, 0);
     }
 }
@@ -68,21 +80,22 @@ __device__ __forceinline__ bool tile_of_block(int nct, int n_rowtiles, int& rt, 
 
 static inline unsigned tiled_grid(int64_t n_rowtiles, int nct) { return (unsigned)(ceil_div(n_rowtiles, 8) * 8 * nct); }
 
-// The weight stage: 1 024 float4, already in LDS order in the packed image
+// The weight stage: 4 * BN float4 (PER = 2 or 4 per thread), already in LDS order in the packed image
+template <int PER>
 struct BStage {
-    float4 v[4];
+    float4 v[PER];
     __device__ __forceinline__ void issue(const float4* __restrict__ img) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = img[threadIdx.x + kTThreads * i];
+        for (int i = 0; i < PER; ++i) v[i] = img[threadIdx.x + kTThreads * i];
     }
     __device__ __forceinline__ void commit(float4* __restrict__ B) const {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) B[threadIdx.x + kTThreads * i] = v[i];
+        for (int i = 0; i < PER; ++i) B[threadIdx.x + kTThreads * i] = v[i];
     }
 };
 
 // ---- forward ----------------------------------------------------------------------------------------------------
-template <int H, bool COMB>
+template <int H, bool COMB, int BM>
 __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                 const float* __restrict__ xb, int64_t ldb,
                                                                 const float* __restrict__ Wimg,
@@ -92,18 +105,19 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __
                                                                 float* __restrict__ out, int64_t ldo, int64_t N,
                                                                 double* __restrict__ stats, GnPrologue pro,
                                                                 int n_rowtiles) {
-    constexpr int KT = COMB ? 2 * H : H, NKS = KT / kTK, NCT = H / 128;
+    using TL = Tile<BM, 256>;  // 256 column slots = 128 columns of the f1 half + the same 128 of the f0 half
+    constexpr int KT = COMB ? 2 * H : H, NKS = KT / kTK, NCT = H / 128, RB = TL::RB, AP = TL::kAPer;
     extern __shared__ float4 smem[];
     int rt, ct;
     if (!tile_of_block(NCT, n_rowtiles, rt, ct)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)rt * kTM;
+    const int64_t row0 = (int64_t)rt * BM;
     // staging assignment: float4 f = tid + 256 i of the A tile: row f >> 2, k-quad f & 3 (4 lanes cover one row's 64 B)
-    int srow[2], skq[2];
-    bool sok[2];
+    int srow[AP], skq[AP];
+    bool sok[AP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AP; ++i) {
         const int f = tid + kTThreads * i;
         srow[i] = f >> 2;
         skq[i] = f & 3;
@@ -115,13 +129,13 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __
         drop.step = pro.rng_state[1];
     }
     const bool side_writer = pro.side != nullptr && ct == 0;  // every column tile computes the operand; one writes it
-    const float4* wimg = reinterpret_cast<const float4*>(Wimg) + (int64_t)ct * NKS * kBImg;
+    const float4* wimg = reinterpret_cast<const float4*>(Wimg) + (int64_t)ct * NKS * TL::kBImg;
 
-    float4 av[2], asc[2], ash[2];
-    BStage bs;
+    float4 av[AP], asc[AP], ash[AP];
+    BStage<TL::kBPer> bs;
     auto issue = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AP; ++i) {
             const int k = ks * kTK + 4 * skq[i];
             const int64_t r = row0 + srow[i];
             const float* src = (!COMB || k < H) ? xa + r * lda + k : xb + r * ldb + (k - H);
@@ -131,11 +145,11 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __
                 ash[i] = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + k);
             }
         }
-        bs.issue(wimg + (int64_t)ks * kBImg);
+        bs.issue(wimg + (int64_t)ks * TL::kBImg);
     };
     auto commit = [&](int ks, float4* stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AP; ++i) {
             const int k = ks * kTK + 4 * skq[i];
             float4 v = av[i];
             if (pro.saved && (!COMB || k < H) && sok[i]) {
@@ -152,14 +166,14 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __
                 v = make_float4(o[0], o[1], o[2], o[3]);
                 if (side_writer) *reinterpret_cast<float4*>(pro.side + r * pro.lds + k) = v;
             }
-            stage[skq[i] * kAPlane + srow[i]] = v;
+            stage[skq[i] * TL::kAPlane + srow[i]] = v;
         }
-        bs.commit(stage + kAImg);
+        bs.commit(stage + TL::kAImg);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[RB][4];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
@@ -169,25 +183,25 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __
     commit(0, smem);
     __syncthreads();
     for (int ks = 0; ks < NKS; ++ks) {
-        float4* cur = smem + (ks & 1) * kStageVecs;
-        float4* nxt = smem + ((ks + 1) & 1) * kStageVecs;
+        float4* cur = smem + (ks & 1) * TL::kStageVecs;
+        float4* nxt = smem + ((ks + 1) & 1) * TL::kStageVecs;
         if (ks + 1 < NKS) issue(ks + 1);  // in flight across this stage's MFMAs
-        tile_mma(acc, cur, cur + kAImg, j, h, wm, wn);
+        tile_mma<BM, 256>(acc, cur, cur + TL::kAImg, j, h, wm, wn);
         if (ks + 1 < NKS) commit(ks + 1, nxt);  // the other buffer: last read in stage ks - 1, before the previous barrier
         __syncthreads();
     }
 
-    // epilogue: acc[rb][cb][i] = row rt*128 + wm*64 + rb*32 + 8(i>>2) + 4h + (i&3); cb 0,1: f1 columns colp, colp+1;
+    // epilogue: acc[rb][cb][i] = row rt*BM + wm*BM/2 + rb*32 + 8(i>>2) + 4h + (i&3); cb 0,1: f1 columns colp, colp+1;
     // cb 2,3: the same two columns of the f0 half
     const int colp = ct * 128 + wn * 64 + 2 * j;
     const float2 b1 = *reinterpret_cast<const float2*>(bias + colp);
     const float2 b0 = *reinterpret_cast<const float2*>(bias + H + colp);
     double s0 = 0.0, s1 = 0.0, q0 = 0.0, q1 = 0.0;  // column sums of `out` over this lane's rows (GraphNorm that follows)
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int64_t r = row0 + wm * 64 + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            const int64_t r = row0 + wm * (BM / 2) + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
             if (r < N) {
                 const bool lab = mask[r] != 0;
                 const float w1 = lab ? zr : omz, w0 = lab ? omz : zr;
@@ -226,8 +240,10 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __
 
 // ---- backward data gradient ---------------------------------------------------------------------------------------
 // out[N, NOUT] = dZ[N, 2H] @ Wstack[2H, NOUT] (+ addend)(* dropout mask), dZ[n, o] = coef(n, o < H) * dsrc[n, o mod H]
-// * act'(T[n, o]) synthesised while staging; WTimg = Wstack^T packed plain-tiled.
-template <int H, int NOUT>
+// * act'(T[n, o]) synthesised while staging; WTimg = Wstack^T packed plain-tiled: a lane holds four consecutive output
+// columns (cb = 0..3).  (A 128-column variant for the trans pair of hidden 128 was built and dropped: every form of it
+// kept staging registers in scratch memory; that one data gradient stays on dense.hip's kernel.)
+template <int H, int NOUT, int BM, int BN>
 __global__ __launch_bounds__(kTThreads, 2) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                   const float* __restrict__ T, int64_t ldt,
                                                                   const uint8_t* __restrict__ mask, float zr, float omz,
@@ -236,57 +252,58 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_dgrad_kernel(const float* 
                                                                   Drop drop, const uint64_t* __restrict__ rng_state,
                                                                   float* __restrict__ out, int64_t ldo, int64_t N,
                                                                   GnBwdStats gs, int n_rowtiles) {
-    constexpr int KT = 2 * H, NKS = KT / kTK, NCT = NOUT / kTN;
-    static_assert(NOUT % kTN == 0, "output width must be a multiple of the column tile");
+    using TL = Tile<BM, BN>;
+    constexpr int KT = 2 * H, NKS = KT / kTK, NCT = NOUT / BN, RB = TL::RB, CB = TL::CB, AP = TL::kAPer;
+    static_assert(NOUT % BN == 0 && CB == 4, "output width must be a multiple of the 256-slot column tile");
     extern __shared__ float4 smem[];
     int rt, ct;
     if (!tile_of_block(NCT, n_rowtiles, rt, ct)) return;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
-    const int64_t row0 = (int64_t)rt * kTM;
-    int srow[2], skq[2];
-    bool sok[2], slab[2];
+    const int64_t row0 = (int64_t)rt * BM;
+    int srow[AP], skq[AP];
+    bool sok[AP], slab[AP];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < AP; ++i) {
         const int f = tid + kTThreads * i;
         srow[i] = f >> 2;
         skq[i] = f & 3;
         sok[i] = row0 + srow[i] < N;
         slab[i] = sok[i] && mask[row0 + srow[i]] != 0;
     }
-    const float4* wimg = reinterpret_cast<const float4*>(WTimg) + (int64_t)ct * NKS * kBImg;
-    float4 dv[2], tv[2];
-    BStage bs;
+    const float4* wimg = reinterpret_cast<const float4*>(WTimg) + (int64_t)ct * NKS * TL::kBImg;
+    float4 dv[AP], tv[AP];
+    BStage<TL::kBPer> bs;
     auto issue = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AP; ++i) {
             const int o = ks * kTK + 4 * skq[i];  // column of dZ
             const int64_t r = row0 + srow[i];
             dv[i] = sok[i] ? *reinterpret_cast<const float4*>(dsrc + r * ldd + (o < H ? o : o - H)) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (act == GLASS_ACT_ELU)
                 tv[i] = sok[i] ? *reinterpret_cast<const float4*>(T + r * ldt + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        bs.issue(wimg + (int64_t)ks * kBImg);
+        bs.issue(wimg + (int64_t)ks * TL::kBImg);
     };
     auto commit = [&](int ks, float4* stage) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < AP; ++i) {
             const int o = ks * kTK + 4 * skq[i];
             const float coef = sok[i] ? ((slab[i] == (o < H)) ? zr : omz) : 0.f;
             float4 v = make_float4(dv[i].x * coef, dv[i].y * coef, dv[i].z * coef, dv[i].w * coef);
             if (act == GLASS_ACT_ELU) {
                 v.x *= elu_grad_f(tv[i].x); v.y *= elu_grad_f(tv[i].y); v.z *= elu_grad_f(tv[i].z); v.w *= elu_grad_f(tv[i].w);
             }
-            stage[skq[i] * kAPlane + srow[i]] = v;
+            stage[skq[i] * TL::kAPlane + srow[i]] = v;
         }
-        bs.commit(stage + kAImg);
+        bs.commit(stage + TL::kAImg);
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[RB][CB];
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
+        for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 
@@ -294,60 +311,69 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_dgrad_kernel(const float* 
     commit(0, smem);
     __syncthreads();
     for (int ks = 0; ks < NKS; ++ks) {
-        float4* cur = smem + (ks & 1) * kStageVecs;
-        float4* nxt = smem + ((ks + 1) & 1) * kStageVecs;
+        float4* cur = smem + (ks & 1) * TL::kStageVecs;
+        float4* nxt = smem + ((ks + 1) & 1) * TL::kStageVecs;
         if (ks + 1 < NKS) issue(ks + 1);
-        tile_mma(acc, cur, cur + kAImg, j, h, wm, wn);
+        tile_mma<BM, BN>(acc, cur, cur + TL::kAImg, j, h, wm, wn);
         if (ks + 1 < NKS) commit(ks + 1, nxt);
         __syncthreads();
     }
 
-    // epilogue: this lane's four consecutive output columns col4 .. col4 + 3 (cb = 0..3) of 32 rows
-    const int col4 = ct * kTN + wn * 128 + 4 * j;
+    // epilogue: this lane's four consecutive output columns col0 .. col0 + 3 (cb = 0..3) of its 16 * RB rows
+    const int col0 = ct * BN + wn * (BN / 2) + CB * j;
     if (drop.p > 0.f) {
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
     }
-    const bool gn_half = gs.partial != nullptr && col4 < H;  // wave-uniform (H is a multiple of 128)
-    float4 g_mu, g_rstd, g_scale, g_shift, g_al;
-    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    const bool gn_half = gs.partial != nullptr && col0 < H;  // wave-uniform (H is a multiple of 128 >= BN / 2)
+    float g_mu[CB], g_rstd[CB], g_scale[CB], g_shift[CB], g_al[CB];
+    double s1[CB], s2[CB];
+#pragma unroll
+    for (int e = 0; e < CB; ++e) s1[e] = s2[e] = 0.0;
     if (gn_half) {
         if (gs.drop.p > 0.f) {
             gs.drop.seed = rng_state[0];
             gs.drop.step = rng_state[1];
         }
-        g_mu = *reinterpret_cast<const float4*>(gs.saved + col4);
-        g_rstd = *reinterpret_cast<const float4*>(gs.saved + H + col4);
-        g_scale = *reinterpret_cast<const float4*>(gs.saved + 2 * H + col4);
-        g_shift = *reinterpret_cast<const float4*>(gs.saved + 3 * H + col4);
-        g_al = *reinterpret_cast<const float4*>(gs.alpha + col4);
+#pragma unroll
+        for (int e = 0; e < CB; ++e) {
+            g_mu[e] = gs.saved[col0 + e];
+            g_rstd[e] = gs.saved[H + col0 + e];
+            g_scale[e] = gs.saved[2 * H + col0 + e];
+            g_shift[e] = gs.saved[3 * H + col0 + e];
+            g_al[e] = gs.alpha[col0 + e];
+        }
     }
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
+    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int64_t r = row0 + wm * 64 + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+            const int64_t r = row0 + wm * (BM / 2) + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
             if (r < N) {
-                float4 v = make_float4(acc[rb][0][i], acc[rb][1][i], acc[rb][2][i], acc[rb][3][i]);
+                float v[CB];
+#pragma unroll
+                for (int e = 0; e < CB; ++e) v[e] = acc[rb][e][i];
                 if (addend) {
-                    const float4 ad = *reinterpret_cast<const float4*>(addend + r * ldadd + col4);
-                    v.x += ad.x; v.y += ad.y; v.z += ad.z; v.w += ad.w;
+                    const float4 ad = *reinterpret_cast<const float4*>(addend + r * ldadd + col0);
+                    v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
                 }
                 if (drop.p > 0.f) {  // gradient w.r.t. the pre-dropout tensor: same mask as the forward drew
                     float ds[4];
-                    drop_scales<4>(drop, r, col4, ds);
-                    v.x *= ds[0]; v.y *= ds[1]; v.z *= ds[2]; v.w *= ds[3];
-                }
-                *reinterpret_cast<float4*>(out + r * ldo + col4) = v;
-                if (gn_half) {
-                    const float4 x4 = *reinterpret_cast<const float4*>(gs.x + r * gs.ldx + col4);
-                    float ds[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (gs.drop.p > 0.f) drop_scales<4>(gs.drop, r, col4, ds);
+                    drop_scales<4>(drop, r, col0, ds);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float gp = f4e(v, e) * ds[e];
-                        if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(f4e(x4, e), f4e(g_scale, e), f4e(g_shift, e)));
-                        const float xhat = (f4e(x4, e) - f4e(g_al, e) * f4e(g_mu, e)) * f4e(g_rstd, e);
+                    for (int e = 0; e < CB; ++e) v[e] *= ds[e];
+                }
+                *reinterpret_cast<float4*>(out + r * ldo + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                if (gn_half) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(gs.x + r * gs.ldx + col0);
+                    const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+                    float ds[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (gs.drop.p > 0.f) drop_scales<4>(gs.drop, r, col0, ds);
+#pragma unroll
+                    for (int e = 0; e < CB; ++e) {
+                        float gp = v[e] * ds[e];
+                        if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv[e], g_scale[e], g_shift[e]));
+                        const float xhat = (xv[e] - g_al[e] * g_mu[e]) * g_rstd[e];
                         s1[e] += (double)gp;
                         s2[e] += (double)gp * (double)xhat;
                     }
@@ -356,54 +382,55 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_dgrad_kernel(const float* 
         }
     if (gs.partial == nullptr) return;
     // partial[rt][2][H] over this row tile: lanes h = 0/1, then the two row waves through LDS
-    double* red = reinterpret_cast<double*>(smem);  // [wm][256 columns][2]
+    double* red = reinterpret_cast<double*>(smem);  // [wm][BN columns][2]
     if (gn_half) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < CB; ++e) {
             s1[e] += __shfl_xor(s1[e], 32);
             s2[e] += __shfl_xor(s2[e], 32);
         }
         if (h == 0) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = wn * 128 + 4 * j + e;
-                red[(wm * 256 + c) * 2] = s1[e];
-                red[(wm * 256 + c) * 2 + 1] = s2[e];
+            for (int e = 0; e < CB; ++e) {
+                const int c = wn * (BN / 2) + CB * j + e;
+                red[(wm * BN + c) * 2] = s1[e];
+                red[(wm * BN + c) * 2 + 1] = s2[e];
             }
         }
     }
     __syncthreads();
-    const int c = ct * kTN + tid;  // 256 threads <-> the 256 columns of this tile
-    if (c < H) {
-        gs.partial[((size_t)rt * 2) * H + c] = red[tid * 2] + red[(256 + tid) * 2];
-        gs.partial[((size_t)rt * 2 + 1) * H + c] = red[tid * 2 + 1] + red[(256 + tid) * 2 + 1];
+    const int c = ct * BN + tid;  // threads 0 .. BN-1 <-> the BN columns of this tile
+    if (tid < BN && c < H) {
+        gs.partial[((size_t)rt * 2) * H + c] = red[tid * 2] + red[(BN + tid) * 2];
+        gs.partial[((size_t)rt * 2 + 1) * H + c] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
     }
 }
 
 template <typename K>
-static void allow_tiled_lds(K kernel) {
-    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTiledLds);
+static void allow_tiled_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
 int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
                      const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,
                      int64_t N, int64_t H, double* stats, const GnPrologue& pro, hipStream_t st) {
-    const int64_t n_rt = ceil_div(N, kTM);
     const bool comb = xb != nullptr;
-#define GLASS_TFWD(HH)                                                                                               \
+#define GLASS_TFWD(HH, BM)                                                                                           \
     if (H == HH) {                                                                                                   \
+        const int64_t n_rt = ceil_div(N, BM);                                                                        \
         const dim3 grid(tiled_grid(n_rt, HH / 128));                                                                 \
+        const size_t lds = Tile<BM, 256>::kLds;                                                                      \
         if (comb) {                                                                                                  \
-            allow_tiled_lds(tiled_fwd_kernel<HH, true>);                                                             \
-            hipLaunchKernelGGL((tiled_fwd_kernel<HH, true>), grid, dim3(kTThreads), kTiledLds, st, xa, lda, xb, ldb, Wimg, \
+            allow_tiled_lds(tiled_fwd_kernel<HH, true, BM>, lds);                                                    \
+            hipLaunchKernelGGL((tiled_fwd_kernel<HH, true, BM>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,   \
                                bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
         } else {                                                                                                     \
-            allow_tiled_lds(tiled_fwd_kernel<HH, false>);                                                            \
-            hipLaunchKernelGGL((tiled_fwd_kernel<HH, false>), grid, dim3(kTThreads), kTiledLds, st, xa, lda, xb, ldb, Wimg, \
+            allow_tiled_lds(tiled_fwd_kernel<HH, false, BM>, lds);                                                   \
+            hipLaunchKernelGGL((tiled_fwd_kernel<HH, false, BM>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,  \
                                bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
         }                                                                                                            \
     }
-    GLASS_TFWD(256) GLASS_TFWD(512)
+    GLASS_TFWD(128, 64) GLASS_TFWD(256, 128) GLASS_TFWD(512, 128)
 #undef GLASS_TFWD
     return launch_status("glass_dual_linear_fwd_f32 (tiled)");
 }
@@ -412,23 +439,23 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
                        float omz, int act, const float* WTimg, int64_t n_out, const float* addend, int64_t ldadd,
                        const Drop& drop, const uint64_t* rng_state, float* out, int64_t ldo, int64_t N, int64_t H,
                        const GnBwdStats& gs, hipStream_t st) {
-    const int64_t n_rt = ceil_div(N, kTM);
-#define GLASS_TDG(HH)                                                                                                \
-    if (H == HH) {                                                                                                   \
-        if (n_out == H) {                                                                                            \
-            allow_tiled_lds(tiled_dgrad_kernel<HH, HH>);                                                             \
-            hipLaunchKernelGGL((tiled_dgrad_kernel<HH, HH>), dim3(tiled_grid(n_rt, HH / kTN)), dim3(kTThreads), kTiledLds, \
-                               st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, \
-                               N, gs, (int)n_rt);                                                                    \
-        } else {                                                                                                     \
-            allow_tiled_lds(tiled_dgrad_kernel<HH, 2 * HH>);                                                         \
-            hipLaunchKernelGGL((tiled_dgrad_kernel<HH, 2 * HH>), dim3(tiled_grid(n_rt, 2 * HH / kTN)), dim3(kTThreads),  \
-                               kTiledLds, st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop,     \
-                               rng_state, out, ldo, N, gs, (int)n_rt);                                               \
-        }                                                                                                            \
+#define GLASS_TDG1(HH, NOUT, BM, BN)                                                                                 \
+    {                                                                                                                \
+        const int64_t n_rt = ceil_div(N, BM);                                                                        \
+        const size_t lds = Tile<BM, BN>::kLds;                                                                       \
+        allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN>, lds);                                                  \
+        hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
+                           st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, \
+                           gs, (int)n_rt);                                                                           \
     }
-    GLASS_TDG(256) GLASS_TDG(512)
-#undef GLASS_TDG
+    if (H == 128) {
+        GLASS_TDG1(128, 256, 64, 256)  // n_out == 2H only: the 128-wide data gradient of the trans pair stays on dense.hip
+    } else if (H == 256) {
+        if (n_out == H) GLASS_TDG1(256, 256, 128, 256) else GLASS_TDG1(256, 512, 128, 256)
+    } else if (H == 512) {
+        if (n_out == H) GLASS_TDG1(512, 512, 128, 256) else GLASS_TDG1(512, 1024, 128, 256)
+    }
+#undef GLASS_TDG1
     return launch_status("glass_dual_linear_dgrad_f32 (tiled)");
 }
 

@@ -222,9 +222,9 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  *     W = [W1; W0] ([2H, K] row-major, K = H or 2H), bias = [b1 | b0].
  *     The kernels consume the weight as a PACKED image produced by glass_dense_pack_batch_f32 once per step:
  *     Wimg from W itself (forward), WTimg from W with the transposed flag (data gradient).  Two kernel families,
- *     chosen by the hidden size: H = 64 / 128 — a wave owns 16 rows and all output columns, v_mfma_f32_16x16x4_f32,
- *     images in that fragment order (layout 0); H = 256 / 512 — LDS-tiled GEMM, workgroup tile 128 rows x 256
- *     columns, v_mfma_f32_32x32x2_f32, images in LDS-stage order (forward: layout 1 "paired", the f1 / f0 halves of
+ *     chosen by the hidden size: H = 64 — a wave owns 16 rows and all output columns, v_mfma_f32_16x16x4_f32,
+ *     images in that fragment order (layout 0); H = 128 / 256 / 512 — LDS-tiled GEMM, workgroup tile 64 (H = 128) or
+ *     128 rows x 256 columns, v_mfma_f32_32x32x2_f32, images in LDS-stage order (forward: layout 1 "paired", the f1 / f0 halves of
  *     a column side by side in a wave; data gradient: layout 2 "plain").  glass_dual_linear_layout(H) tells which.
  *   fwd : xb == NULL (trans): T = xa @ W^T + bias is written to T (kept for the backward),
  *                             out = mix(act(T1), act(T0)).
@@ -238,7 +238,7 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  * ---------------------------------------------------------------------------------------- */
 int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
- * operand layout 2) */
+ * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */
 int glass_dual_linear_layout(int64_t H);
 /* rows covered by one workgroup of the fused kernels at hidden H = rows per `stats` / `gn_partial` entry */
 int64_t glass_dual_linear_stat_rows(int64_t H);

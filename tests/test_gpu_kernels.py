@@ -504,7 +504,7 @@ def _pack(W, transposed, H=64):
     nt, kt = (W.shape[1], W.shape[0]) if transposed else W.shape
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
-    layout = (2 if transposed else 1) if _lib.load().glass_dual_linear_layout(H) == 1 else 0
+    layout = ((2 if nt % 256 == 0 else 0) if transposed else 1) if _lib.load().glass_dual_linear_layout(H) == 1 else 0
     trs = np.array([int(transposed) | (layout << 1)], dtype=np.int32)
     rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                 trs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
@@ -513,10 +513,10 @@ def _pack(W, transposed, H=64):
 
 
 def test_dense_pack_is_a_permutation():
-    """The packed image holds exactly the elements of the operand, in the documented fragment order."""
+    """The packed image holds exactly the elements of the operand, in the documented fragment order (wave16 layout: hidden 64)."""
     W = torch.arange(128 * 64, dtype=torch.float32, device=DEV).reshape(128, 64)
     for transposed in (False, True):
-        img = _pack(W, transposed).cpu()
+        img = _pack(W, transposed, 64).cpu()
         assert sorted(img.tolist()) == W.reshape(-1).cpu().tolist()
         B = (W.t() if transposed else W).cpu()  # logical operand [NT][KT]
         NT, KT = B.shape
@@ -531,23 +531,25 @@ def test_dense_pack_is_a_permutation():
 def test_dense_pack_tiled_layouts():
     """Operand images of the LDS-tiled kernels (hidden 256): a permutation of the operand, element order as documented
     in dense_common.h::tiled_col — image[((ct*NKS + ks)*4 + q)*256 + nl] = B[col(ct, nl)][16 ks + 4 q .. +3]."""
-    H = 256
-    W = torch.arange(2 * H * H, dtype=torch.float32, device=DEV).reshape(2 * H, H)  # trans pair weight [2H][H]
-    for transposed in (False, True):
-        img = _pack(W, transposed, H).cpu()
-        assert sorted(img.tolist()) == W.reshape(-1).cpu().tolist()
-        B = (W.t() if transposed else W).cpu()
-        NT, KT = B.shape
-        NKS = KT // 16
-        for (ct, ks, q, nl) in ((0, 0, 0, 0), (NT // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (NT // 256 - 1, 5, 1, 200)):
-            wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
-            if not transposed:  # paired: cb 0,1 -> f1 columns 2j + cb ; cb 2,3 -> the same columns of the f0 half
-                c = ct * 128 + wn * 64 + 2 * j + (cb & 1)
-                n = H + c if cb >= 2 else c
-            else:               # plain: four consecutive columns per lane
-                n = ct * 256 + wn * 128 + 4 * j + cb
-            off = ((((ct * NKS + ks) * 4 + q) * 256) + nl) * 4
-            assert img[off:off + 4].tolist() == B[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4].tolist()
+    for H in (256, 128):
+        W = torch.arange(2 * H * H, dtype=torch.float32, device=DEV).reshape(2 * H, H)  # trans pair weight [2H][H]
+        for transposed in (False, True):
+            if transposed and H == 128:
+                continue  # 128-wide data-gradient operand: wave16 image (test_dense_pack_is_a_permutation's layout)
+            img = _pack(W, transposed, H).cpu()
+            assert sorted(img.tolist()) == W.reshape(-1).cpu().tolist()
+            B = (W.t() if transposed else W).cpu()
+            NT, KT = B.shape
+            NKS = KT // 16
+            for (ct, ks, q, nl) in ((0, 0, 0, 0), (NT // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (NT // 256 - 1, 5, 1, 200)):
+                wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
+                if not transposed:  # paired: cb 0,1 -> f1 columns 2j + cb ; cb 2,3 -> the same columns of the f0 half
+                    c = ct * 128 + wn * 64 + 2 * j + (cb & 1)
+                    n = H + c if cb >= 2 else c
+                else:               # plain: four consecutive columns per lane
+                    n = ct * 256 + wn * 128 + 4 * j + cb
+                off = ((((ct * NKS + ks) * 4 + q) * 256) + nl) * 4
+                assert img[off:off + 4].tolist() == B[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4].tolist()
 
 
 # ---------------------------------------------------------------------------------- K8 head + loss
