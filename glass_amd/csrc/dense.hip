@@ -583,10 +583,7 @@ static void allow_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-#ifndef GLASS_H128_TILED
-#define GLASS_H128_TILED 1  // hidden 128 on the LDS-tiled kernels (64-row tiles) instead of the two-wave-group wave16 kernels
-#endif
-static bool wave16_shape_ok(int64_t H) { return H == 64 || (H == 128 && !GLASS_H128_TILED); }
+static bool wave16_shape_ok(int64_t H) { return H == 64; }
 // Above this many rows the two halves of the backward of a pair fill the chip on their own (one launch each, the
 // weight gradient with its 4-stage pipeline); below, they run as two branches of one launch (dual_bwd_kernel).
 static constexpr int64_t kFusedBwdMaxRows = 100000;
@@ -597,8 +594,10 @@ static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at 
     return n_pass > 1 ? 2 * image : image;
 }
 
-// Policy: hidden 64 (one wave group per 64 rows) and hidden 128 (two wave groups splitting the output columns, 512
-// threads) on the wave-owns-16-rows kernels of this file; hidden 256 / 512 on the LDS-tiled kernels of dense_tiled.hip.
+// Policy: hidden 64 on the wave-owns-16-rows kernels of this file (one wave group per 64 rows); hidden 128 / 256 / 512 on
+// the LDS-tiled kernels of dense_tiled.hip (hidden 128, N = 50 000: forward 63 -> 57 / 95 -> 87 us, comb data gradient
+// 98 -> 85 us, em_user-shape step 0.82 -> 0.73 ms) — except the 128-wide data gradient of hidden 128's trans pair, which
+// keeps this file's two-wave-group kernel (CS = 2: 512 threads share 64 rows and split the output columns).
 // (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
 
@@ -648,7 +647,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
             hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS, RW>), grid, dim3(kWave * RW * CS), lds_trans, st, xa, lda, \
                                xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
     }
-    GLASS_FWD(64, 1, 4) GLASS_FWD(128, 2, 4)
+    GLASS_FWD(64, 1, 4)
 #undef GLASS_FWD
     return launch_status("glass_dual_linear_fwd_f32");
 }

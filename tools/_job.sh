@@ -1,10 +1,6 @@
-cd "$GRAFT_REPO_ROOT"; out=gpurun_out/r02f; mkdir -p $out
-for spec in "ppi_bp 64" "hpo_neuro 64" "em_user 128" "density-like 64" "powerlaw 256" "powerlaw 64" "calib:4000000 64" "2000000:6000000 64" "30000:90000 64"; do set -- $spec; ./tools/bin/spmm_bench $1 $2 50 --full 2>&1 | python3 -c "
-import sys,json
-for l in sys.stdin:
-    try: d=json.loads(l); print(d['shape'],d['H'],'%.2f us'%d['us_per_pass'],'frac %.3f'%d['frac_of_8TBps'],'err %.1e'%d['spot_rel_err'],'rows',d['rows_checked'])
-    except Exception: print(l.strip()[:200])
-"; done
-python -m pytest tests -m gpu -q --timeout 1500 > $out/pytest.log 2>&1; tail -4 $out/pytest.log
-python bench.py --steps 200 --warmup 20 > $out/bench_c2.json 2> $out/c2.err; python3 -c "
-import json; d=json.load(open('$out/bench_c2.json')); print('C2', d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline']['back_to_back_us'], d['roofline']['frac'], d['roofline']['traffic'], [round(e['frac'],3) for e in d['roofline_hbm']], {k:v['us'] for k,v in list(d['step_breakdown']['calls'].items())[:6]})"
+cd "$GRAFT_REPO_ROOT"; out=gpurun_out/r02g; mkdir -p $out
+python -m pytest tests/test_gpu_kernels.py -m gpu -q -k "dual_linear or dense_pack" > $out/pytest_k.log 2>&1; tail -4 $out/pytest_k.log
+python -m pytest tests/test_gpu_model.py -m gpu -q -k "stack_program or step_program or fused_readout or randomised" --timeout 1500 > $out/pytest_m.log 2>&1; tail -4 $out/pytest_m.log
+python tools/bench_ops.py dual > $out/bench_dual.log 2>&1; tail -7 $out/bench_dual.log
+for wl in em_user; do python bench.py --workload $wl --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm > $out/bench_$wl.json 2> $out/$wl.err; python3 -c "
+import json; d=json.load(open('$out/bench_$wl.json')); print('$wl', d['ms_per_step'], d['value'], {k:v['us'] for k,v in list(d['step_breakdown']['calls'].items())[:6]})"; done
