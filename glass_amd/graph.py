@@ -19,11 +19,6 @@ import torch
 
 from . import _lib
 
-# Measurement hook (bench.py): when set to a list, every K1 launch is bracketed by HIP events
-# recorded on the launch stream and the (start, end) pair is appended.
-K1_EVENT_HOOK = None
-
-
 class CSROperand:
     """One CSR matrix + its K1 plan; `spmm` enqueues Y = M @ X on the current stream."""
     def __init__(self, rowptr, col, val, n_rows, n_cols):
@@ -61,18 +56,11 @@ class CSROperand:
         if out is None:
             out = torch.empty((self.n_rows, H), dtype=torch.float32, device=x.device)
         assert out.stride(1) == 1 and out.shape == (self.n_rows, H)
-        hook = K1_EVENT_HOOK
-        if hook is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         rc = _lib.load().glass_spmm_csr_f32(self.rowptr.data_ptr(), self.col.data_ptr(), self.val.data_ptr(),
                                             x.data_ptr(), x.stride(0), out.data_ptr(), out.stride(0), self.n_rows, H,
                                             self.header.ctypes.data, self.plan.data_ptr(),
                                             self.workspace(H).data_ptr(), torch.cuda.current_stream().cuda_stream)
         _lib.check(rc, "glass_spmm_csr_f32")
-        if hook is not None:
-            e1.record()
-            hook.append((e0, e1, self.n_rows, self.nnz, H))
         return out
 
 
