@@ -33,7 +33,7 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 typedef float k1_f32x4 __attribute__((ext_vector_type(4)));
 // header word indices
 enum { H_MAGIC, H_VER, H_NROWS, H_NNZ, H_NSWEEP, H_NLONG, H_NREDUCE, H_NSLOTS, H_LONG_THR, H_LONG_CHUNK,
-       H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RP_FACTOR, H_MIN_ITEM_DEG, H_RSV2 };
+       H_OFF_SWEEP, H_OFF_LONG, H_OFF_REDUCE, H_RP_FACTOR, H_MIN_ITEM_DEG, H_FLAT_SHARE };
 
 // ---- vector helpers --------------------------------------------------------------------------
 template <int VW> struct Vec;
@@ -124,6 +124,8 @@ __device__ __forceinline__ void reduce_groups(Vec<VW>& acc) {
 //    reduction.  On a degree-1 pattern that is U*G independent 4H-byte gathers in flight per wave behind a single
 //    index round trip (the previous form had 2 per group behind three dependent round trips: 0.55 of the HBM roofline).
 constexpr int64_t kStreamNtBytes = 256ll << 20;  // Infinity Cache size
+constexpr int kFlatMinItems = 8192;   // the flat-capable sweep kernel only on throughput-bound sweeps ...
+constexpr int kFlatMinShare15 = 4;    // ... with >= 4/15 of the sweep cost in flat-eligible items
 // Tunables (overridable only by the laboratory build, tools/Makefile `lab`): gathers in flight per lane group and the
 // sweep item caps
 #ifndef GLASS_K1_U
@@ -136,10 +138,12 @@ constexpr int kGathers = GLASS_K1_U;
 constexpr int kItemRows = 64;                    // rows per sweep item (one coalesced rowptr load per wave)
 constexpr int kItemEdges = GLASS_K1_ITEM_EDGES;  // edges per sweep item (LDS staging: 2 KiB of (col,val) per wave at 256)
 
-// FLAT = false: the plan holds no item short enough for flat mode at this H (header word H_MIN_ITEM_DEG; e.g. every
-// BASELINE graph: mean degree 12-444) -> a specialisation without the flat branch, its LDS staging and its registers
-// (the kernel is latency x occupancy bound on cache-resident graphs: 17 080 one-row waves at ppi_bp-shape are 2-3
-// rounds of the chip, and a wave more per SIMD is a round less).
+// FLAT = false: a specialisation without the flat branch, its LDS staging and its registers (64 instead of 76 VGPRs: 8
+// instead of 6 waves per SIMD); every item then runs in row mode, which is correct for any item.  Chosen on the host
+// (launch_spmm_u) unless flat mode pays: the sweep must be throughput-bound (>= 8 192 items; on small graphs the
+// serial per-group walk of flat mode lengthens the critical path: density-shape 5.9 vs 4.8 us) AND a real share of the
+// work must sit in flat-eligible items (header word H_FLAT_SHARE; ppi_bp-shape: a few low-degree rows out of 17 080
+// qualify, and carrying the flat branch for them cost 13.4 vs 12.2 us per launch).
 template <int VW, int LPR, int U, bool NT, bool FLAT>
 __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
@@ -319,7 +323,10 @@ static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float*
     if (n_waves > 0) {
         dim3 grid((unsigned)ceil_div(n_waves, kBlock / kWave), n_ctiles);
         constexpr int G = kWave / LPR;
-        if (G > 1 && hdr[H_MIN_ITEM_DEG] <= hdr[H_RP_FACTOR] * G)  // some item is short enough for flat mode at this H
+        int g_log2 = 0;
+        while ((1 << g_log2) < G) ++g_log2;
+        const int share15 = (hdr[H_FLAT_SHARE] >> (4 * g_log2)) & 15;  // fifteenths of the sweep cost in flat-eligible items
+        if (G > 1 && n_waves >= kFlatMinItems && share15 >= kFlatMinShare15)
             hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U, NT, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx,
                                Y, ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_RP_FACTOR]);
         else
@@ -401,12 +408,17 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     int64_t acc = 0, it_r0 = 0, it_edges = 0;
     int32_t n_slots = 0;
     bool open = false;
-    int64_t min_item_deg = INT32_MAX;  // min over sweep items of ceil(edges / rows): decides whether flat mode can occur
+    int64_t min_item_deg = INT32_MAX;  // min over sweep items of ceil(edges / rows)
+    int64_t flat_cost[7] = {0, 0, 0, 0, 0, 0, 0}, sweep_cost = 0;  // cost in items flat-eligible at G = 1, 2, 4, .. 64 lane groups
     auto close_item = [&](int64_t r_end) {
         if (!open) return;
-        const int64_t e = (int64_t)rowptr[r_end] - rowptr[it_r0];
-        const int64_t md = ceil_div(e, r_end - it_r0);
+        const int64_t e = (int64_t)rowptr[r_end] - rowptr[it_r0], nr = r_end - it_r0;
+        const int64_t md = ceil_div(e, nr);
         if (md < min_item_deg) min_item_deg = md;
+        const int64_t cost = e + kRowCost * nr;
+        sweep_cost += cost;
+        for (int k = 0; k < 7; ++k)
+            if (e <= (int64_t)kFlatFactor * (1 << k) * nr) flat_cost[k] += cost;  // the kernel's flat-mode test
         sweep.push_back((int32_t)it_r0);
         sweep.push_back((int32_t)r_end);
         sweep.push_back(rowptr[it_r0]);
@@ -466,6 +478,9 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
     // Flat-mode threshold (mean degree of an item's rows <= factor * G, G = lane groups per wave at the launch's H).
     plan[H_RP_FACTOR] = kFlatFactor;
     plan[H_MIN_ITEM_DEG] = (int32_t)min_item_deg;
+    int32_t shares = 0;  // 7 nibbles: floor(15 * share) of the sweep cost that is flat-eligible at G = 2^k
+    for (int k = 0; k < 7; ++k) shares |= (int32_t)(sweep_cost > 0 ? 15 * flat_cost[k] / sweep_cost : 0) << (4 * k);
+    plan[H_FLAT_SHARE] = shares;
     plan[H_OFF_SWEEP] = (int32_t)off_sweep;
     plan[H_OFF_LONG] = (int32_t)off_long;
     plan[H_OFF_REDUCE] = (int32_t)off_reduce;

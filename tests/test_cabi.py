@@ -68,8 +68,16 @@ def _check_plan(rowptr):
     assert covered == np.nonzero(deg < thr)[0].tolist()
     # header word 14: the smallest mean degree (rounded up) of any sweep item — the launch picks the kernel without the
     # flat-mode branch when no item can qualify at its feature width
+    # header word 15: seven nibbles = fifteenths of the sweep cost (edges + 4 per row) lying in items that qualify for flat
+    # mode at G = 1, 2, 4, .. 64 lane groups (edges <= 4 * G * rows) — the launch picks the kernel from it
     if n_sweep:
-        assert hdr[14] == min(-(-(e1 - e0) // (r1 - r0)) for r0, r1, e0, e1 in sweep.tolist())
+        items = sweep.tolist()
+        assert hdr[14] == min(-(-(e1 - e0) // (r1 - r0)) for r0, r1, e0, e1 in items)
+        cost = lambda it: (it[3] - it[2]) + 4 * (it[1] - it[0])
+        total = sum(cost(it) for it in items)
+        for k in range(7):
+            flat = sum(cost(it) for it in items if it[3] - it[2] <= 4 * (1 << k) * (it[1] - it[0]))
+            assert (int(hdr[15]) >> (4 * k)) & 15 == 15 * flat // total
     # every long row (deg >= thr) is covered exactly by its chunks, in order, whole 64-edge batches
     long_rows = np.nonzero(deg >= thr)[0]
     assert sorted(set(longs[:, 0].tolist())) == long_rows.tolist()

@@ -673,20 +673,25 @@ def test_spmm_row_parallel_mode_for_short_rows(H):
 
 
 @pytest.mark.gpu
-def test_spmm_row_parallel_wide_threshold_on_large_graphs():
-    """Flat-mode factor 4 (header word 13): degrees 0-8 at H=64 (mean 4 <= 4 * G = 16) run in flat mode on a graph
-    large enough for the non-temporal index / output streams (n_rows * 260 B + nnz * 8 B > 256 MiB).  Checked against a
-    float64 CSR product built with scipy."""
+@pytest.mark.parametrize("H,n", [(64, 1_100_000), (16, 300_000), (128, 300_000), (17, 200_000)])
+def test_spmm_row_parallel_wide_threshold_on_large_graphs(H, n):
+    """Flat mode (factor 4, header word 13): degrees 0-8 (mean 4 <= 4 * G) on sweeps of >= 8 192 items, where the launch
+    takes the flat-capable kernel (header word 15: share of the sweep cost in flat-eligible items); H = 64 at a size
+    that also takes the non-temporal index / output streams (n_rows * 260 B + nnz * 8 B > 256 MiB); other widths: G = 16,
+    2 and the scalar path.  Checked against a float64 CSR product built with scipy."""
     import scipy.sparse as sp
     from glass_amd.graph import CSRAdj
     rng = np.random.default_rng(5)
-    n, H = 1_100_000, 64
     rows = np.repeat(np.arange(n), rng.integers(0, 9, n))
     cols = rng.integers(0, n, rows.shape[0])
     w = rng.uniform(0.5, 2.0, rows.shape[0]).astype(np.float32)
     x = torch.randn(n, H, generator=torch.Generator().manual_seed(5))
     adj = CSRAdj(torch.from_numpy(np.stack([rows, cols])).to(DEV), torch.from_numpy(w).to(DEV), n, "sum")
-    assert int(adj.fwd.header[13]) == 4 and n * (4 * H + 4) + rows.shape[0] * 8 > (256 << 20)
+    assert int(adj.fwd.header[13]) == 4 and int(adj.fwd.header[4]) >= 8192
+    g_log2 = {64: 2, 16: 4, 128: 1, 17: 1}[H]  # lane groups per wave: 64 / lanes-per-row
+    assert (int(adj.fwd.header[15]) >> (4 * g_log2)) & 15 >= 4  # -> the flat-capable kernel is the one launched
+    if H == 64:
+        assert n * (4 * H + 4) + rows.shape[0] * 8 > (256 << 20)
     y = adj.fwd.spmm(x.to(DEV))
     ref = sp.csr_matrix((w.astype(np.float64), (rows, cols)), shape=(n, n)) @ x.double().numpy()
     assert rel_inf(y.cpu(), torch.from_numpy(ref)) < TOL

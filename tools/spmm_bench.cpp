@@ -4,7 +4,8 @@
 // Also the program to put after `rocprofv3 ... --` for per-kernel traces and PMC counters.
 //
 //   spmm_bench <shape> [H] [iters] [--rp K] [--full]
-//   --rp K : override the plan's flat-mode factor (header word 13) for A/B runs; --full : check EVERY row in fp64
+//   --rp K : override the plan's flat-mode factor (header word 13; K = 0 also clears the flat-share word 15, i.e. the
+//            row-mode-only kernel) for A/B runs; --full : check EVERY row in fp64
 //   shape: ppi_bp | hpo_neuro | em_user | powerlaw | density-like | N:PAIRS[:zipf] | calib:N
 //   calib:N = random permutation matrix (one edge per row, every X row read exactly once): a known
 //   byte count in K1's own access pattern, used to calibrate rocprofv3's FETCH_SIZE / WRITE_SIZE.
@@ -140,7 +141,10 @@ int main(int argc, char** argv) {
     if (glass_spmm_plan_build(g.rowptr.data(), n, nullptr, &words)) return 3;
     std::vector<int32_t> plan(words);
     if (glass_spmm_plan_build(g.rowptr.data(), n, plan.data(), &words)) return 3;
-    if (rp_override >= 0) plan[13] = rp_override;
+    if (rp_override >= 0) {
+        plan[13] = rp_override;
+        if (rp_override == 0) plan[15] = 0;  // no flat-eligible share: the launch takes the row-mode-only kernel
+    }
     const int64_t ws_bytes = glass_spmm_ws_bytes(plan.data(), H);
 
     std::vector<float> X((size_t)n * H);
