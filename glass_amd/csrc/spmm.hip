@@ -369,7 +369,10 @@ using namespace glass;
 // the chunk shrink until it does (never below one 64-edge batch per wave).  Such matrices (<= 1024 rows averaging
 // >= 64 entries) also skip the sweep kernel altogether: EVERY row becomes workgroup items (an empty row one empty
 // item that stores zeros), so the product is two launches (items + reduce) instead of three.
-static constexpr int kLongThrMax = 256;
+#ifndef GLASS_K1_LONG_THR
+#define GLASS_K1_LONG_THR 256
+#endif
+static constexpr int kLongThrMax = GLASS_K1_LONG_THR;
 static constexpr int kLongChunkMax = 2048;
 static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
 static constexpr int kTargetWaves = 32768;  // ~4 rounds of 256 CUs x 32 waves

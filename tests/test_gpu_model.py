@@ -425,7 +425,7 @@ def _emb_pair(layers, jk, aggr, z_ratio, dropout, seed, n=700, n_pairs=4000, V=9
 
 @pytest.mark.parametrize("layers,jk,aggr,hidden", [(1, 1, "mean", 64), (2, 1, "gcn", 64), (3, 1, "sum", 64), (2, 0, "mean", 64),
                                                    (3, 0, "gcn", 64), (2, 1, "mean", 128), (3, 0, "sum", 128),
-                                                   (2, 1, "mean", 256), (1, 0, "gcn", 256)])
+                                                   (2, 1, "mean", 256), (1, 0, "gcn", 256), (1, 1, "sum", 512)])
 def test_stack_program_vs_oracle(layers, jk, aggr, hidden):
     """EmbZGConv as one forward/backward program (glass_amd/stack.py), hidden 64, 128 (column-split dense kernels) and
     256 (LDS-tiled dense kernels; n = 700 is not a multiple of their 128-row tile), against the fp64 oracle: output, every parameter gradient (accumulated in place in the arena), and eval mode."""
