@@ -15,7 +15,9 @@ import torch  # noqa: F401
 from ctypes import c_void_p, c_int, c_int64, c_uint64, c_float, c_double, c_char_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libglass_hip.so")
+# GLASS_HIP_LIB: another build of the same library (laboratory A/B of compile-time variants); the product default is the
+# in-tree build next to this file
+LIB_PATH = os.environ.get("GLASS_HIP_LIB") or os.path.join(_HERE, "libglass_hip.so")
 
 POOL_MODES = {"sum": 0, "mean": 1, "max": 2, "size": 3}
 AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
