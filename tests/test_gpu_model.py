@@ -1039,3 +1039,33 @@ def test_step_program_randomised_configurations():
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_step_program.py"), "12", "2024"],
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("flags,overlapped", [(["--workload", "ppi_bp"], False),
+                                              (["--workload", "em_user", "--features", "nodeid"], True)])
+def test_bench_two_ranks_share_the_gpu_over_gloo(flags, overlapped):
+    """`bench.py --gpus 2` end to end on the 1-GPU box: the launcher starts two ranks that share cuda:0 and exchange over
+    gloo (GLASS_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device).  use_deg features: one small bucket,
+    all-reduced.  use_nodeid features at em_user-shape: the 25.6 MB embedding gradient forms the big bucket — two graphs
+    cut at the tail hook, small all-reduce on the communication stream, reduce-scatter + sharded Adam + all-gather.
+    Timings over gloo mean nothing; the line must be complete, n_gpus 2, the loss finite."""
+    import json
+    import math
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(GLASS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3",
+                          "--no-cpu-baseline", "--no-roofline-hbm", *flags], capture_output=True, text=True, timeout=900,
+                         env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["value"] > 0
+    assert math.isfinite(d["config"]["final_loss"])
+    c = d["collective"]
+    assert c["world"] == 2 and c["overlapped_small_bucket"] is overlapped
+    assert (c["payload_bytes"]["big_reduce_scatter"] > 0) is overlapped and c["payload_bytes"]["small_allreduce"] > 0
