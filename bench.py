@@ -165,8 +165,11 @@ def k1_back_to_back(op, H, launches=50, replays=5):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     g = torch.cuda.CUDAGraph()
+    import torch.distributed as td
+    # thread_local: a process group's watchdog thread may query events while this thread captures (glass_amd/step.py)
+    mode = "thread_local" if (td.is_available() and td.is_initialized()) else "global"
     with torch.cuda.stream(side):
-        with torch.cuda.graph(g, stream=side):
+        with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
             for _ in range(launches):
                 op.spmm(x, out=y)
     torch.cuda.synchronize()

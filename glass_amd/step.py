@@ -121,6 +121,13 @@ class TrainStep:
     def _capture(self):
         dist_on = gdist.is_distributed()
         self._g_fb = torch.cuda.CUDAGraph()
+        # With a process group alive, its watchdog THREAD polls the completion events of earlier collectives with
+        # hipEventQuery.  Under the default capture mode ("global") a call like that from ANY thread while this thread
+        # captures is an error — the watchdog then aborts the process (seen once in ~6 runs of the 1-rank RCCL test).
+        # "thread_local" confines the check to the capturing thread; nothing this thread enqueues is unsafe to capture.
+        mode = "thread_local" if dist_on else "global"
+        if dist_on:
+            torch.cuda.synchronize()  # no collective of the warm-up still in flight when the capture starts
         if not dist_on:
             with torch.cuda.graph(self._g_fb):
                 self._fwd_bwd()
@@ -128,7 +135,7 @@ class TrainStep:
         elif not self._overlap_small_bucket():
             # the collective stays outside the graph; the optimizer is two launches, cheaper eager than a
             # second graph replay
-            with torch.cuda.graph(self._g_fb):
+            with torch.cuda.graph(self._g_fb, capture_error_mode=mode):
                 self._fwd_bwd()
         else:
             # two graphs sharing one memory pool, cut by the program's tail hook: [forward + backward down to the last
@@ -138,11 +145,11 @@ class TrainStep:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._g_fb.capture_begin()
+                self._g_fb.capture_begin(capture_error_mode=mode)
 
                 def cut():
                     self._g_fb.capture_end()
-                    self._g_tail.capture_begin(pool=self._g_fb.pool())
+                    self._g_tail.capture_begin(pool=self._g_fb.pool(), capture_error_mode=mode)
                 self._fwd_bwd(tail_hook=cut)
                 self._g_tail.capture_end()
             torch.cuda.current_stream().wait_stream(side)
