@@ -110,6 +110,13 @@ __device__ __forceinline__ void reduce_groups(Vec<VW>& acc) {
     for (int s = LPR; s < kWave; s <<= 1) acc.xor_add(s);
 }
 
+#ifdef GLASS_K1_TRACE  // laboratory build only (tools/Makefile `lab`): per-wave wall-clock stamps of the sweep kernel
+__device__ unsigned long long* g_k1_trace;
+#define K1_STAMP(slot) do { if (g_k1_trace && lane == 0 && blockIdx.y == 0) g_k1_trace[(size_t)wave * 4 + (slot)] = wall_clock64(); } while (0)
+#else
+#define K1_STAMP(slot) do { } while (0)
+#endif
+
 // ---- sweep kernel: one wave per plan item (r0, r1, e0, e1): <= 64 consecutive short rows holding <= 256 edges ----
 // The item carries its edge range, so the index loads (row pointers, col, val) depend on ONE scalar load of the plan
 // and not on a chain plan -> rowptr -> col: plan -> {rowptr chunk, col/val} -> X rows -> store.
@@ -166,10 +173,12 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
     const int coff = (blockIdx.y * LPR + sub) * VW;
     const bool col_ok = coff < H;
     const float* Xc = X + coff;
+    K1_STAMP(0);  // wave start | item known | row pointers known | done
     const int4 it = reinterpret_cast<const int4*>(items)[wave];
     const int r0 = __builtin_amdgcn_readfirstlane(it.x), r1 = __builtin_amdgcn_readfirstlane(it.y);
     const int e0 = __builtin_amdgcn_readfirstlane(it.z), e1 = __builtin_amdgcn_readfirstlane(it.w);
     const int nrows = r1 - r0, ne = e1 - e0;
+    K1_STAMP(1);
     // start edge of row r0 + lane (lanes past the item hold e1, so "end of row i" is always lane i + 1's value or e1)
     const int rp_reg = (lane < nrows) ? ld_stream<NT>(rowptr + r0 + lane) : e1;
     if (kFlat && ne <= rp_factor * G * nrows) {
@@ -253,6 +262,9 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
         return;
     }
     // ---- row mode ----
+#ifdef GLASS_K1_TRACE
+    if (__builtin_amdgcn_readfirstlane(rp_reg) >= 0) K1_STAMP(2);
+#endif
     int es = e0;
     for (int i = 0; i < nrows; ++i) {
         const int ee = (i + 1 < nrows) ? __builtin_amdgcn_readlane(rp_reg, i + 1) : e1;
@@ -263,6 +275,7 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
         if (grp == 0 && col_ok) acc.template store_out<NT>(Y + (int64_t)(r0 + i) * ldy + coff);
         es = ee;
     }
+    K1_STAMP(3);
 }
 
 // ---- long-row kernel: one workgroup per (row, chunk); 4 waves combine through LDS ------------
@@ -361,6 +374,12 @@ static int launch_spmm(const int32_t* rowptr, const int32_t* col, const float* v
 
 using namespace glass;
 
+#ifdef GLASS_K1_TRACE
+extern "C" int glass_k1_trace_set(unsigned long long* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_k1_trace), &p, sizeof(p));
+}
+#endif
+
 // Plan policy (host).  Rows with >= kLongThr edges are given to whole workgroups in chunks of
 // kLongChunk edges; the rest are swept by waves holding ~edges_per_wave edges each.
 // Matrices with few, long rows (the transposed one-hot selection matrix of the embedding backward:
@@ -376,6 +395,7 @@ static constexpr int kLongThrMax = GLASS_K1_LONG_THR;
 static constexpr int kLongChunkMax = 2048;
 static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
 static constexpr int kTargetWaves = 32768;  // ~4 rounds of 256 CUs x 32 waves
+static constexpr int kMinBudget = 16;        // smallest item budget: on small graphs one degree-12 row per wave (density-shape: 5.0 -> 4.0 us; 32 packed two)
 static constexpr int kFlatFactor = 4;       // flat mode up to a mean degree of 4 G (uniform degree 12 at H = 64: 988 -> 931 us; degree 37: row mode)
 
 extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int32_t* plan, int64_t* plan_words) {
@@ -403,7 +423,7 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
         cost_total += kRowCost + (d < kLongThr ? d : 0);
     }
     int64_t budget = cost_total / kTargetWaves;
-    if (budget < 32) budget = 32;
+    if (budget < kMinBudget) budget = kMinBudget;
     if (budget > 1024) budget = 1024;
     // Sweep items (r0, r1, e0, e1): maximal runs of consecutive SHORT rows under three caps — the cost budget (balance),
     // kItemRows rows and kItemEdges edges (what the kernel stages per wave).  Long rows belong to the workgroup kernel

@@ -1,16 +1,16 @@
 #!/bin/bash
-# K1 laboratory run (GPU box): timing sweep over the lab builds tools/bin/k1_u<U>_e<ITEM_EDGES> (gathers in flight per
-# lane group, sweep item size; built by `make -C tools lab LABFLAGS=...`) on the HBM-bound and the cache-resident
-# shapes.  Output: gpurun_out/k1_lab/perf2.jsonl
+# K1 laboratory run (GPU box): timing sweep over the lab builds tools/bin/k1_u_<name> (compile-time variants of
+# spmm.hip built by `make -C tools lab LABFLAGS=...`) on the HBM-bound and the cache-resident shapes, every row checked
+# in fp64 (--full).  Output: gpurun_out/k1_lab/perf2.jsonl
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/k1_lab
 mkdir -p $out
 : > $out/perf2.jsonl
 for b in tools/bin/k1_u*; do
-  for spec in "calib:4000000 64" "2000000:3000000 64" "2000000:6000000 64" "2000000:12000000 64" "ppi_bp 64" "hpo_neuro 64" "em_user 128" "powerlaw 256" "powerlaw 64" "density-like 64"; do
+  for spec in "calib:4000000 64" "2000000:6000000 64" "ppi_bp 64" "hpo_neuro 64" "hpo_neuro 128" "em_user 128" "powerlaw 64" "powerlaw 256" "density-like 64"; do
     set -- $spec
     echo -n "{\"build\": \"$(basename $b)\", \"r\": " >> $out/perf2.jsonl
-    timeout 300 $b $1 $2 30 >> $out/perf2.jsonl 2>&1 || echo "\"FAIL $spec\"" >> $out/perf2.jsonl
+    timeout 300 $b $1 $2 30 --full >> $out/perf2.jsonl 2>&1 || echo "\"FAIL $spec\"" >> $out/perf2.jsonl
     echo "}" >> $out/perf2.jsonl
   done
 done

@@ -90,6 +90,10 @@ static Graph make_graph(int64_t n, int64_t pairs, double zipf, uint64_t seed) {
     return g;
 }
 
+#ifdef GLASS_K1_TRACE
+extern "C" int glass_k1_trace_set(unsigned long long* p);
+#endif
+
 int main(int argc, char** argv) {
     int rp_override = -1;
     bool full = false;
@@ -189,6 +193,38 @@ int main(int argc, char** argv) {
     float ms = 0;
     HIP_OK(hipEventElapsedTime(&ms, e0, e1));
     const double t = ms * 1e-3 / iters;
+#ifdef GLASS_K1_TRACE
+    {   // one traced launch: per-wave wall-clock stamps (100 MHz) of the sweep kernel
+        const int nw = plan[4];
+        unsigned long long* d_tr;
+        HIP_OK(hipMalloc(&d_tr, (size_t)nw * 32));
+        HIP_OK(hipMemset(d_tr, 0, (size_t)nw * 32));
+        glass_k1_trace_set(d_tr);
+        run();
+        HIP_OK(hipStreamSynchronize(st));
+        glass_k1_trace_set(nullptr);
+        std::vector<unsigned long long> tr((size_t)nw * 4);
+        HIP_OK(hipMemcpy(tr.data(), d_tr, (size_t)nw * 32, hipMemcpyDeviceToHost));
+        unsigned long long t_min = ~0ull, t_max = 0;
+        for (int i = 0; i < nw; ++i) {
+            t_min = std::min(t_min, tr[i * 4]);
+            t_max = std::max(t_max, tr[i * 4 + 3]);
+        }
+        double ph[3] = {0, 0, 0};
+        std::vector<double> starts(nw), lifes(nw);
+        for (int i = 0; i < nw; ++i) {
+            for (int k = 0; k < 3; ++k) ph[k] += (double)(tr[i * 4 + k + 1] - tr[i * 4 + k]) * 10.0;
+            starts[i] = (double)(tr[i * 4] - t_min) * 10.0;
+            lifes[i] = (double)(tr[i * 4 + 3] - tr[i * 4]) * 10.0;
+        }
+        std::sort(starts.begin(), starts.end());
+        std::sort(lifes.begin(), lifes.end());
+        fprintf(stderr, "trace: %d waves, span %.0f ns; mean phase ns: item %.0f, index %.0f, gather %.0f; life p10/p50/p90/max %.0f/%.0f/%.0f/%.0f; "
+                "start p10/p25/p50/p75/p90/max %.0f/%.0f/%.0f/%.0f/%.0f/%.0f\n", nw, (double)(t_max - t_min) * 10.0, ph[0] / nw, ph[1] / nw, ph[2] / nw,
+                lifes[nw / 10], lifes[nw / 2], lifes[nw * 9 / 10], lifes[nw - 1], starts[nw / 10], starts[nw / 4], starts[nw / 2],
+                starts[nw * 3 / 4], starts[nw * 9 / 10], starts[nw - 1]);
+    }
+#endif
     // algorithmic bytes per pass: nnz*(4H+8) + N*(4H+4)
     const double bytes = (double)nnz * (4.0 * H + 8) + (double)n * (4.0 * H + 4);
 
