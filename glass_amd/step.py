@@ -1,8 +1,8 @@
 """One training step of the hot loop (reference impl/train.py:10-16 + ZGDataloader), optionally
 replayed from a captured hipGraph.
 
-The step is a chain of 40-100 short dependent kernels on small graphs (ppi_bp-shape: 42 launches in the step-program
-form, ~0.38 ms of GPU time), so eager launches are host-bound; every kernel in libglass_hip only enqueues work on the
+The step is a chain of 40-100 short dependent kernels on small graphs (ppi_bp-shape: 37 launches in the step-program
+form, ~0.33 ms of GPU time), so eager launches are host-bound; every kernel in libglass_hip only enqueues work on the
 caller's stream (no allocation, no sync, no memset / memcpy nodes), which makes the whole step capturable:
 labels -> forward -> loss -> backward -> [all-reduce] -> Adam.  Dropout masks still change every replay
 because the dropout (seed, step) pair lives in device memory and is advanced by a captured kernel.

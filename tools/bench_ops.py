@@ -104,3 +104,5 @@ if __name__ == "__main__":
         bench_gn()
     if what in ("dual", "all"):
         bench_dual()
+    if what == "dualn":  # workgroup-count quantisation of the hidden-64 kernels: N around multiples of 256 CUs x 64 rows
+        bench_dual(tuple((n, 64) for n in (8192, 12288, 16384, 16448, 17080, 20480, 24576, 32768, 32832)))
