@@ -596,7 +596,7 @@ static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at 
 
 // Policy: hidden 64 on the wave-owns-16-rows kernels of this file (one wave group per 64 rows); hidden 128 / 256 / 512 on
 // the LDS-tiled kernels of dense_tiled.hip (hidden 128, N = 50 000: forward 63 -> 57 / 95 -> 87 us, comb data gradient
-// 98 -> 85 us, em_user-shape step 0.82 -> 0.73 ms) — except the 128-wide data gradient of hidden 128's trans pair, which
+// 98 -> 85 us, em_user-shape step 0.82 -> 0.72 ms) — except the 128-wide data gradient of hidden 128's trans pair, which
 // keeps this file's two-wave-group kernel (CS = 2: 512 threads share 64 rows and split the output columns).
 // (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }

@@ -26,12 +26,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kTK = 16, kTThreads = 256;
 // Tile geometry.  BM rows x BN column slots per workgroup; 4 waves as 2 (rows) x 2 (columns), each BM/2 x BN/2 =
 // RB x CB MFMA tiles.  BM = 128 on large graphs (hidden 256 / 512: a weight byte fetched once per 128 rows); BM = 64 at
-// hidden 128 (config 4, N = 50 000: 782 instead of 391 workgroups for 256 CUs, three per CU instead of a ragged 1-2).
+// hidden 128 (config 4, N = 50 000: 782 instead of 391 workgroups for 256 CUs; at that height the tile is held to 128
+// VGPRs and an unpadded 40 KiB of LDS so that four workgroups fit a CU and all 782 are resident at once).
 // BN = 256 everywhere except the data gradient with a 128-wide output (hidden 128, trans pair).
 template <int BM, int BN>
 struct Tile {
     static constexpr int RB = BM / 64, CB = BN / 64;
-    static constexpr int kAPlane = BM + 2;  // float4 per k-quad plane of the A image (+2: the 4 lanes that stage one row's
+    static constexpr int kAPlane = BM == 64 ? BM : BM + 2;  // float4 per k-quad plane of the A image (+2, BM = 128: the 4 lanes that stage one row's
                                             // 64 B land in 4 different bank groups; reads are per-row consecutive either way)
     static constexpr int kBPlane = BN;
     static constexpr int kAImg = 4 * kAPlane, kBImg = 4 * kBPlane;  // float4 per stage
@@ -96,7 +97,7 @@ struct BStage {
 
 // ---- forward ----------------------------------------------------------------------------------------------------
 template <int H, bool COMB, int BM>
-__global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
+__global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                 const float* __restrict__ xb, int64_t ldb,
                                                                 const float* __restrict__ Wimg,
                                                                 const float* __restrict__ bias,
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(kTThreads, 2) void tiled_fwd_kernel(const float* __
 // columns (cb = 0..3).  (A 128-column variant for the trans pair of hidden 128 was built and dropped: every form of it
 // kept staging registers in scratch memory; that one data gradient stays on dense.hip's kernel.)
 template <int H, int NOUT, int BM, int BN>
-__global__ __launch_bounds__(kTThreads, 2) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
+__global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                   const float* __restrict__ T, int64_t ldt,
                                                                   const uint8_t* __restrict__ mask, float zr, float omz,
                                                                   int act, const float* __restrict__ WTimg,
