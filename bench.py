@@ -54,7 +54,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="ppi_bp", help="ppi_bp | hpo_neuro | em_user | powerlaw | tiny")
+    ap.add_argument("--workload", default="ppi_bp", help="ppi_bp | hpo_neuro | em_user | powerlaw | density (the shipped C1 graph) | tiny")
     ap.add_argument("--features", default="deg", choices=["deg", "nodeid"],
                     help="deg: use_deg-style small table (default); nodeid: V = N embedding table (dense [N,H] "
                          "gradient -> the bucketed collective matters)")
@@ -443,8 +443,8 @@ def main():
             "metric": "aggregated edges/sec (GLASSConv fwd+bwd)", "value": nnz * L * args.steps * world / dt,
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{w.name}-shaped synthetic graph (BASELINE config[1] family): N={N}, nnz={nnz}, "
+            "dtype": "f32", "data": "shipped graph + subgraphs, random-init weights" if w.name == "density" else "synthetic",
+            "config": {"workload": f"{'the shipped density graph (BASELINE config[0])' if w.name == 'density' else w.name + '-shaped synthetic graph (BASELINE config[1] family)'}: N={N}, nnz={nnz}, "
                                    f"hidden={H}, layers={L}, aggr={w.aggr}, pool={w.pool}, z_ratio={w.z_ratio}, "
                                    f"dropout={w.dropout}, batch={w.batch}x{w.sub_size} per rank, "
                                    f"{'use_nodeid (V=N)' if args.features == 'nodeid' else 'use_deg'} features, Adam",

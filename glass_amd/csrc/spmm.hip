@@ -110,6 +110,51 @@ __device__ __forceinline__ void reduce_groups(Vec<VW>& acc) {
     for (int s = LPR; s < kWave; s <<= 1) acc.xor_add(s);
 }
 
+// ---- long rows: one workgroup per (row, chunk); 4 waves combine through LDS --------------------
+template <int VW, int LPR, int U, bool NT>
+__device__ __forceinline__ void long_item_body(const int32_t* __restrict__ col, const float* __restrict__ val,
+                                               const float* __restrict__ X, int64_t ldx, float* __restrict__ Y,
+                                               int64_t ldy, float* __restrict__ partials, int H,
+                                               const int32_t* __restrict__ it, float* lds) {
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+    const int grp = lane / LPR, sub = lane % LPR;
+    const int coff = (blockIdx.y * LPR + sub) * VW;
+    const bool col_ok = coff < H;
+    const int row = it[0], eb = it[1], ee = it[2], slot = it[3];
+    // wave w takes the w-th quarter of the chunk, rounded to whole 64-edge batches
+    const int per = ((ee - eb + 4 * kWave - 1) / (4 * kWave)) * kWave;
+    const int e0 = min(eb + w * per, ee), e1 = min(e0 + per, ee);
+    Vec<VW> acc;
+    acc.zero();
+    gather_edges<VW, LPR, U, NT>(acc, col, val, X + coff, ldx, e0, e1, lane, grp, col_ok);
+    reduce_groups<VW, LPR>(acc);
+    if (grp == 0) acc.store(&lds[(w * LPR + sub) * VW]);
+    __syncthreads();
+    if (w == 0 && grp == 0 && col_ok) {
+        Vec<VW> s, t;
+        s.load(&lds[sub * VW]);
+#pragma unroll
+        for (int k = 1; k < kBlock / kWave; ++k) {
+            t.load(&lds[(k * LPR + sub) * VW]);
+            s.add(t);
+        }
+        float* dst = slot < 0 ? Y + (int64_t)row * ldy : partials + (int64_t)slot * H;
+        s.store(dst + coff);
+    }
+}
+
+// stand-alone form: matrices that are ALL long rows (the selection matrix of the embedding backward)
+template <int VW, int LPR, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void spmm_long_kernel(const int32_t* __restrict__ col,
+                                                           const float* __restrict__ val,
+                                                           const float* __restrict__ X, int64_t ldx,
+                                                           float* __restrict__ Y, int64_t ldy,
+                                                           float* __restrict__ partials, int H,
+                                                           const int32_t* __restrict__ items) {
+    __shared__ float lds[(kBlock / kWave) * LPR * VW];
+    long_item_body<VW, LPR, U, NT>(col, val, X, ldx, Y, ldy, partials, H, items + 4 * (int64_t)blockIdx.x, lds);
+}
+
 #ifdef GLASS_K1_TRACE  // laboratory build only (tools/Makefile `lab`): per-wave wall-clock stamps of the sweep kernel
 __device__ unsigned long long* g_k1_trace;
 #define K1_STAMP(slot) do { if (g_k1_trace && lane == 0 && blockIdx.y == 0) g_k1_trace[(size_t)wave * 4 + (slot)] = wall_clock64(); } while (0)
@@ -152,19 +197,30 @@ constexpr int kItemEdges = GLASS_K1_ITEM_EDGES;  // edges per sweep item (LDS st
 // work must sit in flat-eligible items (header word H_FLAT_SHARE; ppi_bp-shape: a few low-degree rows out of 17 080
 // qualify, and carrying the flat branch for them cost 13.4 vs 12.2 us per launch).
 template <int VW, int LPR, int U, bool NT, bool FLAT>
-__global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
+// (row-only build at H >= 64: held to 64 VGPRs = 8 waves per SIMD; the long-row branch would otherwise cost a 65th)
+__global__ __launch_bounds__(kBlock, (!FLAT && LPR >= 16) ? 8 : 1) void spmm_sweep_kernel(const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col,
                                                             const float* __restrict__ val,
                                                             const float* __restrict__ X, int64_t ldx,
                                                             float* __restrict__ Y, int64_t ldy, int H,
                                                             const int32_t* __restrict__ items, int n_waves,
-                                                            int rp_factor) {
+                                                            int rp_factor, const int32_t* __restrict__ long_items,
+                                                            int n_sweep_blocks, float* __restrict__ partials) {
     constexpr int G = kWave / LPR;
     constexpr int kWaves = kBlock / kWave;
     constexpr bool kFlat = FLAT && G > 1;
     __shared__ int32_t s_rp[kFlat ? kWaves : 1][kFlat ? kItemRows + 1 : 1];
     __shared__ int32_t s_col[kFlat ? kWaves : 1][kFlat ? kItemEdges : 1];
     __shared__ float s_val[kFlat ? kWaves : 1][kFlat ? kItemEdges : 1];
+    __shared__ float s_long[kWaves * LPR * VW];
+    if ((int)blockIdx.x >= n_sweep_blocks) {
+        // The workgroups past the sweep's own run the plan's long-row items in the same launch: on graphs that have both
+        // kinds of rows a second dependent launch for a handful of long rows cost more than the rows themselves (the
+        // shipped density graph: 4 955 sweep waves + 4 long rows, 12.8 us as two launches).
+        long_item_body<VW, LPR, U, NT>(col, val, X, ldx, Y, ldy, partials, H,
+                                       long_items + 4 * (int64_t)((int)blockIdx.x - n_sweep_blocks), s_long);
+        return;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wave = blockIdx.x * kWaves + w;
@@ -278,43 +334,6 @@ __global__ __launch_bounds__(kBlock) void spmm_sweep_kernel(const int32_t* __res
     K1_STAMP(3);
 }
 
-// ---- long-row kernel: one workgroup per (row, chunk); 4 waves combine through LDS ------------
-template <int VW, int LPR, int U, bool NT>
-__global__ __launch_bounds__(kBlock) void spmm_long_kernel(const int32_t* __restrict__ col,
-                                                           const float* __restrict__ val,
-                                                           const float* __restrict__ X, int64_t ldx,
-                                                           float* __restrict__ Y, int64_t ldy,
-                                                           float* __restrict__ partials, int H,
-                                                           const int32_t* __restrict__ items) {
-    __shared__ float lds[(kBlock / kWave) * LPR * VW];
-    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
-    const int grp = lane / LPR, sub = lane % LPR;
-    const int coff = (blockIdx.y * LPR + sub) * VW;
-    const bool col_ok = coff < H;
-    const int32_t* it = items + 4 * (int64_t)blockIdx.x;
-    const int row = it[0], eb = it[1], ee = it[2], slot = it[3];
-    // wave w takes the w-th quarter of the chunk, rounded to whole 64-edge batches
-    const int per = ((ee - eb + 4 * kWave - 1) / (4 * kWave)) * kWave;
-    const int e0 = min(eb + w * per, ee), e1 = min(e0 + per, ee);
-    Vec<VW> acc;
-    acc.zero();
-    gather_edges<VW, LPR, U, NT>(acc, col, val, X + coff, ldx, e0, e1, lane, grp, col_ok);
-    reduce_groups<VW, LPR>(acc);
-    if (grp == 0) acc.store(&lds[(w * LPR + sub) * VW]);
-    __syncthreads();
-    if (w == 0 && grp == 0 && col_ok) {
-        Vec<VW> s, t;
-        s.load(&lds[sub * VW]);
-#pragma unroll
-        for (int k = 1; k < kBlock / kWave; ++k) {
-            t.load(&lds[(k * LPR + sub) * VW]);
-            s.add(t);
-        }
-        float* dst = slot < 0 ? Y + (int64_t)row * ldy : partials + (int64_t)slot * H;
-        s.store(dst + coff);
-    }
-}
-
 // ---- reduce kernel: rows cut into several chunks: sum their partial rows in slot order --------
 __global__ __launch_bounds__(kBlock) void spmm_reduce_kernel(const float* __restrict__ partials, float* __restrict__ Y,
                                                              int64_t ldy, int H, const int32_t* __restrict__ rrows) {
@@ -334,19 +353,20 @@ static int launch_spmm_u(const int32_t* rowptr, const int32_t* col, const float*
     const int n_ctiles = (int)ceil_div(H, (int64_t)LPR * VW);
     const int n_waves = hdr[H_NSWEEP];
     if (n_waves > 0) {
-        dim3 grid((unsigned)ceil_div(n_waves, kBlock / kWave), n_ctiles);
+        const int n_sweep_blocks = (int)ceil_div(n_waves, kBlock / kWave);
+        dim3 grid((unsigned)(n_sweep_blocks + hdr[H_NLONG]), n_ctiles);  // sweep workgroups, then one per long-row item
         constexpr int G = kWave / LPR;
         int g_log2 = 0;
         while ((1 << g_log2) < G) ++g_log2;
         const int share15 = (hdr[H_FLAT_SHARE] >> (4 * g_log2)) & 15;  // fifteenths of the sweep cost in flat-eligible items
         if (G > 1 && n_waves >= kFlatMinItems && share15 >= kFlatMinShare15)
             hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U, NT, true>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx,
-                               Y, ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_RP_FACTOR]);
+                               Y, ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, hdr[H_RP_FACTOR], plan + hdr[H_OFF_LONG],
+                               n_sweep_blocks, ws);
         else
             hipLaunchKernelGGL((spmm_sweep_kernel<VW, LPR, U, NT, false>), grid, dim3(kBlock), 0, st, rowptr, col, val, X, ldx,
-                               Y, ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, 0);
-    }
-    if (hdr[H_NLONG] > 0) {
+                               Y, ldy, (int)H, plan + hdr[H_OFF_SWEEP], n_waves, 0, plan + hdr[H_OFF_LONG], n_sweep_blocks, ws);
+    } else if (hdr[H_NLONG] > 0) {
         dim3 grid((unsigned)hdr[H_NLONG], n_ctiles);
         hipLaunchKernelGGL((spmm_long_kernel<VW, LPR, U, NT>), grid, dim3(kBlock), 0, st, col, val, X, ldx, Y, ldy, ws,
                            (int)H, plan + hdr[H_OFF_LONG]);
@@ -388,6 +408,9 @@ extern "C" int glass_k1_trace_set(unsigned long long* p) {
 // the chunk shrink until it does (never below one 64-edge batch per wave).  Such matrices (<= 1024 rows averaging
 // >= 64 entries) also skip the sweep kernel altogether: EVERY row becomes workgroup items (an empty row one empty
 // item that stores zeros), so the product is two launches (items + reduce) instead of three.
+#ifndef GLASS_K1_SMALL_ROWS
+#define GLASS_K1_SMALL_ROWS 16384
+#endif
 #ifndef GLASS_K1_LONG_THR
 #define GLASS_K1_LONG_THR 256
 #endif
@@ -414,6 +437,10 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
         kLongChunk /= 2;
         if (kLongThr > 64) kLongThr /= 2;
     }
+    // Small sweeps (at most ~2 generations of resident waves) are latency-bound: the launch lasts as long as its longest
+    // wave, and a wave walks a row of d edges in d/32 dependent rounds.  There a row of >= 64 edges is worth a workgroup
+    // (4 waves share it); the long-row items ride in the sweep launch, so they cost no launch of their own.
+    if (n_rows <= GLASS_K1_SMALL_ROWS && kLongThr > 64) kLongThr = 64;
     const bool all_long = n_rows > 0 && n_rows <= 1024 && nnz >= 64 * n_rows;
     if (all_long) kLongThr = 0;
     int64_t cost_total = 0;

@@ -31,8 +31,11 @@ class Workload:
     lr: float = 1e-3
 
 
-# BASELINE.json configs C2..C5 (C1 is the shipped density graph: see datasets.py)
+# BASELINE.json configs C1..C5.  C1 is the shipped density graph (dataset_/density/graph.npz: N = 4 998, 29 962 undirected
+# edges, 250 labelled subgraphs x 20 nodes) at SURVEY.md §8d's model (hidden 64, 2 layers, config/density.yml otherwise);
+# its n_pairs entry is informational — make_workload reads the real graph and its real subgraphs.
 WORKLOADS = {
+    "density": Workload("density", 4998, 29962, 64, 2, "sum", "size", 1.0, 0.0, 2, 20, 3),
     "ppi_bp": Workload("ppi_bp", 17080, 316951, 64, 2, "mean", "sum", 0.95, 0.5, 80, 10, 6, lr=0.0005),
     "hpo_neuro": Workload("hpo_neuro", 14587, 3238174, 64, 2, "gcn", "sum", 0.85, 0.5, 99, 15, 10, True, lr=0.002),
     "em_user": Workload("em_user", 50000, 500000, 128, 1, "gcn", "size", 0.75, 0.5, 6, 155, 2),
@@ -100,9 +103,26 @@ def make_subgraphs(n_node, n_sub, size, n_class, seed=1, multilabel=False):
     return pos, y
 
 
+def _shipped_density(w, n_batches):
+    """The real C1 graph: symmetrised, sorted by (row, col), use_deg features, the dataset's own subgraphs and labels
+    (cycled when more batches are asked for than the 250 subgraphs give)."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dataset_", "density", "graph.npz"))
+    e = z["edges"].astype(np.int64)
+    row = np.concatenate([e[:, 0], e[:, 1]])
+    col = np.concatenate([e[:, 1], e[:, 0]])
+    order = np.argsort(row * w.n_node + col, kind="stable")
+    ei = np.stack([row[order], col[order]])
+    ew = np.ones(ei.shape[1], dtype=np.float32)
+    idx = np.arange(w.batch * n_batches) % z["subG"].shape[0]
+    return ei, ew, degree_feature(ei, w.n_node), z["subG"].astype(np.int64)[idx], z["label"].astype(np.int64)[idx]
+
+
 def make_workload(name, seed=0, n_batches=4):
     """Graph + features + n_batches*batch subgraphs for a named workload (numpy arrays)."""
     w = WORKLOADS[name]
+    if name == "density":
+        return (w, *_shipped_density(w, n_batches))
     ei, ew = make_graph(w.n_node, w.n_pairs, seed, w.powerlaw)
     x = degree_feature(ei, w.n_node)
     pos, y = make_subgraphs(w.n_node, w.batch * n_batches, w.sub_size, w.n_class, seed + 1, w.multilabel)

@@ -108,6 +108,10 @@ def test_plan_builder_shapes():
     assert hdr[5] == 0 and hdr[4] == 20000  # ppi_bp-like: one row per wave
     hdr = _check_plan(np.concatenate([[0], np.cumsum(np.full(5000, 12))]))
     assert hdr[4] == 5000  # density-like: the budget floor (16 cost units) still gives every degree-12 row its own wave
+    hdr = _check_plan(np.concatenate([[0], np.cumsum([10] * 3000 + [100, 300, 63])]))
+    assert hdr[8] == 64 and hdr[5] == 2  # latency-bound sweep (<= 16 384 rows): rows of >= 64 edges go to workgroups
+    hdr = _check_plan(np.concatenate([[0], np.cumsum([10] * 20000 + [100, 300, 63])]))
+    assert hdr[8] == 256 and hdr[5] == 1
     hdr = _check_plan(np.concatenate([[0], np.cumsum(rng.choice([0, 0, 40, 300, 5000], 60))]))  # selection-matrix-like
     assert hdr[4] == 0 and hdr[5] >= 60 and hdr[8] == 0
 
