@@ -408,8 +408,8 @@ extern "C" int glass_k1_trace_set(unsigned long long* p) {
 // the chunk shrink until it does (never below one 64-edge batch per wave).  Such matrices (<= 1024 rows averaging
 // >= 64 entries) also skip the sweep kernel altogether: EVERY row becomes workgroup items (an empty row one empty
 // item that stores zeros), so the product is two launches (items + reduce) instead of three.
-#ifndef GLASS_K1_SMALL_ROWS
-#define GLASS_K1_SMALL_ROWS 16384
+#ifndef GLASS_K1_SMALL_COST
+#define GLASS_K1_SMALL_COST (2ll << 20)   // edges + 4 per row: below this a product is latency-bound (plan policy)
 #endif
 #ifndef GLASS_K1_LONG_THR
 #define GLASS_K1_LONG_THR 256
@@ -437,10 +437,17 @@ extern "C" int glass_spmm_plan_build(const int32_t* rowptr, int64_t n_rows, int3
         kLongChunk /= 2;
         if (kLongThr > 64) kLongThr /= 2;
     }
-    // Small sweeps (at most ~2 generations of resident waves) are latency-bound: the launch lasts as long as its longest
-    // wave, and a wave walks a row of d edges in d/32 dependent rounds.  There a row of >= 64 edges is worth a workgroup
-    // (4 waves share it); the long-row items ride in the sweep launch, so they cost no launch of their own.
-    if (n_rows <= GLASS_K1_SMALL_ROWS && kLongThr > 64) kLongThr = 64;
+    // Small products (a few generations of resident waves at most) are latency-bound: the launch lasts as long as its
+    // longest wave, and a wave walks d edges in d/32 dependent rounds.  There a row of >= 64 edges is worth a workgroup
+    // (4 waves share it; the long-row items ride in the sweep launch, so they cost no launch of their own) and a chunk
+    // is 512 edges (2 batches per wave; longer rows pay the reduce launch instead of a 16-round chain).  Measured,
+    // us per product at H = 64 (2048-edge chunks / threshold 256 -> this): shipped density graph 12.8 -> 6.1; N = 4 998
+    // Zipf 0.8 19.4 -> 8.1; N = 17 080, 634 k edges, Zipf 0.5 31.6 -> 16.3; N = 14 587, 1.2 M edges, Zipf 0.7 35.2 -> 24.7.
+    // Throughput-bound products keep the large chunks (hpo_neuro-shape, 6.5 M edges: 75.8 vs 77.8 with 512).
+    if (nnz + 4 * n_rows <= GLASS_K1_SMALL_COST) {
+        if (kLongThr > 64) kLongThr = 64;
+        if (kLongChunk > 512) kLongChunk = 512;
+    }
     const bool all_long = n_rows > 0 && n_rows <= 1024 && nnz >= 64 * n_rows;
     if (all_long) kLongThr = 0;
     int64_t cost_total = 0;

@@ -109,9 +109,9 @@ def test_plan_builder_shapes():
     hdr = _check_plan(np.concatenate([[0], np.cumsum(np.full(5000, 12))]))
     assert hdr[4] == 5000  # density-like: the budget floor (16 cost units) still gives every degree-12 row its own wave
     hdr = _check_plan(np.concatenate([[0], np.cumsum([10] * 3000 + [100, 300, 63])]))
-    assert hdr[8] == 64 and hdr[5] == 2  # latency-bound sweep (<= 16 384 rows): rows of >= 64 edges go to workgroups
-    hdr = _check_plan(np.concatenate([[0], np.cumsum([10] * 20000 + [100, 300, 63])]))
-    assert hdr[8] == 256 and hdr[5] == 1
+    assert hdr[8] == 64 and hdr[9] == 512 and hdr[5] == 2  # latency-bound product (edges + 4 rows <= 2 Mi): rows of >= 64 edges go to workgroups
+    hdr = _check_plan(np.concatenate([[0], np.cumsum([40] * 60000 + [100, 300, 63])]))
+    assert hdr[8] == 256 and hdr[9] == 2048 and hdr[5] == 1  # throughput-bound: long rows start at 256 edges, 2048-edge chunks
     hdr = _check_plan(np.concatenate([[0], np.cumsum(rng.choice([0, 0, 40, 300, 5000], 60))]))  # selection-matrix-like
     assert hdr[4] == 0 and hdr[5] >= 60 and hdr[8] == 0
 
