@@ -53,7 +53,8 @@ const char* glass_last_error_string(void);
  * The launch schedule ("plan") depends only on the row pointer: short rows are dealt to wavefronts as
  * items (r0, r1, e0, e1) — runs of <= 64 consecutive rows holding <= 256 edges, edge-balanced, each
  * carrying its own edge range so that the kernel's index loads hang off one plan read; rows longer
- * than a threshold are cut into chunks that a whole workgroup reduces through LDS, and rows longer
+ * than a threshold are cut into chunks that a whole workgroup reduces through LDS (the trailing
+ * workgroups of the same launch), and rows longer
  * than one chunk are summed from per-chunk partial rows in a fixed order (no float atomics ->
  * bitwise repeatable).  Header words: magic, version (2), n_rows, nnz, #items, #long chunks,
  * #reduce rows, #partial slots, long threshold, long chunk, offsets of the three sections, and the
