@@ -116,13 +116,13 @@ class ParamArena(FlatGradBucket):
                     # MFMA images of W (forward operand, [NT=2H][KT=K]) and of W^T (data-gradient operand,
                     # [NT=K][KT=2H]); refreshed by ONE launch per training forward (Adam changes W in between).
                     # flags = transposed | layout << 1 (layout 0: wave16 images; tiled kernels: forward operand
-                    # paired = 1, data-gradient operand plain = 2)
+                    # paired = 1, data-gradient operand plain = 2, or split = 3 for the 128-wide output of hidden 128's
+                    # trans pair: both halves of the product side by side in one 256-slot tile)
                     tiled = _lib.load().glass_dual_linear_layout(O // 2) == 1
                     Wimg, WTimg = torch.empty_like(W).reshape(-1), torch.empty_like(W).reshape(-1)
                     self._packs.append((W, Wimg, O, K, 0 | ((1 << 1) if tiled else 0)))
-                    # data-gradient operand: NT = K output columns in 256-column tiles; a 128-wide output (hidden 128,
-                    # trans pair) keeps the wave16 kernel and its image
-                    plain = 2 if K % 256 == 0 else 0
+                    # data-gradient operand: NT = K output columns in 256-column tiles
+                    plain = 2 if K % 256 == 0 else 3
                     self._packs.append((W, WTimg, K, O, 1 | ((plain << 1) if tiled else 0)))
                     mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)
                 else:

@@ -16,8 +16,8 @@
 // 16-column output tile, the same chunk of row (16t+i) of the [out][in] weight — both are plain 16-B
 // loads of consecutive floats; MFMA step s multiplies element s of the four chunks (the matrix core
 // sums over k in any order, so no transposes or shuffles are needed).  The weight slice of a K-pass is
-// staged once per workgroup in LDS, pre-permuted into consumption order (see WStage).  Hidden sizes 64 and 128
-// (128: two wave groups split the output columns); 256 / 512 take the LDS-tiled kernels of dense_tiled.hip.
+// staged once per workgroup in LDS, pre-permuted into consumption order (see WStage).  Hidden size 64; 128 / 256 / 512
+// take the LDS-tiled kernels of dense_tiled.hip.
 #include "common.h"
 #include "dense_common.h"
 #include "wgrad_common.h"
@@ -564,6 +564,18 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
         }
         return;
     }
+    if (j.layout == kLayoutTiledSplit) {
+        // split data-gradient operand (hidden 128, trans pair: NT = 128 outputs, KT = 256 = the two stacked halves): one
+        // 256-slot column tile holds BOTH halves side by side over K = KT / 2 — slot v < NT: B[v][k], else B[v - NT][KT/2 + k]
+        const int NKS = j.KT / 32;
+        for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
+            const int nl = l & 255, q = (l >> 8) & 3, ks = l >> 10;
+            const int v = tiled_col(kLayoutTiledPlain, 0, nl, 0);
+            if (ks < NKS)
+                reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, v % j.NT, (v / j.NT) * (j.KT / 2) + 16 * ks + 4 * q);
+        }
+        return;
+    }
     // tiled layouts (dense_tiled.hip): dst[((ct * NKS + ks) * 4 + q) * 256 + nl] (float4) = B[tiled_col(ct, nl)][16 ks + 4 q ..+3]
     const int NKS = j.KT / 16, H = j.NT / 2;  // H only meaningful for the paired layout (NT = 2H)
     for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
@@ -595,9 +607,10 @@ static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at 
 }
 
 // Policy: hidden 64 on the wave-owns-16-rows kernels of this file (one wave group per 64 rows); hidden 128 / 256 / 512 on
-// the LDS-tiled kernels of dense_tiled.hip (hidden 128, N = 50 000: forward 63 -> 57 / 95 -> 87 us, comb data gradient
-// 98 -> 85 us, em_user-shape step 0.82 -> 0.72 ms) — except the 128-wide data gradient of hidden 128's trans pair, which
-// keeps this file's two-wave-group kernel (CS = 2: 512 threads share 64 rows and split the output columns).
+// the LDS-tiled kernels of dense_tiled.hip (hidden 128, N = 50 000 against round 1's two-wave-group kernels of this file:
+// forward 63 -> 53 / 95 -> 85 us, data gradient 79 -> 56 (trans, split tile) / 98 -> 80 us (comb), em_user-shape step
+// 0.82 -> 0.70 ms).  The CS > 1 form of the kernels below (wave groups splitting the output columns) is no longer
+// instantiated.
 // (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
 
@@ -694,7 +707,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         return glass_dual_linear_wgrad_f32(dsrc, ldd, T, ldt, mask, z_ratio, act, wg->X, wg->ldx, wg->X2, wg->ldx2, n_nodes, H,
                                            nullptr, 0, nullptr, 0, wg->ws, stream);
     };
-    if (tiled_here(H) && !(H == 128 && n_out == H)) {  // (hidden 128, 128-wide output: wave16 kernel below, wave16 image)
+    if (tiled_here(H)) {
         const int rc = launch_tiled_dgrad(dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, n_out, addend, ldadd, drop, rng_state,
                                           out, ldo, n_nodes, H, gs, st);
         return rc ? rc : wgrad_after();
@@ -732,7 +745,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         else                                                                                                       \
             hipLaunchKernelGGL((dual_dgrad_kernel<HH, 2 * HH, CS, RW>), grid, dim3(kWave * RW * CS), lds_dg, st, dargs); \
     }
-    GLASS_DG(64, 1, 4) GLASS_DG(128, 2, 4)
+    GLASS_DG(64, 1, 4)
 #undef GLASS_DG
     const int rc = launch_status("glass_dual_linear_dgrad_f32");
     return rc ? rc : wgrad_after();
@@ -776,8 +789,10 @@ extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const*
                           aligned16(dst[k]),
                       "dense_pack_batch: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", k);
         const int layout = transposed[k] >> 1;
-        GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0),
-                      "dense_pack_batch: job %d: unknown layout %d or NT not a multiple of 256 for a tiled layout", k, layout);
+        GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
+                          (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)),
+                      "dense_pack_batch: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
+                      "layout that is not the transposed 128 x 256 operand", k, layout);
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout};
     }
     hipLaunchKernelGGL(pack_batch_kernel, dim3(32, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream, b,

@@ -32,7 +32,7 @@ struct GnBwdStats {
 };
 
 // Operand-image layouts written by glass_dense_pack_batch_f32 (bits 1.. of its per-job flags; bit 0 = transposed source)
-enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2 };
+enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2, kLayoutTiledSplit = 3 };
 
 // dense_tiled.hip
 bool tiled_shape_ok(int64_t H);

@@ -242,10 +242,14 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
 // ---- backward data gradient ---------------------------------------------------------------------------------------
 // out[N, NOUT] = dZ[N, 2H] @ Wstack[2H, NOUT] (+ addend)(* dropout mask), dZ[n, o] = coef(n, o < H) * dsrc[n, o mod H]
 // * act'(T[n, o]) synthesised while staging; WTimg = Wstack^T packed plain-tiled: a lane holds four consecutive output
-// columns (cb = 0..3).  (A 128-column variant for the trans pair of hidden 128 was built and dropped: every form of it
-// kept staging registers in scratch memory; that one data gradient stays on dense.hip's kernel.)
-template <int H, int NOUT, int BM, int BN>
-__global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
+// columns (cb = 0..3).
+// SPLIT (hidden 128, trans pair: a 128-wide output would fill only half of the 256-slot column tile): the product is
+// dZ1 @ W1 + dZ0 @ W0 with both terms [N, 128] — the two wave columns of the workgroup take one term each: the left
+// pair of waves multiplies the f1 half (its own A image) into column slots 0..127, the right pair the f0 half into slots
+// 128..255, K is H instead of 2H, and the right pair hands its accumulators to the left through LDS before the epilogue.
+// Operand image: layout kLayoutTiledSplit (slot s < 128: Wstack[k][s], else Wstack[H + k][s - 128]).
+template <int H, int NOUT, int BM, int BN, bool SPLIT>
+__global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                   const float* __restrict__ T, int64_t ldt,
                                                                   const uint8_t* __restrict__ mask, float zr, float omz,
                                                                   int act, const float* __restrict__ WTimg,
@@ -254,8 +258,11 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kerne
                                                                   float* __restrict__ out, int64_t ldo, int64_t N,
                                                                   GnBwdStats gs, int n_rowtiles) {
     using TL = Tile<BM, BN>;
-    constexpr int KT = 2 * H, NKS = KT / kTK, NCT = NOUT / BN, RB = TL::RB, CB = TL::CB, AP = TL::kAPer;
-    static_assert(NOUT % BN == 0 && CB == 4, "output width must be a multiple of the 256-slot column tile");
+    constexpr int KT = SPLIT ? H : 2 * H, NKS = KT / kTK, NCT = SPLIT ? 1 : NOUT / BN, RB = TL::RB, CB = TL::CB, AP = TL::kAPer;
+    constexpr int NA = SPLIT ? 2 : 1;                          // A images per stage
+    constexpr int kStage = NA * TL::kAImg + TL::kBImg;         // float4 per stage
+    static_assert(CB == 4 && (SPLIT ? (NOUT == H && 2 * NOUT == BN) : NOUT % BN == 0),
+                  "output width must be a multiple of the 256-slot column tile (SPLIT: exactly half of one)");
     extern __shared__ float4 smem[];
     int rt, ct;
     if (!tile_of_block(NCT, n_rowtiles, rt, ct)) return;
@@ -273,16 +280,18 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kerne
         slab[i] = sok[i] && mask[row0 + srow[i]] != 0;
     }
     const float4* wimg = reinterpret_cast<const float4*>(WTimg) + (int64_t)ct * NKS * TL::kBImg;
-    float4 dv[AP], tv[AP];
+    float4 dv[AP], tv[AP], tw[SPLIT ? AP : 1];
     BStage<TL::kBPer> bs;
     auto issue = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            const int o = ks * kTK + 4 * skq[i];  // column of dZ
+            const int o = ks * kTK + 4 * skq[i];  // column of dZ (SPLIT: of both halves)
             const int64_t r = row0 + srow[i];
             dv[i] = sok[i] ? *reinterpret_cast<const float4*>(dsrc + r * ldd + (o < H ? o : o - H)) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act == GLASS_ACT_ELU)
+            if (act == GLASS_ACT_ELU) {
                 tv[i] = sok[i] ? *reinterpret_cast<const float4*>(T + r * ldt + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (SPLIT) tw[i] = sok[i] ? *reinterpret_cast<const float4*>(T + r * ldt + H + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
         bs.issue(wimg + (int64_t)ks * TL::kBImg);
     };
@@ -296,8 +305,16 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kerne
                 v.x *= elu_grad_f(tv[i].x); v.y *= elu_grad_f(tv[i].y); v.z *= elu_grad_f(tv[i].z); v.w *= elu_grad_f(tv[i].w);
             }
             stage[skq[i] * TL::kAPlane + srow[i]] = v;
+            if (SPLIT) {  // the f0 half of the same dsrc columns: the other label coefficient, the other half of T
+                const float c0 = sok[i] ? (slab[i] ? omz : zr) : 0.f;
+                float4 u = make_float4(dv[i].x * c0, dv[i].y * c0, dv[i].z * c0, dv[i].w * c0);
+                if (act == GLASS_ACT_ELU) {
+                    u.x *= elu_grad_f(tw[i].x); u.y *= elu_grad_f(tw[i].y); u.z *= elu_grad_f(tw[i].z); u.w *= elu_grad_f(tw[i].w);
+                }
+                stage[TL::kAImg + skq[i] * TL::kAPlane + srow[i]] = u;
+            }
         }
-        bs.commit(stage + TL::kAImg);
+        bs.commit(stage + NA * TL::kAImg);
     };
 
     f32x16 acc[RB][CB];
@@ -312,13 +329,35 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kerne
     commit(0, smem);
     __syncthreads();
     for (int ks = 0; ks < NKS; ++ks) {
-        float4* cur = smem + (ks & 1) * TL::kStageVecs;
-        float4* nxt = smem + ((ks + 1) & 1) * TL::kStageVecs;
+        float4* cur = smem + (ks & 1) * kStage;
+        float4* nxt = smem + ((ks + 1) & 1) * kStage;
         if (ks + 1 < NKS) issue(ks + 1);
-        tile_mma<BM, BN>(acc, cur, cur + TL::kAImg, j, h, wm, wn);
+        tile_mma<BM, BN>(acc, cur + (SPLIT ? wn * TL::kAImg : 0), cur + NA * TL::kAImg, j, h, wm, wn);
         if (ks + 1 < NKS) commit(ks + 1, nxt);
         __syncthreads();
     }
+    if (SPLIT) {  // right wave column -> left wave column (same row block, same lane <-> same rows and column slots)
+        float* xf = reinterpret_cast<float*>(smem);
+        if (wn == 1) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) xf[(((wm * RB + rb) * CB + cb) * 16 + i) * 64 + lane] = acc[rb][cb][i];
+        }
+        __syncthreads();
+        if (wn == 0) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[rb][cb][i] += xf[(((wm * RB + rb) * CB + cb) * 16 + i) * 64 + lane];
+        }
+        __syncthreads();  // the statistics below reuse this memory
+    }
+    const bool active = !SPLIT || wn == 0;  // waves that own output columns
 
     // epilogue: this lane's four consecutive output columns col0 .. col0 + 3 (cb = 0..3) of its 16 * RB rows
     const int col0 = ct * BN + wn * (BN / 2) + CB * j;
@@ -326,7 +365,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kerne
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
     }
-    const bool gn_half = gs.partial != nullptr && col0 < H;  // wave-uniform (H is a multiple of 128 >= BN / 2)
+    const bool gn_half = active && gs.partial != nullptr && col0 < H;  // wave-uniform (H is a multiple of 128 >= BN / 2)
     float g_mu[CB], g_rstd[CB], g_scale[CB], g_shift[CB], g_al[CB];
     double s1[CB], s2[CB];
 #pragma unroll
@@ -350,7 +389,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_dgrad_kerne
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int64_t r = row0 + wm * (BM / 2) + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-            if (r < N) {
+            if (active && r < N) {
                 float v[CB];
 #pragma unroll
                 for (int e = 0; e < CB; ++e) v[e] = acc[rb][e][i];
@@ -444,13 +483,19 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
     {                                                                                                                \
         const int64_t n_rt = ceil_div(N, BM);                                                                        \
         const size_t lds = Tile<BM, BN>::kLds;                                                                       \
-        allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN>, lds);                                                  \
-        hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
+        allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, false>, lds);                                           \
+        hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, false>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
                            st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, \
                            gs, (int)n_rt);                                                                           \
     }
-    if (H == 128) {
-        GLASS_TDG1(128, 256, 64, 256)  // n_out == 2H only: the 128-wide data gradient of the trans pair stays on dense.hip
+    if (H == 128 && n_out == H) {  // trans pair: the two terms of the product side by side in one 256-slot tile
+        const int64_t n_rt = ceil_div(N, 64);
+        const size_t lds = 2 * (size_t)(2 * Tile<64, 256>::kAImg + Tile<64, 256>::kBImg) * sizeof(float4);
+        hipLaunchKernelGGL((tiled_dgrad_kernel<128, 128, 64, 256, true>), dim3(tiled_grid(n_rt, 1)), dim3(kTThreads), lds, st,
+                           dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, gs,
+                           (int)n_rt);
+    } else if (H == 128) {
+        GLASS_TDG1(128, 256, 64, 256)
     } else if (H == 256) {
         if (n_out == H) GLASS_TDG1(256, 256, 128, 256) else GLASS_TDG1(256, 512, 128, 256)
     } else if (H == 512) {

@@ -226,7 +226,9 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  *     chosen by the hidden size: H = 64 — a wave owns 16 rows and all output columns, v_mfma_f32_16x16x4_f32,
  *     images in that fragment order (layout 0); H = 128 / 256 / 512 — LDS-tiled GEMM, workgroup tile 64 (H = 128) or
  *     128 rows x 256 columns, v_mfma_f32_32x32x2_f32, images in LDS-stage order (forward: layout 1 "paired", the f1 / f0 halves of
- *     a column side by side in a wave; data gradient: layout 2 "plain").  glass_dual_linear_layout(H) tells which.
+ *     a column side by side in a wave; data gradient: layout 2 "plain", or layout 3 "split" for the 128-wide output of
+ *     H = 128's trans pair: the transposed [128][256] operand, both stacked halves side by side in one 256-slot tile over
+ *     K = 128).  glass_dual_linear_layout(H) tells which family.
  *   fwd : xb == NULL (trans): T = xa @ W^T + bias is written to T (kept for the backward),
  *                             out = mix(act(T1), act(T0)).
  *         xb != NULL (comb) : the input is the virtual concatenation [xa || xb] (no cat copy),

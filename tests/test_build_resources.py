@@ -68,4 +68,4 @@ def test_dense_kernels_keep_vector_loads():
         vector = len(re.findall(r"global_load_dwordx4", body))
         assert scalar == 0 and vector >= 10, (m.group(1), scalar, vector)
         found += 1
-    assert found >= 8
+    assert found >= 6  # fwd x2, dgrad x2, fused bwd x2 at hidden 64

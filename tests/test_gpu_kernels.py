@@ -499,13 +499,14 @@ def test_dual_linear_mix_fused(H, N, comb):
 
 def _pack(W, transposed, H=64):
     """glass_dense_pack_batch_f32 on one matrix: operand image of W ([NT][KT]) or of W^T, in the layout the fused dense
-    kernels of hidden size H read (flags = transposed | layout << 1: forward operand paired, data-gradient plain)."""
+    kernels of hidden size H read (flags = transposed | layout << 1: forward operand paired, data-gradient plain, or split for a
+    128-wide output)."""
     from glass_amd import _lib
     img = torch.empty(W.numel(), device=DEV)
     nt, kt = (W.shape[1], W.shape[0]) if transposed else W.shape
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
-    layout = ((2 if nt % 256 == 0 else 0) if transposed else 1) if _lib.load().glass_dual_linear_layout(H) == 1 else 0
+    layout = ((2 if nt % 256 == 0 else 3) if transposed else 1) if _lib.load().glass_dual_linear_layout(H) == 1 else 0
     trs = np.array([int(transposed) | (layout << 1)], dtype=np.int32)
     rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                 trs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
@@ -535,12 +536,20 @@ def test_dense_pack_tiled_layouts():
     for H in (256, 128):
         W = torch.arange(2 * H * H, dtype=torch.float32, device=DEV).reshape(2 * H, H)  # trans pair weight [2H][H]
         for transposed in (False, True):
-            if transposed and H == 128:
-                continue  # 128-wide data-gradient operand: wave16 image (test_dense_pack_is_a_permutation's layout)
             img = _pack(W, transposed, H).cpu()
             assert sorted(img.tolist()) == W.reshape(-1).cpu().tolist()
             B = (W.t() if transposed else W).cpu()
             NT, KT = B.shape
+            if transposed and H == 128:
+                # split layout: ONE 256-slot tile over K = KT / 2 holds both stacked halves side by side —
+                # slot v = wn*128 + 4j + cb: v < 128 -> B[v][k], else B[v - 128][KT/2 + k]
+                for (ks, q, nl) in ((0, 0, 0), (KT // 32 - 1, 3, 255), (3, 2, 97), (5, 1, 200)):
+                    wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
+                    v = wn * 128 + 4 * j + cb
+                    k = (v // NT) * (KT // 2) + 16 * ks + 4 * q
+                    off = (((ks * 4 + q) * 256) + nl) * 4
+                    assert img[off:off + 4].tolist() == B[v % NT, k:k + 4].tolist()
+                continue
             NKS = KT // 16
             for (ct, ks, q, nl) in ((0, 0, 0, 0), (NT // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (NT // 256 - 1, 5, 1, 200)):
                 wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
