@@ -191,7 +191,8 @@ __device__ __forceinline__ void gn_prologue16(float (&a)[kKC], const FwdRaw& raw
 
 // CS = column split: CS wave groups of 4 waves share the same 64 rows, each owning 1/CS of the 64-column output
 // groups (hidden 64: CS = 1, a wave holds all 8 tiles; hidden 128: CS = 2, 8 of the 16 tiles per wave -> the
-// accumulators, staging registers and operand chunks fit the register file without spills).
+// accumulators, staging registers and operand chunks fit the register file without spills).  Only CS = 1 (hidden 64) is
+// instantiated now: hidden 128 runs on dense_tiled.hip.
 template <int H, bool COMB, int CS, int RW>
 __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
