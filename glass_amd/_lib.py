@@ -24,7 +24,7 @@ AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
 ACT_NONE, ACT_ELU = 0, 1
 PLAN_HEADER_WORDS = 16
 EMBED_NORM_MAX_ROWS = 8192  # GLASS_EMBED_NORM_MAX_ROWS
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GlassHipError(RuntimeError):
@@ -80,7 +80,8 @@ SIGNATURES = {
     "glass_embed_norm_bwd_f32": (c_int, [_P, _P, _I, _P, _P, _P, _P, _P, c_int, _P, _P, _P, c_int, _I, _P]),
     "glass_dual_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, _I, _P,
                                             c_int, _P, _P]),
-    "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _I, _P, _P]),
+    "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "glass_dual_linear_dgrad_layout": (c_int, [_I, _I]),
     "glass_head_loss_fwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _I, _I, _I, _P, _P, _P, _P]),
     "glass_head_loss_bwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _P, _I, _I, _I, _P, _I, _P, _P, c_int, _P]),
     "glass_adam_step_f32": (c_int, [_P, _P, _P, _P, _I, _P, c_double, c_double, c_double, c_double, _P, _P]),

@@ -119,11 +119,15 @@ class ParamArena(FlatGradBucket):
                     # paired = 1, data-gradient operand plain = 2, or split = 3 for the 128-wide output of hidden 128's
                     # trans pair: both halves of the product side by side in one 256-slot tile)
                     tiled = _lib.load().glass_dual_linear_layout(O // 2) == 1
-                    Wimg, WTimg = torch.empty_like(W).reshape(-1), torch.empty_like(W).reshape(-1)
-                    self._packs.append((W, Wimg, O, K, 0 | ((1 << 1) if tiled else 0)))
-                    # data-gradient operand: NT = K output columns in 256-column tiles
-                    plain = 2 if K % 256 == 0 else 3
-                    self._packs.append((W, WTimg, K, O, 1 | ((plain << 1) if tiled else 0)))
+                    # data-gradient operand (NT = K output columns): the library names its layout; layout 4 (comb pair
+                    # at hidden 256 / 512) appends the effective weight of unlabeled rows -> 1.5 x the floats, and needs
+                    # the pair's z_ratio
+                    dlay = int(_lib.load().glass_dual_linear_dgrad_layout(O // 2, K))
+                    Wimg = torch.empty_like(W).reshape(-1)
+                    WTimg = torch.empty(W.numel() * 3 // 2 if dlay == 4 else W.numel(), dtype=W.dtype, device=W.device)
+                    zr = float(getattr(mod, "z_ratio", 0.0))
+                    self._packs.append((W, Wimg, O, K, 0 | ((1 << 1) if tiled else 0), zr))
+                    self._packs.append((W, WTimg, K, O, 1 | (dlay << 1), zr))
                     mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)
                 else:
                     mod._stack[kind] = (W, b, dW, db)
@@ -132,7 +136,8 @@ class ParamArena(FlatGradBucket):
                            np.array([p[1].data_ptr() for p in self._packs], dtype=np.uint64),
                            np.array([p[2] for p in self._packs], dtype=np.int64),
                            np.array([p[3] for p in self._packs], dtype=np.int64),
-                           np.array([p[4] for p in self._packs], dtype=np.int32), len(self._packs))
+                           np.array([p[4] for p in self._packs], dtype=np.int32),
+                           np.array([p[5] for p in self._packs], dtype=np.float32), len(self._packs))
         from .models import EmbZGConv
         for mod in model.modules():
             if isinstance(mod, EmbZGConv):
@@ -143,14 +148,14 @@ class ParamArena(FlatGradBucket):
         """Re-pack every stacked weight into the operand images of the fused dense kernels (forward: W,
         data gradient: W^T): one launch for the whole model.  rng_state (the device-resident dropout counter,
         ops.rng_state): advanced by the same launch — the two once-per-step prologue jobs share it."""
-        src, dst, nt, kt, tr, k = self._pack_args
+        src, dst, nt, kt, tr, zr, k = self._pack_args
         from . import _lib, ops
         if k == 0 and rng_state is not None:
             ops.rng_advance(rng_state.device)
         for i in range(0, k, 16):
             n = min(16, k - i)
             rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
-                                                        kt[i:].ctypes.data, tr[i:].ctypes.data, n,
+                                                        kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, n,
                                                         rng_state.data_ptr() if (rng_state is not None and i == 0) else 0,
                                                         torch.cuda.current_stream().cuda_stream)
             _lib.check(rc, "glass_dense_pack_batch_f32")

@@ -540,6 +540,7 @@ struct PackJob {
     const float* src;
     float* dst;
     int NT, KT, transposed, layout;
+    float zr;  // kLayoutTiledPlainEff: the pair's z_ratio
 };
 constexpr int kMaxPackJobs = 16;
 struct PackBatch {
@@ -579,10 +580,24 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
     }
     // tiled layouts (dense_tiled.hip): dst[((ct * NKS + ks) * 4 + q) * 256 + nl] (float4) = B[tiled_col(ct, nl)][16 ks + 4 q ..+3]
     const int NKS = j.KT / 16, H = j.NT / 2;  // H only meaningful for the paired layout (NT = 2H)
+    const int lay = j.layout == kLayoutTiledPlainEff ? kLayoutTiledPlain : j.layout;
     for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
         const int nl = l & 255, q = (l >> 8) & 3, tile = l >> 10;
         const int ct = tile / NKS, ks = tile % NKS;
-        reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tiled_col(j.layout, ct, nl, H), 16 * ks + 4 * q);
+        reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tiled_col(lay, ct, nl, H), 16 * ks + 4 * q);
+    }
+    if (j.layout != kLayoutTiledPlainEff) return;
+    // appendix: B_unl[n][k] = (1 - z) * B[n][k] + z * B[n][KT/2 + k], k < KT/2 (k <-> the f1 / f0 halves of the stacked
+    // output index: an unlabeled row weighs f1 with 1 - z and f0 with z), same plain tiling over K' = KT / 2
+    const int NKS2 = NKS / 2;
+    float4* app = reinterpret_cast<float4*>(j.dst) + total;
+    const float zr = j.zr, omz = 1.f - j.zr;
+    for (int l = blockIdx.x * kBlock + threadIdx.x; l < total / 2; l += gridDim.x * kBlock) {
+        const int nl = l & 255, q = (l >> 8) & 3, tile = l >> 10;
+        const int ct = tile / NKS2, ks = tile % NKS2;
+        const int n = tiled_col(kLayoutTiledPlain, ct, nl, H), k = 16 * ks + 4 * q;
+        const float4 a = pack_fetch(j, n, k), b = pack_fetch(j, n, j.KT / 2 + k);
+        app[l] = make_float4(omz * a.x + zr * b.x, omz * a.y + zr * b.y, omz * a.z + zr * b.z, omz * a.w + zr * b.w);
     }
 }
 
@@ -618,6 +633,15 @@ extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H)
 // Operand-image layout glass_dense_pack_batch_f32 must produce for hidden size H: 0 = wave16 images (forward and data
 // gradient alike), 1 = tiled (forward operand: paired layout; data-gradient operand: plain layout)
 extern "C" int glass_dual_linear_layout(int64_t H) { return tiled_here(H) ? 1 : 0; }
+
+// Layout code (flags >> 1 of glass_dense_pack_batch_f32) of the DATA-GRADIENT operand image glass_dual_linear_dgrad_f32 /
+// _bwd_f32 read for (H, n_out): 0 wave16, 2 plain, 3 split (hidden 128, 128-wide output), 4 plain + effective-weight
+// appendix (comb pair at hidden 256 / 512: the image holds 1.5 x the weight's floats).
+extern "C" int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out) {
+    if (!tiled_here(H)) return kLayoutWave16;
+    if (tiled_eff_shape(H, n_out)) return kLayoutTiledPlainEff;
+    return n_out % 256 == 0 ? kLayoutTiledPlain : kLayoutTiledSplit;
+}
 
 // rows per workgroup = rows per epilogue statistics partial
 extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return tiled_here(H) ? tiled_rows(H) : 64; }
@@ -778,23 +802,24 @@ extern "C" int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const f
 }
 
 extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,
-                                          const int64_t* KT, const int32_t* transposed, int64_t n_jobs,
-                                          uint64_t* rng_state, void* stream) {
+                                          const int64_t* KT, const int32_t* transposed, const float* z_ratio,
+                                          int64_t n_jobs, uint64_t* rng_state, void* stream) {
     GLASS_REQUIRE(src && dst && NT && KT && transposed && n_jobs >= 0 && n_jobs <= kMaxPackJobs,
                   "dense_pack_batch: bad arguments (at most %d matrices per call)", kMaxPackJobs);
     if (n_jobs == 0) return rng_state ? glass_rng_advance(rng_state, stream) : 0;
     PackBatch b;
-    for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0, 0};
+    for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0, 0, 0.f};
     for (int k = 0; k < n_jobs; ++k) {
         GLASS_REQUIRE(src[k] && dst[k] && NT[k] > 0 && NT[k] % 64 == 0 && KT[k] > 0 && KT[k] % 64 == 0 && aligned16(src[k]) &&
                           aligned16(dst[k]),
                       "dense_pack_batch: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", k);
         const int layout = transposed[k] >> 1;
         GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
-                          (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)),
+                          (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
+                          (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio),
                       "dense_pack_batch: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
                       "layout that is not the transposed 128 x 256 operand", k, layout);
-        b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout};
+        b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f};
     }
     hipLaunchKernelGGL(pack_batch_kernel, dim3(32, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream, b,
                        rng_state);

@@ -19,6 +19,8 @@
 // halves inside a wave, both kernels give a lane consecutive columns -> wide stores.
 #include "dense_common.h"
 
+#include <type_traits>
+
 namespace glass {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -42,6 +44,7 @@ struct Tile {
 };
 
 bool tiled_shape_ok(int64_t H) { return H == 128 || H == 256 || H == 512; }
+bool tiled_eff_shape(int64_t H, int64_t n_out) { return (H == 256 || H == 512) && n_out == 2 * H; }
 int tiled_rows(int64_t H) { return H == 128 ? 64 : 128; }
 
 __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
@@ -248,7 +251,11 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
 // pair of waves multiplies the f1 half (its own A image) into column slots 0..127, the right pair the f0 half into slots
 // 128..255, K is H instead of 2H, and the right pair hands its accumulators to the left through LDS before the epilogue.
 // Operand image: layout kLayoutTiledSplit (slot s < 128: Wstack[k][s], else Wstack[H + k][s - 128]).
-template <int H, int NOUT, int BM, int BN, bool SPLIT>
+// EFF (comb pair, hidden 256 / 512): the operand image carries an appendix, the effective weight of UNLABELED rows
+// (1-z) W1 + z W0 over K = H (kLayoutTiledPlainEff).  dZ has no activation factor for the comb pair, so a row tile without
+// a labeled row is dc @ W_unl — half the K loop; tiles that hold a labeled row take the two-term product as before.  With
+// B*Smax labeled nodes among N (config 5: 2 048 of 1 M) most 128-row tiles qualify.
+template <int H, int NOUT, int BM, int BN, bool SPLIT, bool EFF>
 __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                   const float* __restrict__ T, int64_t ldt,
                                                                   const uint8_t* __restrict__ mask, float zr, float omz,
@@ -279,7 +286,15 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
         sok[i] = row0 + srow[i] < N;
         slab[i] = sok[i] && mask[row0 + srow[i]] != 0;
     }
-    const float4* wimg = reinterpret_cast<const float4*>(WTimg) + (int64_t)ct * NKS * TL::kBImg;
+    bool pure = false;  // workgroup-uniform: no labeled row in this tile -> single-term product with the appendix image
+    if (EFF) {
+        bool any = false;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) any = any || slab[i];
+        pure = act == GLASS_ACT_NONE && __syncthreads_or(any ? 1 : 0) == 0;
+    }
+    const float4* wimg = reinterpret_cast<const float4*>(WTimg) +
+                         (pure ? (int64_t)NCT * NKS * TL::kBImg + (int64_t)ct * (NKS / 2) * TL::kBImg : (int64_t)ct * NKS * TL::kBImg);
     float4 dv[AP], tv[AP], tw[SPLIT ? AP : 1];
     BStage<TL::kBPer> bs;
     auto issue = [&](int ks) __attribute__((always_inline)) {
@@ -299,7 +314,7 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const int o = ks * kTK + 4 * skq[i];
-            const float coef = sok[i] ? ((slab[i] == (o < H)) ? zr : omz) : 0.f;
+            const float coef = sok[i] ? (pure ? 1.f : ((slab[i] == (o < H)) ? zr : omz)) : 0.f;
             float4 v = make_float4(dv[i].x * coef, dv[i].y * coef, dv[i].z * coef, dv[i].w * coef);
             if (act == GLASS_ACT_ELU) {
                 v.x *= elu_grad_f(tv[i].x); v.y *= elu_grad_f(tv[i].y); v.z *= elu_grad_f(tv[i].z); v.w *= elu_grad_f(tv[i].w);
@@ -325,17 +340,23 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 
-    issue(0);
-    commit(0, smem);
-    __syncthreads();
-    for (int ks = 0; ks < NKS; ++ks) {
-        float4* cur = smem + (ks & 1) * kStage;
-        float4* nxt = smem + ((ks + 1) & 1) * kStage;
-        if (ks + 1 < NKS) issue(ks + 1);
-        tile_mma<BM, BN>(acc, cur + (SPLIT ? wn * TL::kAImg : 0), cur + NA * TL::kAImg, j, h, wm, wn);
-        if (ks + 1 < NKS) commit(ks + 1, nxt);
+    // the K loop with a compile-time trip count (a run-time bound sent the staging registers to scratch memory)
+    auto k_loop = [&](auto n_c) __attribute__((always_inline)) {
+        constexpr int n = decltype(n_c)::value;
+        issue(0);
+        commit(0, smem);
         __syncthreads();
-    }
+        for (int ks = 0; ks < n; ++ks) {
+            float4* cur = smem + (ks & 1) * kStage;
+            float4* nxt = smem + ((ks + 1) & 1) * kStage;
+            if (ks + 1 < n) issue(ks + 1);
+            tile_mma<BM, BN>(acc, cur + (SPLIT ? wn * TL::kAImg : 0), cur + NA * TL::kAImg, j, h, wm, wn);
+            if (ks + 1 < n) commit(ks + 1, nxt);
+            __syncthreads();
+        }
+    };
+    if (EFF && pure) k_loop(std::integral_constant<int, NKS / 2>{});
+    else k_loop(std::integral_constant<int, NKS>{});
     if (SPLIT) {  // right wave column -> left wave column (same row block, same lane <-> same rows and column slots)
         float* xf = reinterpret_cast<float*>(smem);
         if (wn == 1) {
@@ -483,15 +504,16 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
     {                                                                                                                \
         const int64_t n_rt = ceil_div(N, BM);                                                                        \
         const size_t lds = Tile<BM, BN>::kLds;                                                                       \
-        allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, false>, lds);                                           \
-        hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, false>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
+        constexpr bool kEff = NOUT == 2 * HH && HH >= 256; /* tiled_eff_shape */                                     \
+        allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>, lds);                                     \
+        hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
                            st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, \
                            gs, (int)n_rt);                                                                           \
     }
     if (H == 128 && n_out == H) {  // trans pair: the two terms of the product side by side in one 256-slot tile
         const int64_t n_rt = ceil_div(N, 64);
         const size_t lds = 2 * (size_t)(2 * Tile<64, 256>::kAImg + Tile<64, 256>::kBImg) * sizeof(float4);
-        hipLaunchKernelGGL((tiled_dgrad_kernel<128, 128, 64, 256, true>), dim3(tiled_grid(n_rt, 1)), dim3(kTThreads), lds, st,
+        hipLaunchKernelGGL((tiled_dgrad_kernel<128, 128, 64, 256, true, false>), dim3(tiled_grid(n_rt, 1)), dim3(kTThreads), lds, st,
                            dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, gs,
                            (int)n_rt);
     } else if (H == 128) {

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLASS_ABI_VERSION 1
+#define GLASS_ABI_VERSION 2
 
 #define GLASS_E_ARG (-1)       /* bad argument (null pointer, negative size, misaligned ld) */
 #define GLASS_E_PLAN (-2)      /* plan blob does not match the call (magic / sizes) */
@@ -243,6 +243,8 @@ int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
  * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */
 int glass_dual_linear_layout(int64_t H);
+/* layout code of the data-gradient operand image for (H, n_out): 0, 2, 3 or 4 (see glass_dense_pack_batch_f32) */
+int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out);
 /* rows covered by one workgroup of the fused kernels at hidden H = rows per `stats` / `gn_partial` entry */
 int64_t glass_dual_linear_stat_rows(int64_t H);
 /*   fwd, stats != NULL: the epilogue also writes the column statistics of `out` for the GraphNorm that consumes
@@ -295,12 +297,17 @@ int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, c
                                         const int32_t* accumulate, void* stream);
 /*     Pack up to 16 weight operands B[NT][KT] (NT, KT multiples of 64) into MFMA image order in one launch.
  *     flags[k] bit 0 = transposed: 0: B = src[k] ([NT][KT] row-major); 1: B[n][k] = src[k][k][n] (src is [KT][NT]).
- *     flags[k] >> 1 = layout: 0 wave16, 1 tiled paired (NT = 2H), 2 tiled plain (tiled: NT a multiple of 256).
- *     dst[k] holds NT*KT floats.  The pointer / size arrays are HOST arrays. */
+ *     flags[k] >> 1 = layout: 0 wave16, 1 tiled paired (NT = 2H), 2 tiled plain (tiled: NT a multiple of 256), 3 tiled
+ *     split (the transposed 128 x 256 operand), 4 tiled plain followed by the effective weight of unlabeled rows
+ *     (1 - z_ratio[k]) * B[:, :KT/2] + z_ratio[k] * B[:, KT/2:] in the same tiling over K = KT/2 (dst[k] then holds
+ *     1.5 * NT*KT floats; transposed operands only) — glass_dual_linear_dgrad_layout(H, n_out) names the layout the
+ *     data-gradient kernels read.  z_ratio (may be NULL when no job has layout 4): per-job label mix of the pair.
+ *     dst[k] holds NT*KT floats otherwise.  The pointer / size arrays are HOST arrays. */
 /*     rng_state (may be NULL): the same launch also advances the dropout stream, rng_state[1] += 1 (both are
  *     once-per-step prologue work; equivalent to a following glass_rng_advance). */
 int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
-                               const int32_t* flags, int64_t n_jobs, uint64_t* rng_state, void* stream);
+                               const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
+                               void* stream);
 
 /* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
  *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened

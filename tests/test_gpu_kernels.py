@@ -398,10 +398,10 @@ def test_pack_launch_advances_dropout_stream():
     nts, kts, trs = np.array([128], dtype=np.int64), np.array([64], dtype=np.int64), np.array([0], dtype=np.int32)
     for expect in (1, 2):
         rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
-                                                    trs.ctypes.data, 1, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                                    trs.ctypes.data, 0, 1, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0 and st.tolist() == [77, expect]
     assert torch.equal(img, _pack(W, False))
-    rc = _lib.load().glass_dense_pack_batch_f32(0, 0, 0, 0, 0, 0, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rc = _lib.load().glass_dense_pack_batch_f32(0, 0, 0, 0, 0, 0, 0, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc != 0  # null arrays are rejected even for zero jobs
 
 
@@ -509,7 +509,7 @@ def _pack(W, transposed, H=64):
     layout = ((2 if nt % 256 == 0 else 3) if transposed else 1) if _lib.load().glass_dual_linear_layout(H) == 1 else 0
     trs = np.array([int(transposed) | (layout << 1)], dtype=np.int32)
     rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
-                                                trs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
+                                                trs.ctypes.data, 0, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     return img
 
@@ -560,6 +560,35 @@ def test_dense_pack_tiled_layouts():
                     n = ct * 256 + wn * 128 + 4 * j + cb
                 off = ((((ct * NKS + ks) * 4 + q) * 256) + nl) * 4
                 assert img[off:off + 4].tolist() == B[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4].tolist()
+
+
+def test_dense_pack_effective_weight_appendix():
+    """Layout 4 (comb pair's data-gradient operand at hidden 256 / 512): the plain image, then the effective weight of
+    unlabeled rows (1 - z) * B[:, :KT/2] + z * B[:, KT/2:] in the same tiling over K = KT / 2."""
+    from glass_amd import _lib
+    H, z = 256, 0.9
+    assert _lib.load().glass_dual_linear_dgrad_layout(H, 2 * H) == 4 and _lib.load().glass_dual_linear_dgrad_layout(H, H) == 2
+    assert _lib.load().glass_dual_linear_dgrad_layout(128, 128) == 3 and _lib.load().glass_dual_linear_dgrad_layout(64, 64) == 0
+    gen = torch.Generator().manual_seed(3)
+    W = torch.randn(2 * H, 2 * H, generator=gen).to(DEV)  # comb weight [2H out][2H in]; operand B = W^T: [NT = 2H in][KT = 2H out]
+    img = torch.empty(W.numel() * 3 // 2, device=DEV)
+    src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
+    nts, kts = np.array([2 * H], dtype=np.int64), np.array([2 * H], dtype=np.int64)
+    trs, zs = np.array([1 | (4 << 1)], dtype=np.int32), np.array([z], dtype=np.float32)
+    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+                                                trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(img[:W.numel()], _pack(W, True, H))  # the plain part is layout 2
+    B = W.t().cpu()
+    Beff = ((1 - np.float32(z)) * B[:, :H] + np.float32(z) * B[:, H:])
+    app = img[W.numel():].cpu()
+    NT, K2 = 2 * H, H
+    NKS = K2 // 16
+    for (ct, ks, q, nl) in ((0, 0, 0, 0), (NT // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (1, 5, 1, 200)):
+        wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
+        n = ct * 256 + wn * 128 + 4 * j + cb
+        off = ((((ct * NKS + ks) * 4 + q) * 256) + nl) * 4
+        assert torch.allclose(app[off:off + 4], Beff[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4], rtol=0, atol=1e-6)
 
 
 # ---------------------------------------------------------------------------------- K8 head + loss
