@@ -82,6 +82,7 @@ SIGNATURES = {
                                             c_int, _P, _P]),
     "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "glass_dual_linear_dgrad_layout": (c_int, [_I, _I]),
+    "glass_dual_linear_fwd_layout": (c_int, [_I, _I]),
     "glass_head_loss_fwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _I, _I, _I, _P, _P, _P, _P]),
     "glass_head_loss_bwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _P, _I, _I, _I, _P, _I, _P, _P, c_int, _P]),
     "glass_adam_step_f32": (c_int, [_P, _P, _P, _P, _I, _P, c_double, c_double, c_double, c_double, _P, _P]),

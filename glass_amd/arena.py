@@ -123,10 +123,11 @@ class ParamArena(FlatGradBucket):
                     # at hidden 256 / 512) appends the effective weight of unlabeled rows -> 1.5 x the floats, and needs
                     # the pair's z_ratio
                     dlay = int(_lib.load().glass_dual_linear_dgrad_layout(O // 2, K))
-                    Wimg = torch.empty_like(W).reshape(-1)
+                    flay = int(_lib.load().glass_dual_linear_fwd_layout(O // 2, K))  # 5: same appendix for the forward
+                    Wimg = torch.empty(W.numel() * 3 // 2 if flay == 5 else W.numel(), dtype=W.dtype, device=W.device)
                     WTimg = torch.empty(W.numel() * 3 // 2 if dlay == 4 else W.numel(), dtype=W.dtype, device=W.device)
                     zr = float(getattr(mod, "z_ratio", 0.0))
-                    self._packs.append((W, Wimg, O, K, 0 | ((1 << 1) if tiled else 0), zr))
+                    self._packs.append((W, Wimg, O, K, 0 | (flay << 1), zr))
                     self._packs.append((W, WTimg, K, O, 1 | (dlay << 1), zr))
                     mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)
                 else:

@@ -580,11 +580,25 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
     }
     // tiled layouts (dense_tiled.hip): dst[((ct * NKS + ks) * 4 + q) * 256 + nl] (float4) = B[tiled_col(ct, nl)][16 ks + 4 q ..+3]
     const int NKS = j.KT / 16, H = j.NT / 2;  // H only meaningful for the paired layout (NT = 2H)
-    const int lay = j.layout == kLayoutTiledPlainEff ? kLayoutTiledPlain : j.layout;
+    const int lay = j.layout == kLayoutTiledPlainEff ? kLayoutTiledPlain : j.layout == kLayoutTiledPairedEff ? kLayoutTiledPaired : j.layout;
     for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
         const int nl = l & 255, q = (l >> 8) & 3, tile = l >> 10;
         const int ct = tile / NKS, ks = tile % NKS;
         reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tiled_col(lay, ct, nl, H), 16 * ks + 4 * q);
+    }
+    if (j.layout == kLayoutTiledPairedEff) {
+        // appendix of the forward operand: W_unl[n][k] = (1 - z) * B[n][k] + z * B[NT/2 + n][k], n < NT/2 (an unlabeled
+        // row weighs the f1 half with 1 - z and the f0 half with z), plain tiling: 256 output columns per column tile
+        float4* app = reinterpret_cast<float4*>(j.dst) + total;
+        const float zr = j.zr, omz = 1.f - j.zr;
+        for (int l = blockIdx.x * kBlock + threadIdx.x; l < total / 2; l += gridDim.x * kBlock) {
+            const int nl = l & 255, q = (l >> 8) & 3, tile = l >> 10;
+            const int ct = tile / NKS, ks = tile % NKS;
+            const int n = tiled_col(kLayoutTiledPlain, ct, nl, H), k = 16 * ks + 4 * q;
+            const float4 a = pack_fetch(j, n, k), b = pack_fetch(j, H + n, k);
+            app[l] = make_float4(omz * a.x + zr * b.x, omz * a.y + zr * b.y, omz * a.z + zr * b.z, omz * a.w + zr * b.w);
+        }
+        return;
     }
     if (j.layout != kLayoutTiledPlainEff) return;
     // appendix: B_unl[n][k] = (1 - z) * B[n][k] + z * B[n][KT/2 + k], k < KT/2 (k <-> the f1 / f0 halves of the stacked
@@ -637,6 +651,12 @@ extern "C" int glass_dual_linear_layout(int64_t H) { return tiled_here(H) ? 1 : 
 // Layout code (flags >> 1 of glass_dense_pack_batch_f32) of the DATA-GRADIENT operand image glass_dual_linear_dgrad_f32 /
 // _bwd_f32 read for (H, n_out): 0 wave16, 2 plain, 3 split (hidden 128, 128-wide output), 4 plain + effective-weight
 // appendix (comb pair at hidden 256 / 512: the image holds 1.5 x the weight's floats).
+// ... and of the FORWARD operand image for (H, K = input width): 0 wave16, 1 paired, 5 paired + effective-weight appendix
+// (comb pair, K = 2H, at hidden 256 / 512: 1.5 x the weight's floats)
+extern "C" int glass_dual_linear_fwd_layout(int64_t H, int64_t K) {
+    if (!tiled_here(H)) return kLayoutWave16;
+    return tiled_eff_shape(H, K) ? kLayoutTiledPairedEff : kLayoutTiledPaired;
+}
 extern "C" int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out) {
     if (!tiled_here(H)) return kLayoutWave16;
     if (tiled_eff_shape(H, n_out)) return kLayoutTiledPlainEff;
@@ -816,7 +836,8 @@ extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const*
         const int layout = transposed[k] >> 1;
         GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
                           (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
-                          (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio),
+                          (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio) ||
+                          (layout == kLayoutTiledPairedEff && NT[k] % 512 == 0 && !(transposed[k] & 1) && z_ratio),
                       "dense_pack_batch: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
                       "layout that is not the transposed 128 x 256 operand", k, layout);
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f};

@@ -32,7 +32,10 @@ struct GnBwdStats {
 };
 
 // Operand-image layouts written by glass_dense_pack_batch_f32 (bits 1.. of its per-job flags; bit 0 = transposed source)
-enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2, kLayoutTiledSplit = 3, kLayoutTiledPlainEff = 4 };
+enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2, kLayoutTiledSplit = 3, kLayoutTiledPlainEff = 4,
+       kLayoutTiledPairedEff = 5 };
+// kLayoutTiledPairedEff: the paired forward image of a comb pair followed by W_unl = (1-z)*W1 + z*W0 ([H][KT]) in the plain
+// tiling — row tiles without a labeled row produce 256 output columns per column tile from it
 // kLayoutTiledPlainEff: the plain data-gradient image of a comb pair followed by the image of its UNLABELED-row effective
 // weight (1-z)*W1 + z*W0 over K = KT / 2 — row tiles without a labeled row multiply that one instead (half the K loop)
 bool tiled_eff_shape(int64_t H, int64_t n_out);  // dense_tiled.hip: shapes whose data gradient reads a PlainEff image

@@ -99,7 +99,11 @@ struct BStage {
 };
 
 // ---- forward ----------------------------------------------------------------------------------------------------
-template <int H, bool COMB, int BM>
+// EFF (comb pair, hidden 256 / 512): the operand image carries an appendix, W_unl = (1-z) W1 + z W0 ([H][2H], plain
+// layout).  The comb pair has no activation before the mix, so a row tile WITHOUT a labeled row is one product
+// [g || x_] @ W_unl^T + b_unl over 256 output columns per column tile — half the column tiles of the two-weight form: the
+// blocks of the upper half of the column tiles leave at once.  Row tiles that hold a labeled row take the usual path.
+template <int H, bool COMB, int BM, bool EFF>
 __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                 const float* __restrict__ xb, int64_t ldb,
                                                                 const float* __restrict__ Wimg,
@@ -113,7 +117,16 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
     constexpr int KT = COMB ? 2 * H : H, NKS = KT / kTK, NCT = H / 128, RB = TL::RB, AP = TL::kAPer;
     extern __shared__ float4 smem[];
     int rt, ct;
-    if (!tile_of_block(NCT, n_rowtiles, rt, ct)) return;
+    if (EFF) {
+        // column tile major: the blocks of the upper column tiles — which leave at once for every row tile without a labeled
+        // row — sit at the END of the grid instead of alternating with working blocks in groups of 8
+        const int per = (int)(gridDim.x / NCT);
+        ct = (int)blockIdx.x / per;
+        rt = (int)blockIdx.x % per;
+        if (rt >= n_rowtiles) return;
+    } else if (!tile_of_block(NCT, n_rowtiles, rt, ct)) {
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
     const int64_t row0 = (int64_t)rt * BM;
@@ -132,8 +145,15 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
+    bool pure = false;  // workgroup-uniform: no labeled row in this row tile
+    if (EFF) {
+        const int64_t r = row0 + tid;
+        pure = __syncthreads_or((tid < BM && r < N && mask[r] != 0) ? 1 : 0) == 0 && act == GLASS_ACT_NONE && T == nullptr;
+        if (pure && ct >= NCT / 2) return;  // 256 output columns per block now: the lower half of the column tiles covers H
+    }
     const bool side_writer = pro.side != nullptr && ct == 0;  // every column tile computes the operand; one writes it
-    const float4* wimg = reinterpret_cast<const float4*>(Wimg) + (int64_t)ct * NKS * TL::kBImg;
+    const float4* wimg = reinterpret_cast<const float4*>(Wimg) +
+                         (pure ? (int64_t)(NCT + ct) * NKS * TL::kBImg : (int64_t)ct * NKS * TL::kBImg);
 
     float4 av[AP], asc[AP], ash[AP];
     BStage<TL::kBPer> bs;
@@ -195,6 +215,48 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
         __syncthreads();
     }
 
+    if (EFF && pure) {
+        // single-weight epilogue: plain layout — this lane's four consecutive columns col0 .. col0 + 3 (cb = 0..3)
+        const int col0 = ct * 256 + wn * 128 + 4 * j;
+        const float4 c1 = *reinterpret_cast<const float4*>(bias + col0), c0 = *reinterpret_cast<const float4*>(bias + H + col0);
+        const float be[4] = {omz * c1.x + zr * c0.x, omz * c1.y + zr * c0.y, omz * c1.z + zr * c0.z, omz * c1.w + zr * c0.w};
+        double ss[4] = {0.0, 0.0, 0.0, 0.0}, qq[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t r = row0 + wm * (BM / 2) + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                if (r < N) {
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        o[e] = acc[rb][e][i] + be[e];
+                        ss[e] += (double)o[e];
+                        qq[e] += (double)o[e] * (double)o[e];
+                    }
+                    *reinterpret_cast<float4*>(out + r * ldo + col0) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        if (stats == nullptr) return;
+        double* red = reinterpret_cast<double*>(smem);  // [wm][256 columns][2]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ss[e] += __shfl_xor(ss[e], 32);
+            qq[e] += __shfl_xor(qq[e], 32);
+        }
+        if (h == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = wn * 128 + 4 * j + e;
+                red[(wm * 256 + c) * 2] = ss[e];
+                red[(wm * 256 + c) * 2 + 1] = qq[e];
+            }
+        }
+        __syncthreads();
+        stats[((size_t)rt * 2) * H + ct * 256 + tid] = red[tid * 2] + red[(256 + tid) * 2];
+        stats[((size_t)rt * 2 + 1) * H + ct * 256 + tid] = red[tid * 2 + 1] + red[(256 + tid) * 2 + 1];
+        return;
+    }
     // epilogue: acc[rb][cb][i] = row rt*BM + wm*BM/2 + rb*32 + 8(i>>2) + 4h + (i&3); cb 0,1: f1 columns colp, colp+1;
     // cb 2,3: the same two columns of the f0 half
     const int colp = ct * 128 + wn * 64 + 2 * j;
@@ -482,12 +544,13 @@ int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb,
         const dim3 grid(tiled_grid(n_rt, HH / 128));                                                                 \
         const size_t lds = Tile<BM, 256>::kLds;                                                                      \
         if (comb) {                                                                                                  \
-            allow_tiled_lds(tiled_fwd_kernel<HH, true, BM>, lds);                                                    \
-            hipLaunchKernelGGL((tiled_fwd_kernel<HH, true, BM>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,   \
+            constexpr bool kEff = HH >= 256; /* tiled_eff_shape: the image has the effective-weight appendix */      \
+            allow_tiled_lds(tiled_fwd_kernel<HH, true, BM, kEff>, lds);                                              \
+            hipLaunchKernelGGL((tiled_fwd_kernel<HH, true, BM, kEff>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg, \
                                bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
         } else {                                                                                                     \
-            allow_tiled_lds(tiled_fwd_kernel<HH, false, BM>, lds);                                                   \
-            hipLaunchKernelGGL((tiled_fwd_kernel<HH, false, BM>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,  \
+            allow_tiled_lds(tiled_fwd_kernel<HH, false, BM, false>, lds);                                            \
+            hipLaunchKernelGGL((tiled_fwd_kernel<HH, false, BM, false>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg, \
                                bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
         }                                                                                                            \
     }

@@ -243,8 +243,10 @@ int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
  * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */
 int glass_dual_linear_layout(int64_t H);
-/* layout code of the data-gradient operand image for (H, n_out): 0, 2, 3 or 4 (see glass_dense_pack_batch_f32) */
+/* layout code of the data-gradient operand image for (H, n_out): 0, 2, 3 or 4, and of the forward operand image for
+ * (H, K = input width): 0, 1 or 5 (see glass_dense_pack_batch_f32) */
 int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out);
+int glass_dual_linear_fwd_layout(int64_t H, int64_t K);
 /* rows covered by one workgroup of the fused kernels at hidden H = rows per `stats` / `gn_partial` entry */
 int64_t glass_dual_linear_stat_rows(int64_t H);
 /*   fwd, stats != NULL: the epilogue also writes the column statistics of `out` for the GraphNorm that consumes
@@ -301,7 +303,9 @@ int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, c
  *     split (the transposed 128 x 256 operand), 4 tiled plain followed by the effective weight of unlabeled rows
  *     (1 - z_ratio[k]) * B[:, :KT/2] + z_ratio[k] * B[:, KT/2:] in the same tiling over K = KT/2 (dst[k] then holds
  *     1.5 * NT*KT floats; transposed operands only) — glass_dual_linear_dgrad_layout(H, n_out) names the layout the
- *     data-gradient kernels read.  z_ratio (may be NULL when no job has layout 4): per-job label mix of the pair.
+ *     data-gradient kernels read; 5 tiled paired followed by (1 - z) * B[:NT/2] + z * B[NT/2:] in the plain tiling
+ *     (forward operand of a comb pair, again 1.5 * NT*KT floats; glass_dual_linear_fwd_layout).  z_ratio (may be NULL
+ *     when no job has layout 4 / 5): per-job label mix of the pair.
  *     dst[k] holds NT*KT floats otherwise.  The pointer / size arrays are HOST arrays. */
 /*     rng_state (may be NULL): the same launch also advances the dropout stream, rng_state[1] += 1 (both are
  *     once-per-step prologue work; equivalent to a following glass_rng_advance). */

@@ -591,6 +591,34 @@ def test_dense_pack_effective_weight_appendix():
         assert torch.allclose(app[off:off + 4], Beff[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4], rtol=0, atol=1e-6)
 
 
+def test_dense_pack_forward_effective_weight_appendix():
+    """Layout 5 (comb pair's forward operand at hidden 256 / 512): the paired image, then W_unl = (1 - z) * W[:H] + z * W[H:]
+    ([H][2H]) in the plain tiling (256 output columns per column tile)."""
+    from glass_amd import _lib
+    H, z = 256, 0.85
+    assert _lib.load().glass_dual_linear_fwd_layout(H, 2 * H) == 5 and _lib.load().glass_dual_linear_fwd_layout(H, H) == 1
+    assert _lib.load().glass_dual_linear_fwd_layout(128, 256) == 1 and _lib.load().glass_dual_linear_fwd_layout(64, 128) == 0
+    gen = torch.Generator().manual_seed(4)
+    W = torch.randn(2 * H, 2 * H, generator=gen).to(DEV)  # comb weight [2H out][2H in] = the operand B itself
+    img = torch.empty(W.numel() * 3 // 2, device=DEV)
+    src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
+    nts, kts = np.array([2 * H], dtype=np.int64), np.array([2 * H], dtype=np.int64)
+    trs, zs = np.array([0 | (5 << 1)], dtype=np.int32), np.array([z], dtype=np.float32)
+    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+                                                trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert torch.equal(img[:W.numel()], _pack(W, False, H))  # the first part is the paired layout
+    Wc = W.cpu()
+    Weff = (1 - np.float32(z)) * Wc[:H] + np.float32(z) * Wc[H:]
+    app = img[W.numel():].cpu()
+    NKS = 2 * H // 16
+    for (ct, ks, q, nl) in ((0, 0, 0, 0), (H // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (0, 17, 1, 200)):
+        wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
+        n = ct * 256 + wn * 128 + 4 * j + cb
+        off = ((((ct * NKS + ks) * 4 + q) * 256) + nl) * 4
+        assert torch.allclose(app[off:off + 4], Weff[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4], rtol=0, atol=1e-6)
+
+
 # ---------------------------------------------------------------------------------- K8 head + loss
 @pytest.mark.parametrize("mode,B,C,K", [(0, 80, 128, 6), (0, 7, 17, 3), (1, 99, 128, 10), (1, 5, 64, 1)])
 def test_head_loss_fused(mode, B, C, K):

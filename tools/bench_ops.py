@@ -65,7 +65,9 @@ def bench_dual(shapes=((17080, 64), (50000, 128), (1000000, 256))):
         model = build_glass(H, 1, 5, 3, "mean", "sum", 0.9).to(DEV).train()
         ParamArena(model)
         conv = model.conv.convs[0]
-        mask = (torch.rand(N, device=DEV) < 0.05).to(torch.uint8)
+        # labeled fraction: 5 % by default (every 128-row tile holds a labeled row: the two-weight path of the comb kernels);
+        # GLASS_LAB_LABELED=0.002 is config 5's density (most tiles take the effective-weight path)
+        mask = (torch.rand(N, device=DEV) < float(os.environ.get("GLASS_LAB_LABELED", "0.05"))).to(torch.uint8)
         f32 = dict(dtype=torch.float32, device=DEV)
         h, a = torch.randn(N, H, **f32), torch.randn(N, H, **f32)
         T, m, c = torch.empty(N, 2 * H, **f32), torch.empty(N, H, **f32), torch.empty(N, H, **f32)
