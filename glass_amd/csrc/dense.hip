@@ -650,16 +650,16 @@ extern "C" int glass_dual_linear_layout(int64_t H) { return tiled_here(H) ? 1 : 
 
 // Layout code (flags >> 1 of glass_dense_pack_batch_f32) of the DATA-GRADIENT operand image glass_dual_linear_dgrad_f32 /
 // _bwd_f32 read for (H, n_out): 0 wave16, 2 plain, 3 split (hidden 128, 128-wide output), 4 plain + effective-weight
-// appendix (comb pair at hidden 256 / 512: the image holds 1.5 x the weight's floats).
+// appendix (comb pair: the image holds 1.5 x the weight's floats).
 // ... and of the FORWARD operand image for (H, K = input width): 0 wave16, 1 paired, 5 paired + effective-weight appendix
 // (comb pair, K = 2H, at hidden 256 / 512: 1.5 x the weight's floats)
 extern "C" int glass_dual_linear_fwd_layout(int64_t H, int64_t K) {
     if (!tiled_here(H)) return kLayoutWave16;
-    return tiled_eff_shape(H, K) ? kLayoutTiledPairedEff : kLayoutTiledPaired;
+    return tiled_eff_fwd_shape(H, K) ? kLayoutTiledPairedEff : kLayoutTiledPaired;
 }
 extern "C" int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out) {
     if (!tiled_here(H)) return kLayoutWave16;
-    if (tiled_eff_shape(H, n_out)) return kLayoutTiledPlainEff;
+    if (tiled_eff_dgrad_shape(H, n_out)) return kLayoutTiledPlainEff;
     return n_out % 256 == 0 ? kLayoutTiledPlain : kLayoutTiledSplit;
 }
 

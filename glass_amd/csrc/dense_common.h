@@ -38,7 +38,8 @@ enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2, kLayout
 // tiling — row tiles without a labeled row produce 256 output columns per column tile from it
 // kLayoutTiledPlainEff: the plain data-gradient image of a comb pair followed by the image of its UNLABELED-row effective
 // weight (1-z)*W1 + z*W0 over K = KT / 2 — row tiles without a labeled row multiply that one instead (half the K loop)
-bool tiled_eff_shape(int64_t H, int64_t n_out);  // dense_tiled.hip: shapes whose data gradient reads a PlainEff image
+bool tiled_eff_dgrad_shape(int64_t H, int64_t n_out);  // dense_tiled.hip: shapes whose data gradient reads a PlainEff image
+bool tiled_eff_fwd_shape(int64_t H, int64_t K);        // ... whose forward reads a PairedEff image
 
 // dense_tiled.hip
 bool tiled_shape_ok(int64_t H);

@@ -44,7 +44,10 @@ struct Tile {
 };
 
 bool tiled_shape_ok(int64_t H) { return H == 128 || H == 256 || H == 512; }
-bool tiled_eff_shape(int64_t H, int64_t n_out) { return (H == 256 || H == 512) && n_out == 2 * H; }
+// shapes whose operand images carry the effective-weight appendix: the comb pair's data gradient at every tiled size, its
+// forward where halving the column tiles is possible (hidden 128 has a single one)
+bool tiled_eff_dgrad_shape(int64_t H, int64_t n_out) { return tiled_shape_ok(H) && n_out == 2 * H; }
+bool tiled_eff_fwd_shape(int64_t H, int64_t K) { return (H == 256 || H == 512) && K == 2 * H; }
 int tiled_rows(int64_t H) { return H == 128 ? 64 : 128; }
 
 __device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
@@ -313,7 +316,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
 // pair of waves multiplies the f1 half (its own A image) into column slots 0..127, the right pair the f0 half into slots
 // 128..255, K is H instead of 2H, and the right pair hands its accumulators to the left through LDS before the epilogue.
 // Operand image: layout kLayoutTiledSplit (slot s < 128: Wstack[k][s], else Wstack[H + k][s - 128]).
-// EFF (comb pair, hidden 256 / 512): the operand image carries an appendix, the effective weight of UNLABELED rows
+// EFF (comb pair): the operand image carries an appendix, the effective weight of UNLABELED rows
 // (1-z) W1 + z W0 over K = H (kLayoutTiledPlainEff).  dZ has no activation factor for the comb pair, so a row tile without
 // a labeled row is dc @ W_unl — half the K loop; tiles that hold a labeled row take the two-term product as before.  With
 // B*Smax labeled nodes among N (config 5: 2 048 of 1 M) most 128-row tiles qualify.
@@ -544,7 +547,7 @@ int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb,
         const dim3 grid(tiled_grid(n_rt, HH / 128));                                                                 \
         const size_t lds = Tile<BM, 256>::kLds;                                                                      \
         if (comb) {                                                                                                  \
-            constexpr bool kEff = HH >= 256; /* tiled_eff_shape: the image has the effective-weight appendix */      \
+            constexpr bool kEff = HH >= 256; /* tiled_eff_fwd_shape: the image has the effective-weight appendix */  \
             allow_tiled_lds(tiled_fwd_kernel<HH, true, BM, kEff>, lds);                                              \
             hipLaunchKernelGGL((tiled_fwd_kernel<HH, true, BM, kEff>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg, \
                                bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
@@ -567,7 +570,7 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
     {                                                                                                                \
         const int64_t n_rt = ceil_div(N, BM);                                                                        \
         const size_t lds = Tile<BM, BN>::kLds;                                                                       \
-        constexpr bool kEff = NOUT == 2 * HH && HH >= 256; /* tiled_eff_shape */                                     \
+        constexpr bool kEff = NOUT == 2 * HH; /* tiled_eff_dgrad_shape */                                            \
         allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>, lds);                                     \
         hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
                            st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, \

@@ -20,6 +20,10 @@ namespace glass {
 constexpr int kWO = 128, kWI = 256, kWK = 16, kWThreads = 256;
 constexpr int kWStage = kWK * (kWO + kWI);  // floats per stage: 6 144 = 24 KiB
 constexpr int kWTile = kWO * kWI;
+// Mode header the partial kernel leaves behind the bias partials for the reduce kernel (which is launched later, by
+// glass_linear_wgrad_reduce_batch_f32, from (N, O, I) alone): [0] = 1.0f when the partials are in effective-weight form,
+// [1] = z_ratio.
+constexpr int kWHeaderFloats = 4;
 
 bool wgrad_tiled_shape(int64_t N, int64_t O, int64_t I) { return O >= 512 && O % kWO == 0 && I % kWI == 0 && N >= 65536; }
 
@@ -29,12 +33,13 @@ TiledWgradGeom wgrad_tiled_geom(int64_t N, int64_t O, int64_t I) {
     g.nz = (int)(O / kWO);
     // about two resident workgroups per CU over all (slab, tile) pairs, slabs of whole 16-row stages, at most 256 slabs
     int64_t slabs = ceil_div(512, (int64_t)g.ny * g.nz);
+    if (I == O) slabs *= 2;  // comb-shaped: in the effective-weight mode half of the output tiles hold labeled rows only
     if (slabs > 256) slabs = 256;
     int64_t rows = ceil_div(ceil_div(N, slabs), kWK) * kWK;
     g.rows_per_slab = (int)rows;
     g.n_slabs = (int)ceil_div(N, rows);
     g.part_w_floats = (int64_t)g.n_slabs * g.ny * g.nz * kWTile;
-    g.part_b_floats = (int64_t)g.n_slabs * g.nz * kWO;
+    g.part_b_floats = (int64_t)g.n_slabs * g.nz * kWO + kWHeaderFloats;  // + the mode header behind the bias partials
     return g;
 }
 
@@ -45,6 +50,7 @@ struct StageCtx {
     int a_col; bool a_first;
     int64_t r0, r1;
     int tid;
+    bool eff, lab;  // effective-weight mode; labeled-rows tile of it
 };
 
 template <bool SYNTH>
@@ -79,7 +85,7 @@ struct WStageRegs {
         for (int a = 0; a < 2; ++a) {
             float4 g = ga[a];
             if (SYNTH) {
-                const float cf = ((mk[a] != 0) == c.a_first) ? sy.zr : sy.omz;
+                const float cf = c.eff ? ((c.lab && mk[a] == 0) ? 0.f : 1.f) : (((mk[a] != 0) == c.a_first) ? sy.zr : sy.omz);
                 g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
                 if (sy.act == GLASS_ACT_ELU) {
                     g.x *= elu_grad_f(ta[a].x); g.y *= elu_grad_f(ta[a].y); g.z *= elu_grad_f(ta[a].z); g.w *= elu_grad_f(ta[a].w);
@@ -94,15 +100,27 @@ struct WStageRegs {
     }
 };
 
-template <bool SYNTH>
+// EFF (comb pair: no activation factor in G): G[n, o] is dc[n, o mod H] times a coefficient that depends only on the row's
+// label and on the half o belongs to, so the f1 and f0 halves of dW are two scalings of the SAME matrix for every unlabeled
+// row.  The lower half of the output tiles then accumulates S = sum over ALL rows of dc^T X (coefficient 1), the upper half
+// L = the same sum over the LABELED rows only — stages of 16 rows without a labeled row are skipped there, and with
+// B*Smax labeled nodes among N almost all are — and the reduce kernel forms  dW1 = (1-z) S + (2z-1) L,  dW0 = z S - (2z-1) L
+// (bias likewise).  Half the matrix work of the two-product form.
+template <bool SYNTH, bool EFF>
 __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* __restrict__ G, int64_t ldg,
                                                                   const float* __restrict__ X, int64_t ldx, int64_t N,
                                                                   int rows_per_slab, float* __restrict__ part_w,
-                                                                  float* __restrict__ part_b, WgradSynth sy) {
+                                                                  float* __restrict__ part_b, float* __restrict__ header,
+                                                                  WgradSynth sy) {
     extern __shared__ float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
-    const int o0 = blockIdx.z * kWO, i0 = blockIdx.y * kWI;
+    if (header && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
+        header[0] = EFF ? 1.f : 0.f;
+        header[1] = sy.zr;
+    }
+    const bool lab_tile = EFF && blockIdx.z >= gridDim.z / 2;  // the labeled-rows sum of output tile z - nz/2
+    const int o0 = (lab_tile ? blockIdx.z - gridDim.z / 2 : blockIdx.z) * kWO, i0 = blockIdx.y * kWI;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
     const int64_t r1 = min(N, r0 + rows_per_slab);
     const int n_steps = (int)((r1 - r0 + kWK - 1) / kWK);
@@ -121,7 +139,7 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
         xcol = b_col - sy.H;
     }
     WStageRegs<SYNTH> sr;
-    const StageCtx cx{G, ldg, xsrc, xld, xcol, a_col, a_first, r0, r1, tid};
+    const StageCtx cx{G, ldg, xsrc, xld, xcol, a_col, a_first, r0, r1, tid, EFF, lab_tile};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
     f32x16 acc[2][4];
@@ -132,13 +150,7 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
 #pragma unroll
             for (int k = 0; k < 16; ++k) acc[rb][cb][k] = 0.f;
 
-    sr.issue(cx, sy, 0);
-    sr.commit(cx, sy, wsm, bsum);
-    __syncthreads();
-    for (int step = 0; step < n_steps; ++step) {
-        const float* cur = wsm + (step & 1) * kWStage;
-        float* nxt = wsm + ((step + 1) & 1) * kWStage;
-        if (step + 1 < n_steps) sr.issue(cx, sy, step + 1);
+    auto stage_mma = [&](const float* cur) __attribute__((always_inline)) {
         const float* A = cur + wm * 64 + j;
         const float* B = cur + kWK * kWO + wn * 128 + j;
 #pragma unroll
@@ -155,8 +167,46 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
                 for (int cb = 0; cb < 4; ++cb)
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[rb], bv[cb], acc[rb][cb], 0, 0, 0);
         }
-        if (step + 1 < n_steps) sr.commit(cx, sy, nxt, bsum);
+    };
+    if (lab_tile) {
+        // labeled rows only: one flag per 16-row stage first (LDS, behind the two stage buffers), then only the flagged
+        // stages are loaded and multiplied — few, so without the software pipeline
+        int* flag = reinterpret_cast<int*>(wsm + 2 * kWStage);
+        for (int st0 = 0; st0 < n_steps; st0 += kWThreads) {
+            const int stp = st0 + tid;
+            if (stp < n_steps) {
+                const int64_t b = r0 + (int64_t)stp * kWK;
+                int any = 0;
+                if (b + kWK <= r1 && ((reinterpret_cast<uintptr_t>(sy.mask + b) & 15u) == 0)) {
+                    const uint4 m4 = *reinterpret_cast<const uint4*>(sy.mask + b);
+                    any = (m4.x | m4.y | m4.z | m4.w) != 0;
+                } else {
+                    for (int64_t n = b; n < b + kWK && n < r1; ++n) any |= sy.mask[n] != 0;
+                }
+                flag[stp] = any;
+            }
+        }
         __syncthreads();
+        for (int step = 0; step < n_steps; ++step) {
+            if (!flag[step]) continue;  // workgroup-uniform
+            sr.issue(cx, sy, step);
+            sr.commit(cx, sy, wsm, bsum);
+            __syncthreads();
+            stage_mma(wsm);
+            __syncthreads();
+        }
+    } else {
+        sr.issue(cx, sy, 0);
+        sr.commit(cx, sy, wsm, bsum);
+        __syncthreads();
+        for (int step = 0; step < n_steps; ++step) {
+            const float* cur = wsm + (step & 1) * kWStage;
+            float* nxt = wsm + ((step + 1) & 1) * kWStage;
+            if (step + 1 < n_steps) sr.issue(cx, sy, step + 1);
+            stage_mma(cur);
+            if (step + 1 < n_steps) sr.commit(cx, sy, nxt, bsum);
+            __syncthreads();
+        }
     }
 
     // partial tile, plain [128][256]: acc[rb][cb][k] = output wm*64 + rb*32 + 8(k>>2) + 4h + (k&3), input wn*128 + cb*32 + j
@@ -188,31 +238,52 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
 }
 
 // dW[o0 + r][i0 + c] (+)= sum over slabs, in slab order; one thread per 4 consecutive inputs.  grid (kWTile / 4 / 256 +
-// 1, ny * nz): the last x-block of an input-tile-0 chunk reduces the bias partials.
+// 1, ny * nz): the last x-block of an input-tile-0 chunk reduces the bias partials.  header[0] != 0: the partials are in
+// effective-weight form (tiled_wgrad_kernel<.., EFF>): output tile z of the f1 half = (1-z) S + (2z-1) L, of the f0 half
+// = z S - (2z-1) L with S / L the slab sums of chunks zz and nz/2 + zz.
 __global__ __launch_bounds__(kWThreads) void tiled_wgrad_reduce_kernel(const float* __restrict__ part_w,
-                                                                      const float* __restrict__ part_b, int n_slabs,
-                                                                      int ny, float* __restrict__ dW, int64_t lddw,
+                                                                      const float* __restrict__ part_b,
+                                                                      const float* __restrict__ header, int n_slabs,
+                                                                      int ny, int nz, float* __restrict__ dW, int64_t lddw,
                                                                       float* __restrict__ db, int accumulate) {
     const int chunk = blockIdx.y, z = chunk / ny, y = chunk % ny;
+    const bool eff = header[0] != 0.f;
+    const float zr = header[1];
+    const int zz = eff ? z % (nz / 2) : z;
+    const float cs = !eff ? 1.f : (z < nz / 2 ? 1.f - zr : zr);             // weight of the all-rows sum
+    const float cl = !eff ? 0.f : (z < nz / 2 ? 2.f * zr - 1.f : 1.f - 2.f * zr);  // ... of the labeled-rows sum
     if (blockIdx.x == kWTile / 4 / kWThreads) {  // bias block
         if (y != 0 || db == nullptr || threadIdx.x >= kWO) return;
-        const float* p = part_b + (int64_t)z * n_slabs * kWO + threadIdx.x;
-        float s = 0.f;
+        const float* p = part_b + (int64_t)zz * n_slabs * kWO + threadIdx.x;
+        float s = 0.f, l = 0.f;
         for (int b = 0; b < n_slabs; ++b) s += p[(int64_t)b * kWO];
+        if (eff) {
+            const float* pl = part_b + (int64_t)(nz / 2 + zz) * n_slabs * kWO + threadIdx.x;
+            for (int b = 0; b < n_slabs; ++b) l += pl[(int64_t)b * kWO];
+        }
+        s = cs * s + cl * l;
         float* d = db + z * kWO + threadIdx.x;
         *d = accumulate ? *d + s : s;
         return;
     }
     const int e = (blockIdx.x * kWThreads + threadIdx.x) * 4;  // element of the [128][256] tile
-    const float* p = part_w + (int64_t)chunk * n_slabs * kWTile + e;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = 0; b < n_slabs; b += 4) {
-        float4 v[4];
+    auto slab_sum = [&](int ch) __attribute__((always_inline)) {
+        const float* p = part_w + (int64_t)ch * n_slabs * kWTile + e;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = 0; b < n_slabs; b += 4) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            v[u] = b + u < n_slabs ? *reinterpret_cast<const float4*>(p + (int64_t)(b + u) * kWTile) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < 4; ++u)
+                v[u] = b + u < n_slabs ? *reinterpret_cast<const float4*>(p + (int64_t)(b + u) * kWTile) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        return s;
+    };
+    float4 s = slab_sum(zz * ny + y);
+    if (eff) {
+        const float4 l = slab_sum((nz / 2 + zz) * ny + y);
+        s = make_float4(cs * s.x + cl * l.x, cs * s.y + cl * l.y, cs * s.z + cl * l.z, cs * s.w + cl * l.w);
     }
     float* d = dW + (int64_t)(z * kWO + e / kWI) * lddw + y * kWI + e % kWI;
     if (accumulate) {
@@ -222,20 +293,33 @@ __global__ __launch_bounds__(kWThreads) void tiled_wgrad_reduce_kernel(const flo
     }
 }
 
+static inline float* header_of(float* part_b, const TiledWgradGeom& g) { return part_b + g.part_b_floats - kWHeaderFloats; }
+
 void launch_tiled_wgrad_partial(const float* X, int64_t ldx, int64_t N, int64_t O, int64_t I, const WgradSynth& sy,
                                 float* part_w, float* part_b, hipStream_t st) {
     const TiledWgradGeom g = wgrad_tiled_geom(N, O, I);
-    const size_t lds = 2 * (size_t)kWStage * sizeof(float);
     const dim3 grid(g.n_slabs, g.ny, g.nz);
-    hipLaunchKernelGGL(tiled_wgrad_kernel<true>, grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N, g.rows_per_slab, part_w,
-                       part_b, sy);
+    float* header = header_of(part_w + g.part_w_floats, g);  // (the bias partials always sit behind the weight partials)
+    // comb pair (virtual concatenation as the input, no activation factor, both halves of the output present)
+    const bool eff = sy.X2 != nullptr && sy.act == GLASS_ACT_NONE && I == O && g.nz % 2 == 0 && O == 2 * (int64_t)sy.H;
+    if (eff) {
+        const size_t lds = 2 * (size_t)kWStage * sizeof(float) + (size_t)ceil_div((int64_t)g.rows_per_slab, (int64_t)kWK) * sizeof(int);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)tiled_wgrad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((tiled_wgrad_kernel<true, true>), grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N,
+                           g.rows_per_slab, part_w, part_b, header, sy);
+    } else {
+        const size_t lds = 2 * (size_t)kWStage * sizeof(float);
+        hipLaunchKernelGGL((tiled_wgrad_kernel<true, false>), grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N,
+                           g.rows_per_slab, part_w, part_b, header, sy);
+    }
 }
 
 void launch_tiled_wgrad_reduce(const float* part_w, const float* part_b, int64_t N, int64_t O, int64_t I, float* dW,
                                int64_t lddw, float* db, int accumulate, hipStream_t st) {
     const TiledWgradGeom g = wgrad_tiled_geom(N, O, I);
     hipLaunchKernelGGL(tiled_wgrad_reduce_kernel, dim3(kWTile / 4 / kWThreads + 1, g.ny * g.nz), dim3(kWThreads), 0, st,
-                       part_w, part_b, g.n_slabs, g.ny, dW, lddw, db, accumulate);
+                       part_w, part_b, header_of(const_cast<float*>(part_b), g), g.n_slabs, g.ny, g.nz, dW, lddw, db, accumulate);
 }
 
 }  // namespace glass

@@ -569,6 +569,7 @@ def test_dense_pack_effective_weight_appendix():
     H, z = 256, 0.9
     assert _lib.load().glass_dual_linear_dgrad_layout(H, 2 * H) == 4 and _lib.load().glass_dual_linear_dgrad_layout(H, H) == 2
     assert _lib.load().glass_dual_linear_dgrad_layout(128, 128) == 3 and _lib.load().glass_dual_linear_dgrad_layout(64, 64) == 0
+    assert _lib.load().glass_dual_linear_dgrad_layout(128, 256) == 4
     gen = torch.Generator().manual_seed(3)
     W = torch.randn(2 * H, 2 * H, generator=gen).to(DEV)  # comb weight [2H out][2H in]; operand B = W^T: [NT = 2H in][KT = 2H out]
     img = torch.empty(W.numel() * 3 // 2, device=DEV)
