@@ -620,6 +620,47 @@ def test_dense_pack_forward_effective_weight_appendix():
         assert torch.allclose(app[off:off + 4], Weff[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("pattern", ["none", "one_per_tile_3", "sparse", "all"])
+def test_comb_pair_effective_weight_paths(pattern):
+    """Comb pair at hidden 256 on the tiled kernels: row tiles without a labeled row take the effective-weight path
+    (one product), tiles holding one the two-product path — forward (+ statistics) and data gradient against fp64 for
+    label patterns that exercise both inside one launch."""
+    from glass_amd import stack
+    from glass_amd.arena import ParamArena
+    from glass_amd.factory import build_glass
+    torch.manual_seed(7)
+    N, H, z = 1000, 256, 0.9   # 8 row tiles of 128 (the last one ragged)
+    model = build_glass(H, 1, 5, 3, "mean", "sum", z).to(DEV).train()
+    ParamArena(model)
+    st = model.conv.convs[0]._stack["comb"]
+    mask = torch.zeros(N, dtype=torch.uint8, device=DEV)
+    if pattern == "one_per_tile_3":
+        mask[3 * 128 + 17] = 1
+    elif pattern == "sparse":
+        mask[torch.tensor([5, 300, 301, 999], device=DEV)] = 1
+    elif pattern == "all":
+        mask[:] = 1
+    a, h = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+    c = torch.empty(N, H, device=DEV)
+    nblk = -(-N // int(stack._lib.load().glass_dual_linear_stat_rows(H)))
+    cstat = torch.empty(nblk, 2, H, dtype=torch.float64, device=DEV)
+    stack._dual_fwd(a, h, st, mask, z, 0, None, c, cstat)
+    W, b = st[0].double(), st[1].double()
+    x = torch.cat([a, h], 1).double()
+    C1, C0 = x @ W[:H].t() + b[:H], x @ W[H:].t() + b[H:]
+    lab = mask.bool().unsqueeze(1)
+    ref = torch.where(lab, z * C1 + (1 - z) * C0, (1 - z) * C1 + z * C0)
+    assert rel_inf(c.double(), ref) < 1e-5
+    assert rel_inf(cstat[:, 0].sum(0), ref.sum(0)) < 1e-5 and rel_inf(cstat[:, 1].sum(0), (ref * ref).sum(0)) < 1e-5
+    # data gradient: dIN = [w1 dc | w0 dc] @ Wstack
+    dc = torch.randn(N, H, device=DEV)
+    din = torch.empty(N, 2 * H, device=DEV)
+    stack._dual_dgrad(dc, None, st, mask, z, 0, 2 * H, None, din)
+    w1 = torch.where(lab, torch.tensor(z, device=DEV, dtype=torch.float64), torch.tensor(1 - z, device=DEV, dtype=torch.float64))
+    dref = (w1 * dc.double()) @ W[:H] + ((1 - w1) * dc.double()) @ W[H:]
+    assert rel_inf(din.double(), dref) < 1e-5
+
+
 # ---------------------------------------------------------------------------------- K8 head + loss
 @pytest.mark.parametrize("mode,B,C,K", [(0, 80, 128, 6), (0, 7, 17, 3), (1, 99, 128, 10), (1, 5, 64, 1)])
 def test_head_loss_fused(mode, B, C, K):
