@@ -317,9 +317,9 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
 // 128..255, K is H instead of 2H, and the right pair hands its accumulators to the left through LDS before the epilogue.
 // Operand image: layout kLayoutTiledSplit (slot s < 128: Wstack[k][s], else Wstack[H + k][s - 128]).
 // EFF (comb pair): the operand image carries an appendix, the effective weight of UNLABELED rows
-// (1-z) W1 + z W0 over K = H (kLayoutTiledPlainEff).  dZ has no activation factor for the comb pair, so a row tile without
-// a labeled row is dc @ W_unl — half the K loop; tiles that hold a labeled row take the two-term product as before.  With
-// B*Smax labeled nodes among N (config 5: 2 048 of 1 M) most 128-row tiles qualify.
+// (1-z) W1 + z W0 over K = H (kLayoutTiledPlainEff).  dZ has no activation factor for the comb pair, so an unlabeled row of
+// the product is dc @ W_unl — half the K loop.  A tile runs that for ALL its rows and then corrects its (few) labeled rows
+// with a thread-per-column dot product; only tiles with more than 16 labeled rows fall back to the two-term product.
 template <int H, int NOUT, int BM, int BN, bool SPLIT, bool EFF>
 __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                   const float* __restrict__ T, int64_t ldt,
@@ -351,12 +351,28 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
         sok[i] = row0 + srow[i] < N;
         slab[i] = sok[i] && mask[row0 + srow[i]] != 0;
     }
-    bool pure = false;  // workgroup-uniform: no labeled row in this tile -> single-term product with the appendix image
-    if (EFF) {
-        bool any = false;
-#pragma unroll
-        for (int i = 0; i < AP; ++i) any = any || slab[i];
-        pure = act == GLASS_ACT_NONE && __syncthreads_or(any ? 1 : 0) == 0;
+    // EFF: the single-term product (appendix image, K = H) for the whole tile when it holds at most kMaxFix labeled rows;
+    // those rows get their label's weight back afterwards as a correction (below).  fix[] (LDS behind the stage
+    // buffers): [1..4] labeled rows per wave, [8 .. 8+BM) correction slot of a tile row or -1, then the slots' rows.
+    constexpr int kMaxFix = 16;
+    int* fix = reinterpret_cast<int*>(smem + 2 * kStage);
+    bool pure = false;  // workgroup-uniform
+    int n_fix = 0;
+    if (EFF && act == GLASS_ACT_NONE) {
+        const bool flag = tid < BM && row0 + tid < N && mask[row0 + tid] != 0;
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) fix[1 + w] = __popcll(bal);
+        if (tid < BM) fix[8 + tid] = -1;
+        __syncthreads();
+        int off = 0;
+        for (int ww = 0; ww < w; ++ww) off += fix[1 + ww];
+        n_fix = fix[1] + fix[2] + fix[3] + fix[4];
+        pure = n_fix <= kMaxFix;
+        if (flag && pure) {
+            const int ci = off + __popcll(bal & ((1ull << lane) - 1ull));  // ordered by row
+            fix[8 + tid] = ci;
+            fix[8 + BM + ci] = tid;
+        }
     }
     const float4* wimg = reinterpret_cast<const float4*>(WTimg) +
                          (pure ? (int64_t)NCT * NKS * TL::kBImg + (int64_t)ct * (NKS / 2) * TL::kBImg : (int64_t)ct * NKS * TL::kBImg);
@@ -444,6 +460,27 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
         __syncthreads();  // the statistics below reuse this memory
     }
     const bool active = !SPLIT || wn == 0;  // waves that own output columns
+    // EFF: a labeled row r of a single-term tile is owed  (z - (1-z)) * sum_k dc[r,k] (B[c][k] - B[c][H+k])  in every
+    // column c — its label's weight minus the unlabeled one.  One thread per column slot, the main image read as it lies
+    // (consecutive threads, consecutive float4); the row's owner lanes add it in the epilogue.
+    const float* corr = reinterpret_cast<const float*>(smem);  // [n_fix][256 slots] (the loop's last barrier freed the stages)
+    const bool fixing = EFF && pure && n_fix > 0;
+    if (fixing) {
+        const float4* main_img = reinterpret_cast<const float4*>(WTimg) + (int64_t)ct * NKS * TL::kBImg;
+        float* cw = reinterpret_cast<float*>(smem);
+        for (int f = 0; f < n_fix; ++f) {
+            const float* drow = dsrc + (row0 + fix[8 + BM + f]) * ldd;
+            float sacc = 0.f;
+#pragma unroll 4
+            for (int kq = 0; kq < H / 4; ++kq) {
+                const float4 d = *reinterpret_cast<const float4*>(drow + 4 * kq);
+                const float4 b1 = main_img[(int64_t)kq * 256 + tid], b0 = main_img[(int64_t)(kq + H / 4) * 256 + tid];
+                sacc += d.x * (b1.x - b0.x) + d.y * (b1.y - b0.y) + d.z * (b1.z - b0.z) + d.w * (b1.w - b0.w);
+            }
+            cw[f * 256 + tid] = (zr - omz) * sacc;
+        }
+        __syncthreads();
+    }
 
     // epilogue: this lane's four consecutive output columns col0 .. col0 + 3 (cb = 0..3) of its 16 * RB rows
     const int col0 = ct * BN + wn * (BN / 2) + CB * j;
@@ -479,6 +516,13 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
                 float v[CB];
 #pragma unroll
                 for (int e = 0; e < CB; ++e) v[e] = acc[rb][e][i];
+                if (fixing) {
+                    const int ci = fix[8 + wm * (BM / 2) + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3)];
+                    if (ci >= 0) {
+#pragma unroll
+                        for (int e = 0; e < CB; ++e) v[e] += corr[ci * 256 + wn * (BN / 2) + e * 32 + j];
+                    }
+                }
                 if (addend) {
                     const float4 ad = *reinterpret_cast<const float4*>(addend + r * ldadd + col0);
                     v[0] += ad.x; v[1] += ad.y; v[2] += ad.z; v[3] += ad.w;
@@ -509,6 +553,7 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
     if (gs.partial == nullptr) return;
     // partial[rt][2][H] over this row tile: lanes h = 0/1, then the two row waves through LDS
     double* red = reinterpret_cast<double*>(smem);  // [wm][BN columns][2]
+    if (fixing) __syncthreads();  // `red` lies over the corrections other waves may still be reading
     if (gn_half) {
 #pragma unroll
         for (int e = 0; e < CB; ++e) {
@@ -569,8 +614,8 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
 #define GLASS_TDG1(HH, NOUT, BM, BN)                                                                                 \
     {                                                                                                                \
         const int64_t n_rt = ceil_div(N, BM);                                                                        \
-        const size_t lds = Tile<BM, BN>::kLds;                                                                       \
         constexpr bool kEff = NOUT == 2 * HH; /* tiled_eff_dgrad_shape */                                            \
+        const size_t lds = Tile<BM, BN>::kLds + (kEff ? 1024 : 0); /* + the labeled-row bookkeeping */               \
         allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>, lds);                                     \
         hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
                            st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, \

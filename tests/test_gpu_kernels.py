@@ -477,7 +477,7 @@ def test_dual_linear_mix_fused(H, N, comb):
     # HIP
     Wg, bg = W.to(DEV), b.to(DEV)
     dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
-    Wimg, WTimg = _pack(Wg, False, H), _pack(Wg, True, H)
+    Wimg, WTimg = _pack(Wg, False, H, zr), _pack(Wg, True, H, zr)
     lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)  # carriers for the autograd edges only
     # as under a ParamArena: the parameters' .grad ARE views of the stacked gradient buffers (the in-place path is only
     # taken while that holds: ops._arena_grads_live)
@@ -497,19 +497,27 @@ def test_dual_linear_mix_fused(H, N, comb):
     assert torch.equal(out2, out.detach())
 
 
-def _pack(W, transposed, H=64):
+def _pack(W, transposed, H=64, z=None):
     """glass_dense_pack_batch_f32 on one matrix: operand image of W ([NT][KT]) or of W^T, in the layout the fused dense
-    kernels of hidden size H read (flags = transposed | layout << 1: forward operand paired, data-gradient plain, or split for a
-    128-wide output)."""
+    kernels of hidden size H read.  z = the pair's z_ratio: the layout the KERNELS read for this operand (the library's
+    glass_dual_linear_{fwd,dgrad}_layout, incl. the effective-weight appendix of the comb pair); z = None: the base
+    layout without an appendix (forward paired, data-gradient plain / split), as the layout tests address it."""
     from glass_amd import _lib
-    img = torch.empty(W.numel(), device=DEV)
+    lib = _lib.load()
     nt, kt = (W.shape[1], W.shape[0]) if transposed else W.shape
+    if lib.glass_dual_linear_layout(H) != 1:
+        layout = 0
+    elif z is not None:
+        layout = lib.glass_dual_linear_dgrad_layout(H, nt) if transposed else lib.glass_dual_linear_fwd_layout(H, kt)
+    else:
+        layout = (2 if nt % 256 == 0 else 3) if transposed else 1
+    img = torch.empty(W.numel() * 3 // 2 if layout in (4, 5) else W.numel(), device=DEV)
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
-    layout = ((2 if nt % 256 == 0 else 3) if transposed else 1) if _lib.load().glass_dual_linear_layout(H) == 1 else 0
     trs = np.array([int(transposed) | (layout << 1)], dtype=np.int32)
-    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
-                                                trs.ctypes.data, 0, 1, 0, torch.cuda.current_stream().cuda_stream)
+    zs = np.array([0.0 if z is None else z], dtype=np.float32)
+    rc = lib.glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+                                        trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     return img
 
@@ -620,11 +628,11 @@ def test_dense_pack_forward_effective_weight_appendix():
         assert torch.allclose(app[off:off + 4], Weff[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("pattern", ["none", "one_per_tile_3", "sparse", "all"])
+@pytest.mark.parametrize("pattern", ["none", "one_per_tile_3", "sparse", "cap16", "cap17", "all"])
 def test_comb_pair_effective_weight_paths(pattern):
-    """Comb pair at hidden 256 on the tiled kernels: row tiles without a labeled row take the effective-weight path
-    (one product), tiles holding one the two-product path — forward (+ statistics) and data gradient against fp64 for
-    label patterns that exercise both inside one launch."""
+    """Comb pair at hidden 256 on the tiled kernels: the effective-weight (one product) and two-product paths — forward
+    (+ statistics) and data gradient (one product for every tile with <= 16 labeled rows, those rows corrected
+    afterwards) against fp64, for label patterns that exercise the paths side by side inside one launch."""
     from glass_amd import stack
     from glass_amd.arena import ParamArena
     from glass_amd.factory import build_glass
@@ -638,6 +646,11 @@ def test_comb_pair_effective_weight_paths(pattern):
         mask[3 * 128 + 17] = 1
     elif pattern == "sparse":
         mask[torch.tensor([5, 300, 301, 999], device=DEV)] = 1
+    elif pattern == "cap16":   # the most labeled rows a single-product tile corrects afterwards
+        mask[2 * 128 + torch.arange(0, 128, 8, device=DEV)] = 1
+    elif pattern == "cap17":   # one more: that tile falls back to the two-product path
+        mask[2 * 128 + torch.arange(0, 128, 8, device=DEV)] = 1
+        mask[2 * 128 + 3] = 1
     elif pattern == "all":
         mask[:] = 1
     a, h = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
@@ -659,6 +672,19 @@ def test_comb_pair_effective_weight_paths(pattern):
     w1 = torch.where(lab, torch.tensor(z, device=DEV, dtype=torch.float64), torch.tensor(1 - z, device=DEV, dtype=torch.float64))
     dref = (w1 * dc.double()) @ W[:H] + ((1 - w1) * dc.double()) @ W[H:]
     assert rel_inf(din.double(), dref) < 1e-5
+    # the same launch with the backward-GraphNorm column sums in its epilogue (the LDS reduction of those sums reuses the
+    # memory the labeled-row corrections are read from)
+    gmod = model.conv.convs[0].gn
+    gx = torch.randn(N, H, device=DEV)
+    saved = torch.cat([gx.mean(0), 1.0 / (gx.var(0, unbiased=False) + 1e-5).sqrt(), torch.ones(H, device=DEV),
+                       torch.zeros(H, device=DEV)]).contiguous()
+    gpart = torch.empty(nblk, 2, H, dtype=torch.float64, device=DEV)
+    din2 = torch.empty_like(din)
+    stack._dual_dgrad(dc, None, st, mask, z, 0, 2 * H, None, din2, gn=(gpart, gx, saved, gmod.mean_scale, 0, 0.0, 0))
+    assert torch.equal(din2, din)
+    g = dref[:, :H]
+    xhat = (gx.double() - gmod.mean_scale.double() * saved[:H].double()) * saved[H:2 * H].double()
+    assert rel_inf(gpart[:, 0].sum(0), g.sum(0)) < 1e-5 and rel_inf(gpart[:, 1].sum(0), (g * xhat).sum(0)) < 1e-5
 
 
 # ---------------------------------------------------------------------------------- K8 head + loss
