@@ -105,7 +105,8 @@ struct BStage {
 // EFF (comb pair, hidden 256 / 512): the operand image carries an appendix, W_unl = (1-z) W1 + z W0 ([H][2H], plain
 // layout).  The comb pair has no activation before the mix, so a row tile WITHOUT a labeled row is one product
 // [g || x_] @ W_unl^T + b_unl over 256 output columns per column tile — half the column tiles of the two-weight form: the
-// blocks of the upper half of the column tiles leave at once.  Row tiles that hold a labeled row take the usual path.
+// blocks of the upper half of the column tiles leave at once.  A tile with up to 3 labeled rows runs the same product for
+// all its rows and corrects those rows afterwards; beyond that it takes the two-weight path.
 template <int H, bool COMB, int BM, bool EFF>
 __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                 const float* __restrict__ xb, int64_t ldb,
@@ -148,11 +149,29 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
-    bool pure = false;  // workgroup-uniform: no labeled row in this row tile
-    if (EFF) {
-        const int64_t r = row0 + tid;
-        pure = __syncthreads_or((tid < BM && r < N && mask[r] != 0) ? 1 : 0) == 0 && act == GLASS_ACT_NONE && T == nullptr;
+    // EFF: the single-weight product for the whole tile when it holds at most kMaxFix labeled rows; those rows get their
+    // label's weight back afterwards (correction below).  fix[] (LDS behind the stage buffers): [1..4] labeled rows per
+    // wave, [8 .. 8+BM) correction slot of a tile row or -1, then the slots' rows.
+    constexpr int kMaxFix = 3;  // a correction costs about a third of the second product of the two-weight path
+    int* fix = reinterpret_cast<int*>(smem + 2 * TL::kStageVecs);
+    bool pure = false;  // workgroup-uniform
+    int n_fix = 0;
+    if (EFF && act == GLASS_ACT_NONE && T == nullptr) {
+        const bool flag = tid < BM && row0 + tid < N && mask[row0 + tid] != 0;
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) fix[1 + w] = __popcll(bal);
+        if (tid < BM) fix[8 + tid] = -1;
+        __syncthreads();
+        int off = 0;
+        for (int ww = 0; ww < w; ++ww) off += fix[1 + ww];
+        n_fix = fix[1] + fix[2] + fix[3] + fix[4];
+        pure = n_fix <= kMaxFix;
         if (pure && ct >= NCT / 2) return;  // 256 output columns per block now: the lower half of the column tiles covers H
+        if (flag && pure) {
+            const int ci = off + __popcll(bal & ((1ull << lane) - 1ull));  // ordered by row
+            fix[8 + tid] = ci;
+            fix[8 + BM + ci] = tid;
+        }
     }
     const bool side_writer = pro.side != nullptr && ct == 0;  // every column tile computes the operand; one writes it
     const float4* wimg = reinterpret_cast<const float4*>(Wimg) +
@@ -219,6 +238,54 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
     }
 
     if (EFF && pure) {
+        // A labeled row r is owed  (z - (1-z)) * ( sum_k A[r,k] (W1[c][k] - W0[c][k]) + b1[c] - b0[c] )  in every column c:
+        // its label's weight minus the unlabeled one.  One thread per column of this block, A[r,:] rebuilt as the staging
+        // code builds it (GraphNorm prologue), W1 / W0 read from the paired main image; added in the epilogue below.
+        const float* corr = reinterpret_cast<const float*>(smem);  // [n_fix][256] (the loop's last barrier freed the stages)
+        const bool fixing = n_fix > 0;
+        if (fixing) {
+            float* cw = reinterpret_cast<float*>(smem);
+            const int c = ct * 256 + (tid >> 7) * 128 + 4 * (tid & 31) + ((tid >> 5) & 3);  // column of plain slot tid
+            // its f1 / f0 slots in the paired image: column tile c / 128, slot wn*128 + cb*32 + j with c % 128 = wn*64 + 2j + (cb & 1)
+            const int cp = c & 127;
+            const float4* img1 = reinterpret_cast<const float4*>(Wimg) + (int64_t)(c >> 7) * NKS * TL::kBImg +
+                                 ((cp >> 6) * 128 + (cp & 1) * 32 + ((cp & 63) >> 1));
+            const float4* img0 = img1 + 64;  // cb + 2: the same column of the f0 half
+            const float db = bias[c] - bias[H + c];
+            float4* arow = reinterpret_cast<float4*>(cw + kMaxFix * 256);  // the operand row, built once by KT / 4 threads
+            for (int f = 0; f < n_fix; ++f) {
+                const int64_t r = row0 + fix[8 + BM + f];
+                for (int kq = tid; kq < KT / 4; kq += kTThreads) {
+                    const int k = 4 * kq;
+                    float4 v = (k < H) ? *reinterpret_cast<const float4*>(xa + r * lda + k)
+                                       : *reinterpret_cast<const float4*>(xb + r * ldb + (k - H));
+                    if (pro.saved && k < H) {
+                        const float4 sc = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + k);
+                        const float4 sh = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + k);
+                        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (drop.p > 0.f) drop_scales<4>(drop, r, k, ds);
+                        float o[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            if (pro.act == GLASS_ACT_ELU) o[e] = elu_f(o[e]);
+                            o[e] *= ds[e];
+                        }
+                        v = make_float4(o[0], o[1], o[2], o[3]);
+                    }
+                    arow[kq] = v;
+                }
+                __syncthreads();
+                float sacc = 0.f;
+#pragma unroll 4
+                for (int kq = 0; kq < KT / 4; ++kq) {
+                    const float4 v = arow[kq];
+                    const float4 w1v = img1[(int64_t)kq * 256], w0v = img0[(int64_t)kq * 256];
+                    sacc += v.x * (w1v.x - w0v.x) + v.y * (w1v.y - w0v.y) + v.z * (w1v.z - w0v.z) + v.w * (w1v.w - w0v.w);
+                }
+                cw[f * 256 + tid] = (zr - omz) * (sacc + db);
+                __syncthreads();  // arow is rebuilt for the next row; after the last one: corrections visible
+            }
+        }
         // single-weight epilogue: plain layout — this lane's four consecutive columns col0 .. col0 + 3 (cb = 0..3)
         const int col0 = ct * 256 + wn * 128 + 4 * j;
         const float4 c1 = *reinterpret_cast<const float4*>(bias + col0), c0 = *reinterpret_cast<const float4*>(bias + H + col0);
@@ -231,9 +298,11 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
                 const int64_t r = row0 + wm * (BM / 2) + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
                 if (r < N) {
                     float o[4];
+                    const int ci = fixing ? fix[8 + wm * (BM / 2) + rb * 32 + 8 * (i >> 2) + 4 * h + (i & 3)] : -1;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         o[e] = acc[rb][e][i] + be[e];
+                        if (ci >= 0) o[e] += corr[ci * 256 + wn * 128 + e * 32 + j];
                         ss[e] += (double)o[e];
                         qq[e] += (double)o[e] * (double)o[e];
                     }
@@ -242,6 +311,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
             }
         if (stats == nullptr) return;
         double* red = reinterpret_cast<double*>(smem);  // [wm][256 columns][2]
+        if (fixing) __syncthreads();  // `red` lies over the corrections other waves may still be reading
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             ss[e] += __shfl_xor(ss[e], 32);
@@ -319,7 +389,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
 // EFF (comb pair): the operand image carries an appendix, the effective weight of UNLABELED rows
 // (1-z) W1 + z W0 over K = H (kLayoutTiledPlainEff).  dZ has no activation factor for the comb pair, so an unlabeled row of
 // the product is dc @ W_unl — half the K loop.  A tile runs that for ALL its rows and then corrects its (few) labeled rows
-// with a thread-per-column dot product; only tiles with more than 16 labeled rows fall back to the two-term product.
+// with a thread-per-column dot product; only tiles with more than 7 labeled rows fall back to the two-term product.
 template <int H, int NOUT, int BM, int BN, bool SPLIT, bool EFF>
 __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                   const float* __restrict__ T, int64_t ldt,
@@ -354,7 +424,7 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
     // EFF: the single-term product (appendix image, K = H) for the whole tile when it holds at most kMaxFix labeled rows;
     // those rows get their label's weight back afterwards as a correction (below).  fix[] (LDS behind the stage
     // buffers): [1..4] labeled rows per wave, [8 .. 8+BM) correction slot of a tile row or -1, then the slots' rows.
-    constexpr int kMaxFix = 16;
+    constexpr int kMaxFix = 7;  // a correction costs about an eighth of the second term of the two-term product
     int* fix = reinterpret_cast<int*>(smem + 2 * kStage);
     bool pure = false;  // workgroup-uniform
     int n_fix = 0;
@@ -590,7 +660,8 @@ int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb,
     if (H == HH) {                                                                                                   \
         const int64_t n_rt = ceil_div(N, BM);                                                                        \
         const dim3 grid(tiled_grid(n_rt, HH / 128));                                                                 \
-        const size_t lds = Tile<BM, 256>::kLds;                                                                      \
+        /* + the labeled-row bookkeeping of the effective-weight path (hidden 256 / 512, comb pair) */             \
+        const size_t lds = Tile<BM, 256>::kLds + ((comb && HH >= 256) ? 1024 : 0);                                   \
         if (comb) {                                                                                                  \
             constexpr bool kEff = HH >= 256; /* tiled_eff_fwd_shape: the image has the effective-weight appendix */  \
             allow_tiled_lds(tiled_fwd_kernel<HH, true, BM, kEff>, lds);                                              \

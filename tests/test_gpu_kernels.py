@@ -628,10 +628,10 @@ def test_dense_pack_forward_effective_weight_appendix():
         assert torch.allclose(app[off:off + 4], Weff[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4], rtol=0, atol=1e-6)
 
 
-@pytest.mark.parametrize("pattern", ["none", "one_per_tile_3", "sparse", "cap16", "cap17", "all"])
+@pytest.mark.parametrize("pattern", ["none", "one_per_tile_3", "sparse", "cap3", "cap4", "cap7", "cap8", "all"])
 def test_comb_pair_effective_weight_paths(pattern):
     """Comb pair at hidden 256 on the tiled kernels: the effective-weight (one product) and two-product paths — forward
-    (+ statistics) and data gradient (one product for every tile with <= 16 labeled rows, those rows corrected
+    (+ statistics) and data gradient (one product for every tile with few labeled rows, those rows corrected
     afterwards) against fp64, for label patterns that exercise the paths side by side inside one launch."""
     from glass_amd import stack
     from glass_amd.arena import ParamArena
@@ -646,11 +646,9 @@ def test_comb_pair_effective_weight_paths(pattern):
         mask[3 * 128 + 17] = 1
     elif pattern == "sparse":
         mask[torch.tensor([5, 300, 301, 999], device=DEV)] = 1
-    elif pattern == "cap16":   # the most labeled rows a single-product tile corrects afterwards
-        mask[2 * 128 + torch.arange(0, 128, 8, device=DEV)] = 1
-    elif pattern == "cap17":   # one more: that tile falls back to the two-product path
-        mask[2 * 128 + torch.arange(0, 128, 8, device=DEV)] = 1
-        mask[2 * 128 + 3] = 1
+    elif pattern.startswith("cap"):   # at / just past the most labeled rows a single-product tile corrects afterwards
+        k = int(pattern[3:])          # (3 in the forward, 7 in the data gradient; one more falls back to two products)
+        mask[2 * 128 + torch.arange(k, device=DEV) * 17 + 5] = 1
     elif pattern == "all":
         mask[:] = 1
     a, h = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
