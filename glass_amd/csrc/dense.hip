@@ -517,9 +517,13 @@ template <int H, int NT>
 __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_dgrad_blocks, const float* __restrict__ X,
                                                             int64_t ldx, int O, int I, int rows_per_slab, int gx, int gy,
                                                             float* __restrict__ part_w, float* __restrict__ part_b,
-                                                            WgradSynth sy) {
+                                                            float* __restrict__ wg_header, WgradSynth sy) {
     extern __shared__ float4 lds_w[];
     const int b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0) {  // the partials below are in the plain form (mode header read by the reduce launch)
+        wg_header[0] = 0.f;
+        wg_header[1] = sy.zr;
+    }
     if (b < n_dgrad_blocks) {
         dual_dgrad_body<H, NT, 1, 4>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
                                      A.rng_state, A.out, A.ldo, A.N, A.gs, b, lds_w);
@@ -773,11 +777,13 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         if (n_out == H) {
             allow_lds(dual_bwd_kernel<64, 64>, lds_fused);
             hipLaunchKernelGGL((dual_bwd_kernel<64, 64>), dim3(blocks), dim3(kBlock), lds_fused, st, dargs, (int)grid.x, wg->X,
-                               wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats, sy);
+                               wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats,
+                               part_w + g.part_w_floats + g.part_b_floats - kWgradHeaderFloats, sy);
         } else {
             allow_lds(dual_bwd_kernel<64, 128>, lds_fused);
             hipLaunchKernelGGL((dual_bwd_kernel<64, 128>), dim3(blocks), dim3(kBlock), lds_fused, st, dargs, (int)grid.x, wg->X,
-                               wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats, sy);
+                               wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats,
+                               part_w + g.part_w_floats + g.part_b_floats - kWgradHeaderFloats, sy);
         }
         return launch_status("glass_dual_linear_bwd_f32");
     }

@@ -23,22 +23,29 @@ namespace glass {
 
 // The partial-sum kernel body lives in wgrad_common.h (wgrad_partial_body): it is also one branch of the fused
 // backward launch of dense.hip.
-template <bool SYNTH>
+template <bool SYNTH, bool EFF>
 __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* __restrict__ G, int64_t ldg,
                                                                   const float* __restrict__ X, int64_t ldx,
                                                                   int64_t N, int O, int I, int rows_per_slab,
                                                                   float* __restrict__ part_w,
-                                                                  float* __restrict__ part_b, WgradSynth sy) {
+                                                                  float* __restrict__ part_b, float* __restrict__ header,
+                                                                  WgradSynth sy) {
     __shared__ float lds[2 * kTile + 8 * kOT];  // 64 KiB: two wave-sized accumulator images; + bias partials [wave*2 + h][o]
-    wgrad_partial_body<SYNTH, 4>(G, ldg, X, ldx, N, O, I, rows_per_slab, part_w, part_b, sy, blockIdx.x, blockIdx.y,
-                                 blockIdx.z, gridDim.x, gridDim.y, lds, lds + 2 * kTile);
+    if (header && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        header[0] = EFF ? 1.f : 0.f;  // tells the (possibly deferred) reduce launch which form the partials have
+        header[1] = sy.zr;
+    }
+    wgrad_partial_body<SYNTH, 4, EFF>(G, ldg, X, ldx, N, O, I, rows_per_slab, part_w, part_b, sy, blockIdx.x, blockIdx.y,
+                                      blockIdx.z, gridDim.x, gridDim.y, lds, lds + 2 * kTile, gridDim.z);
 }
 
 // Sum the slab partials and scatter to dW[o,i] / db[o].  A [n_slabs x 8192(+128)] column reduction:
 // 16 lanes x float4 cover 64 columns, 16 row slots walk the slabs (4 loads in flight each) and are
 // combined through LDS in slot order -> fixed summation order.
+// header (behind the bias partials): [0] != 0: effective-weight form (wgrad_partial_body<.., EFF>) — output tile z of the f1
+// half = (1-z) S + (2z-1) L, of the f0 half = z S - (2z-1) L with S / L the slab sums of tiles zz and nz/2 + zz.
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part_w, const float* __restrict__ part_b,
-                                                  int n_slabs, int ny, int O, int I, float* __restrict__ dW,
+                                                  int n_slabs, int ny, int nz, int O, int I, float* __restrict__ dW,
                                                   int64_t lddw, float* __restrict__ db, int accumulate, float4* lds,
                                                   int chunk /* z * ny + y */) {
     const int z = chunk / ny, y = chunk % ny;
@@ -46,26 +53,40 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
     const int k0 = blockIdx.x * 64 + tc * 4;       // first of this thread's 4 columns
     const bool is_bias = k0 >= kTile;
     if (is_bias && (y != 0 || db == nullptr)) return;  // whole workgroup: blockIdx.x is uniform
-    const float* p;
-    int64_t stride;
-    if (!is_bias) {
-        p = part_w + (int64_t)chunk * n_slabs * kTile + k0;
-        stride = kTile;
-    } else {
-        p = part_b + (int64_t)z * n_slabs * kOT + (k0 - kTile);
-        stride = kOT;
-    }
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int b = tr; b < n_slabs; b += 64) {
-        float4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int bb = b + 16 * u;
-            v[u] = bb < n_slabs ? *reinterpret_cast<const float4*>(p + (int64_t)bb * stride)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* header = part_b + (int64_t)nz * n_slabs * kOT;
+    const bool eff = header[0] != 0.f;
+    const float zr = header[1];
+    const int zz = eff ? z % (nz / 2) : z;
+    const float cs = !eff ? 1.f : (z < nz / 2 ? 1.f - zr : zr);
+    const float cl = !eff ? 0.f : (z < nz / 2 ? 2.f * zr - 1.f : 1.f - 2.f * zr);
+    auto slab_sum = [&](int zsrc) __attribute__((always_inline)) {
+        const float* p;
+        int64_t stride;
+        if (!is_bias) {
+            p = part_w + (int64_t)(zsrc * ny + y) * n_slabs * kTile + k0;
+            stride = kTile;
+        } else {
+            p = part_b + (int64_t)zsrc * n_slabs * kOT + (k0 - kTile);
+            stride = kOT;
         }
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = tr; b < n_slabs; b += 64) {
+            float4 v[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + 16 * u;
+                v[u] = bb < n_slabs ? *reinterpret_cast<const float4*>(p + (int64_t)bb * stride)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        return s;
+    };
+    float4 s = slab_sum(zz);
+    if (eff) {  // (workgroup-uniform)
+        const float4 l = slab_sum(nz / 2 + zz);
+        s = make_float4(cs * s.x + cl * l.x, cs * s.y + cl * l.y, cs * s.z + cl * l.z, cs * s.w + cl * l.w);
     }
     lds[threadIdx.x] = s;
     __syncthreads();
@@ -97,10 +118,10 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
 
 __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __restrict__ part_w,
                                                               const float* __restrict__ part_b, int n_slabs, int ny,
-                                                              int O, int I, float* __restrict__ dW, int64_t lddw,
+                                                              int nz, int O, int I, float* __restrict__ dW, int64_t lddw,
                                                               float* __restrict__ db, int accumulate) {
     __shared__ float4 lds[kBlock];
-    wgrad_reduce_body(part_w, part_b, n_slabs, ny, O, I, dW, lddw, db, accumulate, lds, blockIdx.y);
+    wgrad_reduce_body(part_w, part_b, n_slabs, ny, nz, O, I, dW, lddw, db, accumulate, lds, blockIdx.y);
 }
 
 // Several weight gradients reduced by ONE launch (blockIdx.z = job): the partial kernels of a backward pass write to
@@ -121,7 +142,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_batch_kernel(ReduceBatch 
     __shared__ float4 lds[kBlock];
     const ReduceJob& j = batch.job[blockIdx.z];
     if ((int)blockIdx.y >= j.ny * j.nz) return;
-    wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
+    wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.nz, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
 }
 
 WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
@@ -131,6 +152,9 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     // 52 vs 80 — fewer, longer slabs amortise the pipeline fill and halve the partial traffic).
     const int64_t tiles = ceil_div(I, kIT) * ceil_div(O, kOT);
     int64_t max_slabs = kMaxSlabs / tiles;
+    // comb-shaped (I == O, an even number of output tiles): in the effective-weight form half of the output tiles hold the
+    // few labeled rows only, so the other half gets twice the slabs to fill the chip
+    if (I == O && ceil_div(O, kOT) % 2 == 0) max_slabs *= 2;
     if (max_slabs > 128) max_slabs = 128;
     // Small graphs: this kernel shares ONE launch with the data gradient of the same pair (dual_bwd_kernel: N/64 row
     // tiles + these slabs, two workgroups per CU).  Keep the sum within the 512 resident workgroups of the chip — a
@@ -148,7 +172,7 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     g.ny = (int)ceil_div(I, kIT);
     g.nz = (int)ceil_div(O, kOT);
     g.part_w_floats = (int64_t)g.n_slabs * g.ny * g.nz * kTile;
-    g.part_b_floats = (int64_t)g.n_slabs * g.nz * kOT;
+    g.part_b_floats = (int64_t)g.n_slabs * g.nz * kOT + kWgradHeaderFloats;  // + the mode header behind the bias partials
     return g;
 }
 
@@ -219,10 +243,11 @@ extern "C" int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* 
     const WgradGeom g = wgrad_geom(N, O, I);
     float* part_w = (float*)ws;
     float* part_b = part_w + g.part_w_floats;
-    hipLaunchKernelGGL(wgrad_partial_kernel<false>, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, G, ldg, X, ldx, N,
-                       (int)O, (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr, WgradSynth{});
+    float* header = part_b + g.part_b_floats - kWgradHeaderFloats;
+    hipLaunchKernelGGL((wgrad_partial_kernel<false, false>), dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, G, ldg, X, ldx, N,
+                       (int)O, (int)I, g.rows_per_slab, part_w, db ? part_b : nullptr, header, WgradSynth{});
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st,
-                       part_w, part_b, g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
+                       part_w, part_b, g.n_slabs, g.ny, g.nz, (int)O, (int)I, dW, lddw, db, accumulate);
     return launch_status("glass_linear_wgrad_f32");
 }
 
@@ -256,11 +281,21 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     const WgradGeom g = wgrad_geom(N, O, I);
     float* part_w = (float*)ws;
     float* part_b = part_w + g.part_w_floats;
-    hipLaunchKernelGGL(wgrad_partial_kernel<true>, dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X, ldx,
-                       N, (int)O, (int)I, g.rows_per_slab, part_w, (db || !dW) ? part_b : nullptr, sy);
+    float* header = part_b + g.part_b_floats - kWgradHeaderFloats;
+    // comb pair (virtual concatenation as the input, no activation factor) with an even number of output tiles: the
+    // effective-weight form of the partials (wgrad_common.h) — half the matrix work; the labeled-row list of a slab must
+    // fit the workgroup's LDS image area
+    const bool eff = X2 != nullptr && act == GLASS_ACT_NONE && I == O && O == 2 * H && g.nz % 2 == 0 &&
+                     g.rows_per_slab <= 2 * kTile - 64;
+    if (eff)
+        hipLaunchKernelGGL((wgrad_partial_kernel<true, true>), dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X,
+                           ldx, N, (int)O, (int)I, g.rows_per_slab, part_w, (db || !dW) ? part_b : nullptr, header, sy);
+    else
+        hipLaunchKernelGGL((wgrad_partial_kernel<true, false>), dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X,
+                           ldx, N, (int)O, (int)I, g.rows_per_slab, part_w, (db || !dW) ? part_b : nullptr, header, sy);
     if (dW)  // dW == NULL: partial sums only; the caller reduces later with glass_linear_wgrad_reduce_batch_f32
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st, part_w,
-                           part_b, g.n_slabs, g.ny, (int)O, (int)I, dW, lddw, db, accumulate);
+                           part_b, g.n_slabs, g.ny, g.nz, (int)O, (int)I, dW, lddw, db, accumulate);
     return launch_status("glass_dual_linear_wgrad_f32");
 }
 

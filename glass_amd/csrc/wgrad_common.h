@@ -40,15 +40,21 @@ __device__ __forceinline__ int acc_index(int t, int u, int reg, int lane) { retu
 // lds: 2 * kTile floats (two wave-sized accumulator images), lds_b: 8 * kOT floats (bias partials [wave*2 + h][o]).
 // kStages: pipeline stages of raw loads kept in flight (4 on large graphs; 2 in the fused backward launch of small
 // graphs, where a slab holds only a few stages and registers decide whether two workgroups share a CU).
-template <bool SYNTH, int kStages>
+// EFF (comb pair, no activation factor; gz = number of output tiles, even): effective-weight form of the partials, as in
+// wgrad_tiled.hip — output tiles bz < gz/2 hold S = sum over ALL rows of dc^T X (coefficient 1), tiles bz >= gz/2 hold
+// L = the same sum over the slab's LABELED rows, found once per workgroup (ordered list in LDS) and walked through the
+// same pipeline; the reduce kernels form dW1 = (1-z) S + (2z-1) L, dW0 = z S - (2z-1) L from the mode header.
+constexpr int kWgradHeaderFloats = 4;  // behind the bias partials: [0] = 1.0f in effective-weight form, [1] = z_ratio
+template <bool SYNTH, int kStages, bool EFF = false>
 __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, int64_t ldg,
                                                    const float* __restrict__ X, int64_t ldx, int64_t N, int O, int I,
                                                    int rows_per_slab, float* __restrict__ part_w,
                                                    float* __restrict__ part_b, const WgradSynth& sy, int bx, int by, int bz,
-                                                   int gx, int gy, float* lds, float* lds_b) {
+                                                   int gx, int gy, float* lds, float* lds_b, int gz = 0) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int o0 = bz * kOT + 4 * c;   // this lane's 4 outputs
+    const bool lab_tile = EFF && bz >= gz / 2;
+    const int o0 = (lab_tile ? bz - gz / 2 : bz) * kOT + 4 * c;   // this lane's 4 outputs
     const int i0 = by * kIT + 2 * c;   // this lane's 2 inputs
     const bool o_ok = o0 < O, i_ok = i0 < I;   // O % 4 == 0 and I % 2 == 0 (checked on the host)
     const int64_t r0 = (int64_t)bx * rows_per_slab;
@@ -78,12 +84,37 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
     };
     Stage st[kStages];
     const bool first = o0 < sy.H;  // SYNTH: this lane's four outputs lie in the f1 half
+    // EFF, labeled-rows tile: the slab's labeled rows in row order (LDS, over the accumulator images, which are only
+    // written after the loop); the pipeline then walks list positions instead of rows
+    int* lab_list = reinterpret_cast<int*>(lds);
+    int n_lab = 0;
+    if (lab_tile) {
+        int* cnt = lab_list + 2 * kTile - 8;  // per-wave counts at the far end of the image area
+        const int span = (int)(r1 - r0);
+        int base = 0;
+        for (int c0 = 0; c0 < span; c0 += kBlock) {  // chunks of 256 rows, ordered compaction by wave ballots
+            const int64_t n = r0 + c0 + (int)threadIdx.x;
+            const bool flag = c0 + (int)threadIdx.x < span && sy.mask[n] != 0;
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) cnt[w] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int ww = 0; ww < w; ++ww) off += cnt[ww];
+            if (flag) lab_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = c0 + (int)threadIdx.x;
+            base += cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            __syncthreads();
+        }
+        n_lab = base;
+    }
+    const int64_t r_end = lab_tile ? r0 + n_lab : r1;  // the pipeline's row counter runs over [r0, r_end)
     auto load_stage = [&](int64_t nb, Stage& S) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int64_t want = nb + h + 8 * s;
+            const int64_t pos = nb + h + 8 * s;
+            const bool in = pos < r_end;
+            const int64_t want = !lab_tile ? pos : (in ? r0 + lab_list[pos - r0] : r1);
             const int64_t nn = want < r1 ? want : r1 - 1;
-            S.live[s] = want < r1;
+            S.live[s] = in && want < r1;
             S.g[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             S.x[s] = make_float2(0.f, 0.f);
             if (!SYNTH) {
@@ -102,13 +133,13 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
     const int64_t nb0 = r0 + 2 * w;  // wave-uniform (MFMA needs every lane in the loop)
 #pragma unroll
     for (int k = 0; k < kStages; ++k) load_stage(nb0 + 16 * k, st[k]);
-    for (int64_t nb = nb0; nb < r1; nb += 16 * kStages) {
+    for (int64_t nb = nb0; nb < r_end; nb += 16 * kStages) {
 #pragma unroll
         for (int k = 0; k < kStages; ++k) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 float4 g = st[k].g[s];
-                if (SYNTH) {
+                if (SYNTH && !EFF) {
                     const float cf = ((st[k].mk[s] != 0) == first) ? sy.zr : sy.omz;
                     g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
                     if (sy.act == GLASS_ACT_ELU) {
@@ -133,6 +164,7 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
     }
 
     // ---- combine the 4 waves through LDS: waves 0,1 store; waves 2,3 add; everyone sums the pair ----
+    if (lab_tile) __syncthreads();  // the row list lies in the image area: every wave is done reading it
     if (w < 2) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
