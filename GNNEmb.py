@@ -9,6 +9,7 @@ best trial's embeddings go to `<path><name>_64.pt`, the file `GLASSTest.py --use
     python GNNEmb.py --use_nodeid --device 0 --dataset density --name density --optruns 3
 """
 import argparse
+import os
 import functools
 import itertools
 import random
@@ -143,6 +144,9 @@ def main(argv=None):
         score, emb = run.work(64, params["conv_layer"], params["dropout"], False, 1e-3, 131072, params["aggr"])
         print(f"trial {trial} params {params} score {score}", flush=True)
         if score > best_score:
+            out_dir = os.path.dirname(f"{args.path}{args.name}_64.pt")
+            if out_dir:
+                os.makedirs(out_dir, exist_ok=True)  # a fresh checkout has no Emb/ directory
             torch.save(emb, f"{args.path}{args.name}_64.pt")
             best_score, best_params = score, params
     print("best params ", best_params)
