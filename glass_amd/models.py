@@ -68,6 +68,13 @@ class Seq(nn.Module):
         return out
 
 
+class Linear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) whose weight gradient runs on the split-K MFMA kernel
+    (ops.LinearFn) — for layers applied to every node or to a large edge batch."""
+    def forward(self, x):
+        return ops.linear(x, self)
+
+
 class MLP(nn.Module):
     """Linear / GraphNorm / Dropout / activation stack with the reference's layer ordering
     (only GNNEmb / GNNSeg use it; GLASSTest's head is a bare nn.Linear)."""
@@ -84,7 +91,7 @@ class MLP(nn.Module):
         dims = [input_channels] + [hidden_channels] * (num_layers - 1) + [output_channels]
         mods = []
         for i in range(num_layers):
-            mods.append(nn.Linear(dims[i], dims[i + 1]))
+            mods.append(Linear(dims[i], dims[i + 1]))
             if i + 1 < num_layers or tail_activation:
                 mods += tail(dims[i + 1])
         self.seq = Seq(mods)
@@ -353,8 +360,8 @@ class MyGCNConv(nn.Module):
     """Unlabeled message-passing layer: comb_fn([GraphNorm(adj @ act(trans_fn(x_))) || x_])."""
     def __init__(self, in_channels: int, out_channels: int, activation=nn.ReLU(inplace=True), aggr="mean"):
         super().__init__()
-        self.trans_fn = nn.Linear(in_channels, out_channels)
-        self.comb_fn = nn.Linear(in_channels + out_channels, out_channels)
+        self.trans_fn = Linear(in_channels, out_channels)
+        self.comb_fn = Linear(in_channels + out_channels, out_channels)
         self.adj = None
         self.activation = activation
         self.aggr = aggr

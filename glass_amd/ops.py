@@ -264,6 +264,41 @@ def linear_wgrad(G, X, dW, db, accumulate, slot=0):
     return True
 
 
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b for a plain nn.Linear whose weight gradient reduces over MANY rows into a tiny [O, I] output (the
+    SSL pre-training path's MyGCNConv / MLP layers over all nodes or a 131 072-edge batch): forward and dx are library
+    GEMMs through torch, dW / db the split-K MFMA kernel (glass_linear_wgrad_f32) — the library takes 160-290 us per
+    such weight gradient at ppi_bp-shape (rocprofv3: 44 % of a pre-training step), the kernel 20-40."""
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, W.t()) if b is not None else x @ W.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dx = dy @ W if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1]:
+            dyc, xc = dy.contiguous(), x.contiguous()
+            dW = torch.empty_like(W)
+            db = torch.empty(W.shape[0], dtype=W.dtype, device=W.device) if ctx.has_bias else None
+            if not (dyc.is_cuda and linear_wgrad(dyc, xc, dW, db, accumulate=False, slot=("linear", W.shape))):
+                dW = dyc.t() @ xc
+                db = dyc.sum(0) if ctx.has_bias else None
+        elif ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(0)
+        return dx, dW, db
+
+
+def linear(x, lin):
+    """nn.Linear forward through LinearFn (2-D CUDA fp32 inputs; anything else: torch's own)."""
+    if x.dim() == 2 and x.is_cuda and x.dtype == torch.float32 and lin.weight.dtype == torch.float32:
+        return LinearFn.apply(x, lin.weight, lin.bias)
+    return torch.nn.functional.linear(x, lin.weight, lin.bias)
+
+
 def _wgrad_supported(G, X, dW):
     O, I = G.shape[1], X.shape[1]
     return not (O % 4 or I % 2 or G.stride(0) % 4 or X.stride(0) % 2 or G.data_ptr() % 16 or X.data_ptr() % 8 or
