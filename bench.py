@@ -135,7 +135,8 @@ class _BracketLib:
 
     def __getattr__(self, name):
         fn = getattr(self._lib, name)
-        if not name.endswith("_f32") and name not in ("glass_maxzoz_i64", "glass_copy_pair", "glass_rng_advance"):
+        if not name.endswith("_f32") and name not in ("glass_maxzoz_i64", "glass_copy_pair", "glass_rng_advance",
+                                                      "glass_batch_labels"):
             return fn
         sink = self._sink
 

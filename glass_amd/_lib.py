@@ -24,7 +24,7 @@ AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
 ACT_NONE, ACT_ELU = 0, 1
 PLAN_HEADER_WORDS = 16
 EMBED_NORM_MAX_ROWS = 8192  # GLASS_EMBED_NORM_MAX_ROWS
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GlassHipError(RuntimeError):
@@ -85,6 +85,14 @@ SIGNATURES = {
     "glass_dual_linear_fwd_layout": (c_int, [_I, _I]),
     "glass_head_loss_fwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _I, _I, _I, _P, _P, _P, _P]),
     "glass_head_loss_bwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _P, _I, _I, _I, _P, _I, _P, _P, c_int, _P]),
+    "glass_batch_labels_ws_bytes": (c_int64, [_I]),
+    "glass_batch_labels": (c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, c_int, _P]),
+    "glass_comb_eff_supported": (c_int, [_I]),
+    "glass_comb_eff_blocks": (c_int64, [_I, _I, _I]),
+    "glass_comb_eff_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, _P, _I, _I, _I, _P, _P, c_int, c_float, _P,
+                                       c_uint64, _P, _I, _P, _P, _I, _P]),
+    "glass_comb_eff_bwd_f32": (c_int, [_P, _I, _P, c_double, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, c_int, c_float, _P,
+                                       c_uint64, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "glass_adam_step_f32": (c_int, [_P, _P, _P, _P, _I, _P, c_double, c_double, c_double, c_double, _P, _P]),
 }
 

@@ -96,6 +96,7 @@ class ParamArena(FlatGradBucket):
         for mod in model.modules():
             if isinstance(mod, GLASSConv):
                 mod._stack = {}
+                mod._stack_eff = {}
             if isinstance(mod, GraphNorm):
                 mod._direct_grad = True
         stacks = {}
@@ -126,10 +127,16 @@ class ParamArena(FlatGradBucket):
                     flay = int(_lib.load().glass_dual_linear_fwd_layout(O // 2, K))  # 5: same appendix for the forward
                     Wimg = torch.empty(W.numel() * 3 // 2 if flay == 5 else W.numel(), dtype=W.dtype, device=W.device)
                     WTimg = torch.empty(W.numel() * 3 // 2 if dlay == 4 else W.numel(), dtype=W.dtype, device=W.device)
-                    zr = float(getattr(mod, "z_ratio", 0.0))
-                    self._packs.append((W, Wimg, O, K, 0 | (flay << 1), zr))
-                    self._packs.append((W, WTimg, K, O, 1 | (dlay << 1), zr))
+                    self._packs.append((W, Wimg, O, K, 0 | (flay << 1), mod))
+                    self._packs.append((W, WTimg, K, O, 1 | (dlay << 1), mod))
                     mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)
+                    if kind == "comb" and K == O and _lib.load().glass_comb_eff_supported(O // 2):
+                        # hidden 64: the comb pair's effective per-label weights (layouts 6 / 7: unlabeled-row image, then
+                        # labeled-row image) for glass_comb_eff_fwd/bwd_f32 — taken when the batch's labeled rows are listed
+                        We, WTe = torch.empty_like(Wimg), torch.empty_like(WTimg)
+                        self._packs.append((W, We, O, K, 0 | (6 << 1), mod))
+                        self._packs.append((W, WTe, K, O, 1 | (7 << 1), mod))
+                        mod._stack_eff = {"comb": (We, WTe)}
                 else:
                     mod._stack[kind] = (W, b, dW, db)
         import numpy as np
@@ -138,7 +145,7 @@ class ParamArena(FlatGradBucket):
                            np.array([p[2] for p in self._packs], dtype=np.int64),
                            np.array([p[3] for p in self._packs], dtype=np.int64),
                            np.array([p[4] for p in self._packs], dtype=np.int32),
-                           np.array([p[5] for p in self._packs], dtype=np.float32), len(self._packs))
+                           np.zeros(len(self._packs), dtype=np.float32), len(self._packs))
         from .models import EmbZGConv
         for mod in model.modules():
             if isinstance(mod, EmbZGConv):
@@ -151,6 +158,8 @@ class ParamArena(FlatGradBucket):
         ops.rng_state): advanced by the same launch — the two once-per-step prologue jobs share it."""
         src, dst, nt, kt, tr, zr, k = self._pack_args
         from . import _lib, ops
+        for i, p in enumerate(self._packs):  # the pairs' CURRENT z_ratio (the kernels receive the live value as well)
+            zr[i] = float(getattr(p[5], "z_ratio", 0.0))
         if k == 0 and rng_state is not None:
             ops.rng_advance(rng_state.device)
         for i in range(0, k, 16):

@@ -535,6 +535,298 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
                                 t / (gx * gy), gx, gy, lds, lds + 2 * kTile);
 }
 
+// ---- comb pair through effective per-label weights (hidden 64) ------------------------------------------------------
+// The comb pair has no activation between its two Linear layers and the label mix (reference impl/models.py:169-173), and
+// the mix weights take two values per row, so
+//     y[r] = w1(r) * C1[r] + w0(r) * C0[r] = [g || x_][r] . (w1 W1 + w0 W0)^T + (w1 b1 + w0 b0):
+// ONE product per row with one of two effective weights.  At hidden 64 a launch lasts as long as its slowest wave (one
+// wave per SIMD), so the saving only shows when EVERY wave runs the short path: all row tiles multiply the unlabeled-row
+// weight W_unl = (1-z) W1 + z W0 and do not store their labeled rows; the unique labeled rows of the batch (LabRows, from
+// glass_batch_labels) are gathered 16 per wave by a few extra workgroups of the same launch, which multiply W_lab and
+// store them.  Every row is written exactly once (no atomics, no ordering between workgroups), the GraphNorm statistics
+// of the output come from both kinds of workgroup (one partial each).  Half the MFMAs, half the weight staging, no mix
+// in the epilogue; results differ from the two-product form by rounding only.
+struct EffRows {
+    int64_t row;      // this lane's A-operand row (-1: none)
+    int32_t erow[4];  // rows of this lane's accumulator registers (-1: not stored by this workgroup)
+    bool extra;
+};
+
+// Workgroup-uniform early exit for extra workgroups beyond the list: returns false.
+template <int RW>
+__device__ __forceinline__ bool eff_rows(EffRows& R, int block, const uint8_t* __restrict__ mask, int64_t N,
+                                         const LabRows& lab, int w, int i, int q) {
+    R.extra = block >= lab.n_main;
+    if (!R.extra) {
+        const int64_t row0 = ((int64_t)block * RW + w) * 16;
+        R.row = row0 + i < N ? row0 + i : -1;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int64_t r = row0 + 4 * q + reg;
+            R.erow[reg] = (r < N && mask[r] == 0) ? (int32_t)r : -1;
+        }
+        return true;
+    }
+    const int n_lab = lab.count[0];
+    const int base = ((block - lab.n_main) * RW + w) * 16;
+    if ((block - lab.n_main) * RW * 16 >= n_lab) return false;
+    R.row = base + i < n_lab ? lab.rows[base + i] : -1;
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int k = base + 4 * q + reg;
+        R.erow[reg] = k < n_lab ? lab.rows[k] : -1;
+    }
+    return true;
+}
+
+template <int H, int RW>
+__global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* __restrict__ xa, int64_t lda,
+                                                                 const float* __restrict__ xb, int64_t ldb,
+                                                                 const float* __restrict__ Wimg,
+                                                                 const float* __restrict__ bias,
+                                                                 const uint8_t* __restrict__ mask, float zr, float omz,
+                                                                 float* __restrict__ out, int64_t ldo, int64_t N,
+                                                                 double* __restrict__ stats, GnPrologue pro, LabRows lab) {
+    constexpr int KT = 2 * H, KQ = KT / 4, NT = H, NLOC = NT / 16;
+    constexpr int THREADS = kWave * RW;
+    static_assert(H == 64, "one 64-column group per wave");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    EffRows R;
+    if (!eff_rows<RW>(R, blockIdx.x, mask, N, lab, w, i, q)) {  // extra workgroup beyond the list: an empty partial
+        if (stats)
+            for (int c = threadIdx.x; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
+        return;
+    }
+    const bool row_ok = R.row >= 0;
+    const int64_t row = row_ok ? R.row : 0;
+    const float* arow = (q < 2) ? xa + row * lda + q * KQ : xb + row * ldb + (q - 2) * KQ;  // KQ = H/2
+    const float* W = Wimg + (R.extra ? NT * KT : 0);
+    const float c1 = R.extra ? zr : omz, c0 = R.extra ? omz : zr;  // weights of the f1 / f0 halves for this kind of row
+    // bias of the effective Linear, fetched before the product (the epilogue then waits for nothing)
+    const float4 b1 = *reinterpret_cast<const float4*>(bias + 4 * i), b0 = *reinterpret_cast<const float4*>(bias + H + 4 * i);
+    extern __shared__ float4 lds_w[];
+    f32x4 acc[NLOC];
+#pragma unroll
+    for (int t = 0; t < NLOC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    const bool pro_lane = pro.saved != nullptr && row_ok && q < 2;  // lanes whose chunk belongs to xa
+    GnPrologue pro_w = pro;
+    if (R.extra) pro_w.side = nullptr;  // the row's own tile wrote the normalised operand
+    staged_product<NT, KT, NLOC, NLOC, THREADS, FwdRaw>(
+        acc, W, lds_w, lane, 0, 0,
+        [&](int kc, FwdRaw& raw) __attribute__((always_inline)) {
+            load16(raw.x, arow + kc * kKC, row_ok);
+            if (pro_lane) {
+                const int col0 = q * KQ + kc * kKC;
+#pragma unroll
+                for (int v = 0; v < kKC / 4; ++v) {
+                    raw.sc[v] = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + col0 + 4 * v);
+                    raw.sh[v] = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + col0 + 4 * v);
+                }
+            }
+        },
+        [&](int kc, const FwdRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s2 = 0; s2 < kKC; ++s2) a[s2] = raw.x[s2];
+            if (pro_lane) gn_prologue16(a, raw, pro_w, drop, row, q * KQ + kc * kKC);
+        });
+    // epilogue: acc[k][reg] is row erow[reg], column 4i + k
+    const float be[4] = {c1 * b1.x + c0 * b0.x, c1 * b1.y + c0 * b0.y, c1 * b1.z + c0 * b0.z, c1 * b1.w + c0 * b0.w};
+    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        if (R.erow[reg] < 0) continue;
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            o[k] = acc[k][reg] + be[k];
+            ssum[k] += o[k];
+            ssq[k] = fmaf(o[k], o[k], ssq[k]);
+        }
+        *reinterpret_cast<float4*>(out + (int64_t)R.erow[reg] * ldo + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (stats == nullptr) return;
+    __syncthreads();  // every wave is done with the weight images in LDS
+    double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double s = (double)ssum[k], q2 = (double)ssq[k];
+        s += __shfl_xor(s, 16);
+        q2 += __shfl_xor(q2, 16);
+        s += __shfl_xor(s, 32);
+        q2 += __shfl_xor(q2, 32);
+        if (q == 0) {
+            red[(w * H + 4 * i + k) * 2] = s;
+            red[(w * H + 4 * i + k) * 2 + 1] = q2;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += THREADS) {
+        double s = 0.0, q2 = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < RW; ++ww) {
+            s += red[(ww * H + c) * 2];
+            q2 += red[(ww * H + c) * 2 + 1];
+        }
+        stats[((size_t)blockIdx.x * 2) * H + c] = s;
+        stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+    }
+}
+
+// Data gradient of the comb pair in the same form:  d[g || x_][r] = dc[r] . (w1 W1 + w0 W0): K = H instead of 2H (one
+// K pass), the mix coefficient folded into the weight.  The first H output columns are the gradient of conv.gn's output:
+// its backward column sums are accumulated by the epilogue as in dual_dgrad_body (one partial per workgroup, the extra
+// ones included).
+struct DgradEffArgs {
+    const float* dsrc; int64_t ldd;
+    const uint8_t* mask;
+    const float* WT;  // unl | lab images
+    const uint64_t* rng_state;
+    float* out; int64_t ldo;
+    int64_t N;
+    GnBwdStats gs;
+    LabRows lab;
+};
+
+struct DcRaw {
+    float d[kKC];
+};
+
+template <int H, int RW>
+__device__ __forceinline__ void comb_dgrad_eff_body(const float* __restrict__ dsrc, int64_t ldd,
+                                                    const uint8_t* __restrict__ mask, const float* __restrict__ WT,
+                                                    const uint64_t* __restrict__ rng_state, float* __restrict__ out,
+                                                    int64_t ldo, int64_t N, GnBwdStats gs, LabRows lab, int block,
+                                                    float4* lds_w) {
+    constexpr int KT = H, KQ = KT / 4, NT = 2 * H, NGL = NT / 64, NLOC = 4 * NGL;
+    constexpr int THREADS = kWave * RW;
+    static_assert(H == 64 && KQ == kKC, "one K pass of 64");
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int i = lane & 15, q = lane >> 4;
+    EffRows R;
+    if (!eff_rows<RW>(R, block, mask, N, lab, w, i, q)) {  // extra workgroup beyond the list: an empty partial
+        if (gs.partial)
+            for (int c = threadIdx.x; c < 2 * H; c += THREADS) gs.partial[(size_t)block * 2 * H + c] = 0.0;
+        return;
+    }
+    const bool row_ok = R.row >= 0;
+    const float* drow = dsrc + (row_ok ? R.row : 0) * ldd + q * KQ;
+    const float* W = WT + (R.extra ? NT * KT : 0);
+    f32x4 acc[NLOC];
+#pragma unroll
+    for (int t = 0; t < NLOC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 g_mu, g_rstd, g_scale, g_shift, g_al;
+    if (gs.partial) {  // before the product: the epilogue then waits for the GraphNorm input rows only
+        if (gs.drop.p > 0.f) {
+            gs.drop.seed = rng_state[0];
+            gs.drop.step = rng_state[1];
+        }
+        g_mu = *reinterpret_cast<const float4*>(gs.saved + 4 * i);
+        g_rstd = *reinterpret_cast<const float4*>(gs.saved + H + 4 * i);
+        g_scale = *reinterpret_cast<const float4*>(gs.saved + 2 * H + 4 * i);
+        g_shift = *reinterpret_cast<const float4*>(gs.saved + 3 * H + 4 * i);
+        g_al = *reinterpret_cast<const float4*>(gs.alpha + 4 * i);
+    }
+    staged_product<NT, KT, NLOC, NLOC, THREADS, DcRaw>(
+        acc, W, lds_w, lane, 0, 0,
+        [&](int kc, DcRaw& raw) __attribute__((always_inline)) { load16(raw.d, drow + kc * kKC, row_ok); },
+        [&](int, const DcRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s = 0; s < kKC; ++s) a[s] = raw.d[s];
+        });
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        if (R.erow[reg] < 0) continue;
+        const int64_t r = R.erow[reg];
+#pragma unroll
+        for (int gl = 0; gl < NGL; ++gl) {
+            const int c = 64 * gl + 4 * i;
+            const float4 v = make_float4(acc[4 * gl][reg], acc[4 * gl + 1][reg], acc[4 * gl + 2][reg], acc[4 * gl + 3][reg]);
+            *reinterpret_cast<float4*>(out + r * ldo + c) = v;
+            if (gs.partial && gl == 0) {
+                const float4 x4 = *reinterpret_cast<const float4*>(gs.x + r * gs.ldx + c);
+                const float xv[4] = {x4.x, x4.y, x4.z, x4.w}, dy[4] = {v.x, v.y, v.z, v.w};
+                const float mu[4] = {g_mu.x, g_mu.y, g_mu.z, g_mu.w}, rs[4] = {g_rstd.x, g_rstd.y, g_rstd.z, g_rstd.w};
+                const float sc[4] = {g_scale.x, g_scale.y, g_scale.z, g_scale.w};
+                const float sh[4] = {g_shift.x, g_shift.y, g_shift.z, g_shift.w};
+                const float al[4] = {g_al.x, g_al.y, g_al.z, g_al.w};
+                float ds[4] = {1.f, 1.f, 1.f, 1.f};
+                if (gs.drop.p > 0.f) drop_scales<4>(gs.drop, r, c, ds);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float gp = dy[k] * ds[k];
+                    if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv[k], sc[k], sh[k]));
+                    const float xhat = (xv[k] - al[k] * mu[k]) * rs[k];
+                    s1[k] += gp;
+                    s2[k] = fmaf(gp, xhat, s2[k]);
+                }
+            }
+        }
+    }
+    if (gs.partial == nullptr) return;
+    __syncthreads();  // every wave is done with the weight image in LDS
+    double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        double a = (double)s1[k], b2 = (double)s2[k];
+        a += __shfl_xor(a, 16);
+        b2 += __shfl_xor(b2, 16);
+        a += __shfl_xor(a, 32);
+        b2 += __shfl_xor(b2, 32);
+        if (q == 0) {
+            red[(w * H + 4 * i + k) * 2] = a;
+            red[(w * H + 4 * i + k) * 2 + 1] = b2;
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += THREADS) {
+        double a = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int ww = 0; ww < RW; ++ww) {
+            a += red[(ww * H + c) * 2];
+            b2 += red[(ww * H + c) * 2 + 1];
+        }
+        gs.partial[((size_t)block * 2) * H + c] = a;
+        gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
+    }
+}
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void comb_dgrad_eff_kernel(DgradEffArgs A) {
+    extern __shared__ float4 lds_w[];
+    comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, blockIdx.x, lds_w);
+}
+
+// Fused backward launch of the comb pair in effective-weight form: data-gradient row tiles (main + extra), then the
+// weight-gradient slabs (dual_bwd_kernel's second branch).
+template <int H>
+__global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A, int n_dgrad_blocks,
+                                                                const float* __restrict__ X, int64_t ldx, int O, int I,
+                                                                int rows_per_slab, int gx, int gy,
+                                                                float* __restrict__ part_w, float* __restrict__ part_b,
+                                                                float* __restrict__ wg_header, WgradSynth sy) {
+    extern __shared__ float4 lds_w[];
+    const int b = blockIdx.x;
+    if (b == 0 && threadIdx.x == 0) {  // the partials below are in the plain form (mode header read by the reduce launch)
+        wg_header[0] = 0.f;
+        wg_header[1] = sy.zr;
+    }
+    if (b < n_dgrad_blocks) {
+        comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, b, lds_w);
+        return;
+    }
+    const int t = b - n_dgrad_blocks;
+    float* lds = reinterpret_cast<float*>(lds_w);
+    wgrad_partial_body<true, 2>(nullptr, 0, X, ldx, A.N, O, I, rows_per_slab, part_w, part_b, sy, t % gx, (t / gx) % gy,
+                                t / (gx * gy), gx, gy, lds, lds + 2 * kTile);
+}
+
 // ---- packing of the stacked weights into MFMA images (one launch for the whole model, once per step) ------
 // job: logical operand B[NT][KT] (row = output column of the product, col = k).  transposed == 0: B = src
 // ([NT][KT] row-major, the forward weight [2H][K]); transposed == 1: B[n][k] = src[k][n] with src [KT][NT]
@@ -567,6 +859,27 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
             const int lane = l & 63, v = (l >> 6) & 3, t = (l >> 8) % NTILES, kc = (l >> 8) / NTILES;
             const int jj = lane & 15, q = lane >> 4;
             reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tile_col(t, jj), q * KQ + kc * kKC + 4 * v);
+        }
+        return;
+    }
+    if (j.layout == kLayoutWave16EffFwd || j.layout == kLayoutWave16EffDgrad) {
+        // comb pair, hidden 64: two wave16 images of the effective weights c1 * (f1 half) + c0 * (f0 half) — unlabeled rows
+        // (c1, c0) = (1-z, z), then labeled rows (z, 1-z).  Forward: the halves are the two row blocks of B (NT/2 outputs
+        // each); data gradient (transposed source): the two halves of k (the stacked output index of the pair).
+        const bool fwd = j.layout == kLayoutWave16EffFwd;
+        const int NTe = fwd ? j.NT / 2 : j.NT, KTe = fwd ? j.KT : j.KT / 2;
+        const int KQ = KTe / 4, NTILES = NTe / 16, per = NTe * KTe / 4;
+        const float zr = j.zr, omz = 1.f - j.zr;
+        for (int l = blockIdx.x * kBlock + threadIdx.x; l < 2 * per; l += gridDim.x * kBlock) {
+            const int img = l >= per, ll = img ? l - per : l;
+            const int lane = ll & 63, v = (ll >> 6) & 3, t = (ll >> 8) % NTILES, kc = (ll >> 8) / NTILES;
+            const int jj = lane & 15, q = lane >> 4;
+            const int n = tile_col(t, jj), k = q * KQ + kc * kKC + 4 * v;
+            const float4 a = pack_fetch(j, n, k);
+            const float4 b = fwd ? pack_fetch(j, j.NT / 2 + n, k) : pack_fetch(j, n, j.KT / 2 + k);
+            const float c1 = img ? zr : omz, c0 = img ? omz : zr;
+            reinterpret_cast<float4*>(j.dst)[l] = make_float4(c1 * a.x + c0 * b.x, c1 * a.y + c0 * b.y, c1 * a.z + c0 * b.z,
+                                                              c1 * a.w + c0 * b.w);
         }
         return;
     }
@@ -827,6 +1140,99 @@ extern "C" int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const f
                         n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, &wg, stream);
 }
 
+// ---- comb pair in effective-weight form (hidden 64; see comb_fwd_eff_kernel) -----------------------------------------
+extern "C" int glass_comb_eff_supported(int64_t H) { return H == 64 ? 1 : 0; }
+
+// workgroups of the launch = entries of `stats` / `gn_partial`: row tiles + extra workgroups for up to lab_cap listed rows
+extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap) {
+    if (H != 64 || n_nodes <= 0 || lab_cap < 0) return GLASS_E_ARG;
+    return ceil_div(n_nodes, 64) + ceil_div(lab_cap, 64);
+}
+
+extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,
+                                      const float* bias, const uint8_t* mask, double z_ratio, float* out, int64_t ldo,
+                                      int64_t n_nodes, int64_t H, double* stats, const float* gn_saved, int gn_act,
+                                      float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
+                                      int64_t ldxo, const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap,
+                                      void* stream) {
+    GLASS_REQUIRE(xa && xb && Wimg_eff && bias && mask && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
+                  "comb_eff_fwd: null pointer");
+    if (H != 64) {
+        set_error("comb_eff_fwd: hidden size %lld not supported (64)", (long long)H);
+        return GLASS_E_UNSUPPORTED;
+    }
+    GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved) &&
+                                p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
+                                (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                  "comb_eff_fwd: bad GraphNorm prologue arguments");
+    GLASS_REQUIRE(lda >= H && lda % 4 == 0 && aligned16(xa) && ldb >= H && ldb % 4 == 0 && aligned16(xb) &&
+                      aligned16(Wimg_eff) && aligned16(bias) && ldo >= H && ldo % 4 == 0 && aligned16(out),
+                  "comb_eff_fwd: operands must be 16-B aligned with ld %% 4 == 0");
+    const int n_main = (int)ceil_div(n_nodes, 64);
+    const dim3 grid((unsigned)(n_main + ceil_div(lab_cap, 64)));
+    const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
+    const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
+    const LabRows lab{lab_rows, lab_count, n_main};
+    const size_t lds = lds_bytes(H, 2);  // two K passes of the [H][2H] effective weight
+    hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
+                       bias, mask, zr, omz, out, ldo, n_nodes, stats, pro, lab);
+    return launch_status("glass_comb_eff_fwd_f32");
+}
+
+extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint8_t* mask, double z_ratio,
+                                      const float* WTimg_eff, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
+                                      double* gn_partial, const float* gn_x, int64_t gn_ldx, const float* gn_saved,
+                                      const float* gn_alpha, int gn_act, float gn_p_drop, const uint64_t* rng_state,
+                                      uint64_t gn_call_id, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
+                                      void* ws, const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap,
+                                      void* stream) {
+    GLASS_REQUIRE(dsrc && mask && WTimg_eff && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
+                  "comb_eff_bwd: null pointer");
+    if (H != 64) {
+        set_error("comb_eff_bwd: hidden size %lld not supported (64)", (long long)H);
+        return GLASS_E_UNSUPPORTED;
+    }
+    GLASS_REQUIRE(ldd >= H && ldd % 4 == 0 && aligned16(dsrc) && aligned16(WTimg_eff) && ldo >= 2 * H && ldo % 4 == 0 &&
+                      aligned16(out),
+                  "comb_eff_bwd: operands must be 16-B aligned with ld %% 4 == 0");
+    GLASS_REQUIRE(!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && gn_ldx % 4 == 0 && aligned16(gn_x) &&
+                                  aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
+                                  (gn_p_drop == 0.f || rng_state) && (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                  "comb_eff_bwd: bad GraphNorm statistics arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int n_main = (int)ceil_div(n_nodes, 64);
+    const unsigned n_dg = (unsigned)(n_main + ceil_div(lab_cap, 64));
+    const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
+    const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
+    const DgradEffArgs dargs{dsrc, ldd, mask, WTimg_eff, rng_state, out, ldo, n_nodes, gs, LabRows{lab_rows, lab_count, n_main}};
+    const size_t lds_dg = lds_bytes(2 * H, 1);  // one K pass of the [2H][H] effective weight
+    if (!X) {  // data gradient only
+        hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);
+        return launch_status("glass_comb_eff_bwd_f32 (dgrad)");
+    }
+    GLASS_REQUIRE(X2 && ws && ldx >= H && ldx % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 7u) == 0 && ldx2 >= H &&
+                      ldx2 % 2 == 0 && (reinterpret_cast<uintptr_t>(X2) & 7u) == 0,
+                  "comb_eff_bwd: the pair's inputs must be 8-B aligned with even leading dimensions");
+    const int64_t O = 2 * H, I = 2 * H;
+    if (n_nodes > kFusedBwdMaxRows || wgrad_tiled_shape(n_nodes, O, I)) {  // large graph: two launches
+        hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);
+        const int rc = launch_status("glass_comb_eff_bwd_f32 (dgrad)");
+        return rc ? rc : glass_dual_linear_wgrad_f32(dsrc, ldd, nullptr, 0, mask, z_ratio, GLASS_ACT_NONE, X, ldx, X2, ldx2,
+                                                     n_nodes, H, nullptr, 0, nullptr, 0, ws, stream);
+    }
+    const WgradGeom g = wgrad_geom(n_nodes, O, I);
+    float* part_w = (float*)ws;
+    const WgradSynth sy{dsrc, ldd, nullptr, 0, mask, zr, omz, GLASS_ACT_NONE, (int)H, X2, ldx2};
+    const size_t lds_wg = (size_t)(2 * kTile + 8 * kOT) * sizeof(float);
+    const size_t lds_fused = lds_dg > lds_wg ? lds_dg : lds_wg;
+    const unsigned blocks = n_dg + (unsigned)(g.n_slabs * g.ny * g.nz);
+    allow_lds(comb_bwd_eff_kernel<64>, lds_fused);
+    hipLaunchKernelGGL((comb_bwd_eff_kernel<64>), dim3(blocks), dim3(kBlock), lds_fused, st, dargs, (int)n_dg, X, ldx, (int)O,
+                       (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats,
+                       part_w + g.part_w_floats + g.part_b_floats - kWgradHeaderFloats, sy);
+    return launch_status("glass_comb_eff_bwd_f32");
+}
+
 extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,
                                           const int64_t* KT, const int32_t* transposed, const float* z_ratio,
                                           int64_t n_jobs, uint64_t* rng_state, void* stream) {
@@ -843,7 +1249,9 @@ extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const*
         GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
                           (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
                           (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio) ||
-                          (layout == kLayoutTiledPairedEff && NT[k] % 512 == 0 && !(transposed[k] & 1) && z_ratio),
+                          (layout == kLayoutTiledPairedEff && NT[k] % 512 == 0 && !(transposed[k] & 1) && z_ratio) ||
+                          (layout == kLayoutWave16EffFwd && NT[k] % 128 == 0 && !(transposed[k] & 1) && z_ratio) ||
+                          (layout == kLayoutWave16EffDgrad && KT[k] % 128 == 0 && (transposed[k] & 1) && z_ratio),
                       "dense_pack_batch: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
                       "layout that is not the transposed 128 x 256 operand", k, layout);
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f};

@@ -31,9 +31,21 @@ struct GnBwdStats {
     Drop drop;
 };
 
+// The unique labeled rows of the batch (glass_batch_labels): the comb pair in effective-weight form runs every row tile
+// with the unlabeled-row weight and `n_main` row tiles first, then ceil(cap / 64) extra workgroups that recompute the listed
+// rows with the labeled-row weight (the main tiles do not store those rows).
+struct LabRows {
+    const int32_t* rows;   // [cap] unique labeled node ids, first-occurrence order
+    const int32_t* count;  // device word: how many of them
+    int n_main;            // row-tile workgroups in front of the extra ones
+};
+
 // Operand-image layouts written by glass_dense_pack_batch_f32 (bits 1.. of its per-job flags; bit 0 = transposed source)
 enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2, kLayoutTiledSplit = 3, kLayoutTiledPlainEff = 4,
-       kLayoutTiledPairedEff = 5 };
+       kLayoutTiledPairedEff = 5, kLayoutWave16EffFwd = 6, kLayoutWave16EffDgrad = 7 };
+// kLayoutWave16EffFwd / EffDgrad (comb pair at hidden 64, dense.hip): TWO wave16 images back to back, of the effective weight
+// of unlabeled rows (1-z)*W1 + z*W0 and of labeled rows z*W1 + (1-z)*W0 — forward: [H outputs][2H inputs]; data gradient
+// (transposed source): [2H outputs of the product = inputs of the pair][H].  NT*KT floats, as the plain image.
 // kLayoutTiledPairedEff: the paired forward image of a comb pair followed by W_unl = (1-z)*W1 + z*W0 ([H][KT]) in the plain
 // tiling — row tiles without a labeled row produce 256 output columns per column tile from it
 // kLayoutTiledPlainEff: the plain data-gradient image of a comb pair followed by the image of its UNLABELED-row effective

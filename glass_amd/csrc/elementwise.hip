@@ -290,7 +290,7 @@ extern "C" int glass_embed_label_f32(const int64_t* x, const float* W, int64_t V
     GLASS_REQUIRE(x && W && out && mask, "embed_label: null pointer");
     GLASS_REQUIRE(n_nodes > 0 && H > 0 && V > 0 && ldo >= H, "embed_label: bad sizes");
     hipStream_t st = (hipStream_t)stream;
-    if (!z) {  // no z, no pos: all labeled
+    if (!z && !(pos == nullptr && n_pos < 0)) {  // no z, no pos: all labeled (n_pos < 0: mask is an input, left alone)
         int64_t fb = ceil_div(n_nodes, kBlock);
         if (fb > 2048) fb = 2048;
         hipLaunchKernelGGL(fill_u8_kernel, dim3((unsigned)fb), dim3(kBlock), 0, st, mask, n_nodes, (uint8_t)(pos ? 0 : 1));

@@ -214,13 +214,14 @@ extern "C" int glass_embed_norm_fwd_f32(const int64_t* x, const float* W, int64_
     hipStream_t st = (hipStream_t)stream;
     // no z: the table kernel fills the label bytes (0 when pos will be scattered by the gather kernel, else all 1)
     int64_t tab_blocks = ceil_div(H, kTabCols);
-    if (!z) {  // a few more workgroups share the byte fill
+    const bool mask_given = !z && !pos && n_pos < 0;  // the label bytes are an INPUT (glass_batch_labels wrote them)
+    if (!z && !mask_given) {  // a few more workgroups share the byte fill
         int64_t fill_blocks = ceil_div(n_nodes, (int64_t)kBlock * 16);
         if (fill_blocks > 64) fill_blocks = 64;
         if (fill_blocks > tab_blocks) tab_blocks = fill_blocks;
     }
     hipLaunchKernelGGL(emb_table_fwd_kernel, dim3((unsigned)tab_blocks), dim3(kBlock), 0, st, W, (int)V, (int)H,
-                       class_rowptr, gamma, beta, alpha, eps, saved, table, z ? nullptr : mask, pos ? 0 : 1, n_nodes);
+                       class_rowptr, gamma, beta, alpha, eps, saved, table, (z || mask_given) ? nullptr : mask, pos ? 0 : 1, n_nodes);
     const bool vec = H % 4 == 0 && ldo % 4 == 0 && aligned16(table) && aligned16(out);
     const int vw = vec ? 4 : 1;
     const int cw = (int)ceil_div(H, vw);

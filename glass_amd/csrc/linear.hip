@@ -160,7 +160,8 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     // tiles + these slabs, two workgroups per CU).  Keep the sum within the 512 resident workgroups of the chip — a
     // handful of surplus workgroups would wait for a free slot and run as a second round (28 vs ~21 us at ppi_bp-shape).
     if (N <= 100000) {
-        const int64_t room = (2 * 256 - 4 - ceil_div(N, 64)) / tiles;
+        // (- 20: the launch header's slack and up to 16 extra row tiles of the comb pair's labeled rows, glass_comb_eff_bwd_f32)
+        const int64_t room = (2 * 256 - 20 - ceil_div(N, 64)) / tiles;
         if (room >= 32 && room < max_slabs) max_slabs = room;
     }
     if (max_slabs < 32) max_slabs = 32;

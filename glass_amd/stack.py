@@ -36,6 +36,70 @@ def _check(rc, what):
     _lib.check(rc, what)
 
 
+USE_COMB_EFF = os.environ.get("GLASS_COMB_EFF", "1") != "0"  # A/B switch: comb pair through effective per-label weights
+
+
+class BatchLabels:
+    """Label state of one subgraph batch on the device (glass_batch_labels; utils.MaxZOZ, reference impl/utils.py:32-45):
+    the label bytes `mask` (maintained incrementally from batch to batch), the unique labeled rows `rows[:count]` in
+    first-occurrence order.  `cap` = capacity of the list = B * Smax (fixes the grids of the kernels that walk it)."""
+    def __init__(self, n_nodes, cap, device):
+        self.n, self.cap = int(n_nodes), int(cap)
+        self.mask = torch.zeros(self.n, dtype=torch.uint8, device=device)
+        self.rows = torch.zeros(max(self.cap, 1), dtype=torch.int32, device=device)
+        self.count = torch.zeros(4, dtype=torch.int32, device=device)
+        self.ws = torch.empty(self.n, dtype=torch.int32, device=device)
+        self.loaded = False
+
+    def load(self, pos_src, pos_dst=None, y_src=None, y_dst=None):
+        """Labels of `pos_src`; with pos_dst / y_dst the batch is also copied into those fixed buffers (pos_dst must hold
+        the PREVIOUS batch — all -1 before the first one — because its labels are cleared incrementally)."""
+        if pos_src.numel() != self.cap:
+            raise ValueError(f"BatchLabels: batch of {pos_src.numel()} entries, capacity {self.cap}")
+        yb = 0 if y_src is None else y_src.numel() * y_src.element_size()
+        incremental = 1 if pos_dst is not None else 0  # without fixed buffers the N label bytes are zero-filled each time
+        rc = _lib.load().glass_batch_labels(pos_src.data_ptr(), pos_src.numel(), 0 if pos_dst is None else pos_dst.data_ptr(),
+                                            0 if y_src is None else y_src.data_ptr(), 0 if y_dst is None else y_dst.data_ptr(),
+                                            yb, self.mask.data_ptr(), self.rows.data_ptr(), self.count.data_ptr(),
+                                            self.ws.data_ptr(), self.n, incremental, _stream())
+        _check(rc, "glass_batch_labels")
+        self.loaded = True
+
+
+def _comb_eff_ok(conv, labels, H):
+    return (USE_COMB_EFF and labels is not None and "comb" in getattr(conv, "_stack_eff", {}) and
+            bool(_lib.load().glass_comb_eff_supported(H)))
+
+
+def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
+    n, H = xa.shape
+    saved, gact, gp, gcall, xa_out = gn
+    grng = ops.rng_state(xa.device).data_ptr() if gp > 0 else 0
+    rc = _lib.load().glass_comb_eff_fwd_f32(xa.data_ptr(), xa.stride(0), xb.data_ptr(), xb.stride(0),
+                                            conv._stack_eff["comb"][0].data_ptr(), conv._stack["comb"][1].data_ptr(),
+                                            mask.data_ptr(), float(conv.z_ratio), out.data_ptr(), out.stride(0), n, H,
+                                            stats.data_ptr(), saved.data_ptr(), gact, float(gp), grng, gcall,
+                                            xa_out.data_ptr(), xa_out.stride(0), labels.rows.data_ptr(),
+                                            labels.count.data_ptr(), labels.cap, _stream())
+    _check(rc, "glass_comb_eff_fwd_f32")
+
+
+def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels):
+    n, H = dsrc.shape
+    gpart, gx, gsaved, galpha, gact, gp, gcall = gn
+    rng = ops.rng_state(dsrc.device).data_ptr() if gp > 0 else 0
+    stack = conv._stack["comb"]
+    ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, 2 * H, slot=("stack", len(pending)))
+    rc = _lib.load().glass_comb_eff_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), mask.data_ptr(), float(conv.z_ratio),
+                                            conv._stack_eff["comb"][1].data_ptr(), out.data_ptr(), out.stride(0), n, H,
+                                            gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(),
+                                            galpha.data_ptr(), gact, float(gp), rng, gcall, xa.data_ptr(), xa.stride(0),
+                                            xb.data_ptr(), xb.stride(0), ws.data_ptr(), labels.rows.data_ptr(),
+                                            labels.count.data_ptr(), labels.cap, _stream())
+    _check(rc, "glass_comb_eff_bwd_f32")
+    pending.append((ws.data_ptr(), n, 2 * H, 2 * H, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
+
+
 class _GN:
     """Launch helpers for one GraphNorm module (weights read in place; gradients accumulated in place)."""
     def __init__(self, mod):
@@ -263,7 +327,7 @@ class StackProgram:
             emb.input_emb.weight.grad is not None
 
     # ---------------------------------------------------------------------------------------------
-    def forward(self, x_flat, z, edge_index, edge_weight, keep, readout=None, acc=1):
+    def forward(self, x_flat, z, edge_index, edge_weight, keep, readout=None, acc=1, labels=None):
         """Returns (out, state).  keep=False (no gradient wanted): intermediates are dropped as soon as possible.
         readout = (pos, pool_mode, head Linear, target, loss_mode): instead of the final GraphNorm apply, run the
         fused training readout (K8r) — out = (loss, logits) and state carries the gradient of the JK buffer."""
@@ -284,11 +348,23 @@ class StackProgram:
               "stat_rows": int(lib.glass_dual_linear_stat_rows(H))}  # rows per workgroup of the fused dense kernels
         # labels: z (int64 [N], > 0 = labeled), None (all labeled), or ("pos", pos): labeled = the nodes listed in the
         # padded subgraph matrix — utils.MaxZOZ without materialising z (a byte memset + scatter inside the gather)
-        if isinstance(z, tuple):
+        # labels (BatchLabels, already loaded for this batch): the label bytes are an input and the unique labeled rows are
+        # listed — the comb pairs then run in effective-weight form at hidden 64.  With ("pos", pos) and no labels handed
+        # in, they are computed here (one extra launch; the replayed training step hands them in).
+        if isinstance(z, tuple) and labels is None and USE_COMB_EFF and train and \
+                any("comb" in getattr(c, "_stack_eff", {}) for c in emb.convs):
+            labels = BatchLabels(n, z[1].numel(), dev)
+            labels.load(z[1])
+        if labels is not None:
+            zp, pp, npos = 0, 0, -1
+            mask = labels.mask
+        elif isinstance(z, tuple):
             zp, pp, npos = 0, z[1].data_ptr(), z[1].numel()
+            mask = torch.empty(n, dtype=torch.uint8, device=dev)
         else:
             zp, pp, npos = (0 if z is None else z.data_ptr()), 0, 0
-        mask = torch.empty(n, dtype=torch.uint8, device=dev)
+            mask = torch.empty(n, dtype=torch.uint8, device=dev)
+        st["labels"] = labels
         h = torch.empty((n, H), **f32)
         st["mask"] = mask
         gn0 = emb.emb_gn
@@ -336,9 +412,13 @@ class StackProgram:
             last = l + 1 == L
             c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
             # the comb kernel's epilogue also leaves the column statistics of c for the GraphNorm(s) that read it
-            cstat = torch.empty((-(-n // st["stat_rows"]), 2, H), dtype=torch.float64, device=dev)
-            _dual_fwd(a, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c, cstat,
-                      gn=(gsaved, ACT_NONE, pc, conv.call_base, g))
+            if _comb_eff_ok(conv, labels, H):
+                cstat = torch.empty((int(lib.glass_comb_eff_blocks(n, H, labels.cap)), 2, H), dtype=torch.float64, device=dev)
+                _comb_eff_fwd(a, h, conv, mask, c, cstat, (gsaved, ACT_NONE, pc, conv.call_base, g), labels)
+            else:
+                cstat = torch.empty((-(-n // st["stat_rows"]), 2, H), dtype=torch.float64, device=dev)
+                _dual_fwd(a, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c, cstat,
+                          gn=(gsaved, ACT_NONE, pc, conv.call_base, g))
             cstats.append(cstat)
             rec = {"h": h, "T": T, "a": a, "g": g, "gsaved": gsaved, "c": c, "pc": pc}
             if not last:
@@ -413,9 +493,16 @@ class StackProgram:
                 _GN(emb.gns[l]).bwd_from_stats(dh_next, rec["c"], rec["nsaved"], dc, npart, ACT_ELU, p, conv.call_base + 1,
                                                addend=djk[:, l * H:(l + 1) * H] if emb.jk else None, acc=acc)
             din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
-            gpart = torch.empty((nblk, 2, H), **f64)  # conv.gn's backward column sums, from this kernel's epilogue
-            _dual_bwd(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din, rec["g"], rec["h"], pending,
-                      acc, gn=(gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base))
+            # conv.gn's backward column sums come from this kernel's epilogue
+            labels = st.get("labels")
+            if _comb_eff_ok(conv, labels, H):
+                gpart = torch.empty((int(_lib.load().glass_comb_eff_blocks(n, H, labels.cap)), 2, H), **f64)
+                _comb_eff_bwd(dc, conv, mask, din, rec["g"], rec["h"], pending, acc,
+                              (gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base), labels)
+            else:
+                gpart = torch.empty((nblk, 2, H), **f64)
+                _dual_bwd(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din, rec["g"], rec["h"],
+                          pending, acc, gn=(gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base))
             da = torch.empty((n, H), **f32)
             _GN(conv.gn).bwd_from_stats(din[:, :H], rec["a"], rec["gsaved"], da, gpart, ACT_NONE, rec["pc"], conv.call_base,
                                         acc=acc)
@@ -469,13 +556,14 @@ class StackProgram:
         return out
 
     def loss_and_grads(self, x_flat, z, edge_index, edge_weight, pos, pool_mode, head, target, loss_mode, overwrite=False,
-                       tail_hook=None):
+                       tail_hook=None, labels=None):
         """One training pass WITHOUT the autograd tape: forward, fused readout, backward; every parameter gradient
         (stack, final GraphNorm, head) is accumulated into the gradient arena — or, with overwrite=True, stored over
         whatever is there (no zero-fill of the arena needed when written_params() covers it).  Returns (loss, logits)."""
         with torch.no_grad():
             (loss, logits), st = self.forward(x_flat, z, edge_index, edge_weight, True,
-                                              readout=(pos, pool_mode, head, target, loss_mode), acc=0 if overwrite else 1)
+                                              readout=(pos, pool_mode, head, target, loss_mode), acc=0 if overwrite else 1,
+                                              labels=labels)
             self.backward(st, None, tail_hook)
         return loss, logits
 
@@ -524,7 +612,7 @@ def _program(emb):
     return prog
 
 
-def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, overwrite=False, tail_hook=None):
+def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, overwrite=False, tail_hook=None, labels=None):
     """(loss, logits) of model(x, ..., pos, z) under loss_fn, gradients accumulated in place (see step_supported).
     z = "pos": label the nodes listed in pos (what utils.MaxZOZ(x, pos) would mark) without materialising z."""
     emb = model.conv
@@ -542,7 +630,7 @@ def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, o
             raise ValueError("z must be a tensor, None or 'pos'")
         z = ("pos", pos)
     return prog.loss_and_grads(x_flat, z, edge_index, edge_weight, pos, model.pools[0].mode, model.preds[0], target,
-                               loss_fn.mode, overwrite, tail_hook)
+                               loss_fn.mode, overwrite, tail_hook, labels)
 
 
 class StackFn(torch.autograd.Function):

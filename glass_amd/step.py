@@ -32,6 +32,7 @@ class TrainStep:
         self.preserve_state = preserve_state
         self.graphed = False
         self._pos = self._y = None
+        self._labels = None  # stack.BatchLabels of the step program: label bytes + unique labeled rows of the current batch
         self._loss = torch.zeros((), device=x.device)
         self._one = torch.ones((), device=x.device)
         self._g_fb = self._g_tail = None
@@ -63,7 +64,7 @@ class TrainStep:
             if not overwrite:
                 self.bucket.zero()
             loss, _logits = stack.loss_and_grads(self.model, self.loss_fn, self.x, self.ei, self.ew, self._pos, "pos",
-                                                 self._y, overwrite, tail_hook)
+                                                 self._y, overwrite, tail_hook, labels=self._labels)
             self._loss = loss
             return
         if tail_hook is not None:
@@ -197,15 +198,20 @@ class TrainStep:
         return out
 
     def __call__(self, pos, y):
-        if self._pos is None:
-            self._pos, self._y = pos.clone(), y.clone()
-            self._warmup()
-            if self.use_graph:
-                self._capture()
+        first = self._pos is None
+        if first:
+            self._pos, self._y = torch.full_like(pos, -1), y.clone()
+            if self._program_step() and pos.is_cuda and pos.dtype == torch.int64:
+                from . import stack
+                self._labels = stack.BatchLabels(self.x.shape[0], pos.numel(), pos.device)
         if pos.shape != self._pos.shape:
             raise ValueError("TrainStep needs a fixed batch shape (drop_last=True): "
                              f"{tuple(pos.shape)} vs {tuple(self._pos.shape)}")
         self._load_batch(pos, y)
+        if first:
+            self._warmup()
+            if self.use_graph:
+                self._capture()
         if hasattr(self.opt, "sync_lr"):
             self.opt.sync_lr()  # a scheduler may have changed the learning rate since the capture
         if self.graphed:
@@ -221,7 +227,17 @@ class TrainStep:
         return self._loss
 
     def _load_batch(self, pos, y):
-        """The batch into the step's fixed buffers: one launch for both tensors when they are plain device tensors."""
+        """The batch into the step's fixed buffers: one launch for both tensors when they are plain device tensors — with
+        the step program the same launch maintains the label bytes and lists the unique labeled rows (glass_batch_labels)."""
+        if self._labels is not None:
+            pos_c = pos if pos.is_contiguous() else pos.contiguous()
+            if (y.is_cuda and y.is_contiguous() and y.dtype == self._y.dtype and y.shape == self._y.shape and y.numel() and
+                    (y.element_size() * y.numel()) % 4 == 0):
+                self._labels.load(pos_c, self._pos, y, self._y)
+            else:
+                self._labels.load(pos_c, self._pos)
+                self._y.copy_(y)
+            return
         if (pos.is_cuda and y.is_cuda and pos.is_contiguous() and y.is_contiguous() and pos.dtype == self._pos.dtype and
                 y.dtype == self._y.dtype and y.shape == self._y.shape and pos.numel() and y.numel() and
                 (pos.element_size() * pos.numel()) % 4 == 0 and (y.element_size() * y.numel()) % 4 == 0):

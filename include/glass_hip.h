@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GLASS_ABI_VERSION 2
+#define GLASS_ABI_VERSION 3
 
 #define GLASS_E_ARG (-1)       /* bad argument (null pointer, negative size, misaligned ld) */
 #define GLASS_E_PLAN (-2)      /* plan blob does not match the call (magic / sizes) */
@@ -90,11 +90,26 @@ int glass_adj_values_f32(const int32_t* rowptr, const int32_t* col, const float*
 int glass_maxzoz_i64(const int64_t* pos, int64_t n_pos /* B*Smax, -1 = padding */, int64_t* z, int64_t n_nodes,
                      void* stream);
 
+/* K4b labels of one subgraph batch for a replayed training step: utils.MaxZOZ (impl/utils.py:32-45) as label BYTES plus
+ *     the list of the unique labeled rows, and the batch hand-over of ZGDataloader (impl/SubGDataset.py:75-96), in one
+ *     single-workgroup launch.  pos_src int64[n_pos] (-1 padding) is copied to pos_dst (may be NULL), y_bytes of target to
+ *     y_dst (4-byte granularity; 0 = none).  mask uint8[n_nodes]: incremental != 0 — it holds the labels of the batch
+ *     currently in pos_dst (all zero before the first call, pos_dst all -1): those are cleared, the new ones set, no pass
+ *     over the n_nodes bytes; incremental == 0 — zero-filled here first.  lab_rows int32[n_pos] receives the UNIQUE labeled
+ *     node ids in first-occurrence order, lab_count[0] their number (the entry with the lowest index naming a node owns
+ *     it: integer atomicMin on a scratch word per named node, ordered compaction by ballots — deterministic).
+ *     ws = int32[n_nodes] scratch (glass_batch_labels_ws_bytes; only the named nodes' words are touched). */
+int64_t glass_batch_labels_ws_bytes(int64_t n_nodes);
+int glass_batch_labels(const int64_t* pos_src, int64_t n_pos, int64_t* pos_dst, const void* y_src, void* y_dst,
+                       int64_t y_bytes, uint8_t* mask, int32_t* lab_rows, int32_t* lab_count, void* ws, int64_t n_nodes,
+                       int incremental, void* stream);
+
 /* K3+K4 fused label + embedding   replaces `mask=(z>0.5)` and `input_emb(x)`
  *     (impl/models.py:242-248):  out[n,:] = W[x[n],:],  mask[n] = label of node n.
  *     The label comes from `z` (int64[N], as MaxZOZ produced it) when z != NULL, else from
  *     `pos` (int64[n_pos], -1 pad) scattered here; both NULL -> every node labeled
- *     (impl/models.py:243-244). An index of x outside [0,V) yields a zero row here; callers
+ *     (impl/models.py:243-244) — unless n_pos < 0: then mask is an INPUT (written by glass_batch_labels)
+ *     and is left alone (the same convention holds in glass_embed_norm_fwd_f32). An index of x outside [0,V) yields a zero row here; callers
  *     validate x once per dataset (nn.Embedding would raise IndexError). */
 int glass_embed_label_f32(const int64_t* x, const float* W, int64_t V, const int64_t* z, const int64_t* pos,
                           int64_t n_pos, float* out, int64_t ldo, uint8_t* mask, int64_t n_nodes, int64_t H,
@@ -290,6 +305,29 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
                                 double z_ratio, int act, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
                                 int64_t N, int64_t H, float* dW, int64_t lddw, float* db, int accumulate, void* ws,
                                 void* stream);
+/*   The comb pair in EFFECTIVE-WEIGHT form (hidden 64; impl/models.py:169-173).  No activation sits between the comb
+ *   pair's Linear layers and the label mix, so  y[r] = [g || x_][r] . (w1(r) W1 + w0(r) W0)^T + (w1 b1 + w0 b0): one product
+ *   per row with one of two effective weights.  Every row tile multiplies the unlabeled-row weight (1-z) W1 + z W0 and
+ *   skips the store of its labeled rows; the unique labeled rows of the batch (lab_rows / lab_count from
+ *   glass_batch_labels; lab_cap = capacity of the list, fixes the grid) are gathered 16 per wave by extra workgroups of
+ *   the same launch, which multiply z W1 + (1-z) W0 — every row written once, no atomics; half the matrix work of
+ *   glass_dual_linear_fwd_f32 / _bwd_f32 on the same pair.  Wimg_eff / WTimg_eff: operand images of layout 6 / 7
+ *   (glass_dense_pack_batch_f32).  stats / gn_partial hold glass_comb_eff_blocks(n_nodes, H, lab_cap) entries of [2][H]
+ *   doubles (row tiles, then extra workgroups).  Other arguments as in glass_dual_linear_fwd_f32 (xb != NULL, act none,
+ *   no T) and glass_dual_linear_bwd_f32 (n_out = 2H, no addend, no dropout on the output; X == NULL: data gradient only). */
+int glass_comb_eff_supported(int64_t H);
+int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap);
+int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,
+                           const float* bias, const uint8_t* mask, double z_ratio, float* out, int64_t ldo,
+                           int64_t n_nodes, int64_t H, double* stats, const float* gn_saved, int gn_act, float p_drop,
+                           const uint64_t* rng_state, uint64_t call_id, float* xa_out, int64_t ldxo,
+                           const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap, void* stream);
+int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint8_t* mask, double z_ratio, const float* WTimg_eff,
+                           float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
+                           int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
+                           const uint64_t* rng_state, uint64_t gn_call_id, const float* X, int64_t ldx, const float* X2,
+                           int64_t ldx2, void* ws, const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap,
+                           void* stream);
 /*     Deferred reduction: glass_dual_linear_wgrad_f32 with dW == NULL only writes the per-slab partial sums
  *     into `ws` (one scratch buffer per pending gradient); this call then reduces n_jobs of them — job j is
  *     the gradient of a [O[j], I[j]] weight over N[j] rows — into dW[j] / db[j] (db[j] may be NULL) with ONE
@@ -304,8 +342,10 @@ int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, c
  *     (1 - z_ratio[k]) * B[:, :KT/2] + z_ratio[k] * B[:, KT/2:] in the same tiling over K = KT/2 (dst[k] then holds
  *     1.5 * NT*KT floats; transposed operands only) — glass_dual_linear_dgrad_layout(H, n_out) names the layout the
  *     data-gradient kernels read; 5 tiled paired followed by (1 - z) * B[:NT/2] + z * B[NT/2:] in the plain tiling
- *     (forward operand of a comb pair, again 1.5 * NT*KT floats; glass_dual_linear_fwd_layout).  z_ratio (may be NULL
- *     when no job has layout 4 / 5): per-job label mix of the pair.
+ *     (forward operand of a comb pair, again 1.5 * NT*KT floats; glass_dual_linear_fwd_layout); 6 (not transposed, NT = 2H
+ *     stacked outputs) / 7 (transposed, KT = 2H): the two wave16 images of the comb pair's effective weights, unlabeled rows
+ *     (1-z) * f1 half + z * f0 half, then labeled rows z * f1 half + (1-z) * f0 half, NT*KT floats in all — the operands of
+ *     glass_comb_eff_fwd_f32 / _bwd_f32.  z_ratio (may be NULL when no job has layout 4 - 7): per-job label mix of the pair.
  *     dst[k] holds NT*KT floats otherwise.  The pointer / size arrays are HOST arrays. */
 /*     rng_state (may be NULL): the same launch also advances the dropout stream, rng_state[1] += 1 (both are
  *     once-per-step prologue work; equivalent to a following glass_rng_advance). */

@@ -918,3 +918,143 @@ def test_copy_pair():
     assert rc == 0 and torch.equal(da, a) and torch.equal(db, b)
     assert _lib.load().glass_copy_pair(da.data_ptr(), a.data_ptr(), 6, db.data_ptr(), b.data_ptr(), 4,
                                        torch.cuda.current_stream().cuda_stream) != 0  # 4-byte granularity
+
+
+# ---------------------------------------------------------------------------------- K4b batch labels + comb pair, hidden 64
+def _first_occurrence_unique(pos_flat, n):
+    seen, rows = set(), []
+    for p in pos_flat.tolist():
+        if 0 <= p < n and p not in seen:
+            seen.add(p)
+            rows.append(p)
+    return rows
+
+
+@pytest.mark.parametrize("B,S,n", [(80, 10, 17080), (3, 7, 50), (99, 155, 5000), (1, 1, 9)])
+def test_batch_labels(B, S, n):
+    """glass_batch_labels: label bytes == utils.MaxZOZ's z (impl/utils.py:32-45), unique labeled rows in first-occurrence
+    order, the batch copied into the fixed buffers; three batches through the incremental form (labels of the previous
+    batch cleared without a pass over the N bytes) and one through the stand-alone form.  Integer outputs: exact."""
+    from glass_amd import stack
+    rng = np.random.default_rng(B * 1000 + S)
+    labels = stack.BatchLabels(n, B * S, DEV)
+    pos_fix = torch.full((B, S), -1, dtype=torch.int64, device=DEV)
+    y_fix = torch.zeros(B, dtype=torch.int64, device=DEV)
+    for it in range(3):
+        pos = rng.integers(0, min(n, max(4, B * S // 2)), (B, S))   # small id range -> many nodes shared by subgraphs
+        pos[rng.random((B, S)) < 0.3] = -1                           # padding
+        if B * S > 1:
+            pos.flat[0] = pos.flat[-1] if pos.flat[-1] >= 0 else 0   # a duplicate at the extreme entries
+        y = rng.integers(0, 5, B)
+        pos_t, y_t = torch.from_numpy(pos).to(DEV), torch.from_numpy(y).to(DEV)
+        labels.load(pos_t, pos_fix, y_t, y_fix)
+        z = O.max_zero_one(torch.zeros(n, 1, 1, dtype=torch.int64), torch.from_numpy(pos))
+        assert torch.equal(labels.mask.cpu().to(torch.int64), z), it
+        rows = _first_occurrence_unique(pos.reshape(-1), n)
+        assert int(labels.count[0]) == len(rows)
+        assert labels.rows[:len(rows)].cpu().tolist() == rows
+        assert torch.equal(pos_fix.cpu(), torch.from_numpy(pos)) and torch.equal(y_fix.cpu(), torch.from_numpy(y))
+    solo = stack.BatchLabels(n, B * S, DEV)
+    solo.mask.fill_(1)   # the stand-alone form zero-fills the N bytes itself
+    solo.load(pos_t)
+    assert torch.equal(solo.mask, labels.mask) and int(solo.count[0]) == int(labels.count[0])
+    assert torch.equal(solo.rows[:len(rows)], labels.rows[:len(rows)])
+
+
+@pytest.mark.parametrize("N,pattern", [(17080, "batch"), (1000, "none"), (1000, "one"), (1000, "tile_full"), (77, "all"),
+                                       (5000, "dense")])
+@pytest.mark.parametrize("p_drop", [0.0, 0.5])
+def test_comb_pair_effective_weight_hidden64(N, pattern, p_drop):
+    """Comb pair at hidden 64 in effective-weight form (glass_comb_eff_fwd/bwd_f32: every row tile multiplies the
+    unlabeled-row weight, the listed labeled rows are recomputed by extra workgroups) against fp64 — forward with the
+    GraphNorm prologue (+ dropout, side output) and the output statistics, data gradient with the backward-GraphNorm column
+    sums, weight / bias gradient — and against the two-product kernels on the same inputs.  reference impl/models.py:165-173."""
+    from glass_amd import stack, ops
+    from glass_amd.arena import ParamArena
+    from glass_amd.factory import build_glass
+    torch.manual_seed(11)
+    H, z = 64, 0.95
+    model = build_glass(H, 1, 5, 3, "mean", "sum", z).to(DEV).train()
+    arena = ParamArena(model)
+    conv = model.conv.convs[0]
+    st = conv._stack["comb"]
+    rng = np.random.default_rng(N)
+    if pattern == "batch":      # ppi_bp-shape: 80 subgraphs x 10 nodes, nodes shared between subgraphs, some padding
+        pos = rng.integers(0, N, (80, 10))
+        pos[:, 8:][rng.random((80, 2)) < 0.5] = -1
+        pos[5] = pos[4]
+    elif pattern == "none":
+        pos = np.full((4, 5), -1)
+    elif pattern == "one":
+        pos = np.full((4, 5), -1)
+        pos[2, 3] = 517
+    elif pattern == "tile_full":  # every row of one 16-row wave tile and of one 64-row workgroup tile
+        pos = np.concatenate([np.arange(32, 48), np.arange(640, 704)]).reshape(8, 10)
+    elif pattern == "all":
+        pos = np.arange(N + 3).reshape(-1, 10) % N   # every node, three of them twice
+    else:                        # a third of the rows labeled: more extra workgroups than a batch ever has
+        pos = rng.permutation(N)[:1660].reshape(-1, 10)
+    pos_t = torch.from_numpy(pos.astype(np.int64)).to(DEV)
+    labels = stack.BatchLabels(N, pos_t.numel(), DEV)
+    labels.load(pos_t)
+    mask = labels.mask
+    lab = mask.bool().unsqueeze(1)
+    ops.rng_seed(99, DEV)
+    arena.refresh_transposes(ops.rng_state(DEV))
+    a, h = torch.randn(N, H, device=DEV) * 2 + 0.5, torch.randn(N, H, device=DEV)
+    gmod = conv.gn
+    with torch.no_grad():
+        gmod.weight.uniform_(0.5, 1.5)
+        gmod.bias.uniform_(-0.3, 0.3)
+        gmod.mean_scale.uniform_(0.7, 1.1)
+    gsaved = stack._GN(gmod).stats(a)
+    call = 16
+    # ---- forward: eff form vs two-product kernel vs fp64
+    nblk_eff = int(stack._lib.load().glass_comb_eff_blocks(N, H, labels.cap))
+    c, g = torch.empty(N, H, device=DEV), torch.empty(N, H, device=DEV)
+    cstat = torch.empty(nblk_eff, 2, H, dtype=torch.float64, device=DEV)
+    stack._comb_eff_fwd(a, h, conv, mask, c, cstat, (gsaved, 0, p_drop, call, g), labels)
+    c2, g2 = torch.empty(N, H, device=DEV), torch.empty(N, H, device=DEV)
+    cstat2 = torch.empty(-(-N // 64), 2, H, dtype=torch.float64, device=DEV)
+    stack._dual_fwd(a, h, st, mask, z, 0, None, c2, cstat2, gn=(gsaved, 0, p_drop, call, g2))
+    assert torch.equal(g, g2)   # the normalised (+ dropped) operand: same arithmetic, same mask
+    W, b = st[0].double(), st[1].double()
+    x = torch.cat([g, h], 1).double()
+    C1, C0 = x @ W[:H].t() + b[:H], x @ W[H:].t() + b[H:]
+    ref = torch.where(lab, z * C1 + (1 - z) * C0, (1 - z) * C1 + z * C0)
+    assert rel_inf(c.double(), ref) < TOL and rel_inf(c2.double(), ref) < TOL
+    assert rel_inf(cstat[:, 0].sum(0), ref.sum(0)) < TOL and rel_inf(cstat[:, 1].sum(0), (ref * ref).sum(0)) < TOL
+    if p_drop == 0:   # g = GraphNorm(a) checked against fp64 as well
+        mu = a.double().mean(0)
+        o = a.double() - gmod.mean_scale.double() * mu
+        gref = gmod.weight.double() * o / (o.pow(2).mean(0) + gmod.eps).sqrt() + gmod.bias.double()
+        assert rel_inf(g.double(), gref) < TOL
+    # ---- backward: data gradient (+ conv.gn's backward column sums) and weight-gradient partials, one launch
+    for p in (st[2], st[3]):
+        p.zero_()
+    dc = torch.randn(N, H, device=DEV)
+    din = torch.empty(N, 2 * H, device=DEV)
+    gpart = torch.empty(nblk_eff, 2, H, dtype=torch.float64, device=DEV)
+    pending = []
+    stack._comb_eff_bwd(dc, conv, mask, din, g, h, pending, 0, (gpart, a, gsaved, gmod.mean_scale, 0, p_drop, call), labels)
+    stack._reduce_pending(pending)
+    w1 = torch.where(lab, torch.tensor(z, device=DEV, dtype=torch.float64), torch.tensor(1 - z, device=DEV, dtype=torch.float64))
+    dZ = torch.cat([w1 * dc.double(), (1 - w1) * dc.double()], 1)
+    dref = dZ @ W
+    assert rel_inf(din.double(), dref) < TOL
+    assert rel_inf(st[2].double(), dZ.t() @ x) < TOL and rel_inf(st[3].double(), dZ.sum(0)) < TOL
+    keep = (g != 0).double() / (1 - p_drop) if p_drop > 0 else torch.ones_like(dref[:, :H])
+    if p_drop > 0:   # where the normalised value itself is 0 the mask cannot be read back from g: use the two-product kernel's sums
+        gpart2 = torch.empty(-(-N // 64), 2, H, dtype=torch.float64, device=DEV)
+        din2 = torch.empty_like(din)
+        stack._dual_dgrad(dc, None, st, mask, z, 0, 2 * H, None, din2, gn=(gpart2, a, gsaved, gmod.mean_scale, 0, p_drop, call))
+        assert rel_inf(din.double(), din2.double()) < TOL
+        assert rel_inf(gpart.sum(0), gpart2.sum(0)) < TOL
+    else:
+        gg = dref[:, :H] * keep
+        xhat = (a.double() - gmod.mean_scale.double() * gsaved[:H].double()) * gsaved[H:2 * H].double()
+        assert rel_inf(gpart[:, 0].sum(0), gg.sum(0)) < TOL and rel_inf(gpart[:, 1].sum(0), (gg * xhat).sum(0)) < TOL
+    # repeatable bit for bit
+    c3 = torch.empty_like(c)
+    stack._comb_eff_fwd(a, h, conv, mask, c3, cstat, (gsaved, 0, p_drop, call, g), labels)
+    assert torch.equal(c3, c)
