@@ -58,7 +58,7 @@ SIGNATURES = {
     "glass_readout_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_readout_train_f32": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, c_int, _P, _P, _P, c_int, _I, _P, _P, _P, _P, _P, _I,
                                         _P, _P, c_int, _P, _P, _P, c_int, _P, _I, _I, _P]),
-    "glass_linear_wgrad_reduce_batch_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "glass_linear_wgrad_reduce_batch_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "glass_segment_pool_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _I, _P, _I, _I, _P]),
     "glass_segment_pool_bwd_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _P, _I, _I, _I, _P]),
     "glass_linear_wgrad_ws_bytes": (c_int64, [_I, _I, _I]),
@@ -89,6 +89,7 @@ SIGNATURES = {
     "glass_batch_labels": (c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, c_int, _P]),
     "glass_comb_eff_supported": (c_int, [_I]),
     "glass_comb_eff_blocks": (c_int64, [_I, _I, _I]),
+    "glass_comb_eff_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_comb_eff_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, _P, _I, _I, _I, _P, _P, c_int, c_float, _P,
                                        c_uint64, _P, _I, _P, _P, _I, _P]),
     "glass_comb_eff_bwd_f32": (c_int, [_P, _I, _P, c_double, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, c_int, c_float, _P,

@@ -804,27 +804,23 @@ __global__ __launch_bounds__(kBlock) void comb_dgrad_eff_kernel(DgradEffArgs A) 
 }
 
 // Fused backward launch of the comb pair in effective-weight form: data-gradient row tiles (main + extra), then the
-// weight-gradient slabs (dual_bwd_kernel's second branch).
+// weight-gradient blocks in S / L form (wgrad_sl_body: row slabs, then the labeled-row tiles).
 template <int H>
-__global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A, int n_dgrad_blocks,
-                                                                const float* __restrict__ X, int64_t ldx, int O, int I,
-                                                                int rows_per_slab, int gx, int gy,
-                                                                float* __restrict__ part_w, float* __restrict__ part_b,
-                                                                float* __restrict__ wg_header, WgradSynth sy) {
+__global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A, int n_dgrad_blocks, WgradSL sl, float zr,
+                                                                float* __restrict__ part_w, float* __restrict__ part_b) {
     extern __shared__ float4 lds_w[];
     const int b = blockIdx.x;
-    if (b == 0 && threadIdx.x == 0) {  // the partials below are in the plain form (mode header read by the reduce launch)
-        wg_header[0] = 0.f;
-        wg_header[1] = sy.zr;
+    if (b == 0 && threadIdx.x == 0) {  // mode header behind the bias partials, read by the (deferred) reduce launch
+        float* header = part_b + (int64_t)(sl.n_s + sl.n_l) * kSLOut;
+        header[0] = 2.f;
+        header[1] = zr;
     }
     if (b < n_dgrad_blocks) {
         comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, b, lds_w);
         return;
     }
-    const int t = b - n_dgrad_blocks;
     float* lds = reinterpret_cast<float*>(lds_w);
-    wgrad_partial_body<true, 2>(nullptr, 0, X, ldx, A.N, O, I, rows_per_slab, part_w, part_b, sy, t % gx, (t / gx) % gy,
-                                t / (gx * gy), gx, gy, lds, lds + 2 * kTile);
+    wgrad_sl_body<2>(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
 }
 
 // ---- packing of the stacked weights into MFMA images (one launch for the whole model, once per step) ------
@@ -1202,7 +1198,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
     hipStream_t st = (hipStream_t)stream;
     const int n_main = (int)ceil_div(n_nodes, 64);
     const unsigned n_dg = (unsigned)(n_main + ceil_div(lab_cap, 64));
-    const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
+    const float zr = (float)z_ratio;
     const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
     const DgradEffArgs dargs{dsrc, ldd, mask, WTimg_eff, rng_state, out, ldo, n_nodes, gs, LabRows{lab_rows, lab_count, n_main}};
     const size_t lds_dg = lds_bytes(2 * H, 1);  // one K pass of the [2H][H] effective weight
@@ -1210,27 +1206,33 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
         hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);
         return launch_status("glass_comb_eff_bwd_f32 (dgrad)");
     }
-    GLASS_REQUIRE(X2 && ws && ldx >= H && ldx % 2 == 0 && (reinterpret_cast<uintptr_t>(X) & 7u) == 0 && ldx2 >= H &&
-                      ldx2 % 2 == 0 && (reinterpret_cast<uintptr_t>(X2) & 7u) == 0,
-                  "comb_eff_bwd: the pair's inputs must be 8-B aligned with even leading dimensions");
-    const int64_t O = 2 * H, I = 2 * H;
-    if (n_nodes > kFusedBwdMaxRows || wgrad_tiled_shape(n_nodes, O, I)) {  // large graph: two launches
-        hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);
-        const int rc = launch_status("glass_comb_eff_bwd_f32 (dgrad)");
-        return rc ? rc : glass_dual_linear_wgrad_f32(dsrc, ldd, nullptr, 0, mask, z_ratio, GLASS_ACT_NONE, X, ldx, X2, ldx2,
-                                                     n_nodes, H, nullptr, 0, nullptr, 0, ws, stream);
-    }
-    const WgradGeom g = wgrad_geom(n_nodes, O, I);
+    GLASS_REQUIRE(X2 && ws && ldx >= H && ldx % 4 == 0 && aligned16(X) && ldx2 >= H && ldx2 % 4 == 0 && aligned16(X2) &&
+                      aligned16(ws),
+                  "comb_eff_bwd: the pair's inputs must be 16-B aligned with ld %% 4 == 0");
+    // weight-gradient partials in S / L form (wgrad_common.h): reduced later by glass_linear_wgrad_reduce_batch_f32 with
+    // lab_cap[job] = this call's lab_cap
+    const WgradSLGeom g = wgrad_sl_geom(n_nodes, lab_cap);
     float* part_w = (float*)ws;
-    const WgradSynth sy{dsrc, ldd, nullptr, 0, mask, zr, omz, GLASS_ACT_NONE, (int)H, X2, ldx2};
-    const size_t lds_wg = (size_t)(2 * kTile + 8 * kOT) * sizeof(float);
+    float* part_b = part_w + g.part_w_floats;
+    const WgradSL sl{dsrc, ldd, X, ldx, X2, ldx2, lab_rows, lab_count, g.n_s, g.rows_per_slab, g.n_l};
+    if (n_nodes > kFusedBwdMaxRows) {  // large graph: the two halves fill the chip on their own
+        hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);
+        launch_wgrad_sl(sl, n_nodes, zr, part_w, part_b, st);
+        return launch_status("glass_comb_eff_bwd_f32 (two launches)");
+    }
+    const size_t lds_wg = (size_t)(2 * kTile + 8 * kSLOut) * sizeof(float);
     const size_t lds_fused = lds_dg > lds_wg ? lds_dg : lds_wg;
-    const unsigned blocks = n_dg + (unsigned)(g.n_slabs * g.ny * g.nz);
     allow_lds(comb_bwd_eff_kernel<64>, lds_fused);
-    hipLaunchKernelGGL((comb_bwd_eff_kernel<64>), dim3(blocks), dim3(kBlock), lds_fused, st, dargs, (int)n_dg, X, ldx, (int)O,
-                       (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats,
-                       part_w + g.part_w_floats + g.part_b_floats - kWgradHeaderFloats, sy);
+    hipLaunchKernelGGL((comb_bwd_eff_kernel<64>), dim3(n_dg + (unsigned)(g.n_s + g.n_l)), dim3(kBlock), lds_fused, st, dargs,
+                       (int)n_dg, sl, zr, part_w, part_b);
     return launch_status("glass_comb_eff_bwd_f32");
+}
+
+// scratch bytes of glass_comb_eff_bwd_f32's weight-gradient partials
+extern "C" int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t lab_cap) {
+    if (H != 64 || n_nodes <= 0 || lab_cap < 0) return GLASS_E_ARG;
+    const WgradSLGeom g = wgrad_sl_geom(n_nodes, lab_cap);
+    return (g.part_w_floats + g.part_b_floats) * (int64_t)sizeof(float);
 }
 
 extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,

@@ -44,6 +44,67 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
 // combined through LDS in slot order -> fixed summation order.
 // header (behind the bias partials): [0] != 0: effective-weight form (wgrad_partial_body<.., EFF>) — output tile z of the f1
 // half = (1-z) S + (2z-1) L, of the f0 half = z S - (2z-1) L with S / L the slab sums of tiles zz and nz/2 + zz.
+// S / L form (wgrad_sl_body; comb pair at hidden 64): n_s slab tiles then n_l labeled-row tiles, one [64 x 128] tile each;
+// dW[o][i] = (1-z) S + (2z-1) L, dW[64 + o][i] = z S - (2z-1) L, bias gradients likewise from the [64] column sums.
+__device__ __forceinline__ void wgrad_reduce_sl_body(const float* __restrict__ part_w, const float* __restrict__ part_b,
+                                                     int n_s, int n_l, float* __restrict__ dW, int64_t lddw,
+                                                     float* __restrict__ db, int accumulate, float4* lds) {
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int k0 = blockIdx.x * 64 + tc * 4;
+    const bool is_bias = k0 >= kTile;
+    if (is_bias && (k0 - kTile >= kSLOut || db == nullptr)) return;  // whole workgroup: 64 columns per block
+    const float zr = part_b[(int64_t)(n_s + n_l) * kSLOut + 1];
+    const float* p = is_bias ? part_b + (k0 - kTile) : part_w + k0;
+    const int64_t stride = is_bias ? kSLOut : kTile;
+    auto run_sum = [&](int b0, int b1) __attribute__((always_inline)) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b = b0 + tr; b < b1; b += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + 16 * u;
+                v[u] = bb < b1 ? *reinterpret_cast<const float4*>(p + (int64_t)bb * stride) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        return s;
+    };
+    const float4 sS = run_sum(0, n_s), sL = run_sum(n_s, n_s + n_l);
+    lds[threadIdx.x] = sS;
+    lds[kBlock + threadIdx.x] = sL;
+    __syncthreads();
+    if (tr != 0) return;
+    float4 S = sS, L = sL;
+    for (int r = 1; r < 16; ++r) {
+        const float4 a = lds[r * 16 + tc], b = lds[kBlock + r * 16 + tc];
+        S.x += a.x; S.y += a.y; S.z += a.z; S.w += a.w;
+        L.x += b.x; L.y += b.y; L.z += b.z; L.w += b.w;
+    }
+    const float sv[4] = {S.x, S.y, S.z, S.w}, lv[4] = {L.x, L.y, L.z, L.w};
+    const float cl = 2.f * zr - 1.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = k0 + q;
+        const float g1 = (1.f - zr) * sv[q] + cl * lv[q], g0 = zr * sv[q] - cl * lv[q];
+        if (!is_bias) {
+            // decode k = ((t*4+u)*16 + reg)*64 + lane  ->  (o, i) = (2m + t, 4n + u)
+            const int lane = k & 63, reg = (k >> 6) & 15, tu = k >> 10;
+            const int t = tu >> 2, u = tu & 3;
+            const int m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), n = lane & 31;
+            const int o = 2 * m + t, i = 4 * n + u;
+            float* d1 = dW + (int64_t)o * lddw + i;
+            float* d0 = dW + (int64_t)(kSLOut + o) * lddw + i;
+            *d1 = accumulate ? *d1 + g1 : g1;
+            *d0 = accumulate ? *d0 + g0 : g0;
+        } else {
+            const int o = k - kTile;
+            db[o] = accumulate ? db[o] + g1 : g1;
+            db[kSLOut + o] = accumulate ? db[kSLOut + o] + g0 : g0;
+        }
+    }
+}
+
 __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part_w, const float* __restrict__ part_b,
                                                   int n_slabs, int ny, int nz, int O, int I, float* __restrict__ dW,
                                                   int64_t lddw, float* __restrict__ db, int accumulate, float4* lds,
@@ -129,6 +190,7 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_kernel(const float* __res
 struct ReduceJob {
     const float *part_w, *part_b;
     int n_slabs, ny, nz, O, I, accumulate;
+    int n_l;  // > 0: S / L form (n_slabs = n_s slab tiles, then n_l labeled-row tiles; ny = nz = 1)
     float* dW;
     int64_t lddw;
     float* db;
@@ -139,9 +201,13 @@ struct ReduceBatch {
 };
 
 __global__ __launch_bounds__(kBlock) void wgrad_reduce_batch_kernel(ReduceBatch batch) {
-    __shared__ float4 lds[kBlock];
+    __shared__ float4 lds[2 * kBlock];
     const ReduceJob& j = batch.job[blockIdx.z];
     if ((int)blockIdx.y >= j.ny * j.nz) return;
+    if (j.n_l > 0) {
+        wgrad_reduce_sl_body(j.part_w, j.part_b, j.n_slabs, j.n_l, j.dW, j.lddw, j.db, j.accumulate, lds);
+        return;
+    }
     wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.nz, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
 }
 
@@ -160,8 +226,7 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     // tiles + these slabs, two workgroups per CU).  Keep the sum within the 512 resident workgroups of the chip — a
     // handful of surplus workgroups would wait for a free slot and run as a second round (28 vs ~21 us at ppi_bp-shape).
     if (N <= 100000) {
-        // (- 20: the launch header's slack and up to 16 extra row tiles of the comb pair's labeled rows, glass_comb_eff_bwd_f32)
-        const int64_t room = (2 * 256 - 20 - ceil_div(N, 64)) / tiles;
+        const int64_t room = (2 * 256 - 4 - ceil_div(N, 64)) / tiles;
         if (room >= 32 && room < max_slabs) max_slabs = room;
     }
     if (max_slabs < 32) max_slabs = 32;
@@ -175,6 +240,40 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     g.part_w_floats = (int64_t)g.n_slabs * g.ny * g.nz * kTile;
     g.part_b_floats = (int64_t)g.n_slabs * g.nz * kOT + kWgradHeaderFloats;  // + the mode header behind the bias partials
     return g;
+}
+
+WgradSLGeom wgrad_sl_geom(int64_t N, int64_t lab_cap) {
+    WgradSLGeom g;
+    g.n_l = (int)ceil_div(lab_cap > 0 ? lab_cap : 1, 64);
+    // small graphs: the slabs share ONE launch with the data gradient's row tiles (comb_bwd_eff_kernel: N/64 + n_l row
+    // tiles, two workgroups per CU) — keep the sum within the 512 resident workgroups of the chip
+    int64_t room = N <= 100000 ? 2 * 256 - 4 - ceil_div(N, 64) - 2 * g.n_l : 256;
+    if (room > 256) room = 256;
+    if (room < 32) room = 32;
+    int64_t rows = ceil_div(N, room);
+    if (rows < 64) rows = 64;
+    rows = ceil_div(rows, 8) * 8;  // whole row pairs for each of the 4 waves
+    g.rows_per_slab = (int)rows;
+    g.n_s = (int)ceil_div(N, rows);
+    g.part_w_floats = (int64_t)(g.n_s + g.n_l) * kTile;
+    g.part_b_floats = (int64_t)(g.n_s + g.n_l) * kSLOut + kWgradHeaderFloats;
+    return g;
+}
+
+// stand-alone launch of the S / L partials (large graphs; small ones run them inside comb_bwd_eff_kernel, dense.hip)
+__global__ __launch_bounds__(kBlock, 1) void wgrad_sl_kernel(WgradSL a, int64_t N, float zr, float* __restrict__ part_w,
+                                                             float* __restrict__ part_b) {
+    __shared__ float lds[2 * kTile + 8 * kSLOut];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        float* header = part_b + (int64_t)(a.n_s + a.n_l) * kSLOut;
+        header[0] = 2.f;
+        header[1] = zr;
+    }
+    wgrad_sl_body<4>(a, N, blockIdx.x, part_w, part_b, lds, lds + 2 * kTile);
+}
+
+void launch_wgrad_sl(const WgradSL& a, int64_t N, float zr, float* part_w, float* part_b, hipStream_t st) {
+    hipLaunchKernelGGL(wgrad_sl_kernel, dim3((unsigned)(a.n_s + a.n_l)), dim3(kBlock), 0, st, a, N, zr, part_w, part_b);
 }
 
 // ---- fused Adam over the flat parameter arena --------------------------------------------------
@@ -303,7 +402,7 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
 extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, const int64_t* N,
                                                    const int64_t* O, const int64_t* I, float* const* dW,
                                                    const int64_t* lddw, float* const* db, const int32_t* accumulate,
-                                                   void* stream) {
+                                                   const int64_t* lab_cap, void* stream) {
     GLASS_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (ws && N && O && I && dW && lddw && db && accumulate)),
                   "wgrad_reduce_batch: null pointer");
     if (n_jobs == 0) return 0;
@@ -312,11 +411,20 @@ extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* c
         const int nj = (int)(n_jobs - j0 < kMaxReduceJobs ? n_jobs - j0 : kMaxReduceJobs);
         ReduceBatch b;
         int max_chunks = 0;
-        for (int k = 0; k < kMaxReduceJobs; ++k) b.job[k] = ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
+        for (int k = 0; k < kMaxReduceJobs; ++k) b.job[k] = ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
         for (int k = 0; k < nj; ++k) {
             const int64_t j = j0 + k;
             GLASS_REQUIRE(ws[j] && dW[j] && N[j] > 0 && O[j] > 0 && I[j] > 0 && lddw[j] >= I[j],
                           "wgrad_reduce_batch: bad job %lld", (long long)j);
+            if (lab_cap && lab_cap[j] > 0) {  // S / L partials of glass_comb_eff_bwd_f32 (hidden 64: O = I = 128)
+                GLASS_REQUIRE(O[j] == 2 * kSLOut && I[j] == 2 * kSLOut && db[j], "wgrad_reduce_batch: job %lld is not a comb pair of hidden 64", (long long)j);
+                const WgradSLGeom g = wgrad_sl_geom(N[j], lab_cap[j]);
+                const float* part_w = (const float*)ws[j];
+                b.job[k] = ReduceJob{part_w, part_w + g.part_w_floats, g.n_s, 1, 1, (int)O[j], (int)I[j], accumulate[j], g.n_l,
+                                     dW[j], lddw[j], db[j]};
+                if (max_chunks < 1) max_chunks = 1;
+                continue;
+            }
             if (wgrad_tiled_shape(N[j], O[j], I[j])) {  // partials of the tiled kernel (what glass_dual_linear_wgrad_f32
                                                         // writes at this shape): their own reduce launch
                 const TiledWgradGeom t = wgrad_tiled_geom(N[j], O[j], I[j]);
@@ -327,7 +435,7 @@ extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* c
             const WgradGeom g = wgrad_geom(N[j], O[j], I[j]);
             const float* part_w = (const float*)ws[j];
             b.job[k] = ReduceJob{part_w, part_w + g.part_w_floats, g.n_slabs, g.ny, g.nz, (int)O[j], (int)I[j],
-                                 accumulate[j], dW[j], lddw[j], db[j]};
+                                 accumulate[j], 0, dW[j], lddw[j], db[j]};
             if (g.ny * g.nz > max_chunks) max_chunks = g.ny * g.nz;
         }
         if (max_chunks > 0)

@@ -199,6 +199,136 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
     }
 }
 
+// ---- comb pair at hidden 64: weight gradient in effective-weight ("S / L") form -------------------------------------
+// dW1 = sum_r w1(r) dc[r]^T c[r], dW0 = sum_r w0(r) dc[r]^T c[r] with c = [g || x_] and (w1, w0) = (z, 1-z) on labeled rows,
+// (1-z, z) elsewhere, so with  S = sum over ALL rows of dc^T c  and  L = the same sum over the LABELED rows:
+//     dW1 = (1-z) S + (2z-1) L,   dW0 = z S - (2z-1) L      (bias gradients likewise from the column sums of dc).
+// S is ONE [H x 2H] product over the rows instead of the [2H x 2H] of the plain form (half the matrix work); L walks the
+// batch's unique labeled rows (glass_batch_labels) — a few workgroups.  Roles of the two MFMA operands swapped against
+// wgrad_partial_body: a lane reads float2 of dc (outputs o = 2m + t) and float4 of c (inputs i = 4n + u), so ONE workgroup
+// tile covers all 64 x 128 outputs: acc[t < 2][u < 4], the same 8 accumulator tiles.  Blocks [0, n_s) take row slabs,
+// blocks [n_s, n_s + n_l) take 64 list positions each; partial tiles [n_s + n_l][kTile], bias partials [n_s + n_l][64],
+// then the mode header {2, z_ratio, n_s, n_l}; combined by the reduce kernels (linear.hip).
+struct WgradSL {
+    const float* dc; int64_t ldd;
+    const float* X; int64_t ldx;     // g   [N,H]
+    const float* X2; int64_t ldx2;   // x_  [N,H]
+    const int32_t* lab_rows;
+    const int32_t* lab_count;
+    int n_s, rows_per_slab, n_l;
+};
+struct WgradSLGeom {
+    int n_s, rows_per_slab, n_l;
+    int64_t part_w_floats, part_b_floats;  // part_b_floats includes the header
+};
+WgradSLGeom wgrad_sl_geom(int64_t N, int64_t lab_cap);  // linear.hip
+void launch_wgrad_sl(const WgradSL& a, int64_t N, float zr, float* part_w, float* part_b, hipStream_t st);  // linear.hip
+constexpr int kSLOut = 64;  // outputs of the S / L tile (H)
+
+__device__ __forceinline__ int acc_index_sl(int t, int u, int reg, int lane) { return ((t * 4 + u) * 16 + reg) * 64 + lane; }
+
+template <int kStages>
+__device__ __forceinline__ void wgrad_sl_body(const WgradSL& a, int64_t N, int blk, float* __restrict__ part_w,
+                                              float* __restrict__ part_b, float* lds, float* lds_b) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const bool lab = blk >= a.n_s;
+    int64_t r0, r_end;
+    if (!lab) {
+        r0 = (int64_t)blk * a.rows_per_slab;
+        r_end = min(N, r0 + a.rows_per_slab);
+    } else {
+        const int64_t n_lab = a.lab_count[0];
+        r0 = (int64_t)(blk - a.n_s) * 64;
+        r_end = min(n_lab, r0 + 64);
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
+    float2 bsum = make_float2(0.f, 0.f);
+    struct Stage {
+        float2 g[2];
+        float4 x[2];
+        bool live[2];
+    };
+    Stage st[kStages];
+    const float* xbase = c < 16 ? a.X + 4 * c : a.X2 + (4 * c - 64);
+    const int64_t xld = c < 16 ? a.ldx : a.ldx2;
+    auto load_stage = [&](int64_t nb, Stage& S) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int64_t pos = nb + h + 8 * s;
+            const bool in = pos < r_end;
+            int64_t row = in ? pos : 0;
+            if (lab) row = in ? a.lab_rows[pos] : 0;
+            S.live[s] = in;
+            S.g[s] = *reinterpret_cast<const float2*>(a.dc + row * a.ldd + 2 * c);
+            S.x[s] = *reinterpret_cast<const float4*>(xbase + row * xld);
+        }
+    };
+    const int64_t nb0 = r0 + 2 * w;  // wave-uniform (MFMA needs every lane in the loop)
+#pragma unroll
+    for (int k = 0; k < kStages; ++k) load_stage(nb0 + 16 * k, st[k]);
+    for (int64_t nb = nb0; nb < r_end; nb += 16 * kStages) {
+#pragma unroll
+        for (int k = 0; k < kStages; ++k) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float2 g = st[k].g[s];
+                if (!st[k].live[s]) g = make_float2(0.f, 0.f);
+                const float gv[2] = {g.x, g.y};
+                const float xv[4] = {st[k].x[s].x, st[k].x[s].y, st[k].x[s].z, st[k].x[s].w};
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
+                bsum.x += g.x;
+                bsum.y += g.y;
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the refill below from being sunk into later stages
+            load_stage(nb + 16 * (k + kStages), st[k]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- combine the 4 waves through LDS: waves 0,1 store; waves 2,3 add; everyone sums the pair ----
+    if (w < 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index_sl(t, u, k, lane)] = acc[t][u][k];
+    }
+    *reinterpret_cast<float2*>(&lds_b[(w * 2 + h) * kSLOut + 2 * c]) = bsum;
+    __syncthreads();
+    if (w >= 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index_sl(t, u, k, lane)] += acc[t][u][k];
+    }
+    __syncthreads();
+    float* pw = part_w + (int64_t)blk * kTile;
+    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
+        const float4 p = *reinterpret_cast<const float4*>(&lds[k]);
+        const float4 q = *reinterpret_cast<const float4*>(&lds[kTile + k]);
+        *reinterpret_cast<float4*>(pw + k) = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+    }
+    if (threadIdx.x < kSLOut) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds_b[k * kSLOut + threadIdx.x];
+        part_b[(int64_t)blk * kSLOut + threadIdx.x] = s;
+    }
+}
+
 // wgrad_tiled.hip: used by glass_dual_linear_wgrad_f32 (and the deferred reduction of its partials) when
 // wgrad_tiled_shape(N, O, I) — the partial kernel writes plain [slab][tile][128][256] partial
 // sums (+ [slab][o-tile][128] bias partials), the reduce kernel sums the slabs in order into dW / db.

@@ -203,8 +203,8 @@ _retired_ws = []
 _side = {}
 
 
-def _wgrad_workspace(device, N, O, I, slot=0):
-    nbytes = _lib.load().glass_linear_wgrad_ws_bytes(N, O, I)
+def _wgrad_workspace(device, N, O, I, slot=0, min_bytes=0):
+    nbytes = max(_lib.load().glass_linear_wgrad_ws_bytes(N, O, I), min_bytes)
     ws = _wgrad_ws.get((device, slot))
     if ws is None or ws.numel() * 4 < nbytes:
         if ws is not None:

@@ -89,7 +89,8 @@ def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels):
     gpart, gx, gsaved, galpha, gact, gp, gcall = gn
     rng = ops.rng_state(dsrc.device).data_ptr() if gp > 0 else 0
     stack = conv._stack["comb"]
-    ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, 2 * H, slot=("stack", len(pending)))
+    ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, 2 * H, slot=("stack", len(pending)),
+                              min_bytes=int(_lib.load().glass_comb_eff_ws_bytes(n, H, labels.cap)))
     rc = _lib.load().glass_comb_eff_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), mask.data_ptr(), float(conv.z_ratio),
                                             conv._stack_eff["comb"][1].data_ptr(), out.data_ptr(), out.stride(0), n, H,
                                             gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(),
@@ -97,7 +98,8 @@ def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels):
                                             xb.data_ptr(), xb.stride(0), ws.data_ptr(), labels.rows.data_ptr(),
                                             labels.count.data_ptr(), labels.cap, _stream())
     _check(rc, "glass_comb_eff_bwd_f32")
-    pending.append((ws.data_ptr(), n, 2 * H, 2 * H, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
+    # (9th field: the partials are in S / L form for a labeled-row list of that capacity)
+    pending.append((ws.data_ptr(), n, 2 * H, 2 * H, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc, labels.cap))
 
 
 class _GN:
@@ -290,14 +292,14 @@ def _reduce_pending(pending):
         dev = _wgrad_keep[0][0].device
         torch.cuda.current_stream().wait_stream(_wgrad_streams[dev])
         _wgrad_keep.clear()
-    cols = list(zip(*pending))
+    cols = list(zip(*[p if len(p) == 9 else p + (0, ) for p in pending]))
     u64 = lambda v: np.array(v, dtype=np.uint64)
     i64 = lambda v: np.array(v, dtype=np.int64)
     ws, N, O, I, dW, ld, db = u64(cols[0]), i64(cols[1]), i64(cols[2]), i64(cols[3]), u64(cols[4]), i64(cols[5]), u64(cols[6])
-    acc = np.array(cols[7], dtype=np.int32)
+    acc, cap = np.array(cols[7], dtype=np.int32), i64(cols[8])
     rc = _lib.load().glass_linear_wgrad_reduce_batch_f32(len(pending), ws.ctypes.data, N.ctypes.data, O.ctypes.data,
                                                          I.ctypes.data, dW.ctypes.data, ld.ctypes.data, db.ctypes.data,
-                                                         acc.ctypes.data, _stream())
+                                                         acc.ctypes.data, cap.ctypes.data, _stream())
     _check(rc, "glass_linear_wgrad_reduce_batch_f32")
 
 

@@ -314,9 +314,13 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
  *   glass_dual_linear_fwd_f32 / _bwd_f32 on the same pair.  Wimg_eff / WTimg_eff: operand images of layout 6 / 7
  *   (glass_dense_pack_batch_f32).  stats / gn_partial hold glass_comb_eff_blocks(n_nodes, H, lab_cap) entries of [2][H]
  *   doubles (row tiles, then extra workgroups).  Other arguments as in glass_dual_linear_fwd_f32 (xb != NULL, act none,
- *   no T) and glass_dual_linear_bwd_f32 (n_out = 2H, no addend, no dropout on the output; X == NULL: data gradient only). */
+ *   no T) and glass_dual_linear_bwd_f32 (n_out = 2H, no addend, no dropout on the output; X == NULL: data gradient only).
+ *   The weight-gradient partials written to `ws` are in S / L form: one [H x 2H] product over all rows plus the same over the
+ *   listed rows (half the matrix work of the plain form); reduce them with glass_linear_wgrad_reduce_batch_f32, lab_cap[j]
+ *   = this call's lab_cap. */
 int glass_comb_eff_supported(int64_t H);
 int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap);
+int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t lab_cap); /* `ws` of glass_comb_eff_bwd_f32 */
 int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,
                            const float* bias, const uint8_t* mask, double z_ratio, float* out, int64_t ldo,
                            int64_t n_nodes, int64_t H, double* stats, const float* gn_saved, int gn_act, float p_drop,
@@ -331,10 +335,12 @@ int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint8_t* mask, 
 /*     Deferred reduction: glass_dual_linear_wgrad_f32 with dW == NULL only writes the per-slab partial sums
  *     into `ws` (one scratch buffer per pending gradient); this call then reduces n_jobs of them — job j is
  *     the gradient of a [O[j], I[j]] weight over N[j] rows — into dW[j] / db[j] (db[j] may be NULL) with ONE
- *     launch.  All array arguments are HOST arrays. */
+ *     launch.  All array arguments are HOST arrays.  lab_cap (may be NULL): lab_cap[j] > 0 marks job j as the partials
+ *     of glass_comb_eff_bwd_f32 called with that list capacity (S / L form: dW1 = (1-z) S + (2z-1) L, dW0 = z S - (2z-1) L
+ *     with S the all-rows and L the labeled-rows sum of dc^T [g || x_]). */
 int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, const int64_t* N, const int64_t* O,
                                         const int64_t* I, float* const* dW, const int64_t* lddw, float* const* db,
-                                        const int32_t* accumulate, void* stream);
+                                        const int32_t* accumulate, const int64_t* lab_cap, void* stream);
 /*     Pack up to 16 weight operands B[NT][KT] (NT, KT multiples of 64) into MFMA image order in one launch.
  *     flags[k] bit 0 = transposed: 0: B = src[k] ([NT][KT] row-major); 1: B[n][k] = src[k][k][n] (src is [KT][NT]).
  *     flags[k] >> 1 = layout: 0 wave16, 1 tiled paired (NT = 2H), 2 tiled plain (tiled: NT a multiple of 256), 3 tiled

@@ -177,8 +177,8 @@ def test_step_program_entry_points_validate_on_the_host():
     assert lib.glass_graphnorm_bwd_from_stats_f32(p, 4, p, 4, p, 4, None, 0, 4, 4, p, p, p, None, 3, p, p, p, 1, 0, 0.0, None,
                                                   0, p, None) == -1
     # deferred reduction and batch copy
-    assert lib.glass_linear_wgrad_reduce_batch_f32(0, None, None, None, None, None, None, None, None, None) == 0
-    assert lib.glass_linear_wgrad_reduce_batch_f32(1, None, None, None, None, None, None, None, None, None) == -1
+    assert lib.glass_linear_wgrad_reduce_batch_f32(0, None, None, None, None, None, None, None, None, None, None) == 0
+    assert lib.glass_linear_wgrad_reduce_batch_f32(1, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.glass_copy_pair(p, p, 6, p, p, 4, None) == -1 and lib.glass_copy_pair(None, p, 4, p, p, 4, None) == -1
     # fused dense forward: GraphNorm prologue without a side output is rejected before any launch
     assert lib.glass_dual_linear_fwd_f32(p, 64, None, 0, p, p, p, 0.9, 1, p, 128, p, 64, 16, 64, None, p, 0, 0.0, None, 0,
