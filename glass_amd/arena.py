@@ -152,7 +152,7 @@ class ParamArena(FlatGradBucket):
                 mod._glass_arena = self  # EmbZGConv.forward refreshes the images once per training forward
         self.refresh_transposes()
 
-    def refresh_transposes(self, rng_state=None):
+    def refresh_transposes(self, rng_state=None, table=None):
         """Re-pack every stacked weight into the operand images of the fused dense kernels (forward: W,
         data gradient: W^T): one launch for the whole model.  rng_state (the device-resident dropout counter,
         ops.rng_state): advanced by the same launch — the two once-per-step prologue jobs share it."""
@@ -160,17 +160,34 @@ class ParamArena(FlatGradBucket):
         from . import _lib, ops
         for i, p in enumerate(self._packs):  # the pairs' CURRENT z_ratio (the kernels receive the live value as well)
             zr[i] = float(getattr(p[5], "z_ratio", 0.0))
-        if k == 0 and rng_state is not None:
+        if k == 0 and rng_state is not None and table is None:
             ops.rng_advance(rng_state.device)
-        for i in range(0, k, 16):
+        # table = (W, V, class_rowptr, emb_gn module, saved[4H], table-or-None): emb_gn's statistics through the embedding
+        # table ride in the (first) pack launch — glass_step_prologue_f32
+        for i in range(0, max(k, 1), 16):
             n = min(16, k - i)
-            rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
-                                                        kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, n,
-                                                        rng_state.data_ptr() if (rng_state is not None and i == 0) else 0,
-                                                        torch.cuda.current_stream().cuda_stream)
-            _lib.check(rc, "glass_dense_pack_batch_f32")
+            rng = rng_state.data_ptr() if (rng_state is not None and i == 0) else 0
+            st = torch.cuda.current_stream().cuda_stream
+            if table is not None and i == 0:
+                W, V, rowptr, gn, saved, tab = table
+                rc = _lib.load().glass_step_prologue_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
+                                                         kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, n, rng,
+                                                         W.data_ptr(), V, rowptr.data_ptr(), gn.weight.data_ptr(),
+                                                         gn.bias.data_ptr(), gn.mean_scale.data_ptr(), float(gn.eps),
+                                                         saved.data_ptr(), 0 if tab is None else tab.data_ptr(), W.shape[1], st)
+                _lib.check(rc, "glass_step_prologue_f32")
+            elif n > 0:
+                rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
+                                                            kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, n, rng, st)
+                _lib.check(rc, "glass_dense_pack_batch_f32")
+            else:
+                continue
             if rng_state is not None and i == 0:
                 ops.note_rng_advance(rng_state.device)
+
+    def offset_of(self, param):
+        """Element offset of a parameter inside the flat buffers (None: not in the arena)."""
+        return self._offsets.get(id(param))
 
     def attached(self):
         base_p, base_g = self.flat_param.untyped_storage().data_ptr(), self.flat.untyped_storage().data_ptr()

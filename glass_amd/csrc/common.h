@@ -108,4 +108,51 @@ __device__ __forceinline__ void drop_scales(const Drop& d, int64_t row, int c0, 
     }
 }
 
+// ---- Adam (torch.optim.Adam, single-tensor formulation, amsgrad off) --------------------------------------------------
+//   m = lerp(m, g, 1-b1); v = v*b2 + (1-b2)*g*g; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// Shared by the stand-alone optimizer launch (linear.hip) and the step's last launch, where it rides behind the
+// embedding-table backward (embnorm.hip).
+struct AdamCoef {
+    float step_size, bc2_sqrt, w1, w2, beta2, eps, weight_decay;
+};
+
+__device__ __forceinline__ AdamCoef adam_coef(int64_t step_now, float lr, float beta1, float beta2, float eps, float weight_decay) {
+    const double t = (double)step_now;
+    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    AdamCoef c;
+    c.step_size = (float)((double)lr / bc1);
+    c.bc2_sqrt = (float)sqrt(bc2);
+    c.w1 = 1.f - beta1;
+    c.w2 = 1.f - beta2;
+    c.beta2 = beta2;
+    c.eps = eps;
+    c.weight_decay = weight_decay;
+    return c;
+}
+
+__device__ __forceinline__ void adam_update(const AdamCoef& c, float* __restrict__ p, float gk, float* __restrict__ m,
+                                            float* __restrict__ v, int64_t k) {
+    const float pk = p[k];
+    if (c.weight_decay != 0.f) gk = fmaf(c.weight_decay, pk, gk);
+    const float mk = m[k] + c.w1 * (gk - m[k]);
+    const float vk = v[k] * c.beta2 + c.w2 * gk * gk;
+    m[k] = mk;
+    v[k] = vk;
+    const float denom = sqrtf(vk) / c.bc2_sqrt + c.eps;
+    p[k] = pk - c.step_size * (mk / denom);
+}
+
+// step_dev = int64[2]: (steps completed, ticket).  Every workgroup reads the count first and takes a ticket last; the
+// workgroup that takes the last ticket publishes count + 1 and clears the ticket.
+__device__ __forceinline__ void adam_ticket(int64_t* __restrict__ step_dev, int64_t step_now) {
+    __syncthreads();  // every thread of this workgroup has read step_dev[0]
+    if (threadIdx.x == 0) {
+        const unsigned long long taken = atomicAdd(reinterpret_cast<unsigned long long*>(step_dev + 1), 1ull) + 1ull;
+        if (taken == gridDim.x) {
+            step_dev[1] = 0;
+            step_dev[0] = step_now;
+        }
+    }
+}
+
 }  // namespace glass

@@ -21,6 +21,7 @@
 #include "common.h"
 #include "dense_common.h"
 #include "wgrad_common.h"
+#include "emb_table.h"
 
 #include <stdlib.h>
 
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
                                                                const uint8_t* __restrict__ mask, float zr, float omz,
                                                                int act, float* __restrict__ T, int64_t ldt,
                                                                float* __restrict__ out, int64_t ldo, int64_t N,
-                                                               double* __restrict__ stats, GnPrologue pro) {
+                                                               double* __restrict__ stats, GnPrologue pro,
+                                                               const int64_t* __restrict__ xa_index, int xa_rows) {
     constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H;
     constexpr int THREADS = kWave * RW * CS;  // RW row waves (16 rows each) x CS column groups
     constexpr int NG = H / 64;       // 64-column groups per half
@@ -217,7 +219,14 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
     // this lane's K-chunk of its A row: q*KQ .. (q+1)*KQ of [xa || xb]
     const float* arow;
     if (!COMB) {
-        arow = xa + row * lda + q * KQ;
+        // xa_index: row n of the operand is row xa_index[n] of xa (the embedding table: the lookup of
+        // impl/models.py:248 happens in this load; the prologue's side output is the [N,H] layer input)
+        int64_t src = row;
+        if (xa_index) {
+            src = row_ok ? xa_index[row] : 0;
+            src = src < 0 ? 0 : (src >= xa_rows ? xa_rows - 1 : src);
+        }
+        arow = xa + src * lda + q * KQ;
     } else {
         arow = (q < 2) ? xa + row * lda + q * KQ : xb + row * ldb + (q - 2) * KQ;  // KQ = H/2
     }
@@ -845,8 +854,27 @@ __device__ __forceinline__ float4 pack_fetch(const PackJob& j, int n, int k) {
                        j.src[(int64_t)(k + 3) * j.NT + n]);
 }
 
-__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state) {
+// The other once-per-step prologue job rides in the same launch (grid row n_jobs): emb_gn's statistics through the
+// embedding table (embnorm.hip, emb_table.h) — it only depends on the parameters, like the packing.
+struct TableJob {
+    const float* W;  // nullptr: none
+    int V, H;
+    const int32_t* rowptr;
+    const float *gamma, *beta, *alpha;
+    float eps;
+    float *saved, *table;
+};
+
+__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state, TableJob tab, int n_jobs) {
     if (rng_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rng_state[1] += 1;  // see glass_rng_advance
+    if ((int)blockIdx.y >= n_jobs) {
+        __shared__ double tab_lds[kBlock * 2];
+        __shared__ float tab_coef[2 * kTabCols];
+        if (tab.W && (int)blockIdx.x < (tab.H + kTabCols - 1) / kTabCols)
+            emb_table_fwd_block(blockIdx.x, tab.W, tab.V, tab.H, tab.rowptr, tab.gamma, tab.beta, tab.alpha, tab.eps, tab.saved,
+                                tab.table, tab_lds, tab_coef);
+        return;
+    }
     const PackJob j = batch.job[blockIdx.y];
     const int total = j.NT * j.KT / 4;  // float4 elements
     if (j.layout == kLayoutWave16) {
@@ -956,6 +984,8 @@ static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at 
 // instantiated.
 // (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
+// glass_dual_linear_fwd_f32 with xa_index (the trans pair of layer 0 gathers its operand rows from the embedding table)
+extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return wave16_shape_ok(H) ? 1 : 0; }
 
 // Operand-image layout glass_dense_pack_batch_f32 must produce for hidden size H: 0 = wave16 images (forward and data
 // gradient alike), 1 = tiled (forward operand: paired layout; data-gradient operand: plain layout)
@@ -984,8 +1014,15 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
                                          int64_t ldt, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
                                          double* stats, const float* gn_saved, int gn_act, float p_drop,
                                          const uint64_t* rng_state, uint64_t call_id, float* xa_out, int64_t ldxo,
-                                         void* stream) {
+                                         const int64_t* xa_index, int64_t xa_rows, void* stream) {
     GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
+    GLASS_REQUIRE(!xa_index || (gn_saved && !xb && xa_rows > 0 && xa_rows < (1ll << 31)),
+                  "dual_linear_fwd: a gathered operand needs the GraphNorm prologue (its side output is the gathered, "
+                  "normalised [N,H] input) and is the trans pair's");
+    if (xa_index && !wave16_shape_ok(H)) {
+        set_error("dual_linear_fwd: gathered operand only at hidden 64 (glass_dual_linear_fwd_gather_supported)");
+        return GLASS_E_UNSUPPORTED;
+    }
     GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved) &&
                                 p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
                                 (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
@@ -1013,10 +1050,11 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
         allow_lds(dual_fwd_kernel<HH, false, CS, RW>, lds_trans);                                                  \
         if (comb)                                                                                                  \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, true, CS, RW>), grid, dim3(kWave * RW * CS), lds_comb, st, xa, lda,  \
-                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro, nullptr, 0); \
         else                                                                                                       \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS, RW>), grid, dim3(kWave * RW * CS), lds_trans, st, xa, lda, \
-                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro);       \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro, xa_index,  \
+                               (int)xa_rows);                                                                      \
     }
     GLASS_FWD(64, 1, 4)
 #undef GLASS_FWD
@@ -1235,18 +1273,17 @@ extern "C" int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t l
     return (g.part_w_floats + g.part_b_floats) * (int64_t)sizeof(float);
 }
 
-extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,
-                                          const int64_t* KT, const int32_t* transposed, const float* z_ratio,
-                                          int64_t n_jobs, uint64_t* rng_state, void* stream) {
-    GLASS_REQUIRE(src && dst && NT && KT && transposed && n_jobs >= 0 && n_jobs <= kMaxPackJobs,
-                  "dense_pack_batch: bad arguments (at most %d matrices per call)", kMaxPackJobs);
-    if (n_jobs == 0) return rng_state ? glass_rng_advance(rng_state, stream) : 0;
+static int pack_launch(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
+                       const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
+                       const TableJob& tab, void* stream, const char* what) {
+    GLASS_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs && (n_jobs == 0 || (src && dst && NT && KT && transposed)),
+                  "%s: bad arguments (at most %d matrices per call)", what, kMaxPackJobs);
     PackBatch b;
     for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0, 0, 0.f};
     for (int k = 0; k < n_jobs; ++k) {
         GLASS_REQUIRE(src[k] && dst[k] && NT[k] > 0 && NT[k] % 64 == 0 && KT[k] > 0 && KT[k] % 64 == 0 && aligned16(src[k]) &&
                           aligned16(dst[k]),
-                      "dense_pack_batch: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", k);
+                      "%s: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", what, k);
         const int layout = transposed[k] >> 1;
         GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
                           (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
@@ -1254,11 +1291,35 @@ extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const*
                           (layout == kLayoutTiledPairedEff && NT[k] % 512 == 0 && !(transposed[k] & 1) && z_ratio) ||
                           (layout == kLayoutWave16EffFwd && NT[k] % 128 == 0 && !(transposed[k] & 1) && z_ratio) ||
                           (layout == kLayoutWave16EffDgrad && KT[k] % 128 == 0 && (transposed[k] & 1) && z_ratio),
-                      "dense_pack_batch: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
-                      "layout that is not the transposed 128 x 256 operand", k, layout);
+                      "%s: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
+                      "layout that is not the transposed 128 x 256 operand", what, k, layout);
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f};
     }
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(32, (unsigned)n_jobs), dim3(kBlock), 0, (hipStream_t)stream, b,
-                       rng_state);
-    return launch_status("glass_dense_pack_batch_f32");
+    unsigned gx = 32;
+    if (tab.W && (unsigned)ceil_div(tab.H, kTabCols) > gx) gx = (unsigned)ceil_div(tab.H, kTabCols);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(gx, (unsigned)n_jobs + (tab.W ? 1u : 0u)), dim3(kBlock), 0, (hipStream_t)stream, b,
+                       rng_state, tab, (int)n_jobs);
+    return launch_status(what);
+}
+
+extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,
+                                          const int64_t* KT, const int32_t* transposed, const float* z_ratio,
+                                          int64_t n_jobs, uint64_t* rng_state, void* stream) {
+    GLASS_REQUIRE(src && dst && NT && KT && transposed && n_jobs >= 0 && n_jobs <= kMaxPackJobs,
+                  "dense_pack_batch: bad arguments (at most %d matrices per call)", kMaxPackJobs);
+    if (n_jobs == 0) return rng_state ? glass_rng_advance(rng_state, stream) : 0;
+    return pack_launch(src, dst, NT, KT, transposed, z_ratio, n_jobs, rng_state, TableJob{}, stream, "glass_dense_pack_batch_f32");
+}
+
+// The once-per-step prologue as ONE launch: the weight packing above + emb_gn's statistics through the embedding table
+// (the first half of glass_embed_norm_fwd_f32: saved[4H]; table may be NULL when the consumer gathers from W itself).
+extern "C" int glass_step_prologue_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
+                                       const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
+                                       const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma,
+                                       const float* beta, const float* alpha, float eps, float* saved, float* table,
+                                       int64_t H, void* stream) {
+    GLASS_REQUIRE(W && class_rowptr && gamma && beta && alpha && saved && H > 0 && V > 0 && V <= GLASS_EMBED_NORM_MAX_ROWS,
+                  "step_prologue: bad embedding-table arguments (at most %d rows)", GLASS_EMBED_NORM_MAX_ROWS);
+    const TableJob tab{W, (int)V, (int)H, class_rowptr, gamma, beta, alpha, eps, saved, table};
+    return pack_launch(src, dst, NT, KT, transposed, z_ratio, n_jobs, rng_state, tab, stream, "glass_step_prologue_f32");
 }

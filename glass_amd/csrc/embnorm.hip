@@ -12,24 +12,10 @@
 //     S1 = sum_v G[v],  S2 = sum_v G[v]*xhat[v],  dW[v] = A*G[v] + cnt[v]*(Bx*W[v] + K)
 // — instead of backward statistics + finalize + apply over [N,H] and an extra add into dW.
 #include "common.h"
+#include "emb_table.h"
 #include "gn_math.h"
 
 namespace glass {
-
-constexpr int kTabCols = 16;                    // columns per workgroup (one per lane of a 16-lane group)
-constexpr int kTabSlots = kBlock / kTabCols;    // row slots per workgroup (16): V ~ 60 rows -> 4 sequential loads each
-
-// Sum the two fp64 accumulators of this thread's column over the row slots (fixed order); result valid in slot 0.
-__device__ __forceinline__ void slot_reduce(double& a, double& b, double* lds, int tc, int tr) {
-    lds[threadIdx.x * 2] = a;
-    lds[threadIdx.x * 2 + 1] = b;
-    __syncthreads();
-    if (tr == 0)
-        for (int r = 1; r < kTabSlots; ++r) {
-            a += lds[(r * kTabCols + tc) * 2];
-            b += lds[(r * kTabCols + tc) * 2 + 1];
-        }
-}
 
 __global__ __launch_bounds__(kBlock) void emb_table_fwd_kernel(const float* __restrict__ W, int V, int H,
                                                                const int32_t* __restrict__ rowptr,
@@ -47,32 +33,7 @@ __global__ __launch_bounds__(kBlock) void emb_table_fwd_kernel(const float* __re
         for (int64_t n = (int64_t)blockIdx.x * kBlock + threadIdx.x; n < n_nodes; n += (int64_t)gridDim.x * kBlock)
             mask_fill[n] = (uint8_t)fill_value;
     if ((int)blockIdx.x >= (H + kTabCols - 1) / kTabCols) return;  // extra workgroups only help with the fill
-    const int tc = threadIdx.x & (kTabCols - 1), tr = threadIdx.x / kTabCols;
-    const int c = blockIdx.x * kTabCols + tc;
-    const bool ok = c < H;
-    double s = 0.0, q = 0.0;
-    if (ok)
-        for (int v = tr; v < V; v += kTabSlots) {
-            const double cn = (double)(rowptr[v + 1] - rowptr[v]);
-            const double w = (double)W[(int64_t)v * H + c];
-            s += cn * w;
-            q += cn * w * w;
-        }
-    slot_reduce(s, q, lds, tc, tr);
-    if (tr == 0 && ok) {
-        float mu, rstd, scale, shift;
-        gn_fwd_coeffs(s, q, (double)rowptr[V], gamma[c], beta[c], alpha[c], eps, mu, rstd, scale, shift);
-        saved[c] = mu;
-        saved[H + c] = rstd;
-        saved[2 * H + c] = scale;
-        saved[3 * H + c] = shift;
-        coef[tc] = scale;
-        coef[kTabCols + tc] = shift;
-    }
-    __syncthreads();
-    if (!ok) return;
-    const float scale = coef[tc], shift = coef[kTabCols + tc];
-    for (int v = tr; v < V; v += kTabSlots) table[(int64_t)v * H + c] = fmaf(W[(int64_t)v * H + c], scale, shift);
+    emb_table_fwd_block(blockIdx.x, W, V, H, rowptr, gamma, beta, alpha, eps, saved, table, lds, coef);
 }
 
 __global__ __launch_bounds__(kBlock) void emb_table_bwd_kernel(const float* __restrict__ G, const float* __restrict__ W,
@@ -118,6 +79,109 @@ __global__ __launch_bounds__(kBlock) void emb_table_bwd_kernel(const float* __re
         const float d = fmaf(A, G[o], cn * fmaf(Bx, W[o], K));
         dW[o] = accumulate_w ? dW[o] + d : d;
     }
+}
+
+// The step's LAST launch on the table path: what is left of the selection product on K1 (rows cut into several chunks:
+// their partial rows summed in slot order), the table backward above, and Adam over the whole parameter arena.
+//   workgroups [0, n_tab): 16 table columns each — slot sums -> G, column sums, dW; then Adam on exactly the elements this
+//     workgroup produced (table columns, emb_gn's three vectors), by the threads that wrote their gradients;
+//   workgroups [n_tab, grid): Adam over the rest of the arena (every other gradient was final before this launch).
+// Three dependent launches (spmm_reduce, emb_table_bwd, adam) become one.
+struct TailAdam {
+    float* p;        // nullptr: no optimizer step here
+    float* g;
+    float *m, *v;
+    int64_t n;       // arena elements
+    const float* lr;
+    float beta1, beta2, eps, weight_decay;
+    int64_t* step;
+    int64_t off_W, off_gamma, off_beta, off_alpha;  // arena offsets of the table [V*H] and emb_gn's vectors [H]
+};
+
+// (W, gamma, alpha alias the parameter arena ad.p, which this kernel updates: no __restrict__ on them)
+__global__ __launch_bounds__(kBlock) void emb_tail_kernel(float* __restrict__ G, const float* W, int V, int H,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const float* gamma, const float* alpha,
+                                                          const float* __restrict__ saved, float* dW,
+                                                          int accumulate_w, float* __restrict__ dgamma,
+                                                          float* __restrict__ dbeta, float* __restrict__ dalpha,
+                                                          int accumulate, const float* __restrict__ partials,
+                                                          const int32_t* __restrict__ rrows, int n_reduce, TailAdam ad,
+                                                          int n_tab) {
+    __shared__ double lds[kBlock * 2];
+    __shared__ float coef[3 * kTabCols];
+    int64_t step_now = 0;
+    AdamCoef ac{};
+    if (ad.p) {
+        step_now = ad.step[0] + 1;
+        ac = adam_coef(step_now, ad.lr[0], ad.beta1, ad.beta2, ad.eps, ad.weight_decay);
+    }
+    if ((int)blockIdx.x >= n_tab) {  // Adam over everything this launch did not produce itself
+        const int64_t nb = (int64_t)gridDim.x - n_tab;
+        const int64_t tab_lo = ad.off_W, tab_hi = ad.off_W + (int64_t)V * H;
+        for (int64_t k = ((int64_t)blockIdx.x - n_tab) * kBlock + threadIdx.x; k < ad.n; k += nb * kBlock) {
+            if ((k >= tab_lo && k < tab_hi) || (k >= ad.off_gamma && k < ad.off_gamma + H) ||
+                (k >= ad.off_beta && k < ad.off_beta + H) || (k >= ad.off_alpha && k < ad.off_alpha + H))
+                continue;
+            adam_update(ac, ad.p, ad.g[k], ad.m, ad.v, k);
+        }
+        adam_ticket(ad.step, step_now);
+        return;
+    }
+    const int tc = threadIdx.x & (kTabCols - 1), tr = threadIdx.x / kTabCols;
+    const int c = blockIdx.x * kTabCols + tc;
+    const bool ok = c < H;
+    // rows of the selection product that were cut into several chunks: partial rows summed in slot order
+    if (ok)
+        for (int rr = tr; rr < n_reduce; rr += kTabSlots) {
+            const int row = rrows[3 * rr], first = rrows[3 * rr + 1], n = rrows[3 * rr + 2];
+            float sum = 0.f;
+            for (int k = 0; k < n; ++k) sum += partials[(int64_t)(first + k) * H + c];
+            G[(int64_t)row * H + c] = sum;
+        }
+    if (n_reduce > 0) __syncthreads();
+    double s1 = 0.0, s2 = 0.0;
+    if (ok) {
+        const float mu = saved[c], rstd = saved[H + c], al = alpha[c];
+        for (int v = tr; v < V; v += kTabSlots) {
+            const float g = G[(int64_t)v * H + c];
+            const float xhat = (W[(int64_t)v * H + c] - al * mu) * rstd;
+            s1 += (double)g;
+            s2 += (double)g * (double)xhat;
+        }
+    }
+    slot_reduce(s1, s2, lds, tc, tr);
+    if (tr == 0 && ok) {
+        float A, Bx, K, da;
+        gn_bwd_coeffs(s1, s2, (double)rowptr[V], gamma[c], alpha[c], saved[c], saved[H + c], A, Bx, K, da);
+        const float g_gamma = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+        const float g_beta = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+        const float g_alpha = (accumulate ? dalpha[c] : 0.f) + da;
+        dgamma[c] = g_gamma;
+        dbeta[c] = g_beta;
+        dalpha[c] = g_alpha;
+        coef[tc] = A;
+        coef[kTabCols + tc] = Bx;
+        coef[2 * kTabCols + tc] = K;
+        if (ad.p) {
+            adam_update(ac, ad.p, g_gamma, ad.m, ad.v, ad.off_gamma + c);
+            adam_update(ac, ad.p, g_beta, ad.m, ad.v, ad.off_beta + c);
+            adam_update(ac, ad.p, g_alpha, ad.m, ad.v, ad.off_alpha + c);
+        }
+    }
+    __syncthreads();
+    if (ok) {
+        const float A = coef[tc], Bx = coef[kTabCols + tc], K = coef[2 * kTabCols + tc];
+        for (int v = tr; v < V; v += kTabSlots) {
+            const int64_t o = (int64_t)v * H + c;
+            const float cn = (float)(rowptr[v + 1] - rowptr[v]);
+            float d = fmaf(A, G[o], cn * fmaf(Bx, W[o], K));
+            if (accumulate_w) d += dW[o];
+            dW[o] = d;
+            if (ad.p) adam_update(ac, ad.p, d, ad.m, ad.v, ad.off_W + o);  // (W aliases ad.p + off_W: read above, updated here)
+        }
+    }
+    if (ad.p) adam_ticket(ad.step, step_now);
 }
 
 // out[n,:] = dropout(table[x[n],:]), mask[n] = label byte (from z, or scattered from pos, or all ones)
@@ -251,4 +315,38 @@ extern "C" int glass_embed_norm_bwd_f32(const float* G, const float* W, int64_t 
                        W, (int)V, (int)H, class_rowptr, gamma, alpha, saved, dW, accumulate_w, dgamma, dbeta, dalpha,
                        accumulate);
     return launch_status("glass_embed_norm_bwd_f32");
+}
+
+extern "C" int glass_embed_norm_bwd_adam_f32(float* G, const float* W, int64_t V, const int32_t* class_rowptr,
+                                             const float* gamma, const float* alpha, const float* saved, float* dW,
+                                             int accumulate_w, float* dgamma, float* dbeta, float* dalpha, int accumulate,
+                                             int64_t H, const float* partials, const int32_t* reduce_rows, int64_t n_reduce,
+                                             float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
+                                             const float* lr_dev, double beta1, double beta2, double eps,
+                                             double weight_decay, int64_t* step_dev, int64_t off_W, int64_t off_gamma,
+                                             int64_t off_beta, int64_t off_alpha, void* stream) {
+    GLASS_REQUIRE(G && W && class_rowptr && gamma && alpha && saved && dW && dgamma && dbeta && dalpha,
+                  "embed_norm_bwd_adam: null pointer");
+    GLASS_REQUIRE(H > 0 && V > 0 && V <= GLASS_EMBED_NORM_MAX_ROWS && n_reduce >= 0 && (n_reduce == 0 || (partials && reduce_rows)),
+                  "embed_norm_bwd_adam: bad sizes");
+    TailAdam ad{};
+    const int n_tab = (int)ceil_div(H, kTabCols);
+    int64_t blocks = n_tab;
+    if (param) {
+        GLASS_REQUIRE(grad && exp_avg && exp_avg_sq && lr_dev && step_dev && n_param > 0 && off_W >= 0 &&
+                          off_W + V * H <= n_param && off_gamma >= 0 && off_gamma + H <= n_param && off_beta >= 0 &&
+                          off_beta + H <= n_param && off_alpha >= 0 && off_alpha + H <= n_param && dW == grad + off_W &&
+                          W == param + off_W && dgamma == grad + off_gamma && dbeta == grad + off_beta &&
+                          dalpha == grad + off_alpha,
+                      "embed_norm_bwd_adam: the table and emb_gn's vectors must be views of the arena at the given offsets");
+        ad = TailAdam{param, grad, exp_avg, exp_avg_sq, n_param, lr_dev, (float)beta1, (float)beta2, (float)eps,
+                      (float)weight_decay, step_dev, off_W, off_gamma, off_beta, off_alpha};
+        int64_t rest = ceil_div(n_param, kBlock);
+        if (rest > 2048) rest = 2048;
+        blocks += rest;
+    }
+    hipLaunchKernelGGL(emb_tail_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, G, W, (int)V, (int)H,
+                       class_rowptr, gamma, alpha, saved, dW, accumulate_w, dgamma, dbeta, dalpha, accumulate, partials,
+                       reduce_rows, (int)n_reduce, ad, n_tab);
+    return launch_status("glass_embed_norm_bwd_adam_f32");
 }

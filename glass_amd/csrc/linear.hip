@@ -288,30 +288,10 @@ __global__ __launch_bounds__(kBlock) void adam_kernel(float* __restrict__ p, con
                                                       float eps, float weight_decay,
                                                       int64_t* __restrict__ step_dev) {
     const int64_t step_now = step_dev[0] + 1;
-    const double t = (double)step_now;
-    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
-    const float step_size = (float)((double)lr_dev[0] / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
-    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock) {
-        float gk = g[k];
-        const float pk = p[k];
-        if (weight_decay != 0.f) gk = fmaf(weight_decay, pk, gk);
-        const float mk = m[k] + w1 * (gk - m[k]);
-        const float vk = v[k] * beta2 + w2 * gk * gk;
-        m[k] = mk;
-        v[k] = vk;
-        const float denom = sqrtf(vk) / bc2_sqrt + eps;
-        p[k] = pk - step_size * (mk / denom);
-    }
-    __syncthreads();  // every thread of this workgroup has read step_dev[0]
-    if (threadIdx.x == 0) {
-        const unsigned long long taken = atomicAdd(reinterpret_cast<unsigned long long*>(step_dev + 1), 1ull) + 1ull;
-        if (taken == gridDim.x) {
-            step_dev[1] = 0;
-            step_dev[0] = step_now;
-        }
-    }
+    const AdamCoef c = adam_coef(step_now, lr_dev[0], beta1, beta2, eps, weight_decay);
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < n; k += (int64_t)gridDim.x * kBlock)
+        adam_update(c, p, g[k], m, v, k);
+    adam_ticket(step_dev, step_now);
 }
 
 }  // namespace glass

@@ -338,6 +338,98 @@ __global__ __launch_bounds__(kOrdBlock) void readout_scatter_ordered_kernel(cons
     }
 }
 
+// R3 + R4 as ONE launch when the batch's unique pooled rows are listed (glass_batch_labels: the pooled rows of a step ARE
+// its labeled rows): workgroups [0, n_dense) write  d jk = Bx*x + K  on every row that is NOT pooled (label byte 0);
+// the workgroups behind them take 16 listed rows each, one per wave, and write the row's full value
+// Bx*x + K + A * (sum of g over the subgraphs holding it, in (b, s) order) — every row written once, no atomics, the same
+// arithmetic in the same order as R3 followed by the ordered R4 (bitwise equal).
+__global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                    float* __restrict__ dx, int64_t lddx, int64_t N, int C,
+                                                                    int tc_log2, const float* __restrict__ coef,
+                                                                    const uint8_t* __restrict__ mask,
+                                                                    const int64_t* __restrict__ pos, int Smax, int n_pos,
+                                                                    const float* __restrict__ dys,
+                                                                    const int32_t* __restrict__ lab_rows,
+                                                                    const int32_t* __restrict__ lab_count, int n_dense) {
+    extern __shared__ int32_t nodes[];
+    if ((int)blockIdx.x < n_dense) {
+        const int TC = 1 << tc_log2, rpb = kOrdBlock >> tc_log2;
+        const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+        const int c0 = tc * 4;
+        if (c0 >= C) return;
+        const float4 Bx = *reinterpret_cast<const float4*>(coef + C + c0);
+        const float4 K = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
+        const int64_t stride = (int64_t)n_dense * rpb;
+        for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * 4) {
+            float4 v[4];
+            bool live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + u * stride;
+                live[u] = rr < N && mask[rr] == 0;
+                if (live[u]) v[u] = *reinterpret_cast<const float4*>(x + rr * ldx + c0);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + u * stride;
+                if (!live[u]) continue;
+                *reinterpret_cast<float4*>(dx + rr * lddx + c0) =
+                    make_float4(fmaf(Bx.x, v[u].x, K.x), fmaf(Bx.y, v[u].y, K.y), fmaf(Bx.z, v[u].z, K.z),
+                                fmaf(Bx.w, v[u].w, K.w));
+            }
+        }
+        return;
+    }
+    constexpr int kWaves = kOrdBlock / kWave;
+    const int n_lab = lab_count[0];
+    const int first = ((int)blockIdx.x - n_dense) * kWaves;
+    if (first >= n_lab) return;  // (workgroup-uniform)
+    for (int j = threadIdx.x; j < n_pos; j += kOrdBlock) {
+        const int64_t p = pos[j];
+        nodes[j] = (p >= 0 && p < N) ? (int32_t)p : -1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (first + w >= n_lab) return;
+    const int node = lab_rows[first + w];
+    float4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j0 = 0; j0 < n_pos; j0 += kWave) {
+        const int jj = j0 + lane;
+        unsigned long long hits = __ballot(jj < n_pos && nodes[jj] == node);
+        while (hits) {
+            const int bit = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const float* grow = dys + (int64_t)((j0 + bit) / Smax) * C;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int c = lane * 4 + kWave * 4 * t;
+                if (c < C) {
+                    const float4 A = *reinterpret_cast<const float4*>(coef + c);
+                    const float4 g = *reinterpret_cast<const float4*>(grow + c);
+                    acc[t].x = fmaf(A.x, g.x, acc[t].x);
+                    acc[t].y = fmaf(A.y, g.y, acc[t].y);
+                    acc[t].z = fmaf(A.z, g.z, acc[t].z);
+                    acc[t].w = fmaf(A.w, g.w, acc[t].w);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int c = lane * 4 + kWave * 4 * t;
+        if (c < C) {
+            const float4 Bx = *reinterpret_cast<const float4*>(coef + C + c);
+            const float4 K = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+            const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)node * ldx + c);
+            float4 o = make_float4(fmaf(Bx.x, xv.x, K.x), fmaf(Bx.y, xv.y, K.y), fmaf(Bx.z, xv.z, K.z), fmaf(Bx.w, xv.w, K.w));
+            o.x += acc[t].x; o.y += acc[t].y; o.z += acc[t].z; o.w += acc[t].w;
+            *reinterpret_cast<float4*>(dx + (int64_t)node * lddx + c) = o;
+        }
+    }
+}
+
 // R4: d jk[n] += A * g on the pooled rows
 __global__ __launch_bounds__(kBlock) void readout_scatter_kernel(const int64_t* __restrict__ pos, int Smax,
                                                                  const float* __restrict__ dys,
@@ -379,7 +471,8 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
                                        const float* Wh, const float* bh, const void* target, int loss_mode, int64_t K,
                                        const float* grad_loss, float* pooled, float* logits, float* loss, float* djk,
                                        int64_t lddj, float* dWh, float* dbh, int acc_head, float* dgamma, float* dbeta,
-                                       float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C, void* stream) {
+                                       float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
+                                       const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count, void* stream) {
     GLASS_REQUIRE(jk && gn_saved && gamma && alpha && pos && Wh && bh && target && grad_loss && pooled && logits && loss &&
                       djk && dWh && dbh && ws,
                   "readout_train: null pointer");
@@ -407,6 +500,17 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     if (sizeof(float) * (size_t)B > lds2) lds2 = sizeof(float) * (size_t)B;
     GLASS_REQUIRE(lds2 <= 64 * 1024, "readout_train: batch too large for the LDS staging");
     hipLaunchKernelGGL(readout_reduce_kernel, dim3((unsigned)(K + 1 + ceil_div(C, kFinCols))), dim3(kBlock), lds2, st, a2);
+    if (mask && lab_rows && lab_count && B * Smax <= kReadoutOrderedMax) {
+        // the pooled rows are listed (glass_batch_labels on this pos): dense and sparse part as ONE launch
+        const int rpb1 = kOrdBlock / tc;
+        int64_t n_dense = ceil_div(n_nodes, (int64_t)rpb1 * 4);
+        if (n_dense > 2048) n_dense = 2048;
+        const int64_t n_sparse = ceil_div(B * Smax, (int64_t)(kOrdBlock / kWave));
+        hipLaunchKernelGGL(readout_backfill_kernel, dim3((unsigned)(n_dense + n_sparse)), dim3(kOrdBlock),
+                           sizeof(int32_t) * (size_t)(B * Smax), st, jk, ldj, djk, lddj, n_nodes, (int)C, tc_log2, w.coef, mask,
+                           pos, (int)Smax, (int)(B * Smax), w.dys, lab_rows, lab_count, (int)n_dense);
+        return launch_status("glass_readout_train_f32");
+    }
     const int rpb = kBlock / tc;
     int64_t blocks = ceil_div(n_nodes, (int64_t)rpb * 4);
     if (blocks > 4096) blocks = 4096;

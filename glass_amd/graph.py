@@ -132,3 +132,23 @@ class Selection:
         rowptr = _csr_from_sorted(x_flat[perm], n_rows_table)
         self.op = CSROperand(rowptr, perm.to(torch.int32).contiguous(),
                              torch.ones(n, dtype=torch.float32, device=x_flat.device), n_rows_table, n)
+        # the same plan with its reduce launch switched off (header word 6 = number of reduce rows): the consumer sums the
+        # partial rows itself (glass_embed_norm_bwd_adam_f32)
+        self._hdr_noreduce = self.op.header.copy()
+        self._n_reduce = int(self.op.header[6])
+        self._off_reduce = int(self.op.header[12])
+        self._hdr_noreduce[6] = 0
+
+    def product_without_reduce(self, x):
+        """G = S^T @ x on K1 WITHOUT the final reduce launch: rows cut into several chunks are left as partial rows.
+        Returns (G, partials pointer, device pointer of the plan's reduce list, number of reduce rows)."""
+        op = self.op
+        H = x.shape[1]
+        G = torch.empty((op.n_rows, H), dtype=torch.float32, device=x.device)
+        ws = op.workspace(H)
+        rc = _lib.load().glass_spmm_csr_f32(op.rowptr.data_ptr(), op.col.data_ptr(), op.val.data_ptr(), x.data_ptr(),
+                                            x.stride(0), G.data_ptr(), G.stride(0), op.n_rows, H,
+                                            self._hdr_noreduce.ctypes.data, op.plan.data_ptr(), ws.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "glass_spmm_csr_f32")
+        return G, ws.data_ptr(), op.plan.data_ptr() + 4 * self._off_reduce, self._n_reduce

@@ -424,7 +424,7 @@ class DualLinearMixFn(torch.autograd.Function):
                                                    0 if xb is None else ldb, Wimg.data_ptr(), b.data_ptr(),
                                                    mask.data_ptr(), float(z_ratio), act, 0 if T is None else T.data_ptr(),
                                                    2 * H, out.data_ptr(), out.stride(0), n, H, 0, 0, 0, 0.0, 0, 0, 0, 0,
-                                                   _stream())
+                                                   0, 0, _stream())
         _lib.check(rc, "glass_dual_linear_fwd_f32")
         ctx.save_for_backward(xa, xb, T, mask)
         ctx.cfg = (float(z_ratio), act, stack, n, H)

@@ -27,6 +27,17 @@ class FlatAdam(torch.optim.Optimizer):
             self.lr_dev.fill_(lr)
             self._lr_host = lr
 
+    def fusable(self):
+        """The update can ride in the step program's last launch (glass_embed_norm_bwd_adam_f32): one unsharded arena."""
+        return not self.arena.sharded() and self.arena.attached()
+
+    def fused_args(self):
+        """(param, grad, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps, weight_decay, step_dev) of the whole arena."""
+        g, a = self.param_groups[0], self.arena
+        return (a.flat_param.data_ptr(), a.flat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                a.flat_param.numel(), self.lr_dev.data_ptr(), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                float(g["weight_decay"]), self.step_dev.data_ptr())
+
     def zero_grad(self, set_to_none=False):
         self.arena.zero()
 

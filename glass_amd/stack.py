@@ -36,6 +36,8 @@ def _check(rc, what):
     _lib.check(rc, what)
 
 
+USE_FUSED_TAIL = os.environ.get("GLASS_FUSED_TAIL", "1") != "0"  # A/B switch: K1 slot sums + table backward + Adam as one launch
+USE_GATHER_IN_TRANS = os.environ.get("GLASS_GATHER_IN_TRANS", "1") != "0"  # A/B switch: embedding lookup inside layer 0's trans kernel
 USE_COMB_EFF = os.environ.get("GLASS_COMB_EFF", "1") != "0"  # A/B switch: comb pair through effective per-label weights
 
 
@@ -181,23 +183,26 @@ class _GN:
         _check(rc, "glass_graphnorm_bwd_f32")
 
 
-def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None, gn=None):
+def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None, gn=None, xa_index=None):
     """stats: [ceil(n/64), 2, H] float64 — per-workgroup column sums of `out` for the GraphNorm that follows.
     gn = (saved, act, p_drop, call_id, xa_out): xa is the raw input of a GraphNorm with final statistics `saved`; the
-    kernel normalises (+act +dropout) while loading and writes the normalised operand to xa_out."""
-    n, H = xa.shape
+    kernel normalises (+act +dropout) while loading and writes the normalised operand to xa_out.
+    xa_index (int64 [n]): operand row k is row xa_index[k] of xa (the embedding table; needs gn, whose side output xa_out
+    is then the gathered, normalised [n, H] layer input)."""
+    n, H = (xa_index.shape[0] if xa_index is not None else xa.shape[0]), xa.shape[1]
     if gn is not None:
         saved, gact, gp, gcall, xa_out = gn
         grng = ops.rng_state(xa.device).data_ptr() if gp > 0 else 0
         gargs = (saved.data_ptr(), gact, float(gp), grng, gcall, xa_out.data_ptr(), xa_out.stride(0))
     else:
         gargs = (0, 0, 0.0, 0, 0, 0, 0)
+    iargs = (0, 0) if xa_index is None else (xa_index.data_ptr(), xa.shape[0])
     rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                                0 if xb is None else xb.stride(0), stack[4].data_ptr(),
                                                stack[1].data_ptr(), mask.data_ptr(), float(z_ratio), act,
                                                0 if T is None else T.data_ptr(), 0 if T is None else T.stride(0),
                                                out.data_ptr(), out.stride(0), n, H,
-                                               0 if stats is None else stats.data_ptr(), *gargs, _stream())
+                                               0 if stats is None else stats.data_ptr(), *gargs, *iargs, _stream())
     _check(rc, "glass_dual_linear_fwd_f32")
 
 
@@ -345,7 +350,6 @@ class StackProgram:
         f32 = dict(dtype=torch.float32, device=dev)
         # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
         advance = train and (p > 0 or any(c.dropout > 0 for c in emb.convs))
-        emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
         st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc), "rng_epoch": ops.rng_epoch(dev),
               "stat_rows": int(lib.glass_dual_linear_stat_rows(H))}  # rows per workgroup of the fused dense kernels
         # labels: z (int64 [N], > 0 = labeled), None (all labeled), or ("pos", pos): labeled = the nodes listed in the
@@ -353,8 +357,7 @@ class StackProgram:
         # labels (BatchLabels, already loaded for this batch): the label bytes are an input and the unique labeled rows are
         # listed — the comb pairs then run in effective-weight form at hidden 64.  With ("pos", pos) and no labels handed
         # in, they are computed here (one extra launch; the replayed training step hands them in).
-        if isinstance(z, tuple) and labels is None and USE_COMB_EFF and train and \
-                any("comb" in getattr(c, "_stack_eff", {}) for c in emb.convs):
+        if isinstance(z, tuple) and labels is None and USE_COMB_EFF and train:
             labels = BatchLabels(n, z[1].numel(), dev)
             labels.load(z[1])
         if labels is not None:
@@ -370,7 +373,25 @@ class StackProgram:
         h = torch.empty((n, H), **f32)
         st["mask"] = mask
         gn0 = emb.emb_gn
-        if V <= _lib.EMBED_NORM_MAX_ROWS and USE_EMBED_TABLE:
+        use_table = V <= _lib.EMBED_NORM_MAX_ROWS and USE_EMBED_TABLE
+        # Hidden 64 with the label bytes already made (labels): layer 0's trans kernel gathers its operand rows from the
+        # embedding table itself (xa_index) and normalises them with emb_gn's table statistics, which ride in the prologue
+        # launch next to the weight packing — no table-apply kernel, no gather launch.
+        first_gn = None
+        if use_table and labels is not None and USE_GATHER_IN_TRANS and lib.glass_dual_linear_fwd_gather_supported(H):
+            sel = emb._selection(x_flat)
+            saved = torch.empty(4 * H, **f32)
+            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None,
+                                                table=(W, V, sel.op.rowptr, gn0, saved, None))
+            st["emb_table"], st["emb_saved"] = sel, saved
+            first_gn = (saved, ACT_NONE, p, 1)
+        else:
+            # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
+            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
+        st["rng_epoch"] = ops.rng_epoch(dev)  # (the prologue launch above advanced the dropout stream)
+        if first_gn is not None:
+            pass
+        elif use_table:
             # K3n: lookup + emb_gn + dropout through the V-row table (statistics are count-weighted sums over W)
             sel = emb._selection(x_flat)
             saved = torch.empty(4 * H, **f32)
@@ -401,7 +422,10 @@ class StackProgram:
             pc = float(conv.dropout) if train else 0.0
             T = torch.empty((n, 2 * H), **f32)
             m = torch.empty((n, H), **f32)
-            if pending_gn is None:
+            if pending_gn is None and first_gn is not None:
+                # h = dropout(emb_gn(input_emb(x))) is this kernel's side output
+                _dual_fwd(W, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m, gn=(*first_gn, h), xa_index=x_flat)
+            elif pending_gn is None:
                 _dual_fwd(h, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m)
             else:
                 # gns[l-1] (+ELU +dropout) is applied by the trans kernel while it loads c_{l-1}; h = its side output
@@ -450,6 +474,8 @@ class StackProgram:
         pooled, logits = torch.empty((B, C), **f32), torch.empty((B, K), **f32)
         loss, djk = torch.empty((), **f32), torch.empty((n, C), **f32)
         tgt = target.contiguous().to(torch.int64 if loss_mode == 0 else torch.float32)
+        labels = st.get("labels")  # the batch's label bytes + unique labeled rows = its pooled rows (same pos)
+        largs = (0, 0, 0) if labels is None else (labels.mask.data_ptr(), labels.rows.data_ptr(), labels.count.data_ptr())
         _check(lib.glass_readout_train_f32(jk.data_ptr(), jk.stride(0), saved.data_ptr(), gn.weight.data_ptr(),
                                            gn.mean_scale.data_ptr(), pos.data_ptr(), B, Smax, _lib.POOL_MODES[pool_mode],
                                            head.weight.data_ptr(), head.bias.data_ptr(), tgt.data_ptr(), loss_mode, K,
@@ -457,13 +483,13 @@ class StackProgram:
                                            djk.data_ptr(), djk.stride(0), head.weight.grad.data_ptr(),
                                            head.bias.grad.data_ptr(), st["acc"], gn.weight.grad.data_ptr(),
                                            gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), st["acc"], ws.data_ptr(),
-                                           n, C,
+                                           n, C, *largs,
                                            _stream()), "glass_readout_train_f32")
         st["djk"] = djk
         return loss, logits
 
     # ---------------------------------------------------------------------------------------------
-    def backward(self, st, dout, tail_hook=None):
+    def backward(self, st, dout, tail_hook=None, fused_opt=None):
         """tail_hook: called once every gradient except the embedding's and emb_gn's has been written (the data-parallel
         step starts the all-reduce of the small gradient bucket there, beside the rest of this backward pass)."""
         emb = self.emb
@@ -526,6 +552,24 @@ class StackProgram:
         if tail_hook is not None:
             tail_hook()
         W, gn0 = emb.input_emb.weight, emb.emb_gn
+        self.applied_optimizer = False
+        if "emb_table" in st and USE_FUSED_TAIL:
+            # the selection product's partial-row sums, the table backward and — with fused_opt (optim.FlatAdam) — Adam over
+            # the whole arena as ONE launch
+            sel, arena = st["emb_table"], emb._glass_arena
+            offs = [arena.offset_of(t) for t in (W, gn0.weight, gn0.bias, gn0.mean_scale)]
+            opt_ok = fused_opt is not None and all(o is not None for o in offs) and fused_opt.fusable() and acc == 0
+            G, ws, rrows, n_red = sel.product_without_reduce(dh_next)
+            oargs = (*fused_opt.fused_args(), *offs) if opt_ok else (0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0)
+            _check(_lib.load().glass_embed_norm_bwd_adam_f32(G.data_ptr(), W.data_ptr(), W.shape[0], sel.op.rowptr.data_ptr(),
+                                                             gn0.weight.data_ptr(), gn0.mean_scale.data_ptr(),
+                                                             st["emb_saved"].data_ptr(), W.grad.data_ptr(), acc,
+                                                             gn0.weight.grad.data_ptr(), gn0.bias.grad.data_ptr(),
+                                                             gn0.mean_scale.grad.data_ptr(), acc, H, ws, rrows, n_red,
+                                                             *oargs, _stream()),
+                   "glass_embed_norm_bwd_adam_f32")
+            self.applied_optimizer = opt_ok
+            return
         if "emb_table" in st:
             sel = st["emb_table"]
             G = sel.op.spmm(dh_next)  # [V,H]: per table row, the sum of its nodes' (masked) gradients, on K1
@@ -558,7 +602,7 @@ class StackProgram:
         return out
 
     def loss_and_grads(self, x_flat, z, edge_index, edge_weight, pos, pool_mode, head, target, loss_mode, overwrite=False,
-                       tail_hook=None, labels=None):
+                       tail_hook=None, labels=None, fused_opt=None):
         """One training pass WITHOUT the autograd tape: forward, fused readout, backward; every parameter gradient
         (stack, final GraphNorm, head) is accumulated into the gradient arena — or, with overwrite=True, stored over
         whatever is there (no zero-fill of the arena needed when written_params() covers it).  Returns (loss, logits)."""
@@ -566,7 +610,7 @@ class StackProgram:
             (loss, logits), st = self.forward(x_flat, z, edge_index, edge_weight, True,
                                               readout=(pos, pool_mode, head, target, loss_mode), acc=0 if overwrite else 1,
                                               labels=labels)
-            self.backward(st, None, tail_hook)
+            self.backward(st, None, tail_hook, fused_opt if overwrite else None)
         return loss, logits
 
 
@@ -614,7 +658,10 @@ def _program(emb):
     return prog
 
 
-def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, overwrite=False, tail_hook=None, labels=None):
+def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, overwrite=False, tail_hook=None, labels=None,
+                   fused_opt=None):
+    """fused_opt (optim.FlatAdam over the model's arena, overwrite mode only): the optimizer step rides in the backward's
+    last launch when it can — `applied_optimizer(model)` tells whether it did (else call fused_opt.step())."""
     """(loss, logits) of model(x, ..., pos, z) under loss_fn, gradients accumulated in place (see step_supported).
     z = "pos": label the nodes listed in pos (what utils.MaxZOZ(x, pos) would mark) without materialising z."""
     emb = model.conv
@@ -632,7 +679,11 @@ def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, o
             raise ValueError("z must be a tensor, None or 'pos'")
         z = ("pos", pos)
     return prog.loss_and_grads(x_flat, z, edge_index, edge_weight, pos, model.pools[0].mode, model.preds[0], target,
-                               loss_fn.mode, overwrite, tail_hook, labels)
+                               loss_fn.mode, overwrite, tail_hook, labels, fused_opt)
+
+
+def applied_optimizer(model):
+    return bool(getattr(_program(model.conv), "applied_optimizer", False))
 
 
 class StackFn(torch.autograd.Function):

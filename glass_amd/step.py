@@ -55,7 +55,9 @@ class TrainStep:
         return (self._fused_head() and hasattr(self.bucket, "flat_param") and self.x.dim() == 3 and
                 self.x.shape[1:] == (1, 1) and stack.step_supported(self.model, self.loss_fn))
 
-    def _fwd_bwd(self, tail_hook=None):
+    def _fwd_bwd(self, tail_hook=None, apply_opt=False):
+        """Forward + backward of one batch.  apply_opt: the optimizer step may ride in the backward's last launch (step
+        program, optim.FlatAdam, one rank); returns True when it did."""
         from . import stack
         if self._program_step():
             # whole step as one explicit program: no autograd tape, fused readout, labels straight from pos, and
@@ -63,10 +65,11 @@ class TrainStep:
             overwrite = stack.covers_arena(self.model, self.bucket)
             if not overwrite:
                 self.bucket.zero()
+            fused = self.opt if (apply_opt and overwrite and hasattr(self.opt, "fused_args")) else None
             loss, _logits = stack.loss_and_grads(self.model, self.loss_fn, self.x, self.ei, self.ew, self._pos, "pos",
-                                                 self._y, overwrite, tail_hook, labels=self._labels)
+                                                 self._y, overwrite, tail_hook, labels=self._labels, fused_opt=fused)
             self._loss = loss
-            return
+            return stack.applied_optimizer(self.model)
         if tail_hook is not None:
             raise RuntimeError("tail_hook needs the step program")
         z = utils.MaxZOZ(self.x, self._pos)
@@ -100,9 +103,11 @@ class TrainStep:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(self.warmup_iters):
-                self._fwd_bwd()
+                solo = not gdist.is_distributed()
+                done = self._fwd_bwd(apply_opt=solo)
                 self.bucket.all_reduce_mean()
-                self.opt.step()
+                if not done:
+                    self.opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if snap is not None:
@@ -131,8 +136,8 @@ class TrainStep:
             torch.cuda.synchronize()  # no collective of the warm-up still in flight when the capture starts
         if not dist_on:
             with torch.cuda.graph(self._g_fb):
-                self._fwd_bwd()
-                self.opt.step()
+                if not self._fwd_bwd(apply_opt=True):  # (with the step program Adam rides in the backward's last launch)
+                    self.opt.step()
         elif not self._overlap_small_bucket():
             # the collective stays outside the graph; the optimizer is two launches, cheaper eager than a
             # second graph replay
@@ -218,12 +223,11 @@ class TrainStep:
             self._g_fb.replay()
             if self._split:
                 self._exchange_and_update()
-        else:
+        elif gdist.is_distributed():
             self._fwd_bwd()
-            if gdist.is_distributed():
-                self._exchange_and_update()
-            else:
-                self.opt.step()
+            self._exchange_and_update()
+        elif not self._fwd_bwd(apply_opt=True):
+            self.opt.step()
         return self._loss
 
     def _load_batch(self, pos, y):

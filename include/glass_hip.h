@@ -201,6 +201,22 @@ int glass_embed_norm_bwd_f32(const float* G, const float* W, int64_t V, const in
                              const float* gamma, const float* alpha, const float* saved, float* dW, int accumulate_w,
                              float* dgamma, float* dbeta, float* dalpha, int accumulate, int64_t H, void* stream);
 
+/*   bwd_adam: the step's last launch on the table path — (a) rows of the selection product G that K1 cut into several
+ *        chunks are summed here from its partial rows (partials = the product's scratch, reduce_rows = the plan's reduce
+ *        list on the device: (row, first slot, count) triples; call glass_spmm_csr_f32 with a header copy whose reduce
+ *        count is 0), (b) glass_embed_norm_bwd_f32, (c) Adam (glass_adam_step_f32's update and step counter) over the whole
+ *        arena param / grad / exp_avg / exp_avg_sq [n_param]: the table workgroups update exactly the elements whose
+ *        gradients they produced (the table at arena offset off_W, emb_gn's weight / bias / mean_scale at off_gamma /
+ *        off_beta / off_alpha — dW, dgamma, ... must be those views), the other workgroups the rest.  param == NULL: (a) +
+ *        (b) only.  Three dependent launches (K1's reduce, the table backward, Adam) as one. */
+int glass_embed_norm_bwd_adam_f32(float* G, const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma,
+                                  const float* alpha, const float* saved, float* dW, int accumulate_w, float* dgamma,
+                                  float* dbeta, float* dalpha, int accumulate, int64_t H, const float* partials,
+                                  const int32_t* reduce_rows, int64_t n_reduce, float* param, float* grad, float* exp_avg,
+                                  float* exp_avg_sq, int64_t n_param, const float* lr_dev, double beta1, double beta2,
+                                  double eps, double weight_decay, int64_t* step_dev, int64_t off_W, int64_t off_gamma,
+                                  int64_t off_beta, int64_t off_alpha, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K7  subgraph pooling   replaces pad2batch + emb[pos] + global_{add,mean,max}_pool /
  *     GraphSizeNorm (impl/models.py:346-350, 294-319; impl/utils.py:18-29)
@@ -270,12 +286,17 @@ int64_t glass_dual_linear_stat_rows(int64_t H);
  *   fwd, gn_saved != NULL: xa is the INPUT of a GraphNorm whose statistics are final (gn_saved[4H] from
  *   glass_graphnorm_finalize_f32 / _stats_f32); the kernel computes dropout(act(xa*scale + shift)) while loading
  *   (gn_act, p_drop, rng_state, call_id as in glass_graphnorm_fwd_f32), multiplies THAT, and writes it to xa_out
- *   [n_nodes, H] for the backward — no separate GraphNorm apply launch. */
+ *   [n_nodes, H] for the backward — no separate GraphNorm apply launch.
+ *   fwd, xa_index != NULL (trans pair, with gn_saved; glass_dual_linear_fwd_gather_supported(H)): operand row n is row
+ *   xa_index[n] of xa [xa_rows, H] — the embedding lookup `input_emb(x)` (impl/models.py:248) happens in the operand load:
+ *   xa = the embedding table, gn_saved = emb_gn's statistics through the table (glass_step_prologue_f32), xa_out receives
+ *   dropout(emb_gn(input_emb(x))) [n_nodes, H], the layer input — no gather launch. */
+int glass_dual_linear_fwd_gather_supported(int64_t H);
 int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg,
                               const float* bias, const uint8_t* mask, double z_ratio, int act, float* T, int64_t ldt,
                               float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* stats, const float* gn_saved,
                               int gn_act, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
-                              int64_t ldxo, void* stream);
+                              int64_t ldxo, const int64_t* xa_index, int64_t xa_rows, void* stream);
 /*   dgrad epilogue: out = (dZ @ W + addend) * dropmask(p_drop, rng_state, call_id) — the mask of the dropout that
  *   produced this layer's input (same mask layout as glass_graphnorm_fwd_f32), so the consumer receives the
  *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL).
@@ -358,6 +379,15 @@ int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, c
 int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
                                const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
                                void* stream);
+/*     The once-per-step prologue as ONE launch: glass_dense_pack_batch_f32 (same first eight arguments; n_jobs may be 0)
+ *     plus the statistics of emb_gn through the embedding table — the first half of glass_embed_norm_fwd_f32
+ *     (impl/models.py:248-249): saved[4H] = mean, rstd, scale, shift of GraphNorm(W[x]) as count-weighted sums over the V
+ *     table rows (class_rowptr as there); table[V,H] = W*scale + shift, or NULL when the consumer normalises while
+ *     gathering from W (glass_dual_linear_fwd_f32 with xa_index). */
+int glass_step_prologue_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
+                            const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
+                            const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma, const float* beta,
+                            const float* alpha, float eps, float* saved, float* table, int64_t H, void* stream);
 
 /* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
  *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened
@@ -382,7 +412,10 @@ int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const float* W, co
  *      grad_loss = device scalar seed.  Outputs: pooled [B,C], logits [B,K], loss [1], djk [N,C] (overwritten);
  *      dWh/dbh and dgamma/dbeta/dalpha are accumulated when acc_* != 0.
  *      Bitwise repeatable while B*Smax <= 16 384 (ordered, atomic-free scatter of the sparse part); beyond that the
- *      scatter uses float atomics. */
+ *      scatter uses float atomics.  mask / lab_rows / lab_count (all three, or NULL): the label bytes and the unique
+ *      labeled rows glass_batch_labels produced for THIS pos — the pooled rows of a step are its labeled rows — then the
+ *      dense part skips them and extra workgroups of the same launch write their full value: three launches, bitwise
+ *      equal to the four. */
 int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, const float* gamma,
                               const float* beta, const float* alpha, float eps, float* saved, void* ws, void* stream);
 int glass_readout_supported(int64_t C, int64_t K, int pool_mode);
@@ -392,7 +425,7 @@ int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved,
                             const void* target, int loss_mode, int64_t K, const float* grad_loss, float* pooled,
                             float* logits, float* loss, float* djk, int64_t lddj, float* dWh, float* dbh, int acc_head,
                             float* dgamma, float* dbeta, float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
-                            void* stream);
+                            const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count, void* stream);
 
 /*     Two small device-to-device copies in one launch (4-byte granularity): a training step that is replayed from a
  *     captured graph reads its batch (pos, target) from fixed buffers; this fills both per step. */

@@ -11,7 +11,8 @@ def main():
     f = glob.glob(f"{d}/**/*_kernel_stats.csv", recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    embed = [int(r["Calls"]) for r in rows if "embed_label" in r["Name"] or "embed_gather" in r["Name"]]
+    embed = [int(r["Calls"]) for r in rows if "embed_label" in r["Name"] or "embed_gather" in r["Name"] or
+             "readout_subgraph" in r["Name"]]
     steps = embed[0] if embed else 1
     print(f"{f}: total kernel time {tot/1e6:.2f} ms over {steps} steps = {tot/1e3/steps:.1f} us/step, "
           f"{sum(int(r['Calls']) for r in rows)/steps:.0f} kernels/step")
