@@ -130,16 +130,22 @@ __device__ __forceinline__ AdamCoef adam_coef(int64_t step_now, float lr, float 
     return c;
 }
 
-__device__ __forceinline__ void adam_update(const AdamCoef& c, float* __restrict__ p, float gk, float* __restrict__ m,
-                                            float* __restrict__ v, int64_t k) {
-    const float pk = p[k];
+// one element, on values: (pk, mk, vk) in -> updated in place
+__device__ __forceinline__ void adam_element(const AdamCoef& c, float& pk, float gk, float& mk, float& vk) {
     if (c.weight_decay != 0.f) gk = fmaf(c.weight_decay, pk, gk);
-    const float mk = m[k] + c.w1 * (gk - m[k]);
-    const float vk = v[k] * c.beta2 + c.w2 * gk * gk;
+    mk = mk + c.w1 * (gk - mk);
+    vk = vk * c.beta2 + c.w2 * gk * gk;
+    const float denom = sqrtf(vk) / c.bc2_sqrt + c.eps;
+    pk = pk - c.step_size * (mk / denom);
+}
+
+__device__ __forceinline__ void adam_update(const AdamCoef& c, float* p, float gk, float* __restrict__ m,
+                                            float* __restrict__ v, int64_t k) {
+    float pk = p[k], mk = m[k], vk = v[k];
+    adam_element(c, pk, gk, mk, vk);
     m[k] = mk;
     v[k] = vk;
-    const float denom = sqrtf(vk) / c.bc2_sqrt + c.eps;
-    p[k] = pk - c.step_size * (mk / denom);
+    p[k] = pk;
 }
 
 // step_dev = int64[2]: (steps completed, ticket).  Every workgroup reads the count first and takes a ticket last; the

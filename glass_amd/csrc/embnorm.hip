@@ -131,6 +131,24 @@ __global__ __launch_bounds__(kBlock) void emb_tail_kernel(float* __restrict__ G,
     const int tc = threadIdx.x & (kTabCols - 1), tr = threadIdx.x / kTabCols;
     const int c = blockIdx.x * kTabCols + tc;
     const bool ok = c < H;
+    // Small tables (the degree feature: ~60 rows): a thread owns <= 4 table elements of its column — everything it will
+    // need of them (weight = parameter, row count, Adam moments) is requested BEFORE the slot sums, so the launch is not a
+    // chain of six dependent round trips.
+    constexpr int kOwn = 4;
+    const bool small = V <= kOwn * kTabSlots;
+    float w_own[kOwn], cn_own[kOwn], m_own[kOwn], v_own[kOwn];
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            const int v = tr + kTabSlots * k;
+            const bool live = ok && v < V;
+            const int64_t o = (int64_t)(live ? v : 0) * H + (ok ? c : 0);
+            w_own[k] = live ? W[o] : 0.f;
+            cn_own[k] = live ? (float)(rowptr[v + 1] - rowptr[v]) : 0.f;
+            m_own[k] = (live && ad.p) ? ad.m[ad.off_W + o] : 0.f;
+            v_own[k] = (live && ad.p) ? ad.v[ad.off_W + o] : 0.f;
+        }
+    }
     // rows of the selection product that were cut into several chunks: partial rows summed in slot order
     if (ok)
         for (int rr = tr; rr < n_reduce; rr += kTabSlots) {
@@ -141,7 +159,22 @@ __global__ __launch_bounds__(kBlock) void emb_tail_kernel(float* __restrict__ G,
         }
     if (n_reduce > 0) __syncthreads();
     double s1 = 0.0, s2 = 0.0;
-    if (ok) {
+    float g_own[kOwn];
+    if (ok && small) {
+        const float mu = saved[c], rstd = saved[H + c], al = alpha[c];
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            const int v = tr + kTabSlots * k;
+            g_own[k] = v < V ? G[(int64_t)v * H + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {  // (same order of the fp64 sums as the general loop below)
+            if (tr + kTabSlots * k >= V) continue;
+            const float xhat = (w_own[k] - al * mu) * rstd;
+            s1 += (double)g_own[k];
+            s2 += (double)g_own[k] * (double)xhat;
+        }
+    } else if (ok) {
         const float mu = saved[c], rstd = saved[H + c], al = alpha[c];
         for (int v = tr; v < V; v += kTabSlots) {
             const float g = G[(int64_t)v * H + c];
@@ -170,7 +203,25 @@ __global__ __launch_bounds__(kBlock) void emb_tail_kernel(float* __restrict__ G,
         }
     }
     __syncthreads();
-    if (ok) {
+    if (ok && small) {
+        const float A = coef[tc], Bx = coef[kTabCols + tc], K = coef[2 * kTabCols + tc];
+#pragma unroll
+        for (int k = 0; k < kOwn; ++k) {
+            const int v = tr + kTabSlots * k;
+            if (v >= V) continue;
+            const int64_t o = (int64_t)v * H + c;
+            float d = fmaf(A, g_own[k], cn_own[k] * fmaf(Bx, w_own[k], K));
+            if (accumulate_w) d += dW[o];
+            dW[o] = d;
+            if (ad.p) {  // (the weight IS the parameter: W aliases ad.p + off_W)
+                float pk = w_own[k];
+                adam_element(ac, pk, d, m_own[k], v_own[k]);
+                ad.m[ad.off_W + o] = m_own[k];
+                ad.v[ad.off_W + o] = v_own[k];
+                ad.p[ad.off_W + o] = pk;
+            }
+        }
+    } else if (ok) {
         const float A = coef[tc], Bx = coef[kTabCols + tc], K = coef[2 * kTabCols + tc];
         for (int v = tr; v < V; v += kTabSlots) {
             const int64_t o = (int64_t)v * H + c;

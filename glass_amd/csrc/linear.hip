@@ -16,6 +16,7 @@
 // fp32 MFMA is an exact k-ordered fmaf chain, so numerics equal a plain fp32 reduction.
 #include "common.h"
 #include "wgrad_common.h"
+#include "spmm_common.h"
 
 #include <stdlib.h>
 
@@ -242,6 +243,63 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     return g;
 }
 
+// The batched reduction carrying a K1 product whose plan holds workgroup items only (the selection product of the embedding
+// backward: G = S^T dh, reference impl/models.py:248 backward): both only need the backward chain to be finished, so they
+// share a launch — grid slices z < n_jobs reduce, the slices behind them run one plan item per workgroup.
+struct SelJob {
+    const int32_t *col, *items;
+    const float *val, *X;
+    int64_t ldx;
+    float* Y;
+    int64_t ldy;
+    float* partials;
+    int H, n_items;
+};
+
+template <int LPR>
+__global__ __launch_bounds__(kBlock) void wgrad_reduce_sel_kernel(ReduceBatch batch, int n_jobs, SelJob sel) {
+    __shared__ float4 lds[2 * kBlock];
+    if ((int)blockIdx.z >= n_jobs) {
+        const int item = (((int)blockIdx.z - n_jobs) * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x;
+        if (item >= sel.n_items) return;
+        // (blockIdx.y inside long_item_body is the column tile: LPR * 4 >= H here, one tile)
+        const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x >> 6;
+        const int grp = lane / LPR, sub = lane % LPR;
+        const int coff = sub * 4;
+        const bool col_ok = coff < sel.H;
+        const int32_t* it = sel.items + 4 * (int64_t)item;
+        const int row = it[0], eb = it[1], ee = it[2], slot = it[3];
+        const int per = ((ee - eb + 4 * kWave - 1) / (4 * kWave)) * kWave;
+        const int e0 = min(eb + w * per, ee), e1 = min(e0 + per, ee);
+        float* lf = reinterpret_cast<float*>(lds);
+        Vec<4> acc;
+        acc.zero();
+        gather_edges<4, LPR, 8, false>(acc, sel.col, sel.val, sel.X + coff, sel.ldx, e0, e1, lane, grp, col_ok);
+        reduce_groups<4, LPR>(acc);
+        if (grp == 0) acc.store(&lf[(w * LPR + sub) * 4]);
+        __syncthreads();
+        if (w == 0 && grp == 0 && col_ok) {
+            Vec<4> s2, t;
+            s2.load(&lf[sub * 4]);
+#pragma unroll
+            for (int k = 1; k < kBlock / kWave; ++k) {
+                t.load(&lf[(k * LPR + sub) * 4]);
+                s2.add(t);
+            }
+            float* dst = slot < 0 ? sel.Y + (int64_t)row * sel.ldy : sel.partials + (int64_t)slot * sel.H;
+            s2.store(dst + coff);
+        }
+        return;
+    }
+    const ReduceJob& j = batch.job[blockIdx.z];
+    if ((int)blockIdx.y >= j.ny * j.nz) return;
+    if (j.n_l > 0) {
+        wgrad_reduce_sl_body(j.part_w, j.part_b, j.n_slabs, j.n_l, j.dW, j.lddw, j.db, j.accumulate, lds);
+        return;
+    }
+    wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.nz, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
+}
+
 WgradSLGeom wgrad_sl_geom(int64_t N, int64_t lab_cap) {
     WgradSLGeom g;
     g.n_l = (int)ceil_div(lab_cap > 0 ? lab_cap : 1, 64);
@@ -379,16 +437,16 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     return launch_status("glass_dual_linear_wgrad_f32");
 }
 
-extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, const int64_t* N,
-                                                   const int64_t* O, const int64_t* I, float* const* dW,
-                                                   const int64_t* lddw, float* const* db, const int32_t* accumulate,
-                                                   const int64_t* lab_cap, void* stream) {
+static int reduce_batch_impl(int64_t n_jobs, const void* const* ws, const int64_t* N, const int64_t* O, const int64_t* I,
+                             float* const* dW, const int64_t* lddw, float* const* db, const int32_t* accumulate,
+                             const int64_t* lab_cap, const SelJob* sel, void* stream) {
     GLASS_REQUIRE(n_jobs >= 0 && (n_jobs == 0 || (ws && N && O && I && dW && lddw && db && accumulate)),
                   "wgrad_reduce_batch: null pointer");
-    if (n_jobs == 0) return 0;
+    if (n_jobs == 0 && !sel) return 0;
     hipStream_t st = (hipStream_t)stream;
-    for (int64_t j0 = 0; j0 < n_jobs; j0 += kMaxReduceJobs) {
-        const int nj = (int)(n_jobs - j0 < kMaxReduceJobs ? n_jobs - j0 : kMaxReduceJobs);
+    bool sel_done = sel == nullptr;
+    for (int64_t j0 = 0; j0 < n_jobs || !sel_done; j0 += kMaxReduceJobs) {
+        const int nj = (int)(n_jobs - j0 < kMaxReduceJobs ? (n_jobs - j0 > 0 ? n_jobs - j0 : 0) : kMaxReduceJobs);
         ReduceBatch b;
         int max_chunks = 0;
         for (int k = 0; k < kMaxReduceJobs; ++k) b.job[k] = ReduceJob{nullptr, nullptr, 0, 0, 0, 0, 0, 0, 0, nullptr, 0, nullptr};
@@ -418,10 +476,56 @@ extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* c
                                  accumulate[j], 0, dW[j], lddw[j], db[j]};
             if (g.ny * g.nz > max_chunks) max_chunks = g.ny * g.nz;
         }
-        if (max_chunks > 0)
-            hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((kTile + kOT) / 64, max_chunks, nj), dim3(kBlock), 0, st, b);
+        const unsigned gx = (kTile + kOT) / 64;
+        if (!sel_done) {  // the product's items ride behind this batch of jobs
+            sel_done = true;
+            const unsigned gy = (unsigned)(max_chunks > 0 ? max_chunks : 1);
+            const unsigned zs = (unsigned)ceil_div(sel->n_items, (int64_t)gx * gy);
+            const dim3 grid(gx, gy, (unsigned)nj + zs);
+            if (sel->H <= 64)
+                hipLaunchKernelGGL((wgrad_reduce_sel_kernel<16>), grid, dim3(kBlock), 0, st, b, nj, *sel);
+            else if (sel->H <= 128)
+                hipLaunchKernelGGL((wgrad_reduce_sel_kernel<32>), grid, dim3(kBlock), 0, st, b, nj, *sel);
+            else
+                hipLaunchKernelGGL((wgrad_reduce_sel_kernel<64>), grid, dim3(kBlock), 0, st, b, nj, *sel);
+        } else if (max_chunks > 0) {
+            hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(gx, max_chunks, nj), dim3(kBlock), 0, st, b);
+        }
     }
     return launch_status("glass_linear_wgrad_reduce_batch_f32");
+}
+
+extern "C" int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, const int64_t* N,
+                                                   const int64_t* O, const int64_t* I, float* const* dW,
+                                                   const int64_t* lddw, float* const* db, const int32_t* accumulate,
+                                                   const int64_t* lab_cap, void* stream) {
+    return reduce_batch_impl(n_jobs, ws, N, O, I, dW, lddw, db, accumulate, lab_cap, nullptr, stream);
+}
+
+// The batched reduction + a K1 product Y = M @ X in ONE launch when M's plan holds workgroup items only (no sweep items:
+// the selection matrix of the embedding backward) and X is 16-B aligned with H % 4 == 0, H <= 256; otherwise the two calls
+// one after the other.  The plan's reduce launch (rows cut into several chunks) follows as in glass_spmm_csr_f32 — pass a
+// header copy with the reduce count zeroed when the consumer sums the partial rows itself.
+extern "C" int glass_wgrad_reduce_spmm_f32(int64_t n_jobs, const void* const* ws, const int64_t* N, const int64_t* O,
+                                           const int64_t* I, float* const* dW, const int64_t* lddw, float* const* db,
+                                           const int32_t* accumulate, const int64_t* lab_cap, const int32_t* rowptr,
+                                           const int32_t* col, const float* val, const float* X, int64_t ldx, float* Y,
+                                           int64_t ldy, int64_t n_rows, int64_t H, const int32_t* hdr,
+                                           const int32_t* plan_dev, void* ws_spmm, void* stream) {
+    GLASS_REQUIRE(hdr && plan_dev && X && Y, "wgrad_reduce_spmm: null pointer");
+    const bool fusable = hdr[H_MAGIC] == kPlanMagic && hdr[H_VER] == kPlanVersion && hdr[H_NROWS] == n_rows &&
+                         hdr[H_NSWEEP] == 0 && hdr[H_NLONG] > 0 && H % 4 == 0 && H <= 256 && ldx % 4 == 0 && ldy % 4 == 0 &&
+                         aligned16(X) && aligned16(Y) && col && val && (hdr[H_NSLOTS] == 0 || (ws_spmm && aligned16(ws_spmm)));
+    if (!fusable) {
+        const int rc = glass_linear_wgrad_reduce_batch_f32(n_jobs, ws, N, O, I, dW, lddw, db, accumulate, lab_cap, stream);
+        return rc ? rc : glass_spmm_csr_f32(rowptr, col, val, X, ldx, Y, ldy, n_rows, H, hdr, plan_dev, ws_spmm, stream);
+    }
+    const SelJob sel{col, plan_dev + hdr[H_OFF_LONG], val, X, ldx, Y, ldy, (float*)ws_spmm, (int)H, hdr[H_NLONG]};
+    const int rc = reduce_batch_impl(n_jobs, ws, N, O, I, dW, lddw, db, accumulate, lab_cap, &sel, stream);
+    if (rc) return rc;
+    if (hdr[H_NREDUCE] > 0)  // rows cut into several chunks: the plan's own reduce launch
+        return glass_spmm_reduce_rows_f32((const float*)ws_spmm, Y, ldy, H, plan_dev + hdr[H_OFF_REDUCE], hdr[H_NREDUCE], stream);
+    return 0;
 }
 
 extern "C" int glass_adam_step_f32(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,

@@ -290,7 +290,12 @@ def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending, acc=1):
     pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
 
 
-def _reduce_pending(pending):
+def _reduce_pending(pending, product=None):
+    """One launch for all deferred weight-gradient reductions.  product = (graph.Selection, x): the same launch also carries
+    the selection product G = S^T x of the embedding backward, WITHOUT its reduce step (the table backward sums the partial
+    rows itself); returns (G, partials pointer, reduce-list pointer, number of reduce rows) then."""
+    if product is not None:
+        return _reduce_pending_with_product(pending, *product)
     if not pending:
         return
     if USE_WGRAD_STREAM and _wgrad_keep:
@@ -306,6 +311,29 @@ def _reduce_pending(pending):
                                                          I.ctypes.data, dW.ctypes.data, ld.ctypes.data, db.ctypes.data,
                                                          acc.ctypes.data, cap.ctypes.data, _stream())
     _check(rc, "glass_linear_wgrad_reduce_batch_f32")
+
+
+def _reduce_pending_with_product(pending, sel, x):
+    if USE_WGRAD_STREAM and _wgrad_keep:
+        dev = _wgrad_keep[0][0].device
+        torch.cuda.current_stream().wait_stream(_wgrad_streams[dev])
+        _wgrad_keep.clear()
+    cols = list(zip(*[p if len(p) == 9 else p + (0, ) for p in pending])) if pending else [()] * 9
+    u64 = lambda v: np.array(v, dtype=np.uint64)
+    i64 = lambda v: np.array(v, dtype=np.int64)
+    ws, N, O, I, dW, ld, db = u64(cols[0]), i64(cols[1]), i64(cols[2]), i64(cols[3]), u64(cols[4]), i64(cols[5]), u64(cols[6])
+    acc, cap = np.array(cols[7], dtype=np.int32), i64(cols[8])
+    op = sel.op
+    H = x.shape[1]
+    G = torch.empty((op.n_rows, H), dtype=torch.float32, device=x.device)
+    wsp = op.workspace(H)
+    rc = _lib.load().glass_wgrad_reduce_spmm_f32(len(pending), ws.ctypes.data, N.ctypes.data, O.ctypes.data, I.ctypes.data,
+                                                 dW.ctypes.data, ld.ctypes.data, db.ctypes.data, acc.ctypes.data,
+                                                 cap.ctypes.data, op.rowptr.data_ptr(), op.col.data_ptr(), op.val.data_ptr(),
+                                                 x.data_ptr(), x.stride(0), G.data_ptr(), G.stride(0), op.n_rows, H,
+                                                 sel._hdr_noreduce.ctypes.data, op.plan.data_ptr(), wsp.data_ptr(), _stream())
+    _check(rc, "glass_wgrad_reduce_spmm_f32")
+    return G, wsp.data_ptr(), op.plan.data_ptr() + 4 * sel._off_reduce, sel._n_reduce
 
 
 class StackProgram:
@@ -548,18 +576,21 @@ class StackProgram:
                       acc, drop, gn)
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations
-        _reduce_pending(pending)
-        if tail_hook is not None:
-            tail_hook()
         W, gn0 = emb.input_emb.weight, emb.emb_gn
         self.applied_optimizer = False
-        if "emb_table" in st and USE_FUSED_TAIL:
+        fused_tail = "emb_table" in st and USE_FUSED_TAIL
+        # the deferred weight-gradient reductions — and, on the table path, the selection product of the embedding
+        # backward in the same launch (both only wait for the end of the chain above)
+        prod = _reduce_pending(pending, (st["emb_table"], dh_next) if fused_tail else None)
+        if tail_hook is not None:
+            tail_hook()
+        if fused_tail:
             # the selection product's partial-row sums, the table backward and — with fused_opt (optim.FlatAdam) — Adam over
             # the whole arena as ONE launch
             sel, arena = st["emb_table"], emb._glass_arena
             offs = [arena.offset_of(t) for t in (W, gn0.weight, gn0.bias, gn0.mean_scale)]
             opt_ok = fused_opt is not None and all(o is not None for o in offs) and fused_opt.fusable() and acc == 0
-            G, ws, rrows, n_red = sel.product_without_reduce(dh_next)
+            G, ws, rrows, n_red = prod
             oargs = (*fused_opt.fused_args(), *offs) if opt_ok else (0, 0, 0, 0, 0, 0, 0.0, 0.0, 0.0, 0.0, 0, 0, 0, 0, 0)
             _check(_lib.load().glass_embed_norm_bwd_adam_f32(G.data_ptr(), W.data_ptr(), W.shape[0], sel.op.rowptr.data_ptr(),
                                                              gn0.weight.data_ptr(), gn0.mean_scale.data_ptr(),

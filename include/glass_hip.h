@@ -362,6 +362,17 @@ int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint8_t* mask, 
 int glass_linear_wgrad_reduce_batch_f32(int64_t n_jobs, const void* const* ws, const int64_t* N, const int64_t* O,
                                         const int64_t* I, float* const* dW, const int64_t* lddw, float* const* db,
                                         const int32_t* accumulate, const int64_t* lab_cap, void* stream);
+/*     The same reduction and a K1 product Y = M @ X as ONE launch when M's plan holds workgroup items only (the one-hot
+ *     selection matrix of the embedding backward, glass_embed_label_f32's note) — both only wait for the end of the
+ *     backward chain; otherwise the two calls in sequence.  Arguments: those of the reduction, then those of
+ *     glass_spmm_csr_f32.  glass_spmm_reduce_rows_f32: the reduce step of a K1 plan on its own (partial rows -> Y). */
+int glass_wgrad_reduce_spmm_f32(int64_t n_jobs, const void* const* ws, const int64_t* N, const int64_t* O, const int64_t* I,
+                                float* const* dW, const int64_t* lddw, float* const* db, const int32_t* accumulate,
+                                const int64_t* lab_cap, const int32_t* rowptr, const int32_t* col, const float* val,
+                                const float* X, int64_t ldx, float* Y, int64_t ldy, int64_t n_rows, int64_t H,
+                                const int32_t* plan_header_host, const int32_t* plan_dev, void* ws_spmm, void* stream);
+int glass_spmm_reduce_rows_f32(const float* partials, float* Y, int64_t ldy, int64_t H, const int32_t* reduce_rows_dev,
+                               int64_t n_reduce, void* stream);
 /*     Pack up to 16 weight operands B[NT][KT] (NT, KT multiples of 64) into MFMA image order in one launch.
  *     flags[k] bit 0 = transposed: 0: B = src[k] ([NT][KT] row-major); 1: B[n][k] = src[k][k][n] (src is [KT][NT]).
  *     flags[k] >> 1 = layout: 0 wave16, 1 tiled paired (NT = 2H), 2 tiled plain (tiled: NT a multiple of 256), 3 tiled
