@@ -89,10 +89,15 @@ class Run:
         loader drops the last partial batch; without it plain loaders are used and nothing is dropped.  All shuffle."""
         if self.args.use_maxzeroone:
             make = functools.partial(SubGDataset.ZGDataloader, z_fn=utils.MaxZOZ, shuffle=True)
-            return (make(self.trn, batch_size, drop_last=True), make(self.val, batch_size, drop_last=False),
-                    make(self.tst, batch_size, drop_last=False))
-        return tuple(SubGDataset.GDataloader(ds, batch_size, shuffle=True, drop_last=False)
-                     for ds in (self.trn, self.val, self.tst))
+            # (under torch.distributed the TRAINING loader hands every rank its slice of each batch — subgraph-batch data
+            # parallelism, glass_amd/dist.py; evaluation loaders are never sharded, so scores agree on every rank)
+            from glass_amd import dist as gdist
+            return (make(self.trn, batch_size, drop_last=True, shard=gdist.is_distributed()),
+                    make(self.val, batch_size, drop_last=False), make(self.tst, batch_size, drop_last=False))
+        from glass_amd import dist as gdist
+        return (SubGDataset.GDataloader(self.trn, batch_size, shuffle=True, drop_last=False, shard=gdist.is_distributed()),
+                SubGDataset.GDataloader(self.val, batch_size, shuffle=True, drop_last=False),
+                SubGDataset.GDataloader(self.tst, batch_size, shuffle=True, drop_last=False))
 
     def build_model(self, hidden_dim, conv_layer, dropout, jk, pool, z_ratio, aggr):
         a = self.args

@@ -15,17 +15,29 @@ config[1]: the ppi_bp-shaped synthetic graph, hidden=64 (config/ppi_bp.yml hyper
 dropout 0.5).  Multi-GPU = subgraph-batch data parallelism: replicated graph, per-rank batch fixed
 ("weak"), gradient all-reduce per step (--features nodeid: bucketed, see glass_amd/dist.py).
 
+Timing: after W warm-up steps, BLOCKS of exactly K steps are timed, each bracketed by a barrier +
+torch.cuda.synchronize() on both sides and taken as the MAX over ranks; at least 25 blocks and at least
+0.25 s in all (a K = 20 block of this step is 6 ms: one block alone is at the mercy of a single host
+hiccup).  ms_per_step / value come from the MEDIAN block; min / max / blocks are printed beside it.
+
 The JSON line also carries
   roofline       : the CSR aggregation kernel (K1) inside the step — algorithmic bytes
                    nnz*(4H+8)+N*(4H+4) per launch / its average duration.  Durations come from HIP events
                    recorded on the launch stream around every K1 launch of an instrumented pass, minus the
                    bracket's own cost, which is CALIBRATED in the same process on the same kernel and shape
-                   (bracketed average - back-to-back average of a 50-launch hipGraph).  The bound is the
-                   level X is served from: "l2" (34.5 TB/s aggregate) while X <= 32 MiB, "hbm" (8 TB/s) beyond.
+                   (bracketed average - back-to-back average of a 50-launch hipGraph).  Two utilisations, both
+                   <= 1 by construction: every gathered byte passes an XCD L2 (algorithmic rate / 34.5 TB/s
+                   aggregate), and the L2-miss traffic passes the memory side — the Infinity Cache while X fits
+                   its 256 MiB (the guide's gathered-row rate, 8.6 TB/s chip-wide), HBM (8 TB/s) beyond.
+                   `frac` = the larger one, `bound` names it.  `traffic` = memory-side bytes per launch from
+                   PMC counters collected IN THIS RUN (a child `rocprofv3 --kernel-trace --pmc FETCH_SIZE`,
+                   then WRITE_SIZE, on tools/bin/spmm_bench at the same shape: separate passes, KiB units,
+                   FETCH_SIZE doubled per the gfx950 rule) or null.
   roofline_hbm   : K1 alone, same process, on shapes whose X cannot be cache-resident (N = 4 M permutation
                    = no reuse at all; N = 2 M uniform, mean degree 6), hidden 64, against the 8 TB/s HBM peak.
-  step_breakdown : device time per C-ABI entry point per step (same bracket method), and the MFMA
-                   fraction of the largest one when it is a dense kernel.
+  step_breakdown : device time per C-ABI entry point per step (same bracket method); the dense (MFMA)
+                   calls with the FLOPs they EXECUTE (effective-weight kernels run one product where the
+                   reference formulation has two) next to the reference formulation's.
   cpu_baseline   : the oracle (CPU restatement of the reference path, torch ops on host cores) timed
                    on a bounded sample of the same workload on rank 0 at N=1.
 """
@@ -45,8 +57,10 @@ sys.path.insert(0, ROOT)
 
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md §L2: aggregate of the 8 XCD L2s
 HBM_PEAK_GBPS = 8000.0   # spec (6.29 TB/s measured achievable copy)
+IC_GATHER_GBPS = 8600.0  # MI355X_MICROARCH.md §Indexed rows: uniformly random rows of a 38 MB table (Infinity Cache), chip-wide
 MFMA_F32_TFLOPS = 157.3  # dense fp32 matrix-core peak
-L2_TOTAL_BYTES = 32 << 20
+L2_XCD_BYTES = 4 << 20
+IC_BYTES = 256 << 20
 
 
 def parse(argv=None):
@@ -61,6 +75,10 @@ def parse(argv=None):
     ap.add_argument("--dropout", type=float, default=None, help="override the workload's YAML dropout")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline-hbm", action="store_true", help="skip the stand-alone HBM-bound K1 measurements")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the child rocprofv3 --pmc passes that measure K1's memory-side traffic (roofline.traffic = null); "
+                         "use it when this command itself runs under rocprofv3")
+    ap.add_argument("--min-blocks", type=int, default=25, help="timed blocks of --steps steps each (median reported)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline steps (0 = size to ~15 s)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a captured hipGraph when possible")
     ap.add_argument("--dry-run", action="store_true",
@@ -77,6 +95,11 @@ def _free_port():
 def spawn_ranks(args):
     """--gpus N without a torchrun environment: start the N ranks as a child job.  Nothing in this process has
     touched the GPU yet (no torch.cuda call, libglass_hip not loaded); the child processes are fresh interpreters."""
+    if os.environ.get("GLASS_BENCH_BACKEND", "nccl") == "nccl" and args.gpus > torch.cuda.device_count() and not args.dry_run:
+        # (device_count() does not initialise the GPU) — refuse before any rank can hang in init_process_group
+        print(f"bench.py: --gpus {args.gpus} but this node has {torch.cuda.device_count()} GPU(s); RCCL needs one GPU per "
+              "rank (GLASS_BENCH_BACKEND=gloo shares one GPU between ranks for a plumbing smoke test)", file=sys.stderr)
+        return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
@@ -240,6 +263,73 @@ def roofline_hbm_entries(dev):
     return out
 
 
+def k1_pmc_traffic(workload, H, timeout=240):
+    """Memory-side bytes per K1 launch at this workload's shape, measured NOW: two child runs of tools/bin/spmm_bench under
+    `rocprofv3 --kernel-trace --pmc <counter>` — FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE
+    doubled (gfx950 reports half the bytes of wide loads; MI355X_MICROARCH.md §HBM).  None when the shape has no
+    stand-alone generator, a tool is missing, or a pass fails — never a stale number."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = os.path.join(ROOT, "tools", "bin", "spmm_bench")
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if workload not in ("ppi_bp", "hpo_neuro", "em_user", "powerlaw") or not os.path.exists(exe) or not os.path.exists(rocprof):
+        return None, "no stand-alone generator for this shape, or spmm_bench / rocprofv3 missing"
+    vals = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="glass_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run([rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", exe, workload,
+                            str(H), "10"], cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            rows = [r for r in csv.DictReader(open(files[0])) if r["Counter_Name"] == ctr and "spmm_" in r["Kernel_Name"]]
+            names = sorted({r["Kernel_Name"].split("(")[0] for r in rows})
+            lead = [n for n in names if "sweep" in n] or [n for n in names if "long" in n]
+            launches = sum(1 for r in rows if r["Kernel_Name"].split("(")[0] == lead[0])
+            vals[ctr] = sum(float(r["Counter_Value"]) for r in rows) / launches
+            shutil.rmtree(d, ignore_errors=True)
+    except Exception as e:  # noqa: BLE001 — any failure means "not measured"
+        return None, f"PMC pass failed: {type(e).__name__}"
+    return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
+        "this run: child rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB, FETCH_SIZE x2 per the "
+        "gfx950 rule) on tools/bin/spmm_bench at the same shape")
+
+
+def dense_flop_model(N, H, L, pos_batches, lab_cap):
+    """FLOPs per step of the fused Linear-pair kernels: the reference formulation's (two products per row of every pair,
+    impl/models.py:158-173) and the ones the kernels EXECUTE.  The comb pair has no activation before the label mix, so a
+    row needs one product with an effective weight: hidden 64 — every row tile runs one product, the listed labeled rows a
+    second time (glass_comb_eff_*); hidden 256 / 512 forward and 128 / 256 / 512 data gradient — row tiles holding at most
+    3 / 7 labeled rows run one product (dense_tiled.hip kMaxFix); weight gradient — one all-rows product plus the labeled
+    rows (S / L forms).  The tile census is taken from the benchmark's own batches."""
+    import numpy as np
+    pair = 2.0 * N * H * (2 * H)          # one [N,H] x [H,2H] product = 4 N H^2
+    ref = {"trans_fwd": pair, "comb_fwd": 2 * pair, "trans_dgrad": pair, "comb_dgrad": 2 * pair, "trans_wgrad": pair,
+           "comb_wgrad": 2 * pair}
+    ex = dict(ref)
+    n_lab, frac_one_fwd, frac_one_dg = [], [], []
+    tile = 64 if H == 128 else 128
+    for pos in pos_batches:
+        ids = np.unique(pos[pos >= 0])
+        n_lab.append(len(ids))
+        per_tile = np.bincount(ids // tile, minlength=-(-N // tile))
+        frac_one_fwd.append(float((per_tile <= 3).mean()))
+        frac_one_dg.append(float((per_tile <= 7).mean()))
+    lab = float(np.mean(n_lab)) / N
+    if H == 64 and lab_cap:
+        ex["comb_fwd"] = ex["comb_dgrad"] = ex["comb_wgrad"] = pair * (1.0 + lab)
+    elif H in (128, 256, 512):
+        f1, d1 = float(np.mean(frac_one_fwd)), float(np.mean(frac_one_dg))
+        if H >= 256:
+            ex["comb_fwd"] = pair * (f1 + 2 * (1 - f1))
+        ex["comb_dgrad"] = pair * (d1 + 2 * (1 - d1))
+        ex["comb_wgrad"] = pair * (1.0 + min(1.0, 16 * lab))   # S + the 16-row stages (or the rows) that hold a label
+    return {k: v * L for k, v in ref.items()}, {k: v * L for k, v in ex.items()}
+
+
 def dry_run(args, world, rank):
     """Process-group plumbing without a GPU (gloo): the same barrier / max-over-ranks / rank-0-prints protocol."""
     import torch.distributed as td
@@ -278,6 +368,11 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path is the only product path)")
     n_dev = torch.cuda.device_count()
     backend = os.environ.get("GLASS_BENCH_BACKEND", "nccl")  # "gloo": smoke-test the N>1 path on a 1-GPU box
+    if backend == "nccl" and world > n_dev:
+        if rank == 0:
+            print(f"bench.py: world size {world} but this node has {n_dev} GPU(s); RCCL needs one GPU per rank",
+                  file=sys.stderr)
+        sys.exit(2)  # every rank leaves before init_process_group: nobody waits for a rank that cannot start
     if backend == "gloo":
         local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
@@ -293,7 +388,25 @@ def main():
     from glass_amd.factory import build_glass
 
     n_batches = 16
-    w, ei_np, ew_np, x_np, pos_np, y_np = synth.make_workload(args.workload, seed=0, n_batches=n_batches * world)
+    if world == 1:
+        w, ei_np, ew_np, x_np, pos_np, y_np = synth.make_workload(args.workload, seed=0, n_batches=n_batches * world)
+    else:
+        # rank 0 generates the synthetic workload ONCE (config 5: a 20 M-edge rejection sampler), the other ranks load it
+        import numpy as np
+        import torch.distributed as td
+        share = f"/tmp/glass_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}.npz"
+        w = synth.WORKLOADS[args.workload]
+        if rank == 0:
+            w, ei_np, ew_np, x_np, pos_np, y_np = synth.make_workload(args.workload, seed=0, n_batches=n_batches * world)
+            np.savez(share + ".tmp.npz", ei=ei_np, ew=ew_np, x=x_np, pos=pos_np, y=y_np)
+            os.replace(share + ".tmp.npz", share)
+        td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()
+        if rank != 0:
+            with np.load(share) as z:
+                ei_np, ew_np, x_np, pos_np, y_np = z["ei"], z["ew"], z["x"], z["pos"], z["y"]
+        td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()
+        if rank == 0:
+            os.remove(share)
     if args.dropout is not None:
         w.dropout = args.dropout
     if args.features == "nodeid":
@@ -331,25 +444,52 @@ def main():
             td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup, 0)
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps, args.warmup)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
+    def timed_block(offset):
+        barrier()
+        t0 = time.perf_counter()
+        run(args.steps, offset)
+        barrier()
+        return time.perf_counter() - t0
+
+    def max_over_ranks(values):
+        if world == 1:
+            return list(values)
         import torch.distributed as td
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor(values, device=dev, dtype=torch.float64)
         td.all_reduce(t, op=td.ReduceOp.MAX)
-        dt = t.item()
+        return t.tolist()
+
+    run(args.warmup, 0)
+    # blocks of EXACTLY --steps steps, each bracketed by barrier + synchronize; the first one sizes the run (same count on
+    # every rank: it is derived from the max over ranks)
+    first = max_over_ranks([timed_block(args.warmup)])[0]
+    n_blocks = int(min(max(args.min_blocks, -(-0.25 // max(first, 1e-6))), 400))
+    times = [first] + [timed_block(args.warmup + (1 + b) * args.steps) for b in range(n_blocks - 1)]
+    times = sorted(max_over_ranks(times))
+    dt = times[len(times) // 2]  # the median block
     last_loss = stepper.last_loss()
     collective = stepper.collective_share() if hasattr(stepper, "collective_share") else None
+    if world > 1 and collective is not None:
+        # exposed share of the exchange = step time with it - step time without it (same blocks protocol; the ranks'
+        # parameters diverge from here on, which only the timing below and the instrumented pass see)
+        if stepper.graphed and not stepper.collective_in_graph:
+            stepper.exchange_enabled = False
+            off = args.warmup + n_blocks * args.steps
+            t_wo = sorted(max_over_ranks([timed_block(off + b * args.steps) for b in range(max(5, n_blocks // 3))]))
+            stepper.exchange_enabled = True
+            collective["exposed_us"] = (dt - t_wo[len(t_wo) // 2]) / args.steps * 1e6
+            collective["exposed_method"] = "median block with the exchange - median block with the collectives skipped"
+        else:
+            collective["exposed_us"] = None
+            collective["exposed_method"] = "the exchange is captured inside the step's graph: no separate timing"
+        collective["capture_error"] = stepper.capture_error
 
     # ---- device time per C-ABI call inside the step, K1 roofline (rank 0 reports; every rank runs the same code) ----
     # A second, instrumented pass of the same steps, eager (events cannot sit inside the replayed graph).  An eager
     # step is host-bound here, which would count host starvation between two records as kernel time, so each step
     # is queued behind a GPU-side spin long enough for the host to run ahead.
     adj = model.conv.convs[0].adj.fwd
+    adj_ptrs = {model.conv.convs[0].adj.fwd.rowptr.data_ptr(), model.conv.convs[0].adj.bwd.rowptr.data_ptr()}
     t_b2b, (kx, ky) = k1_back_to_back(adj, H)
     t_brk = k1_bracketed(adj, kx, ky)
     bracket_cost = max(t_brk - t_b2b, 0.0)  # what one event pair adds to the reading of this kernel on this box
@@ -378,59 +518,87 @@ def main():
     for name, e0, e1, a in calls:
         t_us = max(e0.elapsed_time(e1) * 1e3 - bracket_cost * 1e6, 0.0)
         per_call.setdefault(name, []).append(t_us)
-        if name == "glass_spmm_csr_f32" and a[7] == N and a[8] == H:  # adjacency launches (n_rows, H), not the selection product
+        # adjacency launches only (the CSR of A or of A^T by its row pointer): not the selection product of the embedding
+        # backward, which has the same (n_rows, H) under --features nodeid
+        if name == "glass_spmm_csr_f32" and a[0] in adj_ptrs:
             k1_us.append(t_us)
+    if not k1_us:
+        raise SystemExit("bench.py: no adjacency launch of glass_spmm_csr_f32 seen in the instrumented pass")
     k1_avg = sum(k1_us) / len(k1_us) * 1e-6
     alg_bytes = _k1_alg_bytes(nnz, N, H)
     x_bytes = N * H * 4
-    cache_resident = x_bytes <= L2_TOTAL_BYTES
-    peak = L2_PEAK_GBPS if cache_resident else HBM_PEAK_GBPS
-    roofline = {"bound": "l2" if cache_resident else "hbm", "achieved": alg_bytes / k1_avg / 1e9, "peak": peak,
-                "unit": "GB/s", "frac": alg_bytes / k1_avg / 1e9 / peak, "traffic": None,
+    traffic, traffic_source = (None, "--no-pmc") if (args.no_pmc or rank != 0 or world != 1) else k1_pmc_traffic(args.workload, H)
+    # Two levels, two utilisations (each <= 1 by construction): every gathered byte passes an XCD L2; what misses there
+    # passes the memory side — Infinity Cache while X fits it, HBM beyond.
+    mem_level, mem_peak = ("infinity_cache", IC_GATHER_GBPS) if x_bytes <= IC_BYTES else ("hbm", HBM_PEAK_GBPS)
+    alg_rate = alg_bytes / k1_avg / 1e9
+    u_l2 = alg_rate / L2_PEAK_GBPS
+    if traffic is not None:
+        mem_rate = min(traffic, alg_bytes) / k1_avg / 1e9 if mem_level == "hbm" else traffic / k1_avg / 1e9
+        u_mem = mem_rate / mem_peak
+    elif mem_level == "hbm":
+        mem_rate, u_mem = alg_rate, alg_rate / mem_peak   # compulsory bytes: a lower bound of the traffic
+    else:
+        mem_rate, u_mem = None, None
+    if x_bytes <= L2_XCD_BYTES or u_mem is None or u_l2 >= u_mem:
+        bound, achieved, peak, frac = "l2", alg_rate, L2_PEAK_GBPS, u_l2
+    else:
+        bound, achieved, peak, frac = mem_level, mem_rate, mem_peak, u_mem
+    roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "traffic": traffic,
                 "kernel": "glass_spmm_csr_f32 (spmm_sweep_kernel) inside the training step",
-                "regime": (f"X = {x_bytes / 2**20:.1f} MiB <= 32 MiB of L2: gathers are served by the XCD L2s / Infinity "
-                           "Cache, so the bound is the aggregate L2 rate (34.5 TB/s)") if cache_resident else
-                          f"X = {x_bytes / 2**20:.0f} MiB: gathers go to HBM (8 TB/s spec)",
-                "frac_of_hbm_peak": alg_bytes / k1_avg / 1e9 / HBM_PEAK_GBPS,
+                "regime": f"X = {x_bytes / 2**20:.1f} MiB: " + (
+                    "fits one XCD's 4 MiB L2" if x_bytes <= L2_XCD_BYTES else
+                    "beyond one XCD's L2, inside the 256 MiB Infinity Cache (L2 misses are gathered rows from it: 8.6 TB/s "
+                    "chip-wide, MI355X_MICROARCH.md §Indexed rows)" if x_bytes <= IC_BYTES else
+                    "beyond the Infinity Cache: L2 misses go to HBM (8 TB/s spec)"),
+                "utilisation": {"l2_algorithmic": u_l2, "memory_side": u_mem, "memory_level": mem_level,
+                                "note": "frac = the larger of the two; algorithmic bytes / 34.5 TB/s (every gathered byte passes "
+                                        "an XCD L2) and memory-side traffic / that level's peak"},
+                "frac_of_hbm_peak_algorithmic": alg_rate / HBM_PEAK_GBPS,
                 "alg_bytes_per_launch": alg_bytes, "avg_launch_us": k1_avg * 1e6, "launches_timed": len(k1_us),
                 "back_to_back_us": t_b2b * 1e6, "bracketed_standalone_us": t_brk * 1e6,
-                "bracket_cost_us": bracket_cost * 1e6,
+                "bracket_cost_us": bracket_cost * 1e6, "traffic_source": traffic_source,
                 "timing": "HIP events on the launch stream around each in-step launch, minus the bracket cost calibrated "
                           "on the same kernel/shape (bracketed - back-to-back hipGraph average)"}
-    prof = os.path.join(ROOT, "profiles", "r02_k1_traffic.json")
-    if os.path.exists(prof):
-        try:
-            with open(prof) as f:
-                roofline["traffic"] = json.load(f).get(args.workload, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-    if roofline["traffic"]:
-        roofline["traffic_source"] = "profiles/r02_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
 
     n_prof = max(k1_steps, 1)
     breakdown = sorted(((name, sum(v) / n_prof, len(v) / n_prof) for name, v in per_call.items()), key=lambda r: -r[1])
     step_breakdown = {"unit": "us per step (device time, calibrated event brackets, eager instrumented pass)",
                       "calls": {name: {"us": round(us, 2), "launch_groups": round(cnt, 2)} for name, us, cnt in breakdown},
                       "total_us": round(sum(us for _, us, _ in breakdown), 1)}
-    dense_flops = {"glass_dual_linear_fwd_f32": 2.0 * N * (3 * H) * (2 * H) * L,       # trans K=H + comb K=2H, 2H outputs
-                   "glass_dual_linear_dgrad_f32": 2.0 * N * (2 * H) * (3 * H) * L,     # comb -> 2H, trans -> H outputs
-                   "glass_dual_linear_wgrad_f32": 2.0 * N * (2 * H) * (3 * H) * L,
-                   "glass_dual_linear_bwd_f32": 4.0 * N * (2 * H) * (3 * H) * L}   # data + weight gradient in one call
+    # dense (MFMA) calls: FLOPs of the reference formulation and FLOPs executed, per C-ABI entry point
+    lab_cap = pos_g.shape[1] * pos_g.shape[2] if getattr(stepper, "_labels", None) is not None else 0
+    f_ref, f_ex = dense_flop_model(N, H, L, [pos_g[b].cpu().numpy() for b in range(min(n_batches, 4))], lab_cap)
+    calls_of = {"glass_dual_linear_fwd_f32": ("trans_fwd", ) if "glass_comb_eff_fwd_f32" in per_call else ("trans_fwd", "comb_fwd"),
+                "glass_comb_eff_fwd_f32": ("comb_fwd", ),
+                "glass_comb_eff_bwd_f32": ("comb_dgrad", "comb_wgrad"),
+                "glass_dual_linear_bwd_f32": ("trans_dgrad", "trans_wgrad") if "glass_comb_eff_bwd_f32" in per_call else
+                                             ("trans_dgrad", "trans_wgrad", "comb_dgrad", "comb_wgrad"),
+                "glass_dual_linear_dgrad_f32": ("trans_dgrad", "comb_dgrad"),
+                "glass_dual_linear_wgrad_f32": ("trans_wgrad", "comb_wgrad")}
     top = breakdown[0]
     dominant = {"kernel": top[0], "us_per_step": round(top[1], 2), "share_of_step": round(top[1] / step_breakdown["total_us"], 3)}
-    if top[0] in dense_flops:
-        tf = dense_flops[top[0]] / (top[1] * 1e-6) / 1e12
-        dominant.update({"bound": "mfma", "achieved": tf, "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_TFLOPS})
+    if top[0] in calls_of:
+        ex = sum(f_ex[k] for k in calls_of[top[0]]) / (top[1] * 1e-6) / 1e12
+        rf = sum(f_ref[k] for k in calls_of[top[0]]) / (top[1] * 1e-6) / 1e12
+        dominant.update({"bound": "mfma", "achieved": ex, "peak": MFMA_F32_TFLOPS, "unit": "TFLOP/s", "frac": ex / MFMA_F32_TFLOPS,
+                         "frac_reference_formulation": rf / MFMA_F32_TFLOPS})
     elif top[0] == "glass_spmm_csr_f32":
         dominant.update({"bound": roofline["bound"], "frac": roofline["frac"]})
     step_breakdown["dominant"] = dominant
-    dense_us = sum(us for name, us, _ in breakdown if name in dense_flops)
+    dense_us = sum(us for name, us, _ in breakdown if name in calls_of)
     if dense_us > 0:
-        tf = sum(fl for name, fl in dense_flops.items() if name in per_call) / (dense_us * 1e-6) / 1e12
-        step_breakdown["dense_mfma"] = {"us_per_step": round(dense_us, 1), "achieved": tf, "peak": MFMA_F32_TFLOPS,
-                                        "unit": "TFLOP/s", "frac": tf / MFMA_F32_TFLOPS,
-                                        "flops": "the reference formulation's (two products per row of every Linear pair); at "
-                                                 "hidden 256 / 512 row tiles of the comb pair without a labeled row run one"}
+        seen = [k for name in per_call if name in calls_of for k in calls_of[name]]
+        ex = sum(f_ex[k] for k in seen) / (dense_us * 1e-6) / 1e12
+        rf = sum(f_ref[k] for k in seen) / (dense_us * 1e-6) / 1e12
+        step_breakdown["dense_mfma"] = {"us_per_step": round(dense_us, 1), "achieved": ex, "peak": MFMA_F32_TFLOPS,
+                                        "unit": "TFLOP/s", "frac": ex / MFMA_F32_TFLOPS,
+                                        "frac_reference_formulation": rf / MFMA_F32_TFLOPS,
+                                        "gflop_executed_per_step": sum(f_ex[k] for k in seen) / 1e9,
+                                        "gflop_reference_per_step": sum(f_ref[k] for k in seen) / 1e9,
+                                        "flops": "frac counts EXECUTED FLOPs (effective-weight kernels run one product per row of the "
+                                                 "comb pair where the reference formulation, impl/models.py:169-173, has two); "
+                                                 "frac_reference_formulation divides the reference's FLOPs by the same time"}
 
     hbm = None
     if rank == 0 and world == 1 and not args.no_roofline_hbm:
@@ -445,7 +613,11 @@ def main():
         out = {
             "metric": "aggregated edges/sec (GLASSConv fwd+bwd)", "value": nnz * L * args.steps * world / dt,
             "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "ms_per_step_min": times[0] / args.steps * 1e3,
+            "ms_per_step_max": times[-1] / args.steps * 1e3, "blocks": len(times), "timed_region_s": sum(times),
+            "timing": f"median of {len(times)} blocks of exactly {args.steps} steps, each bracketed by barrier + "
+                      "torch.cuda.synchronize(), max over ranks per block",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "shipped graph + subgraphs, random-init weights" if w.name == "density" else "synthetic",
             "config": {"workload": f"{'the shipped density graph (BASELINE config[0])' if w.name == 'density' else w.name + '-shaped synthetic graph (BASELINE config[1] family)'}: N={N}, nnz={nnz}, "
                                    f"hidden={H}, layers={L}, aggr={w.aggr}, pool={w.pool}, z_ratio={w.z_ratio}, "

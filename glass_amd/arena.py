@@ -79,6 +79,10 @@ class ParamArena(FlatGradBucket):
             total = (off + 3) // 4 * 4
             self.big_start = total
         self._exchange = None
+        # the optimizer updates the big bucket shard-wise (reduce-scatter + all-gather): only an optimizer that knows how
+        # (optim.FlatAdam) switches this on; otherwise all_reduce_mean() leaves the mean gradient of EVERY parameter in
+        # `flat`, the FlatGradBucket contract any torch optimizer relies on
+        self.shard_optimizer = False
         self.model = model
         model._glass_grad_bucket = self  # dist.bucket_for(model) -> the arena (train.train's all-reduce hook)
         self.params = params
@@ -206,13 +210,16 @@ class ParamArena(FlatGradBucket):
         """True when the big bucket is exchanged by reduce-scatter: the optimizer must then update the small bucket
         and this rank's shard only, and call exchange.gather_params()."""
         ex = self.exchange
-        return ex is not None and ex.has_big
+        return self.shard_optimizer and ex is not None and ex.has_big
 
     def all_reduce_mean(self):
         from .ops import join_side_streams
         join_side_streams()  # the side-stream weight gradients must have landed in the arena
         ex = self.exchange
         if ex is None:
+            return
+        if ex.has_big and not self.shard_optimizer:
+            FlatGradBucket.all_reduce_mean(self)  # one all-reduce over the whole flat buffer
             return
         ex.reduce_small()
         ex.reduce_big()

@@ -10,6 +10,7 @@ from . import _lib
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, arena, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.arena = arena
+        arena.shard_optimizer = True  # this optimizer updates an embedding-sized bucket shard-wise (step() below)
         super().__init__(arena.params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         dev = arena.flat.device
         self.exp_avg = torch.zeros_like(arena.flat)

@@ -11,11 +11,18 @@ the gradient arena, eager fused Adam launches).  The exchange is bucketed (dist.
 (layer / head parameters) is all-reduced; an embedding-sized bucket (`--use_nodeid`) is reduce-scattered, Adam updates
 this rank's shard, and the updated parameter shards are all-gathered.  With such a bucket the backward pass is captured
 as TWO graphs cut where the small bucket becomes final, and its all-reduce runs on a second stream beside the rest of
-the backward (emb_gn + embedding gradient) and beside the big bucket's reduce-scatter."""
+the backward (emb_gn + embedding gradient).  (The big bucket's reduce-scatter is issued on the same process group, i.e.
+on RCCL's one internal stream for that group: it queues behind the small all-reduce — only the overlap with the backward
+tail is real.)"""
+import os
+
 import torch
 
 from . import dist as gdist
 from . import utils
+
+
+CAPTURE_COLLECTIVE = os.environ.get("GLASS_CAPTURE_COLLECTIVE", "1") != "0"  # try the RCCL exchange + Adam inside the step's graph
 
 
 class TrainStep:
@@ -40,6 +47,9 @@ class TrainStep:
         self._comm_stream = None
         self.time_collective = False   # bench.py: record HIP events around the exchange of the last steps
         self._coll_events = []
+        self.collective_in_graph = False  # the RCCL exchange + Adam were captured with the step (one replay per step)
+        self.capture_error = None
+        self.exchange_enabled = True    # bench.py: False = skip the collectives (timing of the exposed share; ranks diverge)
 
     # -- the step body, split at the collective ---------------------------------------------------
     def _fused_head(self):
@@ -139,10 +149,28 @@ class TrainStep:
                 if not self._fwd_bwd(apply_opt=True):  # (with the step program Adam rides in the backward's last launch)
                     self.opt.step()
         elif not self._overlap_small_bucket():
-            # the collective stays outside the graph; the optimizer is two launches, cheaper eager than a
-            # second graph replay
-            with torch.cuda.graph(self._g_fb, capture_error_mode=mode):
-                self._fwd_bwd()
+            # First choice: the WHOLE data-parallel step as one replay — forward/backward, the RCCL all-reduce of the
+            # gradient arena and Adam captured together (RCCL collectives are capturable; gloo's are host code).  A refused
+            # capture raises inside the context manager, the partial capture is discarded and the split form below is taken:
+            # the process stays usable either way.
+            import torch.distributed as td
+            if CAPTURE_COLLECTIVE and td.get_backend() == "nccl":
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode=mode):
+                        self._fwd_bwd()
+                        self.bucket.all_reduce_mean()
+                        self.opt.step()
+                    self._g_fb, self.collective_in_graph = g, True
+                except Exception as e:  # noqa: BLE001 — whatever the runtime refuses: fall back
+                    self.capture_error = repr(e)
+                    torch.cuda.synchronize()
+                    self._g_fb = torch.cuda.CUDAGraph()
+            if not self.collective_in_graph:
+                # the collective stays outside the graph; the optimizer is two launches, cheaper eager than a
+                # second graph replay
+                with torch.cuda.graph(self._g_fb, capture_error_mode=mode):
+                    self._fwd_bwd()
         else:
             # two graphs sharing one memory pool, cut by the program's tail hook: [forward + backward down to the last
             # layer / head gradient] | [emb_gn + embedding gradient]
@@ -159,7 +187,7 @@ class TrainStep:
                 self._fwd_bwd(tail_hook=cut)
                 self._g_tail.capture_end()
             torch.cuda.current_stream().wait_stream(side)
-        self._split = dist_on
+        self._split = dist_on and not self.collective_in_graph
         self.graphed = True
 
     def _exchange_and_update(self):
@@ -168,14 +196,17 @@ class TrainStep:
         if self.time_collective:
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             ev[0].record()
-        if self._g_tail is not None:
+        if not self.exchange_enabled:
+            if self._g_tail is not None:
+                self._g_tail.replay()
+        elif self._g_tail is not None:
             main, comm = torch.cuda.current_stream(), self._comm_stream
             ex = self.bucket.exchange
             comm.wait_stream(main)             # the small bucket is final here
             with torch.cuda.stream(comm):
-                ex.reduce_small()              # beside the tail of the backward pass ...
+                ex.reduce_small()              # beside the tail of the backward pass
             self._g_tail.replay()
-            ex.reduce_big()                    # ... and beside the big bucket's reduce-scatter
+            ex.reduce_big()                    # (same process group: runs after the small all-reduce inside RCCL)
             main.wait_stream(comm)
         else:
             self.bucket.all_reduce_mean()
@@ -195,7 +226,8 @@ class TrainStep:
         red = [a.elapsed_time(b) * 1e3 for a, b, _ in self._coll_events]
         upd = [b.elapsed_time(c) * 1e3 for _, b, c in self._coll_events]
         out = {"exchange_us": sum(red) / len(red), "adam_and_gather_us": sum(upd) / len(upd), "steps_timed": len(red),
-               "overlapped_small_bucket": self._g_tail is not None}
+               "small_bucket_overlaps_backward_tail": self._g_tail is not None,
+               "collective_in_graph": self.collective_in_graph}
         ex = getattr(self.bucket, "exchange", None)
         if ex is not None:
             out["payload_bytes"] = ex.payload_bytes()

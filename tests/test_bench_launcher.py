@@ -37,3 +37,15 @@ def test_child_failure_propagates():
     import torch
     if not torch.cuda.is_available():
         assert p.returncode != 0
+
+
+def test_more_ranks_than_gpus_is_refused_before_any_rank_starts():
+    """`--gpus N` beyond the node's GPU count under RCCL: a clear message and a non-zero exit from the launcher itself —
+    no rank is started that would wait in init_process_group for peers that cannot come up."""
+    import torch
+    n = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "GLASS_BENCH_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 2), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 2 and "RCCL needs one GPU per rank" in p.stderr
+    assert "torch.distributed" not in p.stderr  # refused by the launcher, not by a failing child job

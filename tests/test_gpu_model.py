@@ -1023,7 +1023,11 @@ def test_split_step_with_rccl_allreduce_on_one_rank():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_PORT="29578", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:   # a free port, not a fixed one: two test runs on one box must not collide
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "dist_step_probe.py")], capture_output=True, text=True,
                          timeout=600, env=env, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -1069,5 +1073,5 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(flags, overlapped):
     assert d["n_gpus"] == 2 and d["steps"] == 10 and d["scaling"] == "weak" and d["value"] > 0
     assert math.isfinite(d["config"]["final_loss"])
     c = d["collective"]
-    assert c["world"] == 2 and c["overlapped_small_bucket"] is overlapped
+    assert c["world"] == 2 and c["small_bucket_overlaps_backward_tail"] is overlapped
     assert (c["payload_bytes"]["big_reduce_scatter"] > 0) is overlapped and c["payload_bytes"]["small_allreduce"] > 0

@@ -14,8 +14,9 @@ import torch
 import torch.distributed as td
 
 
-def run(dist_mode, nodeid=False):
-    from glass_amd import synth, losses, ops, dist as gdist
+def run(dist_mode, nodeid=False, capture_collective=True):
+    from glass_amd import synth, losses, ops, dist as gdist, step as step_mod
+    step_mod.CAPTURE_COLLECTIVE = capture_collective
     from glass_amd.arena import ParamArena
     from glass_amd.optim import FlatAdam
     from glass_amd.step import TrainStep
@@ -39,9 +40,13 @@ def run(dist_mode, nodeid=False):
         b = k % 4
         step(pos[b * B:(b + 1) * B], y[b * B:(b + 1) * B])
     torch.cuda.synchronize()
-    assert step.graphed and step._split == bool(dist_mode)
-    assert (step._g_tail is not None) == bool(dist_mode and nodeid)  # two graphs + overlapped small all-reduce
-    return hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest()
+    # one small bucket: the exchange + Adam are captured with the step when RCCL allows it (else the split form);
+    # with an embedding-sized bucket: two graphs + the small all-reduce beside the backward tail, collectives eager
+    assert step.graphed and (step._split or step.collective_in_graph) == bool(dist_mode)
+    assert not (step.collective_in_graph and not capture_collective)
+    assert (step._g_tail is not None) == bool(dist_mode and nodeid)
+    form = "one-graph" if step.collective_in_graph else ("split" if step._split else "single")
+    return hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest(), form, step.capture_error
 
 
 if __name__ == "__main__":
@@ -50,11 +55,16 @@ if __name__ == "__main__":
     single = {nid: run(False, nid) for nid in (False, True)}
     td.init_process_group("nccl", device_id=torch.device("cuda", 0))
     split = {nid: run(True, nid) for nid in (False, True)}
+    eager_coll = run(True, False, capture_collective=False)  # the split form, whatever the capture attempt above did
     td.barrier(device_ids=[0])
     td.destroy_process_group()
     ok = True
     for nid in (False, True):
-        same = single[nid] == split[nid]
+        same = single[nid][0] == split[nid][0]
         ok = ok and same
-        print("nodeid" if nid else "deg", "single", single[nid], "split", split[nid], "same" if same else "DIFFERENT")
+        print("nodeid" if nid else "deg", "single", single[nid][0], split[nid][1], split[nid][0],
+              "same" if same else "DIFFERENT", "capture_error:", split[nid][2])
+    same = single[False][0] == eager_coll[0]
+    ok = ok and same and eager_coll[1] == "split"
+    print("deg single", single[False][0], eager_coll[1], eager_coll[0], "same" if same else "DIFFERENT")
     print("ALL EQUAL" if ok else "MISMATCH")

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 tag=${1:-prof_c2}; shift
 out=gpurun_out/$tag
 mkdir -p $out
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm "$@" > $out/bench_line.json 2> $out/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm --no-pmc "$@" > $out/bench_line.json 2> $out/bench.err
 cp $(ls $out/trace/*/*kernel_stats.csv | head -1) $out/kernel_stats.csv
 python3 tools/prof_summary.py $out/trace 45
 python3 -c "

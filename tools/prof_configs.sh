@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/prof3
 mkdir -p $out
 for w in density hpo_neuro em_user; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/$w -- python3 bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm > $out/${w}_line.json 2> $out/$w.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/$w -- python3 bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm --no-pmc > $out/${w}_line.json 2> $out/$w.err
   cp $(ls $out/$w/*/*kernel_stats.csv | head -1) $out/r02_bench_${w}_kernel_stats.csv
   echo "== $w"; python3 tools/prof_summary.py $out/$w 30
 done
