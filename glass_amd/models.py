@@ -228,6 +228,8 @@ class EmbZGConv(nn.Module):
         x_flat = x.reshape(n)
         if x_flat.dtype != torch.int64:
             x_flat = x_flat.to(torch.int64)
+        if not x_flat.is_contiguous():  # a channel slice of a [N, C, 1] feature tensor: the kernels read a dense int64[N]
+            x_flat = x_flat.contiguous()
         if z is not None:
             # reference: mask = (z > 0.5) for whatever z holds (impl/models.py:243-248); the kernels read int64
             if z.numel() != n:
@@ -243,6 +245,14 @@ class EmbZGConv(nn.Module):
         p = self.dropout if self.training else 0.0
         if self.training and (p > 0 or any(c.dropout > 0 for c in self.convs)):
             ops.rng_advance(x.device)  # new dropout masks for this forward/backward pair
+            # ... read from a private snapshot of the (seed, step) words by this forward's ops and by their backward, so
+            # further training forwards may come before it (NodeEmb over several channels, gradient accumulation)
+            with ops.rng_scope(x.device, ops.rng_snapshot(x.device) if torch.is_grad_enabled() else None):
+                return self._forward_per_op(x_flat, z, edge_index, edge_weight, p)
+        return self._forward_per_op(x_flat, z, edge_index, edge_weight, p)
+
+    def _forward_per_op(self, x_flat, z, edge_index, edge_weight, p):
+        n = x_flat.shape[0]
         arena = getattr(self, "_glass_arena", None)
         if arena is not None:
             arena.refresh_transposes()  # operand images (W, W^T) of the fused dense kernels follow the weights
@@ -332,9 +342,22 @@ class GLASS(nn.Module):
         self.preds = preds
         self.pools = pools
 
+    def _channels(self, x):
+        """The feature channels of x [N, C, F] as dense tensors, made once per feature tensor: x is static per dataset, and
+        the conv caches its selection CSR (and captured graphs hold its pointers) by the tensor it is handed."""
+        if x.shape[1] == 1:
+            return [x.reshape(x.shape[0], x.shape[-1])]
+        cache = self.__dict__.setdefault("_chan_cache", {})
+        key = (x.data_ptr(), tuple(x.shape), x._version)
+        hit = cache.get(key)
+        if hit is None:
+            if len(cache) >= 8:
+                cache.clear()
+            hit = cache[key] = (x, [x[:, c, :].contiguous() for c in range(x.shape[1])])
+        return hit[1]
+
     def NodeEmb(self, x, edge_index, edge_weight, z=None):
-        embs = [self.conv(x[:, c, :].reshape(x.shape[0], x.shape[-1]), edge_index, edge_weight, z)
-                for c in range(x.shape[1])]
+        embs = [self.conv(xc, edge_index, edge_weight, z) for xc in self._channels(x)]
         if len(embs) == 1:
             return embs[0]  # mean over a single feature channel is the identity
         return torch.stack(embs, dim=1).mean(dim=1)
@@ -434,7 +457,7 @@ class EdgeGNN(nn.Module):
         self.preds = preds
         self.pools = pools
 
-    NodeEmb = GLASS.NodeEmb
+    NodeEmb, _channels = GLASS.NodeEmb, GLASS._channels
 
     def Pool(self, emb, subG_node, pool):
         return ops.segment_pool(emb, subG_node, "mean")  # emb[subG_node].mean(dim=1); pairs carry no padding

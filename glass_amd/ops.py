@@ -37,7 +37,16 @@ def _rows(t):
 _rng = {}
 
 
+def _dev(device):
+    """One key per device however it is spelled ("cuda:0", torch.device("cuda", 0), torch.device("cuda"))."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return d
+
+
 def rng_state(device):
+    device = _dev(device)
     st = _rng.get(device)
     if st is None:
         st = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
@@ -47,6 +56,7 @@ def rng_state(device):
 
 def rng_seed(seed, device):
     """(Re)seed the dropout stream IN PLACE: captured graphs keep reading the same device words."""
+    device = _dev(device)
     st = _rng.get(device)
     new = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64)
     if st is None:
@@ -65,11 +75,12 @@ _rng_epoch = {}
 
 
 def note_rng_advance(device):
+    device = _dev(device)
     _rng_epoch[device] = _rng_epoch.get(device, 0) + 1
 
 
 def rng_epoch(device):
-    return _rng_epoch.get(device, 0)
+    return _rng_epoch.get(_dev(device), 0)
 
 
 def check_rng_epoch(device, epoch, what):
@@ -77,6 +88,41 @@ def check_rng_epoch(device, epoch, what):
         raise RuntimeError(f"{what}: the dropout stream was advanced by another training forward between this "
                            "forward and its backward; its mask can no longer be regenerated (run backward() before "
                            "the next training forward, or use dropout 0)")
+
+
+# ---- the dropout words of the CURRENT pass -------------------------------------------------------------------------
+# A training forward on the autograd paths takes a private 16-byte snapshot of (seed, step) right after advancing the
+# stream; every kernel of that forward AND of its backward reads the snapshot, so any number of training forwards may lie
+# between a forward and its backward (GLASS.NodeEmb over several feature channels, reference impl/models.py:336-344;
+# gradient accumulation; two model calls before loss.backward()).  The tape-free step program (stack.loss_and_grads)
+# runs forward and backward back to back and reads the live words — no copy launch in the replayed step.
+_rng_cur = {}
+
+
+def rng_tensor(device):
+    """The (seed, step) words the kernels launched NOW read: the current pass's snapshot, else the live stream."""
+    t = _rng_cur.get(_dev(device))
+    return t if t is not None else rng_state(device)
+
+
+def rng_snapshot(device):
+    """A private copy of the live words (one small device copy; a captured graph replays it with the step)."""
+    return rng_state(device).clone()
+
+
+class rng_scope:
+    """`with rng_scope(device, words):` — the kernels launched inside read `words` (None: the live stream)."""
+    def __init__(self, device, words):
+        self.device, self.words = _dev(device), words
+
+    def __enter__(self):
+        self.prev = _rng_cur.get(self.device)
+        _rng_cur[self.device] = self.words
+        return self.words
+
+    def __exit__(self, *exc):
+        _rng_cur[self.device] = self.prev
+        return False
 
 
 def rng_advance(device):
@@ -497,7 +543,8 @@ class GraphNormFn(torch.autograd.Function):
         y = torch.empty((n, C), dtype=torch.float32, device=x.device)
         saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         ws = _graphnorm_ws(x.device, n, C)
-        rng = rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        words = rng_tensor(x.device) if p_drop > 0 else None  # this pass's (seed, step): the backward re-reads THESE
+        rng = words.data_ptr() if words is not None else 0
         g, b, a = gamma.contiguous(), beta.contiguous(), alpha.contiguous()
         rc = _lib.load().glass_graphnorm_fwd_f32(x.data_ptr(), ldx, y.data_ptr(), C, n, C, g.data_ptr(), b.data_ptr(),
                                                  a.data_ptr(), eps, saved.data_ptr(), act, p_drop, rng, call_id,
@@ -505,6 +552,7 @@ class GraphNormFn(torch.autograd.Function):
         _lib.check(rc, "glass_graphnorm_fwd_f32")
         ctx.save_for_backward(x, g, a, saved)
         ctx.cfg = (act, p_drop, call_id)
+        ctx.rng_words = words
         ctx.rng_epoch = rng_epoch(x.device)
         # direct: parameter gradients are accumulated straight into the flat gradient arena
         ctx.direct = (gamma, beta, alpha) if (direct and all(t.grad is not None for t in (gamma, beta, alpha))) else None
@@ -525,9 +573,9 @@ class GraphNormFn(torch.autograd.Function):
             dg, db, da = dparams[0], dparams[1], dparams[2]
             accumulate = 0
         ws = _graphnorm_ws(x.device, n, C)
-        if p_drop > 0:
+        if p_drop > 0 and ctx.rng_words is rng_state(x.device):  # no snapshot was taken: the live words must be unchanged
             check_rng_epoch(x.device, ctx.rng_epoch, "GraphNormFn.backward")
-        rng = rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rng = ctx.rng_words.data_ptr() if p_drop > 0 else 0
         rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), lddy, x.data_ptr(), x.stride(0), dx.data_ptr(), C, 0, 0,
                                                  n, C, g.data_ptr(), a.data_ptr(), saved.data_ptr(), dg.data_ptr(),
                                                  db.data_ptr(), da.data_ptr(), accumulate, act, p_drop, rng, call_id,

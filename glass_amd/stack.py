@@ -76,7 +76,7 @@ def _comb_eff_ok(conv, labels, H):
 def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
     n, H = xa.shape
     saved, gact, gp, gcall, xa_out = gn
-    grng = ops.rng_state(xa.device).data_ptr() if gp > 0 else 0
+    grng = ops.rng_tensor(xa.device).data_ptr() if gp > 0 else 0
     rc = _lib.load().glass_comb_eff_fwd_f32(xa.data_ptr(), xa.stride(0), xb.data_ptr(), xb.stride(0),
                                             conv._stack_eff["comb"][0].data_ptr(), conv._stack["comb"][1].data_ptr(),
                                             mask.data_ptr(), float(conv.z_ratio), out.data_ptr(), out.stride(0), n, H,
@@ -89,7 +89,7 @@ def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
 def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels):
     n, H = dsrc.shape
     gpart, gx, gsaved, galpha, gact, gp, gcall = gn
-    rng = ops.rng_state(dsrc.device).data_ptr() if gp > 0 else 0
+    rng = ops.rng_tensor(dsrc.device).data_ptr() if gp > 0 else 0
     stack = conv._stack["comb"]
     ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, 2 * H, slot=("stack", len(pending)),
                               min_bytes=int(_lib.load().glass_comb_eff_ws_bytes(n, H, labels.cap)))
@@ -114,7 +114,7 @@ class _GN:
         n, C = x.shape
         saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
         ws = ops._graphnorm_ws(x.device, n, C)
-        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rng = ops.rng_tensor(x.device).data_ptr() if p_drop > 0 else 0
         rc = _lib.load().glass_graphnorm_fwd_f32(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), n, C,
                                                  m.weight.data_ptr(), m.bias.data_ptr(), m.mean_scale.data_ptr(),
                                                  float(m.eps), saved.data_ptr(), act, float(p_drop), rng, call_id,
@@ -148,7 +148,7 @@ class _GN:
 
     def apply(self, x, y, saved, act, p_drop, call_id):
         n, C = x.shape
-        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rng = ops.rng_tensor(x.device).data_ptr() if p_drop > 0 else 0
         rc = _lib.load().glass_graphnorm_apply_f32(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), n, C,
                                                    saved.data_ptr(), act, float(p_drop), rng, call_id, _stream())
         _check(rc, "glass_graphnorm_apply_f32")
@@ -158,7 +158,7 @@ class _GN:
         m = self.mod
         n, C = x.shape
         ws = ops._graphnorm_ws(x.device, n, C)
-        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rng = ops.rng_tensor(x.device).data_ptr() if p_drop > 0 else 0
         ap, lda = (0, 0) if addend is None else (addend.data_ptr(), addend.stride(0))
         rc = _lib.load().glass_graphnorm_bwd_from_stats_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0),
                                                             dx.data_ptr(), dx.stride(0), ap, lda, n, C,
@@ -173,7 +173,7 @@ class _GN:
         m = self.mod
         n, C = x.shape
         ws = ops._graphnorm_ws(x.device, n, C)
-        rng = ops.rng_state(x.device).data_ptr() if p_drop > 0 else 0
+        rng = ops.rng_tensor(x.device).data_ptr() if p_drop > 0 else 0
         ap, lda = (0, 0) if addend is None else (addend.data_ptr(), addend.stride(0))
         rc = _lib.load().glass_graphnorm_bwd_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dx.data_ptr(),
                                                  dx.stride(0), ap, lda, n, C, m.weight.data_ptr(),
@@ -192,7 +192,7 @@ def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None, gn=None, xa
     n, H = (xa_index.shape[0] if xa_index is not None else xa.shape[0]), xa.shape[1]
     if gn is not None:
         saved, gact, gp, gcall, xa_out = gn
-        grng = ops.rng_state(xa.device).data_ptr() if gp > 0 else 0
+        grng = ops.rng_tensor(xa.device).data_ptr() if gp > 0 else 0
         gargs = (saved.data_ptr(), gact, float(gp), grng, gcall, xa_out.data_ptr(), xa_out.stride(0))
     else:
         gargs = (0, 0, 0.0, 0, 0, 0, 0)
@@ -217,7 +217,7 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=Non
         gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall)
     else:
         gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0)
-    rng = ops.rng_state(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
+    rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
     rc = _lib.load().glass_dual_linear_dgrad_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
                                                  0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
                                                  stack[5].data_ptr(), n_out, 0 if addend is None else addend.data_ptr(),
@@ -244,7 +244,7 @@ def _dual_bwd(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, xa, xb, pe
         gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall)
     else:
         gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0)
-    rng = ops.rng_state(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
+    rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
     ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, I, slot=("stack", len(pending)))
     rc = _lib.load().glass_dual_linear_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
                                                0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
@@ -362,10 +362,17 @@ class StackProgram:
             emb.input_emb.weight.grad is not None
 
     # ---------------------------------------------------------------------------------------------
-    def forward(self, x_flat, z, edge_index, edge_weight, keep, readout=None, acc=1, labels=None):
+    def forward(self, x_flat, z, edge_index, edge_weight, keep, readout=None, acc=1, labels=None, snapshot_rng=False):
         """Returns (out, state).  keep=False (no gradient wanted): intermediates are dropped as soon as possible.
         readout = (pos, pool_mode, head Linear, target, loss_mode): instead of the final GraphNorm apply, run the
-        fused training readout (K8r) — out = (loss, logits) and state carries the gradient of the JK buffer."""
+        fused training readout (K8r) — out = (loss, logits) and state carries the gradient of the JK buffer.
+        snapshot_rng: this pass keeps a private copy of the dropout words (seed, step) for its backward, so other training
+        forwards may come in between (the autograd path); False: forward and backward run back to back on the live words."""
+        dev = x_flat.device
+        with ops.rng_scope(dev, None):  # (the prologue advances the LIVE stream; the snapshot, if any, is taken right after)
+            return self._forward(x_flat, z, edge_index, edge_weight, keep, readout, acc, labels, snapshot_rng)
+
+    def _forward(self, x_flat, z, edge_index, edge_weight, keep, readout, acc, labels, snapshot_rng):
         from .models import buildAdj
         emb, lib = self.emb, _lib.load()
         dev = x_flat.device
@@ -417,6 +424,8 @@ class StackProgram:
             # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
             emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
         st["rng_epoch"] = ops.rng_epoch(dev)  # (the prologue launch above advanced the dropout stream)
+        st["rng_words"] = ops.rng_snapshot(dev) if (snapshot_rng and advance and keep) else None
+        ops._rng_cur[ops._dev(dev)] = st["rng_words"]  # the rest of this forward (inside forward()'s rng_scope) reads the snapshot
         if first_gn is not None:
             pass
         elif use_table:
@@ -424,7 +433,7 @@ class StackProgram:
             sel = emb._selection(x_flat)
             saved = torch.empty(4 * H, **f32)
             table = torch.empty((V, H), **f32)
-            rng = ops.rng_state(dev).data_ptr() if p > 0 else 0
+            rng = ops.rng_tensor(dev).data_ptr() if p > 0 else 0
             _check(lib.glass_embed_norm_fwd_f32(x_flat.data_ptr(), W.data_ptr(), V, sel.op.rowptr.data_ptr(),
                                                 gn0.weight.data_ptr(), gn0.bias.data_ptr(), gn0.mean_scale.data_ptr(),
                                                 float(gn0.eps), saved.data_ptr(), table.data_ptr(),
@@ -518,6 +527,10 @@ class StackProgram:
 
     # ---------------------------------------------------------------------------------------------
     def backward(self, st, dout, tail_hook=None, fused_opt=None):
+        with ops.rng_scope(st["mask"].device, st.get("rng_words")):  # the masks of THIS pass's forward
+            return self._backward(st, dout, tail_hook, fused_opt)
+
+    def _backward(self, st, dout, tail_hook, fused_opt):
         """tail_hook: called once every gradient except the embedding's and emb_gn's has been written (the data-parallel
         step starts the all-reduce of the small gradient bucket there, beside the rest of this backward pass)."""
         emb = self.emb
@@ -525,8 +538,8 @@ class StackProgram:
         dev = st["mask"].device
         f32 = dict(dtype=torch.float32, device=dev)
         mask, jk = st["mask"], st["jk"]
-        if p > 0 or any(rec is not None and rec["pc"] > 0 for rec in st["layers"]):
-            ops.check_rng_epoch(dev, st["rng_epoch"], "StackProgram.backward")
+        if st.get("rng_words") is None and (p > 0 or any(rec is not None and rec["pc"] > 0 for rec in st["layers"])):
+            ops.check_rng_epoch(dev, st["rng_epoch"], "StackProgram.backward")  # live words: they must be this pass's still
         acc = st["acc"]  # 1: add into the gradient arena; 0: overwrite (every gradient is written exactly once)
         if "djk" in st:  # the fused readout already went through the final GraphNorm
             djk = st["djk"]
@@ -723,7 +736,7 @@ class StackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prog, x_flat, z, edge_index, edge_weight, *params):
         keep = any(ctx.needs_input_grad)
-        out, st = prog.forward(x_flat, z, edge_index, edge_weight, keep)
+        out, st = prog.forward(x_flat, z, edge_index, edge_weight, keep, snapshot_rng=True)
         ctx.prog, ctx.st, ctx.n_in = prog, st, 5 + len(params)
         return out
 

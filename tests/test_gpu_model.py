@@ -982,21 +982,89 @@ def test_detached_grads_fall_back_to_autograd():
     assert rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys)) < TOL
 
 
-def test_second_training_forward_before_backward_is_refused():
-    """dropout masks are regenerated in backward from the live (seed, step) words; a second training
-    forward advances them.  The backward of the first forward must refuse to run rather than use the wrong masks."""
-    from glass_amd import synth
+@pytest.mark.parametrize("arena", [False, True])
+def test_several_training_forwards_before_backward_with_dropout(arena):
+    """Dropout masks are regenerated in the backward pass from the (seed, step) words of THEIR forward: every training
+    forward on the autograd paths keeps a private snapshot, so two forwards may precede the backwards (gradient
+    accumulation; round 2 refused this).  The accumulated gradient must equal the sum of the two passes run one at a
+    time from the same dropout words.  arena=False: per-op path; True: the stack program as one autograd node."""
+    from glass_amd import synth, ops
+    from glass_amd.arena import ParamArena
     from impl import utils
-    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=5, n_batches=1)
+    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=5, n_batches=2)
     ei, ew, x, pos, y = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x, pos, y))
+    B = w.batch
     torch.manual_seed(0)
-    model = build_glass(w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=0.5).to(DEV).train()
-    z = utils.MaxZOZ(x, pos)
-    l1 = nn.CrossEntropyLoss()(model(x, ei, ew, pos, z), y)
-    l2 = nn.CrossEntropyLoss()(model(x, ei, ew, pos, z), y)
-    l2.backward()  # the latest forward: fine
-    with pytest.raises(RuntimeError, match="dropout stream was advanced"):
-        l1.backward()
+    model = build_glass(64 if arena else w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio,
+                        dropout=0.3).to(DEV).train()
+    if arena:
+        ParamArena(model)
+    params = [p for p in model.parameters()]
+    loss = nn.CrossEntropyLoss()
+    batches = [(pos[:B], y[:B]), (pos[B:2 * B], y[B:2 * B])]
+
+    def grads_of(fn):
+        for p in params:
+            if p.grad is not None:
+                p.grad.zero_()
+        fn()
+        return torch.cat([p.grad.reshape(-1).clone() for p in params])
+
+    def both_then_backward():
+        ops.rng_seed(77, DEV)
+        ls = [loss(model(x, ei, ew, ps, utils.MaxZOZ(x, ps)), ys) for ps, ys in batches]  # two forwards ...
+        ls[0].backward()                                                                   # ... then the backwards,
+        ls[1].backward()                                                                   # oldest first
+
+    def one_at_a_time():
+        ops.rng_seed(77, DEV)
+        for ps, ys in batches:   # the stream advances once per training forward either way: same (seed, step) per pass
+            loss(model(x, ei, ew, ps, utils.MaxZOZ(x, ps)), ys).backward()
+
+    g_acc, g_seq = grads_of(both_then_backward), grads_of(one_at_a_time)
+    assert float(g_seq.abs().max()) > 0
+    assert torch.equal(g_acc, g_seq)   # same kernels, same masks, same accumulation order
+
+
+def test_node_emb_over_two_feature_channels_trains_with_dropout():
+    """GLASS.NodeEmb loops self.conv over the feature channels and averages (reference impl/models.py:336-344): with
+    dropout on, every channel's pass draws its own masks and its backward regenerates exactly those.  For a loss that is
+    linear in the node embedding, the gradient of the 2-channel model is the mean of the two single-channel gradients
+    taken from the same dropout words."""
+    from glass_amd import synth, ops
+    from glass_amd.arena import ParamArena
+    w, ei, ew, x, pos, y = synth.make_workload("tiny", seed=6, n_batches=1)
+    ei, ew, x = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x))
+    torch.manual_seed(1)
+    model = build_glass(64, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=0.3).to(DEV).train()
+    ParamArena(model)
+    params = list(model.conv.parameters())
+    xb = x.flip(0)                                   # a second feature channel: the same table rows, other nodes
+    x2 = torch.cat([x, xb], dim=1)                   # [N, 2, 1]
+    z = (torch.arange(x.shape[0], device=DEV) % 7 == 0).to(torch.int64)
+    R = torch.randn(x.shape[0], model.conv.gns[-1].weight.shape[0], device=DEV)
+
+    def grads(fn):
+        for p in params:
+            p.grad.zero_()
+        fn()
+        return torch.cat([p.grad.reshape(-1).clone() for p in params])
+
+    def two_channels():
+        ops.rng_seed(5, DEV)
+        (model.NodeEmb(x2, ei, ew, z) * R).sum().backward()
+
+    def channel(k, xc):
+        def run():
+            ops.rng_seed(5, DEV)
+            ops.rng_state(DEV)[1] = k                # the k-th training forward since the seed
+            (model.NodeEmb(xc, ei, ew, z) * R).sum().backward()
+        return run
+
+    g2, ga, gb = grads(two_channels), grads(channel(0, x)), grads(channel(1, xb))
+    ref = 0.5 * (ga.double() + gb.double())
+    assert float(ref.abs().max()) > 0
+    assert rel_inf(g2.double(), ref) < 1e-5
 
 
 def test_label_vector_dtypes_and_shapes():
