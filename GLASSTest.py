@@ -16,7 +16,9 @@ import numpy as np
 import torch
 import torch.nn as nn
 import yaml
-from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss
+from torch.nn import CrossEntropyLoss
+
+from glass_amd import losses as glass_losses
 from torch.optim import lr_scheduler
 
 import datasets
@@ -55,7 +57,9 @@ class Run:
         self.args = args
         base = datasets.load_dataset(args.dataset)
         if base.y.unique().shape[0] == 2:  # binary / multi-label: BCE on flattened logits + micro-F1 of (logit > 0)
-            self.loss_fn = lambda x, y: BCEWithLogitsLoss()(x.flatten(), y.flatten())
+            # (glass_amd.losses.BCEWithLogits computes exactly BCEWithLogitsLoss()(x.flatten(), y.flatten()) — the reference's
+            # lambda, GLASSTest.py:57-58 — as a class the training step can recognise and fuse with the head)
+            self.loss_fn = glass_losses.BCEWithLogits()
             self.output_channels = base.y.shape[1] if base.y.ndim > 1 else 1
             self.score_fn = metrics.binaryf1
         else:  # multi-class

@@ -91,6 +91,7 @@ SIGNATURES = {
     "glass_dual_linear_dgrad_layout": (c_int, [_I, _I]),
     "glass_dual_linear_fwd_layout": (c_int, [_I, _I]),
     "glass_head_loss_fwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _I, _I, _I, _P, _P, _P, _P]),
+    "glass_head_linear_f32": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _I, _P]),
     "glass_head_loss_bwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _P, _I, _I, _I, _P, _I, _P, _P, c_int, _P]),
     "glass_batch_labels_ws_bytes": (c_int64, [_I]),
     "glass_batch_labels": (c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, c_int, _P]),

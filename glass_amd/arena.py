@@ -117,7 +117,10 @@ class ParamArena(FlatGradBucket):
                 (W, dW), (b, db) = views
                 O, K = W.shape  # [2H, K]
                 from . import ops
-                if O % 64 == 0 and K % 64 == 0 and ops.dual_linear_supported(O // 2):
+                if ops.dual_linear_supported(O // 2) and _lib.load().glass_dual_linear_layout(O // 2) == 2:
+                    # hidden <= 32 (dense_narrow.hip): the kernels read the row-major weight itself — no packed images
+                    mod._stack[kind] = (W, b, dW, db, W, W)
+                elif O % 64 == 0 and K % 64 == 0 and ops.dual_linear_supported(O // 2):
                     # MFMA images of W (forward operand, [NT=2H][KT=K]) and of W^T (data-gradient operand,
                     # [NT=K][KT=2H]); refreshed by ONE launch per training forward (Adam changes W in between).
                     # flags = transposed | layout << 1 (layout 0: wave16 images; tiled kernels: forward operand

@@ -971,7 +971,7 @@ static bool wave16_shape_ok(int64_t H) { return H == 64; }
 // weight gradient with its 4-stage pipeline); below, they run as two branches of one launch (dual_bwd_kernel).
 static constexpr int64_t kFusedBwdMaxRows = 100000;
 static bool tiled_here(int64_t H) { return tiled_shape_ok(H) && !wave16_shape_ok(H); }
-static bool dense_shape_ok(int64_t H) { return wave16_shape_ok(H) || tiled_shape_ok(H); }
+static bool dense_shape_ok(int64_t H) { return wave16_shape_ok(H) || tiled_shape_ok(H) || narrow_shape_ok(H); }
 static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at once: two when K needs more than one pass
     const size_t image = (size_t)NT * 256;
     return n_pass > 1 ? 2 * image : image;
@@ -985,11 +985,11 @@ static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at 
 // (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
 // glass_dual_linear_fwd_f32 with xa_index (the trans pair of layer 0 gathers its operand rows from the embedding table)
-extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return wave16_shape_ok(H) ? 1 : 0; }
+extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return (wave16_shape_ok(H) || narrow_shape_ok(H)) ? 1 : 0; }
 
 // Operand-image layout glass_dense_pack_batch_f32 must produce for hidden size H: 0 = wave16 images (forward and data
 // gradient alike), 1 = tiled (forward operand: paired layout; data-gradient operand: plain layout)
-extern "C" int glass_dual_linear_layout(int64_t H) { return tiled_here(H) ? 1 : 0; }
+extern "C" int glass_dual_linear_layout(int64_t H) { return narrow_shape_ok(H) ? 2 : tiled_here(H) ? 1 : 0; }
 
 // Layout code (flags >> 1 of glass_dense_pack_batch_f32) of the DATA-GRADIENT operand image glass_dual_linear_dgrad_f32 /
 // _bwd_f32 read for (H, n_out): 0 wave16, 2 plain, 3 split (hidden 128, 128-wide output), 4 plain + effective-weight
@@ -1007,7 +1007,7 @@ extern "C" int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out) {
 }
 
 // rows per workgroup = rows per epilogue statistics partial
-extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return tiled_here(H) ? tiled_rows(H) : 64; }
+extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return narrow_shape_ok(H) ? narrow_rows() : tiled_here(H) ? tiled_rows(H) : 64; }
 
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
@@ -1019,17 +1019,24 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     GLASS_REQUIRE(!xa_index || (gn_saved && !xb && xa_rows > 0 && xa_rows < (1ll << 31)),
                   "dual_linear_fwd: a gathered operand needs the GraphNorm prologue (its side output is the gathered, "
                   "normalised [N,H] input) and is the trans pair's");
-    if (xa_index && !wave16_shape_ok(H)) {
+    if (xa_index && !wave16_shape_ok(H) && !narrow_shape_ok(H)) {
         set_error("dual_linear_fwd: gathered operand only at hidden 64 (glass_dual_linear_fwd_gather_supported)");
         return GLASS_E_UNSUPPORTED;
     }
-    GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved) &&
+    GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && (narrow_shape_ok(H) || (ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved))) &&
                                 p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
                                 (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
                   "dual_linear_fwd: bad GraphNorm prologue arguments");
     if (!dense_shape_ok(H)) {
-        set_error("dual_linear_fwd: hidden size %lld not supported (64, 128, 256, 512)", (long long)H);
+        set_error("dual_linear_fwd: hidden size %lld not supported (<= 32, 64, 128, 256, 512)", (long long)H);
         return GLASS_E_UNSUPPORTED;
+    }
+    if (narrow_shape_ok(H)) {  // thread-per-row kernels: any alignment, the weight as it is (no packed image)
+        GLASS_REQUIRE(lda >= H && (!xb || ldb >= H) && ldo >= H && (!T || ldt >= 2 * H) && (!gn_saved || ldxo >= H),
+                      "dual_linear_fwd: leading dimensions");
+        const GnPrologue npro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
+        return launch_narrow_fwd(xa, lda, xb, ldb, W, bias, mask, (float)z_ratio, (float)(1.0 - z_ratio), act, T, ldt, out, ldo,
+                                 n_nodes, H, stats, npro, xa_index, xa_rows, (hipStream_t)stream);
     }
     const bool comb = xb != nullptr;
     GLASS_REQUIRE(lda >= H && lda % 4 == 0 && aligned16(xa) && (!comb || (ldb >= H && ldb % 4 == 0 && aligned16(xb))) &&
@@ -1080,6 +1087,19 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
     if (!dense_shape_ok(H) || (n_out != H && n_out != 2 * H)) {
         set_error("dual_linear_dgrad: unsupported shape H=%lld n_out=%lld", (long long)H, (long long)n_out);
         return GLASS_E_UNSUPPORTED;
+    }
+    if (narrow_shape_ok(H)) {  // thread-per-row kernels: any alignment; WT = the row-major weight itself ([2H][n_out])
+        GLASS_REQUIRE(ldd >= H && ldo >= n_out && (act == GLASS_ACT_NONE || (T && ldt >= 2 * H)) && (!addend || ldadd >= n_out) &&
+                          (!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && (gn_p_drop == 0.f || rng_state))),
+                      "dual_linear_dgrad: bad arguments");
+        const GnBwdStats ngs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
+                             make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
+        const int rc = launch_narrow_dgrad(dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio,
+                                           (float)(1.0 - z_ratio), act, WT, n_out, addend, ldadd, make_drop(p_drop, call_id, n_out),
+                                           rng_state, out, ldo, n_nodes, H, ngs, (hipStream_t)stream);
+        if (rc || !wg) return rc;
+        return glass_dual_linear_wgrad_f32(dsrc, ldd, T, ldt, mask, z_ratio, act, wg->X, wg->ldx, wg->X2, wg->ldx2, n_nodes, H,
+                                           nullptr, 0, nullptr, 0, wg->ws, stream);
     }
     GLASS_REQUIRE(ldd >= H && ldd % 4 == 0 && aligned16(dsrc) && aligned16(WT) && ldo >= n_out && ldo % 4 == 0 &&
                       aligned16(out) && (act == GLASS_ACT_NONE || (T && ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))) &&

@@ -41,6 +41,7 @@ struct LabRows {
 };
 
 // Operand-image layouts written by glass_dense_pack_batch_f32 (bits 1.. of its per-job flags; bit 0 = transposed source)
+// (glass_dual_linear_layout(H) == 2: no images at all — the narrow kernels read the row-major weight)
 enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2, kLayoutTiledSplit = 3, kLayoutTiledPlainEff = 4,
        kLayoutTiledPairedEff = 5, kLayoutWave16EffFwd = 6, kLayoutWave16EffDgrad = 7 };
 // kLayoutWave16EffFwd / EffDgrad (comb pair at hidden 64, dense.hip): TWO wave16 images back to back, of the effective weight
@@ -63,6 +64,21 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
                        float omz, int act, const float* WTimg, int64_t n_out, const float* addend, int64_t ldadd,
                        const Drop& drop, const uint64_t* rng_state, float* out, int64_t ldo, int64_t N, int64_t H,
                        const GnBwdStats& gs, hipStream_t st);
+// dense_narrow.hip: hidden <= 32 (the shipped YAMLs' widths: 8, 17, 20) — a thread owns a row, weights read as they are
+struct WgradSynth;
+bool narrow_shape_ok(int64_t H);
+int narrow_rows();
+void narrow_wgrad_geom(int64_t N, int64_t O, int64_t I, int* n_slabs, int* stride);
+int launch_narrow_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W, const float* bias,
+                      const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,
+                      int64_t N, int64_t H, double* stats, const GnPrologue& pro, const int64_t* xa_index, int64_t xa_rows,
+                      hipStream_t st);
+int launch_narrow_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, float zr, float omz,
+                        int act, const float* W, int64_t n_out, const float* addend, int64_t ldadd, const Drop& drop,
+                        const uint64_t* rng_state, float* out, int64_t ldo, int64_t N, int64_t H, const GnBwdStats& gs,
+                        hipStream_t st);
+int launch_narrow_wgrad(const WgradSynth& sy, const float* X, int64_t ldx, int64_t N, int64_t O, int64_t I, float* part,
+                        hipStream_t st);
 // image element source of the tiled layouts (used by the pack kernel): output column of image slot nl of column tile ct
 __host__ __device__ inline int tiled_col(int layout, int ct, int nl, int H) {
     const int wn = nl >> 7, cb = (nl >> 5) & 3, j = nl & 31;

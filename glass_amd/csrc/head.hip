@@ -62,6 +62,23 @@ __global__ __launch_bounds__(kBlock) void head_logits_kernel(const float* __rest
     loss_rows[b] = term;
 }
 
+// The head alone (evaluation: no target, no loss): logits[b, k] = pooled[b, :] . W[k, :] + bias[k], one wave per (b, k) pair
+// strided over the workgroup — any K.
+__global__ __launch_bounds__(kBlock) void head_linear_kernel(const float* __restrict__ pooled, int64_t ldp,
+                                                             const float* __restrict__ W, const float* __restrict__ bias, int C,
+                                                             int K, float* __restrict__ logits, int64_t ldl) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float* p = pooled + (int64_t)b * ldp;
+    for (int k = w; k < K; k += kBlock / kWave) {
+        const float* wr = W + (int64_t)k * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += kWave) s = fmaf(p[c], wr[c], s);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) logits[(int64_t)b * ldl + k] = s + (bias ? bias[k] : 0.f);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void head_loss_mean_kernel(const float* __restrict__ loss_rows, int B, float denom,
                                                                 float* __restrict__ loss) {
     __shared__ double red[kBlock];
@@ -166,4 +183,12 @@ extern "C" int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const f
     hipLaunchKernelGGL(head_loss_bwd_kernel, dim3((unsigned)(B + K)), dim3(kBlock), lds, (hipStream_t)stream, pooled, ldp, W,
                        prob, target, mode, grad_loss, (int)B, (int)C, (int)K, dpooled, lddp, dW, db, accumulate);
     return launch_status("glass_head_loss_bwd_f32");
+}
+
+extern "C" int glass_head_linear_f32(const float* pooled, int64_t ldp, const float* W, const float* bias, int64_t B, int64_t C,
+                                     int64_t K, float* logits, int64_t ldl, void* stream) {
+    GLASS_REQUIRE(pooled && W && logits && B > 0 && C > 0 && K > 0 && ldp >= C && ldl >= K && B < (1ll << 31), "head_linear: bad arguments");
+    hipLaunchKernelGGL(head_linear_kernel, dim3((unsigned)B), dim3(kBlock), 0, (hipStream_t)stream, pooled, ldp, W, bias, (int)C,
+                       (int)K, logits, ldl);
+    return launch_status("glass_head_linear_f32");
 }

@@ -17,6 +17,7 @@
 #include "common.h"
 #include "wgrad_common.h"
 #include "spmm_common.h"
+#include "dense_common.h"
 
 #include <stdlib.h>
 
@@ -102,6 +103,46 @@ __device__ __forceinline__ void wgrad_reduce_sl_body(const float* __restrict__ p
             const int o = k - kTile;
             db[o] = accumulate ? db[o] + g1 : g1;
             db[kSLOut + o] = accumulate ? db[kSLOut + o] + g0 : g0;
+        }
+    }
+}
+
+// narrow form (dense_narrow.hip; hidden <= 32): plain row-major slab partials [n_slabs][stride] = dW[O][I] then db[O]
+__device__ __forceinline__ void wgrad_reduce_narrow_body(const float* __restrict__ part, int n_slabs, int stride, int O, int I,
+                                                         float* __restrict__ dW, int64_t lddw, float* __restrict__ db,
+                                                         int accumulate, float4* lds) {
+    const int tc = threadIdx.x & 15, tr = threadIdx.x >> 4;
+    const int k0 = blockIdx.x * 64 + tc * 4;
+    if (blockIdx.x * 64 >= stride) return;  // (workgroup-uniform)
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 < stride)
+        for (int b = tr; b < n_slabs; b += 64) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int bb = b + 16 * u;
+                v[u] = bb < n_slabs ? *reinterpret_cast<const float4*>(part + (int64_t)bb * stride + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+    lds[threadIdx.x] = s;
+    __syncthreads();
+    if (tr != 0 || k0 >= stride) return;
+    for (int r = 1; r < 16; ++r) {
+        const float4 o = lds[r * 16 + tc];
+        s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    const float sv[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int k = k0 + q;
+        if (k < O * I) {
+            float* d = dW + (int64_t)(k / I) * lddw + (k % I);
+            *d = accumulate ? *d + sv[q] : sv[q];
+        } else if (k < O * I + O && db) {
+            const int o = k - O * I;
+            db[o] = accumulate ? db[o] + sv[q] : sv[q];
         }
     }
 }
@@ -192,6 +233,7 @@ struct ReduceJob {
     const float *part_w, *part_b;
     int n_slabs, ny, nz, O, I, accumulate;
     int n_l;  // > 0: S / L form (n_slabs = n_s slab tiles, then n_l labeled-row tiles; ny = nz = 1)
+              // < 0: narrow form, -n_l = the slab stride in floats (ny = nz = 1)
     float* dW;
     int64_t lddw;
     float* db;
@@ -207,6 +249,10 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_batch_kernel(ReduceBatch 
     if ((int)blockIdx.y >= j.ny * j.nz) return;
     if (j.n_l > 0) {
         wgrad_reduce_sl_body(j.part_w, j.part_b, j.n_slabs, j.n_l, j.dW, j.lddw, j.db, j.accumulate, lds);
+        return;
+    }
+    if (j.n_l < 0) {
+        wgrad_reduce_narrow_body(j.part_w, j.n_slabs, -j.n_l, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds);
         return;
     }
     wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.nz, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
@@ -297,6 +343,10 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_sel_kernel(ReduceBatch ba
         wgrad_reduce_sl_body(j.part_w, j.part_b, j.n_slabs, j.n_l, j.dW, j.lddw, j.db, j.accumulate, lds);
         return;
     }
+    if (j.n_l < 0) {
+        wgrad_reduce_narrow_body(j.part_w, j.n_slabs, -j.n_l, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds);
+        return;
+    }
     wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.nz, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
 }
 
@@ -360,6 +410,11 @@ extern "C" int64_t glass_linear_wgrad_ws_bytes(int64_t N, int64_t O, int64_t I) 
     if (N <= 0 || O <= 0 || I <= 0) return GLASS_E_ARG;
     const WgradGeom g = wgrad_geom(N, O, I);
     int64_t floats = g.part_w_floats + g.part_b_floats;
+    if (O <= 2 * 32 && I <= 2 * 32) {  // narrow pairs (dense_narrow.hip)
+        int n_slabs, stride;
+        narrow_wgrad_geom(N, O, I, &n_slabs, &stride);
+        if ((int64_t)n_slabs * stride > floats) floats = (int64_t)n_slabs * stride;
+    }
     if (wgrad_tiled_shape(N, O, I)) {  // glass_dual_linear_wgrad_f32 takes the tiled kernel there: room for either geometry
         const TiledWgradGeom t = wgrad_tiled_geom(N, O, I);
         if (t.part_w_floats + t.part_b_floats > floats) floats = t.part_w_floats + t.part_b_floats;
@@ -397,6 +452,15 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     const int64_t O = 2 * H, I = X2 ? 2 * H : H;
     GLASS_REQUIRE(ldd >= H && ldx >= H && (!dW || lddw >= I) && (!X2 || ldx2 >= H) && (act == GLASS_ACT_NONE || (T && ldt >= O)),
                   "dual_linear_wgrad: bad sizes");
+    if (narrow_shape_ok(H)) {  // hidden <= 32: thread-owned outputs over 256-row slabs (dense_narrow.hip), any alignment
+        const WgradSynth nsy{dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
+                             act, (int)H, X2, ldx2};
+        int rc = launch_narrow_wgrad(nsy, X, ldx, N, O, I, (float*)ws, (hipStream_t)stream);
+        if (rc || !dW) return rc;
+        const void* wsp = ws;
+        const int32_t accum = accumulate;
+        return glass_linear_wgrad_reduce_batch_f32(1, &wsp, &N, &O, &I, &dW, &lddw, &db, &accum, nullptr, stream);
+    }
     if (H % 64 || ldd % 4 || ldx % 2 || (X2 && ldx2 % 2) || !aligned16(dsrc) || (reinterpret_cast<uintptr_t>(X) & 7u) ||
         (X2 && (reinterpret_cast<uintptr_t>(X2) & 7u)) || (act != GLASS_ACT_NONE && (ldt % 4 || !aligned16(T)))) {
         set_error("dual_linear_wgrad: needs H%%64==0 and aligned operands (H=%lld)", (long long)H);
@@ -459,6 +523,14 @@ static int reduce_batch_impl(int64_t n_jobs, const void* const* ws, const int64_
                 const WgradSLGeom g = wgrad_sl_geom(N[j], lab_cap[j]);
                 const float* part_w = (const float*)ws[j];
                 b.job[k] = ReduceJob{part_w, part_w + g.part_w_floats, g.n_s, 1, 1, (int)O[j], (int)I[j], accumulate[j], g.n_l,
+                                     dW[j], lddw[j], db[j]};
+                if (max_chunks < 1) max_chunks = 1;
+                continue;
+            }
+            if (O[j] < 128 && narrow_shape_ok(O[j] / 2)) {  // hidden <= 32: plain slab partials of dense_narrow.hip
+                int n_slabs, stride;
+                narrow_wgrad_geom(N[j], O[j], I[j], &n_slabs, &stride);
+                b.job[k] = ReduceJob{(const float*)ws[j], nullptr, n_slabs, 1, 1, (int)O[j], (int)I[j], accumulate[j], -stride,
                                      dW[j], lddw[j], db[j]};
                 if (max_chunks < 1) max_chunks = 1;
                 continue;

@@ -75,6 +75,8 @@ struct R1Args {
 };
 
 // dynamic LDS (floats): pooled_s[C] | xh_s[C] | red[kBlock*8] | zs[kReadoutMaxK] | dl[kReadoutMaxK]
+// VW = floats per lane and access: 4 (C % 4 == 0, 16-B aligned rows) or 1 (any C: the 17-wide layers of config/component.yml)
+template <int VW>
 __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
     extern __shared__ float sm[];
     const int C = a.C, K = a.K;
@@ -90,13 +92,13 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
     // ---- pool the normalised rows; also sum xhat over the subgraph's rows ----
     const int TC = 1 << a.tc_log2, rpb = kBlock >> a.tc_log2;
     const int tc = tid & (TC - 1), tr = tid >> a.tc_log2;
-    const int c0 = tc * 4;
+    const int c0 = tc * VW;
     const bool ok = c0 < C;
     float accy[4] = {0.f, 0.f, 0.f, 0.f}, acch[4] = {0.f, 0.f, 0.f, 0.f};
     if (ok) {
-        float mu[4], rstd[4], scale[4], shift[4], al[4];
+        float mu[VW], rstd[VW], scale[VW], shift[VW], al[VW];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < VW; ++k) {
             mu[k] = a.saved[c0 + k];
             rstd[k] = a.saved[C + c0 + k];
             scale[k] = a.saved[2 * C + c0 + k];
@@ -106,10 +108,15 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
         for (int j = tr; j < a.Smax; j += rpb) {
             const int64_t node = prow[j];
             if (node < 0 || node >= a.n_nodes) continue;
-            const float4 v = *reinterpret_cast<const float4*>(a.jk + node * a.ldj + c0);
-            const float x[4] = {v.x, v.y, v.z, v.w};
+            float x[VW];
+            if (VW == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(a.jk + node * a.ldj + c0);
+                x[0] = v.x; x[VW > 1 ? 1 : 0] = v.y; x[VW > 2 ? 2 : 0] = v.z; x[VW > 3 ? 3 : 0] = v.w;
+            } else {
+                x[0] = a.jk[node * a.ldj + c0];
+            }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < VW; ++k) {
                 accy[k] += fmaf(x[k], scale[k], shift[k]);
                 acch[k] += (x[k] - al[k] * mu[k]) * rstd[k];
             }
@@ -124,17 +131,16 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
     if (tr == 0 && ok) {
         for (int r = 1; r < rpb; ++r)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < VW; ++k) {
                 accy[k] += red[(r * TC + tc) * 8 + k];
                 acch[k] += red[(r * TC + tc) * 8 + 4 + k];
             }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < VW; ++k) {
             pooled_s[c0 + k] = accy[k] * sc;
             xh_s[c0 + k] = acch[k];
+            a.pooled[(int64_t)b * C + c0 + k] = accy[k] * sc;
         }
-        *reinterpret_cast<float4*>(a.pooled + (int64_t)b * C + c0) =
-            make_float4(accy[0] * sc, accy[1] * sc, accy[2] * sc, accy[3] * sc);
     }
     __syncthreads();
     // ---- logits: wave w takes classes w, w+4, ... ----
@@ -430,6 +436,28 @@ __global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float
     }
 }
 
+// R3 + R4 for ANY C (scalar accesses; the 17-wide layers of config/component.yml): one wave per node, lanes over the
+// columns; a labeled (= pooled) node walks the padded pos matrix in (b, s) order and adds A * g of every subgraph that holds
+// it — atomic-free, bitwise repeatable, no size limit on pos.
+__global__ __launch_bounds__(kBlock) void readout_backfill_scalar_kernel(const float* __restrict__ x, int64_t ldx,
+                                                                        float* __restrict__ dx, int64_t lddx, int64_t N, int C,
+                                                                        const float* __restrict__ coef,
+                                                                        const uint8_t* __restrict__ mask,
+                                                                        const int64_t* __restrict__ pos, int Smax, int n_pos,
+                                                                        const float* __restrict__ dys) {
+    const int lane = threadIdx.x & 63;
+    const int64_t node = (int64_t)blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (node >= N) return;
+    const bool lab = mask[node] != 0;  // wave-uniform
+    for (int c = lane; c < C; c += kWave) {
+        float acc = 0.f;
+        if (lab)
+            for (int j = 0; j < n_pos; ++j)
+                if (pos[j] == node) acc = fmaf(coef[c], dys[(int64_t)(j / Smax) * C + c], acc);
+        dx[node * lddx + c] = fmaf(coef[C + c], x[node * ldx + c], coef[2 * C + c]) + acc;
+    }
+}
+
 // R4: d jk[n] += A * g on the pooled rows
 __global__ __launch_bounds__(kBlock) void readout_scatter_kernel(const int64_t* __restrict__ pos, int Smax,
                                                                  const float* __restrict__ dys,
@@ -457,7 +485,7 @@ __global__ __launch_bounds__(kBlock) void readout_scatter_kernel(const int64_t* 
 using namespace glass;
 
 extern "C" int glass_readout_supported(int64_t C, int64_t K, int pool_mode) {
-    return (C > 0 && C % 4 == 0 && C <= 4 * kBlock && K > 0 && K <= kReadoutMaxK &&
+    return (C > 0 && C <= 4 * kBlock && K > 0 && K <= kReadoutMaxK &&
             (pool_mode == GLASS_POOL_SUM || pool_mode == GLASS_POOL_MEAN || pool_mode == GLASS_POOL_SIZE)) ? 1 : 0;
 }
 
@@ -483,23 +511,33 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
                   "K <= 256, pool sum|mean|size", (long long)C, (long long)K, pool_mode, loss_mode);
         return GLASS_E_UNSUPPORTED;
     }
-    GLASS_REQUIRE(ldj % 4 == 0 && lddj % 4 == 0 && aligned16(jk) && aligned16(djk) && aligned16(pooled) && aligned16(ws),
-                  "readout_train: operands must be 16-B aligned with ld %% 4 == 0");
+    const bool vec = C % 4 == 0 && ldj % 4 == 0 && lddj % 4 == 0 && aligned16(jk) && aligned16(djk) && aligned16(pooled);
+    GLASS_REQUIRE(aligned16(ws) && (vec || mask),
+                  "readout_train: operands must be 16-B aligned with C %% 4 == 0 and ld %% 4 == 0 — or the label bytes given "
+                  "(scalar form for any C)");
     hipStream_t st = (hipStream_t)stream;
     const ReadoutWs w = carve_ws(ws, B, C, K);
-    const int tc = pow2_ceil_cap(C / 4, kBlock);
+    const int tc = pow2_ceil_cap(vec ? C / 4 : C, kBlock);
     int tc_log2 = 0;
     while ((1 << tc_log2) < tc) ++tc_log2;
     R1Args a1{jk, ldj, gn_saved, alpha, pos, (int)Smax, pool_mode, Wh, bh, target, loss_mode, (int)B, (int)C, (int)K,
               grad_loss, pooled, logits, w, n_nodes, tc_log2};
     const size_t lds1 = sizeof(float) * (size_t)(2 * C + kBlock * 8 + 2 * kReadoutMaxK);
-    hipLaunchKernelGGL(readout_subgraph_kernel, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
+    if (vec)
+        hipLaunchKernelGGL(readout_subgraph_kernel<4>, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
+    else
+        hipLaunchKernelGGL(readout_subgraph_kernel<1>, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
     R2Args a2{pooled, w, (int)B, (int)C, (int)K, loss_mode, dWh, dbh, acc_head, loss, n_nodes, gamma, alpha, gn_saved,
               dgamma, dbeta, dalpha, acc_gn};
     size_t lds2 = sizeof(double) * kBlock * 2;
     if (sizeof(float) * (size_t)B > lds2) lds2 = sizeof(float) * (size_t)B;
     GLASS_REQUIRE(lds2 <= 64 * 1024, "readout_train: batch too large for the LDS staging");
     hipLaunchKernelGGL(readout_reduce_kernel, dim3((unsigned)(K + 1 + ceil_div(C, kFinCols))), dim3(kBlock), lds2, st, a2);
+    if (!vec) {  // any C: scalar dense + sparse part as one launch (needs the label bytes = the pooled rows of this pos)
+        hipLaunchKernelGGL(readout_backfill_scalar_kernel, dim3((unsigned)ceil_div(n_nodes, kBlock / kWave)), dim3(kBlock), 0, st,
+                           jk, ldj, djk, lddj, n_nodes, (int)C, w.coef, mask, pos, (int)Smax, (int)(B * Smax), w.dys);
+        return launch_status("glass_readout_train_f32");
+    }
     if (mask && lab_rows && lab_count && B * Smax <= kReadoutOrderedMax) {
         // the pooled rows are listed (glass_batch_labels on this pos): dense and sparse part as ONE launch
         const int rpb1 = kOrdBlock / tc;

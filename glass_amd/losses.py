@@ -25,6 +25,19 @@ class BCEWithLogits(nn.Module):
         return nn.functional.binary_cross_entropy_with_logits(pred.flatten(), y.flatten())
 
 
+def fusable_mode(loss_fn):
+    """0 (cross-entropy) / 1 (BCE with logits on the flattened tensors) when the training step can fuse this loss with the
+    head, else None.  Besides this module's marker classes, torch's own CrossEntropyLoss with default settings qualifies —
+    what the reference driver builds for multi-class sets (GLASSTest.py:69); its binary case is a lambda around
+    BCEWithLogitsLoss (GLASSTest.py:57-58), which cannot be recognised: use BCEWithLogits() above."""
+    if isinstance(loss_fn, (CrossEntropy, BCEWithLogits)):
+        return loss_fn.mode
+    if (type(loss_fn) is nn.CrossEntropyLoss and loss_fn.weight is None and loss_fn.reduction == "mean" and
+            loss_fn.ignore_index == -100 and getattr(loss_fn, "label_smoothing", 0.0) == 0.0):
+        return 0
+    return None
+
+
 class HeadLossFn(torch.autograd.Function):
     """loss = L(pooled @ W^T + b, target) — forward in one launch, backward in one launch."""
     @staticmethod

@@ -372,7 +372,24 @@ class GLASS(nn.Module):
     def forward(self, x, edge_index, edge_weight, subG_node, z=None, id=0):
         emb = self.NodeEmb(x, edge_index, edge_weight, z)
         emb = self.Pool(emb, subG_node, self.pools[id])
-        return self.preds[id](emb)
+        return _head(self.preds[id], emb)
+
+
+def _head(pred, emb):
+    """The prediction head.  A bare nn.Linear under no_grad (evaluation: train.test) runs as one small kernel of this
+    library (glass_head_linear_f32) instead of a library GEMM; anything else is the module itself."""
+    if (type(pred) is nn.Linear and not torch.is_grad_enabled() and emb.is_cuda and emb.dim() == 2 and
+            emb.dtype == torch.float32 and pred.weight.dtype == torch.float32):
+        from . import _lib
+        emb = emb if emb.stride(1) == 1 else emb.contiguous()
+        w = pred.weight if pred.weight.is_contiguous() else pred.weight.contiguous()
+        out = torch.empty((emb.shape[0], w.shape[0]), dtype=torch.float32, device=emb.device)
+        rc = _lib.load().glass_head_linear_f32(emb.data_ptr(), emb.stride(0), w.data_ptr(),
+                                               0 if pred.bias is None else pred.bias.data_ptr(), emb.shape[0], emb.shape[1],
+                                               w.shape[0], out.data_ptr(), out.stride(0), torch.cuda.current_stream().cuda_stream)
+        _lib.check(rc, "glass_head_linear_f32")
+        return out
+    return pred(emb)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -392,7 +392,7 @@ class StackProgram:
         # labels (BatchLabels, already loaded for this batch): the label bytes are an input and the unique labeled rows are
         # listed — the comb pairs then run in effective-weight form at hidden 64.  With ("pos", pos) and no labels handed
         # in, they are computed here (one extra launch; the replayed training step hands them in).
-        if isinstance(z, tuple) and labels is None and USE_COMB_EFF and train:
+        if isinstance(z, tuple) and labels is None and train:
             labels = BatchLabels(n, z[1].numel(), dev)
             labels.load(z[1])
         if labels is not None:
@@ -512,6 +512,10 @@ class StackProgram:
         loss, djk = torch.empty((), **f32), torch.empty((n, C), **f32)
         tgt = target.contiguous().to(torch.int64 if loss_mode == 0 else torch.float32)
         labels = st.get("labels")  # the batch's label bytes + unique labeled rows = its pooled rows (same pos)
+        if labels is None and not (C % 4 == 0 and jk.stride(0) % 4 == 0):
+            # any-width (scalar) form needs the pooled rows marked: the labels came as a z tensor, so mark them from pos here
+            labels = BatchLabels(n, pos.numel(), dev)
+            labels.load(pos)
         largs = (0, 0, 0) if labels is None else (labels.mask.data_ptr(), labels.rows.data_ptr(), labels.count.data_ptr())
         _check(lib.glass_readout_train_f32(jk.data_ptr(), jk.stride(0), saved.data_ptr(), gn.weight.data_ptr(),
                                            gn.mean_scale.data_ptr(), pos.data_ptr(), B, Smax, _lib.POOL_MODES[pool_mode],
@@ -682,7 +686,7 @@ def step_supported(model, loss_fn):
     if not (isinstance(pool, PoolModule) and pool.trans_fn is None and pool.mode in ("sum", "mean", "size")):
         return False
     if not (type(head) is nn.Linear and head.bias is not None and head.weight.grad is not None and
-            head.bias.grad is not None and isinstance(loss_fn, (losses.CrossEntropy, losses.BCEWithLogits))):
+            head.bias.grad is not None and losses.fusable_mode(loss_fn) is not None):
         return False
     C = emb.gns[-1].weight.shape[0]
     return head.weight.shape[1] == C and bool(_lib.load().glass_readout_supported(C, head.weight.shape[0],
@@ -708,6 +712,7 @@ def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, o
     last launch when it can — `applied_optimizer(model)` tells whether it did (else call fused_opt.step())."""
     """(loss, logits) of model(x, ..., pos, z) under loss_fn, gradients accumulated in place (see step_supported).
     z = "pos": label the nodes listed in pos (what utils.MaxZOZ(x, pos) would mark) without materialising z."""
+    from . import losses
     emb = model.conv
     if x.dim() != 3 or x.shape[1] != 1 or x.shape[2] != 1:
         raise NotImplementedError("one integer feature per node (x of shape [N,1,1])")
@@ -723,7 +728,7 @@ def loss_and_grads(model, loss_fn, x, edge_index, edge_weight, pos, z, target, o
             raise ValueError("z must be a tensor, None or 'pos'")
         z = ("pos", pos)
     return prog.loss_and_grads(x_flat, z, edge_index, edge_weight, pos, model.pools[0].mode, model.preds[0], target,
-                               loss_fn.mode, overwrite, tail_hook, labels, fused_opt)
+                               losses.fusable_mode(loss_fn), overwrite, tail_hook, labels, fused_opt)
 
 
 def applied_optimizer(model):

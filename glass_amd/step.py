@@ -57,8 +57,7 @@ class TrainStep:
         import torch.nn as nn
         from . import losses
         head = self.model.preds[0]
-        return (isinstance(self.loss_fn, (losses.CrossEntropy, losses.BCEWithLogits)) and type(head) is nn.Linear and
-                head.bias is not None)
+        return losses.fusable_mode(self.loss_fn) is not None and type(head) is nn.Linear and head.bias is not None
 
     def _program_step(self):
         from . import stack
@@ -88,7 +87,7 @@ class TrainStep:
             from . import losses
             emb = self.model.NodeEmb(self.x, self.ei, self.ew, z)
             pooled = self.model.Pool(emb, self._pos, self.model.pools[0])
-            loss, _logits = losses.head_loss(pooled, self.model.preds[0], self._y, self.loss_fn.mode,
+            loss, _logits = losses.head_loss(pooled, self.model.preds[0], self._y, losses.fusable_mode(self.loss_fn),
                                              direct=hasattr(self.bucket, "flat_param"))
         else:
             pred = self.model(self.x, self.ei, self.ew, self._pos, z, id=0)

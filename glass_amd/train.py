@@ -7,18 +7,20 @@ import torch
 
 from . import dist as gdist
 
-USE_GRAPH = os.environ.get("GLASS_TRAIN_GRAPH", "1") != "0"
+USE_GRAPH = os.environ.get("GLASS_TRAIN_GRAPH", "1") != "0"   # 0: the same training step, eager launches instead of a replay
+USE_STEP = os.environ.get("GLASS_TRAIN_STEP", "1") != "0"     # 0: the plain per-batch loop below (autograd, optimizer.step())
 
 
 def _graph_step(optimizer, model, dataloader, loss_fn):
-    """A hipGraph-replayed step (glass_amd.step.TrainStep) when the epoch is graph-safe: a GLASS model on the GPU,
+    """The training step object (glass_amd.step.TrainStep: the step program, replayed from a hipGraph unless
+    GLASS_TRAIN_GRAPH=0) when the epoch is graph-safe: a GLASS model on the GPU,
     ZGDataloader with z_fn = MaxZOZ and drop_last (fixed batch shape), and an optimizer whose step is capturable
     (FlatAdam: its learning rate lives in device memory, so schedulers keep working under replay).  Cached on the model.  None -> eager loop."""
     from . import utils
     from .SubGDataset import ZGDataloader
     from .models import GLASS
     from .optim import FlatAdam
-    if not (USE_GRAPH and isinstance(model, GLASS) and isinstance(dataloader, ZGDataloader) and
+    if not (USE_STEP and isinstance(model, GLASS) and isinstance(dataloader, ZGDataloader) and
             dataloader.z_fn is utils.MaxZOZ and dataloader.drop_last and dataloader.Gdataset.x.is_cuda and
             len(dataloader) > 0):
         return None
@@ -27,13 +29,13 @@ def _graph_step(optimizer, model, dataloader, loss_fn):
         # Python-float lr would be baked into the captured graph and a scheduler's changes silently ignored
         return None
     ds = dataloader.Gdataset
-    key = (id(optimizer), id(loss_fn), id(ds.x), id(ds.edge_index), dataloader.batch_size, gdist.world_size())
+    key = (id(optimizer), id(loss_fn), id(ds.x), id(ds.edge_index), dataloader.batch_size, gdist.world_size(), USE_GRAPH)
     cache = model.__dict__.setdefault("_glass_train_steps", {})
     step = cache.get(key)
     if step is None:
         from .step import TrainStep
         step = TrainStep(model, optimizer, loss_fn, ds.x, ds.edge_index, ds.edge_attr, gdist.bucket_for(model),
-                         use_graph=True, warmup_iters=2, preserve_state=True)
+                         use_graph=USE_GRAPH, warmup_iters=2, preserve_state=True)  # GLASS_TRAIN_GRAPH=0: the same step, eager launches
         cache.clear()  # one live graph per model
         cache[key] = step
     return step

@@ -413,6 +413,10 @@ int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const float* W, co
                             int mode, const float* grad_loss, int64_t B, int64_t C, int64_t K, float* dpooled,
                             int64_t lddp, float* dW, float* db, int accumulate, void* stream);
 
+/*     The head alone, for evaluation (no target): logits[B,K] = pooled[B,C] @ W[K,C]^T + bias (bias may be NULL). */
+int glass_head_linear_f32(const float* pooled, int64_t ldp, const float* W, const float* bias, int64_t B, int64_t C, int64_t K,
+                          float* logits, int64_t ldl, void* stream);
+
 /* K8r  training-step readout: final GraphNorm apply -> subgraph pooling -> Linear head -> loss AND the whole
  *      backward down to the gradient of the GraphNorm INPUT, in four launches (impl/models.py:266/271, 346-350;
  *      GLASSTest.py:159-160, 57-58/69).  Only pooled rows carry a gradient into the GraphNorm output, so its two
@@ -426,7 +430,7 @@ int glass_head_loss_bwd_f32(const float* pooled, int64_t ldp, const float* W, co
  *      scatter uses float atomics.  mask / lab_rows / lab_count (all three, or NULL): the label bytes and the unique
  *      labeled rows glass_batch_labels produced for THIS pos — the pooled rows of a step are its labeled rows — then the
  *      dense part skips them and extra workgroups of the same launch write their full value: three launches, bitwise
- *      equal to the four. */
+ *      equal to the four.  C % 4 != 0 (or unaligned rows): scalar kernels, which need the label bytes (mask). */
 int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, const float* gamma,
                               const float* beta, const float* alpha, float eps, float* saved, void* ws, void* stream);
 int glass_readout_supported(int64_t C, int64_t K, int pool_mode);

@@ -157,7 +157,7 @@ def test_step_program_entry_points_validate_on_the_host():
     p = x.ctypes.data
     # readout support matrix: C multiple of 4 and <= 1024, K <= 256, pooling sum(0) | mean(1) | size(3)
     assert lib.glass_readout_supported(128, 6, 0) == 1 and lib.glass_readout_supported(128, 6, 3) == 1
-    assert lib.glass_readout_supported(128, 6, 2) == 0 and lib.glass_readout_supported(130, 6, 0) == 0
+    assert lib.glass_readout_supported(128, 6, 2) == 0 and lib.glass_readout_supported(130, 6, 0) == 1  # any C (scalar form)
     assert lib.glass_readout_supported(2048, 6, 0) == 0 and lib.glass_readout_supported(128, 300, 0) == 0
     assert lib.glass_readout_ws_bytes(80, 128, 6) >= 8 * 2 * 80 * 128 + 4 * (4 * 128 + 80 * 128 + 80 * 6 + 80)
     assert lib.glass_readout_ws_bytes(0, 128, 6) == -1

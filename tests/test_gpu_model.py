@@ -380,7 +380,7 @@ def test_train_epoch_graph_path_matches_eager_path():
     ds = SubGDataset.GDataset(*(torch.from_numpy(a) for a in (x, ei, ew, pos, y))).to(DEV)
     results = []
     for use_graph in (False, True):
-        train.USE_GRAPH = use_graph
+        train.USE_STEP = use_graph   # False: the plain per-batch autograd loop; True: TrainStep, replayed from a hipGraph
         torch.manual_seed(0)
         model = build_glass(w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio).to(DEV)
         opt = FlatAdam(ParamArena(model), lr=5e-3)
@@ -389,7 +389,7 @@ def test_train_epoch_graph_path_matches_eager_path():
         losses = [train.train(opt, model, loader, nn.CrossEntropyLoss()) for _ in range(4)]
         results.append((losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()))
         assert ("_glass_train_steps" in model.__dict__) == use_graph
-    train.USE_GRAPH = True
+    train.USE_STEP = True
     assert np.allclose(results[0][0], results[1][0], rtol=2e-5, atol=0)
     assert rel_inf(results[1][1], results[0][1]) < 1e-4
     assert results[0][0][-1] < results[0][0][0]
@@ -427,7 +427,11 @@ def _emb_pair(layers, jk, aggr, z_ratio, dropout, seed, n=700, n_pairs=4000, V=9
 
 @pytest.mark.parametrize("layers,jk,aggr,hidden", [(1, 1, "mean", 64), (2, 1, "gcn", 64), (3, 1, "sum", 64), (2, 0, "mean", 64),
                                                    (3, 0, "gcn", 64), (2, 1, "mean", 128), (3, 0, "sum", 128),
-                                                   (2, 1, "mean", 256), (1, 0, "gcn", 256), (1, 1, "sum", 512)])
+                                                   (2, 1, "mean", 256), (1, 0, "gcn", 256), (1, 1, "sum", 512),
+                                                   # the widths of the reference's own YAMLs for the shipped sets (thread-per-row
+                                                   # kernels, dense_narrow.hip): density / cut_ratio 8, component 17, coreness 20
+                                                   (1, 1, "sum", 8), (2, 0, "mean", 8), (1, 1, "sum", 17), (3, 1, "gcn", 17),
+                                                   (2, 1, "sum", 20), (2, 1, "mean", 32), (1, 0, "gcn", 4)])
 def test_stack_program_vs_oracle(layers, jk, aggr, hidden):
     """EmbZGConv as one forward/backward program (glass_amd/stack.py), hidden 64, 128 (column-split dense kernels) and
     256 (LDS-tiled dense kernels; n = 700 is not a multiple of their 128-row tile), against the fp64 oracle: output, every parameter gradient (accumulated in place in the arena), and eval mode."""
@@ -457,7 +461,7 @@ def test_stack_program_vs_oracle(layers, jk, aggr, hidden):
     assert rel_inf(ye.cpu(), orc.eval()(x.reshape(-1), ei, ew.double(), None).detach()) < TOL
 
 
-@pytest.mark.parametrize("hidden", [64, 256])
+@pytest.mark.parametrize("hidden", [64, 256, 17, 20])
 def test_stack_program_matches_per_op_path_with_dropout(monkeypatch, hidden):
     """Same kernels, same dropout call ids: with dropout 0.5 the program and the per-op autograd path must draw the
     same masks, so outputs and gradients agree to rounding (the gradient sums are merely associated differently).
@@ -523,8 +527,11 @@ def test_stack_program_large_tables(V, n):
     assert rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys)) < TOL
 
 
-@pytest.mark.parametrize("pool,multilabel", [("sum", False), ("mean", False), ("size", True)])
-def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel):
+@pytest.mark.parametrize("pool,multilabel,H,L", [("sum", False, 64, 2), ("mean", False, 64, 2), ("size", True, 64, 2),
+                                                 # the shipped sets' own widths: component (17, one layer: a 17-column readout),
+                                                 # coreness (20, two layers), density / cut_ratio (8)
+                                                 ("sum", False, 17, 1), ("mean", False, 20, 2), ("size", True, 8, 1)])
+def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel, H, L):
     """stack.loss_and_grads (no tape; final GraphNorm apply + pool + head + loss and their backward as K8r) against
     (a) the autograd path of the same model and (b) the fp64 oracle: loss, logits, every gradient.  The subgraphs
     share nodes and are ragged (padding -1)."""
@@ -532,7 +539,7 @@ def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel):
     from glass_amd.arena import ParamArena
     from impl import utils
     from glass_amd import synth
-    n, H, L, K, B, S = 900, 64, 2, 5, 12, 9
+    n, K, B, S = 900, 5, 12, 9
     torch.manual_seed(21)
     model = build_glass(H, L, 7, K, "mean", pool, 0.9)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
