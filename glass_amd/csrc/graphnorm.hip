@@ -340,6 +340,19 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __res
 
 __global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
 
+// The keep-scales (0 or 1 / (1 - p)) a dropout with this call id draws under the CURRENT (seed, step) words for an
+// [N, C] tensor — written out, so that a checker can hand the very same masks to a reference implementation.
+__global__ __launch_bounds__(kBlock) void dropout_scales_kernel(Drop drop, const uint64_t* __restrict__ rng_state, int64_t N,
+                                                                int C, float* __restrict__ out) {
+    drop.seed = rng_state[0];
+    drop.step = rng_state[1];
+    for (int64_t k = (int64_t)blockIdx.x * kBlock + threadIdx.x; k < N * C; k += (int64_t)gridDim.x * kBlock) {
+        float ds[1];
+        drop_scales<1>(drop, k / C, (int)(k % C), ds);
+        out[k] = ds[0];
+    }
+}
+
 static unsigned apply_blocks(int64_t n_rows, const Tiling& t) {
     int64_t b = ceil_div(n_rows, (int64_t)t.rpb * kUnroll);
     if (b < 1) b = 1;
@@ -519,4 +532,14 @@ extern "C" int glass_rng_advance(uint64_t* rng_state, void* stream) {
     GLASS_REQUIRE(rng_state, "rng_advance: null pointer");
     hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, rng_state);
     return launch_status("glass_rng_advance");
+}
+
+extern "C" int glass_dropout_scales_f32(const uint64_t* rng_state, uint64_t call_id, float p_drop, int64_t n_rows, int64_t C,
+                                        float* out, void* stream) {
+    GLASS_REQUIRE(rng_state && out && n_rows > 0 && C > 0 && p_drop > 0.f && p_drop < 1.f, "dropout_scales: bad arguments");
+    int64_t blocks = ceil_div(n_rows * C, kBlock);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(dropout_scales_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream,
+                       make_drop(p_drop, call_id, C), rng_state, n_rows, (int)C, out);
+    return launch_status("glass_dropout_scales_f32");
 }

@@ -177,6 +177,11 @@ int glass_graphnorm_bwd_from_stats_f32(const float* dy, int64_t lddy, const floa
                                        float* dalpha, int accumulate, int act, float p_drop, const uint64_t* rng_state,
                                        uint64_t call_id, void* ws, void* stream);
 int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 */
+/*     Checker's hook: the keep-scales (0 or 1/(1-p)) the dropout with `call_id` draws for an [n_rows, C] tensor under the
+ *     CURRENT rng_state words, written to out — so a test can hand the very masks of a dropout-on step to the CPU oracle
+ *     (the masks are regenerated from (seed, step, call id, element) everywhere, never stored). */
+int glass_dropout_scales_f32(const uint64_t* rng_state, uint64_t call_id, float p_drop, int64_t n_rows, int64_t C, float* out,
+                             void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K3n  embedding lookup + emb_gn + dropout through the embedding TABLE   (replaces the chain

@@ -138,6 +138,22 @@ def segment_pool(emb, batch, n_seg, mode):
 # ----------------------------------------------------------------------------------------
 # model                                                   (reference impl/models.py:114-355)
 # ----------------------------------------------------------------------------------------
+# Dropout (models.py:166, 251, 259: F.dropout with the YAML's p).  A test may FEED the masks: `mask_feed(list)` makes the
+# next dropouts, in call order, multiply by the given keep-scale tensors (0 or 1/(1-p)) instead of drawing their own — how
+# a dropout-on run of the HIP path is compared with this restatement on the very same masks.
+_MASK_FEED = []
+
+
+def mask_feed(scales):
+    _MASK_FEED[:] = list(scales)
+
+
+def _dropout(h, p, training):
+    if training and p > 0 and _MASK_FEED:
+        return h * _MASK_FEED.pop(0).to(h.dtype)
+    return F.dropout(h, p=p, training=training)
+
+
 def _mix(mask, zr, f1, f0):
     """models.py:161-162 / 172-173: labeled rows zr*f1+(1-zr)*f0, unlabeled zr*f0+(1-zr)*f1."""
     return torch.where(mask, zr * f1 + (1 - zr) * f0, zr * f0 + (1 - zr) * f1)
@@ -159,7 +175,7 @@ class OracleConv(nn.Module):
         f1 = act(self.trans_fns[1](x_in))
         f0 = act(self.trans_fns[0](x_in))
         h = self.adj @ _mix(mask, self.z_ratio, f1, f0)
-        h = F.dropout(self.gn(h), p=self.dropout, training=self.training)
+        h = _dropout(self.gn(h), self.dropout, self.training)
         h = torch.cat((h, x_in), dim=-1)
         return _mix(mask, self.z_ratio, self.comb_fns[1](h), self.comb_fns[0](h))
 
@@ -181,13 +197,13 @@ class OracleEmbZGConv(nn.Module):
         mask = torch.ones(n, 1, dtype=torch.bool) if z is None else (z > 0.5).reshape(-1, 1)
         act = F.elu  # GLASSTest.py:143 nn.ELU(inplace=True)
         h = self.emb_gn(self.input_emb(x).reshape(n, -1))
-        h = F.dropout(h, p=self.dropout, training=self.training)
+        h = _dropout(h, self.dropout, self.training)
         saved = []
         for l, conv in enumerate(self.convs):
             h = conv(h, edge_index, edge_weight, mask, act)
             saved.append(h)  # JK keeps the RAW conv outputs (models.py:254-255,260-264)
             if l + 1 < len(self.convs):
-                h = F.dropout(act(self.gns[l](h)), p=self.dropout, training=self.training)
+                h = _dropout(act(self.gns[l](h)), self.dropout, self.training)
         return self.gns[-1](torch.cat(saved, dim=-1) if self.jk else saved[-1])
 
 

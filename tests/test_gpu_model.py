@@ -705,6 +705,62 @@ def test_step_program_full_size_vs_oracle(name):
     assert err < max(TOL, 2 * o_grad)
 
 
+@pytest.mark.parametrize("name", ["ppi_bp", "em_user"])
+def test_benchmarked_dropout_step_vs_oracle_on_the_same_masks(name):
+    """The benchmarked step WITH its YAML dropout (0.5) at the full BASELINE shapes against the fp64 oracle given the very
+    masks the kernels drew: the library writes out the keep-scales of every dropout of the pass (glass_dropout_scales_f32:
+    same counter-based hash, same (seed, step) words) and the oracle multiplies by them instead of drawing its own
+    (reference impl/models.py:166, 251, 259).  Round 2 could only check dropout-on runs statistically."""
+    from glass_amd import synth, stack, losses, ops, _lib
+    from glass_amd.arena import ParamArena
+    w, ei, ew, x, pos, y = synth.make_workload(name, seed=0, n_batches=1)
+    assert w.dropout == 0.5
+    ei, ew, x, pos, y = (torch.from_numpy(a) for a in (ei, ew, x, pos, y))
+    torch.manual_seed(0)
+    model = build_glass(w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=w.dropout)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    loss_fn = losses.BCEWithLogits() if w.multilabel else losses.CrossEntropy()
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    assert stack.step_supported(model, loss_fn) and stack.covers_arena(model, arena)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    ops.rng_seed(2024, DEV)
+    loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg, overwrite=True)
+    # the masks of that pass, in the oracle's call order: emb_gn's dropout (call id 1), then per layer conv.gn's (16 (l+1))
+    # and, between layers, the one behind gns[l] (16 (l+1) + 1)
+    N, H, L = x.shape[0], w.hidden, w.layers
+    ids = [1]
+    for l in range(L):
+        ids.append(16 * (l + 1))
+        if l + 1 < L:
+            ids.append(16 * (l + 1) + 1)
+    feed = []
+    for cid in ids:
+        m = torch.empty(N, H, device=DEV)
+        _lib.check(_lib.load().glass_dropout_scales_f32(ops.rng_state(DEV).data_ptr(), cid, w.dropout, N, H, m.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream), "glass_dropout_scales_f32")
+        feed.append(m.cpu())
+        kept = float((feed[-1] > 0).double().mean())
+        assert abs(kept - 0.5) < 0.01 and set(feed[-1].unique().tolist()) == {0.0, 2.0}
+    orc = O.OracleGLASS(w.hidden, w.layers, int(x.max()), w.n_class, aggr=w.aggr, pool=w.pool, z_ratio=w.z_ratio,
+                        dropout=w.dropout)
+    orc.load_state_dict(sd)
+    orc = orc.double().train()
+    O.mask_feed(feed)
+    po = orc(x, ei, ew.double(), pos, O.max_zero_one(x, pos))
+    assert not O._MASK_FEED  # every fed mask was consumed, in order
+    lo = loss_fn(po, y.double() if w.multilabel else y)
+    lo.backward()
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    keys = sorted(mine)
+    e_pred, e_loss = rel_inf(logits.cpu(), po.detach()), abs(loss.item() - lo.item()) / abs(lo.item())
+    err = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
+    print(f"{name} (dropout 0.5, same masks): logits {e_pred:.2e} loss {e_loss:.2e} grad {err:.2e}")
+    record_parity(f"step_program_dropout_same_masks/{name}", logits_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf=err)
+    assert e_pred < TOL and e_loss < TOL and err < TOL
+
+
 def test_large_batches_fall_back_to_atomic_scatters():
     """pos matrices beyond the LDS staging of the ordered scatters (readout: B*Smax > 16 384, pool backward:
     > 12 288) take the float-atomic kernels: same results within tolerance (not bitwise repeatable)."""
