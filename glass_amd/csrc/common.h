@@ -116,12 +116,20 @@ struct AdamCoef {
     float step_size, bc2_sqrt, w1, w2, beta2, eps, weight_decay;
 };
 
+// (the two double-precision pow() are evaluated by ONE thread per workgroup and broadcast through LDS: as per-thread code
+// they were a visible share of a launch whose useful work is a few loads and a dozen flops per element)
 __device__ __forceinline__ AdamCoef adam_coef(int64_t step_now, float lr, float beta1, float beta2, float eps, float weight_decay) {
-    const double t = (double)step_now;
-    const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+    __shared__ float s_bc[2];
+    if (threadIdx.x == 0) {
+        const double t = (double)step_now;
+        const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+        s_bc[0] = (float)((double)lr / bc1);
+        s_bc[1] = (float)sqrt(bc2);
+    }
+    __syncthreads();
     AdamCoef c;
-    c.step_size = (float)((double)lr / bc1);
-    c.bc2_sqrt = (float)sqrt(bc2);
+    c.step_size = s_bc[0];
+    c.bc2_sqrt = s_bc[1];
     c.w1 = 1.f - beta1;
     c.w2 = 1.f - beta2;
     c.beta2 = beta2;

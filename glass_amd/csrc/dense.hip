@@ -23,6 +23,10 @@
 #include "wgrad_common.h"
 #include "emb_table.h"
 
+#ifndef GLASS_WGRAD_STAGED
+#define GLASS_WGRAD_STAGED 0  // laboratory switch: slabs through LDS whole (wgrad_*_staged_body) — measured slower, see DESIGN.md
+#endif
+
 #include <stdlib.h>
 
 namespace glass {
@@ -540,6 +544,11 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
     }
     const int t = b - n_dgrad_blocks;  // slab fastest, then input tile, then output tile (as the 3-D grid of the stand-alone launch)
     float* lds = reinterpret_cast<float*>(lds_w);
+    if (GLASS_WGRAD_STAGED && NT == 64 && rows_per_slab <= kStageRows && sy.X2 == nullptr) {
+        // trans pair on a small graph (one 128 x 64 tile per slab): the whole slab through LDS, one memory round trip
+        wgrad_synth_staged_body(X, ldx, A.N, rows_per_slab, part_w, part_b, sy, t, gx, lds, lds + 2 * kTile);
+        return;
+    }
     wgrad_partial_body<true, 2>(nullptr, 0, X, ldx, A.N, O, I, rows_per_slab, part_w, part_b, sy, t % gx, (t / gx) % gy,
                                 t / (gx * gy), gx, gy, lds, lds + 2 * kTile);
 }
@@ -829,7 +838,10 @@ __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A,
         return;
     }
     float* lds = reinterpret_cast<float*>(lds_w);
-    wgrad_sl_body<2>(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
+    if (GLASS_WGRAD_STAGED && sl.rows_per_slab <= kStageRows)  // small graph: the whole slab through LDS, one memory round trip
+        wgrad_sl_staged_body(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
+    else
+        wgrad_sl_body<2>(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
 }
 
 // ---- packing of the stacked weights into MFMA images (one launch for the whole model, once per step) ------

@@ -275,6 +275,7 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     if (N <= 100000) {
         const int64_t room = (2 * 256 - 4 - ceil_div(N, 64)) / tiles;
         if (room >= 32 && room < max_slabs) max_slabs = room;
+        // (laboratory: with GLASS_WGRAD_STAGED the trans pair wants room slabs of <= 80 rows instead)
     }
     if (max_slabs < 32) max_slabs = 32;
     int64_t rows = ceil_div(N, max_slabs);

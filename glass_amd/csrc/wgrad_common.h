@@ -329,6 +329,215 @@ __device__ __forceinline__ void wgrad_sl_body(const WgradSL& a, int64_t N, int b
     }
 }
 
+// ---- small graphs: the whole slab through LDS ------------------------------------------------------------------------
+// In the fused backward launch of a small graph a slab is <= 80 rows and a wave's share of it 10 row pairs: the register
+// pipeline above then IS its fill — every stage waits a full memory round trip for loads issued two stages earlier, and
+// the weight-gradient branch, not the data gradient, sets the launch's length.  Here the workgroup requests the slab's
+// operands ONCE, all loads in flight together (one round trip), parks them in LDS (the gradient operand already
+// synthesised), and the MFMA loop reads LDS only.  Same pairs per wave in the same order, same combine: bitwise the results
+// of the pipelined bodies.  The staging area is the combine area (2 * kTile floats), reused after a barrier.
+constexpr int kStageRows = 80;  // 80 rows x 192 floats = 60 KiB of the 64 KiB image area
+
+// SYNTH form (trans pair): dZ [rows][2H = 128] synthesised while staging, X [rows][64].  O = 128, I = 64, one tile.
+__device__ __forceinline__ void wgrad_synth_staged_body(const float* __restrict__ X, int64_t ldx, int64_t N, int rows_per_slab,
+                                                        float* __restrict__ part_w, float* __restrict__ part_b,
+                                                        const WgradSynth& sy, int bx, int gx, float* lds, float* lds_b) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t r0 = (int64_t)bx * rows_per_slab;
+    const int nrows = (int)(min(N, r0 + rows_per_slab) - r0);
+    const int nrows8 = (nrows + 7) & ~7;
+    float* dz_s = lds;                       // [kStageRows][128]
+    float* x_s = lds + kStageRows * 128;     // [kStageRows][64]
+    // every load of the slab is issued before the first LDS store (registers: the accumulators are not live yet)
+    constexpr int kSynthItems = kStageRows * 32 / kBlock, kXItems = kStageRows * 16 / kBlock;  // 10, 5
+    float4 dv[kSynthItems], tv[kSynthItems], xv4[kXItems];
+    float cfv[kSynthItems];
+#pragma unroll
+    for (int k = 0; k < kSynthItems; ++k) {
+        const int item = threadIdx.x + kBlock * k, row = item >> 5, oq = item & 31;
+        dv[k] = tv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        cfv[k] = 0.f;
+        if (row < nrows) {
+            const int64_t n = r0 + row;
+            dv[k] = *reinterpret_cast<const float4*>(sy.dsrc + n * sy.ldd + 4 * (oq & 15));
+            if (sy.act == GLASS_ACT_ELU) tv[k] = *reinterpret_cast<const float4*>(sy.T + n * sy.ldt + 4 * oq);
+            cfv[k] = ((sy.mask[n] != 0) == (oq < 16)) ? sy.zr : sy.omz;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kXItems; ++k) {
+        const int item = threadIdx.x + kBlock * k, row = item >> 4, q = item & 15;
+        xv4[k] = row < nrows ? *reinterpret_cast<const float4*>(X + (r0 + row) * ldx + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < kSynthItems; ++k) {
+        const int item = threadIdx.x + kBlock * k, row = item >> 5, oq = item & 31;
+        if (row >= nrows8) continue;
+        float4 g = make_float4(dv[k].x * cfv[k], dv[k].y * cfv[k], dv[k].z * cfv[k], dv[k].w * cfv[k]);
+        if (sy.act == GLASS_ACT_ELU) {
+            g.x *= elu_grad_f(tv[k].x); g.y *= elu_grad_f(tv[k].y); g.z *= elu_grad_f(tv[k].z); g.w *= elu_grad_f(tv[k].w);
+        }
+        *reinterpret_cast<float4*>(dz_s + row * 128 + 4 * oq) = g;
+    }
+#pragma unroll
+    for (int k = 0; k < kXItems; ++k) {
+        const int item = threadIdx.x + kBlock * k, row = item >> 4, q = item & 15;
+        if (row < nrows8) *reinterpret_cast<float4*>(x_s + row * 64 + 4 * q) = xv4[k];
+    }
+    __syncthreads();
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = w; 2 * p < nrows8; p += 4) {  // wave w: row pairs w, w + 4, ... (as the pipelined body)
+        const int row = 2 * p + h;
+        const float4 g = *reinterpret_cast<const float4*>(dz_s + row * 128 + 4 * c);
+        const float2 x = *reinterpret_cast<const float2*>(x_s + row * 64 + 2 * c);
+        const float gv[4] = {g.x, g.y, g.z, g.w};
+        const float xv[2] = {x.x, x.y};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
+        bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+    }
+    __syncthreads();  // every wave is done reading the staged slab: the area becomes the combine area
+    if (w < 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index(t, u, k, lane)] = acc[t][u][k];
+    }
+    *reinterpret_cast<float4*>(&lds_b[(w * 2 + h) * kOT + 4 * c]) = bsum;
+    __syncthreads();
+    if (w >= 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index(t, u, k, lane)] += acc[t][u][k];
+    }
+    __syncthreads();
+    float* pw = part_w + (int64_t)bx * kTile;  // (tile id = slab: one input tile, one output tile)
+    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(&lds[k]);
+        const float4 b = *reinterpret_cast<const float4*>(&lds[kTile + k]);
+        *reinterpret_cast<float4*>(pw + k) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    if (part_b && threadIdx.x < kOT) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds_b[k * kOT + threadIdx.x];
+        part_b[(int64_t)bx * kOT + threadIdx.x] = s;
+    }
+    (void)gx;
+}
+
+// S / L form (comb pair at hidden 64): dc [rows][64], c = [g || x_] [rows][128]; labeled-row blocks gather their rows.
+__device__ __forceinline__ void wgrad_sl_staged_body(const WgradSL& a, int64_t N, int blk, float* __restrict__ part_w,
+                                                     float* __restrict__ part_b, float* lds, float* lds_b) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const bool lab = blk >= a.n_s;
+    int64_t r0;
+    int nrows;
+    if (!lab) {
+        r0 = (int64_t)blk * a.rows_per_slab;
+        nrows = (int)(min(N, r0 + a.rows_per_slab) - r0);
+    } else {
+        const int64_t n_lab = a.lab_count[0];
+        r0 = (int64_t)(blk - a.n_s) * 64;
+        nrows = (int)max((int64_t)0, min(n_lab, r0 + 64) - r0);
+    }
+    const int nrows8 = (nrows + 7) & ~7;
+    float* dc_s = lds;                      // [kStageRows][64]
+    float* x_s = lds + kStageRows * 64;     // [kStageRows][128]
+    // every load of the slab is issued before the first LDS store (registers: the accumulators are not live yet);
+    // item = (row, quad): 16 quads of dc, 16 of g, 16 of x_ per row
+    constexpr int kItems = kStageRows * 48 / kBlock;  // 15
+    float4 v[kItems];
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int item = threadIdx.x + kBlock * k, row = item / 48, q = item % 48;
+        v[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < nrows) {
+            const int64_t n = lab ? (int64_t)a.lab_rows[r0 + row] : r0 + row;
+            v[k] = q < 16 ? *reinterpret_cast<const float4*>(a.dc + n * a.ldd + 4 * q)
+                   : q < 32 ? *reinterpret_cast<const float4*>(a.X + n * a.ldx + 4 * (q - 16))
+                            : *reinterpret_cast<const float4*>(a.X2 + n * a.ldx2 + 4 * (q - 32));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kItems; ++k) {
+        const int item = threadIdx.x + kBlock * k, row = item / 48, q = item % 48;
+        if (row >= nrows8) continue;
+        if (q < 16) *reinterpret_cast<float4*>(dc_s + row * 64 + 4 * q) = v[k];
+        else *reinterpret_cast<float4*>(x_s + row * 128 + 4 * (q - 16)) = v[k];
+    }
+    __syncthreads();
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
+    float2 bsum = make_float2(0.f, 0.f);
+    for (int p = w; 2 * p < nrows8; p += 4) {
+        const int row = 2 * p + h;
+        const float2 g = *reinterpret_cast<const float2*>(dc_s + row * 64 + 2 * c);
+        const float4 x = *reinterpret_cast<const float4*>(x_s + row * 128 + 4 * c);
+        const float gv[2] = {g.x, g.y};
+        const float xv[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[t], xv[u], acc[t][u], 0, 0, 0);
+        bsum.x += g.x;
+        bsum.y += g.y;
+    }
+    __syncthreads();
+    if (w < 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index_sl(t, u, k, lane)] = acc[t][u][k];
+    }
+    *reinterpret_cast<float2*>(&lds_b[(w * 2 + h) * kSLOut + 2 * c]) = bsum;
+    __syncthreads();
+    if (w >= 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index_sl(t, u, k, lane)] += acc[t][u][k];
+    }
+    __syncthreads();
+    float* pw = part_w + (int64_t)blk * kTile;
+    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
+        const float4 p = *reinterpret_cast<const float4*>(&lds[k]);
+        const float4 q = *reinterpret_cast<const float4*>(&lds[kTile + k]);
+        *reinterpret_cast<float4*>(pw + k) = make_float4(p.x + q.x, p.y + q.y, p.z + q.z, p.w + q.w);
+    }
+    if (threadIdx.x < kSLOut) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds_b[k * kSLOut + threadIdx.x];
+        part_b[(int64_t)blk * kSLOut + threadIdx.x] = s;
+    }
+}
+
 // wgrad_tiled.hip: used by glass_dual_linear_wgrad_f32 (and the deferred reduction of its partials) when
 // wgrad_tiled_shape(N, O, I) — the partial kernel writes plain [slab][tile][128][256] partial
 // sums (+ [slab][o-tile][128] bias partials), the reduce kernel sums the slabs in order into dW / db.
