@@ -33,6 +33,21 @@ class GlassHipError(RuntimeError):
 
 _P = c_void_p
 _I = c_int64
+
+
+class GnSrc(ctypes.Structure):
+    """glass_gn_src (include/glass_hip.h): a GraphNorm whose forward sums are still in exact accumulators."""
+    _fields_ = [("acc", c_void_p), ("n_src", c_int64), ("gamma", c_void_p), ("beta", c_void_p), ("alpha", c_void_p),
+                ("eps", c_float)]
+
+    @classmethod
+    def of(cls, acc, n_src, gn):
+        """acc: int64 tensor (n_src consecutive accumulator blocks); gn: the GraphNorm module."""
+        return cls(acc.data_ptr(), n_src, gn.weight.data_ptr(), gn.bias.data_ptr(), gn.mean_scale.data_ptr(), float(gn.eps))
+
+    @property
+    def ptr(self):
+        return ctypes.addressof(self)
 # name -> (restype, argtypes); mirrors include/glass_hip.h one to one
 SIGNATURES = {
     "glass_version": (c_int, []),
@@ -58,7 +73,7 @@ SIGNATURES = {
     "glass_readout_supported": (c_int, [_I, _I, c_int]),
     "glass_readout_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_readout_train_f32": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, c_int, _P, _P, _P, c_int, _I, _P, _P, _P, _P, _P, _I,
-                                        _P, _P, c_int, _P, _P, _P, c_int, _P, _I, _I, _P, _P, _P, _P]),
+                                        _P, _P, c_int, _P, _P, _P, c_int, _P, _I, _I, _P, _P, _P, _P, _P]),
     "glass_linear_wgrad_reduce_batch_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "glass_wgrad_reduce_spmm_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                                             _P, _P]),
@@ -69,16 +84,19 @@ SIGNATURES = {
     "glass_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, c_int, _P, _P]),
     "glass_dual_linear_supported": (c_int, [_I]),
     "glass_dual_linear_layout": (c_int, [_I]),
-    "glass_dual_linear_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, _P, c_int,
-                                          c_float, _P, c_uint64, _P, _I, _P, _I, _P]),
+    "glass_dual_linear_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, c_int, _P, _P,
+                                          c_int, c_float, _P, c_uint64, _P, _I, _P, _I, _P]),
     "glass_dual_linear_fwd_gather_supported": (c_int, [_I]),
-    "glass_step_prologue_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _I, _P]),
+    "glass_step_prologue_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _I, _P, _I, _P]),
     "glass_graphnorm_finalize_f32": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, c_float, _P, _P]),
     "glass_graphnorm_apply_f32": (c_int, [_P, _I, _P, _I, _I, _I, _P, c_int, c_float, _P, c_uint64, _P]),
     "glass_dual_linear_dgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, c_float, _P, c_uint64, _P, _I,
-                                            _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, _P]),
+                                            _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, c_int, _P]),
     "glass_dual_linear_bwd_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, c_float, _P, c_uint64, _P, _I,
-                                          _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, _P, _I, _P, _I, _P, _P]),
+                                          _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, c_int, _P, _I, _P, _I, _P, _P]),
+    "glass_gn_exact_supported": (c_int, [_I]),
+    "glass_gn_exact_words": (c_int64, [_I]),
+    "glass_graphnorm_stats_exact_f32": (c_int, [_P, _I, _I, _I, _P, _P]),
     "glass_graphnorm_bwd_from_stats_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P,
                                                    c_int, c_int, c_float, _P, c_uint64, _P, _P]),
     "glass_embed_norm_fwd_f32": (c_int, [_P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _I, c_float, _P, c_uint64, _P,
@@ -99,10 +117,10 @@ SIGNATURES = {
     "glass_comb_eff_supported": (c_int, [_I]),
     "glass_comb_eff_blocks": (c_int64, [_I, _I, _I]),
     "glass_comb_eff_ws_bytes": (c_int64, [_I, _I, _I]),
-    "glass_comb_eff_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, _P, _I, _I, _I, _P, _P, c_int, c_float, _P,
+    "glass_comb_eff_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, _P, _I, _I, _I, _P, c_int, _P, _P, c_int, c_float, _P,
                                        c_uint64, _P, _I, _P, _P, _I, _P]),
     "glass_comb_eff_bwd_f32": (c_int, [_P, _I, _P, c_double, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, c_int, c_float, _P,
-                                       c_uint64, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
+                                       c_uint64, c_int, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
     "glass_adam_step_f32": (c_int, [_P, _P, _P, _P, _I, _P, c_double, c_double, c_double, c_double, _P, _P]),
 }
 

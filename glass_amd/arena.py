@@ -159,7 +159,7 @@ class ParamArena(FlatGradBucket):
                 mod._glass_arena = self  # EmbZGConv.forward refreshes the images once per training forward
         self.refresh_transposes()
 
-    def refresh_transposes(self, rng_state=None, table=None):
+    def refresh_transposes(self, rng_state=None, table=None, zero=None):
         """Re-pack every stacked weight into the operand images of the fused dense kernels (forward: W,
         data gradient: W^T): one launch for the whole model.  rng_state (the device-resident dropout counter,
         ops.rng_state): advanced by the same launch — the two once-per-step prologue jobs share it."""
@@ -167,7 +167,7 @@ class ParamArena(FlatGradBucket):
         from . import _lib, ops
         for i, p in enumerate(self._packs):  # the pairs' CURRENT z_ratio (the kernels receive the live value as well)
             zr[i] = float(getattr(p[5], "z_ratio", 0.0))
-        if k == 0 and rng_state is not None and table is None:
+        if k == 0 and rng_state is not None and table is None and zero is None:
             ops.rng_advance(rng_state.device)
         # table = (W, V, class_rowptr, emb_gn module, saved[4H], table-or-None): emb_gn's statistics through the embedding
         # table ride in the (first) pack launch — glass_step_prologue_f32
@@ -175,13 +175,18 @@ class ParamArena(FlatGradBucket):
             n = min(16, k - i)
             rng = rng_state.data_ptr() if (rng_state is not None and i == 0) else 0
             st = torch.cuda.current_stream().cuda_stream
-            if table is not None and i == 0:
-                W, V, rowptr, gn, saved, tab = table
+            if (table is not None or zero is not None) and i == 0:
+                # zero = an int64 tensor the same launch zero-fills (the step's exact GraphNorm accumulators)
+                zargs = (0, 0) if zero is None else (zero.data_ptr(), zero.numel())
+                if table is not None:
+                    W, V, rowptr, gn, saved, tab = table
+                    targs = (W.data_ptr(), V, rowptr.data_ptr(), gn.weight.data_ptr(), gn.bias.data_ptr(), gn.mean_scale.data_ptr(),
+                             float(gn.eps), saved.data_ptr(), 0 if tab is None else tab.data_ptr(), W.shape[1])
+                else:
+                    targs = (0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0)
                 rc = _lib.load().glass_step_prologue_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
-                                                         kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, n, rng,
-                                                         W.data_ptr(), V, rowptr.data_ptr(), gn.weight.data_ptr(),
-                                                         gn.bias.data_ptr(), gn.mean_scale.data_ptr(), float(gn.eps),
-                                                         saved.data_ptr(), 0 if tab is None else tab.data_ptr(), W.shape[1], st)
+                                                         kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, max(n, 0), rng,
+                                                         *targs, *zargs, st)
                 _lib.check(rc, "glass_step_prologue_f32")
             elif n > 0:
                 rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,

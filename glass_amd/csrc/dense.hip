@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
                                                                const uint8_t* __restrict__ mask, float zr, float omz,
                                                                int act, float* __restrict__ T, int64_t ldt,
                                                                float* __restrict__ out, int64_t ldo, int64_t N,
-                                                               double* __restrict__ stats, GnPrologue pro,
+                                                               double* __restrict__ stats, int stats_exact, GnPrologue pro,
                                                                const int64_t* __restrict__ xa_index, int xa_rows) {
     constexpr int KT = COMB ? 2 * H : H, KQ = KT / 4, NT = 2 * H;
     constexpr int THREADS = kWave * RW * CS;  // RW row waves (16 rows each) x CS column groups
@@ -246,6 +246,11 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
     const bool pro_lane = pro.saved != nullptr && row_ok && (!COMB || q < 2);  // lanes whose chunk belongs to xa
     GnPrologue pro_w = pro;
     if (cg != 0) pro_w.side = nullptr;  // the wave groups of a row tile compute the same operand; one writes it
+    // scale | shift of the prologue's GraphNorm in LDS: copied from `saved`, or derived here from the exact accumulators its
+    // producers added to (gn_acc.h: no finalize launch between them and this kernel)
+    __shared__ double gn_sums_s[2 * H];
+    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
+    if (pro.saved) gn_fwd_coef_block(pro.src, pro.saved, H, N, gn_sums_s, gn_coef_s, nullptr);
     staged_product<NT, KT, NLOC, 4 * NGL, THREADS, FwdRaw>(
         acc, W, lds_w, lane, 4 * NGL * cg, 4 * (NG + NGL * cg),
         [&](int kc, FwdRaw& raw) __attribute__((always_inline)) {
@@ -254,8 +259,8 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
                 const int col0 = q * KQ + kc * kKC;
 #pragma unroll
                 for (int v = 0; v < kKC / 4; ++v) {
-                    raw.sc[v] = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + col0 + 4 * v);
-                    raw.sh[v] = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + col0 + 4 * v);
+                    raw.sc[v] = *reinterpret_cast<const float4*>(gn_coef_s + col0 + 4 * v);
+                    raw.sh[v] = *reinterpret_cast<const float4*>(gn_coef_s + H + col0 + 4 * v);
                 }
             }
         },
@@ -339,8 +344,13 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
             s += red[(ww * H + c) * 2];
             q2 += red[(ww * H + c) * 2 + 1];
         }
-        stats[((size_t)blockIdx.x * 2) * H + c] = s;
-        stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        if (stats_exact) {  // exact accumulators (gn_acc.h): the consumer folds them, no finalize launch
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 1, c, H, q2, kAccScaleFwd);
+        } else {
+            stats[((size_t)blockIdx.x * 2) * H + c] = s;
+            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        }
     }
 }
 
@@ -508,8 +518,13 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
             a += red[(ww * H + c) * 2];
             b2 += red[(ww * H + c) * 2 + 1];
         }
-        gs.partial[((size_t)block * 2) * H + c] = a;
-        gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
+        if (gs.exact) {  // exact accumulators (gn_acc.h): no finalize launch behind this kernel
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 0, c, H, a, kAccScaleBwd);
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 1, c, H, b2, kAccScaleBwd);
+        } else {
+            gs.partial[((size_t)block * 2) * H + c] = a;
+            gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
+        }
     }
 }
 
@@ -604,7 +619,8 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
                                                                  const float* __restrict__ bias,
                                                                  const uint8_t* __restrict__ mask, float zr, float omz,
                                                                  float* __restrict__ out, int64_t ldo, int64_t N,
-                                                                 double* __restrict__ stats, GnPrologue pro, LabRows lab) {
+                                                                 double* __restrict__ stats, int stats_exact, GnPrologue pro,
+                                                                 LabRows lab) {
     constexpr int KT = 2 * H, KQ = KT / 4, NT = H, NLOC = NT / 16;
     constexpr int THREADS = kWave * RW;
     static_assert(H == 64, "one 64-column group per wave");
@@ -612,7 +628,7 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
     const int i = lane & 15, q = lane >> 4;
     EffRows R;
     if (!eff_rows<RW>(R, blockIdx.x, mask, N, lab, w, i, q)) {  // extra workgroup beyond the list: an empty partial
-        if (stats)
+        if (stats && !stats_exact)
             for (int c = threadIdx.x; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
         return;
     }
@@ -635,6 +651,9 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
     const bool pro_lane = pro.saved != nullptr && row_ok && q < 2;  // lanes whose chunk belongs to xa
     GnPrologue pro_w = pro;
     if (R.extra) pro_w.side = nullptr;  // the row's own tile wrote the normalised operand
+    __shared__ double gn_sums_s[2 * H];
+    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];  // scale | shift of the prologue's GraphNorm (see dual_fwd_kernel)
+    if (pro.saved) gn_fwd_coef_block(pro.src, pro.saved, H, N, gn_sums_s, gn_coef_s, nullptr);
     staged_product<NT, KT, NLOC, NLOC, THREADS, FwdRaw>(
         acc, W, lds_w, lane, 0, 0,
         [&](int kc, FwdRaw& raw) __attribute__((always_inline)) {
@@ -643,8 +662,8 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
                 const int col0 = q * KQ + kc * kKC;
 #pragma unroll
                 for (int v = 0; v < kKC / 4; ++v) {
-                    raw.sc[v] = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + col0 + 4 * v);
-                    raw.sh[v] = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + col0 + 4 * v);
+                    raw.sc[v] = *reinterpret_cast<const float4*>(gn_coef_s + col0 + 4 * v);
+                    raw.sh[v] = *reinterpret_cast<const float4*>(gn_coef_s + H + col0 + 4 * v);
                 }
             }
         },
@@ -691,8 +710,13 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
             s += red[(ww * H + c) * 2];
             q2 += red[(ww * H + c) * 2 + 1];
         }
-        stats[((size_t)blockIdx.x * 2) * H + c] = s;
-        stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        if (stats_exact) {  // exact accumulators (gn_acc.h): the consumer folds them, no finalize launch
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 1, c, H, q2, kAccScaleFwd);
+        } else {
+            stats[((size_t)blockIdx.x * 2) * H + c] = s;
+            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        }
     }
 }
 
@@ -728,7 +752,7 @@ __device__ __forceinline__ void comb_dgrad_eff_body(const float* __restrict__ ds
     const int i = lane & 15, q = lane >> 4;
     EffRows R;
     if (!eff_rows<RW>(R, block, mask, N, lab, w, i, q)) {  // extra workgroup beyond the list: an empty partial
-        if (gs.partial)
+        if (gs.partial && !gs.exact)
             for (int c = threadIdx.x; c < 2 * H; c += THREADS) gs.partial[(size_t)block * 2 * H + c] = 0.0;
         return;
     }
@@ -810,8 +834,13 @@ __device__ __forceinline__ void comb_dgrad_eff_body(const float* __restrict__ ds
             a += red[(ww * H + c) * 2];
             b2 += red[(ww * H + c) * 2 + 1];
         }
-        gs.partial[((size_t)block * 2) * H + c] = a;
-        gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
+        if (gs.exact) {  // exact accumulators (gn_acc.h): no finalize launch behind this kernel
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 0, c, H, a, kAccScaleBwd);
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 1, c, H, b2, kAccScaleBwd);
+        } else {
+            gs.partial[((size_t)block * 2) * H + c] = a;
+            gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
+        }
     }
 }
 
@@ -877,8 +906,19 @@ struct TableJob {
     float *saved, *table;
 };
 
-__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state, TableJob tab, int n_jobs) {
+// ... and so does the zero-fill of the step's exact GraphNorm accumulators (gn_acc.h), spread over every workgroup
+struct ZeroJob {
+    long long* p;  // nullptr: none
+    int64_t n;     // int64 words
+};
+
+__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state, TableJob tab, int n_jobs,
+                                                            ZeroJob zero) {
     if (rng_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rng_state[1] += 1;  // see glass_rng_advance
+    if (zero.p) {
+        const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * kBlock;
+        for (int64_t k = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x; k < zero.n; k += nthreads) zero.p[k] = 0;
+    }
     if ((int)blockIdx.y >= n_jobs) {
         __shared__ double tab_lds[kBlock * 2];
         __shared__ float tab_coef[2 * kTabCols];
@@ -995,6 +1035,18 @@ static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at 
 // 0.82 -> 0.70 ms).  The CS > 1 form of the kernels below (wave groups splitting the output columns) is no longer
 // instantiated.
 // (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
+// exact cross-workgroup GraphNorm sums (gn_acc.h) instead of per-workgroup partials + a finalize launch: the hidden-64 kernels
+extern "C" int glass_gn_exact_supported(int64_t H) { return wave16_shape_ok(H) ? 1 : 0; }
+// gn_src (the C-ABI struct) -> the kernels' form; saved = the [4C] buffer workgroup 0 writes.  NULL gn_src: final statistics.
+static bool make_exact_src(const glass_gn_src* g, const float* saved, GnExactSrc& out) {
+    out = GnExactSrc{nullptr, 1, nullptr, nullptr, nullptr, 0.f, nullptr};
+    if (!g) return true;
+    if (!g->acc || g->n_src != 1 || !g->gamma || !g->beta || !g->alpha || !saved) return false;
+    out = GnExactSrc{reinterpret_cast<const long long*>(g->acc), 1, g->gamma, g->beta, g->alpha, g->eps, const_cast<float*>(saved)};
+    return true;
+}
+extern "C" int64_t glass_gn_exact_words(int64_t C) { return gn_acc_words(C); }  // int64 words of one accumulator block
+
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
 // glass_dual_linear_fwd_f32 with xa_index (the trans pair of layer 0 gathers its operand rows from the embedding table)
 extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return (wave16_shape_ok(H) || narrow_shape_ok(H)) ? 1 : 0; }
@@ -1024,10 +1076,14 @@ extern "C" int64_t glass_dual_linear_stat_rows(int64_t H) { return narrow_shape_
 extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* W,
                                          const float* bias, const uint8_t* mask, double z_ratio, int act, float* T,
                                          int64_t ldt, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
-                                         double* stats, const float* gn_saved, int gn_act, float p_drop,
-                                         const uint64_t* rng_state, uint64_t call_id, float* xa_out, int64_t ldxo,
-                                         const int64_t* xa_index, int64_t xa_rows, void* stream) {
+                                         double* stats, int stats_exact, const float* gn_saved, const glass_gn_src* gn_src,
+                                         int gn_act, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
+                                         int64_t ldxo, const int64_t* xa_index, int64_t xa_rows, void* stream) {
     GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
+    GLASS_REQUIRE((!stats_exact || (stats && wave16_shape_ok(H))) && (!gn_src || (gn_saved && wave16_shape_ok(H))),
+                  "dual_linear_fwd: exact GraphNorm accumulators are served at hidden 64 only (glass_gn_exact_supported)");
+    GnExactSrc esrc;
+    GLASS_REQUIRE(make_exact_src(gn_src, gn_saved, esrc), "dual_linear_fwd: bad gn_src (one accumulator block, all pointers set)");
     GLASS_REQUIRE(!xa_index || (gn_saved && !xb && xa_rows > 0 && xa_rows < (1ll << 31)),
                   "dual_linear_fwd: a gathered operand needs the GraphNorm prologue (its side output is the gathered, "
                   "normalised [N,H] input) and is the trans pair's");
@@ -1046,7 +1102,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     if (narrow_shape_ok(H)) {  // thread-per-row kernels: any alignment, the weight as it is (no packed image)
         GLASS_REQUIRE(lda >= H && (!xb || ldb >= H) && ldo >= H && (!T || ldt >= 2 * H) && (!gn_saved || ldxo >= H),
                       "dual_linear_fwd: leading dimensions");
-        const GnPrologue npro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
+        const GnPrologue npro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
         return launch_narrow_fwd(xa, lda, xb, ldb, W, bias, mask, (float)z_ratio, (float)(1.0 - z_ratio), act, T, ldt, out, ldo,
                                  n_nodes, H, stats, npro, xa_index, xa_rows, (hipStream_t)stream);
     }
@@ -1060,7 +1116,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs > 1 pass and both fit)
     const size_t lds_comb = lds_bytes(2 * H, (int)(2 * H / 64)), lds_trans = lds_bytes(2 * H, (int)(H / 64));
-    const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
+    const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
     if (tiled_here(H))
         return launch_tiled_fwd(xa, lda, xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, H, stats, pro, st);
 #define GLASS_FWD(HH, CS, RW)                                                                                      \
@@ -1069,11 +1125,12 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
         allow_lds(dual_fwd_kernel<HH, false, CS, RW>, lds_trans);                                                  \
         if (comb)                                                                                                  \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, true, CS, RW>), grid, dim3(kWave * RW * CS), lds_comb, st, xa, lda,  \
-                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro, nullptr, 0); \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, \
+                               nullptr, 0);                                                                        \
         else                                                                                                       \
             hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS, RW>), grid, dim3(kWave * RW * CS), lds_trans, st, xa, lda, \
-                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, pro, xa_index,  \
-                               (int)xa_rows);                                                                      \
+                               xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, \
+                               xa_index, (int)xa_rows);                                                            \
     }
     GLASS_FWD(64, 1, 4)
 #undef GLASS_FWD
@@ -1091,8 +1148,8 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
                         int act, const float* WT, int64_t n_out, const float* addend, int64_t ldadd, float p_drop,
                         const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
                         double* gn_partial, const float* gn_x, int64_t gn_ldx, const float* gn_saved,
-                        const float* gn_alpha, int gn_act, float gn_p_drop, uint64_t gn_call_id, const BwdWgrad* wg,
-                        void* stream) {
+                        const float* gn_alpha, int gn_act, float gn_p_drop, uint64_t gn_call_id, int gn_exact,
+                        const BwdWgrad* wg, void* stream) {
     GLASS_REQUIRE(dsrc && mask && WT && out && n_nodes > 0, "dual_linear_dgrad: null pointer");
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || (rng_state && n_out == H)),
                   "dual_linear_dgrad: bad dropout args (the masked output must be the [N,H] layer input)");
@@ -1101,10 +1158,11 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         return GLASS_E_UNSUPPORTED;
     }
     if (narrow_shape_ok(H)) {  // thread-per-row kernels: any alignment; WT = the row-major weight itself ([2H][n_out])
+        GLASS_REQUIRE(!gn_exact, "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only");
         GLASS_REQUIRE(ldd >= H && ldo >= n_out && (act == GLASS_ACT_NONE || (T && ldt >= 2 * H)) && (!addend || ldadd >= n_out) &&
                           (!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && (gn_p_drop == 0.f || rng_state))),
                       "dual_linear_dgrad: bad arguments");
-        const GnBwdStats ngs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
+        const GnBwdStats ngs{gn_partial, 0, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                              make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
         const int rc = launch_narrow_dgrad(dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio,
                                            (float)(1.0 - z_ratio), act, WT, n_out, addend, ldadd, make_drop(p_drop, call_id, n_out),
@@ -1117,6 +1175,8 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
                       aligned16(out) && (act == GLASS_ACT_NONE || (T && ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))) &&
                       (!addend || (ldadd >= n_out && ldadd % 4 == 0 && aligned16(addend))),
                   "dual_linear_dgrad: operands must be 16-B aligned with ld %% 4 == 0");
+    GLASS_REQUIRE(!gn_exact || (gn_partial && wave16_shape_ok(H) && aligned16(gn_partial)),
+                  "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only (glass_gn_exact_supported)");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(n_nodes, glass_dual_linear_stat_rows(H)));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
@@ -1127,7 +1187,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
                                   aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
                                   (gn_p_drop == 0.f || rng_state) && (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
                   "dual_linear_dgrad: bad GraphNorm statistics arguments");
-    const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
+    const GnBwdStats gs{gn_partial, gn_exact, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                         make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
     // the weight-gradient partials of the same pair, as a second launch (large graphs / wide layers) ...
     auto wgrad_after = [&]() -> int {
@@ -1187,10 +1247,10 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                                            const uint64_t* rng_state, uint64_t call_id, float* out, int64_t ldo,
                                            int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
                                            int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act,
-                                           float gn_p_drop, uint64_t gn_call_id, void* stream) {
+                                           float gn_p_drop, uint64_t gn_call_id, int gn_exact, void* stream) {
     return dgrad_launch(dsrc, ldd, T, ldt, mask, z_ratio, act, WT, n_out, addend, ldadd, p_drop, rng_state, call_id, out, ldo,
-                        n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, nullptr,
-                        stream);
+                        n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, gn_exact,
+                        nullptr, stream);
 }
 
 extern "C" int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
@@ -1198,12 +1258,13 @@ extern "C" int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const f
                                          int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id,
                                          float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial,
                                          const float* gn_x, int64_t gn_ldx, const float* gn_saved, const float* gn_alpha,
-                                         int gn_act, float gn_p_drop, uint64_t gn_call_id, const float* X, int64_t ldx,
-                                         const float* X2, int64_t ldx2, void* ws, void* stream) {
+                                         int gn_act, float gn_p_drop, uint64_t gn_call_id, int gn_exact, const float* X,
+                                         int64_t ldx, const float* X2, int64_t ldx2, void* ws, void* stream) {
     GLASS_REQUIRE(X && ws, "dual_linear_bwd: null pointer");
     const BwdWgrad wg{X, ldx, X2, ldx2, ws};
     return dgrad_launch(dsrc, ldd, T, ldt, mask, z_ratio, act, WT, n_out, addend, ldadd, p_drop, rng_state, call_id, out, ldo,
-                        n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, &wg, stream);
+                        n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, gn_exact, &wg,
+                        stream);
 }
 
 // ---- comb pair in effective-weight form (hidden 64; see comb_fwd_eff_kernel) -----------------------------------------
@@ -1217,10 +1278,10 @@ extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab
 
 extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,
                                       const float* bias, const uint8_t* mask, double z_ratio, float* out, int64_t ldo,
-                                      int64_t n_nodes, int64_t H, double* stats, const float* gn_saved, int gn_act,
-                                      float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
-                                      int64_t ldxo, const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap,
-                                      void* stream) {
+                                      int64_t n_nodes, int64_t H, double* stats, int stats_exact, const float* gn_saved,
+                                      const glass_gn_src* gn_src, int gn_act, float p_drop, const uint64_t* rng_state,
+                                      uint64_t call_id, float* xa_out, int64_t ldxo, const int32_t* lab_rows,
+                                      const int32_t* lab_count, int64_t lab_cap, void* stream) {
     GLASS_REQUIRE(xa && xb && Wimg_eff && bias && mask && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
                   "comb_eff_fwd: null pointer");
     if (H != 64) {
@@ -1237,11 +1298,14 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     const int n_main = (int)ceil_div(n_nodes, 64);
     const dim3 grid((unsigned)(n_main + ceil_div(lab_cap, 64)));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
-    const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo};
+    GnExactSrc esrc;
+    GLASS_REQUIRE(make_exact_src(gn_src, gn_saved, esrc) && (!stats_exact || stats),
+                  "comb_eff_fwd: bad gn_src (one accumulator block, all pointers set)");
+    const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
     const LabRows lab{lab_rows, lab_count, n_main};
     const size_t lds = lds_bytes(H, 2);  // two K passes of the [H][2H] effective weight
     hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
-                       bias, mask, zr, omz, out, ldo, n_nodes, stats, pro, lab);
+                       bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
     return launch_status("glass_comb_eff_fwd_f32");
 }
 
@@ -1249,9 +1313,9 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
                                       const float* WTimg_eff, float* out, int64_t ldo, int64_t n_nodes, int64_t H,
                                       double* gn_partial, const float* gn_x, int64_t gn_ldx, const float* gn_saved,
                                       const float* gn_alpha, int gn_act, float gn_p_drop, const uint64_t* rng_state,
-                                      uint64_t gn_call_id, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
-                                      void* ws, const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap,
-                                      void* stream) {
+                                      uint64_t gn_call_id, int gn_exact, const float* X, int64_t ldx, const float* X2,
+                                      int64_t ldx2, void* ws, const int32_t* lab_rows, const int32_t* lab_count,
+                                      int64_t lab_cap, void* stream) {
     GLASS_REQUIRE(dsrc && mask && WTimg_eff && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
                   "comb_eff_bwd: null pointer");
     if (H != 64) {
@@ -1269,7 +1333,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
     const int n_main = (int)ceil_div(n_nodes, 64);
     const unsigned n_dg = (unsigned)(n_main + ceil_div(lab_cap, 64));
     const float zr = (float)z_ratio;
-    const GnBwdStats gs{gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
+    const GnBwdStats gs{gn_partial, gn_exact, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
     const DgradEffArgs dargs{dsrc, ldd, mask, WTimg_eff, rng_state, out, ldo, n_nodes, gs, LabRows{lab_rows, lab_count, n_main}};
     const size_t lds_dg = lds_bytes(2 * H, 1);  // one K pass of the [2H][H] effective weight
     if (!X) {  // data gradient only
@@ -1307,7 +1371,7 @@ extern "C" int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t l
 
 static int pack_launch(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
                        const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
-                       const TableJob& tab, void* stream, const char* what) {
+                       const TableJob& tab, void* stream, const char* what, ZeroJob zero = ZeroJob{nullptr, 0}) {
     GLASS_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs && (n_jobs == 0 || (src && dst && NT && KT && transposed)),
                   "%s: bad arguments (at most %d matrices per call)", what, kMaxPackJobs);
     PackBatch b;
@@ -1329,8 +1393,9 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
     }
     unsigned gx = 32;
     if (tab.W && (unsigned)ceil_div(tab.H, kTabCols) > gx) gx = (unsigned)ceil_div(tab.H, kTabCols);
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(gx, (unsigned)n_jobs + (tab.W ? 1u : 0u)), dim3(kBlock), 0, (hipStream_t)stream, b,
-                       rng_state, tab, (int)n_jobs);
+    unsigned gy = (unsigned)n_jobs + (tab.W ? 1u : 0u);
+    if (gy == 0) gy = 1;  // (only the zero-fill / the dropout stream to serve)
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(gx, gy), dim3(kBlock), 0, (hipStream_t)stream, b, rng_state, tab, (int)n_jobs, zero);
     return launch_status(what);
 }
 
@@ -1349,9 +1414,12 @@ extern "C" int glass_step_prologue_f32(const float* const* src, float* const* ds
                                        const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
                                        const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma,
                                        const float* beta, const float* alpha, float eps, float* saved, float* table,
-                                       int64_t H, void* stream) {
-    GLASS_REQUIRE(W && class_rowptr && gamma && beta && alpha && saved && H > 0 && V > 0 && V <= GLASS_EMBED_NORM_MAX_ROWS,
+                                       int64_t H, int64_t* zero_words, int64_t n_zero_words, void* stream) {
+    GLASS_REQUIRE(!W || (class_rowptr && gamma && beta && alpha && saved && H > 0 && V > 0 && V <= GLASS_EMBED_NORM_MAX_ROWS),
                   "step_prologue: bad embedding-table arguments (at most %d rows)", GLASS_EMBED_NORM_MAX_ROWS);
-    const TableJob tab{W, (int)V, (int)H, class_rowptr, gamma, beta, alpha, eps, saved, table};
-    return pack_launch(src, dst, NT, KT, transposed, z_ratio, n_jobs, rng_state, tab, stream, "glass_step_prologue_f32");
+    GLASS_REQUIRE(n_zero_words >= 0 && (n_zero_words == 0 || zero_words), "step_prologue: bad zero-fill arguments");
+    TableJob tab{};
+    if (W) tab = TableJob{W, (int)V, (int)H, class_rowptr, gamma, beta, alpha, eps, saved, table};
+    return pack_launch(src, dst, NT, KT, transposed, z_ratio, n_jobs, rng_state, tab, stream, "glass_step_prologue_f32",
+                       ZeroJob{n_zero_words > 0 ? (long long*)zero_words : nullptr, n_zero_words});
 }

@@ -2,6 +2,7 @@
 // output columns: small graphs, hidden 64 / 128) and dense_tiled.hip (LDS-tiled 32x32x2 MFMA GEMM: hidden 256 / 512).
 #pragma once
 #include "common.h"
+#include "gn_acc.h"
 
 namespace glass {
 
@@ -16,6 +17,7 @@ struct GnPrologue {
     const uint64_t* rng_state;
     float* side;
     int64_t lds;
+    GnExactSrc src;      // src.acc != nullptr: the statistics are still in exact accumulators (gn_acc.h), `saved` gets written
 };
 
 // Optional epilogue of the data-gradient kernels: their first H output columns are the gradient dy of a GraphNorm
@@ -24,7 +26,8 @@ struct GnPrologue {
 // from the tile in registers plus one read of the GraphNorm input x, instead of by a statistics launch re-reading
 // dy and x.  partial[row tile][2][H] doubles, consumed by glass_graphnorm_bwd_from_stats_f32.
 struct GnBwdStats {
-    double* partial;  // nullptr: off
+    double* partial;  // nullptr: off.  exact != 0: not per-workgroup partials but the exact accumulators of gn_acc.h (int64)
+    int exact;
     const float* x; int64_t ldx;
     const float *saved, *alpha;
     int act;

@@ -10,6 +10,7 @@
 // across workgroups by a second tiny kernel in fixed order -> bitwise repeatable.
 #include "common.h"
 #include "gn_math.h"
+#include "gn_acc.h"
 
 namespace glass {
 
@@ -75,7 +76,7 @@ __device__ __forceinline__ void load_cols(float (&dst)[VW], const float* src, in
 // and let row slot 0 write them to partial[blk][which][c].
 template <int VW>
 __device__ __forceinline__ void block_reduce_store(double (&s0)[VW], double (&s1)[VW], double* lds, int tc, int tr,
-                                                   int TC, int rpb, double* partial, int c0, int C) {
+                                                   int TC, int rpb, double* partial, int c0, int C, bool exact = false) {
     double* mine = lds + (size_t)threadIdx.x * 2 * VW;
 #pragma unroll
     for (int k = 0; k < VW; ++k) {
@@ -92,6 +93,16 @@ __device__ __forceinline__ void block_reduce_store(double (&s0)[VW], double (&s1
                 s1[k] += o[VW + k];
             }
         }
+        if (exact) {  // `partial` = exact accumulators (gn_acc.h), forward scale
+            long long* a = reinterpret_cast<long long*>(partial);
+#pragma unroll
+            for (int k = 0; k < VW; ++k)
+                if (c0 + k < C) {
+                    gn_acc_add(a, blockIdx.x % kAccRep, 0, c0 + k, C, s0[k], kAccScaleFwd);
+                    gn_acc_add(a, blockIdx.x % kAccRep, 1, c0 + k, C, s1[k], kAccScaleFwd);
+                }
+            return;
+        }
         double* p = partial + (size_t)blockIdx.x * 2 * C;
 #pragma unroll
         for (int k = 0; k < VW; ++k)
@@ -105,7 +116,7 @@ __device__ __forceinline__ void block_reduce_store(double (&s0)[VW], double (&s1
 // ---- forward statistics: per-column sum(x), sum(x^2) ------------------------------------------
 template <int VW>
 __global__ __launch_bounds__(kBlock) void gn_stats_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int C,
-                                                          int tc_log2, double* __restrict__ partial) {
+                                                          int tc_log2, double* __restrict__ partial, int exact) {
     __shared__ double lds[kBlock * 2 * VW];
     const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
     const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
@@ -133,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void gn_stats_kernel(const float* __restric
                 q[k] += d * d;
             }
     }
-    block_reduce_store<VW>(s, q, lds, tc, tr, TC, rpb, partial, c0, C);
+    block_reduce_store<VW>(s, q, lds, tc, tr, TC, rpb, partial, c0, C, exact != 0);
 }
 
 // ---- finalize: sum the workgroup partials in fixed order; derive mean / rstd / scale / shift ----
@@ -338,6 +349,83 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __res
     }
 }
 
+// Backward apply with the finalize folded in: the two column sums come from the exact accumulators the data-gradient
+// epilogues added to (gn_acc.h); every workgroup folds the replicas and derives the coefficients of ALL columns in its
+// prologue (C <= 128), workgroup 0 also writes the parameter gradients — no finalize launch.
+template <int VW>
+__global__ __launch_bounds__(kBlock) void gn_bwd_apply_acc_kernel(const float* __restrict__ dy, int64_t lddy,
+                                                                  const float* __restrict__ x, int64_t ldx,
+                                                                  float* __restrict__ dx, int64_t lddx,
+                                                                  const float* __restrict__ addend, int64_t ldadd,
+                                                                  int64_t N, int C, int tc_log2,
+                                                                  const float* __restrict__ saved,
+                                                                  const long long* __restrict__ acc,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ alpha,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  float* __restrict__ dalpha, int accumulate, int act,
+                                                                  Drop drop, const uint64_t* __restrict__ rng_state) {
+    __shared__ double sums[kBlock];
+    __shared__ float coef_s[3 * (kBlock / 2)];
+    gn_acc_fold(acc, C, 1, sums, kAccScaleBwd);
+    if ((int)threadIdx.x < C) {
+        const int c = threadIdx.x;
+        float A, Bx, K, da;
+        gn_bwd_coeffs(sums[c], sums[C + c], (double)N, gamma[c], alpha[c], saved[c], saved[C + c], A, Bx, K, da);
+        coef_s[c] = A;
+        coef_s[C + c] = Bx;
+        coef_s[2 * C + c] = K;
+        if (blockIdx.x == 0) {
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
+            if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + da;
+        }
+    }
+    __syncthreads();
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = tc * VW;
+    if (c0 >= C) return;
+    float scale[VW], shift[VW], A[VW], Bx[VW], K[VW];
+    load_cols<VW>(scale, saved + 2 * C, c0, C);
+    load_cols<VW>(shift, saved + 3 * C, c0, C);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+        A[k] = coef_s[c0 + k];
+        Bx[k] = coef_s[C + c0 + k];
+        K[k] = coef_s[2 * C + c0 + k];
+    }
+    if (drop.p > 0.f) {
+        drop.seed = rng_state[0];
+        drop.step = rng_state[1];
+    }
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * kUnroll) {
+        F<VW> g[kUnroll], xv[kUnroll], ad[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr < N) {
+                g[u].load(dy + rr * lddy + c0);
+                xv[u].load(x + rr * ldx + c0);
+                if (addend) ad[u].load(addend + rr * ldadd + c0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (rr >= N) continue;
+            bwd_g<VW>(g[u].a, xv[u].a, scale, shift, act, drop, rr, c0);
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                g[u].a[k] = fmaf(A[k], g[u].a[k], fmaf(Bx[k], xv[u].a[k], K[k]));
+                if (addend) g[u].a[k] += ad[u].a[k];
+            }
+            g[u].store(dx + rr * lddx + c0);
+        }
+    }
+}
+
 __global__ void rng_advance_kernel(uint64_t* st) { st[1] += 1; }
 
 // The keep-scales (0 or 1 / (1 - p)) a dropout with this call id draws under the CURRENT (seed, step) words for an
@@ -386,9 +474,9 @@ extern "C" int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, in
     const Drop drop = make_drop(p_drop, call_id, C);
     dim3 gs(nblk, t.ctiles), ga(apply_blocks(n_rows, t), t.ctiles);
     if (vec) {
-        hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+        hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial, 0);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+        hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial, 0);
     }
     hipLaunchKernelGGL(gn_finalize_src_kernel, dim3((unsigned)ceil_div(C, kFinCols)), dim3(kBlock), 0, st,
                        StatSrc{{partial}}, nblk, (int)C, (int)C, n_rows, gamma, beta, alpha, eps, saved);
@@ -414,13 +502,32 @@ extern "C" int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_
     double* partial = (double*)ws;
     dim3 gs(nblk, t.ctiles);
     if (vec) {
-        hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+        hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial, 0);
     } else {
-        hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial);
+        hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, st, x, ldx, n_rows, (int)C, t.tc_log2, partial, 0);
     }
     hipLaunchKernelGGL(gn_finalize_src_kernel, dim3((unsigned)ceil_div(C, kFinCols)), dim3(kBlock), 0, st,
                        StatSrc{{partial}}, nblk, (int)C, (int)C, n_rows, gamma, beta, alpha, eps, saved);
     return launch_status("glass_graphnorm_stats_f32");
+}
+
+// The statistics pass alone, into exact accumulators (gn_acc.h; zeroed by glass_step_prologue_f32): the consumer kernel
+// derives the coefficients (glass_gn_src), no finalize launch.
+extern "C" int glass_graphnorm_stats_exact_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, int64_t* acc,
+                                               void* stream) {
+    GLASS_REQUIRE(x && acc && n_rows > 0 && C > 0 && ldx >= C, "graphnorm_stats_exact: bad arguments");
+    const bool vec = C % 4 == 0 && ldx % 4 == 0 && aligned16(x);
+    const Tiling t = make_tiling(C, vec);
+    // (fewer, longer workgroups to thin out the adds per replica were slower: 8.3 / 12.7 us with half / a quarter of them)
+    dim3 gs(stat_blocks(n_rows, t), t.ctiles);
+    if (vec) {
+        hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, (hipStream_t)stream, x, ldx, n_rows, (int)C, t.tc_log2,
+                           reinterpret_cast<double*>(acc), 1);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, (hipStream_t)stream, x, ldx, n_rows, (int)C, t.tc_log2,
+                           reinterpret_cast<double*>(acc), 1);
+    }
+    return launch_status("glass_graphnorm_stats_exact_f32");
 }
 
 extern "C" int glass_graphnorm_finalize_f32(const double* const* partials, int64_t n_src, int64_t nblk, int64_t C_each,
@@ -505,9 +612,23 @@ extern "C" int glass_graphnorm_bwd_from_stats_f32(const float* dy, int64_t lddy,
                                                   float* dalpha, int accumulate, int act, float p_drop,
                                                   const uint64_t* rng_state, uint64_t call_id, void* ws, void* stream) {
     GLASS_REQUIRE(dy && x && dx && gamma && alpha && saved && partial && ws, "graphnorm_bwd_from_stats: null pointer");
-    GLASS_REQUIRE(n_rows > 0 && C > 0 && nblk > 0 && nblk < (1ll << 31) && lddy >= C && ldx >= C && lddx >= C &&
+    GLASS_REQUIRE(n_rows > 0 && C > 0 && nblk != 0 && nblk < (1ll << 31) && lddy >= C && ldx >= C && lddx >= C &&
                       (!addend || ldadd >= C),
                   "graphnorm_bwd_from_stats: bad sizes");
+    if (nblk < 0) {
+        // `partial` = the exact accumulators of gn_acc.h (what the data-gradient epilogues added to with gn_exact): finalize
+        // and apply as ONE launch
+        const bool vec4 = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && aligned16(dy) && aligned16(x) &&
+                          aligned16(dx) && (!addend || (ldadd % 4 == 0 && aligned16(addend)));
+        GLASS_REQUIRE(vec4 && (C == 16 || C == 32 || C == 64 || C == 128) && aligned16(partial),
+                      "graphnorm_bwd_from_stats: the exact form serves C = 16 .. 128 (powers of two), 16-B aligned operands");
+        GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd_from_stats: bad dropout args");
+        const Tiling t4 = make_tiling(C, true);
+        hipLaunchKernelGGL(gn_bwd_apply_acc_kernel<4>, dim3(apply_blocks(n_rows, t4)), dim3(kBlock), 0, (hipStream_t)stream, dy, lddy,
+                           x, ldx, dx, lddx, addend, ldadd, n_rows, (int)C, t4.tc_log2, saved, (const long long*)partial, gamma,
+                           alpha, dgamma, dbeta, dalpha, accumulate, act, make_drop(p_drop, call_id, C), rng_state);
+        return launch_status("glass_graphnorm_bwd_from_stats_f32 (exact)");
+    }
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd_from_stats: bad dropout args");
     hipStream_t st = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0 && aligned16(dy) && aligned16(x) &&

@@ -17,6 +17,7 @@
 //       share nodes, because the row already holds the dense part).
 #include "common.h"
 #include "gn_math.h"
+#include "gn_acc.h"
 
 namespace glass {
 
@@ -72,20 +73,28 @@ struct R1Args {
     ReadoutWs ws;
     int64_t n_nodes;
     int tc_log2;
+    GnExactSrc src;  // src.acc: the final GraphNorm's forward sums are still in exact accumulators (gn_acc.h)
 };
 
-// dynamic LDS (floats): pooled_s[C] | xh_s[C] | red[kBlock*8] | zs[kReadoutMaxK] | dl[kReadoutMaxK]
+// dynamic LDS (floats): sums[2C doubles] | coef_s[2C] | mu_rstd_s[2C] | pooled_s[C] | xh_s[C] | red[kBlock*8] |
+// zs[kReadoutMaxK] | dl[kReadoutMaxK]
 // VW = floats per lane and access: 4 (C % 4 == 0, 16-B aligned rows) or 1 (any C: the 17-wide layers of config/component.yml)
 template <int VW>
 __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
     extern __shared__ float sm[];
     const int C = a.C, K = a.K;
-    float* pooled_s = sm;
-    float* xh_s = sm + C;
-    float* red = sm + 2 * C;
+    double* sums = reinterpret_cast<double*>(sm);
+    float* coef_s = sm + 4 * C;
+    float* mu_rstd_s = sm + 6 * C;
+    float* pooled_s = sm + 8 * C;
+    float* xh_s = sm + 9 * C;
+    float* red = sm + 10 * C;
     float* zs = red + kBlock * 8;
     float* dl = zs + kReadoutMaxK;
     const int b = blockIdx.x, tid = threadIdx.x;
+    // the final GraphNorm's coefficients: copied from `saved`, or derived here from the accumulators the comb kernels' epilogues
+    // added to (workgroup 0 writes `saved` for the two launches behind this one)
+    gn_fwd_coef_block(a.src, a.saved, C, a.n_nodes, sums, coef_s, mu_rstd_s);
     const int64_t* prow = a.pos + (int64_t)b * a.Smax;
     const int cnt = valid_count(prow, a.Smax, a.n_nodes);
     const float sc = readout_pool_scale(a.mode, cnt);
@@ -99,10 +108,10 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
         float mu[VW], rstd[VW], scale[VW], shift[VW], al[VW];
 #pragma unroll
         for (int k = 0; k < VW; ++k) {
-            mu[k] = a.saved[c0 + k];
-            rstd[k] = a.saved[C + c0 + k];
-            scale[k] = a.saved[2 * C + c0 + k];
-            shift[k] = a.saved[3 * C + c0 + k];
+            mu[k] = mu_rstd_s[c0 + k];
+            rstd[k] = mu_rstd_s[C + c0 + k];
+            scale[k] = coef_s[c0 + k];
+            shift[k] = coef_s[C + c0 + k];
             al[k] = a.alpha[c0 + k];
         }
         for (int j = tr; j < a.Smax; j += rpb) {
@@ -500,7 +509,8 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
                                        const float* grad_loss, float* pooled, float* logits, float* loss, float* djk,
                                        int64_t lddj, float* dWh, float* dbh, int acc_head, float* dgamma, float* dbeta,
                                        float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
-                                       const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count, void* stream) {
+                                       const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
+                                       const glass_gn_src* gn_src, void* stream) {
     GLASS_REQUIRE(jk && gn_saved && gamma && alpha && pos && Wh && bh && target && grad_loss && pooled && logits && loss &&
                       djk && dWh && dbh && ws,
                   "readout_train: null pointer");
@@ -520,9 +530,17 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     const int tc = pow2_ceil_cap(vec ? C / 4 : C, kBlock);
     int tc_log2 = 0;
     while ((1 << tc_log2) < tc) ++tc_log2;
+    GnExactSrc esrc{nullptr, 1, nullptr, nullptr, nullptr, 0.f, nullptr};
+    if (gn_src) {
+        GLASS_REQUIRE(gn_src->acc && gn_src->gamma && gn_src->beta && gn_src->alpha && gn_src->n_src >= 1 &&
+                          C % gn_src->n_src == 0,
+                      "readout_train: bad gn_src (n_src accumulator blocks of C / n_src columns, all pointers set)");
+        esrc = GnExactSrc{reinterpret_cast<const long long*>(gn_src->acc), (int)gn_src->n_src, gn_src->gamma, gn_src->beta,
+                          gn_src->alpha, gn_src->eps, const_cast<float*>(gn_saved)};
+    }
     R1Args a1{jk, ldj, gn_saved, alpha, pos, (int)Smax, pool_mode, Wh, bh, target, loss_mode, (int)B, (int)C, (int)K,
-              grad_loss, pooled, logits, w, n_nodes, tc_log2};
-    const size_t lds1 = sizeof(float) * (size_t)(2 * C + kBlock * 8 + 2 * kReadoutMaxK);
+              grad_loss, pooled, logits, w, n_nodes, tc_log2, esrc};
+    const size_t lds1 = sizeof(float) * (size_t)(10 * C + kBlock * 8 + 2 * kReadoutMaxK);
     if (vec)
         hipLaunchKernelGGL(readout_subgraph_kernel<4>, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
     else

@@ -469,7 +469,7 @@ class DualLinearMixFn(torch.autograd.Function):
         rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), lda, 0 if xb is None else xb.data_ptr(),
                                                    0 if xb is None else ldb, Wimg.data_ptr(), b.data_ptr(),
                                                    mask.data_ptr(), float(z_ratio), act, 0 if T is None else T.data_ptr(),
-                                                   2 * H, out.data_ptr(), out.stride(0), n, H, 0, 0, 0, 0.0, 0, 0, 0, 0,
+                                                   2 * H, out.data_ptr(), out.stride(0), n, H, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0,
                                                    0, 0, _stream())
         _lib.check(rc, "glass_dual_linear_fwd_f32")
         ctx.save_for_backward(xa, xb, T, mask)
@@ -490,7 +490,7 @@ class DualLinearMixFn(torch.autograd.Function):
             din = torch.empty((n, n_out), dtype=torch.float32, device=dout.device)
             rc = lib.glass_dual_linear_dgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act,
                                                  stack[5].data_ptr(), n_out, 0, 0, 0.0, 0, 0, din.data_ptr(), n_out, n, H,
-                                                 0, 0, 0, 0, 0, 0, 0.0, 0, _stream())
+                                                 0, 0, 0, 0, 0, 0, 0.0, 0, 0, _stream())
             _lib.check(rc, "glass_dual_linear_dgrad_f32")
         I = n_out
         ws = _wgrad_workspace(dout.device, n, 2 * H, I)

@@ -36,6 +36,11 @@ def _check(rc, what):
     _lib.check(rc, what)
 
 
+USE_GN_EXACT = os.environ.get("GLASS_GN_EXACT", "1") != "0"  # A/B switch: exact GraphNorm accumulators instead of partials + finalize
+USE_GN_EXACT_FWD = os.environ.get("GLASS_GN_EXACT_FWD", "1") != "0"  # ... for the forward sums as well
+# above this many rows the partials + finalize form is kept: thousands of workgroups adding to the same few replicas would
+# queue at the memory-side atomic units, and a ~5 us finalize launch no longer shows against the kernels around it
+GN_EXACT_MAX_ROWS = 1 << 18
 USE_FUSED_TAIL = os.environ.get("GLASS_FUSED_TAIL", "1") != "0"  # A/B switch: K1 slot sums + table backward + Adam as one launch
 USE_GATHER_IN_TRANS = os.environ.get("GLASS_GATHER_IN_TRANS", "1") != "0"  # A/B switch: embedding lookup inside layer 0's trans kernel
 USE_COMB_EFF = os.environ.get("GLASS_COMB_EFF", "1") != "0"  # A/B switch: comb pair through effective per-label weights
@@ -73,6 +78,27 @@ def _comb_eff_ok(conv, labels, H):
             bool(_lib.load().glass_comb_eff_supported(H)))
 
 
+class _PendingStats:
+    """Forward sums of a GraphNorm still in exact accumulators (gn_acc.h): the kernel that applies it derives the
+    coefficients from `acc` (n_src consecutive blocks) and writes `saved` [4C] for the backward."""
+    def __init__(self, saved, acc, n_src, mod):
+        self.saved, self.src = saved, _lib.GnSrc.of(acc, n_src, mod)
+
+
+def _saved_args(saved):
+    """(saved pointer, glass_gn_src pointer) of a GraphNorm prologue: final statistics, or pending exact sums."""
+    if isinstance(saved, _PendingStats):
+        return saved.saved.data_ptr(), saved.src.ptr
+    return saved.data_ptr(), 0
+
+
+def _stats_args(stats):
+    """(pointer, stats_exact) of an epilogue statistics target: float64 partials, or int64 exact accumulators."""
+    if stats is None:
+        return 0, 0
+    return stats.data_ptr(), int(stats.dtype == torch.int64)
+
+
 def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
     n, H = xa.shape
     saved, gact, gp, gcall, xa_out = gn
@@ -80,7 +106,7 @@ def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
     rc = _lib.load().glass_comb_eff_fwd_f32(xa.data_ptr(), xa.stride(0), xb.data_ptr(), xb.stride(0),
                                             conv._stack_eff["comb"][0].data_ptr(), conv._stack["comb"][1].data_ptr(),
                                             mask.data_ptr(), float(conv.z_ratio), out.data_ptr(), out.stride(0), n, H,
-                                            stats.data_ptr(), saved.data_ptr(), gact, float(gp), grng, gcall,
+                                            *_stats_args(stats), *_saved_args(saved), gact, float(gp), grng, gcall,
                                             xa_out.data_ptr(), xa_out.stride(0), labels.rows.data_ptr(),
                                             labels.count.data_ptr(), labels.cap, _stream())
     _check(rc, "glass_comb_eff_fwd_f32")
@@ -96,7 +122,8 @@ def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels):
     rc = _lib.load().glass_comb_eff_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), mask.data_ptr(), float(conv.z_ratio),
                                             conv._stack_eff["comb"][1].data_ptr(), out.data_ptr(), out.stride(0), n, H,
                                             gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(),
-                                            galpha.data_ptr(), gact, float(gp), rng, gcall, xa.data_ptr(), xa.stride(0),
+                                            galpha.data_ptr(), gact, float(gp), rng, gcall, int(gpart.dtype == torch.int64),
+                                            xa.data_ptr(), xa.stride(0),
                                             xb.data_ptr(), xb.stride(0), ws.data_ptr(), labels.rows.data_ptr(),
                                             labels.count.data_ptr(), labels.cap, _stream())
     _check(rc, "glass_comb_eff_bwd_f32")
@@ -133,6 +160,14 @@ class _GN:
         _check(rc, "glass_graphnorm_stats_f32")
         return saved
 
+    def stats_exact(self, x, acc):
+        """The statistics pass alone, into exact accumulators: the consumer derives the coefficients (no finalize launch)."""
+        n, C = x.shape
+        saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
+        rc = _lib.load().glass_graphnorm_stats_exact_f32(x.data_ptr(), x.stride(0), n, C, acc.data_ptr(), _stream())
+        _check(rc, "glass_graphnorm_stats_exact_f32")
+        return _PendingStats(saved, acc, 1, self.mod)
+
     def finalize(self, stats, n_rows):
         """saved[4C] from statistics the producers' epilogues wrote (list of [nblk, 2, C_each] float64 buffers)."""
         m = self.mod
@@ -163,7 +198,7 @@ class _GN:
         rc = _lib.load().glass_graphnorm_bwd_from_stats_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0),
                                                             dx.data_ptr(), dx.stride(0), ap, lda, n, C,
                                                             m.weight.data_ptr(), m.mean_scale.data_ptr(), saved.data_ptr(),
-                                                            partial.data_ptr(), partial.shape[0],
+                                                            partial.data_ptr(), -1 if partial.dtype == torch.int64 else partial.shape[0],
                                                             m.weight.grad.data_ptr(), m.bias.grad.data_ptr(),
                                                             m.mean_scale.grad.data_ptr(), acc, act, float(p_drop), rng,
                                                             call_id, ws.data_ptr(), _stream())
@@ -193,16 +228,16 @@ def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None, gn=None, xa
     if gn is not None:
         saved, gact, gp, gcall, xa_out = gn
         grng = ops.rng_tensor(xa.device).data_ptr() if gp > 0 else 0
-        gargs = (saved.data_ptr(), gact, float(gp), grng, gcall, xa_out.data_ptr(), xa_out.stride(0))
+        gargs = (*_saved_args(saved), gact, float(gp), grng, gcall, xa_out.data_ptr(), xa_out.stride(0))
     else:
-        gargs = (0, 0, 0.0, 0, 0, 0, 0)
+        gargs = (0, 0, 0, 0.0, 0, 0, 0, 0)
     iargs = (0, 0) if xa_index is None else (xa_index.data_ptr(), xa.shape[0])
     rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                                0 if xb is None else xb.stride(0), stack[4].data_ptr(),
                                                stack[1].data_ptr(), mask.data_ptr(), float(z_ratio), act,
                                                0 if T is None else T.data_ptr(), 0 if T is None else T.stride(0),
-                                               out.data_ptr(), out.stride(0), n, H,
-                                               0 if stats is None else stats.data_ptr(), *gargs, *iargs, _stream())
+                                               out.data_ptr(), out.stride(0), n, H, *_stats_args(stats), *gargs, *iargs,
+                                               _stream())
     _check(rc, "glass_dual_linear_fwd_f32")
 
 
@@ -214,9 +249,10 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=Non
     p_drop, call_id = drop if drop is not None else (0.0, 0)
     if gn is not None:
         gpart, gx, gsaved, galpha, gact, gp, gcall = gn
-        gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall)
+        gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall,
+                 int(gpart.dtype == torch.int64))  # int64 buffer = the exact accumulators of gn_acc.h
     else:
-        gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0)
+        gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0, 0)
     rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
     rc = _lib.load().glass_dual_linear_dgrad_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
                                                  0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
@@ -241,9 +277,10 @@ def _dual_bwd(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, xa, xb, pe
     p_drop, call_id = drop if drop is not None else (0.0, 0)
     if gn is not None:
         gpart, gx, gsaved, galpha, gact, gp, gcall = gn
-        gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall)
+        gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall,
+                 int(gpart.dtype == torch.int64))
     else:
-        gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0)
+        gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0, 0)
     rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
     ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, I, slot=("stack", len(pending)))
     rc = _lib.load().glass_dual_linear_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
@@ -413,16 +450,30 @@ class StackProgram:
         # embedding table itself (xa_index) and normalises them with emb_gn's table statistics, which ride in the prologue
         # launch next to the weight packing — no table-apply kernel, no gather launch.
         first_gn = None
+        # exact cross-workgroup GraphNorm sums (gn_acc.h) for the backward column sums: one int64 block per GraphNorm whose
+        # backward sums come from a data-gradient epilogue (conv.gn of every layer, gns[l] between layers), zero-filled by the
+        # prologue launch — their finalize launches disappear
+        # ... and for the forward sums when the fused readout applies the final GraphNorm: [L] blocks for conv.gn's sums of a_l,
+        # then [L] for the sums of c_l (consecutive: the column blocks of the jumping-knowledge buffer)
+        acc_all = acc_bwd = acc_fwd = None
+        if USE_GN_EXACT and lib.glass_gn_exact_supported(H) and n <= GN_EXACT_MAX_ROWS:
+            n_bwd = 2 * L - 1 if keep else 0
+            n_fwd = 2 * L if (readout is not None and USE_GN_EXACT_FWD) else 0
+            if n_bwd + n_fwd:
+                acc_all = torch.empty((n_bwd + n_fwd, int(lib.glass_gn_exact_words(H))), dtype=torch.int64, device=dev)
+                acc_bwd = acc_all[:n_bwd] if n_bwd else None
+                acc_fwd = acc_all[n_bwd:] if n_fwd else None
+        st["gn_exact"] = acc_bwd
         if use_table and labels is not None and USE_GATHER_IN_TRANS and lib.glass_dual_linear_fwd_gather_supported(H):
             sel = emb._selection(x_flat)
             saved = torch.empty(4 * H, **f32)
             emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None,
-                                                table=(W, V, sel.op.rowptr, gn0, saved, None))
+                                                table=(W, V, sel.op.rowptr, gn0, saved, None), zero=acc_all)
             st["emb_table"], st["emb_saved"] = sel, saved
             first_gn = (saved, ACT_NONE, p, 1)
         else:
             # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
-            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None)
+            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None, zero=acc_all)
         st["rng_epoch"] = ops.rng_epoch(dev)  # (the prologue launch above advanced the dropout stream)
         st["rng_words"] = ops.rng_snapshot(dev) if (snapshot_rng and advance and keep) else None
         ops._rng_cur[ops._dev(dev)] = st["rng_words"]  # the rest of this forward (inside forward()'s rng_scope) reads the snapshot
@@ -471,26 +522,36 @@ class StackProgram:
             a = conv.adj.fwd.spmm(m)
             # conv.gn: statistics + finalize here, the apply (+dropout) rides in the comb kernel's operand load
             g = torch.empty((n, H), **f32)
-            gsaved = _GN(conv.gn).stats(a)
+            gsaved = _GN(conv.gn).stats(a) if acc_fwd is None else _GN(conv.gn).stats_exact(a, acc_fwd[l])
             last = l + 1 == L
             c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
             # the comb kernel's epilogue also leaves the column statistics of c for the GraphNorm(s) that read it
             if _comb_eff_ok(conv, labels, H):
-                cstat = torch.empty((int(lib.glass_comb_eff_blocks(n, H, labels.cap)), 2, H), dtype=torch.float64, device=dev)
+                cstat = acc_fwd[L + l] if acc_fwd is not None else \
+                    torch.empty((int(lib.glass_comb_eff_blocks(n, H, labels.cap)), 2, H), dtype=torch.float64, device=dev)
                 _comb_eff_fwd(a, h, conv, mask, c, cstat, (gsaved, ACT_NONE, pc, conv.call_base, g), labels)
             else:
-                cstat = torch.empty((-(-n // st["stat_rows"]), 2, H), dtype=torch.float64, device=dev)
+                cstat = acc_fwd[L + l] if acc_fwd is not None else \
+                    torch.empty((-(-n // st["stat_rows"]), 2, H), dtype=torch.float64, device=dev)
                 _dual_fwd(a, h, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, None, c, cstat,
                           gn=(gsaved, ACT_NONE, pc, conv.call_base, g))
             cstats.append(cstat)
-            rec = {"h": h, "T": T, "a": a, "g": g, "gsaved": gsaved, "c": c, "pc": pc}
+            rec = {"h": h, "T": T, "a": a, "g": g, "gsaved": getattr(gsaved, "saved", gsaved), "c": c, "pc": pc}
             if not last:
-                rec["nsaved"] = _GN(emb.gns[l]).finalize([cstat], n)
-                pending_gn, c_prev = (rec["nsaved"], ACT_ELU, p, conv.call_base + 1), c
+                if acc_fwd is not None:   # the next layer's trans kernel derives gns[l]'s coefficients from the sums of c_l
+                    nsaved = _PendingStats(torch.empty(4 * H, **f32), cstat, 1, emb.gns[l])
+                else:
+                    nsaved = _GN(emb.gns[l]).finalize([cstat], n)
+                rec["nsaved"] = getattr(nsaved, "saved", nsaved)
+                pending_gn, c_prev = (nsaved, ACT_ELU, p, conv.call_base + 1), c
             layers.append(rec if keep else None)
         st["jk"], st["layers"] = jk, layers
         gnf = _GN(emb.gns[-1])
-        st["final_saved"] = gnf.finalize(cstats if emb.jk else cstats[-1:], n)
+        if acc_fwd is not None:  # the readout's first kernel derives the final GraphNorm's coefficients
+            st["final_saved"] = _PendingStats(torch.empty(4 * C_out, **f32), acc_fwd[L:] if emb.jk else acc_fwd[2 * L - 1],
+                                              L if emb.jk else 1, emb.gns[-1])
+        else:
+            st["final_saved"] = gnf.finalize(cstats if emb.jk else cstats[-1:], n)
         if readout is not None:
             return self._readout(st, jk, *readout), st
         out = torch.empty((n, C_out), **f32)
@@ -506,7 +567,9 @@ class StackProgram:
         K = head.weight.shape[0]
         dev = jk.device
         f32 = dict(dtype=torch.float32, device=dev)
-        saved = st["final_saved"]
+        final = st["final_saved"]  # (kept alive across the call below: the glass_gn_src struct lives in it)
+        saved, src = _saved_args(final)
+        st["final_saved"] = getattr(final, "saved", final)
         ws = torch.empty(lib.glass_readout_ws_bytes(B, C, K) // 8 + 1, dtype=torch.float64, device=dev)
         pooled, logits = torch.empty((B, C), **f32), torch.empty((B, K), **f32)
         loss, djk = torch.empty((), **f32), torch.empty((n, C), **f32)
@@ -517,15 +580,14 @@ class StackProgram:
             labels = BatchLabels(n, pos.numel(), dev)
             labels.load(pos)
         largs = (0, 0, 0) if labels is None else (labels.mask.data_ptr(), labels.rows.data_ptr(), labels.count.data_ptr())
-        _check(lib.glass_readout_train_f32(jk.data_ptr(), jk.stride(0), saved.data_ptr(), gn.weight.data_ptr(),
+        _check(lib.glass_readout_train_f32(jk.data_ptr(), jk.stride(0), saved, gn.weight.data_ptr(),
                                            gn.mean_scale.data_ptr(), pos.data_ptr(), B, Smax, _lib.POOL_MODES[pool_mode],
                                            head.weight.data_ptr(), head.bias.data_ptr(), tgt.data_ptr(), loss_mode, K,
                                            _one(dev).data_ptr(), pooled.data_ptr(), logits.data_ptr(), loss.data_ptr(),
                                            djk.data_ptr(), djk.stride(0), head.weight.grad.data_ptr(),
                                            head.bias.grad.data_ptr(), st["acc"], gn.weight.grad.data_ptr(),
                                            gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), st["acc"], ws.data_ptr(),
-                                           n, C, *largs,
-                                           _stream()), "glass_readout_train_f32")
+                                           n, C, *largs, src, _stream()), "glass_readout_train_f32")
         st["djk"] = djk
         return loss, logits
 
@@ -568,7 +630,16 @@ class StackProgram:
             din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
             # conv.gn's backward column sums come from this kernel's epilogue
             labels = st.get("labels")
-            if _comb_eff_ok(conv, labels, H):
+            acc_all = st.get("gn_exact")
+            if acc_all is not None:
+                gpart = acc_all[2 * l]   # exact accumulators: the sums are final when the kernel is, no finalize launch
+            if acc_all is not None and _comb_eff_ok(conv, labels, H):
+                _comb_eff_bwd(dc, conv, mask, din, rec["g"], rec["h"], pending, acc,
+                              (gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base), labels)
+            elif acc_all is not None:
+                _dual_bwd(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din, rec["g"], rec["h"],
+                          pending, acc, gn=(gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base))
+            elif _comb_eff_ok(conv, labels, H):
                 gpart = torch.empty((int(_lib.load().glass_comb_eff_blocks(n, H, labels.cap)), 2, H), **f64)
                 _comb_eff_bwd(dc, conv, mask, din, rec["g"], rec["h"], pending, acc,
                               (gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base), labels)
@@ -587,7 +658,7 @@ class StackProgram:
             gn = None
             if l > 0:
                 below, cb = st["layers"][l - 1], emb.convs[l - 1]
-                npart = torch.empty((nblk, 2, H), **f64)
+                npart = acc_all[2 * l - 1] if acc_all is not None else torch.empty((nblk, 2, H), **f64)
                 gn = (npart, below["c"], below["nsaved"], emb.gns[l - 1].mean_scale, ACT_ELU, p, cb.call_base + 1)
             _dual_bwd(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, rec["h"], None, pending,
                       acc, drop, gn)

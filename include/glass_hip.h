@@ -25,6 +25,8 @@
 
 #ifdef __cplusplus
 extern "C" {
+
+typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a kernel input: defined with K5's entries */
 #endif
 
 #define GLASS_ABI_VERSION 3
@@ -297,11 +299,14 @@ int64_t glass_dual_linear_stat_rows(int64_t H);
  *   xa = the embedding table, gn_saved = emb_gn's statistics through the table (glass_step_prologue_f32), xa_out receives
  *   dropout(emb_gn(input_emb(x))) [n_nodes, H], the layer input — no gather launch. */
 int glass_dual_linear_fwd_gather_supported(int64_t H);
+/*   stats_exact != 0 / gn_src != NULL (hidden 64): the exact-accumulator forms of `stats` and `gn_saved`, see
+ *   glass_gn_src below. */
 int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg,
                               const float* bias, const uint8_t* mask, double z_ratio, int act, float* T, int64_t ldt,
-                              float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* stats, const float* gn_saved,
-                              int gn_act, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
-                              int64_t ldxo, const int64_t* xa_index, int64_t xa_rows, void* stream);
+                              float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* stats, int stats_exact,
+                              const float* gn_saved, const glass_gn_src* gn_src, int gn_act, float p_drop,
+                              const uint64_t* rng_state, uint64_t call_id, float* xa_out, int64_t ldxo,
+                              const int64_t* xa_index, int64_t xa_rows, void* stream);
 /*   dgrad epilogue: out = (dZ @ W + addend) * dropmask(p_drop, rng_state, call_id) — the mask of the dropout that
  *   produced this layer's input (same mask layout as glass_graphnorm_fwd_f32), so the consumer receives the
  *   gradient w.r.t. the pre-dropout tensor; p_drop = 0 disables it (rng_state may be NULL).
@@ -314,7 +319,7 @@ int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
                                 int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* out,
                                 int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
                                 int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
-                                uint64_t gn_call_id, void* stream);
+                                uint64_t gn_call_id, int gn_exact, void* stream);
 /*   bwd: the whole backward of one pair for the step program — exactly glass_dual_linear_dgrad_f32 (same arguments)
  *   followed by glass_dual_linear_wgrad_f32 with dW == NULL (partial sums of dW / db into `ws`, reduced later by
  *   glass_linear_wgrad_reduce_batch_f32; X / X2 = the pair's inputs).  At hidden 64 on graphs of up to 100 000 nodes
@@ -325,8 +330,8 @@ int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const float* T, in
                               int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* out,
                               int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
                               int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
-                              uint64_t gn_call_id, const float* X, int64_t ldx, const float* X2, int64_t ldx2, void* ws,
-                              void* stream);
+                              uint64_t gn_call_id, int gn_exact, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
+                              void* ws, void* stream);
 int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                                 double z_ratio, int act, const float* X, int64_t ldx, const float* X2, int64_t ldx2,
                                 int64_t N, int64_t H, float* dW, int64_t lddw, float* db, int accumulate, void* ws,
@@ -349,15 +354,16 @@ int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap);
 int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t lab_cap); /* `ws` of glass_comb_eff_bwd_f32 */
 int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,
                            const float* bias, const uint8_t* mask, double z_ratio, float* out, int64_t ldo,
-                           int64_t n_nodes, int64_t H, double* stats, const float* gn_saved, int gn_act, float p_drop,
-                           const uint64_t* rng_state, uint64_t call_id, float* xa_out, int64_t ldxo,
-                           const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap, void* stream);
+                           int64_t n_nodes, int64_t H, double* stats, int stats_exact, const float* gn_saved,
+                           const glass_gn_src* gn_src, int gn_act, float p_drop, const uint64_t* rng_state,
+                           uint64_t call_id, float* xa_out, int64_t ldxo, const int32_t* lab_rows,
+                           const int32_t* lab_count, int64_t lab_cap, void* stream);
 int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint8_t* mask, double z_ratio, const float* WTimg_eff,
                            float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
                            int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
-                           const uint64_t* rng_state, uint64_t gn_call_id, const float* X, int64_t ldx, const float* X2,
-                           int64_t ldx2, void* ws, const int32_t* lab_rows, const int32_t* lab_count, int64_t lab_cap,
-                           void* stream);
+                           const uint64_t* rng_state, uint64_t gn_call_id, int gn_exact, const float* X, int64_t ldx,
+                           const float* X2, int64_t ldx2, void* ws, const int32_t* lab_rows, const int32_t* lab_count,
+                           int64_t lab_cap, void* stream);
 /*     Deferred reduction: glass_dual_linear_wgrad_f32 with dW == NULL only writes the per-slab partial sums
  *     into `ws` (one scratch buffer per pending gradient); this call then reduces n_jobs of them — job j is
  *     the gradient of a [O[j], I[j]] weight over N[j] rows — into dW[j] / db[j] (db[j] may be NULL) with ONE
@@ -399,11 +405,38 @@ int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const
  *     plus the statistics of emb_gn through the embedding table — the first half of glass_embed_norm_fwd_f32
  *     (impl/models.py:248-249): saved[4H] = mean, rstd, scale, shift of GraphNorm(W[x]) as count-weighted sums over the V
  *     table rows (class_rowptr as there); table[V,H] = W*scale + shift, or NULL when the consumer normalises while
- *     gathering from W (glass_dual_linear_fwd_f32 with xa_index). */
+ *     gathering from W (glass_dual_linear_fwd_f32 with xa_index).
+ *     W == NULL: no table job.  zero_words / n_zero_words: int64 words the same launch zero-fills — the step's exact
+ *     GraphNorm accumulators (below). */
 int glass_step_prologue_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
                             const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
                             const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma, const float* beta,
-                            const float* alpha, float eps, float* saved, float* table, int64_t H, void* stream);
+                            const float* alpha, float eps, float* saved, float* table, int64_t H, int64_t* zero_words,
+                            int64_t n_zero_words, void* stream);
+/*     Exact cross-workgroup GraphNorm sums (hidden 64): the whole-graph GraphNorm (PyG GraphNorm with batch = None,
+ *     impl/models.py:165,249,257,266,271) needs column sums over ALL rows between every pair of kernels of the step.
+ *     Instead of per-workgroup fp64 partials + a finalize launch, the producers add their per-workgroup sums into
+ *     FIXED-POINT accumulators with 64-bit integer atomics: int64 [replicas][2][C][2 limbs] = glass_gn_exact_words(C)
+ *     words per GraphNorm (column block), zeroed per step by glass_step_prologue_f32.  Integer addition is
+ *     associative, so the sums do not depend on the order the workgroups arrive in — bitwise repeatable (float atomics
+ *     are not).  Forward sums: resolution 2^-52 per workgroup partial, range 2^50; backward sums: 2^-64, range 2^38.
+ *     The consumers fold the replicas in every workgroup's prologue and derive the coefficients themselves:
+ *       backward (gn_exact != 0 on the data-gradient entries): glass_graphnorm_bwd_from_stats_f32 with nblk = -1 and
+ *         partial = the accumulators — finalize + apply as ONE launch;
+ *       forward (stats_exact != 0: `stats` points to accumulators; glass_graphnorm_stats_exact_f32 for a stand-alone
+ *         statistics pass): the kernel that applies the GraphNorm receives a glass_gn_src — the accumulators and the
+ *         GraphNorm's parameters — instead of final statistics, and its workgroup 0 writes gn_saved[4C] (mean, rstd,
+ *         scale, shift) for the backward.  n_src accumulator blocks of C / n_src columns each (the column blocks of a
+ *         jumping-knowledge buffer, impl/models.py:268-270); the dense kernels take n_src = 1. */
+struct glass_gn_src {
+    const int64_t* acc;
+    int64_t n_src;
+    const float *gamma, *beta, *alpha;
+    float eps;
+};
+int glass_gn_exact_supported(int64_t H);
+int64_t glass_gn_exact_words(int64_t C);
+int glass_graphnorm_stats_exact_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, int64_t* acc, void* stream);
 
 /* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
  *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened
@@ -445,7 +478,8 @@ int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved,
                             const void* target, int loss_mode, int64_t K, const float* grad_loss, float* pooled,
                             float* logits, float* loss, float* djk, int64_t lddj, float* dWh, float* dbh, int acc_head,
                             float* dgamma, float* dbeta, float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
-                            const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count, void* stream);
+                            const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
+                            const glass_gn_src* gn_src, void* stream);
 
 /*     Two small device-to-device copies in one launch (4-byte granularity): a training step that is replayed from a
  *     captured graph reads its batch (pos, target) from fixed buffers; this fills both per step. */

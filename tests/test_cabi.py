@@ -161,7 +161,8 @@ def test_step_program_entry_points_validate_on_the_host():
     assert lib.glass_readout_supported(2048, 6, 0) == 0 and lib.glass_readout_supported(128, 300, 0) == 0
     assert lib.glass_readout_ws_bytes(80, 128, 6) >= 8 * 2 * 80 * 128 + 4 * (4 * 128 + 80 * 128 + 80 * 6 + 80)
     assert lib.glass_readout_ws_bytes(0, 128, 6) == -1
-    args = [p, 128, p, p, p, p, 80, 10, 2, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 1000, 128, None, None, None, None]
+    args = [p, 128, p, p, p, p, 80, 10, 2, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 1000, 128, None, None, None, None,
+            None]
     assert lib.glass_readout_train_f32(*args) == -3  # max pooling is not fusable
     # table path: more rows than GLASS_EMBED_NORM_MAX_ROWS
     assert lib.glass_embed_norm_fwd_f32(p, p, 10000, p, p, p, p, 1e-5, p, p, None, None, 0, 0.0, None, 1, p, 64, p, 10, 64,
@@ -181,8 +182,15 @@ def test_step_program_entry_points_validate_on_the_host():
     assert lib.glass_linear_wgrad_reduce_batch_f32(1, None, None, None, None, None, None, None, None, None, None) == -1
     assert lib.glass_copy_pair(p, p, 6, p, p, 4, None) == -1 and lib.glass_copy_pair(None, p, 4, p, p, 4, None) == -1
     # fused dense forward: GraphNorm prologue without a side output is rejected before any launch
-    assert lib.glass_dual_linear_fwd_f32(p, 64, None, 0, p, p, p, 0.9, 1, p, 128, p, 64, 16, 64, None, p, 0, 0.0, None, 0,
+    assert lib.glass_dual_linear_fwd_f32(p, 64, None, 0, p, p, p, 0.9, 1, p, 128, p, 64, 16, 64, None, 0, p, None, 0, 0.0, None, 0,
                                          None, 0, None, 0, None) == -1
+    # exact GraphNorm accumulators: hidden 64 only; a glass_gn_src with a missing pointer is rejected before any launch
+    assert lib.glass_gn_exact_supported(64) == 1 and lib.glass_gn_exact_supported(128) == 0 and lib.glass_gn_exact_supported(16) == 0
+    assert lib.glass_gn_exact_words(64) > 0 and lib.glass_gn_exact_words(64) % (2 * 64 * 2) == 0
+    bad = _lib.GnSrc(p, 1, p, None, p, 1e-5)
+    assert lib.glass_dual_linear_fwd_f32(p, 64, None, 0, p, p, p, 0.9, 1, p, 128, p, 64, 16, 64, None, 0, p, bad.ptr, 0, 0.0, None,
+                                         0, p, 64, None, 0, None) == -1
+    assert lib.glass_graphnorm_stats_exact_f32(p, 64, 16, 64, None, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

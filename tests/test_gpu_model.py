@@ -483,6 +483,29 @@ def test_stack_program_matches_per_op_path_with_dropout(monkeypatch, hidden):
     assert rel_inf(res[0][1].cpu(), res[1][1].cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("layers", [1, 3])
+def test_exact_graphnorm_accumulators_match_partial_sums(monkeypatch, layers):
+    """Hidden 64: the backward column sums of the GraphNorms accumulated with 64-bit fixed-point atomics (gn_acc.h, no
+    finalize launch) against the per-workgroup partials + finalize form: same masks, gradients equal to fp32 rounding;
+    and the exact form twice -> bit-identical gradients (integer atomics commute, float atomics would not)."""
+    from glass_amd import ops, stack, _lib
+    emb, arena, _orc, (x, ei, ew, z), gout = _emb_pair(layers, 1, "mean", 0.95, 0.5, seed=5, H=64)
+    assert _lib.load().glass_gn_exact_supported(64) == 1 and _lib.load().glass_gn_exact_supported(128) == 0
+    emb.train()
+    args = [t.to(DEV) for t in (x, ei, ew, z)]
+    res = []
+    for exact in (True, False, True):
+        monkeypatch.setattr(stack, "USE_GN_EXACT", exact)
+        ops.rng_seed(99, torch.device(DEV))
+        arena.zero()
+        y = emb(*args)
+        y.backward(gout.to(DEV))
+        res.append((y.detach().clone(), arena.flat.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    assert rel_inf(res[0][1].cpu(), res[1][1].cpu()) < 1e-6
+    assert torch.equal(res[0][1], res[2][1])
+
+
 def test_eval_after_optimizer_step_uses_current_weights():
     """The fused dense kernels read packed operand images of the weights; they must be re-packed whenever the
     weights may have changed, also for a no-grad evaluation right after an optimizer step."""
