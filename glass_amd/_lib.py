@@ -37,13 +37,14 @@ _I = c_int64
 
 class GnSrc(ctypes.Structure):
     """glass_gn_src (include/glass_hip.h): a GraphNorm whose forward sums are still in exact accumulators."""
-    _fields_ = [("acc", c_void_p), ("n_src", c_int64), ("gamma", c_void_p), ("beta", c_void_p), ("alpha", c_void_p),
-                ("eps", c_float)]
+    _fields_ = [("acc", c_void_p), ("n_src", c_int64), ("n_rep", c_int64), ("gamma", c_void_p), ("beta", c_void_p),
+                ("alpha", c_void_p), ("eps", c_float)]
 
     @classmethod
-    def of(cls, acc, n_src, gn):
-        """acc: int64 tensor (n_src consecutive accumulator blocks); gn: the GraphNorm module."""
-        return cls(acc.data_ptr(), n_src, gn.weight.data_ptr(), gn.bias.data_ptr(), gn.mean_scale.data_ptr(), float(gn.eps))
+    def of(cls, acc, n_src, n_rep, gn):
+        """acc: int64 tensor (n_src consecutive accumulator blocks, n_rep replicas used); gn: the GraphNorm module."""
+        return cls(acc.data_ptr(), n_src, n_rep, gn.weight.data_ptr(), gn.bias.data_ptr(), gn.mean_scale.data_ptr(),
+                   float(gn.eps))
 
     @property
     def ptr(self):
@@ -96,7 +97,7 @@ SIGNATURES = {
                                           _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, c_int, _P, _I, _P, _I, _P, _P]),
     "glass_gn_exact_supported": (c_int, [_I]),
     "glass_gn_exact_words": (c_int64, [_I]),
-    "glass_graphnorm_stats_exact_f32": (c_int, [_P, _I, _I, _I, _P, _P]),
+    "glass_graphnorm_stats_exact_f32": (c_int, [_P, _I, _I, _I, _P, c_int, _P]),
     "glass_graphnorm_bwd_from_stats_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P,
                                                    c_int, c_int, c_float, _P, c_uint64, _P, _P]),
     "glass_embed_norm_fwd_f32": (c_int, [_P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _P, _P, _I, c_float, _P, c_uint64, _P,

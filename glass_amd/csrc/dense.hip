@@ -31,6 +31,15 @@
 
 namespace glass {
 
+#ifndef GLASS_FUSED_WGRAD_STAGES
+#define GLASS_FUSED_WGRAD_STAGES 2  // pipeline stages of the weight-gradient workgroups inside the fused backward launches
+#endif
+#ifdef GLASS_DENSE_TRACE
+__device__ unsigned long long* g_dense_trace;
+__device__ int g_dense_trace_sel;
+#endif
+
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kKC = 16;  // K elements per lane per pass (64 per wave-step group)
@@ -130,13 +139,23 @@ __device__ __forceinline__ void mfma_pass_lds(f32x4 (&acc)[NTILES], const float 
     }
 }
 
-// Whole product for one wave's 16 rows: passes over K in chunks of 64 (16 per lane), weight slices
-// double-buffered through LDS.  The A operand of pass kc is produced in two steps so that the loads of pass kc+1
-// stay in flight across the MFMAs of pass kc: `issue(kc, raw)` only starts the global loads into `raw`;
-// `finish(kc, raw, a)` (run after the current pass) turns them into the operand chunk (prologue arithmetic).
-template <int NT, int KT, int NLOC, int HALF, int THREADS, typename Raw, typename Issue, typename Finish>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// Whole product for one wave's 16 rows: passes over K in chunks of 64 (16 per lane), weight slices double-buffered
+// through LDS.  The A operand of pass kc is produced in two steps so that the loads of pass kc+1 stay in flight across the
+// MFMAs of pass kc: `issue(kc, raw)` only starts the global loads into `raw`; `finish(kc, raw, a)` (run after the current
+// pass) turns them into the operand chunk (prologue arithmetic).  `between()` runs once the loads of the FIRST pass are in
+// flight: it may issue further loads and write LDS but holds no barrier (on CDNA a workgroup barrier drains the wave's
+// outstanding loads — vmcnt counts loads and stores and the barrier's release fence waits for it — so a barrier there
+// would serialise two memory round trips); the barrier behind the first commit publishes what it wrote.  The forward
+// kernels derive their GraphNorm coefficients there, the accumulator loads joining the round trip of the operand loads.
+// (Requesting BOTH passes up front — one round trip for everything — was slower: 17.8 vs 16.6 us for the comb forward,
+// 18.0 vs 17.5 for the trans backward; the burst of every workgroup's loads is bandwidth-bound, and the pipelined form
+// starts its MFMAs when half of the data has arrived.)
+template <int NT, int KT, int NLOC, int HALF, int THREADS, typename Raw, typename Issue, typename Finish, typename Between = NoHook>
 __device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* __restrict__ W, float4* lds, int lane,
-                                               int base0, int base1, Issue issue, Finish finish) {
+                                               int base0, int base1, Issue issue, Finish finish, Between between = Between()) {
     constexpr int NKC = KT / 4 / kKC;
     constexpr int kVecs = WStage<NT, THREADS>::kVecs;
     static_assert(WStage<NT, THREADS>::kPerThread <= 8, "weight image too large for one staging object");
@@ -144,10 +163,11 @@ __device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* 
     ws.fetch(W, 0);
     Raw raw;
     issue(0, raw);
+    between();
     ws.commit(lds);
+    __syncthreads();
     float a[kKC];
     finish(0, raw, a);
-    __syncthreads();
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
         if (kc + 1 < NKC) {
@@ -171,21 +191,22 @@ __device__ __forceinline__ void staged_product(f32x4 (&acc)[NLOC], const float* 
 // same layer read it) — the GraphNorm apply launch and its read of xa disappear.
 struct FwdRaw {
     float x[kKC];
-    float4 sc[kKC / 4], sh[kKC / 4];  // GraphNorm scale / shift of this chunk's columns (prologue lanes only)
 };
 
-__device__ __forceinline__ void gn_prologue16(float (&a)[kKC], const FwdRaw& raw, const GnPrologue& pro,
+// coef_s (LDS): scale[C] | shift[C] of the prologue's GraphNorm (gn_fwd_coef_block)
+__device__ __forceinline__ void gn_prologue16(float (&a)[kKC], const float* coef_s, const GnPrologue& pro,
                                               const Drop& drop, int64_t row, int col0) {
 #pragma unroll
     for (int v = 0; v < kKC / 4; ++v) {
-        const float4 s4 = raw.sc[v], h4 = raw.sh[v];
+        const float4 s4 = *reinterpret_cast<const float4*>(coef_s + col0 + 4 * v);
+        const float4 h4 = *reinterpret_cast<const float4*>(coef_s + pro.C + col0 + 4 * v);
         const float scale[4] = {s4.x, s4.y, s4.z, s4.w}, shift[4] = {h4.x, h4.y, h4.z, h4.w};
         float ds[4] = {1.f, 1.f, 1.f, 1.f};
         if (drop.p > 0.f) drop_scales<4>(drop, row, col0 + 4 * v, ds);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float h = fmaf(a[4 * v + k], scale[k], shift[k]);
-            if (pro.act == GLASS_ACT_ELU) h = elu_f(h);
+            if (pro.act == GLASS_ACT_ELU) h = elu_fast_f(h);
             a[4 * v + k] = h * ds[k];
         }
         if (pro.side)
@@ -214,6 +235,7 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
     constexpr int NGL = NG / CS;     // ... owned by one wave
     constexpr int NLOC = 8 * NGL;    // local tiles: 4*NGL of the f1 half, then 4*NGL of the f0 half
     static_assert(KQ % kKC == 0 && NG % CS == 0, "hidden size must be a multiple of 64 * CS");
+    D_STAMP(2, 0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int rw = w % RW, cg = w / RW;  // row wave, column group
     const int i = lane & 15, q = lane >> 4;
@@ -248,27 +270,22 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
     if (cg != 0) pro_w.side = nullptr;  // the wave groups of a row tile compute the same operand; one writes it
     // scale | shift of the prologue's GraphNorm in LDS: copied from `saved`, or derived here from the exact accumulators its
     // producers added to (gn_acc.h: no finalize launch between them and this kernel)
-    __shared__ double gn_sums_s[2 * H];
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
-    if (pro.saved) gn_fwd_coef_block(pro.src, pro.saved, H, N, gn_sums_s, gn_coef_s, nullptr);
     staged_product<NT, KT, NLOC, 4 * NGL, THREADS, FwdRaw>(
         acc, W, lds_w, lane, 4 * NGL * cg, 4 * (NG + NGL * cg),
-        [&](int kc, FwdRaw& raw) __attribute__((always_inline)) {
-            load16(raw.x, arow + kc * kKC, row_ok);
-            if (pro_lane) {
-                const int col0 = q * KQ + kc * kKC;
-#pragma unroll
-                for (int v = 0; v < kKC / 4; ++v) {
-                    raw.sc[v] = *reinterpret_cast<const float4*>(gn_coef_s + col0 + 4 * v);
-                    raw.sh[v] = *reinterpret_cast<const float4*>(gn_coef_s + H + col0 + 4 * v);
-                }
-            }
-        },
+        [&](int kc, FwdRaw& raw) __attribute__((always_inline)) { load16(raw.x, arow + kc * kKC, row_ok); },
         [&](int kc, const FwdRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
+            if (kc == 0) D_STAMP(2, 5);
 #pragma unroll
             for (int s2 = 0; s2 < kKC; ++s2) a[s2] = raw.x[s2];
-            if (pro_lane) gn_prologue16(a, raw, pro_w, drop, row, q * KQ + kc * kKC);
+            if (pro_lane) gn_prologue16(a, gn_coef_s, pro_w, drop, row, q * KQ + kc * kKC);
+            if (kc == 0) D_STAMP(2, 6);
+        },
+        [&]() __attribute__((always_inline)) {  // (its accumulator loads join the round trip of the operand loads above)
+            if (pro.saved) gn_fwd_coef_nobarrier<H, THREADS>(pro.src, pro.saved, N, gn_coef_s);
+            D_STAMP(2, 1);
         });
+    D_STAMP(2, 2);
     // epilogue: acc[4gl+k][reg] is row row0 + 4q + reg, column 64g + 4i + k (g = NGL*cg + gl) -> float4 per (row, group)
     float ssum[NGL][4], ssq[NGL][4];  // this lane's column sums over its (up to) 4 rows, for the GraphNorm that follows
 #pragma unroll
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
             *reinterpret_cast<float4*>(out + r * ldo + c) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
+    D_STAMP(2, 3);
     if (stats == nullptr) return;
     // Column statistics of `out` for the GraphNorm that consumes it (its statistics pass is skipped):
     // stats[blockIdx.x][2][H] = per-workgroup sum / sum of squares over its 16*RW rows, in fp64 from here on.
@@ -345,13 +363,13 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
             q2 += red[(ww * H + c) * 2 + 1];
         }
         if (stats_exact) {  // exact accumulators (gn_acc.h): the consumer folds them, no finalize launch
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 0, c, H, s, kAccScaleFwd);
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 1, c, H, q2, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
         } else {
             stats[((size_t)blockIdx.x * 2) * H + c] = s;
             stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
         }
-    }
+    }    D_STAMP(2, 4);
 }
 
 struct DgradRaw {
@@ -425,6 +443,7 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
                 a[s] = v;
             }
         });
+    D_STAMP(4, 2);
     if (drop.p > 0.f) {
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
@@ -490,6 +509,7 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
             }
         }
     }
+    D_STAMP(4, 3);
     if (gs.partial == nullptr) return;
     __syncthreads();  // every wave is done with the weight images in LDS
     double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
@@ -519,8 +539,8 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
             b2 += red[(ww * H + c) * 2 + 1];
         }
         if (gs.exact) {  // exact accumulators (gn_acc.h): no finalize launch behind this kernel
-            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 0, c, H, a, kAccScaleBwd);
-            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 1, c, H, b2, kAccScaleBwd);
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % gs.exact, 0, c, H, a, kAccScaleBwd);
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % gs.exact, 1, c, H, b2, kAccScaleBwd);
         } else {
             gs.partial[((size_t)block * 2) * H + c] = a;
             gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
@@ -553,10 +573,13 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
         wg_header[1] = sy.zr;
     }
     if (b < n_dgrad_blocks) {
+        D_STAMP(4, 0);
         dual_dgrad_body<H, NT, 1, 4>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
                                      A.rng_state, A.out, A.ldo, A.N, A.gs, b, lds_w);
+        D_STAMP(4, 4);
         return;
     }
+    D_STAMP(4, 5);
     const int t = b - n_dgrad_blocks;  // slab fastest, then input tile, then output tile (as the 3-D grid of the stand-alone launch)
     float* lds = reinterpret_cast<float*>(lds_w);
     if (GLASS_WGRAD_STAGED && NT == 64 && rows_per_slab <= kStageRows && sy.X2 == nullptr) {
@@ -564,8 +587,9 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
         wgrad_synth_staged_body(X, ldx, A.N, rows_per_slab, part_w, part_b, sy, t, gx, lds, lds + 2 * kTile);
         return;
     }
-    wgrad_partial_body<true, 2>(nullptr, 0, X, ldx, A.N, O, I, rows_per_slab, part_w, part_b, sy, t % gx, (t / gx) % gy,
+    wgrad_partial_body<true, GLASS_FUSED_WGRAD_STAGES>(nullptr, 0, X, ldx, A.N, O, I, rows_per_slab, part_w, part_b, sy, t % gx, (t / gx) % gy,
                                 t / (gx * gy), gx, gy, lds, lds + 2 * kTile);
+    D_STAMP(4, 6);
 }
 
 // ---- comb pair through effective per-label weights (hidden 64) ------------------------------------------------------
@@ -624,6 +648,7 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
     constexpr int KT = 2 * H, KQ = KT / 4, NT = H, NLOC = NT / 16;
     constexpr int THREADS = kWave * RW;
     static_assert(H == 64, "one 64-column group per wave");
+    D_STAMP(1, 0);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int i = lane & 15, q = lane >> 4;
     EffRows R;
@@ -651,27 +676,23 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
     const bool pro_lane = pro.saved != nullptr && row_ok && q < 2;  // lanes whose chunk belongs to xa
     GnPrologue pro_w = pro;
     if (R.extra) pro_w.side = nullptr;  // the row's own tile wrote the normalised operand
-    __shared__ double gn_sums_s[2 * H];
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];  // scale | shift of the prologue's GraphNorm (see dual_fwd_kernel)
-    if (pro.saved) gn_fwd_coef_block(pro.src, pro.saved, H, N, gn_sums_s, gn_coef_s, nullptr);
     staged_product<NT, KT, NLOC, NLOC, THREADS, FwdRaw>(
         acc, W, lds_w, lane, 0, 0,
-        [&](int kc, FwdRaw& raw) __attribute__((always_inline)) {
-            load16(raw.x, arow + kc * kKC, row_ok);
-            if (pro_lane) {
-                const int col0 = q * KQ + kc * kKC;
-#pragma unroll
-                for (int v = 0; v < kKC / 4; ++v) {
-                    raw.sc[v] = *reinterpret_cast<const float4*>(gn_coef_s + col0 + 4 * v);
-                    raw.sh[v] = *reinterpret_cast<const float4*>(gn_coef_s + H + col0 + 4 * v);
-                }
-            }
-        },
+        [&](int kc, FwdRaw& raw) __attribute__((always_inline)) { load16(raw.x, arow + kc * kKC, row_ok); },
         [&](int kc, const FwdRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
+            if (kc == 0) D_STAMP(1, 5);
 #pragma unroll
             for (int s2 = 0; s2 < kKC; ++s2) a[s2] = raw.x[s2];
-            if (pro_lane) gn_prologue16(a, raw, pro_w, drop, row, q * KQ + kc * kKC);
+            if (pro_lane) gn_prologue16(a, gn_coef_s, pro_w, drop, row, q * KQ + kc * kKC);
+            if (kc == 0) D_STAMP(1, 6);
+            if (kc == 1) D_STAMP(1, 7);
+        },
+        [&]() __attribute__((always_inline)) {
+            if (pro.saved) gn_fwd_coef_nobarrier<H, THREADS>(pro.src, pro.saved, N, gn_coef_s);
+            D_STAMP(1, 1);
         });
+    D_STAMP(1, 2);
     // epilogue: acc[k][reg] is row erow[reg], column 4i + k
     const float be[4] = {c1 * b1.x + c0 * b0.x, c1 * b1.y + c0 * b0.y, c1 * b1.z + c0 * b0.z, c1 * b1.w + c0 * b0.w};
     float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -687,6 +708,7 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
         }
         *reinterpret_cast<float4*>(out + (int64_t)R.erow[reg] * ldo + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    D_STAMP(1, 3);
     if (stats == nullptr) return;
     __syncthreads();  // every wave is done with the weight images in LDS
     double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
@@ -711,13 +733,13 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
             q2 += red[(ww * H + c) * 2 + 1];
         }
         if (stats_exact) {  // exact accumulators (gn_acc.h): the consumer folds them, no finalize launch
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 0, c, H, s, kAccScaleFwd);
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % kAccRep, 1, c, H, q2, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
         } else {
             stats[((size_t)blockIdx.x * 2) * H + c] = s;
             stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
         }
-    }
+    }    D_STAMP(1, 4);
 }
 
 // Data gradient of the comb pair in the same form:  d[g || x_][r] = dc[r] . (w1 W1 + w0 W0): K = H instead of 2H (one
@@ -781,6 +803,7 @@ __device__ __forceinline__ void comb_dgrad_eff_body(const float* __restrict__ ds
 #pragma unroll
             for (int s = 0; s < kKC; ++s) a[s] = raw.d[s];
         });
+    D_STAMP(3, 2);
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) {
@@ -811,6 +834,7 @@ __device__ __forceinline__ void comb_dgrad_eff_body(const float* __restrict__ ds
             }
         }
     }
+    D_STAMP(3, 3);
     if (gs.partial == nullptr) return;
     __syncthreads();  // every wave is done with the weight image in LDS
     double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
@@ -835,8 +859,8 @@ __device__ __forceinline__ void comb_dgrad_eff_body(const float* __restrict__ ds
             b2 += red[(ww * H + c) * 2 + 1];
         }
         if (gs.exact) {  // exact accumulators (gn_acc.h): no finalize launch behind this kernel
-            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 0, c, H, a, kAccScaleBwd);
-            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % kAccRep, 1, c, H, b2, kAccScaleBwd);
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % gs.exact, 0, c, H, a, kAccScaleBwd);
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % gs.exact, 1, c, H, b2, kAccScaleBwd);
         } else {
             gs.partial[((size_t)block * 2) * H + c] = a;
             gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
@@ -863,14 +887,18 @@ __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A,
         header[1] = zr;
     }
     if (b < n_dgrad_blocks) {
+        D_STAMP(3, 0);
         comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, b, lds_w);
+        D_STAMP(3, 4);
         return;
     }
+    D_STAMP(3, 5);
     float* lds = reinterpret_cast<float*>(lds_w);
     if (GLASS_WGRAD_STAGED && sl.rows_per_slab <= kStageRows)  // small graph: the whole slab through LDS, one memory round trip
         wgrad_sl_staged_body(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
     else
-        wgrad_sl_body<2>(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
+        wgrad_sl_body<GLASS_FUSED_WGRAD_STAGES>(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
+    D_STAMP(3, 6);
 }
 
 // ---- packing of the stacked weights into MFMA images (one launch for the whole model, once per step) ------
@@ -1036,13 +1064,21 @@ static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at 
 // instantiated.
 // (A/B switches live in the Python layer, glass_amd/ops.py: the library keeps no state.)
 // exact cross-workgroup GraphNorm sums (gn_acc.h) instead of per-workgroup partials + a finalize launch: the hidden-64 kernels
+#ifdef GLASS_DENSE_TRACE
+extern "C" int glass_dense_trace_set(unsigned long long* p, int sel) {
+    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dense_trace), &p, sizeof(p));
+    return rc ? rc : (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dense_trace_sel), &sel, sizeof(sel));
+}
+#endif
 extern "C" int glass_gn_exact_supported(int64_t H) { return wave16_shape_ok(H) ? 1 : 0; }
 // gn_src (the C-ABI struct) -> the kernels' form; saved = the [4C] buffer workgroup 0 writes.  NULL gn_src: final statistics.
+static bool rep_ok(int64_t n_rep) { return n_rep == 2 || n_rep == 4 || n_rep == 8 || n_rep == 16; }  // <= kAccRep, even
 static bool make_exact_src(const glass_gn_src* g, const float* saved, GnExactSrc& out) {
-    out = GnExactSrc{nullptr, 1, nullptr, nullptr, nullptr, 0.f, nullptr};
+    out = GnExactSrc{nullptr, 1, kAccRep, nullptr, nullptr, nullptr, 0.f, nullptr};
     if (!g) return true;
-    if (!g->acc || g->n_src != 1 || !g->gamma || !g->beta || !g->alpha || !saved) return false;
-    out = GnExactSrc{reinterpret_cast<const long long*>(g->acc), 1, g->gamma, g->beta, g->alpha, g->eps, const_cast<float*>(saved)};
+    if (!g->acc || g->n_src != 1 || !rep_ok(g->n_rep) || !g->gamma || !g->beta || !g->alpha || !saved) return false;
+    out = GnExactSrc{reinterpret_cast<const long long*>(g->acc), 1, (int)g->n_rep, g->gamma, g->beta, g->alpha, g->eps,
+                     const_cast<float*>(saved)};
     return true;
 }
 extern "C" int64_t glass_gn_exact_words(int64_t C) { return gn_acc_words(C); }  // int64 words of one accumulator block
@@ -1080,7 +1116,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
                                          int gn_act, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
                                          int64_t ldxo, const int64_t* xa_index, int64_t xa_rows, void* stream) {
     GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
-    GLASS_REQUIRE((!stats_exact || (stats && wave16_shape_ok(H))) && (!gn_src || (gn_saved && wave16_shape_ok(H))),
+    GLASS_REQUIRE((!stats_exact || (stats && wave16_shape_ok(H) && rep_ok(stats_exact))) && (!gn_src || (gn_saved && wave16_shape_ok(H))),
                   "dual_linear_fwd: exact GraphNorm accumulators are served at hidden 64 only (glass_gn_exact_supported)");
     GnExactSrc esrc;
     GLASS_REQUIRE(make_exact_src(gn_src, gn_saved, esrc), "dual_linear_fwd: bad gn_src (one accumulator block, all pointers set)");
@@ -1175,7 +1211,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
                       aligned16(out) && (act == GLASS_ACT_NONE || (T && ldt >= 2 * H && ldt % 4 == 0 && aligned16(T))) &&
                       (!addend || (ldadd >= n_out && ldadd % 4 == 0 && aligned16(addend))),
                   "dual_linear_dgrad: operands must be 16-B aligned with ld %% 4 == 0");
-    GLASS_REQUIRE(!gn_exact || (gn_partial && wave16_shape_ok(H) && aligned16(gn_partial)),
+    GLASS_REQUIRE(!gn_exact || (gn_partial && wave16_shape_ok(H) && aligned16(gn_partial) && rep_ok(gn_exact)),
                   "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only (glass_gn_exact_supported)");
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(n_nodes, glass_dual_linear_stat_rows(H)));
@@ -1299,7 +1335,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     const dim3 grid((unsigned)(n_main + ceil_div(lab_cap, 64)));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     GnExactSrc esrc;
-    GLASS_REQUIRE(make_exact_src(gn_src, gn_saved, esrc) && (!stats_exact || stats),
+    GLASS_REQUIRE(make_exact_src(gn_src, gn_saved, esrc) && (!stats_exact || (stats && rep_ok(stats_exact))),
                   "comb_eff_fwd: bad gn_src (one accumulator block, all pointers set)");
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
     const LabRows lab{lab_rows, lab_count, n_main};
@@ -1329,6 +1365,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
                                   aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
                                   (gn_p_drop == 0.f || rng_state) && (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
                   "comb_eff_bwd: bad GraphNorm statistics arguments");
+    GLASS_REQUIRE(!gn_exact || (gn_partial && rep_ok(gn_exact)), "comb_eff_bwd: gn_exact = replicas of the accumulators (2, 4, 8, 16)");
     hipStream_t st = (hipStream_t)stream;
     const int n_main = (int)ceil_div(n_nodes, 64);
     const unsigned n_dg = (unsigned)(n_main + ceil_div(lab_cap, 64));

@@ -10,6 +10,20 @@ namespace glass {
 // are already final (saved[4C] = mean, rstd, scale, shift); the kernel normalises (+ ELU + dropout) its operand while
 // staging it, uses it as the MFMA operand and writes it to `side` (the layer's backward and, for the trans pair, the
 // comb pair of the same layer read it) — the GraphNorm apply launch and its read of xa disappear.
+// Laboratory build only (-DGLASS_DENSE_TRACE; tools/dense_trace.py): per-wave wall-clock stamps (100 MHz) of the phases of
+// one selected dense kernel, [workgroup][wave][8 slots].
+#ifdef GLASS_DENSE_TRACE
+extern __device__ unsigned long long* g_dense_trace;
+extern __device__ int g_dense_trace_sel;
+#define D_STAMP(sel, slot)                                                                                         \
+    do {                                                                                                           \
+        if (g_dense_trace && g_dense_trace_sel == (sel) && (threadIdx.x & 63) == 0)                                \
+            g_dense_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64();            \
+    } while (0)
+#else
+#define D_STAMP(sel, slot) do { } while (0)
+#endif
+
 struct GnPrologue {
     const float* saved;  // nullptr: no prologue
     int C, act;

@@ -19,7 +19,10 @@ namespace glass {
 #ifndef GLASS_ACC_REP
 #define GLASS_ACC_REP 16
 #endif
-// replicas a column's adds are spread over (workgroup b -> replica b % kAccRep).  Adds to ONE address queue at the memory-side
+// replicas a block holds room for; a producer spreads its adds over the first n_rep of them (workgroup b -> replica
+// b % n_rep) and the consumer folds the same n_rep — 16 behind the statistics kernel, whose ~134 workgroups all finish
+// together, 4 behind the dense kernels' epilogues, which finish spread over the launch (every consumer workgroup reads
+// n_rep * 2 KB at hidden 64: with 16 that was as much L2 traffic as the weight image).  Adds to ONE address queue at the memory-side
 // atomic unit (~100 ns each, measured: the 134-workgroup statistics kernel 10.6 / 8.1 / 6.6 us with 4 / 8 / 16 replicas, 5.4 us
 // when it writes plain partials); the consumers' fold loads are all in flight at once, so their cost barely moves.
 constexpr int kAccRep = GLASS_ACC_REP;
@@ -46,7 +49,8 @@ __device__ __forceinline__ void gn_acc_add(long long* __restrict__ acc, int rep,
 // Every thread of the workgroup calls this; afterwards out[which * C + c] (LDS doubles, 2 * C of them, C = n_src * C_each)
 // holds the two sums of every column.  acc: n_src consecutive accumulator blocks of C_each columns — block k covers columns
 // k * C_each .. (the column blocks of a jumping-knowledge buffer, each summed by the kernel that wrote it).
-__device__ __forceinline__ void gn_acc_fold(const long long* __restrict__ acc, int C_each, int n_src, double* out, double scale) {
+__device__ __forceinline__ void gn_acc_fold(const long long* __restrict__ acc, int C_each, int n_src, double* out, double scale,
+                                            int n_rep = kAccRep) {
     const int C = C_each * n_src;
     const double inv = 1.0 / scale;
     for (int item = threadIdx.x; item < 2 * C; item += blockDim.x) {
@@ -56,6 +60,7 @@ __device__ __forceinline__ void gn_acc_fold(const long long* __restrict__ acc, i
         long long hi = 0, lo = 0;
 #pragma unroll
         for (int r = 0; r < kAccRep; ++r) {
+            if (r >= n_rep) break;  // (the producers of this sum used the first n_rep replicas)
             const long long* p = base + gn_acc_index(r, which, cl, C_each);
             hi += p[0];
             lo += p[1];
@@ -69,6 +74,7 @@ __device__ __forceinline__ void gn_acc_fold(const long long* __restrict__ acc, i
 struct GnExactSrc {
     const long long* acc;  // nullptr: the statistics are final in `saved` already
     int n_src;             // accumulator blocks (of C / n_src columns each)
+    int n_rep;             // replicas the producers spread their adds over (the first n_rep of a block's kAccRep)
     const float *gamma, *beta, *alpha;
     float eps;
     float* saved_w;        // [4C] mean, rstd, scale, shift: written by workgroup 0 for the backward
@@ -79,7 +85,7 @@ struct GnExactSrc {
 __device__ __forceinline__ void gn_fwd_coef_block(const GnExactSrc& src, const float* __restrict__ saved, int C, int64_t N,
                                                   double* sums, float* coef_s, float* mu_rstd_s) {
     if (src.acc) {
-        gn_acc_fold(src.acc, C / src.n_src, src.n_src, sums, kAccScaleFwd);
+        gn_acc_fold(src.acc, C / src.n_src, src.n_src, sums, kAccScaleFwd, src.n_rep);
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float mu, rstd, scale, shift;
             gn_fwd_coeffs(sums[c], sums[C + c], (double)N, src.gamma[c], src.beta[c], src.alpha[c], src.eps, mu, rstd, scale, shift);
@@ -103,6 +109,71 @@ __device__ __forceinline__ void gn_fwd_coef_block(const GnExactSrc& src, const f
         }
     }
     __syncthreads();
+}
+
+// The two sums of C columns held by ONE accumulator block, for a workgroup of T = 4C threads, WITHOUT a barrier or LDS:
+// wave w, lane l: column c = 16w + (l & 15), sum `which` = (l >> 4) & 1, replica half = l >> 5 — every 16 lanes read 256
+// contiguous bytes per load (with the four lanes of a column ADJACENT, each lane quad touched four cache lines per load and
+// the fold cost 2.4 us more) — all loads in flight at once next to whatever the caller issued before; the four lanes of
+// a column combine by lane shuffles (integer adds: any order gives the same bits).  Returns true in the lanes l < 16, which
+// then hold v0 = sum 0 and v1 = sum 1 of their column `col`.
+template <int C, int T>
+__device__ __forceinline__ bool gn_acc_col_sums(const long long* __restrict__ acc, int n_rep, double scale, int& col, double& v0,
+                                                double& v1) {
+    static_assert(T == 4 * C && C % 16 == 0 && kAccRep % 2 == 0, "four lanes per column, sixteen columns per wave");
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = 16 * w + (l & 15), which = (l >> 4) & 1, half = l >> 5;
+    col = c;
+    long long vh[kAccRep / 2], vl[kAccRep / 2];
+    const int per = n_rep >> 1;  // replicas per lane (n_rep is even)
+#pragma unroll
+    for (int r = 0; r < kAccRep / 2; ++r) {
+        const int rr = r < per ? half * per + r : 0;  // (clamped: a replica read twice is not added)
+        const long long* p = acc + gn_acc_index(rr, which, c, C);
+        vh[r] = p[0];
+        vl[r] = p[1];
+    }
+    long long hi = 0, lo = 0;
+#pragma unroll
+    for (int r = 0; r < kAccRep / 2; ++r) {
+        hi += r < per ? vh[r] : 0;
+        lo += r < per ? vl[r] : 0;
+    }
+    hi += __shfl_xor(hi, 32);
+    lo += __shfl_xor(lo, 32);
+    const double v = ((double)hi + (double)lo * (1.0 / 1099511627776.0)) * (1.0 / scale);
+    const double other = __shfl_xor(v, 16);  // lanes with which == 0 receive sum 1
+    v0 = v;
+    v1 = other;
+    return l < 16;
+}
+
+// Forward coefficients of a GraphNorm (C columns, one accumulator block) into coef_s (LDS: scale[C] | shift[C]) WITHOUT a
+// barrier: the caller's next barrier publishes them.  Workgroup 0 also writes saved_w.
+template <int C, int T>
+__device__ __forceinline__ void gn_fwd_coef_nobarrier(const GnExactSrc& src, const float* __restrict__ saved, int64_t N,
+                                                      float* coef_s) {
+    const int t = threadIdx.x;
+    if (!src.acc) {  // final statistics: scale | shift are saved[2C .. 4C)
+        if (t < 2 * C) coef_s[t] = saved[2 * C + t];
+        return;
+    }
+    const int c = 16 * (t >> 6) + (t & 15);
+    const float gamma = src.gamma[c], beta = src.beta[c], alpha = src.alpha[c];
+    double s, q;
+    int col;
+    if (gn_acc_col_sums<C, T>(src.acc, src.n_rep, kAccScaleFwd, col, s, q)) {
+        float mu, rstd, scale, shift;
+        gn_fwd_coeffs(s, q, (double)N, gamma, beta, alpha, src.eps, mu, rstd, scale, shift);
+        coef_s[c] = scale;
+        coef_s[C + c] = shift;
+        if (blockIdx.x == 0 && src.saved_w) {
+            src.saved_w[c] = mu;
+            src.saved_w[C + c] = rstd;
+            src.saved_w[2 * C + c] = scale;
+            src.saved_w[3 * C + c] = shift;
+        }
+    }
 }
 
 }  // namespace glass

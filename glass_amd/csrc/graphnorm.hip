@@ -76,7 +76,7 @@ __device__ __forceinline__ void load_cols(float (&dst)[VW], const float* src, in
 // and let row slot 0 write them to partial[blk][which][c].
 template <int VW>
 __device__ __forceinline__ void block_reduce_store(double (&s0)[VW], double (&s1)[VW], double* lds, int tc, int tr,
-                                                   int TC, int rpb, double* partial, int c0, int C, bool exact = false) {
+                                                   int TC, int rpb, double* partial, int c0, int C, int exact = 0) {
     double* mine = lds + (size_t)threadIdx.x * 2 * VW;
 #pragma unroll
     for (int k = 0; k < VW; ++k) {
@@ -98,8 +98,8 @@ __device__ __forceinline__ void block_reduce_store(double (&s0)[VW], double (&s1
 #pragma unroll
             for (int k = 0; k < VW; ++k)
                 if (c0 + k < C) {
-                    gn_acc_add(a, blockIdx.x % kAccRep, 0, c0 + k, C, s0[k], kAccScaleFwd);
-                    gn_acc_add(a, blockIdx.x % kAccRep, 1, c0 + k, C, s1[k], kAccScaleFwd);
+                    gn_acc_add(a, blockIdx.x % exact, 0, c0 + k, C, s0[k], kAccScaleFwd);
+                    gn_acc_add(a, blockIdx.x % exact, 1, c0 + k, C, s1[k], kAccScaleFwd);
                 }
             return;
         }
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void gn_stats_kernel(const float* __restric
                 q[k] += d * d;
             }
     }
-    block_reduce_store<VW>(s, q, lds, tc, tr, TC, rpb, partial, c0, C, exact != 0);
+    block_reduce_store<VW>(s, q, lds, tc, tr, TC, rpb, partial, c0, C, exact);
 }
 
 // ---- finalize: sum the workgroup partials in fixed order; derive mean / rstd / scale / shift ----
@@ -351,15 +351,17 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __res
 
 // Backward apply with the finalize folded in: the two column sums come from the exact accumulators the data-gradient
 // epilogues added to (gn_acc.h); every workgroup folds the replicas and derives the coefficients of ALL columns in its
-// prologue (C <= 128), workgroup 0 also writes the parameter gradients — no finalize launch.
-template <int VW>
+// prologue (C <= 128), workgroup 0 also writes the parameter gradients — no finalize launch.  The thread's first batch of
+// rows is requested BEFORE the fold so that both share one memory round trip (a barrier drains outstanding loads);
+// CC = 64: the barrier-free fold by four lanes per column, CC = 0: any C <= 128 through LDS.
+template <int VW, int CC>
 __global__ __launch_bounds__(kBlock) void gn_bwd_apply_acc_kernel(const float* __restrict__ dy, int64_t lddy,
                                                                   const float* __restrict__ x, int64_t ldx,
                                                                   float* __restrict__ dx, int64_t lddx,
                                                                   const float* __restrict__ addend, int64_t ldadd,
                                                                   int64_t N, int C, int tc_log2,
                                                                   const float* __restrict__ saved,
-                                                                  const long long* __restrict__ acc,
+                                                                  const long long* __restrict__ acc, int n_rep,
                                                                   const float* __restrict__ gamma,
                                                                   const float* __restrict__ alpha,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
@@ -367,25 +369,47 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_acc_kernel(const float* _
                                                                   Drop drop, const uint64_t* __restrict__ rng_state) {
     __shared__ double sums[kBlock];
     __shared__ float coef_s[3 * (kBlock / 2)];
-    gn_acc_fold(acc, C, 1, sums, kAccScaleBwd);
-    if ((int)threadIdx.x < C) {
-        const int c = threadIdx.x;
+    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
+    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
+    const int c0 = tc * VW;
+    const bool col_ok = c0 < C;
+    const int64_t stride = (int64_t)gridDim.x * rpb;
+    const int64_t r_first = (int64_t)blockIdx.x * rpb + tr;
+    F<VW> g[kUnroll], xv[kUnroll], ad[kUnroll];
+    auto load_batch = [&](int64_t r) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int64_t rr = r + u * stride;
+            if (col_ok && rr < N) {
+                g[u].load(dy + rr * lddy + c0);
+                xv[u].load(x + rr * ldx + c0);
+                if (addend) ad[u].load(addend + rr * ldadd + c0);
+            }
+        }
+    };
+    load_batch(r_first);
+    auto finish_col = [&](int c, double s1, double s2) __attribute__((always_inline)) {
         float A, Bx, K, da;
-        gn_bwd_coeffs(sums[c], sums[C + c], (double)N, gamma[c], alpha[c], saved[c], saved[C + c], A, Bx, K, da);
+        gn_bwd_coeffs(s1, s2, (double)N, gamma[c], alpha[c], saved[c], saved[C + c], A, Bx, K, da);
         coef_s[c] = A;
         coef_s[C + c] = Bx;
         coef_s[2 * C + c] = K;
         if (blockIdx.x == 0) {
-            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)sums[C + c];
-            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)sums[c];
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
             if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + da;
         }
+    };
+    if (CC > 0) {
+        double s1, s2;
+        int col;
+        if (gn_acc_col_sums<(CC > 0 ? CC : 64), kBlock>(acc, n_rep, kAccScaleBwd, col, s1, s2)) finish_col(col, s1, s2);
+    } else {
+        gn_acc_fold(acc, C, 1, sums, kAccScaleBwd, n_rep);
+        if ((int)threadIdx.x < C) finish_col(threadIdx.x, sums[threadIdx.x], sums[C + threadIdx.x]);
     }
     __syncthreads();
-    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
-    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
-    const int c0 = tc * VW;
-    if (c0 >= C) return;
+    if (!col_ok) return;
     float scale[VW], shift[VW], A[VW], Bx[VW], K[VW];
     load_cols<VW>(scale, saved + 2 * C, c0, C);
     load_cols<VW>(shift, saved + 3 * C, c0, C);
@@ -399,18 +423,8 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_acc_kernel(const float* _
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
     }
-    const int64_t stride = (int64_t)gridDim.x * rpb;
-    for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * kUnroll) {
-        F<VW> g[kUnroll], xv[kUnroll], ad[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int64_t rr = r + u * stride;
-            if (rr < N) {
-                g[u].load(dy + rr * lddy + c0);
-                xv[u].load(x + rr * ldx + c0);
-                if (addend) ad[u].load(addend + rr * ldadd + c0);
-            }
-        }
+    for (int64_t r = r_first; r < N; r += stride * kUnroll) {
+        if (r != r_first) load_batch(r);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int64_t rr = r + u * stride;
@@ -514,18 +528,18 @@ extern "C" int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_
 // The statistics pass alone, into exact accumulators (gn_acc.h; zeroed by glass_step_prologue_f32): the consumer kernel
 // derives the coefficients (glass_gn_src), no finalize launch.
 extern "C" int glass_graphnorm_stats_exact_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, int64_t* acc,
-                                               void* stream) {
-    GLASS_REQUIRE(x && acc && n_rows > 0 && C > 0 && ldx >= C, "graphnorm_stats_exact: bad arguments");
+                                               int n_rep, void* stream) {
+    GLASS_REQUIRE(x && acc && n_rows > 0 && C > 0 && ldx >= C && n_rep >= 1 && n_rep <= kAccRep, "graphnorm_stats_exact: bad arguments");
     const bool vec = C % 4 == 0 && ldx % 4 == 0 && aligned16(x);
     const Tiling t = make_tiling(C, vec);
     // (fewer, longer workgroups to thin out the adds per replica were slower: 8.3 / 12.7 us with half / a quarter of them)
     dim3 gs(stat_blocks(n_rows, t), t.ctiles);
     if (vec) {
         hipLaunchKernelGGL(gn_stats_kernel<4>, gs, dim3(kBlock), 0, (hipStream_t)stream, x, ldx, n_rows, (int)C, t.tc_log2,
-                           reinterpret_cast<double*>(acc), 1);
+                           reinterpret_cast<double*>(acc), n_rep);
     } else {
         hipLaunchKernelGGL(gn_stats_kernel<1>, gs, dim3(kBlock), 0, (hipStream_t)stream, x, ldx, n_rows, (int)C, t.tc_log2,
-                           reinterpret_cast<double*>(acc), 1);
+                           reinterpret_cast<double*>(acc), n_rep);
     }
     return launch_status("glass_graphnorm_stats_exact_f32");
 }
@@ -624,9 +638,16 @@ extern "C" int glass_graphnorm_bwd_from_stats_f32(const float* dy, int64_t lddy,
                       "graphnorm_bwd_from_stats: the exact form serves C = 16 .. 128 (powers of two), 16-B aligned operands");
         GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd_from_stats: bad dropout args");
         const Tiling t4 = make_tiling(C, true);
-        hipLaunchKernelGGL(gn_bwd_apply_acc_kernel<4>, dim3(apply_blocks(n_rows, t4)), dim3(kBlock), 0, (hipStream_t)stream, dy, lddy,
-                           x, ldx, dx, lddx, addend, ldadd, n_rows, (int)C, t4.tc_log2, saved, (const long long*)partial, gamma,
-                           alpha, dgamma, dbeta, dalpha, accumulate, act, make_drop(p_drop, call_id, C), rng_state);
+        const int n_rep = (int)-nblk;  // replicas the producers used
+        GLASS_REQUIRE(n_rep <= kAccRep && (n_rep == 1 || n_rep % 2 == 0), "graphnorm_bwd_from_stats: nblk = -(replicas), 2 .. 16");
+        if (C == 64 && n_rep >= 2)
+            hipLaunchKernelGGL((gn_bwd_apply_acc_kernel<4, 64>), dim3(apply_blocks(n_rows, t4)), dim3(kBlock), 0, (hipStream_t)stream,
+                               dy, lddy, x, ldx, dx, lddx, addend, ldadd, n_rows, (int)C, t4.tc_log2, saved, (const long long*)partial,
+                               n_rep, gamma, alpha, dgamma, dbeta, dalpha, accumulate, act, make_drop(p_drop, call_id, C), rng_state);
+        else
+            hipLaunchKernelGGL((gn_bwd_apply_acc_kernel<4, 0>), dim3(apply_blocks(n_rows, t4)), dim3(kBlock), 0, (hipStream_t)stream,
+                               dy, lddy, x, ldx, dx, lddx, addend, ldadd, n_rows, (int)C, t4.tc_log2, saved, (const long long*)partial,
+                               n_rep, gamma, alpha, dgamma, dbeta, dalpha, accumulate, act, make_drop(p_drop, call_id, C), rng_state);
         return launch_status("glass_graphnorm_bwd_from_stats_f32 (exact)");
     }
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_bwd_from_stats: bad dropout args");

@@ -268,14 +268,17 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     // comb-shaped (I == O, an even number of output tiles): in the effective-weight form half of the output tiles hold the
     // few labeled rows only, so the other half gets twice the slabs to fill the chip
     if (I == O && ceil_div(O, kOT) % 2 == 0) max_slabs *= 2;
+    const int64_t lim = max_slabs;
     if (max_slabs > 128) max_slabs = 128;
     // Small graphs: this kernel shares ONE launch with the data gradient of the same pair (dual_bwd_kernel: N/64 row
     // tiles + these slabs, two workgroups per CU).  Keep the sum within the 512 resident workgroups of the chip — a
     // handful of surplus workgroups would wait for a free slot and run as a second round (28 vs ~21 us at ppi_bp-shape).
     if (N <= 100000) {
         const int64_t room = (2 * 256 - 4 - ceil_div(N, 64)) / tiles;
-        if (room >= 32 && room < max_slabs) max_slabs = room;
-        // (laboratory: with GLASS_WGRAD_STAGED the trans pair wants room slabs of <= 80 rows instead)
+        // ... and use all of them: inside the shared launch the weight-gradient workgroups are the longer ones (phase
+        // stamps at ppi_bp-shape, trans pair: 126 slabs of 136 rows live 17.9 us beside data-gradient tiles done after
+        // 14.6 us; 238 slabs of 72 rows: the launch 19.5 -> 17.5 us, the deferred reduction + 0.9 us)
+        if (room >= 32) max_slabs = room < lim ? room : lim;
     }
     if (max_slabs < 32) max_slabs = 32;
     int64_t rows = ceil_div(N, max_slabs);

@@ -530,12 +530,12 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     const int tc = pow2_ceil_cap(vec ? C / 4 : C, kBlock);
     int tc_log2 = 0;
     while ((1 << tc_log2) < tc) ++tc_log2;
-    GnExactSrc esrc{nullptr, 1, nullptr, nullptr, nullptr, 0.f, nullptr};
+    GnExactSrc esrc{nullptr, 1, kAccRep, nullptr, nullptr, nullptr, 0.f, nullptr};
     if (gn_src) {
         GLASS_REQUIRE(gn_src->acc && gn_src->gamma && gn_src->beta && gn_src->alpha && gn_src->n_src >= 1 &&
-                          C % gn_src->n_src == 0,
+                          C % gn_src->n_src == 0 && gn_src->n_rep >= 1 && gn_src->n_rep <= kAccRep,
                       "readout_train: bad gn_src (n_src accumulator blocks of C / n_src columns, all pointers set)");
-        esrc = GnExactSrc{reinterpret_cast<const long long*>(gn_src->acc), (int)gn_src->n_src, gn_src->gamma, gn_src->beta,
+        esrc = GnExactSrc{reinterpret_cast<const long long*>(gn_src->acc), (int)gn_src->n_src, (int)gn_src->n_rep, gn_src->gamma, gn_src->beta,
                           gn_src->alpha, gn_src->eps, const_cast<float*>(gn_saved)};
     }
     R1Args a1{jk, ldj, gn_saved, alpha, pos, (int)Smax, pool_mode, Wh, bh, target, loss_mode, (int)B, (int)C, (int)K,

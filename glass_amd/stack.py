@@ -81,8 +81,8 @@ def _comb_eff_ok(conv, labels, H):
 class _PendingStats:
     """Forward sums of a GraphNorm still in exact accumulators (gn_acc.h): the kernel that applies it derives the
     coefficients from `acc` (n_src consecutive blocks) and writes `saved` [4C] for the backward."""
-    def __init__(self, saved, acc, n_src, mod):
-        self.saved, self.src = saved, _lib.GnSrc.of(acc, n_src, mod)
+    def __init__(self, saved, acc, n_src, mod, n_rep):
+        self.saved, self.src = saved, _lib.GnSrc.of(acc, n_src, n_rep, mod)
 
 
 def _saved_args(saved):
@@ -92,11 +92,22 @@ def _saved_args(saved):
     return saved.data_ptr(), 0
 
 
+# replicas of the exact accumulators (gn_acc.h) by producer: the stand-alone statistics kernel's workgroups all finish
+# together (their adds to one replica queue up: 10.6 / 8.1 / 6.6 us with 4 / 8 / 16), the dense kernels' epilogues are spread
+# over the launch — and every consumer workgroup reads n_rep * 2 KB
+REP_STATS, REP_DENSE = 16, int(os.environ.get("GLASS_REP_DENSE", "16"))
+
+
+def _rep(t):
+    """replicas in use for an accumulator tensor (int64), 0 for the float64 partials form"""
+    return REP_DENSE if t.dtype == torch.int64 else 0
+
+
 def _stats_args(stats):
     """(pointer, stats_exact) of an epilogue statistics target: float64 partials, or int64 exact accumulators."""
     if stats is None:
         return 0, 0
-    return stats.data_ptr(), int(stats.dtype == torch.int64)
+    return stats.data_ptr(), _rep(stats)
 
 
 def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
@@ -122,7 +133,7 @@ def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels):
     rc = _lib.load().glass_comb_eff_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), mask.data_ptr(), float(conv.z_ratio),
                                             conv._stack_eff["comb"][1].data_ptr(), out.data_ptr(), out.stride(0), n, H,
                                             gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(),
-                                            galpha.data_ptr(), gact, float(gp), rng, gcall, int(gpart.dtype == torch.int64),
+                                            galpha.data_ptr(), gact, float(gp), rng, gcall, _rep(gpart),
                                             xa.data_ptr(), xa.stride(0),
                                             xb.data_ptr(), xb.stride(0), ws.data_ptr(), labels.rows.data_ptr(),
                                             labels.count.data_ptr(), labels.cap, _stream())
@@ -164,9 +175,9 @@ class _GN:
         """The statistics pass alone, into exact accumulators: the consumer derives the coefficients (no finalize launch)."""
         n, C = x.shape
         saved = torch.empty(4 * C, dtype=torch.float32, device=x.device)
-        rc = _lib.load().glass_graphnorm_stats_exact_f32(x.data_ptr(), x.stride(0), n, C, acc.data_ptr(), _stream())
+        rc = _lib.load().glass_graphnorm_stats_exact_f32(x.data_ptr(), x.stride(0), n, C, acc.data_ptr(), REP_STATS, _stream())
         _check(rc, "glass_graphnorm_stats_exact_f32")
-        return _PendingStats(saved, acc, 1, self.mod)
+        return _PendingStats(saved, acc, 1, self.mod, REP_STATS)
 
     def finalize(self, stats, n_rows):
         """saved[4C] from statistics the producers' epilogues wrote (list of [nblk, 2, C_each] float64 buffers)."""
@@ -198,7 +209,7 @@ class _GN:
         rc = _lib.load().glass_graphnorm_bwd_from_stats_f32(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0),
                                                             dx.data_ptr(), dx.stride(0), ap, lda, n, C,
                                                             m.weight.data_ptr(), m.mean_scale.data_ptr(), saved.data_ptr(),
-                                                            partial.data_ptr(), -1 if partial.dtype == torch.int64 else partial.shape[0],
+                                                            partial.data_ptr(), -_rep(partial) if partial.dtype == torch.int64 else partial.shape[0],
                                                             m.weight.grad.data_ptr(), m.bias.grad.data_ptr(),
                                                             m.mean_scale.grad.data_ptr(), acc, act, float(p_drop), rng,
                                                             call_id, ws.data_ptr(), _stream())
@@ -250,7 +261,7 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=Non
     if gn is not None:
         gpart, gx, gsaved, galpha, gact, gp, gcall = gn
         gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall,
-                 int(gpart.dtype == torch.int64))  # int64 buffer = the exact accumulators of gn_acc.h
+                 _rep(gpart))  # int64 buffer = the exact accumulators of gn_acc.h
     else:
         gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0, 0)
     rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
@@ -278,7 +289,7 @@ def _dual_bwd(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, xa, xb, pe
     if gn is not None:
         gpart, gx, gsaved, galpha, gact, gp, gcall = gn
         gargs = (gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(), galpha.data_ptr(), gact, float(gp), gcall,
-                 int(gpart.dtype == torch.int64))
+                 _rep(gpart))
     else:
         gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0, 0)
     rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
@@ -539,7 +550,7 @@ class StackProgram:
             rec = {"h": h, "T": T, "a": a, "g": g, "gsaved": getattr(gsaved, "saved", gsaved), "c": c, "pc": pc}
             if not last:
                 if acc_fwd is not None:   # the next layer's trans kernel derives gns[l]'s coefficients from the sums of c_l
-                    nsaved = _PendingStats(torch.empty(4 * H, **f32), cstat, 1, emb.gns[l])
+                    nsaved = _PendingStats(torch.empty(4 * H, **f32), cstat, 1, emb.gns[l], REP_DENSE)
                 else:
                     nsaved = _GN(emb.gns[l]).finalize([cstat], n)
                 rec["nsaved"] = getattr(nsaved, "saved", nsaved)
@@ -549,7 +560,7 @@ class StackProgram:
         gnf = _GN(emb.gns[-1])
         if acc_fwd is not None:  # the readout's first kernel derives the final GraphNorm's coefficients
             st["final_saved"] = _PendingStats(torch.empty(4 * C_out, **f32), acc_fwd[L:] if emb.jk else acc_fwd[2 * L - 1],
-                                              L if emb.jk else 1, emb.gns[-1])
+                                              L if emb.jk else 1, emb.gns[-1], REP_DENSE)
         else:
             st["final_saved"] = gnf.finalize(cstats if emb.jk else cstats[-1:], n)
         if readout is not None:

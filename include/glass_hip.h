@@ -421,9 +421,13 @@ int glass_step_prologue_f32(const float* const* src, float* const* dst, const in
  *     associative, so the sums do not depend on the order the workgroups arrive in — bitwise repeatable (float atomics
  *     are not).  Forward sums: resolution 2^-52 per workgroup partial, range 2^50; backward sums: 2^-64, range 2^38.
  *     The consumers fold the replicas in every workgroup's prologue and derive the coefficients themselves:
- *       backward (gn_exact != 0 on the data-gradient entries): glass_graphnorm_bwd_from_stats_f32 with nblk = -1 and
- *         partial = the accumulators — finalize + apply as ONE launch;
- *       forward (stats_exact != 0: `stats` points to accumulators; glass_graphnorm_stats_exact_f32 for a stand-alone
+ *     stats_exact / gn_exact / n_rep = the number of replicas (2, 4, 8 or 16; 0 = the partials form) a producer spreads
+ *     its adds over — workgroup b adds to replica b % n_rep — and its consumer folds: adds to ONE address queue at the
+ *     memory-side atomic unit, so producers whose workgroups all finish together want many, while every consumer
+ *     workgroup reads n_rep * 2 KB (hidden 64).
+ *       backward (gn_exact = n_rep on the data-gradient entries): glass_graphnorm_bwd_from_stats_f32 with nblk = -n_rep
+ *         and partial = the accumulators — finalize + apply as ONE launch;
+ *       forward (stats_exact = n_rep: `stats` points to accumulators; glass_graphnorm_stats_exact_f32 for a stand-alone
  *         statistics pass): the kernel that applies the GraphNorm receives a glass_gn_src — the accumulators and the
  *         GraphNorm's parameters — instead of final statistics, and its workgroup 0 writes gn_saved[4C] (mean, rstd,
  *         scale, shift) for the backward.  n_src accumulator blocks of C / n_src columns each (the column blocks of a
@@ -431,12 +435,14 @@ int glass_step_prologue_f32(const float* const* src, float* const* dst, const in
 struct glass_gn_src {
     const int64_t* acc;
     int64_t n_src;
+    int64_t n_rep; /* replicas the producers spread their adds over: the value they were given as stats_exact */
     const float *gamma, *beta, *alpha;
     float eps;
 };
 int glass_gn_exact_supported(int64_t H);
 int64_t glass_gn_exact_words(int64_t C);
-int glass_graphnorm_stats_exact_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, int64_t* acc, void* stream);
+int glass_graphnorm_stats_exact_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, int64_t* acc, int n_rep,
+                                    void* stream);
 
 /* K8  prediction head + loss (the bare nn.Linear head of GLASSTest.py:159-160 followed by
  *     CrossEntropyLoss, GLASSTest.py:69, mode 0, target int64[B]; or BCEWithLogitsLoss on the flattened

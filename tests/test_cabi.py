@@ -187,10 +187,10 @@ def test_step_program_entry_points_validate_on_the_host():
     # exact GraphNorm accumulators: hidden 64 only; a glass_gn_src with a missing pointer is rejected before any launch
     assert lib.glass_gn_exact_supported(64) == 1 and lib.glass_gn_exact_supported(128) == 0 and lib.glass_gn_exact_supported(16) == 0
     assert lib.glass_gn_exact_words(64) > 0 and lib.glass_gn_exact_words(64) % (2 * 64 * 2) == 0
-    bad = _lib.GnSrc(p, 1, p, None, p, 1e-5)
+    bad = _lib.GnSrc(p, 1, 4, p, None, p, 1e-5)
     assert lib.glass_dual_linear_fwd_f32(p, 64, None, 0, p, p, p, 0.9, 1, p, 128, p, 64, 16, 64, None, 0, p, bad.ptr, 0, 0.0, None,
                                          0, p, 64, None, 0, None) == -1
-    assert lib.glass_graphnorm_stats_exact_f32(p, 64, 16, 64, None, None) == -1
+    assert lib.glass_graphnorm_stats_exact_f32(p, 64, 16, 64, None, 16, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -3,7 +3,8 @@
 // stream, prints algorithmic GB/s against the HBM roofline, and spot-checks rows in fp64.
 // Also the program to put after `rocprofv3 ... --` for per-kernel traces and PMC counters.
 //
-//   spmm_bench <shape> [H] [iters] [--rp K] [--full]
+//   spmm_bench <shape> [H] [iters] [--rp K] [--full] [--ld L]
+//   --ld L : row stride of X and Y in floats (>= H; default H): the product over a column block of a wider matrix
 //   --rp K : override the plan's flat-mode factor (header word 13; K = 0 also clears the flat-share word 15, i.e. the
 //            row-mode-only kernel) for A/B runs; --full : check EVERY row in fp64
 //   shape: ppi_bp | hpo_neuro | em_user | powerlaw | density-like | N:PAIRS[:zipf] | calib:N
@@ -97,15 +98,18 @@ extern "C" int glass_k1_trace_set(unsigned long long* p);
 int main(int argc, char** argv) {
     int rp_override = -1;
     bool full = false;
+    int64_t ld = 0;
     std::vector<char*> pos_args;
     for (int i = 1; i < argc; ++i) {
         if (!strcmp(argv[i], "--rp") && i + 1 < argc) rp_override = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--full")) full = true;
+        else if (!strcmp(argv[i], "--ld") && i + 1 < argc) ld = atoll(argv[++i]);
         else pos_args.push_back(argv[i]);
     }
     std::string shape = pos_args.size() > 0 ? pos_args[0] : "ppi_bp";
     int64_t H = pos_args.size() > 1 ? atoll(pos_args[1]) : 64;
     int iters = pos_args.size() > 2 ? atoi(pos_args[2]) : 50;
+    if (ld < H) ld = H;
     int64_t n, pairs;
     double zipf = 0;
     if (shape == "ppi_bp") n = 17080, pairs = 316951;
@@ -151,7 +155,7 @@ int main(int argc, char** argv) {
     }
     const int64_t ws_bytes = glass_spmm_ws_bytes(plan.data(), H);
 
-    std::vector<float> X((size_t)n * H);
+    std::vector<float> X((size_t)n * ld);
     std::mt19937 r32(1);
     std::normal_distribution<float> N01(0.f, 1.f);
     for (auto& v : X) v = N01(r32);
@@ -163,19 +167,19 @@ int main(int argc, char** argv) {
     HIP_OK(hipMalloc(&d_col, nnz * 4));
     HIP_OK(hipMalloc(&d_val, nnz * 4));
     HIP_OK(hipMalloc(&d_plan, words * 4));
-    HIP_OK(hipMalloc(&d_X, (size_t)n * H * 4));
-    HIP_OK(hipMalloc(&d_Y, (size_t)n * H * 4));
+    HIP_OK(hipMalloc(&d_X, (size_t)n * ld * 4));
+    HIP_OK(hipMalloc(&d_Y, (size_t)n * ld * 4));
     if (ws_bytes > 0) HIP_OK(hipMalloc(&d_ws, ws_bytes));
     HIP_OK(hipMemcpy(d_rowptr, g.rowptr.data(), (n + 1) * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_col, g.col.data(), nnz * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_val, g.val.data(), nnz * 4, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(d_plan, plan.data(), words * 4, hipMemcpyHostToDevice));
-    HIP_OK(hipMemcpy(d_X, X.data(), (size_t)n * H * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(d_X, X.data(), (size_t)n * ld * 4, hipMemcpyHostToDevice));
 
     hipStream_t st;
     HIP_OK(hipStreamCreate(&st));
     auto run = [&]() {
-        int rc = glass_spmm_csr_f32(d_rowptr, d_col, d_val, d_X, H, d_Y, H, n, H, plan.data(), d_plan, d_ws, st);
+        int rc = glass_spmm_csr_f32(d_rowptr, d_col, d_val, d_X, ld, d_Y, ld, n, H, plan.data(), d_plan, d_ws, st);
         if (rc) {
             fprintf(stderr, "spmm rc=%d: %s\n", rc, glass_last_error_string());
             exit(4);
@@ -229,8 +233,8 @@ int main(int argc, char** argv) {
     const double bytes = (double)nnz * (4.0 * H + 8) + (double)n * (4.0 * H + 4);
 
     // spot check 64 rows in fp64
-    std::vector<float> Y((size_t)n * H);
-    HIP_OK(hipMemcpy(Y.data(), d_Y, (size_t)n * H * 4, hipMemcpyDeviceToHost));
+    std::vector<float> Y((size_t)n * ld);
+    HIP_OK(hipMemcpy(Y.data(), d_Y, (size_t)n * ld * 4, hipMemcpyDeviceToHost));
     double max_err = 0, max_ref = 0;
     const int64_t n_check = full ? n : 64;
     for (int64_t k = 0; k < n_check; ++k) {
@@ -241,8 +245,8 @@ int main(int argc, char** argv) {
         }
         for (int64_t c = 0; c < H; ++c) {
             double s = 0;
-            for (int32_t e = g.rowptr[r]; e < g.rowptr[r + 1]; ++e) s += (double)g.val[e] * X[(size_t)g.col[e] * H + c];
-            max_err = std::max(max_err, fabs(s - (double)Y[(size_t)r * H + c]));
+            for (int32_t e = g.rowptr[r]; e < g.rowptr[r + 1]; ++e) s += (double)g.val[e] * X[(size_t)g.col[e] * ld + c];
+            max_err = std::max(max_err, fabs(s - (double)Y[(size_t)r * ld + c]));
             max_ref = std::max(max_ref, fabs(s));
         }
     }
