@@ -141,7 +141,7 @@ class ParamArena(FlatGradBucket):
                         # hidden 64: the comb pair's effective per-label weights (layouts 6 / 7: unlabeled-row image, then
                         # labeled-row image) for glass_comb_eff_fwd/bwd_f32 — taken when the batch's labeled rows are listed
                         We, WTe = torch.empty_like(Wimg), torch.empty_like(WTimg)
-                        self._packs.append((W, We, O, K, 0 | (6 << 1), mod))
+                        self._packs.append((W, We, O, K, 0 | (int(_lib.load().glass_comb_eff_fwd_layout(O // 2)) << 1), mod))
                         self._packs.append((W, WTe, K, O, 1 | (7 << 1), mod))
                         mod._stack_eff = {"comb": (We, WTe)}
                 else:

@@ -31,6 +31,9 @@
 
 namespace glass {
 
+#ifndef GLASS_COMB_FWD_V2
+#define GLASS_COMB_FWD_V2 1  // comb forward at hidden 64: weights in registers, rows through LDS in stages (comb_fwd_eff2_kernel)
+#endif
 #ifndef GLASS_FUSED_WGRAD_STAGES
 #define GLASS_FUSED_WGRAD_STAGES 2  // pipeline stages of the weight-gradient workgroups inside the fused backward launches
 #endif
@@ -742,6 +745,209 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
     }    D_STAMP(1, 4);
 }
 
+// ---- comb forward, second form (hidden 64): weights in registers, rows through LDS in four 16-row stages ---------------
+// The first form gives each wave 16 rows and stages the weight image in LDS: every wave of every workgroup is in the same
+// phase at the same time — a burst of loads (the launch's 27 MB in ~3 us), then prologue arithmetic on half the lanes, then
+// 1.7 us of MFMAs, then a burst of stores: 12.7 us per wave for 1.7 us of matrix work (tools/dense_trace.py).  Here a wave
+// owns 16 OUTPUT COLUMNS for all 64 rows of the workgroup: its slice of the effective weight is 32 registers, loaded once,
+// straight from the packed image (no LDS staging, no commit barrier); the rows go through LDS in four stages of 16 rows —
+// every thread loads, normalises (+dropout) and stores one float4 of each half per stage, so the prologue arithmetic is
+// spread over all lanes — double-buffered, with the loads of stage s + 2 in flight across the LDS-only barrier of stage s
+// (s_waitcnt lgkmcnt(0) + s_barrier: a full __syncthreads would drain them), so loads, arithmetic, MFMAs and stores of
+// different stages overlap inside the workgroup.  Column statistics: a wave owns its columns, so the sums fold by lane
+// shuffles and go straight to the accumulators / partials — no LDS reduction.
+// Image: layout kLayoutWave16EffFwdCols (tile t = columns 16t .. 16t+15): float4 ((kc*4 + t)*4 + v)*64 + lane holds
+// W_eff[16t + j][32q + 16kc + 4v ..+3], lane = j + 16q — exactly lane (j, q)'s B operand for k = 32q + 4(4kc + v) + e.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Buffer addressing for the stage loop: an out-of-range offset makes a load return 0 and drops a store, so row validity
+// costs no branch — and the loop holds no CONDITIONAL memory instruction.  That matters for more than the branch: vmcnt
+// counts loads and stores in issue order, and when a younger memory instruction may or may not have been issued the
+// compiler has to wait with vmcnt(0) for an older load — i.e. for every store in flight (the first version of this kernel
+// stalled ~1 us per two stages on its own output stores; ISA: `global_store_dwordx4; s_waitcnt vmcnt(0); ds_write_b128`).
+using buf_rsrc = __amdgpu_buffer_rsrc_t;
+typedef unsigned u32x4 __attribute__((__vector_size__(16)));  // (the builtin's own type; an ext_vector_type took one dword and splat it)
+constexpr int kBufOOB = 0x7fffffff;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(buf_rsrc r, int off) {
+    // (whole-vector copy: __builtin_bit_cast on the ELEMENTS of the vector compiled to one dword load splat four times)
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    float4 f;
+    __builtin_memcpy(&f, &v, sizeof(f));
+    return f;
+}
+__device__ __forceinline__ void buf_store4(buf_rsrc r, int off, const float4& f) {
+    u32x4 v;
+    __builtin_memcpy(&v, &f, sizeof(v));
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store1(buf_rsrc r, int off, float f) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r, off, 0, 0);
+}
+
+template <int H>
+__global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
+                                                               const float* __restrict__ xb, int64_t ldb,
+                                                               const float* __restrict__ Wimg, const float* __restrict__ bias,
+                                                               const uint8_t* __restrict__ mask, float zr, float omz,
+                                                               float* __restrict__ out, int64_t ldo, int64_t N,
+                                                               double* __restrict__ stats, int stats_exact, GnPrologue pro,
+                                                               LabRows lab) {
+    static_assert(H == 64, "four waves x 16 columns");
+    constexpr int KT = 2 * H, RS = KT + 4;  // LDS row stride (floats): + 4 keeps the 16 rows of a b128 read off one bank group
+    __shared__ __attribute__((aligned(16))) float tile[2][16 * RS];
+    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
+    __shared__ int rows_s[64];  // row of each of the workgroup's 64 slots: -1 none; bit 30 set: computed but not stored / counted
+    D_STAMP(1, 0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const bool extra = (int)blockIdx.x >= lab.n_main;
+    int n_lab = 0, base = 0;
+    if (extra) {
+        n_lab = lab.count[0];
+        base = ((int)blockIdx.x - lab.n_main) * 64;
+        if (base >= n_lab) {  // extra workgroup beyond the list: an empty partial
+            if (stats && !stats_exact)
+                for (int c = tid; c < 2 * H; c += kBlock) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
+            return;
+        }
+    }
+    const buf_rsrc r_xa = make_rsrc(xa, N * lda * 4), r_xb = make_rsrc(xb, N * ldb * 4), r_out = make_rsrc(out, N * ldo * 4);
+    const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
+    // this wave's slice of the effective weight: 8 float4 per lane
+    const float4* img = reinterpret_cast<const float4*>(Wimg + (extra ? H * KT : 0));
+    float4 bw[8];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) bw[tt] = img[(((tt >> 2) * 4 + w) * 4 + (tt & 3)) * 64 + lane];
+    const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
+    const float be = c1 * bias[16 * w + j] + c0 * bias[H + 16 * w + j];
+    // the two float4 this thread moves per stage: 4-column group ga of the a half (GraphNorm prologue) and of the h half of
+    // row rs of the stage (one buffer resource per half: wave-uniform)
+    const int rs = tid >> 4, ga = tid & 15;
+    int my_row[4];  // (-1: none)
+    int slot_v = -1;   // row of slot `tid` (threads < 64)
+    unsigned char slot_mask = 0;
+    if (!extra) {
+        const int64_t r0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+        if (tid < 64 && r0 + tid < N) {
+            slot_v = (int)(r0 + tid);
+            slot_mask = mask[r0 + tid];
+        }
+    } else {  // listed rows: through LDS (one load per slot)
+        if (tid < 64) {
+            slot_v = base + tid < n_lab ? lab.rows[base + tid] : -1;
+            rows_s[tid] = slot_v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_row[st] = rows_s[16 * st + rs];
+    }
+    auto issue = [&](int st, float4 (&raw)[2]) __attribute__((always_inline)) {
+        const int r = my_row[st];
+        raw[0] = buf_load4(r_xa, r >= 0 ? (int)((r * lda + 4 * ga) * 4) : kBufOOB);
+        raw[1] = buf_load4(r_xb, r >= 0 ? (int)((r * ldb + 4 * ga) * 4) : kBufOOB);
+    };
+    float4 rawA[2], rawB[2];
+    issue(0, rawA);
+    issue(1, rawB);
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    if (pro.saved) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
+    if (tid < 64) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
+    D_STAMP(1, 1);
+    lds_barrier();  // coefficients + row table
+    const bool pro_on = pro.saved != nullptr;
+    const bool side_on = pro.side != nullptr && !extra;  // (the row's own tile writes the normalised operand)
+    auto stage_store = [&](int st, const float4 (&raw)[2]) __attribute__((always_inline)) {
+        float* T = tile[st & 1];
+        const int r = my_row[st];
+        float a[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w};
+        const bool pl = pro_on && r >= 0;
+        if (pl) {
+            const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
+            const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
+            const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {h4.x, h4.y, h4.z, h4.w};
+            float ds[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.p > 0.f) drop_scales<4>(drop, r, 4 * ga, ds);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float h = fmaf(a[k], sc[k], sh[k]);
+                if (pro.act == GLASS_ACT_ELU) h = elu_fast_f(h);
+                a[k] = h * ds[k];
+            }
+        }
+        const float4 v = make_float4(a[0], a[1], a[2], a[3]);
+        buf_store4(r_side, (pl && side_on) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
+        *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
+        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = raw[1];
+    };
+    float ssum = 0.f, ssq = 0.f;  // this lane's column 16w + j over the rows 4q + r of every stage
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st & 1) {
+            stage_store(st, rawB);
+            if (st + 2 < 4) issue(st + 2, rawB);
+        } else {
+            stage_store(st, rawA);
+            if (st + 2 < 4) issue(st + 2, rawA);
+        }
+        lds_barrier();  // the stage's rows are in LDS (and every wave is done with the buffer the NEXT stage overwrites)
+        const float* T = tile[st & 1] + j * RS + 32 * q;
+        float4 a4[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
+        int rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the dependent-MFMA latency
+#pragma unroll
+        for (int tt = 0; tt < 8; tt += 2) {
+            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+            }
+        }
+        // acc[r] = row slot 16 st + 4q + r, column 16w + j
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
+            const float o = acc0[r] + acc1[r] + be;
+            buf_store1(r_out, live ? (int)((rv[r] * ldo + 16 * w + j) * 4) : kBufOOB, o);
+            ssum += live ? o : 0.f;
+            ssq += live ? o * o : 0.f;
+        }
+    }
+    D_STAMP(1, 3);
+    if (stats == nullptr) return;
+    double s = (double)ssum, q2 = (double)ssq;
+    s += __shfl_xor(s, 16);
+    q2 += __shfl_xor(q2, 16);
+    s += __shfl_xor(s, 32);
+    q2 += __shfl_xor(q2, 32);
+    if (q == 0) {
+        const int c = 16 * w + j;
+        if (stats_exact) {
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
+        } else {
+            stats[((size_t)blockIdx.x * 2) * H + c] = s;
+            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        }
+    }
+    D_STAMP(1, 4);
+}
+
 // Data gradient of the comb pair in the same form:  d[g || x_][r] = dc[r] . (w1 W1 + w0 W0): K = H instead of 2H (one
 // K pass), the mix coefficient folded into the weight.  The first H output columns are the gradient of conv.gn's output:
 // its backward column sums are accumulated by the epilogue as in dual_dgrad_body (one partial per workgroup, the extra
@@ -966,11 +1172,12 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
         }
         return;
     }
-    if (j.layout == kLayoutWave16EffFwd || j.layout == kLayoutWave16EffDgrad) {
+    if (j.layout == kLayoutWave16EffFwd || j.layout == kLayoutWave16EffDgrad || j.layout == kLayoutWave16EffFwdCols) {
         // comb pair, hidden 64: two wave16 images of the effective weights c1 * (f1 half) + c0 * (f0 half) — unlabeled rows
         // (c1, c0) = (1-z, z), then labeled rows (z, 1-z).  Forward: the halves are the two row blocks of B (NT/2 outputs
         // each); data gradient (transposed source): the two halves of k (the stacked output index of the pair).
-        const bool fwd = j.layout == kLayoutWave16EffFwd;
+        const bool fwd = j.layout != kLayoutWave16EffDgrad;
+        const bool cols = j.layout == kLayoutWave16EffFwdCols;  // tile t = columns 16t .. 16t+15 (comb_fwd_eff2_kernel)
         const int NTe = fwd ? j.NT / 2 : j.NT, KTe = fwd ? j.KT : j.KT / 2;
         const int KQ = KTe / 4, NTILES = NTe / 16, per = NTe * KTe / 4;
         const float zr = j.zr, omz = 1.f - j.zr;
@@ -978,7 +1185,7 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
             const int img = l >= per, ll = img ? l - per : l;
             const int lane = ll & 63, v = (ll >> 6) & 3, t = (ll >> 8) % NTILES, kc = (ll >> 8) / NTILES;
             const int jj = lane & 15, q = lane >> 4;
-            const int n = tile_col(t, jj), k = q * KQ + kc * kKC + 4 * v;
+            const int n = cols ? 16 * t + jj : tile_col(t, jj), k = q * KQ + kc * kKC + 4 * v;
             const float4 a = pack_fetch(j, n, k);
             const float4 b = fwd ? pack_fetch(j, j.NT / 2 + n, k) : pack_fetch(j, n, j.KT / 2 + k);
             const float c1 = img ? zr : omz, c0 = img ? omz : zr;
@@ -1312,6 +1519,18 @@ extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab
     return ceil_div(n_nodes, 64) + ceil_div(lab_cap, 64);
 }
 
+// Most rows glass_comb_eff_fwd_f32 serves when every operand's row stride is <= ld floats (32-bit buffer offsets)
+extern "C" int64_t glass_comb_eff_max_rows(int64_t ld) {
+    if (ld <= 0) return GLASS_E_ARG;
+    return GLASS_COMB_FWD_V2 ? ((1ll << 31) - 1) / (4 * ld) : (1ll << 31) - 1;
+}
+
+// Layout code (flags >> 1 of glass_dense_pack_batch_f32) of the forward image glass_comb_eff_fwd_f32 reads
+extern "C" int glass_comb_eff_fwd_layout(int64_t H) {
+    (void)H;
+    return GLASS_COMB_FWD_V2 ? kLayoutWave16EffFwdCols : kLayoutWave16EffFwd;
+}
+
 extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,
                                       const float* bias, const uint8_t* mask, double z_ratio, float* out, int64_t ldo,
                                       int64_t n_nodes, int64_t H, double* stats, int stats_exact, const float* gn_saved,
@@ -1340,8 +1559,15 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
     const LabRows lab{lab_rows, lab_count, n_main};
     const size_t lds = lds_bytes(H, 2);  // two K passes of the [H][2H] effective weight
-    hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
-                       bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
+    const int64_t ld_max = std::max(std::max(lda, ldb), std::max(ldo, gn_saved ? ldxo : (int64_t)0));
+    GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || n_nodes * ld_max * 4 < (1ll << 31),
+                  "comb_eff_fwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets; glass_comb_eff_max_rows)");
+    if (GLASS_COMB_FWD_V2)
+        hipLaunchKernelGGL((comb_fwd_eff2_kernel<64>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, bias,
+                           mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
+    else
+        hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
+                           bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
     return launch_status("glass_comb_eff_fwd_f32");
 }
 
@@ -1422,7 +1648,8 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
                           (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
                           (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio) ||
                           (layout == kLayoutTiledPairedEff && NT[k] % 512 == 0 && !(transposed[k] & 1) && z_ratio) ||
-                          (layout == kLayoutWave16EffFwd && NT[k] % 128 == 0 && !(transposed[k] & 1) && z_ratio) ||
+                          ((layout == kLayoutWave16EffFwd || layout == kLayoutWave16EffFwdCols) && NT[k] % 128 == 0 &&
+                           !(transposed[k] & 1) && z_ratio) ||
                           (layout == kLayoutWave16EffDgrad && KT[k] % 128 == 0 && (transposed[k] & 1) && z_ratio),
                       "%s: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
                       "layout that is not the transposed 128 x 256 operand", what, k, layout);

@@ -111,6 +111,84 @@ __device__ __forceinline__ void gn_fwd_coef_block(const GnExactSrc& src, const f
     __syncthreads();
 }
 
+// The same block in two steps for workgroups of >= 2C threads, so that the caller can put its own independent loads (and
+// the barrier that drains them all) between the requests and their use: `issue` only starts the loads — thread t < 2C
+// takes item t = (which, c) like gn_acc_fold, threads t < C also the column's parameters — `finish` adds, exchanges
+// through LDS and derives the coefficients (two barriers, no memory round trip of its own).
+struct GnCoefEarly {
+    long long h[kAccRep], l[kAccRep];
+    float p0, p1, p2;  // gamma, beta, alpha of column t (exact form) / saved[2C + t], saved[t] (final statistics)
+};
+
+__device__ __forceinline__ void gn_coef_early_issue(const GnExactSrc& src, const float* __restrict__ saved, int C, GnCoefEarly& E) {
+    const int t = threadIdx.x;
+    E.p0 = E.p1 = E.p2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < kAccRep; ++r) E.h[r] = E.l[r] = 0;
+    if (t >= 2 * C) return;
+    if (!src.acc) {
+        E.p0 = saved[2 * C + t];
+        E.p1 = saved[t];
+        return;
+    }
+    const int C_each = C / src.n_src;
+    const int which = t / C, c = t - which * C;
+    const int k = c / C_each, cl = c - k * C_each;
+    const long long* base = src.acc + (size_t)k * gn_acc_words(C_each);
+#pragma unroll
+    for (int r = 0; r < kAccRep; ++r) {
+        const int rr = r < src.n_rep ? r : 0;  // (clamped: a replica read twice is not added)
+        const long long* p = base + gn_acc_index(rr, which, cl, C_each);
+        E.h[r] = p[0];
+        E.l[r] = p[1];
+    }
+    if (t < C) {
+        E.p0 = src.gamma[t];
+        E.p1 = src.beta[t];
+        E.p2 = src.alpha[t];
+    }
+}
+
+__device__ __forceinline__ void gn_coef_early_finish(const GnExactSrc& src, int C, int64_t N, const GnCoefEarly& E, double* sums,
+                                                     float* coef_s, float* mu_rstd_s) {
+    const int t = threadIdx.x;
+    if (!src.acc) {
+        if (t < 2 * C) {
+            coef_s[t] = E.p0;
+            if (mu_rstd_s) mu_rstd_s[t] = E.p1;
+        }
+        __syncthreads();
+        return;
+    }
+    if (t < 2 * C) {
+        long long hi = 0, lo = 0;
+#pragma unroll
+        for (int r = 0; r < kAccRep; ++r) {
+            hi += r < src.n_rep ? E.h[r] : 0;
+            lo += r < src.n_rep ? E.l[r] : 0;
+        }
+        sums[t] = ((double)hi + (double)lo * (1.0 / 1099511627776.0)) * (1.0 / kAccScaleFwd);
+    }
+    __syncthreads();
+    if (t < C) {
+        float mu, rstd, scale, shift;
+        gn_fwd_coeffs(sums[t], sums[C + t], (double)N, E.p0, E.p1, E.p2, src.eps, mu, rstd, scale, shift);
+        coef_s[t] = scale;
+        coef_s[C + t] = shift;
+        if (mu_rstd_s) {
+            mu_rstd_s[t] = mu;
+            mu_rstd_s[C + t] = rstd;
+        }
+        if (blockIdx.x == 0 && src.saved_w) {
+            src.saved_w[t] = mu;
+            src.saved_w[C + t] = rstd;
+            src.saved_w[2 * C + t] = scale;
+            src.saved_w[3 * C + t] = shift;
+        }
+    }
+    __syncthreads();
+}
+
 // The two sums of C columns held by ONE accumulator block, for a workgroup of T = 4C threads, WITHOUT a barrier or LDS:
 // wave w, lane l: column c = 16w + (l & 15), sum `which` = (l >> 4) & 1, replica half = l >> 5 — every 16 lanes read 256
 // contiguous bytes per load (with the four lanes of a column ADJACENT, each lane quad touched four cache lines per load and

@@ -9,7 +9,9 @@
 //     — no pass over the N bytes (incremental == 0: the N bytes are zero-filled here first);
 //   * the UNIQUE labeled rows are listed in first-occurrence order (lab_rows, lab_count): the entry with the lowest
 //     index naming a node owns it (integer atomicMin on a scratch word per named node: the result does not depend on
-//     the order of the atomics), owners are compacted in entry order by ballots — deterministic.
+//     the order of the atomics), owners are compacted in entry order by ballots — deterministic.  The scratch words hold
+//     INT32_MAX between calls (the caller fills them once, every call restores the words it touched), so setting the
+//     label bytes and the atomicMin share a phase: three dependent round trips instead of four (6.7 -> 5.4 us).
 // The list is what lets the comb pair of GLASSConv run ONE product per row (effective per-label weights, dense.hip):
 // every row tile multiplies the unlabeled-row weight, the listed rows are recomputed with the labeled-row weight by a
 // few extra workgroups of the same launch.
@@ -46,24 +48,19 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
         for (int64_t k = head + vecs * 16 + tid; k < N; k += kLabThreads) mask[k] = 0;
     }
     __syncthreads();
-    // 2. the new batch: fixed buffers, label bytes, owner words of the named nodes
+    // 2. the new batch: fixed buffers, label bytes; the lowest entry index naming a node owns it (owner words are
+    //    INT32_MAX on entry)
     for (int e = tid; e < n_pos; e += kLabThreads) {
         const int64_t p = pos_src[e];
         if (pos_dst) pos_dst[e] = p;
         if (p >= 0 && p < N) {
             mask[p] = 1;
-            owner[p] = INT32_MAX;
+            atomicMin(owner + p, e);
         }
     }
     for (int64_t k = tid; k < y_words; k += kLabThreads) y_dst[k] = y_src[k];
     __syncthreads();
-    // 3. the lowest entry index naming a node owns it
-    for (int e = tid; e < n_pos; e += kLabThreads) {
-        const int64_t p = pos_src[e];
-        if (p >= 0 && p < N) atomicMin(owner + p, e);
-    }
-    __syncthreads();
-    // 4. owners, compacted in entry order
+    // 3. owners, compacted in entry order
     int base = 0;
     for (int e0 = 0; e0 < n_pos; e0 += kLabThreads) {
         const int e = e0 + tid;
@@ -82,6 +79,11 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
         __syncthreads();
     }
     if (tid == 0) lab_count[0] = base;
+    // 4. the owner words of the named nodes back to INT32_MAX (every read of them lies before the loop's last barrier)
+    for (int e = tid; e < n_pos; e += kLabThreads) {
+        const int64_t p = pos_src[e];
+        if (p >= 0 && p < N) owner[p] = INT32_MAX;
+    }
 }
 
 }  // namespace glass

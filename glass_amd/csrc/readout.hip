@@ -92,11 +92,36 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
     float* zs = red + kBlock * 8;
     float* dl = zs + kReadoutMaxK;
     const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t* prow = a.pos + (int64_t)b * a.Smax;
+    // Everything that depends on no other load is requested FIRST, so that the barrier inside valid_count drains one
+    // round trip instead of this kernel paying four in a row: the final GraphNorm's accumulators / statistics and
+    // parameters, the thread's first subgraph entries, the head weights of the wave's first class, the target.
+    const bool early = 2 * C <= kBlock;
+    GnCoefEarly E;
+    if (early) gn_coef_early_issue(a.src, a.saved, C, E);
+    const int TCp = 1 << a.tc_log2, rpbp = kBlock >> a.tc_log2;
+    int64_t node_pre[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = (tid >> a.tc_log2) + u * rpbp;
+        node_pre[u] = j < a.Smax ? prow[j] : -1;
+    }
+    float wh_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool wh_early = C <= 4 * kWave && (tid >> 6) < K;
+    if (wh_early)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int c = (tid & 63) + kWave * u;
+            if (c < C) wh_pre[u] = a.Wh[(int64_t)(tid >> 6) * C + c];
+        }
+    (void)TCp;
+    const int cnt = valid_count(prow, a.Smax, a.n_nodes);
     // the final GraphNorm's coefficients: copied from `saved`, or derived here from the accumulators the comb kernels' epilogues
     // added to (workgroup 0 writes `saved` for the two launches behind this one)
-    gn_fwd_coef_block(a.src, a.saved, C, a.n_nodes, sums, coef_s, mu_rstd_s);
-    const int64_t* prow = a.pos + (int64_t)b * a.Smax;
-    const int cnt = valid_count(prow, a.Smax, a.n_nodes);
+    if (early)
+        gn_coef_early_finish(a.src, C, a.n_nodes, E, sums, coef_s, mu_rstd_s);
+    else
+        gn_fwd_coef_block(a.src, a.saved, C, a.n_nodes, sums, coef_s, mu_rstd_s);
     const float sc = readout_pool_scale(a.mode, cnt);
     // ---- pool the normalised rows; also sum xhat over the subgraph's rows ----
     const int TC = 1 << a.tc_log2, rpb = kBlock >> a.tc_log2;
@@ -114,8 +139,9 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
             shift[k] = coef_s[C + c0 + k];
             al[k] = a.alpha[c0 + k];
         }
-        for (int j = tr; j < a.Smax; j += rpb) {
-            const int64_t node = prow[j];
+        int it = 0;
+        for (int j = tr; j < a.Smax; j += rpb, ++it) {
+            const int64_t node = it < 2 ? node_pre[it < 1 ? 0 : 1] : prow[j];
             if (node < 0 || node >= a.n_nodes) continue;
             float x[VW];
             if (VW == 4) {
@@ -157,7 +183,15 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
     for (int k = w; k < K; k += kBlock / kWave) {
         const float* wr = a.Wh + (int64_t)k * C;
         float s = 0.f;
-        for (int c = lane; c < C; c += kWave) s = fmaf(pooled_s[c], wr[c], s);
+        if (wh_early && k == w) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = lane + kWave * u;
+                if (c < C) s = fmaf(pooled_s[c], wh_pre[u], s);
+            }
+        } else {
+            for (int c = lane; c < C; c += kWave) s = fmaf(pooled_s[c], wr[c], s);
+        }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
         if (lane == 0) zs[k] = s + a.bh[k];

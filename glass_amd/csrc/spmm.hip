@@ -292,7 +292,10 @@ extern "C" int glass_k1_trace_set(unsigned long long* p) {
 static constexpr int kLongThrMax = GLASS_K1_LONG_THR;
 static constexpr int kLongChunkMax = 2048;
 static constexpr int kRowCost = 4;        // per-row overhead in edge units (rowptr read, reduce, store)
-static constexpr int kTargetWaves = 32768;  // ~4 rounds of 256 CUs x 32 waves
+#ifndef GLASS_K1_TARGET_WAVES
+#define GLASS_K1_TARGET_WAVES 32768
+#endif
+static constexpr int kTargetWaves = GLASS_K1_TARGET_WAVES;  // ~4 rounds of 256 CUs x 32 waves
 static constexpr int kMinBudget = 16;        // smallest item budget: on small graphs one degree-12 row per wave (density-shape: 5.0 -> 4.0 us; 32 packed two)
 static constexpr int kFlatFactor = 4;       // flat mode up to a mean degree of 4 G (uniform degree 12 at H = 64: 988 -> 931 us; degree 37: row mode)
 

@@ -55,7 +55,7 @@ class BatchLabels:
         self.mask = torch.zeros(self.n, dtype=torch.uint8, device=device)
         self.rows = torch.zeros(max(self.cap, 1), dtype=torch.int32, device=device)
         self.count = torch.zeros(4, dtype=torch.int32, device=device)
-        self.ws = torch.empty(self.n, dtype=torch.int32, device=device)
+        self.ws = torch.full((self.n,), 2**31 - 1, dtype=torch.int32, device=device)  # owner words: INT32_MAX between calls
         self.loaded = False
 
     def load(self, pos_src, pos_dst=None, y_src=None, y_dst=None):
@@ -75,7 +75,7 @@ class BatchLabels:
 
 def _comb_eff_ok(conv, labels, H):
     return (USE_COMB_EFF and labels is not None and "comb" in getattr(conv, "_stack_eff", {}) and
-            bool(_lib.load().glass_comb_eff_supported(H)))
+            bool(_lib.load().glass_comb_eff_supported(H)) and labels.n <= _lib.load().glass_comb_eff_max_rows(4 * H))
 
 
 class _PendingStats:

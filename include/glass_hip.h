@@ -100,7 +100,8 @@ int glass_maxzoz_i64(const int64_t* pos, int64_t n_pos /* B*Smax, -1 = padding *
  *     over the n_nodes bytes; incremental == 0 — zero-filled here first.  lab_rows int32[n_pos] receives the UNIQUE labeled
  *     node ids in first-occurrence order, lab_count[0] their number (the entry with the lowest index naming a node owns
  *     it: integer atomicMin on a scratch word per named node, ordered compaction by ballots — deterministic).
- *     ws = int32[n_nodes] scratch (glass_batch_labels_ws_bytes; only the named nodes' words are touched). */
+ *     ws = int32[n_nodes] scratch (glass_batch_labels_ws_bytes): every word INT32_MAX before the first call — the caller
+ *     fills it once; a call touches the named nodes' words only and restores them. */
 int64_t glass_batch_labels_ws_bytes(int64_t n_nodes);
 int glass_batch_labels(const int64_t* pos_src, int64_t n_pos, int64_t* pos_dst, const void* y_src, void* y_dst,
                        int64_t y_bytes, uint8_t* mask, int32_t* lab_rows, int32_t* lab_count, void* ws, int64_t n_nodes,
@@ -350,6 +351,8 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
  *   listed rows (half the matrix work of the plain form); reduce them with glass_linear_wgrad_reduce_batch_f32, lab_cap[j]
  *   = this call's lab_cap. */
 int glass_comb_eff_supported(int64_t H);
+int glass_comb_eff_fwd_layout(int64_t H); /* pack layout of Wimg_eff for glass_comb_eff_fwd_f32: 6 or 8 */
+int64_t glass_comb_eff_max_rows(int64_t ld); /* most rows the forward serves at operand row strides <= ld floats */
 int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap);
 int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t lab_cap); /* `ws` of glass_comb_eff_bwd_f32 */
 int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,

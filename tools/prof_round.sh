@@ -2,7 +2,7 @@
 # rocprofv3 summaries for profiles/: the bench command itself under --kernel-trace --stats (C2 default and C5), then the
 # K1 stand-alone runs + PMC passes (tools/k1_pmc.sh).  Output: gpurun_out/prof/ ; copy the *.csv / *.json to profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 out=gpurun_out/prof
 mkdir -p $out
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c2 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm --no-pmc > $out/${R}_bench_ppi_bp_bench_line.json 2> $out/c2.err
