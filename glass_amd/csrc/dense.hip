@@ -31,6 +31,9 @@
 
 namespace glass {
 
+#ifndef GLASS_TRANS_FWD_V2
+#define GLASS_TRANS_FWD_V2 1  // trans forward at hidden 64 in the same form (trans_fwd2_kernel)
+#endif
 #ifndef GLASS_COMB_FWD_V2
 #define GLASS_COMB_FWD_V2 1  // comb forward at hidden 64: weights in registers, rows through LDS in stages (comb_fwd_eff2_kernel)
 #endif
@@ -948,6 +951,161 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
     D_STAMP(1, 4);
 }
 
+// ---- trans forward in the same form (hidden 64): out = mix(act(xa W1^T + b1), act(xa W0^T + b0)), T = the two pre-activations
+// A wave owns columns 16w .. 16w+15 of BOTH halves (the label mix needs f1 and f0 of a column in one lane): 2 x 4 float4 of
+// weights per lane (K = 64), 32 MFMAs per 16-row stage; one float4 of the operand per thread and stage.  Image: layout
+// kLayoutWave16Cols.  xa_index: the stage's rows are gathered from the embedding table (layer 0).
+template <int H>
+__global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restrict__ xa, int64_t lda, int64_t xa_rows,
+                                                            const float* __restrict__ Wimg, const float* __restrict__ bias,
+                                                            const uint8_t* __restrict__ mask, float zr, float omz, int act,
+                                                            float* __restrict__ T, int64_t ldt, float* __restrict__ out,
+                                                            int64_t ldo, int64_t N, double* __restrict__ stats, int stats_exact,
+                                                            GnPrologue pro, const int64_t* __restrict__ xa_index) {
+    static_assert(H == 64, "four waves x 16 columns");
+    constexpr int RS = H + 4;  // LDS row stride (floats)
+    __shared__ __attribute__((aligned(16))) float tile[2][16 * RS];
+    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
+    __shared__ int rows_s[64];  // row of each slot: -1 none; bit 30: labeled row (mix weights swapped)
+    D_STAMP(2, 0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const buf_rsrc r_xa = make_rsrc(xa, xa_rows * lda * 4), r_out = make_rsrc(out, N * ldo * 4);
+    const buf_rsrc r_T = make_rsrc(T ? T : out, T ? N * ldt * 4 : 0);
+    const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
+    const float4* img = reinterpret_cast<const float4*>(Wimg);
+    float4 bw1[4], bw0[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bw1[v] = img[(w * 4 + v) * 64 + lane];
+        bw0[v] = img[((4 + w) * 4 + v) * 64 + lane];
+    }
+    const float b1 = bias[16 * w + j], b0 = bias[H + 16 * w + j];
+    const int rs = tid >> 4, ga = tid & 15;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    int my_row[4], my_src[4];  // output row of this thread's float4 per stage (-1 none) and the operand row it comes from
+#pragma unroll
+    for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+    if (xa_index) {
+        int64_t idx[4];
+#pragma unroll
+        for (int st = 0; st < 4; ++st) idx[st] = my_row[st] >= 0 ? xa_index[my_row[st]] : 0;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_src[st] = (int)(idx[st] < 0 ? 0 : (idx[st] >= xa_rows ? xa_rows - 1 : idx[st]));
+    } else {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_src[st] = my_row[st];
+    }
+    int slot_v = -1;
+    unsigned char slot_mask = 0;
+    if (tid < 64 && r0 + tid < N) {
+        slot_v = (int)(r0 + tid);
+        slot_mask = mask[r0 + tid];
+    }
+    auto issue = [&](int st) __attribute__((always_inline)) -> float4 {
+        return buf_load4(r_xa, my_row[st] >= 0 ? (int)((my_src[st] * lda + 4 * ga) * 4) : kBufOOB);
+    };
+    float4 rawA = issue(0), rawB = issue(1);
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    if (pro.saved) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
+    if (tid < 64) rows_s[tid] = slot_mask != 0 ? (slot_v | (1 << 30)) : slot_v;
+    D_STAMP(2, 1);
+    lds_barrier();  // coefficients + row table
+    const bool pro_on = pro.saved != nullptr;
+    auto stage_store = [&](int st, const float4& raw) __attribute__((always_inline)) {
+        const int r = my_row[st];
+        float a[4] = {raw.x, raw.y, raw.z, raw.w};
+        const bool pl = pro_on && r >= 0;
+        if (pl) {
+            const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
+            const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
+            const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {h4.x, h4.y, h4.z, h4.w};
+            float ds[4] = {1.f, 1.f, 1.f, 1.f};
+            if (drop.p > 0.f) drop_scales<4>(drop, r, 4 * ga, ds);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float h = fmaf(a[k], sc[k], sh[k]);
+                if (pro.act == GLASS_ACT_ELU) h = elu_fast_f(h);
+                a[k] = h * ds[k];
+            }
+        }
+        const float4 v = make_float4(a[0], a[1], a[2], a[3]);
+        buf_store4(r_side, (pl && pro.side) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
+        *reinterpret_cast<float4*>(tile[st & 1] + rs * RS + 4 * ga) = v;
+    };
+    float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        if (st & 1) {
+            stage_store(st, rawB);
+            if (st + 2 < 4) rawB = issue(st + 2);
+        } else {
+            stage_store(st, rawA);
+            if (st + 2 < 4) rawA = issue(st + 2);
+        }
+        lds_barrier();
+        const float* A = tile[st & 1] + j * RS + 16 * q;
+        float4 a4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(A + 4 * v);
+        int rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
+            const float y1[4] = {bw1[v].x, bw1[v].y, bw1[v].z, bw1[v].w}, y0[4] = {bw0[v].x, bw0[v].y, bw0[v].z, bw0[v].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y1[e], acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y0[e], acc0, 0, 0, 0);
+            }
+        }
+        const int c = 16 * w + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0;
+            const int row = rv[r] & ((1 << 30) - 1);
+            const bool lab = (rv[r] >> 30) & 1;
+            const float w1 = lab ? zr : omz, w0 = lab ? omz : zr;
+            const float v1 = acc1[r] + b1, v0 = acc0[r] + b0;
+            buf_store1(r_T, (live && T) ? (int)((row * ldt + c) * 4) : kBufOOB, v1);
+            buf_store1(r_T, (live && T) ? (int)((row * ldt + H + c) * 4) : kBufOOB, v0);
+            float a1 = v1, a0 = v0;
+            if (act == GLASS_ACT_ELU) {
+                a1 = elu_fast_f(a1);
+                a0 = elu_fast_f(a0);
+            }
+            const float o = w1 * a1 + w0 * a0;
+            buf_store1(r_out, live ? (int)((row * ldo + c) * 4) : kBufOOB, o);
+            ssum += live ? o : 0.f;
+            ssq += live ? o * o : 0.f;
+        }
+    }
+    D_STAMP(2, 3);
+    if (stats == nullptr) return;
+    double s = (double)ssum, q2 = (double)ssq;
+    s += __shfl_xor(s, 16);
+    q2 += __shfl_xor(q2, 16);
+    s += __shfl_xor(s, 32);
+    q2 += __shfl_xor(q2, 32);
+    if (q == 0) {
+        const int c = 16 * w + j;
+        if (stats_exact) {
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
+        } else {
+            stats[((size_t)blockIdx.x * 2) * H + c] = s;
+            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        }
+    }
+}
+
 // Data gradient of the comb pair in the same form:  d[g || x_][r] = dc[r] . (w1 W1 + w0 W0): K = H instead of 2H (one
 // K pass), the mix coefficient folded into the weight.  The first H output columns are the gradient of conv.gn's output:
 // its backward column sums are accumulated by the epilogue as in dual_dgrad_body (one partial per workgroup, the extra
@@ -1163,12 +1321,14 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
     }
     const PackJob j = batch.job[blockIdx.y];
     const int total = j.NT * j.KT / 4;  // float4 elements
-    if (j.layout == kLayoutWave16) {
+    if (j.layout == kLayoutWave16 || j.layout == kLayoutWave16Cols) {
         const int KQ = j.KT / 4, NTILES = j.NT / 16;
+        const bool cols = j.layout == kLayoutWave16Cols;
         for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
             const int lane = l & 63, v = (l >> 6) & 3, t = (l >> 8) % NTILES, kc = (l >> 8) / NTILES;
             const int jj = lane & 15, q = lane >> 4;
-            reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tile_col(t, jj), q * KQ + kc * kKC + 4 * v);
+            const int n = cols ? 64 * (t >> 2) + 16 * (t & 3) + jj : tile_col(t, jj);
+            reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, n, q * KQ + kc * kKC + 4 * v);
         }
         return;
     }
@@ -1304,6 +1464,7 @@ extern "C" int glass_dual_linear_layout(int64_t H) { return narrow_shape_ok(H) ?
 // ... and of the FORWARD operand image for (H, K = input width): 0 wave16, 1 paired, 5 paired + effective-weight appendix
 // (comb pair, K = 2H, at hidden 256 / 512: 1.5 x the weight's floats)
 extern "C" int glass_dual_linear_fwd_layout(int64_t H, int64_t K) {
+    if (GLASS_TRANS_FWD_V2 && wave16_shape_ok(H) && K == H) return kLayoutWave16Cols;  // trans pair at hidden 64: trans_fwd2_kernel
     if (!tiled_here(H)) return kLayoutWave16;
     return tiled_eff_fwd_shape(H, K) ? kLayoutTiledPairedEff : kLayoutTiledPaired;
 }
@@ -1374,6 +1535,15 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
             hipLaunchKernelGGL((dual_fwd_kernel<HH, false, CS, RW>), grid, dim3(kWave * RW * CS), lds_trans, st, xa, lda, \
                                xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, \
                                xa_index, (int)xa_rows);                                                            \
+    }
+    if (GLASS_TRANS_FWD_V2 && !comb && H == 64) {  // (image in layout kLayoutWave16Cols: glass_dual_linear_fwd_layout)
+        const int64_t src_rows = xa_index ? xa_rows : n_nodes;
+        const int64_t ld_max = std::max(std::max(ldo, T ? ldt : (int64_t)0), gn_saved ? ldxo : (int64_t)0);
+        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31) && src_rows * lda * 4 < (1ll << 31),
+                      "dual_linear_fwd: rows * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
+        hipLaunchKernelGGL((trans_fwd2_kernel<64>), grid, dim3(kBlock), 0, st, xa, lda, src_rows, W, bias, mask, zr, omz, act, T, ldt,
+                           out, ldo, n_nodes, stats, stats_exact, pro, xa_index);
+        return launch_status("glass_dual_linear_fwd_f32");
     }
     GLASS_FWD(64, 1, 4)
 #undef GLASS_FWD
@@ -1644,7 +1814,8 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
                           aligned16(dst[k]),
                       "%s: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", what, k);
         const int layout = transposed[k] >> 1;
-        GLASS_REQUIRE(layout == kLayoutWave16 || ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
+        GLASS_REQUIRE(layout == kLayoutWave16 || (layout == kLayoutWave16Cols && NT[k] == 128 && KT[k] == 64 && !(transposed[k] & 1)) ||
+                          ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
                           (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
                           (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio) ||
                           (layout == kLayoutTiledPairedEff && NT[k] % 512 == 0 && !(transposed[k] & 1) && z_ratio) ||

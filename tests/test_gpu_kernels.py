@@ -506,7 +506,8 @@ def _pack(W, transposed, H=64, z=None):
     lib = _lib.load()
     nt, kt = (W.shape[1], W.shape[0]) if transposed else W.shape
     if lib.glass_dual_linear_layout(H) != 1:
-        layout = 0
+        # wave16 family: the forward operand of the trans pair has its own column order (layout 9) — ask the library
+        layout = 0 if (transposed or z is None) else lib.glass_dual_linear_fwd_layout(H, kt)
     elif z is not None:
         layout = lib.glass_dual_linear_dgrad_layout(H, nt) if transposed else lib.glass_dual_linear_fwd_layout(H, kt)
     else:
