@@ -140,9 +140,13 @@ class ParamArena(FlatGradBucket):
                     if kind == "comb" and K == O and _lib.load().glass_comb_eff_supported(O // 2):
                         # hidden 64: the comb pair's effective per-label weights (layouts 6 / 7: unlabeled-row image, then
                         # labeled-row image) for glass_comb_eff_fwd/bwd_f32 — taken when the batch's labeled rows are listed
-                        We, WTe = torch.empty_like(Wimg), torch.empty_like(WTimg)
+                        lay2 = int(_lib.load().glass_comb_eff_dgrad_layout2(O // 2))
+                        We = torch.empty_like(Wimg)
+                        WTe = torch.empty(WTimg.numel() * (2 if lay2 else 1), dtype=W.dtype, device=W.device)
                         self._packs.append((W, We, O, K, 0 | (int(_lib.load().glass_comb_eff_fwd_layout(O // 2)) << 1), mod))
                         self._packs.append((W, WTe, K, O, 1 | (7 << 1), mod))
+                        if lay2:  # the staged backward's own column order: a second pair of images behind the first
+                            self._packs.append((W, WTe[WTimg.numel():], K, O, 1 | (lay2 << 1), mod))
                         mod._stack_eff = {"comb": (We, WTe)}
                 else:
                     mod._stack[kind] = (W, b, dW, db)

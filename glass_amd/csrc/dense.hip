@@ -31,6 +31,13 @@
 
 namespace glass {
 
+#ifndef GLASS_COMB_BWD_V2
+// comb backward at hidden 64 as ONE staged pass per 64-row tile (comb_bwd_eff2_kernel: data gradient + the tile's own
+// weight-gradient partial).  Correct (the parity suite passes on it) and OFF: 18.1 us against 14.9 us for the two-kinds-of-
+// workgroup launch at ppi_bp-shape — 64 MFMAs + 70 KB of LDS reads per stage make a stage 1.9 us, and 280 such workgroups
+// on 256 CUs leave 24 CUs with two of them (their waves share the matrix cores: lives of 17 us beside a mean of 11.9).
+#define GLASS_COMB_BWD_V2 0
+#endif
 #ifndef GLASS_TRANS_FWD_V2
 #define GLASS_TRANS_FWD_V2 1  // trans forward at hidden 64 in the same form (trans_fwd2_kernel)
 #endif
@@ -790,7 +797,10 @@ __device__ __forceinline__ void buf_store1(buf_rsrc r, int off, float f) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r, off, 0, 0);
 }
 
-template <int H>
+#ifndef GLASS_STAGE_INTERLEAVE
+#define GLASS_STAGE_INTERLEAVE 4
+#endif
+template <int H, bool DROP>
 __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
                                                                const float* __restrict__ Wimg, const float* __restrict__ bias,
@@ -868,40 +878,40 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
     lds_barrier();  // coefficients + row table
     const bool pro_on = pro.saved != nullptr;
     const bool side_on = pro.side != nullptr && !extra;  // (the row's own tile writes the normalised operand)
-    auto stage_store = [&](int st, const float4 (&raw)[2]) __attribute__((always_inline)) {
+    // GraphNorm scale / shift of this thread's four columns (the same in every stage)
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pro_on) {
+        const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
+        const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
+        sc[0] = s4.x, sc[1] = s4.y, sc[2] = s4.z, sc[3] = s4.w;
+        sh[0] = h4.x, sh[1] = h4.y, sh[2] = h4.z, sh[3] = h4.w;
+    }
+    // prep: the prologue arithmetic of one float4 — branch-free, so that it can be scheduled BETWEEN the MFMAs of the
+    // previous stage (the matrix core runs a 16x16x4 for 32 cycles; a wave that issues its MFMAs back to back leaves its
+    // VALU idle meanwhile, and one that runs the prologue first leaves the matrix core idle)
+    auto prep = [&](int st, const float4& raw) __attribute__((always_inline)) -> float4 {
+        const int r = my_row[st];
+        float a[4] = {raw.x, raw.y, raw.z, raw.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = fmaf(a[k], sc[k], sh[k]) * ds[k];
+        return make_float4(a[0], a[1], a[2], a[3]);
+    };
+    auto commit = [&](int st, const float4& v, const float4& hraw) __attribute__((always_inline)) {
         float* T = tile[st & 1];
         const int r = my_row[st];
-        float a[4] = {raw[0].x, raw[0].y, raw[0].z, raw[0].w};
-        const bool pl = pro_on && r >= 0;
-        if (pl) {
-            const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
-            const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
-            const float sc[4] = {s4.x, s4.y, s4.z, s4.w}, sh[4] = {h4.x, h4.y, h4.z, h4.w};
-            float ds[4] = {1.f, 1.f, 1.f, 1.f};
-            if (drop.p > 0.f) drop_scales<4>(drop, r, 4 * ga, ds);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                float h = fmaf(a[k], sc[k], sh[k]);
-                if (pro.act == GLASS_ACT_ELU) h = elu_fast_f(h);
-                a[k] = h * ds[k];
-            }
-        }
-        const float4 v = make_float4(a[0], a[1], a[2], a[3]);
-        buf_store4(r_side, (pl && side_on) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
+        buf_store4(r_side, (pro_on && side_on && r >= 0) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
         *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
-        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = raw[1];
+        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = hraw;
     };
     float ssum = 0.f, ssq = 0.f;  // this lane's column 16w + j over the rows 4q + r of every stage
+    commit(0, prep(0, rawA[0]), rawA[1]);
+    issue(2, rawA);
+    lds_barrier();
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
-        if (st & 1) {
-            stage_store(st, rawB);
-            if (st + 2 < 4) issue(st + 2, rawB);
-        } else {
-            stage_store(st, rawA);
-            if (st + 2 < 4) issue(st + 2, rawA);
-        }
-        lds_barrier();  // the stage's rows are in LDS (and every wave is done with the buffer the NEXT stage overwrites)
+        if (st == 1) D_STAMP(1, 5);
         const float* T = tile[st & 1] + j * RS + 32 * q;
         float4 a4[8];
 #pragma unroll
@@ -909,6 +919,8 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
         int rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st + 1 < 4) vn = prep(st + 1, (st & 1) ? rawA[0] : rawB[0]);  // the NEXT stage's rows (even stages come in rawA)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the dependent-MFMA latency
 #pragma unroll
         for (int tt = 0; tt < 8; tt += 2) {
@@ -921,6 +933,13 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
             }
         }
+        if (st == 1) D_STAMP(1, 2);
+        if (st + 1 < 4) {
+            commit(st + 1, vn, (st & 1) ? rawA[1] : rawB[1]);
+            if (st + 3 < 4) {
+                if (st & 1) issue(st + 3, rawA); else issue(st + 3, rawB);
+            }
+        }
         // acc[r] = row slot 16 st + 4q + r, column 16w + j
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -930,6 +949,15 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
             ssum += live ? o : 0.f;
             ssq += live ? o * o : 0.f;
         }
+#if GLASS_STAGE_INTERLEAVE
+        // one MFMA, then a few of the next stage's VALU instructions, 32 times
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, GLASS_STAGE_INTERLEAVE, 0);
+        }
+#endif
+        if (st + 1 < 4) lds_barrier();  // the next stage's rows are in LDS; every wave is done reading this stage's buffer
     }
     D_STAMP(1, 3);
     if (stats == nullptr) return;
@@ -1238,6 +1266,248 @@ __global__ __launch_bounds__(kBlock) void comb_dgrad_eff_kernel(DgradEffArgs A) 
     comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, blockIdx.x, lds_w);
 }
 
+// ---- comb backward in the staged form (hidden 64): data gradient AND weight-gradient partial from ONE pass over the rows
+// The first form runs the data gradient's row tiles and the weight gradient's row slabs as two kinds of workgroup of one
+// launch: both read dc, each is latency-bound, and the launch lasts as long as the slower kind (phase stamps: 11.1 / 12.1 us
+// lives inside a 14.9 us launch).  Here a workgroup takes 64 rows through LDS in four 16-row stages and uses every stage
+// twice: (a) data gradient d[g || x_] = dc . W_eff (a wave owns 16 columns of each half; the effective weight in 32
+// registers), with the GraphNorm backward sums of the g half from two tiles the LOADER threads prepare (keep-scale u and
+// xhat * u per element: one dropout hash per float4, none in the epilogue); (b) the stage's contribution to this
+// workgroup's own weight-gradient partial  S_wg[o][i] = sum_rows dc[r][o] * [g || x_][r][i]  (a wave owns 16 outputs o and all
+// 128 inputs: 8 accumulator tiles; both operands read from TRANSPOSED tiles, four rows per b128).  The row tiles'
+// partials are the S tiles of the S / L form (every row, labeled or not); the extra workgroups, which hold the listed
+// labeled rows, produce the L tiles — the batched reduce is the same (plain [o][i] order, header[2] = 1).  No separate
+// weight-gradient workgroups: one round of 280 workgroups instead of 505.
+// Image: layout kLayoutWave16EffDgradCols (tile t = columns 64 (t >> 2) + 16 (t & 3) .. + 15 of [dg || dx_]).
+template <int H, bool DROP>
+__global__ __launch_bounds__(kBlock) void comb_bwd_eff2_kernel(DgradEffArgs A, const float* __restrict__ X, int64_t ldx,
+                                                               const float* __restrict__ X2, int64_t ldx2, float zr, int n_l,
+                                                               float* __restrict__ part_w, float* __restrict__ part_b) {
+    static_assert(H == 64, "four waves x 16 columns");
+    constexpr int RS = H + 4;   // plain tiles [16 rows][H]: row stride (floats)
+    constexpr int RT = 20;      // transposed tiles [col][16 rows]: row stride (floats), 16-B aligned
+    struct __attribute__((aligned(16))) Stage {
+        float dcP[16 * RS];       // dc rows                      (data gradient: A operand)
+        float dcT[H * RT];        // dc transposed [o][row]       (weight gradient: A operand; bias partial)
+        float inT[2 * H * RT];    // [g || x_] transposed [i][row] (weight gradient: B operand)
+        float U[16 * RS];         // keep-scale of the GraphNorm's dropout per element of the g half
+        float XU[16 * RS];        // xhat * keep-scale
+    };
+    __shared__ Stage stg[2];
+    __shared__ int rows_s[64];
+    D_STAMP(3, 0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int n_main = A.lab.n_main;
+    const bool extra = (int)blockIdx.x >= n_main;
+    const GnBwdStats& gs = A.gs;
+    const int64_t N = A.N;
+    if (blockIdx.x == 0 && tid == 0) {  // mode header behind the bias partials, read by the (deferred) reduce launch
+        float* header = part_b + (int64_t)(n_main + n_l) * kSLOut;
+        header[0] = 2.f;
+        header[1] = zr;
+        header[2] = 1.f;  // plain [o][i] order of the partial tiles
+    }
+    float* pw = part_w + (int64_t)blockIdx.x * (H * 2 * H);
+    int n_lab = 0, base = 0;
+    if (extra) {
+        n_lab = A.lab.count[0];
+        base = ((int)blockIdx.x - n_main) * 64;
+        if (base >= n_lab) {  // beyond the list: an empty L tile, empty sums
+            for (int k = tid * 4; k < H * 2 * H; k += kBlock * 4) *reinterpret_cast<float4*>(pw + k) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tid < H) part_b[(int64_t)blockIdx.x * kSLOut + tid] = 0.f;
+            if (gs.partial && !gs.exact)
+                for (int c = tid; c < 2 * H; c += kBlock) gs.partial[(size_t)blockIdx.x * 2 * H + c] = 0.0;
+            return;
+        }
+    }
+    const buf_rsrc r_dc = make_rsrc(A.dsrc, N * A.ldd * 4), r_out = make_rsrc(A.out, N * A.ldo * 4);
+    const buf_rsrc r_g = make_rsrc(X, N * ldx * 4), r_x = make_rsrc(X2, N * ldx2 * 4);
+    const buf_rsrc r_a = make_rsrc(gs.partial ? gs.x : A.dsrc, gs.partial ? N * gs.ldx * 4 : 0);
+    // this wave's slices of the effective weight (transposed operand): columns 16w .. of the dg half and of the dx_ half
+    const float4* img = reinterpret_cast<const float4*>(A.WT + (extra ? 2 * H * H : 0));
+    float4 bwg[4], bwx[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bwg[v] = img[(w * 4 + v) * 64 + lane];
+        bwx[v] = img[((4 + w) * 4 + v) * 64 + lane];
+    }
+    const int rs = tid >> 4, ga = tid & 15;  // loader role: row rs of the stage, columns 4 ga .. 4 ga + 3
+    int my_row[4];
+    int slot_v = -1;
+    unsigned char slot_mask = 0;
+    if (!extra) {
+        const int64_t r0 = (int64_t)blockIdx.x * 64;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+        if (tid < 64 && r0 + tid < N) {
+            slot_v = (int)(r0 + tid);
+            slot_mask = A.mask[r0 + tid];
+        }
+    } else {
+        if (tid < 64) {
+            slot_v = base + tid < n_lab ? A.lab.rows[base + tid] : -1;
+            rows_s[tid] = slot_v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_row[st] = rows_s[16 * st + rs];
+    }
+    struct Raw {
+        float4 dc, a, g, x;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int r = my_row[st];
+        R.dc = buf_load4(r_dc, r >= 0 ? (int)((r * A.ldd + 4 * ga) * 4) : kBufOOB);
+        R.a = buf_load4(r_a, r >= 0 ? (int)((r * gs.ldx + 4 * ga) * 4) : kBufOOB);
+        R.g = buf_load4(r_g, r >= 0 ? (int)((r * ldx + 4 * ga) * 4) : kBufOOB);
+        R.x = buf_load4(r_x, r >= 0 ? (int)((r * ldx2 + 4 * ga) * 4) : kBufOOB);
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    // GraphNorm coefficients of this loader thread's four columns
+    float g_mu[4] = {0.f, 0.f, 0.f, 0.f}, g_rs[4] = {0.f, 0.f, 0.f, 0.f}, g_al[4] = {0.f, 0.f, 0.f, 0.f};
+    Drop drop = gs.drop;
+    if (gs.partial) {
+        if (DROP) {
+            drop.seed = A.rng_state[0];
+            drop.step = A.rng_state[1];
+        }
+        const float4 m4 = *reinterpret_cast<const float4*>(gs.saved + 4 * ga);
+        const float4 r4 = *reinterpret_cast<const float4*>(gs.saved + H + 4 * ga);
+        const float4 a4 = *reinterpret_cast<const float4*>(gs.alpha + 4 * ga);
+        g_mu[0] = m4.x, g_mu[1] = m4.y, g_mu[2] = m4.z, g_mu[3] = m4.w;
+        g_rs[0] = r4.x, g_rs[1] = r4.y, g_rs[2] = r4.z, g_rs[3] = r4.w;
+        g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
+    }
+    if (tid < 64) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;
+    // stage -> LDS: the loader's four float4 in the layouts their readers want
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        Stage& S = stg[st & 1];
+        const int r = my_row[st];
+        *reinterpret_cast<float4*>(S.dcP + rs * RS + 4 * ga) = R.dc;
+        const float dcv[4] = {R.dc.x, R.dc.y, R.dc.z, R.dc.w}, gv[4] = {R.g.x, R.g.y, R.g.z, R.g.w};
+        const float xv[4] = {R.x.x, R.x.y, R.x.z, R.x.w}, av[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
+        float u[4], xu[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            S.dcT[(4 * ga + k) * RT + rs] = dcv[k];
+            S.inT[(4 * ga + k) * RT + rs] = gv[k];
+            S.inT[(H + 4 * ga + k) * RT + rs] = xv[k];
+            u[k] = ds[k];
+            xu[k] = (av[k] - g_al[k] * g_mu[k]) * g_rs[k] * ds[k];
+        }
+        *reinterpret_cast<float4*>(S.U + rs * RS + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
+        *reinterpret_cast<float4*>(S.XU + rs * RS + 4 * ga) = make_float4(xu[0], xu[1], xu[2], xu[3]);
+    };
+    commit(0, rawA);
+    issue(2, rawA);
+    D_STAMP(3, 1);
+    lds_barrier();
+    f32x4 wacc[8];  // weight-gradient partial: outputs o = 16w + 4q + r, inputs i = 16 it + j
+#pragma unroll
+    for (int it = 0; it < 8; ++it) wacc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;             // bias partial of output o = tid (threads < 64)
+    float s1 = 0.f, s2 = 0.f;     // GraphNorm backward sums of column 16w + j over this lane's rows
+    const int cg = 16 * w + j;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const Stage& S = stg[st & 1];
+        // ---- (a) data gradient of the stage's 16 rows ----
+        float4 a4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(S.dcP + j * RS + 16 * q + 4 * v);
+        int rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        float uu[4], xx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uu[r] = S.U[(4 * q + r) * RS + cg];
+            xx[r] = S.XU[(4 * q + r) * RS + cg];
+        }
+        // ---- (b) operands of the weight-gradient update: rows 4q .. 4q+3 of column o / i per lane ----
+        const float4 at = *reinterpret_cast<const float4*>(S.dcT + (16 * w + j) * RT + 4 * q);
+        float4 bt[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) bt[it] = *reinterpret_cast<const float4*>(S.inT + (16 * it + j) * RT + 4 * q);
+        float bpart = 0.f;
+        if (tid < H) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 t4 = *reinterpret_cast<const float4*>(S.dcT + tid * RT + 4 * v);
+                bpart += (t4.x + t4.y) + (t4.z + t4.w);
+            }
+        }
+        bsum += bpart;
+        f32x4 accg = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
+            const float yg[4] = {bwg[v].x, bwg[v].y, bwg[v].z, bwg[v].w}, yx[4] = {bwx[v].x, bwx[v].y, bwx[v].z, bwx[v].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yg[e], accg, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yx[e], accx, 0, 0, 0);
+            }
+        }
+        const float av[4] = {at.x, at.y, at.z, at.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float bv[4] = {bt[it].x, bt[it].y, bt[it].z, bt[it].w};
+                wacc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], wacc[it], 0, 0, 0);
+            }
+        // next stage -> LDS (the other buffer: its last readers passed the barrier at the end of the previous iteration)
+        if (st + 1 < 4) {
+            commit(st + 1, (st & 1) ? rawA : rawB);
+            if (st + 3 < 4) {
+                if (st & 1) issue(st + 3, rawA); else issue(st + 3, rawB);
+            }
+        }
+        // data-gradient epilogue: rows 4q + r, columns cg (dg) and H + cg (dx_)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
+            const int row = rv[r] & ((1 << 30) - 1);
+            buf_store1(r_out, live ? (int)((row * A.ldo + cg) * 4) : kBufOOB, accg[r]);
+            buf_store1(r_out, live ? (int)((row * A.ldo + H + cg) * 4) : kBufOOB, accx[r]);
+            const float gp = live ? accg[r] * uu[r] : 0.f;
+            s1 += gp;
+            s2 = fmaf(live ? accg[r] : 0.f, xx[r], s2);
+        }
+        if (st + 1 < 4) lds_barrier();
+    }
+    D_STAMP(3, 3);
+    // weight-gradient partial of this workgroup: plain [o][i]
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(16 * w + 4 * q + r) * (2 * H) + 16 * it + j] = wacc[it][r];
+    if (tid < H) part_b[(int64_t)blockIdx.x * kSLOut + tid] = bsum;
+    if (gs.partial) {
+        double a = (double)s1, b2 = (double)s2;
+        a += __shfl_xor(a, 16);
+        b2 += __shfl_xor(b2, 16);
+        a += __shfl_xor(a, 32);
+        b2 += __shfl_xor(b2, 32);
+        if (q == 0) {
+            if (gs.exact) {
+                gn_acc_add(reinterpret_cast<long long*>(gs.partial), blockIdx.x % gs.exact, 0, cg, H, a, kAccScaleBwd);
+                gn_acc_add(reinterpret_cast<long long*>(gs.partial), blockIdx.x % gs.exact, 1, cg, H, b2, kAccScaleBwd);
+            } else {
+                gs.partial[((size_t)blockIdx.x * 2) * H + cg] = a;
+                gs.partial[((size_t)blockIdx.x * 2 + 1) * H + cg] = b2;
+            }
+        }
+    }
+    D_STAMP(3, 4);
+}
+
 // Fused backward launch of the comb pair in effective-weight form: data-gradient row tiles (main + extra), then the
 // weight-gradient blocks in S / L form (wgrad_sl_body: row slabs, then the labeled-row tiles).
 template <int H>
@@ -1249,6 +1519,7 @@ __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A,
         float* header = part_b + (int64_t)(sl.n_s + sl.n_l) * kSLOut;
         header[0] = 2.f;
         header[1] = zr;
+        header[2] = 0.f;  // (tiles in the permuted accumulator order)
     }
     if (b < n_dgrad_blocks) {
         D_STAMP(3, 0);
@@ -1332,12 +1603,14 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
         }
         return;
     }
-    if (j.layout == kLayoutWave16EffFwd || j.layout == kLayoutWave16EffDgrad || j.layout == kLayoutWave16EffFwdCols) {
+    if (j.layout == kLayoutWave16EffFwd || j.layout == kLayoutWave16EffDgrad || j.layout == kLayoutWave16EffFwdCols ||
+        j.layout == kLayoutWave16EffDgradCols) {
         // comb pair, hidden 64: two wave16 images of the effective weights c1 * (f1 half) + c0 * (f0 half) — unlabeled rows
         // (c1, c0) = (1-z, z), then labeled rows (z, 1-z).  Forward: the halves are the two row blocks of B (NT/2 outputs
         // each); data gradient (transposed source): the two halves of k (the stacked output index of the pair).
-        const bool fwd = j.layout != kLayoutWave16EffDgrad;
-        const bool cols = j.layout == kLayoutWave16EffFwdCols;  // tile t = columns 16t .. 16t+15 (comb_fwd_eff2_kernel)
+        const bool fwd = j.layout == kLayoutWave16EffFwd || j.layout == kLayoutWave16EffFwdCols;
+        // "Cols" forms: tile t = columns 64 (t >> 2) + 16 (t & 3) .. + 15 (the staged kernels: a wave owns 16 consecutive columns)
+        const bool cols = j.layout == kLayoutWave16EffFwdCols || j.layout == kLayoutWave16EffDgradCols;
         const int NTe = fwd ? j.NT / 2 : j.NT, KTe = fwd ? j.KT : j.KT / 2;
         const int KQ = KTe / 4, NTILES = NTe / 16, per = NTe * KTe / 4;
         const float zr = j.zr, omz = 1.f - j.zr;
@@ -1345,7 +1618,7 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
             const int img = l >= per, ll = img ? l - per : l;
             const int lane = ll & 63, v = (ll >> 6) & 3, t = (ll >> 8) % NTILES, kc = (ll >> 8) / NTILES;
             const int jj = lane & 15, q = lane >> 4;
-            const int n = cols ? 16 * t + jj : tile_col(t, jj), k = q * KQ + kc * kKC + 4 * v;
+            const int n = cols ? 64 * (t >> 2) + 16 * (t & 3) + jj : tile_col(t, jj), k = q * KQ + kc * kKC + 4 * v;
             const float4 a = pack_fetch(j, n, k);
             const float4 b = fwd ? pack_fetch(j, j.NT / 2 + n, k) : pack_fetch(j, n, j.KT / 2 + k);
             const float c1 = img ? zr : omz, c0 = img ? omz : zr;
@@ -1416,7 +1689,6 @@ static void allow_lds(K kernel, size_t bytes) {
 static bool wave16_shape_ok(int64_t H) { return H == 64; }
 // Above this many rows the two halves of the backward of a pair fill the chip on their own (one launch each, the
 // weight gradient with its 4-stage pipeline); below, they run as two branches of one launch (dual_bwd_kernel).
-static constexpr int64_t kFusedBwdMaxRows = 100000;
 static bool tiled_here(int64_t H) { return tiled_shape_ok(H) && !wave16_shape_ok(H); }
 static bool dense_shape_ok(int64_t H) { return wave16_shape_ok(H) || tiled_shape_ok(H) || narrow_shape_ok(H); }
 static size_t lds_bytes(int64_t NT, int n_pass) {  // weight images resident at once: two when K needs more than one pass
@@ -1689,6 +1961,13 @@ extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab
     return ceil_div(n_nodes, 64) + ceil_div(lab_cap, 64);
 }
 
+// Layout code(s) of the data-gradient image glass_comb_eff_bwd_f32 reads: 7, and when the staged kernel is compiled in the
+// buffer holds a SECOND pair of images in layout 10 behind the first (returns 10 then; 0 otherwise)
+extern "C" int glass_comb_eff_dgrad_layout2(int64_t H) {
+    (void)H;
+    return GLASS_COMB_BWD_V2 ? kLayoutWave16EffDgradCols : 0;
+}
+
 // Most rows glass_comb_eff_fwd_f32 serves when every operand's row stride is <= ld floats (32-bit buffer offsets)
 extern "C" int64_t glass_comb_eff_max_rows(int64_t ld) {
     if (ld <= 0) return GLASS_E_ARG;
@@ -1732,9 +2011,14 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     const int64_t ld_max = std::max(std::max(lda, ldb), std::max(ldo, gn_saved ? ldxo : (int64_t)0));
     GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || n_nodes * ld_max * 4 < (1ll << 31),
                   "comb_eff_fwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets; glass_comb_eff_max_rows)");
-    if (GLASS_COMB_FWD_V2)
-        hipLaunchKernelGGL((comb_fwd_eff2_kernel<64>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, bias,
-                           mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
+    GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || !gn_saved || gn_act == GLASS_ACT_NONE,
+                  "comb_eff_fwd: the GraphNorm in front of the comb pair has no activation (impl/models.py:165-166)");
+    if (GLASS_COMB_FWD_V2 && gn_saved && p_drop > 0.f)
+        hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
+                           bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
+    else if (GLASS_COMB_FWD_V2)
+        hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
+                           bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
     else
         hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
                            bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
@@ -1787,6 +2071,20 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
         launch_wgrad_sl(sl, n_nodes, zr, part_w, part_b, st);
         return launch_status("glass_comb_eff_bwd_f32 (two launches)");
     }
+    if (GLASS_COMB_BWD_V2) {
+        // staged form: WTimg_eff holds the layout-7 images (read by the kernels above), then the layout-10 images
+        GLASS_REQUIRE(gn_act == GLASS_ACT_NONE, "comb_eff_bwd: the GraphNorm in front of the comb pair has no activation");
+        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(ldx, ldx2), gn_partial ? gn_ldx : (int64_t)0));
+        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "comb_eff_bwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
+        DgradEffArgs d2 = dargs;
+        d2.WT = WTimg_eff + 2 * (2 * H * H);
+        const dim3 grid2((unsigned)(g.n_s + g.n_l));
+        if (gn_partial && gn_p_drop > 0.f)
+            hipLaunchKernelGGL((comb_bwd_eff2_kernel<64, true>), grid2, dim3(kBlock), 0, st, d2, X, ldx, X2, ldx2, zr, g.n_l, part_w, part_b);
+        else
+            hipLaunchKernelGGL((comb_bwd_eff2_kernel<64, false>), grid2, dim3(kBlock), 0, st, d2, X, ldx, X2, ldx2, zr, g.n_l, part_w, part_b);
+        return launch_status("glass_comb_eff_bwd_f32 (staged)");
+    }
     const size_t lds_wg = (size_t)(2 * kTile + 8 * kSLOut) * sizeof(float);
     const size_t lds_fused = lds_dg > lds_wg ? lds_dg : lds_wg;
     allow_lds(comb_bwd_eff_kernel<64>, lds_fused);
@@ -1821,7 +2119,8 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
                           (layout == kLayoutTiledPairedEff && NT[k] % 512 == 0 && !(transposed[k] & 1) && z_ratio) ||
                           ((layout == kLayoutWave16EffFwd || layout == kLayoutWave16EffFwdCols) && NT[k] % 128 == 0 &&
                            !(transposed[k] & 1) && z_ratio) ||
-                          (layout == kLayoutWave16EffDgrad && KT[k] % 128 == 0 && (transposed[k] & 1) && z_ratio),
+                          ((layout == kLayoutWave16EffDgrad || layout == kLayoutWave16EffDgradCols) && KT[k] % 128 == 0 &&
+                           (transposed[k] & 1) && z_ratio),
                       "%s: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
                       "layout that is not the transposed 128 x 256 operand", what, k, layout);
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f};

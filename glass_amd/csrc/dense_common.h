@@ -61,6 +61,7 @@ struct LabRows {
 // (glass_dual_linear_layout(H) == 2: no images at all — the narrow kernels read the row-major weight)
 enum { kLayoutWave16 = 0, kLayoutTiledPaired = 1, kLayoutTiledPlain = 2, kLayoutTiledSplit = 3, kLayoutTiledPlainEff = 4,
        kLayoutTiledPairedEff = 5, kLayoutWave16EffFwd = 6, kLayoutWave16EffDgrad = 7 };
+constexpr int kLayoutWave16EffDgradCols = 10;  // as 7 with that column order (comb_bwd_eff2_kernel)
 constexpr int kLayoutWave16Cols = 9;  // as 0 with tile t = columns 64 (t >> 2) + 16 (t & 3) .. + 15 (trans_fwd2_kernel)
 constexpr int kLayoutWave16EffFwdCols = 8;  // as 6 with tile t = output columns 16t .. 16t+15 (comb_fwd_eff2_kernel)
 // kLayoutWave16EffFwd / EffDgrad (comb pair at hidden 64, dense.hip): TWO wave16 images back to back, of the effective weight

@@ -56,6 +56,7 @@ __device__ __forceinline__ void wgrad_reduce_sl_body(const float* __restrict__ p
     const bool is_bias = k0 >= kTile;
     if (is_bias && (k0 - kTile >= kSLOut || db == nullptr)) return;  // whole workgroup: 64 columns per block
     const float zr = part_b[(int64_t)(n_s + n_l) * kSLOut + 1];
+    const bool plain = part_b[(int64_t)(n_s + n_l) * kSLOut + 2] != 0.f;  // tiles in [o][i] order (comb_bwd_eff2_kernel)
     const float* p = is_bias ? part_b + (k0 - kTile) : part_w + k0;
     const int64_t stride = is_bias ? kSLOut : kTile;
     auto run_sum = [&](int b0, int b1) __attribute__((always_inline)) {
@@ -94,7 +95,7 @@ __device__ __forceinline__ void wgrad_reduce_sl_body(const float* __restrict__ p
             const int lane = k & 63, reg = (k >> 6) & 15, tu = k >> 10;
             const int t = tu >> 2, u = tu & 3;
             const int m = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), n = lane & 31;
-            const int o = 2 * m + t, i = 4 * n + u;
+            const int o = plain ? k >> 7 : 2 * m + t, i = plain ? k & 127 : 4 * n + u;
             float* d1 = dW + (int64_t)o * lddw + i;
             float* d0 = dW + (int64_t)(kSLOut + o) * lddw + i;
             *d1 = accumulate ? *d1 + g1 : g1;
@@ -357,6 +358,14 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_sel_kernel(ReduceBatch ba
 WgradSLGeom wgrad_sl_geom(int64_t N, int64_t lab_cap) {
     WgradSLGeom g;
     g.n_l = (int)ceil_div(lab_cap > 0 ? lab_cap : 1, 64);
+    if (GLASS_COMB_BWD_V2 && N <= kFusedBwdMaxRows) {
+        // staged backward (comb_bwd_eff2_kernel, dense.hip): every 64-row tile of the data gradient writes its own S tile
+        g.rows_per_slab = 64;
+        g.n_s = (int)ceil_div(N, 64);
+        g.part_w_floats = (int64_t)(g.n_s + g.n_l) * kTile;
+        g.part_b_floats = (int64_t)(g.n_s + g.n_l) * kSLOut + kWgradHeaderFloats;
+        return g;
+    }
     // small graphs: the slabs share ONE launch with the data gradient's row tiles (comb_bwd_eff_kernel: N/64 + n_l row
     // tiles, two workgroups per CU) — keep the sum within the 512 resident workgroups of the chip
     int64_t room = N <= 100000 ? 2 * 256 - 4 - ceil_div(N, 64) - 2 * g.n_l : 256;
@@ -380,6 +389,7 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_sl_kernel(WgradSL a, int64_t 
         float* header = part_b + (int64_t)(a.n_s + a.n_l) * kSLOut;
         header[0] = 2.f;
         header[1] = zr;
+        header[2] = 0.f;  // (tiles in the permuted accumulator order)
     }
     wgrad_sl_body<4>(a, N, blockIdx.x, part_w, part_b, lds, lds + 2 * kTile);
 }

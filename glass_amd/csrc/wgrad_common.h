@@ -224,6 +224,10 @@ struct WgradSLGeom {
 WgradSLGeom wgrad_sl_geom(int64_t N, int64_t lab_cap);  // linear.hip
 void launch_wgrad_sl(const WgradSL& a, int64_t N, float zr, float* part_w, float* part_b, hipStream_t st);  // linear.hip
 constexpr int kSLOut = 64;  // outputs of the S / L tile (H)
+constexpr int64_t kFusedBwdMaxRows = 100000;  // up to here the data + weight gradient of a pair share one launch
+#ifndef GLASS_COMB_BWD_V2
+#define GLASS_COMB_BWD_V2 0  // (dense.hip: measured slower, kept as laboratory code)
+#endif
 
 __device__ __forceinline__ int acc_index_sl(int t, int u, int reg, int lane) { return ((t * 4 + u) * 16 + reg) * 64 + lane; }
 

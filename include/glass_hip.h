@@ -352,6 +352,7 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
  *   = this call's lab_cap. */
 int glass_comb_eff_supported(int64_t H);
 int glass_comb_eff_fwd_layout(int64_t H); /* pack layout of Wimg_eff for glass_comb_eff_fwd_f32: 6 or 8 */
+int glass_comb_eff_dgrad_layout2(int64_t H); /* != 0: WTimg_eff holds a second pair of images in this layout behind the layout-7 pair */
 int64_t glass_comb_eff_max_rows(int64_t ld); /* most rows the forward serves at operand row strides <= ld floats */
 int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap);
 int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t lab_cap); /* `ws` of glass_comb_eff_bwd_f32 */

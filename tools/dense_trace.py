@@ -59,7 +59,7 @@ def main():
         st = t[:, :, 0][live] - t0
         print(f"   data waves start  p10/p50/p90/max {pct(st, 10):.0f}/{pct(st, 50):.0f}/{pct(st, 90):.0f}/{st.max():.0f}")
         prev = 0
-        for slot, nm in ((1, "coef"), (2, "product"), (3, "store"), (4, "sums")):
+        for slot, nm in ((1, "coef"), (2, "product"), (3, "stages"), (4, "sums")):
             ok = live & (t[:, :, slot] > 0)
             if not ok.any():
                 continue
@@ -68,7 +68,8 @@ def main():
             prev = slot
         if sel <= 2:  # forward kernels: inside the product — 5 first weight image committed, 6 first operand chunk ready,
             #               7 second chunk ready (after the first pass's MFMAs were issued)
-            for a, b, nm in ((1, 5, "W commit"), (5, 6, "A finish"), (6, 7, "pass0+A1"), (6, 2, "6->end")):
+            # (staged comb forward: 5 stage 1 begins, 6 its rows stored to LDS + next loads issued, 7 barrier passed, 2 MFMAs issued)
+            for a, b, nm in ((1, 5, "1->5"), (5, 6, "5->6"), (6, 7, "6->7"), (7, 2, "7->2"), (2, 3, "2->3")):
                 ok = live & (t[:, :, a] > 0) & (t[:, :, b] > 0)
                 if ok.any():
                     d = (t[:, :, b] - t[:, :, a])[ok]
