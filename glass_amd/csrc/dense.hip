@@ -800,7 +800,9 @@ __device__ __forceinline__ void buf_store1(buf_rsrc r, int off, float f) {
 #ifndef GLASS_STAGE_INTERLEAVE
 #define GLASS_STAGE_INTERLEAVE 4
 #endif
-template <int H, bool DROP>
+// NST = 16-row stages per workgroup (4: 64-row tiles; 5: 80-row tiles, taken when that brings the launch down to one
+// workgroup per CU — 280 workgroups on 256 CUs leave 24 CUs with two, whose waves share the matrix cores and finish last)
+template <int H, bool DROP, int NST>
 __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
                                                                const float* __restrict__ Wimg, const float* __restrict__ bias,
@@ -812,7 +814,8 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
     constexpr int KT = 2 * H, RS = KT + 4;  // LDS row stride (floats): + 4 keeps the 16 rows of a b128 read off one bank group
     __shared__ __attribute__((aligned(16))) float tile[2][16 * RS];
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
-    __shared__ int rows_s[64];  // row of each of the workgroup's 64 slots: -1 none; bit 30 set: computed but not stored / counted
+    constexpr int ROWS = 16 * NST;
+    __shared__ int rows_s[ROWS];  // row of each of the workgroup's slots: -1 none; bit 30 set: computed but not stored / counted
     D_STAMP(1, 0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -820,7 +823,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
     int n_lab = 0, base = 0;
     if (extra) {
         n_lab = lab.count[0];
-        base = ((int)blockIdx.x - lab.n_main) * 64;
+        base = ((int)blockIdx.x - lab.n_main) * ROWS;
         if (base >= n_lab) {  // extra workgroup beyond the list: an empty partial
             if (stats && !stats_exact)
                 for (int c = tid; c < 2 * H; c += kBlock) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
@@ -839,25 +842,25 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
     // the two float4 this thread moves per stage: 4-column group ga of the a half (GraphNorm prologue) and of the h half of
     // row rs of the stage (one buffer resource per half: wave-uniform)
     const int rs = tid >> 4, ga = tid & 15;
-    int my_row[4];  // (-1: none)
+    int my_row[NST];  // (-1: none)
     int slot_v = -1;   // row of slot `tid` (threads < 64)
     unsigned char slot_mask = 0;
     if (!extra) {
-        const int64_t r0 = (int64_t)blockIdx.x * 64;
+        const int64_t r0 = (int64_t)blockIdx.x * ROWS;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
-        if (tid < 64 && r0 + tid < N) {
+        for (int st = 0; st < NST; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+        if (tid < ROWS && r0 + tid < N) {
             slot_v = (int)(r0 + tid);
             slot_mask = mask[r0 + tid];
         }
     } else {  // listed rows: through LDS (one load per slot)
-        if (tid < 64) {
+        if (tid < ROWS) {
             slot_v = base + tid < n_lab ? lab.rows[base + tid] : -1;
             rows_s[tid] = slot_v;
         }
         lds_barrier();
 #pragma unroll
-        for (int st = 0; st < 4; ++st) my_row[st] = rows_s[16 * st + rs];
+        for (int st = 0; st < NST; ++st) my_row[st] = rows_s[16 * st + rs];
     }
     auto issue = [&](int st, float4 (&raw)[2]) __attribute__((always_inline)) {
         const int r = my_row[st];
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
         drop.step = pro.rng_state[1];
     }
     if (pro.saved) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
-    if (tid < 64) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
+    if (tid < ROWS) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
     D_STAMP(1, 1);
     lds_barrier();  // coefficients + row table
     const bool pro_on = pro.saved != nullptr;
@@ -910,7 +913,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
     issue(2, rawA);
     lds_barrier();
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < NST; ++st) {
         if (st == 1) D_STAMP(1, 5);
         const float* T = tile[st & 1] + j * RS + 32 * q;
         float4 a4[8];
@@ -920,7 +923,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
         float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (st + 1 < 4) vn = prep(st + 1, (st & 1) ? rawA[0] : rawB[0]);  // the NEXT stage's rows (even stages come in rawA)
+        if (st + 1 < NST) vn = prep(st + 1, (st & 1) ? rawA[0] : rawB[0]);  // the NEXT stage's rows (even stages come in rawA)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the dependent-MFMA latency
 #pragma unroll
         for (int tt = 0; tt < 8; tt += 2) {
@@ -934,9 +937,9 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
             }
         }
         if (st == 1) D_STAMP(1, 2);
-        if (st + 1 < 4) {
+        if (st + 1 < NST) {
             commit(st + 1, vn, (st & 1) ? rawA[1] : rawB[1]);
-            if (st + 3 < 4) {
+            if (st + 3 < NST) {
                 if (st & 1) issue(st + 3, rawA); else issue(st + 3, rawB);
             }
         }
@@ -957,7 +960,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
             __builtin_amdgcn_sched_group_barrier(0x002, GLASS_STAGE_INTERLEAVE, 0);
         }
 #endif
-        if (st + 1 < 4) lds_barrier();  // the next stage's rows are in LDS; every wave is done reading this stage's buffer
+        if (st + 1 < NST) lds_barrier();  // the next stage's rows are in LDS; every wave is done reading this stage's buffer
     }
     D_STAMP(1, 3);
     if (stats == nullptr) return;
@@ -983,7 +986,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
 // A wave owns columns 16w .. 16w+15 of BOTH halves (the label mix needs f1 and f0 of a column in one lane): 2 x 4 float4 of
 // weights per lane (K = 64), 32 MFMAs per 16-row stage; one float4 of the operand per thread and stage.  Image: layout
 // kLayoutWave16Cols.  xa_index: the stage's rows are gathered from the embedding table (layer 0).
-template <int H>
+template <int H, int NST>
 __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restrict__ xa, int64_t lda, int64_t xa_rows,
                                                             const float* __restrict__ Wimg, const float* __restrict__ bias,
                                                             const uint8_t* __restrict__ mask, float zr, float omz, int act,
@@ -994,7 +997,8 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
     constexpr int RS = H + 4;  // LDS row stride (floats)
     __shared__ __attribute__((aligned(16))) float tile[2][16 * RS];
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
-    __shared__ int rows_s[64];  // row of each slot: -1 none; bit 30: labeled row (mix weights swapped)
+    constexpr int ROWS = 16 * NST;
+    __shared__ int rows_s[ROWS];  // row of each slot: -1 none; bit 30: labeled row (mix weights swapped)
     D_STAMP(2, 0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -1010,23 +1014,23 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
     }
     const float b1 = bias[16 * w + j], b0 = bias[H + 16 * w + j];
     const int rs = tid >> 4, ga = tid & 15;
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
-    int my_row[4], my_src[4];  // output row of this thread's float4 per stage (-1 none) and the operand row it comes from
+    const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+    int my_row[NST], my_src[NST];  // output row of this thread's float4 per stage (-1 none) and the operand row it comes from
 #pragma unroll
-    for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+    for (int st = 0; st < NST; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
     if (xa_index) {
-        int64_t idx[4];
+        int64_t idx[NST];
 #pragma unroll
-        for (int st = 0; st < 4; ++st) idx[st] = my_row[st] >= 0 ? xa_index[my_row[st]] : 0;
+        for (int st = 0; st < NST; ++st) idx[st] = my_row[st] >= 0 ? xa_index[my_row[st]] : 0;
 #pragma unroll
-        for (int st = 0; st < 4; ++st) my_src[st] = (int)(idx[st] < 0 ? 0 : (idx[st] >= xa_rows ? xa_rows - 1 : idx[st]));
+        for (int st = 0; st < NST; ++st) my_src[st] = (int)(idx[st] < 0 ? 0 : (idx[st] >= xa_rows ? xa_rows - 1 : idx[st]));
     } else {
 #pragma unroll
-        for (int st = 0; st < 4; ++st) my_src[st] = my_row[st];
+        for (int st = 0; st < NST; ++st) my_src[st] = my_row[st];
     }
     int slot_v = -1;
     unsigned char slot_mask = 0;
-    if (tid < 64 && r0 + tid < N) {
+    if (tid < ROWS && r0 + tid < N) {
         slot_v = (int)(r0 + tid);
         slot_mask = mask[r0 + tid];
     }
@@ -1040,7 +1044,7 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
         drop.step = pro.rng_state[1];
     }
     if (pro.saved) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
-    if (tid < 64) rows_s[tid] = slot_mask != 0 ? (slot_v | (1 << 30)) : slot_v;
+    if (tid < ROWS) rows_s[tid] = slot_mask != 0 ? (slot_v | (1 << 30)) : slot_v;
     D_STAMP(2, 1);
     lds_barrier();  // coefficients + row table
     const bool pro_on = pro.saved != nullptr;
@@ -1067,13 +1071,13 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
     };
     float ssum = 0.f, ssq = 0.f;
 #pragma unroll
-    for (int st = 0; st < 4; ++st) {
+    for (int st = 0; st < NST; ++st) {
         if (st & 1) {
             stage_store(st, rawB);
-            if (st + 2 < 4) rawB = issue(st + 2);
+            if (st + 2 < NST) rawB = issue(st + 2);
         } else {
             stage_store(st, rawA);
-            if (st + 2 < 4) rawA = issue(st + 2);
+            if (st + 2 < NST) rawA = issue(st + 2);
         }
         lds_barrier();
         const float* A = tile[st & 1] + j * RS + 16 * q;
@@ -1813,8 +1817,15 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
         const int64_t ld_max = std::max(std::max(ldo, T ? ldt : (int64_t)0), gn_saved ? ldxo : (int64_t)0);
         GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31) && src_rows * lda * 4 < (1ll << 31),
                       "dual_linear_fwd: rows * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
-        hipLaunchKernelGGL((trans_fwd2_kernel<64>), grid, dim3(kBlock), 0, st, xa, lda, src_rows, W, bias, mask, zr, omz, act, T, ldt,
-                           out, ldo, n_nodes, stats, stats_exact, pro, xa_index);
+        // 80-row tiles when they bring the launch down to one workgroup per CU (no per-workgroup partials then: their count
+        // is the 64-row geometry of glass_dual_linear_stat_rows)
+        const int64_t wg80 = ceil_div(n_nodes, 80);
+        if ((stats == nullptr || stats_exact) && grid.x > 256 && wg80 <= 256)
+            hipLaunchKernelGGL((trans_fwd2_kernel<64, 5>), dim3((unsigned)wg80), dim3(kBlock), 0, st, xa, lda, src_rows, W, bias, mask,
+                               zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index);
+        else
+            hipLaunchKernelGGL((trans_fwd2_kernel<64, 4>), grid, dim3(kBlock), 0, st, xa, lda, src_rows, W, bias, mask, zr, omz, act,
+                               T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index);
         return launch_status("glass_dual_linear_fwd_f32");
     }
     GLASS_FWD(64, 1, 4)
@@ -1999,8 +2010,16 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     GLASS_REQUIRE(lda >= H && lda % 4 == 0 && aligned16(xa) && ldb >= H && ldb % 4 == 0 && aligned16(xb) &&
                       aligned16(Wimg_eff) && aligned16(bias) && ldo >= H && ldo % 4 == 0 && aligned16(out),
                   "comb_eff_fwd: operands must be 16-B aligned with ld %% 4 == 0");
-    const int n_main = (int)ceil_div(n_nodes, 64);
-    const dim3 grid((unsigned)(n_main + ceil_div(lab_cap, 64)));
+    int n_main = (int)ceil_div(n_nodes, 64);
+    dim3 grid((unsigned)(n_main + ceil_div(lab_cap, 64)));
+    // 80-row tiles when they bring the launch down to one workgroup per CU (and no per-workgroup partials are written:
+    // their count is glass_comb_eff_blocks = the 64-row geometry)
+    const int64_t wg80 = ceil_div(n_nodes, 80) + ceil_div(lab_cap, 80);
+    const bool tall = GLASS_COMB_FWD_V2 && (stats == nullptr || stats_exact) && grid.x > 256 && wg80 <= 256;
+    if (tall) {
+        n_main = (int)ceil_div(n_nodes, 80);
+        grid = dim3((unsigned)wg80);
+    }
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     GnExactSrc esrc;
     GLASS_REQUIRE(make_exact_src(gn_src, gn_saved, esrc) && (!stats_exact || (stats && rep_ok(stats_exact))),
@@ -2013,12 +2032,17 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
                   "comb_eff_fwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets; glass_comb_eff_max_rows)");
     GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || !gn_saved || gn_act == GLASS_ACT_NONE,
                   "comb_eff_fwd: the GraphNorm in front of the comb pair has no activation (impl/models.py:165-166)");
-    if (GLASS_COMB_FWD_V2 && gn_saved && p_drop > 0.f)
-        hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, true>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
-                           bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
-    else if (GLASS_COMB_FWD_V2)
-        hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, false>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
-                           bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
+#define GLASS_CF2(DR, NS)                                                                                                 \
+    hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, DR, NS>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, \
+                       bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
+    const bool dr = gn_saved && p_drop > 0.f;
+    if (GLASS_COMB_FWD_V2) {
+        if (dr && tall) GLASS_CF2(true, 5);
+        else if (dr) GLASS_CF2(true, 4);
+        else if (tall) GLASS_CF2(false, 5);
+        else GLASS_CF2(false, 4);
+    }
+#undef GLASS_CF2
     else
         hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
                            bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
