@@ -169,4 +169,38 @@ __device__ __forceinline__ void adam_ticket(int64_t* __restrict__ step_dev, int6
     }
 }
 
+// ---- LDS-only barrier and buffer addressing (the staged dense kernels) -----------------------------------------------
+// lds_barrier: s_waitcnt lgkmcnt(0) + s_barrier — what a stage hand-over through LDS needs.  __syncthreads() also carries a
+// release fence that waits for vmcnt(0), i.e. it DRAINS the wave's outstanding global loads: a prefetch across it is no
+// prefetch.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Buffer addressing for the stage loop: an out-of-range offset makes a load return 0 and drops a store, so row validity
+// costs no branch — and the loop holds no CONDITIONAL memory instruction.  That matters for more than the branch: vmcnt
+// counts loads and stores in issue order, and when a younger memory instruction may or may not have been issued the
+// compiler has to wait with vmcnt(0) for an older load — i.e. for every store in flight (the first version of this kernel
+// stalled ~1 us per two stages on its own output stores; ISA: `global_store_dwordx4; s_waitcnt vmcnt(0); ds_write_b128`).
+using buf_rsrc = __amdgpu_buffer_rsrc_t;
+typedef unsigned u32x4 __attribute__((__vector_size__(16)));  // (the builtin's own type; an ext_vector_type took one dword and splat it)
+constexpr int kBufOOB = 0x7fffffff;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* p, int64_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(buf_rsrc r, int off) {
+    // (whole-vector copy: __builtin_bit_cast on the ELEMENTS of the vector compiled to one dword load splat four times)
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    float4 f;
+    __builtin_memcpy(&f, &v, sizeof(f));
+    return f;
+}
+__device__ __forceinline__ void buf_store4(buf_rsrc r, int off, const float4& f) {
+    u32x4 v;
+    __builtin_memcpy(&v, &f, sizeof(v));
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store1(buf_rsrc r, int off, float f) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r, off, 0, 0);
+}
+
+
 }  // namespace glass

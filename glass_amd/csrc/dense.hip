@@ -38,6 +38,12 @@ namespace glass {
 // on 256 CUs leave 24 CUs with two of them (their waves share the matrix cores: lives of 17 us beside a mean of 11.9).
 #define GLASS_COMB_BWD_V2 0
 #endif
+#ifndef GLASS_TRANS_DGRAD_V2
+#define GLASS_TRANS_DGRAD_V2 1  // trans data gradient at hidden 64 in the staged form (trans_dgrad2_body)
+#endif
+#ifndef GLASS_TRANS_WGRAD_STAGED2
+#define GLASS_TRANS_WGRAD_STAGED2 1  // trans pair's weight-gradient slabs through LDS in 16-row stages (wgrad_trans_staged2_body)
+#endif
 #ifndef GLASS_TRANS_FWD_V2
 #define GLASS_TRANS_FWD_V2 1  // trans forward at hidden 64 in the same form (trans_fwd2_kernel)
 #endif
@@ -561,9 +567,187 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
     }
 }
 
+// ---- trans data gradient in the staged form (hidden 64): out[N,64] = dZ[N,128] . Wstack (+ addend) (* the input's dropout mask)
+// Same structure as the staged forward kernels: a wave owns 16 output columns (its slice of W^T: 32 registers), the rows
+// go through LDS in four 16-row stages.  The LOADER threads synthesise dZ = mix'(dout) . ELU'(T) (eight elements each) and
+// prepare, per element of the output tile, what the epilogue needs as plain multiply-adds: the addend, the keep-scale of
+// the layer input's dropout, and for the GraphNorm whose output gradient this is  u = keep-scale . act'(x scale + shift)
+// and  xhat . u  — one dropout hash per float4, none in the epilogue; no conditional memory instruction in the stage loop.
+// Image: layout kLayoutWave16Cols of W^T ([64 outputs][128 = f1 | f0]).
+template <int H>
+__device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc, int64_t ldd, const float* __restrict__ T,
+                                                  int64_t ldt, const uint8_t* __restrict__ mask, float zr, float omz, int act,
+                                                  const float* __restrict__ WT, const float* __restrict__ addend, int64_t ldadd,
+                                                  Drop drop, const uint64_t* __restrict__ rng_state, float* __restrict__ out,
+                                                  int64_t ldo, int64_t N, GnBwdStats gs, int block, float* lds) {
+    static_assert(H == 64, "four waves x 16 columns");
+    constexpr int KT = 2 * H, RA = KT + 4, RP = H + 4;
+    constexpr int kBuf = 16 * RA + 4 * 16 * RP;  // A | ADD | M | U | XU  (floats per stage buffer)
+    int* rows_s = reinterpret_cast<int*>(lds + 2 * kBuf);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rs = tid >> 4, ga = tid & 15;
+    const int64_t r0 = (int64_t)block * 64;
+    const buf_rsrc r_d = make_rsrc(dsrc, N * ldd * 4), r_t = make_rsrc(T ? T : dsrc, T ? N * ldt * 4 : 0);
+    const buf_rsrc r_m = make_rsrc(mask, N), r_out = make_rsrc(out, N * ldo * 4);
+    const buf_rsrc r_add = make_rsrc(addend ? addend : dsrc, addend ? N * ldadd * 4 : 0);
+    const buf_rsrc r_x = make_rsrc(gs.partial ? gs.x : dsrc, gs.partial ? N * gs.ldx * 4 : 0);
+    const float4* img = reinterpret_cast<const float4*>(WT);
+    float4 bw[8];
+#pragma unroll
+    for (int tt = 0; tt < 8; ++tt) bw[tt] = img[(((tt >> 2) * 4 + w) * 4 + (tt & 3)) * 64 + lane];
+    int my_row[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+    struct Raw {
+        float4 d, t1, t0, ad, x;
+        unsigned mk;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int r = my_row[st];
+        const bool ok = r >= 0;
+        R.d = buf_load4(r_d, ok ? (int)((r * ldd + 4 * ga) * 4) : kBufOOB);
+        R.t1 = buf_load4(r_t, ok ? (int)((r * ldt + 4 * ga) * 4) : kBufOOB);
+        R.t0 = buf_load4(r_t, ok ? (int)((r * ldt + H + 4 * ga) * 4) : kBufOOB);
+        R.ad = buf_load4(r_add, ok ? (int)((r * ldadd + 4 * ga) * 4) : kBufOOB);
+        R.x = buf_load4(r_x, ok ? (int)((r * gs.ldx + 4 * ga) * 4) : kBufOOB);
+        R.mk = __builtin_amdgcn_raw_buffer_load_b8(r_m, ok ? r : kBufOOB, 0, 0);
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    const bool drop_on = drop.p > 0.f, gn_on = gs.partial != nullptr, gdrop_on = gn_on && gs.drop.p > 0.f;
+    Drop gdrop = gs.drop;
+    if (drop_on || gdrop_on) {
+        drop.seed = gdrop.seed = rng_state[0];
+        drop.step = gdrop.step = rng_state[1];
+    }
+    float g_mu[4] = {0.f, 0.f, 0.f, 0.f}, g_rs[4] = {0.f, 0.f, 0.f, 0.f}, g_al[4] = {0.f, 0.f, 0.f, 0.f};
+    float g_sc[4] = {0.f, 0.f, 0.f, 0.f}, g_sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gn_on) {
+        const float4 m4 = *reinterpret_cast<const float4*>(gs.saved + 4 * ga), r4 = *reinterpret_cast<const float4*>(gs.saved + H + 4 * ga);
+        const float4 s4 = *reinterpret_cast<const float4*>(gs.saved + 2 * H + 4 * ga), h4 = *reinterpret_cast<const float4*>(gs.saved + 3 * H + 4 * ga);
+        const float4 a4 = *reinterpret_cast<const float4*>(gs.alpha + 4 * ga);
+        g_mu[0] = m4.x, g_mu[1] = m4.y, g_mu[2] = m4.z, g_mu[3] = m4.w;
+        g_rs[0] = r4.x, g_rs[1] = r4.y, g_rs[2] = r4.z, g_rs[3] = r4.w;
+        g_sc[0] = s4.x, g_sc[1] = s4.y, g_sc[2] = s4.z, g_sc[3] = s4.w;
+        g_sh[0] = h4.x, g_sh[1] = h4.y, g_sh[2] = h4.z, g_sh[3] = h4.w;
+        g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
+    }
+    if (tid < 64) rows_s[tid] = r0 + tid < N ? (int)(r0 + tid) : -1;
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        float* A = lds + (st & 1) * kBuf;
+        float* ADD = A + 16 * RA;
+        float* M = ADD + 16 * RP;
+        float* U = M + 16 * RP;
+        float* XU = U + 16 * RP;
+        const int r = my_row[st] < 0 ? 0 : my_row[st];
+        const float c1 = R.mk ? zr : omz, c0 = R.mk ? omz : zr;
+        const float d[4] = {R.d.x, R.d.y, R.d.z, R.d.w}, t1[4] = {R.t1.x, R.t1.y, R.t1.z, R.t1.w}, t0[4] = {R.t0.x, R.t0.y, R.t0.z, R.t0.w};
+        const float xv[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
+        float z1[4], z0[4], m[4] = {1.f, 1.f, 1.f, 1.f}, gds[4] = {1.f, 1.f, 1.f, 1.f}, u[4], xu[4];
+        if (drop_on) drop_scales<4>(drop, r, 4 * ga, m);
+        if (gdrop_on) drop_scales<4>(gdrop, r, 4 * ga, gds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            z1[k] = d[k] * c1;
+            z0[k] = d[k] * c0;
+            if (act == GLASS_ACT_ELU) {
+                z1[k] *= elu_grad_f(t1[k]);
+                z0[k] *= elu_grad_f(t0[k]);
+            }
+            float uk = gds[k];
+            if (gs.act == GLASS_ACT_ELU) uk *= elu_grad_f(fmaf(xv[k], g_sc[k], g_sh[k]));
+            u[k] = uk;
+            xu[k] = (xv[k] - g_al[k] * g_mu[k]) * g_rs[k] * uk;
+        }
+        *reinterpret_cast<float4*>(A + rs * RA + 4 * ga) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+        *reinterpret_cast<float4*>(A + rs * RA + H + 4 * ga) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        *reinterpret_cast<float4*>(ADD + rs * RP + 4 * ga) = R.ad;
+        *reinterpret_cast<float4*>(M + rs * RP + 4 * ga) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<float4*>(U + rs * RP + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
+        *reinterpret_cast<float4*>(XU + rs * RP + 4 * ga) = make_float4(xu[0], xu[1], xu[2], xu[3]);
+    };
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    float s1 = 0.f, s2 = 0.f;
+    const int c = 16 * w + j;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const float* A = lds + (st & 1) * kBuf;
+        const float* ADD = A + 16 * RA;
+        const float* M = ADD + 16 * RP;
+        const float* U = M + 16 * RP;
+        const float* XU = U + 16 * RP;
+        float4 a4[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) a4[tt] = *reinterpret_cast<const float4*>(A + j * RA + 32 * q + 4 * tt);
+        int rv[4];
+        float ad[4], mm[4], uu[4], xx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rv[r] = rows_s[16 * st + 4 * q + r];
+            ad[r] = ADD[(4 * q + r) * RP + c];
+            mm[r] = M[(4 * q + r) * RP + c];
+            uu[r] = U[(4 * q + r) * RP + c];
+            xx[r] = XU[(4 * q + r) * RP + c];
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < 8; tt += 2) {
+            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+            }
+        }
+        if (st + 1 < 4) {
+            commit(st + 1, (st & 1) ? rawA : rawB);
+            if (st + 3 < 4) {
+                if (st & 1) issue(st + 3, rawA); else issue(st + 3, rawB);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0;
+            const float v = (acc0[r] + acc1[r] + ad[r]) * mm[r];
+            buf_store1(r_out, live ? (int)((rv[r] * ldo + c) * 4) : kBufOOB, v);
+            const float vl = live ? v : 0.f;
+            s1 = fmaf(vl, uu[r], s1);
+            s2 = fmaf(vl, xx[r], s2);
+        }
+        if (st + 1 < 4) lds_barrier();
+    }
+    if (!gn_on) return;
+    double a = (double)s1, b2 = (double)s2;
+    a += __shfl_xor(a, 16);
+    b2 += __shfl_xor(b2, 16);
+    a += __shfl_xor(a, 32);
+    b2 += __shfl_xor(b2, 32);
+    if (q == 0) {
+        if (gs.exact) {
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % gs.exact, 0, c, H, a, kAccScaleBwd);
+            gn_acc_add(reinterpret_cast<long long*>(gs.partial), block % gs.exact, 1, c, H, b2, kAccScaleBwd);
+        } else {
+            gs.partial[((size_t)block * 2) * H + c] = a;
+            gs.partial[((size_t)block * 2 + 1) * H + c] = b2;
+        }
+    }
+}
+constexpr size_t kTransDgrad2Lds = (size_t)(2 * (16 * (2 * 64 + 4) + 4 * 16 * (64 + 4)) + 64) * sizeof(float);
+
 template <int H, int NT, int CS, int RW>
 __global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(DgradArgs A) {
     extern __shared__ float4 lds_w[];
+    if (GLASS_TRANS_DGRAD_V2 && H == 64 && NT == 64) {
+        trans_dgrad2_body<64>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop, A.rng_state,
+                              A.out, A.ldo, A.N, A.gs, blockIdx.x, reinterpret_cast<float*>(lds_w));
+        return;
+    }
     dual_dgrad_body<H, NT, CS, RW>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
                                    A.rng_state, A.out, A.ldo, A.N, A.gs, blockIdx.x, lds_w);
 }
@@ -581,20 +765,32 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
                                                             float* __restrict__ wg_header, WgradSynth sy) {
     extern __shared__ float4 lds_w[];
     const int b = blockIdx.x;
+    // trans pair at hidden 64: the slabs go through LDS in 16-row stages (wgrad_trans_staged2_body; plain [o][i] tiles)
+    const bool staged2 = GLASS_TRANS_WGRAD_STAGED2 && NT == 64 && O == 128 && I == 64 && sy.X2 == nullptr && gy == 1;
     if (b == 0 && threadIdx.x == 0) {  // the partials below are in the plain form (mode header read by the reduce launch)
         wg_header[0] = 0.f;
         wg_header[1] = sy.zr;
+        wg_header[2] = staged2 ? 1.f : 0.f;
     }
     if (b < n_dgrad_blocks) {
         D_STAMP(4, 0);
-        dual_dgrad_body<H, NT, 1, 4>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
-                                     A.rng_state, A.out, A.ldo, A.N, A.gs, b, lds_w);
+        if (GLASS_TRANS_DGRAD_V2 && H == 64 && NT == 64)
+            trans_dgrad2_body<64>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
+                                  A.rng_state, A.out, A.ldo, A.N, A.gs, b, reinterpret_cast<float*>(lds_w));
+        else
+            dual_dgrad_body<H, NT, 1, 4>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
+                                         A.rng_state, A.out, A.ldo, A.N, A.gs, b, lds_w);
         D_STAMP(4, 4);
         return;
     }
     D_STAMP(4, 5);
     const int t = b - n_dgrad_blocks;  // slab fastest, then input tile, then output tile (as the 3-D grid of the stand-alone launch)
     float* lds = reinterpret_cast<float*>(lds_w);
+    if (staged2) {
+        wgrad_trans_staged2_body(X, ldx, A.N, rows_per_slab, part_w, part_b, sy, t, lds);
+        D_STAMP(4, 6);
+        return;
+    }
     if (GLASS_WGRAD_STAGED && NT == 64 && rows_per_slab <= kStageRows && sy.X2 == nullptr) {
         // trans pair on a small graph (one 128 x 64 tile per slab): the whole slab through LDS, one memory round trip
         wgrad_synth_staged_body(X, ldx, A.N, rows_per_slab, part_w, part_b, sy, t, gx, lds, lds + 2 * kTile);
@@ -768,34 +964,6 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
 // shuffles and go straight to the accumulators / partials — no LDS reduction.
 // Image: layout kLayoutWave16EffFwdCols (tile t = columns 16t .. 16t+15): float4 ((kc*4 + t)*4 + v)*64 + lane holds
 // W_eff[16t + j][32q + 16kc + 4v ..+3], lane = j + 16q — exactly lane (j, q)'s B operand for k = 32q + 4(4kc + v) + e.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// Buffer addressing for the stage loop: an out-of-range offset makes a load return 0 and drops a store, so row validity
-// costs no branch — and the loop holds no CONDITIONAL memory instruction.  That matters for more than the branch: vmcnt
-// counts loads and stores in issue order, and when a younger memory instruction may or may not have been issued the
-// compiler has to wait with vmcnt(0) for an older load — i.e. for every store in flight (the first version of this kernel
-// stalled ~1 us per two stages on its own output stores; ISA: `global_store_dwordx4; s_waitcnt vmcnt(0); ds_write_b128`).
-using buf_rsrc = __amdgpu_buffer_rsrc_t;
-typedef unsigned u32x4 __attribute__((__vector_size__(16)));  // (the builtin's own type; an ext_vector_type took one dword and splat it)
-constexpr int kBufOOB = 0x7fffffff;
-__device__ __forceinline__ buf_rsrc make_rsrc(const void* p, int64_t bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(buf_rsrc r, int off) {
-    // (whole-vector copy: __builtin_bit_cast on the ELEMENTS of the vector compiled to one dword load splat four times)
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-    float4 f;
-    __builtin_memcpy(&f, &v, sizeof(f));
-    return f;
-}
-__device__ __forceinline__ void buf_store4(buf_rsrc r, int off, const float4& f) {
-    u32x4 v;
-    __builtin_memcpy(&v, &f, sizeof(v));
-    __builtin_amdgcn_raw_buffer_store_b128(v, r, off, 0, 0);
-}
-__device__ __forceinline__ void buf_store1(buf_rsrc r, int off, float f) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, f), r, off, 0, 0);
-}
 
 #ifndef GLASS_STAGE_INTERLEAVE
 #define GLASS_STAGE_INTERLEAVE 4
@@ -1745,6 +1913,7 @@ extern "C" int glass_dual_linear_fwd_layout(int64_t H, int64_t K) {
     return tiled_eff_fwd_shape(H, K) ? kLayoutTiledPairedEff : kLayoutTiledPaired;
 }
 extern "C" int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out) {
+    if (GLASS_TRANS_DGRAD_V2 && wave16_shape_ok(H) && n_out == H) return kLayoutWave16Cols;  // trans pair at hidden 64: trans_dgrad2_body
     if (!tiled_here(H)) return kLayoutWave16;
     if (tiled_eff_dgrad_shape(H, n_out)) return kLayoutTiledPlainEff;
     return n_out % 256 == 0 ? kLayoutTiledPlain : kLayoutTiledSplit;
@@ -1877,7 +2046,14 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
     const dim3 grid((unsigned)ceil_div(n_nodes, glass_dual_linear_stat_rows(H)));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
     const float* Tp = act == GLASS_ACT_ELU ? T : nullptr;
-    const size_t lds_dg = lds_bytes(n_out, 2);  // K = 2H always needs >= 2 passes
+    const bool dg2 = GLASS_TRANS_DGRAD_V2 && H == 64 && n_out == H;  // (image in layout kLayoutWave16Cols: glass_dual_linear_dgrad_layout)
+    size_t lds_dg = lds_bytes(n_out, 2);  // K = 2H always needs >= 2 passes
+    if (dg2) {
+        lds_dg = kTransDgrad2Lds;
+        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(act == GLASS_ACT_ELU ? ldt : (int64_t)0, addend ? ldadd : (int64_t)0),
+                                                                     gn_partial ? gn_ldx : (int64_t)0));
+        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "dual_linear_dgrad: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
+    }
     const Drop drop = make_drop(p_drop, call_id, n_out);
     GLASS_REQUIRE(!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && gn_ldx % 4 == 0 && aligned16(gn_x) &&
                                   aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
@@ -2136,7 +2312,9 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
                           aligned16(dst[k]),
                       "%s: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", what, k);
         const int layout = transposed[k] >> 1;
-        GLASS_REQUIRE(layout == kLayoutWave16 || (layout == kLayoutWave16Cols && NT[k] == 128 && KT[k] == 64 && !(transposed[k] & 1)) ||
+        GLASS_REQUIRE(layout == kLayoutWave16 ||
+                          (layout == kLayoutWave16Cols && ((NT[k] == 128 && KT[k] == 64 && !(transposed[k] & 1)) ||
+                                                           (NT[k] == 64 && KT[k] == 128 && (transposed[k] & 1)))) ||
                           ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
                           (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
                           (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio) ||

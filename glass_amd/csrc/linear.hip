@@ -36,6 +36,7 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
     if (header && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
         header[0] = EFF ? 1.f : 0.f;  // tells the (possibly deferred) reduce launch which form the partials have
         header[1] = sy.zr;
+        header[2] = 0.f;  // (tiles in the permuted accumulator order)
     }
     wgrad_partial_body<SYNTH, 4, EFF>(G, ldg, X, ldx, N, O, I, rows_per_slab, part_w, part_b, sy, blockIdx.x, blockIdx.y,
                                       blockIdx.z, gridDim.x, gridDim.y, lds, lds + 2 * kTile, gridDim.z);
@@ -160,6 +161,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
     const float* header = part_b + (int64_t)nz * n_slabs * kOT;
     const bool eff = header[0] != 0.f;
     const float zr = header[1];
+    const bool plain = header[2] != 0.f;  // tiles in [o][i] order (wgrad_trans_staged2_body)
     const int zz = eff ? z % (nz / 2) : z;
     const float cs = !eff ? 1.f : (z < nz / 2 ? 1.f - zr : zr);
     const float cl = !eff ? 0.f : (z < nz / 2 ? 2.f * zr - 1.f : 1.f - 2.f * zr);
@@ -208,7 +210,7 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
             const int lane = k & 63, reg = (k >> 6) & 15, tu = k >> 10;
             const int t = tu >> 1, u = tu & 1;
             const int r = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), cc = lane & 31;
-            const int o = z * kOT + 4 * r + t, i = y * kIT + 2 * cc + u;
+            const int o = z * kOT + (plain ? k >> 6 : 4 * r + t), i = y * kIT + (plain ? k & 63 : 2 * cc + u);
             if (o < O && i < I) {
                 float* d = dW + (int64_t)o * lddw + i;
                 *d = accumulate ? *d + sv[q] : sv[q];

@@ -27,6 +27,7 @@ struct WgradGeom {
 WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I);  // linear.hip
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float wg_f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kOT = 128;            // outputs per workgroup (4 tiles of 32, strided by 4)
 constexpr int kIT = 64;             // inputs per workgroup  (2 tiles of 32, strided by 2)
@@ -197,6 +198,122 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
         for (int k = 0; k < 8; ++k) s += lds_b[k * kOT + threadIdx.x];
         part_b[((int64_t)bz * gx + bx) * kOT + threadIdx.x] = s;
     }
+}
+
+// ---- trans pair at hidden 64, staged form (inside the fused backward launch of small graphs) --------------------------
+// The register-pipelined body above walks a slab two row pairs at a time with 2 stages of prefetch: ~0.5 us of MFMAs per
+// stage against a ~2 us loaded round trip, so a 72-row slab lives 16 us for 2 us of matrix work.  Here the slab goes
+// through LDS in 16-row stages like the staged forward kernels (dense.hip): every thread loads one float4 of the output
+// gradient, of each pre-activation half and of the pair's input per stage (coalesced, buffer-addressed: no conditional
+// memory instruction), synthesises its eight elements of dZ = mix'(dout) . ELU'(T) and writes dZ and the input TRANSPOSED
+// ([column][16 rows]); the loads of stage s + 2 stay in flight across the LDS-only barrier of stage s.  A wave owns 32 of
+// the 128 outputs x all 64 inputs (8 accumulator tiles of 16 x 16) and reads both operands four rows per b128.  Partial
+// tile in plain [o][i] order (header[2] = 1); bias partial = row sums of the dZ tile.
+constexpr int kStg2RT = 20;                              // row stride of the transposed tiles (floats)
+constexpr int kStg2Floats = (128 + 64) * kStg2RT;        // dZ^T [128][RT] + X^T [64][RT] per buffer
+
+__device__ __forceinline__ void wgrad_trans_staged2_body(const float* __restrict__ X, int64_t ldx, int64_t N, int rows_per_slab,
+                                                         float* __restrict__ part_w, float* __restrict__ part_b,
+                                                         const WgradSynth& sy, int bx, float* lds) {
+    constexpr int H = 64, RT = kStg2RT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rs = tid >> 4, ga = tid & 15;
+    const int64_t r0 = (int64_t)bx * rows_per_slab;
+    const int64_t r1 = r0 + rows_per_slab < N ? r0 + rows_per_slab : N;
+    const int n_st = (int)((r1 - r0 + 15) / 16);
+    const buf_rsrc r_d = make_rsrc(sy.dsrc, N * sy.ldd * 4), r_t = make_rsrc(sy.T, N * sy.ldt * 4), r_x = make_rsrc(X, N * ldx * 4);
+    const buf_rsrc r_m = make_rsrc(sy.mask, N);
+    struct Raw {
+        float4 d, t1, t0, x;
+        unsigned mk;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int64_t r = r0 + 16 * st + rs;
+        const bool ok = r < r1;
+        const int ri = (int)r;
+        R.d = buf_load4(r_d, ok ? (int)((ri * sy.ldd + 4 * ga) * 4) : kBufOOB);
+        R.t1 = buf_load4(r_t, ok ? (int)((ri * sy.ldt + 4 * ga) * 4) : kBufOOB);
+        R.t0 = buf_load4(r_t, ok ? (int)((ri * sy.ldt + H + 4 * ga) * 4) : kBufOOB);
+        R.x = buf_load4(r_x, ok ? (int)((ri * ldx + 4 * ga) * 4) : kBufOOB);
+        R.mk = __builtin_amdgcn_raw_buffer_load_b8(r_m, ok ? ri : kBufOOB, 0, 0);
+    };
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        float* dzT = lds + (st & 1) * kStg2Floats;
+        float* xT = dzT + 128 * RT;
+        const float c1 = R.mk ? sy.zr : sy.omz, c0 = R.mk ? sy.omz : sy.zr;
+        const float d[4] = {R.d.x, R.d.y, R.d.z, R.d.w}, xv[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
+        const float t1[4] = {R.t1.x, R.t1.y, R.t1.z, R.t1.w}, t0[4] = {R.t0.x, R.t0.y, R.t0.z, R.t0.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float z1 = d[k] * c1, z0 = d[k] * c0;
+            if (sy.act == GLASS_ACT_ELU) {
+                z1 *= elu_grad_f(t1[k]);
+                z0 *= elu_grad_f(t0[k]);
+            }
+            dzT[(4 * ga + k) * RT + rs] = z1;
+            dzT[(H + 4 * ga + k) * RT + rs] = z0;
+            xT[(4 * ga + k) * RT + rs] = xv[k];
+        }
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    wg_f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[a][it] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;  // bias partial of output o = tid (threads < 128)
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    for (int st = 0; st < n_st; ++st) {
+        const float* dzT = lds + (st & 1) * kStg2Floats;
+        const float* xT = dzT + 128 * RT;
+        float4 at[2], bt[4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) at[a] = *reinterpret_cast<const float4*>(dzT + (16 * (2 * w + a) + j) * RT + 4 * q);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) bt[it] = *reinterpret_cast<const float4*>(xT + (16 * it + j) * RT + 4 * q);
+        if (tid < 128) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 t4 = *reinterpret_cast<const float4*>(dzT + tid * RT + 4 * v);
+                bsum += (t4.x + t4.y) + (t4.z + t4.w);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const float av[4] = {at[a].x, at[a].y, at[a].z, at[a].w};
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const float bv[4] = {bt[it].x, bt[it].y, bt[it].z, bt[it].w};
+                    acc[a][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[a][it], 0, 0, 0);
+                }
+            }
+        if (st + 1 < n_st) {
+            if (st & 1) {
+                commit(st + 1, rawA);
+                issue(st + 3, rawA);
+            } else {
+                commit(st + 1, rawB);
+                issue(st + 3, rawB);
+            }
+            lds_barrier();
+        }
+    }
+    // partial tile, plain [o][i]: o = 16 (2w + a) + 4q + r, i = 16 it + j
+    float* pw = part_w + (int64_t)bx * kTile;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[(16 * (2 * w + a) + 4 * q + r) * H + 16 * it + j] = acc[a][it][r];
+    if (part_b && tid < 128) part_b[(int64_t)bx * kOT + tid] = bsum;
 }
 
 // ---- comb pair at hidden 64: weight gradient in effective-weight ("S / L") form -------------------------------------

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
     if (header && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
         header[0] = EFF ? 1.f : 0.f;
         header[1] = sy.zr;
+        header[2] = 0.f;
     }
     const bool lab_tile = EFF && blockIdx.z >= gridDim.z / 2;  // the labeled-rows sum of output tile z - nz/2
     const int o0 = (lab_tile ? blockIdx.z - gridDim.z / 2 : blockIdx.z) * kWO, i0 = blockIdx.y * kWI;

@@ -507,7 +507,8 @@ def _pack(W, transposed, H=64, z=None):
     nt, kt = (W.shape[1], W.shape[0]) if transposed else W.shape
     if lib.glass_dual_linear_layout(H) != 1:
         # wave16 family: the forward operand of the trans pair has its own column order (layout 9) — ask the library
-        layout = 0 if (transposed or z is None) else lib.glass_dual_linear_fwd_layout(H, kt)
+        layout = 0 if z is None else (lib.glass_dual_linear_dgrad_layout(H, nt) if transposed else
+                                      lib.glass_dual_linear_fwd_layout(H, kt))
     elif z is not None:
         layout = lib.glass_dual_linear_dgrad_layout(H, nt) if transposed else lib.glass_dual_linear_fwd_layout(H, kt)
     else:
@@ -577,7 +578,7 @@ def test_dense_pack_effective_weight_appendix():
     from glass_amd import _lib
     H, z = 256, 0.9
     assert _lib.load().glass_dual_linear_dgrad_layout(H, 2 * H) == 4 and _lib.load().glass_dual_linear_dgrad_layout(H, H) == 2
-    assert _lib.load().glass_dual_linear_dgrad_layout(128, 128) == 3 and _lib.load().glass_dual_linear_dgrad_layout(64, 64) == 0
+    assert _lib.load().glass_dual_linear_dgrad_layout(128, 128) == 3 and _lib.load().glass_dual_linear_dgrad_layout(64, 64) in (0, 9)
     assert _lib.load().glass_dual_linear_dgrad_layout(128, 256) == 4
     gen = torch.Generator().manual_seed(3)
     W = torch.randn(2 * H, 2 * H, generator=gen).to(DEV)  # comb weight [2H out][2H in]; operand B = W^T: [NT = 2H in][KT = 2H out]
