@@ -38,6 +38,12 @@ namespace glass {
 // on 256 CUs leave 24 CUs with two of them (their waves share the matrix cores: lives of 17 us beside a mean of 11.9).
 #define GLASS_COMB_BWD_V2 0
 #endif
+#ifndef GLASS_SL_STAGED2
+#define GLASS_SL_STAGED2 1  // comb pair's S / L weight-gradient tiles through LDS in 16-row stages (wgrad_sl_staged2_body)
+#endif
+#ifndef GLASS_COMB_DGRAD_V2
+#define GLASS_COMB_DGRAD_V2 1  // comb data gradient at hidden 64 in the staged form inside the fused backward launch (comb_dgrad2_body)
+#endif
 #ifndef GLASS_TRANS_DGRAD_V2
 #define GLASS_TRANS_DGRAD_V2 1  // trans data gradient at hidden 64 in the staged form (trans_dgrad2_body)
 #endif
@@ -1451,6 +1457,184 @@ __global__ __launch_bounds__(kBlock) void comb_dgrad_eff_kernel(DgradEffArgs A) 
 // labeled rows, produce the L tiles — the batched reduce is the same (plain [o][i] order, header[2] = 1).  No separate
 // weight-gradient workgroups: one round of 280 workgroups instead of 505.
 // Image: layout kLayoutWave16EffDgradCols (tile t = columns 64 (t >> 2) + 16 (t & 3) .. + 15 of [dg || dx_]).
+// The data-gradient half alone, as a device function for the workgroups [0, n_dgrad) of comb_bwd_eff_kernel (the weight
+// gradient stays with its own workgroups there): image in layout kLayoutWave16EffDgradCols, `lds` >= kCombDgrad2Lds bytes.
+template <int H, bool DROP>
+__device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk, float* lds) {
+    static_assert(H == 64, "four waves x 16 columns");
+    constexpr int RS = H + 4;   // plain tiles [16 rows][H]: row stride (floats)
+    struct __attribute__((aligned(16))) Stage {
+        float dcP[16 * RS];       // dc rows (A operand)
+        float U[16 * RS];         // keep-scale of the GraphNorm's dropout per element of the g half
+        float XU[16 * RS];        // xhat * keep-scale
+    };
+    Stage* stg = reinterpret_cast<Stage*>(lds);
+    int* rows_s = reinterpret_cast<int*>(lds + 2 * (3 * 16 * RS));
+    D_STAMP(3, 0);
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int n_main = A.lab.n_main;
+    const bool extra = (int)blk >= n_main;
+    const GnBwdStats& gs = A.gs;
+    const int64_t N = A.N;
+    int n_lab = 0, base = 0;
+    if (extra) {
+        n_lab = A.lab.count[0];
+        base = ((int)blk - n_main) * 64;
+        if (base >= n_lab) {  // beyond the list: an empty L tile, empty sums
+            if (gs.partial && !gs.exact)
+                for (int c = tid; c < 2 * H; c += kBlock) gs.partial[(size_t)blk * 2 * H + c] = 0.0;
+            return;
+        }
+    }
+    const buf_rsrc r_dc = make_rsrc(A.dsrc, N * A.ldd * 4), r_out = make_rsrc(A.out, N * A.ldo * 4);
+    const buf_rsrc r_a = make_rsrc(gs.partial ? gs.x : A.dsrc, gs.partial ? N * gs.ldx * 4 : 0);
+    // this wave's slices of the effective weight (transposed operand): columns 16w .. of the dg half and of the dx_ half
+    const float4* img = reinterpret_cast<const float4*>(A.WT + (extra ? 2 * H * H : 0));
+    float4 bwg[4], bwx[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bwg[v] = img[(w * 4 + v) * 64 + lane];
+        bwx[v] = img[((4 + w) * 4 + v) * 64 + lane];
+    }
+    const int rs = tid >> 4, ga = tid & 15;  // loader role: row rs of the stage, columns 4 ga .. 4 ga + 3
+    int my_row[4];
+    int slot_v = -1;
+    unsigned char slot_mask = 0;
+    if (!extra) {
+        const int64_t r0 = (int64_t)blk * 64;
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+        if (tid < 64 && r0 + tid < N) {
+            slot_v = (int)(r0 + tid);
+            slot_mask = A.mask[r0 + tid];
+        }
+    } else {
+        if (tid < 64) {
+            slot_v = base + tid < n_lab ? A.lab.rows[base + tid] : -1;
+            rows_s[tid] = slot_v;
+        }
+        lds_barrier();
+#pragma unroll
+        for (int st = 0; st < 4; ++st) my_row[st] = rows_s[16 * st + rs];
+    }
+    struct Raw {
+        float4 dc, a;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int r = my_row[st];
+        R.dc = buf_load4(r_dc, r >= 0 ? (int)((r * A.ldd + 4 * ga) * 4) : kBufOOB);
+        R.a = buf_load4(r_a, r >= 0 ? (int)((r * gs.ldx + 4 * ga) * 4) : kBufOOB);
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    // GraphNorm coefficients of this loader thread's four columns
+    float g_mu[4] = {0.f, 0.f, 0.f, 0.f}, g_rs[4] = {0.f, 0.f, 0.f, 0.f}, g_al[4] = {0.f, 0.f, 0.f, 0.f};
+    Drop drop = gs.drop;
+    if (gs.partial) {
+        if (DROP) {
+            drop.seed = A.rng_state[0];
+            drop.step = A.rng_state[1];
+        }
+        const float4 m4 = *reinterpret_cast<const float4*>(gs.saved + 4 * ga);
+        const float4 r4 = *reinterpret_cast<const float4*>(gs.saved + H + 4 * ga);
+        const float4 a4 = *reinterpret_cast<const float4*>(gs.alpha + 4 * ga);
+        g_mu[0] = m4.x, g_mu[1] = m4.y, g_mu[2] = m4.z, g_mu[3] = m4.w;
+        g_rs[0] = r4.x, g_rs[1] = r4.y, g_rs[2] = r4.z, g_rs[3] = r4.w;
+        g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
+    }
+    if (tid < 64) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;
+    // stage -> LDS: the loader's four float4 in the layouts their readers want
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        Stage& S = stg[st & 1];
+        const int r = my_row[st];
+        *reinterpret_cast<float4*>(S.dcP + rs * RS + 4 * ga) = R.dc;
+        const float av[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
+        float u[4], xu[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            u[k] = ds[k];
+            xu[k] = (av[k] - g_al[k] * g_mu[k]) * g_rs[k] * ds[k];
+        }
+        *reinterpret_cast<float4*>(S.U + rs * RS + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
+        *reinterpret_cast<float4*>(S.XU + rs * RS + 4 * ga) = make_float4(xu[0], xu[1], xu[2], xu[3]);
+    };
+    commit(0, rawA);
+    issue(2, rawA);
+    D_STAMP(3, 1);
+    lds_barrier();
+    float s1 = 0.f, s2 = 0.f;     // GraphNorm backward sums of column 16w + j over this lane's rows
+    const int cg = 16 * w + j;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+        const Stage& S = stg[st & 1];
+        float4 a4[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(S.dcP + j * RS + 16 * q + 4 * v);
+        int rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        float uu[4], xx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            uu[r] = S.U[(4 * q + r) * RS + cg];
+            xx[r] = S.XU[(4 * q + r) * RS + cg];
+        }
+        f32x4 accg = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
+            const float yg[4] = {bwg[v].x, bwg[v].y, bwg[v].z, bwg[v].w}, yx[4] = {bwx[v].x, bwx[v].y, bwx[v].z, bwx[v].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yg[e], accg, 0, 0, 0);
+                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yx[e], accx, 0, 0, 0);
+            }
+        }
+        // next stage -> LDS (the other buffer: its last readers passed the barrier at the end of the previous iteration)
+        if (st + 1 < 4) {
+            commit(st + 1, (st & 1) ? rawA : rawB);
+            if (st + 3 < 4) {
+                if (st & 1) issue(st + 3, rawA); else issue(st + 3, rawB);
+            }
+        }
+        // data-gradient epilogue: rows 4q + r, columns cg (dg) and H + cg (dx_)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
+            const int row = rv[r] & ((1 << 30) - 1);
+            buf_store1(r_out, live ? (int)((row * A.ldo + cg) * 4) : kBufOOB, accg[r]);
+            buf_store1(r_out, live ? (int)((row * A.ldo + H + cg) * 4) : kBufOOB, accx[r]);
+            const float gp = live ? accg[r] * uu[r] : 0.f;
+            s1 += gp;
+            s2 = fmaf(live ? accg[r] : 0.f, xx[r], s2);
+        }
+        if (st + 1 < 4) lds_barrier();
+    }
+    D_STAMP(3, 3);
+    if (gs.partial) {
+        double a = (double)s1, b2 = (double)s2;
+        a += __shfl_xor(a, 16);
+        b2 += __shfl_xor(b2, 16);
+        a += __shfl_xor(a, 32);
+        b2 += __shfl_xor(b2, 32);
+        if (q == 0) {
+            if (gs.exact) {
+                gn_acc_add(reinterpret_cast<long long*>(gs.partial), blk % gs.exact, 0, cg, H, a, kAccScaleBwd);
+                gn_acc_add(reinterpret_cast<long long*>(gs.partial), blk % gs.exact, 1, cg, H, b2, kAccScaleBwd);
+            } else {
+                gs.partial[((size_t)blk * 2) * H + cg] = a;
+                gs.partial[((size_t)blk * 2 + 1) * H + cg] = b2;
+            }
+        }
+    }
+    D_STAMP(3, 4);
+}
+constexpr size_t kCombDgrad2Lds = (size_t)(2 * 3 * 16 * (64 + 4) + 64) * sizeof(float);
+
 template <int H, bool DROP>
 __global__ __launch_bounds__(kBlock) void comb_bwd_eff2_kernel(DgradEffArgs A, const float* __restrict__ X, int64_t ldx,
                                                                const float* __restrict__ X2, int64_t ldx2, float zr, int n_l,
@@ -1691,16 +1875,30 @@ __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A,
         float* header = part_b + (int64_t)(sl.n_s + sl.n_l) * kSLOut;
         header[0] = 2.f;
         header[1] = zr;
-        header[2] = 0.f;  // (tiles in the permuted accumulator order)
+        header[2] = GLASS_SL_STAGED2 ? 1.f : 0.f;  // tiles in plain [o][i] order (staged body) / in the permuted accumulator order
     }
     if (b < n_dgrad_blocks) {
         D_STAMP(3, 0);
-        comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, b, lds_w);
+        if (GLASS_COMB_DGRAD_V2) {  // staged form; its images (layout 10) lie behind the layout-7 pair
+            DgradEffArgs A2 = A;
+            A2.WT = A.WT + 2 * (2 * H * H);
+            if (A.gs.partial && A.gs.drop.p > 0.f)
+                comb_dgrad2_body<H, true>(A2, b, reinterpret_cast<float*>(lds_w));
+            else
+                comb_dgrad2_body<H, false>(A2, b, reinterpret_cast<float*>(lds_w));
+        } else {
+            comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, b, lds_w);
+        }
         D_STAMP(3, 4);
         return;
     }
     D_STAMP(3, 5);
     float* lds = reinterpret_cast<float*>(lds_w);
+    if (GLASS_SL_STAGED2) {
+        wgrad_sl_staged2_body(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds);
+        D_STAMP(3, 6);
+        return;
+    }
     if (GLASS_WGRAD_STAGED && sl.rows_per_slab <= kStageRows)  // small graph: the whole slab through LDS, one memory round trip
         wgrad_sl_staged_body(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds, lds + 2 * kTile);
     else
@@ -2152,7 +2350,7 @@ extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab
 // buffer holds a SECOND pair of images in layout 10 behind the first (returns 10 then; 0 otherwise)
 extern "C" int glass_comb_eff_dgrad_layout2(int64_t H) {
     (void)H;
-    return GLASS_COMB_BWD_V2 ? kLayoutWave16EffDgradCols : 0;
+    return (GLASS_COMB_BWD_V2 || GLASS_COMB_DGRAD_V2) ? kLayoutWave16EffDgradCols : 0;
 }
 
 // Most rows glass_comb_eff_fwd_f32 serves when every operand's row stride is <= ld floats (32-bit buffer offsets)
@@ -2285,7 +2483,13 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
             hipLaunchKernelGGL((comb_bwd_eff2_kernel<64, false>), grid2, dim3(kBlock), 0, st, d2, X, ldx, X2, ldx2, zr, g.n_l, part_w, part_b);
         return launch_status("glass_comb_eff_bwd_f32 (staged)");
     }
+    if (GLASS_COMB_DGRAD_V2) {
+        GLASS_REQUIRE(gn_act == GLASS_ACT_NONE, "comb_eff_bwd: the GraphNorm in front of the comb pair has no activation");
+        const int64_t ld_max = std::max(std::max(ldd, ldo), gn_partial ? gn_ldx : (int64_t)0);
+        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "comb_eff_bwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
+    }
     const size_t lds_wg = (size_t)(2 * kTile + 8 * kSLOut) * sizeof(float);
+    static_assert(kCombDgrad2Lds <= (size_t)(2 * kTile + 8 * kSLOut) * sizeof(float), "the staged data gradient fits the fused launch's LDS");
     const size_t lds_fused = lds_dg > lds_wg ? lds_dg : lds_wg;
     allow_lds(comb_bwd_eff_kernel<64>, lds_fused);
     hipLaunchKernelGGL((comb_bwd_eff_kernel<64>), dim3(n_dg + (unsigned)(g.n_s + g.n_l)), dim3(kBlock), lds_fused, st, dargs,

@@ -348,6 +348,108 @@ constexpr int64_t kFusedBwdMaxRows = 100000;  // up to here the data + weight gr
 
 __device__ __forceinline__ int acc_index_sl(int t, int u, int reg, int lane) { return ((t * 4 + u) * 16 + reg) * 64 + lane; }
 
+// S / L tiles in the staged form (see wgrad_trans_staged2_body): the slab's rows — or, for an L tile, the listed labeled
+// rows (their indices fetched up front: at most 64 per tile) — go through LDS in 16-row stages as TRANSPOSED tiles of dc
+// ([64][16]) and of [g || x_] ([128][16]); a wave owns 16 outputs x all 128 inputs.  Plain [o][i] tile (header[2] = 1).
+__device__ __forceinline__ void wgrad_sl_staged2_body(const WgradSL& a, int64_t N, int blk, float* __restrict__ part_w,
+                                                      float* __restrict__ part_b, float* lds) {
+    constexpr int H = 64, RT = kStg2RT;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rs = tid >> 4, ga = tid & 15;
+    const bool lab = blk >= a.n_s;
+    int64_t r0, r_end;
+    if (!lab) {
+        r0 = (int64_t)blk * a.rows_per_slab;
+        r_end = min(N, r0 + a.rows_per_slab);
+    } else {
+        const int64_t n_lab = a.lab_count[0];
+        r0 = (int64_t)(blk - a.n_s) * 64;
+        r_end = min(n_lab, r0 + 64);
+    }
+    const int n_st = r_end > r0 ? (int)((r_end - r0 + 15) / 16) : 0;
+    int li[4] = {-1, -1, -1, -1};  // L tile: the rows of this thread's list positions of stages 0 .. 3
+    if (lab) {
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            const int64_t pos = r0 + 16 * st + rs;
+            li[st] = pos < r_end ? a.lab_rows[pos] : -1;
+        }
+    }
+    const buf_rsrc r_d = make_rsrc(a.dc, N * a.ldd * 4), r_g = make_rsrc(a.X, N * a.ldx * 4), r_x = make_rsrc(a.X2, N * a.ldx2 * 4);
+    struct Raw {
+        float4 d, g, x;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int64_t pos = r0 + 16 * st + rs;
+        int row = pos < r_end ? (int)pos : -1;
+        if (lab) row = st == 0 ? li[0] : st == 1 ? li[1] : st == 2 ? li[2] : st == 3 ? li[3] : -1;
+        R.d = buf_load4(r_d, row >= 0 ? (int)((row * a.ldd + 4 * ga) * 4) : kBufOOB);
+        R.g = buf_load4(r_g, row >= 0 ? (int)((row * a.ldx + 4 * ga) * 4) : kBufOOB);
+        R.x = buf_load4(r_x, row >= 0 ? (int)((row * a.ldx2 + 4 * ga) * 4) : kBufOOB);
+    };
+    auto commit = [&](int buf, const Raw& R) __attribute__((always_inline)) {
+        float* dcT = lds + buf * kStg2Floats;
+        float* inT = dcT + H * RT;
+        const float d[4] = {R.d.x, R.d.y, R.d.z, R.d.w}, g[4] = {R.g.x, R.g.y, R.g.z, R.g.w}, x[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            dcT[(4 * ga + k) * RT + rs] = d[k];
+            inT[(4 * ga + k) * RT + rs] = g[k];
+            inT[(H + 4 * ga + k) * RT + rs] = x[k];
+        }
+    };
+    wg_f32x4 acc[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) acc[it] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;  // bias partial of output o = tid (threads < 64)
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const float* dcT = lds + buf * kStg2Floats;
+        const float* inT = dcT + H * RT;
+        const float4 at = *reinterpret_cast<const float4*>(dcT + (16 * w + j) * RT + 4 * q);
+        float4 bt[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) bt[it] = *reinterpret_cast<const float4*>(inT + (16 * it + j) * RT + 4 * q);
+        if (tid < H) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const float4 t4 = *reinterpret_cast<const float4*>(dcT + tid * RT + 4 * v);
+                bsum += (t4.x + t4.y) + (t4.z + t4.w);
+            }
+        }
+        const float av[4] = {at.x, at.y, at.z, at.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const float bv[4] = {bt[it].x, bt[it].y, bt[it].z, bt[it].w};
+                acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[it], 0, 0, 0);
+            }
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    for (int st = 0; st < n_st; st += 2) {  // two stages per trip: buffers / registers alternate statically
+        compute(0);
+        commit(1, rawB);      // stage st + 1 (zeros beyond the end)
+        issue(st + 3, rawB);
+        lds_barrier();
+        compute(1);
+        commit(0, rawA);      // stage st + 2
+        issue(st + 4, rawA);
+        lds_barrier();
+    }
+    float* pw = part_w + (int64_t)blk * kTile;
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(16 * w + 4 * q + r) * (2 * H) + 16 * it + j] = acc[it][r];
+    if (tid < H) part_b[(int64_t)blk * kSLOut + tid] = bsum;
+}
+
 template <int kStages>
 __device__ __forceinline__ void wgrad_sl_body(const WgradSL& a, int64_t N, int blk, float* __restrict__ part_w,
                                               float* __restrict__ part_b, float* lds, float* lds_b) {
