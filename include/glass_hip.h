@@ -282,8 +282,8 @@ int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
  * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */
 int glass_dual_linear_layout(int64_t H);
-/* layout code of the data-gradient operand image for (H, n_out): 0, 2, 3 or 4, and of the forward operand image for
- * (H, K = input width): 0, 1 or 5 (see glass_dense_pack_batch_f32) */
+/* layout code of the data-gradient operand image for (H, n_out): 0, 2, 3, 4 or 9, and of the forward operand image for
+ * (H, K = input width): 0, 1, 5 or 9 (see glass_dense_pack_batch_f32) */
 int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out);
 int glass_dual_linear_fwd_layout(int64_t H, int64_t K);
 /* rows covered by one workgroup of the fused kernels at hidden H = rows per `stats` / `gn_partial` entry */
@@ -398,8 +398,15 @@ int glass_spmm_reduce_rows_f32(const float* partials, float* Y, int64_t ldy, int
  *     (forward operand of a comb pair, again 1.5 * NT*KT floats; glass_dual_linear_fwd_layout); 6 (not transposed, NT = 2H
  *     stacked outputs) / 7 (transposed, KT = 2H): the two wave16 images of the comb pair's effective weights, unlabeled rows
  *     (1-z) * f1 half + z * f0 half, then labeled rows z * f1 half + (1-z) * f0 half, NT*KT floats in all — the operands of
- *     glass_comb_eff_fwd_f32 / _bwd_f32.  z_ratio (may be NULL when no job has layout 4 - 7): per-job label mix of the pair.
- *     dst[k] holds NT*KT floats otherwise.  The pointer / size arrays are HOST arrays. */
+ *     glass_comb_eff_fwd_f32 / _bwd_f32.  Layouts 8 / 10 / 9 are 6 / 7 / 0 with another order of the output columns inside a
+ *     tile — tile t holds columns 64 (t >> 2) + 16 (t & 3) .. + 15 — for the "staged" hidden-64 kernels, where a wave owns 16
+ *     consecutive output columns and keeps its slice of the operand in registers: 8 = forward image of the comb pair
+ *     (glass_comb_eff_fwd_layout), 10 = its data-gradient images, packed BEHIND the layout-7 pair in the same buffer
+ *     (glass_comb_eff_dgrad_layout2), 9 = both operands of the trans pair (glass_dual_linear_fwd_layout(64, 64),
+ *     glass_dual_linear_dgrad_layout(64, 64)).  z_ratio (may be NULL when no job has layout 4 - 8, 10): per-job label mix of
+ *     the pair.  dst[k] holds NT*KT floats otherwise.  The pointer / size arrays are HOST arrays.
+ *     The staged kernels address their row operands through buffer resources (32-bit offsets): rows * ld * 4 < 2^31,
+ *     checked per call; glass_comb_eff_max_rows(ld) tells the limit. */
 /*     rng_state (may be NULL): the same launch also advances the dropout stream, rng_state[1] += 1 (both are
  *     once-per-step prologue work; equivalent to a following glass_rng_advance). */
 int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
