@@ -35,6 +35,19 @@ _P = c_void_p
 _I = c_int64
 
 
+class GnBwdSrc(ctypes.Structure):
+    """glass_gn_bwd_src (include/glass_hip.h): the comb pair's gradient operand derived on load from a GraphNorm's output
+    gradient (its backward apply fused into glass_comb_eff_bwd_f32)."""
+    _fields_ = [("acc", c_void_p), ("n_rep", c_int64), ("dy", c_void_p), ("lddy", c_int64), ("x", c_void_p), ("ldx", c_int64),
+                ("addend", c_void_p), ("ldadd", c_int64), ("saved", c_void_p), ("gamma", c_void_p), ("alpha", c_void_p),
+                ("dgamma", c_void_p), ("dbeta", c_void_p), ("dalpha", c_void_p), ("accumulate", c_int), ("act", c_int),
+                ("p_drop", c_float), ("call_id", c_uint64)]
+
+    @property
+    def ptr(self):
+        return ctypes.addressof(self)
+
+
 class GnSrc(ctypes.Structure):
     """glass_gn_src (include/glass_hip.h): a GraphNorm whose forward sums are still in exact accumulators."""
     _fields_ = [("acc", c_void_p), ("n_src", c_int64), ("n_rep", c_int64), ("gamma", c_void_p), ("beta", c_void_p),
@@ -124,7 +137,8 @@ SIGNATURES = {
     "glass_comb_eff_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, _P, _I, _I, _I, _P, c_int, _P, _P, c_int, c_float, _P,
                                        c_uint64, _P, _I, _P, _P, _I, _P]),
     "glass_comb_eff_bwd_f32": (c_int, [_P, _I, _P, c_double, _P, _P, _I, _I, _I, _P, _P, _I, _P, _P, c_int, c_float, _P,
-                                       c_uint64, c_int, _P, _I, _P, _I, _P, _P, _P, _I, _P]),
+                                       c_uint64, c_int, _P, _I, _P, _I, _P, _P, _P, _I, _P, _P]),
+    "glass_comb_eff_bwd_gn_src_supported": (c_int, [_I, _I]),
     "glass_adam_step_f32": (c_int, [_P, _P, _P, _P, _I, _P, c_double, c_double, c_double, c_double, _P, _P]),
 }
 

@@ -1325,6 +1325,7 @@ struct DgradEffArgs {
     int64_t N;
     GnBwdStats gs;
     LabRows lab;
+    GnBwdSrc src;  // src.acc != nullptr: dsrc is derived on load (staged bodies only)
 };
 
 struct DcRaw {
@@ -1470,6 +1471,9 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
     };
     Stage* stg = reinterpret_cast<Stage*>(lds);
     int* rows_s = reinterpret_cast<int*>(lds + 2 * (3 * 16 * RS));
+    float* coef_s = lds + 2 * (3 * 16 * RS) + 64;  // [5][64] A | Bx | K | scale | shift of the GraphNorm dc comes from (src)
+    const GnBwdSrc& src = A.src;
+    const bool src_on = src.acc != nullptr;
     D_STAMP(3, 0);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -1487,7 +1491,11 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
             return;
         }
     }
-    const buf_rsrc r_dc = make_rsrc(A.dsrc, N * A.ldd * 4), r_out = make_rsrc(A.out, N * A.ldo * 4);
+    const buf_rsrc r_dc = src_on ? make_rsrc(src.dy, N * src.lddy * 4) : make_rsrc(A.dsrc, N * A.ldd * 4);
+    const int64_t ld_dc = src_on ? src.lddy : A.ldd;
+    const buf_rsrc r_sx = make_rsrc(src_on ? src.x : A.out, src_on ? N * src.ldx * 4 : 0);
+    const buf_rsrc r_sad = make_rsrc((src_on && src.addend) ? src.addend : A.out, (src_on && src.addend) ? N * src.ldadd * 4 : 0);
+    const buf_rsrc r_out = make_rsrc(A.out, N * A.ldo * 4);
     const buf_rsrc r_a = make_rsrc(gs.partial ? gs.x : A.dsrc, gs.partial ? N * gs.ldx * 4 : 0);
     // this wave's slices of the effective weight (transposed operand): columns 16w .. of the dg half and of the dx_ half
     const float4* img = reinterpret_cast<const float4*>(A.WT + (extra ? 2 * H * H : 0));
@@ -1519,11 +1527,13 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
         for (int st = 0; st < 4; ++st) my_row[st] = rows_s[16 * st + rs];
     }
     struct Raw {
-        float4 dc, a;
+        float4 dc, a, sx, sad;  // (src: dc holds dy; sx / sad the GraphNorm's input and the addend)
     };
     auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
         const int r = my_row[st];
-        R.dc = buf_load4(r_dc, r >= 0 ? (int)((r * A.ldd + 4 * ga) * 4) : kBufOOB);
+        R.dc = buf_load4(r_dc, r >= 0 ? (int)((r * ld_dc + 4 * ga) * 4) : kBufOOB);
+        R.sx = buf_load4(r_sx, r >= 0 ? (int)((r * src.ldx + 4 * ga) * 4) : kBufOOB);
+        R.sad = buf_load4(r_sad, r >= 0 ? (int)((r * src.ldadd + 4 * ga) * 4) : kBufOOB);
         R.a = buf_load4(r_a, r >= 0 ? (int)((r * gs.ldx + 4 * ga) * 4) : kBufOOB);
     };
     Raw rawA, rawB;
@@ -1545,11 +1555,28 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
         g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
     }
     if (tid < 64) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;
+    Drop sdrop = src.drop;
+    if (src_on) {
+        if (sdrop.p > 0.f) {
+            sdrop.seed = A.rng_state[0];
+            sdrop.step = A.rng_state[1];
+        }
+        gn_bwd_coef_nobarrier(src.acc, src.n_rep, N, src.saved, src.gamma, src.alpha, src.dgamma, src.dbeta, src.dalpha,
+                              src.accumulate, blk == 0, coef_s);
+        lds_barrier();  // coefficients before the first stage is prepared
+    }
     // stage -> LDS: the loader's four float4 in the layouts their readers want
     auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
         Stage& S = stg[st & 1];
         const int r = my_row[st];
-        *reinterpret_cast<float4*>(S.dcP + rs * RS + 4 * ga) = R.dc;
+        float4 dcv = R.dc;
+        if (src_on) {
+            float sds[4] = {1.f, 1.f, 1.f, 1.f};
+            if (sdrop.p > 0.f) drop_scales<4>(sdrop, r < 0 ? 0 : r, 4 * ga, sds);
+            dcv = gn_bwd_apply4(R.dc, R.sx, R.sad, coef_s, 4 * ga, src.act, sds);
+            if (r < 0) dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        *reinterpret_cast<float4*>(S.dcP + rs * RS + 4 * ga) = dcv;
         const float av[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
         float ds[4] = {1.f, 1.f, 1.f, 1.f};
         if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
@@ -1633,7 +1660,7 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
     }
     D_STAMP(3, 4);
 }
-constexpr size_t kCombDgrad2Lds = (size_t)(2 * 3 * 16 * (64 + 4) + 64) * sizeof(float);
+constexpr size_t kCombDgrad2Lds = (size_t)(2 * 3 * 16 * (64 + 4) + 64 + 5 * 64) * sizeof(float);
 
 template <int H, bool DROP>
 __global__ __launch_bounds__(kBlock) void comb_bwd_eff2_kernel(DgradEffArgs A, const float* __restrict__ X, int64_t ldx,
@@ -2346,6 +2373,11 @@ extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab
     return ceil_div(n_nodes, 64) + ceil_div(lab_cap, 64);
 }
 
+// dsrc_gn of glass_comb_eff_bwd_f32: both staged bodies inside the fused launch
+extern "C" int glass_comb_eff_bwd_gn_src_supported(int64_t n_nodes, int64_t H) {
+    return (GLASS_COMB_DGRAD_V2 && GLASS_SL_STAGED2 && !GLASS_COMB_BWD_V2 && H == 64 && n_nodes > 0 && n_nodes <= kFusedBwdMaxRows) ? 1 : 0;
+}
+
 // Layout code(s) of the data-gradient image glass_comb_eff_bwd_f32 reads: 7, and when the staged kernel is compiled in the
 // buffer holds a SECOND pair of images in layout 10 behind the first (returns 10 then; 0 otherwise)
 extern "C" int glass_comb_eff_dgrad_layout2(int64_t H) {
@@ -2429,9 +2461,29 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
                                       const float* gn_alpha, int gn_act, float gn_p_drop, const uint64_t* rng_state,
                                       uint64_t gn_call_id, int gn_exact, const float* X, int64_t ldx, const float* X2,
                                       int64_t ldx2, void* ws, const int32_t* lab_rows, const int32_t* lab_count,
-                                      int64_t lab_cap, void* stream) {
-    GLASS_REQUIRE(dsrc && mask && WTimg_eff && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
+                                      int64_t lab_cap, const glass_gn_bwd_src* dsrc_gn, void* stream) {
+    GLASS_REQUIRE((dsrc || dsrc_gn) && mask && WTimg_eff && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
                   "comb_eff_bwd: null pointer");
+    GnBwdSrc gsrc{};
+    if (dsrc_gn) {
+        const glass_gn_bwd_src& g = *dsrc_gn;
+        if (!glass_comb_eff_bwd_gn_src_supported(n_nodes, H) || !X) {
+            set_error("comb_eff_bwd: dsrc_gn is served by the staged fused launch only (hidden 64, small graphs, with the weight gradient)");
+            return GLASS_E_UNSUPPORTED;
+        }
+        GLASS_REQUIRE(g.acc && rep_ok(g.n_rep) && g.dy && g.x && g.saved && g.gamma && g.alpha && g.lddy >= H && g.lddy % 4 == 0 &&
+                          g.ldx >= H && g.ldx % 4 == 0 && aligned16(g.dy) && aligned16(g.x) && aligned16(g.saved) &&
+                          (!g.addend || (g.ldadd >= H && g.ldadd % 4 == 0 && aligned16(g.addend))) && g.p_drop >= 0.f && g.p_drop < 1.f &&
+                          (g.p_drop == 0.f || rng_state) && (g.act == GLASS_ACT_NONE || g.act == GLASS_ACT_ELU) &&
+                          n_nodes * std::max(std::max(g.lddy, g.ldx), g.addend ? g.ldadd : (int64_t)0) * 4 < (1ll << 31),
+                      "comb_eff_bwd: bad dsrc_gn");
+        gsrc = GnBwdSrc{reinterpret_cast<const long long*>(g.acc), (int)g.n_rep, g.dy, g.lddy, g.x, g.ldx, g.addend, g.ldadd, g.saved,
+                        g.gamma, g.alpha, g.dgamma, g.dbeta, g.dalpha, g.accumulate, g.act, make_drop(g.p_drop, g.call_id, H)};
+        if (!dsrc) {
+            dsrc = g.dy;  // (only its alignment is looked at below)
+            ldd = g.lddy;
+        }
+    }
     if (H != 64) {
         set_error("comb_eff_bwd: hidden size %lld not supported (64)", (long long)H);
         return GLASS_E_UNSUPPORTED;
@@ -2449,7 +2501,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
     const unsigned n_dg = (unsigned)(n_main + ceil_div(lab_cap, 64));
     const float zr = (float)z_ratio;
     const GnBwdStats gs{gn_partial, gn_exact, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
-    const DgradEffArgs dargs{dsrc, ldd, mask, WTimg_eff, rng_state, out, ldo, n_nodes, gs, LabRows{lab_rows, lab_count, n_main}};
+    const DgradEffArgs dargs{dsrc, ldd, mask, WTimg_eff, rng_state, out, ldo, n_nodes, gs, LabRows{lab_rows, lab_count, n_main}, gsrc};
     const size_t lds_dg = lds_bytes(2 * H, 1);  // one K pass of the [2H][H] effective weight
     if (!X) {  // data gradient only
         hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);
@@ -2463,7 +2515,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
     const WgradSLGeom g = wgrad_sl_geom(n_nodes, lab_cap);
     float* part_w = (float*)ws;
     float* part_b = part_w + g.part_w_floats;
-    const WgradSL sl{dsrc, ldd, X, ldx, X2, ldx2, lab_rows, lab_count, g.n_s, g.rows_per_slab, g.n_l};
+    const WgradSL sl{dsrc, ldd, X, ldx, X2, ldx2, lab_rows, lab_count, g.n_s, g.rows_per_slab, g.n_l, gsrc, rng_state};
     if (n_nodes > kFusedBwdMaxRows) {  // large graph: the two halves fill the chip on their own
         hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);
         launch_wgrad_sl(sl, n_nodes, zr, part_w, part_b, st);

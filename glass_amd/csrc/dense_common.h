@@ -48,6 +48,23 @@ struct GnBwdStats {
     Drop drop;
 };
 
+// The gradient operand of the comb pair's backward NOT materialised: it is the input gradient of the GraphNorm between
+// two layers (gns[l], impl/models.py:257-259 backward), derived while the staged kernels load their rows —
+//   dc = A * g + Bx * x + K (+ addend),  g = dy * dropmask * act'(x * scale + shift)
+// with the coefficients from that GraphNorm's two backward sums (exact accumulators, gn_acc.h): the backward-apply launch
+// between the next layer's trans backward and this launch disappears.  acc == nullptr: off (dsrc is final).
+struct GnBwdSrc {
+    const long long* acc;
+    int n_rep;
+    const float* dy; int64_t lddy;
+    const float* x; int64_t ldx;
+    const float* addend; int64_t ldadd;
+    const float *saved, *gamma, *alpha;
+    float *dgamma, *dbeta, *dalpha;
+    int accumulate, act;
+    Drop drop;
+};
+
 // The unique labeled rows of the batch (glass_batch_labels): the comb pair in effective-weight form runs every row tile
 // with the unlabeled-row weight and `n_main` row tiles first, then ceil(cap / 64) extra workgroups that recompute the listed
 // rows with the labeled-row weight (the main tiles do not store those rows).

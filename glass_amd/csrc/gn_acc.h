@@ -254,4 +254,54 @@ __device__ __forceinline__ void gn_fwd_coef_nobarrier(const GnExactSrc& src, con
     }
 }
 
+// Backward coefficients of a GraphNorm (64 columns, one accumulator block) into coef_s (LDS floats [5 * 64]: A | Bx | K |
+// scale | shift) WITHOUT a barrier (the caller's next barrier publishes them); the workgroup with write_params also writes
+// the parameter gradients (dgamma = s2, dbeta = s1, dalpha).  Every thread of the 256-thread workgroup calls it.
+__device__ __forceinline__ void gn_bwd_coef_nobarrier(const long long* __restrict__ acc, int n_rep, int64_t N,
+                                                      const float* __restrict__ saved, const float* __restrict__ gamma,
+                                                      const float* __restrict__ alpha, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta, float* __restrict__ dalpha, int accumulate,
+                                                      bool write_params, float* coef_s) {
+    constexpr int C = 64;
+    const int t = threadIdx.x;
+    const int c = 16 * (t >> 6) + (t & 15);
+    const float ga = gamma[c], al = alpha[c], mu = saved[c], rstd = saved[C + c], sc = saved[2 * C + c], sh = saved[3 * C + c];
+    double s1, s2;
+    int col;
+    if (gn_acc_col_sums<C, 256>(acc, n_rep, kAccScaleBwd, col, s1, s2)) {
+        float A, Bx, K, da;
+        gn_bwd_coeffs(s1, s2, (double)N, ga, al, mu, rstd, A, Bx, K, da);
+        coef_s[c] = A;
+        coef_s[C + c] = Bx;
+        coef_s[2 * C + c] = K;
+        coef_s[3 * C + c] = sc;
+        coef_s[4 * C + c] = sh;
+        if (write_params) {
+            if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+            if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+            if (dalpha) dalpha[c] = (accumulate ? dalpha[c] : 0.f) + da;
+        }
+    }
+}
+
+// dc (four columns of one row) from the GraphNorm's output gradient: the arithmetic of gn_bwd_apply_acc_kernel
+__device__ __forceinline__ float4 gn_bwd_apply4(const float4& dy, const float4& x, const float4& ad, const float* coef_s, int c0,
+                                                int act, const float (&ds)[4]) {
+    constexpr int C = 64;
+    const float4 A = *reinterpret_cast<const float4*>(coef_s + c0), Bx = *reinterpret_cast<const float4*>(coef_s + C + c0);
+    const float4 K = *reinterpret_cast<const float4*>(coef_s + 2 * C + c0);
+    const float4 sc = *reinterpret_cast<const float4*>(coef_s + 3 * C + c0), sh = *reinterpret_cast<const float4*>(coef_s + 4 * C + c0);
+    const float dv[4] = {dy.x, dy.y, dy.z, dy.w}, xv[4] = {x.x, x.y, x.z, x.w}, av[4] = {ad.x, ad.y, ad.z, ad.w};
+    const float Av[4] = {A.x, A.y, A.z, A.w}, Bv[4] = {Bx.x, Bx.y, Bx.z, Bx.w}, Kv[4] = {K.x, K.y, K.z, K.w};
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float g = dv[k] * ds[k];
+        if (act == GLASS_ACT_ELU) g *= elu_grad_f(fmaf(xv[k], scv[k], shv[k]));
+        o[k] = fmaf(Av[k], g, fmaf(Bv[k], xv[k], Kv[k])) + av[k];
+    }
+    return make_float4(o[0], o[1], o[2], o[3]);
+}
+
 }  // namespace glass

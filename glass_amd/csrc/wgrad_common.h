@@ -2,6 +2,7 @@
 // small graphs / narrow layers) and wgrad_tiled.hip (LDS-tiled 128 x 256 tile: hidden >= 256 on large graphs).
 #pragma once
 #include "common.h"
+#include "dense_common.h"
 
 namespace glass {
 
@@ -333,6 +334,8 @@ struct WgradSL {
     const int32_t* lab_rows;
     const int32_t* lab_count;
     int n_s, rows_per_slab, n_l;
+    GnBwdSrc src;  // src.acc != nullptr: dc is derived on load (staged body only)
+    const uint64_t* rng_state;
 };
 struct WgradSLGeom {
     int n_s, rows_per_slab, n_l;
@@ -376,22 +379,45 @@ __device__ __forceinline__ void wgrad_sl_staged2_body(const WgradSL& a, int64_t 
             li[st] = pos < r_end ? a.lab_rows[pos] : -1;
         }
     }
-    const buf_rsrc r_d = make_rsrc(a.dc, N * a.ldd * 4), r_g = make_rsrc(a.X, N * a.ldx * 4), r_x = make_rsrc(a.X2, N * a.ldx2 * 4);
+    const GnBwdSrc& src = a.src;
+    const bool src_on = src.acc != nullptr;
+    Drop sdrop = src.drop;
+    if (src_on && sdrop.p > 0.f) {
+        sdrop.seed = a.rng_state[0];
+        sdrop.step = a.rng_state[1];
+    }
+    float* coef_s = lds + 2 * kStg2Floats;  // [5][64] (src)
+    const buf_rsrc r_d = src_on ? make_rsrc(src.dy, N * src.lddy * 4) : make_rsrc(a.dc, N * a.ldd * 4);
+    const int64_t ld_d = src_on ? src.lddy : a.ldd;
+    const buf_rsrc r_sx = make_rsrc(src_on ? src.x : a.X, src_on ? N * src.ldx * 4 : 0);
+    const buf_rsrc r_sad = make_rsrc((src_on && src.addend) ? src.addend : a.X, (src_on && src.addend) ? N * src.ldadd * 4 : 0);
+    const buf_rsrc r_g = make_rsrc(a.X, N * a.ldx * 4), r_x = make_rsrc(a.X2, N * a.ldx2 * 4);
     struct Raw {
-        float4 d, g, x;
+        float4 d, g, x, sx, sad;
+        int row;
     };
     auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
         const int64_t pos = r0 + 16 * st + rs;
         int row = pos < r_end ? (int)pos : -1;
         if (lab) row = st == 0 ? li[0] : st == 1 ? li[1] : st == 2 ? li[2] : st == 3 ? li[3] : -1;
-        R.d = buf_load4(r_d, row >= 0 ? (int)((row * a.ldd + 4 * ga) * 4) : kBufOOB);
+        R.row = row;
+        R.d = buf_load4(r_d, row >= 0 ? (int)((row * ld_d + 4 * ga) * 4) : kBufOOB);
+        R.sx = buf_load4(r_sx, row >= 0 ? (int)((row * src.ldx + 4 * ga) * 4) : kBufOOB);
+        R.sad = buf_load4(r_sad, row >= 0 ? (int)((row * src.ldadd + 4 * ga) * 4) : kBufOOB);
         R.g = buf_load4(r_g, row >= 0 ? (int)((row * a.ldx + 4 * ga) * 4) : kBufOOB);
         R.x = buf_load4(r_x, row >= 0 ? (int)((row * a.ldx2 + 4 * ga) * 4) : kBufOOB);
     };
     auto commit = [&](int buf, const Raw& R) __attribute__((always_inline)) {
         float* dcT = lds + buf * kStg2Floats;
         float* inT = dcT + H * RT;
-        const float d[4] = {R.d.x, R.d.y, R.d.z, R.d.w}, g[4] = {R.g.x, R.g.y, R.g.z, R.g.w}, x[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
+        float4 dcv = R.d;
+        if (src_on) {
+            float sds[4] = {1.f, 1.f, 1.f, 1.f};
+            if (sdrop.p > 0.f) drop_scales<4>(sdrop, R.row < 0 ? 0 : R.row, 4 * ga, sds);
+            dcv = gn_bwd_apply4(R.d, R.sx, R.sad, coef_s, 4 * ga, src.act, sds);
+            if (R.row < 0) dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const float d[4] = {dcv.x, dcv.y, dcv.z, dcv.w}, g[4] = {R.g.x, R.g.y, R.g.z, R.g.w}, x[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             dcT[(4 * ga + k) * RT + rs] = d[k];
@@ -429,6 +455,10 @@ __device__ __forceinline__ void wgrad_sl_staged2_body(const WgradSL& a, int64_t 
     Raw rawA, rawB;
     issue(0, rawA);
     issue(1, rawB);
+    if (src_on) {
+        gn_bwd_coef_nobarrier(src.acc, src.n_rep, N, src.saved, src.gamma, src.alpha, nullptr, nullptr, nullptr, 0, false, coef_s);
+        lds_barrier();  // coefficients before the first stage is prepared
+    }
     commit(0, rawA);
     issue(2, rawA);
     lds_barrier();

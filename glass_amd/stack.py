@@ -37,6 +37,7 @@ def _check(rc, what):
 
 
 USE_GN_EXACT = os.environ.get("GLASS_GN_EXACT", "1") != "0"  # A/B switch: exact GraphNorm accumulators instead of partials + finalize
+USE_GN_BWD_IN_COMB = os.environ.get("GLASS_GN_BWD_IN_COMB", "1") != "0"  # gns[l]'s backward apply inside the comb backward launch
 USE_GN_EXACT_FWD = os.environ.get("GLASS_GN_EXACT_FWD", "1") != "0"  # ... for the forward sums as well
 # above this many rows the partials + finalize form is kept: thousands of workgroups adding to the same few replicas would
 # queue at the memory-side atomic units, and a ~5 us finalize launch no longer shows against the kernels around it
@@ -123,20 +124,22 @@ def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
     _check(rc, "glass_comb_eff_fwd_f32")
 
 
-def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels):
+def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels, dsrc_gn=None):
+    """dsrc_gn (a _lib.GnBwdSrc): dsrc is not materialised — the kernels derive it on load from the gradient of the
+    GraphNorm behind this layer (glass_gn_bwd_src); dsrc is then only a shape carrier (the tensor dy)."""
     n, H = dsrc.shape
     gpart, gx, gsaved, galpha, gact, gp, gcall = gn
-    rng = ops.rng_tensor(dsrc.device).data_ptr() if gp > 0 else 0
+    rng = ops.rng_tensor(dsrc.device).data_ptr() if (gp > 0 or (dsrc_gn is not None and dsrc_gn.p_drop > 0)) else 0
     stack = conv._stack["comb"]
     ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, 2 * H, slot=("stack", len(pending)),
                               min_bytes=int(_lib.load().glass_comb_eff_ws_bytes(n, H, labels.cap)))
-    rc = _lib.load().glass_comb_eff_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), mask.data_ptr(), float(conv.z_ratio),
+    rc = _lib.load().glass_comb_eff_bwd_f32(0 if dsrc_gn is not None else dsrc.data_ptr(), dsrc.stride(0), mask.data_ptr(), float(conv.z_ratio),
                                             conv._stack_eff["comb"][1].data_ptr(), out.data_ptr(), out.stride(0), n, H,
                                             gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(),
                                             galpha.data_ptr(), gact, float(gp), rng, gcall, _rep(gpart),
                                             xa.data_ptr(), xa.stride(0),
                                             xb.data_ptr(), xb.stride(0), ws.data_ptr(), labels.rows.data_ptr(),
-                                            labels.count.data_ptr(), labels.cap, _stream())
+                                            labels.count.data_ptr(), labels.cap, 0 if dsrc_gn is None else dsrc_gn.ptr, _stream())
     _check(rc, "glass_comb_eff_bwd_f32")
     # (9th field: the partials are in S / L form for a labeled-row list of that capacity)
     pending.append((ws.data_ptr(), n, 2 * H, 2 * H, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc, labels.cap))
@@ -632,8 +635,20 @@ class StackProgram:
             conv, rec = emb.convs[l], st["layers"][l]
             last = l + 1 == L
             # gradient w.r.t. the raw conv output c_l
+            dc_src = None
             if last:
                 dc = djk[:, l * H:(l + 1) * H] if emb.jk else djk
+            elif (USE_GN_BWD_IN_COMB and npart.dtype == torch.int64 and _comb_eff_ok(conv, st.get("labels"), H) and
+                  _lib.load().glass_comb_eff_bwd_gn_src_supported(n, H)):
+                # gns[l]'s backward apply rides in the comb launch's operand loads (glass_gn_bwd_src): no launch, no dc
+                m = emb.gns[l]
+                ad = djk[:, l * H:(l + 1) * H] if emb.jk else None
+                dc_src = _lib.GnBwdSrc(npart.data_ptr(), _rep(npart), dh_next.data_ptr(), dh_next.stride(0), rec["c"].data_ptr(),
+                                       rec["c"].stride(0), 0 if ad is None else ad.data_ptr(), 0 if ad is None else ad.stride(0),
+                                       rec["nsaved"].data_ptr(), m.weight.data_ptr(), m.mean_scale.data_ptr(),
+                                       m.weight.grad.data_ptr(), m.bias.grad.data_ptr(), m.mean_scale.grad.data_ptr(), acc, ACT_ELU,
+                                       float(p), conv.call_base + 1)
+                dc = dh_next  # (shape carrier)
             else:
                 dc = torch.empty((n, H), **f32)
                 _GN(emb.gns[l]).bwd_from_stats(dh_next, rec["c"], rec["nsaved"], dc, npart, ACT_ELU, p, conv.call_base + 1,
@@ -646,7 +661,8 @@ class StackProgram:
                 gpart = acc_all[2 * l]   # exact accumulators: the sums are final when the kernel is, no finalize launch
             if acc_all is not None and _comb_eff_ok(conv, labels, H):
                 _comb_eff_bwd(dc, conv, mask, din, rec["g"], rec["h"], pending, acc,
-                              (gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base), labels)
+                              (gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base), labels,
+                              dsrc_gn=dc_src)
             elif acc_all is not None:
                 _dual_bwd(dc, None, conv._stack["comb"], mask, conv.z_ratio, ACT_NONE, 2 * H, None, din, rec["g"], rec["h"],
                           pending, acc, gn=(gpart, rec["a"], rec["gsaved"], conv.gn.mean_scale, ACT_NONE, rec["pc"], conv.call_base))

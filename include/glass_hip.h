@@ -26,6 +26,7 @@
 #ifdef __cplusplus
 extern "C" {
 
+typedef struct glass_gn_bwd_src glass_gn_bwd_src;
 typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a kernel input: defined with K5's entries */
 #endif
 
@@ -362,12 +363,33 @@ int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_
                            const glass_gn_src* gn_src, int gn_act, float p_drop, const uint64_t* rng_state,
                            uint64_t call_id, float* xa_out, int64_t ldxo, const int32_t* lab_rows,
                            const int32_t* lab_count, int64_t lab_cap, void* stream);
+/*   dsrc_gn != NULL (hidden 64, small graphs: glass_comb_eff_bwd_gn_src_supported): dsrc is NOT materialised — it is the
+ *   input gradient of the GraphNorm between two layers (gns[l], impl/models.py:257-259 backward) and the kernels derive
+ *   it while loading their rows: dc = A * g + Bx * x + K (+ addend), g = dy * dropmask * act'(x * scale + shift), with the
+ *   coefficients from that GraphNorm's two backward sums in exact accumulators (what glass_graphnorm_bwd_from_stats_f32
+ *   with nblk = -n_rep would apply in a launch of its own); workgroup 0 writes dgamma / dbeta / dalpha. */
+struct glass_gn_bwd_src {
+    const int64_t* acc;
+    int64_t n_rep;
+    const float* dy;
+    int64_t lddy;
+    const float* x;
+    int64_t ldx;
+    const float* addend; /* may be NULL */
+    int64_t ldadd;
+    const float *saved, *gamma, *alpha;
+    float *dgamma, *dbeta, *dalpha;
+    int accumulate, act;
+    float p_drop;
+    uint64_t call_id;
+};
+int glass_comb_eff_bwd_gn_src_supported(int64_t n_nodes, int64_t H);
 int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint8_t* mask, double z_ratio, const float* WTimg_eff,
                            float* out, int64_t ldo, int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
                            int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act, float gn_p_drop,
                            const uint64_t* rng_state, uint64_t gn_call_id, int gn_exact, const float* X, int64_t ldx,
                            const float* X2, int64_t ldx2, void* ws, const int32_t* lab_rows, const int32_t* lab_count,
-                           int64_t lab_cap, void* stream);
+                           int64_t lab_cap, const glass_gn_bwd_src* dsrc_gn, void* stream);
 /*     Deferred reduction: glass_dual_linear_wgrad_f32 with dW == NULL only writes the per-slab partial sums
  *     into `ws` (one scratch buffer per pending gradient); this call then reduces n_jobs of them — job j is
  *     the gradient of a [O[j], I[j]] weight over N[j] rows — into dW[j] / db[j] (db[j] may be NULL) with ONE
