@@ -538,6 +538,10 @@ def main():
         u_mem = mem_rate / mem_peak
     elif mem_level == "hbm":
         mem_rate, u_mem = alg_rate, alg_rate / mem_peak   # compulsory bytes: a lower bound of the traffic
+        if u_mem > 1.0:
+            # more algorithmic bytes per second than HBM can deliver: part of the gathers were served by the Infinity
+            # Cache (skewed graphs); without the counters the memory-side rate is unknown — no fraction above 1 is printed
+            mem_rate, u_mem = None, None
     else:
         mem_rate, u_mem = None, None
     if x_bytes <= L2_XCD_BYTES or u_mem is None or u_l2 >= u_mem:

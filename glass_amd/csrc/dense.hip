@@ -1244,16 +1244,11 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
         *reinterpret_cast<float4*>(tile[st & 1] + rs * RS + 4 * ga) = v;
     };
     float ssum = 0.f, ssq = 0.f;
+    stage_store(0, rawA);
+    if (2 < NST) rawA = issue(2);
+    lds_barrier();
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
-        if (st & 1) {
-            stage_store(st, rawB);
-            if (st + 2 < NST) rawB = issue(st + 2);
-        } else {
-            stage_store(st, rawA);
-            if (st + 2 < NST) rawA = issue(st + 2);
-        }
-        lds_barrier();
         const float* A = tile[st & 1] + j * RS + 16 * q;
         float4 a4[4];
 #pragma unroll
@@ -1270,6 +1265,17 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
             for (int e = 0; e < 4; ++e) {
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y1[e], acc1, 0, 0, 0);
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y0[e], acc0, 0, 0, 0);
+            }
+        }
+        // the next stage's rows -> the other buffer (its readers passed the barrier at the end of the previous iteration);
+        // behind the MFMAs in program order, so the prologue arithmetic overlaps their execution
+        if (st + 1 < NST) {
+            if (st & 1) {
+                stage_store(st + 1, rawA);
+                if (st + 3 < NST) rawA = issue(st + 3);
+            } else {
+                stage_store(st + 1, rawB);
+                if (st + 3 < NST) rawB = issue(st + 3);
             }
         }
         const int c = 16 * w + j;
@@ -1292,6 +1298,7 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
             ssum += live ? o : 0.f;
             ssq += live ? o * o : 0.f;
         }
+        if (st + 1 < NST) lds_barrier();
     }
     D_STAMP(2, 3);
     if (stats == nullptr) return;
