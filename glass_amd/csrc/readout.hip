@@ -74,6 +74,8 @@ struct R1Args {
     int64_t n_nodes;
     int tc_log2;
     GnExactSrc src;  // src.acc: the final GraphNorm's forward sums are still in exact accumulators (gn_acc.h)
+    long long* bwd_acc;  // != nullptr: the subgraph's share of the two backward column sums goes to exact accumulators
+    int bwd_rep;         // (the backfill launch folds them: no reduce launch in between)
 };
 
 // dynamic LDS (floats): sums[2C doubles] | coef_s[2C] | mu_rstd_s[2C] | pooled_s[C] | xh_s[C] | red[kBlock*8] |
@@ -233,8 +235,13 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
         for (int k = 0; k < K; ++k) s = fmaf(dl[k], a.Wh[(int64_t)k * C + c], s);
         const float dy = sc * s;
         a.ws.dys[(int64_t)b * C + c] = dy;
-        part[c] = (double)cnt * (double)dy;
-        part[C + c] = (double)dy * (double)xh_s[c];
+        if (a.bwd_acc) {
+            gn_acc_add(a.bwd_acc, b % a.bwd_rep, 0, c, C, (double)cnt * (double)dy, kAccScaleBwd);
+            gn_acc_add(a.bwd_acc, b % a.bwd_rep, 1, c, C, (double)dy * (double)xh_s[c], kAccScaleBwd);
+        } else {
+            part[c] = (double)cnt * (double)dy;
+            part[C + c] = (double)dy * (double)xh_s[c];
+        }
     }
 }
 
@@ -392,6 +399,22 @@ __global__ __launch_bounds__(kOrdBlock) void readout_scatter_ordered_kernel(cons
 // the workgroups behind them take 16 listed rows each, one per wave, and write the row's full value
 // Bx*x + K + A * (sum of g over the subgraphs holding it, in (b, s) order) — every row written once, no atomics, the same
 // arithmetic in the same order as R3 followed by the ordered R4 (bitwise equal).
+// Two-launch form (fin.acc != nullptr): the GraphNorm backward finalize is folded into this launch — every dense / sparse
+// workgroup folds the exact accumulators the subgraph kernel added to and derives A | Bx | K itself (workgroup 0 writes the
+// parameter gradients) — and the other roles of the reduce launch (head weight / bias gradient rows, mean loss) are extra
+// workgroups behind the sparse ones.  Dynamic LDS: nodes[n_pos] int32 | (two-launch form) sums[2C] doubles | coef[3C].
+struct BackfillFin {
+    const long long* acc;  // nullptr: coefficients come from `coef` (three-launch form)
+    int n_rep;
+    const float *gamma, *alpha, *saved;
+    float *dgamma, *dbeta, *dalpha;
+    int acc_gn;
+    // head / loss roles
+    const float* pooled; const float* dlogits; const float* loss_rows;
+    float *dWh, *dbh, *loss;
+    int B, K, loss_mode, acc_head;
+};
+
 __global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float* __restrict__ x, int64_t ldx,
                                                                     float* __restrict__ dx, int64_t lddx, int64_t N, int C,
                                                                     int tc_log2, const float* __restrict__ coef,
@@ -399,15 +422,64 @@ __global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float
                                                                     const int64_t* __restrict__ pos, int Smax, int n_pos,
                                                                     const float* __restrict__ dys,
                                                                     const int32_t* __restrict__ lab_rows,
-                                                                    const int32_t* __restrict__ lab_count, int n_dense) {
+                                                                    const int32_t* __restrict__ lab_count, int n_dense, int n_sparse,
+                                                                    BackfillFin fin) {
     extern __shared__ int32_t nodes[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n_dense + n_sparse) {  // head gradient row k, or the mean loss (two-launch form)
+        const int blk = (int)blockIdx.x - n_dense - n_sparse;
+        if (blk < fin.K) {
+            float* dl = reinterpret_cast<float*>(nodes);  // [B]
+            for (int b = tid; b < fin.B; b += kOrdBlock) dl[b] = fin.dlogits[(int64_t)b * fin.K + blk];
+            __syncthreads();
+            for (int c = tid; c < C; c += kOrdBlock) {
+                float sum = 0.f;
+#pragma unroll 8
+                for (int b = 0; b < fin.B; ++b) sum = fmaf(dl[b], fin.pooled[(int64_t)b * C + c], sum);
+                float* d = fin.dWh + (int64_t)blk * C + c;
+                *d = fin.acc_head ? *d + sum : sum;
+            }
+            if (tid == 0) {
+                float sum = 0.f;
+                for (int b = 0; b < fin.B; ++b) sum += dl[b];
+                fin.dbh[blk] = fin.acc_head ? fin.dbh[blk] + sum : sum;
+            }
+        } else if (tid < kWave) {  // mean loss: one wave, fixed order
+            double part = 0.0;
+            for (int b = tid; b < fin.B; b += kWave) part += (double)fin.loss_rows[b];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+            if (tid == 0)
+                fin.loss[0] = (float)(part / (fin.loss_mode == kLossCE ? (double)fin.B : (double)fin.B * (double)fin.K));
+        }
+        return;
+    }
+    if (fin.acc) {
+        double* sums = reinterpret_cast<double*>(nodes + ((n_pos + 1) & ~1));
+        float* coef_s = reinterpret_cast<float*>(sums + 2 * C);
+        gn_acc_fold(fin.acc, C, 1, sums, kAccScaleBwd, fin.n_rep);
+        for (int c = tid; c < C; c += kOrdBlock) {
+            float A, Bx, K, da;
+            gn_bwd_coeffs(sums[c], sums[C + c], (double)N, fin.gamma[c], fin.alpha[c], fin.saved[c], fin.saved[C + c], A, Bx, K, da);
+            coef_s[c] = A;
+            coef_s[C + c] = Bx;
+            coef_s[2 * C + c] = K;
+            if (blockIdx.x == 0) {
+                if (fin.dgamma) fin.dgamma[c] = (fin.acc_gn ? fin.dgamma[c] : 0.f) + (float)sums[C + c];
+                if (fin.dbeta) fin.dbeta[c] = (fin.acc_gn ? fin.dbeta[c] : 0.f) + (float)sums[c];
+                if (fin.dalpha) fin.dalpha[c] = (fin.acc_gn ? fin.dalpha[c] : 0.f) + da;
+            }
+        }
+        __syncthreads();
+    }
+    const float* cf = fin.acc ? reinterpret_cast<const float*>(reinterpret_cast<double*>(nodes + ((n_pos + 1) & ~1)) + 2 * C) : coef;  // (LDS or global)
     if ((int)blockIdx.x < n_dense) {
         const int TC = 1 << tc_log2, rpb = kOrdBlock >> tc_log2;
         const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
         const int c0 = tc * 4;
         if (c0 >= C) return;
-        const float4 Bx = *reinterpret_cast<const float4*>(coef + C + c0);
-        const float4 K = *reinterpret_cast<const float4*>(coef + 2 * C + c0);
+        const float4 Bx = *reinterpret_cast<const float4*>(cf + C + c0);
+        const float4 K = *reinterpret_cast<const float4*>(cf + 2 * C + c0);
         const int64_t stride = (int64_t)n_dense * rpb;
         for (int64_t r = (int64_t)blockIdx.x * rpb + tr; r < N; r += stride * 4) {
             float4 v[4];
@@ -455,7 +527,7 @@ __global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float
             for (int t = 0; t < 4; ++t) {
                 const int c = lane * 4 + kWave * 4 * t;
                 if (c < C) {
-                    const float4 A = *reinterpret_cast<const float4*>(coef + c);
+                    const float4 A = *reinterpret_cast<const float4*>(cf + c);
                     const float4 g = *reinterpret_cast<const float4*>(grow + c);
                     acc[t].x = fmaf(A.x, g.x, acc[t].x);
                     acc[t].y = fmaf(A.y, g.y, acc[t].y);
@@ -469,8 +541,8 @@ __global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float
     for (int t = 0; t < 4; ++t) {
         const int c = lane * 4 + kWave * 4 * t;
         if (c < C) {
-            const float4 Bx = *reinterpret_cast<const float4*>(coef + C + c);
-            const float4 K = *reinterpret_cast<const float4*>(coef + 2 * C + c);
+            const float4 Bx = *reinterpret_cast<const float4*>(cf + C + c);
+            const float4 K = *reinterpret_cast<const float4*>(cf + 2 * C + c);
             const float4 xv = *reinterpret_cast<const float4*>(x + (int64_t)node * ldx + c);
             float4 o = make_float4(fmaf(Bx.x, xv.x, K.x), fmaf(Bx.y, xv.y, K.y), fmaf(Bx.z, xv.z, K.z), fmaf(Bx.w, xv.w, K.w));
             o.x += acc[t].x; o.y += acc[t].y; o.z += acc[t].z; o.w += acc[t].w;
@@ -544,7 +616,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
                                        int64_t lddj, float* dWh, float* dbh, int acc_head, float* dgamma, float* dbeta,
                                        float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
                                        const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
-                                       const glass_gn_src* gn_src, void* stream) {
+                                       const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* stream) {
     GLASS_REQUIRE(jk && gn_saved && gamma && alpha && pos && Wh && bh && target && grad_loss && pooled && logits && loss &&
                       djk && dWh && dbh && ws,
                   "readout_train: null pointer");
@@ -572,8 +644,13 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
         esrc = GnExactSrc{reinterpret_cast<const long long*>(gn_src->acc), (int)gn_src->n_src, (int)gn_src->n_rep, gn_src->gamma, gn_src->beta,
                           gn_src->alpha, gn_src->eps, const_cast<float*>(gn_saved)};
     }
+    // two-launch form: the subgraph kernel adds its backward column sums to exact accumulators, the one-launch backfill folds
+    // them and carries the head-gradient / loss roles — no reduce launch (needs the listed pooled rows: see below)
+    const bool two = gn_bwd_acc != nullptr && vec && mask && lab_rows && lab_count && B * Smax <= kReadoutOrderedMax;
+    GLASS_REQUIRE(!gn_bwd_acc || (gn_bwd_rep >= 1 && gn_bwd_rep <= kAccRep), "readout_train: gn_bwd_rep = replicas of gn_bwd_acc (1 .. 16)");
     R1Args a1{jk, ldj, gn_saved, alpha, pos, (int)Smax, pool_mode, Wh, bh, target, loss_mode, (int)B, (int)C, (int)K,
-              grad_loss, pooled, logits, w, n_nodes, tc_log2, esrc};
+              grad_loss, pooled, logits, w, n_nodes, tc_log2, esrc, two ? reinterpret_cast<long long*>(gn_bwd_acc) : nullptr,
+              gn_bwd_rep};
     const size_t lds1 = sizeof(float) * (size_t)(10 * C + kBlock * 8 + 2 * kReadoutMaxK);
     if (vec)
         hipLaunchKernelGGL(readout_subgraph_kernel<4>, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
@@ -584,7 +661,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     size_t lds2 = sizeof(double) * kBlock * 2;
     if (sizeof(float) * (size_t)B > lds2) lds2 = sizeof(float) * (size_t)B;
     GLASS_REQUIRE(lds2 <= 64 * 1024, "readout_train: batch too large for the LDS staging");
-    hipLaunchKernelGGL(readout_reduce_kernel, dim3((unsigned)(K + 1 + ceil_div(C, kFinCols))), dim3(kBlock), lds2, st, a2);
+    if (!two) hipLaunchKernelGGL(readout_reduce_kernel, dim3((unsigned)(K + 1 + ceil_div(C, kFinCols))), dim3(kBlock), lds2, st, a2);
     if (!vec) {  // any C: scalar dense + sparse part as one launch (needs the label bytes = the pooled rows of this pos)
         hipLaunchKernelGGL(readout_backfill_scalar_kernel, dim3((unsigned)ceil_div(n_nodes, kBlock / kWave)), dim3(kBlock), 0, st,
                            jk, ldj, djk, lddj, n_nodes, (int)C, w.coef, mask, pos, (int)Smax, (int)(B * Smax), w.dys);
@@ -596,9 +673,21 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
         int64_t n_dense = ceil_div(n_nodes, (int64_t)rpb1 * 4);
         if (n_dense > 2048) n_dense = 2048;
         const int64_t n_sparse = ceil_div(B * Smax, (int64_t)(kOrdBlock / kWave));
-        hipLaunchKernelGGL(readout_backfill_kernel, dim3((unsigned)(n_dense + n_sparse)), dim3(kOrdBlock),
-                           sizeof(int32_t) * (size_t)(B * Smax), st, jk, ldj, djk, lddj, n_nodes, (int)C, tc_log2, w.coef, mask,
-                           pos, (int)Smax, (int)(B * Smax), w.dys, lab_rows, lab_count, (int)n_dense);
+        BackfillFin fin{};
+        size_t lds3 = sizeof(int32_t) * (size_t)(B * Smax);
+        unsigned extra = 0;
+        if (two) {
+            fin = BackfillFin{reinterpret_cast<const long long*>(gn_bwd_acc), gn_bwd_rep, gamma, alpha, gn_saved, dgamma, dbeta, dalpha,
+                              acc_gn, pooled, w.dlogits, w.loss_rows, dWh, dbh, loss, (int)B, (int)K, loss_mode, acc_head};
+            lds3 = sizeof(int32_t) * (size_t)((B * Smax + 1) & ~1ll) + sizeof(double) * 2 * (size_t)C + sizeof(float) * 3 * (size_t)C;
+            if (lds3 < sizeof(float) * (size_t)B) lds3 = sizeof(float) * (size_t)B;
+            extra = (unsigned)K + 1;
+            if (lds3 > 64 * 1024)
+                (void)hipFuncSetAttribute((const void*)readout_backfill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+        }
+        hipLaunchKernelGGL(readout_backfill_kernel, dim3((unsigned)(n_dense + n_sparse) + extra), dim3(kOrdBlock), lds3, st, jk, ldj, djk,
+                           lddj, n_nodes, (int)C, tc_log2, w.coef, mask, pos, (int)Smax, (int)(B * Smax), w.dys, lab_rows, lab_count,
+                           (int)n_dense, (int)n_sparse, fin);
         return launch_status("glass_readout_train_f32");
     }
     const int rpb = kBlock / tc;

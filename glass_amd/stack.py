@@ -37,6 +37,7 @@ def _check(rc, what):
 
 
 USE_GN_EXACT = os.environ.get("GLASS_GN_EXACT", "1") != "0"  # A/B switch: exact GraphNorm accumulators instead of partials + finalize
+USE_READOUT_TWO = os.environ.get("GLASS_READOUT_TWO", "1") != "0"  # readout as two launches (backward sums in exact accumulators)
 USE_GN_BWD_IN_COMB = os.environ.get("GLASS_GN_BWD_IN_COMB", "1") != "0"  # gns[l]'s backward apply inside the comb backward launch
 USE_GN_EXACT_FWD = os.environ.get("GLASS_GN_EXACT_FWD", "1") != "0"  # ... for the forward sums as well
 # above this many rows the partials + finalize form is kept: thousands of workgroups adding to the same few replicas would
@@ -469,15 +470,22 @@ class StackProgram:
         # prologue launch — their finalize launches disappear
         # ... and for the forward sums when the fused readout applies the final GraphNorm: [L] blocks for conv.gn's sums of a_l,
         # then [L] for the sums of c_l (consecutive: the column blocks of the jumping-knowledge buffer)
-        acc_all = acc_bwd = acc_fwd = None
+        acc_all = acc_bwd = acc_fwd = acc_ro = None
         if USE_GN_EXACT and lib.glass_gn_exact_supported(H) and n <= GN_EXACT_MAX_ROWS:
             n_bwd = 2 * L - 1 if keep else 0
             n_fwd = 2 * L if (readout is not None and USE_GN_EXACT_FWD) else 0
+            # ... and one block of L*H (jk) / H columns for the final GraphNorm's backward sums, added to by the readout's
+            # first kernel and folded by its backfill launch (two launches instead of three)
+            w_h = int(lib.glass_gn_exact_words(H))
+            w_ro = int(lib.glass_gn_exact_words(H * L if emb.jk else H)) if (readout is not None and keep and USE_READOUT_TWO) else 0
             if n_bwd + n_fwd:
-                acc_all = torch.empty((n_bwd + n_fwd, int(lib.glass_gn_exact_words(H))), dtype=torch.int64, device=dev)
-                acc_bwd = acc_all[:n_bwd] if n_bwd else None
-                acc_fwd = acc_all[n_bwd:] if n_fwd else None
+                acc_all = torch.empty((n_bwd + n_fwd) * w_h + w_ro, dtype=torch.int64, device=dev)
+                blocks = acc_all[:(n_bwd + n_fwd) * w_h].view(n_bwd + n_fwd, w_h)
+                acc_bwd = blocks[:n_bwd] if n_bwd else None
+                acc_fwd = blocks[n_bwd:] if n_fwd else None
+                acc_ro = acc_all[(n_bwd + n_fwd) * w_h:] if w_ro else None
         st["gn_exact"] = acc_bwd
+        st["gn_exact_readout"] = acc_ro
         if use_table and labels is not None and USE_GATHER_IN_TRANS and lib.glass_dual_linear_fwd_gather_supported(H):
             sel = emb._selection(x_flat)
             saved = torch.empty(4 * H, **f32)
@@ -581,6 +589,7 @@ class StackProgram:
         K = head.weight.shape[0]
         dev = jk.device
         f32 = dict(dtype=torch.float32, device=dev)
+        acc_ro = st.get("gn_exact_readout")  # (the library takes the two-launch form only with the listed pooled rows)
         final = st["final_saved"]  # (kept alive across the call below: the glass_gn_src struct lives in it)
         saved, src = _saved_args(final)
         st["final_saved"] = getattr(final, "saved", final)
@@ -601,7 +610,8 @@ class StackProgram:
                                            djk.data_ptr(), djk.stride(0), head.weight.grad.data_ptr(),
                                            head.bias.grad.data_ptr(), st["acc"], gn.weight.grad.data_ptr(),
                                            gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), st["acc"], ws.data_ptr(),
-                                           n, C, *largs, src, _stream()), "glass_readout_train_f32")
+                                           n, C, *largs, src, 0 if acc_ro is None else acc_ro.data_ptr(), REP_DENSE, _stream()),
+               "glass_readout_train_f32")
         st["djk"] = djk
         return loss, logits
 

@@ -518,7 +518,11 @@ int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved,
                             float* logits, float* loss, float* djk, int64_t lddj, float* dWh, float* dbh, int acc_head,
                             float* dgamma, float* dbeta, float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
                             const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
-                            const glass_gn_src* gn_src, void* stream);
+                            const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* stream);
+/*      gn_bwd_acc != NULL (with the listed pooled rows): two launches instead of three — the subgraph kernel adds its share of
+ *      the final GraphNorm's two backward column sums to these exact accumulators (glass_gn_exact_words(C) words, zeroed by
+ *      the caller per step, gn_bwd_rep replicas in use), the backfill launch folds them and also carries the head-gradient
+ *      rows and the mean loss. */
 
 /*     Two small device-to-device copies in one launch (4-byte granularity): a training step that is replayed from a
  *     captured graph reads its batch (pos, target) from fixed buffers; this fills both per step. */
