@@ -132,6 +132,7 @@ SIGNATURES = {
     "glass_comb_eff_blocks": (c_int64, [_I, _I, _I]),
     "glass_comb_eff_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_comb_eff_fwd_layout": (c_int, [_I]),
+    "glass_comb_eff_fwd_supported": (c_int, [_I]),
     "glass_comb_eff_max_rows": (c_int64, [_I]),
     "glass_comb_eff_dgrad_layout2": (c_int, [_I]),
     "glass_comb_eff_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, _P, _I, _I, _I, _P, c_int, _P, _P, c_int, c_float, _P,

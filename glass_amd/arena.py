@@ -148,6 +148,12 @@ class ParamArena(FlatGradBucket):
                         if lay2:  # the staged backward's own column order: a second pair of images behind the first
                             self._packs.append((W, WTe[WTimg.numel():], K, O, 1 | (lay2 << 1), mod))
                         mod._stack_eff = {"comb": (We, WTe)}
+                    elif kind == "comb" and K == O and _lib.load().glass_comb_eff_fwd_supported(O // 2):
+                        # hidden 128: the forward alone runs in effective-weight form (layout 8 image of W_unl | W_lab,
+                        # 2H * H floats each); its backward stays on the tiled kernels
+                        We = torch.empty(W.numel(), dtype=W.dtype, device=W.device)
+                        self._packs.append((W, We, O, K, 0 | (int(_lib.load().glass_comb_eff_fwd_layout(O // 2)) << 1), mod))
+                        mod._stack_eff = {"comb": (We, None)}
                 else:
                     mod._stack[kind] = (W, b, dW, db)
         import numpy as np

@@ -977,14 +977,15 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
 // NST = 16-row stages per workgroup (4: 64-row tiles; 5: 80-row tiles, taken when that brings the launch down to one
 // workgroup per CU — 280 workgroups on 256 CUs leave 24 CUs with two, whose waves share the matrix cores and finish last)
 template <int H, bool DROP, int NST>
-__global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
+__global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
                                                                const float* __restrict__ Wimg, const float* __restrict__ bias,
                                                                const uint8_t* __restrict__ mask, float zr, float omz,
                                                                float* __restrict__ out, int64_t ldo, int64_t N,
                                                                double* __restrict__ stats, int stats_exact, GnPrologue pro,
                                                                LabRows lab) {
-    static_assert(H == 64, "four waves x 16 columns");
+    static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
+    constexpr int THREADS = 4 * H, NTL = H / 16, KF4 = (2 * H) / 16;  // threads, 16-column tiles, float4 per lane of a weight slice
     constexpr int KT = 2 * H, RS = KT + 4;  // LDS row stride (floats): + 4 keeps the 16 rows of a b128 read off one bank group
     __shared__ __attribute__((aligned(16))) float tile[2][16 * RS];
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
@@ -1000,7 +1001,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
         base = ((int)blockIdx.x - lab.n_main) * ROWS;
         if (base >= n_lab) {  // extra workgroup beyond the list: an empty partial
             if (stats && !stats_exact)
-                for (int c = tid; c < 2 * H; c += kBlock) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
+                for (int c = tid; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
             return;
         }
     }
@@ -1008,14 +1009,14 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
     const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
     // this wave's slice of the effective weight: 8 float4 per lane
     const float4* img = reinterpret_cast<const float4*>(Wimg + (extra ? H * KT : 0));
-    float4 bw[8];
+    float4 bw[KF4];
 #pragma unroll
-    for (int tt = 0; tt < 8; ++tt) bw[tt] = img[(((tt >> 2) * 4 + w) * 4 + (tt & 3)) * 64 + lane];
+    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
     const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
     const float be = c1 * bias[16 * w + j] + c0 * bias[H + 16 * w + j];
     // the two float4 this thread moves per stage: 4-column group ga of the a half (GraphNorm prologue) and of the h half of
     // row rs of the stage (one buffer resource per half: wave-uniform)
-    const int rs = tid >> 4, ga = tid & 15;
+    const int rs = tid / (H / 4), ga = tid % (H / 4);
     int my_row[NST];  // (-1: none)
     int slot_v = -1;   // row of slot `tid` (threads < 64)
     unsigned char slot_mask = 0;
@@ -1049,7 +1050,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
-    if (pro.saved) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
+    if (pro.saved) gn_fwd_coef_nobarrier<H, THREADS>(pro.src, pro.saved, N, gn_coef_s);
     if (tid < ROWS) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
     D_STAMP(1, 1);
     lds_barrier();  // coefficients + row table
@@ -1089,10 +1090,10 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
 #pragma unroll
     for (int st = 0; st < NST; ++st) {
         if (st == 1) D_STAMP(1, 5);
-        const float* T = tile[st & 1] + j * RS + 32 * q;
-        float4 a4[8];
+        const float* T = tile[st & 1] + j * RS + (KT / 4) * q;
+        float4 a4[KF4];
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
+        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
         int rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
@@ -1100,7 +1101,7 @@ __global__ __launch_bounds__(kBlock) void comb_fwd_eff2_kernel(const float* __re
         if (st + 1 < NST) vn = prep(st + 1, (st & 1) ? rawA[0] : rawB[0]);  // the NEXT stage's rows (even stages come in rawA)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the dependent-MFMA latency
 #pragma unroll
-        for (int tt = 0; tt < 8; tt += 2) {
+        for (int tt = 0; tt < KF4; tt += 2) {
             const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
             const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
             const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
@@ -2373,10 +2374,12 @@ extern "C" int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const f
 
 // ---- comb pair in effective-weight form (hidden 64; see comb_fwd_eff_kernel) -----------------------------------------
 extern "C" int glass_comb_eff_supported(int64_t H) { return H == 64 ? 1 : 0; }
+// ... the FORWARD alone also at hidden 128 (staged kernel with 8 waves; the backward of that width stays on the tiled kernels)
+extern "C" int glass_comb_eff_fwd_supported(int64_t H) { return (H == 64 || (GLASS_COMB_FWD_V2 && H == 128)) ? 1 : 0; }
 
 // workgroups of the launch = entries of `stats` / `gn_partial`: row tiles + extra workgroups for up to lab_cap listed rows
 extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap) {
-    if (H != 64 || n_nodes <= 0 || lab_cap < 0) return GLASS_E_ARG;
+    if (!glass_comb_eff_fwd_supported(H) || n_nodes <= 0 || lab_cap < 0) return GLASS_E_ARG;
     return ceil_div(n_nodes, 64) + ceil_div(lab_cap, 64);
 }
 
@@ -2412,10 +2415,11 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
                                       const int32_t* lab_count, int64_t lab_cap, void* stream) {
     GLASS_REQUIRE(xa && xb && Wimg_eff && bias && mask && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
                   "comb_eff_fwd: null pointer");
-    if (H != 64) {
-        set_error("comb_eff_fwd: hidden size %lld not supported (64)", (long long)H);
+    if (!glass_comb_eff_fwd_supported(H)) {
+        set_error("comb_eff_fwd: hidden size %lld not supported (64, 128)", (long long)H);
         return GLASS_E_UNSUPPORTED;
     }
+    GLASS_REQUIRE(H == 64 || !stats_exact, "comb_eff_fwd: exact GraphNorm accumulators are served at hidden 64 only");
     GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved) &&
                                 p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
                                 (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
@@ -2445,15 +2449,20 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
                   "comb_eff_fwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets; glass_comb_eff_max_rows)");
     GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || !gn_saved || gn_act == GLASS_ACT_NONE,
                   "comb_eff_fwd: the GraphNorm in front of the comb pair has no activation (impl/models.py:165-166)");
-#define GLASS_CF2(DR, NS)                                                                                                 \
-    hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, DR, NS>), grid, dim3(kBlock), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, \
+#define GLASS_CF2(HH, DR, NS)                                                                                             \
+    hipLaunchKernelGGL((comb_fwd_eff2_kernel<HH, DR, NS>), grid, dim3(4 * HH), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, \
                        bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
     const bool dr = gn_saved && p_drop > 0.f;
-    if (GLASS_COMB_FWD_V2) {
-        if (dr && tall) GLASS_CF2(true, 5);
-        else if (dr) GLASS_CF2(true, 4);
-        else if (tall) GLASS_CF2(false, 5);
-        else GLASS_CF2(false, 4);
+    if (GLASS_COMB_FWD_V2 && H == 128) {
+        if (dr && tall) GLASS_CF2(128, true, 5);
+        else if (dr) GLASS_CF2(128, true, 4);
+        else if (tall) GLASS_CF2(128, false, 5);
+        else GLASS_CF2(128, false, 4);
+    } else if (GLASS_COMB_FWD_V2) {
+        if (dr && tall) GLASS_CF2(64, true, 5);
+        else if (dr) GLASS_CF2(64, true, 4);
+        else if (tall) GLASS_CF2(64, false, 5);
+        else GLASS_CF2(64, false, 4);
     }
 #undef GLASS_CF2
     else

@@ -76,8 +76,15 @@ class BatchLabels:
 
 
 def _comb_eff_ok(conv, labels, H):
-    return (USE_COMB_EFF and labels is not None and "comb" in getattr(conv, "_stack_eff", {}) and
+    """forward AND backward of the comb pair in effective-weight form (hidden 64)"""
+    return (USE_COMB_EFF and labels is not None and getattr(conv, "_stack_eff", {}).get("comb", (None, None))[1] is not None and
             bool(_lib.load().glass_comb_eff_supported(H)) and labels.n <= _lib.load().glass_comb_eff_max_rows(4 * H))
+
+
+def _comb_eff_fwd_ok(conv, labels, H):
+    """the forward alone (also hidden 128)"""
+    return (USE_COMB_EFF and labels is not None and "comb" in getattr(conv, "_stack_eff", {}) and
+            bool(_lib.load().glass_comb_eff_fwd_supported(H)) and labels.n <= _lib.load().glass_comb_eff_max_rows(4 * H))
 
 
 class _PendingStats:
@@ -548,7 +555,7 @@ class StackProgram:
             last = l + 1 == L
             c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
             # the comb kernel's epilogue also leaves the column statistics of c for the GraphNorm(s) that read it
-            if _comb_eff_ok(conv, labels, H):
+            if _comb_eff_fwd_ok(conv, labels, H):
                 cstat = acc_fwd[L + l] if acc_fwd is not None else \
                     torch.empty((int(lib.glass_comb_eff_blocks(n, H, labels.cap)), 2, H), dtype=torch.float64, device=dev)
                 _comb_eff_fwd(a, h, conv, mask, c, cstat, (gsaved, ACT_NONE, pc, conv.call_base, g), labels)

@@ -352,6 +352,7 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
  *   listed rows (half the matrix work of the plain form); reduce them with glass_linear_wgrad_reduce_batch_f32, lab_cap[j]
  *   = this call's lab_cap. */
 int glass_comb_eff_supported(int64_t H);
+int glass_comb_eff_fwd_supported(int64_t H); /* the forward alone: also hidden 128 */
 int glass_comb_eff_fwd_layout(int64_t H); /* pack layout of Wimg_eff for glass_comb_eff_fwd_f32: 6 or 8 */
 int glass_comb_eff_dgrad_layout2(int64_t H); /* != 0: WTimg_eff holds a second pair of images in this layout behind the layout-7 pair */
 int64_t glass_comb_eff_max_rows(int64_t ld); /* most rows the forward serves at operand row strides <= ld floats */
