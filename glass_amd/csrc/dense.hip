@@ -586,22 +586,23 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
                                                   const float* __restrict__ WT, const float* __restrict__ addend, int64_t ldadd,
                                                   Drop drop, const uint64_t* __restrict__ rng_state, float* __restrict__ out,
                                                   int64_t ldo, int64_t N, GnBwdStats gs, int block, float* lds) {
-    static_assert(H == 64, "four waves x 16 columns");
+    static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
+    constexpr int NTL = H / 16, KF4 = (2 * H) / 16;
     constexpr int KT = 2 * H, RA = KT + 4, RP = H + 4;
     constexpr int kBuf = 16 * RA + 4 * 16 * RP;  // A | ADD | M | U | XU  (floats per stage buffer)
     int* rows_s = reinterpret_cast<int*>(lds + 2 * kBuf);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int rs = tid >> 4, ga = tid & 15;
+    const int rs = tid / (H / 4), ga = tid % (H / 4);
     const int64_t r0 = (int64_t)block * 64;
     const buf_rsrc r_d = make_rsrc(dsrc, N * ldd * 4), r_t = make_rsrc(T ? T : dsrc, T ? N * ldt * 4 : 0);
     const buf_rsrc r_m = make_rsrc(mask, N), r_out = make_rsrc(out, N * ldo * 4);
     const buf_rsrc r_add = make_rsrc(addend ? addend : dsrc, addend ? N * ldadd * 4 : 0);
     const buf_rsrc r_x = make_rsrc(gs.partial ? gs.x : dsrc, gs.partial ? N * gs.ldx * 4 : 0);
     const float4* img = reinterpret_cast<const float4*>(WT);
-    float4 bw[8];
+    float4 bw[KF4];
 #pragma unroll
-    for (int tt = 0; tt < 8; ++tt) bw[tt] = img[(((tt >> 2) * 4 + w) * 4 + (tt & 3)) * 64 + lane];
+    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
     int my_row[4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
@@ -686,9 +687,9 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
         const float* M = ADD + 16 * RP;
         const float* U = M + 16 * RP;
         const float* XU = U + 16 * RP;
-        float4 a4[8];
+        float4 a4[KF4];
 #pragma unroll
-        for (int tt = 0; tt < 8; ++tt) a4[tt] = *reinterpret_cast<const float4*>(A + j * RA + 32 * q + 4 * tt);
+        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(A + j * RA + (KT / 4) * q + 4 * tt);
         int rv[4];
         float ad[4], mm[4], uu[4], xx[4];
 #pragma unroll
@@ -701,7 +702,7 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tt = 0; tt < 8; tt += 2) {
+        for (int tt = 0; tt < KF4; tt += 2) {
             const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
             const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
             const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
@@ -744,7 +745,15 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
         }
     }
 }
-constexpr size_t kTransDgrad2Lds = (size_t)(2 * (16 * (2 * 64 + 4) + 4 * 16 * (64 + 4)) + 64) * sizeof(float);
+constexpr size_t trans_dgrad2_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 64) * sizeof(float); }
+constexpr size_t kTransDgrad2Lds = trans_dgrad2_lds(64);
+
+template <int H>
+__global__ __launch_bounds__(4 * H) void trans_dgrad2_kernel(DgradArgs A) {
+    extern __shared__ float4 lds_w[];
+    trans_dgrad2_body<H>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop, A.rng_state, A.out,
+                         A.ldo, A.N, A.gs, blockIdx.x, reinterpret_cast<float*>(lds_w));
+}
 
 template <int H, int NT, int CS, int RW>
 __global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(DgradArgs A) {
@@ -2146,7 +2155,7 @@ extern "C" int glass_dual_linear_fwd_layout(int64_t H, int64_t K) {
     return tiled_eff_fwd_shape(H, K) ? kLayoutTiledPairedEff : kLayoutTiledPaired;
 }
 extern "C" int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out) {
-    if (GLASS_TRANS_DGRAD_V2 && wave16_shape_ok(H) && n_out == H) return kLayoutWave16Cols;  // trans pair at hidden 64: trans_dgrad2_body
+    if (GLASS_TRANS_DGRAD_V2 && (wave16_shape_ok(H) || H == 128) && n_out == H) return kLayoutWave16Cols;  // trans pair at hidden 64 / 128: trans_dgrad2_body
     if (!tiled_here(H)) return kLayoutWave16;
     if (tiled_eff_dgrad_shape(H, n_out)) return kLayoutTiledPlainEff;
     return n_out % 256 == 0 ? kLayoutTiledPlain : kLayoutTiledSplit;
@@ -2300,6 +2309,18 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         return glass_dual_linear_wgrad_f32(dsrc, ldd, T, ldt, mask, z_ratio, act, wg->X, wg->ldx, wg->X2, wg->ldx2, n_nodes, H,
                                            nullptr, 0, nullptr, 0, wg->ws, stream);
     };
+    if (GLASS_TRANS_DGRAD_V2 && H == 128 && n_out == H) {  // staged form with 8 waves (image in layout kLayoutWave16Cols)
+        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(act == GLASS_ACT_ELU ? ldt : (int64_t)0, addend ? ldadd : (int64_t)0),
+                                                                     gn_partial ? gn_ldx : (int64_t)0));
+        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "dual_linear_dgrad: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
+        GLASS_REQUIRE(!gn_exact, "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only");
+        const DgradArgs d128{dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs};
+        const size_t lds128 = trans_dgrad2_lds(128);
+        allow_lds(trans_dgrad2_kernel<128>, lds128);
+        hipLaunchKernelGGL((trans_dgrad2_kernel<128>), dim3((unsigned)ceil_div(n_nodes, 64)), dim3(512), lds128, st, d128);
+        const int rc = launch_status("glass_dual_linear_dgrad_f32 (staged, hidden 128)");
+        return rc ? rc : wgrad_after();
+    }
     if (tiled_here(H)) {
         const int rc = launch_tiled_dgrad(dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, n_out, addend, ldadd, drop, rng_state,
                                           out, ldo, n_nodes, H, gs, st);
@@ -2586,7 +2607,8 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
         const int layout = transposed[k] >> 1;
         GLASS_REQUIRE(layout == kLayoutWave16 ||
                           (layout == kLayoutWave16Cols && ((NT[k] == 128 && KT[k] == 64 && !(transposed[k] & 1)) ||
-                                                           (NT[k] == 64 && KT[k] == 128 && (transposed[k] & 1)))) ||
+                                                           (NT[k] == 64 && KT[k] == 128 && (transposed[k] & 1)) ||
+                                                           (NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)))) ||
                           ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
                           (layout == kLayoutTiledSplit && NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)) ||
                           (layout == kLayoutTiledPlainEff && NT[k] % 256 == 0 && KT[k] % 32 == 0 && (transposed[k] & 1) && z_ratio) ||
