@@ -261,6 +261,99 @@ __global__ __launch_bounds__(kBlock) void wgrad_reduce_batch_kernel(ReduceBatch 
     wgrad_reduce_body(j.part_w, j.part_b, j.n_slabs, j.ny, j.nz, j.O, j.I, j.dW, j.lddw, j.db, j.accumulate, lds, blockIdx.y);
 }
 
+// ---- thin outputs (O <= 3): the last Linear of the pre-training head maps hidden -> 1 over 131 072 pair rows
+// (reference GNNEmb.py: MLP(hidden, hidden, 1, 2)); the MFMA slab kernel wants O % 4 == 0 and a library GEMM of shape
+// [1 x N] . [N x I] runs at 288 us (rocprofv3, ppi_bp-shape).  Here: row slabs over the workgroups, TC lanes x float4 over
+// the input columns, row slots combined through LDS in fixed order, partials reduced in fp64 by a second tiny launch.
+constexpr int kThinMaxO = 3;
+constexpr int kThinMaxBlocks = 1024;
+
+template <int O>
+__global__ __launch_bounds__(kBlock) void wgrad_thin_partial_kernel(const float* __restrict__ G, int64_t ldg,
+                                                                    const float* __restrict__ X, int64_t ldx, int64_t N, int I,
+                                                                    int rows_per_blk, int tc_log2, float* __restrict__ part) {
+    __shared__ float red[kBlock * (O * 4 + O)];
+    const int TC = 1 << tc_log2, li = threadIdx.x & (TC - 1), slot = threadIdx.x >> tc_log2, n_slot = kBlock >> tc_log2;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_blk;
+    const int64_t r1 = r0 + rows_per_blk < N ? r0 + rows_per_blk : N;
+    float* my = part + (size_t)blockIdx.x * (O * I + O);
+    for (int ch = 0; ch * TC * 4 < I; ++ch) {  // uniform trip count (barriers inside)
+        const int c0 = (ch * TC + li) * 4;
+        float acc[O][4], accb[O];
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            accb[o] = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[o][k] = 0.f;
+        }
+        if (c0 < I)
+            for (int64_t r = r0 + slot; r < r1; r += n_slot) {
+                const float4 x = *reinterpret_cast<const float4*>(X + r * ldx + c0);
+#pragma unroll
+                for (int o = 0; o < O; ++o) {
+                    const float g = G[r * ldg + o];
+                    acc[o][0] = fmaf(g, x.x, acc[o][0]);
+                    acc[o][1] = fmaf(g, x.y, acc[o][1]);
+                    acc[o][2] = fmaf(g, x.z, acc[o][2]);
+                    acc[o][3] = fmaf(g, x.w, acc[o][3]);
+                    accb[o] += g;
+                }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) red[threadIdx.x * (O * 4 + O) + o * 4 + k] = acc[o][k];
+            red[threadIdx.x * (O * 4 + O) + O * 4 + o] = accb[o];
+        }
+        __syncthreads();
+        if (slot == 0 && c0 < I) {
+#pragma unroll
+            for (int o = 0; o < O; ++o) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
+                for (int t = 0; t < n_slot; ++t) {
+                    const float* q = red + ((t << tc_log2) + li) * (O * 4 + O);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) s[k] += q[o * 4 + k];
+                    sb += q[O * 4 + o];
+                }
+                *reinterpret_cast<float4*>(my + o * I + c0) = make_float4(s[0], s[1], s[2], s[3]);
+                if (ch == 0 && li == 0) my[O * I + o] = sb;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void wgrad_thin_reduce_kernel(const float* __restrict__ part, int n_blk, int O, int I,
+                                                                   float* __restrict__ dW, int64_t lddw, float* __restrict__ db,
+                                                                   int accumulate) {
+    // four outputs per workgroup, 64 slots striding over the partial blocks; slots combined in fixed order
+    __shared__ double red[kBlock];
+    const int ob = threadIdx.x & 3, slot = threadIdx.x >> 2, stride = O * I + O;
+    const int idx = blockIdx.x * 4 + ob;
+    double s = 0.0;
+    if (idx < stride)
+        for (int b = slot; b < n_blk; b += kBlock / 4) s += (double)part[(size_t)b * stride + idx];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (slot != 0 || idx >= stride) return;
+    double t = 0.0;
+    for (int r = 0; r < kBlock / 4; ++r) t += red[r * 4 + ob];
+    const float v = (float)t;
+    if (idx < O * I) {
+        float* d = dW + (int64_t)(idx / I) * lddw + idx % I;
+        *d = accumulate ? *d + v : v;
+    } else if (db) {
+        float* d = db + (idx - O * I);
+        *d = accumulate ? *d + v : v;
+    }
+}
+
+static int thin_blocks(int64_t N) {
+    const int64_t b = ceil_div(N, 64);
+    return (int)(b < kThinMaxBlocks ? b : kThinMaxBlocks);
+}
+
 WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     WgradGeom g;
     // Slab count: about one workgroup per CU over all (slab, input-chunk, output-chunk) triples, at most 128
@@ -427,6 +520,7 @@ extern "C" int64_t glass_linear_wgrad_ws_bytes(int64_t N, int64_t O, int64_t I) 
     if (N <= 0 || O <= 0 || I <= 0) return GLASS_E_ARG;
     const WgradGeom g = wgrad_geom(N, O, I);
     int64_t floats = g.part_w_floats + g.part_b_floats;
+    if (O <= kThinMaxO && (int64_t)thin_blocks(N) * (O * I + O) > floats) floats = (int64_t)thin_blocks(N) * (O * I + O);
     if (O <= 2 * 32 && I <= 2 * 32) {  // narrow pairs (dense_narrow.hip)
         int n_slabs, stride;
         narrow_wgrad_geom(N, O, I, &n_slabs, &stride);
@@ -444,6 +538,24 @@ extern "C" int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* 
                                       void* stream) {
     GLASS_REQUIRE(G && X && dW && ws, "linear_wgrad: null pointer");
     GLASS_REQUIRE(N > 0 && O > 0 && I > 0 && ldg >= O && ldx >= I && lddw >= I, "linear_wgrad: bad sizes");
+    if (O <= kThinMaxO && I % 4 == 0 && ldx % 4 == 0 && aligned16(X) && aligned16(ws)) {  // thin outputs (hidden -> 1 heads)
+        hipStream_t st = (hipStream_t)stream;
+        const int nb = thin_blocks(N);
+        const int rows = (int)ceil_div(N, nb);
+        const int tc = pow2_ceil_cap(I / 4, 64);
+        int tl = 0;
+        while ((1 << tl) < tc) ++tl;
+        float* part = (float*)ws;
+        if (O == 1)
+            hipLaunchKernelGGL(wgrad_thin_partial_kernel<1>, dim3(nb), dim3(kBlock), 0, st, G, ldg, X, ldx, N, (int)I, rows, tl, part);
+        else if (O == 2)
+            hipLaunchKernelGGL(wgrad_thin_partial_kernel<2>, dim3(nb), dim3(kBlock), 0, st, G, ldg, X, ldx, N, (int)I, rows, tl, part);
+        else
+            hipLaunchKernelGGL(wgrad_thin_partial_kernel<3>, dim3(nb), dim3(kBlock), 0, st, G, ldg, X, ldx, N, (int)I, rows, tl, part);
+        hipLaunchKernelGGL(wgrad_thin_reduce_kernel, dim3((unsigned)ceil_div(O * I + O, (int64_t)4)), dim3(kBlock), 0, st, part,
+                           nb, (int)O, (int)I, dW, lddw, db, accumulate);
+        return launch_status("glass_linear_wgrad_f32");
+    }
     if (O % 4 || I % 2 || ldg % 4 || ldx % 2 || !aligned16(G) || (reinterpret_cast<uintptr_t>(X) & 7u)) {
         set_error("linear_wgrad: needs O%%4==0, I%%2==0, ldg%%4==0, ldx%%2==0 and 16-B/8-B aligned G/X "
                   "(O=%lld I=%lld ldg=%lld ldx=%lld)", (long long)O, (long long)I, (long long)ldg, (long long)ldx);

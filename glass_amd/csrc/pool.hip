@@ -206,6 +206,221 @@ __global__ __launch_bounds__(kBlock) void pool_bwd_ordered_kernel(const float* _
     }
 }
 
+// ---- node pairs (Smax = 2): the link-prediction batches of the pre-training path (reference GNNEmb.py:144: 131 072 edge /
+// non-edge pairs per step; impl/models.py:498-503 pools them with the same mean).  One workgroup per subgraph is the wrong
+// shape for two entries: here G lanes cover an embedding row and a workgroup takes 256 / G pairs.
+template <int VW>
+__global__ __launch_bounds__(kBlock) void pair_fwd_kernel(const float* __restrict__ emb, int64_t lde,
+                                                          const int64_t* __restrict__ pairs, int64_t B, int mode,
+                                                          float* __restrict__ out, int64_t ldo, int64_t n_nodes, int C,
+                                                          int g_log2) {
+    const int G = 1 << g_log2, li = threadIdx.x & (G - 1);
+    const int64_t p = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> g_log2;
+    if (p >= B) return;
+    const int64_t a = pairs[2 * p], b = pairs[2 * p + 1];
+    const bool va = a >= 0 && a < n_nodes, vb = b >= 0 && b < n_nodes;
+    const float sc = pool_scale(mode, (int)va + (int)vb);
+    for (int c0 = li * VW; c0 < C; c0 += G * VW) {
+        P<VW> x, y, o;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) x.a[k] = y.a[k] = 0.f;
+        if (va) x.load(emb + a * lde + c0);
+        if (vb) y.load(emb + b * lde + c0);
+#pragma unroll
+        for (int k = 0; k < VW; ++k) o.a[k] = (x.a[k] + y.a[k]) * sc;
+        o.store(out + p * ldo + c0);
+    }
+}
+
+// Backward of the pair pool without a float atomic: the entries (pair, side) are bucketed by node — counts by integer
+// atomics, offsets by a one-workgroup scan, entry lists filled through integer cursors (their order inside a node's list
+// is arbitrary) — and each node's row is the sum of its entries' scaled gradient rows taken in EXACT fixed point
+// (hi * 2^-20 + lo * 2^-60 in two 64-bit integers per column: integer addition commutes, so the arbitrary list order does
+// not reach the result).  Bitwise repeatable; every row of demb is written (rows without an entry: zeros).
+__global__ __launch_bounds__(kBlock) void pair_zero_kernel(int32_t* __restrict__ off, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) off[i] = 0;
+}
+
+// counts per node (off[node + 1]) and, from the same returning atomic, the entry's rank inside its node's list
+__global__ __launch_bounds__(kBlock) void pair_rank_kernel(const int64_t* __restrict__ pairs, int64_t n_entries,
+                                                           int64_t n_nodes, int32_t* __restrict__ off,
+                                                           int32_t* __restrict__ rank) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_entries) return;
+    const int64_t node = pairs[e];
+    if (node >= 0 && node < n_nodes) rank[e] = atomicAdd(off + node + 1, 1);
+}
+
+// off[0 .. n_nodes] (off[0] = 0, off[i + 1] = entries of node i) -> inclusive prefix sums in place: one workgroup, 4096
+// elements per round (b128 per thread, wave scans by lane shuffles, the 16 wave totals through LDS, a running carry)
+__global__ __launch_bounds__(1024) void pair_scan_kernel(int32_t* __restrict__ off, int64_t n) {
+    __shared__ int32_t wsum[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int32_t carry = 0;
+    for (int64_t base = 0; base < n; base += 4096) {
+        const int64_t i = base + 4 * threadIdx.x;
+        int32_t v[4] = {0, 0, 0, 0};
+        if (i + 3 < n) {
+            const int4 q = *reinterpret_cast<const int4*>(off + i);
+            v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) v[k] = off[i + k];
+        }
+        v[1] += v[0];
+        v[2] += v[1];
+        v[3] += v[2];
+        int32_t incl = v[3];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int32_t before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int32_t t = wsum[k];
+            if (k < w) before += t;
+            total += t;
+        }
+        const int32_t excl = carry + before + incl - v[3];
+        if (i + 3 < n) {
+            *reinterpret_cast<int4*>(off + i) = make_int4(excl + v[0], excl + v[1], excl + v[2], excl + v[3]);
+        } else {
+            for (int k = 0; k < 4; ++k)
+                if (i + k < n) off[i + k] = excl + v[k];
+        }
+        carry += total;
+        __syncthreads();
+    }
+}
+
+// list[off[node] + rank] = (pair << 1) | (both entries of the pair valid): what the gather needs without reading pairs
+__global__ __launch_bounds__(kBlock) void pair_fill_kernel(const int64_t* __restrict__ pairs, int64_t n_entries,
+                                                           int64_t n_nodes, const int32_t* __restrict__ off,
+                                                           const int32_t* __restrict__ rank, int32_t* __restrict__ list) {
+    const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (e >= n_entries) return;
+    const int64_t node = pairs[e], other = pairs[e ^ 1];
+    if (node >= 0 && node < n_nodes) list[off[node] + rank[e]] = (int32_t)((e >> 1) << 1) | (int32_t)(other >= 0 && other < n_nodes);
+}
+
+struct ExactSum {
+    long long hi, lo;
+    __device__ __forceinline__ void add(float v) {
+        double sv = (double)v * 1048576.0;  // 2^20
+        sv = fmin(fmax(sv, -4.0e18), 4.0e18);
+        const double fl = floor(sv);
+        hi += (long long)fl;
+        lo += (long long)((sv - fl) * 1099511627776.0);  // 2^40
+    }
+    __device__ __forceinline__ float value() const {
+        return (float)(((double)hi + (double)lo * (1.0 / 1099511627776.0)) * (1.0 / 1048576.0));
+    }
+};
+
+constexpr int kPairLongList = 64;  // entries from which a node's list is summed by the whole workgroup
+
+template <int VW>
+__global__ __launch_bounds__(kBlock) void pair_gather_kernel(const float* __restrict__ dout, int64_t ldd,
+                                                             int mode,
+                                                             const int32_t* __restrict__ off, const int32_t* __restrict__ list,
+                                                             float* __restrict__ demb, int64_t lde, int64_t n_nodes, int C,
+                                                             int g_log2) {
+    __shared__ long long red[kBlock * VW * 2];
+    const int G = 1 << g_log2, li = threadIdx.x & (G - 1), slot = threadIdx.x >> g_log2, n_slot = kBlock >> g_log2;
+    const int64_t node0 = (int64_t)blockIdx.x * n_slot;
+    const float sc1 = pool_scale(mode, 1), sc2 = pool_scale(mode, 2);
+    auto scaled_row = [&](int e, int c0, float (&v)[VW]) __attribute__((always_inline)) {
+        P<VW> g;
+        g.load(dout + (int64_t)(e >> 1) * ldd + c0);
+        const float sc = (e & 1) ? sc2 : sc1;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) v[k] = g.a[k] * sc;
+    };
+    // short lists: one lane group per node
+    {
+        const int64_t node = node0 + slot;
+        const int beg = node < n_nodes ? off[node] : 0, end = node < n_nodes ? off[node + 1] : 0;
+        if (node < n_nodes && end - beg < kPairLongList) {
+            for (int c0 = li * VW; c0 < C; c0 += G * VW) {
+                ExactSum s[VW];
+#pragma unroll
+                for (int k = 0; k < VW; ++k) s[k].hi = s[k].lo = 0;
+                int i = beg;
+                for (; i + 3 < end; i += 4) {  // four independent chains of loads in flight
+                    float v0[VW], v1[VW], v2[VW], v3[VW];
+                    const int e0 = list[i], e1 = list[i + 1], e2 = list[i + 2], e3 = list[i + 3];
+                    scaled_row(e0, c0, v0);
+                    scaled_row(e1, c0, v1);
+                    scaled_row(e2, c0, v2);
+                    scaled_row(e3, c0, v3);
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) {
+                        s[k].add(v0[k]);
+                        s[k].add(v1[k]);
+                        s[k].add(v2[k]);
+                        s[k].add(v3[k]);
+                    }
+                }
+                for (; i < end; ++i) {
+                    float v0[VW];
+                    scaled_row(list[i], c0, v0);
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) s[k].add(v0[k]);
+                }
+                P<VW> o;
+#pragma unroll
+                for (int k = 0; k < VW; ++k) o.a[k] = s[k].value();
+                o.store(demb + node * lde + c0);
+            }
+        }
+    }
+    // long lists: the whole workgroup takes one node at a time (its lane groups stride over the entries)
+    for (int t = 0; t < n_slot; ++t) {
+        const int64_t node = node0 + t;
+        if (node >= n_nodes) break;
+        const int beg = off[node], end = off[node + 1];
+        if (end - beg < kPairLongList) continue;  // workgroup-uniform
+        for (int ch = 0; ch * G * VW < C; ++ch) {  // uniform trip count: barriers inside
+            const int c0 = (ch * G + li) * VW;
+            ExactSum s[VW];
+#pragma unroll
+            for (int k = 0; k < VW; ++k) s[k].hi = s[k].lo = 0;
+            if (c0 < C)
+                for (int i = beg + slot; i < end; i += n_slot) {
+                    float v0[VW];
+                    scaled_row(list[i], c0, v0);
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) s[k].add(v0[k]);
+                }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < VW; ++k) {
+                red[(threadIdx.x * VW + k) * 2] = s[k].hi;
+                red[(threadIdx.x * VW + k) * 2 + 1] = s[k].lo;
+            }
+            __syncthreads();
+            if (slot == 0 && c0 < C) {
+                P<VW> o;
+#pragma unroll
+                for (int k = 0; k < VW; ++k) {
+                    ExactSum tsum{0, 0};
+                    for (int r = 0; r < n_slot; ++r) {
+                        tsum.hi += red[(((r << g_log2) + li) * VW + k) * 2];
+                        tsum.lo += red[(((r << g_log2) + li) * VW + k) * 2 + 1];
+                    }
+                    o.a[k] = tsum.value();
+                }
+                o.store(demb + node * lde + c0);
+            }
+        }
+    }
+}
+
 constexpr int64_t kPoolOrderedMax = 12288;  // pos entries (+ B scales) staged in LDS: <= 64 KiB
 
 }  // namespace glass
@@ -271,4 +486,64 @@ extern "C" int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const 
         hipLaunchKernelGGL(pool_bwd_kernel<1>, grid, dim3(kBlock), 0, st, dout, ldd, pos, (int)Smax, mode, argmax, demb,
                            lde, n_nodes, (int)C, tc_log2);
     return launch_status("glass_segment_pool_bwd_f32");
+}
+
+
+// ---- pair pool (Smax = 2, sum | mean | size) ----
+static int pair_group_log2(int64_t C, bool vec) {
+    const int cw = (int)ceil_div(C, vec ? 4 : 1);
+    const int g = pow2_ceil_cap(cw, 64);
+    int l = 0;
+    while ((1 << l) < g) ++l;
+    return l;
+}
+
+extern "C" int64_t glass_pair_pool_ws_bytes(int64_t n_nodes, int64_t B) {
+    if (n_nodes <= 0 || B <= 0) return 0;
+    return (int64_t)sizeof(int32_t) * (((n_nodes + 1 + 3) & ~(int64_t)3) + 4 * B);
+}
+
+extern "C" int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t* pairs, int64_t B, int mode, float* out,
+                                   int64_t ldo, int64_t n_nodes, int64_t C, void* stream) {
+    int rc = pool_args_ok(emb, pairs, out, B, 2, mode, C, lde, ldo);
+    if (rc) return rc;
+    GLASS_REQUIRE(mode != GLASS_POOL_MAX, "pair_pool: sum | mean | size only");
+    const bool vec = C % 4 == 0 && lde % 4 == 0 && ldo % 4 == 0 && aligned16(emb) && aligned16(out);
+    const int gl = pair_group_log2(C, vec);
+    const unsigned grid = (unsigned)ceil_div(B << gl, (int64_t)kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    if (vec)
+        hipLaunchKernelGGL(pair_fwd_kernel<4>, dim3(grid), dim3(kBlock), 0, st, emb, lde, pairs, B, mode, out, ldo, n_nodes,
+                           (int)C, gl);
+    else
+        hipLaunchKernelGGL(pair_fwd_kernel<1>, dim3(grid), dim3(kBlock), 0, st, emb, lde, pairs, B, mode, out, ldo, n_nodes,
+                           (int)C, gl);
+    return launch_status("glass_pair_pool_f32");
+}
+
+extern "C" int glass_pair_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pairs, int64_t B, int mode, float* demb,
+                                       int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream) {
+    int rc = pool_args_ok(dout, pairs, demb, B, 2, mode, C, ldd, lde);
+    if (rc) return rc;
+    GLASS_REQUIRE(mode != GLASS_POOL_MAX && ws && aligned16(ws) && n_nodes > 0 && 2 * B < (1ll << 30) && n_nodes < (1ll << 31),
+                  "pair_pool_bwd: sum | mean | size only, 16-B aligned workspace, fewer than 2^30 entries and 2^31 nodes");
+    const bool vec = C % 4 == 0 && ldd % 4 == 0 && lde % 4 == 0 && aligned16(dout) && aligned16(demb);
+    const int gl = pair_group_log2(C, vec);
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* off = (int32_t*)ws;  // [n_nodes + 1], then rank [2B] and list [2B]
+    int32_t* rank = off + ((n_nodes + 1 + 3) & ~(int64_t)3);
+    int32_t* list = rank + 2 * B;
+    const unsigned ge = (unsigned)ceil_div(2 * B, (int64_t)kBlock);
+    hipLaunchKernelGGL(pair_zero_kernel, dim3((unsigned)ceil_div(n_nodes + 1, (int64_t)kBlock)), dim3(kBlock), 0, st, off, n_nodes + 1);
+    hipLaunchKernelGGL(pair_rank_kernel, dim3(ge), dim3(kBlock), 0, st, pairs, 2 * B, n_nodes, off, rank);
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, st, off, n_nodes + 1);
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(ge), dim3(kBlock), 0, st, pairs, 2 * B, n_nodes, off, rank, list);
+    const unsigned gg = (unsigned)ceil_div(n_nodes, (int64_t)(kBlock >> gl));
+    if (vec)
+        hipLaunchKernelGGL(pair_gather_kernel<4>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, mode, off, list, demb, lde,
+                           n_nodes, (int)C, gl);
+    else
+        hipLaunchKernelGGL(pair_gather_kernel<1>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, mode, off, list, demb, lde,
+                           n_nodes, (int)C, gl);
+    return launch_status("glass_pair_pool_bwd_f32");
 }

@@ -300,7 +300,8 @@ def linear_wgrad(G, X, dW, db, accumulate, slot=0):
     X, ldx = _rows(X)
     N, O = G.shape
     I = X.shape[1]
-    if O % 4 or I % 2 or ldg % 4 or ldx % 2 or G.data_ptr() % 16 or X.data_ptr() % 8 or dW.stride(1) != 1:
+    thin = O <= 3 and I % 4 == 0 and ldx % 4 == 0 and X.data_ptr() % 16 == 0  # hidden -> 1 heads: the library's thin kernels
+    if dW.stride(1) != 1 or not (thin or not (O % 4 or I % 2 or ldg % 4 or ldx % 2 or G.data_ptr() % 16 or X.data_ptr() % 8)):
         return False
     ws = _wgrad_workspace(G.device, N, O, I, slot)
     rc = _lib.load().glass_linear_wgrad_f32(G.data_ptr(), ldg, X.data_ptr(), ldx, N, O, I, dW.data_ptr(), dW.stride(0),
@@ -324,7 +325,12 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, W = ctx.saved_tensors
-        dx = dy @ W if ctx.needs_input_grad[0] else None
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        elif W.shape[0] == 1:
+            dx = dy * W  # one output: an outer product (bitwise what the K = 1 GEMM gives), no library call
+        else:
+            dx = dy @ W
         dW = db = None
         if ctx.needs_input_grad[1]:
             dyc, xc = dy.contiguous(), x.contiguous()
@@ -610,6 +616,17 @@ def warn_atomic_fallback(what, entries, limit):
                   "bitwise repeatable between runs", RuntimeWarning, stacklevel=3)
 
 
+_scratch_bufs = {}
+
+
+def _scratch(key, device, nbytes):
+    """Uninitialised device scratch of at least `nbytes`, one buffer per key (kept for the process's life)."""
+    buf = _scratch_bufs.get((device, key))
+    if buf is None or buf.numel() < nbytes:
+        buf = _scratch_bufs[(device, key)] = torch.empty(int(nbytes) + 16, dtype=torch.uint8, device=device)
+    return buf
+
+
 class SegmentPoolFn(torch.autograd.Function):
     """out[b] = reduce over the non-padding nodes of pos[b] of emb[node]  (sum|mean|max|size)."""
     @staticmethod
@@ -624,6 +641,13 @@ class SegmentPoolFn(torch.autograd.Function):
         n, C = emb.shape
         B, Smax = pos.shape
         out = torch.empty((B, C), dtype=torch.float32, device=emb.device)
+        if Smax == 2 and mode != "max":  # node pairs (link-prediction batches): lane groups per pair, not a workgroup
+            rc = _lib.load().glass_pair_pool_f32(emb.data_ptr(), lde, pos.data_ptr(), B, POOL_MODES[mode], out.data_ptr(), C,
+                                                 n, C, _stream())
+            _lib.check(rc, "glass_pair_pool_f32")
+            ctx.save_for_backward(pos, None)
+            ctx.cfg = (mode, n, C)
+            return out
         argmax = torch.empty((B, C), dtype=torch.int32, device=emb.device) if mode == "max" else None
         rc = _lib.load().glass_segment_pool_f32(emb.data_ptr(), lde, pos.data_ptr(), B, Smax, POOL_MODES[mode],
                                                 out.data_ptr(), C, 0 if argmax is None else argmax.data_ptr(), n, C,
@@ -639,6 +663,14 @@ class SegmentPoolFn(torch.autograd.Function):
         mode, n, C = ctx.cfg
         dout, ldd = _rows(dout)
         B, Smax = pos.shape
+        if Smax == 2 and mode != "max":  # exact, atomic-free backward; writes every row
+            lib = _lib.load()
+            demb = torch.empty((n, C), dtype=torch.float32, device=dout.device)
+            ws = _scratch(("pair_pool", n, B), dout.device, lib.glass_pair_pool_ws_bytes(n, B))
+            rc = lib.glass_pair_pool_bwd_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, POOL_MODES[mode], demb.data_ptr(), C, n,
+                                             C, ws.data_ptr(), _stream())
+            _lib.check(rc, "glass_pair_pool_bwd_f32")
+            return demb, None, None
         if mode == "max" or B * Smax > POOL_ORDERED_MAX:
             warn_atomic_fallback("segment pool backward", B * Smax, POOL_ORDERED_MAX)
         demb = torch.zeros((n, C), dtype=torch.float32, device=dout.device)

@@ -243,6 +243,19 @@ int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* po
                                const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C,
                                void* stream);
 
+/* Node pairs (Smax = 2; sum | mean | size): the link-prediction batches of the pre-training path — replaces
+ * emb[subG_node] + torch.mean(emb, dim=1) (impl/models.py:497-498, 501-503; 131 072 pairs per step, GNNEmb.py).  Same
+ * values as glass_segment_pool_f32 on a [B, 2] matrix (a -1 entry is padding).  The backward writes EVERY row of demb (no
+ * zero-fill needed) and uses no float atomic: entries are bucketed by node (integer counts, a scan, integer cursors) and
+ * a node's row is the sum of its entries' scaled gradient rows taken in exact fixed point (two 64-bit integers per
+ * column), so the result does not depend on the order of the lists -> bitwise repeatable.  `ws`: glass_pair_pool_ws_bytes
+ * bytes of scratch (need not be initialised). */
+int64_t glass_pair_pool_ws_bytes(int64_t n_nodes, int64_t B);
+int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t* pairs, int64_t B, int mode, float* out, int64_t ldo,
+                        int64_t n_nodes, int64_t C, void* stream);
+int glass_pair_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pairs, int64_t B, int mode, float* demb,
+                            int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * K5w weight / bias gradient of the stacked Linears   (autograd backward of nn.Linear at
  *     impl/models.py:158-159,169-170 — the measured dominant dense contraction of the step)

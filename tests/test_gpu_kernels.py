@@ -288,6 +288,64 @@ def test_pool_ragged(mode, C):
     assert rel_inf(eg.grad.cpu(), ec.grad) < 1e-6
 
 
+@pytest.mark.parametrize("mode", ["sum", "mean", "size"])
+@pytest.mark.parametrize("C", [64, 20, 17, 320])
+def test_pair_pool(mode, C):
+    """Node pairs (the pre-training path's link batches): lane-group kernels; the backward is bucketed by node and summed in
+    exact fixed point — no float atomic, bitwise repeatable; padding entries, a hub node whose list the whole workgroup sums,
+    nodes no pair names (zero rows), a wider (strided) embedding buffer."""
+    from glass_amd import ops
+    n, B = 3000, 20000
+    rng = np.random.default_rng(C)
+    pairs = rng.integers(0, n - 50, size=(B, 2))   # the last 50 nodes are named by no pair
+    pairs[::7, 0] = 11                              # hub: ~2900 entries
+    pairs[5, 1] = -1                                # one-sided pair
+    pairs[6, :] = -1                                # empty pair -> 0
+    wide = torch.randn(n, C + 4, generator=torch.Generator().manual_seed(C))
+    gout = torch.randn(B, C, generator=torch.Generator().manual_seed(C + 1))
+    post = torch.from_numpy(pairs)
+    ec = wide[:, :C].double().requires_grad_(True)
+    batch, p = O.pad_to_batch(post)
+    ref = O.segment_pool(ec[p], batch, B, mode)
+    ref.backward(gout.double())
+    wg = wide.to(DEV)
+    eg = wg[:, :C].requires_grad_(True)
+    y = ops.segment_pool(eg, post.to(DEV), mode)
+    y.backward(gout.to(DEV))
+    assert rel_inf(y.detach().cpu(), ref.detach()) < 1e-6
+    assert float(y[6].abs().max()) == 0.0
+    assert rel_inf(eg.grad.cpu(), ec.grad) < 1e-6
+    assert float(eg.grad[n - 50:].abs().max()) == 0.0
+    g1 = eg.grad.clone()
+    eg.grad = None
+    ops.segment_pool(eg, post.to(DEV), mode).backward(gout.to(DEV))
+    assert torch.equal(g1, eg.grad)
+
+
+@pytest.mark.parametrize("N,O,I", [(131072, 1, 64), (5000, 2, 20), (77, 3, 256), (100000, 1, 320)])
+def test_linear_wgrad_thin_outputs(N, O, I):
+    """Weight / bias gradient of a Linear with 1-3 outputs (the pre-training head's hidden -> 1 layer) on the thin kernels
+    instead of a library GEMM: vs fp64, accumulate mode, repeatable."""
+    from glass_amd import ops
+    gen = torch.Generator().manual_seed(N + O)
+    G = torch.randn(N, O, generator=gen)
+    X = torch.randn(N, I, generator=gen)
+    Gg, Xg = G.to(DEV), X.to(DEV)
+    ref_w, ref_b = G.double().t() @ X.double(), G.double().sum(0)
+    dW, db = torch.full((O, I), 3.0, device=DEV), torch.full((O, ), -2.0, device=DEV)
+    assert ops.linear_wgrad(Gg, Xg, dW, db, False)
+    assert rel_inf(dW.cpu(), ref_w) < TOL and rel_inf(db.cpu(), ref_b) < TOL
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    ops.linear_wgrad(Gg, Xg, dW2, db2, False)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    ops.linear_wgrad(Gg, Xg, dW2, db2, True)
+    assert rel_inf(dW2.cpu(), 2 * ref_w) < TOL and rel_inf(db2.cpu(), 2 * ref_b) < TOL
+    lin = torch.nn.Linear(I, O).to(DEV)
+    xg = Xg.clone().requires_grad_(True)
+    ops.linear(xg, lin).backward(Gg)
+    assert rel_inf(lin.weight.grad.cpu(), ref_w) < TOL and rel_inf(xg.grad.cpu(), G.double() @ lin.weight.detach().cpu().double()) < TOL
+
+
 def test_pool_unknown_mode_raises():
     from glass_amd import ops
     with pytest.raises(NotImplementedError):
