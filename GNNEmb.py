@@ -43,6 +43,56 @@ def parse_args(argv=None):
     return p.parse_args(argv)
 
 
+class GraphedPairStep:
+    """Forward + backward of one link batch, replayed from a hipGraph once a batch shape has been seen.
+
+    The pre-training step is ~95 short launches (0.8 ms of kernel time at ppi_bp-shape, tools/ssl_step.py) that an eager
+    loop enqueues in ~1.8 ms: host-bound.  Every kernel of libglass_hip only enqueues work on the caller's stream, so the
+    per-op autograd path captures as it is (the way impl.train's TrainStep does for the GLASS step).  A shape's first batch
+    runs eagerly (it builds the CSR / plans / scratch buffers), the second one is captured, later ones copy the batch into
+    the graph's static buffers and replay.  The optimizer (and the reference's per-batch plateau scheduler, which needs the
+    loss on the host) stay outside the graph.  GLASS_SSL_GRAPH=0 keeps the eager loop."""
+    def __init__(self, model, loss_fn, x, edge_index, edge_attr):
+        self.model, self.loss_fn = model, loss_fn
+        self.x, self.ei, self.ea = x, edge_index, edge_attr
+        self.seen, self.graphs = set(), {}
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.enabled = os.environ.get("GLASS_SSL_GRAPH", "1") != "0"
+
+    def _fwd_bwd(self, pairs, target):
+        emb = self.model.NodeEmb(self.x, self.ei, self.ea)
+        loss = self.loss_fn(self.model.preds[0](self.model.Pool(emb, pairs, None)), target)
+        loss.backward()
+        return loss.detach()
+
+    def __call__(self, pairs, target):
+        """Leaves the batch's gradients in .grad of every parameter and returns the loss (a 0-d device tensor)."""
+        key = (tuple(pairs.shape), tuple(target.shape), target.dtype)
+        ent = self.graphs.get(key)
+        if ent is None and not (self.enabled and key in self.seen):
+            self.seen.add(key)
+            for p in self.params:
+                p.grad = None
+            return self._fwd_bwd(pairs, target)
+        if ent is None:
+            s_pairs, s_target = pairs.clone(), target.clone()
+            for p in self.params:
+                p.grad = None
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            loss = torch.zeros((), device=pairs.device)  # caller-owned: outside the graph's private pool
+            with torch.cuda.graph(g):
+                loss.copy_(self._fwd_bwd(s_pairs, s_target))
+            ent = self.graphs[key] = (g, s_pairs, s_target, loss, [p.grad for p in self.params])
+        g, s_pairs, s_target, loss, grads = ent
+        s_pairs.copy_(pairs)
+        s_target.copy_(target)
+        g.replay()
+        for p, gr in zip(self.params, grads):  # (an eager batch of another shape in between re-pointed .grad)
+            p.grad = gr
+        return loss
+
+
 class Pretrain:
     def __init__(self, args):
         self.args = args
@@ -79,13 +129,13 @@ class Pretrain:
         """At most `max_batches` link-prediction batches (the whole graph is re-embedded for each); the plateau scheduler
         is stepped per batch, before the optimizer.  Returns the mean batch loss."""
         model.train()
+        step = model.__dict__.get("_pair_step")
+        if step is None:
+            step = model.__dict__["_pair_step"] = GraphedPairStep(model, loss_fn, self.trn.x, self.trn.edge_index,
+                                                                  self.trn.edge_attr)
         seen = []
         for batch in itertools.islice(loader, max_batches):
-            pairs, target = batch[-2], batch[-1]
-            optimizer.zero_grad()
-            emb = model.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr)
-            loss = loss_fn(model.preds[0](model.Pool(emb, pairs, None)), target)
-            loss.backward()
+            loss = step(batch[-2], batch[-1])
             scheduler.step(loss)
             seen.append(loss.item())
             optimizer.step()

@@ -368,6 +368,50 @@ def test_pretraining_driver_learns_links(tmp_path, capsys):
     assert score > 0.6  # binary F1 on a balanced edge / non-edge set: well above the 0.5 of an untrained model
 
 
+def test_pretraining_graphed_step_matches_eager_step():
+    """GNNEmb.GraphedPairStep: the link-prediction forward + backward replayed from a hipGraph (third batch of a shape
+    onwards) leaves the gradients and loss of the eager step — dropout 0, same batches; a batch of another shape in between
+    runs eagerly and does not disturb the captured one."""
+    import functools
+    import GNNEmb
+    from impl import models
+    from glass_amd import synth
+    w, ei, ew, x, _pos, _y = synth.make_workload("tiny", seed=2, n_batches=1)
+    ei, ew, x = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x))
+    rng = np.random.default_rng(5)
+    h = 64
+
+    def build():
+        torch.manual_seed(3)
+        conv = models.EmbGConv(h, h, h, 2, max_deg=int(x.max()), activation=nn.ReLU(inplace=True), jk=False, dropout=0.0,
+                               conv=functools.partial(models.MyGCNConv, aggr="mean"), gn=True)
+        head = models.MLP(h, h, 1, 2, dropout=0.0, activation=nn.ReLU(inplace=True))
+        return models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()])).to(DEV).train()
+
+    def loss_fn(pred, t):
+        return nn.BCEWithLogitsLoss()(pred.flatten(), t.flatten())
+
+    batches = []
+    for k in range(6):
+        nb = 333 if k == 3 else 2048
+        batches.append((torch.from_numpy(rng.integers(0, w.n_node, size=(nb, 2))).to(DEV),
+                        torch.from_numpy(rng.integers(0, 2, size=nb).astype(np.float32)).to(DEV)))
+    runs = []
+    for graph in (False, True):
+        model = build()
+        step = GNNEmb.GraphedPairStep(model, loss_fn, x, ei, ew)
+        step.enabled = graph
+        opt = torch.optim.SGD(model.parameters(), lr=0.05)
+        losses = []
+        for pairs, target in batches:
+            losses.append(float(step(pairs, target)))
+            opt.step()
+        assert bool(step.graphs) == graph
+        runs.append((losses, torch.cat([p.detach().flatten() for p in model.parameters()]).cpu()))
+    assert runs[0][0] == pytest.approx(runs[1][0], rel=1e-6)
+    assert rel_inf(runs[1][1], runs[0][1]) < 1e-6
+
+
 def test_train_epoch_graph_path_matches_eager_path():
     """impl.train.train replays the step from a hipGraph when the epoch is graph-safe (FlatAdam, ZGDataloader with
     MaxZOZ, drop_last).  The state-preserving warm-up must leave the trajectory untouched: epoch losses and final

@@ -1,6 +1,7 @@
 """Link-prediction pre-training step (GNNEmb.py's inner loop) at a bench workload's graph shape: time per step and, under
 rocprofv3 --kernel-trace --stats, the kernel table of the SSL path (EdgeGNN = EmbGConv(MyGCNConv) + pair mean pool + MLP).
-    python tools/ssl_step.py [workload] [steps] [conv_layers] [dropout] [pairs]
+    python tools/ssl_step.py [workload] [steps] [conv_layers] [dropout] [pairs] [eager|graph]
+"graph": the step as GNNEmb.py runs it (GraphedPairStep: forward + backward replayed from a hipGraph, optimizer eager).
 The pairs are random node pairs (the reference's batch: 131072 edge / non-edge pairs, GNNEmb.py:144)."""
 import functools
 import os
@@ -36,13 +37,23 @@ def main():
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     loss_fn = nn.BCEWithLogitsLoss()
 
-    def step():
-        opt.zero_grad()
-        emb = model.NodeEmb(x, ei, ew)
-        loss = loss_fn(model.preds[0](model.Pool(emb, pairs, None)).flatten(), target)
-        loss.backward()
-        opt.step()
-        return loss
+    mode = sys.argv[6] if len(sys.argv) > 6 else "eager"
+    if mode == "graph":
+        import GNNEmb
+        graphed = GNNEmb.GraphedPairStep(model, lambda pred, t: loss_fn(pred.flatten(), t), x, ei, ew)
+
+        def step():
+            loss = graphed(pairs, target)
+            opt.step()
+            return loss
+    else:
+        def step():
+            opt.zero_grad()
+            emb = model.NodeEmb(x, ei, ew)
+            loss = loss_fn(model.preds[0](model.Pool(emb, pairs, None)).flatten(), target)
+            loss.backward()
+            opt.step()
+            return loss
 
     for _ in range(5):
         step()
@@ -52,7 +63,7 @@ def main():
         loss = step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print(f"ssl_step {name}: N={w.n_node} H={h} layers={layers} dropout={dropout} pairs={n_pairs}: {dt * 1e3:.3f} ms/step (eager), "
+    print(f"ssl_step {name}: N={w.n_node} H={h} layers={layers} dropout={dropout} pairs={n_pairs}: {dt * 1e3:.3f} ms/step ({mode}), "
           f"loss {loss.item():.5f}")
 
 
