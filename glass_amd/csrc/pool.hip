@@ -298,14 +298,36 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(int32_t* __restrict__ o
     }
 }
 
-// list[off[node] + rank] = (pair << 1) | (both entries of the pair valid): what the gather needs without reading pairs
-__global__ __launch_bounds__(kBlock) void pair_fill_kernel(const int64_t* __restrict__ pairs, int64_t n_entries,
+// list[off[node] + rank] = (pair << 1) | (both entries of the pair valid): what the gather needs without reading pairs.
+// Subgraphs of any padded width (Smax != 2): the entry's subgraph index; its scale comes from the scale array.
+__global__ __launch_bounds__(kBlock) void pair_fill_kernel(const int64_t* __restrict__ pairs, int64_t n_entries, int Smax,
                                                            int64_t n_nodes, const int32_t* __restrict__ off,
                                                            const int32_t* __restrict__ rank, int32_t* __restrict__ list) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_entries) return;
-    const int64_t node = pairs[e], other = pairs[e ^ 1];
-    if (node >= 0 && node < n_nodes) list[off[node] + rank[e]] = (int32_t)((e >> 1) << 1) | (int32_t)(other >= 0 && other < n_nodes);
+    const int64_t node = pairs[e];
+    if (node < 0 || node >= n_nodes) return;
+    if (Smax == 2) {
+        const int64_t other = pairs[e ^ 1];
+        list[off[node] + rank[e]] = (int32_t)((e >> 1) << 1) | (int32_t)(other >= 0 && other < n_nodes);
+    } else {
+        list[off[node] + rank[e]] = (int32_t)(e / Smax);
+    }
+}
+
+// scale[b] of every subgraph (one wave per padded row)
+__global__ __launch_bounds__(kBlock) void pool_scale_kernel(const int64_t* __restrict__ pos, int B, int Smax, int mode,
+                                                            int64_t n_nodes, float* __restrict__ scale) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t* prow = pos + (int64_t)b * Smax;
+    int cnt = 0;
+    for (int j0 = 0; j0 < Smax; j0 += kWave) {
+        const int j = j0 + lane;
+        cnt += __popcll(__ballot(j < Smax && prow[j] >= 0 && prow[j] < n_nodes));
+    }
+    if (lane == 0) scale[b] = pool_scale(mode, cnt);
 }
 
 struct ExactSum {
@@ -326,7 +348,7 @@ constexpr int kPairLongList = 64;  // entries from which a node's list is summed
 
 template <int VW>
 __global__ __launch_bounds__(kBlock) void pair_gather_kernel(const float* __restrict__ dout, int64_t ldd,
-                                                             int mode,
+                                                             int mode, const float* __restrict__ scale,
                                                              const int32_t* __restrict__ off, const int32_t* __restrict__ list,
                                                              float* __restrict__ demb, int64_t lde, int64_t n_nodes, int C,
                                                              int g_log2) {
@@ -336,8 +358,9 @@ __global__ __launch_bounds__(kBlock) void pair_gather_kernel(const float* __rest
     const float sc1 = pool_scale(mode, 1), sc2 = pool_scale(mode, 2);
     auto scaled_row = [&](int e, int c0, float (&v)[VW]) __attribute__((always_inline)) {
         P<VW> g;
-        g.load(dout + (int64_t)(e >> 1) * ldd + c0);
-        const float sc = (e & 1) ? sc2 : sc1;
+        const int b = scale ? e : (e >> 1);  // (workgroup-uniform choice: pairs carry their count in bit 0)
+        g.load(dout + (int64_t)b * ldd + c0);
+        const float sc = scale ? scale[b] : ((e & 1) ? sc2 : sc1);
 #pragma unroll
         for (int k = 0; k < VW; ++k) v[k] = g.a[k] * sc;
     };
@@ -498,9 +521,19 @@ static int pair_group_log2(int64_t C, bool vec) {
     return l;
 }
 
+static int64_t bucketed_ws_words(int64_t n_nodes, int64_t B, int64_t Smax) {
+    // off [n_nodes + 1, padded to 4] | rank [E] | list [E] | scale [B] (Smax != 2)
+    return ((n_nodes + 1 + 3) & ~(int64_t)3) + 2 * B * Smax + (Smax == 2 ? 0 : B);
+}
+
 extern "C" int64_t glass_pair_pool_ws_bytes(int64_t n_nodes, int64_t B) {
     if (n_nodes <= 0 || B <= 0) return 0;
-    return (int64_t)sizeof(int32_t) * (((n_nodes + 1 + 3) & ~(int64_t)3) + 4 * B);
+    return (int64_t)sizeof(int32_t) * bucketed_ws_words(n_nodes, B, 2);
+}
+
+extern "C" int64_t glass_segment_pool_bwd_exact_ws_bytes(int64_t n_nodes, int64_t B, int64_t Smax) {
+    if (n_nodes <= 0 || B <= 0 || Smax <= 0) return 0;
+    return (int64_t)sizeof(int32_t) * bucketed_ws_words(n_nodes, B, Smax);
 }
 
 extern "C" int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t* pairs, int64_t B, int mode, float* out,
@@ -521,29 +554,46 @@ extern "C" int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t*
     return launch_status("glass_pair_pool_f32");
 }
 
-extern "C" int glass_pair_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pairs, int64_t B, int mode, float* demb,
-                                       int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream) {
-    int rc = pool_args_ok(dout, pairs, demb, B, 2, mode, C, ldd, lde);
+// sum | mean | size backward of a padded node matrix of any width, bucketed by node, exact sums (see pair_gather_kernel)
+static int bucketed_pool_bwd(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode, float* demb,
+                             int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream, const char* what) {
+    int rc = pool_args_ok(dout, pos, demb, B, Smax, mode, C, ldd, lde);
     if (rc) return rc;
-    GLASS_REQUIRE(mode != GLASS_POOL_MAX && ws && aligned16(ws) && n_nodes > 0 && 2 * B < (1ll << 30) && n_nodes < (1ll << 31),
-                  "pair_pool_bwd: sum | mean | size only, 16-B aligned workspace, fewer than 2^30 entries and 2^31 nodes");
+    GLASS_REQUIRE(mode != GLASS_POOL_MAX && ws && aligned16(ws) && n_nodes > 0 && B * Smax < (1ll << 30) && n_nodes < (1ll << 31),
+                  "pool backward (exact): sum | mean | size only, 16-B aligned workspace, fewer than 2^30 entries and 2^31 nodes");
     const bool vec = C % 4 == 0 && ldd % 4 == 0 && lde % 4 == 0 && aligned16(dout) && aligned16(demb);
     const int gl = pair_group_log2(C, vec);
     hipStream_t st = (hipStream_t)stream;
-    int32_t* off = (int32_t*)ws;  // [n_nodes + 1], then rank [2B] and list [2B]
+    const int64_t E = B * Smax;
+    int32_t* off = (int32_t*)ws;
     int32_t* rank = off + ((n_nodes + 1 + 3) & ~(int64_t)3);
-    int32_t* list = rank + 2 * B;
-    const unsigned ge = (unsigned)ceil_div(2 * B, (int64_t)kBlock);
+    int32_t* list = rank + E;
+    float* scale = Smax == 2 ? nullptr : reinterpret_cast<float*>(list + E);
+    const unsigned ge = (unsigned)ceil_div(E, (int64_t)kBlock);
     hipLaunchKernelGGL(pair_zero_kernel, dim3((unsigned)ceil_div(n_nodes + 1, (int64_t)kBlock)), dim3(kBlock), 0, st, off, n_nodes + 1);
-    hipLaunchKernelGGL(pair_rank_kernel, dim3(ge), dim3(kBlock), 0, st, pairs, 2 * B, n_nodes, off, rank);
+    if (scale)
+        hipLaunchKernelGGL(pool_scale_kernel, dim3((unsigned)ceil_div(B, (int64_t)(kBlock / kWave))), dim3(kBlock), 0, st, pos, (int)B,
+                           (int)Smax, mode, n_nodes, scale);
+    hipLaunchKernelGGL(pair_rank_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, n_nodes, off, rank);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, st, off, n_nodes + 1);
-    hipLaunchKernelGGL(pair_fill_kernel, dim3(ge), dim3(kBlock), 0, st, pairs, 2 * B, n_nodes, off, rank, list);
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, (int)Smax, n_nodes, off, rank, list);
     const unsigned gg = (unsigned)ceil_div(n_nodes, (int64_t)(kBlock >> gl));
     if (vec)
-        hipLaunchKernelGGL(pair_gather_kernel<4>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, mode, off, list, demb, lde,
+        hipLaunchKernelGGL(pair_gather_kernel<4>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, mode, scale, off, list, demb, lde,
                            n_nodes, (int)C, gl);
     else
-        hipLaunchKernelGGL(pair_gather_kernel<1>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, mode, off, list, demb, lde,
+        hipLaunchKernelGGL(pair_gather_kernel<1>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, mode, scale, off, list, demb, lde,
                            n_nodes, (int)C, gl);
-    return launch_status("glass_pair_pool_bwd_f32");
+    return launch_status(what);
+}
+
+extern "C" int glass_pair_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pairs, int64_t B, int mode, float* demb,
+                                       int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream) {
+    return bucketed_pool_bwd(dout, ldd, pairs, B, 2, mode, demb, lde, n_nodes, C, ws, stream, "glass_pair_pool_bwd_f32");
+}
+
+extern "C" int glass_segment_pool_bwd_exact_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax,
+                                                int mode, float* demb, int64_t lde, int64_t n_nodes, int64_t C, void* ws,
+                                                void* stream) {
+    return bucketed_pool_bwd(dout, ldd, pos, B, Smax, mode, demb, lde, n_nodes, C, ws, stream, "glass_segment_pool_bwd_exact_f32");
 }

@@ -600,8 +600,10 @@ def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id
 # K7  subgraph pooling
 # ---------------------------------------------------------------------------------------------
 # Largest padded node matrices (B * Smax entries) the ORDERED, atomic-free scatters stage in LDS (pool.hip kPoolOrderedMax,
-# readout.hip kReadoutOrderedMax).  Beyond them — and for max pooling — the library falls back to float atomics: same
-# values within rounding, but no longer bitwise repeatable from run to run.  Said once, loudly, instead of silently.
+# readout.hip kReadoutOrderedMax).  Beyond them the pool backward buckets the entries by node and sums in exact fixed point
+# (glass_segment_pool_bwd_exact_f32: still no float atomic); the fused readout beyond its limit — and max pooling — falls
+# back to float atomics: same values within rounding, but no longer bitwise repeatable from run to run.  Said once,
+# loudly, instead of silently.
 POOL_ORDERED_MAX, READOUT_ORDERED_MAX = 12288, 16384
 _atomic_warned = set()
 
@@ -671,7 +673,15 @@ class SegmentPoolFn(torch.autograd.Function):
                                              C, ws.data_ptr(), _stream())
             _lib.check(rc, "glass_pair_pool_bwd_f32")
             return demb, None, None
-        if mode == "max" or B * Smax > POOL_ORDERED_MAX:
+        if mode != "max" and B * Smax + B > POOL_ORDERED_MAX:  # beyond the LDS staging: bucketed by node, exact sums (no float atomics)
+            lib = _lib.load()
+            demb = torch.empty((n, C), dtype=torch.float32, device=dout.device)
+            ws = _scratch(("pool_exact", n, B, Smax), dout.device, lib.glass_segment_pool_bwd_exact_ws_bytes(n, B, Smax))
+            rc = lib.glass_segment_pool_bwd_exact_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, Smax, POOL_MODES[mode],
+                                                      demb.data_ptr(), C, n, C, ws.data_ptr(), _stream())
+            _lib.check(rc, "glass_segment_pool_bwd_exact_f32")
+            return demb, None, None
+        if mode == "max":
             warn_atomic_fallback("segment pool backward", B * Smax, POOL_ORDERED_MAX)
         demb = torch.zeros((n, C), dtype=torch.float32, device=dout.device)
         rc = _lib.load().glass_segment_pool_bwd_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, Smax, POOL_MODES[mode],

@@ -235,7 +235,7 @@ int glass_embed_norm_bwd_adam_f32(float* G, const float* W, int64_t V, const int
  *     Backward scatters into demb (must be ZEROED by the caller).  sum / mean / size with B*Smax + B <= 12 288:
  *     ordered and atomic-free (pos staged in LDS; the first entry naming a node sums all its occurrences in
  *     (b, s) order) -> bitwise repeatable.  Larger batches and max pooling: float atomics, order-dependent only
- *     beyond two sharers of a node.
+ *     beyond two sharers of a node (for sum / mean / size use glass_segment_pool_bwd_exact_f32 below instead).
  * ---------------------------------------------------------------------------------------- */
 int glass_segment_pool_f32(const float* emb, int64_t lde, const int64_t* pos, int64_t B, int64_t Smax, int mode,
                            float* out, int64_t ldo, int32_t* argmax, int64_t n_nodes, int64_t C, void* stream);
@@ -250,6 +250,12 @@ int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* po
  * a node's row is the sum of its entries' scaled gradient rows taken in exact fixed point (two 64-bit integers per
  * column), so the result does not depend on the order of the lists -> bitwise repeatable.  `ws`: glass_pair_pool_ws_bytes
  * bytes of scratch (need not be initialised). */
+/* The same backward for a padded node matrix of ANY width (sum | mean | size): what glass_segment_pool_bwd_f32 computes,
+ * without its LDS staging limit (12 288 entries) and without float atomics beyond it — five small launches instead of
+ * one, every row of demb written, bitwise repeatable.  `ws`: glass_segment_pool_bwd_exact_ws_bytes bytes. */
+int64_t glass_segment_pool_bwd_exact_ws_bytes(int64_t n_nodes, int64_t B, int64_t Smax);
+int glass_segment_pool_bwd_exact_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode,
+                                     float* demb, int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream);
 int64_t glass_pair_pool_ws_bytes(int64_t n_nodes, int64_t B);
 int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t* pairs, int64_t B, int mode, float* out, int64_t ldo,
                         int64_t n_nodes, int64_t C, void* stream);

@@ -289,6 +289,40 @@ def test_pool_ragged(mode, C):
 
 
 @pytest.mark.parametrize("mode", ["sum", "mean", "size"])
+@pytest.mark.parametrize("C", [64, 17])
+def test_pool_backward_beyond_lds_staging_is_exact_and_repeatable(mode, C):
+    """Padded node matrices beyond the ordered scatter's LDS staging (12 288 entries): the backward buckets the entries by
+    node and sums in exact fixed point instead of falling back to float atomics — vs fp64, bitwise repeatable, a node
+    shared by every subgraph (its list is summed by the whole workgroup), an all-padding row, no warning."""
+    import warnings
+    from glass_amd import ops
+    n, B, S = 4000, 500, 37
+    rng = np.random.default_rng(C + 7)
+    pos = np.full((B, S), -1, dtype=np.int64)
+    for b in range(B):
+        k = rng.integers(1, S)
+        pos[b, :k] = rng.choice(n - 100, k, replace=False) + 1
+        pos[b, k] = 0      # node 0 sits in every subgraph
+    pos[3, :] = -1
+    emb = torch.randn(n, C, generator=torch.Generator().manual_seed(C))
+    gout = torch.randn(B, C, generator=torch.Generator().manual_seed(C + 1))
+    post = torch.from_numpy(pos)
+    ec = emb.double().requires_grad_(True)
+    batch, p = O.pad_to_batch(post)
+    O.segment_pool(ec[p], batch, B, mode).backward(gout.double())
+    eg = emb.to(DEV).requires_grad_(True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ops.segment_pool(eg, post.to(DEV), mode).backward(gout.to(DEV))
+    assert rel_inf(eg.grad.cpu(), ec.grad) < 1e-6
+    assert float(eg.grad[n - 99:].abs().max()) == 0.0
+    g1 = eg.grad.clone()
+    eg.grad = None
+    ops.segment_pool(eg, post.to(DEV), mode).backward(gout.to(DEV))
+    assert torch.equal(g1, eg.grad)
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean", "size"])
 @pytest.mark.parametrize("C", [64, 20, 17, 320])
 def test_pair_pool(mode, C):
     """Node pairs (the pre-training path's link batches): lane-group kernels; the backward is bucketed by node and summed in
