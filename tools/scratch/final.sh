@@ -1,0 +1,22 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+R=r03
+out=gpurun_out/final
+rm -rf $out; mkdir -p $out
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c2 -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm --no-pmc > $out/${R}_bench_ppi_bp_bench_line.json 2> $out/c2.err
+cp $(ls $out/c2/*/*kernel_stats.csv | head -1) $out/${R}_bench_ppi_bp_kernel_stats.csv
+python3 tools/prof_summary.py $out/c2 24 | cut -c1-70,88-140
+rm -rf $out/c2
+for w in density hpo_neuro em_user; do
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/$w -- python3 bench.py --workload $w --steps 200 --warmup 20 --no-cpu-baseline --no-roofline-hbm --no-pmc > $out/${R}_bench_${w}_bench_line.json 2> $out/$w.err
+  cp $(ls $out/$w/*/*kernel_stats.csv | head -1) $out/${R}_bench_${w}_kernel_stats.csv
+  echo "== $w"; python3 tools/prof_summary.py $out/$w 3 | cut -c1-70,88-140
+  rm -rf $out/$w
+done
+bash tools/prof_ssl.sh $R > $out/ssl.log 2>&1; head -3 gpurun_out/${R}_ssl_step.txt
+mv gpurun_out/${R}_ssl_step* $out/
+timeout 300 python3 tools/ssl_step.py ppi_bp 100 2 0.5 131072 graph >> $out/${R}_ssl_step.txt; tail -1 $out/${R}_ssl_step.txt
+timeout 900 python3 bench.py > $out/${R}_bench_ppi_bp_default_bench_line.json 2> $out/default.err; echo "default rc=$?"; cut -c1-400 $out/${R}_bench_ppi_bp_default_bench_line.json
+timeout 900 python3 bench.py --workload em_user > $out/${R}_bench_em_user_default_bench_line.json 2> $out/default_em.err; echo "em_user default rc=$?"; cut -c1-300 $out/${R}_bench_em_user_default_bench_line.json
+timeout 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+du -sh $out
