@@ -2138,7 +2138,7 @@ extern "C" int64_t glass_gn_exact_words(int64_t C) { return gn_acc_words(C); }  
 
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
 // glass_dual_linear_fwd_f32 with xa_index (the trans pair of layer 0 gathers its operand rows from the embedding table)
-extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return (wave16_shape_ok(H) || narrow_shape_ok(H)) ? 1 : 0; }
+extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return (wave16_shape_ok(H) || narrow_shape_ok(H) || tiled_here(H)) ? 1 : 0; }
 
 // Operand-image layout glass_dense_pack_batch_f32 must produce for hidden size H: 0 = wave16 images (forward and data
 // gradient alike), 1 = tiled (forward operand: paired layout; data-gradient operand: plain layout)
@@ -2178,8 +2178,8 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     GLASS_REQUIRE(!xa_index || (gn_saved && !xb && xa_rows > 0 && xa_rows < (1ll << 31)),
                   "dual_linear_fwd: a gathered operand needs the GraphNorm prologue (its side output is the gathered, "
                   "normalised [N,H] input) and is the trans pair's");
-    if (xa_index && !wave16_shape_ok(H) && !narrow_shape_ok(H)) {
-        set_error("dual_linear_fwd: gathered operand only at hidden 64 (glass_dual_linear_fwd_gather_supported)");
+    if (xa_index && !wave16_shape_ok(H) && !narrow_shape_ok(H) && !tiled_here(H)) {
+        set_error("dual_linear_fwd: gathered operand not served at this hidden size (glass_dual_linear_fwd_gather_supported)");
         return GLASS_E_UNSUPPORTED;
     }
     GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && (narrow_shape_ok(H) || (ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved))) &&
@@ -2208,8 +2208,12 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs > 1 pass and both fit)
     const size_t lds_comb = lds_bytes(2 * H, (int)(2 * H / 64)), lds_trans = lds_bytes(2 * H, (int)(H / 64));
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
-    if (tiled_here(H))
-        return launch_tiled_fwd(xa, lda, xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, H, stats, pro, st);
+    if (tiled_here(H)) {
+        GnPrologue tpro = pro;
+        tpro.gather = xa_index;
+        tpro.gather_rows = xa_rows;
+        return launch_tiled_fwd(xa, lda, xb, ldb, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, H, stats, tpro, st);
+    }
 #define GLASS_FWD(HH, CS, RW)                                                                                      \
     if (H == HH) {                                                                                                 \
         allow_lds(dual_fwd_kernel<HH, true, CS, RW>, lds_comb);                                                    \

@@ -32,6 +32,8 @@ struct GnPrologue {
     float* side;
     int64_t lds;
     GnExactSrc src;      // src.acc != nullptr: the statistics are still in exact accumulators (gn_acc.h), `saved` gets written
+    const int64_t* gather = nullptr;  // tiled forward (trans pair, layer 0): operand row n is row gather[n] of xa (the embedding table)
+    int64_t gather_rows = 0;          // rows of that table (indices are clamped into it)
 };
 
 // Optional epilogue of the data-gradient kernels: their first H output columns are the gradient dy of a GraphNorm

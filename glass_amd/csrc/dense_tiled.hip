@@ -144,6 +144,18 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
         skq[i] = f & 3;
         sok[i] = row0 + srow[i] < N;
     }
+    // operand rows of xa: the tile's own rows, or (trans pair of layer 0) the rows of the embedding table its nodes index —
+    // the lookup of input_emb fused into this load (reference impl/models.py:243-244); side output, dropout and statistics
+    // stay keyed by the node row
+    int64_t arow[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        arow[i] = row0 + srow[i];
+        if (!COMB && pro.gather && sok[i]) {
+            const int64_t g = pro.gather[arow[i]];
+            arow[i] = g < 0 ? 0 : (g >= pro.gather_rows ? pro.gather_rows - 1 : g);
+        }
+    }
     Drop drop = pro.drop;
     if (pro.saved && drop.p > 0.f) {
         drop.seed = pro.rng_state[0];
@@ -184,7 +196,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
         for (int i = 0; i < AP; ++i) {
             const int k = ks * kTK + 4 * skq[i];
             const int64_t r = row0 + srow[i];
-            const float* src = (!COMB || k < H) ? xa + r * lda + k : xb + r * ldb + (k - H);
+            const float* src = (!COMB || k < H) ? xa + (COMB ? r : arow[i]) * lda + k : xb + r * ldb + (k - H);
             av[i] = sok[i] ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
             if (pro.saved && (!COMB || k < H)) {
                 asc[i] = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + k);
