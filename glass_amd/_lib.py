@@ -114,6 +114,7 @@ SIGNATURES = {
     "glass_dual_linear_bwd_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, c_float, _P, c_uint64, _P, _I,
                                           _I, _I, _P, _P, _I, _P, _P, c_int, c_float, c_uint64, c_int, _P, _I, _P, _I, _P, _P]),
     "glass_gn_exact_supported": (c_int, [_I]),
+    "glass_gn_exact_fwd_supported": (c_int, [_I]),
     "glass_gn_exact_words": (c_int64, [_I]),
     "glass_graphnorm_stats_exact_f32": (c_int, [_P, _I, _I, _I, _P, c_int, _P]),
     "glass_graphnorm_bwd_from_stats_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P,

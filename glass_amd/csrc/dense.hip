@@ -2124,6 +2124,8 @@ extern "C" int glass_dense_trace_set(unsigned long long* p, int sel) {
 }
 #endif
 extern "C" int glass_gn_exact_supported(int64_t H) { return wave16_shape_ok(H) ? 1 : 0; }
+// ... the FORWARD sums alone (statistics kernel -> staged comb forward -> readout): also hidden 128
+extern "C" int glass_gn_exact_fwd_supported(int64_t H) { return (wave16_shape_ok(H) || (GLASS_COMB_FWD_V2 && H == 128)) ? 1 : 0; }
 // gn_src (the C-ABI struct) -> the kernels' form; saved = the [4C] buffer workgroup 0 writes.  NULL gn_src: final statistics.
 static bool rep_ok(int64_t n_rep) { return n_rep == 2 || n_rep == 4 || n_rep == 8 || n_rep == 16; }  // <= kAccRep, even
 static bool make_exact_src(const glass_gn_src* g, const float* saved, GnExactSrc& out) {
@@ -2444,7 +2446,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
         set_error("comb_eff_fwd: hidden size %lld not supported (64, 128)", (long long)H);
         return GLASS_E_UNSUPPORTED;
     }
-    GLASS_REQUIRE(H == 64 || !stats_exact, "comb_eff_fwd: exact GraphNorm accumulators are served at hidden 64 only");
+    GLASS_REQUIRE((!stats_exact && !gn_src) || glass_gn_exact_fwd_supported(H), "comb_eff_fwd: exact GraphNorm accumulators not served at this hidden size (glass_gn_exact_fwd_supported)");
     GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved) &&
                                 p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
                                 (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),

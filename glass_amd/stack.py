@@ -43,6 +43,7 @@ USE_GN_EXACT_FWD = os.environ.get("GLASS_GN_EXACT_FWD", "1") != "0"  # ... for t
 # above this many rows the partials + finalize form is kept: thousands of workgroups adding to the same few replicas would
 # queue at the memory-side atomic units, and a ~5 us finalize launch no longer shows against the kernels around it
 GN_EXACT_MAX_ROWS = 1 << 18
+GN_EXACT_FWD_ONLY_MAX_ROWS = 1 << 14  # the forward sums alone (hidden 128, one layer): see StackProgram.forward
 USE_FUSED_TAIL = os.environ.get("GLASS_FUSED_TAIL", "1") != "0"  # A/B switch: K1 slot sums + table backward + Adam as one launch
 USE_GATHER_IN_TRANS = os.environ.get("GLASS_GATHER_IN_TRANS", "1") != "0"  # A/B switch: embedding lookup inside layer 0's trans kernel
 USE_COMB_EFF = os.environ.get("GLASS_COMB_EFF", "1") != "0"  # A/B switch: comb pair through effective per-label weights
@@ -478,8 +479,18 @@ class StackProgram:
         # ... and for the forward sums when the fused readout applies the final GraphNorm: [L] blocks for conv.gn's sums of a_l,
         # then [L] for the sums of c_l (consecutive: the column blocks of the jumping-knowledge buffer)
         acc_all = acc_bwd = acc_fwd = acc_ro = None
-        if USE_GN_EXACT and lib.glass_gn_exact_supported(H) and n <= GN_EXACT_MAX_ROWS:
-            n_bwd = 2 * L - 1 if keep else 0
+        exact_all = USE_GN_EXACT and bool(lib.glass_gn_exact_supported(H)) and n <= GN_EXACT_MAX_ROWS
+        # the forward sums alone where every kernel that applies such a GraphNorm takes the pending form: the staged comb
+        # forward (conv.gn) and the readout (final GraphNorm) do at hidden 128 too, the tiled trans kernel (gns[l] between
+        # layers) does not — so: one layer, comb pair in effective-weight form
+        # (measured at hidden 128, one layer, with / without: 0.2552 / 0.2564 ms at N = 12 000, 0.3526 / 0.3491 at 20 000,
+        # 0.6272 / 0.6106 at 50 000 — every consumer workgroup folds 64 KB of replicas, which only pays while the launch is
+        # about one workgroup per CU: hence the row limit)
+        exact_fwd_only = (not exact_all and USE_GN_EXACT and n <= GN_EXACT_FWD_ONLY_MAX_ROWS and
+                          bool(lib.glass_gn_exact_fwd_supported(H)) and L == 1 and
+                          all(_comb_eff_fwd_ok(conv, labels, H) for conv in emb.convs))
+        if exact_all or exact_fwd_only:
+            n_bwd = 2 * L - 1 if (keep and exact_all) else 0
             n_fwd = 2 * L if (readout is not None and USE_GN_EXACT_FWD) else 0
             # ... and one block of L*H (jk) / H columns for the final GraphNorm's backward sums, added to by the readout's
             # first kernel and folded by its backfill launch (two launches instead of three)

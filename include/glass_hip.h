@@ -493,6 +493,8 @@ struct glass_gn_src {
     float eps;
 };
 int glass_gn_exact_supported(int64_t H);
+int glass_gn_exact_fwd_supported(int64_t H); /* the forward sums alone (glass_graphnorm_stats_exact_f32 -> glass_comb_eff_fwd_f32 ->
+                                                 glass_readout_train_f32): also hidden 128 */
 int64_t glass_gn_exact_words(int64_t C);
 int glass_graphnorm_stats_exact_f32(const float* x, int64_t ldx, int64_t n_rows, int64_t C, int64_t* acc, int n_rep,
                                     void* stream);

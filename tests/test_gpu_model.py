@@ -597,7 +597,10 @@ def test_stack_program_large_tables(V, n):
 @pytest.mark.parametrize("pool,multilabel,H,L", [("sum", False, 64, 2), ("mean", False, 64, 2), ("size", True, 64, 2),
                                                  # the shipped sets' own widths: component (17, one layer: a 17-column readout),
                                                  # coreness (20, two layers), density / cut_ratio (8)
-                                                 ("sum", False, 17, 1), ("mean", False, 20, 2), ("size", True, 8, 1)])
+                                                 ("sum", False, 17, 1), ("mean", False, 20, 2), ("size", True, 8, 1),
+                                                 # hidden 128: one layer takes the forward GraphNorm sums through exact accumulators
+                                                 # (statistics kernel -> staged comb forward -> readout), two layers do not
+                                                 ("size", False, 128, 1), ("sum", True, 128, 2)])
 def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel, H, L):
     """stack.loss_and_grads (no tape; final GraphNorm apply + pool + head + loss and their backward as K8r) against
     (a) the autograd path of the same model and (b) the fp64 oracle: loss, logits, every gradient.  The subgraphs
