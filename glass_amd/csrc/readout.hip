@@ -74,6 +74,7 @@ struct R1Args {
     int64_t n_nodes;
     int tc_log2;
     GnExactSrc src;  // src.acc: the final GraphNorm's forward sums are still in exact accumulators (gn_acc.h)
+    int stash;           // != 0: the padded row's node ids are staged in LDS (Smax ints behind the other arrays) by the counting pass
     long long* bwd_acc;  // != nullptr: the subgraph's share of the two backward column sums goes to exact accumulators
     int bwd_rep;         // (the backfill launch folds them: no reduce launch in between)
 };
@@ -117,7 +118,15 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
             if (c < C) wh_pre[u] = a.Wh[(int64_t)(tid >> 6) * C + c];
         }
     (void)TCp;
-    const int cnt = valid_count(prow, a.Smax, a.n_nodes);
+    int* ids = reinterpret_cast<int*>(dl + kReadoutMaxK);  // [Smax] node id or -1 (a.stash)
+    int cnt = 0;
+    for (int j0 = 0; j0 < a.Smax; j0 += kBlock) {  // (valid_count, keeping what it read)
+        const int j = j0 + tid;
+        const int64_t pj = j < a.Smax ? prow[j] : -1;
+        const bool okj = pj >= 0 && pj < a.n_nodes;
+        if (a.stash && j < a.Smax) ids[j] = okj ? (int)pj : -1;
+        cnt += __syncthreads_count(okj);
+    }
     // the final GraphNorm's coefficients: copied from `saved`, or derived here from the accumulators the comb kernels' epilogues
     // added to (workgroup 0 writes `saved` for the two launches behind this one)
     if (early)
@@ -141,21 +150,58 @@ __global__ __launch_bounds__(kBlock) void readout_subgraph_kernel(R1Args a) {
             shift[k] = coef_s[C + c0 + k];
             al[k] = a.alpha[c0 + k];
         }
-        int it = 0;
-        for (int j = tr; j < a.Smax; j += rpb, ++it) {
-            const int64_t node = it < 2 ? node_pre[it < 1 ? 0 : 1] : prow[j];
-            if (node < 0 || node >= a.n_nodes) continue;
-            float x[VW];
-            if (VW == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(a.jk + node * a.ldj + c0);
-                x[0] = v.x; x[VW > 1 ? 1 : 0] = v.y; x[VW > 2 ? 2 : 0] = v.z; x[VW > 3 ? 3 : 0] = v.w;
-            } else {
-                x[0] = a.jk[node * a.ldj + c0];
-            }
+        if (a.Smax <= 2 * rpb) {  // at most two entries per row slot: both were requested before the first barrier
+            int it = 0;
+            for (int j = tr; j < a.Smax; j += rpb, ++it) {
+                const int64_t node = node_pre[it < 1 ? 0 : 1];
+                if (node < 0 || node >= a.n_nodes) continue;
+                float x[VW];
+                if (VW == 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(a.jk + node * a.ldj + c0);
+                    x[0] = v.x; x[VW > 1 ? 1 : 0] = v.y; x[VW > 2 ? 2 : 0] = v.z; x[VW > 3 ? 3 : 0] = v.w;
+                } else {
+                    x[0] = a.jk[node * a.ldj + c0];
+                }
 #pragma unroll
-            for (int k = 0; k < VW; ++k) {
-                accy[k] += fmaf(x[k], scale[k], shift[k]);
-                acch[k] += (x[k] - al[k] * mu[k]) * rstd[k];
+                for (int k = 0; k < VW; ++k) {
+                    accy[k] += fmaf(x[k], scale[k], shift[k]);
+                    acch[k] += (x[k] - al[k] * mu[k]) * rstd[k];
+                }
+            }
+        } else {
+            // long subgraphs (em_user: 155 .. 499 nodes): a slot walks many entries, each a dependent pos -> row pair of round
+            // trips — four entries per round, ids first, then the four rows (unconditional loads: a padding entry reads row
+            // 0 and is dropped), added in the same (ascending j) order as the plain loop
+            constexpr int U = 4;
+            for (int j0 = tr; j0 < a.Smax; j0 += U * rpb) {
+                int64_t nd[U];
+                bool live[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int j = j0 + u * rpb;
+                    nd[u] = j >= a.Smax ? -1 : a.stash ? (int64_t)ids[j] : (j0 == tr && u < 2) ? node_pre[u] : prow[j];
+                }
+                float x[U][VW];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    live[u] = nd[u] >= 0 && nd[u] < a.n_nodes;
+                    const float* src = a.jk + (live[u] ? nd[u] : 0) * a.ldj + c0;
+                    if (VW == 4) {
+                        const float4 v = *reinterpret_cast<const float4*>(src);
+                        x[u][0] = v.x; x[u][VW > 1 ? 1 : 0] = v.y; x[u][VW > 2 ? 2 : 0] = v.z; x[u][VW > 3 ? 3 : 0] = v.w;
+                    } else {
+                        x[u][0] = src[0];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    if (!live[u]) continue;
+#pragma unroll
+                    for (int k = 0; k < VW; ++k) {
+                        accy[k] += fmaf(x[u][k], scale[k], shift[k]);
+                        acch[k] += (x[u][k] - al[k] * mu[k]) * rstd[k];
+                    }
+                }
             }
         }
     }
@@ -648,10 +694,12 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     // them and carries the head-gradient / loss roles — no reduce launch (needs the listed pooled rows: see below)
     const bool two = gn_bwd_acc != nullptr && vec && mask && lab_rows && lab_count && B * Smax <= kReadoutOrderedMax;
     GLASS_REQUIRE(!gn_bwd_acc || (gn_bwd_rep >= 1 && gn_bwd_rep <= kAccRep), "readout_train: gn_bwd_rep = replicas of gn_bwd_acc (1 .. 16)");
+    // long subgraphs: the row's node ids staged in LDS by the counting pass (while everything stays within 64 KB)
+    const int stash = Smax > 2 * (kBlock >> tc_log2) && sizeof(float) * (size_t)(10 * C + kBlock * 8 + 2 * kReadoutMaxK + Smax) <= 64 * 1024;
     R1Args a1{jk, ldj, gn_saved, alpha, pos, (int)Smax, pool_mode, Wh, bh, target, loss_mode, (int)B, (int)C, (int)K,
-              grad_loss, pooled, logits, w, n_nodes, tc_log2, esrc, two ? reinterpret_cast<long long*>(gn_bwd_acc) : nullptr,
+              grad_loss, pooled, logits, w, n_nodes, tc_log2, esrc, stash, two ? reinterpret_cast<long long*>(gn_bwd_acc) : nullptr,
               gn_bwd_rep};
-    const size_t lds1 = sizeof(float) * (size_t)(10 * C + kBlock * 8 + 2 * kReadoutMaxK);
+    const size_t lds1 = sizeof(float) * (size_t)(10 * C + kBlock * 8 + 2 * kReadoutMaxK + (stash ? Smax : 0));
     if (vec)
         hipLaunchKernelGGL(readout_subgraph_kernel<4>, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
     else

@@ -595,6 +595,9 @@ def test_stack_program_large_tables(V, n):
 
 
 @pytest.mark.parametrize("pool,multilabel,H,L", [("sum", False, 64, 2), ("mean", False, 64, 2), ("size", True, 64, 2),
+                                                 # long padded rows (em_user's subgraphs): the readout stages the node ids in
+                                                 # LDS and walks four entries per round (H < 0 marks the case: |H|, S = 75)
+                                                 ("mean", False, -64, 2), ("size", True, -128, 1),
                                                  # the shipped sets' own widths: component (17, one layer: a 17-column readout),
                                                  # coreness (20, two layers), density / cut_ratio (8)
                                                  ("sum", False, 17, 1), ("mean", False, 20, 2), ("size", True, 8, 1),
@@ -609,7 +612,8 @@ def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel, H
     from glass_amd.arena import ParamArena
     from impl import utils
     from glass_amd import synth
-    n, K, B, S = 900, 5, 12, 9
+    n, K, B, S = 900, 5, 12, (75 if H < 0 else 9)
+    H = abs(H)
     torch.manual_seed(21)
     model = build_glass(H, L, 7, K, "mean", pool, 0.9)
     sd = {k: v.clone() for k, v in model.state_dict().items()}
@@ -618,6 +622,9 @@ def test_fused_readout_step_matches_autograd_path_and_oracle(pool, multilabel, H
     x = torch.from_numpy(rng.integers(0, 8, n)).reshape(n, 1, 1)
     pos = rng.integers(0, 40, (B, S))          # drawn from 40 nodes: heavy sharing between subgraphs
     pos[:, -3:][rng.random((B, 3)) < 0.5] = -1
+    if S > 9:
+        pos[rng.random((B, S)) < 0.2] = -1      # padding anywhere in a long row
+        pos[:, 0] = rng.integers(0, 40, B)
     pos[0, 1:] = -1                            # a single-node subgraph
     pos = torch.from_numpy(pos)
     y = torch.from_numpy((rng.random((B, K)) < 0.4).astype(np.float32)) if multilabel else torch.from_numpy(rng.integers(0, K, B))
