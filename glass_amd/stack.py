@@ -502,6 +502,11 @@ class StackProgram:
                 acc_bwd = blocks[:n_bwd] if n_bwd else None
                 acc_fwd = blocks[n_bwd:] if n_fwd else None
                 acc_ro = acc_all[(n_bwd + n_fwd) * w_h:] if w_ro else None
+        elif (USE_GN_EXACT and USE_READOUT_TWO and readout is not None and keep and labels is not None and H % 4 == 0 and
+              (H * L if emb.jk else H) <= 128 and n <= (1 << 16)):
+            # the readout's own block alone: its backward column sums in exact accumulators, folded by the backfill launch —
+            # two launches instead of three (every backfill workgroup folds n_rep * 2C sums: narrow outputs, mid-size graphs)
+            acc_all = acc_ro = torch.empty(int(lib.glass_gn_exact_words(H * L if emb.jk else H)), dtype=torch.int64, device=dev)
         st["gn_exact"] = acc_bwd
         st["gn_exact_readout"] = acc_ro
         if use_table and labels is not None and USE_GATHER_IN_TRANS and lib.glass_dual_linear_fwd_gather_supported(H):
