@@ -1,4 +1,6 @@
 #!/bin/bash
+# End-of-round refresh of profiles/: kernel tables + bench lines of C1-C4 (C5: tools/prof_round.sh), the pre-training step,
+# the default bench lines (counters + CPU baseline), smoke().  Output: gpurun_out/final/ ; copy r03_* to profiles/.
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 R=r03
 out=gpurun_out/final
