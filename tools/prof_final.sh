@@ -15,6 +15,11 @@ for w in density hpo_neuro em_user; do
   echo "== $w"; python3 tools/prof_summary.py $out/$w 3 | cut -c1-70,88-140
   rm -rf $out/$w
 done
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/c5 -- python3 bench.py --workload powerlaw --steps 20 --warmup 3 --no-cpu-baseline --no-roofline-hbm --no-pmc > $out/${R}_bench_powerlaw_bench_line.json 2> $out/c5.err
+cp $(ls $out/c5/*/*kernel_stats.csv | head -1) $out/${R}_bench_powerlaw_kernel_stats.csv
+echo "== powerlaw"; python3 tools/prof_summary.py $out/c5 3 | cut -c1-70,88-140
+rm -rf $out/c5
+GLASS_BENCH_BACKEND=gloo timeout 600 python3 bench.py --gpus 2 --steps 50 --warmup 5 --no-cpu-baseline --no-roofline-hbm --no-pmc > $out/${R}_bench_gloo2_smoke.json 2> $out/gloo2.err; echo "gloo2 rc=$?"; cut -c1-300 $out/${R}_bench_gloo2_smoke.json
 bash tools/prof_ssl.sh $R > $out/ssl.log 2>&1; head -3 gpurun_out/${R}_ssl_step.txt
 mv gpurun_out/${R}_ssl_step* $out/
 timeout 300 python3 tools/ssl_step.py ppi_bp 100 2 0.5 131072 graph >> $out/${R}_ssl_step.txt; tail -1 $out/${R}_ssl_step.txt
