@@ -32,6 +32,9 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
                                                                    int incremental) {
     __shared__ int wave_cnt[kLabThreads / kWave];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // this thread's first entry of the NEW batch is requested before anything else: its round trip runs beside phase 1's
+    // (the barrier between the phases would otherwise put the two loads in a row)
+    const int64_t p_first = tid < n_pos ? pos_src[tid] : -1;
     // 1. labels of the previous batch off (or all N bytes)
     if (incremental) {
         if (pos_dst)
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
     // 2. the new batch: fixed buffers, label bytes; the lowest entry index naming a node owns it (owner words are
     //    INT32_MAX on entry)
     for (int e = tid; e < n_pos; e += kLabThreads) {
-        const int64_t p = pos_src[e];
+        const int64_t p = e == tid ? p_first : pos_src[e];
         if (pos_dst) pos_dst[e] = p;
         if (p >= 0 && p < N) {
             mask[p] = 1;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
     int base = 0;
     for (int e0 = 0; e0 < n_pos; e0 += kLabThreads) {
         const int e = e0 + tid;
-        const int64_t p = e < n_pos ? pos_src[e] : -1;
+        const int64_t p = e0 == 0 ? p_first : (e < n_pos ? pos_src[e] : -1);
         const bool own = p >= 0 && p < N && __hip_atomic_load(owner + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e;
         const unsigned long long bal = __ballot(own);
         if (lane == 0) wave_cnt[w] = __popcll(bal);
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
     if (tid == 0) lab_count[0] = base;
     // 4. the owner words of the named nodes back to INT32_MAX (every read of them lies before the loop's last barrier)
     for (int e = tid; e < n_pos; e += kLabThreads) {
-        const int64_t p = pos_src[e];
+        const int64_t p = e == tid ? p_first : pos_src[e];
         if (p >= 0 && p < N) owner[p] = INT32_MAX;
     }
 }
