@@ -695,7 +695,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     const bool two = gn_bwd_acc != nullptr && vec && mask && lab_rows && lab_count && B * Smax <= kReadoutOrderedMax;
     GLASS_REQUIRE(!gn_bwd_acc || (gn_bwd_rep >= 1 && gn_bwd_rep <= kAccRep), "readout_train: gn_bwd_rep = replicas of gn_bwd_acc (1 .. 16)");
     // long subgraphs: the row's node ids staged in LDS by the counting pass (while everything stays within 64 KB)
-    const int stash = Smax > 2 * (kBlock >> tc_log2) && sizeof(float) * (size_t)(10 * C + kBlock * 8 + 2 * kReadoutMaxK + Smax) <= 64 * 1024;
+    const int stash = Smax > 2 * (kBlock >> tc_log2) && n_nodes < (1ll << 31) && sizeof(float) * (size_t)(10 * C + kBlock * 8 + 2 * kReadoutMaxK + Smax) <= 64 * 1024;
     R1Args a1{jk, ldj, gn_saved, alpha, pos, (int)Smax, pool_mode, Wh, bh, target, loss_mode, (int)B, (int)C, (int)K,
               grad_loss, pooled, logits, w, n_nodes, tc_log2, esrc, stash, two ? reinterpret_cast<long long*>(gn_bwd_acc) : nullptr,
               gn_bwd_rep};
