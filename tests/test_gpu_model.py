@@ -782,6 +782,53 @@ def test_step_program_full_size_vs_oracle(name):
     assert err < max(TOL, 2 * o_grad)
 
 
+def test_pretraining_step_full_size_vs_oracle():
+    """The link-prediction pre-training step at the size GNNEmb.py runs it — ppi_bp-shaped graph (N = 17 080, nnz = 633 902),
+    131 072 node pairs, hidden 64, two MyGCNConv layers, MLP head, BCE — through the per-op path the driver uses (pair-pool
+    kernels with the exact backward, thin-output weight gradient, K1, GraphNorm) against the fp64 oracle, dropout 0:
+    predictions, loss, every gradient; and the fp32 CPU oracle against fp64 as this input's noise floor."""
+    import functools
+    from impl import models
+    from glass_amd import synth
+    w, ei, ew, x, _pos, _y = synth.make_workload("ppi_bp", seed=0, n_batches=1)
+    rng = np.random.default_rng(11)
+    n_pairs, h, layers = 131072, 64, 2
+    pairs = torch.from_numpy(rng.integers(0, w.n_node, size=(n_pairs, 2)))
+    y = torch.from_numpy(rng.integers(0, 2, size=n_pairs).astype(np.float32))
+    ei, ew, x = (torch.from_numpy(a) for a in (ei, ew, x))
+    torch.manual_seed(0)
+    conv = models.EmbGConv(h, h, h, layers, max_deg=int(x.max()), activation=nn.ReLU(inplace=True), jk=False, dropout=0.0,
+                           conv=functools.partial(models.MyGCNConv, aggr=w.aggr), gn=True)
+    head = models.MLP(h, h, 1, 2, dropout=0.0, activation=nn.ReLU(inplace=True))
+    model = models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()]))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    pred = model(x.to(DEV), ei.to(DEV), ew.to(DEV), pairs.to(DEV))
+    loss = nn.BCEWithLogitsLoss()(pred.flatten(), y.to(DEV))
+    loss.backward()
+    res = {}
+    for dt in (torch.float64, torch.float32):
+        orc = O.OracleEdgeGNN(h, layers, int(x.max()), aggr=w.aggr, jk=False)
+        orc.load_state_dict(sd)
+        orc = orc.to(dt).train()
+        po = orc(x, ei, ew.to(dt), pairs)
+        lo = nn.BCEWithLogitsLoss()(po.flatten(), y.to(dt))
+        lo.backward()
+        res[dt] = (po.detach(), lo.item(), {k: p.grad for k, p in orc.named_parameters()})
+    po, lo, theirs = res[torch.float64]
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    keys = sorted(mine)
+    assert keys == sorted(theirs)
+    e_pred, e_loss = rel_inf(pred.detach().cpu(), po), abs(loss.item() - lo) / abs(lo)
+    err = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
+    o_pred, o_grad = rel_inf(res[torch.float32][0], po), rel_inf(flat_grads(res[torch.float32][2], keys), flat_grads(theirs, keys))
+    print(f"pre-training step vs fp64 oracle: pred {e_pred:.2e} loss {e_loss:.2e} grad {err:.2e} | cpu-fp32-vs-fp64 {o_pred:.2e} {o_grad:.2e}")
+    record_parity("pretraining_step/ppi_bp_131072_pairs", pred_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf=err,
+                  oracle_fp32_vs_fp64_pred=o_pred, oracle_fp32_vs_fp64_grad=o_grad)
+    assert e_pred < TOL and e_loss < TOL
+    assert err < max(TOL, 2 * o_grad)
+
+
 @pytest.mark.parametrize("name", ["ppi_bp", "em_user"])
 def test_benchmarked_dropout_step_vs_oracle_on_the_same_masks(name):
     """The benchmarked step WITH its YAML dropout (0.5) at the full BASELINE shapes against the fp64 oracle given the very
