@@ -27,6 +27,8 @@ for it in range(N_CASES):
     V = int(rng.integers(3, 40))  # two distinct feature rows make emb_gn ill-conditioned
     B = int(rng.integers(1, 30))
     S = int(rng.integers(1, 25))
+    if rng.random() < 0.15:  # long padded rows (em_user-like subgraphs): the readout's staged-id form
+        S = int(rng.integers(40, 200))
     zr = float(rng.uniform(0.5, 1.0))
     torch.manual_seed(it)
     model = build_glass(H, L, V - 1, K, aggr, pool, zr)
@@ -64,4 +66,10 @@ for it in range(N_CASES):
     flag = "" if max(e1, e2, e3) < 1e-5 else "  <-- FAIL"
     print(f"{it:2d} H={H} L={L} {aggr:4s} {pool:4s} ml={int(multilabel)} K={K} n={n} nnz={ei.shape[1]} V={V} B={B} S={S}: logits {e1:.1e} grad {e2:.1e} loss {e3:.1e}{flag}")
 print("worst", worst)
+from helpers import record_parity
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 12345
+record_parity(f"fuzz/step_program_{'hidden64_large_n_' if os.environ.get('FUZZ_BIG') == '1' else ''}{N_CASES}_random_configs_seed{seed}",
+              cases=N_CASES, worst_rel_inf_logits_grad_loss=worst,
+              note="tools/fuzz_step_program.py: hidden 64/128/256, L 1-3, all aggr/pool/loss, ragged subgraphs with repeated nodes "
+                   "(15 % with 40-200 entries per row), vs fp64 oracle")
 sys.exit(0 if worst < 1e-5 else 1)
