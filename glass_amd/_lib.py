@@ -87,7 +87,8 @@ SIGNATURES = {
     "glass_readout_supported": (c_int, [_I, _I, c_int]),
     "glass_readout_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_readout_train_f32": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, c_int, _P, _P, _P, c_int, _I, _P, _P, _P, _P, _P, _I,
-                                        _P, _P, c_int, _P, _P, _P, c_int, _P, _I, _I, _P, _P, _P, _P, _P, c_int, _P]),
+                                        _P, _P, c_int, _P, _P, _P, c_int, _P, _I, _I, _P, _P, _P, _P, _P, c_int, _P, _P]),
+    "glass_readout_scatter_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_linear_wgrad_reduce_batch_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "glass_wgrad_reduce_spmm_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
                                             _P, _P]),

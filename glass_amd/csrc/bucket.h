@@ -1,0 +1,37 @@
+// Node-bucketed entry lists of a padded node matrix (pool.hip) and the exact fixed-point sum their consumers use, shared
+// with the fused readout's large-batch scatter (readout.hip).
+#pragma once
+#include "common.h"
+
+namespace glass {
+
+// hi * 2^-20 + lo * 2^-60 in two 64-bit integers: integer addition commutes, so a sum over a list whose order is
+// arbitrary (filled through atomics) is the same bits every run
+struct ExactSum {
+    long long hi, lo;
+    __device__ __forceinline__ void add(float v) {
+        double sv = (double)v * 1048576.0;  // 2^20
+        sv = fmin(fmax(sv, -4.0e18), 4.0e18);
+        const double fl = floor(sv);
+        hi += (long long)fl;
+        lo += (long long)((sv - fl) * 1099511627776.0);  // 2^40
+    }
+    __device__ __forceinline__ float value() const {
+        return (float)(((double)hi + (double)lo * (1.0 / 1099511627776.0)) * (1.0 / 1048576.0));
+    }
+};
+
+struct BucketLists {
+    const int32_t* off;   // [n_nodes + 1]: entries of node i are list[off[i] .. off[i + 1])
+    const int32_t* list;  // subgraph index of each entry (plain form) — or (pair << 1) | both-valid for Smax == 2 pairs
+    float* scale;         // [B] (plain form with a pooling mode) or nullptr
+};
+
+// words (int32) of workspace for bucket_build
+int64_t bucket_ws_words(int64_t n_nodes, int64_t B, int64_t Smax, bool pair_form);
+// Four small launches on `st` (zero, rank, scan, fill; + the subgraph scales when mode >= 0 and not the pair form).
+// pair_form (Smax == 2 only): the list carries the pair's count in bit 0 instead of a scale array.
+int bucket_build(const int64_t* pos, int64_t B, int64_t Smax, int mode, bool pair_form, int64_t n_nodes, void* ws, hipStream_t st,
+                 BucketLists* out);
+
+}  // namespace glass

@@ -2,6 +2,7 @@
 // global_{add,mean,max}_pool / GraphSizeNorm (reference impl/models.py:346-350, 294-319;
 // impl/utils.py:18-29).  One workgroup per subgraph: TC lanes x 16 B cover an embedding row,
 // 256/TC row slots walk the padded node list; slots are combined through LDS in fixed order.
+#include "bucket.h"
 #include "common.h"
 
 #include <float.h>
@@ -301,13 +302,13 @@ __global__ __launch_bounds__(1024) void pair_scan_kernel(int32_t* __restrict__ o
 // list[off[node] + rank] = (pair << 1) | (both entries of the pair valid): what the gather needs without reading pairs.
 // Subgraphs of any padded width (Smax != 2): the entry's subgraph index; its scale comes from the scale array.
 __global__ __launch_bounds__(kBlock) void pair_fill_kernel(const int64_t* __restrict__ pairs, int64_t n_entries, int Smax,
-                                                           int64_t n_nodes, const int32_t* __restrict__ off,
+                                                           int pair_form, int64_t n_nodes, const int32_t* __restrict__ off,
                                                            const int32_t* __restrict__ rank, int32_t* __restrict__ list) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_entries) return;
     const int64_t node = pairs[e];
     if (node < 0 || node >= n_nodes) return;
-    if (Smax == 2) {
+    if (pair_form) {
         const int64_t other = pairs[e ^ 1];
         list[off[node] + rank[e]] = (int32_t)((e >> 1) << 1) | (int32_t)(other >= 0 && other < n_nodes);
     } else {
@@ -329,20 +330,6 @@ __global__ __launch_bounds__(kBlock) void pool_scale_kernel(const int64_t* __res
     }
     if (lane == 0) scale[b] = pool_scale(mode, cnt);
 }
-
-struct ExactSum {
-    long long hi, lo;
-    __device__ __forceinline__ void add(float v) {
-        double sv = (double)v * 1048576.0;  // 2^20
-        sv = fmin(fmax(sv, -4.0e18), 4.0e18);
-        const double fl = floor(sv);
-        hi += (long long)fl;
-        lo += (long long)((sv - fl) * 1099511627776.0);  // 2^40
-    }
-    __device__ __forceinline__ float value() const {
-        return (float)(((double)hi + (double)lo * (1.0 / 1099511627776.0)) * (1.0 / 1048576.0));
-    }
-};
 
 constexpr int kPairLongList = 64;  // entries from which a node's list is summed by the whole workgroup
 
@@ -521,19 +508,43 @@ static int pair_group_log2(int64_t C, bool vec) {
     return l;
 }
 
-static int64_t bucketed_ws_words(int64_t n_nodes, int64_t B, int64_t Smax) {
-    // off [n_nodes + 1, padded to 4] | rank [E] | list [E] | scale [B] (Smax != 2)
-    return ((n_nodes + 1 + 3) & ~(int64_t)3) + 2 * B * Smax + (Smax == 2 ? 0 : B);
+namespace glass {
+int64_t bucket_ws_words(int64_t n_nodes, int64_t B, int64_t Smax, bool pair_form) {
+    // off [n_nodes + 1, padded to 4] | rank [E] | list [E] | scale [B] (plain form)
+    return ((n_nodes + 1 + 3) & ~(int64_t)3) + 2 * B * Smax + (pair_form ? 0 : B);
 }
+
+int bucket_build(const int64_t* pos, int64_t B, int64_t Smax, int mode, bool pair_form, int64_t n_nodes, void* ws, hipStream_t st,
+                 BucketLists* out) {
+    GLASS_REQUIRE(pos && ws && aligned16(ws) && B > 0 && Smax > 0 && n_nodes > 0 && B * Smax < (1ll << 30) && n_nodes < (1ll << 31) &&
+                      (!pair_form || Smax == 2),
+                  "bucket_build: 16-B aligned workspace, fewer than 2^30 entries and 2^31 nodes");
+    const int64_t E = B * Smax;
+    int32_t* off = (int32_t*)ws;
+    int32_t* rank = off + ((n_nodes + 1 + 3) & ~(int64_t)3);
+    int32_t* list = rank + E;
+    float* scale = (pair_form || mode < 0) ? nullptr : reinterpret_cast<float*>(list + E);
+    const unsigned ge = (unsigned)ceil_div(E, (int64_t)kBlock);
+    hipLaunchKernelGGL(pair_zero_kernel, dim3((unsigned)ceil_div(n_nodes + 1, (int64_t)kBlock)), dim3(kBlock), 0, st, off, n_nodes + 1);
+    if (scale)
+        hipLaunchKernelGGL(pool_scale_kernel, dim3((unsigned)ceil_div(B, (int64_t)(kBlock / kWave))), dim3(kBlock), 0, st, pos, (int)B,
+                           (int)Smax, mode, n_nodes, scale);
+    hipLaunchKernelGGL(pair_rank_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, n_nodes, off, rank);
+    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, st, off, n_nodes + 1);
+    hipLaunchKernelGGL(pair_fill_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, (int)Smax, pair_form ? 1 : 0, n_nodes, off, rank, list);
+    *out = BucketLists{off, list, scale};
+    return 0;
+}
+}  // namespace glass
 
 extern "C" int64_t glass_pair_pool_ws_bytes(int64_t n_nodes, int64_t B) {
     if (n_nodes <= 0 || B <= 0) return 0;
-    return (int64_t)sizeof(int32_t) * bucketed_ws_words(n_nodes, B, 2);
+    return (int64_t)sizeof(int32_t) * bucket_ws_words(n_nodes, B, 2, true);
 }
 
 extern "C" int64_t glass_segment_pool_bwd_exact_ws_bytes(int64_t n_nodes, int64_t B, int64_t Smax) {
     if (n_nodes <= 0 || B <= 0 || Smax <= 0) return 0;
-    return (int64_t)sizeof(int32_t) * bucketed_ws_words(n_nodes, B, Smax);
+    return (int64_t)sizeof(int32_t) * bucket_ws_words(n_nodes, B, Smax, Smax == 2);
 }
 
 extern "C" int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t* pairs, int64_t B, int mode, float* out,
@@ -564,19 +575,11 @@ static int bucketed_pool_bwd(const float* dout, int64_t ldd, const int64_t* pos,
     const bool vec = C % 4 == 0 && ldd % 4 == 0 && lde % 4 == 0 && aligned16(dout) && aligned16(demb);
     const int gl = pair_group_log2(C, vec);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t E = B * Smax;
-    int32_t* off = (int32_t*)ws;
-    int32_t* rank = off + ((n_nodes + 1 + 3) & ~(int64_t)3);
-    int32_t* list = rank + E;
-    float* scale = Smax == 2 ? nullptr : reinterpret_cast<float*>(list + E);
-    const unsigned ge = (unsigned)ceil_div(E, (int64_t)kBlock);
-    hipLaunchKernelGGL(pair_zero_kernel, dim3((unsigned)ceil_div(n_nodes + 1, (int64_t)kBlock)), dim3(kBlock), 0, st, off, n_nodes + 1);
-    if (scale)
-        hipLaunchKernelGGL(pool_scale_kernel, dim3((unsigned)ceil_div(B, (int64_t)(kBlock / kWave))), dim3(kBlock), 0, st, pos, (int)B,
-                           (int)Smax, mode, n_nodes, scale);
-    hipLaunchKernelGGL(pair_rank_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, n_nodes, off, rank);
-    hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, st, off, n_nodes + 1);
-    hipLaunchKernelGGL(pair_fill_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, (int)Smax, n_nodes, off, rank, list);
+    BucketLists bl;
+    rc = bucket_build(pos, B, Smax, mode, Smax == 2, n_nodes, ws, st, &bl);
+    if (rc) return rc;
+    const int32_t *off = bl.off, *list = bl.list;
+    const float* scale = bl.scale;
     const unsigned gg = (unsigned)ceil_div(n_nodes, (int64_t)(kBlock >> gl));
     if (vec)
         hipLaunchKernelGGL(pair_gather_kernel<4>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, mode, scale, off, list, demb, lde,

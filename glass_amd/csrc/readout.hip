@@ -15,6 +15,7 @@
 //   R4  sparse part: d jk[n] += A * g[n] on the pooled rows: an ordered, atomic-free scatter (bitwise repeatable) while
 //       pos fits LDS (B*Smax <= 16 384); beyond that float atomics (order-dependent in the last bits when subgraphs
 //       share nodes, because the row already holds the dense part).
+#include "bucket.h"
 #include "common.h"
 #include "gn_math.h"
 #include "gn_acc.h"
@@ -641,6 +642,77 @@ __global__ __launch_bounds__(kBlock) void readout_scatter_kernel(const int64_t* 
     }
 }
 
+// R4 beyond the ordered scatter's LDS staging, still without float atomics: the entries are bucketed by node (bucket.h) and a
+// pooled node's row gets  d jk[n] += sum over its entries of A * g[subgraph]  with the sum taken in exact fixed point — the
+// lists' arbitrary order does not reach the result.  One lane group (16 B per lane) per node; long lists by the whole
+// workgroup.  The dense part (readout_dense_kernel) wrote every row before.
+__global__ __launch_bounds__(kBlock) void readout_gather_add_kernel(const int32_t* __restrict__ off, const int32_t* __restrict__ list,
+                                                                    const float* __restrict__ dys, const float* __restrict__ coef,
+                                                                    float* __restrict__ dx, int64_t lddx, int64_t n_nodes, int C,
+                                                                    int tc_log2) {
+    __shared__ long long red[kBlock * 4 * 2];
+    const int G = 1 << tc_log2, li = threadIdx.x & (G - 1), slot = threadIdx.x >> tc_log2, n_slot = kBlock >> tc_log2;
+    const int64_t node0 = (int64_t)blockIdx.x * n_slot;
+    const int c0 = li * 4;
+    const bool ok = c0 < C;
+    const float4 A = ok ? *reinterpret_cast<const float4*>(coef + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int kLong = 64;
+    {
+        const int64_t node = node0 + slot;
+        const int beg = node < n_nodes ? off[node] : 0, end = node < n_nodes ? off[node + 1] : 0;
+        if (ok && end > beg && end - beg < kLong) {
+            ExactSum s[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k].hi = s[k].lo = 0;
+            for (int i = beg; i < end; ++i) {
+                const float4 g = *reinterpret_cast<const float4*>(dys + (int64_t)list[i] * C + c0);
+                s[0].add(A.x * g.x); s[1].add(A.y * g.y); s[2].add(A.z * g.z); s[3].add(A.w * g.w);
+            }
+            float4* d = reinterpret_cast<float4*>(dx + node * lddx + c0);
+            float4 o = *d;
+            o.x += s[0].value(); o.y += s[1].value(); o.z += s[2].value(); o.w += s[3].value();
+            *d = o;
+        }
+    }
+    for (int t = 0; t < n_slot; ++t) {
+        const int64_t node = node0 + t;
+        if (node >= n_nodes) break;
+        const int beg = off[node], end = off[node + 1];
+        if (end - beg < kLong) continue;  // workgroup-uniform
+        ExactSum s[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k].hi = s[k].lo = 0;
+        if (ok)
+            for (int i = beg + slot; i < end; i += n_slot) {
+                const float4 g = *reinterpret_cast<const float4*>(dys + (int64_t)list[i] * C + c0);
+                s[0].add(A.x * g.x); s[1].add(A.y * g.y); s[2].add(A.z * g.z); s[3].add(A.w * g.w);
+            }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[(threadIdx.x * 4 + k) * 2] = s[k].hi;
+            red[(threadIdx.x * 4 + k) * 2 + 1] = s[k].lo;
+        }
+        __syncthreads();
+        if (slot == 0 && ok) {
+            float add[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ExactSum tsum{0, 0};
+                for (int r = 0; r < n_slot; ++r) {
+                    tsum.hi += red[(((r << tc_log2) + li) * 4 + k) * 2];
+                    tsum.lo += red[(((r << tc_log2) + li) * 4 + k) * 2 + 1];
+                }
+                add[k] = tsum.value();
+            }
+            float4* d = reinterpret_cast<float4*>(dx + node * lddx + c0);
+            float4 o = *d;
+            o.x += add[0]; o.y += add[1]; o.z += add[2]; o.w += add[3];
+            *d = o;
+        }
+    }
+}
+
 }  // namespace glass
 
 using namespace glass;
@@ -655,6 +727,13 @@ extern "C" int64_t glass_readout_ws_bytes(int64_t B, int64_t C, int64_t K) {
     return (int64_t)sizeof(double) * 2 * B * C + (int64_t)sizeof(float) * (4 * C + B * C + B * K + B) + 64;
 }
 
+// scratch of the exact large-batch scatter (0: the batch fits the ordered scatter's LDS staging, nothing needed)
+extern "C" int64_t glass_readout_scatter_ws_bytes(int64_t n_nodes, int64_t B, int64_t Smax) {
+    if (n_nodes <= 0 || B <= 0 || Smax <= 0) return GLASS_E_ARG;
+    if (B * Smax <= kReadoutOrderedMax) return 0;
+    return (int64_t)sizeof(int32_t) * bucket_ws_words(n_nodes, B, Smax, false);
+}
+
 extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved, const float* gamma,
                                        const float* alpha, const int64_t* pos, int64_t B, int64_t Smax, int pool_mode,
                                        const float* Wh, const float* bh, const void* target, int loss_mode, int64_t K,
@@ -662,7 +741,8 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
                                        int64_t lddj, float* dWh, float* dbh, int acc_head, float* dgamma, float* dbeta,
                                        float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
                                        const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
-                                       const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* stream) {
+                                       const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* scatter_ws,
+                                       void* stream) {
     GLASS_REQUIRE(jk && gn_saved && gamma && alpha && pos && Wh && bh && target && grad_loss && pooled && logits && loss &&
                       djk && dWh && dbh && ws,
                   "readout_train: null pointer");
@@ -747,6 +827,13 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
         const int64_t parts = ceil_div(Smax, (int64_t)(kOrdBlock / kWave));
         hipLaunchKernelGGL(readout_scatter_ordered_kernel, dim3((unsigned)(B * parts)), dim3(kOrdBlock), sizeof(int32_t) * (size_t)(B * Smax),
                            st, pos, (int)Smax, (int)(B * Smax), w.dys, w.coef, djk, lddj, n_nodes, (int)C);
+    } else if (scatter_ws) {
+        // exact, atomic-free: entries bucketed by node, then one gather-add per pooled node (glass_readout_scatter_ws_bytes)
+        BucketLists bl;
+        int rc = bucket_build(pos, B, Smax, -1, false, n_nodes, scatter_ws, st, &bl);
+        if (rc) return rc;
+        hipLaunchKernelGGL(readout_gather_add_kernel, dim3((unsigned)ceil_div(n_nodes, (int64_t)(kBlock / tc))), dim3(kBlock), 0, st,
+                           bl.off, bl.list, w.dys, w.coef, djk, lddj, n_nodes, (int)C, tc_log2);
     } else {
         hipLaunchKernelGGL(readout_scatter_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, pos, (int)Smax, w.dys, w.coef,
                            djk, lddj, n_nodes, (int)C, tc_log2);

@@ -600,10 +600,9 @@ def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id
 # K7  subgraph pooling
 # ---------------------------------------------------------------------------------------------
 # Largest padded node matrices (B * Smax entries) the ORDERED, atomic-free scatters stage in LDS (pool.hip kPoolOrderedMax,
-# readout.hip kReadoutOrderedMax).  Beyond them the pool backward buckets the entries by node and sums in exact fixed point
-# (glass_segment_pool_bwd_exact_f32: still no float atomic); the fused readout beyond its limit — and max pooling — falls
-# back to float atomics: same values within rounding, but no longer bitwise repeatable from run to run.  Said once,
-# loudly, instead of silently.
+# readout.hip kReadoutOrderedMax).  Beyond them the pool backward and the fused readout bucket the entries by node and sum
+# in exact fixed point (bucket.h: still no float atomic); max pooling's backward uses float atomics: same values within
+# rounding, but not bitwise repeatable from run to run.  Said once, loudly, instead of silently.
 POOL_ORDERED_MAX, READOUT_ORDERED_MAX = 12288, 16384
 _atomic_warned = set()
 

@@ -607,8 +607,8 @@ class StackProgram:
         lib, gn = _lib.load(), self.emb.gns[-1]
         n, C = jk.shape
         B, Smax = pos.shape
-        if B * Smax > ops.READOUT_ORDERED_MAX:
-            ops.warn_atomic_fallback("fused readout", B * Smax, ops.READOUT_ORDERED_MAX)
+        sws_bytes = int(lib.glass_readout_scatter_ws_bytes(n, B, Smax))  # > 0: beyond the ordered scatter's LDS staging
+        sws = ops._scratch(("readout_scatter", n, B, Smax), jk.device, sws_bytes).data_ptr() if sws_bytes > 0 else 0
         K = head.weight.shape[0]
         dev = jk.device
         f32 = dict(dtype=torch.float32, device=dev)
@@ -633,7 +633,7 @@ class StackProgram:
                                            djk.data_ptr(), djk.stride(0), head.weight.grad.data_ptr(),
                                            head.bias.grad.data_ptr(), st["acc"], gn.weight.grad.data_ptr(),
                                            gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), st["acc"], ws.data_ptr(),
-                                           n, C, *largs, src, 0 if acc_ro is None else acc_ro.data_ptr(), REP_DENSE, _stream()),
+                                           n, C, *largs, src, 0 if acc_ro is None else acc_ro.data_ptr(), REP_DENSE, sws, _stream()),
                "glass_readout_train_f32")
         st["djk"] = djk
         return loss, logits

@@ -525,8 +525,9 @@ int glass_head_linear_f32(const float* pooled, int64_t ldp, const float* W, cons
  *      pool_mode sum|mean|size; loss_mode 0 = cross-entropy (target int64[B]), 1 = BCE-with-logits (float[B,K]);
  *      grad_loss = device scalar seed.  Outputs: pooled [B,C], logits [B,K], loss [1], djk [N,C] (overwritten);
  *      dWh/dbh and dgamma/dbeta/dalpha are accumulated when acc_* != 0.
- *      Bitwise repeatable while B*Smax <= 16 384 (ordered, atomic-free scatter of the sparse part); beyond that the
- *      scatter uses float atomics.  mask / lab_rows / lab_count (all three, or NULL): the label bytes and the unique
+ *      Bitwise repeatable: B*Smax <= 16 384 by an ordered, atomic-free scatter of the sparse part staged in LDS; beyond that
+ *      by node-bucketed exact sums when scatter_ws (glass_readout_scatter_ws_bytes bytes, uninitialised scratch) is given —
+ *      with scatter_ws == NULL the large-batch scatter falls back to float atomics.  mask / lab_rows / lab_count (all three, or NULL): the label bytes and the unique
  *      labeled rows glass_batch_labels produced for THIS pos — the pooled rows of a step are its labeled rows — then the
  *      dense part skips them and extra workgroups of the same launch write their full value: three launches, bitwise
  *      equal to the four.  C % 4 != 0 (or unaligned rows): scalar kernels, which need the label bytes (mask). */
@@ -534,13 +535,14 @@ int glass_graphnorm_stats_f32(const float* x, int64_t ldx, int64_t n_rows, int64
                               const float* beta, const float* alpha, float eps, float* saved, void* ws, void* stream);
 int glass_readout_supported(int64_t C, int64_t K, int pool_mode);
 int64_t glass_readout_ws_bytes(int64_t B, int64_t C, int64_t K);
+int64_t glass_readout_scatter_ws_bytes(int64_t n_nodes, int64_t B, int64_t Smax); /* 0 while B*Smax <= 16 384 */
 int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved, const float* gamma, const float* alpha,
                             const int64_t* pos, int64_t B, int64_t Smax, int pool_mode, const float* Wh, const float* bh,
                             const void* target, int loss_mode, int64_t K, const float* grad_loss, float* pooled,
                             float* logits, float* loss, float* djk, int64_t lddj, float* dWh, float* dbh, int acc_head,
                             float* dgamma, float* dbeta, float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
                             const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
-                            const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* stream);
+                            const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* scatter_ws, void* stream);
 /*      gn_bwd_acc != NULL (with the listed pooled rows): two launches instead of three — the subgraph kernel adds its share of
  *      the final GraphNorm's two backward column sums to these exact accumulators (glass_gn_exact_words(C) words, zeroed by
  *      the caller per step, gn_bwd_rep replicas in use), the backfill launch folds them and also carries the head-gradient

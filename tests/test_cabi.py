@@ -161,8 +161,9 @@ def test_step_program_entry_points_validate_on_the_host():
     assert lib.glass_readout_supported(2048, 6, 0) == 0 and lib.glass_readout_supported(128, 300, 0) == 0
     assert lib.glass_readout_ws_bytes(80, 128, 6) >= 8 * 2 * 80 * 128 + 4 * (4 * 128 + 80 * 128 + 80 * 6 + 80)
     assert lib.glass_readout_ws_bytes(0, 128, 6) == -1
+    assert lib.glass_readout_scatter_ws_bytes(1000, 80, 10) == 0 and lib.glass_readout_scatter_ws_bytes(50000, 200, 155) > 4 * 2 * 200 * 155
     args = [p, 128, p, p, p, p, 80, 10, 2, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 1000, 128, None, None, None, None,
-            None, 0, None]
+            None, 0, None, None]
     assert lib.glass_readout_train_f32(*args) == -3  # max pooling is not fusable
     # table path: more rows than GLASS_EMBED_NORM_MAX_ROWS
     assert lib.glass_embed_norm_fwd_f32(p, p, 10000, p, p, p, p, 1e-5, p, p, None, None, 0, 0.0, None, 1, p, 64, p, 10, 64,

@@ -885,9 +885,10 @@ def test_benchmarked_dropout_step_vs_oracle_on_the_same_masks(name):
     assert e_pred < TOL and e_loss < TOL and err < TOL
 
 
-def test_large_batches_fall_back_to_atomic_scatters():
+def test_large_batches_stay_exact_and_repeatable():
     """pos matrices beyond the LDS staging of the ordered scatters (readout: B*Smax > 16 384, pool backward:
-    > 12 288) take the float-atomic kernels: same results within tolerance (not bitwise repeatable)."""
+    > 12 288) take the node-bucketed exact sums (bucket.h) instead of float atomics: no warning, results within tolerance
+    of the fp64 oracle AND bitwise equal between two runs (every subgraph shares node 7)."""
     from glass_amd import stack, losses, ops, synth
     from glass_amd.arena import ParamArena
     n, H, L, K, B, S = 3000, 64, 1, 4, 132, 128          # B*S = 16 896
@@ -899,16 +900,23 @@ def test_large_batches_fall_back_to_atomic_scatters():
     x = torch.from_numpy(rng.integers(0, 6, n)).reshape(n, 1, 1)
     pos = np.stack([rng.choice(n, S, replace=False) for _ in range(B)])
     pos[:, -40:][rng.random((B, 40)) < 0.5] = -1
+    pos[:, 0] = 7                                        # a node shared by every subgraph: its list is summed by a whole workgroup
     pos = torch.from_numpy(pos)
     y = torch.from_numpy(rng.integers(0, K, B))
     loss_fn = losses.CrossEntropy()
     model.to(DEV).train()
     arena = ParamArena(model)
     xg, eig, ewg, posg, yg = x.to(DEV), torch.from_numpy(ei).to(DEV), torch.from_numpy(ew).to(DEV), pos.to(DEV), y.to(DEV)
+    import warnings
     arena.zero()
     ops._atomic_warned.clear()
-    with pytest.warns(RuntimeWarning, match="not bitwise repeatable"):  # the fallback announces itself (once per kind)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
         loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg)
+        first = arena.flat.clone()
+        arena.zero()
+        loss2, _ = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg)
+    assert torch.equal(first, arena.flat) and loss.item() == loss2.item()
     orc = O.OracleGLASS(H, L, 5, K, aggr="mean", pool="sum", z_ratio=0.8)
     orc.load_state_dict(sd)
     orc = orc.double().train()
