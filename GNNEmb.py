@@ -81,8 +81,16 @@ class GraphedPairStep:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             loss = torch.zeros((), device=pairs.device)  # caller-owned: outside the graph's private pool
-            with torch.cuda.graph(g):
-                loss.copy_(self._fwd_bwd(s_pairs, s_target))
+            try:
+                with torch.cuda.graph(g):
+                    loss.copy_(self._fwd_bwd(s_pairs, s_target))
+            except Exception as e:  # noqa: BLE001 — whatever the runtime refuses to capture: keep training eagerly
+                print(f"GraphedPairStep: capture refused ({e!r}); continuing with the eager step", flush=True)
+                self.enabled = False
+                torch.cuda.synchronize()
+                for p in self.params:
+                    p.grad = None
+                return self._fwd_bwd(pairs, target)
             ent = self.graphs[key] = (g, s_pairs, s_target, loss, [p.grad for p in self.params])
         g, s_pairs, s_target, loss, grads = ent
         s_pairs.copy_(pairs)
