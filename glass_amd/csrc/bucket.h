@@ -32,6 +32,6 @@ int64_t bucket_ws_words(int64_t n_nodes, int64_t B, int64_t Smax, bool pair_form
 // Four small launches on `st` (zero, rank, scan, fill; + the subgraph scales when mode >= 0 and not the pair form).
 // pair_form (Smax == 2 only): the list carries the pair's count in bit 0 instead of a scale array.
 int bucket_build(const int64_t* pos, int64_t B, int64_t Smax, int mode, bool pair_form, int64_t n_nodes, void* ws, hipStream_t st,
-                 BucketLists* out);
+                 BucketLists* out, bool dedup = false);  // dedup: a node named twice by one row is listed once for it
 
 }  // namespace glass

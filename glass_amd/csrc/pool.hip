@@ -244,13 +244,24 @@ __global__ __launch_bounds__(kBlock) void pair_zero_kernel(int32_t* __restrict__
 }
 
 // counts per node (off[node + 1]) and, from the same returning atomic, the entry's rank inside its node's list
+// dedup_smax > 0 (= Smax): a node named several times by one padded row is listed once for that row (its first entry;
+// the others get rank -1) — the max-pool backward asks "which subgraphs hold this node", not "how often"
 __global__ __launch_bounds__(kBlock) void pair_rank_kernel(const int64_t* __restrict__ pairs, int64_t n_entries,
                                                            int64_t n_nodes, int32_t* __restrict__ off,
-                                                           int32_t* __restrict__ rank) {
+                                                           int32_t* __restrict__ rank, int dedup_smax) {
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_entries) return;
     const int64_t node = pairs[e];
-    if (node >= 0 && node < n_nodes) rank[e] = atomicAdd(off + node + 1, 1);
+    if (node < 0 || node >= n_nodes) return;
+    if (dedup_smax > 0) {
+        const int64_t row0 = e - e % dedup_smax;
+        for (int64_t k = row0; k < e; ++k)
+            if (pairs[k] == node) {
+                rank[e] = -1;
+                return;
+            }
+    }
+    rank[e] = atomicAdd(off + node + 1, 1);
 }
 
 // off[0 .. n_nodes] (off[0] = 0, off[i + 1] = entries of node i) -> inclusive prefix sums in place: one workgroup, 4096
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(kBlock) void pair_fill_kernel(const int64_t* __rest
     const int64_t e = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (e >= n_entries) return;
     const int64_t node = pairs[e];
-    if (node < 0 || node >= n_nodes) return;
+    if (node < 0 || node >= n_nodes || rank[e] < 0) return;
     if (pair_form) {
         const int64_t other = pairs[e ^ 1];
         list[off[node] + rank[e]] = (int32_t)((e >> 1) << 1) | (int32_t)(other >= 0 && other < n_nodes);
@@ -431,6 +442,37 @@ __global__ __launch_bounds__(kBlock) void pair_gather_kernel(const float* __rest
     }
 }
 
+// Max-pool backward on the same lists (deduplicated per row): node n's row is, per column, the sum of dout[b][c] over the
+// subgraphs b that hold n AND whose argmax for that column is n — exact sums again, every row written.
+template <int VW>
+__global__ __launch_bounds__(kBlock) void pool_max_gather_kernel(const float* __restrict__ dout, int64_t ldd,
+                                                                 const int32_t* __restrict__ argmax,
+                                                                 const int32_t* __restrict__ off, const int32_t* __restrict__ list,
+                                                                 float* __restrict__ demb, int64_t lde, int64_t n_nodes, int C,
+                                                                 int g_log2) {
+    const int G = 1 << g_log2, li = threadIdx.x & (G - 1), slot = threadIdx.x >> g_log2, n_slot = kBlock >> g_log2;
+    const int64_t node = (int64_t)blockIdx.x * n_slot + slot;
+    if (node >= n_nodes) return;
+    const int beg = off[node], end = off[node + 1];
+    for (int c0 = li * VW; c0 < C; c0 += G * VW) {
+        ExactSum s[VW];
+#pragma unroll
+        for (int k = 0; k < VW; ++k) s[k].hi = s[k].lo = 0;
+        for (int i = beg; i < end; ++i) {
+            const int64_t b = list[i];
+            P<VW> g;
+            g.load(dout + b * ldd + c0);
+#pragma unroll
+            for (int k = 0; k < VW; ++k)
+                if (argmax[b * C + c0 + k] == (int32_t)node) s[k].add(g.a[k]);
+        }
+        P<VW> o;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) o.a[k] = s[k].value();
+        o.store(demb + node * lde + c0);
+    }
+}
+
 constexpr int64_t kPoolOrderedMax = 12288;  // pos entries (+ B scales) staged in LDS: <= 64 KiB
 
 }  // namespace glass
@@ -515,7 +557,7 @@ int64_t bucket_ws_words(int64_t n_nodes, int64_t B, int64_t Smax, bool pair_form
 }
 
 int bucket_build(const int64_t* pos, int64_t B, int64_t Smax, int mode, bool pair_form, int64_t n_nodes, void* ws, hipStream_t st,
-                 BucketLists* out) {
+                 BucketLists* out, bool dedup) {
     GLASS_REQUIRE(pos && ws && aligned16(ws) && B > 0 && Smax > 0 && n_nodes > 0 && B * Smax < (1ll << 30) && n_nodes < (1ll << 31) &&
                       (!pair_form || Smax == 2),
                   "bucket_build: 16-B aligned workspace, fewer than 2^30 entries and 2^31 nodes");
@@ -529,7 +571,7 @@ int bucket_build(const int64_t* pos, int64_t B, int64_t Smax, int mode, bool pai
     if (scale)
         hipLaunchKernelGGL(pool_scale_kernel, dim3((unsigned)ceil_div(B, (int64_t)(kBlock / kWave))), dim3(kBlock), 0, st, pos, (int)B,
                            (int)Smax, mode, n_nodes, scale);
-    hipLaunchKernelGGL(pair_rank_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, n_nodes, off, rank);
+    hipLaunchKernelGGL(pair_rank_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, n_nodes, off, rank, dedup ? (int)Smax : 0);
     hipLaunchKernelGGL(pair_scan_kernel, dim3(1), dim3(1024), 0, st, off, n_nodes + 1);
     hipLaunchKernelGGL(pair_fill_kernel, dim3(ge), dim3(kBlock), 0, st, pos, E, (int)Smax, pair_form ? 1 : 0, n_nodes, off, rank, list);
     *out = BucketLists{off, list, scale};
@@ -599,4 +641,26 @@ extern "C" int glass_segment_pool_bwd_exact_f32(const float* dout, int64_t ldd, 
                                                 int mode, float* demb, int64_t lde, int64_t n_nodes, int64_t C, void* ws,
                                                 void* stream) {
     return bucketed_pool_bwd(dout, ldd, pos, B, Smax, mode, demb, lde, n_nodes, C, ws, stream, "glass_segment_pool_bwd_exact_f32");
+}
+
+extern "C" int glass_segment_pool_max_bwd_exact_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax,
+                                                    const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C,
+                                                    void* ws, void* stream) {
+    int rc = pool_args_ok(dout, pos, demb, B, Smax, GLASS_POOL_MAX, C, ldd, lde);
+    if (rc) return rc;
+    GLASS_REQUIRE(argmax && ws && aligned16(ws), "segment_pool_max_bwd_exact: argmax and a 16-B aligned workspace required");
+    const bool vec = C % 4 == 0 && ldd % 4 == 0 && lde % 4 == 0 && aligned16(dout) && aligned16(demb);
+    const int gl = pair_group_log2(C, vec);
+    hipStream_t st = (hipStream_t)stream;
+    BucketLists bl;
+    rc = bucket_build(pos, B, Smax, -1, false, n_nodes, ws, st, &bl, true);
+    if (rc) return rc;
+    const unsigned gg = (unsigned)ceil_div(n_nodes, (int64_t)(kBlock >> gl));
+    if (vec)
+        hipLaunchKernelGGL(pool_max_gather_kernel<4>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, argmax, bl.off, bl.list, demb, lde,
+                           n_nodes, (int)C, gl);
+    else
+        hipLaunchKernelGGL(pool_max_gather_kernel<1>, dim3(gg), dim3(kBlock), 0, st, dout, ldd, argmax, bl.off, bl.list, demb, lde,
+                           n_nodes, (int)C, gl);
+    return launch_status("glass_segment_pool_max_bwd_exact_f32");
 }

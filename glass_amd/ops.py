@@ -601,8 +601,8 @@ def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id
 # ---------------------------------------------------------------------------------------------
 # Largest padded node matrices (B * Smax entries) the ORDERED, atomic-free scatters stage in LDS (pool.hip kPoolOrderedMax,
 # readout.hip kReadoutOrderedMax).  Beyond them the pool backward and the fused readout bucket the entries by node and sum
-# in exact fixed point (bucket.h: still no float atomic); max pooling's backward uses float atomics: same values within
-# rounding, but not bitwise repeatable from run to run.  Said once, loudly, instead of silently.
+# in exact fixed point (bucket.h: still no float atomic), and so does max pooling's backward.  (warn_atomic_fallback stays
+# for callers of the C ABI's float-atomic forms through this module.)
 POOL_ORDERED_MAX, READOUT_ORDERED_MAX = 12288, 16384
 _atomic_warned = set()
 
@@ -680,8 +680,14 @@ class SegmentPoolFn(torch.autograd.Function):
                                                       demb.data_ptr(), C, n, C, ws.data_ptr(), _stream())
             _lib.check(rc, "glass_segment_pool_bwd_exact_f32")
             return demb, None, None
-        if mode == "max":
-            warn_atomic_fallback("segment pool backward", B * Smax, POOL_ORDERED_MAX)
+        if mode == "max":  # exact too: the node's subgraph list (deduplicated per row), gradients of the columns it won
+            lib = _lib.load()
+            demb = torch.empty((n, C), dtype=torch.float32, device=dout.device)
+            ws = _scratch(("pool_exact", n, B, Smax), dout.device, lib.glass_segment_pool_bwd_exact_ws_bytes(n, B, Smax) + 4 * B)
+            rc = lib.glass_segment_pool_max_bwd_exact_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, Smax, argmax.data_ptr(),
+                                                          demb.data_ptr(), C, n, C, ws.data_ptr(), _stream())
+            _lib.check(rc, "glass_segment_pool_max_bwd_exact_f32")
+            return demb, None, None
         demb = torch.zeros((n, C), dtype=torch.float32, device=dout.device)
         rc = _lib.load().glass_segment_pool_bwd_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, Smax, POOL_MODES[mode],
                                                     0 if argmax is None else argmax.data_ptr(), demb.data_ptr(), C, n,

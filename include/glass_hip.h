@@ -256,6 +256,12 @@ int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* po
 int64_t glass_segment_pool_bwd_exact_ws_bytes(int64_t n_nodes, int64_t B, int64_t Smax);
 int glass_segment_pool_bwd_exact_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode,
                                      float* demb, int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream);
+/* ... and for max pooling (argmax from glass_segment_pool_f32): node n receives, per column, the gradients of the subgraphs
+ * whose maximum it is — summed exactly over the node's (per-row deduplicated) subgraph list instead of by float atomics.
+ * `ws`: glass_segment_pool_bwd_exact_ws_bytes bytes. */
+int glass_segment_pool_max_bwd_exact_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax,
+                                         const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C, void* ws,
+                                         void* stream);
 int64_t glass_pair_pool_ws_bytes(int64_t n_nodes, int64_t B);
 int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t* pairs, int64_t B, int mode, float* out, int64_t ldo,
                         int64_t n_nodes, int64_t C, void* stream);

@@ -286,6 +286,37 @@ def test_pool_ragged(mode, C):
     assert rel_inf(y.detach().cpu(), ref.detach()) < 1e-6
     assert float(y[3].abs().max()) == 0.0
     assert rel_inf(eg.grad.cpu(), ec.grad) < 1e-6
+    g1 = eg.grad.clone()   # no float atomic in any mode (max: exact sums over the node's subgraph list): bitwise repeatable
+    eg.grad = None
+    ops.segment_pool(eg, post.to(DEV), mode).backward(gout.to(DEV))
+    assert torch.equal(g1, eg.grad)
+
+
+def test_pool_max_backward_with_repeated_nodes():
+    """Max pooling's backward through the node-bucketed lists: a node named twice by one row (a tie between its own two
+    entries) counts once for it, a node that wins most columns in every subgraph collects all their gradients."""
+    from glass_amd import ops
+    n, B, S, C = 50, 300, 9, 20
+    rng = np.random.default_rng(3)
+    pos = rng.integers(0, n, (B, S))
+    pos[:, 3] = pos[:, 1]                   # a repeated node in every row
+    pos[rng.random((B, S)) < 0.2] = -1
+    pos[:, 0] = 5                           # node 5 in every subgraph
+    emb = torch.randn(n, C, generator=torch.Generator().manual_seed(1))
+    emb[5] += 3.0                           # node 5 wins most columns everywhere
+    gout = torch.randn(B, C, generator=torch.Generator().manual_seed(2))
+    post = torch.from_numpy(pos)
+    ec = emb.double().requires_grad_(True)
+    batch, p = O.pad_to_batch(post)
+    O.segment_pool(ec[p], batch, B, "max").backward(gout.double())
+    eg = emb.to(DEV).requires_grad_(True)
+    y = ops.segment_pool(eg, post.to(DEV), "max")
+    y.backward(gout.to(DEV))
+    assert rel_inf(eg.grad.cpu(), ec.grad) < 1e-6
+    g1 = eg.grad.clone()
+    eg.grad = None
+    ops.segment_pool(eg, post.to(DEV), "max").backward(gout.to(DEV))
+    assert torch.equal(g1, eg.grad)
 
 
 @pytest.mark.parametrize("mode", ["sum", "mean", "size"])
