@@ -162,6 +162,16 @@ def test_step_program_entry_points_validate_on_the_host():
     assert lib.glass_readout_ws_bytes(80, 128, 6) >= 8 * 2 * 80 * 128 + 4 * (4 * 128 + 80 * 128 + 80 * 6 + 80)
     assert lib.glass_readout_ws_bytes(0, 128, 6) == -1
     assert lib.glass_readout_scatter_ws_bytes(1000, 80, 10) == 0 and lib.glass_readout_scatter_ws_bytes(50000, 200, 155) > 4 * 2 * 200 * 155
+    # node-bucketed exact backward of the pools (bucket.h): offsets + rank + list (+ subgraph scales unless node pairs)
+    assert lib.glass_pair_pool_ws_bytes(17080, 131072) == 4 * (17084 + 4 * 131072)
+    assert lib.glass_segment_pool_bwd_exact_ws_bytes(3000, 500, 37) == 4 * (3004 + 2 * 500 * 37 + 500)
+    assert lib.glass_segment_pool_bwd_exact_ws_bytes(3000, 500, 2) == lib.glass_pair_pool_ws_bytes(3000, 500)
+    assert lib.glass_pair_pool_ws_bytes(0, 5) == 0
+    # exact GraphNorm accumulators: everything at hidden 64, the forward sums alone also at hidden 128
+    assert lib.glass_gn_exact_supported(64) == 1 and lib.glass_gn_exact_supported(128) == 0
+    assert lib.glass_gn_exact_fwd_supported(64) == 1 and lib.glass_gn_exact_fwd_supported(128) == 1 and lib.glass_gn_exact_fwd_supported(256) == 0
+    # layer 0's trans kernel gathers from the embedding table at every dense width
+    assert all(lib.glass_dual_linear_fwd_gather_supported(h) == 1 for h in (8, 17, 64, 128, 256, 512))
     args = [p, 128, p, p, p, p, 80, 10, 2, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 1000, 128, None, None, None, None,
             None, 0, None, None]
     assert lib.glass_readout_train_f32(*args) == -3  # max pooling is not fusable
