@@ -57,6 +57,7 @@ sys.path.insert(0, ROOT)
 
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md §L2: aggregate of the 8 XCD L2s
 HBM_PEAK_GBPS = 8000.0   # spec (6.29 TB/s measured achievable copy)
+HBM_COPY_GBPS = 6290.0   # MI355X_MICROARCH.md §HBM: what a float4 copy achieves; an "HBM" rate above it was cache-assisted
 IC_GATHER_GBPS = 8600.0  # MI355X_MICROARCH.md §Indexed rows: uniformly random rows of a 38 MB table (Infinity Cache), chip-wide
 MFMA_F32_TFLOPS = 157.3  # dense fp32 matrix-core peak
 L2_XCD_BYTES = 4 << 20
@@ -240,7 +241,9 @@ def roofline_hbm_entries(dev):
     b = _k1_alg_bytes(n, n, H)
     out.append({"shape": "permutation N=4000000 (degree 1, no reuse)", "H": H, "bound": "hbm", "avg_launch_us": t * 1e6,
                 "alg_bytes_per_launch": b, "achieved": b / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": b / t / 1e9 / HBM_PEAK_GBPS})
+                "frac": b / t / 1e9 / HBM_PEAK_GBPS, "cache_assisted": False, "evidence_for_hbm_target": True,
+                "label": "HBM-bound, no reuse: every X row is fetched exactly once and X (1 GB) is 4x the Infinity Cache — THE "
+                         "figure the >= 0.60-of-HBM-roofline target is answered with"})
     del op, keep, col, rowptr
     # (b) uniform random graph, N = 2 M, 6 M undirected pairs (mean degree 6): X = 512 MB > Infinity Cache
     n, pairs = 2_000_000, 6_000_000
@@ -255,12 +258,41 @@ def roofline_hbm_entries(dev):
                            torch.full((2 * pairs, ), 1.0 / 6.0, device=dev), n, n)
     t, keep = k1_back_to_back(op, H, launches=10, replays=3)
     b = _k1_alg_bytes(2 * pairs, n, H)
+    rate = b / t / 1e9
     out.append({"shape": "uniform N=2000000 nnz=12000000 (mean degree 6)", "H": H, "bound": "hbm", "avg_launch_us": t * 1e6,
-                "alg_bytes_per_launch": b, "achieved": b / t / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": b / t / 1e9 / HBM_PEAK_GBPS})
+                "alg_bytes_per_launch": b, "achieved": rate, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": rate / HBM_PEAK_GBPS, "cache_assisted": rate > HBM_COPY_GBPS, "evidence_for_hbm_target": False,
+                "label": "memory-side (HBM + Infinity Cache): X is 512 MB, half of it fits the 256 MiB Infinity Cache and each row "
+                         "is gathered 6 times, so part of the algorithmic bytes never reaches HBM — a rate above the 6.3 TB/s an HBM "
+                         "copy achieves is cache-assisted, not HBM evidence"})
     del op, keep
     torch.cuda.empty_cache()
     return out
+
+
+_PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "ROCTRACER_", "HSA_TOOLS_")
+
+
+def under_profiler(env=None):
+    """True when this process was started by a profiler (rocprofv3 preloads its tool library and exports ROCP_* /
+    ROCPROF* variables).  A child rocprofv3 started from here would inherit them: its launcher would initialise the GPU
+    before it execs the program (the exec-after-GPU-init this pool forbids) and the outer trace would be instrumented
+    twice."""
+    env = os.environ if env is None else env
+    if "rocprof" in env.get("LD_PRELOAD", "").lower():
+        return True
+    return any(k.startswith(_PROFILER_ENV_PREFIXES) for k in env)
+
+
+def child_env_without_profiler(env=None):
+    """The environment for a child process that must not inherit an outer profiler's hooks."""
+    env = dict(os.environ if env is None else env)
+    for k in list(env):
+        if k.startswith(_PROFILER_ENV_PREFIXES):
+            del env[k]
+    if "rocprof" in env.get("LD_PRELOAD", "").lower():
+        del env["LD_PRELOAD"]
+    return env
 
 
 def k1_pmc_traffic(workload, H, timeout=240):
@@ -276,11 +308,15 @@ def k1_pmc_traffic(workload, H, timeout=240):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if workload not in ("ppi_bp", "hpo_neuro", "em_user", "powerlaw") or not os.path.exists(exe) or not os.path.exists(rocprof):
         return None, "no stand-alone generator for this shape, or spmm_bench / rocprofv3 missing"
+    if under_profiler():
+        return None, "running under a profiler (LD_PRELOAD / ROCP_* / ROCPROF_* set): the child PMC passes are skipped"
     vals = {}
+    d = None
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             d = tempfile.mkdtemp(prefix="glass_pmc_", dir="/tmp")
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = child_env_without_profiler()
+            env["TMPDIR"] = "/tmp"
             subprocess.run([rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", exe, workload,
                             str(H), "10"], cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, check=True)
@@ -291,8 +327,12 @@ def k1_pmc_traffic(workload, H, timeout=240):
             launches = sum(1 for r in rows if r["Kernel_Name"].split("(")[0] == lead[0])
             vals[ctr] = sum(float(r["Counter_Value"]) for r in rows) / launches
             shutil.rmtree(d, ignore_errors=True)
+            d = None
     except Exception as e:  # noqa: BLE001 — any failure means "not measured"
         return None, f"PMC pass failed: {type(e).__name__}"
+    finally:
+        if d is not None:
+            shutil.rmtree(d, ignore_errors=True)
     return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
         "this run: child rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB, FETCH_SIZE x2 per the "
         "gfx950 rule) on tools/bin/spmm_bench at the same shape")
@@ -330,13 +370,58 @@ def dense_flop_model(N, H, L, pos_batches, lab_cap):
     return {k: v * L for k, v in ref.items()}, {k: v * L for k, v in ex.items()}
 
 
+def shared_workload(name, n_batches, world, rank):
+    """The synthetic workload, made BEFORE init_process_group: rank 0 generates it once (config 5: a 20 M-edge rejection
+    sampler, ~a minute) and publishes it atomically as a temp .npz; the other ranks wait for the FILE, not inside a
+    collective, so no process-group timeout is running meanwhile, and a rank-0 failure shows up as their own timeout with
+    a message.  Returns (workload, arrays, share path or None); rank 0 removes the file (`finally`) once a
+    barrier has told it that every rank holds the data."""
+    import numpy as np
+    from glass_amd import synth
+    if world == 1:
+        w, *arrs = synth.make_workload(name, seed=0, n_batches=n_batches * world)
+        return w, tuple(arrs), None
+    share = f"/tmp/glass_bench_{os.environ.get('MASTER_PORT', '0')}_{name}_{world}.npz"
+    if rank == 0:
+        w, *arrs = synth.make_workload(name, seed=0, n_batches=n_batches * world)
+        np.savez(share + ".tmp.npz", **dict(zip(("ei", "ew", "x", "pos", "y"), arrs)))
+        os.replace(share + ".tmp.npz", share)
+        return w, tuple(arrs), share
+    w = synth.WORKLOADS[name]
+    deadline = time.time() + float(os.environ.get("GLASS_BENCH_WORKLOAD_TIMEOUT", "1800"))
+    while not os.path.exists(share):
+        if time.time() > deadline:
+            raise SystemExit(f"bench.py rank {rank}: rank 0 did not publish the workload ({share}) in time")
+        time.sleep(0.2)
+    with np.load(share) as z:
+        arrs = tuple(z[k] for k in ("ei", "ew", "x", "pos", "y"))
+    return w, arrs, share
+
+
 def dry_run(args, world, rank):
-    """Process-group plumbing without a GPU (gloo): the same barrier / max-over-ranks / rank-0-prints protocol."""
+    """Process-group plumbing without a GPU (gloo): the workload hand-over (rank 0 generates, the others load the file before
+    any collective), the same barrier / max-over-ranks / rank-0-prints protocol, and the `collective` block every N > 1 line
+    carries.  The CPU suite runs it with --gpus 8 (tests/test_bench_launcher.py)."""
+    import zlib
     import torch.distributed as td
+    name = args.workload if args.workload in ("tiny", "density", "ppi_bp") else "tiny"  # (no minute-long samplers in a dry run)
+    w, arrs, share = shared_workload(name, 2, world, rank)
+    try:
+        if world > 1:
+            td.init_process_group("gloo")
+            td.barrier()
+    finally:
+        if share is not None and rank == 0 and os.path.exists(share):
+            os.remove(share)
+    crc = float(zlib.crc32(arrs[0].tobytes()) ^ zlib.crc32(arrs[3].tobytes()))
+    same = True
     if world > 1:
-        td.init_process_group("gloo")
-    if world > 1:
-        td.barrier()
+        lo, hi = torch.tensor([crc], dtype=torch.float64), torch.tensor([crc], dtype=torch.float64)
+        td.all_reduce(lo, op=td.ReduceOp.MIN)
+        td.all_reduce(hi, op=td.ReduceOp.MAX)
+        same = bool(lo.item() == hi.item())
+    # this rank's batches exactly as main() slices them: rank r owns batches r, r + world, ...
+    pos = arrs[3].reshape(2 * world, w.batch, -1)[rank::world]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         pass
@@ -350,9 +435,15 @@ def dry_run(args, world, rank):
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                           "data": "synthetic", "dry_run": True,
-                          "config": {"workload": args.workload, "parallelism": f"subgraph-batch dp{world}"}}), flush=True)
+                          "config": {"workload": name, "parallelism": f"subgraph-batch dp{world}",
+                                     "batches_per_rank": int(pos.shape[0]), "workload_identical_on_all_ranks": same},
+                          "collective": {"world_size": td.get_world_size() if world > 1 else 1, "backend": "gloo" if world > 1 else None,
+                                         "rccl_version": None, "in_graph": False, "capture_error": None, "exposed_us": None,
+                                         "payload_bytes": None}}), flush=True)
     if world > 1:
         td.destroy_process_group()
+    if not same:
+        sys.exit(3)
 
 
 def main():
@@ -377,35 +468,22 @@ def main():
         local_rank = local_rank % n_dev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as td
-        if backend == "nccl":
-            td.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
-        else:
-            td.init_process_group(backend)
 
     from glass_amd import synth, ops, graph as ggraph, _lib
     from glass_amd.factory import build_glass
 
     n_batches = 16
-    if world == 1:
-        w, ei_np, ew_np, x_np, pos_np, y_np = synth.make_workload(args.workload, seed=0, n_batches=n_batches * world)
-    else:
-        # rank 0 generates the synthetic workload ONCE (config 5: a 20 M-edge rejection sampler), the other ranks load it
-        import numpy as np
-        import torch.distributed as td
-        share = f"/tmp/glass_bench_{os.environ.get('MASTER_PORT', '0')}_{args.workload}.npz"
-        w = synth.WORKLOADS[args.workload]
-        if rank == 0:
-            w, ei_np, ew_np, x_np, pos_np, y_np = synth.make_workload(args.workload, seed=0, n_batches=n_batches * world)
-            np.savez(share + ".tmp.npz", ei=ei_np, ew=ew_np, x=x_np, pos=pos_np, y=y_np)
-            os.replace(share + ".tmp.npz", share)
-        td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()
-        if rank != 0:
-            with np.load(share) as z:
-                ei_np, ew_np, x_np, pos_np, y_np = z["ei"], z["ew"], z["x"], z["pos"], z["y"]
-        td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()
-        if rank == 0:
+    w, (ei_np, ew_np, x_np, pos_np, y_np), share = shared_workload(args.workload, n_batches, world, rank)
+    try:
+        if world > 1:
+            import torch.distributed as td
+            if backend == "nccl":
+                td.init_process_group("nccl", device_id=dev)  # RCCL over xGMI
+            else:
+                td.init_process_group(backend)
+            td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()  # every rank holds the workload
+    finally:
+        if share is not None and rank == 0 and os.path.exists(share):
             os.remove(share)
     if args.dropout is not None:
         w.dropout = args.dropout
@@ -468,8 +546,8 @@ def main():
     times = sorted(max_over_ranks(times))
     dt = times[len(times) // 2]  # the median block
     last_loss = stepper.last_loss()
-    collective = stepper.collective_share() if hasattr(stepper, "collective_share") else None
-    if world > 1 and collective is not None:
+    collective = stepper.collective_share() if world > 1 else None
+    if collective is not None:
         # exposed share of the exchange = step time with it - step time without it (same blocks protocol; the ranks'
         # parameters diverge from here on, which only the timing below and the instrumented pass see)
         if stepper.graphed and not stepper.collective_in_graph:
@@ -482,7 +560,6 @@ def main():
         else:
             collective["exposed_us"] = None
             collective["exposed_method"] = "the exchange is captured inside the step's graph: no separate timing"
-        collective["capture_error"] = stepper.capture_error
 
     # ---- device time per C-ABI call inside the step, K1 roofline (rank 0 reports; every rank runs the same code) ----
     # A second, instrumented pass of the same steps, eager (events cannot sit inside the replayed graph).  An eager
@@ -556,9 +633,15 @@ def main():
                     "chip-wide, MI355X_MICROARCH.md §Indexed rows)" if x_bytes <= IC_BYTES else
                     "beyond the Infinity Cache: L2 misses go to HBM (8 TB/s spec)"),
                 "utilisation": {"l2_algorithmic": u_l2, "memory_side": u_mem, "memory_level": mem_level,
+                                "memory_side_label": "memory-side (HBM + Infinity Cache): FETCH_SIZE / WRITE_SIZE count the L2's "
+                                                     "fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md §HBM) — "
+                                                     "not HBM-only traffic",
                                 "note": "frac = the larger of the two; algorithmic bytes / 34.5 TB/s (every gathered byte passes "
                                         "an XCD L2) and memory-side traffic / that level's peak"},
                 "frac_of_hbm_peak_algorithmic": alg_rate / HBM_PEAK_GBPS,
+                "algorithmic_cache_assisted": alg_rate > HBM_COPY_GBPS,
+                "hbm_evidence": "algorithmic bytes / 8 TB/s above 6.3 / 8 = 0.79 cannot have come from HBM alone (cache-assisted); "
+                                "the HBM-bound figure of this kernel is roofline_hbm[0] (no-reuse permutation)",
                 "alg_bytes_per_launch": alg_bytes, "avg_launch_us": k1_avg * 1e6, "launches_timed": len(k1_us),
                 "back_to_back_us": t_b2b * 1e6, "bracketed_standalone_us": t_brk * 1e6,
                 "bracket_cost_us": bracket_cost * 1e6, "traffic_source": traffic_source,

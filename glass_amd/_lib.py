@@ -95,6 +95,7 @@ SIGNATURES = {
     "glass_spmm_reduce_rows_f32": (c_int, [_P, _P, _I, _I, _P, _I, _P]),
     "glass_segment_pool_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _I, _P, _I, _I, _P]),
     "glass_segment_pool_bwd_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _P, _I, _I, _I, _P]),
+    "glass_segment_pool_bwd_atomic_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _P, _I, _I, _I, _P]),
     "glass_segment_pool_max_bwd_exact_f32": (c_int, [_P, _I, _P, _I, _I, _P, _P, _I, _I, _I, _P, _P]),
     "glass_pair_pool_ws_bytes": (c_int64, [_I, _I]),
     "glass_segment_pool_bwd_exact_ws_bytes": (c_int64, [_I, _I, _I]),

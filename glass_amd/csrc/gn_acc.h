@@ -8,7 +8,13 @@
 // float atomics are not — and every consumer workgroup folds the replicas itself in its prologue (one round trip of 16-32
 // loads per thread).  Representation of a partial sum v (a double): v * 2^52 = hi * 2^40 + lo, hi = floor(v * 2^12) as int64,
 // lo in [0, 2^40): absolute resolution 2^-52 (2.2e-16) per workgroup partial, range |sum| < 2^50 — far inside what fp32
-// activations and their squares can reach over 10^6 rows; out-of-range partials saturate.  Layout: int64
+// activations and their squares can reach over 10^6 rows.  A partial that is NaN, infinite or out of that range does not
+// saturate into a finite wrong sum: it sets a STICKY POISON BIT — bit 63 of the lo limb, by an integer atomicOr; the lo limbs
+// of up to 2^22 in-range adds stay below 2^62, so no carry ever reaches or clears it, and OR commutes with itself like the
+// adds do — and every fold turns a poisoned column into NaN, which the consumers' arithmetic then propagates exactly as the
+// reference's float sums do (a diverging run stays visible; tests/test_gpu_model.py::test_nonfinite_values_reach_the_outputs).
+// Resolution caveat: contributions below 2^-52 (forward) / 2^-64 (backward) of a PARTIAL are truncated — "exact" means the
+// integer sum of the partials is exact and order-independent, not that each partial is represented exactly.  Layout: int64
 // [kAccRep][2 quantities][C][2 limbs], zeroed once per step by the prologue launch (glass_step_prologue_f32).
 #pragma once
 #include "common.h"
@@ -32,16 +38,25 @@ constexpr int kAccRep = GLASS_ACC_REP;
 constexpr double kAccScaleFwd = 4096.0;      // 2^12
 constexpr double kAccScaleBwd = 16777216.0;  // 2^24
 
+constexpr unsigned long long kAccPoison = 1ull << 63;  // bit 63 of a lo limb: some partial of this column was not representable
+// the value of a folded column: NaN when any replica carried the poison bit
+__device__ __forceinline__ double gn_acc_value(long long hi, long long lo, bool poisoned, double inv_scale) {
+    return poisoned ? __longlong_as_double(0x7ff8000000000000ll) : ((double)hi + (double)lo * (1.0 / 1099511627776.0)) * inv_scale;
+}
+
 __device__ __forceinline__ size_t gn_acc_index(int rep, int which, int c, int C) { return (((size_t)rep * 2 + which) * C + c) * 2; }
 __host__ __device__ constexpr int64_t gn_acc_words(int64_t C) { return (int64_t)kAccRep * 2 * C * 2; }
 
 __device__ __forceinline__ void gn_acc_add(long long* __restrict__ acc, int rep, int which, int c, int C, double v, double scale) {
-    double sv = v * scale;
-    sv = fmin(fmax(sv, -4.0e18), 4.0e18);
+    const double sv = v * scale;
+    unsigned long long* p = reinterpret_cast<unsigned long long*>(acc + gn_acc_index(rep, which, c, C));
+    if (!(fabs(sv) <= 4.0e18)) {  // NaN, +-Inf or beyond the fixed-point range: poison the column (sticky, order-independent)
+        atomicOr(p + 1, kAccPoison);
+        return;
+    }
     const double fl = floor(sv);
     const long long hi = (long long)fl;
     const long long lo = (long long)((sv - fl) * 1099511627776.0);  // 2^40
-    unsigned long long* p = reinterpret_cast<unsigned long long*>(acc + gn_acc_index(rep, which, c, C));
     atomicAdd(p, (unsigned long long)hi);
     atomicAdd(p + 1, (unsigned long long)lo);
 }
@@ -58,14 +73,16 @@ __device__ __forceinline__ void gn_acc_fold(const long long* __restrict__ acc, i
         const int k = c / C_each, cl = c - k * C_each;
         const long long* base = acc + (size_t)k * gn_acc_words(C_each);
         long long hi = 0, lo = 0;
+        bool bad = false;
 #pragma unroll
         for (int r = 0; r < kAccRep; ++r) {
             if (r >= n_rep) break;  // (the producers of this sum used the first n_rep replicas)
             const long long* p = base + gn_acc_index(r, which, cl, C_each);
             hi += p[0];
             lo += p[1];
+            bad |= p[1] < 0;
         }
-        out[item] = ((double)hi + (double)lo * (1.0 / 1099511627776.0)) * inv;
+        out[item] = gn_acc_value(hi, lo, bad, inv);
     }
     __syncthreads();
 }
@@ -162,12 +179,14 @@ __device__ __forceinline__ void gn_coef_early_finish(const GnExactSrc& src, int 
     }
     if (t < 2 * C) {
         long long hi = 0, lo = 0;
+        bool bad = false;
 #pragma unroll
         for (int r = 0; r < kAccRep; ++r) {
             hi += r < src.n_rep ? E.h[r] : 0;
             lo += r < src.n_rep ? E.l[r] : 0;
+            bad |= r < src.n_rep && E.l[r] < 0;
         }
-        sums[t] = ((double)hi + (double)lo * (1.0 / 1099511627776.0)) * (1.0 / kAccScaleFwd);
+        sums[t] = gn_acc_value(hi, lo, bad, 1.0 / kAccScaleFwd);
     }
     __syncthreads();
     if (t < C) {
@@ -212,14 +231,17 @@ __device__ __forceinline__ bool gn_acc_col_sums(const long long* __restrict__ ac
         vl[r] = p[1];
     }
     long long hi = 0, lo = 0;
+    int bad = 0;
 #pragma unroll
     for (int r = 0; r < kAccRep / 2; ++r) {
         hi += r < per ? vh[r] : 0;
         lo += r < per ? vl[r] : 0;
+        bad |= (r < per && vl[r] < 0) ? 1 : 0;
     }
     hi += __shfl_xor(hi, 32);
     lo += __shfl_xor(lo, 32);
-    const double v = ((double)hi + (double)lo * (1.0 / 1099511627776.0)) * (1.0 / scale);
+    bad |= __shfl_xor(bad, 32);
+    const double v = gn_acc_value(hi, lo, bad != 0, 1.0 / scale);
     const double other = __shfl_xor(v, 16);  // lanes with which == 0 receive sum 1
     v0 = v;
     v1 = other;

@@ -512,32 +512,59 @@ extern "C" int glass_segment_pool_f32(const float* emb, int64_t lde, const int64
     return launch_status("glass_segment_pool_f32");
 }
 
-extern "C" int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax,
-                                          int mode, const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes,
-                                          int64_t C, void* stream) {
-    int rc = pool_args_ok(dout, pos, demb, B, Smax, mode, C, ldd, lde);
-    if (rc) return rc;
-    GLASS_REQUIRE(mode != GLASS_POOL_MAX || argmax, "segment_pool_bwd: max pooling needs argmax");
+static int pool_bwd_launch_atomic(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode,
+                                  const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C, hipStream_t st) {
     const bool vec = C % 4 == 0 && ldd % 4 == 0 && aligned16(dout);
     const int cw = (int)ceil_div(C, vec ? 4 : 1);
     const int tc = pow2_ceil_cap(cw, kBlock);
     int tc_log2 = 0;
     while ((1 << tc_log2) < tc) ++tc_log2;
     dim3 grid((unsigned)B, (unsigned)ceil_div(cw, tc));
-    hipStream_t st = (hipStream_t)stream;
-    if (mode != GLASS_POOL_MAX && B * Smax + B <= kPoolOrderedMax) {
-        // atomic-free and bitwise repeatable (demb is zero-filled by the caller; untouched rows stay zero)
-        hipLaunchKernelGGL(pool_bwd_ordered_kernel, dim3((unsigned)B), dim3(kBlock), sizeof(int32_t) * (size_t)(B * Smax + B), st,
-                           dout, ldd, pos, (int)Smax, (int)B, mode, demb, lde, n_nodes, (int)C);
-        return launch_status("glass_segment_pool_bwd_f32");
-    }
     if (vec)
         hipLaunchKernelGGL(pool_bwd_kernel<4>, grid, dim3(kBlock), 0, st, dout, ldd, pos, (int)Smax, mode, argmax, demb,
                            lde, n_nodes, (int)C, tc_log2);
     else
         hipLaunchKernelGGL(pool_bwd_kernel<1>, grid, dim3(kBlock), 0, st, dout, ldd, pos, (int)Smax, mode, argmax, demb,
                            lde, n_nodes, (int)C, tc_log2);
+    return 0;
+}
+
+// The bitwise-repeatable entry: ordered, atomic-free while pos fits the LDS staging.  Beyond it (and for max pooling) it
+// REFUSES with GLASS_E_WS instead of silently switching to float atomics: the caller picks glass_segment_pool_bwd_exact_f32 /
+// glass_segment_pool_max_bwd_exact_f32 (workspace, exact) or, knowingly, glass_segment_pool_bwd_atomic_f32.
+extern "C" int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax,
+                                          int mode, const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes,
+                                          int64_t C, void* stream) {
+    int rc = pool_args_ok(dout, pos, demb, B, Smax, mode, C, ldd, lde);
+    if (rc) return rc;
+    (void)argmax;
+    if (mode == GLASS_POOL_MAX) {
+        set_error("glass_segment_pool_bwd_f32: max pooling has no atomic-free form here — use glass_segment_pool_max_bwd_exact_f32 "
+                  "(workspace) or glass_segment_pool_bwd_atomic_f32");
+        return GLASS_E_WS;
+    }
+    if (B * Smax + B > kPoolOrderedMax) {
+        set_error("glass_segment_pool_bwd_f32: B*Smax + B exceeds the ordered scatter's LDS staging — use "
+                  "glass_segment_pool_bwd_exact_f32 (workspace) or glass_segment_pool_bwd_atomic_f32");
+        return GLASS_E_WS;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    // atomic-free and bitwise repeatable (demb is zero-filled by the caller; untouched rows stay zero)
+    hipLaunchKernelGGL(pool_bwd_ordered_kernel, dim3((unsigned)B), dim3(kBlock), sizeof(int32_t) * (size_t)(B * Smax + B), st,
+                       dout, ldd, pos, (int)Smax, (int)B, mode, demb, lde, n_nodes, (int)C);
     return launch_status("glass_segment_pool_bwd_f32");
+}
+
+// The float-atomic scatter under its own name (any size, all four modes; demb zero-filled by the caller): one launch, results
+// within rounding of the exact forms but ORDER-DEPENDENT once three or more entries share a node — not bitwise repeatable.
+extern "C" int glass_segment_pool_bwd_atomic_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax,
+                                                 int mode, const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes,
+                                                 int64_t C, void* stream) {
+    int rc = pool_args_ok(dout, pos, demb, B, Smax, mode, C, ldd, lde);
+    if (rc) return rc;
+    GLASS_REQUIRE(mode != GLASS_POOL_MAX || argmax, "segment_pool_bwd_atomic: max pooling needs argmax");
+    pool_bwd_launch_atomic(dout, ldd, pos, B, Smax, mode, argmax, demb, lde, n_nodes, C, (hipStream_t)stream);
+    return launch_status("glass_segment_pool_bwd_atomic_f32");
 }
 
 

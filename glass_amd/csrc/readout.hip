@@ -620,28 +620,6 @@ __global__ __launch_bounds__(kBlock) void readout_backfill_scalar_kernel(const f
     }
 }
 
-// R4: d jk[n] += A * g on the pooled rows
-__global__ __launch_bounds__(kBlock) void readout_scatter_kernel(const int64_t* __restrict__ pos, int Smax,
-                                                                 const float* __restrict__ dys,
-                                                                 const float* __restrict__ coef, float* __restrict__ dx,
-                                                                 int64_t lddx, int64_t n_nodes, int C, int tc_log2) {
-    const int TC = 1 << tc_log2, rpb = kBlock >> tc_log2;
-    const int tc = threadIdx.x & (TC - 1), tr = threadIdx.x >> tc_log2;
-    const int c0 = tc * 4, b = blockIdx.x;
-    if (c0 >= C) return;
-    const float4 A = *reinterpret_cast<const float4*>(coef + c0);
-    const float4 g = *reinterpret_cast<const float4*>(dys + (int64_t)b * C + c0);
-    const float add[4] = {A.x * g.x, A.y * g.y, A.z * g.z, A.w * g.w};
-    const int64_t* prow = pos + (int64_t)b * Smax;
-    for (int j = tr; j < Smax; j += rpb) {
-        const int64_t node = prow[j];
-        if (node < 0 || node >= n_nodes) continue;
-        float* dst = dx + node * lddx + c0;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) atomicAdd(dst + k, add[k]);
-    }
-}
-
 // R4 beyond the ordered scatter's LDS staging, still without float atomics: the entries are bucketed by node (bucket.h) and a
 // pooled node's row gets  d jk[n] += sum over its entries of A * g[subgraph]  with the sum taken in exact fixed point — the
 // lists' arbitrary order does not reach the result.  One lane group (16 B per lane) per node; long lists by the whole
@@ -757,6 +735,12 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
     GLASS_REQUIRE(aligned16(ws) && (vec || mask),
                   "readout_train: operands must be 16-B aligned with C %% 4 == 0 and ld %% 4 == 0 — or the label bytes given "
                   "(scalar form for any C)");
+    if (B * Smax > kReadoutOrderedMax && !scatter_ws) {
+        // (this entry promises bitwise repeatable results: it never falls back to float atomics)
+        set_error("readout_train: B*Smax = %lld exceeds the ordered scatter's LDS staging (%d entries): pass scatter_ws "
+                  "(glass_readout_scatter_ws_bytes bytes)", (long long)(B * Smax), (int)kReadoutOrderedMax);
+        return GLASS_E_WS;
+    }
     hipStream_t st = (hipStream_t)stream;
     const ReadoutWs w = carve_ws(ws, B, C, K);
     const int tc = pow2_ceil_cap(vec ? C / 4 : C, kBlock);
@@ -834,9 +818,6 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
         if (rc) return rc;
         hipLaunchKernelGGL(readout_gather_add_kernel, dim3((unsigned)ceil_div(n_nodes, (int64_t)(kBlock / tc))), dim3(kBlock), 0, st,
                            bl.off, bl.list, w.dys, w.coef, djk, lddj, n_nodes, (int)C, tc_log2);
-    } else {
-        hipLaunchKernelGGL(readout_scatter_kernel, dim3((unsigned)B), dim3(kBlock), 0, st, pos, (int)Smax, w.dys, w.coef,
-                           djk, lddj, n_nodes, (int)C, tc_log2);
     }
     return launch_status("glass_readout_train_f32");
 }

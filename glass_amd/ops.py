@@ -601,29 +601,24 @@ def graphnorm(x, gamma, beta, alpha, eps=1e-5, act=ACT_NONE, p_drop=0.0, call_id
 # ---------------------------------------------------------------------------------------------
 # Largest padded node matrices (B * Smax entries) the ORDERED, atomic-free scatters stage in LDS (pool.hip kPoolOrderedMax,
 # readout.hip kReadoutOrderedMax).  Beyond them the pool backward and the fused readout bucket the entries by node and sum
-# in exact fixed point (bucket.h: still no float atomic), and so does max pooling's backward.  (warn_atomic_fallback stays
-# for callers of the C ABI's float-atomic forms through this module.)
+# in exact fixed point (bucket.h: still no float atomic), and so does max pooling's backward.  The C ABI's one float-atomic
+# scatter (glass_segment_pool_bwd_atomic_f32) is not used by this module.
 POOL_ORDERED_MAX, READOUT_ORDERED_MAX = 12288, 16384
-_atomic_warned = set()
-
-
-def warn_atomic_fallback(what, entries, limit):
-    if what in _atomic_warned:
-        return
-    _atomic_warned.add(what)
-    import warnings
-    warnings.warn(f"{what}: {entries} padded subgraph entries exceed the {limit} the ordered (atomic-free) scatter stages in "
-                  "LDS (or max pooling is used); falling back to float atomics — results stay within rounding but are not "
-                  "bitwise repeatable between runs", RuntimeWarning, stacklevel=3)
 
 
 _scratch_bufs = {}
 
 
+_retired_scratch = []
+
+
 def _scratch(key, device, nbytes):
-    """Uninitialised device scratch of at least `nbytes`, one buffer per key (kept for the process's life)."""
+    """Uninitialised device scratch of at least `nbytes`, one buffer per key (kept for the process's life).  A buffer that
+    has to grow is RETIRED, not freed: a captured hipGraph may still launch with its pointer (as _wgrad_workspace does)."""
     buf = _scratch_bufs.get((device, key))
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _retired_scratch.append(buf)
         buf = _scratch_bufs[(device, key)] = torch.empty(int(nbytes) + 16, dtype=torch.uint8, device=device)
     return buf
 
@@ -683,7 +678,7 @@ class SegmentPoolFn(torch.autograd.Function):
         if mode == "max":  # exact too: the node's subgraph list (deduplicated per row), gradients of the columns it won
             lib = _lib.load()
             demb = torch.empty((n, C), dtype=torch.float32, device=dout.device)
-            ws = _scratch(("pool_exact", n, B, Smax), dout.device, lib.glass_segment_pool_bwd_exact_ws_bytes(n, B, Smax) + 4 * B)
+            ws = _scratch(("pool_exact_max", n, B, Smax), dout.device, lib.glass_segment_pool_bwd_exact_ws_bytes(n, B, Smax))
             rc = lib.glass_segment_pool_max_bwd_exact_f32(dout.data_ptr(), ldd, pos.data_ptr(), B, Smax, argmax.data_ptr(),
                                                           demb.data_ptr(), C, n, C, ws.data_ptr(), _stream())
             _lib.check(rc, "glass_segment_pool_max_bwd_exact_f32")

@@ -23,6 +23,11 @@ from . import utils
 
 
 CAPTURE_COLLECTIVE = os.environ.get("GLASS_CAPTURE_COLLECTIVE", "1") != "0"  # try the RCCL exchange + Adam inside the step's graph
+# A captured collective is trusted only after ONE replay of the graph has reproduced an eager step (forward/backward, eager
+# RCCL all-reduce, eager Adam) from the same state: exchanged gradient arena and updated parameters compared on every rank,
+# the verdict agreed on by all ranks.  On a mismatch the process keeps running on the split form (graph + eager collective).
+VERIFY_CAPTURED_COLLECTIVE = os.environ.get("GLASS_VERIFY_CAPTURED_COLLECTIVE", "1") != "0"
+_VERIFY_TOL = 1e-5
 
 
 class TrainStep:
@@ -49,6 +54,8 @@ class TrainStep:
         self._coll_events = []
         self.collective_in_graph = False  # the RCCL exchange + Adam were captured with the step (one replay per step)
         self.capture_error = None
+        self.capture_verified = None      # {"grad_rel_inf", "param_rel_inf", "ok"} of the replay-vs-eager check, or None
+        self._force_verify_mismatch = False  # tests: exercise the opt-out path
         self.exchange_enabled = True    # bench.py: False = skip the collectives (timing of the exposed share; ranks diverge)
 
     # -- the step body, split at the collective ---------------------------------------------------
@@ -101,13 +108,9 @@ class TrainStep:
         """Real training steps on the first batch, on a side stream: builds the CSR / plans /
         workspaces / BLAS handles outside any capture.  Runs in eager mode too, so both modes follow
         the same trajectory."""
-        import copy
-        from . import ops
         snap = None
         if self.preserve_state and self.warmup_iters > 0:
-            snap = (copy.deepcopy(self.model.state_dict()), copy.deepcopy(self.opt.state_dict()),
-                    {k: getattr(self.opt, k).clone() for k in ("exp_avg", "exp_avg_sq", "step_dev", "step_dev_shard") if hasattr(self.opt, k)},
-                    ops.rng_state(self.x.device).clone())
+            snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -120,12 +123,57 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if snap is not None:
-            self.model.load_state_dict(snap[0])          # in-place copies: arena aliasing is kept
-            self.opt.load_state_dict(snap[1])
-            for k, v in snap[2].items():
-                getattr(self.opt, k).copy_(v)
-            ops.rng_state(self.x.device).copy_(snap[3])
-            torch.cuda.synchronize()
+            self._restore(snap)
+
+    def _snapshot(self):
+        """Everything a training step changes: parameters, optimizer state (incl. the fused Adam's device-side moments and
+        step counters), the dropout stream."""
+        import copy
+        from . import ops
+        return (copy.deepcopy(self.model.state_dict()), copy.deepcopy(self.opt.state_dict()),
+                {k: getattr(self.opt, k).clone() for k in ("exp_avg", "exp_avg_sq", "step_dev", "step_dev_shard") if hasattr(self.opt, k)},
+                ops.rng_state(self.x.device).clone())
+
+    def _restore(self, snap):
+        from . import ops
+        self.model.load_state_dict(snap[0])          # in-place copies: arena aliasing is kept
+        self.opt.load_state_dict(snap[1])
+        for k, v in snap[2].items():
+            getattr(self.opt, k).copy_(v)
+        ops.rng_state(self.x.device).copy_(snap[3])
+        torch.cuda.synchronize()
+
+    def _verify_collective_capture(self):
+        """One replay of the freshly captured [forward + backward + all-reduce + Adam] graph against the same step run
+        eagerly from the same state (same batch, same dropout words): the exchanged gradient arena and the updated
+        parameters must agree on EVERY rank (rel-inf <= 1e-5: a captured collective may pick another channel count than
+        the eager one, so bitwise equality is not demanded).  The ranks agree on the verdict through an eager all-reduce
+        (MAX) — a rank must never decide alone, or the ranks would issue different collectives from then on.  State is
+        restored afterwards: the trajectory is that of a run without this check.  Returns True when the capture is trusted."""
+        import torch.distributed as td
+        snap = self._snapshot()
+        self._fwd_bwd()
+        self.bucket.all_reduce_mean()
+        self.opt.step()
+        torch.cuda.synchronize()
+        g_eager, p_eager = self.bucket.flat.clone(), self.bucket.flat_param.clone()
+        self._restore(snap)
+        self._g_fb.replay()
+        torch.cuda.synchronize()
+        g_graph, p_graph = self.bucket.flat.clone(), self.bucket.flat_param.clone()
+        self._restore(snap)
+
+        def rel(a, b):
+            d = float(b.abs().max())
+            e = float((a - b).abs().max())
+            return e / (d if d > 0 else 1.0) if (e == e and d == d) else float("inf")
+        e_g, e_p = rel(g_graph, g_eager), rel(p_graph, p_eager)
+        bad = 1.0 if (self._force_verify_mismatch or not (e_g <= _VERIFY_TOL and e_p <= _VERIFY_TOL)) else 0.0
+        flag = torch.tensor([bad], device=self.x.device)
+        td.all_reduce(flag, op=td.ReduceOp.MAX)
+        ok = float(flag.item()) == 0.0
+        self.capture_verified = {"grad_rel_inf": e_g, "param_rel_inf": e_p, "ok": ok, "tol": _VERIFY_TOL}
+        return ok
 
     def _overlap_small_bucket(self):
         """The data-parallel step with an embedding-sized gradient bucket, on the step program: worth cutting the
@@ -165,6 +213,12 @@ class TrainStep:
                     self.capture_error = repr(e)
                     torch.cuda.synchronize()
                     self._g_fb = torch.cuda.CUDAGraph()
+                if self.collective_in_graph and VERIFY_CAPTURED_COLLECTIVE and hasattr(self.bucket, "flat_param"):
+                    if not self._verify_collective_capture():
+                        # automatic opt-out: same process, split form from here on (never a re-exec of a GPU-initialised process)
+                        self.capture_error = (f"captured collective failed the replay-vs-eager check: {self.capture_verified}")
+                        self.collective_in_graph = False
+                        self._g_fb = torch.cuda.CUDAGraph()
             if not self.collective_in_graph:
                 # the collective stays outside the graph; the optimizer is two launches, cheaper eager than a
                 # second graph replay
@@ -217,20 +271,39 @@ class TrainStep:
             self._coll_events = (self._coll_events + [ev])[-64:]
 
     def collective_share(self):
-        """Mean device time of the exchange and of the optimizer part (Adam launches + parameter all-gather) over the
-        recorded steps, with the payload per step (bench.py --features nodeid)."""
-        if not self._coll_events:
+        """What the data-parallel exchange of this step looks like, for the bench line of every N > 1 run (so that "did
+        RCCL see N ranks, and in which form" is answerable from the JSON): world size and backend as torch.distributed
+        reports them, the RCCL version, whether the exchange was captured inside the step's graph (and what the capture
+        attempt or its replay-vs-eager check said), the payload per step — and, in the split form, the mean device time of
+        the exchange and of the optimizer part (Adam launches + parameter all-gather) over the recorded steps.  None on one
+        rank without a process group."""
+        import torch.distributed as td
+        if not (td.is_available() and td.is_initialized()):
             return None
-        torch.cuda.synchronize()
-        red = [a.elapsed_time(b) * 1e3 for a, b, _ in self._coll_events]
-        upd = [b.elapsed_time(c) * 1e3 for _, b, c in self._coll_events]
-        out = {"exchange_us": sum(red) / len(red), "adam_and_gather_us": sum(upd) / len(upd), "steps_timed": len(red),
+        backend = td.get_backend()
+        out = {"world_size": td.get_world_size(), "backend": backend, "rccl_version": None,
+               "in_graph": self.collective_in_graph, "collective_in_graph": self.collective_in_graph,
+               "capture_error": self.capture_error, "capture_verified": self.capture_verified,
                "small_bucket_overlaps_backward_tail": self._g_tail is not None,
-               "collective_in_graph": self.collective_in_graph}
+               "exchange_us": None, "adam_and_gather_us": None, "steps_timed": 0}
+        if backend == "nccl":
+            try:
+                out["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # noqa: BLE001 — a version string must never fail a bench line
+                out["rccl_version"] = f"unavailable ({type(e).__name__})"
         ex = getattr(self.bucket, "exchange", None)
         if ex is not None:
             out["payload_bytes"] = ex.payload_bytes()
             out["world"] = ex.world
+        else:
+            out["payload_bytes"] = {"small_allreduce": self.bucket.flat.numel() * self.bucket.flat.element_size(),
+                                    "big_reduce_scatter": 0, "big_all_gather": 0}
+            out["world"] = td.get_world_size()
+        if self._coll_events:
+            torch.cuda.synchronize()
+            red = [a.elapsed_time(b) * 1e3 for a, b, _ in self._coll_events]
+            upd = [b.elapsed_time(c) * 1e3 for _, b, c in self._coll_events]
+            out.update(exchange_us=sum(red) / len(red), adam_and_gather_us=sum(upd) / len(upd), steps_timed=len(red))
         return out
 
     def __call__(self, pos, y):

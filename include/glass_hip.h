@@ -35,6 +35,8 @@ typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a k
 #define GLASS_E_ARG (-1)       /* bad argument (null pointer, negative size, misaligned ld) */
 #define GLASS_E_PLAN (-2)      /* plan blob does not match the call (magic / sizes) */
 #define GLASS_E_UNSUPPORTED (-3)
+#define GLASS_E_WS (-4)        /* this size needs the workspace form of the call (see its *_ws_bytes query): the entry point
+                                  promises bitwise repeatable results and does not fall back to float atomics */
 
 /* pool modes: AddPool / MeanPool / MaxPool / SizePool (impl/models.py:294-319) */
 #define GLASS_POOL_SUM 0
@@ -234,14 +236,20 @@ int glass_embed_norm_bwd_adam_f32(float* G, const float* W, int64_t V, const int
  *     An all-padding row gives 0 (torch_scatter semantics).
  *     Backward scatters into demb (must be ZEROED by the caller).  sum / mean / size with B*Smax + B <= 12 288:
  *     ordered and atomic-free (pos staged in LDS; the first entry naming a node sums all its occurrences in
- *     (b, s) order) -> bitwise repeatable.  Larger batches and max pooling: float atomics, order-dependent only
- *     beyond two sharers of a node (for sum / mean / size use glass_segment_pool_bwd_exact_f32 below instead).
+ *     (b, s) order) -> bitwise repeatable.  Larger batches and max pooling: glass_segment_pool_bwd_f32 returns
+ *     GLASS_E_WS (it never switches to float atomics by itself) — call glass_segment_pool_bwd_exact_f32 /
+ *     glass_segment_pool_max_bwd_exact_f32 below (workspace, exact fixed-point sums, bitwise repeatable), or, knowingly,
+ *     glass_segment_pool_bwd_atomic_f32: the one-launch float-atomic scatter (any size, all four modes), whose result is
+ *     within rounding of the exact forms but depends on the order of the atomics once three entries share a node.
  * ---------------------------------------------------------------------------------------- */
 int glass_segment_pool_f32(const float* emb, int64_t lde, const int64_t* pos, int64_t B, int64_t Smax, int mode,
                            float* out, int64_t ldo, int32_t* argmax, int64_t n_nodes, int64_t C, void* stream);
 int glass_segment_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode,
                                const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C,
                                void* stream);
+int glass_segment_pool_bwd_atomic_f32(const float* dout, int64_t ldd, const int64_t* pos, int64_t B, int64_t Smax, int mode,
+                                      const int32_t* argmax, float* demb, int64_t lde, int64_t n_nodes, int64_t C,
+                                      void* stream);
 
 /* Node pairs (Smax = 2; sum | mean | size): the link-prediction batches of the pre-training path — replaces
  * emb[subG_node] + torch.mean(emb, dim=1) (impl/models.py:497-498, 501-503; 131 072 pairs per step, GNNEmb.py).  Same
@@ -533,7 +541,7 @@ int glass_head_linear_f32(const float* pooled, int64_t ldp, const float* W, cons
  *      dWh/dbh and dgamma/dbeta/dalpha are accumulated when acc_* != 0.
  *      Bitwise repeatable: B*Smax <= 16 384 by an ordered, atomic-free scatter of the sparse part staged in LDS; beyond that
  *      by node-bucketed exact sums when scatter_ws (glass_readout_scatter_ws_bytes bytes, uninitialised scratch) is given —
- *      with scatter_ws == NULL the large-batch scatter falls back to float atomics.  mask / lab_rows / lab_count (all three, or NULL): the label bytes and the unique
+ *      with scatter_ws == NULL such a batch is refused (GLASS_E_WS): no float atomic is reachable from this entry point.  mask / lab_rows / lab_count (all three, or NULL): the label bytes and the unique
  *      labeled rows glass_batch_labels produced for THIS pos — the pooled rows of a step are its labeled rows — then the
  *      dense part skips them and extra workgroups of the same launch write their full value: three launches, bitwise
  *      equal to the four.  C % 4 != 0 (or unaligned rows): scalar kernels, which need the label bytes (mask). */

@@ -181,21 +181,24 @@ class OracleConv(nn.Module):
 
 
 class OracleEmbZGConv(nn.Module):
-    """`EmbZGConv` (models.py:177-272), gn=True."""
-    def __init__(self, hidden, out, n_layers, max_deg, dropout, aggr, z_ratio, jk=True):
+    """`EmbZGConv` (models.py:177-272).  gn=False (models.py:194, 226-227): no `gns` at all — emb_gn and every conv's own
+    GraphNorm stay.  act: "elu" = the driver's nn.ELU(inplace=True) (GLASSTest.py:143), "relu" = the constructor default
+    nn.ReLU() (models.py:192; NOT in place, so the tensors JK keeps stay raw also without gns)."""
+    def __init__(self, hidden, out, n_layers, max_deg, dropout, aggr, z_ratio, jk=True, gn=True, act="elu"):
         super().__init__()
         self.input_emb = nn.Embedding(int(max_deg) + 1, hidden)
         self.emb_gn = GraphNorm(hidden)
         dims = [hidden] * (n_layers - 1) + [out]
         self.convs = nn.ModuleList([OracleConv(hidden, d, aggr, z_ratio, dropout) for d in dims])
         self.gns = nn.ModuleList([GraphNorm(hidden) for _ in range(n_layers - 1)] +
-                                 [GraphNorm(out + (n_layers - 1) * hidden if jk else out)])
+                                 [GraphNorm(out + (n_layers - 1) * hidden if jk else out)]) if gn else None
         self.jk, self.dropout = jk, dropout
+        self.act = {"elu": F.elu, "relu": F.relu}[act]
 
     def forward(self, x, edge_index, edge_weight, z=None):
         n = x.shape[0]
         mask = torch.ones(n, 1, dtype=torch.bool) if z is None else (z > 0.5).reshape(-1, 1)
-        act = F.elu  # GLASSTest.py:143 nn.ELU(inplace=True)
+        act = self.act
         h = self.emb_gn(self.input_emb(x).reshape(n, -1))
         h = _dropout(h, self.dropout, self.training)
         saved = []
@@ -203,16 +206,17 @@ class OracleEmbZGConv(nn.Module):
             h = conv(h, edge_index, edge_weight, mask, act)
             saved.append(h)  # JK keeps the RAW conv outputs (models.py:254-255,260-264)
             if l + 1 < len(self.convs):
-                h = _dropout(act(self.gns[l](h)), self.dropout, self.training)
-        return self.gns[-1](torch.cat(saved, dim=-1) if self.jk else saved[-1])
+                h = _dropout(act(self.gns[l](h) if self.gns is not None else h), self.dropout, self.training)
+        out = torch.cat(saved, dim=-1) if self.jk else saved[-1]
+        return self.gns[-1](out) if self.gns is not None else out
 
 
 class OracleGLASS(nn.Module):
     """`GLASS` (models.py:322-355) with one head (`preds.0`) and one pool."""
     def __init__(self, hidden, n_layers, max_deg, out_channels, aggr="mean", pool="sum", z_ratio=0.8,
-                 dropout=0.0, jk=True):
+                 dropout=0.0, jk=True, gn=True, act="elu"):
         super().__init__()
-        self.conv = OracleEmbZGConv(hidden, hidden, n_layers, max_deg, dropout, aggr, z_ratio, jk)
+        self.conv = OracleEmbZGConv(hidden, hidden, n_layers, max_deg, dropout, aggr, z_ratio, jk, gn=gn, act=act)
         self.preds = nn.ModuleList([nn.Linear(hidden * n_layers if jk else hidden, out_channels)])
         self.pool = pool
 

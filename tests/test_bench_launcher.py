@@ -49,3 +49,34 @@ def test_more_ranks_than_gpus_is_refused_before_any_rank_starts():
                        env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 2 and "RCCL needs one GPU per rank" in p.stderr
     assert "torch.distributed" not in p.stderr  # refused by the launcher, not by a failing child job
+
+
+def test_eight_ranks_dry_run_end_to_end():
+    """the N = 8 launch the driver will run, end to end on the CPU box — launcher -> 8 ranks -> rank 0
+    generates the workload and the other seven load it from the published file BEFORE any collective -> gloo group ->
+    barrier / max-over-ranks -> one JSON line whose `collective` block answers "how many ranks did the backend see"."""
+    out = _run("--gpus", "8", "--steps", "2", "--warmup", "0", "--dry-run")
+    assert out["n_gpus"] == 8 and out["dry_run"] is True
+    c = out["collective"]
+    assert c["world_size"] == 8 and c["backend"] == "gloo"
+    assert {"in_graph", "capture_error", "exposed_us", "payload_bytes", "rccl_version"} <= set(c)
+    assert out["config"]["workload_identical_on_all_ranks"] is True and out["config"]["batches_per_rank"] == 2
+    import glob
+    assert not glob.glob("/tmp/glass_bench_*_ppi_bp_8.npz*"), "rank 0 must remove the published workload"
+
+
+def test_profiler_environment_is_detected_and_stripped():
+    """bench.py's child `rocprofv3 --pmc` passes are skipped when bench.py itself runs under a profiler
+    (LD_PRELOAD of the rocprofiler tool library / ROCP_* / ROCPROF* variables), and a child environment never inherits those."""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert not bench.under_profiler({"PATH": "/usr/bin"})
+    assert bench.under_profiler({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"})
+    assert bench.under_profiler({"ROCP_TOOL_LIBRARIES": "x"}) and bench.under_profiler({"ROCPROF_OUTPUT_PATH": "/tmp"})
+    env = bench.child_env_without_profiler({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so", "ROCP_TOOL_LIBRARIES": "x",
+                                            "ROCPROFILER_X": "1", "HSA_TOOLS_LIB": "y", "PATH": "/usr/bin", "HOME": "/root"})
+    assert env == {"PATH": "/usr/bin", "HOME": "/root"}
+    assert bench.child_env_without_profiler({"LD_PRELOAD": "/lib/libfoo.so"}) == {"LD_PRELOAD": "/lib/libfoo.so"}
+    import unittest.mock as mock
+    with mock.patch.dict(os.environ, {"ROCP_TOOL_LIBRARIES": "x"}):
+        assert bench.k1_pmc_traffic("ppi_bp", 64) == (None, mock.ANY) or bench.k1_pmc_traffic("ppi_bp", 64)[0] is None

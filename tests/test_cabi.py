@@ -204,6 +204,36 @@ def test_step_program_entry_points_validate_on_the_host():
     assert lib.glass_graphnorm_stats_exact_f32(p, 64, 16, 64, None, 16, None) == -1
 
 
+def test_repeatable_entry_points_refuse_instead_of_falling_back_to_float_atomics():
+    """an entry point that documents bitwise repeatability never reaches a float atomicAdd — beyond the
+    ordered scatter's LDS staging (and for max pooling) it returns GLASS_E_WS and names the workspace form; the one
+    float-atomic scatter is exported under its own name.  The refusals happen before any HIP call (no GPU needed)."""
+    from glass_amd import _lib
+    lib = _lib.load()
+    x = np.zeros(64, dtype=np.float32)
+    p = x.ctypes.data
+    E_WS = -4
+    # sum pooling, 200 x 155 padded entries > 12 288: refused, message names the exact form
+    assert lib.glass_segment_pool_bwd_f32(p, 64, p, 200, 155, 0, None, p, 64, 50000, 64, None) == E_WS
+    msg = lib.glass_last_error_string()
+    assert b"glass_segment_pool_bwd_exact_f32" in msg and b"glass_segment_pool_bwd_atomic_f32" in msg
+    # max pooling at any size: refused (its exact form is glass_segment_pool_max_bwd_exact_f32)
+    assert lib.glass_segment_pool_bwd_f32(p, 64, p, 8, 10, 2, p, p, 64, 1000, 64, None) == E_WS
+    assert b"glass_segment_pool_max_bwd_exact_f32" in lib.glass_last_error_string()
+    # the atomic form validates like the others (max pooling without argmax -> GLASS_E_ARG)
+    assert lib.glass_segment_pool_bwd_atomic_f32(p, 64, p, 8, 10, 2, None, p, 64, 1000, 64, None) == -1
+    # fused readout beyond 16 384 entries without scatter_ws: refused
+    args = [p, 128, p, p, p, p, 200, 155, 0, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 50000, 128, None, None, None,
+            None, None, 0, None, None]
+    assert lib.glass_readout_scatter_ws_bytes(50000, 200, 155) > 0
+    assert lib.glass_readout_train_f32(*args) == E_WS and b"scatter_ws" in lib.glass_last_error_string()
+    # no float atomicAdd left in the readout at all, and exactly one kernel with one in the pool file
+    src = open(os.path.join(ROOT, "glass_amd", "csrc", "readout.hip")).read()
+    assert not re.search(r"atomicAdd\(\s*(dst|dx|djk|demb)", src)
+    pool = open(os.path.join(ROOT, "glass_amd", "csrc", "pool.hip")).read()
+    assert pool.count("void pool_bwd_kernel(") == 1 and "pool_bwd_launch_atomic(" in pool
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from glass_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

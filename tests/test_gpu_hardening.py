@@ -1,0 +1,252 @@
+"""Parity hardening: the reference's constructor defaults the fused kernels do not
+cover, non-finite values through the exact fixed-point sums, and the C ABI's repeatability contract."""
+import functools
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from helpers import load, sd_from, grads_from, rel_inf, flat_grads, record_parity, build_glass
+from oracle import glass_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+DEV = "cuda:0"
+
+POOLS = {"mean": "MeanPool", "max": "MaxPool", "sum": "AddPool", "size": "SizePool"}
+
+
+def _build_defaults(hidden, layers, max_deg, n_class, aggr, pool, zr, gn, act):
+    """GLASS built with the REFERENCE'S constructor defaults where the driver overrides them (impl/models.py:125,192:
+    activation nn.ReLU(); :194 gn flag; :300-303 MaxPool)."""
+    from impl import models
+    conv = models.EmbZGConv(hidden, hidden, layers, max_deg=max_deg, activation=act, jk=True, dropout=0.0,
+                            conv=functools.partial(models.GLASSConv, aggr=aggr, z_ratio=zr, dropout=0.0), gn=gn)
+    return models.GLASS(conv, nn.ModuleList([nn.Linear(hidden * layers, n_class)]), nn.ModuleList([getattr(models, POOLS[pool])()]))
+
+
+@pytest.mark.parametrize("name", ["relu_gn_max_mean", "relu_nogn_sum_gcn", "relu_gn_size_sum"])
+@pytest.mark.parametrize("arena", [False, True])
+def test_g11_reference_constructor_defaults(name, arena):
+    """The product on the paths BEHIND the fused kernels (library GEMM + stand-alone mix / GraphNorm / torch activation):
+    hidden 48 (no dense family), nn.ReLU(), gn=False, MaxPool — against vectors the reference itself produced (fixture g11,
+    fp64 evaluation; tests/golden/make_golden.py g11): logits, loss, every gradient.  With and without a parameter arena."""
+    from impl import utils
+    from glass_amd import stack, losses
+    from glass_amd.arena import ParamArena
+    g = load(f"g11_defaults_{name}.npz")
+    x, ei, ew = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "edge_index", "edge_weight"))
+    pos, y = torch.from_numpy(g["pos"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    model = _build_defaults(int(g["hidden"]), int(g["layers"]), int(g["x"].max()), 3, str(g["aggr"]), str(g["pool"]),
+                            float(g["z_ratio"]), bool(g["gn"]), nn.ReLU())
+    model.load_state_dict(sd_from(g))
+    model.to(DEV).train()
+    if arena:
+        ParamArena(model)
+    assert not stack.step_supported(model, losses.CrossEntropy())  # this IS the fallback path
+    z = utils.MaxZOZ(x, pos)
+    assert np.array_equal(z.cpu().numpy(), g["z"])
+    pred = model(x, ei, ew, pos, z)
+    loss = nn.CrossEntropyLoss()(pred, y)
+    loss.backward()
+    ref = grads_from(g, "grad64/")
+    keys = sorted(ref)
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    assert sorted(mine) == keys
+    e_pred, e_loss = rel_inf(pred.detach().cpu(), g["pred64"]), abs(loss.item() - float(g["loss64"])) / abs(float(g["loss64"]))
+    e_grad = rel_inf(flat_grads(mine, keys), flat_grads(ref, keys))
+    record_parity(f"fallback_path/g11_{name}{'_arena' if arena else ''}", logits_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf=e_grad)
+    assert e_pred < TOL and e_loss < TOL and e_grad < TOL
+    assert rel_inf(pred.detach().cpu(), g["pred"]) < TOL + rel_inf(g["pred"], g["pred64"])
+
+
+@pytest.mark.parametrize("hidden,act,gn,pool", [(96, "relu", True, "max"), (96, "relu", False, "sum"), (50, "relu", True, "mean"),
+                                                (96, "elu", True, "max"), (48, "elu", False, "size")])
+def test_model_outside_the_fused_family_vs_oracle(hidden, act, gn, pool):
+    """A mid-size graph (N = 3 000, 40 000 edges, ragged subgraphs) at widths / activations / pools / gn flags the step
+    program does not take, whatever path the product picks for them, against the fp64 oracle."""
+    from impl import utils
+    from glass_amd import synth
+    from glass_amd.arena import ParamArena
+    n, K = 3000, 4
+    ei, ew = synth.make_graph(n, 20000, 21, 0.4)
+    x = synth.degree_feature(ei, n)
+    pos, y = synth.make_subgraphs(n, 30, 12, K, 1, False)
+    pos[2, 5:] = -1
+    pos[4, :3] = pos[5, :3]
+    ei, ew, x, pos, y = (torch.from_numpy(a) for a in (ei, ew, x, pos, y))
+    torch.manual_seed(hidden)
+    act_mod = nn.ReLU() if act == "relu" else nn.ELU(inplace=True)
+    if act == "elu" and not gn:
+        act_mod = nn.ELU()  # (in place without gns the reference would alias the JK tensors, impl/models.py:254-258)
+    model = _build_defaults(hidden, 2, int(x.max()), K, "mean", pool, 0.85, gn, act_mod)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    ParamArena(model)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    pred = model(xg, eig, ewg, posg, utils.MaxZOZ(xg, posg))
+    loss = nn.CrossEntropyLoss()(pred, yg)
+    loss.backward()
+    orc = O.OracleGLASS(hidden, 2, int(x.max()), K, aggr="mean", pool=pool, z_ratio=0.85, gn=gn, act=act)
+    orc.load_state_dict(sd)
+    orc = orc.double().train()
+    po = orc(x, ei, ew.double(), pos, O.max_zero_one(x, pos))
+    lo = nn.CrossEntropyLoss()(po, y)
+    lo.backward()
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    keys = sorted(mine)
+    assert keys == sorted(theirs)
+    e_pred, e_loss = rel_inf(pred.detach().cpu(), po.detach()), abs(loss.item() - lo.item()) / abs(lo.item())
+    e_grad = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
+    record_parity(f"fallback_path/N3000_hidden{hidden}_{act}_gn{int(gn)}_{pool}", logits_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf=e_grad)
+    assert e_pred < TOL and e_loss < TOL and e_grad < TOL
+
+
+# ---- non-finite values must stay visible (ADVICE r3 on bucket.h) -------------------------
+def _c2_like(hidden=64, n=20000, seed=0):
+    """A graph large enough for the hidden-64 step program to use the exact GraphNorm accumulators (gn_acc.h)."""
+    from glass_amd import synth
+    ei, ew = synth.make_graph(n, 200000, seed, 0.0)
+    x = synth.degree_feature(ei, n)
+    pos, y = synth.make_subgraphs(n, 40, 10, 4, 1, False)
+    return tuple(torch.from_numpy(a) for a in (ei, ew, x, pos, y))
+
+
+def _finite_share(named):
+    return {k: float(torch.isfinite(v).double().mean()) for k, v in named.items()}
+
+
+def test_nonfinite_values_reach_the_outputs():
+    """An Inf activation (a +inf bias entry in layer 0's trans pair) must come out of the step program as non-finite loss and
+    gradients, as it does from the reference arithmetic (the CPU oracle here) — the exact fixed-point GraphNorm
+    accumulators used to clamp a non-finite partial sum to +-4e18 and return a FINITE wrong statistic."""
+    from glass_amd import stack, losses
+    from glass_amd.arena import ParamArena
+    ei, ew, x, pos, y = _c2_like()
+    torch.manual_seed(0)
+    model = build_glass(64, 2, int(x.max()), 4, "mean", "sum", 0.9)
+    with torch.no_grad():
+        model.conv.convs[0].trans_fns[1].bias[3] = float("inf")
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    loss_fn = losses.CrossEntropy()
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    assert stack.step_supported(model, loss_fn)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg, overwrite=stack.covers_arena(model, arena))
+    torch.cuda.synchronize()
+    orc = O.OracleGLASS(64, 2, int(x.max()), 4, aggr="mean", pool="sum", z_ratio=0.9)
+    orc.load_state_dict(sd)
+    orc.train()
+    po = orc(x, ei, ew, pos, O.max_zero_one(x, pos))
+    lo = nn.CrossEntropyLoss()(po, y)
+    lo.backward()
+    assert not torch.isfinite(lo)  # the reference arithmetic: NaN loss
+    assert not torch.isfinite(loss), f"step program returned a finite loss {loss.item()} from an Inf activation"
+    assert not bool(torch.isfinite(logits).all())
+    mine = _finite_share({k: p.grad.cpu() for k, p in model.named_parameters()})
+    theirs = _finite_share({k: p.grad for k, p in orc.named_parameters()})
+    # every parameter whose reference gradient is entirely non-finite must not come out entirely finite here
+    bad = [k for k in theirs if theirs[k] == 0.0 and mine[k] == 1.0]
+    assert not bad, f"finite gradients where the reference has none: {bad}"
+
+
+def test_out_of_range_gradient_sums_poison_instead_of_saturating():
+    """A 1e20 upstream gradient overflows the backward sums' fixed-point range (|sum| < 2^38): the affected statistics must
+    come out NaN (sticky poison bit), not as a saturated finite number.  Every gradient tensor is then either non-finite or
+    right (the reference's, scaled) — never finite garbage."""
+    from impl import utils
+    from glass_amd import stack
+    from glass_amd.arena import ParamArena
+    ei, ew, x, pos, y = _c2_like(seed=1)
+    torch.manual_seed(1)
+    model = build_glass(64, 2, int(x.max()), 4, "mean", "sum", 0.9)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.to(DEV).train()
+    ParamArena(model)
+    assert stack.StackProgram.supported(model.conv)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    scale = 1e20
+    pred = model(xg, eig, ewg, posg, utils.MaxZOZ(xg, posg))
+    (nn.CrossEntropyLoss()(pred, yg) * scale).backward()
+    torch.cuda.synchronize()
+    orc = O.OracleGLASS(64, 2, int(x.max()), 4, aggr="mean", pool="sum", z_ratio=0.9)
+    orc.load_state_dict(sd)
+    orc = orc.double().train()
+    lo = nn.CrossEntropyLoss()(orc(x, ei, ew.double(), pos, O.max_zero_one(x, pos)), y)
+    (lo * scale).backward()
+    n_bad = 0
+    for k, p in model.named_parameters():
+        g, r = p.grad.cpu().double(), dict(orc.named_parameters())[k].grad
+        if bool(torch.isfinite(g).all()):
+            assert rel_inf(g, r) < 1e-4, f"{k}: finite but wrong ({rel_inf(g, r):.2e}) — a saturated sum leaked through"
+        else:
+            n_bad += 1
+    assert n_bad > 0, "the 1e20 gradient did not overflow any exact sum: the test no longer exercises the poison path"
+
+
+@pytest.mark.parametrize("mode", ["sum", "mean", "max"])
+@pytest.mark.parametrize("big", [False, True])
+def test_pool_backward_propagates_nonfinite(mode, big):
+    """A NaN / Inf in dout reaches demb on every pool backward form — ordered scatter (small batches), node-bucketed exact
+    sums (beyond the LDS staging; ExactSum's sticky mark), max pooling's exact form — exactly on the rows the reference's
+    scatter-add would poison, and nowhere else."""
+    from glass_amd import ops
+    n, C = 3000, 64
+    B, S = (500, 37) if big else (40, 12)
+    rng = np.random.default_rng(5 + big)
+    pos = rng.integers(1, n, (B, S))
+    pos[rng.random((B, S)) < 0.2] = -1
+    pos[:, 0] = 0                      # node 0 in every subgraph: a long list
+    post = torch.from_numpy(pos)
+    emb = torch.randn(n, C, generator=torch.Generator().manual_seed(1))
+    gout = torch.randn(B, C, generator=torch.Generator().manual_seed(2))
+    gout[7, 5] = float("nan")
+    gout[9, 11] = float("inf")
+    ec = emb.double().requires_grad_(True)
+    batch, p = O.pad_to_batch(post)
+    O.segment_pool(ec[p], batch, B, mode).backward(gout.double())
+    eg = emb.to(DEV).requires_grad_(True)
+    ops.segment_pool(eg, post.to(DEV), mode).backward(gout.to(DEV))
+    ref_bad, mine_bad = ~torch.isfinite(ec.grad), ~torch.isfinite(eg.grad.cpu())
+    assert bool(ref_bad.any())
+    assert torch.equal(ref_bad, mine_bad), f"{int((ref_bad != mine_bad).sum())} entries differ in finiteness"
+    ok = ~ref_bad
+    assert rel_inf(eg.grad.cpu()[ok], ec.grad[ok]) < 1e-6
+
+
+def test_atomic_pool_backward_is_a_separate_entry_point():
+    """glass_segment_pool_bwd_atomic_f32 (the one float-atomic scatter left, exported under its own name) agrees with the
+    exact form within rounding; the repeatable entry point refuses the same call with GLASS_E_WS."""
+    from glass_amd import _lib, ops
+    lib = _lib.load()
+    n, B, S, C = 4000, 500, 37, 64
+    rng = np.random.default_rng(3)
+    pos = torch.from_numpy(rng.integers(0, n, (B, S))).to(DEV)
+    dout = torch.randn(B, C, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    demb = torch.zeros(n, C, device=DEV)
+    assert lib.glass_segment_pool_bwd_f32(dout.data_ptr(), C, pos.data_ptr(), B, S, 0, None, demb.data_ptr(), C, n, C, st) == -4
+    _lib.check(lib.glass_segment_pool_bwd_atomic_f32(dout.data_ptr(), C, pos.data_ptr(), B, S, 0, None, demb.data_ptr(), C, n, C, st),
+               "glass_segment_pool_bwd_atomic_f32")
+    exact = torch.empty(n, C, device=DEV)
+    ws = torch.empty(int(lib.glass_segment_pool_bwd_exact_ws_bytes(n, B, S)) + 16, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.glass_segment_pool_bwd_exact_f32(dout.data_ptr(), C, pos.data_ptr(), B, S, 0, exact.data_ptr(), C, n, C, ws.data_ptr(), st),
+               "glass_segment_pool_bwd_exact_f32")
+    torch.cuda.synchronize()
+    assert rel_inf(demb.cpu(), exact.cpu()) < 1e-6
+
+
+def test_scratch_buffers_are_retired_not_freed():
+    """ops._scratch hands a captured graph's pointer to nobody else — a buffer that has to grow is kept alive,
+    and the sum / max pool backward use distinct keys."""
+    from glass_amd import ops
+    a = ops._scratch(("t_retire", 1), torch.device(DEV), 1000)
+    pa = a.data_ptr()
+    b = ops._scratch(("t_retire", 1), torch.device(DEV), 100000)
+    assert b.data_ptr() != pa or b.numel() >= 100000
+    assert any(t.data_ptr() == pa for t in ops._retired_scratch)
+    assert ops._scratch(("t_retire", 1), torch.device(DEV), 10).data_ptr() == b.data_ptr()

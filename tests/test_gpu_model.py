@@ -272,7 +272,7 @@ def test_hpo_neuro_shape_vs_oracle():
           f"grad {o_grad:.2e}")
     record_parity("per_op_path/hpo_neuro", logits_rel_inf=e_pred, loss_rel=abs(loss - l64) / abs(l64), grad_rel_inf=e_grad,
                   oracle_fp32_vs_fp64_logits=o_pred, oracle_fp32_vs_fp64_grad=o_grad)
-    assert e_pred < TOL and e_grad < max(TOL, 2 * o_grad)
+    assert e_pred < TOL and e_grad < TOL  # (measured 4e-7: the noise form max(TOL, 2 * o_grad) was 25x looser than the code)
 
 
 def test_eval_forward_bitwise_repeatable():
@@ -779,7 +779,7 @@ def test_step_program_full_size_vs_oracle(name):
     record_parity(f"step_program/{name}", logits_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf=err,
                   oracle_fp32_vs_fp64_logits=o_pred, oracle_fp32_vs_fp64_grad=o_grad)
     assert e_pred < TOL and e_loss < TOL
-    assert err < max(TOL, 2 * o_grad)
+    assert err < TOL  # plain bar (measured 3e-7 .. 5e-7 at all three shapes)
 
 
 def test_pretraining_step_full_size_vs_oracle():
@@ -823,10 +823,19 @@ def test_pretraining_step_full_size_vs_oracle():
     err = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
     o_pred, o_grad = rel_inf(res[torch.float32][0], po), rel_inf(flat_grads(res[torch.float32][2], keys), flat_grads(theirs, keys))
     print(f"pre-training step vs fp64 oracle: pred {e_pred:.2e} loss {e_loss:.2e} grad {err:.2e} | cpu-fp32-vs-fp64 {o_pred:.2e} {o_grad:.2e}")
-    record_parity("pretraining_step/ppi_bp_131072_pairs", pred_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf=err,
+    # Which element carried round 3's 4.18e-5: conv.convs.0.comb_fn.bias.  That conv's output goes
+    # straight into gns[0] (impl/models.py:459-462) whose mean_scale is 1 at init, so the bias shifts a column that the norm
+    # re-centres: its gradient is exactly zero in exact arithmetic and every fp32 evaluation (the CPU oracle's too) returns
+    # N = 17 080 cancelling terms' rounding noise there.  It is graded as such; everything else meets the plain bar.
+    zero = [k for k in keys if k.endswith("comb_fn.bias") and not k.startswith(f"conv.convs.{layers - 1}.")]
+    from helpers import assert_grad_parity, grad_table
+    err_rest, zeros = assert_grad_parity(mine, theirs, keys, TOL, exact_zero=zero, ref32=res[torch.float32][2],
+                                         label="pre-training step")
+    record_parity("pretraining_step/ppi_bp_131072_pairs", pred_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf_all=err,
+                  grad_rel_inf=err_rest, exact_zero_parameters=", ".join(zero),
+                  exact_zero_err=max(v[0] for v in zeros.values()), exact_zero_err_oracle_fp32=max(v[1] for v in zeros.values()),
                   oracle_fp32_vs_fp64_pred=o_pred, oracle_fp32_vs_fp64_grad=o_grad)
     assert e_pred < TOL and e_loss < TOL
-    assert err < max(TOL, 2 * o_grad)
 
 
 @pytest.mark.parametrize("name", ["ppi_bp", "em_user"])
@@ -1099,7 +1108,58 @@ def test_c5_family_hidden256_vs_oracle():
     print(f"C5 family H=256: logits {e_pred:.2e} loss {e_loss:.2e} grad {e_grad:.2e} | cpu-fp32-vs-fp64 {o_pred:.2e} {o_grad:.2e}")
     record_parity("product_dispatch/powerlaw_family_N20000_hidden256", logits_rel_inf=e_pred, loss_rel=e_loss,
                   grad_rel_inf=e_grad, oracle_fp32_vs_fp64_logits=o_pred, oracle_fp32_vs_fp64_grad=o_grad)
-    assert e_pred < TOL and e_loss < TOL and e_grad < max(TOL, 2 * o_grad)
+    assert e_pred < TOL and e_loss < TOL and e_grad < TOL  # plain bar (measured 3.4e-7)
+
+
+def test_c5_family_quarter_size_vs_fp64_oracle():
+    """BASELINE config 5's family at the largest size whose fp64 CPU evaluation finishes inside a test:
+    the power-law generator of config 5 at N = 250 000 / nnz = 5 M, hidden 256, BOTH layers, through the step program,
+    against the fp64 oracle on logits, loss and the flat gradient (round 3 had this only as an off-suite tool record:
+    logits 5.6e-7, gradient 4.7e-7).  Needs ~56 GiB of host memory for the fp64 tape (the GPU box has 3 TB)."""
+    import time
+    import psutil
+    from glass_amd import synth, stack, losses
+    from glass_amd.arena import ParamArena
+    if psutil.virtual_memory().available < 56 * 2**30:
+        pytest.skip("fp64 tape of the N = 250 000 evaluation needs ~56 GiB of host memory")
+    w = synth.WORKLOADS["powerlaw"]
+    n_node, n_pairs = 250_000, 2_500_000
+    ei, ew = synth.make_graph(n_node, n_pairs, 0, w.powerlaw)
+    x = synth.degree_feature(ei, n_node)
+    pos, y = synth.make_subgraphs(n_node, w.batch, w.sub_size, w.n_class, 1, w.multilabel)
+    ei, ew, x, pos, y = (torch.from_numpy(a) for a in (ei, ew, x, pos, y))
+    torch.manual_seed(0)
+    model = build_glass(w.hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio)
+    assert w.hidden == 256 and w.layers == 2
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    loss_fn = losses.CrossEntropy()
+    model.to(DEV).train()
+    arena = ParamArena(model)
+    assert stack.step_supported(model, loss_fn) and stack.covers_arena(model, arena)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg, overwrite=True)
+    torch.cuda.synchronize()
+    mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
+    keys = sorted(mine)
+    t0 = time.time()
+    threads = torch.get_num_threads()
+    torch.set_num_threads(__import__("os").cpu_count())
+    try:
+        orc = O.OracleGLASS(w.hidden, w.layers, int(x.max()), w.n_class, aggr=w.aggr, pool=w.pool, z_ratio=w.z_ratio)
+        orc.load_state_dict(sd)
+        orc = orc.double().train()
+        po = orc(x, ei, ew.double(), pos, O.max_zero_one(x, pos))
+        lo = loss_fn(po, y)
+        lo.backward()
+    finally:
+        torch.set_num_threads(threads)
+    theirs = {k: p.grad for k, p in orc.named_parameters()}
+    e_pred, e_loss = rel_inf(logits.cpu(), po.detach()), abs(loss.item() - lo.item()) / abs(lo.item())
+    e_grad = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
+    print(f"C5 family N=250k H=256 L=2 vs fp64 oracle ({time.time() - t0:.0f} s of CPU): logits {e_pred:.2e} loss {e_loss:.2e} grad {e_grad:.2e}")
+    record_parity("config5_family/powerlaw_N250k_hidden256_L2_vs_fp64_in_suite", n_node=n_node, nnz=ei.shape[1], logits_rel_inf=e_pred,
+                  loss_rel=e_loss, grad_rel_inf=e_grad, oracle_seconds=time.time() - t0)
+    assert e_pred < TOL and e_loss < TOL and e_grad < TOL
 
 
 def test_c5_full_size_hidden256_step(monkeypatch):

@@ -217,3 +217,34 @@ def test_g10_edgegnn_ssl_path(name):
         assert rel_inf(pred.detach(), g["pred" + tag]) < tol
         assert abs(loss.item() - float(g["loss" + tag])) < tol * abs(float(g["loss" + tag]))
         assert rel_inf(flat_grads(mine, keys), flat_grads(ref, keys)) < tol
+
+
+G11 = ["relu_gn_max_mean", "relu_nogn_sum_gcn", "relu_gn_size_sum"]
+
+
+@pytest.mark.parametrize("name", G11)
+def test_g11_reference_constructor_defaults(name):
+    """The reference's constructor defaults outside the fused kernels' coverage — nn.ReLU() (impl/models.py:125,192),
+    gn=False (:194), MaxPool (:300-303), hidden 48 — oracle vs the reference run in fp64 (math pin) and fp32."""
+    g = load(f"g11_defaults_{name}.npz")
+    x, ei, ew = torch.from_numpy(g["x"]), torch.from_numpy(g["edge_index"]), torch.from_numpy(g["edge_weight"])
+    pos, y = torch.from_numpy(g["pos"]), torch.from_numpy(g["y"])
+    assert np.array_equal(O.max_zero_one(x, pos).numpy(), g["z"])
+    ref = grads_from(g, "grad64/")
+    keys = sorted(ref)
+    assert ("conv.gns.0.weight" in keys) == bool(g["gn"])
+    for dt, tol in ((torch.float64, 1e-11), (torch.float32, TOL)):
+        m = O.OracleGLASS(int(g["hidden"]), int(g["layers"]), int(x.max()), 3, aggr=str(g["aggr"]), pool=str(g["pool"]),
+                          z_ratio=float(g["z_ratio"]), gn=bool(g["gn"]), act="relu")
+        m.load_state_dict(sd_from(g))
+        m = m.to(dt).train()
+        pred = m(x, ei, ew.to(dt), pos, O.max_zero_one(x, pos))
+        loss = nn.CrossEntropyLoss()(pred, y)
+        loss.backward()
+        mine = {k: p.grad for k, p in m.named_parameters()}
+        assert sorted(mine) == keys
+        assert rel_inf(pred.detach(), g["pred64"]) < tol
+        assert abs(loss.item() - float(g["loss64"])) < tol * abs(float(g["loss64"]))
+        assert rel_inf(flat_grads(mine, keys), flat_grads(ref, keys)) < tol
+        if dt == torch.float32:
+            assert rel_inf(pred.detach(), g["pred"]) < TOL + rel_inf(g["pred"], g["pred64"])

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as td
 
 
-def run(dist_mode, nodeid=False, capture_collective=True):
+def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False):
     from glass_amd import synth, losses, ops, dist as gdist, step as step_mod
     step_mod.CAPTURE_COLLECTIVE = capture_collective
     from glass_amd.arena import ParamArena
@@ -35,6 +35,7 @@ def run(dist_mode, nodeid=False, capture_collective=True):
     assert (arena.big_start < arena.flat.numel()) == nodeid
     opt = FlatAdam(arena, lr=1e-2)
     step = TrainStep(model, opt, losses.CrossEntropy(), x, ei, ew, arena, use_graph=True, warmup_iters=2, preserve_state=True)
+    step._force_verify_mismatch = force_mismatch  # the replay-vs-eager check of a captured collective reports a mismatch
     B = w.batch
     for k in range(20):
         b = k % 4
@@ -46,7 +47,9 @@ def run(dist_mode, nodeid=False, capture_collective=True):
     assert not (step.collective_in_graph and not capture_collective)
     assert (step._g_tail is not None) == bool(dist_mode and nodeid)
     form = "one-graph" if step.collective_in_graph else ("split" if step._split else "single")
-    return hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest(), form, step.capture_error
+    if step.collective_in_graph:  # a captured collective is only kept after one replay reproduced an eager step
+        assert step.capture_verified and step.capture_verified["ok"], step.capture_verified
+    return hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest(), form, step.capture_error, step.capture_verified
 
 
 if __name__ == "__main__":
@@ -56,6 +59,7 @@ if __name__ == "__main__":
     td.init_process_group("nccl", device_id=torch.device("cuda", 0))
     split = {nid: run(True, nid) for nid in (False, True)}
     eager_coll = run(True, False, capture_collective=False)  # the split form, whatever the capture attempt above did
+    opted_out = run(True, False, force_mismatch=True)         # capture succeeds, the check "fails": automatic opt-out
     td.barrier(device_ids=[0])
     td.destroy_process_group()
     ok = True
@@ -67,4 +71,9 @@ if __name__ == "__main__":
     same = single[False][0] == eager_coll[0]
     ok = ok and same and eager_coll[1] == "split"
     print("deg single", single[False][0], eager_coll[1], eager_coll[0], "same" if same else "DIFFERENT")
+    same = single[False][0] == opted_out[0]
+    # (if the runtime refused the capture in the first place there was nothing to verify: the split form is taken anyway)
+    ok = ok and same and opted_out[1] == "split" and (opted_out[3] is None or "replay-vs-eager" in str(opted_out[2]))
+    print("deg single", single[False][0], "opt-out after a forced mismatch:", opted_out[1], opted_out[0],
+          "same" if same else "DIFFERENT", "verified:", opted_out[3], "| trusted capture:", split[False][3])
     print("ALL EQUAL" if ok else "MISMATCH")
