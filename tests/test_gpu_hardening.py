@@ -213,8 +213,19 @@ def test_pool_backward_propagates_nonfinite(mode, big):
     ops.segment_pool(eg, post.to(DEV), mode).backward(gout.to(DEV))
     ref_bad, mine_bad = ~torch.isfinite(ec.grad), ~torch.isfinite(eg.grad.cpu())
     assert bool(ref_bad.any())
-    assert torch.equal(ref_bad, mine_bad), f"{int((ref_bad != mine_bad).sum())} entries differ in finiteness"
-    ok = ~ref_bad
+    if mode == "max":
+        # torch_scatter routes a subgraph's gradient to the arg-max node only; torch's scatter_reduce("amax") backward (the
+        # oracle's stand-in) multiplies the gradient by a 0/1 mask, which turns the Inf into NaN on EVERY row of subgraph 9
+        # (0 * inf) — an artefact of the stand-in.  Expected here: exactly the two winning nodes, nothing else.
+        want = torch.zeros_like(mine_bad)
+        for b, c in ((7, 5), (9, 11)):
+            rows = post[b][post[b] >= 0]
+            want[rows[emb[rows, c].argmax()], c] = True
+        assert torch.equal(mine_bad, want) and bool((ref_bad | ~mine_bad).all())
+        ok = ~ref_bad
+    else:
+        assert torch.equal(ref_bad, mine_bad), f"{int((ref_bad != mine_bad).sum())} entries differ in finiteness"
+        ok = ~ref_bad
     assert rel_inf(eg.grad.cpu()[ok], ec.grad[ok]) < 1e-6
 
 

@@ -803,39 +803,54 @@ def test_pretraining_step_full_size_vs_oracle():
     model = models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()]))
     sd = {k: v.clone() for k, v in model.state_dict().items()}
     model.to(DEV).train()
+    # the ReLU branches the evaluated path took, in call order (conv 0's trans ReLU, the one behind gns[0], conv 1's, the head's)
+    relu_masks, hooks, seen = [], [], set()
+    for m in model.modules():
+        if isinstance(m, nn.ReLU) and id(m) not in seen:
+            seen.add(id(m))
+            hooks.append(m.register_forward_hook(lambda _m, _i, out: relu_masks.append((out > 0).cpu())))
     pred = model(x.to(DEV), ei.to(DEV), ew.to(DEV), pairs.to(DEV))
+    for hk in hooks:
+        hk.remove()
+    assert len(relu_masks) == 2 * layers
     loss = nn.BCEWithLogitsLoss()(pred.flatten(), y.to(DEV))
     loss.backward()
     res = {}
-    for dt in (torch.float64, torch.float32):
+    for tag, dt, feed in (("fp64", torch.float64, None), ("fp32", torch.float32, None), ("fp64_same_branches", torch.float64, relu_masks)):
         orc = O.OracleEdgeGNN(h, layers, int(x.max()), aggr=w.aggr, jk=False)
         orc.load_state_dict(sd)
         orc = orc.to(dt).train()
+        O.relu_mask_feed(feed or [])
         po = orc(x, ei, ew.to(dt), pairs)
+        O.relu_mask_feed([])
         lo = nn.BCEWithLogitsLoss()(po.flatten(), y.to(dt))
         lo.backward()
-        res[dt] = (po.detach(), lo.item(), {k: p.grad for k, p in orc.named_parameters()})
-    po, lo, theirs = res[torch.float64]
+        res[tag] = (po.detach(), lo.item(), {k: p.grad for k, p in orc.named_parameters()})
+    po, lo, theirs = res["fp64_same_branches"]
     mine = {k: p.grad.cpu() for k, p in model.named_parameters()}
     keys = sorted(mine)
     assert keys == sorted(theirs)
     e_pred, e_loss = rel_inf(pred.detach().cpu(), po), abs(loss.item() - lo) / abs(lo)
     err = rel_inf(flat_grads(mine, keys), flat_grads(theirs, keys))
-    o_pred, o_grad = rel_inf(res[torch.float32][0], po), rel_inf(flat_grads(res[torch.float32][2], keys), flat_grads(theirs, keys))
-    print(f"pre-training step vs fp64 oracle: pred {e_pred:.2e} loss {e_loss:.2e} grad {err:.2e} | cpu-fp32-vs-fp64 {o_pred:.2e} {o_grad:.2e}")
-    # Which element carried round 3's 4.18e-5: conv.convs.0.comb_fn.bias.  That conv's output goes
-    # straight into gns[0] (impl/models.py:459-462) whose mean_scale is 1 at init, so the bias shifts a column that the norm
-    # re-centres: its gradient is exactly zero in exact arithmetic and every fp32 evaluation (the CPU oracle's too) returns
-    # N = 17 080 cancelling terms' rounding noise there.  It is graded as such; everything else meets the plain bar.
-    zero = [k for k in keys if k.endswith("comb_fn.bias") and not k.startswith(f"conv.convs.{layers - 1}.")]
-    from helpers import assert_grad_parity, grad_table
-    err_rest, zeros = assert_grad_parity(mine, theirs, keys, TOL, exact_zero=zero, ref32=res[torch.float32][2],
-                                         label="pre-training step")
-    record_parity("pretraining_step/ppi_bp_131072_pairs", pred_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf_all=err,
-                  grad_rel_inf=err_rest, exact_zero_parameters=", ".join(zero),
-                  exact_zero_err=max(v[0] for v in zeros.values()), exact_zero_err_oracle_fp32=max(v[1] for v in zeros.values()),
+    # What round 3's 4.18e-5 was: ReLU is not differentiable at 0, and among the 8.4 M pre-activations
+    # of the MLP head a few lie within fp32 rounding of 0 — there relu' is decided by the sign of the evaluation's own
+    # rounding error.  Each flip moves preds.0.seq.modlist.0.{bias,weight} (and, through the pooled rows, the conv weights)
+    # by ~1.4e-5 of the largest gradient; the CPU fp32 oracle flips too (its 4.18e-5 was the same elements).  Measured here:
+    # against the fp64 evaluation on ITS OWN branches the error is the flips; on the branches the GPU took it is rounding.
+    own = res["fp64"]
+    err_own = rel_inf(flat_grads(mine, keys), flat_grads(own[2], keys))
+    o_pred = rel_inf(res["fp32"][0], own[0])
+    o_grad = rel_inf(flat_grads(res["fp32"][2], keys), flat_grads(own[2], keys))
+    from helpers import grad_table
+    worst = grad_table(mine, own[2], keys, res["fp32"][2])[0]
+    print(f"pre-training step vs fp64 oracle on the same ReLU branches: pred {e_pred:.2e} loss {e_loss:.2e} grad {err:.2e} | vs fp64 on "
+          f"its own branches: grad {err_own:.2e} (worst {worst[0]} {worst[2]:.2e}; cpu-fp32 there {worst[3]:.2e}) | cpu-fp32-vs-fp64 "
+          f"{o_pred:.2e} {o_grad:.2e}")
+    record_parity("pretraining_step/ppi_bp_131072_pairs", pred_rel_inf=e_pred, loss_rel=e_loss, grad_rel_inf=err,
+                  grad_rel_inf_vs_fp64_on_its_own_relu_branches=err_own, worst_parameter_on_own_branches=worst[0],
                   oracle_fp32_vs_fp64_pred=o_pred, oracle_fp32_vs_fp64_grad=o_grad)
     assert e_pred < TOL and e_loss < TOL
+    assert err < TOL
 
 
 @pytest.mark.parametrize("name", ["ppi_bp", "em_user"])
