@@ -52,18 +52,34 @@ class GraphedPairStep:
     runs eagerly (it builds the CSR / plans / scratch buffers), the second one is captured, later ones copy the batch into
     the graph's static buffers and replay.  The optimizer (and the reference's per-batch plateau scheduler, which needs the
     loss on the host) stay outside the graph.  GLASS_SSL_GRAPH=0 keeps the eager loop."""
-    def __init__(self, model, loss_fn, x, edge_index, edge_attr):
+    def __init__(self, model, loss_fn, x, edge_index, edge_attr, bce_mean=False):
+        """bce_mean: loss_fn is BCEWithLogitsLoss()(pred.flatten(), target.flatten()) (the reference's, GNNEmb.py:129-130) —
+        then a model the step program serves (glass_amd.ssl.PairProgram.supported: hidden 64, ParamArena attached) runs the
+        whole forward + backward as that program: no autograd tape, no library GEMM, ~32 launches instead of ~97."""
         self.model, self.loss_fn = model, loss_fn
         self.x, self.ei, self.ea = x, edge_index, edge_attr
         self.seen, self.graphs = set(), {}
         self.params = [p for p in model.parameters() if p.requires_grad]
         self.enabled = os.environ.get("GLASS_SSL_GRAPH", "1") != "0"
+        from glass_amd import ssl
+        self.program = ssl.program_for(model) if (bce_mean and os.environ.get("GLASS_SSL_PROGRAM", "1") != "0") else None
+        self.key = (id(loss_fn), id(x), id(edge_index), id(edge_attr))  # what a cached step is valid for (train_epoch)
 
     def _fwd_bwd(self, pairs, target):
+        if self.program is not None and self.model.training:
+            # gradients are written into the arena (every .grad is a view of it), overwriting: no zero-fill
+            return self.program.loss_and_grads(self.x, self.ei, self.ea, pairs, target, overwrite=self.program.covers_arena())
         emb = self.model.NodeEmb(self.x, self.ei, self.ea)
         loss = self.loss_fn(self.model.preds[0](self.model.Pool(emb, pairs, None)), target)
         loss.backward()
         return loss.detach()
+
+    def _reset_grads(self):
+        if self.program is None:
+            for p in self.params:
+                p.grad = None
+        elif not self.program.covers_arena():
+            self.model.conv._glass_arena.zero()
 
     def __call__(self, pairs, target):
         """Leaves the batch's gradients in .grad of every parameter and returns the loss (a 0-d device tensor)."""
@@ -71,13 +87,11 @@ class GraphedPairStep:
         ent = self.graphs.get(key)
         if ent is None and not (self.enabled and key in self.seen):
             self.seen.add(key)
-            for p in self.params:
-                p.grad = None
+            self._reset_grads()
             return self._fwd_bwd(pairs, target)
         if ent is None:
             s_pairs, s_target = pairs.clone(), target.clone()
-            for p in self.params:
-                p.grad = None
+            self._reset_grads()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             loss = torch.zeros((), device=pairs.device)  # caller-owned: outside the graph's private pool
@@ -88,16 +102,18 @@ class GraphedPairStep:
                 print(f"GraphedPairStep: capture refused ({e!r}); continuing with the eager step", flush=True)
                 self.enabled = False
                 torch.cuda.synchronize()
-                for p in self.params:
-                    p.grad = None
+                self._reset_grads()
                 return self._fwd_bwd(pairs, target)
             ent = self.graphs[key] = (g, s_pairs, s_target, loss, [p.grad for p in self.params])
         g, s_pairs, s_target, loss, grads = ent
         s_pairs.copy_(pairs)
         s_target.copy_(target)
+        if self.program is not None and not self.program.covers_arena():
+            self.model.conv._glass_arena.zero()
         g.replay()
-        for p, gr in zip(self.params, grads):  # (an eager batch of another shape in between re-pointed .grad)
-            p.grad = gr
+        if self.program is None:
+            for p, gr in zip(self.params, grads):  # (an eager batch of another shape in between re-pointed .grad)
+                p.grad = gr
         return loss
 
 
@@ -129,6 +145,23 @@ class Pretrain:
                           activation=nn.ReLU(inplace=True))
         return models.EdgeGNN(conv, nn.ModuleList([head]), nn.ModuleList([models.MeanPool()])).to(config.device)
 
+    @staticmethod
+    def make_optimizer(model, lr):
+        """Adam as the reference builds it (GNNEmb.py:116).  Where the step program can serve the model (hidden 64, jk off) the
+        parameters are flattened into one arena first and Adam is ONE launch over it (glass_amd.optim.FlatAdam — an
+        Optimizer subclass, so the per-batch ReduceLROnPlateau works unchanged); otherwise torch's Adam."""
+        from glass_amd import ssl
+        from glass_amd.arena import ParamArena
+        from glass_amd.optim import FlatAdam
+        if os.environ.get("GLASS_SSL_PROGRAM", "1") != "0":
+            try:
+                arena = ParamArena(model)
+            except Exception:  # noqa: BLE001 — any layout the arena does not take: plain Adam on the per-op path
+                arena = None
+            if arena is not None and ssl.program_for(model) is not None:
+                return FlatAdam(arena, lr=lr)
+        return Adam(model.parameters(), lr=lr)
+
     def node_embeddings(self, model):
         with torch.no_grad():
             return model.NodeEmb(self.trn.x, self.trn.edge_index, self.trn.edge_attr).detach().cpu()
@@ -138,9 +171,10 @@ class Pretrain:
         is stepped per batch, before the optimizer.  Returns the mean batch loss."""
         model.train()
         step = model.__dict__.get("_pair_step")
-        if step is None:
+        key = (id(loss_fn), id(self.trn.x), id(self.trn.edge_index), id(self.trn.edge_attr))
+        if step is None or step.key != key:  # (a cached step holds its first call's loss_fn and graph tensors: ADVICE r3)
             step = model.__dict__["_pair_step"] = GraphedPairStep(model, loss_fn, self.trn.x, self.trn.edge_index,
-                                                                  self.trn.edge_attr)
+                                                                  self.trn.edge_attr, bce_mean=getattr(loss_fn, "bce_mean", False))
         seen = []
         for batch in itertools.islice(loader, max_batches):
             loss = step(batch[-2], batch[-1])
@@ -158,12 +192,13 @@ class Pretrain:
 
         def loss_fn(pred, target):
             return BCEWithLogitsLoss()(pred.flatten(), target.flatten())
+        loss_fn.bce_mean = True  # (lets the pair step run as the fused program: glass_amd/ssl.py)
 
         scores, emb = [], None
         for _ in range(self.args.repeat):
             model = self.build_model(hidden_dim, conv_layer, dropout, jk, aggr)
+            optimizer = self.make_optimizer(model, lr)
             emb = self.node_embeddings(model)
-            optimizer = Adam(model.parameters(), lr=lr)
             scheduler = lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.7, min_lr=5e-5, patience=50)
             best, stale = 0.0, 0
             for epoch in range(self.args.max_epoch):

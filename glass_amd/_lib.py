@@ -21,10 +21,10 @@ LIB_PATH = os.environ.get("GLASS_HIP_LIB") or os.path.join(_HERE, "libglass_hip.
 
 POOL_MODES = {"sum": 0, "mean": 1, "max": 2, "size": 3}
 AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
-ACT_NONE, ACT_ELU = 0, 1
+ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 PLAN_HEADER_WORDS = 16
 EMBED_NORM_MAX_ROWS = 8192  # GLASS_EMBED_NORM_MAX_ROWS
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GlassHipError(RuntimeError):
@@ -102,6 +102,10 @@ SIGNATURES = {
     "glass_segment_pool_bwd_exact_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _I, _I, _I, _P, _P]),
     "glass_pair_pool_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P]),
     "glass_pair_pool_bwd_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P, _P]),
+    "glass_pair_head_supported": (c_int, [_I]),
+    "glass_pair_head_ws_bytes": (c_int64, [_I, _I]),
+    "glass_pair_head_fwd_f32": (c_int, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, c_float, _P, c_uint64, _P, _P, _P, _P, _P, _P]),
+    "glass_pair_head_bwd_f32": (c_int, [_P, _I, _I, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _P, _P, c_int, _P, _P, _I, _P, _P]),
     "glass_linear_wgrad_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _I, _I, _I, _P, _I, _P, c_int, _P, _P]),
     "glass_dual_linear_supported": (c_int, [_I]),

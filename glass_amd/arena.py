@@ -16,13 +16,21 @@ from .dist import FlatGradBucket
 
 
 def _pairs(model):
-    """[(first, second)] Linear pairs to lay out adjacently: index 1 (labeled) before index 0."""
-    from .models import GLASSConv
+    """[(module, kind, first, second)] Linear pairs to lay out adjacently: index 1 (labeled) before index 0.
+    first = None: a SINGLE Linear (the unlabeled layers of the pre-training path, MyGCNConv: reference
+    impl/models.py:361-397) laid out as the second half of a pair whose first half is an all-zero block of the flat buffer —
+    with z_ratio = 1 and no labeled row the pair kernels then compute exactly the single layer (the first half is weighted
+    by 1 - z = 0 in the forward, its data gradient term is 0, its weight gradient 0): the whole fused stack serves the
+    unlabeled model without a second kernel family."""
+    from .models import GLASSConv, MyGCNConv
     out = []
     for m in model.modules():
         if isinstance(m, GLASSConv):
             out.append((m, "trans", m.trans_fns[1], m.trans_fns[0]))
             out.append((m, "comb", m.comb_fns[1], m.comb_fns[0]))
+        elif isinstance(m, MyGCNConv):
+            out.append((m, "trans", None, m.trans_fn))
+            out.append((m, "comb", None, m.comb_fn))
     return out
 
 
@@ -52,21 +60,33 @@ class ParamArena(FlatGradBucket):
         params = [p for p in params if not any(p is q for q in big)] + big
         order, seen, groups = [], set(), []
         for mod, kind, l1, l0 in _pairs(model):
+            if l1 is None:  # a single Linear: [zero block; weight]
+                for b in (l0.weight, l0.bias):
+                    if b is not None and id(b) not in seen:
+                        groups.append((mod, kind, None, b))
+                        seen.add(id(b))
+                continue
             for a, b in ((l1.weight, l0.weight), (l1.bias, l0.bias)):
                 if a.shape == b.shape and id(a) not in seen and id(b) not in seen:
                     groups.append((mod, kind, a, b))
                     seen.update((id(a), id(b)))
-        grouped = {id(a): (a, b) for _, _, a, b in groups}
-        second = {id(b) for _, _, a, b in groups}
+        grouped = {id(a): (a, b) for _, _, a, b in groups if a is not None}
+        second = {id(b) for _, _, a, b in groups if a is not None}
+        single = {id(b) for _, _, a, b in groups if a is None}
         offsets, off = {}, 0
+        stack_start = {}  # id(second half) -> element offset of the stacked [first; second] block
         for p in params:
             if id(p) in second:
                 continue
             off = (off + 3) // 4 * 4  # 16-B alignment of every group start
+            if id(p) in single:
+                stack_start[id(p)] = off
+                off += p.numel()          # the zero half (never a parameter; Adam leaves zeros with zero gradients alone)
             offsets[id(p)] = off
             off += p.numel()
             if id(p) in grouped:
                 b = grouped[id(p)][1]
+                stack_start[id(b)] = offsets[id(p)]
                 offsets[id(b)] = off  # exactly adjacent: [a; b] is one stacked tensor
                 off += b.numel()
         from . import dist as gdist
@@ -97,17 +117,20 @@ class ParamArena(FlatGradBucket):
                 p.data = view
                 p.grad = self.flat[o:o + p.numel()].view_as(p)
         # stacked views for the fused Linear pairs
+        from .models import MyGCNConv
         for mod in model.modules():
-            if isinstance(mod, GLASSConv):
+            if isinstance(mod, (GLASSConv, MyGCNConv)):
                 mod._stack = {}
                 mod._stack_eff = {}
+            if isinstance(mod, MyGCNConv):
+                mod.z_ratio, mod.dropout = 1.0, 0.0  # (what the pair kernels are told: only the second half counts)
             if isinstance(mod, GraphNorm):
                 mod._direct_grad = True
         stacks = {}
         for mod, kind, a, b in groups:
-            o = offsets[id(a)]
-            n2 = a.numel() + b.numel()
-            shape = (2 * a.shape[0], ) + tuple(a.shape[1:])
+            o = stack_start[id(b)]
+            n2 = 2 * b.numel()
+            shape = (2 * b.shape[0], ) + tuple(b.shape[1:])
             stacks.setdefault((id(mod), kind), [mod, kind]).append(
                 (self.flat_param[o:o + n2].view(shape), self.flat[o:o + n2].view(shape)))
         self._packs = []  # (src weight view, dst image, NT, KT, transposed)
@@ -163,9 +186,9 @@ class ParamArena(FlatGradBucket):
                            np.array([p[3] for p in self._packs], dtype=np.int64),
                            np.array([p[4] for p in self._packs], dtype=np.int32),
                            np.zeros(len(self._packs), dtype=np.float32), len(self._packs))
-        from .models import EmbZGConv
+        from .models import EmbZGConv, EmbGConv
         for mod in model.modules():
-            if isinstance(mod, EmbZGConv):
+            if isinstance(mod, (EmbZGConv, EmbGConv)):
                 mod._glass_arena = self  # EmbZGConv.forward refreshes the images once per training forward
         self.refresh_transposes()
 

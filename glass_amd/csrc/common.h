@@ -48,6 +48,20 @@ __device__ __forceinline__ float elu_grad_f(float h) { return h > 0.f ? 1.f : __
 // exp(h) - 1 with the hardware exponential: absolute error ~1e-7 (fine against the 1e-5 rel-inf bar), a
 // handful of instructions instead of expm1f's ~50 — used where 32 ELUs per lane sit in a kernel epilogue.
 __device__ __forceinline__ float elu_fast_f(float h) { return h > 0.f ? h : __expf(h) - 1.f; }
+// Activation by code (wave-uniform): GLASS_ACT_NONE | GLASS_ACT_ELU (alpha = 1: GLASSTest.py:143) | GLASS_ACT_RELU (the
+// reference's constructor default, impl/models.py:125,192, and the pre-training path's nn.ReLU, GNNEmb.py:90).
+// act_fast: hardware exponential (the dense kernels' prologues / epilogues); act_exact: expm1f (graphnorm.hip's apply);
+// act_grad: the derivative from the PRE-activation value (relu'(0) = 0, as torch's).
+__device__ __forceinline__ float act_fast(int act, float h) {
+    return act == GLASS_ACT_ELU ? elu_fast_f(h) : (act == GLASS_ACT_RELU ? fmaxf(h, 0.f) : h);
+}
+__device__ __forceinline__ float act_exact(int act, float h) {
+    return act == GLASS_ACT_ELU ? elu_f(h) : (act == GLASS_ACT_RELU ? fmaxf(h, 0.f) : h);
+}
+__device__ __forceinline__ float act_grad(int act, float h) {
+    return act == GLASS_ACT_ELU ? elu_grad_f(h) : (act == GLASS_ACT_RELU ? (h > 0.f ? 1.f : 0.f) : 1.f);
+}
+__host__ __device__ inline bool act_code_ok(int act) { return act == GLASS_ACT_NONE || act == GLASS_ACT_ELU || act == GLASS_ACT_RELU; }
 
 // keep-scale of one element from its 32-bit word: 4 consecutive columns share one rand4() call.
 __device__ __forceinline__ float keep_scale(uint32_t word, float p_drop, float inv_keep) {

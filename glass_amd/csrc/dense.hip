@@ -231,7 +231,7 @@ __device__ __forceinline__ void gn_prologue16(float (&a)[kKC], const float* coef
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float h = fmaf(a[4 * v + k], scale[k], shift[k]);
-            if (pro.act == GLASS_ACT_ELU) h = elu_fast_f(h);
+            h = act_fast(pro.act, h);
             a[4 * v + k] = h * ds[k];
         }
         if (pro.side)
@@ -347,10 +347,7 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_fwd_kernel(const float* 
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float a1 = v1[k], a0 = v0[k];
-                if (act == GLASS_ACT_ELU) {
-                    a1 = elu_fast_f(a1);
-                    a0 = elu_fast_f(a0);
-                }
+                a1 = act_fast(act, a1), a0 = act_fast(act, a0);
                 o[k] = w1 * a1 + w0 * a0;
                 ssum[gl][k] += o[k];
                 ssq[gl][k] = fmaf(o[k], o[k], ssq[gl][k]);
@@ -458,13 +455,13 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
         acc, WT, lds_w, lane, NLOC * cg, 0,
         [&](int kc, DgradRaw& raw) __attribute__((always_inline)) {
             load16(raw.d, drow + kc * kKC, row_ok);
-            if (act == GLASS_ACT_ELU) load16(raw.t, trow + kc * kKC, row_ok);
+            if (act != GLASS_ACT_NONE) load16(raw.t, trow + kc * kKC, row_ok);
         },
         [&](int, const DgradRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < kKC; ++s) {
                 float v = raw.d[s] * coef;
-                if (act == GLASS_ACT_ELU) v *= elu_grad_f(raw.t[s]);
+                if (act != GLASS_ACT_NONE) v *= act_grad(act, raw.t[s]);
                 a[s] = v;
             }
         });
@@ -526,7 +523,7 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float gp = dy[k] * ds[k];
-                    if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv[k], sc[k], sh[k]));
+                    gp *= act_grad(gs.act, fmaf(xv[k], sc[k], sh[k]));
                     const float xhat = (xv[k] - al[k] * mu[k]) * rs[k];
                     s1[gl][k] += gp;
                     s2[gl][k] = fmaf(gp, xhat, s2[gl][k]);
@@ -659,12 +656,9 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
         for (int k = 0; k < 4; ++k) {
             z1[k] = d[k] * c1;
             z0[k] = d[k] * c0;
-            if (act == GLASS_ACT_ELU) {
-                z1[k] *= elu_grad_f(t1[k]);
-                z0[k] *= elu_grad_f(t0[k]);
-            }
+            z1[k] *= act_grad(act, t1[k]), z0[k] *= act_grad(act, t0[k]);
             float uk = gds[k];
-            if (gs.act == GLASS_ACT_ELU) uk *= elu_grad_f(fmaf(xv[k], g_sc[k], g_sh[k]));
+            uk *= act_grad(gs.act, fmaf(xv[k], g_sc[k], g_sh[k]));
             u[k] = uk;
             xu[k] = (xv[k] - g_al[k] * g_mu[k]) * g_rs[k] * uk;
         }
@@ -985,8 +979,12 @@ __global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* _
 #endif
 // NST = 16-row stages per workgroup (4: 64-row tiles; 5: 80-row tiles, taken when that brings the launch down to one
 // workgroup per CU — 280 workgroups on 256 CUs leave 24 CUs with two, whose waves share the matrix cores and finish last)
-template <int H, bool DROP, int NST>
-__global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
+// WG = wave groups: 1 = one wave per SIMD (a stage is 16 rows); 2 = TWO waves per SIMD (hidden 64 only: 8 waves, a stage is
+// 32 rows, wave group g multiplies rows 16g .. 16g + 15 of it with the same 16 weight columns) — per stage a SIMD then
+// holds two independent instruction streams, so one wave's LDS-read latency, store issue and barrier wait sit under the
+// other's 32 MFMAs, and the workgroup passes half as many barriers (3 stages instead of 5 for an 80-row tile).
+template <int H, bool DROP, int NST, int WG = 1>
+__global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
                                                                const float* __restrict__ Wimg, const float* __restrict__ bias,
                                                                const uint8_t* __restrict__ mask, float zr, float omz,
@@ -994,14 +992,18 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
                                                                double* __restrict__ stats, int stats_exact, GnPrologue pro,
                                                                LabRows lab) {
     static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
-    constexpr int THREADS = 4 * H, NTL = H / 16, KF4 = (2 * H) / 16;  // threads, 16-column tiles, float4 per lane of a weight slice
+    static_assert(WG == 1 || (WG == 2 && H == 64), "two wave groups: 8 waves at hidden 64");
+    constexpr int THREADS = 4 * H * WG, NTL = H / 16, KF4 = (2 * H) / 16;  // threads, 16-column tiles, float4 per lane of a weight slice
     constexpr int KT = 2 * H, RS = KT + 4;  // LDS row stride (floats): + 4 keeps the 16 rows of a b128 read off one bank group
-    __shared__ __attribute__((aligned(16))) float tile[2][16 * RS];
+    constexpr int SR = 16 * WG, NSTG = (NST + WG - 1) / WG;  // rows per stage, stages per workgroup
+    __shared__ __attribute__((aligned(16))) float tile[2][SR * RS];
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
     constexpr int ROWS = 16 * NST;
     __shared__ int rows_s[ROWS];  // row of each of the workgroup's slots: -1 none; bit 30 set: computed but not stored / counted
+    __shared__ double comb_s[WG > 1 ? 2 * H : 1];  // column sums of wave group 1, handed to group 0
     D_STAMP(1, 0);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int w = wv % NTL, g = wv / NTL;  // column tile, row group
     const int j = lane & 15, q = lane >> 4;
     const bool extra = (int)blockIdx.x >= lab.n_main;
     int n_lab = 0, base = 0;
@@ -1026,13 +1028,14 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
     // the two float4 this thread moves per stage: 4-column group ga of the a half (GraphNorm prologue) and of the h half of
     // row rs of the stage (one buffer resource per half: wave-uniform)
     const int rs = tid / (H / 4), ga = tid % (H / 4);
-    int my_row[NST];  // (-1: none)
-    int slot_v = -1;   // row of slot `tid` (threads < 64)
+    int my_row[NSTG];  // (-1: none)
+    int slot_v = -1;   // row of slot `tid` (threads < ROWS)
     unsigned char slot_mask = 0;
     if (!extra) {
         const int64_t r0 = (int64_t)blockIdx.x * ROWS;
 #pragma unroll
-        for (int st = 0; st < NST; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+        for (int st = 0; st < NSTG; ++st)
+            my_row[st] = (SR * st + rs < ROWS && r0 + SR * st + rs < N) ? (int)(r0 + SR * st + rs) : -1;
         if (tid < ROWS && r0 + tid < N) {
             slot_v = (int)(r0 + tid);
             slot_mask = mask[r0 + tid];
@@ -1044,7 +1047,7 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
         }
         lds_barrier();
 #pragma unroll
-        for (int st = 0; st < NST; ++st) my_row[st] = rows_s[16 * st + rs];
+        for (int st = 0; st < NSTG; ++st) my_row[st] = SR * st + rs < ROWS ? rows_s[SR * st + rs] : -1;
     }
     auto issue = [&](int st, float4 (&raw)[2]) __attribute__((always_inline)) {
         const int r = my_row[st];
@@ -1053,13 +1056,13 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
     };
     float4 rawA[2], rawB[2];
     issue(0, rawA);
-    issue(1, rawB);
+    if (1 < NSTG) issue(1, rawB);
     Drop drop = pro.drop;
     if (pro.saved && drop.p > 0.f) {
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
-    if (pro.saved) gn_fwd_coef_nobarrier<H, THREADS>(pro.src, pro.saved, N, gn_coef_s);
+    if (pro.saved && (WG == 1 || tid < 4 * H)) gn_fwd_coef_nobarrier<H, 4 * H>(pro.src, pro.saved, N, gn_coef_s);
     if (tid < ROWS) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
     D_STAMP(1, 1);
     lds_barrier();  // coefficients + row table
@@ -1094,40 +1097,43 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
     };
     float ssum = 0.f, ssq = 0.f;  // this lane's column 16w + j over the rows 4q + r of every stage
     commit(0, prep(0, rawA[0]), rawA[1]);
-    issue(2, rawA);
+    if (2 < NSTG) issue(2, rawA);
     lds_barrier();
 #pragma unroll
-    for (int st = 0; st < NST; ++st) {
+    for (int st = 0; st < NSTG; ++st) {
         if (st == 1) D_STAMP(1, 5);
-        const float* T = tile[st & 1] + j * RS + (KT / 4) * q;
+        const bool live_grp = SR * st + 16 * g < ROWS;  // (wave-uniform: the last stage of an odd NST has one row group only)
+        const float* T = tile[st & 1] + (16 * g + j) * RS + (KT / 4) * q;
         float4 a4[KF4];
 #pragma unroll
         for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
         int rv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        for (int r = 0; r < 4; ++r) rv[r] = live_grp ? rows_s[(SR * st + 16 * g + 4 * q + r) < ROWS ? SR * st + 16 * g + 4 * q + r : 0] : -1;
         float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (st + 1 < NST) vn = prep(st + 1, (st & 1) ? rawA[0] : rawB[0]);  // the NEXT stage's rows (even stages come in rawA)
+        if (st + 1 < NSTG) vn = prep(st + 1, (st & 1) ? rawA[0] : rawB[0]);  // the NEXT stage's rows (even stages come in rawA)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the dependent-MFMA latency
+        if (WG == 1 || live_grp) {
 #pragma unroll
-        for (int tt = 0; tt < KF4; tt += 2) {
-            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
-            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
-            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+            for (int tt = 0; tt < KF4; tt += 2) {
+                const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+                const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+                const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+                }
             }
         }
         if (st == 1) D_STAMP(1, 2);
-        if (st + 1 < NST) {
+        if (st + 1 < NSTG) {
             commit(st + 1, vn, (st & 1) ? rawA[1] : rawB[1]);
-            if (st + 3 < NST) {
+            if (st + 3 < NSTG) {
                 if (st & 1) issue(st + 3, rawA); else issue(st + 3, rawB);
             }
         }
-        // acc[r] = row slot 16 st + 4q + r, column 16w + j
+        // acc[r] = row slot SR st + 16 g + 4q + r, column 16w + j
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool live = rv[r] >= 0 && !(rv[r] >> 30);
@@ -1138,13 +1144,15 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
         }
 #if GLASS_STAGE_INTERLEAVE
         // one MFMA, then a few of the next stage's VALU instructions, 32 times
+        if (WG == 1) {
 #pragma unroll
-        for (int i = 0; i < 32; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, GLASS_STAGE_INTERLEAVE, 0);
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, GLASS_STAGE_INTERLEAVE, 0);
+            }
         }
 #endif
-        if (st + 1 < NST) lds_barrier();  // the next stage's rows are in LDS; every wave is done reading this stage's buffer
+        if (st + 1 < NSTG) lds_barrier();  // the next stage's rows are in LDS; every wave is done reading this stage's buffer
     }
     D_STAMP(1, 3);
     if (stats == nullptr) return;
@@ -1153,6 +1161,16 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
     q2 += __shfl_xor(q2, 16);
     s += __shfl_xor(s, 32);
     q2 += __shfl_xor(q2, 32);
+    if (WG > 1) {  // one add per column and workgroup, as with one wave group: group 1 hands its sums over
+        if (g == 1 && q == 0) {
+            comb_s[16 * w + j] = s;
+            comb_s[H + 16 * w + j] = q2;
+        }
+        lds_barrier();
+        if (g == 1) return;
+        s += comb_s[16 * w + j];
+        q2 += comb_s[H + 16 * w + j];
+    }
     if (q == 0) {
         const int c = 16 * w + j;
         if (stats_exact) {
@@ -1170,21 +1188,25 @@ __global__ __launch_bounds__(4 * H) void comb_fwd_eff2_kernel(const float* __res
 // A wave owns columns 16w .. 16w+15 of BOTH halves (the label mix needs f1 and f0 of a column in one lane): 2 x 4 float4 of
 // weights per lane (K = 64), 32 MFMAs per 16-row stage; one float4 of the operand per thread and stage.  Image: layout
 // kLayoutWave16Cols.  xa_index: the stage's rows are gathered from the embedding table (layer 0).
-template <int H, int NST>
-__global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restrict__ xa, int64_t lda, int64_t xa_rows,
+template <int H, int NST, int WG = 1>
+__global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __restrict__ xa, int64_t lda, int64_t xa_rows,
                                                             const float* __restrict__ Wimg, const float* __restrict__ bias,
                                                             const uint8_t* __restrict__ mask, float zr, float omz, int act,
                                                             float* __restrict__ T, int64_t ldt, float* __restrict__ out,
                                                             int64_t ldo, int64_t N, double* __restrict__ stats, int stats_exact,
                                                             GnPrologue pro, const int64_t* __restrict__ xa_index) {
     static_assert(H == 64, "four waves x 16 columns");
+    static_assert(WG == 1 || WG == 2, "one or two waves per SIMD (comb_fwd_eff2_kernel)");
     constexpr int RS = H + 4;  // LDS row stride (floats)
-    __shared__ __attribute__((aligned(16))) float tile[2][16 * RS];
+    constexpr int SR = 16 * WG, NSTG = (NST + WG - 1) / WG;  // rows per stage, stages per workgroup
+    __shared__ __attribute__((aligned(16))) float tile[2][SR * RS];
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
     constexpr int ROWS = 16 * NST;
     __shared__ int rows_s[ROWS];  // row of each slot: -1 none; bit 30: labeled row (mix weights swapped)
+    __shared__ double comb_s[WG > 1 ? 2 * H : 1];  // column sums of wave group 1, handed to group 0
     D_STAMP(2, 0);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int w = wv & 3, g = wv >> 2;  // column tile, row group
     const int j = lane & 15, q = lane >> 4;
     const buf_rsrc r_xa = make_rsrc(xa, xa_rows * lda * 4), r_out = make_rsrc(out, N * ldo * 4);
     const buf_rsrc r_T = make_rsrc(T ? T : out, T ? N * ldt * 4 : 0);
@@ -1199,18 +1221,19 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
     const float b1 = bias[16 * w + j], b0 = bias[H + 16 * w + j];
     const int rs = tid >> 4, ga = tid & 15;
     const int64_t r0 = (int64_t)blockIdx.x * ROWS;
-    int my_row[NST], my_src[NST];  // output row of this thread's float4 per stage (-1 none) and the operand row it comes from
+    int my_row[NSTG], my_src[NSTG];  // output row of this thread's float4 per stage (-1 none) and the operand row it comes from
 #pragma unroll
-    for (int st = 0; st < NST; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
+    for (int st = 0; st < NSTG; ++st)
+        my_row[st] = (SR * st + rs < ROWS && r0 + SR * st + rs < N) ? (int)(r0 + SR * st + rs) : -1;
     if (xa_index) {
-        int64_t idx[NST];
+        int64_t idx[NSTG];
 #pragma unroll
-        for (int st = 0; st < NST; ++st) idx[st] = my_row[st] >= 0 ? xa_index[my_row[st]] : 0;
+        for (int st = 0; st < NSTG; ++st) idx[st] = my_row[st] >= 0 ? xa_index[my_row[st]] : 0;
 #pragma unroll
-        for (int st = 0; st < NST; ++st) my_src[st] = (int)(idx[st] < 0 ? 0 : (idx[st] >= xa_rows ? xa_rows - 1 : idx[st]));
+        for (int st = 0; st < NSTG; ++st) my_src[st] = (int)(idx[st] < 0 ? 0 : (idx[st] >= xa_rows ? xa_rows - 1 : idx[st]));
     } else {
 #pragma unroll
-        for (int st = 0; st < NST; ++st) my_src[st] = my_row[st];
+        for (int st = 0; st < NSTG; ++st) my_src[st] = my_row[st];
     }
     int slot_v = -1;
     unsigned char slot_mask = 0;
@@ -1221,13 +1244,14 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
     auto issue = [&](int st) __attribute__((always_inline)) -> float4 {
         return buf_load4(r_xa, my_row[st] >= 0 ? (int)((my_src[st] * lda + 4 * ga) * 4) : kBufOOB);
     };
-    float4 rawA = issue(0), rawB = issue(1);
+    float4 rawA = issue(0), rawB = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (1 < NSTG) rawB = issue(1);
     Drop drop = pro.drop;
     if (pro.saved && drop.p > 0.f) {
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
-    if (pro.saved) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
+    if (pro.saved && (WG == 1 || tid < kBlock)) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
     if (tid < ROWS) rows_s[tid] = slot_mask != 0 ? (slot_v | (1 << 30)) : slot_v;
     D_STAMP(2, 1);
     lds_barrier();  // coefficients + row table
@@ -1245,7 +1269,7 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float h = fmaf(a[k], sc[k], sh[k]);
-                if (pro.act == GLASS_ACT_ELU) h = elu_fast_f(h);
+                h = act_fast(pro.act, h);
                 a[k] = h * ds[k];
             }
         }
@@ -1255,37 +1279,40 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
     };
     float ssum = 0.f, ssq = 0.f;
     stage_store(0, rawA);
-    if (2 < NST) rawA = issue(2);
+    if (2 < NSTG) rawA = issue(2);
     lds_barrier();
 #pragma unroll
-    for (int st = 0; st < NST; ++st) {
-        const float* A = tile[st & 1] + j * RS + 16 * q;
+    for (int st = 0; st < NSTG; ++st) {
+        const bool live_grp = SR * st + 16 * g < ROWS;  // (wave-uniform: the last stage of an odd NST has one row group only)
+        const float* A = tile[st & 1] + (16 * g + j) * RS + 16 * q;
         float4 a4[4];
 #pragma unroll
         for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(A + 4 * v);
         int rv[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        for (int r = 0; r < 4; ++r) rv[r] = live_grp ? rows_s[(SR * st + 16 * g + 4 * q + r) < ROWS ? SR * st + 16 * g + 4 * q + r : 0] : -1;
         f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
+        if (WG == 1 || live_grp) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
-            const float y1[4] = {bw1[v].x, bw1[v].y, bw1[v].z, bw1[v].w}, y0[4] = {bw0[v].x, bw0[v].y, bw0[v].z, bw0[v].w};
+            for (int v = 0; v < 4; ++v) {
+                const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
+                const float y1[4] = {bw1[v].x, bw1[v].y, bw1[v].z, bw1[v].w}, y0[4] = {bw0[v].x, bw0[v].y, bw0[v].z, bw0[v].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y1[e], acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y0[e], acc0, 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y1[e], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y0[e], acc0, 0, 0, 0);
+                }
             }
         }
         // the next stage's rows -> the other buffer (its readers passed the barrier at the end of the previous iteration);
         // behind the MFMAs in program order, so the prologue arithmetic overlaps their execution
-        if (st + 1 < NST) {
+        if (st + 1 < NSTG) {
             if (st & 1) {
                 stage_store(st + 1, rawA);
-                if (st + 3 < NST) rawA = issue(st + 3);
+                if (st + 3 < NSTG) rawA = issue(st + 3);
             } else {
                 stage_store(st + 1, rawB);
-                if (st + 3 < NST) rawB = issue(st + 3);
+                if (st + 3 < NSTG) rawB = issue(st + 3);
             }
         }
         const int c = 16 * w + j;
@@ -1299,16 +1326,13 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
             buf_store1(r_T, (live && T) ? (int)((row * ldt + c) * 4) : kBufOOB, v1);
             buf_store1(r_T, (live && T) ? (int)((row * ldt + H + c) * 4) : kBufOOB, v0);
             float a1 = v1, a0 = v0;
-            if (act == GLASS_ACT_ELU) {
-                a1 = elu_fast_f(a1);
-                a0 = elu_fast_f(a0);
-            }
+            a1 = act_fast(act, a1), a0 = act_fast(act, a0);
             const float o = w1 * a1 + w0 * a0;
             buf_store1(r_out, live ? (int)((row * ldo + c) * 4) : kBufOOB, o);
             ssum += live ? o : 0.f;
             ssq += live ? o * o : 0.f;
         }
-        if (st + 1 < NST) lds_barrier();
+        if (st + 1 < NSTG) lds_barrier();
     }
     D_STAMP(2, 3);
     if (stats == nullptr) return;
@@ -1317,6 +1341,16 @@ __global__ __launch_bounds__(kBlock) void trans_fwd2_kernel(const float* __restr
     q2 += __shfl_xor(q2, 16);
     s += __shfl_xor(s, 32);
     q2 += __shfl_xor(q2, 32);
+    if (WG > 1) {  // one add per column and workgroup: group 1 hands its sums over
+        if (g == 1 && q == 0) {
+            comb_s[16 * w + j] = s;
+            comb_s[H + 16 * w + j] = q2;
+        }
+        lds_barrier();
+        if (g == 1) return;
+        s += comb_s[16 * w + j];
+        q2 += comb_s[H + 16 * w + j];
+    }
     if (q == 0) {
         const int c = 16 * w + j;
         if (stats_exact) {
@@ -1414,7 +1448,7 @@ __device__ __forceinline__ void comb_dgrad_eff_body(const float* __restrict__ ds
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     float gp = dy[k] * ds[k];
-                    if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv[k], sc[k], sh[k]));
+                    gp *= act_grad(gs.act, fmaf(xv[k], sc[k], sh[k]));
                     const float xhat = (xv[k] - al[k] * mu[k]) * rs[k];
                     s1[k] += gp;
                     s2[k] = fmaf(gp, xhat, s2[k]);
@@ -2101,6 +2135,19 @@ static void allow_lds(K kernel, size_t bytes) {
 }
 
 static bool wave16_shape_ok(int64_t H) { return H == 64; }
+// Wave groups of the staged hidden-64 forward kernels (trans_fwd2_kernel / comb_fwd_eff2_kernel): 2 = two waves per SIMD.
+// Measured at ppi_bp-shape (round 4, same box, alternating runs): trans forward 13.2 -> 11.8 us per launch with two groups
+// (three 32-row stages instead of five 16-row ones); the comb forward does not move (12.1 vs 12.0: its stage is 17 KB of
+// LDS traffic for the same 32 MFMAs per wave, and eight waves fetch the weight slices twice) — so trans takes 2, comb 1.
+// GLASS_FWD_WG=1|2 forces both (laboratory A/B; read once per process).
+static int fwd_wave_groups(bool comb) {
+    static const int forced = [] {
+        const char* e = getenv("GLASS_FWD_WG");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced == 1 || forced == 2) return forced;
+    return comb ? 1 : 2;
+}
 // Above this many rows the two halves of the backward of a pair fill the chip on their own (one launch each, the
 // weight gradient with its 4-stage pipeline); below, they run as two branches of one launch (dual_bwd_kernel).
 static bool tiled_here(int64_t H) { return tiled_shape_ok(H) && !wave16_shape_ok(H); }
@@ -2186,7 +2233,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     }
     GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && (narrow_shape_ok(H) || (ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved))) &&
                                 p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
-                                (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                                act_code_ok(gn_act)),
                   "dual_linear_fwd: bad GraphNorm prologue arguments");
     if (!dense_shape_ok(H)) {
         set_error("dual_linear_fwd: hidden size %lld not supported (<= 32, 64, 128, 256, 512)", (long long)H);
@@ -2237,12 +2284,16 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
         // 80-row tiles when they bring the launch down to one workgroup per CU (no per-workgroup partials then: their count
         // is the 64-row geometry of glass_dual_linear_stat_rows)
         const int64_t wg80 = ceil_div(n_nodes, 80);
-        if ((stats == nullptr || stats_exact) && grid.x > 256 && wg80 <= 256)
-            hipLaunchKernelGGL((trans_fwd2_kernel<64, 5>), dim3((unsigned)wg80), dim3(kBlock), 0, st, xa, lda, src_rows, W, bias, mask,
-                               zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index);
-        else
-            hipLaunchKernelGGL((trans_fwd2_kernel<64, 4>), grid, dim3(kBlock), 0, st, xa, lda, src_rows, W, bias, mask, zr, omz, act,
-                               T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index);
+        const bool tall = (stats == nullptr || stats_exact) && grid.x > 256 && wg80 <= 256;
+#define GLASS_TF2(NS, WGN)                                                                                                  \
+    hipLaunchKernelGGL((trans_fwd2_kernel<64, NS, WGN>), tall ? dim3((unsigned)wg80) : grid, dim3(kBlock * WGN), 0, st, xa, lda,     \
+                       src_rows, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index)
+        const int wgn = fwd_wave_groups(false);
+        if (tall && wgn == 2) GLASS_TF2(5, 2);
+        else if (tall) GLASS_TF2(5, 1);
+        else if (wgn == 2) GLASS_TF2(4, 2);
+        else GLASS_TF2(4, 1);
+#undef GLASS_TF2
         return launch_status("glass_dual_linear_fwd_f32");
     }
     GLASS_FWD(64, 1, 4)
@@ -2277,7 +2328,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
                       "dual_linear_dgrad: bad arguments");
         const GnBwdStats ngs{gn_partial, 0, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                              make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
-        const int rc = launch_narrow_dgrad(dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio,
+        const int rc = launch_narrow_dgrad(dsrc, ldd, act != GLASS_ACT_NONE ? T : nullptr, ldt, mask, (float)z_ratio,
                                            (float)(1.0 - z_ratio), act, WT, n_out, addend, ldadd, make_drop(p_drop, call_id, n_out),
                                            rng_state, out, ldo, n_nodes, H, ngs, (hipStream_t)stream);
         if (rc || !wg) return rc;
@@ -2293,19 +2344,19 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)ceil_div(n_nodes, glass_dual_linear_stat_rows(H)));
     const float zr = (float)z_ratio, omz = (float)(1.0 - z_ratio);
-    const float* Tp = act == GLASS_ACT_ELU ? T : nullptr;
+    const float* Tp = act != GLASS_ACT_NONE ? T : nullptr;
     const bool dg2 = GLASS_TRANS_DGRAD_V2 && H == 64 && n_out == H;  // (image in layout kLayoutWave16Cols: glass_dual_linear_dgrad_layout)
     size_t lds_dg = lds_bytes(n_out, 2);  // K = 2H always needs >= 2 passes
     if (dg2) {
         lds_dg = kTransDgrad2Lds;
-        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(act == GLASS_ACT_ELU ? ldt : (int64_t)0, addend ? ldadd : (int64_t)0),
+        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(act != GLASS_ACT_NONE ? ldt : (int64_t)0, addend ? ldadd : (int64_t)0),
                                                                      gn_partial ? gn_ldx : (int64_t)0));
         GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "dual_linear_dgrad: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
     }
     const Drop drop = make_drop(p_drop, call_id, n_out);
     GLASS_REQUIRE(!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && gn_ldx % 4 == 0 && aligned16(gn_x) &&
                                   aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
-                                  (gn_p_drop == 0.f || rng_state) && (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                                  (gn_p_drop == 0.f || rng_state) && act_code_ok(gn_act)),
                   "dual_linear_dgrad: bad GraphNorm statistics arguments");
     const GnBwdStats gs{gn_partial, gn_exact, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act,
                         make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
@@ -2316,7 +2367,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
                                            nullptr, 0, nullptr, 0, wg->ws, stream);
     };
     if (GLASS_TRANS_DGRAD_V2 && H == 128 && n_out == H) {  // staged form with 8 waves (image in layout kLayoutWave16Cols)
-        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(act == GLASS_ACT_ELU ? ldt : (int64_t)0, addend ? ldadd : (int64_t)0),
+        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(act != GLASS_ACT_NONE ? ldt : (int64_t)0, addend ? ldadd : (int64_t)0),
                                                                      gn_partial ? gn_ldx : (int64_t)0));
         GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "dual_linear_dgrad: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
         GLASS_REQUIRE(!gn_exact, "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only");
@@ -2449,7 +2500,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     GLASS_REQUIRE((!stats_exact && !gn_src) || glass_gn_exact_fwd_supported(H), "comb_eff_fwd: exact GraphNorm accumulators not served at this hidden size (glass_gn_exact_fwd_supported)");
     GLASS_REQUIRE(!gn_saved || (xa_out && ldxo >= H && ldxo % 4 == 0 && aligned16(xa_out) && aligned16(gn_saved) &&
                                 p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state) &&
-                                (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                                act_code_ok(gn_act)),
                   "comb_eff_fwd: bad GraphNorm prologue arguments");
     GLASS_REQUIRE(lda >= H && lda % 4 == 0 && aligned16(xa) && ldb >= H && ldb % 4 == 0 && aligned16(xb) &&
                       aligned16(Wimg_eff) && aligned16(bias) && ldo >= H && ldo % 4 == 0 && aligned16(out),
@@ -2479,12 +2530,20 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
 #define GLASS_CF2(HH, DR, NS)                                                                                             \
     hipLaunchKernelGGL((comb_fwd_eff2_kernel<HH, DR, NS>), grid, dim3(4 * HH), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, \
                        bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
+#define GLASS_CF2W(DR, NS)                                                                                                \
+    hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, DR, NS, 2>), grid, dim3(512), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, \
+                       bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
     const bool dr = gn_saved && p_drop > 0.f;
     if (GLASS_COMB_FWD_V2 && H == 128) {
         if (dr && tall) GLASS_CF2(128, true, 5);
         else if (dr) GLASS_CF2(128, true, 4);
         else if (tall) GLASS_CF2(128, false, 5);
         else GLASS_CF2(128, false, 4);
+    } else if (GLASS_COMB_FWD_V2 && fwd_wave_groups(true) == 2) {
+        if (dr && tall) GLASS_CF2W(true, 5);
+        else if (dr) GLASS_CF2W(true, 4);
+        else if (tall) GLASS_CF2W(false, 5);
+        else GLASS_CF2W(false, 4);
     } else if (GLASS_COMB_FWD_V2) {
         if (dr && tall) GLASS_CF2(64, true, 5);
         else if (dr) GLASS_CF2(64, true, 4);
@@ -2492,6 +2551,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
         else GLASS_CF2(64, false, 4);
     }
 #undef GLASS_CF2
+#undef GLASS_CF2W
     else
         hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
                            bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
@@ -2517,7 +2577,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
         GLASS_REQUIRE(g.acc && rep_ok(g.n_rep) && g.dy && g.x && g.saved && g.gamma && g.alpha && g.lddy >= H && g.lddy % 4 == 0 &&
                           g.ldx >= H && g.ldx % 4 == 0 && aligned16(g.dy) && aligned16(g.x) && aligned16(g.saved) &&
                           (!g.addend || (g.ldadd >= H && g.ldadd % 4 == 0 && aligned16(g.addend))) && g.p_drop >= 0.f && g.p_drop < 1.f &&
-                          (g.p_drop == 0.f || rng_state) && (g.act == GLASS_ACT_NONE || g.act == GLASS_ACT_ELU) &&
+                          (g.p_drop == 0.f || rng_state) && act_code_ok(g.act) &&
                           n_nodes * std::max(std::max(g.lddy, g.ldx), g.addend ? g.ldadd : (int64_t)0) * 4 < (1ll << 31),
                       "comb_eff_bwd: bad dsrc_gn");
         gsrc = GnBwdSrc{reinterpret_cast<const long long*>(g.acc), (int)g.n_rep, g.dy, g.lddy, g.x, g.ldx, g.addend, g.ldadd, g.saved,
@@ -2536,7 +2596,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
                   "comb_eff_bwd: operands must be 16-B aligned with ld %% 4 == 0");
     GLASS_REQUIRE(!gn_partial || (gn_x && gn_saved && gn_alpha && gn_ldx >= H && gn_ldx % 4 == 0 && aligned16(gn_x) &&
                                   aligned16(gn_saved) && aligned16(gn_alpha) && gn_p_drop >= 0.f && gn_p_drop < 1.f &&
-                                  (gn_p_drop == 0.f || rng_state) && (gn_act == GLASS_ACT_NONE || gn_act == GLASS_ACT_ELU)),
+                                  (gn_p_drop == 0.f || rng_state) && act_code_ok(gn_act)),
                   "comb_eff_bwd: bad GraphNorm statistics arguments");
     GLASS_REQUIRE(!gn_exact || (gn_partial && rep_ok(gn_exact)), "comb_eff_bwd: gn_exact = replicas of the accumulators (2, 4, 8, 16)");
     hipStream_t st = (hipStream_t)stream;

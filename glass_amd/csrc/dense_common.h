@@ -17,7 +17,7 @@ extern __device__ unsigned long long* g_dense_trace;
 extern __device__ int g_dense_trace_sel;
 #define D_STAMP(sel, slot)                                                                                         \
     do {                                                                                                           \
-        if (g_dense_trace && g_dense_trace_sel == (sel) && (threadIdx.x & 63) == 0)                                \
+        if (g_dense_trace && g_dense_trace_sel == (sel) && (threadIdx.x & 63) == 0 && threadIdx.x < 256)                              \
             g_dense_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64();            \
     } while (0)
 #else

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kNarrowRows) void narrow_fwd_kernel(const float* __
         for (int k = 0; k < HP; ++k) {
             if (k >= H) continue;
             float h = fmaf(x[k], pro.saved[2 * pro.C + k], pro.saved[3 * pro.C + k]);
-            if (pro.act == GLASS_ACT_ELU) h = elu_f(h);
+            h = act_exact(pro.act, h);
             if (drop.p > 0.f) {
                 float ds[1];
                 drop_scales<1>(drop, row, k, ds);
@@ -131,10 +131,7 @@ __global__ __launch_bounds__(kNarrowRows) void narrow_fwd_kernel(const float* __
             T[row * ldt + H + o] = z0;
         }
         float a1 = z1, a0 = z0;
-        if (act == GLASS_ACT_ELU) {
-            a1 = elu_fast_f(a1);
-            a0 = elu_fast_f(a0);
-        }
+        a1 = act_fast(act, a1), a0 = act_fast(act, a0);
         const float v = ok ? w1 * a1 + w0 * a0 : 0.f;
         if (ok) out[row * ldo + o] = v;
         if (stats) narrow_col_partial<HP>((double)v, (double)v * (double)v, o, red);
@@ -165,9 +162,9 @@ __global__ __launch_bounds__(kNarrowRows) void narrow_dgrad_kernel(const float* 
     for (int o = 0; o < HP; ++o) {
         float d = (ok && o < H) ? dsrc[row * ldd + o] : 0.f;
         float g1 = d * c1, g0 = d * c0;
-        if (act == GLASS_ACT_ELU && ok && o < H) {
-            g1 *= elu_grad_f(T[row * ldt + o]);
-            g0 *= elu_grad_f(T[row * ldt + H + o]);
+        if (act != GLASS_ACT_NONE && ok && o < H) {
+            g1 *= act_grad(act, T[row * ldt + o]);
+            g0 *= act_grad(act, T[row * ldt + H + o]);
         }
         dz[o] = g1;
         dz[HP + o] = g0;
@@ -212,7 +209,7 @@ __global__ __launch_bounds__(kNarrowRows) void narrow_dgrad_kernel(const float* 
                     drop_scales<1>(gs.drop, row, j, ds);
                     gp *= ds[0];
                 }
-                if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv, gs.saved[2 * H + j], gs.saved[3 * H + j]));
+                if (gs.act != GLASS_ACT_NONE) gp *= act_grad(gs.act, fmaf(xv, gs.saved[2 * H + j], gs.saved[3 * H + j]));
                 xhat = (xv - gs.alpha[j] * gs.saved[j]) * gs.saved[H + j];
             }
             narrow_col_partial<HP>((double)gp, (double)gp * (double)xhat, j, red);
@@ -245,7 +242,7 @@ __global__ __launch_bounds__(kNarrowRows) void narrow_wgrad_kernel(WgradSynth sy
             const bool first = o < H;
             const float cf = ((sy.mask[n] != 0) == first) ? sy.zr : sy.omz;
             g = sy.dsrc[n * sy.ldd + (first ? o : o - H)] * cf;
-            if (sy.act == GLASS_ACT_ELU) g *= elu_grad_f(sy.T[n * sy.ldt + o]);
+            if (sy.act != GLASS_ACT_NONE) g *= act_grad(sy.act, sy.T[n * sy.ldt + o]);
         }
         dz_s[r][o] = g;
     }

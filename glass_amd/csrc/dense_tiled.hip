@@ -218,7 +218,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
                               fmaf(v.w, asc[i].w, ash[i].w)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (pro.act == GLASS_ACT_ELU) o[e] = elu_f(o[e]);
+                    o[e] = act_exact(pro.act, o[e]);
                     o[e] *= ds[e];
                 }
                 v = make_float4(o[0], o[1], o[2], o[3]);
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
                         float o[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            if (pro.act == GLASS_ACT_ELU) o[e] = elu_f(o[e]);
+                            o[e] = act_exact(pro.act, o[e]);
                             o[e] *= ds[e];
                         }
                         v = make_float4(o[0], o[1], o[2], o[3]);
@@ -363,9 +363,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
                     *reinterpret_cast<float2*>(T + r * ldt + H + colp) = make_float2(v0x, v0y);
                 }
                 float a1x = v1x, a1y = v1y, a0x = v0x, a0y = v0y;
-                if (act == GLASS_ACT_ELU) {
-                    a1x = elu_fast_f(a1x); a1y = elu_fast_f(a1y); a0x = elu_fast_f(a0x); a0y = elu_fast_f(a0y);
-                }
+                a1x = act_fast(act, a1x), a1y = act_fast(act, a1y), a0x = act_fast(act, a0x), a0y = act_fast(act, a0y);
                 const float ox = w1 * a1x + w0 * a0x, oy = w1 * a1y + w0 * a0y;
                 *reinterpret_cast<float2*>(out + r * ldo + colp) = make_float2(ox, oy);
                 s0 += (double)ox; q0 += (double)ox * (double)ox;
@@ -466,7 +464,7 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
             const int o = ks * kTK + 4 * skq[i];  // column of dZ (SPLIT: of both halves)
             const int64_t r = row0 + srow[i];
             dv[i] = sok[i] ? *reinterpret_cast<const float4*>(dsrc + r * ldd + (o < H ? o : o - H)) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (act == GLASS_ACT_ELU) {
+            if (act != GLASS_ACT_NONE) {
                 tv[i] = sok[i] ? *reinterpret_cast<const float4*>(T + r * ldt + o) : make_float4(0.f, 0.f, 0.f, 0.f);
                 if (SPLIT) tw[i] = sok[i] ? *reinterpret_cast<const float4*>(T + r * ldt + H + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -479,15 +477,15 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
             const int o = ks * kTK + 4 * skq[i];
             const float coef = sok[i] ? (pure ? 1.f : ((slab[i] == (o < H)) ? zr : omz)) : 0.f;
             float4 v = make_float4(dv[i].x * coef, dv[i].y * coef, dv[i].z * coef, dv[i].w * coef);
-            if (act == GLASS_ACT_ELU) {
-                v.x *= elu_grad_f(tv[i].x); v.y *= elu_grad_f(tv[i].y); v.z *= elu_grad_f(tv[i].z); v.w *= elu_grad_f(tv[i].w);
+            if (act != GLASS_ACT_NONE) {
+                v.x *= act_grad(act, tv[i].x); v.y *= act_grad(act, tv[i].y); v.z *= act_grad(act, tv[i].z); v.w *= act_grad(act, tv[i].w);
             }
             stage[skq[i] * TL::kAPlane + srow[i]] = v;
             if (SPLIT) {  // the f0 half of the same dsrc columns: the other label coefficient, the other half of T
                 const float c0 = sok[i] ? (slab[i] ? omz : zr) : 0.f;
                 float4 u = make_float4(dv[i].x * c0, dv[i].y * c0, dv[i].z * c0, dv[i].w * c0);
-                if (act == GLASS_ACT_ELU) {
-                    u.x *= elu_grad_f(tw[i].x); u.y *= elu_grad_f(tw[i].y); u.z *= elu_grad_f(tw[i].z); u.w *= elu_grad_f(tw[i].w);
+                if (act != GLASS_ACT_NONE) {
+                    u.x *= act_grad(act, tw[i].x); u.y *= act_grad(act, tw[i].y); u.z *= act_grad(act, tw[i].z); u.w *= act_grad(act, tw[i].w);
                 }
                 stage[TL::kAImg + skq[i] * TL::kAPlane + srow[i]] = u;
             }
@@ -624,7 +622,7 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
 #pragma unroll
                     for (int e = 0; e < CB; ++e) {
                         float gp = v[e] * ds[e];
-                        if (gs.act == GLASS_ACT_ELU) gp *= elu_grad_f(fmaf(xv[e], g_scale[e], g_shift[e]));
+                        if (gs.act != GLASS_ACT_NONE) gp *= act_grad(gs.act, fmaf(xv[e], g_scale[e], g_shift[e]));
                         const float xhat = (xv[e] - g_al[e] * g_mu[e]) * g_rstd[e];
                         s1[e] += (double)gp;
                         s2[e] += (double)gp * (double)xhat;

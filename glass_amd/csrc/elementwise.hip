@@ -168,10 +168,7 @@ __global__ __launch_bounds__(kBlock) void mix_fwd_kernel(const float* __restrict
 #pragma unroll
             for (int k = 0; k < VW; ++k) {
                 float a1 = t1[u].a[k], a0 = t0[u].a[k];
-                if (act == GLASS_ACT_ELU) {
-                    a1 = elu_f(a1);
-                    a0 = elu_f(a0);
-                }
+                a1 = act_exact(act, a1), a0 = act_exact(act, a0);
                 t1[u].a[k] = w1[u] * a1 + w0 * a0;
             }
             t1[u].store(out + rr * ldo + c0);
@@ -198,7 +195,7 @@ __global__ __launch_bounds__(kBlock) void mix_bwd_kernel(const float* __restrict
             const int64_t rr = r + u * stride;
             if (rr < N) {
                 g[u].load(dout + rr * ldd + c0);
-                if (act == GLASS_ACT_ELU) {
+                if (act != GLASS_ACT_NONE) {
                     t1[u].load(T + rr * ldt + c0);
                     t0[u].load(T + rr * ldt + H + c0);
                 }
@@ -214,10 +211,7 @@ __global__ __launch_bounds__(kBlock) void mix_bwd_kernel(const float* __restrict
 #pragma unroll
             for (int k = 0; k < VW; ++k) {
                 float g1 = g[u].a[k] * w1[u], g0 = g[u].a[k] * w0;
-                if (act == GLASS_ACT_ELU) {
-                    g1 *= elu_grad_f(t1[u].a[k]);
-                    g0 *= elu_grad_f(t0[u].a[k]);
-                }
+                g1 *= act_grad(act, t1[u].a[k]), g0 *= act_grad(act, t0[u].a[k]);
                 d1.a[k] = g1;
                 d0.a[k] = g0;
             }

@@ -320,7 +320,7 @@ __device__ __forceinline__ float4 gn_bwd_apply4(const float4& dy, const float4& 
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float g = dv[k] * ds[k];
-        if (act == GLASS_ACT_ELU) g *= elu_grad_f(fmaf(xv[k], scv[k], shv[k]));
+        g *= act_grad(act, fmaf(xv[k], scv[k], shv[k]));
         o[k] = fmaf(Av[k], g, fmaf(Bv[k], xv[k], Kv[k])) + av[k];
     }
     return make_float4(o[0], o[1], o[2], o[3]);

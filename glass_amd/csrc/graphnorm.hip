@@ -208,7 +208,7 @@ __global__ __launch_bounds__(kBlock) void gn_apply_kernel(const float* __restric
 #pragma unroll
             for (int k = 0; k < VW; ++k) {
                 float h = fmaf(v[u].a[k], scale[k], shift[k]);
-                if (act == GLASS_ACT_ELU) h = elu_f(h);
+                h = act_exact(act, h);
                 v[u].a[k] = h * ds[k];
             }
             v[u].store(y + rr * ldy + c0);
@@ -226,9 +226,9 @@ __device__ __forceinline__ void bwd_g(float (&g)[VW], const float (&xv)[VW], con
 #pragma unroll
         for (int k = 0; k < VW; ++k) g[k] *= ds[k];
     }
-    if (act == GLASS_ACT_ELU) {
+    if (act != GLASS_ACT_NONE) {
 #pragma unroll
-        for (int k = 0; k < VW; ++k) g[k] *= elu_grad_f(fmaf(xv[k], scale[k], shift[k]));
+        for (int k = 0; k < VW; ++k) g[k] *= act_grad(act, fmaf(xv[k], scale[k], shift[k]));
     }
 }
 
@@ -479,7 +479,7 @@ extern "C" int glass_graphnorm_fwd_f32(const float* x, int64_t ldx, float* y, in
     GLASS_REQUIRE(n_rows > 0 && C > 0 && ldx >= C && ldy >= C, "graphnorm_fwd: bad sizes N=%lld C=%lld",
                   (long long)n_rows, (long long)C);
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_fwd: bad dropout args");
-    GLASS_REQUIRE(act == GLASS_ACT_NONE || act == GLASS_ACT_ELU, "graphnorm_fwd: bad act %d", act);
+    GLASS_REQUIRE(act_code_ok(act), "graphnorm_fwd: bad act %d", act);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y);
     const Tiling t = make_tiling(C, vec);
@@ -565,7 +565,7 @@ extern "C" int glass_graphnorm_apply_f32(const float* x, int64_t ldx, float* y, 
     GLASS_REQUIRE(x && y && saved, "graphnorm_apply: null pointer");
     GLASS_REQUIRE(n_rows > 0 && C > 0 && ldx >= C && ldy >= C, "graphnorm_apply: bad sizes");
     GLASS_REQUIRE(p_drop >= 0.f && p_drop < 1.f && (p_drop == 0.f || rng_state), "graphnorm_apply: bad dropout args");
-    GLASS_REQUIRE(act == GLASS_ACT_NONE || act == GLASS_ACT_ELU, "graphnorm_apply: bad act %d", act);
+    GLASS_REQUIRE(act_code_ok(act), "graphnorm_apply: bad act %d", act);
     hipStream_t st = (hipStream_t)stream;
     const bool vec = C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && aligned16(x) && aligned16(y);
     const Tiling t = make_tiling(C, vec);

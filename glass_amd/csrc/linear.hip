@@ -582,7 +582,7 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     GLASS_REQUIRE(ldd >= H && ldx >= H && (!dW || lddw >= I) && (!X2 || ldx2 >= H) && (act == GLASS_ACT_NONE || (T && ldt >= O)),
                   "dual_linear_wgrad: bad sizes");
     if (narrow_shape_ok(H)) {  // hidden <= 32: thread-owned outputs over 256-row slabs (dense_narrow.hip), any alignment
-        const WgradSynth nsy{dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
+        const WgradSynth nsy{dsrc, ldd, act != GLASS_ACT_NONE ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
                              act, (int)H, X2, ldx2};
         int rc = launch_narrow_wgrad(nsy, X, ldx, N, O, I, (float*)ws, (hipStream_t)stream);
         if (rc || !dW) return rc;
@@ -596,7 +596,7 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
         return GLASS_E_UNSUPPORTED;
     }
     hipStream_t st = (hipStream_t)stream;
-    const WgradSynth sy{dsrc, ldd, act == GLASS_ACT_ELU ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
+    const WgradSynth sy{dsrc, ldd, act != GLASS_ACT_NONE ? T : nullptr, ldt, mask, (float)z_ratio, (float)(1.0 - z_ratio),
                         act, (int)H, X2, ldx2};
     if (wgrad_tiled_shape(N, O, I)) {  // wide layer on a large graph: LDS-tiled kernel (wgrad_tiled.hip)
         if (ldx % 4 || !aligned16(X) || (X2 && (ldx2 % 4 || !aligned16(X2)))) {

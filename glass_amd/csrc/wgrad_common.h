@@ -124,7 +124,7 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
                 if (i_ok) S.x[s] = *reinterpret_cast<const float2*>(X + nn * ldx + i0);
             } else {  // O = 2H and I are multiples of the tile sizes: every lane is in range
                 S.g[s] = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (first ? o0 : o0 - sy.H));
-                if (sy.act == GLASS_ACT_ELU) S.t[s] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
+                if (sy.act != GLASS_ACT_NONE) S.t[s] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
                 S.mk[s] = sy.mask[nn];
                 S.x[s] = (i0 < sy.H || sy.X2 == nullptr)
                              ? *reinterpret_cast<const float2*>(X + nn * ldx + i0)
@@ -144,10 +144,10 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
                 if (SYNTH && !EFF) {
                     const float cf = ((st[k].mk[s] != 0) == first) ? sy.zr : sy.omz;
                     g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
-                    if (sy.act == GLASS_ACT_ELU) {
+                    if (sy.act != GLASS_ACT_NONE) {
                         const float4 t = st[k].t[s];
-                        g.x *= elu_grad_f(t.x); g.y *= elu_grad_f(t.y); g.z *= elu_grad_f(t.z); g.w *= elu_grad_f(t.w);
-                    }
+                        g.x *= act_grad(sy.act, t.x); g.y *= act_grad(sy.act, t.y); g.z *= act_grad(sy.act, t.z); g.w *= act_grad(sy.act, t.w);
+                        }
                 }
                 if (!st[k].live[s]) g = make_float4(0.f, 0.f, 0.f, 0.f);
                 const float gv[4] = {g.x, g.y, g.z, g.w};
@@ -248,10 +248,7 @@ __device__ __forceinline__ void wgrad_trans_staged2_body(const float* __restrict
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             float z1 = d[k] * c1, z0 = d[k] * c0;
-            if (sy.act == GLASS_ACT_ELU) {
-                z1 *= elu_grad_f(t1[k]);
-                z0 *= elu_grad_f(t0[k]);
-            }
+            z1 *= act_grad(sy.act, t1[k]), z0 *= act_grad(sy.act, t0[k]);
             dzT[(4 * ga + k) * RT + rs] = z1;
             dzT[(H + 4 * ga + k) * RT + rs] = z0;
             xT[(4 * ga + k) * RT + rs] = xv[k];
@@ -614,7 +611,7 @@ __device__ __forceinline__ void wgrad_synth_staged_body(const float* __restrict_
         if (row < nrows) {
             const int64_t n = r0 + row;
             dv[k] = *reinterpret_cast<const float4*>(sy.dsrc + n * sy.ldd + 4 * (oq & 15));
-            if (sy.act == GLASS_ACT_ELU) tv[k] = *reinterpret_cast<const float4*>(sy.T + n * sy.ldt + 4 * oq);
+            if (sy.act != GLASS_ACT_NONE) tv[k] = *reinterpret_cast<const float4*>(sy.T + n * sy.ldt + 4 * oq);
             cfv[k] = ((sy.mask[n] != 0) == (oq < 16)) ? sy.zr : sy.omz;
         }
     }
@@ -628,8 +625,8 @@ __device__ __forceinline__ void wgrad_synth_staged_body(const float* __restrict_
         const int item = threadIdx.x + kBlock * k, row = item >> 5, oq = item & 31;
         if (row >= nrows8) continue;
         float4 g = make_float4(dv[k].x * cfv[k], dv[k].y * cfv[k], dv[k].z * cfv[k], dv[k].w * cfv[k]);
-        if (sy.act == GLASS_ACT_ELU) {
-            g.x *= elu_grad_f(tv[k].x); g.y *= elu_grad_f(tv[k].y); g.z *= elu_grad_f(tv[k].z); g.w *= elu_grad_f(tv[k].w);
+        if (sy.act != GLASS_ACT_NONE) {
+            g.x *= act_grad(sy.act, tv[k].x); g.y *= act_grad(sy.act, tv[k].y); g.z *= act_grad(sy.act, tv[k].z); g.w *= act_grad(sy.act, tv[k].w);
         }
         *reinterpret_cast<float4*>(dz_s + row * 128 + 4 * oq) = g;
     }

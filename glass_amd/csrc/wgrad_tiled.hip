@@ -69,7 +69,7 @@ struct WStageRegs {
                 ga[a] = *reinterpret_cast<const float4*>(c.G + nn * c.ldg + c.a_col);
             } else {
                 ga[a] = *reinterpret_cast<const float4*>(sy.dsrc + nn * sy.ldd + (c.a_first ? c.a_col : c.a_col - sy.H));
-                if (sy.act == GLASS_ACT_ELU) ta[a] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + c.a_col);
+                if (sy.act != GLASS_ACT_NONE) ta[a] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + c.a_col);
                 mk[a] = sy.mask[nn];
             }
         }
@@ -87,8 +87,8 @@ struct WStageRegs {
             if (SYNTH) {
                 const float cf = c.eff ? ((c.lab && mk[a] == 0) ? 0.f : 1.f) : (((mk[a] != 0) == c.a_first) ? sy.zr : sy.omz);
                 g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
-                if (sy.act == GLASS_ACT_ELU) {
-                    g.x *= elu_grad_f(ta[a].x); g.y *= elu_grad_f(ta[a].y); g.z *= elu_grad_f(ta[a].z); g.w *= elu_grad_f(ta[a].w);
+                if (sy.act != GLASS_ACT_NONE) {
+                    g.x *= act_grad(sy.act, ta[a].x); g.y *= act_grad(sy.act, ta[a].y); g.z *= act_grad(sy.act, ta[a].z); g.w *= act_grad(sy.act, ta[a].w);
                 }
             }
             if (!alive[a]) g = make_float4(0.f, 0.f, 0.f, 0.f);

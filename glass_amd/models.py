@@ -16,7 +16,7 @@ import os
 
 from . import ops, stack
 from .graph import CSRAdj, Selection
-from .ops import ACT_ELU, ACT_NONE
+from .ops import ACT_ELU, ACT_NONE, ACT_RELU
 from .utils import batch2pad
 
 
@@ -48,9 +48,13 @@ class GraphNorm(nn.Module):
 
 
 def _act_code(activation):
-    """ELU(alpha=1) is fused into the kernels; any other module runs as a torch GPU op."""
+    """ELU(alpha=1) (the driver's choice, GLASSTest.py:143) and ReLU (the reference's constructor default,
+    impl/models.py:125,192; the pre-training path, GNNEmb.py:90) are fused into the kernels; any other module runs as a
+    torch GPU op."""
     if isinstance(activation, nn.ELU) and activation.alpha == 1.0:
         return ACT_ELU
+    if type(activation) is nn.ReLU:
+        return ACT_RELU
     return None
 
 
@@ -430,6 +434,8 @@ class EmbGConv(nn.Module):
         dims = [input_channels] + [hidden_channels] * (num_layers - 1) + [output_channels]
         self.convs = nn.ModuleList([conv(in_channels=dims[i], out_channels=dims[i + 1], **kwargs)
                                     for i in range(num_layers)])
+        for l, layer in enumerate(self.convs):
+            layer.call_base = 16 * (l + 1)  # dropout streams of the step program (stack.StackProgram, unlabeled mode)
         self.activation = activation
         self.dropout = dropout
         self.gns = nn.ModuleList([GraphNorm(hidden_channels) for _ in range(num_layers - 1)]) if gn else None
@@ -448,6 +454,11 @@ class EmbGConv(nn.Module):
         x_flat = x.reshape(-1)
         if x_flat.dtype != torch.int64:
             x_flat = x_flat.to(torch.int64)
+        if USE_STACK and z is None and stack.StackProgram.supported(self):
+            # the whole stack as one autograd node on the fused kernels (glass_amd/stack.py, unlabeled mode)
+            if not x_flat.is_contiguous():
+                x_flat = x_flat.contiguous()
+            return stack.run(self, x_flat, None, edge_index, edge_weight)
         h, _mask = ops.embed_label(self.input_emb.weight, x_flat, None, self._selection(x_flat))
         h = F.dropout(h, p=self.dropout, training=self.training)
         # The reference appends the GraphNorm output and then applies the activation to that very tensor; with

@@ -9,7 +9,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_NONE, ACT_ELU, POOL_MODES, GlassHipError
+from ._lib import ACT_NONE, ACT_ELU, ACT_RELU, POOL_MODES, GlassHipError
 
 
 def _stream():

@@ -26,7 +26,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .ops import ACT_ELU, ACT_NONE, _stream
+from .ops import ACT_ELU, ACT_NONE, ACT_RELU, _stream
 
 USE_EMBED_TABLE = os.environ.get("GLASS_EMBED_TABLE", "1") != "0"  # A/B switch: lookup + emb_gn through the table
 USE_READOUT = os.environ.get("GLASS_READOUT", "1") != "0"          # A/B switch: fused training readout (K8r)
@@ -402,18 +402,47 @@ class StackProgram:
         self.emb = emb
 
     @staticmethod
+    def supported_unlabeled(emb):
+        """The pre-training stack (models.EmbGConv of MyGCNConv layers: reference impl/models.py:361-473) on the same
+        program: no labels (an all-zero label byte vector, an empty labeled-row list), every Linear as the second half of a
+        pair with z_ratio = 1 (arena._pairs), no GraphNorm behind the embedding, none behind the last layer, no JK — hidden
+        64 (the staged kernels + exact GraphNorm accumulators), ELU or ReLU."""
+        from .models import EmbGConv, MyGCNConv, _act_code
+        if not (isinstance(emb, EmbGConv) and ops.USE_FUSED_DENSE and getattr(emb, "_glass_arena", None) is not None and
+                emb.gns is not None and not emb.jk and len(emb.convs)):
+            return False
+        code = _act_code(emb.activation)
+        H = emb.input_emb.weight.shape[1]
+        lib = _lib.load()
+        if code not in (ACT_ELU, ACT_RELU) or H != 64 or not (USE_GN_EXACT and lib.glass_gn_exact_supported(H) and USE_COMB_EFF and
+                                                            lib.glass_comb_eff_supported(H)):
+            return False
+        for c in emb.convs:
+            st = getattr(c, "_stack", {})
+            if not (isinstance(c, MyGCNConv) and _act_code(c.activation) == code and len(st.get("trans", ())) == 6 and
+                    len(st.get("comb", ())) == 6 and getattr(c, "_stack_eff", {}).get("comb", (None, None))[1] is not None and
+                    c.trans_fn.weight.shape == (H, H) and c.comb_fn.weight.shape == (H, 2 * H)):
+                return False
+        mods = [c.gn for c in emb.convs] + list(emb.gns)
+        return all(getattr(m, "_direct_grad", False) and m.weight.grad is not None for m in mods) and \
+            emb.input_emb.weight.grad is not None
+
+    @staticmethod
     def supported(emb):
-        from .models import GLASSConv, _act_code
+        from .models import GLASSConv, EmbGConv, _act_code
+        if isinstance(emb, EmbGConv):
+            return StackProgram.supported_unlabeled(emb)
         if not ops.USE_FUSED_DENSE or getattr(emb, "_glass_arena", None) is None or emb.gns is None:
             return False
-        if _act_code(emb.activation) != ACT_ELU or not len(emb.convs):
+        code = _act_code(emb.activation)
+        if code not in (ACT_ELU, ACT_RELU) or not len(emb.convs):
             return False
         H = emb.input_emb.weight.shape[1]
         if not ops.dual_linear_supported(H):
             return False
         for c in emb.convs:
             st = getattr(c, "_stack", {})
-            if not (isinstance(c, GLASSConv) and _act_code(c.activation) == ACT_ELU and
+            if not (isinstance(c, GLASSConv) and _act_code(c.activation) == code and
                     len(st.get("trans", ())) == 6 and len(st.get("comb", ())) == 6 and
                     c.trans_fns[0].weight.shape == (H, H) and c.comb_fns[0].weight.shape == (H, 2 * H)):
                 return False
@@ -445,13 +474,22 @@ class StackProgram:
         f32 = dict(dtype=torch.float32, device=dev)
         # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
         advance = train and (p > 0 or any(c.dropout > 0 for c in emb.convs))
-        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc), "rng_epoch": ops.rng_epoch(dev),
+        from .models import _act_code
+        act = _act_code(emb.activation)  # ELU or ReLU, the same code in every layer (supported())
+        st = {"n": n, "H": H, "L": L, "p": p, "x_flat": x_flat, "acc": int(acc), "rng_epoch": ops.rng_epoch(dev), "act": act,
               "stat_rows": int(lib.glass_dual_linear_stat_rows(H))}  # rows per workgroup of the fused dense kernels
         # labels: z (int64 [N], > 0 = labeled), None (all labeled), or ("pos", pos): labeled = the nodes listed in the
         # padded subgraph matrix — utils.MaxZOZ without materialising z (a byte memset + scatter inside the gather)
         # labels (BatchLabels, already loaded for this batch): the label bytes are an input and the unique labeled rows are
         # listed — the comb pairs then run in effective-weight form at hidden 64.  With ("pos", pos) and no labels handed
         # in, they are computed here (one extra launch; the replayed training step hands them in).
+        unl = not hasattr(emb, "emb_gn")  # the unlabeled pre-training stack (models.EmbGConv): see supported_unlabeled
+        st["unlabeled"] = unl
+        if unl:
+            labels = emb.__dict__.get("_glass_no_labels")
+            if labels is None or labels.n != n or labels.mask.device != dev:
+                labels = emb.__dict__["_glass_no_labels"] = BatchLabels(n, 1, dev)  # zero label bytes, count 0 (capacity 1:
+                labels.loaded = True                                                 # the S / L reduce keys on cap > 0)
         if isinstance(z, tuple) and labels is None and train:
             labels = BatchLabels(n, z[1].numel(), dev)
             labels.load(z[1])
@@ -467,8 +505,8 @@ class StackProgram:
         st["labels"] = labels
         h = torch.empty((n, H), **f32)
         st["mask"] = mask
-        gn0 = emb.emb_gn
-        use_table = V <= _lib.EMBED_NORM_MAX_ROWS and USE_EMBED_TABLE
+        gn0 = None if unl else emb.emb_gn
+        use_table = (V <= _lib.EMBED_NORM_MAX_ROWS and USE_EMBED_TABLE) or unl
         # Hidden 64 with the label bytes already made (labels): layer 0's trans kernel gathers its operand rows from the
         # embedding table itself (xa_index) and normalises them with emb_gn's table statistics, which ride in the prologue
         # launch next to the weight packing — no table-apply kernel, no gather launch.
@@ -491,7 +529,7 @@ class StackProgram:
                           all(_comb_eff_fwd_ok(conv, labels, H) for conv in emb.convs))
         if exact_all or exact_fwd_only:
             n_bwd = 2 * L - 1 if (keep and exact_all) else 0
-            n_fwd = 2 * L if (readout is not None and USE_GN_EXACT_FWD) else 0
+            n_fwd = 2 * L if ((readout is not None or unl) and USE_GN_EXACT_FWD) else 0
             # ... and one block of L*H (jk) / H columns for the final GraphNorm's backward sums, added to by the readout's
             # first kernel and folded by its backfill launch (two launches instead of three)
             w_h = int(lib.glass_gn_exact_words(H))
@@ -509,7 +547,17 @@ class StackProgram:
             acc_all = acc_ro = torch.empty(int(lib.glass_gn_exact_words(H * L if emb.jk else H)), dtype=torch.int64, device=dev)
         st["gn_exact"] = acc_bwd
         st["gn_exact_readout"] = acc_ro
-        if use_table and labels is not None and USE_GATHER_IN_TRANS and lib.glass_dual_linear_fwd_gather_supported(H):
+        if unl:
+            # no GraphNorm behind the embedding (impl/models.py:461-463): layer 0's trans kernel gathers the table rows under
+            # identity coefficients (mean 0, rstd 1, scale 1, shift 0) and applies the embedding's dropout (call id 1)
+            sel = emb._selection(x_flat)
+            ident = emb.__dict__.get("_glass_ident_saved")
+            if ident is None or ident.device != dev:
+                ident = emb.__dict__["_glass_ident_saved"] = torch.cat([torch.zeros(H, **f32), torch.ones(2 * H, **f32), torch.zeros(H, **f32)])
+            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None, zero=acc_all)
+            st["emb_table"], st["emb_saved"] = sel, ident
+            first_gn = (ident, ACT_NONE, p, 1)
+        elif use_table and labels is not None and USE_GATHER_IN_TRANS and lib.glass_dual_linear_fwd_gather_supported(H):
             sel = emb._selection(x_flat)
             saved = torch.empty(4 * H, **f32)
             emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None,
@@ -557,13 +605,13 @@ class StackProgram:
             m = torch.empty((n, H), **f32)
             if pending_gn is None and first_gn is not None:
                 # h = dropout(emb_gn(input_emb(x))) is this kernel's side output
-                _dual_fwd(W, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m, gn=(*first_gn, h), xa_index=x_flat)
+                _dual_fwd(W, None, conv._stack["trans"], mask, conv.z_ratio, act, T, m, gn=(*first_gn, h), xa_index=x_flat)
             elif pending_gn is None:
-                _dual_fwd(h, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m)
+                _dual_fwd(h, None, conv._stack["trans"], mask, conv.z_ratio, act, T, m)
             else:
                 # gns[l-1] (+ELU +dropout) is applied by the trans kernel while it loads c_{l-1}; h = its side output
                 h = torch.empty((n, H), **f32)
-                _dual_fwd(c_prev, None, conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, T, m, gn=(*pending_gn, h))
+                _dual_fwd(c_prev, None, conv._stack["trans"], mask, conv.z_ratio, act, T, m, gn=(*pending_gn, h))
             a = conv.adj.fwd.spmm(m)
             # conv.gn: statistics + finalize here, the apply (+dropout) rides in the comb kernel's operand load
             g = torch.empty((n, H), **f32)
@@ -571,7 +619,10 @@ class StackProgram:
             last = l + 1 == L
             c = jk[:, l * H:(l + 1) * H] if emb.jk else (jk if last else torch.empty((n, H), **f32))
             # the comb kernel's epilogue also leaves the column statistics of c for the GraphNorm(s) that read it
-            if _comb_eff_fwd_ok(conv, labels, H):
+            if unl and last:
+                cstat = None  # (nothing normalises the last layer's output: impl/models.py:469)
+                _comb_eff_fwd(a, h, conv, mask, c, None, (gsaved, ACT_NONE, pc, conv.call_base, g), labels)
+            elif _comb_eff_fwd_ok(conv, labels, H):
                 cstat = acc_fwd[L + l] if acc_fwd is not None else \
                     torch.empty((int(lib.glass_comb_eff_blocks(n, H, labels.cap)), 2, H), dtype=torch.float64, device=dev)
                 _comb_eff_fwd(a, h, conv, mask, c, cstat, (gsaved, ACT_NONE, pc, conv.call_base, g), labels)
@@ -588,9 +639,11 @@ class StackProgram:
                 else:
                     nsaved = _GN(emb.gns[l]).finalize([cstat], n)
                 rec["nsaved"] = getattr(nsaved, "saved", nsaved)
-                pending_gn, c_prev = (nsaved, ACT_ELU, p, conv.call_base + 1), c
+                pending_gn, c_prev = (nsaved, act, p, conv.call_base + 1), c
             layers.append(rec if keep else None)
         st["jk"], st["layers"] = jk, layers
+        if unl:
+            return jk, (st if keep else None)  # the raw output of the last layer (no final GraphNorm, no JK)
         gnf = _GN(emb.gns[-1])
         if acc_fwd is not None:  # the readout's first kernel derives the final GraphNorm's coefficients
             st["final_saved"] = _PendingStats(torch.empty(4 * C_out, **f32), acc_fwd[L:] if emb.jk else acc_fwd[2 * L - 1],
@@ -648,13 +701,16 @@ class StackProgram:
         step starts the all-reduce of the small gradient bucket there, beside the rest of this backward pass)."""
         emb = self.emb
         n, H, L, p = st["n"], st["H"], st["L"], st["p"]
+        act = st["act"]
         dev = st["mask"].device
         f32 = dict(dtype=torch.float32, device=dev)
         mask, jk = st["mask"], st["jk"]
         if st.get("rng_words") is None and (p > 0 or any(rec is not None and rec["pc"] > 0 for rec in st["layers"])):
             ops.check_rng_epoch(dev, st["rng_epoch"], "StackProgram.backward")  # live words: they must be this pass's still
         acc = st["acc"]  # 1: add into the gradient arena; 0: overwrite (every gradient is written exactly once)
-        if "djk" in st:  # the fused readout already went through the final GraphNorm
+        if st.get("unlabeled"):
+            djk = dout  # no final GraphNorm: the caller's gradient is the last layer's
+        elif "djk" in st:  # the fused readout already went through the final GraphNorm
             djk = st["djk"]
         else:
             djk = torch.empty_like(jk)
@@ -679,12 +735,12 @@ class StackProgram:
                 dc_src = _lib.GnBwdSrc(npart.data_ptr(), _rep(npart), dh_next.data_ptr(), dh_next.stride(0), rec["c"].data_ptr(),
                                        rec["c"].stride(0), 0 if ad is None else ad.data_ptr(), 0 if ad is None else ad.stride(0),
                                        rec["nsaved"].data_ptr(), m.weight.data_ptr(), m.mean_scale.data_ptr(),
-                                       m.weight.grad.data_ptr(), m.bias.grad.data_ptr(), m.mean_scale.grad.data_ptr(), acc, ACT_ELU,
+                                       m.weight.grad.data_ptr(), m.bias.grad.data_ptr(), m.mean_scale.grad.data_ptr(), acc, act,
                                        float(p), conv.call_base + 1)
                 dc = dh_next  # (shape carrier)
             else:
                 dc = torch.empty((n, H), **f32)
-                _GN(emb.gns[l]).bwd_from_stats(dh_next, rec["c"], rec["nsaved"], dc, npart, ACT_ELU, p, conv.call_base + 1,
+                _GN(emb.gns[l]).bwd_from_stats(dh_next, rec["c"], rec["nsaved"], dc, npart, act, p, conv.call_base + 1,
                                                addend=djk[:, l * H:(l + 1) * H] if emb.jk else None, acc=acc)
             din = torch.empty((n, 2 * H), **f32)  # [d g | d x_]
             # conv.gn's backward column sums come from this kernel's epilogue
@@ -719,13 +775,26 @@ class StackProgram:
             if l > 0:
                 below, cb = st["layers"][l - 1], emb.convs[l - 1]
                 npart = acc_all[2 * l - 1] if acc_all is not None else torch.empty((nblk, 2, H), **f64)
-                gn = (npart, below["c"], below["nsaved"], emb.gns[l - 1].mean_scale, ACT_ELU, p, cb.call_base + 1)
-            _dual_bwd(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, ACT_ELU, H, din[:, H:], dh, rec["h"], None, pending,
+                gn = (npart, below["c"], below["nsaved"], emb.gns[l - 1].mean_scale, act, p, cb.call_base + 1)
+            _dual_bwd(dm, rec["T"], conv._stack["trans"], mask, conv.z_ratio, act, H, din[:, H:], dh, rec["h"], None, pending,
                       acc, drop, gn)
             dh_next = dh
             st["layers"][l] = None  # release this layer's activations
-        W, gn0 = emb.input_emb.weight, emb.emb_gn
+        W = emb.input_emb.weight
         self.applied_optimizer = False
+        if st.get("unlabeled"):
+            # no GraphNorm behind the embedding: the selection product IS the table's gradient (layer 0's data-gradient
+            # epilogue applied the embedding's dropout mask already)
+            _reduce_pending(pending, None)
+            if tail_hook is not None:
+                tail_hook()
+            sel = st["emb_table"]
+            if acc:
+                W.grad.add_(sel.op.spmm(dh_next))
+            else:
+                sel.op.spmm(dh_next, out=W.grad)
+            return
+        gn0 = emb.emb_gn
         fused_tail = "emb_table" in st and USE_FUSED_TAIL
         # the deferred weight-gradient reductions — and, on the table path, the selection product of the embedding
         # backward in the same launch (both only wait for the end of the chain above)
@@ -772,6 +841,13 @@ class StackProgram:
     def written_params(self, head):
         """Every parameter whose gradient loss_and_grads writes (exactly once per call)."""
         emb = self.emb
+        if not hasattr(emb, "emb_gn"):  # the unlabeled pre-training stack: head gradients are the pair head's business
+            out = [emb.input_emb.weight]
+            for gn in [c.gn for c in emb.convs] + list(emb.gns):
+                out += [gn.weight, gn.bias, gn.mean_scale]
+            for c in emb.convs:
+                out += [c.trans_fn.weight, c.trans_fn.bias, c.comb_fn.weight, c.comb_fn.bias]
+            return out
         out = [emb.input_emb.weight, head.weight, head.bias]
         for gn in [emb.emb_gn] + [c.gn for c in emb.convs] + list(emb.gns):
             out += [gn.weight, gn.bias, gn.mean_scale]

@@ -30,7 +30,7 @@ typedef struct glass_gn_bwd_src glass_gn_bwd_src;
 typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a kernel input: defined with K5's entries */
 #endif
 
-#define GLASS_ABI_VERSION 3
+#define GLASS_ABI_VERSION 4
 
 #define GLASS_E_ARG (-1)       /* bad argument (null pointer, negative size, misaligned ld) */
 #define GLASS_E_PLAN (-2)      /* plan blob does not match the call (magic / sizes) */
@@ -47,6 +47,7 @@ typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a k
 /* activation fused into a kernel: none, or ELU(alpha=1) (GLASSTest.py:143) */
 #define GLASS_ACT_NONE 0
 #define GLASS_ACT_ELU 1
+#define GLASS_ACT_RELU 2 /* hidden-64 kernels, the GraphNorm kernels and the stand-alone mix (the reference's constructor default nn.ReLU(), impl/models.py:125,192; the pre-training path, GNNEmb.py:90) */
 
 int glass_version(void);
 const char* glass_last_error_string(void);
@@ -275,6 +276,35 @@ int glass_pair_pool_f32(const float* emb, int64_t lde, const int64_t* pairs, int
                         int64_t n_nodes, int64_t C, void* stream);
 int glass_pair_pool_bwd_f32(const float* dout, int64_t ldd, const int64_t* pairs, int64_t B, int mode, float* demb,
                             int64_t lde, int64_t n_nodes, int64_t C, void* ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K9  link-prediction head of the pre-training path on node pairs, hidden 64 (glass_pair_head_supported)
+ *     replaces EdgeGNN.Pool + MLP(hidden, hidden, 1, 2) + BCEWithLogitsLoss and their autograd
+ *     (impl/models.py:497-509, 33-50; GNNEmb.py:94-99, 129-130, 144: 131 072 pairs per step):
+ *         pooled[p] = (emb[pairs[p,0]] + emb[pairs[p,1]]) / 2
+ *         hid[p]    = relu(dropout(pooled[p] W0^T + b0))           W0 [64,64] row-major, Linear -> Dropout -> ReLU
+ *         logit[p]  = hid[p] . w1 + b1                             w1 [64], b1 [1]
+ *         loss      = mean_p BCE-with-logits(logit[p], target[p])  target float [P]
+ *     forward: ONE launch (pair gather inside the operand load, W0 on the fp32 matrix cores, the rest in the epilogue);
+ *       writes hid [P,64] (row stride 64; its sign pattern is the ReLU / dropout mask), logits [P], dlogit [P] =
+ *       grad_scale * (sigmoid(logit) - target) / P and per-workgroup loss terms into ws.  target == NULL: evaluation
+ *       (logits only; hid, dlogit, ws may be NULL).  Dropout words: (seed, step) at rng_state, stream `call_id`.
+ *     backward: dW0 / db0 / dw1 / db1 (accumulated when `accumulate`, else overwritten) from per-slab partial tiles summed in
+ *       slab order, loss[0] = the mean loss (may be NULL), and demb [N,64] = d loss / d emb, EVERY row written: entries
+ *       bucketed by node, exact fixed-point sums (no float atomic), then the 64 x 64 product with W0 — bitwise repeatable.
+ *       Launches: weight partials, reduce, 4 for the buckets, gather = 7.  ws: glass_pair_head_ws_bytes, the SAME buffer in
+ *       both calls (uninitialised scratch).  pairs entries must be valid node ids (an id outside [0, N) counts as a zero row).
+ * ---------------------------------------------------------------------------------------- */
+int glass_pair_head_supported(int64_t hidden);
+int64_t glass_pair_head_ws_bytes(int64_t n_nodes, int64_t P);
+int glass_pair_head_fwd_f32(const float* emb, int64_t lde, int64_t n_nodes, const int64_t* pairs, int64_t P, const float* W0,
+                            const float* b0, const float* w1, const float* b1, const float* target, float p_drop,
+                            const uint64_t* rng_state, uint64_t call_id, const float* grad_scale, float* hid, float* logits,
+                            float* dlogit, void* ws, void* stream);
+int glass_pair_head_bwd_f32(const float* emb, int64_t lde, int64_t n_nodes, const int64_t* pairs, int64_t P, const float* W0,
+                            const float* w1, const float* hid, const float* dlogit, float p_drop, float* dW0, float* db0,
+                            float* dw1, float* db1, int accumulate, float* loss, float* demb, int64_t ldde, void* ws,
+                            void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * K5w weight / bias gradient of the stacked Linears   (autograd backward of nn.Linear at

@@ -1,6 +1,6 @@
 """Link-prediction pre-training step (GNNEmb.py's inner loop) at a bench workload's graph shape: time per step and, under
 rocprofv3 --kernel-trace --stats, the kernel table of the SSL path (EdgeGNN = EmbGConv(MyGCNConv) + pair mean pool + MLP).
-    python tools/ssl_step.py [workload] [steps] [conv_layers] [dropout] [pairs] [eager|graph]
+    python tools/ssl_step.py [workload] [steps] [conv_layers] [dropout] [pairs] [eager|graph|program|program_eager]
 "graph": the step as GNNEmb.py runs it (GraphedPairStep: forward + backward replayed from a hipGraph, optimizer eager).
 The pairs are random node pairs (the reference's batch: 131072 edge / non-edge pairs, GNNEmb.py:144)."""
 import functools
@@ -38,7 +38,22 @@ def main():
     loss_fn = nn.BCEWithLogitsLoss()
 
     mode = sys.argv[6] if len(sys.argv) > 6 else "eager"
-    if mode == "graph":
+    if mode in ("program", "program_eager"):
+        # the step as GNNEmb.py runs it now: parameters in one arena, FlatAdam, forward + backward as glass_amd.ssl.PairProgram
+        import GNNEmb
+        opt = GNNEmb.Pretrain.make_optimizer(model, 1e-3)
+        from glass_amd import ssl
+        prog = ssl.program_for(model)
+        assert prog is not None, "step program not selected"
+        if mode == "program_eager":
+            os.environ["GLASS_SSL_GRAPH"] = "0"
+        graphed = GNNEmb.GraphedPairStep(model, lambda pred, t: loss_fn(pred.flatten(), t), x, ei, ew, bce_mean=True)
+
+        def step():
+            loss = graphed(pairs, target)
+            opt.step()
+            return loss
+    elif mode == "graph":
         import GNNEmb
         graphed = GNNEmb.GraphedPairStep(model, lambda pred, t: loss_fn(pred.flatten(), t), x, ei, ew)
 
