@@ -291,29 +291,51 @@ __global__ __launch_bounds__(kBlock) void pair_head_wgrad_kernel(PairHeadBwd a) 
     }
 }
 
-// partials -> gradients (slab order: deterministic) + the mean loss.  One thread per output element.
+// partials -> gradients + the mean loss.  16 output elements x 16 slab groups per workgroup: a thread adds the slabs
+// b = g, g + 16, ... (eight loads in flight; a serial walk over 512 slabs cost 123 us: one dependent L2 round trip per slab),
+// the 16 groups are combined through LDS in group order — a fixed summation tree: deterministic.
+constexpr int kPRedElems = 16;
+
 __global__ __launch_bounds__(kBlock) void pair_head_reduce_kernel(const float* __restrict__ part, int n_slabs,
                                                                   const double* __restrict__ loss_part, int n_loss, int64_t P,
                                                                   float* __restrict__ dW0, float* __restrict__ db0,
                                                                   float* __restrict__ dw1, float* __restrict__ db1,
                                                                   float* __restrict__ loss, int accumulate) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e < kPH * kPH + 2 * kPH + 1) {
+    __shared__ float sm[16][kPRedElems];
+    constexpr int kOut = kPH * kPH + 2 * kPH + 1;
+    const int el = threadIdx.x & (kPRedElems - 1), g = threadIdx.x >> 4;
+    const int e = blockIdx.x * kPRedElems + el;
+    float acc = 0.f;
+    if (e < kOut) {
+        for (int b0 = g; b0 < n_slabs; b0 += 16 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + 16 * u;
+                v[u] = b < n_slabs ? part[(int64_t)b * kPPart + e] : 0.f;
+            }
+            acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+    }
+    sm[g][el] = acc;
+    __syncthreads();
+    if (g == 0 && e < kOut) {
         float s = 0.f;
-        for (int b = 0; b < n_slabs; ++b) s += part[(int64_t)b * kPPart + e];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sm[k][el];
         float* dst = e < kPH * kPH ? dW0 + e : e < kPH * kPH + kPH ? db0 + (e - kPH * kPH)
                      : e < kPH * kPH + 2 * kPH ? dw1 + (e - kPH * kPH - kPH) : db1;
         *dst = (accumulate ? *dst : 0.f) + s;
     }
     if (blockIdx.x == gridDim.x - 1 && loss && loss_part) {
-        __shared__ double sm[kBlock];
+        __shared__ double sl[kBlock];
         double s = 0.0;
         for (int k = threadIdx.x; k < n_loss; k += kBlock) s += loss_part[k];
-        sm[threadIdx.x] = s;
+        sl[threadIdx.x] = s;
         __syncthreads();
         if (threadIdx.x == 0) {
             double t = 0.0;
-            for (int k = 0; k < kBlock; ++k) t += sm[k];
+            for (int k = 0; k < kBlock; ++k) t += sl[k];
             loss[0] = (float)(t / (double)P);
         }
     }
@@ -486,7 +508,7 @@ extern "C" int glass_pair_head_bwd_f32(const float* emb, int64_t lde, int64_t n_
     void* bws = reinterpret_cast<char*>(ws) + off;
     PairHeadBwd a{emb, lde, n_nodes, pairs, P, hid, dlogit, w1, inv_keep, part};
     hipLaunchKernelGGL(pair_head_wgrad_kernel, dim3((unsigned)n_slabs), dim3(kBlock), 0, st, a);
-    hipLaunchKernelGGL(pair_head_reduce_kernel, dim3((unsigned)ceil_div(kPH * kPH + 2 * kPH + 1, (int64_t)kBlock)), dim3(kBlock), 0, st,
+    hipLaunchKernelGGL(pair_head_reduce_kernel, dim3((unsigned)ceil_div(kPH * kPH + 2 * kPH + 1, (int64_t)kPRedElems)), dim3(kBlock), 0, st,
                        part, (int)n_slabs, loss ? loss_part : nullptr, (int)n_blk, P, dW0, db0, dw1, db1, loss, accumulate);
     BucketLists bl;
     int rc = bucket_build(pairs, P, 2, GLASS_POOL_MEAN, true, n_nodes, bws, st, &bl);

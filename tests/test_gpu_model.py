@@ -933,7 +933,6 @@ def test_large_batches_stay_exact_and_repeatable():
     xg, eig, ewg, posg, yg = x.to(DEV), torch.from_numpy(ei).to(DEV), torch.from_numpy(ew).to(DEV), pos.to(DEV), y.to(DEV)
     import warnings
     arena.zero()
-    ops._atomic_warned.clear()
     with warnings.catch_warnings():
         warnings.simplefilter("error")
         loss, logits = stack.loss_and_grads(model, loss_fn, xg, eig, ewg, posg, "pos", yg)

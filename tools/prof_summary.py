@@ -12,7 +12,7 @@ def main():
     rows = list(csv.DictReader(open(f)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     embed = [int(r["Calls"]) for r in rows if "embed_label" in r["Name"] or "embed_gather" in r["Name"] or
-             "readout_subgraph" in r["Name"]]
+             "readout_subgraph" in r["Name"] or "pair_head_fwd" in r["Name"]]
     steps = embed[0] if embed else 1
     # the step's own kernels: those launched at least once per step (setup kernels and bench.py's spin kernel — which only
     # queues work behind a sleep so that timed replays are not launch-bound — are listed but not counted)
