@@ -52,15 +52,31 @@ __device__ __forceinline__ float elu_fast_f(float h) { return h > 0.f ? h : __ex
 // reference's constructor default, impl/models.py:125,192, and the pre-training path's nn.ReLU, GNNEmb.py:90).
 // act_fast: hardware exponential (the dense kernels' prologues / epilogues); act_exact: expm1f (graphnorm.hip's apply);
 // act_grad: the derivative from the PRE-activation value (relu'(0) = 0, as torch's).
+#ifdef GLASS_NO_RELU  // laboratory build: what the ELU-only code cost (A/B of the activation-code dispatch)
+__device__ __forceinline__ float act_fast(int act, float h) { return act == GLASS_ACT_ELU ? elu_fast_f(h) : h; }
+__device__ __forceinline__ float act_exact(int act, float h) { return act == GLASS_ACT_ELU ? elu_f(h) : h; }
+__device__ __forceinline__ float act_grad(int act, float h) { return act == GLASS_ACT_ELU ? elu_grad_f(h) : 1.f; }
+#else
+// A three-way select per element (ELU ? .. : RELU ? .. : h) evaluated both activations and cost the benchmarked ELU step
+// 3-4 us at ppi_bp-shape and 15 us at em_user-shape (A/B against an ELU-only build, same box).  Instead: NONE leaves through
+// a wave-uniform branch as the ELU-only code did, and ELU / ReLU share ONE formula whose negative side is scaled by a
+// uniform factor e (1: ELU, 0: ReLU) — the ELU path executes the instruction count it always had, bit-identical results
+// (fmaf(1, exp(h), -1) rounds like exp(h) - 1), ReLU pays an exponential it does not need.
 __device__ __forceinline__ float act_fast(int act, float h) {
-    return act == GLASS_ACT_ELU ? elu_fast_f(h) : (act == GLASS_ACT_RELU ? fmaxf(h, 0.f) : h);
+    if (act == GLASS_ACT_NONE) return h;
+    const float e = act == GLASS_ACT_ELU ? 1.f : 0.f;
+    return h > 0.f ? h : fmaf(e, __expf(h), -e);
 }
 __device__ __forceinline__ float act_exact(int act, float h) {
-    return act == GLASS_ACT_ELU ? elu_f(h) : (act == GLASS_ACT_RELU ? fmaxf(h, 0.f) : h);
+    if (act == GLASS_ACT_NONE) return h;
+    return h > 0.f ? h : (act == GLASS_ACT_ELU ? expm1f(h) : 0.f);
 }
 __device__ __forceinline__ float act_grad(int act, float h) {
-    return act == GLASS_ACT_ELU ? elu_grad_f(h) : (act == GLASS_ACT_RELU ? (h > 0.f ? 1.f : 0.f) : 1.f);
+    if (act == GLASS_ACT_NONE) return 1.f;
+    const float e = act == GLASS_ACT_ELU ? 1.f : 0.f;
+    return h > 0.f ? 1.f : e * __expf(h);
 }
+#endif
 __host__ __device__ inline bool act_code_ok(int act) { return act == GLASS_ACT_NONE || act == GLASS_ACT_ELU || act == GLASS_ACT_RELU; }
 
 // keep-scale of one element from its 32-bit word: 4 consecutive columns share one rand4() call.
