@@ -82,6 +82,10 @@ def parse(argv=None):
     ap.add_argument("--min-blocks", type=int, default=25, help="timed blocks of --steps steps each (median reported)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline steps (0 = size to ~15 s)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a captured hipGraph when possible")
+    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+                    help="eval: the evaluation loop's forward passes (impl/train.py:20-34) over the same batches — one batch per "
+                         "step, K batches side by side as parallel branches of one hipGraph (glass_amd/evalstep.py)")
+    ap.add_argument("--eval-parallel", type=int, default=4, help="--mode eval: batches per replay (the sequential form is timed too)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work; value is null) — CPU-box smoke")
     return ap.parse_args(argv)
@@ -446,6 +450,60 @@ def dry_run(args, world, rank):
         sys.exit(3)
 
 
+def eval_mode(args, w, model, xg, eig, ewg, pos_g, nnz, N, H, L, world, rank, local_rank, backend, dev):
+    """--mode eval: forward-only passes over the batches (train.test's loop: utils.MaxZOZ + GLASS.forward per batch, no
+    dropout), a "step" = one batch.  Timed twice with the same block protocol as the training line: K = 1 (one batch per
+    hipGraph replay) and K = --eval-parallel batches as parallel branches of one graph; `value` is the parallel form's."""
+    from glass_amd.evalstep import EvalGraph
+    model.eval()
+    n_batches = pos_g.shape[0]
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as td
+            td.barrier(device_ids=[local_rank]) if backend == "nccl" else td.barrier()
+        torch.cuda.synchronize()
+
+    results = {}
+    with torch.no_grad():
+        ref = model(xg, eig, ewg, pos_g[0], __import__("glass_amd.utils", fromlist=["MaxZOZ"]).MaxZOZ(xg, pos_g[0])).clone()
+        for k in sorted({1, max(1, args.eval_parallel)}):
+            g = EvalGraph(model, xg, eig, ewg, pos_g[0].shape, k).capture()
+            same = bool(torch.equal(g([pos_g[0]])[0], ref))  # the replayed branch = the eager forward, bit for bit
+
+            def run(steps, offset):
+                for i in range(0, steps, k):
+                    g([pos_g[(offset + i + j) % n_batches] for j in range(min(k, steps - i))])
+            run(args.warmup, 0)
+            blocks = []
+            for b in range(max(args.min_blocks, 5)):
+                barrier()
+                t0 = time.perf_counter()
+                run(args.steps, b * args.steps)
+                barrier()
+                blocks.append(time.perf_counter() - t0)
+            blocks.sort()
+            results[k] = {"ms_per_batch": blocks[len(blocks) // 2] / args.steps * 1e3, "ms_min": blocks[0] / args.steps * 1e3,
+                          "ms_max": blocks[-1] / args.steps * 1e3, "matches_eager_bitwise": same}
+    kk = max(results)
+    dt_ms = results[kk]["ms_per_batch"]
+    if rank == 0:
+        print(json.dumps({
+            "metric": "aggregated edges/sec (GLASSConv fwd, evaluation loop)", "value": nnz * L * world / (dt_ms * 1e-3),
+            "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "mode": "eval",
+            "config": {"workload": f"{w.name}-shaped synthetic graph: N={N}, nnz={nnz}, hidden={H}, layers={L}, aggr={w.aggr}, "
+                                   f"pool={w.pool}, batch={w.batch}x{w.sub_size}, use_deg features, model.eval()",
+                       "step": "MaxZOZ + GLASS.forward of ONE batch (impl/train.py:20-34); K batches per hipGraph replay as "
+                               "parallel branches", "parallel_batches": kk, "hip_graph": True},
+            "sequential": results[1], "parallel": results[kk],
+            "speedup_parallel_over_sequential": results[1]["ms_per_batch"] / dt_ms}), flush=True)
+    if world > 1:
+        import torch.distributed as td
+        td.destroy_process_group()
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -506,6 +564,9 @@ def main():
     pos_g = pos.to(dev).reshape(n_batches * world, w.batch, -1)[rank::world].contiguous()
     y_g = y.to(dev).reshape(n_batches * world, w.batch, *y.shape[1:])[rank::world].contiguous()
     ops.rng_seed(1234 + rank, dev)
+
+    if args.mode == "eval":
+        return eval_mode(args, w, model, xg, eig, ewg, pos_g, nnz, N, H, L, world, rank, local_rank, backend, dev)
 
     from glass_amd.step import TrainStep
     stepper = TrainStep(model, opt, loss_fn, xg, eig, ewg, bucket, use_graph=bool(args.graph))

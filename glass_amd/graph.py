@@ -40,13 +40,17 @@ class CSROperand:
         return int(self.header[3])
 
     def workspace(self, H):
-        ws = self._ws.get(H)
+        """Partial-row scratch of products with rows cut into several chunks: one buffer per feature width and per BRANCH
+        (set_workspace_branch: concurrent products on the same matrix — the parallel evaluation branches of
+        evalstep.EvalGraph — must not share it)."""
+        key = (H, _ws_branch)
+        ws = self._ws.get(key)
         if ws is None:
             nbytes = _lib.load().glass_spmm_ws_bytes(self.header.ctypes.data, H)
             if nbytes < 0:
                 raise _lib.GlassHipError("bad plan header")
             ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=self.rowptr.device)
-            self._ws[H] = ws
+            self._ws[key] = ws
         return ws
 
     def spmm(self, x, out=None):
@@ -69,6 +73,15 @@ def _csr_from_sorted(row, n_rows):
     rowptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=row.device)
     rowptr[1:] = torch.cumsum(counts, 0)
     return rowptr.to(torch.int32)
+
+
+_ws_branch = 0
+
+
+def set_workspace_branch(b):
+    """Which workspace set CSROperand.workspace hands out from now on (0: the default one)."""
+    global _ws_branch
+    _ws_branch = int(b)
 
 
 class CSRAdj:

@@ -49,6 +49,25 @@ USE_GATHER_IN_TRANS = os.environ.get("GLASS_GATHER_IN_TRANS", "1") != "0"  # A/B
 USE_COMB_EFF = os.environ.get("GLASS_COMB_EFF", "1") != "0"  # A/B switch: comb pair through effective per-label weights
 
 
+_PROLOGUE_DONE = False
+
+
+class prologue_done:
+    """Context: the weight images are fresh (someone ran the arena's prologue launch on a stream every forward below is
+    ordered behind) — forwards that need nothing else from the prologue (no dropout step, no accumulator zero-fill, no table
+    statistics: the evaluation forward) skip their own.  evalstep.EvalGraph packs once, then forks its branches."""
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _PROLOGUE_DONE
+        self.prev, _PROLOGUE_DONE = _PROLOGUE_DONE, (self.on or _PROLOGUE_DONE)
+
+    def __exit__(self, *exc):
+        global _PROLOGUE_DONE
+        _PROLOGUE_DONE = self.prev
+
+
 class BatchLabels:
     """Label state of one subgraph batch on the device (glass_batch_labels; utils.MaxZOZ, reference impl/utils.py:32-45):
     the label bytes `mask` (maintained incrementally from batch to batch), the unique labeled rows `rows[:count]` in
@@ -564,6 +583,8 @@ class StackProgram:
                                                 table=(W, V, sel.op.rowptr, gn0, saved, None), zero=acc_all)
             st["emb_table"], st["emb_saved"] = sel, saved
             first_gn = (saved, ACT_NONE, p, 1)
+        elif _PROLOGUE_DONE and not advance and acc_all is None:
+            pass  # (evaluation branch behind a shared prologue: prologue_done)
         else:
             # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
             emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None, zero=acc_all)

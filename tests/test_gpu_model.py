@@ -1412,3 +1412,44 @@ def test_bench_two_ranks_share_the_gpu_over_gloo(flags, overlapped):
     c = d["collective"]
     assert c["world"] == 2 and c["small_bucket_overlaps_backward_tail"] is overlapped
     assert (c["payload_bytes"]["big_reduce_scatter"] > 0) is overlapped and c["payload_bytes"]["small_allreduce"] > 0
+
+
+def test_eval_graph_parallel_branches_match_eager_forward():
+    """evalstep.EvalGraph (train.test's forward passes as K parallel branches of one hipGraph behind a shared prologue):
+    every branch returns bit for bit what the eager forward returns for its batch, for K = 1 .. 4, on a graph whose K1 plan
+    has long rows (per-branch partial-row workspaces) — and train.test gives the same score and loss with and without it."""
+    from glass_amd import synth, train as gtrain
+    from glass_amd.evalstep import EvalGraph
+    from glass_amd.arena import ParamArena
+    from impl import SubGDataset, utils, metrics
+    n = 20000
+    ei, ew = synth.make_graph(n, 150000, 3, 0.9)   # Zipf 0.9: hub rows beyond one chunk
+    x = synth.degree_feature(ei, n)
+    pos, y = synth.make_subgraphs(n, 16 * 9 + 5, 10, 4, 1, False)
+    ei, ew, x, pos, y = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x, pos, y))
+    torch.manual_seed(0)
+    model = build_glass(64, 2, int(x.max()), 4, "mean", "sum", 0.9).to(DEV)
+    ParamArena(model)
+    model.eval()
+    B = 16
+    with torch.no_grad():
+        eager = [model(x, ei, ew, pos[b * B:(b + 1) * B], utils.MaxZOZ(x, pos[b * B:(b + 1) * B])).clone() for b in range(8)]
+        for k in (1, 2, 3, 4):
+            g = EvalGraph(model, x, ei, ew, (B, pos.shape[1]), k).capture()
+            for start in range(0, 8, k):
+                grp = list(range(start, min(start + k, 8)))
+                outs = g([pos[b * B:(b + 1) * B] for b in grp])
+                for b, o in zip(grp, outs):
+                    assert torch.equal(o, eager[b]), (k, b)
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    loader = SubGDataset.ZGDataloader(ds, B, z_fn=utils.MaxZOZ, shuffle=False, drop_last=False)  # 9 full batches + a tail of 5
+    loss_fn = nn.CrossEntropyLoss()
+    a = gtrain.test(model, loader, metrics.microf1, loss_fn)
+    assert model.__dict__.get("_glass_eval_graphs")
+    old = gtrain.USE_EVAL_GRAPH
+    gtrain.USE_EVAL_GRAPH = False
+    try:
+        b = gtrain.test(model, loader, metrics.microf1, loss_fn)
+    finally:
+        gtrain.USE_EVAL_GRAPH = old
+    assert a[0] == b[0] and torch.equal(a[1], b[1])
