@@ -85,7 +85,7 @@ def parse(argv=None):
     ap.add_argument("--mode", default="train", choices=["train", "eval"],
                     help="eval: the evaluation loop's forward passes (impl/train.py:20-34) over the same batches — one batch per "
                          "step, K batches side by side as parallel branches of one hipGraph (glass_amd/evalstep.py)")
-    ap.add_argument("--eval-parallel", type=int, default=4, help="--mode eval: batches per replay (the sequential form is timed too)")
+    ap.add_argument("--eval-parallel", type=int, default=8, help="--mode eval: batches per replay (the sequential form is timed too)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work; value is null) — CPU-box smoke")
     return ap.parse_args(argv)

@@ -15,7 +15,7 @@ from . import stack, utils
 
 
 class EvalGraph:
-    def __init__(self, model, x, edge_index, edge_weight, batch_shape, k=4, id=0):
+    def __init__(self, model, x, edge_index, edge_weight, batch_shape, k=8, id=0):
         self.model, self.x, self.ei, self.ew, self.k, self.id = model, x, edge_index, edge_weight, int(k), id
         dev = x.device
         self.pos = [torch.full(tuple(batch_shape), -1, dtype=torch.int64, device=dev) for _ in range(self.k)]

@@ -530,10 +530,16 @@ _gn_ws = {}
 
 
 def _graphnorm_ws(device, n_rows, C):
-    key = (device, C)
+    """Per-workgroup partial sums of the stand-alone GraphNorm kernels: one buffer per width and per BRANCH
+    (graph.set_workspace_branch: the parallel evaluation branches of evalstep.EvalGraph run the same kernels concurrently
+    and must not share it).  A buffer that has to grow is retired, not freed (a captured graph may hold its pointer)."""
+    from . import graph as ggraph
+    key = (device, C, ggraph._ws_branch)
+    nbytes = _lib.load().glass_graphnorm_ws_bytes(n_rows, C)
     ws = _gn_ws.get(key)
-    if ws is None:
-        nbytes = _lib.load().glass_graphnorm_ws_bytes(n_rows, C)
+    if ws is None or ws.numel() * 8 < nbytes:
+        if ws is not None:
+            _retired_ws.append(ws)
         ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=device)
         _gn_ws[key] = ws
     return ws

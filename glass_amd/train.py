@@ -82,7 +82,7 @@ def train(optimizer, model, dataloader, loss_fn):
 
 
 USE_EVAL_GRAPH = os.environ.get("GLASS_EVAL_GRAPH", "1") != "0"  # 0: one eager forward per evaluation batch
-EVAL_PARALLEL = int(os.environ.get("GLASS_EVAL_PARALLEL", "4"))   # evaluation batches run side by side (evalstep.EvalGraph)
+EVAL_PARALLEL = int(os.environ.get("GLASS_EVAL_PARALLEL", "8"))   # evaluation batches run side by side (evalstep.EvalGraph)
 
 
 def _eval_graph(model, batch, k):
