@@ -223,6 +223,13 @@ __device__ __forceinline__ float4 buf_load4(buf_rsrc r, int off) {
     __builtin_memcpy(&f, &v, sizeof(f));
     return f;
 }
+// glass_pin(x): every later use of x is ordered behind this point (an empty volatile asm that "rewrites" the register), so
+// the compiler cannot hoist a use — and with it the s_waitcnt for the load that produced x — above the loads issued before.
+#define glass_pin(x) asm volatile("" : "+v"(x))
+__device__ __forceinline__ int buf_load1i(buf_rsrc r, int off) { return (int)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0); }
+__device__ __forceinline__ float buf_load1f(buf_rsrc r, int off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 __device__ __forceinline__ void buf_store4(buf_rsrc r, int off, const float4& f) {
     u32x4 v;
     __builtin_memcpy(&v, &f, sizeof(v));

@@ -1005,49 +1005,41 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int w = wv % NTL, g = wv / NTL;  // column tile, row group
     const int j = lane & 15, q = lane >> 4;
+    // ---- prologue: EVERY load it needs is issued before the first value is used (one memory round trip; the first form
+    // waited three times: weights / bias / label byte — a conditional byte load forces vmcnt(0) —, then operands and
+    // accumulators, then gamma / beta / alpha, which the compiler had sunk behind the accumulator wait: tools/dense_trace.py
+    // slots 0 -> 6 -> 1 read 1.7 + 2.0 us).  Order of issue = order of need: the first two stages' operand rows, the
+    // GraphNorm sums, the weight slice, bias, label byte.
     const bool extra = (int)blockIdx.x >= lab.n_main;
-    int n_lab = 0, base = 0;
-    if (extra) {
-        n_lab = lab.count[0];
-        base = ((int)blockIdx.x - lab.n_main) * ROWS;
-        if (base >= n_lab) {  // extra workgroup beyond the list: an empty partial
-            if (stats && !stats_exact)
-                for (int c = tid; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
-            return;
-        }
-    }
+    const int base = extra ? ((int)blockIdx.x - lab.n_main) * ROWS : 0;
     const buf_rsrc r_xa = make_rsrc(xa, N * lda * 4), r_xb = make_rsrc(xb, N * ldb * 4), r_out = make_rsrc(out, N * ldo * 4);
     const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
-    // this wave's slice of the effective weight: 8 float4 per lane
-    const float4* img = reinterpret_cast<const float4*>(Wimg + (extra ? H * KT : 0));
-    float4 bw[KF4];
-#pragma unroll
-    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
-    const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
-    const float be = c1 * bias[16 * w + j] + c0 * bias[H + 16 * w + j];
+    const buf_rsrc r_mask = make_rsrc(mask, N);
     // the two float4 this thread moves per stage: 4-column group ga of the a half (GraphNorm prologue) and of the h half of
     // row rs of the stage (one buffer resource per half: wave-uniform)
     const int rs = tid / (H / 4), ga = tid % (H / 4);
     int my_row[NSTG];  // (-1: none)
-    int slot_v = -1;   // row of slot `tid` (threads < ROWS)
-    unsigned char slot_mask = 0;
+    int n_lab = 0;
     if (!extra) {
         const int64_t r0 = (int64_t)blockIdx.x * ROWS;
 #pragma unroll
         for (int st = 0; st < NSTG; ++st)
             my_row[st] = (SR * st + rs < ROWS && r0 + SR * st + rs < N) ? (int)(r0 + SR * st + rs) : -1;
-        if (tid < ROWS && r0 + tid < N) {
-            slot_v = (int)(r0 + tid);
-            slot_mask = mask[r0 + tid];
-        }
-    } else {  // listed rows: through LDS (one load per slot)
-        if (tid < ROWS) {
-            slot_v = base + tid < n_lab ? lab.rows[base + tid] : -1;
-            rows_s[tid] = slot_v;
-        }
-        lds_barrier();
+    } else {
+        // listed rows: every thread reads its own stage rows straight from the list (the count arrives beside them)
+        const buf_rsrc r_list = make_rsrc(lab.rows, (int64_t)lab.cap * 4);
+        int lr[NSTG];
 #pragma unroll
-        for (int st = 0; st < NSTG; ++st) my_row[st] = SR * st + rs < ROWS ? rows_s[SR * st + rs] : -1;
+        for (int st = 0; st < NSTG; ++st)
+            lr[st] = buf_load1i(r_list, SR * st + rs < ROWS ? (base + SR * st + rs) * 4 : kBufOOB);
+        n_lab = lab.count[0];
+        if (base >= n_lab) {  // extra workgroup beyond the list: an empty partial
+            if (stats && !stats_exact)
+                for (int c = tid; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
+            return;
+        }
+#pragma unroll
+        for (int st = 0; st < NSTG; ++st) my_row[st] = (SR * st + rs < ROWS && base + SR * st + rs < n_lab) ? lr[st] : -1;
     }
     auto issue = [&](int st, float4 (&raw)[2]) __attribute__((always_inline)) {
         const int r = my_row[st];
@@ -1057,12 +1049,48 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     float4 rawA[2], rawB[2];
     issue(0, rawA);
     if (1 < NSTG) issue(1, rawB);
+    GnCoefRegs CR;
+    const bool fold_here = pro.saved && (WG == 1 || tid < 4 * H);  // (wave-uniform)
+    if (fold_here && pro.src.acc) gn_fwd_coef_issue<H, 4 * H>(pro.src, CR);
+    // this wave's slice of the effective weight: 8 float4 per lane
+    const float4* img = reinterpret_cast<const float4*>(Wimg + (extra ? H * KT : 0));
+    float4 bw[KF4];
+#pragma unroll
+    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+    const float bias1 = bias[16 * w + j], bias0 = bias[H + 16 * w + j];
+    // row of slot `tid` (threads < ROWS) and its label byte (main tiles)
+    int slot_v = -1;
+    unsigned slot_mask = 0;
+    if (!extra) {
+        const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+        const bool ok = tid < ROWS && r0 + tid < N;
+        slot_v = ok ? (int)(r0 + tid) : -1;
+        slot_mask = __builtin_amdgcn_raw_buffer_load_b8(r_mask, ok ? (int)(r0 + tid) : kBufOOB, 0, 0);
+    } else {
+        const buf_rsrc r_list = make_rsrc(lab.rows, (int64_t)lab.cap * 4);
+        const int v = buf_load1i(r_list, tid < ROWS ? (base + tid) * 4 : kBufOOB);
+        slot_v = (tid < ROWS && base + tid < n_lab) ? v : -1;
+    }
+    if (fold_here && pro.src.acc) {
+        gn_fwd_coef_issue_params<H>(pro.src, CR);
+        glass_pin(CR.gamma);
+        glass_pin(CR.beta);
+        glass_pin(CR.alpha);
+    }
+    float bias1p = bias1, bias0p = bias0;
+    glass_pin(bias1p);
+    glass_pin(bias0p);
+    glass_pin(slot_mask);
+    D_STAMP(1, 6);
     Drop drop = pro.drop;
     if (pro.saved && drop.p > 0.f) {
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
-    if (pro.saved && (WG == 1 || tid < 4 * H)) gn_fwd_coef_nobarrier<H, 4 * H>(pro.src, pro.saved, N, gn_coef_s);
+    // ---- first use of loaded values
+    const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
+    const float be = c1 * bias1p + c0 * bias0p;
+    if (fold_here) gn_fwd_coef_finish<H, 4 * H>(pro.src, pro.saved, N, CR, gn_coef_s);
     if (tid < ROWS) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
     D_STAMP(1, 1);
     lds_barrier();  // coefficients + row table
@@ -1208,24 +1236,18 @@ __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int w = wv & 3, g = wv >> 2;  // column tile, row group
     const int j = lane & 15, q = lane >> 4;
+    // ---- prologue: every load issued before the first value is used, in order of need (see comb_fwd_eff2_kernel) ----
     const buf_rsrc r_xa = make_rsrc(xa, xa_rows * lda * 4), r_out = make_rsrc(out, N * ldo * 4);
     const buf_rsrc r_T = make_rsrc(T ? T : out, T ? N * ldt * 4 : 0);
     const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
-    const float4* img = reinterpret_cast<const float4*>(Wimg);
-    float4 bw1[4], bw0[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        bw1[v] = img[(w * 4 + v) * 64 + lane];
-        bw0[v] = img[((4 + w) * 4 + v) * 64 + lane];
-    }
-    const float b1 = bias[16 * w + j], b0 = bias[H + 16 * w + j];
+    const buf_rsrc r_mask = make_rsrc(mask, N);
     const int rs = tid >> 4, ga = tid & 15;
     const int64_t r0 = (int64_t)blockIdx.x * ROWS;
     int my_row[NSTG], my_src[NSTG];  // output row of this thread's float4 per stage (-1 none) and the operand row it comes from
 #pragma unroll
     for (int st = 0; st < NSTG; ++st)
         my_row[st] = (SR * st + rs < ROWS && r0 + SR * st + rs < N) ? (int)(r0 + SR * st + rs) : -1;
-    if (xa_index) {
+    if (xa_index) {  // layer 0: the operand rows are gathered from the embedding table (index -> row: a dependent pair)
         int64_t idx[NSTG];
 #pragma unroll
         for (int st = 0; st < NSTG; ++st) idx[st] = my_row[st] >= 0 ? xa_index[my_row[st]] : 0;
@@ -1235,23 +1257,40 @@ __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __
 #pragma unroll
         for (int st = 0; st < NSTG; ++st) my_src[st] = my_row[st];
     }
-    int slot_v = -1;
-    unsigned char slot_mask = 0;
-    if (tid < ROWS && r0 + tid < N) {
-        slot_v = (int)(r0 + tid);
-        slot_mask = mask[r0 + tid];
-    }
     auto issue = [&](int st) __attribute__((always_inline)) -> float4 {
         return buf_load4(r_xa, my_row[st] >= 0 ? (int)((my_src[st] * lda + 4 * ga) * 4) : kBufOOB);
     };
     float4 rawA = issue(0), rawB = make_float4(0.f, 0.f, 0.f, 0.f);
     if (1 < NSTG) rawB = issue(1);
+    GnCoefRegs CR;
+    const bool fold_here = pro.saved && (WG == 1 || tid < kBlock);  // (wave-uniform)
+    if (fold_here && pro.src.acc) gn_fwd_coef_issue<H, kBlock>(pro.src, CR);
+    const float4* img = reinterpret_cast<const float4*>(Wimg);
+    float4 bw1[4], bw0[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        bw1[v] = img[(w * 4 + v) * 64 + lane];
+        bw0[v] = img[((4 + w) * 4 + v) * 64 + lane];
+    }
+    float b1 = bias[16 * w + j], b0 = bias[H + 16 * w + j];
+    const bool slot_ok = tid < ROWS && r0 + tid < N;
+    const int slot_v = slot_ok ? (int)(r0 + tid) : -1;
+    unsigned slot_mask = __builtin_amdgcn_raw_buffer_load_b8(r_mask, slot_ok ? (int)(r0 + tid) : kBufOOB, 0, 0);
+    if (fold_here && pro.src.acc) {
+        gn_fwd_coef_issue_params<H>(pro.src, CR);
+        glass_pin(CR.gamma);
+        glass_pin(CR.beta);
+        glass_pin(CR.alpha);
+    }
+    glass_pin(b1);
+    glass_pin(b0);
+    glass_pin(slot_mask);
     Drop drop = pro.drop;
     if (pro.saved && drop.p > 0.f) {
         drop.seed = pro.rng_state[0];
         drop.step = pro.rng_state[1];
     }
-    if (pro.saved && (WG == 1 || tid < kBlock)) gn_fwd_coef_nobarrier<H, kBlock>(pro.src, pro.saved, N, gn_coef_s);
+    if (fold_here) gn_fwd_coef_finish<H, kBlock>(pro.src, pro.saved, N, CR, gn_coef_s);
     if (tid < ROWS) rows_s[tid] = slot_mask != 0 ? (slot_v | (1 << 30)) : slot_v;
     D_STAMP(2, 1);
     lds_barrier();  // coefficients + row table
@@ -2520,7 +2559,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     GLASS_REQUIRE(make_exact_src(gn_src, gn_saved, esrc) && (!stats_exact || (stats && rep_ok(stats_exact))),
                   "comb_eff_fwd: bad gn_src (one accumulator block, all pointers set)");
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
-    const LabRows lab{lab_rows, lab_count, n_main};
+    const LabRows lab{lab_rows, lab_count, n_main, (int)lab_cap};
     const size_t lds = lds_bytes(H, 2);  // two K passes of the [H][2H] effective weight
     const int64_t ld_max = std::max(std::max(lda, ldb), std::max(ldo, gn_saved ? ldxo : (int64_t)0));
     GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || n_nodes * ld_max * 4 < (1ll << 31),
@@ -2604,7 +2643,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
     const unsigned n_dg = (unsigned)(n_main + ceil_div(lab_cap, 64));
     const float zr = (float)z_ratio;
     const GnBwdStats gs{gn_partial, gn_exact, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, make_drop(gn_partial ? gn_p_drop : 0.f, gn_call_id, H)};
-    const DgradEffArgs dargs{dsrc, ldd, mask, WTimg_eff, rng_state, out, ldo, n_nodes, gs, LabRows{lab_rows, lab_count, n_main}, gsrc};
+    const DgradEffArgs dargs{dsrc, ldd, mask, WTimg_eff, rng_state, out, ldo, n_nodes, gs, LabRows{lab_rows, lab_count, n_main, (int)lab_cap}, gsrc};
     const size_t lds_dg = lds_bytes(2 * H, 1);  // one K pass of the [2H][H] effective weight
     if (!X) {  // data gradient only
         hipLaunchKernelGGL((comb_dgrad_eff_kernel<64>), dim3(n_dg), dim3(kBlock), lds_dg, st, dargs);

@@ -74,6 +74,7 @@ struct LabRows {
     const int32_t* rows;   // [cap] unique labeled node ids, first-occurrence order
     const int32_t* count;  // device word: how many of them
     int n_main;            // row-tile workgroups in front of the extra ones
+    int cap;               // capacity of `rows` (entries): bounds list reads issued before `count` is known
 };
 
 // Operand-image layouts written by glass_dense_pack_batch_f32 (bits 1.. of its per-job flags; bit 0 = transposed source)

@@ -248,6 +248,93 @@ __device__ __forceinline__ bool gn_acc_col_sums(const long long* __restrict__ ac
     return l < 16;
 }
 
+// The same fold in two steps, so that the caller can ISSUE these loads together with everything else its prologue reads and
+// wait once (ISA of the one-step form inside the staged forward kernels: weights / bias / label byte, wait; operands and
+// accumulators, wait; gamma / beta / alpha — sunk by the compiler into the l < 16 branch — wait: three dependent round
+// trips of ~1 us each before the first stage).  issue: 8 x 16-B accumulator loads + 3 parameter loads per lane, no branch;
+// finish: lane shuffles, ONE fp64 division (1 / N) and a reciprocal square root instead of two divisions + sqrt + division,
+// every lane computing (no branch around the arithmetic either), lanes l < 16 writing.
+struct GnCoefRegs {
+    long long vh[kAccRep / 2], vl[kAccRep / 2];
+    float gamma, beta, alpha;
+};
+
+// (issue leaves R untouched when the statistics are final already — no zero-fill on that path: values merged at a join
+// point would make the compiler wait for the loads right there)
+template <int C, int T>
+__device__ __forceinline__ void gn_fwd_coef_issue(const GnExactSrc& src, GnCoefRegs& R) {
+    static_assert(T == 4 * C && C % 16 == 0 && kAccRep % 2 == 0, "four lanes per column, sixteen columns per wave");
+    const int t = threadIdx.x;
+    const int l = t & 63, w = t >> 6;
+    const int c = 16 * w + (l & 15), which = (l >> 4) & 1, half = l >> 5;
+    const int per = src.n_rep >> 1;
+#pragma unroll
+    for (int r = 0; r < kAccRep / 2; ++r) {
+        const int rr = r < per ? half * per + r : 0;  // (clamped: a replica read twice is not added)
+        const long long* p = src.acc + gn_acc_index(rr, which, c, C);
+        R.vh[r] = p[0];
+        R.vl[r] = p[1];
+    }
+}
+
+// gamma / beta / alpha of the lane's column: issue them LAST in the caller's prologue and pin them (glass_pin) behind every
+// other issue — the compiler converts them to double right behind the load wherever that sits, i.e. it waits there for
+// everything issued before (vmcnt counts in order)
+template <int C>
+__device__ __forceinline__ void gn_fwd_coef_issue_params(const GnExactSrc& src, GnCoefRegs& R) {
+    const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = 16 * w + (l & 15);
+    R.gamma = src.gamma[c];
+    R.beta = src.beta[c];
+    R.alpha = src.alpha[c];
+}
+
+template <int C, int T>
+__device__ __forceinline__ void gn_fwd_coef_finish(const GnExactSrc& src, const float* __restrict__ saved, int64_t N,
+                                                   const GnCoefRegs& R, float* coef_s) {
+    const int t = threadIdx.x;
+    const int l = t & 63, w = t >> 6;
+    const int c = 16 * w + (l & 15);
+    if (!src.acc) {  // final statistics: scale | shift are saved[2C .. 4C)   (wave-uniform branch)
+        if (t < 2 * C) coef_s[t] = saved[2 * C + t];
+        return;
+    }
+    const int per = src.n_rep >> 1;
+    long long hi = 0, lo = 0;
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < kAccRep / 2; ++r) {
+        hi += r < per ? R.vh[r] : 0;
+        lo += r < per ? R.vl[r] : 0;
+        bad |= (r < per && R.vl[r] < 0) ? 1 : 0;
+    }
+    hi += __shfl_xor(hi, 32);
+    lo += __shfl_xor(lo, 32);
+    bad |= __shfl_xor(bad, 32);
+    const double v = gn_acc_value(hi, lo, bad != 0, 1.0 / kAccScaleFwd);
+    const double other = __shfl_xor(v, 16);
+    // lanes with which == 0 hold s = sum x in v and q = sum x^2 in `other`; the rest compute on swapped values and write nothing
+    const double s = v, q = other;
+    const double invN = 1.0 / (double)N;
+    const double a = (double)R.alpha;
+    const double mu = s * invN;
+    double var = q * invN - mu * mu * (2.0 * a - a * a);
+    if (var < 0.0) var = 0.0;
+    const double rstd = rsqrt(var + (double)src.eps);
+    const double scale = (double)R.gamma * rstd;
+    const float shift = (float)((double)R.beta - scale * a * mu);
+    if (l < 16) {
+        coef_s[c] = (float)scale;
+        coef_s[C + c] = shift;
+        if (blockIdx.x == 0 && src.saved_w) {
+            src.saved_w[c] = (float)mu;
+            src.saved_w[C + c] = (float)rstd;
+            src.saved_w[2 * C + c] = (float)scale;
+            src.saved_w[3 * C + c] = shift;
+        }
+    }
+}
+
 // Forward coefficients of a GraphNorm (C columns, one accumulator block) into coef_s (LDS: scale[C] | shift[C]) WITHOUT a
 // barrier: the caller's next barrier publishes them.  Workgroup 0 also writes saved_w.
 template <int C, int T>

@@ -69,7 +69,7 @@ def main():
         if sel <= 2:  # forward kernels: inside the product — 5 first weight image committed, 6 first operand chunk ready,
             #               7 second chunk ready (after the first pass's MFMAs were issued)
             # (staged comb forward: 5 stage 1 begins, 6 its rows stored to LDS + next loads issued, 7 barrier passed, 2 MFMAs issued)
-            for a, b, nm in ((1, 5, "1->5"), (5, 6, "5->6"), (6, 7, "6->7"), (7, 2, "7->2"), (2, 3, "2->3")):
+            for a, b, nm in ((0, 6, "0->6 setup"), (6, 1, "6->1 fold"), (1, 5, "1->5"), (5, 2, "5->2"), (2, 3, "2->3")):
                 ok = live & (t[:, :, a] > 0) & (t[:, :, b] > 0)
                 if ok.any():
                     d = (t[:, :, b] - t[:, :, a])[ok]
