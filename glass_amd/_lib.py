@@ -143,6 +143,7 @@ SIGNATURES = {
     "glass_batch_labels": (c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, c_int, _P]),
     "glass_comb_eff_supported": (c_int, [_I]),
     "glass_comb_eff_blocks": (c_int64, [_I, _I, _I]),
+    "glass_comb_eff_fwd_blocks": (c_int64, [_I, _I, _I]),
     "glass_comb_eff_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_comb_eff_fwd_layout": (c_int, [_I]),
     "glass_comb_eff_fwd_supported": (c_int, [_I]),

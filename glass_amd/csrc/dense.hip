@@ -1212,6 +1212,195 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     D_STAMP(1, 4);
 }
 
+// ---- comb forward, third form: the second form with a RUN-TIME number of stages per workgroup ("tall" row tiles) ---------
+// The second form fixes 64 or 80 rows per workgroup.  Beyond 80 x 256 rows a launch then runs in several ROUNDS of
+// workgroups, each paying its own prologue (one memory round trip + the GraphNorm fold, ~3 us) and a drained pipeline: at
+// em_user-shape (N = 50 000, hidden 128: 782 workgroups of eight waves, one per CU) the launch took 52 us for 3.4 us of
+// matrix work per workgroup.  Here a main workgroup takes rows_main rows (a multiple of the stage height, chosen by the
+// host so that the grid is ONE round: ~N / 256), walks them in a run-time loop unrolled by two (the two register sets of
+// the double-buffered loads), and pays the prologue once.  The label byte of a row travels with its operand loads and
+// reaches the epilogue through LDS next to the row id (no per-workgroup row table); the extra workgroups (listed labeled
+// rows, effective labeled weight) keep a small row table and at most 80 rows.
+template <int H, bool DROP, int WG>
+__global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* __restrict__ xa, int64_t lda,
+                                                               const float* __restrict__ xb, int64_t ldb,
+                                                               const float* __restrict__ Wimg, const float* __restrict__ bias,
+                                                               const uint8_t* __restrict__ mask, float zr, float omz,
+                                                               float* __restrict__ out, int64_t ldo, int64_t N,
+                                                               double* __restrict__ stats, int stats_exact, GnPrologue pro,
+                                                               LabRows lab, int rows_main, int rows_extra) {
+    static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
+    static_assert(WG == 1 || (WG == 2 && H == 64), "two wave groups: 8 waves at hidden 64");
+    constexpr int THREADS = 4 * H * WG, NTL = H / 16, KF4 = (2 * H) / 16;
+    constexpr int KT = 2 * H, RS = KT + 4;
+    constexpr int SR = 16 * WG;
+    __shared__ __attribute__((aligned(16))) float tile[2][SR * RS];
+    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
+    __shared__ int rowflag_s[2][SR];   // per stage buffer: row of each slot (-1 none; bit 30: computed but not stored / counted)
+    __shared__ int xrows_s[80];        // extra workgroups: their listed rows
+    __shared__ double comb_s[WG > 1 ? 2 * H : 1];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int w = wv % NTL, g = wv / NTL;
+    const int j = lane & 15, q = lane >> 4;
+    const bool extra = (int)blockIdx.x >= lab.n_main;
+    const int rows_wg = extra ? rows_extra : rows_main;
+    const int nst = (rows_wg + SR - 1) / SR;
+    const int base = extra ? ((int)blockIdx.x - lab.n_main) * rows_extra : 0;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_main;  // (main workgroups)
+    const buf_rsrc r_xa = make_rsrc(xa, N * lda * 4), r_xb = make_rsrc(xb, N * ldb * 4), r_out = make_rsrc(out, N * ldo * 4);
+    const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
+    const buf_rsrc r_mask = make_rsrc(mask, N);
+    const int rs = tid / (H / 4), ga = tid % (H / 4);
+    int n_lab = 0;
+    if (extra) {  // the listed rows through LDS (a dependent pair of round trips, on a few short workgroups)
+        const buf_rsrc r_list = make_rsrc(lab.rows, (int64_t)lab.cap * 4);
+        const int v = buf_load1i(r_list, tid < rows_extra ? (base + tid) * 4 : kBufOOB);
+        n_lab = lab.count[0];
+        if (base >= n_lab) {
+            if (stats && !stats_exact)
+                for (int c = tid; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
+            return;
+        }
+        if (tid < 80) xrows_s[tid] = (tid < rows_extra && base + tid < n_lab) ? v : -1;
+        lds_barrier();
+    }
+    struct Raw {
+        float4 a, h;
+        unsigned mk;
+        int row;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int slot = SR * st + rs;
+        int r = -1;
+        if (st < nst && slot < rows_wg) r = extra ? xrows_s[slot < 80 ? slot : 0] : (r0 + slot < N ? (int)(r0 + slot) : -1);
+        R.row = r;
+        R.a = buf_load4(r_xa, r >= 0 ? (int)((r * lda + 4 * ga) * 4) : kBufOOB);
+        R.h = buf_load4(r_xb, r >= 0 ? (int)((r * ldb + 4 * ga) * 4) : kBufOOB);
+        R.mk = __builtin_amdgcn_raw_buffer_load_b8(r_mask, (r >= 0 && !extra) ? r : kBufOOB, 0, 0);
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    GnCoefRegs CR;
+    const bool fold_here = pro.saved && (WG == 1 || tid < 4 * H);
+    if (fold_here && pro.src.acc) gn_fwd_coef_issue<H, 4 * H>(pro.src, CR);
+    const float4* img = reinterpret_cast<const float4*>(Wimg + (extra ? H * KT : 0));
+    float4 bw[KF4];
+#pragma unroll
+    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+    float bias1 = bias[16 * w + j], bias0 = bias[H + 16 * w + j];
+    if (fold_here && pro.src.acc) {
+        gn_fwd_coef_issue_params<H>(pro.src, CR);
+        glass_pin(CR.gamma);
+        glass_pin(CR.beta);
+        glass_pin(CR.alpha);
+    }
+    glass_pin(bias1);
+    glass_pin(bias0);
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
+    const float be = c1 * bias1 + c0 * bias0;
+    if (fold_here) gn_fwd_coef_finish<H, 4 * H>(pro.src, pro.saved, N, CR, gn_coef_s);
+    lds_barrier();  // coefficients
+    const bool pro_on = pro.saved != nullptr;
+    const bool side_on = pro.side != nullptr && !extra;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pro_on) {
+        const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
+        const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
+        sc[0] = s4.x, sc[1] = s4.y, sc[2] = s4.z, sc[3] = s4.w;
+        sh[0] = h4.x, sh[1] = h4.y, sh[2] = h4.z, sh[3] = h4.w;
+    }
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        float* T = tile[st & 1];
+        const int r = R.row;
+        float a[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = fmaf(a[k], sc[k], sh[k]) * ds[k];
+        const float4 v = make_float4(a[0], a[1], a[2], a[3]);
+        buf_store4(r_side, (pro_on && side_on && r >= 0) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
+        *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
+        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = R.h;
+        if (ga == 0) rowflag_s[st & 1][rs] = (r >= 0 && R.mk != 0) ? (r | (1 << 30)) : r;  // labeled row of a main tile: an extra workgroup stores it
+    };
+    float ssum = 0.f, ssq = 0.f;
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    // one stage: the MFMAs of stage st (buffer st & 1), then stage st + 1's rows (held in Rn) go to the other buffer and the
+    // loads of stage st + 3 are issued into Rn
+    auto stage = [&](int st, Raw& Rn) __attribute__((always_inline)) {
+        const float* T = tile[st & 1] + (16 * g + j) * RS + (KT / 4) * q;
+        float4 a4[KF4];
+#pragma unroll
+        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
+        int rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rowflag_s[st & 1][16 * g + 4 * q + r];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < KF4; tt += 2) {
+            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+            }
+        }
+        if (st + 1 < nst) {
+            commit(st + 1, Rn);
+            issue(st + 3, Rn);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
+            const float o = acc0[r] + acc1[r] + be;
+            buf_store1(r_out, live ? (int)((rv[r] * ldo + 16 * w + j) * 4) : kBufOOB, o);
+            ssum += live ? o : 0.f;
+            ssq += live ? o * o : 0.f;
+        }
+        if (st + 1 < nst) lds_barrier();
+    };
+    for (int st = 0; st < nst; st += 2) {
+        stage(st, rawB);
+        if (st + 1 < nst) stage(st + 1, rawA);
+    }
+    if (stats == nullptr) return;
+    double s = (double)ssum, q2 = (double)ssq;
+    s += __shfl_xor(s, 16);
+    q2 += __shfl_xor(q2, 16);
+    s += __shfl_xor(s, 32);
+    q2 += __shfl_xor(q2, 32);
+    if (WG > 1) {
+        if (g == 1 && q == 0) {
+            comb_s[16 * w + j] = s;
+            comb_s[H + 16 * w + j] = q2;
+        }
+        lds_barrier();
+        if (g == 1) return;
+        s += comb_s[16 * w + j];
+        q2 += comb_s[H + 16 * w + j];
+    }
+    if (q == 0) {
+        const int c = 16 * w + j;
+        if (stats_exact) {
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
+        } else {
+            stats[((size_t)blockIdx.x * 2) * H + c] = s;
+            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        }
+    }
+}
+
 // ---- trans forward in the same form (hidden 64): out = mix(act(xa W1^T + b1), act(xa W0^T + b0)), T = the two pre-activations
 // A wave owns columns 16w .. 16w+15 of BOTH halves (the label mix needs f1 and f0 of a column in one lane): 2 x 4 float4 of
 // weights per lane (K = 64), 32 MFMAs per 16-row stage; one float4 of the operand per thread and stage.  Image: layout
@@ -2495,8 +2684,52 @@ extern "C" int glass_comb_eff_supported(int64_t H) { return H == 64 ? 1 : 0; }
 extern "C" int glass_comb_eff_fwd_supported(int64_t H) { return (H == 64 || (GLASS_COMB_FWD_V2 && H == 128)) ? 1 : 0; }
 
 // workgroups of the launch = entries of `stats` / `gn_partial`: row tiles + extra workgroups for up to lab_cap listed rows
+// Geometry of the comb forward launch in its third form (comb_fwd_eff3_kernel): main workgroups of rows_main rows — one
+// ROUND of the chip (256 workgroups) once the graph is larger than 64 rows x 256, never fewer than 64 rows —, extra
+// workgroups of 64 listed rows.  GLASS_COMB_FWD3=0: the second form's fixed 64 / 80-row tiles (laboratory A/B).
+struct CombFwdGeom {
+    int rows_main, rows_extra, n_main, n_extra;
+};
+static bool comb_fwd3_on() {
+    static const bool on = [] {
+        const char* e = getenv("GLASS_COMB_FWD3");
+        return !(e && e[0] == '0');
+    }();
+    return on && GLASS_COMB_FWD_V2;
+}
+static CombFwdGeom comb_fwd_geom(int64_t n_nodes, int64_t lab_cap, int64_t H);
+// the third form is taken where its tiles are taller than the second form's 80 rows (below that the unrolled second form
+// measured 0.7 us faster per launch at ppi_bp-shape: 24.6 vs 25.3 us for the two launches)
+static bool comb_fwd3_tall(int64_t n_nodes, int64_t lab_cap, int64_t H);
+static CombFwdGeom comb_fwd_geom(int64_t n_nodes, int64_t lab_cap, int64_t H) {
+    CombFwdGeom g;
+    const int64_t sr = (H == 64 && fwd_wave_groups(true) == 2) ? 32 : 16;  // stage height of the kernel that will run
+    int64_t rows = ceil_div(ceil_div(n_nodes, (int64_t)256), sr) * sr;
+    if (rows < 64) rows = 64;
+    g.rows_main = (int)rows;
+    g.rows_extra = 64;
+    g.n_main = (int)ceil_div(n_nodes, rows);
+    g.n_extra = (int)ceil_div(lab_cap, (int64_t)64);
+    return g;
+}
+
+static bool comb_fwd3_tall(int64_t n_nodes, int64_t lab_cap, int64_t H) {
+    return comb_fwd3_on() && comb_fwd_geom(n_nodes, lab_cap, H).rows_main > 80;
+}
+
+// partial-sum entries of the BACKWARD's gn_partial (64-row tiles + the extra workgroups) ...
 extern "C" int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap) {
     if (!glass_comb_eff_fwd_supported(H) || n_nodes <= 0 || lab_cap < 0) return GLASS_E_ARG;
+    return ceil_div(n_nodes, 64) + ceil_div(lab_cap, 64);
+}
+
+// ... and of the FORWARD's `stats` in the partials form: one per workgroup of ITS geometry (tall row tiles on larger graphs)
+extern "C" int64_t glass_comb_eff_fwd_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap) {
+    if (!glass_comb_eff_fwd_supported(H) || n_nodes <= 0 || lab_cap < 0) return GLASS_E_ARG;
+    if (comb_fwd3_tall(n_nodes, lab_cap, H)) {
+        const CombFwdGeom g = comb_fwd_geom(n_nodes, lab_cap, H);
+        return g.n_main + g.n_extra;
+    }
     return ceil_div(n_nodes, 64) + ceil_div(lab_cap, 64);
 }
 
@@ -2573,6 +2806,23 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, DR, NS, 2>), grid, dim3(512), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff, \
                        bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
     const bool dr = gn_saved && p_drop > 0.f;
+    if (comb_fwd3_tall(n_nodes, lab_cap, H)) {
+        const CombFwdGeom cg = comb_fwd_geom(n_nodes, lab_cap, H);
+        const LabRows lab3{lab_rows, lab_count, cg.n_main, (int)lab_cap};
+        const dim3 grid3((unsigned)(cg.n_main + cg.n_extra));
+#define GLASS_CF3(HH, DR, WGN)                                                                                              \
+    hipLaunchKernelGGL((comb_fwd_eff3_kernel<HH, DR, WGN>), grid3, dim3(4 * HH * WGN), 0, (hipStream_t)stream, xa, lda, xb, ldb,   \
+                       Wimg_eff, bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab3, cg.rows_main, cg.rows_extra)
+        if (H == 128) {
+            if (dr) GLASS_CF3(128, true, 1); else GLASS_CF3(128, false, 1);
+        } else if (fwd_wave_groups(true) == 2) {
+            if (dr) GLASS_CF3(64, true, 2); else GLASS_CF3(64, false, 2);
+        } else {
+            if (dr) GLASS_CF3(64, true, 1); else GLASS_CF3(64, false, 1);
+        }
+#undef GLASS_CF3
+        return launch_status("glass_comb_eff_fwd_f32");
+    }
     if (GLASS_COMB_FWD_V2 && H == 128) {
         if (dr && tall) GLASS_CF2(128, true, 5);
         else if (dr) GLASS_CF2(128, true, 4);

@@ -645,7 +645,7 @@ class StackProgram:
                 _comb_eff_fwd(a, h, conv, mask, c, None, (gsaved, ACT_NONE, pc, conv.call_base, g), labels)
             elif _comb_eff_fwd_ok(conv, labels, H):
                 cstat = acc_fwd[L + l] if acc_fwd is not None else \
-                    torch.empty((int(lib.glass_comb_eff_blocks(n, H, labels.cap)), 2, H), dtype=torch.float64, device=dev)
+                    torch.empty((int(lib.glass_comb_eff_fwd_blocks(n, H, labels.cap)), 2, H), dtype=torch.float64, device=dev)
                 _comb_eff_fwd(a, h, conv, mask, c, cstat, (gsaved, ACT_NONE, pc, conv.call_base, g), labels)
             else:
                 cstat = acc_fwd[L + l] if acc_fwd is not None else \

@@ -408,8 +408,8 @@ int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
  *   glass_batch_labels; lab_cap = capacity of the list, fixes the grid) are gathered 16 per wave by extra workgroups of
  *   the same launch, which multiply z W1 + (1-z) W0 — every row written once, no atomics; half the matrix work of
  *   glass_dual_linear_fwd_f32 / _bwd_f32 on the same pair.  Wimg_eff / WTimg_eff: operand images of layout 6 / 7
- *   (glass_dense_pack_batch_f32).  stats / gn_partial hold glass_comb_eff_blocks(n_nodes, H, lab_cap) entries of [2][H]
- *   doubles (row tiles, then extra workgroups).  Other arguments as in glass_dual_linear_fwd_f32 (xb != NULL, act none,
+ *   (glass_dense_pack_batch_f32).  stats holds glass_comb_eff_fwd_blocks(n_nodes, H, lab_cap) and gn_partial
+ *   glass_comb_eff_blocks(n_nodes, H, lab_cap) entries of [2][H] doubles (row tiles, then extra workgroups).  Other arguments as in glass_dual_linear_fwd_f32 (xb != NULL, act none,
  *   no T) and glass_dual_linear_bwd_f32 (n_out = 2H, no addend, no dropout on the output; X == NULL: data gradient only).
  *   The weight-gradient partials written to `ws` are in S / L form: one [H x 2H] product over all rows plus the same over the
  *   listed rows (half the matrix work of the plain form); reduce them with glass_linear_wgrad_reduce_batch_f32, lab_cap[j]
@@ -419,7 +419,8 @@ int glass_comb_eff_fwd_supported(int64_t H); /* the forward alone: also hidden 1
 int glass_comb_eff_fwd_layout(int64_t H); /* pack layout of Wimg_eff for glass_comb_eff_fwd_f32: 6 or 8 */
 int glass_comb_eff_dgrad_layout2(int64_t H); /* != 0: WTimg_eff holds a second pair of images in this layout behind the layout-7 pair */
 int64_t glass_comb_eff_max_rows(int64_t ld); /* most rows the forward serves at operand row strides <= ld floats */
-int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap);
+int64_t glass_comb_eff_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap);     /* entries of the backward's gn_partial */
+int64_t glass_comb_eff_fwd_blocks(int64_t n_nodes, int64_t H, int64_t lab_cap); /* entries of the forward's stats (partials form): one per workgroup of the launch's geometry — tall row tiles (one round of the chip) on graphs beyond 80 x 256 rows */
 int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t lab_cap); /* `ws` of glass_comb_eff_bwd_f32 */
 int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg_eff,
                            const float* bias, const uint8_t* mask, double z_ratio, float* out, int64_t ldo,

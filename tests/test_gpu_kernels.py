@@ -1135,9 +1135,10 @@ def test_comb_pair_effective_weight_hidden64(N, pattern, p_drop):
     gsaved = stack._GN(gmod).stats(a)
     call = 16
     # ---- forward: eff form vs two-product kernel vs fp64
-    nblk_eff = int(stack._lib.load().glass_comb_eff_blocks(N, H, labels.cap))
+    nblk_eff = int(stack._lib.load().glass_comb_eff_blocks(N, H, labels.cap))           # backward partials
+    nblk_fwd = int(stack._lib.load().glass_comb_eff_fwd_blocks(N, H, labels.cap))       # forward partials (its own geometry)
     c, g = torch.empty(N, H, device=DEV), torch.empty(N, H, device=DEV)
-    cstat = torch.empty(nblk_eff, 2, H, dtype=torch.float64, device=DEV)
+    cstat = torch.empty(nblk_fwd, 2, H, dtype=torch.float64, device=DEV)
     stack._comb_eff_fwd(a, h, conv, mask, c, cstat, (gsaved, 0, p_drop, call, g), labels)
     c2, g2 = torch.empty(N, H, device=DEV), torch.empty(N, H, device=DEV)
     cstat2 = torch.empty(-(-N // 64), 2, H, dtype=torch.float64, device=DEV)
