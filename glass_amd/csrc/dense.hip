@@ -739,6 +739,187 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
         }
     }
 }
+// The same body with a RUN-TIME number of stages ("tall" row tiles, see comb_fwd_eff3_kernel): a workgroup takes n_tiles
+// consecutive 64-row tiles, loads its weight slice and the GraphNorm statistics once and keeps the double-buffered stage
+// pipeline running across the tiles; the backward column sums of a GraphNorm are still written per 64-row tile (the partials
+// form keeps its ABI: one entry per tile), flushed every four stages.
+template <int H>
+__global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int tiles_per_wg) {
+    static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
+    extern __shared__ float4 lds_w3[];
+    float* lds = reinterpret_cast<float*>(lds_w3);
+    constexpr int NTL = H / 16, KF4 = (2 * H) / 16;
+    constexpr int KT = 2 * H, RA = KT + 4, RP = H + 4;
+    constexpr int kBuf = 16 * RA + 4 * 16 * RP;  // A | ADD | M | U | XU  (floats per stage buffer)
+    int* rows_s = reinterpret_cast<int*>(lds + 2 * kBuf);  // [2][16]: the rows of the stage in each buffer
+    const float* __restrict__ dsrc = A.dsrc;
+    const int64_t ldd = A.ldd, ldt = A.ldt, ldadd = A.ldadd, ldo = A.ldo, N = A.N;
+    const float zr = A.zr, omz = A.omz;
+    const int act = A.act;
+    const GnBwdStats gs = A.gs;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rs = tid / (H / 4), ga = tid % (H / 4);
+    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
+    const int64_t n_tiles_all = (N + 63) / 64;
+    const int n_tiles = (int)(tile0 + tiles_per_wg <= n_tiles_all ? tiles_per_wg : n_tiles_all - tile0);
+    if (n_tiles <= 0) return;
+    const int nst = 4 * n_tiles;
+    const int64_t r0 = tile0 * 64;
+    const buf_rsrc r_d = make_rsrc(dsrc, N * ldd * 4), r_t = make_rsrc(A.T ? A.T : dsrc, A.T ? N * ldt * 4 : 0);
+    const buf_rsrc r_m = make_rsrc(A.mask, N), r_out = make_rsrc(A.out, N * ldo * 4);
+    const buf_rsrc r_add = make_rsrc(A.addend ? A.addend : dsrc, A.addend ? N * ldadd * 4 : 0);
+    const buf_rsrc r_x = make_rsrc(gs.partial ? gs.x : dsrc, gs.partial ? N * gs.ldx * 4 : 0);
+    struct Raw {
+        float4 d, t1, t0, ad, x;
+        unsigned mk;
+        int row;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int64_t rr = r0 + 16 * st + rs;
+        const bool ok = st < nst && rr < N;
+        const int r = ok ? (int)rr : -1;
+        R.row = r;
+        R.d = buf_load4(r_d, ok ? (int)((r * ldd + 4 * ga) * 4) : kBufOOB);
+        R.t1 = buf_load4(r_t, ok ? (int)((r * ldt + 4 * ga) * 4) : kBufOOB);
+        R.t0 = buf_load4(r_t, ok ? (int)((r * ldt + H + 4 * ga) * 4) : kBufOOB);
+        R.ad = buf_load4(r_add, ok ? (int)((r * ldadd + 4 * ga) * 4) : kBufOOB);
+        R.x = buf_load4(r_x, ok ? (int)((r * gs.ldx + 4 * ga) * 4) : kBufOOB);
+        R.mk = __builtin_amdgcn_raw_buffer_load_b8(r_m, ok ? r : kBufOOB, 0, 0);
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    const float4* img = reinterpret_cast<const float4*>(A.WT);
+    float4 bw[KF4];
+#pragma unroll
+    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+    Drop drop = A.drop;
+    const bool drop_on = drop.p > 0.f, gn_on = gs.partial != nullptr, gdrop_on = gn_on && gs.drop.p > 0.f;
+    Drop gdrop = gs.drop;
+    if (drop_on || gdrop_on) {
+        drop.seed = gdrop.seed = A.rng_state[0];
+        drop.step = gdrop.step = A.rng_state[1];
+    }
+    float g_mu[4] = {0.f, 0.f, 0.f, 0.f}, g_rs[4] = {0.f, 0.f, 0.f, 0.f}, g_al[4] = {0.f, 0.f, 0.f, 0.f};
+    float g_sc[4] = {0.f, 0.f, 0.f, 0.f}, g_sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gn_on) {
+        const float4 m4 = *reinterpret_cast<const float4*>(gs.saved + 4 * ga), r4 = *reinterpret_cast<const float4*>(gs.saved + H + 4 * ga);
+        const float4 s4 = *reinterpret_cast<const float4*>(gs.saved + 2 * H + 4 * ga), h4 = *reinterpret_cast<const float4*>(gs.saved + 3 * H + 4 * ga);
+        const float4 a4 = *reinterpret_cast<const float4*>(gs.alpha + 4 * ga);
+        g_mu[0] = m4.x, g_mu[1] = m4.y, g_mu[2] = m4.z, g_mu[3] = m4.w;
+        g_rs[0] = r4.x, g_rs[1] = r4.y, g_rs[2] = r4.z, g_rs[3] = r4.w;
+        g_sc[0] = s4.x, g_sc[1] = s4.y, g_sc[2] = s4.z, g_sc[3] = s4.w;
+        g_sh[0] = h4.x, g_sh[1] = h4.y, g_sh[2] = h4.z, g_sh[3] = h4.w;
+        g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
+    }
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        float* At = lds + (st & 1) * kBuf;
+        float* ADD = At + 16 * RA;
+        float* M = ADD + 16 * RP;
+        float* U = M + 16 * RP;
+        float* XU = U + 16 * RP;
+        const int r = R.row < 0 ? 0 : R.row;
+        const float c1 = R.mk ? zr : omz, c0 = R.mk ? omz : zr;
+        const float d[4] = {R.d.x, R.d.y, R.d.z, R.d.w}, t1[4] = {R.t1.x, R.t1.y, R.t1.z, R.t1.w}, t0[4] = {R.t0.x, R.t0.y, R.t0.z, R.t0.w};
+        const float xv[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
+        float z1[4], z0[4], m[4] = {1.f, 1.f, 1.f, 1.f}, gds[4] = {1.f, 1.f, 1.f, 1.f}, u[4], xu[4];
+        if (drop_on) drop_scales<4>(drop, r, 4 * ga, m);
+        if (gdrop_on) drop_scales<4>(gdrop, r, 4 * ga, gds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            z1[k] = d[k] * c1;
+            z0[k] = d[k] * c0;
+            z1[k] *= act_grad(act, t1[k]), z0[k] *= act_grad(act, t0[k]);
+            float uk = gds[k];
+            uk *= act_grad(gs.act, fmaf(xv[k], g_sc[k], g_sh[k]));
+            u[k] = uk;
+            xu[k] = (xv[k] - g_al[k] * g_mu[k]) * g_rs[k] * uk;
+        }
+        *reinterpret_cast<float4*>(At + rs * RA + 4 * ga) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+        *reinterpret_cast<float4*>(At + rs * RA + H + 4 * ga) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        *reinterpret_cast<float4*>(ADD + rs * RP + 4 * ga) = R.ad;
+        *reinterpret_cast<float4*>(M + rs * RP + 4 * ga) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<float4*>(U + rs * RP + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
+        *reinterpret_cast<float4*>(XU + rs * RP + 4 * ga) = make_float4(xu[0], xu[1], xu[2], xu[3]);
+        if (ga == 0) rows_s[(st & 1) * 16 + rs] = R.row;
+    };
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    float s1 = 0.f, s2 = 0.f;
+    const int c = 16 * w + j;
+    auto flush = [&](int64_t tile) __attribute__((always_inline)) {  // this lane's column sums of one 64-row tile
+        double a = (double)s1, b2 = (double)s2;
+        a += __shfl_xor(a, 16);
+        b2 += __shfl_xor(b2, 16);
+        a += __shfl_xor(a, 32);
+        b2 += __shfl_xor(b2, 32);
+        if (q == 0) {
+            if (gs.exact) {
+                gn_acc_add(reinterpret_cast<long long*>(gs.partial), (int)(tile % gs.exact), 0, c, H, a, kAccScaleBwd);
+                gn_acc_add(reinterpret_cast<long long*>(gs.partial), (int)(tile % gs.exact), 1, c, H, b2, kAccScaleBwd);
+            } else {
+                gs.partial[((size_t)tile * 2) * H + c] = a;
+                gs.partial[((size_t)tile * 2 + 1) * H + c] = b2;
+            }
+        }
+        s1 = s2 = 0.f;
+    };
+    auto stage = [&](int st, Raw& Rn) __attribute__((always_inline)) {
+        const float* At = lds + (st & 1) * kBuf;
+        const float* ADD = At + 16 * RA;
+        const float* M = ADD + 16 * RP;
+        const float* U = M + 16 * RP;
+        const float* XU = U + 16 * RP;
+        float4 a4[KF4];
+#pragma unroll
+        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(At + j * RA + (KT / 4) * q + 4 * tt);
+        int rv[4];
+        float ad[4], mm[4], uu[4], xx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rv[r] = rows_s[(st & 1) * 16 + 4 * q + r];
+            ad[r] = ADD[(4 * q + r) * RP + c];
+            mm[r] = M[(4 * q + r) * RP + c];
+            uu[r] = U[(4 * q + r) * RP + c];
+            xx[r] = XU[(4 * q + r) * RP + c];
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < KF4; tt += 2) {
+            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+            }
+        }
+        if (st + 1 < nst) {
+            commit(st + 1, Rn);
+            issue(st + 3, Rn);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0;
+            const float v = (acc0[r] + acc1[r] + ad[r]) * mm[r];
+            buf_store1(r_out, live ? (int)((rv[r] * ldo + c) * 4) : kBufOOB, v);
+            const float vl = live ? v : 0.f;
+            s1 = fmaf(vl, uu[r], s1);
+            s2 = fmaf(vl, xx[r], s2);
+        }
+        if (gn_on && (st & 3) == 3) flush(tile0 + (st >> 2));
+        if (st + 1 < nst) lds_barrier();
+    };
+    for (int st = 0; st < nst; st += 2) {
+        stage(st, rawB);
+        stage(st + 1, rawA);  // (nst is a multiple of 4)
+    }
+}
+constexpr size_t trans_dgrad3_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 32) * sizeof(float); }
+
 constexpr size_t trans_dgrad2_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 64) * sizeof(float); }
 constexpr size_t kTransDgrad2Lds = trans_dgrad2_lds(64);
 
@@ -2600,6 +2781,19 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "dual_linear_dgrad: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
         GLASS_REQUIRE(!gn_exact, "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only");
         const DgradArgs d128{dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs};
+        const int64_t n_tiles = ceil_div(n_nodes, 64);
+        static const bool tall_on = [] {
+            const char* e = getenv("GLASS_TRANS_DGRAD3");
+            return !(e && e[0] == '0');
+        }();
+        if (tall_on && n_tiles > 256) {  // more than one round of 64-row tiles: tall tiles, one workgroup per CU (trans_dgrad3_kernel)
+            const int tiles_per_wg = (int)ceil_div(n_tiles, 256);
+            const size_t lds3 = trans_dgrad3_lds(128);
+            allow_lds(trans_dgrad3_kernel<128>, lds3);
+            hipLaunchKernelGGL((trans_dgrad3_kernel<128>), dim3((unsigned)ceil_div(n_tiles, tiles_per_wg)), dim3(512), lds3, st, d128, tiles_per_wg);
+            const int rc3 = launch_status("glass_dual_linear_dgrad_f32 (staged, tall, hidden 128)");
+            return rc3 ? rc3 : wgrad_after();
+        }
         const size_t lds128 = trans_dgrad2_lds(128);
         allow_lds(trans_dgrad2_kernel<128>, lds128);
         hipLaunchKernelGGL((trans_dgrad2_kernel<128>), dim3((unsigned)ceil_div(n_nodes, 64)), dim3(512), lds128, st, d128);
