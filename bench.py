@@ -29,7 +29,9 @@ The JSON line also carries
                    <= 1 by construction: every gathered byte passes an XCD L2 (algorithmic rate / 34.5 TB/s
                    aggregate), and the L2-miss traffic passes the memory side — the Infinity Cache while X fits
                    its 256 MiB (the guide's gathered-row rate, 8.6 TB/s chip-wide), HBM (8 TB/s) beyond.
-                   `frac` = the larger one, `bound` names it.  `traffic` = memory-side bytes per launch from
+                   A third one prices what binds a row gather: the gathered neighbour rows (nnz * 4H bytes) against
+                   the guide's measured whole-row gather rates (18.8 TB/s from L2, 8.6 TB/s from the Infinity Cache),
+                   blended by the measured share of rows that missed L2.  `frac` = the largest, `bound` names it.  `traffic` = memory-side bytes per launch from
                    PMC counters collected IN THIS RUN (a child `rocprofv3 --kernel-trace --pmc FETCH_SIZE`,
                    then WRITE_SIZE, on tools/bin/spmm_bench at the same shape: separate passes, KiB units,
                    FETCH_SIZE doubled per the gfx950 rule) or null.
@@ -59,6 +61,7 @@ L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md §L2: aggregate of the 8 XCD L2s
 HBM_PEAK_GBPS = 8000.0   # spec (6.29 TB/s measured achievable copy)
 HBM_COPY_GBPS = 6290.0   # MI355X_MICROARCH.md §HBM: what a float4 copy achieves; an "HBM" rate above it was cache-assisted
 IC_GATHER_GBPS = 8600.0  # MI355X_MICROARCH.md §Indexed rows: uniformly random rows of a 38 MB table (Infinity Cache), chip-wide
+L2_GATHER_GBPS = 18800.0  # same table: rows of a table shared by every workgroup and served by the XCD's L2 (16.8-18.8 TB/s; the upper end)
 MFMA_F32_TFLOPS = 157.3  # dense fp32 matrix-core peak
 L2_XCD_BYTES = 4 << 20
 IC_BYTES = 256 << 20
@@ -682,7 +685,22 @@ def main():
             mem_rate, u_mem = None, None
     else:
         mem_rate, u_mem = None, None
-    if x_bytes <= L2_XCD_BYTES or u_mem is None or u_l2 >= u_mem:
+    # Third utilisation — the one that binds a ROW GATHER: every neighbour row (4H bytes per edge) is gathered through the CU's
+    # vector L1 from an XCD L2 or, when it misses there, from the Infinity Cache, and the guide measured what whole-row
+    # gathers reach from either level (§Indexed rows: 16.8-18.8 TB/s from L2, 8.6 TB/s from the Infinity Cache — far below
+    # the 34.5 TB/s a streaming read gets from L2).  The share of gathered bytes that missed L2 comes from the counters
+    # (memory-side fetches minus the streamed col / val / rowptr reads and the Y writes); the peak is the harmonic blend.
+    gather_bytes = nnz * 4 * H
+    gather_rate = gather_bytes / k1_avg / 1e9
+    u_gather, gather_peak, miss_share = None, None, None
+    if traffic is not None and x_bytes <= IC_BYTES:
+        miss_bytes = min(max(traffic - (nnz * 8 + N * 4 + N * 4 * H), 0), gather_bytes)
+        miss_share = miss_bytes / gather_bytes
+        gather_peak = 1.0 / ((1.0 - miss_share) / L2_GATHER_GBPS + miss_share / IC_GATHER_GBPS)
+        u_gather = gather_rate / gather_peak
+    if u_gather is not None and u_gather >= max(u_l2, u_mem or 0.0):
+        bound, achieved, peak, frac = "gather_path", gather_rate, gather_peak, u_gather
+    elif x_bytes <= L2_XCD_BYTES or u_mem is None or u_l2 >= u_mem:
         bound, achieved, peak, frac = "l2", alg_rate, L2_PEAK_GBPS, u_l2
     else:
         bound, achieved, peak, frac = mem_level, mem_rate, mem_peak, u_mem
@@ -697,8 +715,15 @@ def main():
                                 "memory_side_label": "memory-side (HBM + Infinity Cache): FETCH_SIZE / WRITE_SIZE count the L2's "
                                                      "fabric requests, Infinity-Cache hits included (MI355X_MICROARCH.md §HBM) — "
                                                      "not HBM-only traffic",
-                                "note": "frac = the larger of the two; algorithmic bytes / 34.5 TB/s (every gathered byte passes "
-                                        "an XCD L2) and memory-side traffic / that level's peak"},
+                                "gather_path": u_gather, "gather_rate_GBps": gather_rate, "gather_peak_GBps": gather_peak,
+                                "gathered_bytes_per_launch": gather_bytes, "gather_l2_miss_share": miss_share,
+                                "gather_path_label": "neighbour-row gathers (nnz * 4H bytes) / launch time, against the guide's measured "
+                                                     "whole-row gather rates blended by where the rows came from: 18.8 TB/s for the share "
+                                                     "served by an XCD L2, 8.6 TB/s for the share that missed to the Infinity Cache "
+                                                     "(MI355X_MICROARCH.md §Indexed rows); the miss share is measured (counters)",
+                                "note": "frac = the largest of the three: algorithmic bytes / 34.5 TB/s (the L2 streaming rate — a row "
+                                        "gather cannot reach it), memory-side traffic / that level's peak (prices only the bytes that "
+                                        "missed L2), gathered bytes / the blended gather rate (the path that binds this kernel)"},
                 "frac_of_hbm_peak_algorithmic": alg_rate / HBM_PEAK_GBPS,
                 "algorithmic_cache_assisted": alg_rate > HBM_COPY_GBPS,
                 "hbm_evidence": "algorithmic bytes / 8 TB/s above 6.3 / 8 = 0.79 cannot have come from HBM alone (cache-assisted); "

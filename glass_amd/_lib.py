@@ -102,6 +102,7 @@ SIGNATURES = {
     "glass_segment_pool_bwd_exact_f32": (c_int, [_P, _I, _P, _I, _I, c_int, _P, _I, _I, _I, _P, _P]),
     "glass_pair_pool_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P]),
     "glass_pair_pool_bwd_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P, _P]),
+    "glass_dense_caps_query": (c_int, [_I, _P]),
     "glass_pair_head_supported": (c_int, [_I]),
     "glass_pair_head_ws_bytes": (c_int64, [_I, _I]),
     "glass_pair_head_fwd_f32": (c_int, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, c_float, _P, c_uint64, _P, _P, _P, _P, _P, _P]),
@@ -158,6 +159,26 @@ SIGNATURES = {
 }
 
 _lib = None
+
+
+class DenseCaps(ctypes.Structure):
+    """include/glass_hip.h: glass_dense_caps — one capability record per hidden width."""
+    _fields_ = [(n, ctypes.c_int32) for n in ("family", "weight_layout", "fwd_layout_trans", "fwd_layout_comb", "dgrad_layout_trans",
+                                              "dgrad_layout_comb", "stat_rows", "fwd_gather", "gn_exact", "gn_exact_fwd", "comb_eff",
+                                              "comb_eff_fwd", "comb_eff_fwd_layout", "comb_eff_dgrad_layout2", "pair_head", "act_codes")]
+
+
+_caps = {}
+
+
+def dense_caps(H):
+    """The library's capability record for hidden width H (cached)."""
+    c = _caps.get(int(H))
+    if c is None:
+        c = DenseCaps()
+        check(load().glass_dense_caps_query(int(H), ctypes.addressof(c)), "glass_dense_caps_query")
+        _caps[int(H)] = c
+    return c
 
 
 def load():

@@ -2595,6 +2595,32 @@ static bool make_exact_src(const glass_gn_src* g, const float* saved, GnExactSrc
 extern "C" int64_t glass_gn_exact_words(int64_t C) { return gn_acc_words(C); }  // int64 words of one accumulator block
 
 extern "C" int glass_dual_linear_supported(int64_t H) { return dense_shape_ok(H) ? 1 : 0; }
+
+extern "C" int glass_pair_head_supported(int64_t hidden);
+extern "C" int glass_dense_caps_query(int64_t H, glass_dense_caps* out) {
+    GLASS_REQUIRE(H > 0 && out, "dense_caps: H > 0 and a record to fill");
+    glass_dense_caps c{};
+    c.family = narrow_shape_ok(H) ? 1 : wave16_shape_ok(H) ? 2 : tiled_here(H) ? 3 : 0;
+    if (c.family) {
+        c.weight_layout = glass_dual_linear_layout(H);
+        c.fwd_layout_trans = glass_dual_linear_fwd_layout(H, H);
+        c.fwd_layout_comb = glass_dual_linear_fwd_layout(H, 2 * H);
+        c.dgrad_layout_trans = glass_dual_linear_dgrad_layout(H, H);
+        c.dgrad_layout_comb = glass_dual_linear_dgrad_layout(H, 2 * H);
+        c.stat_rows = (int32_t)glass_dual_linear_stat_rows(H);
+        c.fwd_gather = glass_dual_linear_fwd_gather_supported(H);
+        c.act_codes = (1 << GLASS_ACT_ELU) | (1 << GLASS_ACT_RELU);
+    }
+    c.gn_exact = glass_gn_exact_supported(H);
+    c.gn_exact_fwd = glass_gn_exact_fwd_supported(H);
+    c.comb_eff = glass_comb_eff_supported(H);
+    c.comb_eff_fwd = glass_comb_eff_fwd_supported(H);
+    c.comb_eff_fwd_layout = c.comb_eff_fwd ? glass_comb_eff_fwd_layout(H) : 0;
+    c.comb_eff_dgrad_layout2 = c.comb_eff ? glass_comb_eff_dgrad_layout2(H) : 0;
+    c.pair_head = glass_pair_head_supported(H);
+    *out = c;
+    return 0;
+}
 // glass_dual_linear_fwd_f32 with xa_index (the trans pair of layer 0 gathers its operand rows from the embedding table)
 extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return (wave16_shape_ok(H) || narrow_shape_ok(H) || tiled_here(H)) ? 1 : 0; }
 

@@ -342,6 +342,25 @@ int glass_linear_wgrad_f32(const float* G, int64_t ldg, const float* X, int64_t 
  *   Hidden sizes 64, 128, 256, 512 (glass_dual_linear_supported); otherwise GLASS_E_UNSUPPORTED and the
  *   caller composes the library GEMM with glass_mix_*.
  * ---------------------------------------------------------------------------------------- */
+/* ONE capability record per hidden width instead of the per-feature queries below (which stay, as thin wrappers of the same
+ * answers): everything a caller needs to know to route a width — which kernel family serves the Linear pairs, which operand
+ * image layouts its weights must be packed in, which fusions exist at that width.  glass_dense_caps fills *out and returns
+ * 0, or GLASS_E_ARG for H <= 0 / out == NULL (out->family = 0 when no hand-written dense kernel serves the width:
+ * the caller then uses library GEMMs + the stand-alone mix / GraphNorm kernels). */
+typedef struct glass_dense_caps {
+    int32_t family;            /* 0 none | 1 narrow (thread per row, hidden <= 32) | 2 staged 16x16x4 MFMA (hidden 64) | 3 LDS-tiled 32x32x2 MFMA (128 / 256 / 512) */
+    int32_t weight_layout;     /* glass_dual_linear_layout: 0 wave16 images, 1 tiled images, 2 row-major weights as they are */
+    int32_t fwd_layout_trans, fwd_layout_comb;       /* glass_dual_linear_fwd_layout(H, H) / (H, 2H) */
+    int32_t dgrad_layout_trans, dgrad_layout_comb;   /* glass_dual_linear_dgrad_layout(H, H) / (H, 2H) */
+    int32_t stat_rows;         /* rows per statistics partial of the forward (glass_dual_linear_stat_rows) */
+    int32_t fwd_gather;        /* layer 0's trans kernel gathers its operand from the embedding table */
+    int32_t gn_exact, gn_exact_fwd;                  /* exact GraphNorm accumulators: all sums / the forward sums alone */
+    int32_t comb_eff, comb_eff_fwd;                  /* comb pair through effective per-label weights: fwd + bwd / fwd alone */
+    int32_t comb_eff_fwd_layout, comb_eff_dgrad_layout2;
+    int32_t pair_head;         /* K9 (pre-training head on node pairs) at this width */
+    int32_t act_codes;         /* bit mask of the activation codes the family fuses: 1 << GLASS_ACT_ELU | 1 << GLASS_ACT_RELU */
+} glass_dense_caps;
+int glass_dense_caps_query(int64_t H, glass_dense_caps* out);
 int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
  * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */

@@ -256,3 +256,22 @@ def test_plan_builder_property_based():
         _check_plan(np.concatenate([[0], np.cumsum(np.asarray(degs, dtype=np.int64))]))
 
     check()
+
+
+def test_dense_capability_record():
+    """glass_dense_caps_query: ONE record per hidden width (the per-feature queries collapsed) — host
+    arithmetic, agrees with the thin per-feature wrappers that remain, and tells which widths fall back to library GEMMs."""
+    from glass_amd import _lib
+    lib = _lib.load()
+    fam = {h: _lib.dense_caps(h).family for h in (8, 17, 20, 32, 48, 64, 96, 128, 192, 256, 384, 512, 1024)}
+    assert fam == {8: 1, 17: 1, 20: 1, 32: 1, 48: 0, 64: 2, 96: 0, 128: 3, 192: 0, 256: 3, 384: 0, 512: 3, 1024: 0}
+    for h in (8, 20, 64, 128, 256, 512):
+        c = _lib.dense_caps(h)
+        assert c.weight_layout == lib.glass_dual_linear_layout(h) and c.stat_rows == lib.glass_dual_linear_stat_rows(h)
+        assert c.fwd_layout_comb == lib.glass_dual_linear_fwd_layout(h, 2 * h) and c.dgrad_layout_trans == lib.glass_dual_linear_dgrad_layout(h, h)
+        assert c.fwd_gather == lib.glass_dual_linear_fwd_gather_supported(h)
+        assert c.gn_exact == lib.glass_gn_exact_supported(h) and c.comb_eff == lib.glass_comb_eff_supported(h)
+        assert c.act_codes == (1 << 1) | (1 << 2)   # ELU and ReLU fused at every served width
+    c64, c128 = _lib.dense_caps(64), _lib.dense_caps(128)
+    assert c64.pair_head == 1 and c128.pair_head == 0 and c64.comb_eff == 1 and c128.comb_eff == 0 and c128.comb_eff_fwd == 1
+    assert lib.glass_dense_caps_query(0, None) == -1
