@@ -1393,6 +1393,233 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     D_STAMP(1, 4);
 }
 
+// ---- the second form with the LDS reads software-pipelined one stage ahead (three LDS buffers, three load sets in flight):
+// GLASS_COMB_FWD_PF=1 (laboratory A/B against comb_fwd_eff2_kernel; hidden 64, one wave group)
+template <int H, bool DROP, int NST>
+__global__ __launch_bounds__(4 * H) void comb_fwd_eff2p_kernel(const float* __restrict__ xa, int64_t lda,
+                                                               const float* __restrict__ xb, int64_t ldb,
+                                                               const float* __restrict__ Wimg, const float* __restrict__ bias,
+                                                               const uint8_t* __restrict__ mask, float zr, float omz,
+                                                               float* __restrict__ out, int64_t ldo, int64_t N,
+                                                               double* __restrict__ stats, int stats_exact, GnPrologue pro,
+                                                               LabRows lab) {
+    static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
+    constexpr int WG = 1;
+    constexpr int THREADS = 4 * H * WG, NTL = H / 16, KF4 = (2 * H) / 16;  // threads, 16-column tiles, float4 per lane of a weight slice
+    constexpr int KT = 2 * H, RS = KT + 4;  // LDS row stride (floats): + 4 keeps the 16 rows of a b128 read off one bank group
+    constexpr int SR = 16 * WG, NSTG = (NST + WG - 1) / WG;  // rows per stage, stages per workgroup
+    __shared__ __attribute__((aligned(16))) float tile[3][SR * RS];
+    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
+    constexpr int ROWS = 16 * NST;
+    __shared__ int rows_s[ROWS];  // row of each of the workgroup's slots: -1 none; bit 30 set: computed but not stored / counted
+    __shared__ double comb_s[WG > 1 ? 2 * H : 1];  // column sums of wave group 1, handed to group 0
+    D_STAMP(1, 0);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int w = wv % NTL, g = wv / NTL;  // column tile, row group
+    const int j = lane & 15, q = lane >> 4;
+    // ---- prologue: EVERY load it needs is issued before the first value is used (one memory round trip; the first form
+    // waited three times: weights / bias / label byte — a conditional byte load forces vmcnt(0) —, then operands and
+    // accumulators, then gamma / beta / alpha, which the compiler had sunk behind the accumulator wait: tools/dense_trace.py
+    // slots 0 -> 6 -> 1 read 1.7 + 2.0 us).  Order of issue = order of need: the first two stages' operand rows, the
+    // GraphNorm sums, the weight slice, bias, label byte.
+    const bool extra = (int)blockIdx.x >= lab.n_main;
+    const int base = extra ? ((int)blockIdx.x - lab.n_main) * ROWS : 0;
+    const buf_rsrc r_xa = make_rsrc(xa, N * lda * 4), r_xb = make_rsrc(xb, N * ldb * 4), r_out = make_rsrc(out, N * ldo * 4);
+    const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
+    const buf_rsrc r_mask = make_rsrc(mask, N);
+    // the two float4 this thread moves per stage: 4-column group ga of the a half (GraphNorm prologue) and of the h half of
+    // row rs of the stage (one buffer resource per half: wave-uniform)
+    const int rs = tid / (H / 4), ga = tid % (H / 4);
+    int my_row[NSTG];  // (-1: none)
+    int n_lab = 0;
+    if (!extra) {
+        const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+#pragma unroll
+        for (int st = 0; st < NSTG; ++st)
+            my_row[st] = (SR * st + rs < ROWS && r0 + SR * st + rs < N) ? (int)(r0 + SR * st + rs) : -1;
+    } else {
+        // listed rows: every thread reads its own stage rows straight from the list (the count arrives beside them)
+        const buf_rsrc r_list = make_rsrc(lab.rows, (int64_t)lab.cap * 4);
+        int lr[NSTG];
+#pragma unroll
+        for (int st = 0; st < NSTG; ++st)
+            lr[st] = buf_load1i(r_list, SR * st + rs < ROWS ? (base + SR * st + rs) * 4 : kBufOOB);
+        n_lab = lab.count[0];
+        if (base >= n_lab) {  // extra workgroup beyond the list: an empty partial
+            if (stats && !stats_exact)
+                for (int c = tid; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
+            return;
+        }
+#pragma unroll
+        for (int st = 0; st < NSTG; ++st) my_row[st] = (SR * st + rs < ROWS && base + SR * st + rs < n_lab) ? lr[st] : -1;
+    }
+    auto issue = [&](int st, float4 (&raw)[2]) __attribute__((always_inline)) {
+        const int r = my_row[st];
+        raw[0] = buf_load4(r_xa, r >= 0 ? (int)((r * lda + 4 * ga) * 4) : kBufOOB);
+        raw[1] = buf_load4(r_xb, r >= 0 ? (int)((r * ldb + 4 * ga) * 4) : kBufOOB);
+    };
+    float4 raw[3][2];  // the loads of three stages in flight (register sets by stage % 3)
+    issue(0, raw[0]);
+    issue(1, raw[1]);
+    issue(2, raw[2]);
+    GnCoefRegs CR;
+    const bool fold_here = pro.saved && (WG == 1 || tid < 4 * H);  // (wave-uniform)
+    if (fold_here && pro.src.acc) gn_fwd_coef_issue<H, 4 * H>(pro.src, CR);
+    // this wave's slice of the effective weight: 8 float4 per lane
+    const float4* img = reinterpret_cast<const float4*>(Wimg + (extra ? H * KT : 0));
+    float4 bw[KF4];
+#pragma unroll
+    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+    const float bias1 = bias[16 * w + j], bias0 = bias[H + 16 * w + j];
+    // row of slot `tid` (threads < ROWS) and its label byte (main tiles)
+    int slot_v = -1;
+    unsigned slot_mask = 0;
+    if (!extra) {
+        const int64_t r0 = (int64_t)blockIdx.x * ROWS;
+        const bool ok = tid < ROWS && r0 + tid < N;
+        slot_v = ok ? (int)(r0 + tid) : -1;
+        slot_mask = __builtin_amdgcn_raw_buffer_load_b8(r_mask, ok ? (int)(r0 + tid) : kBufOOB, 0, 0);
+    } else {
+        const buf_rsrc r_list = make_rsrc(lab.rows, (int64_t)lab.cap * 4);
+        const int v = buf_load1i(r_list, tid < ROWS ? (base + tid) * 4 : kBufOOB);
+        slot_v = (tid < ROWS && base + tid < n_lab) ? v : -1;
+    }
+    if (fold_here && pro.src.acc) {
+        gn_fwd_coef_issue_params<H>(pro.src, CR);
+        glass_pin(CR.gamma);
+        glass_pin(CR.beta);
+        glass_pin(CR.alpha);
+    }
+    float bias1p = bias1, bias0p = bias0;
+    glass_pin(bias1p);
+    glass_pin(bias0p);
+    glass_pin(slot_mask);
+    D_STAMP(1, 6);
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    // ---- first use of loaded values
+    const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
+    const float be = c1 * bias1p + c0 * bias0p;
+    if (fold_here) gn_fwd_coef_finish<H, 4 * H>(pro.src, pro.saved, N, CR, gn_coef_s);
+    if (tid < ROWS) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
+    D_STAMP(1, 1);
+    lds_barrier();  // coefficients + row table
+    const bool pro_on = pro.saved != nullptr;
+    const bool side_on = pro.side != nullptr && !extra;  // (the row's own tile writes the normalised operand)
+    // GraphNorm scale / shift of this thread's four columns (the same in every stage)
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pro_on) {
+        const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
+        const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
+        sc[0] = s4.x, sc[1] = s4.y, sc[2] = s4.z, sc[3] = s4.w;
+        sh[0] = h4.x, sh[1] = h4.y, sh[2] = h4.z, sh[3] = h4.w;
+    }
+    // prep: the prologue arithmetic of one float4 — branch-free, so that it can be scheduled BETWEEN the MFMAs of the
+    // previous stage (the matrix core runs a 16x16x4 for 32 cycles; a wave that issues its MFMAs back to back leaves its
+    // VALU idle meanwhile, and one that runs the prologue first leaves the matrix core idle)
+    auto prep = [&](int st, const float4& raw) __attribute__((always_inline)) -> float4 {
+        const int r = my_row[st];
+        float a[4] = {raw.x, raw.y, raw.z, raw.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = fmaf(a[k], sc[k], sh[k]) * ds[k];
+        return make_float4(a[0], a[1], a[2], a[3]);
+    };
+    auto commit = [&](int st, const float4& v, const float4& hraw) __attribute__((always_inline)) {
+        float* T = tile[st % 3];
+        const int r = my_row[st];
+        buf_store4(r_side, (pro_on && side_on && r >= 0) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
+        *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
+        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = hraw;
+    };
+    float ssum = 0.f, ssq = 0.f;  // this lane's column 16w + j over the rows 4q + r of every stage
+    // Software pipeline over THREE LDS buffers: while the MFMAs of stage s run on fragments already in registers, the
+    // fragments of stage s + 1 are read from LDS (its rows were committed during stage s - 1) and the rows of stage s + 2
+    // are committed — after a stage's barrier no wave waits for an LDS read before its first MFMA.
+    commit(0, prep(0, raw[0][0]), raw[0][1]);
+    if (3 < NSTG) issue(3, raw[0]);
+    commit(1, prep(1, raw[1][0]), raw[1][1]);
+    if (4 < NSTG) issue(4, raw[1]);
+    lds_barrier();
+    float4 a4[2][KF4];
+    {
+        const float* T = tile[0] + (16 * g + j) * RS + (KT / 4) * q;
+#pragma unroll
+        for (int tt = 0; tt < KF4; ++tt) a4[0][tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
+    }
+#pragma unroll
+    for (int st = 0; st < NSTG; ++st) {
+        if (st == 1) D_STAMP(1, 5);
+        if (st + 1 < NSTG) {  // the next stage's fragments: in flight under this stage's MFMAs
+            const float* Tn = tile[(st + 1) % 3] + (16 * g + j) * RS + (KT / 4) * q;
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) a4[(st + 1) & 1][tt] = *reinterpret_cast<const float4*>(Tn + 4 * tt);
+        }
+        int rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tt = 0; tt < KF4; tt += 2) {
+            const float4 xa0 = a4[st & 1][tt], xa1 = a4[st & 1][tt + 1];
+            const float x0[4] = {xa0.x, xa0.y, xa0.z, xa0.w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+            const float x1[4] = {xa1.x, xa1.y, xa1.z, xa1.w};
+            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+            }
+        }
+        if (st == 1) D_STAMP(1, 2);
+        if (st + 2 < NSTG) {
+            commit(st + 2, prep(st + 2, raw[(st + 2) % 3][0]), raw[(st + 2) % 3][1]);
+            if (st + 5 < NSTG) issue(st + 5, raw[(st + 2) % 3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
+            const float o = acc0[r] + acc1[r] + be;
+            buf_store1(r_out, live ? (int)((rv[r] * ldo + 16 * w + j) * 4) : kBufOOB, o);
+            ssum += live ? o : 0.f;
+            ssq += live ? o * o : 0.f;
+        }
+        if (st + 1 < NSTG) lds_barrier();
+    }
+    D_STAMP(1, 3);
+    if (stats == nullptr) return;
+    double s = (double)ssum, q2 = (double)ssq;
+    s += __shfl_xor(s, 16);
+    q2 += __shfl_xor(q2, 16);
+    s += __shfl_xor(s, 32);
+    q2 += __shfl_xor(q2, 32);
+    if (WG > 1) {  // one add per column and workgroup, as with one wave group: group 1 hands its sums over
+        if (g == 1 && q == 0) {
+            comb_s[16 * w + j] = s;
+            comb_s[H + 16 * w + j] = q2;
+        }
+        lds_barrier();
+        if (g == 1) return;
+        s += comb_s[16 * w + j];
+        q2 += comb_s[H + 16 * w + j];
+    }
+    if (q == 0) {
+        const int c = 16 * w + j;
+        if (stats_exact) {
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
+            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
+        } else {
+            stats[((size_t)blockIdx.x * 2) * H + c] = s;
+            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
+        }
+    }
+    D_STAMP(1, 4);
+}
+
 // ---- comb forward, third form: the second form with a RUN-TIME number of stages per workgroup ("tall" row tiles) ---------
 // The second form fixes 64 or 80 rows per workgroup.  Beyond 80 x 256 rows a launch then runs in several ROUNDS of
 // workgroups, each paying its own prologue (one memory round trip + the GraphNorm fold, ~3 us) and a drained pipeline: at
@@ -2910,6 +3137,13 @@ extern "C" int glass_comb_eff_fwd_supported(int64_t H) { return (H == 64 || (GLA
 struct CombFwdGeom {
     int rows_main, rows_extra, n_main, n_extra;
 };
+static bool comb_fwd_pf_on() {
+    static const bool on = [] {
+        const char* e = getenv("GLASS_COMB_FWD_PF");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
 static bool comb_fwd3_on() {
     static const bool on = [] {
         const char* e = getenv("GLASS_COMB_FWD3");
@@ -3053,6 +3287,15 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
         else if (dr) GLASS_CF2W(true, 4);
         else if (tall) GLASS_CF2W(false, 5);
         else GLASS_CF2W(false, 4);
+    } else if (GLASS_COMB_FWD_V2 && comb_fwd_pf_on()) {
+#define GLASS_CF2P(DR, NS)                                                                                                \
+    hipLaunchKernelGGL((comb_fwd_eff2p_kernel<64, DR, NS>), grid, dim3(256), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,  \
+                       bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
+        if (dr && tall) GLASS_CF2P(true, 5);
+        else if (dr) GLASS_CF2P(true, 4);
+        else if (tall) GLASS_CF2P(false, 5);
+        else GLASS_CF2P(false, 4);
+#undef GLASS_CF2P
     } else if (GLASS_COMB_FWD_V2) {
         if (dr && tall) GLASS_CF2(64, true, 5);
         else if (dr) GLASS_CF2(64, true, 4);
