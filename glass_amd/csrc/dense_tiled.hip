@@ -18,6 +18,7 @@
 // slot is a permutation chosen by the weight packing (tiled_col, dense_common.h): the forward pairs the f1 / f0
 // halves inside a wave, both kernels give a lane consecutive columns -> wide stores.
 #include "dense_common.h"
+#include "split_mma.h"
 
 #include <type_traits>
 
@@ -50,7 +51,6 @@ bool tiled_eff_dgrad_shape(int64_t H, int64_t n_out) { return tiled_shape_ok(H) 
 bool tiled_eff_fwd_shape(int64_t H, int64_t K) { return (H == 256 || H == 512) && K == 2 * H; }
 int tiled_rows(int64_t H) { return H == 128 ? 64 : 128; }
 
-__device__ __forceinline__ float f4e(const float4& v, int e) { return e == 0 ? v.x : e == 1 ? v.y : e == 2 ? v.z : v.w; }
 
 // acc[rb][cb] += A(rows wm*BM/2 + rb*32 ..) . B(slots wn*BN/2 + cb*32 ..) over the 16 k of one stage
 template <int BM, int BN>
@@ -72,6 +72,33 @@ __device__ __forceinline__ void tile_mma(f32x16 (&acc)[BM / 64][BN / 64], const 
 #pragma unroll
                 for (int cb = 0; cb < TL::CB; ++cb)
                     acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4e(a[rb], e), f4e(b[cb], e), acc[rb][cb], 0, 0, 0);
+    }
+}
+
+// Stage geometry of either product form (S3: the operands lie in LDS as bf16 pieces, split_mma.h), float4 units; NA = A images
+// per stage (2 in the SPLIT data gradient)
+template <int BM, int BN, bool S3, int NA = 1>
+struct StageGeom {
+    static constexpr int kA = S3 ? SplitImg<BM>::kUnits : Tile<BM, BN>::kAImg;
+    static constexpr int kB = S3 ? SplitImg<BN>::kUnits : Tile<BM, BN>::kBImg;
+    static constexpr int kStage = NA * kA + kB;
+    static constexpr size_t kLds = 2 * (size_t)kStage * sizeof(float4);
+};
+
+// the same tile product from split operand images: 3 + 3 ds_read_b128 per (row block, column block), 6 MFMAs of 16 k each
+template <int BM, int BN>
+__device__ __forceinline__ void tile_mma_s(f32x16 (&acc)[BM / 64][BN / 64], const float4* __restrict__ A,
+                                           const float4* __restrict__ B, int j, int h, int wm, int wn) {
+    constexpr int RB = BM / 64, CB = BN / 64;
+    uint4 a[RB][3];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) SplitImg<BM>::frag(A, wm * (BM / 2) + rb * 32 + j, h, a[rb]);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        uint4 b[3];
+        SplitImg<BN>::frag(B, wn * (BN / 2) + cb * 32 + j, h, b);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) split_mma(acc[rb][cb], a[rb], b);
     }
 }
 
@@ -99,6 +126,12 @@ struct BStage {
 #pragma unroll
         for (int i = 0; i < PER; ++i) B[threadIdx.x + kTThreads * i] = v[i];
     }
+    // split form, 256 slots: this thread holds all 16 k of slot threadIdx.x (k-quad i in v[i])
+    __device__ __forceinline__ void commit_split(float4* __restrict__ B) const {
+        static_assert(PER == 4, "256-slot column tiles");
+        SplitImg<256>::put8(B, threadIdx.x, 0, v[0], v[1]);
+        SplitImg<256>::put8(B, threadIdx.x, 1, v[2], v[3]);
+    }
 };
 
 // ---- forward ----------------------------------------------------------------------------------------------------
@@ -107,8 +140,8 @@ struct BStage {
 // [g || x_] @ W_unl^T + b_unl over 256 output columns per column tile — half the column tiles of the two-weight form: the
 // blocks of the upper half of the column tiles leave at once.  A tile with up to 3 labeled rows runs the same product for
 // all its rows and corrects those rows afterwards; beyond that it takes the two-weight path.
-template <int H, bool COMB, int BM, bool EFF>
-__global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
+template <int H, bool COMB, int BM, bool EFF, bool S3>
+__global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 4 : 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                 const float* __restrict__ xb, int64_t ldb,
                                                                 const float* __restrict__ Wimg,
                                                                 const float* __restrict__ bias,
@@ -118,6 +151,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
                                                                 double* __restrict__ stats, GnPrologue pro,
                                                                 int n_rowtiles) {
     using TL = Tile<BM, 256>;  // 256 column slots = 128 columns of the f1 half + the same 128 of the f0 half
+    using SG = StageGeom<BM, 256, S3>;
     constexpr int KT = COMB ? 2 * H : H, NKS = KT / kTK, NCT = H / 128, RB = TL::RB, AP = TL::kAPer;
     extern __shared__ float4 smem[];
     int rt, ct;
@@ -165,7 +199,7 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
     // label's weight back afterwards (correction below).  fix[] (LDS behind the stage buffers): [1..4] labeled rows per
     // wave, [8 .. 8+BM) correction slot of a tile row or -1, then the slots' rows.
     constexpr int kMaxFix = 3;  // a correction costs about a third of the second product of the two-weight path
-    int* fix = reinterpret_cast<int*>(smem + 2 * TL::kStageVecs);
+    int* fix = reinterpret_cast<int*>(smem + 2 * SG::kStage);
     bool pure = false;  // workgroup-uniform
     int n_fix = 0;
     if (EFF && act == GLASS_ACT_NONE && T == nullptr) {
@@ -224,9 +258,11 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
                 v = make_float4(o[0], o[1], o[2], o[3]);
                 if (side_writer) *reinterpret_cast<float4*>(pro.side + r * pro.lds + k) = v;
             }
-            stage[skq[i] * TL::kAPlane + srow[i]] = v;
+            if constexpr (S3) SplitImg<BM>::put4(stage, srow[i], skq[i], v);
+            else stage[skq[i] * TL::kAPlane + srow[i]] = v;
         }
-        bs.commit(stage + TL::kAImg);
+        if constexpr (S3) bs.commit_split(stage + SG::kA);
+        else bs.commit(stage + SG::kA);
     };
 
     f32x16 acc[RB][4];
@@ -241,10 +277,11 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
     commit(0, smem);
     __syncthreads();
     for (int ks = 0; ks < NKS; ++ks) {
-        float4* cur = smem + (ks & 1) * TL::kStageVecs;
-        float4* nxt = smem + ((ks + 1) & 1) * TL::kStageVecs;
+        float4* cur = smem + (ks & 1) * SG::kStage;
+        float4* nxt = smem + ((ks + 1) & 1) * SG::kStage;
         if (ks + 1 < NKS) issue(ks + 1);  // in flight across this stage's MFMAs
-        tile_mma<BM, 256>(acc, cur, cur + TL::kAImg, j, h, wm, wn);
+        if constexpr (S3) tile_mma_s<BM, 256>(acc, cur, cur + SG::kA, j, h, wm, wn);
+        else tile_mma<BM, 256>(acc, cur, cur + SG::kA, j, h, wm, wn);
         if (ks + 1 < NKS) commit(ks + 1, nxt);  // the other buffer: last read in stage ks - 1, before the previous barrier
         __syncthreads();
     }
@@ -400,8 +437,8 @@ __global__ __launch_bounds__(kTThreads, BM == 64 ? 4 : 2) void tiled_fwd_kernel(
 // (1-z) W1 + z W0 over K = H (kLayoutTiledPlainEff).  dZ has no activation factor for the comb pair, so an unlabeled row of
 // the product is dc @ W_unl — half the K loop.  A tile runs that for ALL its rows and then corrects its (few) labeled rows
 // with a thread-per-column dot product; only tiles with more than 7 labeled rows fall back to the two-term product.
-template <int H, int NOUT, int BM, int BN, bool SPLIT, bool EFF>
-__global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
+template <int H, int NOUT, int BM, int BN, bool SPLIT, bool EFF, bool S3>
+__global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2))) void tiled_dgrad_kernel(const float* __restrict__ dsrc, int64_t ldd,
                                                                   const float* __restrict__ T, int64_t ldt,
                                                                   const uint8_t* __restrict__ mask, float zr, float omz,
                                                                   int act, const float* __restrict__ WTimg,
@@ -412,7 +449,9 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
     using TL = Tile<BM, BN>;
     constexpr int KT = SPLIT ? H : 2 * H, NKS = KT / kTK, NCT = SPLIT ? 1 : NOUT / BN, RB = TL::RB, CB = TL::CB, AP = TL::kAPer;
     constexpr int NA = SPLIT ? 2 : 1;                          // A images per stage
-    constexpr int kStage = NA * TL::kAImg + TL::kBImg;         // float4 per stage
+    using SG = StageGeom<BM, BN, S3, NA>;
+    constexpr int kStage = SG::kStage;                         // float4 per stage
+    static_assert(!S3 || BN == 256, "split operand images: 256-slot column tiles");
     static_assert(CB == 4 && (SPLIT ? (NOUT == H && 2 * NOUT == BN) : NOUT % BN == 0),
                   "output width must be a multiple of the 256-slot column tile (SPLIT: exactly half of one)");
     extern __shared__ float4 smem[];
@@ -480,17 +519,20 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
             if (act != GLASS_ACT_NONE) {
                 v.x *= act_grad(act, tv[i].x); v.y *= act_grad(act, tv[i].y); v.z *= act_grad(act, tv[i].z); v.w *= act_grad(act, tv[i].w);
             }
-            stage[skq[i] * TL::kAPlane + srow[i]] = v;
+            if constexpr (S3) SplitImg<BM>::put4(stage, srow[i], skq[i], v);
+            else stage[skq[i] * TL::kAPlane + srow[i]] = v;
             if (SPLIT) {  // the f0 half of the same dsrc columns: the other label coefficient, the other half of T
                 const float c0 = sok[i] ? (slab[i] ? omz : zr) : 0.f;
                 float4 u = make_float4(dv[i].x * c0, dv[i].y * c0, dv[i].z * c0, dv[i].w * c0);
                 if (act != GLASS_ACT_NONE) {
                     u.x *= act_grad(act, tw[i].x); u.y *= act_grad(act, tw[i].y); u.z *= act_grad(act, tw[i].z); u.w *= act_grad(act, tw[i].w);
                 }
-                stage[TL::kAImg + skq[i] * TL::kAPlane + srow[i]] = u;
+                if constexpr (S3) SplitImg<BM>::put4(stage + SG::kA, srow[i], skq[i], u);
+                else stage[TL::kAImg + skq[i] * TL::kAPlane + srow[i]] = u;
             }
         }
-        bs.commit(stage + NA * TL::kAImg);
+        if constexpr (S3) bs.commit_split(stage + NA * SG::kA);
+        else bs.commit(stage + NA * SG::kA);
     };
 
     f32x16 acc[RB][CB];
@@ -511,7 +553,8 @@ __global__ __launch_bounds__(kTThreads, SPLIT ? 3 : (BM == 64 ? 4 : 2)) void til
             float4* cur = smem + (ks & 1) * kStage;
             float4* nxt = smem + ((ks + 1) & 1) * kStage;
             if (ks + 1 < n) issue(ks + 1);
-            tile_mma<BM, BN>(acc, cur + (SPLIT ? wn * TL::kAImg : 0), cur + NA * TL::kAImg, j, h, wm, wn);
+            if constexpr (S3) tile_mma_s<BM, BN>(acc, cur + (SPLIT ? wn * SG::kA : 0), cur + NA * SG::kA, j, h, wm, wn);
+            else tile_mma<BM, BN>(acc, cur + (SPLIT ? wn * SG::kA : 0), cur + NA * SG::kA, j, h, wm, wn);
             if (ks + 1 < n) commit(ks + 1, nxt);
             __syncthreads();
         }
@@ -662,58 +705,88 @@ static void allow_tiled_lds(K kernel, size_t bytes) {
     if (bytes > 64 * 1024) (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Product form of the tiled kernels: six bf16 partial products per fp32 product (split_mma.h; default) or the f32-input
+// matrix-core instruction (GLASS_DENSE_SPLIT=0: 1/16 of the bf16 rate — the reference point of the accuracy and A/B runs).
+bool tiled_split_products() {
+    static const bool on = [] {
+        const char* e = getenv("GLASS_DENSE_SPLIT");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
+template <int HH, int BM, bool S3>
+static void tiled_fwd_launch(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
+                             const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out,
+                             int64_t ldo, int64_t N, double* stats, const GnPrologue& pro, hipStream_t st) {
+    const bool comb = xb != nullptr;
+    const int64_t n_rt = ceil_div(N, BM);
+    const dim3 grid(tiled_grid(n_rt, HH / 128));
+    // + the labeled-row bookkeeping of the effective-weight path (hidden 256 / 512, comb pair)
+    const size_t lds = StageGeom<BM, 256, S3>::kLds + ((comb && HH >= 256) ? 1024 : 0);
+    if (comb) {
+        constexpr bool kEff = HH >= 256;  // tiled_eff_fwd_shape: the image has the effective-weight appendix
+        allow_tiled_lds(tiled_fwd_kernel<HH, true, BM, kEff, S3>, lds);
+        hipLaunchKernelGGL((tiled_fwd_kernel<HH, true, BM, kEff, S3>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,
+                           bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);
+    } else {
+        allow_tiled_lds(tiled_fwd_kernel<HH, false, BM, false, S3>, lds);
+        hipLaunchKernelGGL((tiled_fwd_kernel<HH, false, BM, false, S3>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,
+                           bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);
+    }
+}
+
 int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
                      const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,
                      int64_t N, int64_t H, double* stats, const GnPrologue& pro, hipStream_t st) {
-    const bool comb = xb != nullptr;
 #define GLASS_TFWD(HH, BM)                                                                                           \
     if (H == HH) {                                                                                                   \
-        const int64_t n_rt = ceil_div(N, BM);                                                                        \
-        const dim3 grid(tiled_grid(n_rt, HH / 128));                                                                 \
-        /* + the labeled-row bookkeeping of the effective-weight path (hidden 256 / 512, comb pair) */             \
-        const size_t lds = Tile<BM, 256>::kLds + ((comb && HH >= 256) ? 1024 : 0);                                   \
-        if (comb) {                                                                                                  \
-            constexpr bool kEff = HH >= 256; /* tiled_eff_fwd_shape: the image has the effective-weight appendix */  \
-            allow_tiled_lds(tiled_fwd_kernel<HH, true, BM, kEff>, lds);                                              \
-            hipLaunchKernelGGL((tiled_fwd_kernel<HH, true, BM, kEff>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg, \
-                               bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
-        } else {                                                                                                     \
-            allow_tiled_lds(tiled_fwd_kernel<HH, false, BM, false>, lds);                                            \
-            hipLaunchKernelGGL((tiled_fwd_kernel<HH, false, BM, false>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg, \
-                               bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);                \
-        }                                                                                                            \
+        if (tiled_split_products())                                                                                  \
+            tiled_fwd_launch<HH, BM, true>(xa, lda, xb, ldb, Wimg, bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, st); \
+        else                                                                                                         \
+            tiled_fwd_launch<HH, BM, false>(xa, lda, xb, ldb, Wimg, bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, st); \
     }
     GLASS_TFWD(128, 64) GLASS_TFWD(256, 128) GLASS_TFWD(512, 128)
 #undef GLASS_TFWD
     return launch_status("glass_dual_linear_fwd_f32 (tiled)");
 }
 
+template <int HH, int NOUT, int BM, int BN, bool SPLIT, bool S3>
+static void tiled_dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, float zr,
+                               float omz, int act, const float* WTimg, const float* addend, int64_t ldadd, const Drop& drop,
+                               const uint64_t* rng_state, float* out, int64_t ldo, int64_t N, const GnBwdStats& gs,
+                               hipStream_t st) {
+    const int64_t n_rt = ceil_div(N, BM);
+    constexpr bool kEff = !SPLIT && NOUT == 2 * HH;  // tiled_eff_dgrad_shape
+    constexpr int NCT = SPLIT ? 1 : NOUT / BN;
+    const size_t lds = StageGeom<BM, BN, S3, SPLIT ? 2 : 1>::kLds + (kEff ? 1024 : 0);  // + the labeled-row bookkeeping
+    allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, SPLIT, kEff, S3>, lds);
+    hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, SPLIT, kEff, S3>), dim3(tiled_grid(n_rt, NCT)), dim3(kTThreads), lds,
+                       st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, gs,
+                       (int)n_rt);
+}
+
 int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, float zr,
                        float omz, int act, const float* WTimg, int64_t n_out, const float* addend, int64_t ldadd,
                        const Drop& drop, const uint64_t* rng_state, float* out, int64_t ldo, int64_t N, int64_t H,
                        const GnBwdStats& gs, hipStream_t st) {
-#define GLASS_TDG1(HH, NOUT, BM, BN)                                                                                 \
+#define GLASS_TDG1(HH, NOUT, BM, BN, SPLIT)                                                                           \
     {                                                                                                                \
-        const int64_t n_rt = ceil_div(N, BM);                                                                        \
-        constexpr bool kEff = NOUT == 2 * HH; /* tiled_eff_dgrad_shape */                                            \
-        const size_t lds = Tile<BM, BN>::kLds + (kEff ? 1024 : 0); /* + the labeled-row bookkeeping */               \
-        allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>, lds);                                     \
-        hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, false, kEff>), dim3(tiled_grid(n_rt, NOUT / BN)), dim3(kTThreads), lds, \
-                           st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, \
-                           gs, (int)n_rt);                                                                           \
+        if (tiled_split_products())                                                                                  \
+            tiled_dgrad_launch<HH, NOUT, BM, BN, SPLIT, true>(dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, \
+                                                              rng_state, out, ldo, N, gs, st);                       \
+        else                                                                                                         \
+            tiled_dgrad_launch<HH, NOUT, BM, BN, SPLIT, false>(dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, \
+                                                               rng_state, out, ldo, N, gs, st);                      \
     }
     if (H == 128 && n_out == H) {  // trans pair: the two terms of the product side by side in one 256-slot tile
-        const int64_t n_rt = ceil_div(N, 64);
-        const size_t lds = 2 * (size_t)(2 * Tile<64, 256>::kAImg + Tile<64, 256>::kBImg) * sizeof(float4);
-        hipLaunchKernelGGL((tiled_dgrad_kernel<128, 128, 64, 256, true, false>), dim3(tiled_grid(n_rt, 1)), dim3(kTThreads), lds, st,
-                           dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, gs,
-                           (int)n_rt);
+        GLASS_TDG1(128, 128, 64, 256, true)
     } else if (H == 128) {
-        GLASS_TDG1(128, 256, 64, 256)
+        GLASS_TDG1(128, 256, 64, 256, false)
     } else if (H == 256) {
-        if (n_out == H) GLASS_TDG1(256, 256, 128, 256) else GLASS_TDG1(256, 512, 128, 256)
+        if (n_out == H) GLASS_TDG1(256, 256, 128, 256, false) else GLASS_TDG1(256, 512, 128, 256, false)
     } else if (H == 512) {
-        if (n_out == H) GLASS_TDG1(512, 512, 128, 256) else GLASS_TDG1(512, 1024, 128, 256)
+        if (n_out == H) GLASS_TDG1(512, 512, 128, 256, false) else GLASS_TDG1(512, 1024, 128, 256, false)
     }
 #undef GLASS_TDG1
     return launch_status("glass_dual_linear_dgrad_f32 (tiled)");

@@ -12,6 +12,7 @@
 // Split over row slabs; slab partials are plain [128][256] tiles summed in slab order by the reduce kernel
 // (deterministic).  fp32 MFMA = exact k-ordered fmaf chain.
 #include "wgrad_common.h"
+#include "split_mma.h"
 
 namespace glass {
 
@@ -20,6 +21,13 @@ namespace glass {
 constexpr int kWO = 128, kWI = 256, kWK = 16, kWThreads = 256;
 constexpr int kWStage = kWK * (kWO + kWI);  // floats per stage: 6 144 = 24 KiB
 constexpr int kWTile = kWO * kWI;
+// Split products (split_mma.h): a stage holds the two operands as bf16 pieces TRANSPOSED — the MFMA's k is the node row, so a
+// fragment is 8 consecutive node rows of one column: [piece][h][slot] 16-byte units.  The staging thread therefore takes
+// consecutive node rows of its column quad (2 of the A tile, 4 of the B tile) and writes one packed word / pair per column
+// and piece; slot <-> column is a permutation chosen so that those writes run over consecutive units: A slot 32 e + q <->
+// output 4 q + e, B slot 128 (q >> 5) + 32 e + (q & 31) <-> input 4 q + e (q = the thread's column quad, e = 0..3).
+constexpr int kWStageS = 4 * (SplitImg<kWO>::kUnits + SplitImg<kWI>::kUnits);  // floats per stage: 9 216 = 36 KiB
+bool tiled_split_products();  // dense_tiled.hip
 // Mode header the partial kernel leaves behind the bias partials for the reduce kernel (which is launched later, by
 // glass_linear_wgrad_reduce_batch_f32, from (N, O, I) alone): [0] = 1.0f when the partials are in effective-weight form,
 // [1] = z_ratio.
@@ -53,7 +61,7 @@ struct StageCtx {
     bool eff, lab;  // effective-weight mode; labeled-rows tile of it
 };
 
-template <bool SYNTH>
+template <bool SYNTH, bool S3>
 struct WStageRegs {
     float4 ga[2], ta[2], xb[4];
     int mk[2];
@@ -62,7 +70,7 @@ struct WStageRegs {
         const int64_t base = c.r0 + (int64_t)step * kWK;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int64_t n = base + ((c.tid + kWThreads * a) >> 5);
+            const int64_t n = base + (S3 ? 2 * (c.tid >> 5) + a : (c.tid + kWThreads * a) >> 5);
             alive[a] = n < c.r1;
             const int64_t nn = alive[a] ? n : c.r1 - 1;  // clamped: loads never wait on a predicate, zeroed at use
             if (!SYNTH) {
@@ -75,12 +83,13 @@ struct WStageRegs {
         }
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-            const int64_t n = base + ((c.tid + kWThreads * b) >> 6);
+            const int64_t n = base + (S3 ? 4 * (c.tid >> 6) + b : (c.tid + kWThreads * b) >> 6);
             const int64_t nn = n < c.r1 ? n : c.r1 - 1;  // rows past the slab: the A operand is zero there
             xb[b] = *reinterpret_cast<const float4*>(c.xsrc + nn * c.xld + c.xcol);
         }
     }
     __device__ __forceinline__ void commit(const StageCtx& c, const WgradSynth& sy, float* stage, float4& bsum) const {
+        float4 gv[2];
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
             float4 g = ga[a];
@@ -93,10 +102,39 @@ struct WStageRegs {
             }
             if (!alive[a]) g = make_float4(0.f, 0.f, 0.f, 0.f);
             bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
-            reinterpret_cast<float4*>(stage)[c.tid + kWThreads * a] = g;
+            if (S3) gv[a] = g;
+            else reinterpret_cast<float4*>(stage)[c.tid + kWThreads * a] = g;
         }
+        if (S3) {
+            // A: node rows 2 g2, 2 g2 + 1 (g2 = tid >> 5) of column quad qa = tid & 31: one packed pair per column and piece
+            const int qa = c.tid & 31, g2 = c.tid >> 5;
+            unsigned* A = reinterpret_cast<unsigned*>(stage);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) reinterpret_cast<float4*>(stage + kWK * kWO)[c.tid + kWThreads * b] = xb[b];
+            for (int e = 0; e < 4; ++e) {
+                unsigned hi, mid, lo;
+                split2(f4e(gv[0], e), f4e(gv[1], e), hi, mid, lo);
+                const int u = (((g2 >> 2) * kWO + e * 32 + qa) << 2) + (g2 & 3);
+                A[u] = hi;
+                A[4 * SplitImg<kWO>::kPlane + u] = mid;
+                A[8 * SplitImg<kWO>::kPlane + u] = lo;
+            }
+            // B: node rows 4 g .. 4 g + 3 (g = tid >> 6) of column quad q = tid & 63: 8 bytes per column and piece
+            const int q = c.tid & 63, g = c.tid >> 6;
+            uint2* B = reinterpret_cast<uint2*>(stage + 4 * SplitImg<kWO>::kUnits);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint2 hi, mid, lo;
+                split2(f4e(xb[0], e), f4e(xb[1], e), hi.x, mid.x, lo.x);
+                split2(f4e(xb[2], e), f4e(xb[3], e), hi.y, mid.y, lo.y);
+                const int u = (((g >> 1) * kWI + (q >> 5) * 128 + e * 32 + (q & 31)) << 1) + (g & 1);
+                B[u] = hi;
+                B[2 * SplitImg<kWI>::kPlane + u] = mid;
+                B[4 * SplitImg<kWI>::kPlane + u] = lo;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) reinterpret_cast<float4*>(stage + kWK * kWO)[c.tid + kWThreads * b] = xb[b];
+        }
     }
 };
 
@@ -106,7 +144,7 @@ struct WStageRegs {
 // L = the same sum over the LABELED rows only — stages of 16 rows without a labeled row are skipped there, and with
 // B*Smax labeled nodes among N almost all are — and the reduce kernel forms  dW1 = (1-z) S + (2z-1) L,  dW0 = z S - (2z-1) L
 // (bias likewise).  Half the matrix work of the two-product form.
-template <bool SYNTH, bool EFF>
+template <bool SYNTH, bool EFF, bool S3>
 __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* __restrict__ G, int64_t ldg,
                                                                   const float* __restrict__ X, int64_t ldx, int64_t N,
                                                                   int rows_per_slab, float* __restrict__ part_w,
@@ -139,7 +177,8 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
         xld = sy.ldx2;
         xcol = b_col - sy.H;
     }
-    WStageRegs<SYNTH> sr;
+    constexpr int kStage = S3 ? kWStageS : kWStage;  // floats per stage
+    WStageRegs<SYNTH, S3> sr;
     const StageCtx cx{G, ldg, xsrc, xld, xcol, a_col, a_first, r0, r1, tid, EFF, lab_tile};
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -152,6 +191,21 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
             for (int k = 0; k < 16; ++k) acc[rb][cb][k] = 0.f;
 
     auto stage_mma = [&](const float* cur) __attribute__((always_inline)) {
+        if constexpr (S3) {
+            const float4* Ai = reinterpret_cast<const float4*>(cur);
+            const float4* Bi = Ai + SplitImg<kWO>::kUnits;
+            uint4 a[2][3];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) SplitImg<kWO>::frag(Ai, wm * 64 + rb * 32 + j, h, a[rb]);
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                uint4 b[3];
+                SplitImg<kWI>::frag(Bi, wn * 128 + cb * 32 + j, h, b);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) split_mma(acc[rb][cb], a[rb], b);
+            }
+            return;
+        }
         const float* A = cur + wm * 64 + j;
         const float* B = cur + kWK * kWO + wn * 128 + j;
 #pragma unroll
@@ -172,7 +226,7 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
     if (lab_tile) {
         // labeled rows only: one flag per 16-row stage first (LDS, behind the two stage buffers), then only the flagged
         // stages are loaded and multiplied — few, so without the software pipeline
-        int* flag = reinterpret_cast<int*>(wsm + 2 * kWStage);
+        int* flag = reinterpret_cast<int*>(wsm + 2 * kStage);
         for (int st0 = 0; st0 < n_steps; st0 += kWThreads) {
             const int stp = st0 + tid;
             if (stp < n_steps) {
@@ -201,8 +255,8 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
         sr.commit(cx, sy, wsm, bsum);
         __syncthreads();
         for (int step = 0; step < n_steps; ++step) {
-            const float* cur = wsm + (step & 1) * kWStage;
-            float* nxt = wsm + ((step + 1) & 1) * kWStage;
+            const float* cur = wsm + (step & 1) * kStage;
+            float* nxt = wsm + ((step + 1) & 1) * kStage;
             if (step + 1 < n_steps) sr.issue(cx, sy, step + 1);
             stage_mma(cur);
             if (step + 1 < n_steps) sr.commit(cx, sy, nxt, bsum);
@@ -217,9 +271,15 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
     for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            const int o = wm * 64 + rb * 32 + 8 * (k >> 2) + 4 * h + (k & 3);
+            if constexpr (S3) {  // slot -> column as the staging laid them out: four consecutive inputs per lane
+                const int o = 4 * (8 * (k >> 2) + 4 * h + (k & 3)) + 2 * wm + rb;
+                *reinterpret_cast<float4*>(pw + o * kWI + 4 * (32 * wn + j)) =
+                    make_float4(acc[rb][0][k], acc[rb][1][k], acc[rb][2][k], acc[rb][3][k]);
+            } else {
+                const int o = wm * 64 + rb * 32 + 8 * (k >> 2) + 4 * h + (k & 3);
 #pragma unroll
-            for (int cb = 0; cb < 4; ++cb) pw[o * kWI + wn * 128 + cb * 32 + j] = acc[rb][cb][k];
+                for (int cb = 0; cb < 4; ++cb) pw[o * kWI + wn * 128 + cb * 32 + j] = acc[rb][cb][k];
+            }
         }
     if (blockIdx.y == 0 && part_b) {
         // 8 threads (tid & 31 equal) hold partial bias sums of the same 4 outputs: combine through LDS in thread order
@@ -303,17 +363,22 @@ void launch_tiled_wgrad_partial(const float* X, int64_t ldx, int64_t N, int64_t 
     float* header = header_of(part_w + g.part_w_floats, g);  // (the bias partials always sit behind the weight partials)
     // comb pair (virtual concatenation as the input, no activation factor, both halves of the output present)
     const bool eff = sy.X2 != nullptr && sy.act == GLASS_ACT_NONE && I == O && g.nz % 2 == 0 && O == 2 * (int64_t)sy.H;
-    if (eff) {
-        const size_t lds = 2 * (size_t)kWStage * sizeof(float) + (size_t)ceil_div((int64_t)g.rows_per_slab, (int64_t)kWK) * sizeof(int);
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)tiled_wgrad_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((tiled_wgrad_kernel<true, true>), grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N,
-                           g.rows_per_slab, part_w, part_b, header, sy);
-    } else {
-        const size_t lds = 2 * (size_t)kWStage * sizeof(float);
-        hipLaunchKernelGGL((tiled_wgrad_kernel<true, false>), grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N,
-                           g.rows_per_slab, part_w, part_b, header, sy);
+    const bool s3 = tiled_split_products();
+    const size_t stage_bytes = (size_t)(s3 ? kWStageS : kWStage) * sizeof(float);
+    const size_t lds = 2 * stage_bytes + (eff ? (size_t)ceil_div((int64_t)g.rows_per_slab, (int64_t)kWK) * sizeof(int) : 0);
+#define GLASS_TWG(EFFV, S3V)                                                                                          \
+    {                                                                                                                \
+        if (lds > 64 * 1024)                                                                                         \
+            (void)hipFuncSetAttribute((const void*)tiled_wgrad_kernel<true, EFFV, S3V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((tiled_wgrad_kernel<true, EFFV, S3V>), grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N,  \
+                           g.rows_per_slab, part_w, part_b, header, sy);                                             \
     }
+    if (eff) {
+        if (s3) GLASS_TWG(true, true) else GLASS_TWG(true, false)
+    } else {
+        if (s3) GLASS_TWG(false, true) else GLASS_TWG(false, false)
+    }
+#undef GLASS_TWG
 }
 
 void launch_tiled_wgrad_reduce(const float* part_w, const float* part_b, int64_t N, int64_t O, int64_t I, float* dW,
