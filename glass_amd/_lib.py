@@ -103,6 +103,8 @@ SIGNATURES = {
     "glass_pair_pool_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P]),
     "glass_pair_pool_bwd_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P, _P]),
     "glass_dense_caps_query": (c_int, [_I, _P]),
+    "glass_dense_product_form": (c_int, []),
+    "glass_dense_product_form_set": (c_int, [c_int]),
     "glass_pair_head_supported": (c_int, [_I]),
     "glass_pair_head_ws_bytes": (c_int64, [_I, _I]),
     "glass_pair_head_fwd_f32": (c_int, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, c_float, _P, c_uint64, _P, _P, _P, _P, _P, _P]),
@@ -165,7 +167,8 @@ class DenseCaps(ctypes.Structure):
     """include/glass_hip.h: glass_dense_caps — one capability record per hidden width."""
     _fields_ = [(n, ctypes.c_int32) for n in ("family", "weight_layout", "fwd_layout_trans", "fwd_layout_comb", "dgrad_layout_trans",
                                               "dgrad_layout_comb", "stat_rows", "fwd_gather", "gn_exact", "gn_exact_fwd", "comb_eff",
-                                              "comb_eff_fwd", "comb_eff_fwd_layout", "comb_eff_dgrad_layout2", "pair_head", "act_codes")]
+                                              "comb_eff_fwd", "comb_eff_fwd_layout", "comb_eff_dgrad_layout2", "pair_head", "act_codes",
+                                              "product_form")]
 
 
 _caps = {}
@@ -178,6 +181,7 @@ def dense_caps(H):
         c = DenseCaps()
         check(load().glass_dense_caps_query(int(H), ctypes.addressof(c)), "glass_dense_caps_query")
         _caps[int(H)] = c
+    c.product_form = load().glass_dense_product_form() if c.family == 3 else 0  # (a process-wide switch, not a constant)
     return c
 
 

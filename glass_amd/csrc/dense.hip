@@ -2837,6 +2837,7 @@ extern "C" int glass_dense_caps_query(int64_t H, glass_dense_caps* out) {
         c.stat_rows = (int32_t)glass_dual_linear_stat_rows(H);
         c.fwd_gather = glass_dual_linear_fwd_gather_supported(H);
         c.act_codes = (1 << GLASS_ACT_ELU) | (1 << GLASS_ACT_RELU);
+        c.product_form = (c.family == 3 && tiled_split_products()) ? 1 : 0;
     }
     c.gn_exact = glass_gn_exact_supported(H);
     c.gn_exact_fwd = glass_gn_exact_fwd_supported(H);
@@ -2846,6 +2847,14 @@ extern "C" int glass_dense_caps_query(int64_t H, glass_dense_caps* out) {
     c.comb_eff_dgrad_layout2 = c.comb_eff ? glass_comb_eff_dgrad_layout2(H) : 0;
     c.pair_head = glass_pair_head_supported(H);
     *out = c;
+    return 0;
+}
+// How the LDS-tiled family (hidden 128 / 256 / 512) forms its fp32 products: 1 = six bf16 partial products of 3-way split
+// operands (split_mma.h: as accurate as the f32-input instruction, 6/16 of its matrix-core cycles), 0 = v_mfma_f32_32x32x2_f32.
+extern "C" int glass_dense_product_form(void) { return tiled_split_products() ? 1 : 0; }
+extern "C" int glass_dense_product_form_set(int form) {
+    GLASS_REQUIRE(form == 0 || form == 1, "dense_product_form_set: 0 (f32-input MFMA) or 1 (split bf16 products)");
+    tiled_split_products_set(form);
     return 0;
 }
 // glass_dual_linear_fwd_f32 with xa_index (the trans pair of layer 0 gathers its operand rows from the embedding table)

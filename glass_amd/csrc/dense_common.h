@@ -96,6 +96,8 @@ bool tiled_eff_fwd_shape(int64_t H, int64_t K);        // ... whose forward read
 
 // dense_tiled.hip
 bool tiled_shape_ok(int64_t H);
+bool tiled_split_products();          // fp32 products as six bf16 partial products (split_mma.h) or the f32-input MFMA
+int tiled_split_products_set(int on);  // -> previous; on < 0: query only
 int tiled_rows(int64_t H);  // rows per workgroup = rows per statistics partial of the tiled kernels (64 at hidden 128, else 128)
 int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
                      const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,

@@ -20,6 +20,7 @@
 #include "dense_common.h"
 #include "split_mma.h"
 
+#include <atomic>
 #include <type_traits>
 
 namespace glass {
@@ -141,7 +142,7 @@ struct BStage {
 // blocks of the upper half of the column tiles leave at once.  A tile with up to 3 labeled rows runs the same product for
 // all its rows and corrects those rows afterwards; beyond that it takes the two-weight path.
 template <int H, bool COMB, int BM, bool EFF, bool S3>
-__global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 4 : 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
+__global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fwd_kernel(const float* __restrict__ xa, int64_t lda,
                                                                 const float* __restrict__ xb, int64_t ldb,
                                                                 const float* __restrict__ Wimg,
                                                                 const float* __restrict__ bias,
@@ -252,7 +253,7 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 4 : 2) void tiled_fw
                               fmaf(v.w, asc[i].w, ash[i].w)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = act_exact(pro.act, o[e]);
+                    o[e] = act_fast(pro.act, o[e]);
                     o[e] *= ds[e];
                 }
                 v = make_float4(o[0], o[1], o[2], o[3]);
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 4 : 2) void tiled_fw
                         float o[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            o[e] = act_exact(pro.act, o[e]);
+                            o[e] = act_fast(pro.act, o[e]);
                             o[e] *= ds[e];
                         }
                         v = make_float4(o[0], o[1], o[2], o[3]);
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
     // the K loop with a compile-time trip count (a run-time bound sent the staging registers to scratch memory)
     auto k_loop = [&](auto n_c) __attribute__((always_inline)) {
         constexpr int n = decltype(n_c)::value;
-        issue(0);
+            issue(0);
         commit(0, smem);
         __syncthreads();
         for (int ks = 0; ks < n; ++ks) {
@@ -706,13 +707,22 @@ static void allow_tiled_lds(K kernel, size_t bytes) {
 }
 
 // Product form of the tiled kernels: six bf16 partial products per fp32 product (split_mma.h; default) or the f32-input
-// matrix-core instruction (GLASS_DENSE_SPLIT=0: 1/16 of the bf16 rate — the reference point of the accuracy and A/B runs).
+// matrix-core instruction (1/16 of the bf16 rate — the reference point of the accuracy and A/B runs).  Process-wide switch:
+// GLASS_DENSE_SPLIT=0 in the environment, or glass_dense_product_form_set (dense.hip) at run time.
+static std::atomic<int> g_split_products{-1};
 bool tiled_split_products() {
-    static const bool on = [] {
+    int v = g_split_products.load(std::memory_order_relaxed);
+    if (v < 0) {
         const char* e = getenv("GLASS_DENSE_SPLIT");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_split_products.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+int tiled_split_products_set(int on) {
+    const int prev = tiled_split_products() ? 1 : 0;
+    if (on >= 0) g_split_products.store(on ? 1 : 0, std::memory_order_relaxed);
+    return prev;
 }
 
 template <int HH, int BM, bool S3>
@@ -723,7 +733,11 @@ static void tiled_fwd_launch(const float* xa, int64_t lda, const float* xb, int6
     const int64_t n_rt = ceil_div(N, BM);
     const dim3 grid(tiled_grid(n_rt, HH / 128));
     // + the labeled-row bookkeeping of the effective-weight path (hidden 256 / 512, comb pair)
-    const size_t lds = StageGeom<BM, 256, S3>::kLds + ((comb && HH >= 256) ? 1024 : 0);
+    static const size_t lab_pad = [] {  // laboratory: GLASS_TILED_LDS_PAD=bytes lowers the workgroups per CU
+        const char* e = getenv("GLASS_TILED_LDS_PAD");
+        return e ? (size_t)atoi(e) : (size_t)0;
+    }();
+    const size_t lds = StageGeom<BM, 256, S3>::kLds + ((comb && HH >= 256) ? 1024 : 0) + lab_pad;
     if (comb) {
         constexpr bool kEff = HH >= 256;  // tiled_eff_fwd_shape: the image has the effective-weight appendix
         allow_tiled_lds(tiled_fwd_kernel<HH, true, BM, kEff, S3>, lds);

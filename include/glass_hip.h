@@ -359,8 +359,20 @@ typedef struct glass_dense_caps {
     int32_t comb_eff_fwd_layout, comb_eff_dgrad_layout2;
     int32_t pair_head;         /* K9 (pre-training head on node pairs) at this width */
     int32_t act_codes;         /* bit mask of the activation codes the family fuses: 1 << GLASS_ACT_ELU | 1 << GLASS_ACT_RELU */
+    int32_t product_form;      /* how an fp32 product is formed on the matrix cores: 0 f32-input MFMA (an fmaf chain), 1 six bf16
+                                  partial products of 3-way split operands (glass_dense_product_form) */
 } glass_dense_caps;
 int glass_dense_caps_query(int64_t H, glass_dense_caps* out);
+/* Product form of the LDS-tiled family (hidden 128 / 256 / 512), process-wide.  gfx950 has no tf32 / xf32 and its f32-input
+ * MFMA runs at 1/16 of the bf16 rate, so by default (form 1) each operand is cut into three bf16 pieces — x = hi + mid + lo
+ * EXACTLY for every fp32 x with |x| >= 2^-100 (each piece the RNE rounding of what the pieces before it left: 8 + 8 + 8 significant bits
+ * plus the signs) — and x*w is the sum of the six partial products whose weight is >= 2^-18 (dropped: mid*lo, lo*mid, lo*lo
+ * <= 3 * 2^-26 |x w|, below one fp32 rounding of the product), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Measured
+ * against fp64 the result is as close as form 0's or closer (profiles/r04_split_product_accuracy.txt; the parity tests run
+ * both).  A non-finite operand gives NaN where form 0 gives Inf or NaN.  Form 0 = v_mfma_f32_32x32x2_f32.  Also settable
+ * before the first call with GLASS_DENSE_SPLIT=0|1 in the environment.  _set returns 0 or GLASS_E_ARG. */
+int glass_dense_product_form(void);
+int glass_dense_product_form_set(int form);
 int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
  * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */

@@ -275,3 +275,12 @@ def test_dense_capability_record():
     c64, c128 = _lib.dense_caps(64), _lib.dense_caps(128)
     assert c64.pair_head == 1 and c128.pair_head == 0 and c64.comb_eff == 1 and c128.comb_eff == 0 and c128.comb_eff_fwd == 1
     assert lib.glass_dense_caps_query(0, None) == -1
+    # the product form of the LDS-tiled family: a process-wide switch the record reports (host state, no GPU call)
+    prev = lib.glass_dense_product_form()
+    try:
+        assert lib.glass_dense_product_form_set(0) == 0 and _lib.dense_caps(256).product_form == 0
+        assert lib.glass_dense_product_form_set(1) == 0 and _lib.dense_caps(256).product_form == 1
+        assert _lib.dense_caps(64).product_form == 0 and _lib.dense_caps(20).product_form == 0  # f32-input MFMA / plain fmaf there
+        assert lib.glass_dense_product_form_set(2) == -1
+    finally:
+        lib.glass_dense_product_form_set(prev)

@@ -620,6 +620,53 @@ def test_dual_linear_mix_fused(H, N, comb):
     assert torch.equal(out2, out.detach())
 
 
+@pytest.mark.parametrize("H,N,comb", [(128, 3001, False), (256, 4099, False), (256, 4099, True), (256, 70001, True)])
+def test_both_product_forms_against_fp64(H, N, comb):
+    """The LDS-tiled kernels (forward, data gradient, weight gradient) once per product form — the f32-input MFMA and the six
+    bf16 partial products of 3-way split operands (split_mma.h) — against the same fp64 composition: the split form is as
+    close as the f32-input instruction (within a factor of two, plus a floor) and both are inside the 1e-5 bar."""
+    import torch.nn as nn
+    from glass_amd import _lib, ops
+    lib = _lib.load()
+    gen = torch.Generator().manual_seed(3 * H + N)
+    K = 2 * H if comb else H
+    act = 0 if comb else 1
+    zr = 0.8
+    W = torch.randn(2 * H, K, generator=gen) / K**0.5
+    b = torch.randn(2 * H, generator=gen) * 0.1
+    xa_h, xb_h = torch.randn(N, H, generator=gen), torch.randn(N, H, generator=gen)
+    mask = torch.rand(N, generator=gen) < 0.02
+    gout = torch.randn(N, H, generator=gen)
+    xa64, xb64 = xa_h.double().requires_grad_(True), xb_h.double().requires_grad_(True)
+    W64, b64 = W.double().requires_grad_(True), b.double().requires_grad_(True)
+    Z = (torch.cat((xa64, xb64), -1) if comb else xa64) @ W64.t() + b64
+    A = torch.nn.functional.elu(Z) if act else Z
+    ref = O._mix(mask.reshape(-1, 1), zr, A[:, :H], A[:, H:])
+    ref.backward(gout.double())
+    want = [ref.detach(), xa64.grad] + ([xb64.grad] if comb else []) + [W64.grad, b64.grad]
+    prev = lib.glass_dense_product_form()
+    errs = {}
+    try:
+        for form in (0, 1):
+            assert lib.glass_dense_product_form_set(form) == 0
+            Wg, bg = W.to(DEV), b.to(DEV)
+            dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
+            Wimg, WTimg = _pack(Wg, False, H, zr), _pack(Wg, True, H, zr)
+            lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)
+            lin1.weight.grad, lin0.weight.grad, lin1.bias.grad, lin0.bias.grad = dW[:H], dW[H:], db[:H], db[H:]
+            xa = xa_h.to(DEV).requires_grad_(True)
+            xb = xb_h.to(DEV).requires_grad_(True) if comb else None
+            out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, Wimg, WTimg))
+            out.backward(gout.to(DEV))
+            got = [out.detach().cpu(), xa.grad.cpu()] + ([xb.grad.cpu()] if comb else []) + [dW.cpu(), db.cpu()]
+            errs[form] = [rel_inf(g_, w_) for g_, w_ in zip(got, want)]
+    finally:
+        lib.glass_dense_product_form_set(prev)
+    for e0, e1 in zip(errs[0], errs[1]):
+        assert e0 < TOL and e1 < TOL, errs
+        assert e1 <= 2.0 * e0 + 2e-7, errs
+
+
 def _pack(W, transposed, H=64, z=None):
     """glass_dense_pack_batch_f32 on one matrix: operand image of W ([NT][KT]) or of W^T, in the layout the fused dense
     kernels of hidden size H read.  z = the pair's z_ratio: the layout the KERNELS read for this operand (the library's

@@ -4,9 +4,9 @@
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/step_pmc
 rm -rf $out; mkdir -p $out
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 W=${1:-ppi_bp}
-ARGS="bench.py --workload $W --steps 30 --warmup 5 --min-blocks 1 --graph 0 --no-cpu-baseline --no-roofline-hbm --no-pmc"
+ARGS="bench.py --workload $W --steps ${STEPS:-30} --warmup ${WARM:-5} --min-blocks 1 --graph 0 --no-cpu-baseline --no-roofline-hbm --no-pmc"
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/mfma -- python3 $ARGS > $out/mfma.log 2>&1
 cp $(ls $out/mfma/*/*counter_collection.csv | head -1) $out/mfma_raw.csv
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES --output-format csv -d $out/lds -- python3 $ARGS > $out/lds.log 2>&1
