@@ -42,6 +42,22 @@ __global__ __launch_bounds__(kBlock, 1) void wgrad_partial_kernel(const float* _
                                       blockIdx.z, gridDim.x, gridDim.y, lds, lds + 2 * kTile, gridDim.z);
 }
 
+// ... with split products (wgrad_partial_split_body): the synthesised-gradient forms only (O = 2H, I = H or 2H: whole tiles)
+template <bool ACT, bool EFF>
+__global__ __launch_bounds__(kBlock, 1) void wgrad_partial_split_kernel(const float* __restrict__ X, int64_t ldx, int64_t N, int O,
+                                                                        int I, int rows_per_slab, float* __restrict__ part_w,
+                                                                        float* __restrict__ part_b, float* __restrict__ header,
+                                                                        WgradSynth sy) {
+    __shared__ float lds[2 * kTile + 8 * kOT];
+    if (header && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) {
+        header[0] = EFF ? 1.f : 0.f;
+        header[1] = sy.zr;
+        header[2] = 0.f;
+    }
+    wgrad_partial_split_body<ACT, EFF>(X, ldx, N, O, I, rows_per_slab, part_w, part_b, sy, blockIdx.x, blockIdx.y, blockIdx.z,
+                                       gridDim.x, gridDim.y, lds, lds + 2 * kTile, gridDim.z);
+}
+
 // Sum the slab partials and scatter to dW[o,i] / db[o].  A [n_slabs x 8192(+128)] column reduction:
 // 16 lanes x float4 cover 64 columns, 16 row slots walk the slabs (4 loads in flight each) and are
 // combined through LDS in slot order -> fixed summation order.
@@ -618,12 +634,26 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     // fit the workgroup's LDS image area
     const bool eff = X2 != nullptr && act == GLASS_ACT_NONE && I == O && O == 2 * H && g.nz % 2 == 0 &&
                      g.rows_per_slab <= 2 * kTile - 64;
-    if (eff)
-        hipLaunchKernelGGL((wgrad_partial_kernel<true, true>), dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X,
-                           ldx, N, (int)O, (int)I, g.rows_per_slab, part_w, (db || !dW) ? part_b : nullptr, header, sy);
+    float* pb_arg = (db || !dW) ? part_b : nullptr;
+    const dim3 grid(g.n_slabs, g.ny, g.nz);
+    // hidden 128 (the widths of the tiled family whose graph or layer is too small for wgrad_tiled.hip): the product form of
+    // that family (glass_dense_product_form) applies here too — six bf16 partial products per fp32 product
+    const bool split = tiled_shape_ok(H) && tiled_split_products() && ldx % 2 == 0;
+    if (split && eff)
+        hipLaunchKernelGGL((wgrad_partial_split_kernel<false, true>), grid, dim3(kBlock), 0, st, X, ldx, N, (int)O, (int)I,
+                           g.rows_per_slab, part_w, pb_arg, header, sy);
+    else if (split && act != GLASS_ACT_NONE)
+        hipLaunchKernelGGL((wgrad_partial_split_kernel<true, false>), grid, dim3(kBlock), 0, st, X, ldx, N, (int)O, (int)I,
+                           g.rows_per_slab, part_w, pb_arg, header, sy);
+    else if (split)
+        hipLaunchKernelGGL((wgrad_partial_split_kernel<false, false>), grid, dim3(kBlock), 0, st, X, ldx, N, (int)O, (int)I,
+                           g.rows_per_slab, part_w, pb_arg, header, sy);
+    else if (eff)
+        hipLaunchKernelGGL((wgrad_partial_kernel<true, true>), grid, dim3(kBlock), 0, st, nullptr, 0, X,
+                           ldx, N, (int)O, (int)I, g.rows_per_slab, part_w, pb_arg, header, sy);
     else
-        hipLaunchKernelGGL((wgrad_partial_kernel<true, false>), dim3(g.n_slabs, g.ny, g.nz), dim3(kBlock), 0, st, nullptr, 0, X,
-                           ldx, N, (int)O, (int)I, g.rows_per_slab, part_w, (db || !dW) ? part_b : nullptr, header, sy);
+        hipLaunchKernelGGL((wgrad_partial_kernel<true, false>), grid, dim3(kBlock), 0, st, nullptr, 0, X,
+                           ldx, N, (int)O, (int)I, g.rows_per_slab, part_w, pb_arg, header, sy);
     if (dW)  // dW == NULL: partial sums only; the caller reduces later with glass_linear_wgrad_reduce_batch_f32
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kTile + kOT) / 64, g.ny * g.nz), dim3(kBlock), 0, st, part_w,
                            part_b, g.n_slabs, g.ny, g.nz, (int)O, (int)I, dW, lddw, db, accumulate);

@@ -2,6 +2,7 @@
 // small graphs / narrow layers) and wgrad_tiled.hip (LDS-tiled 128 x 256 tile: hidden >= 256 on large graphs).
 #pragma once
 #include "common.h"
+#include "split_mma.h"
 #include "dense_common.h"
 
 namespace glass {
@@ -37,6 +38,49 @@ constexpr int kMaxSlabs = 256;
 
 // idx of accumulator (t,u,reg,lane) in the permuted partial layout
 __device__ __forceinline__ int acc_index(int t, int u, int reg, int lane) { return ((t * 2 + u) * 16 + reg) * 64 + lane; }
+
+// The end of a partial-sum workgroup: the four waves' accumulator images combined through LDS (waves 0,1 store; waves 2,3
+// add; everyone sums the pair), the partial tile and the bias partial written.
+__device__ __forceinline__ void wgrad_partial_tail(f32x16 (&acc)[4][2], const float4& bsum, bool lab_tile, int bx, int by, int bz,
+                                                   int gx, int gy, float* __restrict__ part_w, float* __restrict__ part_b,
+                                                   float* lds, float* lds_b) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    // ---- combine the 4 waves through LDS: waves 0,1 store; waves 2,3 add; everyone sums the pair ----
+    if (lab_tile) __syncthreads();  // the row list lies in the image area: every wave is done reading it
+    if (w < 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index(t, u, k, lane)] = acc[t][u][k];
+    }
+    *reinterpret_cast<float4*>(&lds_b[(w * 2 + h) * kOT + 4 * c]) = bsum;
+    __syncthreads();
+    if (w >= 2) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index(t, u, k, lane)] += acc[t][u][k];
+    }
+    __syncthreads();
+    const int64_t tile_id = ((int64_t)bz * gy + by) * gx + bx;
+    float* pw = part_w + tile_id * kTile;
+    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
+        const float4 a = *reinterpret_cast<const float4*>(&lds[k]);
+        const float4 b = *reinterpret_cast<const float4*>(&lds[kTile + k]);
+        *reinterpret_cast<float4*>(pw + k) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    if (by == 0 && part_b && threadIdx.x < kOT) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += lds_b[k * kOT + threadIdx.x];
+        part_b[((int64_t)bz * gx + bx) * kOT + threadIdx.x] = s;
+    }
+}
 
 // Partial sums of one (slab bx, input tile by, output tile bz) of a gx x gy x gz launch, by one 256-thread workgroup.
 // lds: 2 * kTile floats (two wave-sized accumulator images), lds_b: 8 * kOT floats (bias partials [wave*2 + h][o]).
@@ -165,40 +209,135 @@ __device__ __forceinline__ void wgrad_partial_body(const float* __restrict__ G, 
         }
     }
 
-    // ---- combine the 4 waves through LDS: waves 0,1 store; waves 2,3 add; everyone sums the pair ----
-    if (lab_tile) __syncthreads();  // the row list lies in the image area: every wave is done reading it
-    if (w < 2) {
+    wgrad_partial_tail(acc, bsum, lab_tile, bx, by, bz, gx, gy, part_w, part_b, lds, lds_b);
+}
+
+// ---- the same partial sums with split products (split_mma.h) --------------------------------------------------------
+// v_mfma_f32_32x32x16_bf16 sums over 16 node rows per instruction: lane (c, h) feeds rows 8h .. 8h+7 of a 16-row group for
+// its four outputs / two inputs, so a wave takes WHOLE 16-row groups (w, w + 4, ...) instead of row pairs, loads eight rows
+// per lane and stage (float4 of the gradient, of the pre-activation when there is an activation, float2 of the input — the
+// same whole-row coalesced loads as above), synthesises dZ, cuts every 8-row column into three bf16 pieces in registers and
+// runs 8 tiles x 6 partial products = 48 MFMAs (1 536 cycles) per group where the f32-input form runs 64 x 64 cycles for
+// the same 16 rows.  No LDS in the loop; two stages of raw loads in flight (refilled as soon as their values are cut).
+// Accumulator layout, partial layout, labeled-rows tiles and the workgroup tail are those of wgrad_partial_body.
+template <bool ACT, bool EFF>
+__device__ __forceinline__ void wgrad_partial_split_body(const float* __restrict__ X, int64_t ldx, int64_t N, int O, int I,
+                                                         int rows_per_slab, float* __restrict__ part_w,
+                                                         float* __restrict__ part_b, const WgradSynth& sy, int bx, int by,
+                                                         int bz, int gx, int gy, float* lds, float* lds_b, int gz) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const bool lab_tile = EFF && bz >= gz / 2;
+    const int o0 = (lab_tile ? bz - gz / 2 : bz) * kOT + 4 * c;   // this lane's 4 outputs
+    const int i0 = by * kIT + 2 * c;                              // this lane's 2 inputs
+    const int64_t r0 = (int64_t)bx * rows_per_slab;
+    const int64_t r1 = min(N, r0 + rows_per_slab);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[t][u][k] = 0.f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool first = o0 < sy.H;  // this lane's four outputs lie in the f1 half
+    const float e_neg = sy.act == GLASS_ACT_ELU ? 1.f : 0.f;  // act'(t) = t > 0 ? 1 : e_neg * exp(t)  (ELU / ReLU)
+    // EFF, labeled-rows tile: the slab's labeled rows in row order (as wgrad_partial_body)
+    int* lab_list = reinterpret_cast<int*>(lds);
+    int n_lab = 0;
+    if (lab_tile) {
+        int* cnt = lab_list + 2 * kTile - 8;
+        const int span = (int)(r1 - r0);
+        int base = 0;
+        for (int c0 = 0; c0 < span; c0 += kBlock) {
+            const int64_t n = r0 + c0 + (int)threadIdx.x;
+            const bool flag = c0 + (int)threadIdx.x < span && sy.mask[n] != 0;
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) cnt[w] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int ww = 0; ww < w; ++ww) off += cnt[ww];
+            if (flag) lab_list[off + __popcll(bal & ((1ull << lane) - 1ull))] = c0 + (int)threadIdx.x;
+            base += cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            __syncthreads();
+        }
+        n_lab = base;
+    }
+    const int64_t r_end = lab_tile ? r0 + n_lab : r1;  // the row counter runs over [r0, r_end)
+    const float* xsrc = (i0 < sy.H || sy.X2 == nullptr) ? X + i0 : sy.X2 + (i0 - sy.H);
+    const int64_t xld = (i0 < sy.H || sy.X2 == nullptr) ? ldx : sy.ldx2;
+    const float* gsrc = sy.dsrc + (first ? o0 : o0 - sy.H);
+    struct Stage {
+        float4 g[8], t[ACT ? 8 : 1];
+        float2 x[8];
+        int mk[EFF ? 1 : 8];
+        int nlive;  // rows 0 .. nlive-1 of this lane's eight exist
+    };
+    auto load_stage = [&](int64_t pb, Stage& S) __attribute__((always_inline)) {
+        const int64_t p0 = pb + 8 * h;
+        const int64_t left = r_end - p0;
+        S.nlive = left < 0 ? 0 : (left > 8 ? 8 : (int)left);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t pos = p0 + r;
+            const int64_t want = !lab_tile ? pos : (pos < r_end ? r0 + lab_list[pos - r0] : r1);
+            const int64_t nn = want < r1 ? want : r1 - 1;  // clamped: loads never wait on a predicate, zeroed at use
+            S.g[r] = *reinterpret_cast<const float4*>(gsrc + nn * sy.ldd);
+            if (ACT) S.t[r] = *reinterpret_cast<const float4*>(sy.T + nn * sy.ldt + o0);
+            if (!EFF) S.mk[r] = sy.mask[nn];
+            S.x[r] = *reinterpret_cast<const float2*>(xsrc + nn * xld);
+        }
+    };
+    auto cut8 = [](const float (&v)[8], uint4 (&f)[3]) __attribute__((always_inline)) {
+        split2(v[0], v[1], f[0].x, f[1].x, f[2].x);
+        split2(v[2], v[3], f[0].y, f[1].y, f[2].y);
+        split2(v[4], v[5], f[0].z, f[1].z, f[2].z);
+        split2(v[6], v[7], f[0].w, f[1].w, f[2].w);
+    };
+    auto run_stage = [&](Stage& S, int64_t refill_pb) __attribute__((always_inline)) {
+        float gv[4][8], xv[2][8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            float4 g = S.g[r];
+            if (!EFF) {
+                const float cf = ((S.mk[r] != 0) == first) ? sy.zr : sy.omz;
+                g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
+                if (ACT) {
+                    const float4 t = S.t[r];
+                    g.x *= t.x > 0.f ? 1.f : e_neg * __expf(t.x);
+                    g.y *= t.y > 0.f ? 1.f : e_neg * __expf(t.y);
+                    g.z *= t.z > 0.f ? 1.f : e_neg * __expf(t.z);
+                    g.w *= t.w > 0.f ? 1.f : e_neg * __expf(t.w);
+                }
+            }
+            if (r >= S.nlive) g = make_float4(0.f, 0.f, 0.f, 0.f);
+            bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+            gv[0][r] = g.x; gv[1][r] = g.y; gv[2][r] = g.z; gv[3][r] = g.w;
+            xv[0][r] = S.x[r].x; xv[1][r] = S.x[r].y;
+        }
+        uint4 A[4][3], B[2][3];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) cut8(gv[t], A[t]);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) cut8(xv[u], B[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        load_stage(refill_pb, S);  // this stage's registers are free: two groups ahead
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lds[w * kTile + acc_index(t, u, k, lane)] = acc[t][u][k];
+            for (int u = 0; u < 2; ++u) split_mma(acc[t][u], A[t], B[u]);
+    };
+    Stage st[2];
+    const int64_t pb0 = r0 + 16 * w;  // wave-uniform: 16-row groups w, w + 4, ...
+    load_stage(pb0, st[0]);
+    load_stage(pb0 + 64, st[1]);
+    for (int64_t pb = pb0; pb < r_end; pb += 128) {
+        run_stage(st[0], pb + 128);
+        run_stage(st[1], pb + 192);
     }
-    *reinterpret_cast<float4*>(&lds_b[(w * 2 + h) * kOT + 4 * c]) = bsum;
-    __syncthreads();
-    if (w >= 2) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int k = 0; k < 16; ++k) lds[(w - 2) * kTile + acc_index(t, u, k, lane)] += acc[t][u][k];
-    }
-    __syncthreads();
-    const int64_t tile_id = ((int64_t)bz * gy + by) * gx + bx;
-    float* pw = part_w + tile_id * kTile;
-    for (int k = threadIdx.x * 4; k < kTile; k += kBlock * 4) {
-        const float4 a = *reinterpret_cast<const float4*>(&lds[k]);
-        const float4 b = *reinterpret_cast<const float4*>(&lds[kTile + k]);
-        *reinterpret_cast<float4*>(pw + k) = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
-    }
-    if (by == 0 && part_b && threadIdx.x < kOT) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s += lds_b[k * kOT + threadIdx.x];
-        part_b[((int64_t)bz * gx + bx) * kOT + threadIdx.x] = s;
-    }
+    wgrad_partial_tail(acc, bsum, lab_tile, bx, by, bz, gx, gy, part_w, part_b, lds, lds_b);
 }
 
 // ---- trans pair at hidden 64, staged form (inside the fused backward launch of small graphs) --------------------------
