@@ -137,6 +137,7 @@ SIGNATURES = {
     "glass_dual_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, _I, _P,
                                             c_int, _P, _P]),
     "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "glass_dense_image_floats": (_I, [_I, _I, c_int]),
     "glass_dual_linear_dgrad_layout": (c_int, [_I, _I]),
     "glass_dual_linear_fwd_layout": (c_int, [_I, _I]),
     "glass_head_loss_fwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _I, _I, _I, _P, _P, _P, _P]),

@@ -155,8 +155,9 @@ class ParamArena(FlatGradBucket):
                     # the pair's z_ratio
                     dlay = int(_lib.load().glass_dual_linear_dgrad_layout(O // 2, K))
                     flay = int(_lib.load().glass_dual_linear_fwd_layout(O // 2, K))  # 5: same appendix for the forward
-                    Wimg = torch.empty(W.numel() * 3 // 2 if flay == 5 else W.numel(), dtype=W.dtype, device=W.device)
-                    WTimg = torch.empty(W.numel() * 3 // 2 if dlay == 4 else W.numel(), dtype=W.dtype, device=W.device)
+                    # image sizes from the library (appendix of layouts 4 / 5; the cut image behind tiled layouts)
+                    Wimg = torch.empty(int(_lib.load().glass_dense_image_floats(O, K, 0 | (flay << 1))), dtype=W.dtype, device=W.device)
+                    WTimg = torch.empty(int(_lib.load().glass_dense_image_floats(K, O, 1 | (dlay << 1))), dtype=W.dtype, device=W.device)
                     self._packs.append((W, Wimg, O, K, 0 | (flay << 1), mod))
                     self._packs.append((W, WTimg, K, O, 1 | (dlay << 1), mod))
                     mod._stack[kind] = (W, b, dW, db, Wimg, WTimg)

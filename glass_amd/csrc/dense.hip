@@ -20,6 +20,7 @@
 // take the LDS-tiled kernels of dense_tiled.hip.
 #include "common.h"
 #include "dense_common.h"
+#include "split_mma.h"
 #include "wgrad_common.h"
 #include "emb_table.h"
 
@@ -2630,6 +2631,7 @@ struct PackJob {
     float* dst;
     int NT, KT, transposed, layout;
     float zr;  // kLayoutTiledPlainEff: the pair's z_ratio
+    int cut;   // tiled layouts: also write the image cut into bf16 pieces behind the fp32 one (split_mma.h, pack_cut_put)
 };
 constexpr int kMaxPackJobs = 16;
 struct PackBatch {
@@ -2640,6 +2642,17 @@ __device__ __forceinline__ float4 pack_fetch(const PackJob& j, int n, int k) {
     if (!j.transposed) return *reinterpret_cast<const float4*>(j.src + (int64_t)n * j.KT + k);
     return make_float4(j.src[(int64_t)k * j.NT + n], j.src[(int64_t)(k + 1) * j.NT + n], j.src[(int64_t)(k + 2) * j.NT + n],
                        j.src[(int64_t)(k + 3) * j.NT + n]);
+}
+
+// The cut image of a tiled layout (behind the fp32 image and its appendix, same tile numbering): per tile of 16 k x 256 slots
+// [piece 3][h 2][slot 256] 16-byte units = the LDS image of split_mma.h's SplitImg<256>, so that a K step's B operand is 24 KiB
+// copied as it lies (global_load_lds in the tiled kernels).  Element (slot nl, k-quad q): 8 bytes per piece.
+__device__ __forceinline__ void pack_cut_put(float* cut, int tile, int nl, int q, const float4& v) {
+    const Split4 s = split4(v);
+    uint2* p = reinterpret_cast<uint2*>(cut) + (((size_t)tile * 6 + (q >> 1)) * 256 + nl) * 2 + (q & 1);
+    p[0] = s.hi;
+    p[1024] = s.mid;
+    p[2048] = s.lo;
 }
 
 // The other once-per-step prologue job rides in the same launch (grid row n_jobs): emb_gn's statistics through the
@@ -2718,18 +2731,25 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
         for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
             const int nl = l & 255, q = (l >> 8) & 3, ks = l >> 10;
             const int v = tiled_col(kLayoutTiledPlain, 0, nl, 0);
-            if (ks < NKS)
-                reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, v % j.NT, (v / j.NT) * (j.KT / 2) + 16 * ks + 4 * q);
+            if (ks < NKS) {
+                const float4 e = pack_fetch(j, v % j.NT, (v / j.NT) * (j.KT / 2) + 16 * ks + 4 * q);
+                reinterpret_cast<float4*>(j.dst)[l] = e;
+                if (j.cut) pack_cut_put(j.dst + 4 * (size_t)total, ks, nl, q, e);
+            }
         }
         return;
     }
     // tiled layouts (dense_tiled.hip): dst[((ct * NKS + ks) * 4 + q) * 256 + nl] (float4) = B[tiled_col(ct, nl)][16 ks + 4 q ..+3]
     const int NKS = j.KT / 16, H = j.NT / 2;  // H only meaningful for the paired layout (NT = 2H)
     const int lay = j.layout == kLayoutTiledPlainEff ? kLayoutTiledPlain : j.layout == kLayoutTiledPairedEff ? kLayoutTiledPaired : j.layout;
+    const bool has_app = j.layout == kLayoutTiledPlainEff || j.layout == kLayoutTiledPairedEff;
+    float* cut = j.dst + 4 * (size_t)total + (has_app ? 2 * (size_t)total : 0);  // behind the fp32 image and its appendix
     for (int l = blockIdx.x * kBlock + threadIdx.x; l < total; l += gridDim.x * kBlock) {
         const int nl = l & 255, q = (l >> 8) & 3, tile = l >> 10;
         const int ct = tile / NKS, ks = tile % NKS;
-        reinterpret_cast<float4*>(j.dst)[l] = pack_fetch(j, tiled_col(lay, ct, nl, H), 16 * ks + 4 * q);
+        const float4 e = pack_fetch(j, tiled_col(lay, ct, nl, H), 16 * ks + 4 * q);
+        reinterpret_cast<float4*>(j.dst)[l] = e;
+        if (j.cut) pack_cut_put(cut, tile, nl, q, e);
     }
     if (j.layout == kLayoutTiledPairedEff) {
         // appendix of the forward operand: W_unl[n][k] = (1 - z) * B[n][k] + z * B[NT/2 + n][k], n < NT/2 (an unlabeled
@@ -2741,7 +2761,9 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
             const int ct = tile / NKS, ks = tile % NKS;
             const int n = tiled_col(kLayoutTiledPlain, ct, nl, H), k = 16 * ks + 4 * q;
             const float4 a = pack_fetch(j, n, k), b = pack_fetch(j, H + n, k);
-            app[l] = make_float4(omz * a.x + zr * b.x, omz * a.y + zr * b.y, omz * a.z + zr * b.z, omz * a.w + zr * b.w);
+            const float4 e = make_float4(omz * a.x + zr * b.x, omz * a.y + zr * b.y, omz * a.z + zr * b.z, omz * a.w + zr * b.w);
+            app[l] = e;
+            if (j.cut) pack_cut_put(cut, total / 1024 + tile, nl, q, e);
         }
         return;
     }
@@ -2756,7 +2778,9 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
         const int ct = tile / NKS2, ks = tile % NKS2;
         const int n = tiled_col(kLayoutTiledPlain, ct, nl, H), k = 16 * ks + 4 * q;
         const float4 a = pack_fetch(j, n, k), b = pack_fetch(j, n, j.KT / 2 + k);
-        app[l] = make_float4(omz * a.x + zr * b.x, omz * a.y + zr * b.y, omz * a.z + zr * b.z, omz * a.w + zr * b.w);
+        const float4 e = make_float4(omz * a.x + zr * b.x, omz * a.y + zr * b.y, omz * a.z + zr * b.z, omz * a.w + zr * b.w);
+        app[l] = e;
+        if (j.cut) pack_cut_put(cut, total / 1024 + tile, nl, q, e);
     }
 }
 
@@ -3426,7 +3450,7 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
     GLASS_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs && (n_jobs == 0 || (src && dst && NT && KT && transposed)),
                   "%s: bad arguments (at most %d matrices per call)", what, kMaxPackJobs);
     PackBatch b;
-    for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0, 0, 0.f};
+    for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0, 0, 0.f, 0};
     for (int k = 0; k < n_jobs; ++k) {
         GLASS_REQUIRE(src[k] && dst[k] && NT[k] > 0 && NT[k] % 64 == 0 && KT[k] > 0 && KT[k] % 64 == 0 && aligned16(src[k]) &&
                           aligned16(dst[k]),
@@ -3446,7 +3470,10 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
                            (transposed[k] & 1) && z_ratio),
                       "%s: job %d: unknown layout %d, NT not a multiple of 256 for a tiled layout, or a split "
                       "layout that is not the transposed 128 x 256 operand", what, k, layout);
-        b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f};
+        const bool tiled_layout = layout == kLayoutTiledPaired || layout == kLayoutTiledPlain || layout == kLayoutTiledSplit ||
+                                  layout == kLayoutTiledPlainEff || layout == kLayoutTiledPairedEff;
+        b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f,
+                           (tiled_layout && tiled_split_products()) ? 1 : 0};
     }
     unsigned gx = 32;
     if (tab.W && (unsigned)ceil_div(tab.H, kTabCols) > gx) gx = (unsigned)ceil_div(tab.H, kTabCols);
@@ -3454,6 +3481,19 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
     if (gy == 0) gy = 1;  // (only the zero-fill / the dropout stream to serve)
     hipLaunchKernelGGL(pack_batch_kernel, dim3(gx, gy), dim3(kBlock), 0, (hipStream_t)stream, b, rng_state, tab, (int)n_jobs, zero);
     return launch_status(what);
+}
+
+// Floats an operand image of (NT, KT, flags = transposed | layout << 1) occupies: NT*KT, + half of it for the effective-weight
+// appendix of layouts 4 / 5, and for the tiled layouts (1..5) the same again x 3/2 behind it — the image cut into bf16 pieces
+// that the split product form reads (written when glass_dense_product_form() == 1 at pack time).
+extern "C" int64_t glass_dense_image_floats(int64_t NT, int64_t KT, int32_t flags) {
+    if (NT <= 0 || KT <= 0) return GLASS_E_ARG;
+    const int layout = flags >> 1;
+    int64_t base = NT * KT;
+    if (layout == kLayoutTiledPlainEff || layout == kLayoutTiledPairedEff) base += base / 2;
+    const bool tiled_layout = layout == kLayoutTiledPaired || layout == kLayoutTiledPlain || layout == kLayoutTiledSplit ||
+                              layout == kLayoutTiledPlainEff || layout == kLayoutTiledPairedEff;
+    return tiled_layout ? base + base * 3 / 2 : base;
 }
 
 extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,

@@ -135,6 +135,21 @@ struct BStage {
     }
 };
 
+// Split form: a K step's B operand is 24 KiB of the pre-cut image (glass_dense_pack_batch_f32 wrote it in LDS order, dense.hip
+// pack_cut_put) copied global -> LDS by the DMA path: no registers, no vector instructions, no ds_write.  6 instructions per
+// thread; instruction i of wave w lands its 64 x 16 bytes at unit i*256 + w*64 (wave-uniform base + lane x 16).  The copies
+// count on vmcnt like loads: they are complete after the s_waitcnt vmcnt(0) in front of the barrier that publishes the stage.
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+constexpr int kCutTileUnits = 6 * 256;  // 16-byte units per (column tile, K step) of a cut image
+__device__ __forceinline__ void dma_b_stage(const uint4* __restrict__ tile, float4* __restrict__ Bimg) {
+    const int tid = threadIdx.x;
+    const int wbase = __builtin_amdgcn_readfirstlane((tid >> 6) * 64);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        __builtin_amdgcn_global_load_lds(tile + i * 256 + tid, (lds_void_ptr)(uintptr_t)(Bimg + i * 256 + wbase), 16, 0, 0);
+}
+__device__ __forceinline__ void dma_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // ---- forward ----------------------------------------------------------------------------------------------------
 // EFF (comb pair, hidden 256 / 512): the operand image carries an appendix, W_unl = (1-z) W1 + z W0 ([H][2H], plain
 // layout).  The comb pair has no activation before the mix, so a row tile WITHOUT a labeled row is one product
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
                                                                 int act, float* __restrict__ T, int64_t ldt,
                                                                 float* __restrict__ out, int64_t ldo, int64_t N,
                                                                 double* __restrict__ stats, GnPrologue pro,
-                                                                int n_rowtiles) {
+                                                                int n_rowtiles, const float* __restrict__ Wcut) {
     using TL = Tile<BM, 256>;  // 256 column slots = 128 columns of the f1 half + the same 128 of the f0 half
     using SG = StageGeom<BM, 256, S3>;
     constexpr int KT = COMB ? 2 * H : H, NKS = KT / kTK, NCT = H / 128, RB = TL::RB, AP = TL::kAPer;
@@ -223,8 +238,9 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
     const bool side_writer = pro.side != nullptr && ct == 0;  // every column tile computes the operand; one writes it
     const float4* wimg = reinterpret_cast<const float4*>(Wimg) +
                          (pure ? (int64_t)(NCT + ct) * NKS * TL::kBImg : (int64_t)ct * NKS * TL::kBImg);
+    const uint4* wcut = reinterpret_cast<const uint4*>(Wcut) + (int64_t)(pure ? NCT + ct : ct) * NKS * kCutTileUnits;  // S3
 
-    float4 av[AP], asc[AP], ash[AP];
+    float4 av[AP], asc, ash;  // (every float4 of a thread sits in the same k-quad — tid & 3 —: one pair of coefficient vectors)
     BStage<TL::kBPer> bs;
     auto issue = [&](int ks) __attribute__((always_inline)) {
 #pragma unroll
@@ -233,12 +249,13 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
             const int64_t r = row0 + srow[i];
             const float* src = (!COMB || k < H) ? xa + (COMB ? r : arow[i]) * lda + k : xb + r * ldb + (k - H);
             av[i] = sok[i] ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
-            if (pro.saved && (!COMB || k < H)) {
-                asc[i] = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + k);
-                ash[i] = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + k);
+            if (i == 0 && pro.saved && (!COMB || k < H)) {
+                asc = *reinterpret_cast<const float4*>(pro.saved + 2 * pro.C + k);
+                ash = *reinterpret_cast<const float4*>(pro.saved + 3 * pro.C + k);
             }
         }
-        bs.issue(wimg + (int64_t)ks * TL::kBImg);
+        if constexpr (S3) dma_b_stage(wcut + (int64_t)ks * kCutTileUnits, smem + (ks & 1) * SG::kStage + SG::kA);
+        else bs.issue(wimg + (int64_t)ks * TL::kBImg);
     };
     auto commit = [&](int ks, float4* stage) __attribute__((always_inline)) {
 #pragma unroll
@@ -249,8 +266,7 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
                 const int64_t r = row0 + srow[i];
                 float ds[4] = {1.f, 1.f, 1.f, 1.f};
                 if (drop.p > 0.f) drop_scales<4>(drop, r, k, ds);
-                float o[4] = {fmaf(v.x, asc[i].x, ash[i].x), fmaf(v.y, asc[i].y, ash[i].y), fmaf(v.z, asc[i].z, ash[i].z),
-                              fmaf(v.w, asc[i].w, ash[i].w)};
+                float o[4] = {fmaf(v.x, asc.x, ash.x), fmaf(v.y, asc.y, ash.y), fmaf(v.z, asc.z, ash.z), fmaf(v.w, asc.w, ash.w)};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     o[e] = act_fast(pro.act, o[e]);
@@ -262,7 +278,7 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
             if constexpr (S3) SplitImg<BM>::put4(stage, srow[i], skq[i], v);
             else stage[skq[i] * TL::kAPlane + srow[i]] = v;
         }
-        if constexpr (S3) bs.commit_split(stage + SG::kA);
+        if constexpr (S3) dma_drain();  // this stage's B copies (issued a whole K step of MFMAs ago) have landed
         else bs.commit(stage + SG::kA);
     };
 
@@ -446,7 +462,7 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
                                                                   const float* __restrict__ addend, int64_t ldadd,
                                                                   Drop drop, const uint64_t* __restrict__ rng_state,
                                                                   float* __restrict__ out, int64_t ldo, int64_t N,
-                                                                  GnBwdStats gs, int n_rowtiles) {
+                                                                  GnBwdStats gs, int n_rowtiles, const float* __restrict__ Wcut) {
     using TL = Tile<BM, BN>;
     constexpr int KT = SPLIT ? H : 2 * H, NKS = KT / kTK, NCT = SPLIT ? 1 : NOUT / BN, RB = TL::RB, CB = TL::CB, AP = TL::kAPer;
     constexpr int NA = SPLIT ? 2 : 1;                          // A images per stage
@@ -496,6 +512,8 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
     }
     const float4* wimg = reinterpret_cast<const float4*>(WTimg) +
                          (pure ? (int64_t)NCT * NKS * TL::kBImg + (int64_t)ct * (NKS / 2) * TL::kBImg : (int64_t)ct * NKS * TL::kBImg);
+    const uint4* wcut = reinterpret_cast<const uint4*>(Wcut) +
+                        (pure ? (int64_t)NCT * NKS + (int64_t)ct * (NKS / 2) : (int64_t)ct * NKS) * kCutTileUnits;  // S3
     float4 dv[AP], tv[AP], tw[SPLIT ? AP : 1];
     BStage<TL::kBPer> bs;
     auto issue = [&](int ks) __attribute__((always_inline)) {
@@ -509,7 +527,8 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
                 if (SPLIT) tw[i] = sok[i] ? *reinterpret_cast<const float4*>(T + r * ldt + H + o) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
-        bs.issue(wimg + (int64_t)ks * TL::kBImg);
+        if constexpr (S3) dma_b_stage(wcut + (int64_t)ks * kCutTileUnits, smem + (ks & 1) * kStage + NA * SG::kA);
+        else bs.issue(wimg + (int64_t)ks * TL::kBImg);
     };
     auto commit = [&](int ks, float4* stage) __attribute__((always_inline)) {
 #pragma unroll
@@ -532,7 +551,7 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
                 else stage[TL::kAImg + skq[i] * TL::kAPlane + srow[i]] = u;
             }
         }
-        if constexpr (S3) bs.commit_split(stage + NA * SG::kA);
+        if constexpr (S3) dma_drain();
         else bs.commit(stage + NA * SG::kA);
     };
 
@@ -738,15 +757,18 @@ static void tiled_fwd_launch(const float* xa, int64_t lda, const float* xb, int6
         return e ? (size_t)atoi(e) : (size_t)0;
     }();
     const size_t lds = StageGeom<BM, 256, S3>::kLds + ((comb && HH >= 256) ? 1024 : 0) + lab_pad;
+    // the cut image lies behind the fp32 image (and its effective-weight appendix): glass_dense_image_floats
+    const int64_t K = comb ? 2 * HH : HH, base = 2 * (int64_t)HH * K;
+    const float* Wcut = Wimg + ((comb && HH >= 256) ? base + base / 2 : base);
     if (comb) {
         constexpr bool kEff = HH >= 256;  // tiled_eff_fwd_shape: the image has the effective-weight appendix
         allow_tiled_lds(tiled_fwd_kernel<HH, true, BM, kEff, S3>, lds);
         hipLaunchKernelGGL((tiled_fwd_kernel<HH, true, BM, kEff, S3>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,
-                           bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);
+                           bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt, Wcut);
     } else {
         allow_tiled_lds(tiled_fwd_kernel<HH, false, BM, false, S3>, lds);
         hipLaunchKernelGGL((tiled_fwd_kernel<HH, false, BM, false, S3>), grid, dim3(kTThreads), lds, st, xa, lda, xb, ldb, Wimg,
-                           bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt);
+                           bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, (int)n_rt, Wcut);
     }
 }
 
@@ -774,10 +796,12 @@ static void tiled_dgrad_launch(const float* dsrc, int64_t ldd, const float* T, i
     constexpr bool kEff = !SPLIT && NOUT == 2 * HH;  // tiled_eff_dgrad_shape
     constexpr int NCT = SPLIT ? 1 : NOUT / BN;
     const size_t lds = StageGeom<BM, BN, S3, SPLIT ? 2 : 1>::kLds + (kEff ? 1024 : 0);  // + the labeled-row bookkeeping
+    const int64_t base = (int64_t)NOUT * 2 * HH;  // fp32 image [NT = NOUT][KT = 2H]; then its appendix; then the cut image
+    const float* Wcut = WTimg + (kEff ? base + base / 2 : base);
     allow_tiled_lds(tiled_dgrad_kernel<HH, NOUT, BM, BN, SPLIT, kEff, S3>, lds);
     hipLaunchKernelGGL((tiled_dgrad_kernel<HH, NOUT, BM, BN, SPLIT, kEff, S3>), dim3(tiled_grid(n_rt, NCT)), dim3(kTThreads), lds,
                        st, dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, rng_state, out, ldo, N, gs,
-                       (int)n_rt);
+                       (int)n_rt, Wcut);
 }
 
 int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask, float zr,

@@ -683,7 +683,7 @@ def _pack(W, transposed, H=64, z=None):
         layout = lib.glass_dual_linear_dgrad_layout(H, nt) if transposed else lib.glass_dual_linear_fwd_layout(H, kt)
     else:
         layout = (2 if nt % 256 == 0 else 3) if transposed else 1
-    img = torch.empty(W.numel() * 3 // 2 if layout in (4, 5) else W.numel(), device=DEV)
+    img = torch.empty(int(lib.glass_dense_image_floats(nt, kt, int(transposed) | (layout << 1))), device=DEV)
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
     trs = np.array([int(transposed) | (layout << 1)], dtype=np.int32)
@@ -716,10 +716,12 @@ def test_dense_pack_tiled_layouts():
     for H in (256, 128):
         W = torch.arange(2 * H * H, dtype=torch.float32, device=DEV).reshape(2 * H, H)  # trans pair weight [2H][H]
         for transposed in (False, True):
-            img = _pack(W, transposed, H).cpu()
+            full = _pack(W, transposed, H).cpu()
+            img = full[:W.numel()]  # the fp32 image; behind it the same image cut into bf16 pieces (checked below)
             assert sorted(img.tolist()) == W.reshape(-1).cpu().tolist()
             B = (W.t() if transposed else W).cpu()
             NT, KT = B.shape
+            _check_cut_image(full, W.numel())
             if transposed and H == 128:
                 # split layout: ONE 256-slot tile over K = KT / 2 holds both stacked halves side by side —
                 # slot v = wn*128 + 4j + cb: v < 128 -> B[v][k], else B[v - 128][KT/2 + k]
@@ -742,6 +744,21 @@ def test_dense_pack_tiled_layouts():
                 assert img[off:off + 4].tolist() == B[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4].tolist()
 
 
+def _check_cut_image(full, n_fp32):
+    """The cut image behind a tiled fp32 image (glass_dense_image_floats; written in product form 1): per tile of 16 k x 256
+    slots [piece 3][h 2][slot 256] x 8 bf16 — the three pieces of element (slot, k = 8h + t) sum to the fp32 element exactly."""
+    from glass_amd import _lib
+    if not _lib.load().glass_dense_product_form():
+        return
+    assert full.numel() == n_fp32 * 5 // 2
+    fp = full[:n_fp32].reshape(-1, 4, 256, 4)                     # [tile][k-quad][slot][4 k]
+    cut = full[n_fp32:].contiguous().view(torch.int16).reshape(-1, 3, 2, 256, 8)  # [tile][piece][h][slot][8 k]
+    pieces = (cut.to(torch.int32) << 16).view(torch.float32)     # bf16 -> fp32
+    total = pieces[:, 0].double() + pieces[:, 1].double() + pieces[:, 2].double()   # [tile][h][slot][8]
+    want = fp.reshape(-1, 2, 2, 256, 4).permute(0, 1, 3, 2, 4).reshape(-1, 2, 256, 8).double()  # k-quads 2h, 2h+1 side by side
+    assert torch.equal(total, want)
+
+
 def test_dense_pack_effective_weight_appendix():
     """Layout 4 (comb pair's data-gradient operand at hidden 256 / 512): the plain image, then the effective weight of
     unlabeled rows (1 - z) * B[:, :KT/2] + z * B[:, KT/2:] in the same tiling over K = KT / 2."""
@@ -752,17 +769,18 @@ def test_dense_pack_effective_weight_appendix():
     assert _lib.load().glass_dual_linear_dgrad_layout(128, 256) == 4
     gen = torch.Generator().manual_seed(3)
     W = torch.randn(2 * H, 2 * H, generator=gen).to(DEV)  # comb weight [2H out][2H in]; operand B = W^T: [NT = 2H in][KT = 2H out]
-    img = torch.empty(W.numel() * 3 // 2, device=DEV)
+    img = torch.empty(int(_lib.load().glass_dense_image_floats(2 * H, 2 * H, 1 | (4 << 1))), device=DEV)
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([2 * H], dtype=np.int64), np.array([2 * H], dtype=np.int64)
     trs, zs = np.array([1 | (4 << 1)], dtype=np.int32), np.array([z], dtype=np.float32)
     rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                 trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
-    assert torch.equal(img[:W.numel()], _pack(W, True, H))  # the plain part is layout 2
+    assert torch.equal(img[:W.numel()], _pack(W, True, H)[:W.numel()])  # the plain part is layout 2
+    _check_cut_image(img.cpu(), W.numel() * 3 // 2)  # (the cut image covers the appendix too)
     B = W.t().cpu()
     Beff = ((1 - np.float32(z)) * B[:, :H] + np.float32(z) * B[:, H:])
-    app = img[W.numel():].cpu()
+    app = img[W.numel():W.numel() * 3 // 2].cpu()
     NT, K2 = 2 * H, H
     NKS = K2 // 16
     for (ct, ks, q, nl) in ((0, 0, 0, 0), (NT // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (1, 5, 1, 200)):
@@ -781,17 +799,18 @@ def test_dense_pack_forward_effective_weight_appendix():
     assert _lib.load().glass_dual_linear_fwd_layout(128, 256) == 1 and _lib.load().glass_dual_linear_fwd_layout(64, 128) == 0
     gen = torch.Generator().manual_seed(4)
     W = torch.randn(2 * H, 2 * H, generator=gen).to(DEV)  # comb weight [2H out][2H in] = the operand B itself
-    img = torch.empty(W.numel() * 3 // 2, device=DEV)
+    img = torch.empty(int(_lib.load().glass_dense_image_floats(2 * H, 2 * H, 0 | (5 << 1))), device=DEV)
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([2 * H], dtype=np.int64), np.array([2 * H], dtype=np.int64)
     trs, zs = np.array([0 | (5 << 1)], dtype=np.int32), np.array([z], dtype=np.float32)
     rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                 trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
-    assert torch.equal(img[:W.numel()], _pack(W, False, H))  # the first part is the paired layout
+    assert torch.equal(img[:W.numel()], _pack(W, False, H)[:W.numel()])  # the first part is the paired layout
+    _check_cut_image(img.cpu(), W.numel() * 3 // 2)
     Wc = W.cpu()
     Weff = (1 - np.float32(z)) * Wc[:H] + np.float32(z) * Wc[H:]
-    app = img[W.numel():].cpu()
+    app = img[W.numel():W.numel() * 3 // 2].cpu()
     NKS = 2 * H // 16
     for (ct, ks, q, nl) in ((0, 0, 0, 0), (H // 256 - 1, NKS - 1, 3, 255), (0, 3, 2, 97), (0, 17, 1, 200)):
         wn, cb, j = nl >> 7, (nl >> 5) & 3, nl & 31
