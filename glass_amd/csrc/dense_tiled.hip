@@ -127,12 +127,6 @@ struct BStage {
 #pragma unroll
         for (int i = 0; i < PER; ++i) B[threadIdx.x + kTThreads * i] = v[i];
     }
-    // split form, 256 slots: this thread holds all 16 k of slot threadIdx.x (k-quad i in v[i])
-    __device__ __forceinline__ void commit_split(float4* __restrict__ B) const {
-        static_assert(PER == 4, "256-slot column tiles");
-        SplitImg<256>::put8(B, threadIdx.x, 0, v[0], v[1]);
-        SplitImg<256>::put8(B, threadIdx.x, 1, v[2], v[3]);
-    }
 };
 
 // Split form: a K step's B operand is 24 KiB of the pre-cut image (glass_dense_pack_batch_f32 wrote it in LDS order, dense.hip
