@@ -1,9 +1,11 @@
 // fp32 products on the bf16 matrix cores (gfx950 has no xf32 / tf32 form and its f32-input MFMA runs at 1/16 of the bf16
-// rate).  An fp32 value is cut into three bf16 pieces, x = hi + mid + lo exactly up to 2^-27 |x| (each piece the RNE
-// rounding of what the pieces before it left), and a product x*w is the six partial products whose weight is >= 2^-18:
-//   mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi      (dropped: mid*lo, lo*mid, lo*lo <= 3 * 2^-27 |x w|)
+// rate).  An fp32 value is cut into three bf16 pieces, x = hi + mid + lo, each piece the RNE rounding of what the pieces
+// before it left.  The cut is EXACT for |x| >= 2^-100 (8 + 8 + 8 significant bits plus the two sign bits cover fp32's 24;
+// below ~2^-109 the low pieces reach the denormal range; tests/test_split_products.py), and a product x*w is the six partial
+// products whose weight is >= 2^-18:
+//   mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi      (dropped: mid*lo, lo*mid, lo*lo < 2^-24 |x w| together)
 // each one exact in the fp32 accumulator's input (8 x 8 significant bits), summed in fp32 by v_mfma_f32_32x32x16_bf16.
-// The truncation is below one fp32 rounding of the product (2^-24); measured against an fp64 product on this chip
+// The truncation is below one fp32 rounding of the product; measured against an fp64 product on this chip
 // (tools/split_lab.hip, profiles/r04_split_product_accuracy.txt) the result is as close as the f32-input MFMA's or
 // closer (the 16 k of one instruction are summed before the accumulator rounds), at 6/16 of its matrix-core cycles.
 // Non-finite input: the pieces of +-Inf are (Inf, NaN, NaN) -> the product is NaN where the f32 form gives Inf or NaN.

@@ -667,6 +667,42 @@ def test_both_product_forms_against_fp64(H, N, comb):
         assert e1 <= 2.0 * e0 + 2e-7, errs
 
 
+@pytest.mark.parametrize("H,N,comb", [(256, 70001, False), (256, 70001, True), (128, 50003, False)])
+def test_tiled_split_kernels_repeat_bitwise(H, N, comb):
+    """Race screen of the LDS-DMA weight operand (dense_tiled.hip: global_load_lds copies retired by vmcnt(0) + a barrier before
+    the stage is read, re-staged one barrier after its last read): forward + backward of a tiled pair 60 times on the same
+    inputs, every output bit-identical to the first run."""
+    import torch.nn as nn
+    from glass_amd import _lib, ops
+    if not _lib.load().glass_dense_product_form():
+        pytest.skip("split product form switched off")
+    gen = torch.Generator().manual_seed(11 + H + N)
+    K = 2 * H if comb else H
+    act = 0 if comb else 1
+    zr = 0.8
+    Wg = (torch.randn(2 * H, K, generator=gen) / K**0.5).to(DEV)
+    bg = (torch.randn(2 * H, generator=gen) * 0.1).to(DEV)
+    xa_h, xb_h = torch.randn(N, H, generator=gen).to(DEV), torch.randn(N, H, generator=gen).to(DEV)
+    mask = (torch.rand(N, generator=gen) < 0.02).to(DEV).to(torch.uint8)
+    gout = torch.randn(N, H, generator=gen).to(DEV)
+    Wimg, WTimg = _pack(Wg, False, H, zr), _pack(Wg, True, H, zr)
+    first = None
+    for it in range(60):
+        dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
+        lin1, lin0 = nn.Linear(K, H).to(DEV), nn.Linear(K, H).to(DEV)
+        lin1.weight.grad, lin0.weight.grad, lin1.bias.grad, lin0.bias.grad = dW[:H], dW[H:], db[:H], db[H:]
+        xa = xa_h.clone().requires_grad_(True)
+        xb = xb_h.clone().requires_grad_(True) if comb else None
+        out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask, zr, act, (Wg, bg, dW, db, Wimg, WTimg))
+        out.backward(gout)
+        got = [out.detach(), xa.grad] + ([xb.grad] if comb else []) + [dW, db]
+        if first is None:
+            first = [g.clone() for g in got]
+        else:
+            for a, b in zip(got, first):
+                assert torch.equal(a, b), f"run {it} differs from run 0"
+
+
 def _pack(W, transposed, H=64, z=None):
     """glass_dense_pack_batch_f32 on one matrix: operand image of W ([NT][KT]) or of W^T, in the layout the fused dense
     kernels of hidden size H read.  z = the pair's z_ratio: the layout the KERNELS read for this operand (the library's
