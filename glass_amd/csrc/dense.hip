@@ -3473,7 +3473,7 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
         const bool tiled_layout = layout == kLayoutTiledPaired || layout == kLayoutTiledPlain || layout == kLayoutTiledSplit ||
                                   layout == kLayoutTiledPlainEff || layout == kLayoutTiledPairedEff;
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f,
-                           (tiled_layout && tiled_split_products()) ? 1 : 0};
+                           tiled_layout ? 1 : 0};  // (always: a later glass_dense_product_form_set never meets a stale image)
     }
     unsigned gx = 32;
     if (tab.W && (unsigned)ceil_div(tab.H, kTabCols) > gx) gx = (unsigned)ceil_div(tab.H, kTabCols);
@@ -3485,7 +3485,7 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
 
 // Floats an operand image of (NT, KT, flags = transposed | layout << 1) occupies: NT*KT, + half of it for the effective-weight
 // appendix of layouts 4 / 5, and for the tiled layouts (1..5) the same again x 3/2 behind it — the image cut into bf16 pieces
-// that the split product form reads (written when glass_dense_product_form() == 1 at pack time).
+// that the split product form reads (always written, whatever the product form at pack time).
 extern "C" int64_t glass_dense_image_floats(int64_t NT, int64_t KT, int32_t flags) {
     if (NT <= 0 || KT <= 0) return GLASS_E_ARG;
     const int layout = flags >> 1;

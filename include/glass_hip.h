@@ -529,8 +529,8 @@ int glass_spmm_reduce_rows_f32(const float* partials, float* Y, int64_t ldy, int
  *     once-per-step prologue work; equivalent to a following glass_rng_advance). */
 /* Floats the image buffer dst[j] of a pack job must hold: NT*KT; + half of that for the effective-weight appendix of layouts
  * 4 / 5; and for the tiled layouts (1..5) 3/2 of the sum again behind it — the same image cut into three bf16 pieces per
- * element in the order the LDS-tiled kernels copy it to LDS, written when glass_dense_product_form() == 1 at pack time and read
- * by the kernels in that form (so: re-pack after glass_dense_product_form_set).  Host arithmetic; GLASS_E_ARG for NT, KT <= 0. */
+ * element in the order the LDS-tiled kernels copy it to LDS, always written by the pack kernel and read by the kernels in
+ * product form 1 (glass_dense_product_form_set needs no re-pack).  Host arithmetic; GLASS_E_ARG for NT, KT <= 0. */
 int64_t glass_dense_image_floats(int64_t NT, int64_t KT, int32_t flags);
 int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
                                const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,

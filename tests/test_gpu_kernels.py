@@ -781,11 +781,8 @@ def test_dense_pack_tiled_layouts():
 
 
 def _check_cut_image(full, n_fp32):
-    """The cut image behind a tiled fp32 image (glass_dense_image_floats; written in product form 1): per tile of 16 k x 256
+    """The cut image behind a tiled fp32 image (glass_dense_image_floats; written in either product form): per tile of 16 k x 256
     slots [piece 3][h 2][slot 256] x 8 bf16 — the three pieces of element (slot, k = 8h + t) sum to the fp32 element exactly."""
-    from glass_amd import _lib
-    if not _lib.load().glass_dense_product_form():
-        return
     assert full.numel() == n_fp32 * 5 // 2
     fp = full[:n_fp32].reshape(-1, 4, 256, 4)                     # [tile][k-quad][slot][4 k]
     cut = full[n_fp32:].contiguous().view(torch.int16).reshape(-1, 3, 2, 256, 8)  # [tile][piece][h][slot][8 k]
