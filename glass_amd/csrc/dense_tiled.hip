@@ -23,6 +23,25 @@
 #include <atomic>
 #include <type_traits>
 
+// Laboratory build only (-DGLASS_DENSE_TRACE; tools/tiled_trace.py): per-wave wall-clock stamps of the phases of the tiled
+// forward (sel 7) / data gradient (sel 8), [workgroup][wave][8 slots] — this translation unit's own trace words (device
+// symbols are not linked across translation units).
+#ifdef GLASS_DENSE_TRACE
+__device__ unsigned long long* g_tiled_trace;
+__device__ int g_tiled_trace_sel;
+#define T_STAMP(sel, slot)                                                                                         \
+    do {                                                                                                           \
+        if (g_tiled_trace && g_tiled_trace_sel == (sel) && (threadIdx.x & 63) == 0 && blockIdx.x < 4096)            \
+            g_tiled_trace[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64();            \
+    } while (0)
+extern "C" int glass_tiled_trace_set(unsigned long long* p, int sel) {
+    int rc = (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tiled_trace), &p, sizeof(p));
+    return rc ? rc : (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tiled_trace_sel), &sel, sizeof(sel));
+}
+#else
+#define T_STAMP(sel, slot) do { } while (0)
+#endif
+
 namespace glass {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -50,6 +69,17 @@ bool tiled_shape_ok(int64_t H) { return H == 128 || H == 256 || H == 512; }
 // forward where halving the column tiles is possible (hidden 128 has a single one)
 bool tiled_eff_dgrad_shape(int64_t H, int64_t n_out) { return tiled_shape_ok(H) && n_out == 2 * H; }
 bool tiled_eff_fwd_shape(int64_t H, int64_t K) { return (H == 256 || H == 512) && K == 2 * H; }
+bool tiled_split_products();
+// hidden 128: 64-row tiles in the f32-input form (782 workgroups at N = 50 000, four per CU); 128-row tiles in the split form —
+// its stages are 60 KiB at 64 rows too, so only two workgroups fit a CU and 782 of them ran as two rounds (the second one a
+// third full), each re-streaming the whole 196 KiB weight image for 64 rows; 391 tiles of 128 rows are ONE round with half
+// the weight traffic (phase stamps of tools/tiled_trace.py)
+static bool tall128() {
+    static const bool on = [] { const char* e = getenv("GLASS_TILED_H128_ROWS128"); return !(e && e[0] == '0'); }();
+    return on && tiled_split_products();
+}
+// rows per statistics partial: 64 at hidden 128 in either case (the staged hidden-128 kernels of dense.hip share that geometry;
+// a 128-row tile writes the partials of its two row waves separately)
 int tiled_rows(int64_t H) { return H == 128 ? 64 : 128; }
 
 
@@ -284,9 +314,11 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[rb][cb][i] = 0.f;
 
+    T_STAMP(7, 0);
     issue(0);
     commit(0, smem);
     __syncthreads();
+    T_STAMP(7, 1);
     for (int ks = 0; ks < NKS; ++ks) {
         float4* cur = smem + (ks & 1) * SG::kStage;
         float4* nxt = smem + ((ks + 1) & 1) * SG::kStage;
@@ -296,6 +328,7 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
         if (ks + 1 < NKS) commit(ks + 1, nxt);  // the other buffer: last read in stage ks - 1, before the previous barrier
         __syncthreads();
     }
+    T_STAMP(7, 2);
 
     if (EFF && pure) {
         // A labeled row r is owed  (z - (1-z)) * ( sum_k A[r,k] (W1[c][k] - W0[c][k]) + b1[c] - b0[c] )  in every column c:
@@ -418,6 +451,7 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
                 s1 += (double)oy; q1 += (double)oy * (double)oy;
             }
         }
+    T_STAMP(7, 3);
     if (stats == nullptr) return;
     // stats[rt][2][H]: sum / sum of squares of this row tile, columns of this column tile (fp64 from the first add)
     s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32); q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
@@ -428,11 +462,23 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
         red[(wm * 128 + c + 1) * 2] = s1; red[(wm * 128 + c + 1) * 2 + 1] = q1;
     }
     __syncthreads();
-    if (tid < 128) {
+    if (H == 128 && BM == 128) {  // partials per 64 rows (tiled_rows): one per row wave
+        if (tid < 128) {
+#pragma unroll
+            for (int hw = 0; hw < 2; ++hw) {
+                const int64_t part = 2 * (int64_t)rt + hw;
+                if (part * 64 < N) {
+                    stats[((size_t)part * 2) * H + ct * 128 + tid] = red[(hw * 128 + tid) * 2];
+                    stats[((size_t)part * 2 + 1) * H + ct * 128 + tid] = red[(hw * 128 + tid) * 2 + 1];
+                }
+            }
+        }
+    } else if (tid < 128) {
         const double s = red[tid * 2] + red[(128 + tid) * 2], q = red[tid * 2 + 1] + red[(128 + tid) * 2 + 1];
         stats[((size_t)rt * 2) * H + ct * 128 + tid] = s;
         stats[((size_t)rt * 2 + 1) * H + ct * 128 + tid] = q;
     }
+    T_STAMP(7, 4);
 }
 
 // ---- backward data gradient ---------------------------------------------------------------------------------------
@@ -560,9 +606,11 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
     // the K loop with a compile-time trip count (a run-time bound sent the staging registers to scratch memory)
     auto k_loop = [&](auto n_c) __attribute__((always_inline)) {
         constexpr int n = decltype(n_c)::value;
-            issue(0);
+        T_STAMP(8, 0);
+        issue(0);
         commit(0, smem);
         __syncthreads();
+        T_STAMP(8, 1);
         for (int ks = 0; ks < n; ++ks) {
             float4* cur = smem + (ks & 1) * kStage;
             float4* nxt = smem + ((ks + 1) & 1) * kStage;
@@ -575,6 +623,7 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
     };
     if (EFF && pure) k_loop(std::integral_constant<int, NKS / 2>{});
     else k_loop(std::integral_constant<int, NKS>{});
+    T_STAMP(8, 2);
     if (SPLIT) {  // right wave column -> left wave column (same row block, same lane <-> same rows and column slots)
         float* xf = reinterpret_cast<float*>(smem);
         if (wn == 1) {
@@ -687,6 +736,7 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
                 }
             }
         }
+    T_STAMP(8, 3);
     if (gs.partial == nullptr) return;
     // partial[rt][2][H] over this row tile: lanes h = 0/1, then the two row waves through LDS
     double* red = reinterpret_cast<double*>(smem);  // [wm][BN columns][2]
@@ -708,7 +758,18 @@ __global__ __launch_bounds__(kTThreads, S3 ? 2 : (SPLIT ? 3 : (BM == 64 ? 4 : 2)
     }
     __syncthreads();
     const int c = ct * BN + tid;  // threads 0 .. BN-1 <-> the BN columns of this tile
-    if (tid < BN && c < H) {
+    if (H == 128 && BM == 128) {  // partials per 64 rows (tiled_rows): one per row wave
+        if (tid < BN && c < H) {
+#pragma unroll
+            for (int hw = 0; hw < 2; ++hw) {
+                const int64_t part = 2 * (int64_t)rt + hw;
+                if (part * 64 < N) {
+                    gs.partial[((size_t)part * 2) * H + c] = red[(hw * BN + tid) * 2];
+                    gs.partial[((size_t)part * 2 + 1) * H + c] = red[(hw * BN + tid) * 2 + 1];
+                }
+            }
+        }
+    } else if (tid < BN && c < H) {
         gs.partial[((size_t)rt * 2) * H + c] = red[tid * 2] + red[(BN + tid) * 2];
         gs.partial[((size_t)rt * 2 + 1) * H + c] = red[tid * 2 + 1] + red[(BN + tid) * 2 + 1];
     }
@@ -776,6 +837,10 @@ int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb,
         else                                                                                                         \
             tiled_fwd_launch<HH, BM, false>(xa, lda, xb, ldb, Wimg, bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, st); \
     }
+    if (H == 128 && tall128()) {
+        tiled_fwd_launch<128, 128, true>(xa, lda, xb, ldb, Wimg, bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, st);
+        return launch_status("glass_dual_linear_fwd_f32 (tiled)");
+    }
     GLASS_TFWD(128, 64) GLASS_TFWD(256, 128) GLASS_TFWD(512, 128)
 #undef GLASS_TFWD
     return launch_status("glass_dual_linear_fwd_f32 (tiled)");
@@ -813,6 +878,9 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
     }
     if (H == 128 && n_out == H) {  // trans pair: the two terms of the product side by side in one 256-slot tile
         GLASS_TDG1(128, 128, 64, 256, true)
+    } else if (H == 128 && tall128()) {
+        tiled_dgrad_launch<128, 256, 128, 256, false, true>(dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop,
+                                                            rng_state, out, ldo, N, gs, st);
     } else if (H == 128) {
         GLASS_TDG1(128, 256, 64, 256, false)
     } else if (H == 256) {
