@@ -322,10 +322,13 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
     for (int ks = 0; ks < NKS; ++ks) {
         float4* cur = smem + (ks & 1) * SG::kStage;
         float4* nxt = smem + ((ks + 1) & 1) * SG::kStage;
+        if (ks == 2) T_STAMP(7, 5);
         if (ks + 1 < NKS) issue(ks + 1);  // in flight across this stage's MFMAs
         if constexpr (S3) tile_mma_s<BM, 256>(acc, cur, cur + SG::kA, j, h, wm, wn);
         else tile_mma<BM, 256>(acc, cur, cur + SG::kA, j, h, wm, wn);
+        if (ks == 2) T_STAMP(7, 6);
         if (ks + 1 < NKS) commit(ks + 1, nxt);  // the other buffer: last read in stage ks - 1, before the previous barrier
+        if (ks == 2) T_STAMP(7, 7);
         __syncthreads();
     }
     T_STAMP(7, 2);

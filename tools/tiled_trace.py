@@ -56,6 +56,12 @@ def main():
             d = (t[:, :, slot] - t[:, :, prev])[ok]
             print(f"   phase {nm:16s} ({prev}->{slot}) mean {d.mean():.0f}  p50 {np.percentile(d, 50):.0f}  p90 {np.percentile(d, 90):.0f}  max {d.max():.0f}")
             prev = slot
+        if sel == 7:  # inside K step 2 of the forward: 5 top, 6 MFMAs issued, 7 next stage committed (before the barrier)
+            for a, b, nm in ((5, 6, "step 2: loads issued + MFMAs"), (6, 7, "step 2: wait + cut + LDS writes")):
+                ok = live & (t[:, :, a] > 0) & (t[:, :, b] > 0)
+                if ok.any():
+                    d = (t[:, :, b] - t[:, :, a])[ok]
+                    print(f"   {nm:34s} mean {d.mean():.0f}  p50 {np.percentile(d, 50):.0f}  p90 {np.percentile(d, 90):.0f}")
         end = t[:, :, prev][live & (t[:, :, prev] > 0)] - t0
         print(f"   end    p10/p50/p90/max {np.percentile(end, 10):.0f}/{np.percentile(end, 50):.0f}/{np.percentile(end, 90):.0f}/{end.max():.0f}")
         # early starters against late starters: the second round of workgroups
