@@ -105,18 +105,26 @@ class Run:
 
     def build_model(self, hidden_dim, conv_layer, dropout, jk, pool, z_ratio, aggr):
         a = self.args
-        conv = models.EmbZGConv(hidden_dim, hidden_dim, conv_layer, max_deg=self.max_deg,
-                                activation=nn.ELU(inplace=True), jk=jk, dropout=dropout,
-                                conv=functools.partial(models.GLASSConv, aggr=aggr, z_ratio=z_ratio, dropout=dropout),
-                                gn=True)
-        if a.use_nodeid:
-            print("load ", f"./Emb/{a.dataset}_{hidden_dim}.pt")
-            emb = torch.load(f"./Emb/{a.dataset}_{hidden_dim}.pt", map_location=torch.device("cpu")).detach()
-            conv.input_emb = nn.Embedding.from_pretrained(emb, freeze=False)
-        mlp = nn.Linear(hidden_dim * conv_layer if jk else hidden_dim, self.output_channels)
         if pool not in POOLS:
             raise NotImplementedError
-        return models.GLASS(conv, nn.ModuleList([mlp]), nn.ModuleList([POOLS[pool]()])).to(config.device)
+
+        def build(h):
+            conv = models.EmbZGConv(h, h, conv_layer, max_deg=self.max_deg,
+                                    activation=nn.ELU(inplace=True), jk=jk, dropout=dropout,
+                                    conv=functools.partial(models.GLASSConv, aggr=aggr, z_ratio=z_ratio, dropout=dropout),
+                                    gn=True)
+            if a.use_nodeid:
+                print("load ", f"./Emb/{a.dataset}_{hidden_dim}.pt")
+                emb = torch.load(f"./Emb/{a.dataset}_{hidden_dim}.pt", map_location=torch.device("cpu")).detach()
+                if h > emb.shape[1]:  # (a width no kernel family serves runs zero-padded: glass_amd/widths.py)
+                    emb = torch.nn.functional.pad(emb, (0, h - emb.shape[1]))
+                conv.input_emb = nn.Embedding.from_pretrained(emb, freeze=False)
+            mlp = nn.Linear(h * conv_layer if jk else h, self.output_channels)
+            return models.GLASS(conv, nn.ModuleList([mlp]), nn.ModuleList([POOLS[pool]()]))
+
+        # widths outside the kernel families (every shipped config is inside) run at the next family width, zero padded: exact
+        from glass_amd import widths
+        return widths.build_at_fused_width(hidden_dim, build).to(config.device)
 
     def evaluate(self, model, loader):
         """Score of the task metric on one split."""
