@@ -74,9 +74,11 @@ bool tiled_split_products();
 // its stages are 60 KiB at 64 rows too, so only two workgroups fit a CU and 782 of them ran as two rounds (the second one a
 // third full), each re-streaming the whole 196 KiB weight image for 64 rows; 391 tiles of 128 rows are ONE round with half
 // the weight traffic (phase stamps of tools/tiled_trace.py)
-static bool tall128() {
+// ... when the 64-row tiles would not all be resident at once (more than 512 of them); a smaller graph keeps the finer
+// tiles (hidden 96 padded to 128 at N = 17 080: 267 workgroups of 64 rows fill the chip, 134 of 128 rows half of it)
+static bool tall128(int64_t N) {
     static const bool on = [] { const char* e = getenv("GLASS_TILED_H128_ROWS128"); return !(e && e[0] == '0'); }();
-    return on && tiled_split_products();
+    return on && tiled_split_products() && ceil_div(N, 64) > 512;
 }
 // rows per statistics partial: 64 at hidden 128 in either case (the staged hidden-128 kernels of dense.hip share that geometry;
 // a 128-row tile writes the partials of its two row waves separately)
@@ -840,7 +842,7 @@ int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb,
         else                                                                                                         \
             tiled_fwd_launch<HH, BM, false>(xa, lda, xb, ldb, Wimg, bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, st); \
     }
-    if (H == 128 && tall128()) {
+    if (H == 128 && tall128(N)) {
         tiled_fwd_launch<128, 128, true>(xa, lda, xb, ldb, Wimg, bias, mask, zr, omz, act, T, ldt, out, ldo, N, stats, pro, st);
         return launch_status("glass_dual_linear_fwd_f32 (tiled)");
     }
@@ -881,7 +883,7 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
     }
     if (H == 128 && n_out == H) {  // trans pair: the two terms of the product side by side in one 256-slot tile
         GLASS_TDG1(128, 128, 64, 256, true)
-    } else if (H == 128 && tall128()) {
+    } else if (H == 128 && tall128(N)) {
         tiled_dgrad_launch<128, 256, 128, 256, false, true>(dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop,
                                                             rng_state, out, ldo, N, gs, st);
     } else if (H == 128) {
