@@ -169,7 +169,7 @@ class DenseCaps(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("family", "weight_layout", "fwd_layout_trans", "fwd_layout_comb", "dgrad_layout_trans",
                                               "dgrad_layout_comb", "stat_rows", "fwd_gather", "gn_exact", "gn_exact_fwd", "comb_eff",
                                               "comb_eff_fwd", "comb_eff_fwd_layout", "comb_eff_dgrad_layout2", "pair_head", "act_codes",
-                                              "product_form")]
+                                              "product_form", "serve_width")]
 
 
 _caps = {}

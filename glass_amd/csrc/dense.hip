@@ -2863,6 +2863,7 @@ extern "C" int glass_dense_caps_query(int64_t H, glass_dense_caps* out) {
         c.act_codes = (1 << GLASS_ACT_ELU) | (1 << GLASS_ACT_RELU);
         c.product_form = (c.family == 3 && tiled_split_products()) ? 1 : 0;
     }
+    c.serve_width = c.family ? (int32_t)H : (H <= 64 ? 64 : H <= 128 ? 128 : H <= 256 ? 256 : H <= 512 ? 512 : 0);
     c.gn_exact = glass_gn_exact_supported(H);
     c.gn_exact_fwd = glass_gn_exact_fwd_supported(H);
     c.comb_eff = glass_comb_eff_supported(H);

@@ -17,18 +17,14 @@ concatenation in the last GraphNorm and the head), and block b maps to physical 
 """
 import torch
 
-FAMILY_WIDTHS = (64, 128, 256, 512)
-
 
 def fused_width(hidden):
-    """The width the fused step program runs `hidden` at (hidden itself when a kernel family serves it or none can)."""
+    """The width the fused step program runs `hidden` at (hidden itself when a kernel family serves it or none can): the
+    library's own answer, glass_dense_caps(hidden).serve_width."""
     hidden = int(hidden)
-    if hidden <= 32 or hidden in FAMILY_WIDTHS:
-        return hidden
-    for w in FAMILY_WIDTHS:
-        if w >= hidden:
-            return w
-    return hidden
+    from . import _lib
+    w = int(_lib.dense_caps(hidden).serve_width)
+    return w if w > 0 else hidden
 
 
 def _dim_index(log_size, phys_size, H, Hp, device):

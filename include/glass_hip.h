@@ -361,6 +361,10 @@ typedef struct glass_dense_caps {
     int32_t act_codes;         /* bit mask of the activation codes the family fuses: 1 << GLASS_ACT_ELU | 1 << GLASS_ACT_RELU */
     int32_t product_form;      /* how an fp32 product is formed on the matrix cores: 0 f32-input MFMA (an fmaf chain), 1 six bf16
                                   partial products of 3-way split operands (glass_dense_product_form) */
+    int32_t serve_width;       /* the hidden width whose kernels serve H: H itself when family != 0; otherwise the next family
+                                  width (64 / 128 / 256 / 512) — a model laid out zero-padded to it computes the width-H model
+                                  exactly (padded columns stay 0 through every layer, padded parameters get zero gradients;
+                                  glass_amd/widths.py) —; 0 when H > 512 */
 } glass_dense_caps;
 int glass_dense_caps_query(int64_t H, glass_dense_caps* out);
 /* Product form of the LDS-tiled family (hidden 128 / 256 / 512), process-wide.  gfx950 has no tf32 / xf32 and its f32-input

@@ -272,6 +272,8 @@ def test_dense_capability_record():
         assert c.fwd_gather == lib.glass_dual_linear_fwd_gather_supported(h)
         assert c.gn_exact == lib.glass_gn_exact_supported(h) and c.comb_eff == lib.glass_comb_eff_supported(h)
         assert c.act_codes == (1 << 1) | (1 << 2)   # ELU and ReLU fused at every served width
+    assert [_lib.dense_caps(h).serve_width for h in (8, 20, 33, 48, 64, 96, 128, 200, 256, 300, 512, 600)] == \
+        [8, 20, 64, 64, 64, 128, 128, 256, 256, 512, 512, 0]
     c64, c128 = _lib.dense_caps(64), _lib.dense_caps(128)
     assert c64.pair_head == 1 and c128.pair_head == 0 and c64.comb_eff == 1 and c128.comb_eff == 0 and c128.comb_eff_fwd == 1
     assert lib.glass_dense_caps_query(0, None) == -1
