@@ -90,6 +90,11 @@ def parse(argv=None):
                     help="eval: the evaluation loop's forward passes (impl/train.py:20-34) over the same batches — one batch per "
                          "step, K batches side by side as parallel branches of one hipGraph (glass_amd/evalstep.py)")
     ap.add_argument("--eval-parallel", type=int, default=8, help="--mode eval: batches per replay (the sequential form is timed too)")
+    ap.add_argument("--caller", default="step", choices=["step", "reference"],
+                    help="step: bench.py drives glass_amd.step.TrainStep itself (flat arena + FlatAdam built here).  reference: "
+                         "the step is reached the way /root/reference/GLASSTest.py reaches it — buildModel's constructions, "
+                         "torch.optim.Adam(model.parameters()), the driver's own loss callable, ZGDataloader(z_fn=MaxZOZ, "
+                         "shuffle, drop_last) — through impl.train.train, one epoch of exactly --steps batches per timed block")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher / process-group plumbing only (no GPU work; value is null) — CPU-box smoke")
     return ap.parse_args(argv)
@@ -541,7 +546,8 @@ def main():
     from glass_amd import synth, ops, graph as ggraph, _lib
     from glass_amd.factory import build_glass
 
-    n_batches = 16
+    ref_caller = args.caller == "reference"
+    n_batches = args.steps if ref_caller else 16  # (reference caller: one epoch of the loader = one timed block)
     w, (ei_np, ew_np, x_np, pos_np, y_np), share = shared_workload(args.workload, n_batches, world, rank)
     try:
         if world > 1:
@@ -567,9 +573,15 @@ def main():
     model.train()
     from glass_amd.arena import ParamArena
     from glass_amd.optim import FlatAdam
-    bucket = ParamArena(model)  # flat params + grads: stacked weight views, fused Adam, bucketed all-reduce
-    opt = FlatAdam(bucket, lr=w.lr)
-    loss_fn = loss_fn_for(w)
+    if ref_caller:
+        # exactly the reference driver's objects (GLASSTest.py:57-58 / 69, 213): nothing of glass_amd is named here
+        torch_opt = torch.optim.Adam(model.parameters(), lr=w.lr)
+        loss_fn = (lambda p, t: nn.BCEWithLogitsLoss()(p.flatten(), t.flatten())) if w.multilabel else nn.CrossEntropyLoss()
+        bucket = opt = None  # what impl.train.train builds underneath is picked up after the first epoch
+    else:
+        bucket = ParamArena(model)  # flat params + grads: stacked weight views, fused Adam, bucketed all-reduce
+        opt = FlatAdam(bucket, lr=w.lr)
+        loss_fn = loss_fn_for(w)
     xg, eig, ewg = x.to(dev), ei.to(dev), ew.to(dev)
     # this rank's batches: rank r owns batches r, r+world, ...  (disjoint subgraphs; weak scaling)
     pos_g = pos.to(dev).reshape(n_batches * world, w.batch, -1)[rank::world].contiguous()
@@ -580,13 +592,31 @@ def main():
         return eval_mode(args, w, model, xg, eig, ewg, pos_g, nnz, N, H, L, world, rank, local_rank, backend, dev)
 
     from glass_amd.step import TrainStep
-    stepper = TrainStep(model, opt, loss_fn, xg, eig, ewg, bucket, use_graph=bool(args.graph))
-    stepper.time_collective = world > 1  # HIP events around the exchange / optimizer part of every step
+    if ref_caller:
+        from impl import SubGDataset as rSub, train as rtrain, utils as rutils
+        ds = rSub.GDataset(xg, eig, ewg, pos_g.reshape(-1, pos_g.shape[-1]), y_g.reshape(-1, *y_g.shape[2:]))
+        loader = rSub.ZGDataloader(ds, w.batch, z_fn=rutils.MaxZOZ, shuffle=True, drop_last=True)  # GLASSTest.py:107-113
+        assert len(loader) == args.steps
+        rtrain.train(torch_opt, model, loader, loss_fn)  # first epoch: adoption, warm-up, capture
+        steps_built = model.__dict__.get("_glass_train_steps") or {}
+        if len(steps_built) != 1:
+            raise SystemExit("bench.py --caller reference: impl.train.train did not take the TrainStep path")
+        stepper = next(iter(steps_built.values()))
+        opt, bucket = stepper.opt, stepper.bucket
+        if not (stepper._program_step() and (stepper.graphed or not args.graph)):
+            raise SystemExit("bench.py --caller reference: the reference caller is not on the captured step program")
 
-    def run(k, offset):
-        for i in range(k):
-            b = (offset + i) % n_batches
-            stepper(pos_g[b], y_g[b])
+        def run(k, offset):
+            for _ in range(-(-k // args.steps)):  # whole epochs (the warm-up count is rounded up to one)
+                rtrain.train(torch_opt, model, loader, loss_fn)
+    else:
+        stepper = TrainStep(model, opt, loss_fn, xg, eig, ewg, bucket, use_graph=bool(args.graph))
+
+        def run(k, offset):
+            for i in range(k):
+                b = (offset + i) % n_batches
+                stepper(pos_g[b], y_g[b])
+    stepper.time_collective = world > 1  # HIP events around the exchange / optimizer part of every step
 
     def barrier():
         if world > 1:
@@ -815,6 +845,10 @@ def main():
                                    f"{'use_nodeid (V=N)' if args.features == 'nodeid' else 'use_deg'} features, Adam",
                        "parallelism": f"subgraph-batch dp{world}, replicated graph, bucketed gradient all-reduce per step",
                        "step": "MaxZOZ+fwd+loss+bwd+allreduce+Adam", "hip_graph": bool(stepper.graphed),
+                       "caller": ("reference: GLASSTest.py's own objects (buildModel constructions, torch.optim.Adam, its loss callable, "
+                                  "ZGDataloader shuffle+drop_last) through impl.train.train — one epoch (incl. its host sync, the "
+                                  "shuffle and the batch selection) per timed block") if ref_caller else
+                                 "step: bench.py calls glass_amd.step.TrainStep on pre-selected batches",
                        "final_loss": last_loss},
             "roofline": roofline, "roofline_hbm": hbm, "step_breakdown": step_breakdown, "cpu_baseline": cpu,
         }

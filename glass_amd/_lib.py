@@ -24,7 +24,7 @@ AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
 ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 PLAN_HEADER_WORDS = 16
 EMBED_NORM_MAX_ROWS = 8192  # GLASS_EMBED_NORM_MAX_ROWS
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GlassHipError(RuntimeError):
@@ -87,7 +87,7 @@ SIGNATURES = {
     "glass_readout_supported": (c_int, [_I, _I, c_int]),
     "glass_readout_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_readout_train_f32": (c_int, [_P, _I, _P, _P, _P, _P, _I, _I, c_int, _P, _P, _P, c_int, _I, _P, _P, _P, _P, _P, _I,
-                                        _P, _P, c_int, _P, _P, _P, c_int, _P, _I, _I, _P, _P, _P, _P, _P, c_int, _P, _P]),
+                                        _P, _P, c_int, _P, _P, _P, c_int, _P, _I, _I, _P, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "glass_readout_scatter_ws_bytes": (c_int64, [_I, _I, _I]),
     "glass_linear_wgrad_reduce_batch_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "glass_wgrad_reduce_spmm_f32": (c_int, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, _I, _P, _P,
@@ -145,6 +145,7 @@ SIGNATURES = {
     "glass_head_loss_bwd_f32": (c_int, [_P, _I, _P, _P, _P, c_int, _P, _I, _I, _I, _P, _I, _P, _P, c_int, _P]),
     "glass_batch_labels_ws_bytes": (c_int64, [_I]),
     "glass_batch_labels": (c_int, [_P, _I, _P, _P, _P, _I, _P, _P, _P, _P, _I, c_int, _P]),
+    "glass_batch_labels_gather": (c_int, [_P, _I, _I, _P, _I, _P, _I, _P, _P, _P, _P, _P, _P, _I, c_int, _P]),
     "glass_comb_eff_supported": (c_int, [_I]),
     "glass_comb_eff_blocks": (c_int64, [_I, _I, _I]),
     "glass_comb_eff_fwd_blocks": (c_int64, [_I, _I, _I]),

@@ -240,6 +240,23 @@ class ParamArena(FlatGradBucket):
         return all(p.data.untyped_storage().data_ptr() == base_p and p.grad is not None
                    and p.grad.untyped_storage().data_ptr() == base_g for p in self.params)
 
+    def reattach(self):
+        """Point every parameter's .grad (and .data, if something re-allocated it) back into the flat buffers: what
+        `optimizer.zero_grad()` with torch's default set_to_none=True (reference impl/train.py:11) undoes each step.  The
+        parameter VALUES are kept (copied into the arena when .data had moved); a gradient tensor living elsewhere is dropped
+        — it is rewritten before it is read."""
+        base_p = self.flat_param.untyped_storage().data_ptr()
+        base_g = self.flat.untyped_storage().data_ptr()
+        with torch.no_grad():
+            for p in self.params:
+                o = self._offsets[id(p)]
+                if p.data.untyped_storage().data_ptr() != base_p:
+                    view = self.flat_param[o:o + p.numel()].view_as(p)
+                    view.copy_(p.data)
+                    p.data = view
+                if p.grad is None or p.grad.untyped_storage().data_ptr() != base_g:
+                    p.grad = self.flat[o:o + p.numel()].view_as(p)
+
     @property
     def exchange(self):
         """dist.GradExchange over this arena (built on first use, once a process group with > 1 rank exists)."""

@@ -21,9 +21,29 @@ namespace glass {
 
 constexpr int kLabThreads = 1024;
 
-__global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t* __restrict__ pos_src, int n_pos,
+// Where the batch comes from.  Plain: pos_src / y_src ARE the batch.  Gather (kGather): they are the data set's whole
+// padded node matrix [n_all, smax] and target matrix [n_all, y_row_words]; the batch is the rows idx[0 .. n_pos / smax) —
+// what ZGDataloader's `pos[perm], y[perm]` (impl/SubGDataset.py:69-72, 92-96) materialised with two index kernels and a
+// copy is read in place (one more dependent load per entry; a row index outside [0, n_all) reads as padding).
+struct BatchSrc {
+    const int64_t* pos;
+    const uint32_t* y;
+    const int64_t* idx;
+    int smax, y_row_words;
+    int64_t n_all;
+};
+
+template <bool kGather>
+__device__ __forceinline__ int64_t batch_entry(const BatchSrc& s, int e) {
+    if (!kGather) return s.pos[e];
+    const int r = e / s.smax;
+    const int64_t row = s.idx[r];
+    return (row >= 0 && row < s.n_all) ? s.pos[row * s.smax + (e - r * s.smax)] : -1;
+}
+
+template <bool kGather>
+__global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const BatchSrc src, int n_pos,
                                                                    int64_t* __restrict__ pos_dst,
-                                                                   const uint32_t* __restrict__ y_src,
                                                                    uint32_t* __restrict__ y_dst, int64_t y_words,
                                                                    uint8_t* __restrict__ mask,
                                                                    int32_t* __restrict__ lab_rows,
@@ -34,7 +54,7 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // this thread's first entry of the NEW batch is requested before anything else: its round trip runs beside phase 1's
     // (the barrier between the phases would otherwise put the two loads in a row)
-    const int64_t p_first = tid < n_pos ? pos_src[tid] : -1;
+    const int64_t p_first = tid < n_pos ? batch_entry<kGather>(src, tid) : -1;
     // 1. labels of the previous batch off (or all N bytes)
     if (incremental) {
         if (pos_dst)
@@ -54,20 +74,28 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
     // 2. the new batch: fixed buffers, label bytes; the lowest entry index naming a node owns it (owner words are
     //    INT32_MAX on entry)
     for (int e = tid; e < n_pos; e += kLabThreads) {
-        const int64_t p = e == tid ? p_first : pos_src[e];
+        const int64_t p = e == tid ? p_first : batch_entry<kGather>(src, e);
         if (pos_dst) pos_dst[e] = p;
         if (p >= 0 && p < N) {
             mask[p] = 1;
             atomicMin(owner + p, e);
         }
     }
-    for (int64_t k = tid; k < y_words; k += kLabThreads) y_dst[k] = y_src[k];
+    for (int64_t k = tid; k < y_words; k += kLabThreads) {
+        if (!kGather) {
+            y_dst[k] = src.y[k];
+        } else {
+            const int64_t r = k / src.y_row_words;
+            const int64_t row = src.idx[r];
+            y_dst[k] = (row >= 0 && row < src.n_all) ? src.y[row * src.y_row_words + (k - r * src.y_row_words)] : 0u;
+        }
+    }
     __syncthreads();
     // 3. owners, compacted in entry order
     int base = 0;
     for (int e0 = 0; e0 < n_pos; e0 += kLabThreads) {
         const int e = e0 + tid;
-        const int64_t p = e0 == 0 ? p_first : (e < n_pos ? pos_src[e] : -1);
+        const int64_t p = e0 == 0 ? p_first : (e < n_pos ? batch_entry<kGather>(src, e) : -1);
         const bool own = p >= 0 && p < N && __hip_atomic_load(owner + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e;
         const unsigned long long bal = __ballot(own);
         if (lane == 0) wave_cnt[w] = __popcll(bal);
@@ -84,7 +112,7 @@ __global__ __launch_bounds__(kLabThreads) void batch_labels_kernel(const int64_t
     if (tid == 0) lab_count[0] = base;
     // 4. the owner words of the named nodes back to INT32_MAX (every read of them lies before the loop's last barrier)
     for (int e = tid; e < n_pos; e += kLabThreads) {
-        const int64_t p = e == tid ? p_first : pos_src[e];
+        const int64_t p = e == tid ? p_first : batch_entry<kGather>(src, e);
         if (p >= 0 && p < N) owner[p] = INT32_MAX;
     }
 }
@@ -105,8 +133,26 @@ extern "C" int glass_batch_labels(const int64_t* pos_src, int64_t n_pos, int64_t
     GLASS_REQUIRE(y_bytes == 0 || (y_src && y_dst && y_bytes > 0 && y_bytes % 4 == 0 &&
                                    ((reinterpret_cast<uintptr_t>(y_src) | reinterpret_cast<uintptr_t>(y_dst)) & 3u) == 0),
                   "batch_labels: the target copy has 4-byte granularity");
-    hipLaunchKernelGGL(batch_labels_kernel, dim3(1), dim3(kLabThreads), 0, (hipStream_t)stream, pos_src, (int)n_pos, pos_dst,
-                       (const uint32_t*)y_src, (uint32_t*)y_dst, y_bytes / 4, mask, lab_rows, lab_count, (int32_t*)ws,
-                       n_nodes, incremental);
+    const BatchSrc src{pos_src, (const uint32_t*)y_src, nullptr, 1, 1, 0};
+    hipLaunchKernelGGL(batch_labels_kernel<false>, dim3(1), dim3(kLabThreads), 0, (hipStream_t)stream, src, (int)n_pos, pos_dst,
+                       (uint32_t*)y_dst, y_bytes / 4, mask, lab_rows, lab_count, (int32_t*)ws, n_nodes, incremental);
     return launch_status("glass_batch_labels");
+}
+
+extern "C" int glass_batch_labels_gather(const int64_t* pos_all, int64_t n_all, int64_t smax, const void* y_all,
+                                         int64_t y_row_bytes, const int64_t* idx, int64_t n_idx, int64_t* pos_dst, void* y_dst,
+                                         uint8_t* mask, int32_t* lab_rows, int32_t* lab_count, void* ws, int64_t n_nodes,
+                                         int incremental, void* stream) {
+    GLASS_REQUIRE(pos_all && idx && mask && lab_rows && lab_count && ws, "batch_labels_gather: null pointer");
+    GLASS_REQUIRE(n_all > 0 && smax > 0 && n_idx > 0 && n_idx * smax < (1ll << 30) && smax < (1ll << 30) && n_nodes > 0 &&
+                      n_nodes < (1ll << 31),
+                  "batch_labels_gather: bad sizes");
+    GLASS_REQUIRE(y_row_bytes == 0 || (y_all && y_dst && y_row_bytes > 0 && y_row_bytes % 4 == 0 && y_row_bytes < (1ll << 30) &&
+                                       ((reinterpret_cast<uintptr_t>(y_all) | reinterpret_cast<uintptr_t>(y_dst)) & 3u) == 0),
+                  "batch_labels_gather: the target rows have 4-byte granularity");
+    const BatchSrc src{pos_all, (const uint32_t*)y_all, idx, (int)smax, y_row_bytes ? (int)(y_row_bytes / 4) : 1, n_all};
+    hipLaunchKernelGGL(batch_labels_kernel<true>, dim3(1), dim3(kLabThreads), 0, (hipStream_t)stream, src, (int)(n_idx * smax),
+                       pos_dst, (uint32_t*)y_dst, n_idx * (y_row_bytes / 4), mask, lab_rows, lab_count, (int32_t*)ws, n_nodes,
+                       incremental);
+    return launch_status("glass_batch_labels_gather");
 }

@@ -296,6 +296,7 @@ struct R2Args {
     const float* pooled; ReadoutWs ws; int B, C, K, loss_mode;
     float *dWh, *dbh; int acc_head;
     float* loss;
+    float* loss_sum;  // running sum of the step losses (nullable): += this step's loss, same thread, fixed order
     int64_t n_nodes;
     const float *gamma, *alpha, *saved;
     float *dgamma, *dbeta, *dalpha; int acc_gn;
@@ -333,8 +334,11 @@ __global__ __launch_bounds__(kBlock) void readout_reduce_kernel(R2Args a) {
             if (tid < s) smd[tid] += smd[tid + s];
             __syncthreads();
         }
-        if (tid == 0)
-            a.loss[0] = (float)(smd[0] / (a.loss_mode == kLossCE ? (double)a.B : (double)a.B * (double)a.K));
+        if (tid == 0) {
+            const float l = (float)(smd[0] / (a.loss_mode == kLossCE ? (double)a.B : (double)a.B * (double)a.K));
+            a.loss[0] = l;
+            if (a.loss_sum) a.loss_sum[0] += l;
+        }
         return;
     }
     gn_finalize_bwd_block(blk - a.K - 1, a.ws.partial, a.B, a.C, a.n_nodes, a.gamma, a.alpha, a.saved, a.dgamma, a.dbeta,
@@ -460,6 +464,7 @@ struct BackfillFin {
     const float* pooled; const float* dlogits; const float* loss_rows;
     float *dWh, *dbh, *loss;
     int B, K, loss_mode, acc_head;
+    float* loss_sum;  // nullable: += the step's loss
 };
 
 __global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float* __restrict__ x, int64_t ldx,
@@ -496,8 +501,11 @@ __global__ __launch_bounds__(kOrdBlock) void readout_backfill_kernel(const float
             for (int b = tid; b < fin.B; b += kWave) part += (double)fin.loss_rows[b];
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
-            if (tid == 0)
-                fin.loss[0] = (float)(part / (fin.loss_mode == kLossCE ? (double)fin.B : (double)fin.B * (double)fin.K));
+            if (tid == 0) {
+                const float l = (float)(part / (fin.loss_mode == kLossCE ? (double)fin.B : (double)fin.B * (double)fin.K));
+                fin.loss[0] = l;
+                if (fin.loss_sum) fin.loss_sum[0] += l;
+            }
         }
         return;
     }
@@ -720,7 +728,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
                                        float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
                                        const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
                                        const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* scatter_ws,
-                                       void* stream) {
+                                       float* loss_sum, void* stream) {
     GLASS_REQUIRE(jk && gn_saved && gamma && alpha && pos && Wh && bh && target && grad_loss && pooled && logits && loss &&
                       djk && dWh && dbh && ws,
                   "readout_train: null pointer");
@@ -768,7 +776,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
         hipLaunchKernelGGL(readout_subgraph_kernel<4>, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
     else
         hipLaunchKernelGGL(readout_subgraph_kernel<1>, dim3((unsigned)B), dim3(kBlock), lds1, st, a1);
-    R2Args a2{pooled, w, (int)B, (int)C, (int)K, loss_mode, dWh, dbh, acc_head, loss, n_nodes, gamma, alpha, gn_saved,
+    R2Args a2{pooled, w, (int)B, (int)C, (int)K, loss_mode, dWh, dbh, acc_head, loss, loss_sum, n_nodes, gamma, alpha, gn_saved,
               dgamma, dbeta, dalpha, acc_gn};
     size_t lds2 = sizeof(double) * kBlock * 2;
     if (sizeof(float) * (size_t)B > lds2) lds2 = sizeof(float) * (size_t)B;
@@ -790,7 +798,7 @@ extern "C" int glass_readout_train_f32(const float* jk, int64_t ldj, const float
         unsigned extra = 0;
         if (two) {
             fin = BackfillFin{reinterpret_cast<const long long*>(gn_bwd_acc), gn_bwd_rep, gamma, alpha, gn_saved, dgamma, dbeta, dalpha,
-                              acc_gn, pooled, w.dlogits, w.loss_rows, dWh, dbh, loss, (int)B, (int)K, loss_mode, acc_head};
+                              acc_gn, pooled, w.dlogits, w.loss_rows, dWh, dbh, loss, (int)B, (int)K, loss_mode, acc_head, loss_sum};
             lds3 = sizeof(int32_t) * (size_t)((B * Smax + 1) & ~1ll) + sizeof(double) * 2 * (size_t)C + sizeof(float) * 3 * (size_t)C;
             if (lds3 < sizeof(float) * (size_t)B) lds3 = sizeof(float) * (size_t)B;
             extra = (unsigned)K + 1;

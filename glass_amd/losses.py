@@ -2,8 +2,9 @@
 
 `CrossEntropy()` / `BCEWithLogits()` behave exactly like the losses the reference driver builds
 (GLASSTest.py:57-58, 69) when called as `loss_fn(pred, y)`; in addition `glass_amd.step.TrainStep`
-recognises them and, when the model's head is a bare nn.Linear (GLASSTest.py:159-160), runs
-head + loss + their backward as two kernels (`glass_head_loss_fwd/bwd_f32`) instead of ~12 launches."""
+recognises them — and any callable that computes one of them, the reference driver's own lambda included (`fusable_mode`) —
+and, when the model's head is a bare nn.Linear (GLASSTest.py:159-160), runs head + loss + their backward as two kernels
+(`glass_head_loss_fwd/bwd_f32`) instead of ~12 launches."""
 import torch
 import torch.nn as nn
 
@@ -25,17 +26,82 @@ class BCEWithLogits(nn.Module):
         return nn.functional.binary_cross_entropy_with_logits(pred.flatten(), y.flatten())
 
 
+_PROBE_TOL = 1e-6
+_probed = {}  # id(loss_fn) -> (weakref or None, mode or None)
+
+
+def _probe(loss_fn):
+    """Decide by EVALUATION what an opaque callable computes: it is called on small seeded CPU logit / target pairs — value
+    and gradient with respect to the logits must equal the fused head's cross-entropy (int64 class targets, mean reduction)
+    or BCE-with-logits on the flattened tensors (float targets, mean reduction) to 1e-6 on every pair.  The reference's
+    binary loss is such a callable: `lambda x, y: BCEWithLogitsLoss()(x.flatten(), y.flatten())` (GLASSTest.py:57-58).  The
+    pairs have different row counts and class counts, every class occurs, so a sum reduction, class weights, label smoothing
+    or a non-default ignore_index all fail the comparison.  Anything that raises is simply not fusable."""
+    import torch.nn.functional as F
+    gen = torch.Generator().manual_seed(20240613)
+
+    def agree(logits, target, ref):
+        try:
+            x = logits.clone().requires_grad_(True)
+            with torch.enable_grad():
+                out = loss_fn(x, target)
+            if not (isinstance(out, torch.Tensor) and out.dim() == 0 and out.dtype == torch.float32 and out.requires_grad):
+                return False
+            g, = torch.autograd.grad(out, x)
+            xr = logits.clone().requires_grad_(True)
+            with torch.enable_grad():
+                want = ref(xr, target)
+            gr, = torch.autograd.grad(want, xr)
+            got, want = float(out.detach()), float(want.detach())
+            return got == got and abs(got - want) <= _PROBE_TOL * max(1.0, abs(want)) and float((g - gr).abs().max()) <= _PROBE_TOL
+        except Exception:  # noqa: BLE001 — a loss that cannot take these tensors is not one of the two
+            return False
+
+    def ce_pairs():
+        for b, k in ((5, 3), (8, 6)):
+            yield 3.0 * torch.randn(b, k, generator=gen), torch.arange(b) % k
+
+    def bce_pairs():
+        for shape, yshape in (((6, 1), (6, )), ((5, 4), (5, 4))):
+            yield 3.0 * torch.randn(*shape, generator=gen), (torch.rand(*yshape, generator=gen) > 0.5).float()
+
+    if all(agree(x, y, F.cross_entropy) for x, y in ce_pairs()):
+        return 0
+    if all(agree(x, y, lambda a, t: F.binary_cross_entropy_with_logits(a.flatten(), t.flatten())) for x, y in bce_pairs()):
+        return 1
+    return None
+
+
 def fusable_mode(loss_fn):
     """0 (cross-entropy) / 1 (BCE with logits on the flattened tensors) when the training step can fuse this loss with the
-    head, else None.  Besides this module's marker classes, torch's own CrossEntropyLoss with default settings qualifies —
-    what the reference driver builds for multi-class sets (GLASSTest.py:69); its binary case is a lambda around
-    BCEWithLogitsLoss (GLASSTest.py:57-58), which cannot be recognised: use BCEWithLogits() above."""
+    head, else None.  Recognised by type: this module's marker classes and torch's own CrossEntropyLoss with default settings
+    (what the reference driver builds for multi-class sets, GLASSTest.py:69).  Any other callable — the reference's binary
+    case is a lambda around BCEWithLogitsLoss (GLASSTest.py:57-58) — is recognised by what it computes (`_probe`, once per
+    callable)."""
     if isinstance(loss_fn, (CrossEntropy, BCEWithLogits)):
         return loss_fn.mode
     if (type(loss_fn) is nn.CrossEntropyLoss and loss_fn.weight is None and loss_fn.reduction == "mean" and
             loss_fn.ignore_index == -100 and getattr(loss_fn, "label_smoothing", 0.0) == 0.0):
         return 0
-    return None
+    if not callable(loss_fn):
+        return None
+    hit = _probed.get(id(loss_fn))
+    if hit is not None and (hit[0] is None or hit[0]() is loss_fn):
+        return hit[1]
+    import weakref
+    try:
+        ref = weakref.ref(loss_fn)
+    except TypeError:
+        ref = None
+    import warnings
+    with warnings.catch_warnings():  # (a loss of another kind may warn about the probe's shapes: not the user's business)
+        warnings.simplefilter("ignore")
+        mode = _probe(loss_fn)
+    if ref is not None:  # (no weak reference possible: the id could be reused by another object — probe again next time)
+        if len(_probed) > 256:
+            _probed.clear()
+        _probed[id(loss_fn)] = (ref, mode)
+    return mode
 
 
 class HeadLossFn(torch.autograd.Function):

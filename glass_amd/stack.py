@@ -94,6 +94,22 @@ class BatchLabels:
         _check(rc, "glass_batch_labels")
         self.loaded = True
 
+    def load_gather(self, pos_all, y_all, idx, pos_dst, y_dst):
+        """The batch = rows `idx` of the data set's node / target matrices, selected by the label launch itself
+        (glass_batch_labels_gather: ZGDataloader's `pos[perm], y[perm]` without the two index kernels); pos_dst / y_dst
+        receive the selected rows (pos_dst must hold the previous batch, as in load())."""
+        n_all, smax = pos_all.shape
+        if idx.numel() * smax != self.cap:
+            raise ValueError(f"BatchLabels: batch of {idx.numel() * smax} entries, capacity {self.cap}")
+        yrb = 0 if y_all is None else y_all.element_size() * (y_all.numel() // max(y_all.shape[0], 1))
+        rc = _lib.load().glass_batch_labels_gather(pos_all.data_ptr(), n_all, smax, 0 if y_all is None else y_all.data_ptr(), yrb,
+                                                   idx.data_ptr(), idx.numel(), pos_dst.data_ptr(),
+                                                   0 if y_all is None else y_dst.data_ptr(), self.mask.data_ptr(),
+                                                   self.rows.data_ptr(), self.count.data_ptr(), self.ws.data_ptr(), self.n, 1,
+                                                   _stream())
+        _check(rc, "glass_batch_labels_gather")
+        self.loaded = True
+
 
 def _comb_eff_ok(conv, labels, H):
     """forward AND backward of the comb pair in effective-weight form (hidden 64)"""
@@ -419,6 +435,7 @@ class StackProgram:
     """Forward / backward of one EmbZGConv over preselected kernels.  `supported(emb)` is the gate."""
     def __init__(self, emb):
         self.emb = emb
+        self.loss_sum = None  # float32 device scalar the readout adds every step's loss to (step.TrainStep's epoch sum)
 
     @staticmethod
     def supported_unlabeled(emb):
@@ -707,7 +724,8 @@ class StackProgram:
                                            djk.data_ptr(), djk.stride(0), head.weight.grad.data_ptr(),
                                            head.bias.grad.data_ptr(), st["acc"], gn.weight.grad.data_ptr(),
                                            gn.bias.grad.data_ptr(), gn.mean_scale.grad.data_ptr(), st["acc"], ws.data_ptr(),
-                                           n, C, *largs, src, 0 if acc_ro is None else acc_ro.data_ptr(), REP_DENSE, sws, _stream()),
+                                           n, C, *largs, src, 0 if acc_ro is None else acc_ro.data_ptr(), REP_DENSE, sws,
+                                           0 if self.loss_sum is None else self.loss_sum.data_ptr(), _stream()),
                "glass_readout_train_f32")
         st["djk"] = djk
         return loss, logits

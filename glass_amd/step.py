@@ -55,6 +55,10 @@ class TrainStep:
         self._pos = self._y = None
         self._labels = None  # stack.BatchLabels of the step program: label bytes + unique labeled rows of the current batch
         self._loss = torch.zeros((), device=x.device)
+        # running sum of the step losses since reset_loss_sum(): kept by the step itself (the program's readout adds to it in
+        # the launch that stores the loss; other forms add one captured kernel) so that an epoch loop needs no per-step launch
+        self._loss_sum = torch.zeros((), dtype=torch.float32, device=x.device)
+        self._hyper = None              # (betas, eps, weight_decay) baked into the captured optimizer launch
         self._one = torch.ones((), device=x.device)
         self._g_fb = self._g_tail = None
         self._split = False
@@ -94,8 +98,13 @@ class TrainStep:
             if not overwrite:
                 self.bucket.zero()
             fused = self.opt if (apply_opt and overwrite and hasattr(self.opt, "fused_args")) else None
-            loss, _logits = stack.loss_and_grads(self.model, self.loss_fn, self.x, self.ei, self.ew, self._pos, "pos",
-                                                 self._y, overwrite, tail_hook, labels=self._labels, fused_opt=fused)
+            prog = stack._program(self.model.conv)
+            prog.loss_sum = self._loss_sum  # the readout adds this step's loss to the running sum in its own launch
+            try:
+                loss, _logits = stack.loss_and_grads(self.model, self.loss_fn, self.x, self.ei, self.ew, self._pos, "pos",
+                                                     self._y, overwrite, tail_hook, labels=self._labels, fused_opt=fused)
+            finally:
+                prog.loss_sum = None
             self._loss = loss
             return stack.applied_optimizer(self.model)
         if tail_hook is not None:
@@ -115,6 +124,7 @@ class TrainStep:
         # Under capture `loss` lives at a fixed address of the graph's private pool, so keeping the
         # reference replaces a copy kernel; in eager mode it is simply the latest loss tensor.
         self._loss = loss.detach()
+        self._loss_sum.add_(self._loss)
 
     def _warmup(self):
         """Real training steps on the first batch, on a side stream: builds the CSR / plans /
@@ -144,7 +154,7 @@ class TrainStep:
         from . import ops
         return (copy.deepcopy(self.model.state_dict()), copy.deepcopy(self.opt.state_dict()),
                 {k: getattr(self.opt, k).clone() for k in ("exp_avg", "exp_avg_sq", "step_dev", "step_dev_shard") if hasattr(self.opt, k)},
-                ops.rng_state(self.x.device).clone())
+                ops.rng_state(self.x.device).clone(), self._loss_sum.clone())
 
     def _restore(self, snap):
         from . import ops
@@ -153,6 +163,7 @@ class TrainStep:
         for k, v in snap[2].items():
             getattr(self.opt, k).copy_(v)
         ops.rng_state(self.x.device).copy_(snap[3])
+        self._loss_sum.copy_(snap[4])
         torch.cuda.synchronize()
 
     def _verify_collective_capture(self):
@@ -360,21 +371,40 @@ class TrainStep:
             out.update(exchange_us=sum(red) / len(red), adam_and_gather_us=sum(upd) / len(upd), steps_timed=len(red))
         return out
 
-    def __call__(self, pos, y):
+    def reset_loss_sum(self):
+        self._loss_sum.zero_()
+
+    def loss_sum(self):
+        """Device scalar: sum of the losses of the steps since reset_loss_sum() (added in step order, fp32)."""
+        return self._loss_sum
+
+    def __call__(self, pos, y, index=None):
+        """One step on the batch (pos, y).  index (int64 device vector): pos / y are the DATA SET's whole node and target
+        matrices and the batch is their rows `index` — the selection ZGDataloader does with `pos[perm], y[perm]`
+        (impl/SubGDataset.py:69-72) happens inside the step's label launch instead of two index kernels before it."""
+        if index is not None and self._sets is not None:
+            pos, y, index = pos[index], y[index], None  # (the prefetching form loads plain batches)
+        shape = tuple(pos.shape) if index is None else (index.numel(), ) + tuple(pos.shape[1:])
         first = self._pos is None
         if first:
-            self._pos, self._y = torch.full_like(pos, -1), y.clone()
+            self._pos = torch.full(shape, -1, dtype=pos.dtype, device=pos.device)
+            self._y = torch.zeros((shape[0], ) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
             if self._program_step() and pos.is_cuda and pos.dtype == torch.int64:
                 from . import stack
-                self._labels = stack.BatchLabels(self.x.shape[0], pos.numel(), pos.device)
-        if pos.shape != self._pos.shape:
+                self._labels = stack.BatchLabels(self.x.shape[0], self._pos.numel(), pos.device)
+        if shape != tuple(self._pos.shape):
             raise ValueError("TrainStep needs a fixed batch shape (drop_last=True): "
-                             f"{tuple(pos.shape)} vs {tuple(self._pos.shape)}")
+                             f"{shape} vs {tuple(self._pos.shape)}")
         if self._sets is not None:
             return self._call_prefetched(pos, y)
-        self._load_batch(pos, y)
-        if first:
-            self._warmup()
+        self._load_batch(pos, y, index)
+        hyper = self.opt.hyper() if hasattr(self.opt, "hyper") else None
+        if first or (self.graphed and hyper != self._hyper):
+            # (betas / eps / weight_decay are launch arguments: a changed param_groups entry means a new capture; the learning
+            # rate lives in device memory and needs none)
+            if first:
+                self._warmup()
+            self._hyper = hyper
             if self.use_graph:
                 self._capture()
             if self._sets is not None:  # two label sets from here on: this batch sits in set 0 already
@@ -424,9 +454,18 @@ class TrainStep:
             self._exchange_and_update()
         return self._loss
 
-    def _load_batch(self, pos, y):
+    def _load_batch(self, pos, y, index=None):
         """The batch into the step's fixed buffers: one launch for both tensors when they are plain device tensors — with
-        the step program the same launch maintains the label bytes and lists the unique labeled rows (glass_batch_labels)."""
+        the step program the same launch maintains the label bytes and lists the unique labeled rows (glass_batch_labels),
+        and selects the batch's rows itself when `index` is given (glass_batch_labels_gather)."""
+        if index is not None:
+            index = index.contiguous()  # (a data-parallel rank's slice perm[rank::world] is strided)
+            if (self._labels is not None and pos.is_contiguous() and y.is_cuda and y.is_contiguous() and index.is_cuda and
+                    index.dtype == torch.int64 and index.is_contiguous() and y.dtype == self._y.dtype and pos.dim() == 2 and
+                    y.shape[0] == pos.shape[0] and (y.element_size() * (y.numel() // max(y.shape[0], 1))) % 4 == 0):
+                self._labels.load_gather(pos, y, index, self._pos, self._y)
+                return
+            pos, y = pos[index], y[index]
         if self._labels is not None:
             pos_c = pos if pos.is_contiguous() else pos.contiguous()
             if (y.is_cuda and y.is_contiguous() and y.dtype == self._y.dtype and y.shape == self._y.shape and y.numel() and

@@ -13,28 +13,36 @@ USE_STEP = os.environ.get("GLASS_TRAIN_STEP", "1") != "0"     # 0: the plain per
 
 def _graph_step(optimizer, model, dataloader, loss_fn):
     """The training step object (glass_amd.step.TrainStep: the step program, replayed from a hipGraph unless
-    GLASS_TRAIN_GRAPH=0) when the epoch is graph-safe: a GLASS model on the GPU,
-    ZGDataloader with z_fn = MaxZOZ and drop_last (fixed batch shape), and an optimizer whose step is capturable
-    (FlatAdam: its learning rate lives in device memory, so schedulers keep working under replay).  Cached on the model.  None -> eager loop."""
+    GLASS_TRAIN_GRAPH=0) when the epoch is graph-safe: a GLASS model on the GPU, ZGDataloader with z_fn = MaxZOZ and
+    drop_last (fixed batch shape), and an optimizer whose step is capturable — optim.FlatAdam, or a plain
+    `torch.optim.Adam(model.parameters(), lr)` as the reference driver builds it (GLASSTest.py:213), which is taken over
+    in place (optim.adopt: flat parameter arena built on the spot, the torch optimizer's param_groups / state stay the
+    interface, so `ReduceLROnPlateau(optimizer)` and `optimizer.state_dict()` keep working).  Cached on the model.
+    None -> eager loop."""
     from . import utils
     from .SubGDataset import ZGDataloader
     from .models import GLASS
-    from .optim import FlatAdam
+    from .optim import FlatAdam, adopt, adoptable
     if not (USE_STEP and isinstance(model, GLASS) and isinstance(dataloader, ZGDataloader) and
             dataloader.z_fn is utils.MaxZOZ and dataloader.drop_last and dataloader.Gdataset.x.is_cuda and
             len(dataloader) > 0):
         return None
+    engine = optimizer
     if not isinstance(optimizer, FlatAdam):
-        # FlatAdam mirrors param_groups[...]["lr"] into device memory before every replay (sync_lr); a torch optimizer's
-        # Python-float lr would be baked into the captured graph and a scheduler's changes silently ignored
-        return None
+        # a torch optimizer's Python-float lr would be baked into a captured graph and a scheduler's changes silently ignored:
+        # the flat engine mirrors param_groups[0]["lr"] into device memory before every replay (sync_lr)
+        if adoptable(optimizer, model) is not None:
+            return None
+        engine = adopt(optimizer, model)
+    elif not optimizer.arena.attached():
+        optimizer.arena.reattach()
     ds = dataloader.Gdataset
-    key = (id(optimizer), id(loss_fn), id(ds.x), id(ds.edge_index), dataloader.batch_size, gdist.world_size(), USE_GRAPH)
+    key = (id(optimizer), id(engine), id(loss_fn), id(ds.x), id(ds.edge_index), dataloader.batch_size, gdist.world_size(), USE_GRAPH)
     cache = model.__dict__.setdefault("_glass_train_steps", {})
     step = cache.get(key)
     if step is None:
         from .step import TrainStep
-        step = TrainStep(model, optimizer, loss_fn, ds.x, ds.edge_index, ds.edge_attr, gdist.bucket_for(model),
+        step = TrainStep(model, engine, loss_fn, ds.x, ds.edge_index, ds.edge_attr, gdist.bucket_for(model),
                          use_graph=USE_GRAPH, warmup_iters=2, preserve_state=True)  # GLASS_TRAIN_GRAPH=0: the same step, eager launches
         cache.clear()  # one live graph per model
         cache[key] = step
@@ -57,12 +65,27 @@ def train(optimizer, model, dataloader, loss_fn):
     model.train()
     step = _graph_step(optimizer, model, dataloader, loss_fn)
     if step is not None:
-        total, n = None, 0
-        for batch in dataloader:
-            loss = step(batch[3], batch[-1])  # z is recomputed inside the captured step (MaxZOZ kernel)
-            total = loss.clone() if total is None else total.add_(loss)
-            n += 1
-        return _epoch_loss(total / n, dataloader)
+        # The loader's own iteration would select the batch (`pos[perm], y[perm]`: two index kernels) and label it (z_fn =
+        # MaxZOZ) before the step copies and labels it again; the step does all of that in its one label launch from the index
+        # batch (TrainStep.__call__(..., index)), and keeps the running loss sum itself — per step: that launch + one replay.
+        from .SubGDataset import ZGDataloader
+        ds = dataloader.Gdataset
+        step.reset_loss_sum()
+        n = 0
+        if type(dataloader) is ZGDataloader:
+            for perm in dataloader._batches():
+                step(ds.pos, ds.y, perm)
+                n += 1
+        else:  # a subclass may select its batches differently: take them as it yields them
+            for batch in dataloader:
+                step(batch[3], batch[-1])
+                n += 1
+        if n == 0:
+            return float("nan")
+        out = _epoch_loss(step.loss_sum() / n, dataloader)   # (the epoch's one host sync)
+        if hasattr(step.opt, "publish"):
+            step.opt.publish()   # adopted torch.optim.Adam: state[p]["step"] follows the device counter
+        return out
     total_loss = []
     bucket = gdist.bucket_for(model) if gdist.is_distributed() else None
     for batch in dataloader:

@@ -30,7 +30,7 @@ typedef struct glass_gn_bwd_src glass_gn_bwd_src;
 typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a kernel input: defined with K5's entries */
 #endif
 
-#define GLASS_ABI_VERSION 4
+#define GLASS_ABI_VERSION 5
 
 #define GLASS_E_ARG (-1)       /* bad argument (null pointer, negative size, misaligned ld) */
 #define GLASS_E_PLAN (-2)      /* plan blob does not match the call (magic / sizes) */
@@ -110,6 +110,15 @@ int64_t glass_batch_labels_ws_bytes(int64_t n_nodes);
 int glass_batch_labels(const int64_t* pos_src, int64_t n_pos, int64_t* pos_dst, const void* y_src, void* y_dst,
                        int64_t y_bytes, uint8_t* mask, int32_t* lab_rows, int32_t* lab_count, void* ws, int64_t n_nodes,
                        int incremental, void* stream);
+/*     The same with the batch SELECTED in place — replaces `self.get_pos()[perm], self.get_y()[perm]` of the loaders
+ *     (impl/SubGDataset.py:69-72, 92-96: two index kernels + the copy into the step's fixed buffers): pos_all int64[n_all, smax]
+ *     and y_all [n_all, y_row_bytes] are the data set's whole matrices, idx int64[n_idx] the batch's rows (a row index outside
+ *     [0, n_all) reads as an all-padding row with zero target).  The batch has n_idx * smax entries; pos_dst / y_dst (may be
+ *     NULL / y_row_bytes == 0) receive exactly pos_all[idx], y_all[idx].  Everything else as glass_batch_labels. */
+int glass_batch_labels_gather(const int64_t* pos_all, int64_t n_all, int64_t smax, const void* y_all, int64_t y_row_bytes,
+                              const int64_t* idx, int64_t n_idx, int64_t* pos_dst, void* y_dst, uint8_t* mask,
+                              int32_t* lab_rows, int32_t* lab_count, void* ws, int64_t n_nodes, int incremental,
+                              void* stream);
 
 /* K3+K4 fused label + embedding   replaces `mask=(z>0.5)` and `input_emb(x)`
  *     (impl/models.py:242-248):  out[n,:] = W[x[n],:],  mask[n] = label of node n.
@@ -627,8 +636,12 @@ int glass_readout_train_f32(const float* jk, int64_t ldj, const float* gn_saved,
                             float* logits, float* loss, float* djk, int64_t lddj, float* dWh, float* dbh, int acc_head,
                             float* dgamma, float* dbeta, float* dalpha, int acc_gn, void* ws, int64_t n_nodes, int64_t C,
                             const uint8_t* mask, const int32_t* lab_rows, const int32_t* lab_count,
-                            const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* scatter_ws, void* stream);
-/*      gn_bwd_acc != NULL (with the listed pooled rows): two launches instead of three — the subgraph kernel adds its share of
+                            const glass_gn_src* gn_src, int64_t* gn_bwd_acc, int gn_bwd_rep, void* scatter_ws,
+                            float* loss_sum, void* stream);
+/*      loss_sum (nullable): the thread that stores the step's mean loss also adds it to loss_sum[0] — the epoch's running
+ *      sum of impl/train.py:15-17 (`total_loss.append(loss.item())` ... `np.average`) kept on the device in step order, so
+ *      the epoch loop needs neither a host sync nor an extra launch per step.
+ *      gn_bwd_acc != NULL (with the listed pooled rows): two launches instead of three — the subgraph kernel adds its share of
  *      the final GraphNorm's two backward column sums to these exact accumulators (glass_gn_exact_words(C) words, zeroed by
  *      the caller per step, gn_bwd_rep replicas in use), the backfill launch folds them and also carries the head-gradient
  *      rows and the mean loss. */

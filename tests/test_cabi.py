@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in glass_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.glass_version() == _lib.ABI_VERSION == 4
+    assert lib.glass_version() == _lib.ABI_VERSION == 5
 
 
 def test_header_cites_reference_lines():
@@ -173,7 +173,7 @@ def test_step_program_entry_points_validate_on_the_host():
     # layer 0's trans kernel gathers from the embedding table at every dense width
     assert all(lib.glass_dual_linear_fwd_gather_supported(h) == 1 for h in (8, 17, 64, 128, 256, 512))
     args = [p, 128, p, p, p, p, 80, 10, 2, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 1000, 128, None, None, None, None,
-            None, 0, None, None]
+            None, 0, None, None, None]
     assert lib.glass_readout_train_f32(*args) == -3  # max pooling is not fusable
     # table path: more rows than GLASS_EMBED_NORM_MAX_ROWS
     assert lib.glass_embed_norm_fwd_f32(p, p, 10000, p, p, p, p, 1e-5, p, p, None, None, 0, 0.0, None, 1, p, 64, p, 10, 64,
@@ -224,7 +224,7 @@ def test_repeatable_entry_points_refuse_instead_of_falling_back_to_float_atomics
     assert lib.glass_segment_pool_bwd_atomic_f32(p, 64, p, 8, 10, 2, None, p, 64, 1000, 64, None) == -1
     # fused readout beyond 16 384 entries without scatter_ws: refused
     args = [p, 128, p, p, p, p, 200, 155, 0, p, p, p, 0, 6, p, p, p, p, p, 128, p, p, 1, p, p, p, 1, p, 50000, 128, None, None, None,
-            None, None, 0, None, None]
+            None, None, 0, None, None, None]
     assert lib.glass_readout_scatter_ws_bytes(50000, 200, 155) > 0
     assert lib.glass_readout_train_f32(*args) == E_WS and b"scatter_ws" in lib.glass_last_error_string()
     # no float atomicAdd left in the readout at all, and exactly one kernel with one in the pool file

@@ -1,0 +1,223 @@
+"""The REFERENCE'S OWN CALLER on the measured path.
+
+Everything below is constructed the way /root/reference/GLASSTest.py constructs it — `buildModel` (:129-175), the loaders of
+`split()` (:104-126), `Adam(gnn.parameters(), lr=lr)` + `ReduceLROnPlateau(optimizer, factor=resi, min_lr=5e-5)` (:213-216),
+the binary loss as a plain function around `BCEWithLogitsLoss` (:57-58), `CrossEntropyLoss()` (:69) — through the `impl.*`
+module surface only: no ParamArena, no FlatAdam, no glass_amd.losses class.  `impl.train.train` must put that caller on
+the hipGraph step program by itself (optimizer adopted in place, loss recognised by evaluation) and keep every torch-side
+contract: scheduler cuts are followed, `optimizer.state_dict()` carries the moments and the step count, eager use of the
+same optimizer afterwards continues the same state."""
+import copy
+import functools
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss
+from torch.optim import Adam, lr_scheduler
+
+from helpers import load, sd_from, rel_inf, flat_grads
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def reference_build_model(hidden_dim, conv_layer, dropout, jk, pool, z_ratio, aggr, max_deg, output_channels):
+    """GLASSTest.py:129-175, line by line in meaning (module globals `max_deg`, `output_channels` as arguments)."""
+    from impl import models, config
+    conv = models.EmbZGConv(hidden_dim, hidden_dim, conv_layer, max_deg=max_deg, activation=nn.ELU(inplace=True), jk=jk,
+                            dropout=dropout,
+                            conv=functools.partial(models.GLASSConv, aggr=aggr, z_ratio=z_ratio, dropout=dropout), gn=True)
+    mlp = nn.Linear(hidden_dim * (conv_layer) if jk else hidden_dim, output_channels)
+    pool_fn_fn = {"mean": models.MeanPool, "max": models.MaxPool, "sum": models.AddPool, "size": models.SizePool}
+    pool_fn1 = pool_fn_fn[pool]()
+    gnn = models.GLASS(conv, torch.nn.ModuleList([mlp]), torch.nn.ModuleList([pool_fn1])).to(config.device)
+    return gnn
+
+
+def reference_loader(ds, bs, shuffle=True, drop_last=True):
+    """GLASSTest.py:107-113 (`tfunc`)."""
+    from impl import SubGDataset, utils
+    return SubGDataset.ZGDataloader(ds, bs, z_fn=utils.MaxZOZ, shuffle=shuffle, drop_last=drop_last)
+
+
+def reference_binary_loss(x, y):
+    """GLASSTest.py:57-58."""
+    return BCEWithLogitsLoss()(x.flatten(), y.flatten())
+
+
+def _taken_step(model):
+    steps = model.__dict__.get("_glass_train_steps") or {}
+    assert len(steps) == 1, "impl.train.train did not build a TrainStep for the reference caller"
+    return next(iter(steps.values()))
+
+
+@pytest.fixture(autouse=True)
+def _device():
+    from impl import config
+    config.set_device(0)
+
+
+def _g8():
+    g = load("g8_adam.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    ei, ew = torch.from_numpy(g["edge_index"]).to(DEV), torch.from_numpy(g["edge_weight"]).to(DEV)
+    pos, y = torch.from_numpy(g["pos"]).to(DEV), torch.from_numpy(g["y"]).to(DEV)
+    return g, x, ei, ew, pos, y
+
+
+def test_reference_caller_reproduces_g8_on_the_graph_path():
+    """g8 = the reference's own three Adam steps (losses + final weights).  Three one-batch epochs of impl.train.train with
+    the reference's constructions reproduce them, on the captured step program."""
+    from impl import SubGDataset, train
+    from glass_amd import stack
+    g, x, ei, ew, pos, y = _g8()
+    gnn = reference_build_model(int(g["hidden"]), int(g["layers"]), 0.0, True, str(g["pool"]), float(g["z_ratio"]), str(g["aggr"]),
+                                torch.max(x), 3)
+    gnn.load_state_dict(sd_from(g))
+    optimizer = Adam(gnn.parameters(), lr=float(g["lr"]))
+    scd = lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.7, min_lr=5e-5)
+    loss_fn = CrossEntropyLoss()
+    params_before = [p for p in gnn.parameters()]
+    got = []
+    for k in range(3):
+        ds = SubGDataset.GDataset(x, ei, ew, pos[4 * k:4 * k + 4], y[4 * k:4 * k + 4])
+        loss = train.train(optimizer, gnn, reference_loader(ds, 4, shuffle=False), loss_fn)
+        scd.step(loss)
+        got.append(loss)
+    step = _taken_step(gnn)
+    assert step.graphed and step._program_step() and stack.step_supported(gnn, loss_fn), "not the captured step program"
+    assert all(a is b for a, b in zip(params_before, gnn.parameters())), "Parameter identities must survive the adoption"
+    assert np.allclose(got, g["losses"], rtol=1e-5, atol=0), (got, g["losses"])
+    end = sd_from(g, "sd_end/")
+    keys = sorted(end)
+    mine = {k: v.cpu() for k, v in gnn.state_dict().items()}
+    assert rel_inf(flat_grads(mine, keys), flat_grads(end, keys)) < 1e-4
+    # the torch optimizer still tells the truth about its state
+    sd = optimizer.state_dict()
+    assert len(sd["state"]) == len(params_before)
+    assert all(float(s["step"]) == 3.0 for s in sd["state"].values())
+    assert all(float(s["exp_avg_sq"].abs().sum()) > 0 for s in sd["state"].values() if s["exp_avg_sq"].numel() > 8)
+
+
+def _binary_task(seed=0, n=300, n_sub=24, smax=6, k_out=1):
+    gen = torch.Generator().manual_seed(seed)
+    pairs = torch.randint(0, n, (2, 900), generator=gen)
+    pairs = pairs[:, pairs[0] != pairs[1]]
+    ei = torch.cat([pairs, pairs.flip(0)], dim=1)
+    ei = torch.unique(ei, dim=1)
+    ew = torch.ones(ei.shape[1])
+    deg = torch.bincount(ei[0], minlength=n)
+    x = torch.unique(deg, return_inverse=True)[1].reshape(n, 1, 1)
+    pos = torch.stack([torch.randperm(n, generator=gen)[:smax] for _ in range(n_sub)])
+    pos[::3, -2:] = -1
+    y = (torch.rand(n_sub, generator=gen) > 0.5).float() if k_out == 1 else (torch.rand(n_sub, k_out, generator=gen) > 0.5).float()
+    return tuple(t.to(DEV) for t in (x, ei, ew, pos, y))
+
+
+def _eager_epoch(model, opt, loader, loss_fn):
+    """The reference's train() body (impl/train.py:4-17) on the per-op path: what the caller got before adoption."""
+    model.train()
+    out = []
+    for batch in loader:
+        opt.zero_grad()
+        loss = loss_fn(model(*batch[:-1], id=0), batch[-1])
+        loss.backward()
+        out.append(loss.item())
+        opt.step()
+    return float(np.mean(out))
+
+
+@pytest.mark.parametrize("k_out", [1, 3])
+def test_reference_binary_lambda_is_fused_and_scheduler_cut_is_followed(k_out):
+    """Binary / multi-label sets: the reference's loss is an opaque function (GLASSTest.py:57-58).  It is recognised by
+    evaluation, the caller lands on the step program; losses follow an eager twin (same seeds); a ReduceLROnPlateau cut
+    is followed by the very next replay: the parameter update shrinks with the learning rate."""
+    from impl import SubGDataset, train
+    from glass_amd import losses
+    x, ei, ew, pos, y = _binary_task(k_out=k_out)
+    assert losses.fusable_mode(reference_binary_loss) == 1
+    torch.manual_seed(3)
+    gnn = reference_build_model(64, 2, 0.0, True, "sum", 0.9, "mean", torch.max(x), k_out)
+    twin = copy.deepcopy(gnn)
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    optimizer = Adam(gnn.parameters(), lr=1e-2)
+    scd = lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.1, patience=0, min_lr=5e-5)
+    opt_twin = Adam(twin.parameters(), lr=1e-2)
+    for epoch in range(2):
+        torch.manual_seed(100 + epoch)
+        got = train.train(optimizer, gnn, reference_loader(ds, 8), reference_binary_loss)
+        torch.manual_seed(100 + epoch)
+        want = _eager_epoch(twin, opt_twin, reference_loader(ds, 8), reference_binary_loss)
+        assert abs(got - want) <= 2e-4 * abs(want), (epoch, got, want)
+    step = _taken_step(gnn)
+    assert step.graphed and step._program_step()
+    # force a cut: a "loss" far above the best one
+    scd.step(1.0)
+    scd.step(1e9)
+    lr_new = optimizer.param_groups[0]["lr"]
+    assert lr_new == pytest.approx(1e-3)
+    before = torch.cat([p.detach().reshape(-1).clone() for p in gnn.parameters()])
+    one = SubGDataset.GDataset(x, ei, ew, pos[:8], y[:8])
+    train.train(optimizer, gnn, reference_loader(one, 8), reference_binary_loss)
+    assert _taken_step(gnn) is step, "a learning-rate change must not need a new capture"
+    delta = (torch.cat([p.detach().reshape(-1) for p in gnn.parameters()]) - before).abs().max().item()
+    assert 0.05 * lr_new < delta <= 1.5 * lr_new, f"update {delta:.3e} does not follow the cut learning rate {lr_new:.1e}"
+    assert float(step.opt.lr_dev) == pytest.approx(lr_new)
+
+
+def test_adopted_optimizer_state_round_trips_and_eager_use_continues():
+    """optimizer.state_dict() -> a fresh Adam on a fresh model -> training continues exactly as without the round trip; and
+    an eager step of the adopted optimizer in between (zero_grad(set_to_none=True), backward, step) is part of the same
+    trajectory: the next train() call picks its step count up."""
+    from impl import SubGDataset, train
+    x, ei, ew, pos, y = _binary_task(seed=1)
+    torch.manual_seed(5)
+    a = reference_build_model(64, 2, 0.0, True, "sum", 0.9, "mean", torch.max(x), 1)
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    opt_a = Adam(a.parameters(), lr=5e-3)
+    torch.manual_seed(7)
+    train.train(opt_a, a, reference_loader(ds, 8), reference_binary_loss)
+    # checkpoint
+    b = reference_build_model(64, 2, 0.0, True, "sum", 0.9, "mean", torch.max(x), 1)
+    b.load_state_dict(copy.deepcopy(a.state_dict()))
+    opt_b = Adam(b.parameters(), lr=5e-3)
+    opt_b.load_state_dict(copy.deepcopy(opt_a.state_dict()))
+    assert all(float(s["step"]) == 3.0 for s in opt_b.state_dict()["state"].values())
+    for model, opt in ((a, opt_a), (b, opt_b)):
+        torch.manual_seed(8)
+        train.train(opt, model, reference_loader(ds, 8), reference_binary_loss)
+    pa = torch.cat([p.detach().reshape(-1) for p in a.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in b.parameters()])
+    assert torch.equal(pa, pb), f"resumed run diverged: {(pa - pb).abs().max().item():.3e}"
+    assert all(float(s["step"]) == 6.0 for s in opt_b.state_dict()["state"].values())
+    # eager use of the adopted optimizer, reference style
+    from impl import utils
+    opt_a.zero_grad()
+    p8 = pos[:8]
+    loss = reference_binary_loss(a(x, ei, ew, p8, utils.MaxZOZ(x, p8), id=0), y[:8])
+    loss.backward()
+    opt_a.step()
+    assert all(float(s["step"]) == 7.0 for s in opt_a.state_dict()["state"].values())
+    torch.manual_seed(9)
+    train.train(opt_a, a, reference_loader(ds, 8), reference_binary_loss)
+    assert all(float(s["step"]) == 10.0 for s in opt_a.state_dict()["state"].values())
+    assert int(_taken_step(a).opt.step_dev[0]) == 10
+
+
+def test_unadoptable_callers_keep_the_eager_loop():
+    """amsgrad / another optimizer class / an unknown loss: impl.train.train stays on the plain per-batch loop."""
+    from impl import SubGDataset, train
+    x, ei, ew, pos, y = _binary_task(seed=2)
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    torch.manual_seed(1)
+    m = reference_build_model(64, 1, 0.0, True, "mean", 0.8, "gcn", torch.max(x), 1)
+    for opt in (Adam(m.parameters(), lr=1e-3, amsgrad=True), torch.optim.SGD(m.parameters(), lr=1e-3)):
+        loss = train.train(opt, m, reference_loader(ds, 8), reference_binary_loss)
+        assert np.isfinite(loss) and not m.__dict__.get("_glass_train_steps")
+    # an unknown loss with an adoptable optimizer: the step is built, but not as the fused program
+    opt = Adam(m.parameters(), lr=1e-3)
+    loss = train.train(opt, m, reference_loader(ds, 8), lambda p, t: ((p.flatten() - t.flatten()) ** 2).mean())
+    assert np.isfinite(loss)
+    assert not _taken_step(m)._program_step()
