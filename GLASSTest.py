@@ -3,9 +3,12 @@ lines as the reference's GLASSTest.py (flags 14-30, split 77-126, buildModel 129
 
     python GLASSTest.py --use_one --use_seed --use_maxzeroone --repeat 1 --device 0 --dataset density
 
-It differs only below the module surface: parameters live in a flat arena (one fused Adam launch,
-stacked weight views, gradients accumulated by the kernels), and `--dataset synthetic:<workload>`
-selects a seeded synthetic graph (glass_amd/synth.py).  GPU only: `--device -1` stops with an error.
+It builds what the reference builds — `Adam(gnn.parameters(), lr)`, `ReduceLROnPlateau`, the binary loss as a function
+around `BCEWithLogitsLoss`, `CrossEntropyLoss()` — and nothing of glass_amd by name: `impl.train.train` itself moves such a
+caller onto the captured step program (flat parameter arena, fused Adam, fused head + loss; glass_amd/optim.py `adopt`,
+glass_amd/losses.py `fusable_mode`).  The reference's own GLASSTest.py run against this repo's `impl/` gets the same path.
+Extension: `--dataset synthetic:<workload>` selects a seeded synthetic graph (glass_amd/synth.py).  GPU only:
+`--device -1` stops with an error.
 """
 import argparse
 import functools
@@ -16,10 +19,8 @@ import numpy as np
 import torch
 import torch.nn as nn
 import yaml
-from torch.nn import CrossEntropyLoss
-
-from glass_amd import losses as glass_losses
-from torch.optim import lr_scheduler
+from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss
+from torch.optim import Adam, lr_scheduler
 
 import datasets
 from impl import SubGDataset, config, metrics, models, train, utils
@@ -57,9 +58,10 @@ class Run:
         self.args = args
         base = datasets.load_dataset(args.dataset)
         if base.y.unique().shape[0] == 2:  # binary / multi-label: BCE on flattened logits + micro-F1 of (logit > 0)
-            # (glass_amd.losses.BCEWithLogits computes exactly BCEWithLogitsLoss()(x.flatten(), y.flatten()) — the reference's
-            # lambda, GLASSTest.py:57-58 — as a class the training step can recognise and fuse with the head)
-            self.loss_fn = glass_losses.BCEWithLogits()
+            def loss_fn(x, y):  # (the reference's function, GLASSTest.py:57-58; the training step recognises what it computes)
+                return BCEWithLogitsLoss()(x.flatten(), y.flatten())
+
+            self.loss_fn = loss_fn
             self.output_channels = base.y.shape[1] if base.y.ndim > 1 else 1
             self.score_fn = metrics.binaryf1
         else:  # multi-class
@@ -163,8 +165,6 @@ class Run:
     def test(self, pool="size", aggr="mean", hidden_dim=64, conv_layer=8, dropout=0.3, jk=1, lr=1e-3, z_ratio=0.8,
              batch_size=None, resi=0.7):
         """Train `repeat` times with one hyper-parameter set (the YAML keys); prints the reference's log lines."""
-        from glass_amd.arena import ParamArena
-        from glass_amd.optim import FlatAdam
         # evaluation cadence: both the warm-up and the patience are 100 test-set batches' worth of epochs (synthetic
         # sets: a fifth of that)
         batches_in_test = self.tst.y.shape[0] / batch_size
@@ -177,7 +177,7 @@ class Run:
             print(f"repeat {repeat}")
             self.split()
             model = self.build_model(hidden_dim, conv_layer, dropout, jk, pool, z_ratio, aggr)
-            optimizer = FlatAdam(ParamArena(model), lr=lr)  # torch.optim.Adam(lr) semantics, one launch
+            optimizer = Adam(model.parameters(), lr=lr)  # (impl.train.train runs it as one fused launch inside the step's graph)
             scheduler = lr_scheduler.ReduceLROnPlateau(optimizer, factor=resi, min_lr=5e-5)
             epochs, seconds, val, tst = self.fit_once(model, optimizer, scheduler, self.loaders(batch_size), horizon, horizon)
             print(f"end: epoch {epochs}, train time {seconds:.2f} s, val {val:.3f}, tst {tst:.3f}", flush=True)

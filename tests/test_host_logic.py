@@ -241,3 +241,38 @@ def test_subgnn_text_loader_deduplicates_undirected_edges(tmp_path, monkeypatch)
     assert got == {(0, 1): 1.0, (1, 0): 1.0, (1, 2): 1.0, (2, 1): 1.0, (2, 3): 1.0, (3, 2): 1.0, (3, 3): 2.0}
     assert g.pos.shape == (5, 3)
     assert g.mask.tolist() == [0, 0, 1, 1, 2]  # the larger of val / test becomes valid
+
+
+def test_loss_callables_are_recognised_by_what_they_compute():
+    """glass_amd.losses.fusable_mode: the reference driver's binary loss is a plain function around BCEWithLogitsLoss
+    (GLASSTest.py:57-58) — recognised by evaluating it; anything that computes something else is not."""
+    import torch.nn as nn
+    from torch.nn import BCEWithLogitsLoss, CrossEntropyLoss
+    from glass_amd import losses
+
+    def loss_fn(x, y):  # verbatim GLASSTest.py:57-58
+        return BCEWithLogitsLoss()(x.flatten(), y.flatten())
+
+    assert losses.fusable_mode(loss_fn) == 1 and losses.fusable_mode(loss_fn) == 1  # (second call: the cached verdict)
+    assert losses.fusable_mode(CrossEntropyLoss()) == 0
+    assert losses.fusable_mode(lambda p, t: nn.functional.cross_entropy(p, t)) == 0
+    assert losses.fusable_mode(losses.BCEWithLogits()) == 1 and losses.fusable_mode(losses.CrossEntropy()) == 0
+    for other in (CrossEntropyLoss(label_smoothing=0.1), CrossEntropyLoss(reduction="sum"), CrossEntropyLoss(ignore_index=0),
+                  CrossEntropyLoss(weight=torch.tensor([1.0, 2.0, 3.0])), nn.MSELoss(),
+                  lambda p, t: BCEWithLogitsLoss(reduction="sum")(p.flatten(), t.flatten()),
+                  lambda p, t: BCEWithLogitsLoss(pos_weight=torch.tensor(2.0))(p.flatten(), t.flatten()),
+                  lambda p, t: 0.5 * nn.functional.cross_entropy(p, t), lambda p, t: 1.0, None, 3):
+        assert losses.fusable_mode(other) is None, other
+
+
+def test_only_a_plain_adam_over_the_whole_model_is_adopted():
+    """glass_amd.optim.adoptable names the reason a caller's optimizer keeps the eager loop."""
+    import torch.nn as nn
+    from glass_amd import optim
+    m = nn.Linear(4, 3)
+    assert "SGD" in optim.adoptable(torch.optim.SGD(m.parameters(), lr=0.1), m)
+    assert "AdamW" in optim.adoptable(torch.optim.AdamW(m.parameters()), m)
+    assert "amsgrad" in optim.adoptable(torch.optim.Adam(m.parameters(), amsgrad=True), m)
+    assert "group" in optim.adoptable(torch.optim.Adam([{"params": [m.weight]}, {"params": [m.bias], "lr": 0.1}]), m)
+    assert "exactly" in optim.adoptable(torch.optim.Adam([m.weight]), m)
+    assert "GPU" in optim.adoptable(torch.optim.Adam(m.parameters()), m)  # (CPU parameters: the reference's --device -1 case)
