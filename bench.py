@@ -68,6 +68,11 @@ L2_XCD_BYTES = 4 << 20
 IC_BYTES = 256 << 20
 
 
+# which BASELINE.json `configs` entry a workload is
+BASELINE_CONFIG = {"density": "BASELINE config[0]: the reference's own CPU-runnable case, here on the GPU", "ppi_bp": "BASELINE config[1]",
+                   "hpo_neuro": "BASELINE config[2]", "em_user": "BASELINE config[3], one rank's share", "powerlaw": "BASELINE config[4], one rank's share"}
+
+
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -401,8 +406,14 @@ def shared_workload(name, n_batches, world, rank):
     if world == 1:
         w, *arrs = synth.make_workload(name, seed=0, n_batches=n_batches * world)
         return w, tuple(arrs), None
-    share = f"/tmp/glass_bench_{os.environ.get('MASTER_PORT', '0')}_{name}_{world}.npz"
+    # one file per LAUNCH: the ranks of one launch share their parent (the torch.distributed.run agent, or bench.py's own
+    # spawner), so its pid is a nonce a SIGKILLed earlier run with the same port cannot have left behind; rank 0 also
+    # removes whatever sits at the path before it generates, and the real run checks the ranks' CRCs agree (main())
+    share = f"/tmp/glass_bench_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}_{name}_{world}x{n_batches}.npz"
     if rank == 0:
+        for stale in (share, share + ".tmp.npz"):
+            if os.path.exists(stale):
+                os.remove(stale)
         w, *arrs = synth.make_workload(name, seed=0, n_batches=n_batches * world)
         np.savez(share + ".tmp.npz", **dict(zip(("ei", "ew", "x", "pos", "y"), arrs)))
         os.replace(share + ".tmp.npz", share)
@@ -482,10 +493,15 @@ def eval_mode(args, w, model, xg, eig, ewg, pos_g, nnz, N, H, L, world, rank, lo
 
     results = {}
     with torch.no_grad():
-        ref = model(xg, eig, ewg, pos_g[0], __import__("glass_amd.utils", fromlist=["MaxZOZ"]).MaxZOZ(xg, pos_g[0])).clone()
-        for k in sorted({1, max(1, args.eval_parallel)}):
+        from glass_amd.utils import MaxZOZ
+        kmax = max(1, args.eval_parallel)
+        refs = [model(xg, eig, ewg, pos_g[b % n_batches], MaxZOZ(xg, pos_g[b % n_batches])).clone() for b in range(kmax)]
+        for k in sorted({1, kmax}):
             g = EvalGraph(model, xg, eig, ewg, pos_g[0].shape, k).capture()
-            same = bool(torch.equal(g([pos_g[0]])[0], ref))  # the replayed branch = the eager forward, bit for bit
+            # EVERY branch on a real batch of its own (branches sharing scratch would show here): each replayed branch = the
+            # eager forward of its batch, bit for bit
+            outs = g([pos_g[b % n_batches] for b in range(k)])
+            same = all(bool(torch.equal(o, refs[b])) for b, o in enumerate(outs))
 
             def run(steps, offset):
                 for i in range(0, steps, k):
@@ -560,6 +576,16 @@ def main():
     finally:
         if share is not None and rank == 0 and os.path.exists(share):
             os.remove(share)
+    if world > 1:
+        # every rank must hold the SAME workload (a stale or half-written share file would otherwise surface as a late
+        # reshape error, or as ranks training on different graphs): CRC of the edge list and the subgraphs, MIN == MAX
+        import zlib
+        crc = float(zlib.crc32(ei_np.tobytes()) ^ zlib.crc32(pos_np.tobytes()))
+        lo, hi = (torch.tensor([crc], dtype=torch.float64, device=dev if backend == "nccl" else "cpu") for _ in range(2))
+        td.all_reduce(lo, op=td.ReduceOp.MIN)
+        td.all_reduce(hi, op=td.ReduceOp.MAX)
+        if lo.item() != hi.item():
+            raise SystemExit(f"bench.py rank {rank}: the ranks hold different workloads (CRC {lo.item():.0f} .. {hi.item():.0f})")
     if args.dropout is not None:
         w.dropout = args.dropout
     if args.features == "nodeid":
@@ -662,6 +688,16 @@ def main():
         else:
             collective["exposed_us"] = None
             collective["exposed_method"] = "the exchange is captured inside the step's graph: no separate timing"
+        # what the model expects of this line: the exchange sits between the last gradient and Adam, so unless it overlaps the
+        # backward tail (embedding-sized bucket only) all of it is exposed — predicted weak-scaling efficiency of the step
+        ms = dt / args.steps * 1e3
+        pred = collective.get("predicted_us")
+        if pred is not None:
+            hidden = collective["predicted"]["small_allreduce_us"] if collective.get("small_bucket_overlaps_backward_tail") else 0.0
+            collective["predicted_exposed_us"] = pred - hidden
+            collective["predicted_share_of_step"] = (pred - hidden) * 1e-3 / ms
+            collective["predicted_note"] = ("ms_per_step includes the exchange; a 1-GPU step of the same workload + predicted_exposed_us "
+                                            "is what this line should read if the model's constants hold")
 
     # ---- device time per C-ABI call inside the step, K1 roofline (rank 0 reports; every rank runs the same code) ----
     # A second, instrumented pass of the same steps, eager (events cannot sit inside the replayed graph).  An eager
@@ -736,12 +772,13 @@ def main():
         miss_share = miss_bytes / gather_bytes
         gather_peak = 1.0 / ((1.0 - miss_share) / L2_GATHER_GBPS + miss_share / IC_GATHER_GBPS)
         u_gather = gather_rate / gather_peak
-    if u_gather is not None and u_gather >= max(u_l2, u_mem or 0.0):
-        bound, achieved, peak, frac = "gather_path", gather_rate, gather_peak, u_gather
-    elif x_bytes <= L2_XCD_BYTES or u_mem is None or u_l2 >= u_mem:
-        bound, achieved, peak, frac = "l2", alg_rate, L2_PEAK_GBPS, u_l2
-    else:
-        bound, achieved, peak, frac = mem_level, mem_rate, mem_peak, u_mem
+    # ONE definition of `frac`, whatever the numbers turn out to be: the kernel's MEMORY-SIDE traffic per launch (counters: what
+    # missed the XCD L2s) / launch time, against the peak of the level that serves those misses — the Infinity Cache's measured
+    # whole-row gather rate while X fits it, HBM's 8 TB/s beyond.  Without counters the compulsory (algorithmic) bytes stand in at
+    # the HBM level only (a lower bound of the traffic, never above 1); at the Infinity-Cache level there is no stand-in and
+    # frac is null.  The other utilisations are reported beside it under their own names (frac_algorithmic_hbm = SURVEY §8(d)'s
+    # figure, cache-assisted whenever X is cache-resident; frac_gather_path; frac_l2_algorithmic) — never as `frac`.
+    bound, achieved, peak, frac = mem_level, mem_rate, mem_peak, u_mem
     roofline = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": frac, "traffic": traffic,
                 "kernel": "glass_spmm_csr_f32 (spmm_sweep_kernel) inside the training step",
                 "regime": f"X = {x_bytes / 2**20:.1f} MiB: " + (
@@ -759,9 +796,12 @@ def main():
                                                      "whole-row gather rates blended by where the rows came from: 18.8 TB/s for the share "
                                                      "served by an XCD L2, 8.6 TB/s for the share that missed to the Infinity Cache "
                                                      "(MI355X_MICROARCH.md §Indexed rows); the miss share is measured (counters)",
-                                "note": "frac = the largest of the three: algorithmic bytes / 34.5 TB/s (the L2 streaming rate — a row "
-                                        "gather cannot reach it), memory-side traffic / that level's peak (prices only the bytes that "
-                                        "missed L2), gathered bytes / the blended gather rate (the path that binds this kernel)"},
+                                "note": "frac = memory_side, always (memory-side traffic per launch / launch time / the serving level's "
+                                        "peak); l2_algorithmic = algorithmic bytes / 34.5 TB/s (the L2 streaming rate — a row gather "
+                                        "cannot reach it); gather_path = gathered bytes / the blended gather rate"},
+                "frac_definition": "memory-side traffic (rocprofv3 counters, per launch) / avg launch time / peak of the level serving "
+                                   "the L2 misses (infinity_cache: 8.6 TB/s whole-row gathers; hbm: 8.0 TB/s)",
+                "frac_algorithmic_hbm": alg_rate / HBM_PEAK_GBPS, "frac_gather_path": u_gather, "frac_l2_algorithmic": u_l2,
                 "frac_of_hbm_peak_algorithmic": alg_rate / HBM_PEAK_GBPS,
                 "algorithmic_cache_assisted": alg_rate > HBM_COPY_GBPS,
                 "hbm_evidence": "algorithmic bytes / 8 TB/s above 6.3 / 8 = 0.79 cannot have come from HBM alone (cache-assisted); "
@@ -839,7 +879,8 @@ def main():
                       "torch.cuda.synchronize(), max over ranks per block",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "shipped graph + subgraphs, random-init weights" if w.name == "density" else "synthetic",
-            "config": {"workload": f"{'the shipped density graph (BASELINE config[0])' if w.name == 'density' else w.name + '-shaped synthetic graph (BASELINE config[1] family)'}: N={N}, nnz={nnz}, "
+            "config": {"workload": f"{'the shipped density graph' if w.name == 'density' else w.name + '-shaped synthetic graph'} "
+                                   f"({BASELINE_CONFIG.get(w.name, 'not a BASELINE config')}): N={N}, nnz={nnz}, "
                                    f"hidden={H}, layers={L}, aggr={w.aggr}, pool={w.pool}, z_ratio={w.z_ratio}, "
                                    f"dropout={w.dropout}, batch={w.batch}x{w.sub_size} per rank, "
                                    f"{'use_nodeid (V=N)' if args.features == 'nodeid' else 'use_deg'} features, Adam",

@@ -116,7 +116,7 @@ SIGNATURES = {
     "glass_dual_linear_fwd_f32": (c_int, [_P, _I, _P, _I, _P, _P, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, c_int, _P, _P,
                                           c_int, c_float, _P, c_uint64, _P, _I, _P, _I, _P]),
     "glass_dual_linear_fwd_gather_supported": (c_int, [_I]),
-    "glass_step_prologue_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _I, _P, _I, _P]),
+    "glass_step_prologue_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _I, _P, _I, _P]),
     "glass_graphnorm_finalize_f32": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, c_float, _P, _P]),
     "glass_graphnorm_apply_f32": (c_int, [_P, _I, _P, _I, _I, _I, _P, c_int, c_float, _P, c_uint64, _P]),
     "glass_dual_linear_dgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, c_float, _P, c_uint64, _P, _I,
@@ -136,7 +136,7 @@ SIGNATURES = {
                                               _P, _I, _P, c_double, c_double, c_double, c_double, _P, _I, _I, _I, _I, _P]),
     "glass_dual_linear_wgrad_f32": (c_int, [_P, _I, _P, _I, _P, c_double, c_int, _P, _I, _P, _I, _I, _I, _P, _I, _P,
                                             c_int, _P, _P]),
-    "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "glass_dense_pack_batch_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
     "glass_dense_image_floats": (_I, [_I, _I, c_int]),
     "glass_dual_linear_dgrad_layout": (c_int, [_I, _I]),
     "glass_dual_linear_fwd_layout": (c_int, [_I, _I]),

@@ -183,6 +183,7 @@ class ParamArena(FlatGradBucket):
         import numpy as np
         self._pack_args = (np.array([w.data_ptr() for w, *_ in self._packs], dtype=np.uint64),
                            np.array([p[1].data_ptr() for p in self._packs], dtype=np.uint64),
+                           np.array([p[1].numel() for p in self._packs], dtype=np.int64),  # what each image buffer holds
                            np.array([p[2] for p in self._packs], dtype=np.int64),
                            np.array([p[3] for p in self._packs], dtype=np.int64),
                            np.array([p[4] for p in self._packs], dtype=np.int32),
@@ -197,7 +198,7 @@ class ParamArena(FlatGradBucket):
         """Re-pack every stacked weight into the operand images of the fused dense kernels (forward: W,
         data gradient: W^T): one launch for the whole model.  rng_state (the device-resident dropout counter,
         ops.rng_state): advanced by the same launch — the two once-per-step prologue jobs share it."""
-        src, dst, nt, kt, tr, zr, k = self._pack_args
+        src, dst, cap, nt, kt, tr, zr, k = self._pack_args
         from . import _lib, ops
         for i, p in enumerate(self._packs):  # the pairs' CURRENT z_ratio (the kernels receive the live value as well)
             zr[i] = float(getattr(p[5], "z_ratio", 0.0))
@@ -218,12 +219,12 @@ class ParamArena(FlatGradBucket):
                              float(gn.eps), saved.data_ptr(), 0 if tab is None else tab.data_ptr(), W.shape[1])
                 else:
                     targs = (0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0)
-                rc = _lib.load().glass_step_prologue_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
+                rc = _lib.load().glass_step_prologue_f32(src[i:].ctypes.data, dst[i:].ctypes.data, cap[i:].ctypes.data, nt[i:].ctypes.data,
                                                          kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, max(n, 0), rng,
                                                          *targs, *zargs, st)
                 _lib.check(rc, "glass_step_prologue_f32")
             elif n > 0:
-                rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, nt[i:].ctypes.data,
+                rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, cap[i:].ctypes.data, nt[i:].ctypes.data,
                                                             kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, n, rng, st)
                 _lib.check(rc, "glass_dense_pack_batch_f32")
             else:

@@ -3445,10 +3445,10 @@ extern "C" int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t l
     return (g.part_w_floats + g.part_b_floats) * (int64_t)sizeof(float);
 }
 
-static int pack_launch(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
+static int pack_launch(const float* const* src, float* const* dst, const int64_t* dst_floats, const int64_t* NT, const int64_t* KT,
                        const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
                        const TableJob& tab, void* stream, const char* what, ZeroJob zero = ZeroJob{nullptr, 0}) {
-    GLASS_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs && (n_jobs == 0 || (src && dst && NT && KT && transposed)),
+    GLASS_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs && (n_jobs == 0 || (src && dst && dst_floats && NT && KT && transposed)),
                   "%s: bad arguments (at most %d matrices per call)", what, kMaxPackJobs);
     PackBatch b;
     for (int k = 0; k < kMaxPackJobs; ++k) b.job[k] = PackJob{nullptr, nullptr, 0, 0, 0, 0, 0.f, 0};
@@ -3457,6 +3457,10 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
                           aligned16(dst[k]),
                       "%s: job %d needs NT, KT multiples of 64 and 16-B aligned buffers", what, k);
         const int layout = transposed[k] >> 1;
+        // the image sizes differ by layout (appendix, cut image): the caller states what dst[k] holds, nothing is assumed
+        GLASS_REQUIRE(dst_floats[k] >= glass_dense_image_floats(NT[k], KT[k], transposed[k]),
+                      "%s: job %d: dst holds %lld floats, the image of this layout needs %lld (glass_dense_image_floats)", what, k,
+                      (long long)dst_floats[k], (long long)glass_dense_image_floats(NT[k], KT[k], transposed[k]));
         GLASS_REQUIRE(layout == kLayoutWave16 ||
                           (layout == kLayoutWave16Cols && ((NT[k] == 128 && KT[k] == 64 && !(transposed[k] & 1)) ||
                                                            (NT[k] == 64 && KT[k] == 128 && (transposed[k] & 1)) ||
@@ -3497,19 +3501,19 @@ extern "C" int64_t glass_dense_image_floats(int64_t NT, int64_t KT, int32_t flag
     return tiled_layout ? base + base * 3 / 2 : base;
 }
 
-extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT,
-                                          const int64_t* KT, const int32_t* transposed, const float* z_ratio,
-                                          int64_t n_jobs, uint64_t* rng_state, void* stream) {
-    GLASS_REQUIRE(src && dst && NT && KT && transposed && n_jobs >= 0 && n_jobs <= kMaxPackJobs,
+extern "C" int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* dst_floats,
+                                          const int64_t* NT, const int64_t* KT, const int32_t* transposed,
+                                          const float* z_ratio, int64_t n_jobs, uint64_t* rng_state, void* stream) {
+    GLASS_REQUIRE(src && dst && dst_floats && NT && KT && transposed && n_jobs >= 0 && n_jobs <= kMaxPackJobs,
                   "dense_pack_batch: bad arguments (at most %d matrices per call)", kMaxPackJobs);
     if (n_jobs == 0) return rng_state ? glass_rng_advance(rng_state, stream) : 0;
-    return pack_launch(src, dst, NT, KT, transposed, z_ratio, n_jobs, rng_state, TableJob{}, stream, "glass_dense_pack_batch_f32");
+    return pack_launch(src, dst, dst_floats, NT, KT, transposed, z_ratio, n_jobs, rng_state, TableJob{}, stream, "glass_dense_pack_batch_f32");
 }
 
 // The once-per-step prologue as ONE launch: the weight packing above + emb_gn's statistics through the embedding table
 // (the first half of glass_embed_norm_fwd_f32: saved[4H]; table may be NULL when the consumer gathers from W itself).
-extern "C" int glass_step_prologue_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
-                                       const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
+extern "C" int glass_step_prologue_f32(const float* const* src, float* const* dst, const int64_t* dst_floats,
+                                       const int64_t* NT, const int64_t* KT, const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
                                        const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma,
                                        const float* beta, const float* alpha, float eps, float* saved, float* table,
                                        int64_t H, int64_t* zero_words, int64_t n_zero_words, void* stream) {
@@ -3518,6 +3522,6 @@ extern "C" int glass_step_prologue_f32(const float* const* src, float* const* ds
     GLASS_REQUIRE(n_zero_words >= 0 && (n_zero_words == 0 || zero_words), "step_prologue: bad zero-fill arguments");
     TableJob tab{};
     if (W) tab = TableJob{W, (int)V, (int)H, class_rowptr, gamma, beta, alpha, eps, saved, table};
-    return pack_launch(src, dst, NT, KT, transposed, z_ratio, n_jobs, rng_state, tab, stream, "glass_step_prologue_f32",
+    return pack_launch(src, dst, dst_floats, NT, KT, transposed, z_ratio, n_jobs, rng_state, tab, stream, "glass_step_prologue_f32",
                        ZeroJob{n_zero_words > 0 ? (long long*)zero_words : nullptr, n_zero_words});
 }

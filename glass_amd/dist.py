@@ -159,3 +159,44 @@ def bucket_for(model):
         b = FlatGradBucket(list(model.parameters()))
         model._glass_grad_bucket = b
     return b
+
+
+# ---- what the exchange should cost: a stated model, to hold the first multi-rank measurement against ------------------
+# One node, N GPUs, every pair joined by one xGMI link (point to point, ~153 GB/s per direction per link; 7 links per GPU).
+# RCCL runs small all-reduces as a ring (or a tree of similar depth) of 2 (N - 1) dependent steps.  The model:
+#     t(bytes, N) = T_LAUNCH + steps(N) * T_HOP + wire_bytes(bytes, N) / (LINK_GBPS * LINK_EFF)
+# with steps = 2 (N - 1) for all-reduce, (N - 1) for reduce-scatter / all-gather (the latency of a ring: the pessimistic
+# choice), and — the mesh is point to point, so a rank's N - 1 links carry its N - 1 shards side by side — wire bytes per
+# link of bytes / N per half: 2 bytes / N for an all-reduce, bytes / N for a reduce-scatter or all-gather.  T_LAUNCH (the collective's kernel launch + its
+# flag handshake) and T_HOP (one dependent store -> remote poll -> reduce hop over xGMI) are ASSUMPTIONS taken from typical
+# small-message all-reduce latencies on 8-GPU xGMI nodes (20-40 us below 1 MB); no run in this repository has measured
+# them — they are printed with every prediction so that a SCALE run can replace them.
+MODEL_T_LAUNCH_US = 12.0
+MODEL_T_HOP_US = 1.5
+MODEL_LINK_GBPS = 153.0
+MODEL_LINK_EFF = 0.7
+
+
+def predict_collective_us(payload_bytes, world):
+    """{"small_allreduce", "big_reduce_scatter", "big_all_gather": bytes} -> predicted device time of the step's exchange at
+    `world` ranks under the model above: per-collective times, their sum, and the model's parameters."""
+    n = int(world)
+    out = {"world": n, "model": {"t_launch_us": MODEL_T_LAUNCH_US, "t_hop_us": MODEL_T_HOP_US, "link_GBps": MODEL_LINK_GBPS,
+                                "link_efficiency": MODEL_LINK_EFF,
+                                "form": "t = t_launch + steps * t_hop + wire_bytes / (link_GBps * link_efficiency); all-reduce: 2(N-1) "
+                                        "dependent steps, 2 * bytes / N per link (N-1 links side by side); reduce-scatter / all-gather "
+                                        "half of both",
+                                "status": "assumed constants, not measured on this pool"}}
+    if n <= 1:
+        out.update(small_allreduce_us=0.0, big_reduce_scatter_us=0.0, big_all_gather_us=0.0, total_us=0.0)
+        return out
+    bw = MODEL_LINK_GBPS * MODEL_LINK_EFF * 1e3  # bytes per us
+
+    def t(nbytes, steps, wire):
+        return 0.0 if nbytes <= 0 else MODEL_T_LAUNCH_US + steps * MODEL_T_HOP_US + wire * nbytes / bw
+
+    small = t(payload_bytes.get("small_allreduce", 0), 2 * (n - 1), 2.0 / n)
+    rs = t(payload_bytes.get("big_reduce_scatter", 0), n - 1, 1.0 / n)
+    ag = t(payload_bytes.get("big_all_gather", 0), n - 1, 1.0 / n)
+    out.update(small_allreduce_us=small, big_reduce_scatter_us=rs, big_all_gather_us=ag, total_us=small + rs + ag)
+    return out

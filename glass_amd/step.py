@@ -69,6 +69,7 @@ class TrainStep:
         self.capture_error = None
         self.capture_verified = None      # {"grad_rel_inf", "param_rel_inf", "ok"} of the replay-vs-eager check, or None
         self._force_verify_mismatch = False  # tests: exercise the opt-out path
+        self._force_capture_failure = False  # tests: this rank's capture of the collective "fails" (the ranks must agree on it)
         self.exchange_enabled = True    # bench.py: False = skip the collectives (timing of the exposed share; ranks diverge)
         self._sets = None               # two (pos, y, labels, graph, loss) sets when the label launch is prefetched
         self._next = 0
@@ -226,6 +227,8 @@ class TrainStep:
             import torch.distributed as td
             if CAPTURE_COLLECTIVE and td.get_backend() == "nccl":
                 try:
+                    if self._force_capture_failure:
+                        raise RuntimeError("forced capture failure (test hook)")
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode=mode):
                         self._fwd_bwd()
@@ -235,6 +238,16 @@ class TrainStep:
                 except Exception as e:  # noqa: BLE001 — whatever the runtime refuses: fall back
                     self.capture_error = repr(e)
                     torch.cuda.synchronize()
+                    self._g_fb = torch.cuda.CUDAGraph()
+                # The ranks agree on the capture's outcome BEFORE anything else is issued: a rank whose capture failed alone
+                # (graph-pool OOM, a transient refusal) would otherwise start its per-step eager all-reduces while the others
+                # enter the verification below — whose collectives would then pair with that rank's training all-reduces.
+                # One eager all-reduce (MIN) of "captured ok", issued by EVERY rank whatever happened above.
+                ok = torch.tensor([1.0 if self.collective_in_graph else 0.0], device=self.x.device)
+                td.all_reduce(ok, op=td.ReduceOp.MIN)
+                if float(ok.item()) == 0.0 and self.collective_in_graph:
+                    self.capture_error = "another rank could not capture the collective: split form on every rank"
+                    self.collective_in_graph = False
                     self._g_fb = torch.cuda.CUDAGraph()
                 if self.collective_in_graph and VERIFY_CAPTURED_COLLECTIVE and hasattr(self.bucket, "flat_param"):
                     if not self._verify_collective_capture():
@@ -364,6 +377,9 @@ class TrainStep:
             out["payload_bytes"] = {"small_allreduce": self.bucket.flat.numel() * self.bucket.flat.element_size(),
                                     "big_reduce_scatter": 0, "big_all_gather": 0}
             out["world"] = td.get_world_size()
+        # a number to hold the measurement against (dist.predict_collective_us: stated model, assumed constants)
+        out["predicted"] = gdist.predict_collective_us(out["payload_bytes"], out["world"])
+        out["predicted_us"] = out["predicted"]["total_us"]
         if self._coll_events:
             torch.cuda.synchronize()
             red = [a.elapsed_time(b) * 1e3 for a, b, _ in self._coll_events]

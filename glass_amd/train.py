@@ -108,22 +108,51 @@ USE_EVAL_GRAPH = os.environ.get("GLASS_EVAL_GRAPH", "1") != "0"  # 0: one eager 
 EVAL_PARALLEL = int(os.environ.get("GLASS_EVAL_PARALLEL", "8"))   # evaluation batches run side by side (evalstep.EvalGraph)
 
 
+EVAL_GRAPH_MAX_BYTES = int(os.environ.get("GLASS_EVAL_GRAPH_MAX_MB", "8192")) << 20  # activation budget of one cached graph
+
+
+def _eval_branches(model, n_nodes, k):
+    """Parallel branches of one evaluation graph, bounded by memory: every branch keeps its own copy of the forward's
+    activations (~ (4 L + 6) [N, H] fp32 buffers), and up to 4 graphs are cached per model."""
+    try:
+        emb = model.conv
+        H = emb.input_emb.weight.shape[1]
+        L = len(emb.convs)
+    except AttributeError:
+        return k
+    per_branch = 4 * n_nodes * H * (4 * L + 6)
+    return max(1, min(k, EVAL_GRAPH_MAX_BYTES // max(per_branch, 1)))
+
+
 def _eval_graph(model, batch, k):
     """The cached evalstep.EvalGraph for this model / graph tensors / batch shape, or None when the batch is not the plain
-    GLASS evaluation call (x, ei, ea, pos, z) on the GPU."""
+    GLASS evaluation call (x, ei, ea, pos, z) on the GPU — or when its capture failed before (remembered per key: the eager
+    forward then serves that shape)."""
     from .models import GLASS
     if not (USE_EVAL_GRAPH and k > 1 and isinstance(model, GLASS) and len(batch) == 5 and batch[0].is_cuda and
             batch[3].dim() == 2 and batch[3].dtype == torch.int64):
         return None
     x, ei, ea, pos = batch[0], batch[1], batch[2], batch[3]
+    k = _eval_branches(model, x.shape[0], k)
+    if k <= 1:
+        return None
     key = (id(x), id(ei), id(ea), tuple(pos.shape), k)
     cache = model.__dict__.setdefault("_glass_eval_graphs", {})
-    g = cache.get(key)
-    if g is None:
-        from .evalstep import EvalGraph
-        if len(cache) >= 4:
-            cache.clear()
-        g = cache[key] = EvalGraph(model, x, ei, ea, pos.shape, k)
+    if key in cache:
+        return cache[key]  # (None: a capture of this shape failed earlier)
+    from .evalstep import EvalGraph
+    if len(cache) >= 4:
+        cache.clear()
+    g = EvalGraph(model, x, ei, ea, pos.shape, k)
+    try:
+        g.capture()
+    except Exception as e:  # noqa: BLE001 — whatever the runtime or a non-capturable op refuses: the eager loop still works
+        torch.cuda.synchronize()
+        import warnings
+        warnings.warn(f"glass_amd.train.test: evaluation graph not captured ({e!r}); eager forwards for batches of shape "
+                      f"{tuple(pos.shape)}")
+        g = None
+    cache[key] = g
     return g
 
 

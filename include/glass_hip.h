@@ -545,18 +545,20 @@ int glass_spmm_reduce_rows_f32(const float* partials, float* Y, int64_t ldy, int
  * element in the order the LDS-tiled kernels copy it to LDS, always written by the pack kernel and read by the kernels in
  * product form 1 (glass_dense_product_form_set needs no re-pack).  Host arithmetic; GLASS_E_ARG for NT, KT <= 0. */
 int64_t glass_dense_image_floats(int64_t NT, int64_t KT, int32_t flags);
-int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
-                               const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
-                               void* stream);
-/*     The once-per-step prologue as ONE launch: glass_dense_pack_batch_f32 (same first eight arguments; n_jobs may be 0)
+/* dst_floats[k] = floats dst[k] can hold: a job whose image (glass_dense_image_floats) does not fit is refused with
+ * GLASS_E_ARG before anything is launched — the image sizes differ by layout, so the callee never assumes one. */
+int glass_dense_pack_batch_f32(const float* const* src, float* const* dst, const int64_t* dst_floats, const int64_t* NT,
+                               const int64_t* KT, const int32_t* flags, const float* z_ratio, int64_t n_jobs,
+                               uint64_t* rng_state, void* stream);
+/*     The once-per-step prologue as ONE launch: glass_dense_pack_batch_f32 (same first nine arguments; n_jobs may be 0)
  *     plus the statistics of emb_gn through the embedding table — the first half of glass_embed_norm_fwd_f32
  *     (impl/models.py:248-249): saved[4H] = mean, rstd, scale, shift of GraphNorm(W[x]) as count-weighted sums over the V
  *     table rows (class_rowptr as there); table[V,H] = W*scale + shift, or NULL when the consumer normalises while
  *     gathering from W (glass_dual_linear_fwd_f32 with xa_index).
  *     W == NULL: no table job.  zero_words / n_zero_words: int64 words the same launch zero-fills — the step's exact
  *     GraphNorm accumulators (below). */
-int glass_step_prologue_f32(const float* const* src, float* const* dst, const int64_t* NT, const int64_t* KT,
-                            const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
+int glass_step_prologue_f32(const float* const* src, float* const* dst, const int64_t* dst_floats, const int64_t* NT,
+                            const int64_t* KT, const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
                             const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma, const float* beta,
                             const float* alpha, float eps, float* saved, float* table, int64_t H, int64_t* zero_words,
                             int64_t n_zero_words, void* stream);

@@ -129,3 +129,17 @@ def test_two_rank_data_parallel_step(tmp_path):
     # ... and is NOT the global-batch gradient (max-zero-one labels are per batch)
     gg = _grads_on(model, data, torch.arange(8)).numpy()
     assert np.abs(gg - ref).max() > 1e-4 * np.abs(ref).max()
+
+
+def test_collective_prediction_model():
+    """dist.predict_collective_us: the stated model every N > 1 bench line carries — zero on one rank,
+    latency-bound and growing with the ring depth for the 0.2 MB bucket of hidden 64, bandwidth-bound for an embedding-sized
+    bucket; the constants travel with the prediction."""
+    from glass_amd import dist
+    small = {"small_allreduce": 200_000, "big_reduce_scatter": 0, "big_all_gather": 0}
+    assert dist.predict_collective_us(small, 1)["total_us"] == 0.0
+    t = [dist.predict_collective_us(small, n)["total_us"] for n in (2, 4, 8)]
+    assert 10.0 < t[0] < t[1] < t[2] < 60.0
+    big = dist.predict_collective_us({"small_allreduce": 3_200_000, "big_reduce_scatter": 10**9, "big_all_gather": 10**9}, 8)
+    assert big["big_reduce_scatter_us"] > 1000.0 and big["total_us"] == big["small_allreduce_us"] + big["big_reduce_scatter_us"] + big["big_all_gather_us"]
+    assert big["model"]["status"].startswith("assumed") and big["model"]["t_hop_us"] == dist.MODEL_T_HOP_US

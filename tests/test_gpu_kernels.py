@@ -519,13 +519,25 @@ def test_pack_launch_advances_dropout_stream():
     img = torch.empty(W.numel(), device=DEV)
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts, trs = np.array([128], dtype=np.int64), np.array([64], dtype=np.int64), np.array([0], dtype=np.int32)
+    caps = np.array([img.numel()], dtype=np.int64)
     for expect in (1, 2):
-        rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+        rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, caps.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                     trs.ctypes.data, 0, 1, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
         assert rc == 0 and st.tolist() == [77, expect]
     assert torch.equal(img, _pack(W, False))
-    rc = _lib.load().glass_dense_pack_batch_f32(0, 0, 0, 0, 0, 0, 0, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    rc = _lib.load().glass_dense_pack_batch_f32(0, 0, 0, 0, 0, 0, 0, 0, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc != 0  # null arrays are rejected even for zero jobs
+    # a destination smaller than the layout's image is refused before any launch (the image sizes differ by layout)
+    small = np.array([img.numel() - 1], dtype=np.int64)
+    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, small.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+                                                trs.ctypes.data, 0, 1, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == -1 and b"glass_dense_image_floats" in _lib.load().glass_last_error_string()
+    # a tiled layout carries the cut image behind the fp32 image: NT*KT floats are NOT enough there
+    W2, img2 = torch.randn(256, 128, device=DEV), torch.empty(256 * 128, device=DEV)
+    a = [np.array([v], dtype=t) for v, t in ((W2.data_ptr(), np.uint64), (img2.data_ptr(), np.uint64), (img2.numel(), np.int64),
+                                             (256, np.int64), (128, np.int64), (0 | (1 << 1), np.int32))]
+    rc = _lib.load().glass_dense_pack_batch_f32(*(v.ctypes.data for v in a), 0, 1, 0, torch.cuda.current_stream().cuda_stream)
+    assert rc == -1
 
 
 def test_graphnorm_scratch_reuse_stress():
@@ -724,7 +736,8 @@ def _pack(W, transposed, H=64, z=None):
     nts, kts = np.array([nt], dtype=np.int64), np.array([kt], dtype=np.int64)  # keep the host arrays alive
     trs = np.array([int(transposed) | (layout << 1)], dtype=np.int32)
     zs = np.array([0.0 if z is None else z], dtype=np.float32)
-    rc = lib.glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+    caps = np.array([img.numel()], dtype=np.int64)
+    rc = lib.glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, caps.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                         trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     return img
@@ -806,7 +819,8 @@ def test_dense_pack_effective_weight_appendix():
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([2 * H], dtype=np.int64), np.array([2 * H], dtype=np.int64)
     trs, zs = np.array([1 | (4 << 1)], dtype=np.int32), np.array([z], dtype=np.float32)
-    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+    caps = np.array([img.numel()], dtype=np.int64)
+    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, caps.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                 trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert torch.equal(img[:W.numel()], _pack(W, True, H)[:W.numel()])  # the plain part is layout 2
@@ -836,7 +850,8 @@ def test_dense_pack_forward_effective_weight_appendix():
     src, dst = np.array([W.data_ptr()], dtype=np.uint64), np.array([img.data_ptr()], dtype=np.uint64)
     nts, kts = np.array([2 * H], dtype=np.int64), np.array([2 * H], dtype=np.int64)
     trs, zs = np.array([0 | (5 << 1)], dtype=np.int32), np.array([z], dtype=np.float32)
-    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, nts.ctypes.data, kts.ctypes.data,
+    caps = np.array([img.numel()], dtype=np.int64)
+    rc = _lib.load().glass_dense_pack_batch_f32(src.ctypes.data, dst.ctypes.data, caps.ctypes.data, nts.ctypes.data, kts.ctypes.data,
                                                 trs.ctypes.data, zs.ctypes.data, 1, 0, torch.cuda.current_stream().cuda_stream)
     assert rc == 0
     assert torch.equal(img[:W.numel()], _pack(W, False, H)[:W.numel()])  # the first part is the paired layout

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as td
 
 
-def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False):
+def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False, force_capture_failure=False):
     from glass_amd import synth, losses, ops, dist as gdist, step as step_mod
     step_mod.CAPTURE_COLLECTIVE = capture_collective
     from glass_amd.arena import ParamArena
@@ -36,6 +36,7 @@ def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False):
     opt = FlatAdam(arena, lr=1e-2)
     step = TrainStep(model, opt, losses.CrossEntropy(), x, ei, ew, arena, use_graph=True, warmup_iters=2, preserve_state=True)
     step._force_verify_mismatch = force_mismatch  # the replay-vs-eager check of a captured collective reports a mismatch
+    step._force_capture_failure = force_capture_failure  # the capture attempt itself fails: agreed on by all ranks, split form
     B = w.batch
     for k in range(20):
         b = k % 4
@@ -49,7 +50,9 @@ def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False):
     form = "one-graph" if step.collective_in_graph else ("split" if step._split else "single")
     if step.collective_in_graph:  # a captured collective is only kept after one replay reproduced an eager step
         assert step.capture_verified and step.capture_verified["ok"], step.capture_verified
-    return hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest(), form, step.capture_error, step.capture_verified
+    share = step.collective_share()
+    return (hashlib.md5(arena.flat_param.cpu().numpy().tobytes()).hexdigest(), form, step.capture_error, step.capture_verified,
+            share["payload_bytes"] if share else None)
 
 
 if __name__ == "__main__":
@@ -60,6 +63,7 @@ if __name__ == "__main__":
     split = {nid: run(True, nid) for nid in (False, True)}
     eager_coll = run(True, False, capture_collective=False)  # the split form, whatever the capture attempt above did
     opted_out = run(True, False, force_mismatch=True)         # capture succeeds, the check "fails": automatic opt-out
+    refused = run(True, False, force_capture_failure=True)    # the capture attempt fails: outcome agreed (all-reduce MIN), split form
     td.barrier(device_ids=[0])
     td.destroy_process_group()
     ok = True
@@ -76,4 +80,15 @@ if __name__ == "__main__":
     ok = ok and same and opted_out[1] == "split" and (opted_out[3] is None or "replay-vs-eager" in str(opted_out[2]))
     print("deg single", single[False][0], "opt-out after a forced mismatch:", opted_out[1], opted_out[0],
           "same" if same else "DIFFERENT", "verified:", opted_out[3], "| trusted capture:", split[False][3])
+    same = single[False][0] == refused[0]
+    ok = ok and same and refused[1] == "split" and "forced capture failure" in str(refused[2])
+    print("deg single", single[False][0], "capture refused on this rank:", refused[1], refused[0], "same" if same else "DIFFERENT",
+          "capture_error:", refused[2])
+    # what the exchange of this model should cost at N = 2, 4, 8 (glass_amd.dist.predict_collective_us: a stated model with
+    # assumed constants) — the figure a SCALE run's collective.exposed_us is held against
+    from glass_amd import dist as gdist
+    for nid in (False, True):
+        pay = split[nid][4]
+        print("predicted exchange", "nodeid" if nid else "deg", pay,
+              {n: round(gdist.predict_collective_us(pay, n)["total_us"], 1) for n in (2, 4, 8)}, "us at N = 2 / 4 / 8")
     print("ALL EQUAL" if ok else "MISMATCH")
