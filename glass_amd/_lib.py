@@ -103,8 +103,6 @@ SIGNATURES = {
     "glass_pair_pool_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P]),
     "glass_pair_pool_bwd_f32": (c_int, [_P, _I, _P, _I, c_int, _P, _I, _I, _I, _P, _P]),
     "glass_dense_caps_query": (c_int, [_I, _P]),
-    "glass_dense_product_form": (c_int, []),
-    "glass_dense_product_form_set": (c_int, [c_int]),
     "glass_pair_head_supported": (c_int, [_I]),
     "glass_pair_head_ws_bytes": (c_int64, [_I, _I]),
     "glass_pair_head_fwd_f32": (c_int, [_P, _I, _I, _P, _I, _P, _P, _P, _P, _P, c_float, _P, c_uint64, _P, _P, _P, _P, _P, _P]),
@@ -183,8 +181,12 @@ def dense_caps(H):
         c = DenseCaps()
         check(load().glass_dense_caps_query(int(H), ctypes.addressof(c)), "glass_dense_caps_query")
         _caps[int(H)] = c
-    c.product_form = load().glass_dense_product_form() if c.family == 3 else 0  # (a process-wide switch, not a constant)
     return c
+
+
+# options of a dense call: bits above the activation code in the `act` word of glass_dual_linear_{fwd,bwd,dgrad,wgrad}_f32
+ACT_MASK = 0xff
+DENSE_F32_PRODUCTS = 0x100
 
 
 def load():

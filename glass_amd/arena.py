@@ -273,8 +273,6 @@ class ParamArena(FlatGradBucket):
         return self.shard_optimizer and ex is not None and ex.has_big
 
     def all_reduce_mean(self):
-        from .ops import join_side_streams
-        join_side_streams()  # the side-stream weight gradients must have landed in the arena
         ex = self.exchange
         if ex is None:
             return
@@ -285,8 +283,6 @@ class ParamArena(FlatGradBucket):
         ex.reduce_big()
 
     def zero(self):
-        from .ops import join_side_streams
-        join_side_streams()
         if not self.attached():
             raise RuntimeError("ParamArena detached (model.to()/zero_grad(set_to_none=True) after flattening?)")
         self.flat.zero_()

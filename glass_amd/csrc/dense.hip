@@ -60,6 +60,10 @@ namespace glass {
 #ifndef GLASS_FUSED_WGRAD_STAGES
 #define GLASS_FUSED_WGRAD_STAGES 2  // pipeline stages of the weight-gradient workgroups inside the fused backward launches
 #endif
+#if !GLASS_LAB && (GLASS_WGRAD_STAGED || GLASS_COMB_BWD_V2 || !GLASS_SL_STAGED2 || !GLASS_COMB_DGRAD_V2 || !GLASS_TRANS_DGRAD_V2 ||       \
+                   !GLASS_TRANS_WGRAD_STAGED2 || !GLASS_TRANS_FWD_V2 || !GLASS_COMB_FWD_V2)
+#error "the variant switches above select laboratory forms whose kernels live in tools/lab/: build with -DGLASS_LAB=1 (tools/build_trace.sh)"
+#endif
 #ifdef GLASS_DENSE_TRACE
 __device__ unsigned long long* g_dense_trace;
 __device__ int g_dense_trace_sel;
@@ -1036,111 +1040,9 @@ __device__ __forceinline__ bool eff_rows(EffRows& R, int block, const uint8_t* _
     return true;
 }
 
-template <int H, int RW>
-__global__ __launch_bounds__(kWave * RW) void comb_fwd_eff_kernel(const float* __restrict__ xa, int64_t lda,
-                                                                 const float* __restrict__ xb, int64_t ldb,
-                                                                 const float* __restrict__ Wimg,
-                                                                 const float* __restrict__ bias,
-                                                                 const uint8_t* __restrict__ mask, float zr, float omz,
-                                                                 float* __restrict__ out, int64_t ldo, int64_t N,
-                                                                 double* __restrict__ stats, int stats_exact, GnPrologue pro,
-                                                                 LabRows lab) {
-    constexpr int KT = 2 * H, KQ = KT / 4, NT = H, NLOC = NT / 16;
-    constexpr int THREADS = kWave * RW;
-    static_assert(H == 64, "one 64-column group per wave");
-    D_STAMP(1, 0);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int i = lane & 15, q = lane >> 4;
-    EffRows R;
-    if (!eff_rows<RW>(R, blockIdx.x, mask, N, lab, w, i, q)) {  // extra workgroup beyond the list: an empty partial
-        if (stats && !stats_exact)
-            for (int c = threadIdx.x; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
-        return;
-    }
-    const bool row_ok = R.row >= 0;
-    const int64_t row = row_ok ? R.row : 0;
-    const float* arow = (q < 2) ? xa + row * lda + q * KQ : xb + row * ldb + (q - 2) * KQ;  // KQ = H/2
-    const float* W = Wimg + (R.extra ? NT * KT : 0);
-    const float c1 = R.extra ? zr : omz, c0 = R.extra ? omz : zr;  // weights of the f1 / f0 halves for this kind of row
-    // bias of the effective Linear, fetched before the product (the epilogue then waits for nothing)
-    const float4 b1 = *reinterpret_cast<const float4*>(bias + 4 * i), b0 = *reinterpret_cast<const float4*>(bias + H + 4 * i);
-    extern __shared__ float4 lds_w[];
-    f32x4 acc[NLOC];
-#pragma unroll
-    for (int t = 0; t < NLOC; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    Drop drop = pro.drop;
-    if (pro.saved && drop.p > 0.f) {
-        drop.seed = pro.rng_state[0];
-        drop.step = pro.rng_state[1];
-    }
-    const bool pro_lane = pro.saved != nullptr && row_ok && q < 2;  // lanes whose chunk belongs to xa
-    GnPrologue pro_w = pro;
-    if (R.extra) pro_w.side = nullptr;  // the row's own tile wrote the normalised operand
-    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];  // scale | shift of the prologue's GraphNorm (see dual_fwd_kernel)
-    staged_product<NT, KT, NLOC, NLOC, THREADS, FwdRaw>(
-        acc, W, lds_w, lane, 0, 0,
-        [&](int kc, FwdRaw& raw) __attribute__((always_inline)) { load16(raw.x, arow + kc * kKC, row_ok); },
-        [&](int kc, const FwdRaw& raw, float (&a)[kKC]) __attribute__((always_inline)) {
-            if (kc == 0) D_STAMP(1, 5);
-#pragma unroll
-            for (int s2 = 0; s2 < kKC; ++s2) a[s2] = raw.x[s2];
-            if (pro_lane) gn_prologue16(a, gn_coef_s, pro_w, drop, row, q * KQ + kc * kKC);
-            if (kc == 0) D_STAMP(1, 6);
-            if (kc == 1) D_STAMP(1, 7);
-        },
-        [&]() __attribute__((always_inline)) {
-            if (pro.saved) gn_fwd_coef_nobarrier<H, THREADS>(pro.src, pro.saved, N, gn_coef_s);
-            D_STAMP(1, 1);
-        });
-    D_STAMP(1, 2);
-    // epilogue: acc[k][reg] is row erow[reg], column 4i + k
-    const float be[4] = {c1 * b1.x + c0 * b0.x, c1 * b1.y + c0 * b0.y, c1 * b1.z + c0 * b0.z, c1 * b1.w + c0 * b0.w};
-    float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        if (R.erow[reg] < 0) continue;
-        float o[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            o[k] = acc[k][reg] + be[k];
-            ssum[k] += o[k];
-            ssq[k] = fmaf(o[k], o[k], ssq[k]);
-        }
-        *reinterpret_cast<float4*>(out + (int64_t)R.erow[reg] * ldo + 4 * i) = make_float4(o[0], o[1], o[2], o[3]);
-    }
-    D_STAMP(1, 3);
-    if (stats == nullptr) return;
-    __syncthreads();  // every wave is done with the weight images in LDS
-    double* red = reinterpret_cast<double*>(lds_w);  // [RW row waves][H][2]
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        double s = (double)ssum[k], q2 = (double)ssq[k];
-        s += __shfl_xor(s, 16);
-        q2 += __shfl_xor(q2, 16);
-        s += __shfl_xor(s, 32);
-        q2 += __shfl_xor(q2, 32);
-        if (q == 0) {
-            red[(w * H + 4 * i + k) * 2] = s;
-            red[(w * H + 4 * i + k) * 2 + 1] = q2;
-        }
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < H; c += THREADS) {
-        double s = 0.0, q2 = 0.0;
-#pragma unroll
-        for (int ww = 0; ww < RW; ++ww) {
-            s += red[(ww * H + c) * 2];
-            q2 += red[(ww * H + c) * 2 + 1];
-        }
-        if (stats_exact) {  // exact accumulators (gn_acc.h): the consumer folds them, no finalize launch
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
-        } else {
-            stats[((size_t)blockIdx.x * 2) * H + c] = s;
-            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
-        }
-    }    D_STAMP(1, 4);
-}
+#if GLASS_LAB
+#include "../../tools/lab/comb_fwd_eff_v1.inc"  // first form of the comb forward (GLASS_COMB_FWD_V2=0): laboratory builds only
+#endif
 
 // ---- comb forward, second form (hidden 64): weights in registers, rows through LDS in four 16-row stages ---------------
 // The first form gives each wave 16 rows and stages the weight image in LDS: every wave of every workgroup is in the same
@@ -1394,232 +1296,9 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     D_STAMP(1, 4);
 }
 
-// ---- the second form with the LDS reads software-pipelined one stage ahead (three LDS buffers, three load sets in flight):
-// GLASS_COMB_FWD_PF=1 (laboratory A/B against comb_fwd_eff2_kernel; hidden 64, one wave group)
-template <int H, bool DROP, int NST>
-__global__ __launch_bounds__(4 * H) void comb_fwd_eff2p_kernel(const float* __restrict__ xa, int64_t lda,
-                                                               const float* __restrict__ xb, int64_t ldb,
-                                                               const float* __restrict__ Wimg, const float* __restrict__ bias,
-                                                               const uint8_t* __restrict__ mask, float zr, float omz,
-                                                               float* __restrict__ out, int64_t ldo, int64_t N,
-                                                               double* __restrict__ stats, int stats_exact, GnPrologue pro,
-                                                               LabRows lab) {
-    static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
-    constexpr int WG = 1;
-    constexpr int THREADS = 4 * H * WG, NTL = H / 16, KF4 = (2 * H) / 16;  // threads, 16-column tiles, float4 per lane of a weight slice
-    constexpr int KT = 2 * H, RS = KT + 4;  // LDS row stride (floats): + 4 keeps the 16 rows of a b128 read off one bank group
-    constexpr int SR = 16 * WG, NSTG = (NST + WG - 1) / WG;  // rows per stage, stages per workgroup
-    __shared__ __attribute__((aligned(16))) float tile[3][SR * RS];
-    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
-    constexpr int ROWS = 16 * NST;
-    __shared__ int rows_s[ROWS];  // row of each of the workgroup's slots: -1 none; bit 30 set: computed but not stored / counted
-    __shared__ double comb_s[WG > 1 ? 2 * H : 1];  // column sums of wave group 1, handed to group 0
-    D_STAMP(1, 0);
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int w = wv % NTL, g = wv / NTL;  // column tile, row group
-    const int j = lane & 15, q = lane >> 4;
-    // ---- prologue: EVERY load it needs is issued before the first value is used (one memory round trip; the first form
-    // waited three times: weights / bias / label byte — a conditional byte load forces vmcnt(0) —, then operands and
-    // accumulators, then gamma / beta / alpha, which the compiler had sunk behind the accumulator wait: tools/dense_trace.py
-    // slots 0 -> 6 -> 1 read 1.7 + 2.0 us).  Order of issue = order of need: the first two stages' operand rows, the
-    // GraphNorm sums, the weight slice, bias, label byte.
-    const bool extra = (int)blockIdx.x >= lab.n_main;
-    const int base = extra ? ((int)blockIdx.x - lab.n_main) * ROWS : 0;
-    const buf_rsrc r_xa = make_rsrc(xa, N * lda * 4), r_xb = make_rsrc(xb, N * ldb * 4), r_out = make_rsrc(out, N * ldo * 4);
-    const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
-    const buf_rsrc r_mask = make_rsrc(mask, N);
-    // the two float4 this thread moves per stage: 4-column group ga of the a half (GraphNorm prologue) and of the h half of
-    // row rs of the stage (one buffer resource per half: wave-uniform)
-    const int rs = tid / (H / 4), ga = tid % (H / 4);
-    int my_row[NSTG];  // (-1: none)
-    int n_lab = 0;
-    if (!extra) {
-        const int64_t r0 = (int64_t)blockIdx.x * ROWS;
-#pragma unroll
-        for (int st = 0; st < NSTG; ++st)
-            my_row[st] = (SR * st + rs < ROWS && r0 + SR * st + rs < N) ? (int)(r0 + SR * st + rs) : -1;
-    } else {
-        // listed rows: every thread reads its own stage rows straight from the list (the count arrives beside them)
-        const buf_rsrc r_list = make_rsrc(lab.rows, (int64_t)lab.cap * 4);
-        int lr[NSTG];
-#pragma unroll
-        for (int st = 0; st < NSTG; ++st)
-            lr[st] = buf_load1i(r_list, SR * st + rs < ROWS ? (base + SR * st + rs) * 4 : kBufOOB);
-        n_lab = lab.count[0];
-        if (base >= n_lab) {  // extra workgroup beyond the list: an empty partial
-            if (stats && !stats_exact)
-                for (int c = tid; c < 2 * H; c += THREADS) stats[(size_t)blockIdx.x * 2 * H + c] = 0.0;
-            return;
-        }
-#pragma unroll
-        for (int st = 0; st < NSTG; ++st) my_row[st] = (SR * st + rs < ROWS && base + SR * st + rs < n_lab) ? lr[st] : -1;
-    }
-    auto issue = [&](int st, float4 (&raw)[2]) __attribute__((always_inline)) {
-        const int r = my_row[st];
-        raw[0] = buf_load4(r_xa, r >= 0 ? (int)((r * lda + 4 * ga) * 4) : kBufOOB);
-        raw[1] = buf_load4(r_xb, r >= 0 ? (int)((r * ldb + 4 * ga) * 4) : kBufOOB);
-    };
-    float4 raw[3][2];  // the loads of three stages in flight (register sets by stage % 3)
-    issue(0, raw[0]);
-    issue(1, raw[1]);
-    issue(2, raw[2]);
-    GnCoefRegs CR;
-    const bool fold_here = pro.saved && (WG == 1 || tid < 4 * H);  // (wave-uniform)
-    if (fold_here && pro.src.acc) gn_fwd_coef_issue<H, 4 * H>(pro.src, CR);
-    // this wave's slice of the effective weight: 8 float4 per lane
-    const float4* img = reinterpret_cast<const float4*>(Wimg + (extra ? H * KT : 0));
-    float4 bw[KF4];
-#pragma unroll
-    for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
-    const float bias1 = bias[16 * w + j], bias0 = bias[H + 16 * w + j];
-    // row of slot `tid` (threads < ROWS) and its label byte (main tiles)
-    int slot_v = -1;
-    unsigned slot_mask = 0;
-    if (!extra) {
-        const int64_t r0 = (int64_t)blockIdx.x * ROWS;
-        const bool ok = tid < ROWS && r0 + tid < N;
-        slot_v = ok ? (int)(r0 + tid) : -1;
-        slot_mask = __builtin_amdgcn_raw_buffer_load_b8(r_mask, ok ? (int)(r0 + tid) : kBufOOB, 0, 0);
-    } else {
-        const buf_rsrc r_list = make_rsrc(lab.rows, (int64_t)lab.cap * 4);
-        const int v = buf_load1i(r_list, tid < ROWS ? (base + tid) * 4 : kBufOOB);
-        slot_v = (tid < ROWS && base + tid < n_lab) ? v : -1;
-    }
-    if (fold_here && pro.src.acc) {
-        gn_fwd_coef_issue_params<H>(pro.src, CR);
-        glass_pin(CR.gamma);
-        glass_pin(CR.beta);
-        glass_pin(CR.alpha);
-    }
-    float bias1p = bias1, bias0p = bias0;
-    glass_pin(bias1p);
-    glass_pin(bias0p);
-    glass_pin(slot_mask);
-    D_STAMP(1, 6);
-    Drop drop = pro.drop;
-    if (pro.saved && drop.p > 0.f) {
-        drop.seed = pro.rng_state[0];
-        drop.step = pro.rng_state[1];
-    }
-    // ---- first use of loaded values
-    const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
-    const float be = c1 * bias1p + c0 * bias0p;
-    if (fold_here) gn_fwd_coef_finish<H, 4 * H>(pro.src, pro.saved, N, CR, gn_coef_s);
-    if (tid < ROWS) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
-    D_STAMP(1, 1);
-    lds_barrier();  // coefficients + row table
-    const bool pro_on = pro.saved != nullptr;
-    const bool side_on = pro.side != nullptr && !extra;  // (the row's own tile writes the normalised operand)
-    // GraphNorm scale / shift of this thread's four columns (the same in every stage)
-    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (pro_on) {
-        const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
-        const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
-        sc[0] = s4.x, sc[1] = s4.y, sc[2] = s4.z, sc[3] = s4.w;
-        sh[0] = h4.x, sh[1] = h4.y, sh[2] = h4.z, sh[3] = h4.w;
-    }
-    // prep: the prologue arithmetic of one float4 — branch-free, so that it can be scheduled BETWEEN the MFMAs of the
-    // previous stage (the matrix core runs a 16x16x4 for 32 cycles; a wave that issues its MFMAs back to back leaves its
-    // VALU idle meanwhile, and one that runs the prologue first leaves the matrix core idle)
-    auto prep = [&](int st, const float4& raw) __attribute__((always_inline)) -> float4 {
-        const int r = my_row[st];
-        float a[4] = {raw.x, raw.y, raw.z, raw.w};
-        float ds[4] = {1.f, 1.f, 1.f, 1.f};
-        if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) a[k] = fmaf(a[k], sc[k], sh[k]) * ds[k];
-        return make_float4(a[0], a[1], a[2], a[3]);
-    };
-    auto commit = [&](int st, const float4& v, const float4& hraw) __attribute__((always_inline)) {
-        float* T = tile[st % 3];
-        const int r = my_row[st];
-        buf_store4(r_side, (pro_on && side_on && r >= 0) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
-        *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
-        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = hraw;
-    };
-    float ssum = 0.f, ssq = 0.f;  // this lane's column 16w + j over the rows 4q + r of every stage
-    // Software pipeline over THREE LDS buffers: while the MFMAs of stage s run on fragments already in registers, the
-    // fragments of stage s + 1 are read from LDS (its rows were committed during stage s - 1) and the rows of stage s + 2
-    // are committed — after a stage's barrier no wave waits for an LDS read before its first MFMA.
-    commit(0, prep(0, raw[0][0]), raw[0][1]);
-    if (3 < NSTG) issue(3, raw[0]);
-    commit(1, prep(1, raw[1][0]), raw[1][1]);
-    if (4 < NSTG) issue(4, raw[1]);
-    lds_barrier();
-    float4 a4[2][KF4];
-    {
-        const float* T = tile[0] + (16 * g + j) * RS + (KT / 4) * q;
-#pragma unroll
-        for (int tt = 0; tt < KF4; ++tt) a4[0][tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
-    }
-#pragma unroll
-    for (int st = 0; st < NSTG; ++st) {
-        if (st == 1) D_STAMP(1, 5);
-        if (st + 1 < NSTG) {  // the next stage's fragments: in flight under this stage's MFMAs
-            const float* Tn = tile[(st + 1) % 3] + (16 * g + j) * RS + (KT / 4) * q;
-#pragma unroll
-            for (int tt = 0; tt < KF4; ++tt) a4[(st + 1) & 1][tt] = *reinterpret_cast<const float4*>(Tn + 4 * tt);
-        }
-        int rv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int tt = 0; tt < KF4; tt += 2) {
-            const float4 xa0 = a4[st & 1][tt], xa1 = a4[st & 1][tt + 1];
-            const float x0[4] = {xa0.x, xa0.y, xa0.z, xa0.w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
-            const float x1[4] = {xa1.x, xa1.y, xa1.z, xa1.w};
-            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
-            }
-        }
-        if (st == 1) D_STAMP(1, 2);
-        if (st + 2 < NSTG) {
-            commit(st + 2, prep(st + 2, raw[(st + 2) % 3][0]), raw[(st + 2) % 3][1]);
-            if (st + 5 < NSTG) issue(st + 5, raw[(st + 2) % 3]);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
-            const float o = acc0[r] + acc1[r] + be;
-            buf_store1(r_out, live ? (int)((rv[r] * ldo + 16 * w + j) * 4) : kBufOOB, o);
-            ssum += live ? o : 0.f;
-            ssq += live ? o * o : 0.f;
-        }
-        if (st + 1 < NSTG) lds_barrier();
-    }
-    D_STAMP(1, 3);
-    if (stats == nullptr) return;
-    double s = (double)ssum, q2 = (double)ssq;
-    s += __shfl_xor(s, 16);
-    q2 += __shfl_xor(q2, 16);
-    s += __shfl_xor(s, 32);
-    q2 += __shfl_xor(q2, 32);
-    if (WG > 1) {  // one add per column and workgroup, as with one wave group: group 1 hands its sums over
-        if (g == 1 && q == 0) {
-            comb_s[16 * w + j] = s;
-            comb_s[H + 16 * w + j] = q2;
-        }
-        lds_barrier();
-        if (g == 1) return;
-        s += comb_s[16 * w + j];
-        q2 += comb_s[H + 16 * w + j];
-    }
-    if (q == 0) {
-        const int c = 16 * w + j;
-        if (stats_exact) {
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 0, c, H, s, kAccScaleFwd);
-            gn_acc_add(reinterpret_cast<long long*>(stats), blockIdx.x % stats_exact, 1, c, H, q2, kAccScaleFwd);
-        } else {
-            stats[((size_t)blockIdx.x * 2) * H + c] = s;
-            stats[((size_t)blockIdx.x * 2 + 1) * H + c] = q2;
-        }
-    }
-    D_STAMP(1, 4);
-}
+#if GLASS_LAB
+#include "../../tools/lab/comb_fwd_eff2p.inc"  // software-pipelined variant of the second form (measured neutral/negative): laboratory builds only
+#endif
 
 // ---- comb forward, third form: the second form with a RUN-TIME number of stages per workgroup ("tall" row tiles) ---------
 // The second form fixes 64 or 80 rows per workgroup.  Beyond 80 x 256 rows a launch then runs in several ROUNDS of
@@ -2350,234 +2029,9 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
 }
 constexpr size_t kCombDgrad2Lds = (size_t)(2 * 3 * 16 * (64 + 4) + 64 + 5 * 64) * sizeof(float);
 
-template <int H, bool DROP>
-__global__ __launch_bounds__(kBlock) void comb_bwd_eff2_kernel(DgradEffArgs A, const float* __restrict__ X, int64_t ldx,
-                                                               const float* __restrict__ X2, int64_t ldx2, float zr, int n_l,
-                                                               float* __restrict__ part_w, float* __restrict__ part_b) {
-    static_assert(H == 64, "four waves x 16 columns");
-    constexpr int RS = H + 4;   // plain tiles [16 rows][H]: row stride (floats)
-    constexpr int RT = 20;      // transposed tiles [col][16 rows]: row stride (floats), 16-B aligned
-    struct __attribute__((aligned(16))) Stage {
-        float dcP[16 * RS];       // dc rows                      (data gradient: A operand)
-        float dcT[H * RT];        // dc transposed [o][row]       (weight gradient: A operand; bias partial)
-        float inT[2 * H * RT];    // [g || x_] transposed [i][row] (weight gradient: B operand)
-        float U[16 * RS];         // keep-scale of the GraphNorm's dropout per element of the g half
-        float XU[16 * RS];        // xhat * keep-scale
-    };
-    __shared__ Stage stg[2];
-    __shared__ int rows_s[64];
-    D_STAMP(3, 0);
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int j = lane & 15, q = lane >> 4;
-    const int n_main = A.lab.n_main;
-    const bool extra = (int)blockIdx.x >= n_main;
-    const GnBwdStats& gs = A.gs;
-    const int64_t N = A.N;
-    if (blockIdx.x == 0 && tid == 0) {  // mode header behind the bias partials, read by the (deferred) reduce launch
-        float* header = part_b + (int64_t)(n_main + n_l) * kSLOut;
-        header[0] = 2.f;
-        header[1] = zr;
-        header[2] = 1.f;  // plain [o][i] order of the partial tiles
-    }
-    float* pw = part_w + (int64_t)blockIdx.x * (H * 2 * H);
-    int n_lab = 0, base = 0;
-    if (extra) {
-        n_lab = A.lab.count[0];
-        base = ((int)blockIdx.x - n_main) * 64;
-        if (base >= n_lab) {  // beyond the list: an empty L tile, empty sums
-            for (int k = tid * 4; k < H * 2 * H; k += kBlock * 4) *reinterpret_cast<float4*>(pw + k) = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (tid < H) part_b[(int64_t)blockIdx.x * kSLOut + tid] = 0.f;
-            if (gs.partial && !gs.exact)
-                for (int c = tid; c < 2 * H; c += kBlock) gs.partial[(size_t)blockIdx.x * 2 * H + c] = 0.0;
-            return;
-        }
-    }
-    const buf_rsrc r_dc = make_rsrc(A.dsrc, N * A.ldd * 4), r_out = make_rsrc(A.out, N * A.ldo * 4);
-    const buf_rsrc r_g = make_rsrc(X, N * ldx * 4), r_x = make_rsrc(X2, N * ldx2 * 4);
-    const buf_rsrc r_a = make_rsrc(gs.partial ? gs.x : A.dsrc, gs.partial ? N * gs.ldx * 4 : 0);
-    // this wave's slices of the effective weight (transposed operand): columns 16w .. of the dg half and of the dx_ half
-    const float4* img = reinterpret_cast<const float4*>(A.WT + (extra ? 2 * H * H : 0));
-    float4 bwg[4], bwx[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        bwg[v] = img[(w * 4 + v) * 64 + lane];
-        bwx[v] = img[((4 + w) * 4 + v) * 64 + lane];
-    }
-    const int rs = tid >> 4, ga = tid & 15;  // loader role: row rs of the stage, columns 4 ga .. 4 ga + 3
-    int my_row[4];
-    int slot_v = -1;
-    unsigned char slot_mask = 0;
-    if (!extra) {
-        const int64_t r0 = (int64_t)blockIdx.x * 64;
-#pragma unroll
-        for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
-        if (tid < 64 && r0 + tid < N) {
-            slot_v = (int)(r0 + tid);
-            slot_mask = A.mask[r0 + tid];
-        }
-    } else {
-        if (tid < 64) {
-            slot_v = base + tid < n_lab ? A.lab.rows[base + tid] : -1;
-            rows_s[tid] = slot_v;
-        }
-        lds_barrier();
-#pragma unroll
-        for (int st = 0; st < 4; ++st) my_row[st] = rows_s[16 * st + rs];
-    }
-    struct Raw {
-        float4 dc, a, g, x;
-    };
-    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
-        const int r = my_row[st];
-        R.dc = buf_load4(r_dc, r >= 0 ? (int)((r * A.ldd + 4 * ga) * 4) : kBufOOB);
-        R.a = buf_load4(r_a, r >= 0 ? (int)((r * gs.ldx + 4 * ga) * 4) : kBufOOB);
-        R.g = buf_load4(r_g, r >= 0 ? (int)((r * ldx + 4 * ga) * 4) : kBufOOB);
-        R.x = buf_load4(r_x, r >= 0 ? (int)((r * ldx2 + 4 * ga) * 4) : kBufOOB);
-    };
-    Raw rawA, rawB;
-    issue(0, rawA);
-    issue(1, rawB);
-    // GraphNorm coefficients of this loader thread's four columns
-    float g_mu[4] = {0.f, 0.f, 0.f, 0.f}, g_rs[4] = {0.f, 0.f, 0.f, 0.f}, g_al[4] = {0.f, 0.f, 0.f, 0.f};
-    Drop drop = gs.drop;
-    if (gs.partial) {
-        if (DROP) {
-            drop.seed = A.rng_state[0];
-            drop.step = A.rng_state[1];
-        }
-        const float4 m4 = *reinterpret_cast<const float4*>(gs.saved + 4 * ga);
-        const float4 r4 = *reinterpret_cast<const float4*>(gs.saved + H + 4 * ga);
-        const float4 a4 = *reinterpret_cast<const float4*>(gs.alpha + 4 * ga);
-        g_mu[0] = m4.x, g_mu[1] = m4.y, g_mu[2] = m4.z, g_mu[3] = m4.w;
-        g_rs[0] = r4.x, g_rs[1] = r4.y, g_rs[2] = r4.z, g_rs[3] = r4.w;
-        g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
-    }
-    if (tid < 64) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;
-    // stage -> LDS: the loader's four float4 in the layouts their readers want
-    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
-        Stage& S = stg[st & 1];
-        const int r = my_row[st];
-        *reinterpret_cast<float4*>(S.dcP + rs * RS + 4 * ga) = R.dc;
-        const float dcv[4] = {R.dc.x, R.dc.y, R.dc.z, R.dc.w}, gv[4] = {R.g.x, R.g.y, R.g.z, R.g.w};
-        const float xv[4] = {R.x.x, R.x.y, R.x.z, R.x.w}, av[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
-        float ds[4] = {1.f, 1.f, 1.f, 1.f};
-        if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
-        float u[4], xu[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            S.dcT[(4 * ga + k) * RT + rs] = dcv[k];
-            S.inT[(4 * ga + k) * RT + rs] = gv[k];
-            S.inT[(H + 4 * ga + k) * RT + rs] = xv[k];
-            u[k] = ds[k];
-            xu[k] = (av[k] - g_al[k] * g_mu[k]) * g_rs[k] * ds[k];
-        }
-        *reinterpret_cast<float4*>(S.U + rs * RS + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
-        *reinterpret_cast<float4*>(S.XU + rs * RS + 4 * ga) = make_float4(xu[0], xu[1], xu[2], xu[3]);
-    };
-    commit(0, rawA);
-    issue(2, rawA);
-    D_STAMP(3, 1);
-    lds_barrier();
-    f32x4 wacc[8];  // weight-gradient partial: outputs o = 16w + 4q + r, inputs i = 16 it + j
-#pragma unroll
-    for (int it = 0; it < 8; ++it) wacc[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;             // bias partial of output o = tid (threads < 64)
-    float s1 = 0.f, s2 = 0.f;     // GraphNorm backward sums of column 16w + j over this lane's rows
-    const int cg = 16 * w + j;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) {
-        const Stage& S = stg[st & 1];
-        // ---- (a) data gradient of the stage's 16 rows ----
-        float4 a4[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(S.dcP + j * RS + 16 * q + 4 * v);
-        int rv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
-        float uu[4], xx[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            uu[r] = S.U[(4 * q + r) * RS + cg];
-            xx[r] = S.XU[(4 * q + r) * RS + cg];
-        }
-        // ---- (b) operands of the weight-gradient update: rows 4q .. 4q+3 of column o / i per lane ----
-        const float4 at = *reinterpret_cast<const float4*>(S.dcT + (16 * w + j) * RT + 4 * q);
-        float4 bt[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) bt[it] = *reinterpret_cast<const float4*>(S.inT + (16 * it + j) * RT + 4 * q);
-        float bpart = 0.f;
-        if (tid < H) {
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                const float4 t4 = *reinterpret_cast<const float4*>(S.dcT + tid * RT + 4 * v);
-                bpart += (t4.x + t4.y) + (t4.z + t4.w);
-            }
-        }
-        bsum += bpart;
-        f32x4 accg = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
-            const float yg[4] = {bwg[v].x, bwg[v].y, bwg[v].z, bwg[v].w}, yx[4] = {bwx[v].x, bwx[v].y, bwx[v].z, bwx[v].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yg[e], accg, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yx[e], accx, 0, 0, 0);
-            }
-        }
-        const float av[4] = {at.x, at.y, at.z, at.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const float bv[4] = {bt[it].x, bt[it].y, bt[it].z, bt[it].w};
-                wacc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], wacc[it], 0, 0, 0);
-            }
-        // next stage -> LDS (the other buffer: its last readers passed the barrier at the end of the previous iteration)
-        if (st + 1 < 4) {
-            commit(st + 1, (st & 1) ? rawA : rawB);
-            if (st + 3 < 4) {
-                if (st & 1) issue(st + 3, rawA); else issue(st + 3, rawB);
-            }
-        }
-        // data-gradient epilogue: rows 4q + r, columns cg (dg) and H + cg (dx_)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
-            const int row = rv[r] & ((1 << 30) - 1);
-            buf_store1(r_out, live ? (int)((row * A.ldo + cg) * 4) : kBufOOB, accg[r]);
-            buf_store1(r_out, live ? (int)((row * A.ldo + H + cg) * 4) : kBufOOB, accx[r]);
-            const float gp = live ? accg[r] * uu[r] : 0.f;
-            s1 += gp;
-            s2 = fmaf(live ? accg[r] : 0.f, xx[r], s2);
-        }
-        if (st + 1 < 4) lds_barrier();
-    }
-    D_STAMP(3, 3);
-    // weight-gradient partial of this workgroup: plain [o][i]
-#pragma unroll
-    for (int it = 0; it < 8; ++it)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pw[(16 * w + 4 * q + r) * (2 * H) + 16 * it + j] = wacc[it][r];
-    if (tid < H) part_b[(int64_t)blockIdx.x * kSLOut + tid] = bsum;
-    if (gs.partial) {
-        double a = (double)s1, b2 = (double)s2;
-        a += __shfl_xor(a, 16);
-        b2 += __shfl_xor(b2, 16);
-        a += __shfl_xor(a, 32);
-        b2 += __shfl_xor(b2, 32);
-        if (q == 0) {
-            if (gs.exact) {
-                gn_acc_add(reinterpret_cast<long long*>(gs.partial), blockIdx.x % gs.exact, 0, cg, H, a, kAccScaleBwd);
-                gn_acc_add(reinterpret_cast<long long*>(gs.partial), blockIdx.x % gs.exact, 1, cg, H, b2, kAccScaleBwd);
-            } else {
-                gs.partial[((size_t)blockIdx.x * 2) * H + cg] = a;
-                gs.partial[((size_t)blockIdx.x * 2 + 1) * H + cg] = b2;
-            }
-        }
-    }
-    D_STAMP(3, 4);
-}
+#if GLASS_LAB
+#include "../../tools/lab/comb_bwd_eff2.inc"  // one-pass staged comb backward (GLASS_COMB_BWD_V2; measured slower): laboratory builds only
+#endif
 
 // Fused backward launch of the comb pair in effective-weight form: data-gradient row tiles (main + extra), then the
 // weight-gradient blocks in S / L form (wgrad_sl_body: row slabs, then the labeled-row tiles).
@@ -2801,10 +2255,7 @@ static bool wave16_shape_ok(int64_t H) { return H == 64; }
 // LDS traffic for the same 32 MFMAs per wave, and eight waves fetch the weight slices twice) — so trans takes 2, comb 1.
 // GLASS_FWD_WG=1|2 forces both (laboratory A/B; read once per process).
 static int fwd_wave_groups(bool comb) {
-    static const int forced = [] {
-        const char* e = getenv("GLASS_FWD_WG");
-        return e ? atoi(e) : 0;
-    }();
+    const int forced = lab_knob("GLASS_FWD_WG", 0);
     if (forced == 1 || forced == 2) return forced;
     return comb ? 1 : 2;
 }
@@ -2861,7 +2312,7 @@ extern "C" int glass_dense_caps_query(int64_t H, glass_dense_caps* out) {
         c.stat_rows = (int32_t)glass_dual_linear_stat_rows(H);
         c.fwd_gather = glass_dual_linear_fwd_gather_supported(H);
         c.act_codes = (1 << GLASS_ACT_ELU) | (1 << GLASS_ACT_RELU);
-        c.product_form = (c.family == 3 && tiled_split_products()) ? 1 : 0;
+        c.product_form = c.family == 3 ? 1 : 0;  // the family's default; GLASS_DENSE_F32_PRODUCTS in a call's act word opts out
     }
     c.serve_width = c.family ? (int32_t)H : (H <= 64 ? 64 : H <= 128 ? 128 : H <= 256 ? 256 : H <= 512 ? 512 : 0);
     c.gn_exact = glass_gn_exact_supported(H);
@@ -2876,12 +2327,6 @@ extern "C" int glass_dense_caps_query(int64_t H, glass_dense_caps* out) {
 }
 // How the LDS-tiled family (hidden 128 / 256 / 512) forms its fp32 products: 1 = six bf16 partial products of 3-way split
 // operands (split_mma.h: as accurate as the f32-input instruction, 6/16 of its matrix-core cycles), 0 = v_mfma_f32_32x32x2_f32.
-extern "C" int glass_dense_product_form(void) { return tiled_split_products() ? 1 : 0; }
-extern "C" int glass_dense_product_form_set(int form) {
-    GLASS_REQUIRE(form == 0 || form == 1, "dense_product_form_set: 0 (f32-input MFMA) or 1 (split bf16 products)");
-    tiled_split_products_set(form);
-    return 0;
-}
 // glass_dual_linear_fwd_f32 with xa_index (the trans pair of layer 0 gathers its operand rows from the embedding table)
 extern "C" int glass_dual_linear_fwd_gather_supported(int64_t H) { return (wave16_shape_ok(H) || narrow_shape_ok(H) || tiled_here(H)) ? 1 : 0; }
 
@@ -2915,6 +2360,7 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
                                          double* stats, int stats_exact, const float* gn_saved, const glass_gn_src* gn_src,
                                          int gn_act, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* xa_out,
                                          int64_t ldxo, const int64_t* xa_index, int64_t xa_rows, void* stream) {
+    const CallOptions call_options(act);  // act word -> activation code + this call's options
     GLASS_REQUIRE(xa && W && bias && mask && out && n_nodes > 0, "dual_linear_fwd: null pointer");
     GLASS_REQUIRE((!stats_exact || (stats && wave16_shape_ok(H) && rep_ok(stats_exact))) && (!gn_src || (gn_saved && wave16_shape_ok(H))),
                   "dual_linear_fwd: exact GraphNorm accumulators are served at hidden 64 only (glass_gn_exact_supported)");
@@ -2984,11 +2430,13 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
 #define GLASS_TF2(NS, WGN)                                                                                                  \
     hipLaunchKernelGGL((trans_fwd2_kernel<64, NS, WGN>), tall ? dim3((unsigned)wg80) : grid, dim3(kBlock * WGN), 0, st, xa, lda,     \
                        src_rows, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index)
-        const int wgn = fwd_wave_groups(false);
-        if (tall && wgn == 2) GLASS_TF2(5, 2);
-        else if (tall) GLASS_TF2(5, 1);
-        else if (wgn == 2) GLASS_TF2(4, 2);
-        else GLASS_TF2(4, 1);
+#if GLASS_LAB  // the one-wave-group form of the trans forward: laboratory A/B (GLASS_FWD_WG=1)
+        if (fwd_wave_groups(false) == 1) {
+            if (tall) GLASS_TF2(5, 1); else GLASS_TF2(4, 1);
+            return launch_status("glass_dual_linear_fwd_f32");
+        }
+#endif
+        if (tall) GLASS_TF2(5, 2); else GLASS_TF2(4, 2);
 #undef GLASS_TF2
         return launch_status("glass_dual_linear_fwd_f32");
     }
@@ -3069,11 +2517,7 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         GLASS_REQUIRE(!gn_exact, "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only");
         const DgradArgs d128{dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs};
         const int64_t n_tiles = ceil_div(n_nodes, 64);
-        static const bool tall_on = [] {
-            const char* e = getenv("GLASS_TRANS_DGRAD3");
-            return !(e && e[0] == '0');
-        }();
-        if (tall_on && n_tiles > 256) {  // more than one round of 64-row tiles: tall tiles, one workgroup per CU (trans_dgrad3_kernel)
+        if (lab_knob("GLASS_TRANS_DGRAD3", 1) && n_tiles > 256) {  // more than one round of 64-row tiles: tall tiles, one workgroup per CU (trans_dgrad3_kernel)
             const int tiles_per_wg = (int)ceil_div(n_tiles, 256);
             const size_t lds3 = trans_dgrad3_lds(128);
             allow_lds(trans_dgrad3_kernel<128>, lds3);
@@ -3140,6 +2584,7 @@ extern "C" int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const
                                            int64_t n_nodes, int64_t H, double* gn_partial, const float* gn_x,
                                            int64_t gn_ldx, const float* gn_saved, const float* gn_alpha, int gn_act,
                                            float gn_p_drop, uint64_t gn_call_id, int gn_exact, void* stream) {
+    const CallOptions call_options(act);
     return dgrad_launch(dsrc, ldd, T, ldt, mask, z_ratio, act, WT, n_out, addend, ldadd, p_drop, rng_state, call_id, out, ldo,
                         n_nodes, H, gn_partial, gn_x, gn_ldx, gn_saved, gn_alpha, gn_act, gn_p_drop, gn_call_id, gn_exact,
                         nullptr, stream);
@@ -3152,6 +2597,7 @@ extern "C" int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const f
                                          const float* gn_x, int64_t gn_ldx, const float* gn_saved, const float* gn_alpha,
                                          int gn_act, float gn_p_drop, uint64_t gn_call_id, int gn_exact, const float* X,
                                          int64_t ldx, const float* X2, int64_t ldx2, void* ws, void* stream) {
+    const CallOptions call_options(act);
     GLASS_REQUIRE(X && ws, "dual_linear_bwd: null pointer");
     const BwdWgrad wg{X, ldx, X2, ldx2, ws};
     return dgrad_launch(dsrc, ldd, T, ldt, mask, z_ratio, act, WT, n_out, addend, ldadd, p_drop, rng_state, call_id, out, ldo,
@@ -3171,20 +2617,8 @@ extern "C" int glass_comb_eff_fwd_supported(int64_t H) { return (H == 64 || (GLA
 struct CombFwdGeom {
     int rows_main, rows_extra, n_main, n_extra;
 };
-static bool comb_fwd_pf_on() {
-    static const bool on = [] {
-        const char* e = getenv("GLASS_COMB_FWD_PF");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-static bool comb_fwd3_on() {
-    static const bool on = [] {
-        const char* e = getenv("GLASS_COMB_FWD3");
-        return !(e && e[0] == '0');
-    }();
-    return on && GLASS_COMB_FWD_V2;
-}
+static bool comb_fwd_pf_on() { return GLASS_LAB && lab_knob("GLASS_COMB_FWD_PF", 0) == 1; }
+static bool comb_fwd3_on() { return lab_knob("GLASS_COMB_FWD3", 1) != 0 && GLASS_COMB_FWD_V2; }
 static CombFwdGeom comb_fwd_geom(int64_t n_nodes, int64_t lab_cap, int64_t H);
 // the third form is taken where its tiles are taller than the second form's 80 rows (below that the unrolled second form
 // measured 0.7 us faster per launch at ppi_bp-shape: 24.6 vs 25.3 us for the two launches)
@@ -3281,7 +2715,9 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
                   "comb_eff_fwd: bad gn_src (one accumulator block, all pointers set)");
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
     const LabRows lab{lab_rows, lab_count, n_main, (int)lab_cap};
-    const size_t lds = lds_bytes(H, 2);  // two K passes of the [H][2H] effective weight
+#if GLASS_LAB
+    const size_t lds = lds_bytes(H, 2);  // (first form) two K passes of the [H][2H] effective weight
+#endif
     const int64_t ld_max = std::max(std::max(lda, ldb), std::max(ldo, gn_saved ? ldxo : (int64_t)0));
     GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || n_nodes * ld_max * 4 < (1ll << 31),
                   "comb_eff_fwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets; glass_comb_eff_max_rows)");
@@ -3303,8 +2739,10 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
                        Wimg_eff, bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab3, cg.rows_main, cg.rows_extra)
         if (H == 128) {
             if (dr) GLASS_CF3(128, true, 1); else GLASS_CF3(128, false, 1);
+#if GLASS_LAB  // two wave groups on the comb forward: laboratory A/B (GLASS_FWD_WG=2)
         } else if (fwd_wave_groups(true) == 2) {
             if (dr) GLASS_CF3(64, true, 2); else GLASS_CF3(64, false, 2);
+#endif
         } else {
             if (dr) GLASS_CF3(64, true, 1); else GLASS_CF3(64, false, 1);
         }
@@ -3316,6 +2754,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
         else if (dr) GLASS_CF2(128, true, 4);
         else if (tall) GLASS_CF2(128, false, 5);
         else GLASS_CF2(128, false, 4);
+#if GLASS_LAB  // laboratory A/B: two wave groups (GLASS_FWD_WG=2), the software-pipelined second form (GLASS_COMB_FWD_PF=1)
     } else if (GLASS_COMB_FWD_V2 && fwd_wave_groups(true) == 2) {
         if (dr && tall) GLASS_CF2W(true, 5);
         else if (dr) GLASS_CF2W(true, 4);
@@ -3330,6 +2769,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
         else if (tall) GLASS_CF2P(false, 5);
         else GLASS_CF2P(false, 4);
 #undef GLASS_CF2P
+#endif
     } else if (GLASS_COMB_FWD_V2) {
         if (dr && tall) GLASS_CF2(64, true, 5);
         else if (dr) GLASS_CF2(64, true, 4);
@@ -3338,9 +2778,11 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     }
 #undef GLASS_CF2
 #undef GLASS_CF2W
+#if GLASS_LAB  // first form (GLASS_COMB_FWD_V2=0)
     else
         hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
                            bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
+#endif
     return launch_status("glass_comb_eff_fwd_f32");
 }
 
@@ -3410,7 +2852,8 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
         launch_wgrad_sl(sl, n_nodes, zr, part_w, part_b, st);
         return launch_status("glass_comb_eff_bwd_f32 (two launches)");
     }
-    if (GLASS_COMB_BWD_V2) {
+#if GLASS_LAB && GLASS_COMB_BWD_V2
+    {
         // staged form: WTimg_eff holds the layout-7 images (read by the kernels above), then the layout-10 images
         GLASS_REQUIRE(gn_act == GLASS_ACT_NONE, "comb_eff_bwd: the GraphNorm in front of the comb pair has no activation");
         const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(ldx, ldx2), gn_partial ? gn_ldx : (int64_t)0));
@@ -3424,6 +2867,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
             hipLaunchKernelGGL((comb_bwd_eff2_kernel<64, false>), grid2, dim3(kBlock), 0, st, d2, X, ldx, X2, ldx2, zr, g.n_l, part_w, part_b);
         return launch_status("glass_comb_eff_bwd_f32 (staged)");
     }
+#endif
     if (GLASS_COMB_DGRAD_V2) {
         GLASS_REQUIRE(gn_act == GLASS_ACT_NONE, "comb_eff_bwd: the GraphNorm in front of the comb pair has no activation");
         const int64_t ld_max = std::max(std::max(ldd, ldo), gn_partial ? gn_ldx : (int64_t)0);
@@ -3478,7 +2922,7 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
         const bool tiled_layout = layout == kLayoutTiledPaired || layout == kLayoutTiledPlain || layout == kLayoutTiledSplit ||
                                   layout == kLayoutTiledPlainEff || layout == kLayoutTiledPairedEff;
         b.job[k] = PackJob{src[k], dst[k], (int)NT[k], (int)KT[k], transposed[k] & 1, layout, z_ratio ? z_ratio[k] : 0.f,
-                           tiled_layout ? 1 : 0};  // (always: a later glass_dense_product_form_set never meets a stale image)
+                           tiled_layout ? 1 : 0};  // (always: either product form may read this image, call by call)
     }
     unsigned gx = 32;
     if (tab.W && (unsigned)ceil_div(tab.H, kTabCols) > gx) gx = (unsigned)ceil_div(tab.H, kTabCols);

@@ -96,8 +96,33 @@ bool tiled_eff_fwd_shape(int64_t H, int64_t K);        // ... whose forward read
 
 // dense_tiled.hip
 bool tiled_shape_ok(int64_t H);
-bool tiled_split_products();          // fp32 products as six bf16 partial products (split_mma.h) or the f32-input MFMA
-int tiled_split_products_set(int on);  // -> previous; on < 0: query only
+// Options of the CURRENT entry-point call (the bits of its `act` word above GLASS_ACT_MASK), visible to the launch helpers
+// of the other translation units for the duration of that call, on the calling thread only: set by a CallOptions object at
+// the top of the four dense entries, restored when it goes out of scope.  Not state: nothing outlives the call.
+extern thread_local int t_call_options;
+struct CallOptions {
+    int prev;
+    explicit CallOptions(int& act) : prev(t_call_options) {
+        t_call_options = act & ~GLASS_ACT_MASK;
+        act &= GLASS_ACT_MASK;
+    }
+    ~CallOptions() { t_call_options = prev; }
+    CallOptions(const CallOptions&) = delete;
+    CallOptions& operator=(const CallOptions&) = delete;
+};
+// fp32 products as six bf16 partial products (split_mma.h; the tiled family's default) or the f32-input MFMA: per call
+inline bool tiled_split_products() { return !(t_call_options & GLASS_DENSE_F32_PRODUCTS); }
+
+// Laboratory knobs (variants kept for A/B measurements): CONSTANTS in the product build — the library reads no environment
+// variable.  A lab build (tools/build_trace.sh: -DGLASS_LAB=1, linked with tools/lab/lab_knobs.cpp) resolves them at run time.
+#ifndef GLASS_LAB
+#define GLASS_LAB 0
+#endif
+#if GLASS_LAB
+int lab_knob(const char* name, int dflt);
+#else
+inline int lab_knob(const char*, int dflt) { return dflt; }
+#endif
 int tiled_rows(int64_t H);  // rows per workgroup = rows per statistics partial of the tiled kernels (64 at hidden 128, else 128)
 int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
                      const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,

@@ -69,7 +69,6 @@ bool tiled_shape_ok(int64_t H) { return H == 128 || H == 256 || H == 512; }
 // forward where halving the column tiles is possible (hidden 128 has a single one)
 bool tiled_eff_dgrad_shape(int64_t H, int64_t n_out) { return tiled_shape_ok(H) && n_out == 2 * H; }
 bool tiled_eff_fwd_shape(int64_t H, int64_t K) { return (H == 256 || H == 512) && K == 2 * H; }
-bool tiled_split_products();
 // hidden 128: 64-row tiles in the f32-input form (782 workgroups at N = 50 000, four per CU); 128-row tiles in the split form —
 // its stages are 60 KiB at 64 rows too, so only two workgroups fit a CU and 782 of them ran as two rounds (the second one a
 // third full), each re-streaming the whole 196 KiB weight image for 64 rows; 391 tiles of 128 rows are ONE round with half
@@ -77,8 +76,7 @@ bool tiled_split_products();
 // ... when the 64-row tiles would not all be resident at once (more than 512 of them); a smaller graph keeps the finer
 // tiles (hidden 96 padded to 128 at N = 17 080: 267 workgroups of 64 rows fill the chip, 134 of 128 rows half of it)
 static bool tall128(int64_t N) {
-    static const bool on = [] { const char* e = getenv("GLASS_TILED_H128_ROWS128"); return !(e && e[0] == '0'); }();
-    return on && tiled_split_products() && ceil_div(N, 64) > 512;
+    return lab_knob("GLASS_TILED_H128_ROWS128", 1) && tiled_split_products() && ceil_div(N, 64) > 512;
 }
 // rows per statistics partial: 64 at hidden 128 in either case (the staged hidden-128 kernels of dense.hip share that geometry;
 // a 128-row tile writes the partials of its two row waves separately)
@@ -786,23 +784,9 @@ static void allow_tiled_lds(K kernel, size_t bytes) {
 }
 
 // Product form of the tiled kernels: six bf16 partial products per fp32 product (split_mma.h; default) or the f32-input
-// matrix-core instruction (1/16 of the bf16 rate — the reference point of the accuracy and A/B runs).  Process-wide switch:
-// GLASS_DENSE_SPLIT=0 in the environment, or glass_dense_product_form_set (dense.hip) at run time.
-static std::atomic<int> g_split_products{-1};
-bool tiled_split_products() {
-    int v = g_split_products.load(std::memory_order_relaxed);
-    if (v < 0) {
-        const char* e = getenv("GLASS_DENSE_SPLIT");
-        v = (e && e[0] == '0') ? 0 : 1;
-        g_split_products.store(v, std::memory_order_relaxed);
-    }
-    return v != 0;
-}
-int tiled_split_products_set(int on) {
-    const int prev = tiled_split_products() ? 1 : 0;
-    if (on >= 0) g_split_products.store(on ? 1 : 0, std::memory_order_relaxed);
-    return prev;
-}
+// matrix-core instruction (1/16 of the bf16 rate — the reference point of the accuracy and A/B runs): an option of the CALL
+// (GLASS_DENSE_F32_PRODUCTS in the entry's `act` word; dense_common.h CallOptions), never process state.
+thread_local int t_call_options = 0;
 
 template <int HH, int BM, bool S3>
 static void tiled_fwd_launch(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
@@ -812,10 +796,7 @@ static void tiled_fwd_launch(const float* xa, int64_t lda, const float* xb, int6
     const int64_t n_rt = ceil_div(N, BM);
     const dim3 grid(tiled_grid(n_rt, HH / 128));
     // + the labeled-row bookkeeping of the effective-weight path (hidden 256 / 512, comb pair)
-    static const size_t lab_pad = [] {  // laboratory: GLASS_TILED_LDS_PAD=bytes lowers the workgroups per CU
-        const char* e = getenv("GLASS_TILED_LDS_PAD");
-        return e ? (size_t)atoi(e) : (size_t)0;
-    }();
+    const size_t lab_pad = (size_t)lab_knob("GLASS_TILED_LDS_PAD", 0);  // laboratory: bytes of LDS padding lower the workgroups per CU
     const size_t lds = StageGeom<BM, 256, S3>::kLds + ((comb && HH >= 256) ? 1024 : 0) + lab_pad;
     // the cut image lies behind the fp32 image (and its effective-weight appendix): glass_dense_image_floats
     const int64_t K = comb ? 2 * HH : HH, base = 2 * (int64_t)HH * K;

@@ -593,6 +593,7 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
                                            const uint8_t* mask, double z_ratio, int act, const float* X, int64_t ldx,
                                            const float* X2, int64_t ldx2, int64_t N, int64_t H, float* dW,
                                            int64_t lddw, float* db, int accumulate, void* ws, void* stream) {
+    const CallOptions call_options(act);  // act word -> activation code + this call's options (dense_common.h)
     GLASS_REQUIRE(dsrc && mask && X && ws && N > 0 && H > 0, "dual_linear_wgrad: null pointer");
     const int64_t O = 2 * H, I = X2 ? 2 * H : H;
     GLASS_REQUIRE(ldd >= H && ldx >= H && (!dW || lddw >= I) && (!X2 || ldx2 >= H) && (act == GLASS_ACT_NONE || (T && ldt >= O)),
@@ -637,7 +638,7 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     float* pb_arg = (db || !dW) ? part_b : nullptr;
     const dim3 grid(g.n_slabs, g.ny, g.nz);
     // hidden 128 (the widths of the tiled family whose graph or layer is too small for wgrad_tiled.hip): the product form of
-    // that family (glass_dense_product_form) applies here too — six bf16 partial products per fp32 product
+    // that family (this call's options) applies here too — six bf16 partial products per fp32 product
     const bool split = tiled_shape_ok(H) && tiled_split_products() && ldx % 2 == 0;
     if (split && eff)
         hipLaunchKernelGGL((wgrad_partial_split_kernel<false, true>), grid, dim3(kBlock), 0, st, X, ldx, N, (int)O, (int)I,

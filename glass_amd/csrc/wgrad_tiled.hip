@@ -12,6 +12,7 @@
 // Split over row slabs; slab partials are plain [128][256] tiles summed in slab order by the reduce kernel
 // (deterministic).  fp32 MFMA = exact k-ordered fmaf chain.
 #include "wgrad_common.h"
+#include "dense_common.h"
 #include "split_mma.h"
 
 namespace glass {
@@ -27,7 +28,6 @@ constexpr int kWTile = kWO * kWI;
 // and piece; slot <-> column is a permutation chosen so that those writes run over consecutive units: A slot 32 e + q <->
 // output 4 q + e, B slot 128 (q >> 5) + 32 e + (q & 31) <-> input 4 q + e (q = the thread's column quad, e = 0..3).
 constexpr int kWStageS = 4 * (SplitImg<kWO>::kUnits + SplitImg<kWI>::kUnits);  // floats per stage: 9 216 = 36 KiB
-bool tiled_split_products();  // dense_tiled.hip
 // Mode header the partial kernel leaves behind the bias partials for the reduce kernel (which is launched later, by
 // glass_linear_wgrad_reduce_batch_f32, from (N, O, I) alone): [0] = 1.0f when the partials are in effective-weight form,
 // [1] = z_ratio.

@@ -14,9 +14,26 @@ from . import graph as ggraph
 from . import stack, utils
 
 
+# hipGraphExecs WITH PARALLEL BRANCHES are never destroyed.  On this ROCm (7.2, libamdhip64 bundled with torch 2.10) destroying
+# one — torch.cuda.CUDAGraph's destructor: hipGraphExecDestroy — leaves dangling stream pointers behind in the runtime: a
+# later replay of ANOTHER multi-branch exec then crashes on the host in
+#     hip::Graph::UpdateStreams(hip::Stream*, std::vector<hip::Stream*> const&)  <-  hip::GraphExec::Run  <-  hipGraphLaunch
+# (tools/gc_crash_probe.py reproduces it in three iterations of create / replay / drop; with the graphs kept alive it runs
+# clean).  Single-stream graphs (K = 1, the training step) are not affected and are released normally.  A dropped EvalGraph
+# therefore parks its exec (and the private pool that goes with it) here; `retired_bytes()` lets the caller stop creating
+# new multi-branch graphs once the parked pools exceed its budget (train._eval_graph then serves that shape eagerly).
+_RETIRED = []
+_retired_bytes = 0
+
+
+def retired_bytes():
+    return _retired_bytes
+
+
 class EvalGraph:
-    def __init__(self, model, x, edge_index, edge_weight, batch_shape, k=8, id=0):
+    def __init__(self, model, x, edge_index, edge_weight, batch_shape, k=8, id=0, est_bytes=0):
         self.model, self.x, self.ei, self.ew, self.k, self.id = model, x, edge_index, edge_weight, int(k), id
+        self.est_bytes = int(est_bytes)  # the caller's estimate of the private pool (activations of k branches)
         dev = x.device
         self.pos = [torch.full(tuple(batch_shape), -1, dtype=torch.int64, device=dev) for _ in range(self.k)]
         self.out = [None] * self.k
@@ -62,6 +79,13 @@ class EvalGraph:
                     cap.wait_stream(s)
         self.graph = g
         return self
+
+    def __del__(self):
+        global _retired_bytes
+        g = self.__dict__.get("graph")
+        if g is not None and self.k > 1:
+            _RETIRED.append((g, self.out))
+            _retired_bytes += self.est_bytes
 
     def __call__(self, batches):
         """batches: up to K padded node matrices of the captured shape -> their logits (views of the graph's output buffers:

@@ -239,14 +239,21 @@ def mix(T, mask, z_ratio, act):
 # ---------------------------------------------------------------------------------------------
 import os as _os
 
-# Off by default — measured on MI355X (ppi_bp-shape, hipGraph replay, 3 interleaved A/B rounds): 0.765 ms/step
-# with the weight gradients forked onto a side stream vs 0.678 ms/step on one stream: the fork/join
-# dependencies cost more than the overlap of these 10-20 us kernels buys.
-USE_SIDE_STREAM = _os.environ.get("GLASS_SIDE_STREAM", "0") == "1"
+# (Weight gradients on a side stream beside the backward chain were measured on MI355X at ppi_bp-shape, hipGraph replay,
+# 3 interleaved A/B rounds: 0.765 ms/step forked vs 0.678 on one stream — the fork/join dependencies cost more than the
+# overlap of these 10-20 us kernels buys.  The variant is not part of the product; DESIGN.md §7 keeps the record.)
 USE_FUSED_DENSE = _os.environ.get("GLASS_FUSED_DENSE", "1") != "0"  # A/B switch: fused MFMA dense path
+# Product form of the LDS-tiled dense kernels (hidden 128 / 256 / 512): the default is the split-bf16 form; GLASS_DENSE_SPLIT=0
+# (or setting this flag) asks every dense call for the f32-input MFMA instead — an option of each CALL (the library itself
+# keeps no such state: include/glass_hip.h GLASS_DENSE_F32_PRODUCTS)
+DENSE_F32_PRODUCTS = _os.environ.get("GLASS_DENSE_SPLIT", "1") == "0"
+
+
+def act_word(act):
+    """The `act` argument of the dense entries: activation code + this call's options."""
+    return int(act) | (_lib.DENSE_F32_PRODUCTS if DENSE_F32_PRODUCTS else 0)
 _wgrad_ws = {}
 _retired_ws = []
-_side = {}
 
 
 def _wgrad_workspace(device, N, O, I, slot=0, min_bytes=0):
@@ -258,39 +265,6 @@ def _wgrad_workspace(device, N, O, I, slot=0, min_bytes=0):
         ws = torch.empty(nbytes // 4 + 16, dtype=torch.float32, device=device)
         _wgrad_ws[(device, slot)] = ws
     return ws
-
-
-class SideStream:
-    """Weight gradients do not feed the rest of the backward pass, so they run on a second HIP stream
-    beside the dgrad -> GraphNorm -> aggregation chain (most kernels of a small graph fill only part of
-    the 256 CUs).  fork() orders the side stream after everything enqueued so far on the current
-    stream; join() makes the current stream wait for the side work (call before the optimizer).
-    Under hipGraph capture this becomes a fork/join in the graph."""
-    def __init__(self, device):
-        self.stream = torch.cuda.Stream(device=device)
-        self.pending = False
-
-    def fork(self):
-        self.stream.wait_stream(torch.cuda.current_stream())
-        self.pending = True
-        return torch.cuda.stream(self.stream)
-
-    def join(self):
-        if self.pending:
-            torch.cuda.current_stream().wait_stream(self.stream)
-            self.pending = False
-
-
-def side_stream(device):
-    s = _side.get(device)
-    if s is None:
-        s = _side[device] = SideStream(device)
-    return s
-
-
-def join_side_streams():
-    for s in _side.values():
-        s.join()
 
 
 def linear_wgrad(G, X, dW, db, accumulate, slot=0):
@@ -388,18 +362,6 @@ class StackedLinearFn(torch.autograd.Function):
         dT, _ = _rows(dT)
         if ctx.stack is not None and not _arena_grads_live(ctx.stack, ctx.params):
             ctx.stack = None  # .grad no longer aliases the arena: gradients go back through autograd
-        if ctx.stack is not None and _wgrad_supported(dT, x, ctx.stack[2]) and USE_SIDE_STREAM:
-            # accumulate straight into the gradient arena, on the side stream (joined before Adam).
-            # The side stream uses its own scratch; successive wgrads on it are stream-ordered.
-            side = side_stream(dT.device)
-            if not side.pending:  # re-join at the end of this backward pass, whoever called it
-                torch.autograd.Variable._execution_engine.queue_callback(join_side_streams)
-            with side.fork():
-                linear_wgrad(dT, x, ctx.stack[2], ctx.stack[3], True, slot=1)
-                dT.record_stream(side.stream)
-                x.record_stream(side.stream)
-            dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
-            return dx, None, None, None, None, None
         dx = torch.mm(dT, W) if ctx.needs_input_grad[0] else None
         if ctx.stack is not None and _wgrad_supported(dT, x, ctx.stack[2]) and ctx.stack[2].is_contiguous():
             # arena views: dW / db accumulate straight into the gradient arena (no temporaries, no autograd add kernels)
@@ -474,7 +436,7 @@ class DualLinearMixFn(torch.autograd.Function):
             out = torch.empty((n, H), dtype=torch.float32, device=xa.device)
         rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), lda, 0 if xb is None else xb.data_ptr(),
                                                    0 if xb is None else ldb, Wimg.data_ptr(), b.data_ptr(),
-                                                   mask.data_ptr(), float(z_ratio), act, 0 if T is None else T.data_ptr(),
+                                                   mask.data_ptr(), float(z_ratio), act_word(act), 0 if T is None else T.data_ptr(),
                                                    2 * H, out.data_ptr(), out.stride(0), n, H, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0,
                                                    0, 0, _stream())
         _lib.check(rc, "glass_dual_linear_fwd_f32")
@@ -494,7 +456,7 @@ class DualLinearMixFn(torch.autograd.Function):
         din = None
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             din = torch.empty((n, n_out), dtype=torch.float32, device=dout.device)
-            rc = lib.glass_dual_linear_dgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act,
+            rc = lib.glass_dual_linear_dgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act_word(act),
                                                  stack[5].data_ptr(), n_out, 0, 0, 0.0, 0, 0, din.data_ptr(), n_out, n, H,
                                                  0, 0, 0, 0, 0, 0, 0.0, 0, 0, _stream())
             _lib.check(rc, "glass_dual_linear_dgrad_f32")
@@ -507,7 +469,7 @@ class DualLinearMixFn(torch.autograd.Function):
             dW = torch.empty((2 * H, I), dtype=torch.float32, device=dout.device)
             dbias = torch.empty(2 * H, dtype=torch.float32, device=dout.device)
             accumulate = 0
-        rc = lib.glass_dual_linear_wgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act, xa.data_ptr(),
+        rc = lib.glass_dual_linear_wgrad_f32(dout.data_ptr(), ldd, tp, ldt, mask.data_ptr(), z_ratio, act_word(act), xa.data_ptr(),
                                              xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                              0 if xb is None else xb.stride(0), n, H, dW.data_ptr(),
                                              dW.stride(0), dbias.data_ptr(), accumulate, ws.data_ptr(), _stream())

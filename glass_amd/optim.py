@@ -60,8 +60,6 @@ class _FlatAdamCore:
 
     @torch.no_grad()
     def step(self, closure=None):
-        from .ops import join_side_streams
-        join_side_streams()  # weight gradients accumulate on a side stream
         b1, b2, eps, wd = self.hyper()
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()

@@ -292,7 +292,7 @@ def _dual_fwd(xa, xb, stack, mask, z_ratio, act, T, out, stats=None, gn=None, xa
     iargs = (0, 0) if xa_index is None else (xa_index.data_ptr(), xa.shape[0])
     rc = _lib.load().glass_dual_linear_fwd_f32(xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                                0 if xb is None else xb.stride(0), stack[4].data_ptr(),
-                                               stack[1].data_ptr(), mask.data_ptr(), float(z_ratio), act,
+                                               stack[1].data_ptr(), mask.data_ptr(), float(z_ratio), ops.act_word(act),
                                                0 if T is None else T.data_ptr(), 0 if T is None else T.stride(0),
                                                out.data_ptr(), out.stride(0), n, H, *_stats_args(stats), *gargs, *iargs,
                                                _stream())
@@ -313,7 +313,7 @@ def _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop=Non
         gp, gargs = 0.0, (0, 0, 0, 0, 0, 0, 0.0, 0, 0)
     rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
     rc = _lib.load().glass_dual_linear_dgrad_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
-                                                 0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
+                                                 0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), ops.act_word(act),
                                                  stack[5].data_ptr(), n_out, 0 if addend is None else addend.data_ptr(),
                                                  0 if addend is None else addend.stride(0), float(p_drop), rng, call_id,
                                                  out.data_ptr(), out.stride(0), n, H, *gargs, _stream())
@@ -326,7 +326,7 @@ USE_FUSED_BWD = os.environ.get("GLASS_FUSED_BWD", "1") != "0"  # A/B switch: dat
 def _dual_bwd(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, xa, xb, pending, acc, drop=None, gn=None):
     """Backward of one Linear pair: _dual_dgrad + _dual_wgrad through glass_dual_linear_bwd_f32 (ONE launch at hidden 64 on
     small graphs, where the two are independent latency-bound kernels; two launches inside the library otherwise)."""
-    if not USE_FUSED_BWD or USE_WGRAD_STREAM:
+    if not USE_FUSED_BWD:
         _dual_dgrad(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, drop, gn)
         _dual_wgrad(dsrc, T, stack, mask, z_ratio, act, xa, xb, pending, acc)
         return
@@ -342,7 +342,7 @@ def _dual_bwd(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, xa, xb, pe
     rng = ops.rng_tensor(dsrc.device).data_ptr() if (p_drop > 0 or gp > 0) else 0
     ws = ops._wgrad_workspace(dsrc.device, n, 2 * H, I, slot=("stack", len(pending)))
     rc = _lib.load().glass_dual_linear_bwd_f32(dsrc.data_ptr(), dsrc.stride(0), 0 if T is None else T.data_ptr(),
-                                               0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
+                                               0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), ops.act_word(act),
                                                stack[5].data_ptr(), n_out, 0 if addend is None else addend.data_ptr(),
                                                0 if addend is None else addend.stride(0), float(p_drop), rng, call_id,
                                                out.data_ptr(), out.stride(0), n, H, *gargs, xa.data_ptr(), xa.stride(0),
@@ -352,13 +352,9 @@ def _dual_bwd(dsrc, T, stack, mask, z_ratio, act, n_out, addend, out, xa, xb, pe
     pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
 
 
-# A/B switch, off: weight-gradient partial kernels forked onto a second stream inside the captured step (4 forks, one join
-# before the batched reduction).  Measured on MI355X at C2, two interleaved rounds: 0.441 vs 0.386 ms/step — as with the
-# per-op path earlier (0.765 vs 0.678), the fork/join edges of the replayed graph cost more than overlapping these
-# 16 us kernels with the 12-20 us kernels of the main chain buys.
-USE_WGRAD_STREAM = os.environ.get("GLASS_WGRAD_STREAM", "0") == "1"
-_wgrad_streams = {}
-_wgrad_keep = []  # operands of side-stream launches stay referenced until the join
+# (Forking the weight-gradient partial kernels onto a second stream inside the captured step was measured on MI355X at C2,
+# two interleaved rounds: 0.441 vs 0.386 ms/step — the fork/join edges of the replayed graph cost more than overlapping
+# these 16 us kernels with the 12-20 us kernels of the main chain buys.  Not part of the product)
 
 
 def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending, acc=1):
@@ -367,20 +363,11 @@ def _dual_wgrad(dout, T, stack, mask, z_ratio, act, xa, xb, pending, acc=1):
     n, H = dout.shape
     I = H if xb is None else 2 * H
     ws = ops._wgrad_workspace(dout.device, n, 2 * H, I, slot=("stack", len(pending)))
-    stream = None
-    if USE_WGRAD_STREAM:
-        # nothing downstream of the backward chain reads these partial sums before the final reduction: run them beside
-        # the chain (fork here, one join before `_reduce_pending`)
-        stream = _wgrad_streams.get(dout.device)
-        if stream is None:
-            stream = _wgrad_streams[dout.device] = torch.cuda.Stream(device=dout.device)
-        stream.wait_stream(torch.cuda.current_stream())
-        _wgrad_keep.append((dout, T, mask, xa, xb))
     rc = _lib.load().glass_dual_linear_wgrad_f32(dout.data_ptr(), dout.stride(0), 0 if T is None else T.data_ptr(),
-                                                 0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), act,
+                                                 0 if T is None else T.stride(0), mask.data_ptr(), float(z_ratio), ops.act_word(act),
                                                  xa.data_ptr(), xa.stride(0), 0 if xb is None else xb.data_ptr(),
                                                  0 if xb is None else xb.stride(0), n, H, 0, 0, 0, 1, ws.data_ptr(),
-                                                 stream.cuda_stream if stream is not None else _stream())
+                                                 _stream())
     _check(rc, "glass_dual_linear_wgrad_f32")
     pending.append((ws.data_ptr(), n, 2 * H, I, stack[2].data_ptr(), stack[2].stride(0), stack[3].data_ptr(), acc))
 
@@ -393,10 +380,6 @@ def _reduce_pending(pending, product=None):
         return _reduce_pending_with_product(pending, *product)
     if not pending:
         return
-    if USE_WGRAD_STREAM and _wgrad_keep:
-        dev = _wgrad_keep[0][0].device
-        torch.cuda.current_stream().wait_stream(_wgrad_streams[dev])
-        _wgrad_keep.clear()
     cols = list(zip(*[p if len(p) == 9 else p + (0, ) for p in pending]))
     u64 = lambda v: np.array(v, dtype=np.uint64)
     i64 = lambda v: np.array(v, dtype=np.int64)
@@ -409,10 +392,6 @@ def _reduce_pending(pending, product=None):
 
 
 def _reduce_pending_with_product(pending, sel, x):
-    if USE_WGRAD_STREAM and _wgrad_keep:
-        dev = _wgrad_keep[0][0].device
-        torch.cuda.current_stream().wait_stream(_wgrad_streams[dev])
-        _wgrad_keep.clear()
     cols = list(zip(*[p if len(p) == 9 else p + (0, ) for p in pending])) if pending else [()] * 9
     u64 = lambda v: np.array(v, dtype=np.uint64)
     i64 = lambda v: np.array(v, dtype=np.int64)

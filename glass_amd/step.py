@@ -28,15 +28,10 @@ CAPTURE_COLLECTIVE = os.environ.get("GLASS_CAPTURE_COLLECTIVE", "1") != "0"  # t
 # the verdict agreed on by all ranks.  On a mismatch the process keeps running on the split form (graph + eager collective).
 VERIFY_CAPTURED_COLLECTIVE = os.environ.get("GLASS_VERIFY_CAPTURED_COLLECTIVE", "1") != "0"
 _VERIFY_TOL = 1e-5
-# The label launch of step i + 1 (glass_batch_labels: one workgroup, ~7.5 us of dependent round trips, outside the graph
-# because its input pointers change every step) depends on nothing step i computes.  With TWO sets of label / batch
-# buffers and the step captured once per set, it runs on a side stream while step i's graph is still executing: the main
-# stream only waits for an event.  Costs a second graph (its own activation pool).
-# MEASURED AND OFF (round 4, ppi_bp-shape, same box): 0.2688-0.2694 ms/step with it against 0.2448 without — the cross-stream
-# event in front of every graph replay (hipStreamWaitEvent + two event records per step) costs ~25 us, three times what the
-# hidden label launch returns.  Results are bit-identical either way (the suite passes on both); GLASS_PREFETCH_LABELS=1
-# switches it on for another look.
-PREFETCH_LABELS = os.environ.get("GLASS_PREFETCH_LABELS", "0") != "0"
+# (Prefetching the label launch of step i + 1 on a side stream beside step i's graph — two label / batch buffer sets, the step
+# captured once per set — was measured in round 4 at ppi_bp-shape: 0.2688-0.2694 ms/step with it against 0.2448 without;
+# the cross-stream event in front of every replay costs ~25 us, three times what the hidden launch returns.  Not part of
+# the product; DESIGN.md §7 keeps the record.)
 
 
 class TrainStep:
@@ -71,9 +66,6 @@ class TrainStep:
         self._force_verify_mismatch = False  # tests: exercise the opt-out path
         self._force_capture_failure = False  # tests: this rank's capture of the collective "fails" (the ranks must agree on it)
         self.exchange_enabled = True    # bench.py: False = skip the collectives (timing of the exposed share; ranks diverge)
-        self._sets = None               # two (pos, y, labels, graph, loss) sets when the label launch is prefetched
-        self._next = 0
-        self._label_stream = None
 
     # -- the step body, split at the collective ---------------------------------------------------
     def _fused_head(self):
@@ -278,48 +270,6 @@ class TrainStep:
             torch.cuda.current_stream().wait_stream(side)
         self._split = dist_on and not self.collective_in_graph
         self.graphed = True
-        if PREFETCH_LABELS and self._labels is not None and self._g_tail is None:
-            self._capture_second_set(dist_on, mode)
-
-    def _capture_second_set(self, dist_on, mode):
-        """The same step captured again on a second set of batch / label buffers (see PREFETCH_LABELS)."""
-        from . import stack
-        first = {"pos": self._pos, "y": self._y, "labels": self._labels, "g": self._g_fb, "loss": self._loss}
-        self._pos, self._y = torch.full_like(first["pos"], -1), first["y"].clone()
-        self._labels = stack.BatchLabels(self.x.shape[0], first["pos"].numel(), first["pos"].device)
-        self._load_batch(first["pos"].clone(), first["y"].clone())
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        try:
-            if not dist_on:
-                with torch.cuda.graph(g):
-                    if not self._fwd_bwd(apply_opt=True):
-                        self.opt.step()
-            elif self.collective_in_graph:
-                with torch.cuda.graph(g, capture_error_mode=mode):
-                    self._fwd_bwd()
-                    self.bucket.all_reduce_mean()
-                    self.opt.step()
-            else:
-                with torch.cuda.graph(g, capture_error_mode=mode):
-                    self._fwd_bwd()
-        except Exception as e:  # noqa: BLE001 — one set is always enough: keep the first graph alone
-            self.capture_error = (self.capture_error or "") + f" | second label set not captured: {e!r}"
-            torch.cuda.synchronize()
-            self._pos, self._y, self._labels, self._loss = first["pos"], first["y"], first["labels"], first["loss"]
-            return
-        second = {"pos": self._pos, "y": self._y, "labels": self._labels, "g": g, "loss": self._loss}
-        self._sets = [first, second]
-        for st in self._sets:
-            st["free"] = None                      # recorded on the main stream behind the set's last replay
-            st["ready"] = torch.cuda.Event()       # recorded on the label stream behind the set's label launch
-        self._label_stream = torch.cuda.Stream(device=self.x.device)
-        self._use_set(0)
-        self._next = 0
-
-    def _use_set(self, k):
-        st = self._sets[k]
-        self._pos, self._y, self._labels, self._g_fb, self._loss = st["pos"], st["y"], st["labels"], st["g"], st["loss"]
 
     def _exchange_and_update(self):
         """Eager part of the data-parallel step, after the (first) graph: collectives + Adam."""
@@ -398,8 +348,6 @@ class TrainStep:
         """One step on the batch (pos, y).  index (int64 device vector): pos / y are the DATA SET's whole node and target
         matrices and the batch is their rows `index` — the selection ZGDataloader does with `pos[perm], y[perm]`
         (impl/SubGDataset.py:69-72) happens inside the step's label launch instead of two index kernels before it."""
-        if index is not None and self._sets is not None:
-            pos, y, index = pos[index], y[index], None  # (the prefetching form loads plain batches)
         shape = tuple(pos.shape) if index is None else (index.numel(), ) + tuple(pos.shape[1:])
         first = self._pos is None
         if first:
@@ -411,8 +359,6 @@ class TrainStep:
         if shape != tuple(self._pos.shape):
             raise ValueError("TrainStep needs a fixed batch shape (drop_last=True): "
                              f"{shape} vs {tuple(self._pos.shape)}")
-        if self._sets is not None:
-            return self._call_prefetched(pos, y)
         self._load_batch(pos, y, index)
         hyper = self.opt.hyper() if hasattr(self.opt, "hyper") else None
         if first or (self.graphed and hyper != self._hyper):
@@ -423,17 +369,10 @@ class TrainStep:
             self._hyper = hyper
             if self.use_graph:
                 self._capture()
-            if self._sets is not None:  # two label sets from here on: this batch sits in set 0 already
-                self._sets[0]["free"] = None
-                self._next = 1
         if hasattr(self.opt, "sync_lr"):
             self.opt.sync_lr()  # a scheduler may have changed the learning rate since the capture
         if self.graphed:
             self._g_fb.replay()
-            if self._sets is not None:
-                ev = torch.cuda.Event()
-                ev.record()
-                self._sets[0]["free"] = ev
             if self._split:
                 self._exchange_and_update()
         elif gdist.is_distributed():
@@ -441,33 +380,6 @@ class TrainStep:
             self._exchange_and_update()
         elif not self._fwd_bwd(apply_opt=True):
             self.opt.step()
-        return self._loss
-
-    def _call_prefetched(self, pos, y):
-        """One step with the label launch on its own stream: it only waits for the previous use of ITS buffer set (two steps
-        back), so it runs beside the graph of the step before; the main stream waits for its event and replays."""
-        k = self._next
-        self._next ^= 1
-        self._use_set(k)
-        st, side, main = self._sets[k], self._label_stream, torch.cuda.current_stream()
-        if st["free"] is not None:
-            side.wait_event(st["free"])
-        else:
-            side.wait_stream(main)
-        pos.record_stream(side)
-        y.record_stream(side)
-        with torch.cuda.stream(side):
-            self._load_batch(pos, y)
-        st["ready"].record(side)
-        main.wait_event(st["ready"])
-        if hasattr(self.opt, "sync_lr"):
-            self.opt.sync_lr()
-        self._g_fb.replay()
-        if st["free"] is None:
-            st["free"] = torch.cuda.Event()
-        st["free"].record(main)
-        if self._split:
-            self._exchange_and_update()
         return self._loss
 
     def _load_batch(self, pos, y, index=None):

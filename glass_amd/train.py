@@ -112,16 +112,20 @@ EVAL_GRAPH_MAX_BYTES = int(os.environ.get("GLASS_EVAL_GRAPH_MAX_MB", "8192")) <<
 
 
 def _eval_branches(model, n_nodes, k):
-    """Parallel branches of one evaluation graph, bounded by memory: every branch keeps its own copy of the forward's
-    activations (~ (4 L + 6) [N, H] fp32 buffers), and up to 4 graphs are cached per model."""
+    """(parallel branches of one evaluation graph, estimated bytes per branch), bounded by memory: every branch keeps its own
+    copy of the forward's activations (~ (4 L + 6) [N, H] fp32 buffers), up to 4 graphs are cached per model — and the pools
+    of dropped multi-branch graphs stay parked (evalstep._RETIRED: their execs cannot be destroyed safely), so what is
+    parked counts against the same budget."""
+    from . import evalstep
     try:
         emb = model.conv
         H = emb.input_emb.weight.shape[1]
         L = len(emb.convs)
     except AttributeError:
-        return k
+        return k, 0
     per_branch = 4 * n_nodes * H * (4 * L + 6)
-    return max(1, min(k, EVAL_GRAPH_MAX_BYTES // max(per_branch, 1)))
+    budget = EVAL_GRAPH_MAX_BYTES - evalstep.retired_bytes()
+    return max(1, min(k, budget // max(per_branch, 1))), per_branch
 
 
 def _eval_graph(model, batch, k):
@@ -133,7 +137,7 @@ def _eval_graph(model, batch, k):
             batch[3].dim() == 2 and batch[3].dtype == torch.int64):
         return None
     x, ei, ea, pos = batch[0], batch[1], batch[2], batch[3]
-    k = _eval_branches(model, x.shape[0], k)
+    k, per_branch = _eval_branches(model, x.shape[0], k)
     if k <= 1:
         return None
     key = (id(x), id(ei), id(ea), tuple(pos.shape), k)
@@ -143,7 +147,7 @@ def _eval_graph(model, batch, k):
     from .evalstep import EvalGraph
     if len(cache) >= 4:
         cache.clear()
-    g = EvalGraph(model, x, ei, ea, pos.shape, k)
+    g = EvalGraph(model, x, ei, ea, pos.shape, k, est_bytes=k * per_branch)
     try:
         g.capture()
     except Exception as e:  # noqa: BLE001 — whatever the runtime or a non-capturable op refuses: the eager loop still works

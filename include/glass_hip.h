@@ -45,6 +45,21 @@ typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a k
 #define GLASS_POOL_SIZE 3
 
 /* activation fused into a kernel: none, or ELU(alpha=1) (GLASSTest.py:143) */
+/* Activation codes — and the OPTIONS of a dense call: the `act` argument of the four glass_dual_linear_{fwd,bwd,dgrad,wgrad}_f32
+ * entries is a word, activation code in bits 0..7 (GLASS_ACT_MASK), options above.  The library keeps NO mutable state: no
+ * environment variable is read, nothing is process-global; what a call does follows from its arguments alone, so two threads
+ * on two streams with different options each get their own behaviour. */
+#define GLASS_ACT_MASK 0xff
+#define GLASS_DENSE_F32_PRODUCTS 0x100 /* hidden 128 / 256 / 512 (LDS-tiled family): form fp32 products with the f32-input MFMA
+                                          (an fmaf chain, 1/16 of the bf16 matrix rate) instead of the default six bf16 partial
+                                          products of 3-way split operands (glass_dense_caps.product_form).  Same operand images
+                                          either way.  Differences of the default form at the edge of fp32's range: a +-Inf
+                                          operand gives NaN where the f32 form gives +-Inf (pieces Inf, NaN, NaN); finite
+                                          |x| >= 2^127 * (2 - 2^-8) rounds its first piece to Inf -> NaN; below |x| ~ 2^-117 the
+                                          low pieces leave bf16's normal range and the product keeps ~16 instead of 24
+                                          significant bits (measured against fp64, hidden 256: rel-inf <= 1.6e-6 for operands
+                                          scaled down to 2^-115, 3e-5 .. 8e-5 at 2^-120; tests/test_gpu_hardening.py) — a
+                                          caller with such operands passes this bit.  Ignored by the other families. */
 #define GLASS_ACT_NONE 0
 #define GLASS_ACT_ELU 1
 #define GLASS_ACT_RELU 2 /* hidden-64 kernels, the GraphNorm kernels and the stand-alone mix (the reference's constructor default nn.ReLU(), impl/models.py:125,192; the pre-training path, GNNEmb.py:90) */
@@ -369,7 +384,8 @@ typedef struct glass_dense_caps {
     int32_t pair_head;         /* K9 (pre-training head on node pairs) at this width */
     int32_t act_codes;         /* bit mask of the activation codes the family fuses: 1 << GLASS_ACT_ELU | 1 << GLASS_ACT_RELU */
     int32_t product_form;      /* how an fp32 product is formed on the matrix cores: 0 f32-input MFMA (an fmaf chain), 1 six bf16
-                                  partial products of 3-way split operands (glass_dense_product_form) */
+                                  partial products of 3-way split operands — the family's DEFAULT; a call opts out with
+                                  GLASS_DENSE_F32_PRODUCTS in its `act` word */
     int32_t serve_width;       /* the hidden width whose kernels serve H: H itself when family != 0; otherwise the next family
                                   width (64 / 128 / 256 / 512) — a model laid out zero-padded to it computes the width-H model
                                   exactly (padded columns stay 0 through every layer, padded parameters get zero gradients;
@@ -384,8 +400,8 @@ int glass_dense_caps_query(int64_t H, glass_dense_caps* out);
  * against fp64 the result is as close as form 0's or closer (profiles/r04_split_product_accuracy.txt; the parity tests run
  * both).  A non-finite operand gives NaN where form 0 gives Inf or NaN.  Form 0 = v_mfma_f32_32x32x2_f32.  Also settable
  * before the first call with GLASS_DENSE_SPLIT=0|1 in the environment.  _set returns 0 or GLASS_E_ARG. */
-int glass_dense_product_form(void);
-int glass_dense_product_form_set(int form);
+/* (the product form is chosen PER CALL: GLASS_DENSE_F32_PRODUCTS in the `act` word; glass_dense_caps.product_form names the
+ *  default of a width's family) */
 int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
  * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */
@@ -543,7 +559,7 @@ int glass_spmm_reduce_rows_f32(const float* partials, float* Y, int64_t ldy, int
 /* Floats the image buffer dst[j] of a pack job must hold: NT*KT; + half of that for the effective-weight appendix of layouts
  * 4 / 5; and for the tiled layouts (1..5) 3/2 of the sum again behind it — the same image cut into three bf16 pieces per
  * element in the order the LDS-tiled kernels copy it to LDS, always written by the pack kernel and read by the kernels in
- * product form 1 (glass_dense_product_form_set needs no re-pack).  Host arithmetic; GLASS_E_ARG for NT, KT <= 0. */
+ * product form 1 (a call with GLASS_DENSE_F32_PRODUCTS reads the fp32 image: no re-pack between the forms).  Host arithmetic; GLASS_E_ARG for NT, KT <= 0. */
 int64_t glass_dense_image_floats(int64_t NT, int64_t KT, int32_t flags);
 /* dst_floats[k] = floats dst[k] can hold: a job whose image (glass_dense_image_floats) does not fit is refused with
  * GLASS_E_ARG before anything is launched — the image sizes differ by layout, so the callee never assumes one. */

@@ -277,12 +277,31 @@ def test_dense_capability_record():
     c64, c128 = _lib.dense_caps(64), _lib.dense_caps(128)
     assert c64.pair_head == 1 and c128.pair_head == 0 and c64.comb_eff == 1 and c128.comb_eff == 0 and c128.comb_eff_fwd == 1
     assert lib.glass_dense_caps_query(0, None) == -1
-    # the product form of the LDS-tiled family: a process-wide switch the record reports (host state, no GPU call)
-    prev = lib.glass_dense_product_form()
-    try:
-        assert lib.glass_dense_product_form_set(0) == 0 and _lib.dense_caps(256).product_form == 0
-        assert lib.glass_dense_product_form_set(1) == 0 and _lib.dense_caps(256).product_form == 1
-        assert _lib.dense_caps(64).product_form == 0 and _lib.dense_caps(20).product_form == 0  # f32-input MFMA / plain fmaf there
-        assert lib.glass_dense_product_form_set(2) == -1
-    finally:
-        lib.glass_dense_product_form_set(prev)
+    # the product form of the LDS-tiled family: the record names the family's DEFAULT; a call opts out in its own act word
+    assert _lib.dense_caps(256).product_form == 1 and _lib.dense_caps(128).product_form == 1
+    assert _lib.dense_caps(64).product_form == 0 and _lib.dense_caps(20).product_form == 0  # f32-input MFMA / plain fmaf there
+
+
+def test_library_keeps_no_mutable_state():
+    """"no global state -> re-entrant and thread-safe per stream".  The library reads no environment variable
+    (laboratory knobs are constants in the product build), exports no setter, and the one behavioural choice a caller has —
+    the product form of the tiled dense family — is an option bit of each call's `act` word (the GPU side of this contract:
+    tests/test_gpu_hardening.py::test_two_threads_two_streams_two_product_forms)."""
+    from glass_amd import _lib
+    lib = _lib.load()
+    csrc = os.path.join(ROOT, "glass_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            text = open(os.path.join(csrc, name)).read()
+            assert "getenv" not in text, f"{name} reads the environment"
+            assert not re.search(r"^static\s+std::atomic|^std::atomic", text, re.M), f"{name} has a process-global atomic"
+    header = open(os.path.join(ROOT, "include", "glass_hip.h")).read()
+    assert "GLASS_DENSE_F32_PRODUCTS" in header and "GLASS_ACT_MASK" in header
+    for gone in ("glass_dense_product_form", "glass_dense_product_form_set"):
+        assert not hasattr(lib, gone) and (gone + "(") not in header
+    assert _lib.DENSE_F32_PRODUCTS == 0x100 and _lib.ACT_MASK == 0xff
+    # an act word with an unknown activation code under the mask is still refused; option bits alone do not make it valid
+    x = np.zeros(64, dtype=np.float32)
+    p = x.ctypes.data
+    assert lib.glass_dual_linear_fwd_f32(p, 64, None, 0, p, p, p, 0.9, 7 | 0x100, p, 128, p, 64, 16, 64, None, 0, None, None, 0, 0.0,
+                                         None, 0, None, 0, None, 0, None) != 0

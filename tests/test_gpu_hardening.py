@@ -261,3 +261,135 @@ def test_scratch_buffers_are_retired_not_freed():
     assert b.data_ptr() != pa or b.numel() >= 100000
     assert any(t.data_ptr() == pa for t in ops._retired_scratch)
     assert ops._scratch(("t_retire", 1), torch.device(DEV), 10).data_ptr() == b.data_ptr()
+
+
+# ---------------------------------------------------------------------- product forms of the tiled dense family: edges
+def _comb256(scale_log2=0, inf_at=None, gout_inf_at=None, f32_form=False):
+    """A hidden-256 comb pair (no activation, zero bias) through ops.dual_linear_mix in one product form; operands scaled by
+    2^-scale_log2.  -> (out, d xa, fp64 out, fp64 d xa)"""
+    from glass_amd import ops
+    from test_gpu_kernels import _pack
+    H, N, zr = 256, 2100, 0.8
+    gen = torch.Generator().manual_seed(5)
+    W = torch.randn(2 * H, 2 * H, generator=gen) / (2 * H) ** 0.5
+    xa_h, xb_h = torch.randn(N, H, generator=gen), torch.randn(N, H, generator=gen)
+    mask = torch.rand(N, generator=gen) < 0.05
+    sc = 2.0 ** (-scale_log2)
+    xa64, xb64 = (xa_h.double() * sc).requires_grad_(True), xb_h.double() * sc
+    Z = torch.cat((xa64, xb64), -1) @ W.double().t()
+    ref = O._mix(mask.reshape(-1, 1), zr, Z[:, :H], Z[:, H:])
+    ref.backward(torch.full_like(ref, sc))
+    prev = ops.DENSE_F32_PRODUCTS
+    ops.DENSE_F32_PRODUCTS = f32_form  # an option of every dense CALL (its act word), not library state
+    try:
+        Wg, bg = W.to(DEV), torch.zeros(2 * H, device=DEV)
+        dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
+        Wimg, WTimg = _pack(Wg, False, H, zr), _pack(Wg, True, H, zr)
+        lin1, lin0 = nn.Linear(2 * H, H).to(DEV), nn.Linear(2 * H, H).to(DEV)
+        lin1.weight.grad, lin0.weight.grad, lin1.bias.grad, lin0.bias.grad = dW[:H], dW[H:], db[:H], db[H:]
+        xa = (xa_h * sc).to(DEV)
+        if inf_at is not None:
+            xa[inf_at] = float("inf")
+        xa.requires_grad_(True)
+        xb = (xb_h * sc).to(DEV).requires_grad_(True)
+        out = ops.dual_linear_mix(xa, xb, lin1, lin0, mask.to(DEV).to(torch.uint8), zr, 0, (Wg, bg, dW, db, Wimg, WTimg))
+        g = torch.full_like(out, sc)
+        if gout_inf_at is not None:
+            g[gout_inf_at] = float("inf")
+        out.backward(g)
+    finally:
+        ops.DENSE_F32_PRODUCTS = prev
+    return out.detach().cpu(), xa.grad.cpu(), ref.detach(), xa64.grad
+
+
+@pytest.mark.parametrize("f32_form", [False, True])
+def test_tiled_product_forms_nonfinite_in_nonfinite_out(f32_form):
+    """an Inf activation / an Inf upstream gradient through a hidden-256 layer, in BOTH product forms: every
+    value the Inf feeds comes out non-finite (the f32-input MFMA gives +-Inf / NaN as the reference's fp32 GEMM does; the split
+    form cuts Inf into (Inf, NaN, NaN) and gives NaN — documented in include/glass_hip.h at GLASS_DENSE_F32_PRODUCTS), and no
+    other row is touched."""
+    clean, dclean, _r, _d = _comb256(f32_form=f32_form)
+    out, dx, _r, _d = _comb256(inf_at=(5, 7), gout_inf_at=(9, 3), f32_form=f32_form)
+    assert not bool(torch.isfinite(out[5]).any()), "an Inf operand left finite outputs in its row"
+    assert bool(torch.isnan(out[5]).any()) if not f32_form else bool(torch.isinf(out[5]).any())
+    assert not bool(torch.isfinite(dx[9]).any()), "an Inf upstream gradient left finite data gradients in its row"
+    rows = torch.ones(out.shape[0], dtype=torch.bool)
+    rows[5] = False
+    assert torch.equal(out[rows], clean[rows])
+    rows[5], rows[9] = True, False
+    assert torch.equal(dx[rows], dclean[rows])
+
+
+@pytest.mark.parametrize("scale_log2", [0, 100, 110, 115, 120])
+def test_tiled_product_forms_near_the_bottom_of_the_range(scale_log2):
+    """Operands scaled by 2^-100 .. 2^-120.  The f32-input form holds 1e-5 against fp64 throughout.  The
+    split form (three bf16 pieces per operand) holds it while the low piece stays in bf16's normal range — measured: down to
+    operand magnitudes of 2^-115 (8e-7 .. 1.6e-6); at 2^-120 the low pieces flush and the product keeps ~16 significant
+    bits (3e-5 / 8e-5): the documented limit below which a caller passes GLASS_DENSE_F32_PRODUCTS (|x| < 2^-117 ~ 6e-36 is
+    far below anything a GraphNorm-ed activation takes)."""
+    out, dx, ref, dref = _comb256(scale_log2, f32_form=True)
+    assert rel_inf(out, ref) < 1e-5 and rel_inf(dx, dref) < 1e-5
+    out, dx, ref, dref = _comb256(scale_log2, f32_form=False)
+    e_out, e_dx = rel_inf(out, ref), rel_inf(dx, dref)
+    record_parity(f"split_form_operands_2^-{scale_log2}", out_rel_inf=e_out, dx_rel_inf=e_dx)
+    if scale_log2 <= 115:
+        assert e_out < 1e-5 and e_dx < 1e-5, (e_out, e_dx)
+    else:
+        assert e_out < 2e-4 and e_dx < 2e-4, (e_out, e_dx)  # 16 significant bits left: degraded, never garbage
+
+
+def test_two_threads_two_streams_two_product_forms():
+    """the library is re-entrant per stream with no global state.  Two host threads, each on its own HIP stream,
+    call glass_dual_linear_fwd_f32 concurrently with DIFFERENT option words (f32-input products / split products): every one
+    of each thread's results is bit-identical to that form's single-threaded result — and the two forms do differ in bits,
+    so a leak of one thread's option into the other's calls would show."""
+    import threading
+    from glass_amd import _lib
+    from test_gpu_kernels import _pack
+    lib = _lib.load()
+    H, N, zr, iters = 256, 4099, 0.8, 40
+    gen = torch.Generator().manual_seed(17)
+    W = (torch.randn(2 * H, H, generator=gen) / H ** 0.5).to(DEV)
+    bias = (0.1 * torch.randn(2 * H, generator=gen)).to(DEV)
+    xa = torch.randn(N, H, generator=gen).to(DEV)
+    mask = (torch.rand(N, generator=gen) < 0.1).to(DEV).to(torch.uint8)
+    Wimg = _pack(W, False, H, zr)
+
+    def fwd(word, T, out, stream):
+        rc = lib.glass_dual_linear_fwd_f32(xa.data_ptr(), xa.stride(0), 0, 0, Wimg.data_ptr(), bias.data_ptr(), mask.data_ptr(), zr,
+                                           word, T.data_ptr(), T.stride(0), out.data_ptr(), out.stride(0), N, H, 0, 0, 0, 0, 0, 0.0,
+                                           0, 0, 0, 0, 0, 0, stream)
+        assert rc == 0, lib.glass_last_error_string()
+
+    words = {"f32": 1 | _lib.DENSE_F32_PRODUCTS, "split": 1}
+    want = {}
+    for name, word in words.items():
+        T, out = torch.empty(N, 2 * H, device=DEV), torch.empty(N, H, device=DEV)
+        fwd(word, T, out, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        want[name] = out.clone()
+    assert not torch.equal(want["f32"], want["split"]), "the two product forms agree bit for bit: the test could not see a leak"
+    got, errors = {}, []
+
+    def worker(name):
+        try:
+            st = torch.cuda.Stream()
+            outs = [torch.empty(N, H, device=DEV) for _ in range(iters)]
+            T = torch.empty(N, 2 * H, device=DEV)
+            for o in outs:
+                fwd(words[name], T, o, st.cuda_stream)
+            st.synchronize()
+            got[name] = outs
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, repr(e)))
+
+    torch.cuda.synchronize()
+    threads = [threading.Thread(target=worker, args=(n, )) for n in words]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for name in words:
+        bad = [i for i, o in enumerate(got[name]) if not torch.equal(o, want[name])]
+        assert not bad, f"thread '{name}': results {bad} differ from its own product form's"

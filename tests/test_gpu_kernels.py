@@ -656,11 +656,11 @@ def test_both_product_forms_against_fp64(H, N, comb):
     ref = O._mix(mask.reshape(-1, 1), zr, A[:, :H], A[:, H:])
     ref.backward(gout.double())
     want = [ref.detach(), xa64.grad] + ([xb64.grad] if comb else []) + [W64.grad, b64.grad]
-    prev = lib.glass_dense_product_form()
+    prev = ops.DENSE_F32_PRODUCTS
     errs = {}
     try:
         for form in (0, 1):
-            assert lib.glass_dense_product_form_set(form) == 0
+            ops.DENSE_F32_PRODUCTS = form == 0  # an option of every dense CALL (act word), not library state
             Wg, bg = W.to(DEV), b.to(DEV)
             dW, db = torch.zeros_like(Wg), torch.zeros_like(bg)
             Wimg, WTimg = _pack(Wg, False, H, zr), _pack(Wg, True, H, zr)
@@ -673,7 +673,7 @@ def test_both_product_forms_against_fp64(H, N, comb):
             got = [out.detach().cpu(), xa.grad.cpu()] + ([xb.grad.cpu()] if comb else []) + [dW.cpu(), db.cpu()]
             errs[form] = [rel_inf(g_, w_) for g_, w_ in zip(got, want)]
     finally:
-        lib.glass_dense_product_form_set(prev)
+        ops.DENSE_F32_PRODUCTS = prev
     for e0, e1 in zip(errs[0], errs[1]):
         assert e0 < TOL and e1 < TOL, errs
         assert e1 <= 2.0 * e0 + 2e-7, errs
@@ -686,7 +686,7 @@ def test_tiled_split_kernels_repeat_bitwise(H, N, comb):
     inputs, every output bit-identical to the first run."""
     import torch.nn as nn
     from glass_amd import _lib, ops
-    if not _lib.load().glass_dense_product_form():
+    if ops.DENSE_F32_PRODUCTS:
         pytest.skip("split product form switched off")
     gen = torch.Generator().manual_seed(11 + H + N)
     K = 2 * H if comb else H

@@ -1453,3 +1453,34 @@ def test_eval_graph_parallel_branches_match_eager_forward():
     finally:
         gtrain.USE_EVAL_GRAPH = old
     assert a[0] == b[0] and torch.equal(a[1], b[1])
+
+
+def test_dropped_multi_branch_eval_graphs_do_not_crash_later_replays():
+    """Regression for a host crash inside hipGraphLaunch (hip::Graph::UpdateStreams) after a hipGraphExec with parallel
+    branches had been destroyed: evalstep parks such execs instead of destroying them (evalstep._RETIRED).  Create / replay /
+    drop / collect six times, replaying a freshly captured multi-branch graph each round."""
+    import gc
+    from glass_amd import synth, evalstep
+    from glass_amd.evalstep import EvalGraph
+    from glass_amd.arena import ParamArena
+    from impl import utils
+    n = 3000
+    ei, ew = synth.make_graph(n, 20000, 5, 0.5)
+    x = synth.degree_feature(ei, n)
+    pos, _y = synth.make_subgraphs(n, 64, 8, 3, 1, False)
+    ei, ew, x, pos = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x, pos))
+    parked = len(evalstep._RETIRED)
+    for it in range(6):
+        torch.manual_seed(it)
+        model = build_glass(64, 1, int(x.max()), 3, "sum", "mean", 0.8).to(DEV)
+        ParamArena(model)
+        model.eval()
+        with torch.no_grad():
+            want = [model(x, ei, ew, pos[8 * b:8 * b + 8], utils.MaxZOZ(x, pos[8 * b:8 * b + 8])).clone() for b in range(4)]
+            g = EvalGraph(model, x, ei, ew, (8, pos.shape[1]), 4).capture()
+            outs = g([pos[8 * b:8 * b + 8] for b in range(4)])
+            torch.cuda.synchronize()
+            assert all(torch.equal(o, w) for o, w in zip(outs, want))
+        del g, outs, model
+        gc.collect()
+    assert len(evalstep._RETIRED) >= parked + 6  # (earlier tests' graphs may be collected here as well)
