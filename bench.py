@@ -91,7 +91,8 @@ def parse(argv=None):
     ap.add_argument("--min-blocks", type=int, default=25, help="timed blocks of --steps steps each (median reported)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU baseline steps (0 = size to ~15 s)")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step from a captured hipGraph when possible")
-    ap.add_argument("--mode", default="train", choices=["train", "eval"],
+    ap.add_argument("--no-floor", action="store_true", help="skip the launch-chain floor of the step (a child rocprofv3 --kernel-trace pass)")
+    ap.add_argument("--mode", default="train", choices=["train", "eval", "trace"],
                     help="eval: the evaluation loop's forward passes (impl/train.py:20-34) over the same batches — one batch per "
                          "step, K batches side by side as parallel branches of one hipGraph (glass_amd/evalstep.py)")
     ap.add_argument("--eval-parallel", type=int, default=8, help="--mode eval: batches per replay (the sequential form is timed too)")
@@ -361,6 +362,95 @@ def k1_pmc_traffic(workload, H, timeout=240):
     return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
         "this run: child rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB, FETCH_SIZE x2 per the "
         "gfx950 rule) on tools/bin/spmm_bench at the same shape")
+
+
+def step_floor(args, n_replays=2000, timeout=300):
+    """Latency floor of the step's chain of launches ON THIS BOX: (1) a child `rocprofv3 --kernel-trace` run of this file in
+    --mode trace lists the kernels of one replayed step with their grid, block and dynamic-LDS sizes; (2) the same chain —
+    the label launch eager, the rest captured in one hipGraph, one stream, every node depending on its predecessor — is
+    replayed with a kernel that does nothing (glass_empty_launch) at the same geometries.  What that costs per step is what
+    the step would cost if every kernel were free: launch latency, workgroup dispatch and the graph's node-to-node
+    hand-over.  -> dict, or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 missing"
+    if under_profiler():
+        return None, "running under a profiler: the child kernel-trace pass is skipped"
+    d = tempfile.mkdtemp(prefix="glass_floor_", dir="/tmp")
+    try:
+        env = child_env_without_profiler()
+        env["TMPDIR"] = "/tmp"
+        cmd = [rocprof, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--mode", "trace", "--workload", args.workload, "--features", args.features, "--caller", args.caller, "--steps", "6",
+               "--warmup", "2", "--graph", str(args.graph)] + (["--dropout", str(args.dropout)] if args.dropout is not None else [])
+        subprocess.run(cmd, cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        rows = sorted(csv.DictReader(open(files[0])), key=lambda r: int(r["Start_Timestamp"]))
+    except Exception as e:  # noqa: BLE001 — any failure means "not measured"
+        return None, f"kernel-trace pass failed: {type(e).__name__}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    names = [r["Kernel_Name"].split("(")[0] for r in rows]
+    # the trace ends with identical replays: the shortest period p with names[-p:] == names[-2p:-p] == names[-3p:-2p]
+    period = next((p for p in range(2, len(names) // 3) if names[-p:] == names[-2 * p:-p] == names[-3 * p:-2 * p]), None)
+    if period is None:
+        return None, "no periodic step found in the kernel trace"
+    step_rows = rows[-period:]
+
+    def geom(r):
+        wg = [max(int(r[f"Workgroup_Size_{a}"]), 1) for a in "XYZ"]
+        grid = [max(int(r[f"Grid_Size_{a}"]), 1) // w for a, w in zip("XYZ", wg)]  # (rocprofv3 reports the grid in work-items)
+        return grid, wg[0] * wg[1] * wg[2], int(r.get("LDS_Block_Size", 0) or 0)
+    chain = [geom(r) for r in step_rows]
+    # the step starts with the label launch (eager, outside the graph): rotate the period so that it comes first
+    first = next((i for i, r in enumerate(step_rows) if "batch_labels" in r["Kernel_Name"]), 0)
+    chain = chain[first:] + chain[:first]
+    kernel_us = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in step_rows) / 1e3
+    from glass_amd import _lib
+    lib = _lib.load()
+
+    def launch(g):
+        (gx, gy, gz), block, lds = g
+        _lib.check(lib.glass_empty_launch(gx, gy, gz, block, min(lds, 160 * 1024), torch.cuda.current_stream().cuda_stream), "glass_empty_launch")
+    eager_head = chain[:1] if first is not None and "batch_labels" in step_rows[first]["Kernel_Name"] else []
+    body = chain[len(eager_head):]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for g in chain:
+            launch(g)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for g in body:
+            launch(g)
+
+    def one_step():
+        for g in eager_head:
+            launch(g)
+        graph.replay()
+    for _ in range(50):
+        one_step()
+    torch.cuda.synchronize()
+    blocks = []
+    per = max(n_replays // 10, 1)
+    for _ in range(10):
+        t0 = time.perf_counter()
+        for _ in range(per):
+            one_step()
+        torch.cuda.synchronize()
+        blocks.append((time.perf_counter() - t0) / per)
+    blocks.sort()
+    return {"us": blocks[len(blocks) // 2] * 1e6, "us_min": blocks[0] * 1e6, "launches": len(chain), "in_graph": len(body),
+            "kernel_time_us_in_trace": kernel_us,
+            "method": "the step's launch chain (child rocprofv3 --kernel-trace of --mode trace: kernel order, grids, block sizes, dynamic "
+                      "LDS) replayed with glass_empty_launch at the same geometries — label launch eager, the rest one hipGraph on one "
+                      "stream; median of 10 blocks"}, None
 
 
 def dense_flop_model(N, H, L, pos_batches, lab_cap):
@@ -643,6 +733,12 @@ def main():
                 b = (offset + i) % n_batches
                 stepper(pos_g[b], y_g[b])
     stepper.time_collective = world > 1  # HIP events around the exchange / optimizer part of every step
+    if args.mode == "trace":
+        # child of step_floor(): a few replays of the step under rocprofv3 --kernel-trace, nothing else
+        run(max(args.warmup, 1), 0)
+        run(args.steps, 0)
+        torch.cuda.synchronize()
+        return
 
     def barrier():
         if world > 1:
@@ -865,6 +961,14 @@ def main():
         del eager
         hbm = roofline_hbm_entries(dev)
 
+    floor = None
+    if rank == 0 and world == 1 and not args.no_floor:
+        floor, why = step_floor(args)
+        if floor is None:
+            floor = {"us": None, "reason": why}
+        else:
+            floor["share_of_step"] = floor["us"] * 1e-3 / (dt / args.steps * 1e3)
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, ei, ew, x, pos, y, args.cpu_steps)
@@ -891,7 +995,8 @@ def main():
                                   "shuffle and the batch selection) per timed block") if ref_caller else
                                  "step: bench.py calls glass_amd.step.TrainStep on pre-selected batches",
                        "final_loss": last_loss},
-            "roofline": roofline, "roofline_hbm": hbm, "step_breakdown": step_breakdown, "cpu_baseline": cpu,
+            "roofline": roofline, "roofline_hbm": hbm, "step_breakdown": step_breakdown, "step_floor": floor, "cpu_baseline": cpu,
+            "step_floor_us": None if floor is None else floor["us"],
         }
         if collective is not None:
             out["collective"] = collective

@@ -80,6 +80,7 @@ SIGNATURES = {
     "glass_graphnorm_bwd_f32": (c_int, [_P, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, c_int, c_int, c_float,
                                         _P, c_uint64, _P, _P]),
     "glass_rng_advance": (c_int, [_P, _P]),
+    "glass_empty_launch": (c_int, [_I, _I, _I, _I, _I, _P]),
     "glass_dropout_scales_f32": (c_int, [_P, c_uint64, c_float, _I, _I, _P, _P]),
     "glass_dual_linear_stat_rows": (c_int64, [_I]),
     "glass_copy_pair": (c_int, [_P, _P, _I, _P, _P, _I, _P]),

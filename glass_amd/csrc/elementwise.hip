@@ -350,3 +350,21 @@ extern "C" int glass_copy_pair(void* dst0, const void* src0, int64_t bytes0, voi
                        (const uint32_t*)src0, bytes0 / 4, (uint32_t*)dst1, (const uint32_t*)src1, bytes1 / 4);
     return launch_status("glass_copy_pair");
 }
+
+// ---- measurement aid: a kernel that does nothing, launched with a given geometry --------------------------------------
+// bench.py replays the training step's chain of launches with these (same grids, block sizes and dynamic LDS) to measure
+// the latency floor of that chain on the box it runs on (`step_floor`): what the step would cost if every kernel were free.
+namespace glass {
+__global__ void empty_kernel() {}
+}  // namespace glass
+
+extern "C" int glass_empty_launch(int64_t grid_x, int64_t grid_y, int64_t grid_z, int64_t block, int64_t lds_bytes, void* stream) {
+    GLASS_REQUIRE(grid_x > 0 && grid_y > 0 && grid_z > 0 && grid_x < (1ll << 31) && grid_y < 65536 && grid_z < 65536 && block > 0 &&
+                      block <= 1024 && lds_bytes >= 0 && lds_bytes <= 160 * 1024,
+                  "empty_launch: bad geometry");
+    if (lds_bytes > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)glass::empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL(glass::empty_kernel, dim3((unsigned)grid_x, (unsigned)grid_y, (unsigned)grid_z), dim3((unsigned)block),
+                       (size_t)lds_bytes, (hipStream_t)stream);
+    return glass::launch_status("glass_empty_launch");
+}

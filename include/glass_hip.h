@@ -208,6 +208,9 @@ int glass_graphnorm_bwd_from_stats_f32(const float* dy, int64_t lddy, const floa
                                        float* dalpha, int accumulate, int act, float p_drop, const uint64_t* rng_state,
                                        uint64_t call_id, void* ws, void* stream);
 int glass_rng_advance(uint64_t* rng_state, void* stream); /* rng_state[1] += 1 */
+/*     Measurement aid (bench.py `step_floor`): launch a kernel that does nothing with the given grid / block / dynamic-LDS
+ *     geometry — the training step's chain of launches replayed with these is the latency floor of that chain. */
+int glass_empty_launch(int64_t grid_x, int64_t grid_y, int64_t grid_z, int64_t block, int64_t lds_bytes, void* stream);
 /*     Checker's hook: the keep-scales (0 or 1/(1-p)) the dropout with `call_id` draws for an [n_rows, C] tensor under the
  *     CURRENT rng_state words, written to out — so a test can hand the very masks of a dropout-on step to the CPU oracle
  *     (the masks are regenerated from (seed, step, call id, element) everywhere, never stored). */
