@@ -332,10 +332,16 @@ def k1_pmc_traffic(workload, H, timeout=240):
     import tempfile
     exe = os.path.join(ROOT, "tools", "bin", "spmm_bench")
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if workload not in ("ppi_bp", "hpo_neuro", "em_user", "powerlaw") or not os.path.exists(exe) or not os.path.exists(rocprof):
-        return None, "no stand-alone generator for this shape, or spmm_bench / rocprofv3 missing"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 missing"
     if under_profiler():
         return None, "running under a profiler (LD_PRELOAD / ROCP_* / ROCPROF_* set): the child PMC passes are skipped"
+    # the stand-alone K1 program where it has a generator for the shape; otherwise (the shipped density graph) the K1 launches
+    # of a few eager steps of this file itself (--mode trace --graph 0): same kernels, same matrix, counted per dispatch
+    standalone = workload in ("ppi_bp", "hpo_neuro", "em_user", "powerlaw") and os.path.exists(exe)
+    child = [exe, workload, str(H), "10"] if standalone else \
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "trace", "--graph", "0", "--workload", workload, "--steps", "4",
+         "--warmup", "1"]
     vals = {}
     d = None
     try:
@@ -343,8 +349,8 @@ def k1_pmc_traffic(workload, H, timeout=240):
             d = tempfile.mkdtemp(prefix="glass_pmc_", dir="/tmp")
             env = child_env_without_profiler()
             env["TMPDIR"] = "/tmp"
-            subprocess.run([rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", exe, workload,
-                            str(H), "10"], cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL,
+            subprocess.run([rocprof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", *child],
+                           cwd="/tmp", env=env, timeout=timeout, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL, check=True)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             rows = [r for r in csv.DictReader(open(files[0])) if r["Counter_Name"] == ctr and "spmm_" in r["Kernel_Name"]]
@@ -361,7 +367,8 @@ def k1_pmc_traffic(workload, H, timeout=240):
             shutil.rmtree(d, ignore_errors=True)
     return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
         "this run: child rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB, FETCH_SIZE x2 per the "
-        "gfx950 rule) on tools/bin/spmm_bench at the same shape")
+        "gfx950 rule) on " + ("tools/bin/spmm_bench at the same shape" if standalone else
+                              "the K1 launches of four eager steps of bench.py --mode trace on the same graph"))
 
 
 def step_floor(args, n_replays=2000, timeout=300):
