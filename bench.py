@@ -424,6 +424,8 @@ def step_floor(args, n_replays=2000, timeout=300):
         (gx, gy, gz), block, lds = g
         _lib.check(lib.glass_empty_launch(gx, gy, gz, block, min(lds, 160 * 1024), torch.cuda.current_stream().cuda_stream), "glass_empty_launch")
     eager_head = chain[:1] if first is not None and "batch_labels" in step_rows[first]["Kernel_Name"] else []
+    if os.environ.get("GLASS_FLOOR_ALL_IN_GRAPH") == "1":  # what-if: the label launch captured with the rest
+        eager_head = []
     body = chain[len(eager_head):]
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
