@@ -221,3 +221,40 @@ def test_unadoptable_callers_keep_the_eager_loop():
     loss = train.train(opt, m, reference_loader(ds, 8), lambda p, t: ((p.flatten() - t.flatten()) ** 2).mean())
     assert np.isfinite(loss)
     assert not _taken_step(m)._program_step()
+
+
+def test_adopted_adam_follows_weight_decay_and_a_beta_change():
+    """Hyper-parameters other than the learning rate are launch arguments of the fused update: the adopted engine reads them
+    from optimizer.param_groups — weight_decay (torch.optim.Adam's L2 form) from the start, and a later change of `betas`
+    triggers a new capture — so the trajectory keeps following an eager twin driven by the same torch optimizer settings."""
+    from impl import SubGDataset, train
+    x, ei, ew, pos, y = _binary_task(seed=4)
+    torch.manual_seed(11)
+    gnn = reference_build_model(64, 2, 0.0, True, "sum", 0.9, "mean", torch.max(x), 1)
+    twin = copy.deepcopy(gnn)
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    opt = Adam(gnn.parameters(), lr=5e-3, weight_decay=1e-2)
+    opt_twin = Adam(twin.parameters(), lr=5e-3, weight_decay=1e-2)
+    for epoch in range(3):
+        if epoch == 2:
+            for o in (opt, opt_twin):
+                o.param_groups[0]["betas"] = (0.8, 0.99)
+        torch.manual_seed(200 + epoch)
+        got = train.train(opt, gnn, reference_loader(ds, 8), reference_binary_loss)
+        torch.manual_seed(200 + epoch)
+        want = _eager_epoch(twin, opt_twin, reference_loader(ds, 8), reference_binary_loss)
+        assert abs(got - want) <= 2e-4 * abs(want), (epoch, got, want)
+    step = _taken_step(gnn)
+    assert step.graphed and step._hyper == (0.8, 0.99, 1e-8, 1e-2)
+    pa = torch.cat([p.detach().reshape(-1) for p in gnn.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in twin.parameters()])
+    assert rel_inf(pa.cpu(), pb.cpu()) < 2e-3
+    # weight decay really acted: the parameters of a run without it differ by far more than the twin does
+    torch.manual_seed(11)
+    free = reference_build_model(64, 2, 0.0, True, "sum", 0.9, "mean", torch.max(x), 1)
+    opt_free = Adam(free.parameters(), lr=5e-3)
+    for epoch in range(3):
+        torch.manual_seed(200 + epoch)
+        train.train(opt_free, free, reference_loader(ds, 8), reference_binary_loss)
+    pf = torch.cat([p.detach().reshape(-1) for p in free.parameters()])
+    assert rel_inf(pa.cpu(), pf.cpu()) > 10 * rel_inf(pa.cpu(), pb.cpu())
