@@ -1,11 +1,15 @@
 """CPU tests of the host-side mirror of the reference interface (no GPU compute): module surface,
 index helpers, loaders, metrics, config, synthetic generators, gradient bucket."""
+import os
+
 import numpy as np
 import pytest
 import torch
 import torch.nn as nn
 
 from helpers import load, build_glass
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_drop_in_surface():
@@ -276,3 +280,34 @@ def test_only_a_plain_adam_over_the_whole_model_is_adopted():
     assert "group" in optim.adoptable(torch.optim.Adam([{"params": [m.weight]}, {"params": [m.bias], "lr": 0.1}]), m)
     assert "exactly" in optim.adoptable(torch.optim.Adam([m.weight]), m)
     assert "GPU" in optim.adoptable(torch.optim.Adam(m.parameters()), m)  # (CPU parameters: the reference's --device -1 case)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/GLASSTest.py"), reason="authoring container only: needs /root/reference")
+def test_reference_driver_file_runs_over_this_repos_modules_up_to_the_first_kernel():
+    """The drop-in claim at its source: /root/reference/GLASSTest.py itself — unmodified, executed with this repo's root first
+    on sys.path — imports `impl.*` and `datasets` from HERE, parses its flags, loads and splits the shipped density set, runs
+    its own `buildModel`, builds its loaders, `Adam(gnn.parameters(), lr)` and `ReduceLROnPlateau`, and calls
+    `impl.train.train`.  Without a GPU that call stops at the first kernel with GlassHipError (there is deliberately no CPU
+    fallback) — everything before it is the module surface working as the reference expects.  On a GPU box the
+    same objects take the captured step program: tests/test_gpu_reference_caller.py."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, runpy\n"
+        "sys.dont_write_bytecode = True\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "sys.argv = ['GLASSTest.py', '--use_one', '--use_seed', '--use_maxzeroone', '--repeat', '1', '--device', '-1', '--dataset', 'density']\n"
+        "try:\n"
+        "    runpy.run_path('/root/reference/GLASSTest.py', run_name='__main__')\n"
+        "except BaseException as e:\n"
+        "    import impl.models, impl.train, datasets\n"
+        "    print('ENDED', type(e).__name__, '|', impl.models.__file__, '|', impl.train.__file__, '|', datasets.__file__)\n"
+        "    import traceback; traceback.print_exc()\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                         env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
+    text = out.stdout + out.stderr
+    assert "ENDED GlassHipError" in text, text[-3000:]
+    ended = [ln for ln in out.stdout.splitlines() if ln.startswith("ENDED")][0]
+    assert ended.count(os.path.join(ROOT, "glass_amd")) == 2 and os.path.join(ROOT, "datasets.py") in ended, ended
+    assert "repeat 0" in out.stdout                      # reached the training loop of the reference's test()
+    assert "glass_amd/train.py" in text and "in train" in text  # ... and died inside impl.train.train, at a kernel call
