@@ -20,14 +20,39 @@ from . import stack, utils
 #     hip::Graph::UpdateStreams(hip::Stream*, std::vector<hip::Stream*> const&)  <-  hip::GraphExec::Run  <-  hipGraphLaunch
 # (tools/gc_crash_probe.py reproduces it in three iterations of create / replay / drop; with the graphs kept alive it runs
 # clean).  Single-stream graphs (K = 1, the training step) are not affected and are released normally.  A dropped EvalGraph
-# therefore parks its exec (and the private pool that goes with it) here; `retired_bytes()` lets the caller stop creating
-# new multi-branch graphs once the parked pools exceed its budget (train._eval_graph then serves that shape eagerly).
+# therefore parks its exec here.  So that parked execs do not pin memory, ALL evaluation graphs of a device capture into ONE
+# shared memory pool (torch.cuda.graph(pool=...)): the allocator hands the blocks a dropped graph's tensors occupied to the
+# next capture — a parked graph is never replayed again, so nobody minds its buffers being overwritten.  Live graphs sharing
+# the pool alias each other's INTERMEDIATES too (the documented property of shared pools): harmless here, because a replay
+# recomputes everything from its own inputs (`pos`, allocated outside the pool), replays of different graphs never overlap
+# (one stream of replays), and callers clone the outputs they keep (`__call__`).  `retired_bytes()` is what parked graphs
+# would still cost without that sharing: 0.
 _RETIRED = []
-_retired_bytes = 0
+_POOLS = {}
+
+
+def _pool(device):
+    h = _POOLS.get(device)
+    if h is None:
+        h = _POOLS[device] = torch.cuda.graph_pool_handle()
+    return h
 
 
 def retired_bytes():
-    return _retired_bytes
+    return 0
+
+
+# ... and every evaluation graph of a device forks onto the SAME side streams: the caching allocator keeps its free blocks
+# per stream, so graphs (and their eager warm-ups) on ever new streams of torch's 32-stream pool could not reuse each other's
+# memory — reserved memory grew by a model's activations per dropped graph until the stream pool wrapped around.
+_STREAMS = {}
+
+
+def _streams(device, k):
+    have = _STREAMS.setdefault(device, [])
+    while len(have) < k:
+        have.append(torch.cuda.Stream(device=device))
+    return have[:k]
 
 
 class EvalGraph:
@@ -37,7 +62,7 @@ class EvalGraph:
         dev = x.device
         self.pos = [torch.full(tuple(batch_shape), -1, dtype=torch.int64, device=dev) for _ in range(self.k)]
         self.out = [None] * self.k
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.k)]
+        self.streams = _streams(dev, self.k)
         self.graph = None
 
     def _branch(self, i):
@@ -67,7 +92,7 @@ class EvalGraph:
             cur.wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with torch.cuda.graph(g, pool=_pool(self.x.device)):
             cap = torch.cuda.current_stream()
             shared = self._prologue()
             with stack.prologue_done(shared):
@@ -81,11 +106,9 @@ class EvalGraph:
         return self
 
     def __del__(self):
-        global _retired_bytes
         g = self.__dict__.get("graph")
         if g is not None and self.k > 1:
-            _RETIRED.append((g, self.out))
-            _retired_bytes += self.est_bytes
+            _RETIRED.append(g)  # the exec only: its output tensors go back to the shared pool
 
     def __call__(self, batches):
         """batches: up to K padded node matrices of the captured shape -> their logits (views of the graph's output buffers:

@@ -1470,6 +1470,7 @@ def test_dropped_multi_branch_eval_graphs_do_not_crash_later_replays():
     pos, _y = synth.make_subgraphs(n, 64, 8, 3, 1, False)
     ei, ew, x, pos = (torch.from_numpy(a).to(DEV) for a in (ei, ew, x, pos))
     parked = len(evalstep._RETIRED)
+    reserved = []
     for it in range(6):
         torch.manual_seed(it)
         model = build_glass(64, 1, int(x.max()), 3, "sum", "mean", 0.8).to(DEV)
@@ -1483,4 +1484,8 @@ def test_dropped_multi_branch_eval_graphs_do_not_crash_later_replays():
             assert all(torch.equal(o, w) for o, w in zip(outs, want))
         del g, outs, model
         gc.collect()
+        reserved.append(torch.cuda.memory_reserved())
     assert len(evalstep._RETIRED) >= parked + 6  # (earlier tests' graphs may be collected here as well)
+    # parked execs pin no memory of their own: every evaluation graph captures into one shared pool, so after the first
+    # rounds the reserved memory stops growing
+    assert reserved[-1] <= reserved[2] + (8 << 20), reserved
