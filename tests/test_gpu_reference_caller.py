@@ -258,3 +258,19 @@ def test_adopted_adam_follows_weight_decay_and_a_beta_change():
         train.train(opt_free, free, reference_loader(ds, 8), reference_binary_loss)
     pf = torch.cat([p.detach().reshape(-1) for p in free.parameters()])
     assert rel_inf(pa.cpu(), pf.cpu()) > 10 * rel_inf(pa.cpu(), pb.cpu())
+
+
+def test_reference_caller_randomised_configurations():
+    """tools/fuzz_reference_caller.py: 12 random configurations — every kernel family's widths (8 / 17 / 20, 64, 128) and one
+    without a family (48), 1-3 layers, all aggregations and pools (max pooling included), cross-entropy and the reference's
+    binary / multi-label loss function, ragged subgraphs, batch sizes that do not divide the set — of GLASSTest.py's own
+    objects through impl.train.train against an eager per-op twin: epoch losses, parameters, optimizer step counts, and the
+    captured step program wherever a family serves the width."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_reference_caller.py"), "12", "7"],
+                         capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "on the captured step program" in out.stdout
