@@ -113,9 +113,9 @@ EVAL_GRAPH_MAX_BYTES = int(os.environ.get("GLASS_EVAL_GRAPH_MAX_MB", "8192")) <<
 
 def _eval_branches(model, n_nodes, k):
     """(parallel branches of one evaluation graph, estimated bytes per branch), bounded by memory: every branch keeps its own
-    copy of the forward's activations (~ (4 L + 6) [N, H] fp32 buffers), up to 4 graphs are cached per model — and the pools
-    of dropped multi-branch graphs stay parked (evalstep._RETIRED: their execs cannot be destroyed safely), so what is
-    parked counts against the same budget."""
+    copy of the forward's activations (~ (4 L + 6) [N, H] fp32 buffers).  (All evaluation graphs of a device share one
+    memory pool — evalstep._pool — so neither the up-to-4 cached graphs of a model nor the parked execs of dropped ones add
+    up; evalstep.retired_bytes() reports what parked execs pin beyond that: nothing.)"""
     from . import evalstep
     try:
         emb = model.conv
