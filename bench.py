@@ -371,6 +371,12 @@ def k1_pmc_traffic(workload, H, timeout=240):
                               "the K1 launches of four eager steps of bench.py --mode trace on the same graph"))
 
 
+def trailing_period(names):
+    """A kernel trace that ends with identical replays of one step: the shortest period p >= 2 with the last three windows of p
+    names equal (None when there is none)."""
+    return next((p for p in range(2, len(names) // 3 + 1) if names[-p:] == names[-2 * p:-p] == names[-3 * p:-2 * p]), None)
+
+
 def step_floor(args, n_replays=2000, timeout=300):
     """Latency floor of the step's chain of launches ON THIS BOX: (1) a child `rocprofv3 --kernel-trace` run of this file in
     --mode trace lists the kernels of one replayed step with their grid, block and dynamic-LDS sizes; (2) the same chain —
@@ -402,8 +408,7 @@ def step_floor(args, n_replays=2000, timeout=300):
     finally:
         shutil.rmtree(d, ignore_errors=True)
     names = [r["Kernel_Name"].split("(")[0] for r in rows]
-    # the trace ends with identical replays: the shortest period p with names[-p:] == names[-2p:-p] == names[-3p:-2p]
-    period = next((p for p in range(2, len(names) // 3) if names[-p:] == names[-2 * p:-p] == names[-3 * p:-2 * p]), None)
+    period = trailing_period(names)
     if period is None:
         return None, "no periodic step found in the kernel trace"
     step_rows = rows[-period:]

@@ -80,3 +80,30 @@ def test_profiler_environment_is_detected_and_stripped():
     import unittest.mock as mock
     with mock.patch.dict(os.environ, {"ROCP_TOOL_LIBRARIES": "x"}):
         assert bench.k1_pmc_traffic("ppi_bp", 64) == (None, mock.ANY) or bench.k1_pmc_traffic("ppi_bp", 64)[0] is None
+
+
+def test_trailing_period_of_a_kernel_trace():
+    """bench.step_floor finds one replayed step in a kernel trace as the shortest trailing period seen three times."""
+    import bench
+    step = ["labels", "pack", "fwd", "k1", "k1", "bwd", "adam"]
+    assert bench.trailing_period(["setup", "csr", "warm"] + step * 5) == len(step)
+    assert bench.trailing_period(["a", "b"] * 3) == 2
+    assert bench.trailing_period(["a", "b", "c", "a", "b", "c", "a", "b"]) is None      # fewer than three full periods
+    assert bench.trailing_period(["x"] * 2 + step * 2) is None
+
+
+def test_f1_distribution_comparison_rule():
+    """tools/f1_table.compare: |mean_gpu - mean_ref| <= 2 sqrt(se_gpu^2 + se_ref^2) with the driver's own standard error
+    (np.std / sqrt(n), GLASSTest.py:266-268)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import f1_table
+    import numpy as np
+    a, b = [0.90, 0.92, 0.94, 0.96], [0.91, 0.93, 0.95, 0.97]
+    c = f1_table.compare(a, b)
+    se = np.std(a) / 2.0
+    assert abs(c["gpu_se"] - se) < 1e-12 and abs(c["gap"] - 0.01) < 1e-12 and abs(c["bound_2sigma"] - 2 * np.sqrt(2) * se) < 1e-12 and c["ok"]
+    assert not f1_table.compare([0.5] * 4, [0.9, 0.91, 0.9, 0.91])["ok"]
+    ref = f1_table.reference_table("density", "use_one")
+    assert ref is not None and len(ref["tst"]) == 10 and "--use_one" in ref["command"] and "--repeat 10" in ref["command"]
