@@ -36,6 +36,37 @@ def _pairs(model):
 
 BIG_PARAM_ELEMS = 1 << 18  # parameters from 1 MB up (the use_nodeid embedding table) form the "big" bucket
 
+# what a ParamArena (and the loops of train.py) hang on a model and its submodules: per-process runtime objects
+_RUNTIME_ATTRS = ("_glass_grad_bucket", "_glass_arena", "_glass_stack_prog", "_stack", "_stack_eff", "_direct_grad", "_sel_cache",
+                  "_chan_cache", "_glass_train_steps", "_glass_eval_graphs", "_glass_adopted_adam")
+
+
+def strip_runtime(model):
+    """Make `model` a plain module again: every parameter gets storage of its own (a copy of its current values), gradients
+    are dropped, and every runtime attachment — arena, stacked weight views and operand images, step / evaluation graphs, the
+    adopted optimizer engine — is removed.  The next training call builds fresh ones.  Used by the models' __deepcopy__: a
+    deep copy of an arena would keep the ORIGINAL's device pointers in its launch argument arrays."""
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data = p.data.clone()
+            p.grad = None
+    for mod in model.modules():
+        for name in _RUNTIME_ATTRS:
+            mod.__dict__.pop(name, None)
+    return model
+
+
+def deepcopy_plain(module, memo):
+    """__deepcopy__ body of the model classes: an ordinary deep copy of the module tree, then strip_runtime on the copy."""
+    import copy
+    new = module.__class__.__new__(module.__class__)
+    memo[id(module)] = new
+    for k, v in module.__dict__.items():
+        new.__dict__[k] = None if k in _RUNTIME_ATTRS else copy.deepcopy(v, memo)
+    for k in _RUNTIME_ATTRS:
+        new.__dict__.pop(k, None)
+    return strip_runtime(new)
+
 
 class ParamArena(FlatGradBucket):
     def __init__(self, model, big_elems=BIG_PARAM_ELEMS):

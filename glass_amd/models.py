@@ -346,6 +346,12 @@ class GLASS(nn.Module):
         self.preds = preds
         self.pools = pools
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(model) (an early-stopping snapshot, a twin): a PLAIN copy — own parameter storage, no arena, no captured
+        graphs, no adopted optimizer (arena.strip_runtime); it gets its own runtime objects the first time it trains."""
+        from .arena import deepcopy_plain
+        return deepcopy_plain(self, memo)
+
     def _channels(self, x):
         """The feature channels of x [N, C, F] as dense tensors, made once per feature tensor: x is static per dataset, and
         the conv caches its selection CSR (and captured graphs hold its pointers) by the tensor it is handed."""
@@ -485,7 +491,7 @@ class EdgeGNN(nn.Module):
         self.preds = preds
         self.pools = pools
 
-    NodeEmb, _channels = GLASS.NodeEmb, GLASS._channels
+    NodeEmb, _channels, __deepcopy__ = GLASS.NodeEmb, GLASS._channels, GLASS.__deepcopy__
 
     def Pool(self, emb, subG_node, pool):
         return ops.segment_pool(emb, subG_node, "mean")  # emb[subG_node].mean(dim=1); pairs carry no padding

@@ -211,9 +211,11 @@ def adopt(optimizer, model):
         arena = ParamArena(model)
     elif not arena.attached():
         arena.reattach()
-    eng = model.__dict__.get("_glass_adopted_adam")
+    from .utils import RuntimeCache
+    slot = model.__dict__.setdefault("_glass_adopted_adam", RuntimeCache())  # (deepcopy / pickle of the model: an empty slot)
+    eng = slot.get("engine")
     if eng is None or eng.torch_opt is not optimizer or eng.arena is not arena:
-        eng = model.__dict__["_glass_adopted_adam"] = AdoptedAdam(optimizer, arena)
+        eng = slot["engine"] = AdoptedAdam(optimizer, arena)
     else:
         eng.import_state()
     return eng

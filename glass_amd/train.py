@@ -38,7 +38,7 @@ def _graph_step(optimizer, model, dataloader, loss_fn):
         optimizer.arena.reattach()
     ds = dataloader.Gdataset
     key = (id(optimizer), id(engine), id(loss_fn), id(ds.x), id(ds.edge_index), dataloader.batch_size, gdist.world_size(), USE_GRAPH)
-    cache = model.__dict__.setdefault("_glass_train_steps", {})
+    cache = model.__dict__.setdefault("_glass_train_steps", utils.RuntimeCache())
     step = cache.get(key)
     if step is None:
         from .step import TrainStep
@@ -133,6 +133,7 @@ def _eval_graph(model, batch, k):
     GLASS evaluation call (x, ei, ea, pos, z) on the GPU — or when its capture failed before (remembered per key: the eager
     forward then serves that shape)."""
     from .models import GLASS
+    from .utils import RuntimeCache
     if not (USE_EVAL_GRAPH and k > 1 and isinstance(model, GLASS) and len(batch) == 5 and batch[0].is_cuda and
             batch[3].dim() == 2 and batch[3].dtype == torch.int64):
         return None
@@ -141,7 +142,7 @@ def _eval_graph(model, batch, k):
     if k <= 1:
         return None
     key = (id(x), id(ei), id(ea), tuple(pos.shape), k)
-    cache = model.__dict__.setdefault("_glass_eval_graphs", {})
+    cache = model.__dict__.setdefault("_glass_eval_graphs", RuntimeCache())
     if key in cache:
         return cache[key]  # (None: a capture of this shape failed earlier)
     from .evalstep import EvalGraph

@@ -31,3 +31,14 @@ def batch2pad(batch):
     pad = torch.full((vals.shape[0], int(counts.max())), -1, dtype=torch.int64, device=batch.device)
     pad[seg, within] = order
     return pad
+
+
+class RuntimeCache(dict):
+    """What the training / evaluation loops hang on a model (captured hipGraphs, the adopted optimizer engine): per-process
+    runtime objects, not model state.  `copy.deepcopy(model)` (an early-stopping snapshot, a twin in a test) and pickling get
+    an EMPTY cache instead of trying to copy device graphs — the copy simply builds its own on first use."""
+    def __deepcopy__(self, memo):
+        return RuntimeCache()
+
+    def __reduce__(self):
+        return (RuntimeCache, ())

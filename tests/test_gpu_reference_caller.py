@@ -274,3 +274,34 @@ def test_reference_caller_randomised_configurations():
                          capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "on the captured step program" in out.stdout
+
+
+def test_deepcopy_after_training_gives_an_independent_plain_model():
+    """A caller that snapshots its best model with copy.deepcopy AFTER impl.train.train has adopted the optimizer (arena,
+    captured step, evaluation graphs on the model): the copy is a plain model with the same weights, trains on its own —
+    landing on the step program again — and training it leaves the original untouched (a value copy of the arena would have
+    kept the original's device pointers in its launch arguments)."""
+    from impl import SubGDataset, train, metrics
+    from glass_amd import arena
+    x, ei, ew, pos, y = _binary_task(seed=6)
+    torch.manual_seed(2)
+    gnn = reference_build_model(64, 2, 0.0, True, "sum", 0.9, "mean", torch.max(x), 1)
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    opt = Adam(gnn.parameters(), lr=5e-3)
+    torch.manual_seed(1)
+    train.train(opt, gnn, reference_loader(ds, 8), reference_binary_loss)
+    train.test(gnn, reference_loader(ds, 8, drop_last=False), metrics.binaryf1, reference_binary_loss)
+    assert gnn.__dict__.get("_glass_train_steps") and gnn.__dict__.get("_glass_grad_bucket") is not None
+    snap = copy.deepcopy(gnn)
+    assert not any(k in m.__dict__ for m in snap.modules() for k in arena._RUNTIME_ATTRS)
+    before = {k: v.clone() for k, v in gnn.state_dict().items()}
+    assert all(torch.equal(v, snap.state_dict()[k]) for k, v in before.items())
+    opt2 = Adam(snap.parameters(), lr=5e-3)
+    torch.manual_seed(2)
+    train.train(opt2, snap, reference_loader(ds, 8), reference_binary_loss)
+    assert _taken_step(snap)._program_step() and _taken_step(snap) is not _taken_step(gnn)
+    assert all(torch.equal(v, gnn.state_dict()[k]) for k, v in before.items()), "training the copy changed the original"
+    assert any(not torch.equal(v, snap.state_dict()[k]) for k, v in before.items())
+    # and the original keeps training on its own graph
+    torch.manual_seed(3)
+    assert np.isfinite(train.train(opt, gnn, reference_loader(ds, 8), reference_binary_loss))

@@ -311,3 +311,22 @@ def test_reference_driver_file_runs_over_this_repos_modules_up_to_the_first_kern
     assert ended.count(os.path.join(ROOT, "glass_amd")) == 2 and os.path.join(ROOT, "datasets.py") in ended, ended
     assert "repeat 0" in out.stdout                      # reached the training loop of the reference's test()
     assert "glass_amd/train.py" in text and "in train" in text  # ... and died inside impl.train.train, at a kernel call
+
+
+def test_deepcopy_of_a_model_is_a_plain_independent_copy():
+    """copy.deepcopy(model) — an early-stopping snapshot in a caller's loop — gives a plain module: same weights, own storage,
+    none of the runtime attachments the training loops hang on a model (those hold device pointers and captured graphs;
+    glass_amd.arena.strip_runtime).  The GPU side — a copy taken AFTER impl.train.train adopted the optimizer and built the
+    arena — is tests/test_gpu_reference_caller.py::test_deepcopy_after_training_gives_an_independent_plain_model."""
+    import copy
+    from glass_amd import arena
+    from glass_amd.utils import RuntimeCache
+    torch.manual_seed(0)
+    m = build_glass(16, 2, 5, 3, "mean", "sum", 0.8)
+    m.__dict__["_glass_train_steps"] = RuntimeCache(a=object())   # what train.train would leave behind
+    m.conv.__dict__["_glass_arena"] = object()
+    c = copy.deepcopy(m)
+    assert all(torch.equal(a, b) and a.data_ptr() != b.data_ptr() for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+    assert not any(k in mod.__dict__ for mod in c.modules() for k in arena._RUNTIME_ATTRS)
+    assert "_glass_train_steps" in m.__dict__ and m.conv.__dict__["_glass_arena"] is not None   # the original keeps its own
+    assert copy.deepcopy(RuntimeCache(x=1)) == {} and isinstance(copy.deepcopy(RuntimeCache(x=1)), RuntimeCache)
