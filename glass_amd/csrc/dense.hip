@@ -1309,7 +1309,13 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
 // the double-buffered loads), and pays the prologue once.  The label byte of a row travels with its operand loads and
 // reaches the epilogue through LDS next to the row id (no per-workgroup row table); the extra workgroups (listed labeled
 // rows, effective labeled weight) keep a small row table and at most 80 rows.
-template <int H, bool DROP, int WG>
+// SP (hidden 128): the product in the split form of the tiled family (split_mma.h: every operand value cut into three bf16 pieces,
+// six partial products per fp32 product on v_mfma_f32_16x16x32_bf16) — this kernel's matrix pipes were 0.45 busy on the f32-input
+// MFMA (profiles/r05_step_pmc_em_user_summary.csv), 18 us of a 41 us launch; the split form needs 6/16 of those cycles.  The
+// rows are cut ONCE, by the staging thread, and lie in LDS as three bf16 planes; the weight slice of a wave is cut once per
+// workgroup from the SAME fp32 image (lane (j, q) owns k = 64 q .. 64 q + 63 of its column either way: block b of 32 k takes
+// its k = 64 q + 8 b .. + 7).  Results as close to fp64 as the f32-input form (tests/test_gpu_kernels.py).
+template <int H, bool DROP, int WG, bool SP = false>
 __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
                                                                const float* __restrict__ Wimg, const float* __restrict__ bias,
@@ -1322,7 +1328,11 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* 
     constexpr int THREADS = 4 * H * WG, NTL = H / 16, KF4 = (2 * H) / 16;
     constexpr int KT = 2 * H, RS = KT + 4;
     constexpr int SR = 16 * WG;
-    __shared__ __attribute__((aligned(16))) float tile[2][SR * RS];
+    static_assert(!SP || (H == 128 && WG == 1), "split form: hidden 128");
+    constexpr int RSB = KT + 8;        // SP: bf16 elements per row of a piece plane (528 B: 16-B aligned, rows 4 banks apart)
+    constexpr int kPlane = SR * RSB;   // bf16 elements per piece plane
+    __shared__ __attribute__((aligned(16))) float tile[SP ? 1 : 2][SP ? 4 : SR * RS];
+    __shared__ __attribute__((aligned(16))) unsigned short tile_s[SP ? 2 : 1][SP ? 3 * kPlane : 8];  // [buffer][piece][row][k]
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
     __shared__ int rowflag_s[2][SR];   // per stage buffer: row of each slot (-1 none; bit 30: computed but not stored / counted)
     __shared__ int xrows_s[80];        // extra workgroups: their listed rows
@@ -1393,6 +1403,17 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* 
     const float c1 = extra ? zr : omz, c0 = extra ? omz : zr;
     const float be = c1 * bias1 + c0 * bias0;
     if (fold_here) gn_fwd_coef_finish<H, 4 * H>(pro.src, pro.saved, N, CR, gn_coef_s);
+    // SP: the wave's weight slice as bf16 pieces, block b = the lane's k = 64 q + 8 b .. + 7 (bw[2b], bw[2b + 1])
+    uint4 bwc[SP ? KF4 / 2 : 1][3];
+    if constexpr (SP) {
+#pragma unroll
+        for (int b = 0; b < KF4 / 2; ++b) {
+            const Split4 s0 = split4(bw[2 * b]), s1 = split4(bw[2 * b + 1]);
+            bwc[b][0] = make_uint4(s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y);
+            bwc[b][1] = make_uint4(s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y);
+            bwc[b][2] = make_uint4(s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y);
+        }
+    }
     lds_barrier();  // coefficients
     const bool pro_on = pro.saved != nullptr;
     const bool side_on = pro.side != nullptr && !extra;
@@ -1404,7 +1425,7 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* 
         sh[0] = h4.x, sh[1] = h4.y, sh[2] = h4.z, sh[3] = h4.w;
     }
     auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
-        float* T = tile[st & 1];
+        float* T = tile[SP ? 0 : (st & 1)];
         const int r = R.row;
         float a[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
         float ds[4] = {1.f, 1.f, 1.f, 1.f};
@@ -1413,8 +1434,19 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* 
         for (int k = 0; k < 4; ++k) a[k] = fmaf(a[k], sc[k], sh[k]) * ds[k];
         const float4 v = make_float4(a[0], a[1], a[2], a[3]);
         buf_store4(r_side, (pro_on && side_on && r >= 0) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
-        *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
-        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = R.h;
+        if constexpr (SP) {
+            const Split4 sa = split4(v), sh4 = split4(R.h);
+            unsigned short* P = tile_s[st & 1] + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = sa.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = sa.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = sa.lo;
+            *reinterpret_cast<uint2*>(P + H) = sh4.hi;
+            *reinterpret_cast<uint2*>(P + kPlane + H) = sh4.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane + H) = sh4.lo;
+        } else {
+            *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
+            *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = R.h;
+        }
         if (ga == 0) rowflag_s[st & 1][rs] = (r >= 0 && R.mk != 0) ? (r | (1 << 30)) : r;  // labeled row of a main tile: an extra workgroup stores it
     };
     float ssum = 0.f, ssq = 0.f;
@@ -1424,23 +1456,44 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* 
     // one stage: the MFMAs of stage st (buffer st & 1), then stage st + 1's rows (held in Rn) go to the other buffer and the
     // loads of stage st + 3 are issued into Rn
     auto stage = [&](int st, Raw& Rn) __attribute__((always_inline)) {
-        const float* T = tile[st & 1] + (16 * g + j) * RS + (KT / 4) * q;
-        float4 a4[KF4];
-#pragma unroll
-        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
         int rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = rowflag_s[st & 1][16 * g + 4 * q + r];
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP) {
+            // lane (j, q): row j of the stage, k = 64 q + 8 b .. + 7 of block b: one 16-byte read per piece
+            const unsigned short* P = tile_s[st & 1] + (16 * g + j) * RSB + (KT / 4) * q;
 #pragma unroll
-        for (int tt = 0; tt < KF4; tt += 2) {
-            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
-            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
-            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+            for (int b = 0; b < KF4 / 2; ++b) {
+                uint4 af[3];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const uint4*>(P + p * kPlane + 8 * b);
+#define GLASS_SMMA16(ACC, pa, pb)                                                                                     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[pa]), __builtin_bit_cast(bf16x8, bwc[b][pb]), ACC, 0, 0, 0)
+                if (b & 1) {
+                    GLASS_SMMA16(acc1, 1, 1); GLASS_SMMA16(acc1, 2, 0); GLASS_SMMA16(acc1, 0, 2);
+                    GLASS_SMMA16(acc1, 1, 0); GLASS_SMMA16(acc1, 0, 1); GLASS_SMMA16(acc1, 0, 0);
+                } else {
+                    GLASS_SMMA16(acc0, 1, 1); GLASS_SMMA16(acc0, 2, 0); GLASS_SMMA16(acc0, 0, 2);
+                    GLASS_SMMA16(acc0, 1, 0); GLASS_SMMA16(acc0, 0, 1); GLASS_SMMA16(acc0, 0, 0);
+                }
+#undef GLASS_SMMA16
+            }
+        } else {
+            const float* T = tile[SP ? 0 : (st & 1)] + (16 * g + j) * RS + (KT / 4) * q;
+            float4 a4[KF4];
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
+#pragma unroll
+            for (int tt = 0; tt < KF4; tt += 2) {
+                const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+                const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+                const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+                }
             }
         }
         if (st + 1 < nst) {
@@ -2685,6 +2738,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
                                       const glass_gn_src* gn_src, int gn_act, float p_drop, const uint64_t* rng_state,
                                       uint64_t call_id, float* xa_out, int64_t ldxo, const int32_t* lab_rows,
                                       const int32_t* lab_count, int64_t lab_cap, void* stream) {
+    const CallOptions call_options(gn_act);  // gn_act word -> activation code of the GraphNorm prologue + this call's options
     GLASS_REQUIRE(xa && xb && Wimg_eff && bias && mask && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
                   "comb_eff_fwd: null pointer");
     if (!glass_comb_eff_fwd_supported(H)) {
@@ -2737,7 +2791,12 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
 #define GLASS_CF3(HH, DR, WGN)                                                                                              \
     hipLaunchKernelGGL((comb_fwd_eff3_kernel<HH, DR, WGN>), grid3, dim3(4 * HH * WGN), 0, (hipStream_t)stream, xa, lda, xb, ldb,   \
                        Wimg_eff, bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab3, cg.rows_main, cg.rows_extra)
-        if (H == 128) {
+#define GLASS_CF3S(DR)                                                                                                      \
+    hipLaunchKernelGGL((comb_fwd_eff3_kernel<128, DR, 1, true>), grid3, dim3(512), 0, (hipStream_t)stream, xa, lda, xb, ldb,       \
+                       Wimg_eff, bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab3, cg.rows_main, cg.rows_extra)
+        if (H == 128 && tiled_split_products()) {  // (the split form of the tiled family; GLASS_DENSE_F32_PRODUCTS in gn_act opts out)
+            if (dr) GLASS_CF3S(true); else GLASS_CF3S(false);
+        } else if (H == 128) {
             if (dr) GLASS_CF3(128, true, 1); else GLASS_CF3(128, false, 1);
 #if GLASS_LAB  // two wave groups on the comb forward: laboratory A/B (GLASS_FWD_WG=2)
         } else if (fwd_wave_groups(true) == 2) {
@@ -2747,6 +2806,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
             if (dr) GLASS_CF3(64, true, 1); else GLASS_CF3(64, false, 1);
         }
 #undef GLASS_CF3
+#undef GLASS_CF3S
         return launch_status("glass_comb_eff_fwd_f32");
     }
     if (GLASS_COMB_FWD_V2 && H == 128) {

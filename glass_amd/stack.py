@@ -162,7 +162,7 @@ def _comb_eff_fwd(xa, xb, conv, mask, out, stats, gn, labels):
     rc = _lib.load().glass_comb_eff_fwd_f32(xa.data_ptr(), xa.stride(0), xb.data_ptr(), xb.stride(0),
                                             conv._stack_eff["comb"][0].data_ptr(), conv._stack["comb"][1].data_ptr(),
                                             mask.data_ptr(), float(conv.z_ratio), out.data_ptr(), out.stride(0), n, H,
-                                            *_stats_args(stats), *_saved_args(saved), gact, float(gp), grng, gcall,
+                                            *_stats_args(stats), *_saved_args(saved), ops.act_word(gact), float(gp), grng, gcall,
                                             xa_out.data_ptr(), xa_out.stride(0), labels.rows.data_ptr(),
                                             labels.count.data_ptr(), labels.cap, _stream())
     _check(rc, "glass_comb_eff_fwd_f32")
