@@ -46,7 +46,7 @@ typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a k
 
 /* activation fused into a kernel: none, or ELU(alpha=1) (GLASSTest.py:143) */
 /* Activation codes — and the OPTIONS of a dense call: the `act` argument of the four glass_dual_linear_{fwd,bwd,dgrad,wgrad}_f32
- * entries is a word, activation code in bits 0..7 (GLASS_ACT_MASK), options above.  The library keeps NO mutable state: no
+ * entries (and the `gn_act` argument of glass_comb_eff_fwd_f32) is a word, activation code in bits 0..7 (GLASS_ACT_MASK), options above.  The library keeps NO mutable state: no
  * environment variable is read, nothing is process-global; what a call does follows from its arguments alone, so two threads
  * on two streams with different options each get their own behaviour. */
 #define GLASS_ACT_MASK 0xff
