@@ -149,17 +149,20 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
                                                                   const float* __restrict__ X, int64_t ldx, int64_t N,
                                                                   int rows_per_slab, float* __restrict__ part_w,
                                                                   float* __restrict__ part_b, float* __restrict__ header,
-                                                                  WgradSynth sy) {
+                                                                  WgradSynth sy, int z0, int nz_all) {
+    // (z0, nz_all): this launch covers output tiles z0 .. z0 + gridDim.z - 1 of nz_all — the split form launches the
+    // all-rows tiles on tiled_wgrad8_kernel and only the labeled-rows tiles here
     extern __shared__ float wsm[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
+    const int bz = blockIdx.z + z0;
     if (header && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && tid == 0) {
         header[0] = EFF ? 1.f : 0.f;
         header[1] = sy.zr;
         header[2] = 0.f;
     }
-    const bool lab_tile = EFF && blockIdx.z >= gridDim.z / 2;  // the labeled-rows sum of output tile z - nz/2
-    const int o0 = (lab_tile ? blockIdx.z - gridDim.z / 2 : blockIdx.z) * kWO, i0 = blockIdx.y * kWI;
+    const bool lab_tile = EFF && bz >= nz_all / 2;  // the labeled-rows sum of output tile z - nz/2
+    const int o0 = (lab_tile ? bz - nz_all / 2 : bz) * kWO, i0 = blockIdx.y * kWI;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_slab;
     const int64_t r1 = min(N, r0 + rows_per_slab);
     const int n_steps = (int)((r1 - r0 + kWK - 1) / kWK);
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
     }
 
     // partial tile, plain [128][256]: acc[rb][cb][k] = output wm*64 + rb*32 + 8(k>>2) + 4h + (k&3), input wn*128 + cb*32 + j
-    const int64_t tile_id = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int64_t tile_id = ((int64_t)bz * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     float* pw = part_w + tile_id * kWTile;
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb)
@@ -293,7 +296,233 @@ __global__ __launch_bounds__(kWThreads, 2) void tiled_wgrad_kernel(const float* 
                 const float4 o = red[tid + 32 * r];
                 s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
             }
-            *reinterpret_cast<float4*>(part_b + ((int64_t)blockIdx.z * gridDim.x + blockIdx.x) * kWO + 4 * tid) = s;
+            *reinterpret_cast<float4*>(part_b + ((int64_t)bz * gridDim.x + blockIdx.x) * kWO + 4 * tid) = s;
+        }
+    }
+}
+
+// ---- split form, all-rows tiles: eight waves, three stages of raw rows in flight --------------------------------------
+// The four-wave kernel above keeps ONE stage of raw loads in registers, issued a single MFMA phase (0.7 us) before it is cut:
+// every step waits out the rest of the operand rows' round trip, and two workgroups per CU only half hide it (MFMA busy 0.36 -
+// 0.40 at config 5; 249 registers: no room for a second set).  Here the same 128 x 256 tile and the same LDS image belong to
+// EIGHT waves — wave (wm, wn) owns 64 outputs x 64 inputs: 64 accumulator registers —, so a lane has room for THREE sets of
+// raw rows: stage k is requested three steps before it is cut (under the MFMAs of steps k - 4 .. k - 2), the hand-over
+// barrier waits for LDS only, and the two waves of a SIMD fill each other's cut / LDS phases with MFMAs.
+//   * No conditional memory instruction in the loop (common.h, lds_barrier): buffer loads on resources that start at the
+//     slab's first row and end behind its last — a row past the slab reads as zero, so there is no clamp, no liveness flag
+//     and the loop runs whole triples of steps.  Waves 0-3 stage the gradient operand (2 rows x one column quad: gradient,
+//     pre-activation, the rows' label bytes as ONE 16-bit load), waves 4-7 the input operand (4 rows x one column quad):
+//     the same five load instructions in either kind of wave, on resources selected per wave in scalar registers.
+//   * Every use of a set's values is pinned behind the point where its stage is cut (glass_pin) — the compiler otherwise
+//     computes a LATER stage's label coefficient or zero-extension early and waits for the youngest loads there; the
+//     file is compiled without SLP vectorisation for the same reason (Makefile).
+//   * LDS writes without bank conflicts: a wave's lanes write consecutive words — lane l of an A wave holds row pair
+//     4 (w & 1) + (l & 3) of column quad (l >> 2) + 16 (w >> 1); lane l of a B wave row quad 2 (w & 1) + (l & 1) of column quad
+//     (l >> 1) + 32 (w >> 1) (the four-wave mapping wrote 4-way conflicts: 0.45 of its LDS cycles).
+constexpr int kW8Threads = 512;
+struct W8Set {
+    float4 v[4];          // A wave: gradient rows 0, 1, pre-activation rows 0, 1; B wave: input rows 0 .. 3
+    unsigned short mk2;   // A wave: the two rows' label bytes (kept as loaded: the zero-extension is a use)
+    __device__ __forceinline__ void pin() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { glass_pin(v[k].x); glass_pin(v[k].y); glass_pin(v[k].z); glass_pin(v[k].w); }
+        glass_pin(mk2);
+    }
+};
+
+template <bool EFF>
+__global__ __launch_bounds__(kW8Threads, 1) void tiled_wgrad8_kernel(const float* __restrict__ X, int64_t ldx, int64_t N,
+                                                                    int rows_per_slab, float* __restrict__ part_w,
+                                                                    float* __restrict__ part_b, float* __restrict__ header,
+                                                                    WgradSynth sy, int n_slabs, int ny, int nz) {
+    extern __shared__ float wsm[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);  // (scalar: the per-wave resource selection below stays in SGPRs)
+    const int wm = w & 1, wn = w >> 1, j = lane & 31, h = lane >> 5;
+    if (header && blockIdx.x == 0 && tid == 0) {
+        header[0] = EFF ? 1.f : 0.f;
+        header[1] = sy.zr;
+        header[2] = 0.f;
+    }
+    // XCD-aware placement (1-D grid; consecutive workgroup ids go round the 8 XCDs, each with its own L2): the ny * nz tiles
+    // of ONE slab — which read the same rows: every input tile the slab's gradient rows, every output tile its input rows —
+    // get consecutive ids on the SAME XCD (output tile fastest), so they run side by side and the re-reads are L2 hits
+    // instead of HBM reads.  With the plain (slab, y, z) grid the z tiles of a slab ran whole rounds apart.
+    int bx, by, bz;
+    {
+        const int lin = blockIdx.x, T = ny * nz;
+        int t;
+        if (n_slabs % 8 == 0) {
+            const int c = lin & 7, m = lin >> 3;
+            t = m % T;
+            bx = c + 8 * (m / T);
+        } else {
+            t = lin % T;
+            bx = lin / T;
+        }
+        bz = t % nz;
+        by = t / nz;
+    }
+    const int o0 = bz * kWO, i0 = by * kWI;
+    const int64_t r0 = (int64_t)bx * rows_per_slab;
+    const int64_t r1 = min(N, r0 + rows_per_slab);
+    const int64_t rows = r1 - r0;
+    const int n_steps = (int)((rows + kWK - 1) / kWK);
+    const bool is_a = w < 4;
+    const bool a_first = o0 < sy.H;                           // this tile's outputs lie in the f1 half (a tile never straddles)
+    const bool x_second = sy.X2 != nullptr && i0 >= sy.H;     // ... its inputs in the second half of [X | X2]
+    const bool has_t = !EFF && sy.act != GLASS_ACT_NONE;
+    // the four row slots of a set: (resource, this thread's byte offset in stage 0, bytes per stage)
+    const float* xs = x_second ? sy.X2 : X;
+    const int64_t xld = x_second ? sy.ldx2 : ldx;
+    const buf_rsrc r_g = make_rsrc(sy.dsrc + r0 * sy.ldd, rows * sy.ldd * 4);
+    const buf_rsrc r_t = make_rsrc(has_t ? sy.T + r0 * sy.ldt : sy.dsrc, has_t ? rows * sy.ldt * 4 : 0);  // none: zeros
+    const buf_rsrc r_x = make_rsrc(xs + r0 * xld, rows * xld * 4);
+    const buf_rsrc r_m = make_rsrc(sy.mask + r0, (!EFF && is_a) ? rows : 0);
+    const buf_rsrc rs01 = is_a ? r_g : r_x, rs23 = is_a ? r_t : r_x;
+    const int step01 = (int)(kWK * (is_a ? sy.ldd : xld) * 4), step23 = (int)(kWK * (is_a ? sy.ldt : xld) * 4);
+    // A wave: row pair g2 = 4 (w & 1) + (l & 3), column quad qa = (l >> 2) + 16 (w >> 1)
+    const int g2 = 4 * (w & 1) + (lane & 3), qa = (lane >> 2) + 16 * ((w >> 1) & 1);
+    // B wave: row quad gq = 2 (w & 1) + (l & 1), column quad qb = (l >> 1) + 32 ((w - 4) >> 1)
+    const int gq = 2 * (w & 1) + (lane & 1), qb = (lane >> 1) + 32 * ((w >> 1) & 1);
+    const int a_col = o0 + 4 * qa;
+    int off[4];
+    if (is_a) {
+        const int g_col = a_first ? a_col : a_col - sy.H;
+        off[0] = (int)(((2 * g2) * sy.ldd + g_col) * 4);
+        off[1] = (int)(((2 * g2 + 1) * sy.ldd + g_col) * 4);
+        off[2] = (int)(((2 * g2) * sy.ldt + a_col) * 4);
+        off[3] = (int)(((2 * g2 + 1) * sy.ldt + a_col) * 4);
+    } else {
+        const int xcol = (x_second ? i0 - sy.H : i0) + 4 * qb;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) off[b] = (int)(((4 * gq + b) * xld + xcol) * 4);
+    }
+    const int off_m = 2 * g2;
+    const float e_neg = sy.act == GLASS_ACT_RELU ? 0.f : 1.f;  // act'(t) = t > 0 ? 1 : e_neg * exp(t); none: t reads 0, factor 1
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    auto issue = [&](W8Set& S, int step) __attribute__((always_inline)) {
+        S.v[0] = buf_load4(rs01, off[0] + step * step01);
+        S.v[1] = buf_load4(rs01, off[1] + step * step01);
+        S.v[2] = buf_load4(rs23, off[2] + step * step23);
+        S.v[3] = buf_load4(rs23, off[3] + step * step23);
+        S.mk2 = __builtin_amdgcn_raw_buffer_load_b16(r_m, off_m + step * kWK, 0, 0);
+    };
+    auto commit = [&](W8Set& S, float* stage) __attribute__((always_inline)) {
+        S.pin();
+        if (is_a) {  // wave-uniform
+            float4 gv[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                float4 g = S.v[a];
+                if (!EFF) {
+                    const float4 t = S.v[2 + a];
+                    const float cf = ((((unsigned)S.mk2 >> (8 * a)) & 0xffu) != 0) == a_first ? sy.zr : sy.omz;
+                    g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
+                    g.x *= t.x > 0.f ? 1.f : e_neg * __expf(t.x);
+                    g.y *= t.y > 0.f ? 1.f : e_neg * __expf(t.y);
+                    g.z *= t.z > 0.f ? 1.f : e_neg * __expf(t.z);
+                    g.w *= t.w > 0.f ? 1.f : e_neg * __expf(t.w);
+                }
+                bsum.x += g.x; bsum.y += g.y; bsum.z += g.z; bsum.w += g.w;
+                gv[a] = g;
+            }
+            unsigned* A = reinterpret_cast<unsigned*>(stage);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                unsigned hi, mid, lo;
+                split2(f4e(gv[0], e), f4e(gv[1], e), hi, mid, lo);
+                const int u = (((g2 >> 2) * kWO + e * 32 + qa) << 2) + (g2 & 3);
+                A[u] = hi;
+                A[4 * SplitImg<kWO>::kPlane + u] = mid;
+                A[8 * SplitImg<kWO>::kPlane + u] = lo;
+            }
+        } else {
+            uint2* B = reinterpret_cast<uint2*>(stage + 4 * SplitImg<kWO>::kUnits);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                uint2 hi, mid, lo;
+                split2(f4e(S.v[0], e), f4e(S.v[1], e), hi.x, mid.x, lo.x);
+                split2(f4e(S.v[2], e), f4e(S.v[3], e), hi.y, mid.y, lo.y);
+                const int u = (((gq >> 1) * kWI + (qb >> 5) * 128 + e * 32 + (qb & 31)) << 1) + (gq & 1);
+                B[u] = hi;
+                B[2 * SplitImg<kWI>::kPlane + u] = mid;
+                B[4 * SplitImg<kWI>::kPlane + u] = lo;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[rb][cb][k] = 0.f;
+    auto stage_mma = [&](const float* cur) __attribute__((always_inline)) {
+        const float4* Ai = reinterpret_cast<const float4*>(cur);
+        const float4* Bi = Ai + SplitImg<kWO>::kUnits;
+        uint4 a[2][3];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) SplitImg<kWO>::frag(Ai, wm * 64 + rb * 32 + j, h, a[rb]);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            uint4 b[3];
+            SplitImg<kWI>::frag(Bi, wn * 64 + cb * 32 + j, h, b);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) split_mma(acc[rb][cb], a[rb], b);
+        }
+    };
+
+    W8Set s0, s1, s2;
+    auto step_fn = [&](int step, W8Set& nxt_regs) __attribute__((always_inline)) {
+        stage_mma(wsm + (step & 1) * kWStageS);
+        __builtin_amdgcn_sched_barrier(0);  // (nothing of a later step moves up across these)
+        commit(nxt_regs, wsm + ((step + 1) & 1) * kWStageS);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(nxt_regs, step + 4);
+        lds_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    issue(s0, 0);
+    issue(s1, 1);
+    issue(s2, 2);
+    commit(s0, wsm);
+    issue(s0, 3);
+    lds_barrier();
+    for (int step = 0; step < n_steps; step += 3) {  // whole triples: steps past the slab read zeros and add zeros
+        step_fn(step, s1);
+        step_fn(step + 1, s2);
+        step_fn(step + 2, s0);
+    }
+
+    // partial tile, plain [128][256]: slot -> column as the staging laid them out.  Output slot wm*64 + rb*32 + r
+    // (r = 8 (k >> 2) + 4 h + (k & 3)) is output 4 r + 2 wm + rb; input slot wn*64 + cb*32 + j is input
+    // 4 (32 (wn >> 1) + j) + 2 (wn & 1) + cb: two consecutive inputs per lane
+    const int64_t tile_id = ((int64_t)bz * ny + by) * n_slabs + bx;
+    float* pw = part_w + tile_id * kWTile;
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int o = 4 * (8 * (k >> 2) + 4 * h + (k & 3)) + 2 * wm + rb;
+            *reinterpret_cast<float2*>(pw + o * kWI + 4 * (32 * (wn >> 1) + j) + 2 * (wn & 1)) = make_float2(acc[rb][0][k], acc[rb][1][k]);
+        }
+    if (by == 0 && part_b) {
+        // the 8 A threads of a column quad (l & 3, w & 1) hold partial bias sums of its 4 outputs: combined in a fixed order
+        __syncthreads();  // every wave is done with the stages
+        float4* red = reinterpret_cast<float4*>(wsm);
+        if (is_a) red[qa * 8 + (lane & 3) + 4 * (w & 1)] = bsum;
+        __syncthreads();
+        if (tid < 32) {
+            float4 s = red[tid * 8];
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                const float4 o = red[tid * 8 + r];
+                s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+            }
+            *reinterpret_cast<float4*>(part_b + ((int64_t)bz * n_slabs + bx) * kWO + 4 * tid) = s;
         }
     }
 }
@@ -371,12 +600,32 @@ void launch_tiled_wgrad_partial(const float* X, int64_t ldx, int64_t N, int64_t 
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)tiled_wgrad_kernel<true, EFFV, S3V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((tiled_wgrad_kernel<true, EFFV, S3V>), grid, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N,  \
-                           g.rows_per_slab, part_w, part_b, header, sy);                                             \
+                           g.rows_per_slab, part_w, part_b, header, sy, 0, g.nz);                                     \
     }
-    if (eff) {
-        if (s3) GLASS_TWG(true, true) else GLASS_TWG(true, false)
+    if (s3) {
+        // split form: the all-rows tiles on the eight-wave kernel, the labeled-rows tiles of the effective-weight form on the
+        // four-wave kernel (stages without a labeled row are skipped there: short workgroups)
+        const int nz8 = eff ? g.nz / 2 : g.nz;
+        const dim3 grid8((unsigned)(g.n_slabs * g.ny * nz8));
+        const size_t lds8 = 2 * (size_t)kWStageS * sizeof(float);
+        if (eff) {
+            (void)hipFuncSetAttribute((const void*)tiled_wgrad8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+            hipLaunchKernelGGL((tiled_wgrad8_kernel<true>), grid8, dim3(kW8Threads), lds8, st, X, ldx, N, g.rows_per_slab, part_w,
+                               part_b, header, sy, g.n_slabs, g.ny, nz8);
+            const dim3 gridl(g.n_slabs, g.ny, g.nz / 2);
+            if (lds > 64 * 1024)
+                (void)hipFuncSetAttribute((const void*)tiled_wgrad_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL((tiled_wgrad_kernel<true, true, true>), gridl, dim3(kWThreads), lds, st, nullptr, 0, X, ldx, N,
+                               g.rows_per_slab, part_w, part_b, nullptr, sy, g.nz / 2, g.nz);
+        } else {
+            (void)hipFuncSetAttribute((const void*)tiled_wgrad8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+            hipLaunchKernelGGL((tiled_wgrad8_kernel<false>), grid8, dim3(kW8Threads), lds8, st, X, ldx, N, g.rows_per_slab, part_w,
+                               part_b, header, sy, g.n_slabs, g.ny, nz8);
+        }
+    } else if (eff) {
+        GLASS_TWG(true, false)
     } else {
-        if (s3) GLASS_TWG(false, true) else GLASS_TWG(false, false)
+        GLASS_TWG(false, false)
     }
 #undef GLASS_TWG
 }

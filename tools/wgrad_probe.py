@@ -12,11 +12,20 @@ sys.path.insert(0, ROOT)
 from glass_amd import _lib, ops  # noqa: E402
 
 DEV = "cuda:0"
+if os.environ.get("GLASS_PROBE_LIB"):  # A/B against another build of the library (laboratory use)
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["GLASS_PROBE_LIB"])
 lib = _lib.load()
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+NS = tuple(int(v) for v in sys.argv[2].split(",")) if len(sys.argv) > 2 else (12500, 25000, 50000, 100000, 200000)
+EAGER_ITERS = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # under a counter collection: a few eager launches, no graph
 
 
 def timeit(fn, iters=50, warm=10):
+    if EAGER_ITERS:
+        for _ in range(EAGER_ITERS):
+            fn()
+        torch.cuda.synchronize()
+        return float("nan")
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
@@ -36,7 +45,7 @@ def timeit(fn, iters=50, warm=10):
 
 for comb in (False, True):
     res = []
-    for N in (12500, 25000, 50000, 100000, 200000):
+    for N in NS:
         gen = torch.Generator().manual_seed(N)
         dsrc = torch.randn(N, H, generator=gen).to(DEV)
         T = torch.randn(N, 2 * H, generator=gen).to(DEV)
