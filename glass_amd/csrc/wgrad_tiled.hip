@@ -475,6 +475,7 @@ __global__ __launch_bounds__(kW8Threads, 1) void tiled_wgrad8_kernel(const float
         }
     };
 
+    if (is_a) __builtin_amdgcn_s_setprio(1);  // the A waves (more vector work per cut) first on the matrix pipe: -2 % measured
     W8Set s0, s1, s2;
     auto step_fn = [&](int step, W8Set& nxt_regs) __attribute__((always_inline)) {
         stage_mma(wsm + (step & 1) * kWStageS);

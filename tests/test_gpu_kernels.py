@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load, rel_inf
+from helpers import load, rel_inf, record_parity
 from oracle import glass_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -630,6 +630,58 @@ def test_dual_linear_mix_fused(H, N, comb):
     out2 = ops.dual_linear_mix(xa.detach(), None if xb is None else xb.detach(), lin1, lin0,
                                mask.to(DEV).to(torch.uint8), zr, act, (Wg, bg, dW, db, Wimg, WTimg))
     assert torch.equal(out2, out.detach())
+
+
+@pytest.mark.parametrize("N", [71680, 70001, 65536 + 17])
+@pytest.mark.parametrize("comb,act", [(False, 1), (False, 2), (False, 0), (True, 0)])
+def test_tiled_wgrad_eight_wave_kernel(N, comb, act):
+    """glass_dual_linear_wgrad_f32 at hidden 256 on a graph of >= 65 536 rows: the all-rows tiles run on the eight-wave kernel
+    (wgrad_tiled.hip: three stages of raw rows in flight, rows past a slab read as zero through the buffer resource, one
+    16-bit load for a thread's two label bytes).  N = 71 680 gives 128 slabs — the XCD-aware placement; the other sizes a slab
+    count that is not a multiple of 8 (plain placement) and a ragged last slab.  ELU / ReLU / no activation for the trans
+    pair (pre-activations NULL without one), the comb pair in effective-weight form (labeled-rows tiles on the four-wave
+    kernel); vs the fp64 sums, twice (bitwise repeat: no atomics, fixed slab order)."""
+    from glass_amd import ops, _lib
+    lib = _lib.load()
+    H = 256
+    gen = torch.Generator().manual_seed(N + 7 * act + comb)
+    zr = 0.8
+    dsrc = torch.randn(N, H + 8, generator=gen)[:, 4:4 + H]  # strided views: ld = H + 8, 16-B aligned columns
+    T = torch.randn(N, 2 * H, generator=gen)
+    X = torch.randn(N, H, generator=gen)
+    X2 = torch.randn(N, H, generator=gen) if comb else None
+    mask = torch.rand(N, generator=gen) < 0.01
+    # fp64: G[n, o] = coef(mask[n], o < H) * dsrc[n, o mod H] * act'(T[n, o]);  dW = G^T [X | X2],  db = column sums of G
+    c1 = torch.where(mask, zr, 1 - zr).double().reshape(-1, 1)
+    G = torch.cat((c1 * dsrc.double(), (1 - c1) * dsrc.double()), 1)
+    if act == 1:
+        G = G * torch.where(T > 0, torch.ones(()), torch.exp(T)).double()
+    elif act == 2:
+        G = G * (T > 0).double()
+    Xin = torch.cat((X, X2), 1).double() if comb else X.double()
+    dW_ref, db_ref = G.t() @ Xin, G.sum(0)
+    dg, Tg, Xg, mg = dsrc.to(DEV), T.to(DEV), X.to(DEV), mask.to(DEV).to(torch.uint8)
+    dg = torch.randn(N, H + 8, device=DEV)
+    dg[:, 4:4 + H] = dsrc.to(DEV)
+    dgv = dg[:, 4:4 + H]
+    X2g = X2.to(DEV) if comb else None
+    I = 2 * H if comb else H
+    ws = ops._wgrad_workspace(torch.device(DEV), N, 2 * H, I, slot=("t8", N, comb, act))
+    got = []
+    for _ in range(2):
+        dW = torch.full((2 * H, I), float("nan"), device=DEV)
+        db = torch.full((2 * H,), float("nan"), device=DEV)
+        rc = lib.glass_dual_linear_wgrad_f32(dgv.data_ptr(), dgv.stride(0), Tg.data_ptr() if act else 0, Tg.stride(0) if act else 0,
+                                             mg.data_ptr(), zr, ops.act_word(act), Xg.data_ptr(), Xg.stride(0),
+                                             0 if X2g is None else X2g.data_ptr(), 0 if X2g is None else X2g.stride(0), N, H,
+                                             dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, ws.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, lib.glass_last_error_string()
+        got.append((dW.cpu(), db.cpu()))
+    assert rel_inf(got[0][0], dW_ref) < TOL and rel_inf(got[0][1], db_ref) < TOL
+    assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+    record_parity(f"kernel/tiled_wgrad8_H256_N{N}_{'comb' if comb else 'trans'}_act{act}", dW_rel_inf=rel_inf(got[0][0], dW_ref),
+                  db_rel_inf=rel_inf(got[0][1], db_ref))
 
 
 @pytest.mark.parametrize("H,N,comb", [(128, 3001, False), (256, 4099, False), (256, 4099, True), (256, 70001, True)])
