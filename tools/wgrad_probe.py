@@ -46,12 +46,12 @@ def timeit(fn, iters=50, warm=10):
 for comb in (False, True):
     res = []
     for N in NS:
-        gen = torch.Generator().manual_seed(N)
-        dsrc = torch.randn(N, H, generator=gen).to(DEV)
-        T = torch.randn(N, 2 * H, generator=gen).to(DEV)
-        X = torch.randn(N, H, generator=gen).to(DEV)
-        X2 = torch.randn(N, H, generator=gen).to(DEV) if comb else None
-        mask = (torch.rand(N, generator=gen) < 0.02).to(DEV).to(torch.uint8)
+        gen = torch.Generator(device=DEV).manual_seed(N)
+        dsrc = torch.randn(N, H, generator=gen, device=DEV)
+        T = torch.randn(N, 2 * H, generator=gen, device=DEV)
+        X = torch.randn(N, H, generator=gen, device=DEV)
+        X2 = torch.randn(N, H, generator=gen, device=DEV) if comb else None
+        mask = (torch.rand(N, generator=gen, device=DEV) < float(os.environ.get("PROBE_LABELED", "0.02"))).to(torch.uint8)
         I = 2 * H if comb else H
         ws = ops._wgrad_workspace(torch.device(DEV), N, 2 * H, I, slot=("probe", N, comb))
         act = 0 if comb else 1
