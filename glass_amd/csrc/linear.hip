@@ -620,6 +620,10 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
             set_error("dual_linear_wgrad: the tiled kernel needs ld %% 4 == 0 and 16-B aligned inputs");
             return GLASS_E_UNSUPPORTED;
         }
+        if (reinterpret_cast<uintptr_t>(mask) & 1u) {  // (the eight-wave kernel reads a thread's two label bytes as one 16-bit load)
+            set_error("dual_linear_wgrad: the tiled kernel needs a 2-byte aligned label mask");
+            return GLASS_E_UNSUPPORTED;
+        }
         const TiledWgradGeom t = wgrad_tiled_geom(N, O, I);
         float* pw = (float*)ws;
         launch_tiled_wgrad_partial(X, ldx, N, O, I, sy, pw, (db || !dW) ? pw + t.part_w_floats : nullptr, st);

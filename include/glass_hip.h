@@ -452,7 +452,9 @@ int glass_dual_linear_dgrad_f32(const float* dsrc, int64_t ldd, const float* T, 
  *   followed by glass_dual_linear_wgrad_f32 with dW == NULL (partial sums of dW / db into `ws`, reduced later by
  *   glass_linear_wgrad_reduce_batch_f32; X / X2 = the pair's inputs).  At hidden 64 on graphs of up to 100 000 nodes
  *   the two are independent, latency-bound 12-17 us kernels: there they run as two branches of ONE launch (their
- *   workgroups share the CUs); otherwise as the two launches. */
+ *   workgroups share the CUs); otherwise as the two launches.
+ *   wgrad at hidden >= 256 on n_nodes >= 65 536 (the LDS-tiled kernels): X / X2 16-byte aligned with ld % 4 == 0 and
+ *   `mask` 2-byte aligned, else GLASS_E_UNSUPPORTED. */
 int glass_dual_linear_bwd_f32(const float* dsrc, int64_t ldd, const float* T, int64_t ldt, const uint8_t* mask,
                               double z_ratio, int act, const float* WTimg, int64_t n_out, const float* addend,
                               int64_t ldadd, float p_drop, const uint64_t* rng_state, uint64_t call_id, float* out,
