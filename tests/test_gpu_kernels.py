@@ -632,10 +632,10 @@ def test_dual_linear_mix_fused(H, N, comb):
     assert torch.equal(out2, out.detach())
 
 
-@pytest.mark.parametrize("N", [71680, 70001, 65536 + 17])
+@pytest.mark.parametrize("N,H", [(71680, 256), (70001, 256), (65536 + 17, 256), (65536 + 40, 512)])
 @pytest.mark.parametrize("comb,act", [(False, 1), (False, 2), (False, 0), (True, 0)])
-def test_tiled_wgrad_eight_wave_kernel(N, comb, act):
-    """glass_dual_linear_wgrad_f32 at hidden 256 on a graph of >= 65 536 rows: the all-rows tiles run on the eight-wave kernel
+def test_tiled_wgrad_eight_wave_kernel(N, H, comb, act):
+    """glass_dual_linear_wgrad_f32 at hidden 256 / 512 on a graph of >= 65 536 rows: the all-rows tiles run on the eight-wave kernel
     (wgrad_tiled.hip: three stages of raw rows in flight, rows past a slab read as zero through the buffer resource, one
     16-bit load for a thread's two label bytes).  N = 71 680 gives 128 slabs — the XCD-aware placement; the other sizes a slab
     count that is not a multiple of 8 (plain placement) and a ragged last slab.  ELU / ReLU / no activation for the trans
@@ -643,7 +643,6 @@ def test_tiled_wgrad_eight_wave_kernel(N, comb, act):
     kernel); vs the fp64 sums, twice (bitwise repeat: no atomics, fixed slab order)."""
     from glass_amd import ops, _lib
     lib = _lib.load()
-    H = 256
     gen = torch.Generator().manual_seed(N + 7 * act + comb)
     zr = 0.8
     dsrc = torch.randn(N, H + 8, generator=gen)[:, 4:4 + H]  # strided views: ld = H + 8, 16-B aligned columns
@@ -666,7 +665,7 @@ def test_tiled_wgrad_eight_wave_kernel(N, comb, act):
     dgv = dg[:, 4:4 + H]
     X2g = X2.to(DEV) if comb else None
     I = 2 * H if comb else H
-    ws = ops._wgrad_workspace(torch.device(DEV), N, 2 * H, I, slot=("t8", N, comb, act))
+    ws = ops._wgrad_workspace(torch.device(DEV), N, 2 * H, I, slot=("t8", N, H, comb, act))
     got = []
     for _ in range(2):
         dW = torch.full((2 * H, I), float("nan"), device=DEV)
@@ -680,7 +679,7 @@ def test_tiled_wgrad_eight_wave_kernel(N, comb, act):
         got.append((dW.cpu(), db.cpu()))
     assert rel_inf(got[0][0], dW_ref) < TOL and rel_inf(got[0][1], db_ref) < TOL
     assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
-    record_parity(f"kernel/tiled_wgrad8_H256_N{N}_{'comb' if comb else 'trans'}_act{act}", dW_rel_inf=rel_inf(got[0][0], dW_ref),
+    record_parity(f"kernel/tiled_wgrad8_H{H}_N{N}_{'comb' if comb else 'trans'}_act{act}", dW_rel_inf=rel_inf(got[0][0], dW_ref),
                   db_rel_inf=rel_inf(got[0][1], db_ref))
     if N == 70001 and not comb and act == 1:  # a label mask at an odd address is refused, not misread (one 16-bit load per row pair)
         odd = torch.zeros(N + 1, dtype=torch.uint8, device=DEV)[1:]
