@@ -41,6 +41,18 @@ _RUNTIME_ATTRS = ("_glass_grad_bucket", "_glass_arena", "_glass_stack_prog", "_s
                   "_chan_cache", "_glass_train_steps", "_glass_eval_graphs", "_glass_adopted_adam")
 
 
+def drop_captured_graphs(model):
+    """Forget every hipGraph cached on `model` (train.py: `_glass_train_steps`, `_glass_eval_graphs`).  A captured graph holds the
+    parameters' device ADDRESSES: whenever a parameter's storage moves — an arena built around an existing model, a
+    re-allocated .data copied back by reattach() — a cached graph would keep replaying on the old, freed storage (an
+    evaluation before the first training epoch is the common case: test() caches its graph on the per-parameter storage,
+    the first train() then adopts the optimizer and builds the arena).  The next call captures afresh."""
+    for name in ("_glass_train_steps", "_glass_eval_graphs"):
+        c = model.__dict__.get(name)
+        if c:
+            c.clear()
+
+
 def strip_runtime(model):
     """Make `model` a plain module again: every parameter gets storage of its own (a copy of its current values), gradients
     are dropped, and every runtime attachment — arena, stacked weight views and operand images, step / evaluation graphs, the
@@ -140,6 +152,7 @@ class ParamArena(FlatGradBucket):
         self.flat_param = torch.zeros(total, dtype=dtype, device=dev)
         self.flat = torch.zeros(total, dtype=dtype, device=dev)  # gradients (FlatGradBucket API)
         self._offsets = offsets
+        drop_captured_graphs(model)  # every parameter's storage moves below
         with torch.no_grad():
             for p in params:
                 o = offsets[id(p)]
@@ -279,6 +292,8 @@ class ParamArena(FlatGradBucket):
         — it is rewritten before it is read."""
         base_p = self.flat_param.untyped_storage().data_ptr()
         base_g = self.flat.untyped_storage().data_ptr()
+        if any(p.data.untyped_storage().data_ptr() != base_p for p in self.params):
+            drop_captured_graphs(self.model)  # (a moved .data: cached graphs hold the old addresses)
         with torch.no_grad():
             for p in self.params:
                 o = self._offsets[id(p)]

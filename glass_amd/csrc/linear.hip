@@ -625,6 +625,16 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
             return GLASS_E_UNSUPPORTED;
         }
         const TiledWgradGeom t = wgrad_tiled_geom(N, O, I);
+        {  // 32-bit buffer offsets: a slab plus the whole triples of steps read past it must stay below 2^31 bytes on every operand
+            int64_t ldmax = ldd > ldx ? ldd : ldx;
+            if (act != GLASS_ACT_NONE && ldt > ldmax) ldmax = ldt;
+            if (X2 && ldx2 > ldmax) ldmax = ldx2;
+            if (((int64_t)t.rows_per_slab + 6 * 16) * ldmax * 4 >= (int64_t)1 << 31) {
+                set_error("dual_linear_wgrad: leading dimension %lld too wide for the tiled kernel's 32-bit slab offsets",
+                          (long long)ldmax);
+                return GLASS_E_UNSUPPORTED;
+            }
+        }
         float* pw = (float*)ws;
         launch_tiled_wgrad_partial(X, ldx, N, O, I, sy, pw, (db || !dW) ? pw + t.part_w_floats : nullptr, st);
         if (dW) launch_tiled_wgrad_reduce(pw, pw + t.part_w_floats, N, O, I, dW, lddw, db, accumulate, st);

@@ -399,6 +399,16 @@ __global__ __launch_bounds__(kW8Threads, 1) void tiled_wgrad8_kernel(const float
         for (int b = 0; b < 4; ++b) off[b] = (int)(((4 * gq + b) * xld + xcol) * 4);
     }
     const int off_m = 2 * g2;
+    // A slab with an ODD row count (the last slab of an odd N): its final pair (rows - 1, rows) straddles the end of r_m, and
+    // a raw-buffer access that is only partly in range returns 0 for the whole 16 bits — the last real row's label byte is
+    // therefore read once up front (wave-uniform) and put back at the one step where this lane holds that pair.
+    unsigned last_lbl = 0;
+    int strad_step = -1;
+    if (!EFF && is_a && (rows & 1)) {
+        last_lbl = sy.mask[r1 - 1];
+        const int d = (int)(rows - 1) - off_m;
+        if (d >= 0 && d % kWK == 0) strad_step = d / kWK;
+    }
     const float e_neg = sy.act == GLASS_ACT_RELU ? 0.f : 1.f;  // act'(t) = t > 0 ? 1 : e_neg * exp(t); none: t reads 0, factor 1
     float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
@@ -409,16 +419,17 @@ __global__ __launch_bounds__(kW8Threads, 1) void tiled_wgrad8_kernel(const float
         S.v[3] = buf_load4(rs23, off[3] + step * step23);
         S.mk2 = __builtin_amdgcn_raw_buffer_load_b16(r_m, off_m + step * kWK, 0, 0);
     };
-    auto commit = [&](W8Set& S, float* stage) __attribute__((always_inline)) {
+    auto commit = [&](W8Set& S, float* stage, int cstep) __attribute__((always_inline)) {
         S.pin();
         if (is_a) {  // wave-uniform
             float4 gv[2];
+            const unsigned mk = (unsigned)S.mk2 | (cstep == strad_step ? last_lbl : 0u);
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
                 float4 g = S.v[a];
                 if (!EFF) {
                     const float4 t = S.v[2 + a];
-                    const float cf = ((((unsigned)S.mk2 >> (8 * a)) & 0xffu) != 0) == a_first ? sy.zr : sy.omz;
+                    const float cf = (((mk >> (8 * a)) & 0xffu) != 0) == a_first ? sy.zr : sy.omz;
                     g.x *= cf; g.y *= cf; g.z *= cf; g.w *= cf;
                     g.x *= t.x > 0.f ? 1.f : e_neg * __expf(t.x);
                     g.y *= t.y > 0.f ? 1.f : e_neg * __expf(t.y);
@@ -480,7 +491,7 @@ __global__ __launch_bounds__(kW8Threads, 1) void tiled_wgrad8_kernel(const float
     auto step_fn = [&](int step, W8Set& nxt_regs) __attribute__((always_inline)) {
         stage_mma(wsm + (step & 1) * kWStageS);
         __builtin_amdgcn_sched_barrier(0);  // (nothing of a later step moves up across these)
-        commit(nxt_regs, wsm + ((step + 1) & 1) * kWStageS);
+        commit(nxt_regs, wsm + ((step + 1) & 1) * kWStageS, step + 1);
         __builtin_amdgcn_sched_barrier(0);
         issue(nxt_regs, step + 4);
         lds_barrier();
@@ -489,7 +500,7 @@ __global__ __launch_bounds__(kW8Threads, 1) void tiled_wgrad8_kernel(const float
     issue(s0, 0);
     issue(s1, 1);
     issue(s2, 2);
-    commit(s0, wsm);
+    commit(s0, wsm, 0);
     issue(s0, 3);
     lds_barrier();
     for (int step = 0; step < n_steps; step += 3) {  // whole triples: steps past the slab read zeros and add zeros

@@ -183,7 +183,8 @@ def adoptable(optimizer, model):
     if len(optimizer.param_groups) != 1:
         return "more than one parameter group"
     g = optimizer.param_groups[0]
-    for key in ("amsgrad", "maximize", "capturable", "differentiable"):
+    # fused=True: its eager step() wants state['step'] on the parameter's device; import_state installs a CPU scalar
+    for key in ("amsgrad", "maximize", "capturable", "differentiable", "fused"):
         if g.get(key, False):
             return f"{key}=True"
     if isinstance(g["lr"], torch.Tensor):

@@ -95,14 +95,14 @@ def build_glass(*args, **kwargs):
 
 
 def record_parity(config, **metrics):
-    """Append one parity record (achieved rel-inf numbers, not just pass/fail) to gpurun_out/parity_r05.json under the
-    repo root — gpurun merges that directory back, and the file is then committed as profiles/parity_r05.json."""
+    """Append one parity record (achieved rel-inf numbers, not just pass/fail) to gpurun_out/parity_r06.json under the
+    repo root — gpurun merges that directory back, and the file is then committed as profiles/parity_r06.json."""
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_dir = os.path.join(root, "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
-        path = os.path.join(out_dir, "parity_r05.json")
+        path = os.path.join(out_dir, "parity_r06.json")
         data = json.load(open(path)) if os.path.exists(path) else {}
         data[config] = {k: (v if isinstance(v, (bool, str)) else float(v)) for k, v in metrics.items()}
         with open(path, "w") as f:

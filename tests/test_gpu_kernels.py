@@ -650,6 +650,8 @@ def test_tiled_wgrad_eight_wave_kernel(N, H, comb, act):
     X = torch.randn(N, H, generator=gen)
     X2 = torch.randn(N, H, generator=gen) if comb else None
     mask = torch.rand(N, generator=gen) < 0.01
+    mask[-1] = True   # odd N: the last slab's final row pair (N - 1, N) straddles the label resource's end — the last real
+    mask[-4] = True   # row's byte must not read as 0 (a partly out-of-range 16-bit buffer load returns 0 for both bytes)
     # fp64: G[n, o] = coef(mask[n], o < H) * dsrc[n, o mod H] * act'(T[n, o]);  dW = G^T [X | X2],  db = column sums of G
     c1 = torch.where(mask, zr, 1 - zr).double().reshape(-1, 1)
     G = torch.cat((c1 * dsrc.double(), (1 - c1) * dsrc.double()), 1)

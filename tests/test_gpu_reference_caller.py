@@ -305,3 +305,121 @@ def test_deepcopy_after_training_gives_an_independent_plain_model():
     # and the original keeps training on its own graph
     torch.manual_seed(3)
     assert np.isfinite(train.train(opt, gnn, reference_loader(ds, 8), reference_binary_loss))
+
+
+def _nodeid_task(n, seed=0, n_sub=24, smax=7, n_class=3):
+    """A `--use_nodeid` data set as /root/reference/datasets.py:58-61 makes it: x = arange(N) (V = N), unit edge weights."""
+    gen = torch.Generator().manual_seed(seed)
+    pairs = torch.randint(0, n, (2, 6 * n), generator=gen)
+    pairs = pairs[:, pairs[0] != pairs[1]]
+    ei = torch.unique(torch.cat([pairs, pairs.flip(0)], dim=1), dim=1)
+    ew = torch.ones(ei.shape[1])
+    x = torch.arange(n, dtype=torch.int64).reshape(n, 1, -1)
+    pos = torch.stack([torch.randperm(n, generator=gen)[:smax] for _ in range(n_sub)])
+    pos[::4, -2:] = -1
+    pos[1, 0] = pos[0, 0]                    # a node shared by two subgraphs of one batch
+    pos[:, 1] = n - 1 - torch.arange(n_sub)  # the last table rows are named too
+    y = torch.randint(0, n_class, (n_sub,), generator=gen)
+    return x, ei, ew, pos, y
+
+
+@pytest.mark.parametrize("n", [5000, 9000])
+def test_reference_caller_use_nodeid_from_pretrained(n):
+    """The README recipe for the real-world sets (/root/reference/GLASSTest.py:152-157): `buildModel` re-assigns
+    `conv.input_emb = nn.Embedding.from_pretrained(emb, freeze=False)` — an [N, hidden] table, V = N — on a graph whose
+    features are the node ids.  Through impl.train.train with the reference's own objects: the caller lands on the captured
+    step program (adoption builds the arena with the table in the big bucket: 5 000 x 64 floats >= 1 MB; 5 000 rows run the
+    lookup + emb_gn through the table kernels, 9 000 rows — beyond 8 192 — the [N, H] kernels), three one-batch epochs
+    equal an eager twin, the first step's gradients equal the fp64 oracle's on the flat vector INCLUDING the table's rows,
+    and optimizer.state_dict() carries the table's moments."""
+    from impl import SubGDataset, train, utils
+    from glass_amd import stack
+    from oracle import glass_oracle as O
+    H, L, n_class, bs = 64, 2, 3, 8
+    x, ei, ew, pos, y = _nodeid_task(n, seed=n)
+    torch.manual_seed(n)
+    emb = torch.randn(n, H)                  # (stands for ./Emb/<dataset>_64.pt, the pre-training path's output)
+    gnn = reference_build_model(H, L, 0.0, True, "sum", 0.9, "mean", torch.max(x), n_class)
+    gnn.conv.input_emb = nn.Embedding.from_pretrained(emb.clone(), freeze=False)   # GLASSTest.py:157
+    from impl import config
+    gnn = gnn.to(config.device)
+    assert gnn.conv.input_emb.weight.requires_grad and tuple(gnn.conv.input_emb.weight.shape) == (n, H)
+    sd0 = {k: v.detach().cpu().clone() for k, v in gnn.state_dict().items()}
+    twin = copy.deepcopy(gnn)
+    xg, eig, ewg, posg, yg = (t.to(DEV) for t in (x, ei, ew, pos, y))
+    optimizer = Adam(gnn.parameters(), lr=1e-3)
+    opt_twin = Adam(twin.parameters(), lr=1e-3)
+    loss_fn = CrossEntropyLoss()
+    table_param = gnn.conv.input_emb.weight
+    got, want = [], []
+    for k in range(3):
+        ds = SubGDataset.GDataset(xg, eig, ewg, posg[bs * k:bs * k + bs], yg[bs * k:bs * k + bs])
+        got.append(train.train(optimizer, gnn, reference_loader(ds, bs, shuffle=False), loss_fn))
+        if k == 0:  # the gradient buffers still hold step 0's gradients (they are rewritten, not accumulated, by the next step)
+            grads0 = {kk: p.grad.detach().cpu().clone() for kk, p in gnn.named_parameters()}
+        want.append(_eager_epoch(twin, opt_twin, reference_loader(ds, bs, shuffle=False), loss_fn))
+    step = _taken_step(gnn)
+    assert step.graphed and step._program_step() and stack.step_supported(gnn, loss_fn), "not the captured step program"
+    assert gnn.conv.input_emb.weight is table_param, "the table's Parameter identity must survive the adoption"
+    arena = gnn.__dict__["_glass_grad_bucket"]
+    assert arena.big_start < arena.flat.numel() and any(p is table_param for p in arena.params), "table not in the big bucket"
+    assert np.allclose(got, want, rtol=2e-5, atol=0), (got, want)
+    pa = torch.cat([p.detach().reshape(-1) for p in gnn.parameters()]).cpu()
+    pb = torch.cat([p.detach().reshape(-1) for p in twin.parameters()]).cpu()
+    assert rel_inf(pa, pb) < 1e-4
+    # step 0 against the fp64 oracle: loss and the flat gradient vector, table included
+    orc = O.OracleGLASS(H, L, n - 1, n_class, aggr="mean", pool="sum", z_ratio=0.9).double()
+    orc.load_state_dict({k: v.double() for k, v in sd0.items()})
+    orc.train()
+    p0 = pos[:bs]
+    lo = nn.CrossEntropyLoss()(orc(x, ei, ew.double(), p0, O.max_zero_one(x, p0)), y[:bs])
+    lo.backward()
+    assert abs(got[0] - lo.item()) <= 1e-5 * abs(lo.item()), (got[0], lo.item())
+    keys = sorted(k for k, _ in orc.named_parameters())
+    assert "conv.input_emb.weight" in keys
+    ref = {k: p.grad for k, p in orc.named_parameters()}
+    e_all = rel_inf(flat_grads(grads0, keys), flat_grads(ref, keys))
+    e_tab = rel_inf(grads0["conv.input_emb.weight"], ref["conv.input_emb.weight"])
+    from helpers import record_parity
+    record_parity(f"reference_caller/use_nodeid_N{n}", loss_rel=abs(got[0] - lo.item()) / abs(lo.item()), grad_rel_inf=e_all,
+                  table_grad_rel_inf=e_tab)
+    assert e_all < 1e-5 and e_tab < 1e-5, (e_all, e_tab)
+    # the torch optimizer tells the truth about the table's state
+    sd = optimizer.state_dict()
+    idx = [i for i, p in enumerate(optimizer.param_groups[0]["params"]) if p is table_param][0]
+    st = sd["state"][sd["param_groups"][0]["params"][idx]]
+    assert float(st["step"]) == 3.0 and tuple(st["exp_avg"].shape) == (n, H)
+    tw = opt_twin.state_dict()["state"][opt_twin.state_dict()["param_groups"][0]["params"][idx]]
+    assert rel_inf(st["exp_avg"].cpu(), tw["exp_avg"].cpu()) < 1e-4 and rel_inf(st["exp_avg_sq"].cpu(), tw["exp_avg_sq"].cpu()) < 1e-4
+    assert int((st["exp_avg"].abs().sum(1) > 0).sum()) > 100, "the table's first moment is empty"
+
+
+def test_evaluation_before_the_first_training_epoch_is_not_replayed_on_stale_parameters():
+    """test() -> train() -> test() (an epoch-0 baseline, or a resumed checkpoint evaluated first): the first test() caches its
+    evaluation hipGraph on the model's per-parameter storage; the first train() adopts the optimizer and moves every
+    parameter into the flat arena.  The cached graph holds the OLD addresses — it must be dropped (arena.drop_captured_graphs),
+    not replayed: the second test() equals eager forwards of the trained model."""
+    from impl import SubGDataset, train, metrics, utils
+    x, ei, ew, pos, y = _binary_task(seed=8, n_sub=32)
+    torch.manual_seed(4)
+    gnn = reference_build_model(64, 2, 0.0, True, "sum", 0.9, "mean", torch.max(x), 1)
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    opt = Adam(gnn.parameters(), lr=2e-2)
+
+    def eager_score():
+        gnn.eval()
+        with torch.no_grad():
+            pred = torch.cat([gnn(x, ei, ew, pos[i:i + 8], utils.MaxZOZ(x, pos[i:i + 8])) for i in range(0, pos.shape[0], 8)])
+        return pred
+
+    s0, l0 = train.test(gnn, reference_loader(ds, 8, shuffle=False, drop_last=False), metrics.binaryf1, reference_binary_loss)
+    assert gnn.__dict__.get("_glass_eval_graphs"), "the evaluation did not run from a cached graph: the case is not exercised"
+    assert abs(float(l0) - float(reference_binary_loss(eager_score(), y))) < 1e-6
+    for epoch in range(3):
+        torch.manual_seed(30 + epoch)
+        train.train(opt, gnn, reference_loader(ds, 8), reference_binary_loss)
+    assert _taken_step(gnn)._program_step()
+    s1, l1 = train.test(gnn, reference_loader(ds, 8, shuffle=False, drop_last=False), metrics.binaryf1, reference_binary_loss)
+    want = float(reference_binary_loss(eager_score(), y))
+    assert abs(float(l1) - want) < 1e-6 * max(1.0, abs(want)), (float(l1), want, float(l0))
+    assert abs(float(l1) - float(l0)) > 1e-3, "training did not move the loss: the check above proves nothing"

@@ -30,6 +30,8 @@ config.set_device(0)
 N_CASES = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 2025
 rng = np.random.default_rng(SEED)
+rng_id = np.random.default_rng(SEED + 77)  # (its own stream: the configurations of earlier rounds stay what they were)
+n_nodeid = 0
 worst_loss, worst_par, n_prog = 0.0, 0.0, 0
 for it in range(N_CASES):
     H = int(rng.choice([8, 17, 20, 64, 64, 128, 48]))
@@ -45,8 +47,15 @@ for it in range(N_CASES):
     V = int(rng.integers(3, 30))
     zr = float(rng.uniform(0.5, 1.0))
     lr = float(10 ** rng.uniform(-3.3, -2.0))
+    # --use_nodeid (GLASSTest.py:152-157, datasets.py:58-61): x = arange(N) and an [N, hidden] table put in place of input_emb by
+    # nn.Embedding.from_pretrained(emb, freeze=False); at hidden 64 / 128 large enough for the arena's big bucket (>= 1 MB)
+    nodeid = bool(rng_id.random() < 0.3) or it == 1
+    if nodeid and H in (64, 128):
+        n = max(n, (1 << 18) // H + int(rng_id.integers(1, 400)))
     ei, ew = synth.make_graph(n, min(int(rng.integers(n, 5 * n)), n * (n - 1) // 4), it, float(rng.choice([0.0, 0.7])))
     x = torch.from_numpy(rng.integers(0, V, n)).reshape(n, 1, 1)
+    if nodeid:
+        x = torch.arange(n, dtype=torch.int64).reshape(n, 1, 1)
     pos = rng.integers(0, n, (n_sub, S))
     pos[rng.random((n_sub, S)) < 0.25] = -1
     pos[:, 0] = rng.integers(0, n, n_sub)
@@ -56,6 +65,10 @@ for it in range(N_CASES):
     loss_fn = CrossEntropyLoss() if kind == "ce" else reference_binary_loss
     torch.manual_seed(it)
     gnn = reference_build_model(H, L, 0.0, True, pool, zr, aggr, torch.max(xg), K)
+    if nodeid:
+        gnn.conv.input_emb = torch.nn.Embedding.from_pretrained(torch.randn(n, H), freeze=False)
+        gnn = gnn.to(config.device)
+        n_nodeid += 1
     twin = copy.deepcopy(gnn)
     ds = SubGDataset.GDataset(xg, eig, ewg, posg, yg)
     opt, opt_twin = Adam(gnn.parameters(), lr=lr), Adam(twin.parameters(), lr=lr)
@@ -83,11 +96,12 @@ for it in range(N_CASES):
     expect_program = H in (8, 17, 20, 64, 128) and pool != "max"
     ok = ok and (program == expect_program)
     worst_loss, worst_par = max(worst_loss, e_loss), max(worst_par, e_par)
-    print(f"{it:2d} H={H:3d} L={L} {aggr:4s} {pool:4s} {kind:10s} K={K} n={n} subs={n_sub}x{S} bs={bs} lr={lr:.1e}: loss {e_loss:.1e} params "
+    print(f"{it:2d} H={H:3d} L={L} {aggr:4s} {pool:4s} {kind:10s} K={K} n={n} subs={n_sub}x{S} bs={bs} lr={lr:.1e}{' nodeid' if nodeid else ''}: loss {e_loss:.1e} params "
           f"{e_par:.1e} steps {sorted(counts)} program={program}{'' if ok else '  <-- FAIL'}", flush=True)
     if not ok:
         sys.exit(1)
-print(f"worst: epoch loss {worst_loss:.2e}, parameters {worst_par:.2e}; {n_prog} of {N_CASES} cases on the captured step program")
+print(f"worst: epoch loss {worst_loss:.2e}, parameters {worst_par:.2e}; {n_prog} of {N_CASES} cases on the captured step program, "
+      f"{n_nodeid} with a from_pretrained node-id table")
 record_parity(f"fuzz/reference_caller_{N_CASES}_random_configs_seed{SEED}", cases=N_CASES, worst_epoch_loss_rel=worst_loss,
-              worst_param_rel_inf=worst_par, on_step_program=n_prog,
+              worst_param_rel_inf=worst_par, on_step_program=n_prog, nodeid_cases=n_nodeid,
               note="tools/fuzz_reference_caller.py: GLASSTest.py's own objects through impl.train.train vs an eager per-op twin, two epochs")
