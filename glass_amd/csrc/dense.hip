@@ -1067,7 +1067,9 @@ __device__ __forceinline__ bool eff_rows(EffRows& R, int block, const uint8_t* _
 // 32 rows, wave group g multiplies rows 16g .. 16g + 15 of it with the same 16 weight columns) — per stage a SIMD then
 // holds two independent instruction streams, so one wave's LDS-read latency, store issue and barrier wait sit under the
 // other's 32 MFMAs, and the workgroup passes half as many barriers (3 stages instead of 5 for an 80-row tile).
-template <int H, bool DROP, int NST, int WG = 1>
+// SP: the products in the split form (split_mma.h, see comb_fwd_eff3_kernel): rows cut once by the staging thread into three bf16
+// planes, the weight slice cut once per wave; 24 MFMAs of 16 cycles per 16-row stage at hidden 64 instead of 32 of 32.
+template <int H, bool DROP, int NST, int WG = 1, bool SP = false>
 __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* __restrict__ xa, int64_t lda,
                                                                const float* __restrict__ xb, int64_t ldb,
                                                                const float* __restrict__ Wimg, const float* __restrict__ bias,
@@ -1080,7 +1082,11 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     constexpr int THREADS = 4 * H * WG, NTL = H / 16, KF4 = (2 * H) / 16;  // threads, 16-column tiles, float4 per lane of a weight slice
     constexpr int KT = 2 * H, RS = KT + 4;  // LDS row stride (floats): + 4 keeps the 16 rows of a b128 read off one bank group
     constexpr int SR = 16 * WG, NSTG = (NST + WG - 1) / WG;  // rows per stage, stages per workgroup
-    __shared__ __attribute__((aligned(16))) float tile[2][SR * RS];
+    static_assert(!SP || WG == 1, "split form: one wave group");
+    constexpr int RSB = KT + 8;        // SP: bf16 elements per row of a piece plane (16-B aligned, rows 4 banks apart)
+    constexpr int kPlane = SR * RSB;   // bf16 elements per piece plane
+    __shared__ __attribute__((aligned(16))) float tile[SP ? 1 : 2][SP ? 4 : SR * RS];
+    __shared__ __attribute__((aligned(16))) unsigned short tile_s[SP ? 2 : 1][SP ? 3 * kPlane : 8];  // [buffer][piece][row][k]
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
     constexpr int ROWS = 16 * NST;
     __shared__ int rows_s[ROWS];  // row of each of the workgroup's slots: -1 none; bit 30 set: computed but not stored / counted
@@ -1176,6 +1182,17 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     const float be = c1 * bias1p + c0 * bias0p;
     if (fold_here) gn_fwd_coef_finish<H, 4 * H>(pro.src, pro.saved, N, CR, gn_coef_s);
     if (tid < ROWS) rows_s[tid] = (!extra && slot_mask != 0) ? (slot_v | (1 << 30)) : slot_v;  // labeled row of a main tile: an extra workgroup stores it
+    // SP: the wave's weight slice as bf16 pieces, block b = the lane's k = (KT / 4) q + 8 b .. + 7 (bw[2b], bw[2b + 1])
+    uint4 bwc[SP ? KF4 / 2 : 1][3];
+    if constexpr (SP) {
+#pragma unroll
+        for (int b = 0; b < KF4 / 2; ++b) {
+            const Split4 s0 = split4(bw[2 * b]), s1 = split4(bw[2 * b + 1]);
+            bwc[b][0] = make_uint4(s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y);
+            bwc[b][1] = make_uint4(s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y);
+            bwc[b][2] = make_uint4(s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y);
+        }
+    }
     D_STAMP(1, 1);
     lds_barrier();  // coefficients + row table
     const bool pro_on = pro.saved != nullptr;
@@ -1201,11 +1218,22 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
         return make_float4(a[0], a[1], a[2], a[3]);
     };
     auto commit = [&](int st, const float4& v, const float4& hraw) __attribute__((always_inline)) {
-        float* T = tile[st & 1];
+        float* T = tile[SP ? 0 : (st & 1)];
         const int r = my_row[st];
         buf_store4(r_side, (pro_on && side_on && r >= 0) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
-        *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
-        *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = hraw;
+        if constexpr (SP) {
+            const Split4 sa = split4(v), sh4 = split4(hraw);
+            unsigned short* P = tile_s[st & 1] + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = sa.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = sa.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = sa.lo;
+            *reinterpret_cast<uint2*>(P + H) = sh4.hi;
+            *reinterpret_cast<uint2*>(P + kPlane + H) = sh4.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane + H) = sh4.lo;
+        } else {
+            *reinterpret_cast<float4*>(T + rs * RS + 4 * ga) = v;
+            *reinterpret_cast<float4*>(T + rs * RS + H + 4 * ga) = hraw;
+        }
     };
     float ssum = 0.f, ssq = 0.f;  // this lane's column 16w + j over the rows 4q + r of every stage
     commit(0, prep(0, rawA[0]), rawA[1]);
@@ -1215,17 +1243,40 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
     for (int st = 0; st < NSTG; ++st) {
         if (st == 1) D_STAMP(1, 5);
         const bool live_grp = SR * st + 16 * g < ROWS;  // (wave-uniform: the last stage of an odd NST has one row group only)
-        const float* T = tile[st & 1] + (16 * g + j) * RS + (KT / 4) * q;
-        float4 a4[KF4];
+        const float* T = tile[SP ? 0 : (st & 1)] + (16 * g + j) * RS + (KT / 4) * q;
+        float4 a4[SP ? 1 : KF4];
+        uint4 af[SP ? KF4 / 2 : 1][3];
+        if constexpr (SP) {
+            // lane (j, q): row j of the stage, k = (KT / 4) q + 8 b .. + 7 of block b: one 16-byte read per piece
+            const unsigned short* P = tile_s[st & 1] + (16 * g + j) * RSB + (KT / 4) * q;
 #pragma unroll
-        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
+            for (int b = 0; b < KF4 / 2; ++b)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) af[b][pc] = *reinterpret_cast<const uint4*>(P + pc * kPlane + 8 * b);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(T + 4 * tt);
+        }
         int rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = live_grp ? rows_s[(SR * st + 16 * g + 4 * q + r) < ROWS ? SR * st + 16 * g + 4 * q + r : 0] : -1;
         float4 vn = make_float4(0.f, 0.f, 0.f, 0.f);
         if (st + 1 < NSTG) vn = prep(st + 1, (st & 1) ? rawA[0] : rawB[0]);  // the NEXT stage's rows (even stages come in rawA)
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains hide the dependent-MFMA latency
-        if (WG == 1 || live_grp) {
+        if constexpr (SP) {
+#define GLASS_SMMA16(ACC, B, pa, pb)                                                                                  \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[B][pa]), __builtin_bit_cast(bf16x8, bwc[B][pb]), ACC, 0, 0, 0)
+#pragma unroll
+            for (int b = 0; b < KF4 / 2; b += 2) {  // two K blocks side by side (two chains), small terms first
+                GLASS_SMMA16(acc0, b, 1, 1); GLASS_SMMA16(acc1, b + 1, 1, 1);
+                GLASS_SMMA16(acc0, b, 2, 0); GLASS_SMMA16(acc1, b + 1, 2, 0);
+                GLASS_SMMA16(acc0, b, 0, 2); GLASS_SMMA16(acc1, b + 1, 0, 2);
+                GLASS_SMMA16(acc0, b, 1, 0); GLASS_SMMA16(acc1, b + 1, 1, 0);
+                GLASS_SMMA16(acc0, b, 0, 1); GLASS_SMMA16(acc1, b + 1, 0, 1);
+                GLASS_SMMA16(acc0, b, 0, 0); GLASS_SMMA16(acc1, b + 1, 0, 0);
+            }
+#undef GLASS_SMMA16
+        } else if (WG == 1 || live_grp) {
 #pragma unroll
             for (int tt = 0; tt < KF4; tt += 2) {
                 const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
@@ -1258,9 +1309,9 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff2_kernel(const float* 
         // one MFMA, then a few of the next stage's VALU instructions, 32 times
         if (WG == 1) {
 #pragma unroll
-            for (int i = 0; i < 32; ++i) {
+            for (int i = 0; i < (SP ? 6 * (KF4 / 2) : 32); ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, GLASS_STAGE_INTERLEAVE, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SP ? GLASS_STAGE_INTERLEAVE + 2 : GLASS_STAGE_INTERLEAVE, 0);
             }
         }
 #endif
@@ -1328,7 +1379,7 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* 
     constexpr int THREADS = 4 * H * WG, NTL = H / 16, KF4 = (2 * H) / 16;
     constexpr int KT = 2 * H, RS = KT + 4;
     constexpr int SR = 16 * WG;
-    static_assert(!SP || (H == 128 && WG == 1), "split form: hidden 128");
+    static_assert(!SP || WG == 1, "split form: one wave group");
     constexpr int RSB = KT + 8;        // SP: bf16 elements per row of a piece plane (528 B: 16-B aligned, rows 4 banks apart)
     constexpr int kPlane = SR * RSB;   // bf16 elements per piece plane
     __shared__ __attribute__((aligned(16))) float tile[SP ? 1 : 2][SP ? 4 : SR * RS];
@@ -1546,7 +1597,10 @@ __global__ __launch_bounds__(4 * H * WG) void comb_fwd_eff3_kernel(const float* 
 // A wave owns columns 16w .. 16w+15 of BOTH halves (the label mix needs f1 and f0 of a column in one lane): 2 x 4 float4 of
 // weights per lane (K = 64), 32 MFMAs per 16-row stage; one float4 of the operand per thread and stage.  Image: layout
 // kLayoutWave16Cols.  xa_index: the stage's rows are gathered from the embedding table (layer 0).
-template <int H, int NST, int WG = 1>
+// SP: the products in the split form of the tiled family (split_mma.h; see comb_fwd_eff3_kernel): the staging thread cuts its
+// float4 once into three bf16 pieces (planes [piece][row][k], rows 72 bf16 apart: a fragment read of 16 lanes covers all 64
+// banks once), a wave cuts its two weight slices once; 24 MFMAs of 16 cycles per 16-row stage instead of 32 of 32.
+template <int H, int NST, int WG = 1, bool SP = false>
 __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __restrict__ xa, int64_t lda, int64_t xa_rows,
                                                             const float* __restrict__ Wimg, const float* __restrict__ bias,
                                                             const uint8_t* __restrict__ mask, float zr, float omz, int act,
@@ -1557,7 +1611,10 @@ __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __
     static_assert(WG == 1 || WG == 2, "one or two waves per SIMD (comb_fwd_eff2_kernel)");
     constexpr int RS = H + 4;  // LDS row stride (floats)
     constexpr int SR = 16 * WG, NSTG = (NST + WG - 1) / WG;  // rows per stage, stages per workgroup
-    __shared__ __attribute__((aligned(16))) float tile[2][SR * RS];
+    constexpr int RSB = H + 8;         // SP: bf16 elements per row of a piece plane (144 B)
+    constexpr int kPlane = SR * RSB;   // bf16 elements per piece plane
+    __shared__ __attribute__((aligned(16))) float tile[SP ? 1 : 2][SP ? 4 : SR * RS];
+    __shared__ __attribute__((aligned(16))) unsigned short tile_s[SP ? 2 : 1][SP ? 3 * kPlane : 8];  // [buffer][piece][row][k]
     __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
     constexpr int ROWS = 16 * NST;
     __shared__ int rows_s[ROWS];  // row of each slot: -1 none; bit 30: labeled row (mix weights swapped)
@@ -1622,6 +1679,21 @@ __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __
     }
     if (fold_here) gn_fwd_coef_finish<H, kBlock>(pro.src, pro.saved, N, CR, gn_coef_s);
     if (tid < ROWS) rows_s[tid] = slot_mask != 0 ? (slot_v | (1 << 30)) : slot_v;
+    // SP: the wave's two weight slices as bf16 pieces, block b = the lane's k = 16 q + 8 b .. + 7 (bw[2b], bw[2b + 1])
+    uint4 bwc1[SP ? 2 : 1][3], bwc0[SP ? 2 : 1][3];
+    if constexpr (SP) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const Split4 s0 = split4(bw1[2 * b]), s1 = split4(bw1[2 * b + 1]);
+            bwc1[b][0] = make_uint4(s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y);
+            bwc1[b][1] = make_uint4(s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y);
+            bwc1[b][2] = make_uint4(s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y);
+            const Split4 u0 = split4(bw0[2 * b]), u1 = split4(bw0[2 * b + 1]);
+            bwc0[b][0] = make_uint4(u0.hi.x, u0.hi.y, u1.hi.x, u1.hi.y);
+            bwc0[b][1] = make_uint4(u0.mid.x, u0.mid.y, u1.mid.x, u1.mid.y);
+            bwc0[b][2] = make_uint4(u0.lo.x, u0.lo.y, u1.lo.x, u1.lo.y);
+        }
+    }
     D_STAMP(2, 1);
     lds_barrier();  // coefficients + row table
     const bool pro_on = pro.saved != nullptr;
@@ -1644,7 +1716,15 @@ __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __
         }
         const float4 v = make_float4(a[0], a[1], a[2], a[3]);
         buf_store4(r_side, (pl && pro.side) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
-        *reinterpret_cast<float4*>(tile[st & 1] + rs * RS + 4 * ga) = v;
+        if constexpr (SP) {
+            const Split4 sa = split4(v);
+            unsigned short* P = tile_s[st & 1] + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = sa.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = sa.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = sa.lo;
+        } else {
+            *reinterpret_cast<float4*>(tile[SP ? 0 : (st & 1)] + rs * RS + 4 * ga) = v;
+        }
     };
     float ssum = 0.f, ssq = 0.f;
     stage_store(0, rawA);
@@ -1653,15 +1733,37 @@ __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __
 #pragma unroll
     for (int st = 0; st < NSTG; ++st) {
         const bool live_grp = SR * st + 16 * g < ROWS;  // (wave-uniform: the last stage of an odd NST has one row group only)
-        const float* A = tile[st & 1] + (16 * g + j) * RS + 16 * q;
-        float4 a4[4];
-#pragma unroll
-        for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(A + 4 * v);
         int rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = live_grp ? rows_s[(SR * st + 16 * g + 4 * q + r) < ROWS ? SR * st + 16 * g + 4 * q + r : 0] : -1;
         f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
-        if (WG == 1 || live_grp) {
+        if constexpr (SP) {
+            if (WG == 1 || live_grp) {
+                // lane (j, q): row j of the row group, k = 16 q + 8 b .. + 7 of block b: one 16-byte read per piece
+                const unsigned short* P = tile_s[st & 1] + (16 * g + j) * RSB + 16 * q;
+                uint4 af[2][3];
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int pc = 0; pc < 3; ++pc) af[b][pc] = *reinterpret_cast<const uint4*>(P + pc * kPlane + 8 * b);
+#define GLASS_SMMA16(ACC, BW, pa, pb)                                                                                 \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[b][pa]), __builtin_bit_cast(bf16x8, BW[b][pb]), ACC, 0, 0, 0)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {  // small terms first; the two halves' chains interleave
+                    GLASS_SMMA16(acc1, bwc1, 1, 1); GLASS_SMMA16(acc0, bwc0, 1, 1);
+                    GLASS_SMMA16(acc1, bwc1, 2, 0); GLASS_SMMA16(acc0, bwc0, 2, 0);
+                    GLASS_SMMA16(acc1, bwc1, 0, 2); GLASS_SMMA16(acc0, bwc0, 0, 2);
+                    GLASS_SMMA16(acc1, bwc1, 1, 0); GLASS_SMMA16(acc0, bwc0, 1, 0);
+                    GLASS_SMMA16(acc1, bwc1, 0, 1); GLASS_SMMA16(acc0, bwc0, 0, 1);
+                    GLASS_SMMA16(acc1, bwc1, 0, 0); GLASS_SMMA16(acc0, bwc0, 0, 0);
+                }
+#undef GLASS_SMMA16
+            }
+        } else if (WG == 1 || live_grp) {
+            const float* A = tile[SP ? 0 : (st & 1)] + (16 * g + j) * RS + 16 * q;
+            float4 a4[4];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(A + 4 * v);
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
                 const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
@@ -2307,6 +2409,8 @@ static bool wave16_shape_ok(int64_t H) { return H == 64; }
 // (three 32-row stages instead of five 16-row ones); the comb forward does not move (12.1 vs 12.0: its stage is 17 KB of
 // LDS traffic for the same 32 MFMAs per wave, and eight waves fetch the weight slices twice) — so trans takes 2, comb 1.
 // GLASS_FWD_WG=1|2 forces both (laboratory A/B; read once per process).
+// hidden 64: the staged kernels' products in the split form of the tiled family (split_mma.h) — per call, like there
+static bool h64_split_products() { return tiled_split_products() && lab_knob("GLASS_H64_SPLIT", 1) != 0; }
 static int fwd_wave_groups(bool comb) {
     const int forced = lab_knob("GLASS_FWD_WG", 0);
     if (forced == 1 || forced == 2) return forced;
@@ -2489,6 +2593,14 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
             return launch_status("glass_dual_linear_fwd_f32");
         }
 #endif
+        if (h64_split_products()) {
+#define GLASS_TF2S(NS)                                                                                                      \
+    hipLaunchKernelGGL((trans_fwd2_kernel<64, NS, 2, true>), tall ? dim3((unsigned)wg80) : grid, dim3(kBlock * 2), 0, st, xa, lda,  \
+                       src_rows, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index)
+            if (tall) GLASS_TF2S(5); else GLASS_TF2S(4);
+#undef GLASS_TF2S
+            return launch_status("glass_dual_linear_fwd_f32");
+        }
         if (tall) GLASS_TF2(5, 2); else GLASS_TF2(4, 2);
 #undef GLASS_TF2
         return launch_status("glass_dual_linear_fwd_f32");
@@ -2830,6 +2942,15 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
         else GLASS_CF2P(false, 4);
 #undef GLASS_CF2P
 #endif
+    } else if (GLASS_COMB_FWD_V2 && h64_split_products()) {
+#define GLASS_CF2S(DR, NS)                                                                                                \
+    hipLaunchKernelGGL((comb_fwd_eff2_kernel<64, DR, NS, 1, true>), grid, dim3(256), 0, (hipStream_t)stream, xa, lda, xb, ldb,    \
+                       Wimg_eff, bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
+        if (dr && tall) GLASS_CF2S(true, 5);
+        else if (dr) GLASS_CF2S(true, 4);
+        else if (tall) GLASS_CF2S(false, 5);
+        else GLASS_CF2S(false, 4);
+#undef GLASS_CF2S
     } else if (GLASS_COMB_FWD_V2) {
         if (dr && tall) GLASS_CF2(64, true, 5);
         else if (dr) GLASS_CF2(64, true, 4);

@@ -691,7 +691,9 @@ def test_tiled_wgrad_eight_wave_kernel(N, H, comb, act):
         assert rc != 0 and b"2-byte" in lib.glass_last_error_string()
 
 
-@pytest.mark.parametrize("H,N,comb", [(128, 3001, False), (256, 4099, False), (256, 4099, True), (256, 70001, True)])
+@pytest.mark.parametrize("H,N,comb", [(128, 3001, False), (256, 4099, False), (256, 4099, True), (256, 70001, True),
+                                      # hidden 64 (round 6: the staged forward kernels take the split form too)
+                                      (64, 3001, False), (64, 17080, False), (64, 3001, True)])
 def test_both_product_forms_against_fp64(H, N, comb):
     """The LDS-tiled kernels (forward, data gradient, weight gradient) once per product form — the f32-input MFMA and the six
     bf16 partial products of 3-way split operands (split_mma.h) — against the same fp64 composition: the split form is as
@@ -1262,7 +1264,8 @@ def test_batch_labels(B, S, n):
 @pytest.mark.parametrize("N,pattern", [(17080, "batch"), (1000, "none"), (1000, "one"), (1000, "tile_full"), (77, "all"),
                                        (5000, "dense")])
 @pytest.mark.parametrize("p_drop", [0.0, 0.5])
-def test_comb_pair_effective_weight_hidden64(N, pattern, p_drop):
+@pytest.mark.parametrize("f32_products", [False, True])
+def test_comb_pair_effective_weight_hidden64(N, pattern, p_drop, f32_products, monkeypatch):
     """Comb pair at hidden 64 in effective-weight form (glass_comb_eff_fwd/bwd_f32: every row tile multiplies the
     unlabeled-row weight, the listed labeled rows are recomputed by extra workgroups) against fp64 — forward with the
     GraphNorm prologue (+ dropout, side output) and the output statistics, data gradient with the backward-GraphNorm column
@@ -1270,6 +1273,8 @@ def test_comb_pair_effective_weight_hidden64(N, pattern, p_drop):
     from glass_amd import stack, ops
     from glass_amd.arena import ParamArena
     from glass_amd.factory import build_glass
+    # the forward's product form (split bf16 pieces by default, the f32-input MFMA as the per-call option): both against fp64
+    monkeypatch.setattr(ops, "DENSE_F32_PRODUCTS", f32_products)
     torch.manual_seed(11)
     H, z = 64, 0.95
     model = build_glass(H, 1, 5, 3, "mean", "sum", z).to(DEV).train()
