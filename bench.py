@@ -96,6 +96,9 @@ def parse(argv=None):
                     help="eval: the evaluation loop's forward passes (impl/train.py:20-34) over the same batches — one batch per "
                          "step, K batches side by side as parallel branches of one hipGraph (glass_amd/evalstep.py)")
     ap.add_argument("--eval-parallel", type=int, default=8, help="--mode eval: batches per replay (the sequential form is timed too)")
+    ap.add_argument("--head-labels", type=int, default=1,
+                    help="1: the label launch of the step's batch rides in the graph's head launch (prologue || labels, "
+                         "glass_step_head_f32, batch named by a device-resident cursor); 0: eager label launch in front of every replay")
     ap.add_argument("--caller", default="step", choices=["step", "reference"],
                     help="step: bench.py drives glass_amd.step.TrainStep itself (flat arena + FlatAdam built here).  reference: "
                          "the step is reached the way /root/reference/GLASSTest.py reaches it — buildModel's constructions, "
@@ -741,8 +744,18 @@ def main():
                 rtrain.train(torch_opt, model, loader, loss_fn)
     else:
         stepper = TrainStep(model, opt, loss_fn, xg, eig, ewg, bucket, use_graph=bool(args.graph))
+        # the pre-selected batches as one "data set" + index batches: the step's head launch then labels its batch itself
+        # through a device-resident cursor that cycles over them (TrainStep.begin_epoch: prologue || labels as ONE launch,
+        # nothing in front of the replay) — what impl.train.train does per epoch with the loader's permutation
+        head = bool(args.graph) and args.head_labels and stepper.begin_epoch(
+            pos_g.reshape(-1, pos_g.shape[-1]), y_g.reshape(-1, *y_g.shape[2:]),
+            torch.arange(n_batches * w.batch, device=dev).reshape(n_batches, w.batch), wrap=True)
 
         def run(k, offset):
+            if head:
+                for _ in range(k):
+                    stepper.next_step()
+                return
             for i in range(k):
                 b = (offset + i) % n_batches
                 stepper(pos_g[b], y_g[b])
@@ -1010,6 +1023,7 @@ def main():
                                   "ZGDataloader shuffle+drop_last) through impl.train.train — one epoch (incl. its host sync, the "
                                   "shuffle and the batch selection) per timed block") if ref_caller else
                                  "step: bench.py calls glass_amd.step.TrainStep on pre-selected batches",
+                       "labels_in_head_launch": bool(getattr(getattr(stepper, "_labels", None), "in_head", False)),
                        "final_loss": last_loss},
             "roofline": roofline, "roofline_hbm": hbm, "step_breakdown": step_breakdown, "step_floor": floor, "cpu_baseline": cpu,
             "step_floor_us": None if floor is None else floor["us"],

@@ -238,10 +238,12 @@ class ParamArena(FlatGradBucket):
                 mod._glass_arena = self  # EmbZGConv.forward refreshes the images once per training forward
         self.refresh_transposes()
 
-    def refresh_transposes(self, rng_state=None, table=None, zero=None):
+    def refresh_transposes(self, rng_state=None, table=None, zero=None, head=None):
         """Re-pack every stacked weight into the operand images of the fused dense kernels (forward: W,
         data gradient: W^T): one launch for the whole model.  rng_state (the device-resident dropout counter,
         ops.rng_state): advanced by the same launch — the two once-per-step prologue jobs share it."""
+        # head: a stack.BatchLabels with an epoch source (set_epoch) — the label launch of the step's batch rides in this
+        # launch (glass_step_head_f32: prologue || labels, the batch named by the device-resident cursor)
         src, dst, cap, nt, kt, tr, zr, k = self._pack_args
         from . import _lib, ops
         for i, p in enumerate(self._packs):  # the pairs' CURRENT z_ratio (the kernels receive the live value as well)
@@ -254,7 +256,7 @@ class ParamArena(FlatGradBucket):
             n = min(16, k - i)
             rng = rng_state.data_ptr() if (rng_state is not None and i == 0) else 0
             st = torch.cuda.current_stream().cuda_stream
-            if (table is not None or zero is not None) and i == 0:
+            if (table is not None or zero is not None or head is not None) and i == 0:
                 # zero = an int64 tensor the same launch zero-fills (the step's exact GraphNorm accumulators)
                 zargs = (0, 0) if zero is None else (zero.data_ptr(), zero.numel())
                 if table is not None:
@@ -263,10 +265,17 @@ class ParamArena(FlatGradBucket):
                              float(gn.eps), saved.data_ptr(), 0 if tab is None else tab.data_ptr(), W.shape[1])
                 else:
                     targs = (0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0)
-                rc = _lib.load().glass_step_prologue_f32(src[i:].ctypes.data, dst[i:].ctypes.data, cap[i:].ctypes.data, nt[i:].ctypes.data,
+                if head is not None:
+                    rc = _lib.load().glass_step_head_f32(src[i:].ctypes.data, dst[i:].ctypes.data, cap[i:].ctypes.data, nt[i:].ctypes.data,
                                                          kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, max(n, 0), rng,
-                                                         *targs, *zargs, st)
-                _lib.check(rc, "glass_step_prologue_f32")
+                                                         *targs, *zargs, *head.head_args(), st)
+                    _lib.check(rc, "glass_step_head_f32")
+                    head.loaded = True
+                else:
+                    rc = _lib.load().glass_step_prologue_f32(src[i:].ctypes.data, dst[i:].ctypes.data, cap[i:].ctypes.data, nt[i:].ctypes.data,
+                                                             kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, max(n, 0), rng,
+                                                             *targs, *zargs, st)
+                    _lib.check(rc, "glass_step_prologue_f32")
             elif n > 0:
                 rc = _lib.load().glass_dense_pack_batch_f32(src[i:].ctypes.data, dst[i:].ctypes.data, cap[i:].ctypes.data, nt[i:].ctypes.data,
                                                             kt[i:].ctypes.data, tr[i:].ctypes.data, zr[i:].ctypes.data, n, rng, st)

@@ -20,6 +20,7 @@
 // take the LDS-tiled kernels of dense_tiled.hip.
 #include "common.h"
 #include "dense_common.h"
+#include "labels_body.h"
 #include "split_mma.h"
 #include "wgrad_common.h"
 #include "emb_table.h"
@@ -2281,11 +2282,13 @@ struct ZeroJob {
     int64_t n;     // int64 words
 };
 
-__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state, TableJob tab, int n_jobs,
-                                                            ZeroJob zero) {
+// (a device function: the stand-alone prologue launch below, and the first grid rows of the step's head launch; `rows` = the
+// grid rows that run it — the zero-fill is spread over exactly those; kBlock threads per workgroup take part)
+__device__ __forceinline__ void pack_batch_body(const PackBatch& batch, uint64_t* rng_state, const TableJob& tab, int n_jobs,
+                                                const ZeroJob& zero, int rows) {
     if (rng_state && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) rng_state[1] += 1;  // see glass_rng_advance
     if (zero.p) {
-        const int64_t nthreads = (int64_t)gridDim.x * gridDim.y * kBlock;
+        const int64_t nthreads = (int64_t)gridDim.x * rows * kBlock;
         for (int64_t k = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * kBlock + threadIdx.x; k < zero.n; k += nthreads) zero.p[k] = 0;
     }
     if ((int)blockIdx.y >= n_jobs) {
@@ -2391,6 +2394,47 @@ __global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uin
         app[l] = e;
         if (j.cut) pack_cut_put(cut, total / 1024 + tile, nl, q, e);
     }
+}
+
+__global__ __launch_bounds__(kBlock) void pack_batch_kernel(PackBatch batch, uint64_t* rng_state, TableJob tab, int n_jobs,
+                                                            ZeroJob zero) {
+    pack_batch_body(batch, rng_state, tab, n_jobs, zero, (int)gridDim.y);
+}
+
+// ---- the head of a replayed step: prologue || labels as ONE launch (glass_step_head_f32) ------------------------------
+// The prologue (weight images, table statistics, accumulator zero-fill: depends on the parameters only) and the label
+// launch (depends on the batch only) are the two independent kernels at the head of every step, ~4.5 and ~6.5 us each at
+// ppi_bp-shape, and each is a chain of dependent round trips that leaves the chip idle.  Side by side in one grid the
+// shorter one disappears from the step's chain.  Grid rows [0, rows): the prologue's (its kBlock-thread roles on the first
+// kBlock threads of a kLabThreads-wide workgroup; the other waves end at once — a barrier never counts ended waves); row
+// `rows`, workgroup 0: the label workgroup (labels_body.h).  Which batch: a device-resident cursor (glass_batch_cursor) —
+// a captured launch cannot take a new pointer per replay.
+struct LabelJob {
+    glass_batch_cursor* cur;
+    int n_idx, smax, y_row_words;
+    int64_t* pos_dst;
+    uint32_t* y_dst;
+    uint8_t* mask;
+    int32_t *lab_rows, *lab_count, *owner;
+    int64_t N;
+};
+
+__global__ __launch_bounds__(kLabThreads) void step_head_kernel(PackBatch batch, uint64_t* rng_state, TableJob tab, int n_jobs,
+                                                                ZeroJob zero, int rows, LabelJob lj) {
+    if ((int)blockIdx.y < rows) {
+        if (threadIdx.x >= kBlock) return;
+        pack_batch_body(batch, rng_state, tab, n_jobs, zero, rows);
+        return;
+    }
+    if (blockIdx.x != 0) return;
+    // (wave-uniform scalar loads: one dependent round trip in front of the body's own)
+    const int64_t n_b = lj.cur->n_batches, c = lj.cur->cursor;
+    const int64_t b = c < 0 ? 0 : (lj.cur->wrap ? c % n_b : (c >= n_b ? n_b - 1 : c));
+    const BatchSrc src{lj.cur->pos_all, reinterpret_cast<const uint32_t*>(lj.cur->y_all), lj.cur->idx + b * lj.n_idx, lj.smax,
+                       lj.y_row_words > 0 ? lj.y_row_words : 1, lj.cur->n_all};
+    batch_labels_body<true>(src, lj.n_idx * lj.smax, lj.pos_dst, lj.y_dst, (int64_t)lj.n_idx * lj.y_row_words, lj.mask, lj.lab_rows,
+                            lj.lab_count, lj.owner, lj.N, 1);
+    if (threadIdx.x == 0) lj.cur->cursor = c + 1;  // (every read of the cursor lies before the body's barriers)
 }
 
 }  // namespace glass
@@ -3072,7 +3116,8 @@ extern "C" int64_t glass_comb_eff_ws_bytes(int64_t n_nodes, int64_t H, int64_t l
 
 static int pack_launch(const float* const* src, float* const* dst, const int64_t* dst_floats, const int64_t* NT, const int64_t* KT,
                        const int32_t* transposed, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
-                       const TableJob& tab, void* stream, const char* what, ZeroJob zero = ZeroJob{nullptr, 0}) {
+                       const TableJob& tab, void* stream, const char* what, ZeroJob zero = ZeroJob{nullptr, 0},
+                       const LabelJob* lj = nullptr) {
     GLASS_REQUIRE(n_jobs >= 0 && n_jobs <= kMaxPackJobs && (n_jobs == 0 || (src && dst && dst_floats && NT && KT && transposed)),
                   "%s: bad arguments (at most %d matrices per call)", what, kMaxPackJobs);
     PackBatch b;
@@ -3109,7 +3154,11 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
     if (tab.W && (unsigned)ceil_div(tab.H, kTabCols) > gx) gx = (unsigned)ceil_div(tab.H, kTabCols);
     unsigned gy = (unsigned)n_jobs + (tab.W ? 1u : 0u);
     if (gy == 0) gy = 1;  // (only the zero-fill / the dropout stream to serve)
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(gx, gy), dim3(kBlock), 0, (hipStream_t)stream, b, rng_state, tab, (int)n_jobs, zero);
+    if (lj)
+        hipLaunchKernelGGL(step_head_kernel, dim3(gx, gy + 1), dim3(kLabThreads), 0, (hipStream_t)stream, b, rng_state, tab, (int)n_jobs,
+                           zero, (int)gy, *lj);
+    else
+        hipLaunchKernelGGL(pack_batch_kernel, dim3(gx, gy), dim3(kBlock), 0, (hipStream_t)stream, b, rng_state, tab, (int)n_jobs, zero);
     return launch_status(what);
 }
 
@@ -3149,4 +3198,30 @@ extern "C" int glass_step_prologue_f32(const float* const* src, float* const* ds
     if (W) tab = TableJob{W, (int)V, (int)H, class_rowptr, gamma, beta, alpha, eps, saved, table};
     return pack_launch(src, dst, dst_floats, NT, KT, transposed, z_ratio, n_jobs, rng_state, tab, stream, "glass_step_prologue_f32",
                        ZeroJob{n_zero_words > 0 ? (long long*)zero_words : nullptr, n_zero_words});
+}
+
+// The head of a replayed step: the prologue above and the label launch of the step's batch (labels.hip) in one grid.
+extern "C" int glass_step_head_f32(const float* const* src, float* const* dst, const int64_t* dst_floats, const int64_t* NT,
+                                   const int64_t* KT, const int32_t* transposed, const float* z_ratio, int64_t n_jobs,
+                                   uint64_t* rng_state, const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma,
+                                   const float* beta, const float* alpha, float eps, float* saved, float* table, int64_t H,
+                                   int64_t* zero_words, int64_t n_zero_words, glass_batch_cursor* cur, int64_t n_idx,
+                                   int64_t smax, int64_t y_row_bytes, int64_t* pos_dst, void* y_dst, uint8_t* mask,
+                                   int32_t* lab_rows, int32_t* lab_count, void* ws, int64_t n_nodes, void* stream) {
+    GLASS_REQUIRE(!W || (class_rowptr && gamma && beta && alpha && saved && H > 0 && V > 0 && V <= GLASS_EMBED_NORM_MAX_ROWS),
+                  "step_head: bad embedding-table arguments (at most %d rows)", GLASS_EMBED_NORM_MAX_ROWS);
+    GLASS_REQUIRE(n_zero_words >= 0 && (n_zero_words == 0 || zero_words), "step_head: bad zero-fill arguments");
+    GLASS_REQUIRE(cur && pos_dst && mask && lab_rows && lab_count && ws, "step_head: null pointer");
+    GLASS_REQUIRE(smax > 0 && n_idx > 0 && n_idx * smax < (1ll << 30) && n_nodes > 0 && n_nodes < (1ll << 31) &&
+                      (reinterpret_cast<uintptr_t>(cur) & 7u) == 0,
+                  "step_head: bad sizes");
+    GLASS_REQUIRE(y_row_bytes == 0 || (y_dst && y_row_bytes > 0 && y_row_bytes % 4 == 0 && y_row_bytes < (1ll << 30) &&
+                                       (reinterpret_cast<uintptr_t>(y_dst) & 3u) == 0),
+                  "step_head: the target rows have 4-byte granularity");
+    TableJob tab{};
+    if (W) tab = TableJob{W, (int)V, (int)H, class_rowptr, gamma, beta, alpha, eps, saved, table};
+    const LabelJob lj{cur, (int)n_idx, (int)smax, (int)(y_row_bytes / 4), pos_dst, (uint32_t*)y_dst, mask, lab_rows, lab_count,
+                      (int32_t*)ws, n_nodes};
+    return pack_launch(src, dst, dst_floats, NT, KT, transposed, z_ratio, n_jobs, rng_state, tab, stream, "glass_step_head_f32",
+                       ZeroJob{n_zero_words > 0 ? (long long*)zero_words : nullptr, n_zero_words}, &lj);
 }

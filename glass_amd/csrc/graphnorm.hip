@@ -147,6 +147,56 @@ __global__ __launch_bounds__(kBlock) void gn_stats_kernel(const float* __restric
     block_reduce_store<VW>(s, q, lds, tc, tr, TC, rpb, partial, c0, C, exact);
 }
 
+// The same sums at C = 64 straight into the exact accumulators, shaped for a launch that is all latency (round 6; the
+// step's two statistics launches at ppi_bp-shape, 6.6 us each): ONE round of loads per thread where the graph allows it
+// (row tiles of 16 * nst rows, one workgroup per CU: thread (rs, ga) takes rows rs + 16 st, columns 4 ga .. + 3, up to
+// five rows in flight), the 16 row slots of a column folded by lane shuffles + one pass through LDS instead of a serial
+// walk by 16 threads, and the 2 x 64 sums added by 128 threads (two atomics each) instead of 16 threads with 16 each.
+__global__ __launch_bounds__(kBlock) void gn_stats64_exact_kernel(const float* __restrict__ x, int64_t ldx, int64_t N, int nst,
+                                                                  long long* __restrict__ acc, int n_rep) {
+    constexpr int C = 64, kRound = 5;
+    __shared__ double red[4][2 * C];
+    const int tid = threadIdx.x, rs = tid >> 4, ga = tid & 15, lane = tid & 63, w = tid >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * 16 * nst;
+    double s[4] = {0.0, 0.0, 0.0, 0.0}, q[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int st0 = 0; st0 < nst; st0 += kRound) {
+        float4 v[kRound];
+#pragma unroll
+        for (int u = 0; u < kRound; ++u) {
+            const int64_t r = r0 + 16 * (st0 + u) + rs;
+            v[u] = (st0 + u < nst && r < N) ? *reinterpret_cast<const float4*>(x + r * ldx + 4 * ga) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kRound; ++u) {
+            const double a[4] = {(double)v[u].x, (double)v[u].y, (double)v[u].z, (double)v[u].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                s[k] += a[k];
+                q[k] += a[k] * a[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {  // the wave's four row slots of column 4 ga + k (lanes ga, ga + 16, ga + 32, ga + 48)
+        s[k] += __shfl_xor(s[k], 16);
+        q[k] += __shfl_xor(q[k], 16);
+        s[k] += __shfl_xor(s[k], 32);
+        q[k] += __shfl_xor(q[k], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            red[w][4 * ga + k] = s[k];
+            red[w][C + 4 * ga + k] = q[k];
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * C) {  // fixed order over the four waves; the integer adds commute: bitwise repeatable
+        const double t = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+        gn_acc_add(acc, blockIdx.x % n_rep, tid / C, tid % C, C, t, kAccScaleFwd);
+    }
+}
+
 // ---- finalize: sum the workgroup partials in fixed order; derive mean / rstd / scale / shift ----
 // Up to 8 partial buffers [nblk][2][C_each], source k covering columns k*C_each .. (k+1)*C_each - 1 (one source for
 // the statistics kernel above; several when the statistics come from the epilogues of the kernels that wrote the
@@ -531,6 +581,14 @@ extern "C" int glass_graphnorm_stats_exact_f32(const float* x, int64_t ldx, int6
                                                int n_rep, void* stream) {
     GLASS_REQUIRE(x && acc && n_rows > 0 && C > 0 && ldx >= C && n_rep >= 1 && n_rep <= kAccRep, "graphnorm_stats_exact: bad arguments");
     const bool vec = C % 4 == 0 && ldx % 4 == 0 && aligned16(x);
+    if (vec && C == 64) {
+        // one round of <= 5 rows per thread while the graph fits 256 workgroups of 80 rows; taller tiles beyond
+        int nst = (int)ceil_div(ceil_div(n_rows, (int64_t)256), (int64_t)16);
+        if (nst < 5) nst = n_rows >= 80 * 64 ? 5 : (nst < 1 ? 1 : nst);
+        hipLaunchKernelGGL(gn_stats64_exact_kernel, dim3((unsigned)ceil_div(n_rows, (int64_t)16 * nst)), dim3(kBlock), 0, (hipStream_t)stream,
+                           x, ldx, n_rows, nst, reinterpret_cast<long long*>(acc), n_rep);
+        return launch_status("glass_graphnorm_stats_exact_f32");
+    }
     const Tiling t = make_tiling(C, vec);
     // (fewer, longer workgroups to thin out the adds per replica were slower: 8.3 / 12.7 us with half / a quarter of them)
     dim3 gs(stat_blocks(n_rows, t), t.ctiles);

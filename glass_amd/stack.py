@@ -79,6 +79,37 @@ class BatchLabels:
         self.count = torch.zeros(4, dtype=torch.int32, device=device)
         self.ws = torch.full((self.n,), 2**31 - 1, dtype=torch.int32, device=device)  # owner words: INT32_MAX between calls
         self.loaded = False
+        # epoch source of the in-graph label launch (glass_step_head_f32): a glass_batch_cursor in device memory + what it
+        # points to (kept alive here); None: the batch is labeled by an eager load() / load_gather() in front of the step
+        self.cursor = None
+        self._epoch = None
+        self.in_head = False   # the step's head launch labels the batch (set by TrainStep while an epoch source is installed)
+
+    def set_epoch(self, pos_all, y_all, idx_batches, pos_dst, y_dst, wrap=False):
+        """Install the epoch's batches for the in-graph label launch: idx_batches int64 [n_batches, n_idx] (device, contiguous:
+        the rows of every batch, in step order), pos_all / y_all the data set's matrices; the cursor restarts at batch 0
+        (wrap: it cycles over the batches instead of stopping at the last one).  One small host-to-device copy per epoch; the step's graph reads everything through the cursor (fixed address)."""
+        n_all, smax = pos_all.shape
+        n_b, n_idx = idx_batches.shape
+        if n_idx * smax != self.cap:
+            raise ValueError(f"BatchLabels: batches of {n_idx * smax} entries, capacity {self.cap}")
+        yrb = 0 if y_all is None else y_all.element_size() * (y_all.numel() // max(y_all.shape[0], 1))
+        if self.cursor is None:
+            self.cursor = torch.zeros(8, dtype=torch.int64, device=self.mask.device)
+        desc = torch.tensor([pos_all.data_ptr(), 0 if y_all is None else y_all.data_ptr(), idx_batches.data_ptr(), n_all, n_b, 0, 1 if wrap else 0, 0],
+                            dtype=torch.int64)
+        self.cursor.copy_(desc)
+        self._epoch = (pos_all, y_all, idx_batches, pos_dst, y_dst, int(n_idx), int(smax), int(yrb))
+
+    def head_args(self):
+        """The label arguments of glass_step_head_f32 (behind the prologue's)."""
+        _pos_all, y_all, _idx, pos_dst, y_dst, n_idx, smax, yrb = self._epoch
+        return (self.cursor.data_ptr(), n_idx, smax, yrb, pos_dst.data_ptr(), 0 if y_all is None else y_dst.data_ptr(),
+                self.mask.data_ptr(), self.rows.data_ptr(), self.count.data_ptr(), self.ws.data_ptr(), self.n)
+
+    def head_signature(self):
+        """What a captured head launch baked in besides the cursor's address: batch shape and target row size."""
+        return None if self._epoch is None else self._epoch[5:]
 
     def load(self, pos_src, pos_dst=None, y_src=None, y_dst=None):
         """Labels of `pos_src`; with pos_dst / y_dst the batch is also copied into those fixed buffers (pos_dst must hold
@@ -562,6 +593,8 @@ class StackProgram:
             acc_all = acc_ro = torch.empty(int(lib.glass_gn_exact_words(H * L if emb.jk else H)), dtype=torch.int64, device=dev)
         st["gn_exact"] = acc_bwd
         st["gn_exact_readout"] = acc_ro
+        # the step's head launch labels the batch itself (TrainStep.begin_epoch: prologue || labels, glass_step_head_f32)
+        head = labels if (labels is not None and getattr(labels, "in_head", False) and train) else None
         if unl:
             # no GraphNorm behind the embedding (impl/models.py:461-463): layer 0's trans kernel gathers the table rows under
             # identity coefficients (mean 0, rstd 1, scale 1, shift 0) and applies the embedding's dropout (call id 1)
@@ -569,21 +602,21 @@ class StackProgram:
             ident = emb.__dict__.get("_glass_ident_saved")
             if ident is None or ident.device != dev:
                 ident = emb.__dict__["_glass_ident_saved"] = torch.cat([torch.zeros(H, **f32), torch.ones(2 * H, **f32), torch.zeros(H, **f32)])
-            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None, zero=acc_all)
+            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None, zero=acc_all, head=head)
             st["emb_table"], st["emb_saved"] = sel, ident
             first_gn = (ident, ACT_NONE, p, 1)
         elif use_table and labels is not None and USE_GATHER_IN_TRANS and lib.glass_dual_linear_fwd_gather_supported(H):
             sel = emb._selection(x_flat)
             saved = torch.empty(4 * H, **f32)
             emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None,
-                                                table=(W, V, sel.op.rowptr, gn0, saved, None), zero=acc_all)
+                                                table=(W, V, sel.op.rowptr, gn0, saved, None), zero=acc_all, head=head)
             st["emb_table"], st["emb_saved"] = sel, saved
             first_gn = (saved, ACT_NONE, p, 1)
-        elif _PROLOGUE_DONE and not advance and acc_all is None:
+        elif _PROLOGUE_DONE and not advance and acc_all is None and head is None:
             pass  # (evaluation branch behind a shared prologue: prologue_done)
         else:
             # once-per-step prologue, one launch: operand images of the current weights + new dropout masks
-            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None, zero=acc_all)
+            emb._glass_arena.refresh_transposes(ops.rng_state(dev) if advance else None, zero=acc_all, head=head)
         st["rng_epoch"] = ops.rng_epoch(dev)  # (the prologue launch above advanced the dropout stream)
         st["rng_words"] = ops.rng_snapshot(dev) if (snapshot_rng and advance and keep) else None
         ops._rng_cur[ops._dev(dev)] = st["rng_words"]  # the rest of this forward (inside forward()'s rng_scope) reads the snapshot

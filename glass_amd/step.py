@@ -66,6 +66,8 @@ class TrainStep:
         self._force_verify_mismatch = False  # tests: exercise the opt-out path
         self._force_capture_failure = False  # tests: this rank's capture of the collective "fails" (the ranks must agree on it)
         self.exchange_enabled = True    # bench.py: False = skip the collectives (timing of the exposed share; ranks diverge)
+        self._head_sig = None           # batch shape / target row size baked into a capture whose head launch labels the batch
+        self._recapture = False         # the label form (in the head launch / eager in front of the step) changed since the capture
 
     # -- the step body, split at the collective ---------------------------------------------------
     def _fused_head(self):
@@ -344,6 +346,58 @@ class TrainStep:
         """Device scalar: sum of the losses of the steps since reset_loss_sum() (added in step order, fp32)."""
         return self._loss_sum
 
+    def _alloc_batch(self, shape, pos, y):
+        """The step's fixed batch buffers (first use) — and, on the step program, the label state of the batch."""
+        self._pos = torch.full(shape, -1, dtype=pos.dtype, device=pos.device)
+        self._y = torch.zeros((shape[0], ) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
+        if self._program_step() and pos.is_cuda and pos.dtype == torch.int64:
+            from . import stack
+            self._labels = stack.BatchLabels(self.x.shape[0], self._pos.numel(), pos.device)
+
+    def begin_epoch(self, pos_all, y_all, idx_batches, wrap=False):
+        """The epoch's batches up front: pos_all / y_all the DATA SET's node and target matrices, idx_batches int64
+        [n_steps, B] the rows of every batch in step order (ZGDataloader's permutation cut into batches; a data-parallel
+        rank passes its own slices).  When the step runs as a captured program, its HEAD launch then labels the batch
+        itself — prologue || labels as one launch (glass_step_head_f32), the batch named by a device-resident cursor that
+        the launch advances — and next_step() is one graph replay with no launch in front of it.  Returns False when this
+        step cannot take that form (no step program, eager mode, unsuitable tensors): the caller keeps calling
+        step(pos_all, y_all, index) per batch."""
+        if not (self.use_graph and pos_all.is_cuda and pos_all.dim() == 2 and pos_all.dtype == torch.int64 and
+                pos_all.is_contiguous() and y_all.is_cuda and y_all.is_contiguous() and y_all.shape[0] == pos_all.shape[0] and
+                idx_batches.is_cuda and idx_batches.dim() == 2 and idx_batches.dtype == torch.int64 and
+                idx_batches.is_contiguous() and idx_batches.shape[0] > 0 and
+                (y_all.element_size() * (y_all.numel() // max(y_all.shape[0], 1))) % 4 == 0):
+            return False
+        shape = (idx_batches.shape[1], ) + tuple(pos_all.shape[1:])
+        first = self._pos is None
+        if first:
+            if not self._program_step():
+                return False      # (nothing allocated: the caller's step(pos, y, index) does its own first-use work)
+            self._alloc_batch(shape, pos_all, y_all)
+        if self._labels is None or shape != tuple(self._pos.shape) or y_all.dtype != self._y.dtype:
+            return False
+        was_head = self._labels.in_head
+        self._labels.set_epoch(pos_all, y_all, idx_batches, self._pos, self._y, wrap=wrap)
+        self._labels.in_head = True
+        sig = self._labels.head_signature()
+        hyper = self.opt.hyper() if hasattr(self.opt, "hyper") else None
+        if first or not self.graphed or hyper != self._hyper or sig != self._head_sig or not was_head or self._recapture:
+            if first:
+                self._warmup()   # (eager steps through the same head launch: they consume the first batches of the cursor)
+            self._hyper, self._head_sig, self._recapture = hyper, sig, False
+            self._capture()
+            self._labels.set_epoch(pos_all, y_all, idx_batches, self._pos, self._y, wrap=wrap)  # cursor back to batch 0
+        return True
+
+    def next_step(self):
+        """One step on the cursor's batch (after begin_epoch returned True): a graph replay."""
+        if hasattr(self.opt, "sync_lr"):
+            self.opt.sync_lr()
+        self._g_fb.replay()
+        if self._split:
+            self._exchange_and_update()
+        return self._loss
+
     def __call__(self, pos, y, index=None):
         """One step on the batch (pos, y).  index (int64 device vector): pos / y are the DATA SET's whole node and target
         matrices and the batch is their rows `index` — the selection ZGDataloader does with `pos[perm], y[perm]`
@@ -351,17 +405,18 @@ class TrainStep:
         shape = tuple(pos.shape) if index is None else (index.numel(), ) + tuple(pos.shape[1:])
         first = self._pos is None
         if first:
-            self._pos = torch.full(shape, -1, dtype=pos.dtype, device=pos.device)
-            self._y = torch.zeros((shape[0], ) + tuple(y.shape[1:]), dtype=y.dtype, device=y.device)
-            if self._program_step() and pos.is_cuda and pos.dtype == torch.int64:
-                from . import stack
-                self._labels = stack.BatchLabels(self.x.shape[0], self._pos.numel(), pos.device)
+            self._alloc_batch(shape, pos, y)
         if shape != tuple(self._pos.shape):
             raise ValueError("TrainStep needs a fixed batch shape (drop_last=True): "
                              f"{shape} vs {tuple(self._pos.shape)}")
+        if self._labels is not None and self._labels.in_head:
+            # this call labels its batch eagerly: a graph captured with the labels in its head launch has to go
+            self._labels.in_head = False
+            self._recapture = self.graphed
         self._load_batch(pos, y, index)
         hyper = self.opt.hyper() if hasattr(self.opt, "hyper") else None
-        if first or (self.graphed and hyper != self._hyper):
+        if first or (self.graphed and (hyper != self._hyper or self._recapture)):
+            self._recapture = False
             # (betas / eps / weight_decay are launch arguments: a changed param_groups entry means a new capture; the learning
             # rate lives in device memory and needs none)
             if first:

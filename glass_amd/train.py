@@ -9,6 +9,7 @@ from . import dist as gdist
 
 USE_GRAPH = os.environ.get("GLASS_TRAIN_GRAPH", "1") != "0"   # 0: the same training step, eager launches instead of a replay
 USE_STEP = os.environ.get("GLASS_TRAIN_STEP", "1") != "0"     # 0: the plain per-batch loop below (autograd, optimizer.step())
+USE_HEAD_LABELS = os.environ.get("GLASS_HEAD_LABELS", "1") != "0"  # 0: the label launch eager in front of every replay
 
 
 def _graph_step(optimizer, model, dataloader, loss_fn):
@@ -73,9 +74,17 @@ def train(optimizer, model, dataloader, loss_fn):
         step.reset_loss_sum()
         n = 0
         if type(dataloader) is ZGDataloader:
-            for perm in dataloader._batches():
-                step(ds.pos, ds.y, perm)
-                n += 1
+            batches = list(dataloader._batches())
+            # the whole epoch's index batches up front: the step's head launch then selects and labels its batch itself through
+            # a device-resident cursor (TrainStep.begin_epoch: one launch less per step, nothing in front of the replay)
+            if USE_HEAD_LABELS and batches and step.begin_epoch(ds.pos, ds.y, torch.stack(batches)):
+                for _ in batches:
+                    step.next_step()
+                    n += 1
+            else:
+                for perm in batches:
+                    step(ds.pos, ds.y, perm)
+                    n += 1
         else:  # a subclass may select its batches differently: take them as it yields them
             for batch in dataloader:
                 step(batch[3], batch[-1])

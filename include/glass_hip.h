@@ -583,6 +583,32 @@ int glass_step_prologue_f32(const float* const* src, float* const* dst, const in
                             const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma, const float* beta,
                             const float* alpha, float eps, float* saved, float* table, int64_t H, int64_t* zero_words,
                             int64_t n_zero_words, void* stream);
+/*     The head of a REPLAYED training step as ONE launch: glass_step_prologue_f32 (same first 21 arguments) and, beside it in
+ *     the same grid, the label launch glass_batch_labels_gather for the step's batch (impl/utils.py:32-45,
+ *     impl/SubGDataset.py:69-72, 92-96) — the two depend on nothing but the parameters and the batch, so the shorter one
+ *     (~5 us at ppi_bp-shape) disappears from the step's chain.  Inside a captured graph no launch argument can follow the
+ *     epoch's shuffle, so the batch is named by a DEVICE-RESIDENT cursor: `cur` points to a glass_batch_cursor in device
+ *     memory that the caller fills once per epoch — the data set's matrices, the epoch's index batches idx[n_batches][n_idx]
+ *     (ZGDataloader's permutation cut into batches; a data-parallel rank stores its own slices) and cursor = 0; every launch
+ *     takes batch min(cursor, n_batches - 1) (wrap != 0: cursor % n_batches) and advances the cursor by one.  n_idx, smax, y_row_bytes are launch arguments
+ *     (the batch shape is fixed for a captured step).  pos_dst .. ws, n_nodes as in glass_batch_labels_gather (incremental
+ *     form: pos_dst holds the previous batch). */
+typedef struct glass_batch_cursor {
+    const int64_t* pos_all; /* [n_all, smax] padded node matrix of the data set */
+    const void* y_all;      /* [n_all, y_row_bytes] targets (NULL: none) */
+    const int64_t* idx;     /* [n_batches, n_idx] rows of every batch of the epoch */
+    int64_t n_all;
+    int64_t n_batches;
+    int64_t cursor;         /* next batch; advanced by the launch */
+    int64_t wrap;           /* != 0: batch cursor % n_batches (a loop over the same batches) instead of the clamp */
+} glass_batch_cursor;
+int glass_step_head_f32(const float* const* src, float* const* dst, const int64_t* dst_floats, const int64_t* NT,
+                        const int64_t* KT, const int32_t* flags, const float* z_ratio, int64_t n_jobs, uint64_t* rng_state,
+                        const float* W, int64_t V, const int32_t* class_rowptr, const float* gamma, const float* beta,
+                        const float* alpha, float eps, float* saved, float* table, int64_t H, int64_t* zero_words,
+                        int64_t n_zero_words, glass_batch_cursor* cur, int64_t n_idx, int64_t smax, int64_t y_row_bytes,
+                        int64_t* pos_dst, void* y_dst, uint8_t* mask, int32_t* lab_rows, int32_t* lab_count, void* ws,
+                        int64_t n_nodes, void* stream);
 /*     Exact cross-workgroup GraphNorm sums (hidden 64): the whole-graph GraphNorm (PyG GraphNorm with batch = None,
  *     impl/models.py:165,249,257,266,271) needs column sums over ALL rows between every pair of kernels of the step.
  *     Instead of per-workgroup fp64 partials + a finalize launch, the producers add their per-workgroup sums into

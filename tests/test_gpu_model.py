@@ -693,6 +693,93 @@ def _train_probe(name, hidden, dropout, steps, use_graph=True):
     return arena.flat_param.clone()
 
 
+def _train_probe_head(name, hidden, dropout, steps, switch_at=None):
+    """_train_probe's run with the labels in the step's HEAD launch (TrainStep.begin_epoch / next_step: prologue || labels,
+    the batch named by the device cursor); switch_at: from that step on the eager-label form step(pos, y) again."""
+    from glass_amd import synth, losses, ops
+    from glass_amd.arena import ParamArena
+    from glass_amd.optim import FlatAdam
+    from glass_amd.step import TrainStep
+    dev = torch.device(DEV)
+    w, ei, ew, x, pos, y = synth.make_workload(name, seed=0, n_batches=4)
+    ei, ew, x, pos, y = (torch.from_numpy(a).to(dev) for a in (ei, ew, x, pos, y))
+    pos[:, 0] = pos[0, 0]
+    torch.manual_seed(0)
+    ops.rng_seed(321, dev)
+    model = build_glass(hidden, w.layers, int(x.max()), w.n_class, w.aggr, w.pool, w.z_ratio, dropout=dropout).to(dev).train()
+    arena = ParamArena(model)
+    opt = FlatAdam(arena, lr=1e-2)
+    step = TrainStep(model, opt, losses.CrossEntropy(), x, ei, ew, arena, use_graph=True, warmup_iters=2, preserve_state=True)
+    B = w.batch
+    idx = torch.arange(4 * B, device=dev).reshape(4, B)
+    assert step.begin_epoch(pos, y, idx, wrap=True), "the step program did not take the head-label form"
+    losses_seen = []
+    for k in range(steps):
+        if switch_at is not None and k >= switch_at:
+            b = k % 4
+            losses_seen.append(step(pos[b * B:(b + 1) * B], y[b * B:(b + 1) * B]).clone())
+        else:
+            losses_seen.append(step.next_step().clone())
+    torch.cuda.synchronize()
+    cur = int(step._labels.cursor[5])
+    return arena.flat_param.clone(), torch.stack(losses_seen), cur, step
+
+
+def test_labels_in_the_head_launch_equal_the_eager_label_launch():
+    """Round 6: prologue || labels as ONE in-graph launch over a device cursor (glass_step_head_f32).  Same kernels' bodies,
+    same order of everything else: 40 steps over 4 cycling batches give BIT-identical parameters to the form with an eager
+    label launch in front of every replay; the cursor advanced once per replay; switching back to step(pos, y) mid-run
+    (a new capture without the labels in the head) stays on the same trajectory; an exhausted cursor without wrap stays on
+    the last batch."""
+    ref = _train_probe("tiny", 64, 0.5, 40)
+    got, _l, cur, step = _train_probe_head("tiny", 64, 0.5, 40)
+    assert step.graphed and step._program_step() and step._labels.in_head
+    assert cur == 40, f"cursor at {cur} after 40 replays"
+    assert torch.equal(ref, got)
+    mixed, _l2, _c, step2 = _train_probe_head("tiny", 64, 0.5, 40, switch_at=20)
+    assert not step2._labels.in_head
+    assert torch.equal(ref, mixed)
+
+
+def test_step_head_labels_match_the_label_launch():
+    """glass_step_head_f32 against glass_batch_labels_gather through the C ABI: two batches in a row (incremental label
+    bytes), the second one with a duplicate node and a padded tail — label bytes, unique-row list and count, the copied batch
+    and targets are identical; the cursor advances, clamps at the last batch without wrap and cycles with it."""
+    import numpy as np
+    from glass_amd import stack, _lib
+    lib = _lib.load()
+    dev = torch.device(DEV)
+    n, n_all, smax, B = 3000, 40, 7, 8
+    rng = np.random.default_rng(5)
+    pos_all = torch.from_numpy(rng.integers(0, n, (n_all, smax))).to(dev)
+    pos_all[3, 2] = pos_all[5, 1]
+    pos_all[::3, -2:] = -1
+    y_all = torch.from_numpy(rng.integers(0, 5, (n_all, 1))).to(dev)
+    idx = torch.from_numpy(rng.permutation(n_all)[:3 * B].reshape(3, B).astype(np.int64)).to(dev)
+    a, b = stack.BatchLabels(n, B * smax, dev), stack.BatchLabels(n, B * smax, dev)
+    pa, pb = (torch.full((B, smax), -1, dtype=torch.int64, device=dev) for _ in range(2))
+    ya, yb = (torch.zeros((B, 1), dtype=torch.int64, device=dev) for _ in range(2))
+    b.set_epoch(pos_all, y_all, idx, pb, yb)
+    st = torch.cuda.current_stream().cuda_stream
+    for k in range(5):  # batches 0, 1, 2, then the clamp: 2, 2
+        a.load_gather(pos_all, y_all, idx[min(k, 2)], pa, ya)
+        rc = lib.glass_step_head_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, *b.head_args(), st)
+        assert rc == 0, lib.glass_last_error_string()
+        torch.cuda.synchronize()
+        assert int(b.cursor[5]) == k + 1
+        na = int(a.count[0])
+        assert na == int(b.count[0]) and na > 0
+        assert torch.equal(a.mask, b.mask) and torch.equal(a.rows[:na], b.rows[:na])
+        assert torch.equal(pa, pb) and torch.equal(ya, yb)
+        assert torch.equal(b.ws, torch.full_like(b.ws, 2**31 - 1))
+    b.set_epoch(pos_all, y_all, idx, pb, yb, wrap=True)
+    for k in range(4):  # 0, 1, 2, 0
+        rc = lib.glass_step_head_f32(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, *b.head_args(), st)
+        assert rc == 0, lib.glass_last_error_string()
+    torch.cuda.synchronize()
+    assert torch.equal(pb, pos_all[idx[0]]) and torch.equal(yb, y_all[idx[0]])
+
+
 @pytest.mark.parametrize("hidden", [16, 64])
 def test_training_is_bitwise_repeatable(hidden):
     """The same seeded training twice -> bit-identical parameters, on the per-op path (hidden 16) and on the step
