@@ -324,7 +324,7 @@ def child_env_without_profiler(env=None):
     return env
 
 
-def k1_pmc_traffic(workload, H, timeout=240):
+def k1_pmc_traffic(workload, H, timeout=240, csr=None):
     """Memory-side bytes per K1 launch at this workload's shape, measured NOW: two child runs of tools/bin/spmm_bench under
     `rocprofv3 --kernel-trace --pmc <counter>` — FETCH_SIZE and WRITE_SIZE in separate passes, KiB units, FETCH_SIZE
     doubled (gfx950 reports half the bytes of wide loads; MI355X_MICROARCH.md §HBM).  None when the shape has no
@@ -342,6 +342,19 @@ def k1_pmc_traffic(workload, H, timeout=240):
     # the stand-alone K1 program where it has a generator for the shape; otherwise (the shipped density graph) the K1 launches
     # of a few eager steps of this file itself (--mode trace --graph 0): same kernels, same matrix, counted per dispatch
     standalone = workload in ("ppi_bp", "hpo_neuro", "em_user", "powerlaw") and os.path.exists(exe)
+    csr_file = None
+    if not standalone and csr is not None and os.path.exists(exe):
+        # a graph without a generator in the stand-alone program (the shipped density graph): its CSR as this run holds it,
+        # dumped for tools/bin/spmm_bench file:<path> — same kernel, same matrix, K1 alone under the counters
+        import numpy as np
+        rowptr, col, val = (t.detach().cpu().numpy() for t in csr)
+        fd, csr_file = tempfile.mkstemp(prefix="glass_csr_", suffix=".bin", dir="/tmp")
+        with os.fdopen(fd, "wb") as f:
+            np.array([rowptr.shape[0] - 1, col.shape[0]], dtype=np.int64).tofile(f)
+            rowptr.astype(np.int32).tofile(f)
+            col.astype(np.int32).tofile(f)
+            val.astype(np.float32).tofile(f)
+        workload, standalone = "file:" + csr_file, True
     child = [exe, workload, str(H), "10"] if standalone else \
         [sys.executable, os.path.join(ROOT, "bench.py"), "--mode", "trace", "--graph", "0", "--workload", workload, "--steps", "4",
          "--warmup", "1"]
@@ -368,6 +381,8 @@ def k1_pmc_traffic(workload, H, timeout=240):
     finally:
         if d is not None:
             shutil.rmtree(d, ignore_errors=True)
+        if csr_file is not None and os.path.exists(csr_file):
+            os.remove(csr_file)
     return int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), (
         "this run: child rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes, KiB, FETCH_SIZE x2 per the "
         "gfx950 rule) on " + ("tools/bin/spmm_bench at the same shape" if standalone else
@@ -867,7 +882,7 @@ def main():
     k1_avg = sum(k1_us) / len(k1_us) * 1e-6
     alg_bytes = _k1_alg_bytes(nnz, N, H)
     x_bytes = N * H * 4
-    traffic, traffic_source = (None, "--no-pmc") if (args.no_pmc or rank != 0 or world != 1) else k1_pmc_traffic(args.workload, H)
+    traffic, traffic_source = (None, "--no-pmc") if (args.no_pmc or rank != 0 or world != 1) else k1_pmc_traffic(args.workload, H, csr=(adj.rowptr, adj.col, adj.val))
     # Two levels, two utilisations (each <= 1 by construction): every gathered byte passes an XCD L2; what misses there
     # passes the memory side — Infinity Cache while X fits it, HBM beyond.
     mem_level, mem_peak = ("infinity_cache", IC_GATHER_GBPS) if x_bytes <= IC_BYTES else ("hbm", HBM_PEAK_GBPS)
@@ -1030,6 +1045,26 @@ def main():
         }
         if collective is not None:
             out["collective"] = collective
+        # the forecast a SCALE run is to be held against: per world size the exposed exchange time under
+        # the stated model (glass_amd/dist.py: assumed constants) and efficiency = step / (step + exposed), from THIS line's
+        # step time scaled to one rank's share of it (N = 1: the step itself; N > 1: the measured step minus its predicted exposed part)
+        try:
+            from glass_amd import dist as gdist
+            fb = getattr(bucket, "flat", None)
+            if fb is not None:
+                es = fb.element_size()
+                big0 = int(getattr(bucket, "big_start", fb.numel()) or fb.numel())
+                big = (fb.numel() - big0) * es if (getattr(bucket, "shard_optimizer", False) or world == 1) else 0
+                payload = {"small_allreduce": (big0 if big else fb.numel()) * es, "big_reduce_scatter": big, "big_all_gather": big}
+                ms1 = dt / args.steps * 1e3
+                overlaps = bool(big)
+                if world > 1 and collective is not None and collective.get("predicted_exposed_us") is not None:
+                    ms1 = max(ms1 - collective["predicted_exposed_us"] * 1e-3, 1e-6)
+                fc = gdist.predict_scaling(payload, ms1, overlaps_small=overlaps)
+                out["collective_forecast"] = fc
+                out["predicted_efficiency"] = {str(r["world"]): round(r["ring_efficiency"], 4) for r in fc["per_world"]}
+        except Exception as e:  # noqa: BLE001 — a forecast must never fail a bench line
+            out["collective_forecast"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as td

@@ -2631,11 +2631,8 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
 #define GLASS_TF2(NS, WGN)                                                                                                  \
     hipLaunchKernelGGL((trans_fwd2_kernel<64, NS, WGN>), tall ? dim3((unsigned)wg80) : grid, dim3(kBlock * WGN), 0, st, xa, lda,     \
                        src_rows, W, bias, mask, zr, omz, act, T, ldt, out, ldo, n_nodes, stats, stats_exact, pro, xa_index)
-#if GLASS_LAB  // the one-wave-group form of the trans forward: laboratory A/B (GLASS_FWD_WG=1)
-        if (fwd_wave_groups(false) == 1) {
-            if (tall) GLASS_TF2(5, 1); else GLASS_TF2(4, 1);
-            return launch_status("glass_dual_linear_fwd_f32");
-        }
+#if GLASS_LAB
+#include "../../tools/lab/dispatch_trans_fwd_wg1.inc"
 #endif
         if (h64_split_products()) {
 #define GLASS_TF2S(NS)                                                                                                      \
@@ -2926,7 +2923,7 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
     const LabRows lab{lab_rows, lab_count, n_main, (int)lab_cap};
 #if GLASS_LAB
-    const size_t lds = lds_bytes(H, 2);  // (first form) two K passes of the [H][2H] effective weight
+#include "../../tools/lab/dispatch_comb_fwd_v1_lds.inc"
 #endif
     const int64_t ld_max = std::max(std::max(lda, ldb), std::max(ldo, gn_saved ? ldxo : (int64_t)0));
     GLASS_REQUIRE(!GLASS_COMB_FWD_V2 || n_nodes * ld_max * 4 < (1ll << 31),
@@ -2954,9 +2951,8 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
             if (dr) GLASS_CF3S(true); else GLASS_CF3S(false);
         } else if (H == 128) {
             if (dr) GLASS_CF3(128, true, 1); else GLASS_CF3(128, false, 1);
-#if GLASS_LAB  // two wave groups on the comb forward: laboratory A/B (GLASS_FWD_WG=2)
-        } else if (fwd_wave_groups(true) == 2) {
-            if (dr) GLASS_CF3(64, true, 2); else GLASS_CF3(64, false, 2);
+#if GLASS_LAB
+#include "../../tools/lab/dispatch_comb_fwd3_wg2.inc"
 #endif
         } else {
             if (dr) GLASS_CF3(64, true, 1); else GLASS_CF3(64, false, 1);
@@ -2970,21 +2966,8 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
         else if (dr) GLASS_CF2(128, true, 4);
         else if (tall) GLASS_CF2(128, false, 5);
         else GLASS_CF2(128, false, 4);
-#if GLASS_LAB  // laboratory A/B: two wave groups (GLASS_FWD_WG=2), the software-pipelined second form (GLASS_COMB_FWD_PF=1)
-    } else if (GLASS_COMB_FWD_V2 && fwd_wave_groups(true) == 2) {
-        if (dr && tall) GLASS_CF2W(true, 5);
-        else if (dr) GLASS_CF2W(true, 4);
-        else if (tall) GLASS_CF2W(false, 5);
-        else GLASS_CF2W(false, 4);
-    } else if (GLASS_COMB_FWD_V2 && comb_fwd_pf_on()) {
-#define GLASS_CF2P(DR, NS)                                                                                                \
-    hipLaunchKernelGGL((comb_fwd_eff2p_kernel<64, DR, NS>), grid, dim3(256), 0, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,  \
-                       bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab)
-        if (dr && tall) GLASS_CF2P(true, 5);
-        else if (dr) GLASS_CF2P(true, 4);
-        else if (tall) GLASS_CF2P(false, 5);
-        else GLASS_CF2P(false, 4);
-#undef GLASS_CF2P
+#if GLASS_LAB
+#include "../../tools/lab/dispatch_comb_fwd2_wg2_pf.inc"
 #endif
     } else if (GLASS_COMB_FWD_V2 && h64_split_products()) {
 #define GLASS_CF2S(DR, NS)                                                                                                \
@@ -3003,10 +2986,8 @@ extern "C" int glass_comb_eff_fwd_f32(const float* xa, int64_t lda, const float*
     }
 #undef GLASS_CF2
 #undef GLASS_CF2W
-#if GLASS_LAB  // first form (GLASS_COMB_FWD_V2=0)
-    else
-        hipLaunchKernelGGL((comb_fwd_eff_kernel<64, 4>), grid, dim3(kBlock), lds, (hipStream_t)stream, xa, lda, xb, ldb, Wimg_eff,
-                           bias, mask, zr, omz, out, ldo, n_nodes, stats, stats_exact, pro, lab);
+#if GLASS_LAB
+#include "../../tools/lab/dispatch_comb_fwd_v1.inc"
 #endif
     return launch_status("glass_comb_eff_fwd_f32");
 }
@@ -3078,20 +3059,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
         return launch_status("glass_comb_eff_bwd_f32 (two launches)");
     }
 #if GLASS_LAB && GLASS_COMB_BWD_V2
-    {
-        // staged form: WTimg_eff holds the layout-7 images (read by the kernels above), then the layout-10 images
-        GLASS_REQUIRE(gn_act == GLASS_ACT_NONE, "comb_eff_bwd: the GraphNorm in front of the comb pair has no activation");
-        const int64_t ld_max = std::max(std::max(ldd, ldo), std::max(std::max(ldx, ldx2), gn_partial ? gn_ldx : (int64_t)0));
-        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "comb_eff_bwd: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
-        DgradEffArgs d2 = dargs;
-        d2.WT = WTimg_eff + 2 * (2 * H * H);
-        const dim3 grid2((unsigned)(g.n_s + g.n_l));
-        if (gn_partial && gn_p_drop > 0.f)
-            hipLaunchKernelGGL((comb_bwd_eff2_kernel<64, true>), grid2, dim3(kBlock), 0, st, d2, X, ldx, X2, ldx2, zr, g.n_l, part_w, part_b);
-        else
-            hipLaunchKernelGGL((comb_bwd_eff2_kernel<64, false>), grid2, dim3(kBlock), 0, st, d2, X, ldx, X2, ldx2, zr, g.n_l, part_w, part_b);
-        return launch_status("glass_comb_eff_bwd_f32 (staged)");
-    }
+#include "../../tools/lab/dispatch_comb_bwd_v2.inc"
 #endif
     if (GLASS_COMB_DGRAD_V2) {
         GLASS_REQUIRE(gn_act == GLASS_ACT_NONE, "comb_eff_bwd: the GraphNorm in front of the comb pair has no activation");

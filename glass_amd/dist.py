@@ -200,3 +200,39 @@ def predict_collective_us(payload_bytes, world):
     ag = t(payload_bytes.get("big_all_gather", 0), n - 1, 1.0 / n)
     out.update(small_allreduce_us=small, big_reduce_scatter_us=rs, big_all_gather_us=ag, total_us=small + rs + ag)
     return out
+
+
+# The one-shot form of the small-bucket exchange (glass_amd/peer.py, csrc/peer_allreduce.hip): every rank reads its N - 1 peers'
+# gradient arenas through xGMI peer mappings — N - 1 links side by side, ONE dependent hop (flag store -> remote poll) instead of
+# a ring's 2 (N - 1) — reduces in fixed rank order and applies Adam in the same launch.  Same status: assumed constants.
+MODEL_T_ONESHOT_FLAG_US = 4.0   # publish "my gradients are final" + see every peer's flag (one store + one polled read over xGMI)
+
+
+def predict_oneshot_us(payload_bytes, world):
+    """Predicted EXTRA device time of the one-shot fused all-reduce + Adam over the plain (1-rank) Adam launch it replaces."""
+    n = int(world)
+    if n <= 1:
+        return 0.0
+    nbytes = payload_bytes.get("small_allreduce", 0)
+    bw = MODEL_LINK_GBPS * MODEL_LINK_EFF * 1e3
+    return MODEL_T_ONESHOT_FLAG_US + nbytes / bw   # each peer's arena crosses its own link once
+
+
+def predict_scaling(payload_bytes, step_ms_1gpu, overlaps_small=False, worlds=(1, 2, 4, 8)):
+    """The forecast a SCALE run is to be held against (weak scaling, replicated graph: per-rank work is the 1-GPU step): per
+    world size the exchange time under the ring model, what of it is exposed (all of it unless the small bucket overlaps the
+    backward tail — embedding-sized bucket only), the predicted step time and efficiency = step / (step + exposed); the same
+    for the one-shot fused form."""
+    out = []
+    for n in worlds:
+        p = predict_collective_us(payload_bytes, n)
+        exposed = p["total_us"] - (p["small_allreduce_us"] if overlaps_small else 0.0)
+        one = predict_oneshot_us(payload_bytes, n) + p["big_reduce_scatter_us"] + p["big_all_gather_us"]
+        step_us = step_ms_1gpu * 1e3
+        out.append({"world": n, "ring_exchange_us": p["total_us"], "ring_exposed_us": exposed,
+                    "ring_efficiency": step_us / (step_us + exposed) if step_us > 0 else None,
+                    "oneshot_exposed_us": one, "oneshot_efficiency": step_us / (step_us + one) if step_us > 0 else None})
+    return {"per_world": out, "step_ms_1gpu": step_ms_1gpu,
+            "model": {"t_launch_us": MODEL_T_LAUNCH_US, "t_hop_us": MODEL_T_HOP_US, "link_GBps": MODEL_LINK_GBPS,
+                      "link_efficiency": MODEL_LINK_EFF, "t_oneshot_flag_us": MODEL_T_ONESHOT_FLAG_US,
+                      "status": "assumed constants, not measured on this pool (no multi-GPU run has been available)"}}

@@ -423,3 +423,45 @@ def test_evaluation_before_the_first_training_epoch_is_not_replayed_on_stale_par
     want = float(reference_binary_loss(eager_score(), y))
     assert abs(float(l1) - want) < 1e-6 * max(1.0, abs(want)), (float(l1), want, float(l0))
     assert abs(float(l1) - float(l0)) > 1e-3, "training did not move the loss: the check above proves nothing"
+
+
+_SWITCHES = [("glass_amd.train", "USE_STEP", False), ("glass_amd.train", "USE_GRAPH", False), ("glass_amd.train", "USE_HEAD_LABELS", False),
+             ("glass_amd.train", "USE_EVAL_GRAPH", False), ("glass_amd.models", "USE_STACK", False), ("glass_amd.ops", "USE_FUSED_DENSE", False),
+             ("glass_amd.stack", "USE_COMB_EFF", False), ("glass_amd.stack", "USE_GN_EXACT", False), ("glass_amd.stack", "USE_READOUT", False),
+             ("glass_amd.stack", "USE_READOUT_TWO", False), ("glass_amd.stack", "USE_GN_BWD_IN_COMB", False),
+             ("glass_amd.stack", "USE_GATHER_IN_TRANS", False), ("glass_amd.stack", "USE_EMBED_TABLE", False),
+             ("glass_amd.stack", "USE_FUSED_TAIL", False), ("glass_amd.stack", "USE_FUSED_BWD", False), ("glass_amd.ops", "DENSE_F32_PRODUCTS", True)]
+
+
+@pytest.mark.parametrize("module,name,value", _SWITCHES, ids=[f"{m.split('.')[-1]}.{n}" for m, n, _ in _SWITCHES])
+def test_every_python_switch_family_reproduces_g8(module, name, value, monkeypatch):
+    """One suite case per Python A/B switch (the environment variables GLASS_TRAIN_STEP / GLASS_TRAIN_GRAPH / GLASS_HEAD_LABELS /
+    GLASS_EVAL_GRAPH / GLASS_STACK / GLASS_FUSED_DENSE / GLASS_COMB_EFF / GLASS_GN_EXACT / GLASS_READOUT(_TWO) /
+    GLASS_GN_BWD_IN_COMB / GLASS_GATHER_IN_TRANS / GLASS_EMBED_TABLE / GLASS_FUSED_TAIL / GLASS_FUSED_BWD / GLASS_DENSE_SPLIT) in
+    its NON-default position: the reference's three Adam steps (fixture g8: losses and final weights from a run of the
+    reference itself) through impl.train.train with the reference's own objects, then an evaluation pass through
+    impl.train.test that equals eager forwards — every fallback form of the product is the same arithmetic."""
+    import importlib
+    from impl import SubGDataset, train, metrics, utils
+    monkeypatch.setattr(importlib.import_module(module), name, value)
+    g, x, ei, ew, pos, y = _g8()
+    gnn = reference_build_model(int(g["hidden"]), int(g["layers"]), 0.0, True, str(g["pool"]), float(g["z_ratio"]), str(g["aggr"]),
+                                torch.max(x), 3)
+    gnn.load_state_dict(sd_from(g))
+    optimizer = Adam(gnn.parameters(), lr=float(g["lr"]))
+    loss_fn = CrossEntropyLoss()
+    got = []
+    for k in range(3):
+        ds = SubGDataset.GDataset(x, ei, ew, pos[4 * k:4 * k + 4], y[4 * k:4 * k + 4])
+        got.append(train.train(optimizer, gnn, reference_loader(ds, 4, shuffle=False), loss_fn))
+    assert np.allclose(got, g["losses"], rtol=1e-5, atol=0), (module, name, got, g["losses"])
+    end = sd_from(g, "sd_end/")
+    keys = sorted(end)
+    mine = {k: v.cpu() for k, v in gnn.state_dict().items()}
+    assert rel_inf(flat_grads(mine, keys), flat_grads(end, keys)) < 1e-4
+    ds = SubGDataset.GDataset(x, ei, ew, pos, y)
+    _s, l1 = train.test(gnn, reference_loader(ds, 4, shuffle=False, drop_last=False), metrics.microf1, loss_fn)
+    gnn.eval()
+    with torch.no_grad():
+        want = loss_fn(torch.cat([gnn(x, ei, ew, pos[i:i + 4], utils.MaxZOZ(x, pos[i:i + 4])) for i in range(0, pos.shape[0], 4)]), y)
+    assert abs(float(l1) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))

@@ -118,6 +118,7 @@ int main(int argc, char** argv) {
     else if (shape == "powerlaw") n = 1000000, pairs = 10000000, zipf = 0.8;
     else if (shape == "density-like") n = 4998, pairs = 29962;
     else if (shape.rfind("calib:", 0) == 0) n = atoll(shape.c_str() + 6), pairs = -1;
+    else if (shape.rfind("file:", 0) == 0) n = 0, pairs = -2;  // a CSR dumped by bench.py (the shipped density graph): see below
     else {
         double z = 0;
         long long a = 0, b = 0;
@@ -129,7 +130,26 @@ int main(int argc, char** argv) {
         n = a, pairs = b, zipf = z;
     }
     Graph g;
-    if (pairs < 0) {  // permutation matrix
+    if (pairs == -2) {
+        // file:<path> — int64 n, int64 nnz, int32 rowptr[n + 1], int32 col[nnz], float val[nnz] (little endian, as numpy wrote them)
+        FILE* f = fopen(shape.c_str() + 5, "rb");
+        int64_t hdr[2] = {0, 0};
+        if (!f || fread(hdr, 8, 2, f) != 2 || hdr[0] <= 0 || hdr[1] <= 0) {
+            fprintf(stderr, "cannot read %s\n", shape.c_str() + 5);
+            return 1;
+        }
+        n = hdr[0];
+        g.n = n;
+        g.rowptr.resize(n + 1);
+        g.col.resize(hdr[1]);
+        g.val.resize(hdr[1]);
+        if (fread(g.rowptr.data(), 4, n + 1, f) != (size_t)(n + 1) || fread(g.col.data(), 4, hdr[1], f) != (size_t)hdr[1] ||
+            fread(g.val.data(), 4, hdr[1], f) != (size_t)hdr[1]) {
+            fprintf(stderr, "short read on %s\n", shape.c_str() + 5);
+            return 1;
+        }
+        fclose(f);
+    } else if (pairs < 0) {  // permutation matrix
         g.n = n;
         g.rowptr.resize(n + 1);
         g.col.resize(n);
