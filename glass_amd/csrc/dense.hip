@@ -583,7 +583,12 @@ __device__ __forceinline__ void dual_dgrad_body(const float* __restrict__ dsrc, 
 // the layer input's dropout, and for the GraphNorm whose output gradient this is  u = keep-scale . act'(x scale + shift)
 // and  xhat . u  — one dropout hash per float4, none in the epilogue; no conditional memory instruction in the stage loop.
 // Image: layout kLayoutWave16Cols of W^T ([64 outputs][128 = f1 | f0]).
-template <int H>
+// SP (hidden 64, inside the fused backward launch): the product in the split form (split_mma.h) — the loader cuts its eight
+// elements of dZ once into three bf16 planes ([piece][row][k], rows 136 bf16 apart), the wave its weight slice once; 24 MFMAs
+// of 16 cycles per stage instead of 32 of 32.  In the fused launch two workgroups share a CU's matrix pipes (this body's tiles and
+// the weight-gradient slabs): there the matrix time IS the launch time (a timing-only build that skipped 5 of 8 MFMAs in the
+// four backward bodies: 0.2418 -> 0.2311 ms per step at ppi_bp-shape).
+template <int H, bool SP = false>
 __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc, int64_t ldd, const float* __restrict__ T,
                                                   int64_t ldt, const uint8_t* __restrict__ mask, float zr, float omz, int act,
                                                   const float* __restrict__ WT, const float* __restrict__ addend, int64_t ldadd,
@@ -592,7 +597,10 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
     static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
     constexpr int NTL = H / 16, KF4 = (2 * H) / 16;
     constexpr int KT = 2 * H, RA = KT + 4, RP = H + 4;
-    constexpr int kBuf = 16 * RA + 4 * 16 * RP;  // A | ADD | M | U | XU  (floats per stage buffer)
+    static_assert(!SP || H == 64, "split form: hidden 64");
+    constexpr int RSB = KT + 8, kPlane = 16 * RSB;  // SP: bf16 per row of a piece plane, per plane
+    constexpr int kAFloats = SP ? (3 * kPlane) / 2 : 16 * RA;
+    constexpr int kBuf = kAFloats + 4 * 16 * RP;  // A | ADD | M | U | XU  (floats per stage buffer)
     int* rows_s = reinterpret_cast<int*>(lds + 2 * kBuf);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
@@ -606,6 +614,16 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
     float4 bw[KF4];
 #pragma unroll
     for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+    uint4 bwc[SP ? KF4 / 2 : 1][3];  // SP: block b = the lane's k = (KT / 4) q + 8 b .. + 7 (bw[2b], bw[2b + 1])
+    if constexpr (SP) {
+#pragma unroll
+        for (int b = 0; b < KF4 / 2; ++b) {
+            const Split4 c0 = split4(bw[2 * b]), c1 = split4(bw[2 * b + 1]);
+            bwc[b][0] = make_uint4(c0.hi.x, c0.hi.y, c1.hi.x, c1.hi.y);
+            bwc[b][1] = make_uint4(c0.mid.x, c0.mid.y, c1.mid.x, c1.mid.y);
+            bwc[b][2] = make_uint4(c0.lo.x, c0.lo.y, c1.lo.x, c1.lo.y);
+        }
+    }
     int my_row[4];
 #pragma unroll
     for (int st = 0; st < 4; ++st) my_row[st] = r0 + 16 * st + rs < N ? (int)(r0 + 16 * st + rs) : -1;
@@ -647,7 +665,7 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
     if (tid < 64) rows_s[tid] = r0 + tid < N ? (int)(r0 + tid) : -1;
     auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
         float* A = lds + (st & 1) * kBuf;
-        float* ADD = A + 16 * RA;
+        float* ADD = A + kAFloats;
         float* M = ADD + 16 * RP;
         float* U = M + 16 * RP;
         float* XU = U + 16 * RP;
@@ -668,8 +686,19 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
             u[k] = uk;
             xu[k] = (xv[k] - g_al[k] * g_mu[k]) * g_rs[k] * uk;
         }
-        *reinterpret_cast<float4*>(A + rs * RA + 4 * ga) = make_float4(z1[0], z1[1], z1[2], z1[3]);
-        *reinterpret_cast<float4*>(A + rs * RA + H + 4 * ga) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        if constexpr (SP) {
+            const Split4 s1c = split4(make_float4(z1[0], z1[1], z1[2], z1[3])), s0c = split4(make_float4(z0[0], z0[1], z0[2], z0[3]));
+            unsigned short* P = reinterpret_cast<unsigned short*>(A) + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = s1c.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = s1c.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = s1c.lo;
+            *reinterpret_cast<uint2*>(P + H) = s0c.hi;
+            *reinterpret_cast<uint2*>(P + kPlane + H) = s0c.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane + H) = s0c.lo;
+        } else {
+            *reinterpret_cast<float4*>(A + rs * RA + 4 * ga) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+            *reinterpret_cast<float4*>(A + rs * RA + H + 4 * ga) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        }
         *reinterpret_cast<float4*>(ADD + rs * RP + 4 * ga) = R.ad;
         *reinterpret_cast<float4*>(M + rs * RP + 4 * ga) = make_float4(m[0], m[1], m[2], m[3]);
         *reinterpret_cast<float4*>(U + rs * RP + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
@@ -683,13 +712,22 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const float* A = lds + (st & 1) * kBuf;
-        const float* ADD = A + 16 * RA;
+        const float* ADD = A + kAFloats;
         const float* M = ADD + 16 * RP;
         const float* U = M + 16 * RP;
         const float* XU = U + 16 * RP;
-        float4 a4[KF4];
+        float4 a4[SP ? 1 : KF4];
+        uint4 af[SP ? KF4 / 2 : 1][3];
+        if constexpr (SP) {
+            const unsigned short* P = reinterpret_cast<const unsigned short*>(A) + j * RSB + (KT / 4) * q;
 #pragma unroll
-        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(A + j * RA + (KT / 4) * q + 4 * tt);
+            for (int b = 0; b < KF4 / 2; ++b)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) af[b][pc] = *reinterpret_cast<const uint4*>(P + pc * kPlane + 8 * b);
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(A + j * RA + (KT / 4) * q + 4 * tt);
+        }
         int rv[4];
         float ad[4], mm[4], uu[4], xx[4];
 #pragma unroll
@@ -701,15 +739,31 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
             xx[r] = XU[(4 * q + r) * RP + c];
         }
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP) {
+#define GLASS_SMMA16(ACC, B, pa, pb)                                                                                  \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[B][pa]), __builtin_bit_cast(bf16x8, bwc[B][pb]), ACC, 0, 0, 0)
 #pragma unroll
-        for (int tt = 0; tt < KF4; tt += 2) {
-            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
-            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
-            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+            for (int b = 0; b < KF4 / 2; b += 2) {  // two K blocks side by side (two chains), small terms first
+                GLASS_SMMA16(acc0, b, 1, 1); GLASS_SMMA16(acc1, b + 1, 1, 1);
+                GLASS_SMMA16(acc0, b, 2, 0); GLASS_SMMA16(acc1, b + 1, 2, 0);
+                GLASS_SMMA16(acc0, b, 0, 2); GLASS_SMMA16(acc1, b + 1, 0, 2);
+                GLASS_SMMA16(acc0, b, 1, 0); GLASS_SMMA16(acc1, b + 1, 1, 0);
+                GLASS_SMMA16(acc0, b, 0, 1); GLASS_SMMA16(acc1, b + 1, 0, 1);
+                GLASS_SMMA16(acc0, b, 0, 0); GLASS_SMMA16(acc1, b + 1, 0, 0);
+            }
+#undef GLASS_SMMA16
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+            for (int tt = 0; tt < KF4; tt += 2) {
+                const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+                const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+                const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!GLASS_MFMA_KEEP(tt * 2 + e)) continue;
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+                }
             }
         }
         if (st + 1 < 4) {
@@ -927,6 +981,7 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int ti
 constexpr size_t trans_dgrad3_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 32) * sizeof(float); }
 
 constexpr size_t trans_dgrad2_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 64) * sizeof(float); }
+constexpr size_t kTransDgrad2SplitLds = (size_t)(2 * ((3 * 16 * (2 * 64 + 8)) / 2 + 4 * 16 * (64 + 4)) + 64) * sizeof(float);  // SP at hidden 64
 constexpr size_t kTransDgrad2Lds = trans_dgrad2_lds(64);
 
 template <int H>
@@ -954,7 +1009,7 @@ __global__ __launch_bounds__(kWave * RW * CS) void dual_dgrad_kernel(DgradArgs A
 // branches of ONE launch their workgroups share the CUs (two per CU: <= 256 registers, 68 KiB LDS) and the pair costs
 // about the longer of the two instead of their sum, with one launch boundary less.  (The same overlap through a
 // second stream inside the captured step cost more in graph edges than it saved: DESIGN.md §5.)
-template <int H, int NT>
+template <int H, int NT, bool SP = false>
 __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_dgrad_blocks, const float* __restrict__ X,
                                                             int64_t ldx, int O, int I, int rows_per_slab, int gx, int gy,
                                                             float* __restrict__ part_w, float* __restrict__ part_b,
@@ -971,8 +1026,8 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
     if (b < n_dgrad_blocks) {
         D_STAMP(4, 0);
         if (GLASS_TRANS_DGRAD_V2 && H == 64 && NT == 64)
-            trans_dgrad2_body<64>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
-                                  A.rng_state, A.out, A.ldo, A.N, A.gs, b, reinterpret_cast<float*>(lds_w));
+            trans_dgrad2_body<64, SP>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
+                                      A.rng_state, A.out, A.ldo, A.N, A.gs, b, reinterpret_cast<float*>(lds_w));
         else
             dual_dgrad_body<H, NT, 1, 4>(A.dsrc, A.ldd, A.T, A.ldt, A.mask, A.zr, A.omz, A.act, A.WT, A.addend, A.ldadd, A.drop,
                                          A.rng_state, A.out, A.ldo, A.N, A.gs, b, lds_w);
@@ -983,7 +1038,10 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
     const int t = b - n_dgrad_blocks;  // slab fastest, then input tile, then output tile (as the 3-D grid of the stand-alone launch)
     float* lds = reinterpret_cast<float*>(lds_w);
     if (staged2) {
-        wgrad_trans_staged2_body(X, ldx, A.N, rows_per_slab, part_w, part_b, sy, t, lds);
+        if constexpr (SP)
+            wgrad_trans_staged2s_body(X, ldx, A.N, rows_per_slab, part_w, part_b, sy, t, lds);
+        else
+            wgrad_trans_staged2_body(X, ldx, A.N, rows_per_slab, part_w, part_b, sy, t, lds);
         D_STAMP(4, 6);
         return;
     }
@@ -1983,18 +2041,22 @@ __global__ __launch_bounds__(kBlock) void comb_dgrad_eff_kernel(DgradEffArgs A) 
 // Image: layout kLayoutWave16EffDgradCols (tile t = columns 64 (t >> 2) + 16 (t & 3) .. + 15 of [dg || dx_]).
 // The data-gradient half alone, as a device function for the workgroups [0, n_dgrad) of comb_bwd_eff_kernel (the weight
 // gradient stays with its own workgroups there): image in layout kLayoutWave16EffDgradCols, `lds` >= kCombDgrad2Lds bytes.
-template <int H, bool DROP>
+// SP: the two products in the split form (split_mma.h; see trans_dgrad2_body): dc cut once by the loader into three bf16
+// planes ([piece][row][k], rows 72 bf16 apart), the two weight slices cut once per wave; 24 MFMAs of 16 cycles per stage.
+template <int H, bool DROP, bool SP = false>
 __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk, float* lds) {
     static_assert(H == 64, "four waves x 16 columns");
     constexpr int RS = H + 4;   // plain tiles [16 rows][H]: row stride (floats)
+    constexpr int RSB = H + 8, kPlane = 16 * RSB;  // SP: bf16 per row of a piece plane, per plane
+    constexpr int kDcFloats = SP ? (3 * kPlane) / 2 : 16 * RS;
     struct __attribute__((aligned(16))) Stage {
-        float dcP[16 * RS];       // dc rows (A operand)
+        float dcP[kDcFloats];     // dc rows (A operand; SP: the three bf16 planes)
         float U[16 * RS];         // keep-scale of the GraphNorm's dropout per element of the g half
         float XU[16 * RS];        // xhat * keep-scale
     };
     Stage* stg = reinterpret_cast<Stage*>(lds);
-    int* rows_s = reinterpret_cast<int*>(lds + 2 * (3 * 16 * RS));
-    float* coef_s = lds + 2 * (3 * 16 * RS) + 64;  // [5][64] A | Bx | K | scale | shift of the GraphNorm dc comes from (src)
+    int* rows_s = reinterpret_cast<int*>(lds + 2 * (kDcFloats + 2 * 16 * RS));
+    float* coef_s = lds + 2 * (kDcFloats + 2 * 16 * RS) + 64;  // [5][64] A | Bx | K | scale | shift of the GraphNorm dc comes from (src)
     const GnBwdSrc& src = A.src;
     const bool src_on = src.acc != nullptr;
     D_STAMP(3, 0);
@@ -2027,6 +2089,20 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
     for (int v = 0; v < 4; ++v) {
         bwg[v] = img[(w * 4 + v) * 64 + lane];
         bwx[v] = img[((4 + w) * 4 + v) * 64 + lane];
+    }
+    uint4 bwgc[SP ? 2 : 1][3], bwxc[SP ? 2 : 1][3];  // SP: block b = the lane's k = 16 q + 8 b .. + 7
+    if constexpr (SP) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const Split4 c0 = split4(bwg[2 * b]), c1 = split4(bwg[2 * b + 1]);
+            bwgc[b][0] = make_uint4(c0.hi.x, c0.hi.y, c1.hi.x, c1.hi.y);
+            bwgc[b][1] = make_uint4(c0.mid.x, c0.mid.y, c1.mid.x, c1.mid.y);
+            bwgc[b][2] = make_uint4(c0.lo.x, c0.lo.y, c1.lo.x, c1.lo.y);
+            const Split4 d0 = split4(bwx[2 * b]), d1 = split4(bwx[2 * b + 1]);
+            bwxc[b][0] = make_uint4(d0.hi.x, d0.hi.y, d1.hi.x, d1.hi.y);
+            bwxc[b][1] = make_uint4(d0.mid.x, d0.mid.y, d1.mid.x, d1.mid.y);
+            bwxc[b][2] = make_uint4(d0.lo.x, d0.lo.y, d1.lo.x, d1.lo.y);
+        }
     }
     const int rs = tid >> 4, ga = tid & 15;  // loader role: row rs of the stage, columns 4 ga .. 4 ga + 3
     int my_row[4];
@@ -2099,7 +2175,15 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
             dcv = gn_bwd_apply4(R.dc, R.sx, R.sad, coef_s, 4 * ga, src.act, sds);
             if (r < 0) dcv = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        *reinterpret_cast<float4*>(S.dcP + rs * RS + 4 * ga) = dcv;
+        if constexpr (SP) {
+            const Split4 sc = split4(dcv);
+            unsigned short* P = reinterpret_cast<unsigned short*>(S.dcP) + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = sc.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = sc.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = sc.lo;
+        } else {
+            *reinterpret_cast<float4*>(S.dcP + rs * RS + 4 * ga) = dcv;
+        }
         const float av[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
         float ds[4] = {1.f, 1.f, 1.f, 1.f};
         if (DROP) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
@@ -2121,9 +2205,18 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
         const Stage& S = stg[st & 1];
-        float4 a4[4];
+        float4 a4[SP ? 1 : 4];
+        uint4 af[SP ? 2 : 1][3];
+        if constexpr (SP) {
+            const unsigned short* P = reinterpret_cast<const unsigned short*>(S.dcP) + j * RSB + 16 * q;
 #pragma unroll
-        for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(S.dcP + j * RS + 16 * q + 4 * v);
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) af[b][pc] = *reinterpret_cast<const uint4*>(P + pc * kPlane + 8 * b);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) a4[v] = *reinterpret_cast<const float4*>(S.dcP + j * RS + 16 * q + 4 * v);
+        }
         int rv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) rv[r] = rows_s[16 * st + 4 * q + r];
@@ -2134,14 +2227,30 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
             xx[r] = S.XU[(4 * q + r) * RS + cg];
         }
         f32x4 accg = {0.f, 0.f, 0.f, 0.f}, accx = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP) {
+#define GLASS_SMMA16(ACC, BW, pa, pb)                                                                                 \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[b][pa]), __builtin_bit_cast(bf16x8, BW[b][pb]), ACC, 0, 0, 0)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) {
-            const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
-            const float yg[4] = {bwg[v].x, bwg[v].y, bwg[v].z, bwg[v].w}, yx[4] = {bwx[v].x, bwx[v].y, bwx[v].z, bwx[v].w};
+            for (int b = 0; b < 2; ++b) {  // small terms first; the two halves' chains interleave
+                GLASS_SMMA16(accg, bwgc, 1, 1); GLASS_SMMA16(accx, bwxc, 1, 1);
+                GLASS_SMMA16(accg, bwgc, 2, 0); GLASS_SMMA16(accx, bwxc, 2, 0);
+                GLASS_SMMA16(accg, bwgc, 0, 2); GLASS_SMMA16(accx, bwxc, 0, 2);
+                GLASS_SMMA16(accg, bwgc, 1, 0); GLASS_SMMA16(accx, bwxc, 1, 0);
+                GLASS_SMMA16(accg, bwgc, 0, 1); GLASS_SMMA16(accx, bwxc, 0, 1);
+                GLASS_SMMA16(accg, bwgc, 0, 0); GLASS_SMMA16(accx, bwxc, 0, 0);
+            }
+#undef GLASS_SMMA16
+        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                accg = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yg[e], accg, 0, 0, 0);
-                accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yx[e], accx, 0, 0, 0);
+            for (int v = 0; v < 4; ++v) {
+                const float x[4] = {a4[v].x, a4[v].y, a4[v].z, a4[v].w};
+                const float yg[4] = {bwg[v].x, bwg[v].y, bwg[v].z, bwg[v].w}, yx[4] = {bwx[v].x, bwx[v].y, bwx[v].z, bwx[v].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!GLASS_MFMA_KEEP(v * 4 + e)) continue;
+                    accg = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yg[e], accg, 0, 0, 0);
+                    accx = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], yx[e], accx, 0, 0, 0);
+                }
             }
         }
         // next stage -> LDS (the other buffer: its last readers passed the barrier at the end of the previous iteration)
@@ -2184,6 +2293,7 @@ __device__ __forceinline__ void comb_dgrad2_body(const DgradEffArgs& A, int blk,
     D_STAMP(3, 4);
 }
 constexpr size_t kCombDgrad2Lds = (size_t)(2 * 3 * 16 * (64 + 4) + 64 + 5 * 64) * sizeof(float);
+constexpr size_t kCombDgrad2SplitLds = (size_t)(2 * ((3 * 16 * (64 + 8)) / 2 + 2 * 16 * (64 + 4)) + 64 + 5 * 64) * sizeof(float);  // SP
 
 #if GLASS_LAB
 #include "../../tools/lab/comb_bwd_eff2.inc"  // one-pass staged comb backward (GLASS_COMB_BWD_V2; measured slower): laboratory builds only
@@ -2191,7 +2301,7 @@ constexpr size_t kCombDgrad2Lds = (size_t)(2 * 3 * 16 * (64 + 4) + 64 + 5 * 64) 
 
 // Fused backward launch of the comb pair in effective-weight form: data-gradient row tiles (main + extra), then the
 // weight-gradient blocks in S / L form (wgrad_sl_body: row slabs, then the labeled-row tiles).
-template <int H>
+template <int H, bool SP = false>
 __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A, int n_dgrad_blocks, WgradSL sl, float zr,
                                                                 float* __restrict__ part_w, float* __restrict__ part_b) {
     extern __shared__ float4 lds_w[];
@@ -2208,9 +2318,9 @@ __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A,
             DgradEffArgs A2 = A;
             A2.WT = A.WT + 2 * (2 * H * H);
             if (A.gs.partial && A.gs.drop.p > 0.f)
-                comb_dgrad2_body<H, true>(A2, b, reinterpret_cast<float*>(lds_w));
+                comb_dgrad2_body<H, true, SP>(A2, b, reinterpret_cast<float*>(lds_w));
             else
-                comb_dgrad2_body<H, false>(A2, b, reinterpret_cast<float*>(lds_w));
+                comb_dgrad2_body<H, false, SP>(A2, b, reinterpret_cast<float*>(lds_w));
         } else {
             comb_dgrad_eff_body<H, 4>(A.dsrc, A.ldd, A.mask, A.WT, A.rng_state, A.out, A.ldo, A.N, A.gs, A.lab, b, lds_w);
         }
@@ -2220,7 +2330,10 @@ __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A,
     D_STAMP(3, 5);
     float* lds = reinterpret_cast<float*>(lds_w);
     if (GLASS_SL_STAGED2) {
-        wgrad_sl_staged2_body(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds);
+        if constexpr (SP)
+            wgrad_sl_staged2s_body(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds);
+        else
+            wgrad_sl_staged2_body(sl, A.N, b - n_dgrad_blocks, part_w, part_b, lds);
         D_STAMP(3, 6);
         return;
     }
@@ -2755,7 +2868,17 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         const size_t lds_wg = (size_t)(2 * kTile + 8 * kOT) * sizeof(float);
         const size_t lds_fused = lds_dg > lds_wg ? lds_dg : lds_wg;
         const unsigned blocks = grid.x + (unsigned)(g.n_slabs * g.ny * g.nz);
-        if (n_out == H) {
+        // split products (the call's option, as in the forward): both bodies of the trans pair's fused launch, when they are the
+        // staged ones (slabs of whole 32-row stages: wgrad_geom rounds them so for every fused launch)
+        const bool sp = n_out == H && h64_split_products() && GLASS_TRANS_DGRAD_V2 && GLASS_TRANS_WGRAD_STAGED2 && O == 128 && I == 64 &&
+                        g.ny == 1 && g.rows_per_slab % 32 == 0;
+        if (sp) {
+            const size_t lds_sp = std::max(kTransDgrad2SplitLds, kStg2sLdsBytes);
+            allow_lds(dual_bwd_kernel<64, 64, true>, lds_sp);
+            hipLaunchKernelGGL((dual_bwd_kernel<64, 64, true>), dim3(blocks), dim3(kBlock), lds_sp, st, dargs, (int)grid.x, wg->X,
+                               wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats,
+                               part_w + g.part_w_floats + g.part_b_floats - kWgradHeaderFloats, sy);
+        } else if (n_out == H) {
             allow_lds(dual_bwd_kernel<64, 64>, lds_fused);
             hipLaunchKernelGGL((dual_bwd_kernel<64, 64>), dim3(blocks), dim3(kBlock), lds_fused, st, dargs, (int)grid.x, wg->X,
                                wg->ldx, (int)O, (int)I, g.rows_per_slab, g.n_slabs, g.ny, part_w, part_w + g.part_w_floats,
@@ -2999,6 +3122,7 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
                                       uint64_t gn_call_id, int gn_exact, const float* X, int64_t ldx, const float* X2,
                                       int64_t ldx2, void* ws, const int32_t* lab_rows, const int32_t* lab_count,
                                       int64_t lab_cap, const glass_gn_bwd_src* dsrc_gn, void* stream) {
+    const CallOptions call_options(gn_act);  // gn_act word -> activation code of conv.gn + this call's options (product form)
     GLASS_REQUIRE((dsrc || dsrc_gn) && mask && WTimg_eff && out && lab_rows && lab_count && n_nodes > 0 && lab_cap >= 0,
                   "comb_eff_bwd: null pointer");
     GnBwdSrc gsrc{};
@@ -3069,6 +3193,14 @@ extern "C" int glass_comb_eff_bwd_f32(const float* dsrc, int64_t ldd, const uint
     const size_t lds_wg = (size_t)(2 * kTile + 8 * kSLOut) * sizeof(float);
     static_assert(kCombDgrad2Lds <= (size_t)(2 * kTile + 8 * kSLOut) * sizeof(float), "the staged data gradient fits the fused launch's LDS");
     const size_t lds_fused = lds_dg > lds_wg ? lds_dg : lds_wg;
+    if (h64_split_products() && GLASS_COMB_DGRAD_V2 && GLASS_SL_STAGED2 && g.rows_per_slab % 32 == 0) {
+        // split products (the call's option: GLASS_DENSE_F32_PRODUCTS in gn_act opts out) in both staged bodies
+        const size_t lds_sp = std::max(kCombDgrad2SplitLds, kStg2sLdsBytes);
+        allow_lds(comb_bwd_eff_kernel<64, true>, lds_sp);
+        hipLaunchKernelGGL((comb_bwd_eff_kernel<64, true>), dim3(n_dg + (unsigned)(g.n_s + g.n_l)), dim3(kBlock), lds_sp, st, dargs,
+                           (int)n_dg, sl, zr, part_w, part_b);
+        return launch_status("glass_comb_eff_bwd_f32");
+    }
     allow_lds(comb_bwd_eff_kernel<64>, lds_fused);
     hipLaunchKernelGGL((comb_bwd_eff_kernel<64>), dim3(n_dg + (unsigned)(g.n_s + g.n_l)), dim3(kBlock), lds_fused, st, dargs,
                        (int)n_dg, sl, zr, part_w, part_b);

@@ -123,6 +123,13 @@ int lab_knob(const char* name, int dflt);
 #else
 inline int lab_knob(const char*, int dflt) { return dflt; }
 #endif
+// Timing-only laboratory switch (results WRONG): keep 3 of every 8 MFMAs of the hidden-64 backward bodies — the matrix-core
+// time their split product form would leave (6/16) — to bound what that form can return before building it.  Never in the product.
+#if GLASS_LAB && defined(GLASS_LAB_MFMA38)
+#define GLASS_MFMA_KEEP(i) (((i) & 7) < 3)
+#else
+#define GLASS_MFMA_KEEP(i) true
+#endif
 int tiled_rows(int64_t H);  // rows per workgroup = rows per statistics partial of the tiled kernels (64 at hidden 128, else 128)
 int launch_tiled_fwd(const float* xa, int64_t lda, const float* xb, int64_t ldb, const float* Wimg, const float* bias,
                      const uint8_t* mask, float zr, float omz, int act, float* T, int64_t ldt, float* out, int64_t ldo,

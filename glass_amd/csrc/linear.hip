@@ -396,7 +396,7 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     int64_t rows = ceil_div(N, max_slabs);
     if (rows < 64) rows = 64;
     rows = ceil_div(rows, 8) * 8;  // whole row pairs for each of the 4 waves
-    if (N <= kFusedBwdMaxRows) rows = ceil_div(rows, 16) * 16;  // (the staged bodies of the fused launches walk 16-row stages)
+    if (N <= kFusedBwdMaxRows) rows = ceil_div(rows, 32) * 32;  // (the staged bodies of the fused launches walk 16-row stages, 32-row ones in the split form)
     g.rows_per_slab = (int)rows;
     g.n_slabs = (int)ceil_div(N, rows);
     g.ny = (int)ceil_div(I, kIT);
@@ -486,6 +486,7 @@ WgradSLGeom wgrad_sl_geom(int64_t N, int64_t lab_cap) {
     int64_t rows = ceil_div(N, room);
     if (rows < 64) rows = 64;
     rows = ceil_div(rows, 8) * 8;  // whole row pairs for each of the 4 waves
+    if (N <= kFusedBwdMaxRows) rows = ceil_div(rows, 32) * 32;  // whole 32-row stages of the staged body's split form (dense.hip)
     g.rows_per_slab = (int)rows;
     g.n_s = (int)ceil_div(N, rows);
     g.part_w_floats = (int64_t)(g.n_s + g.n_l) * kTile;

@@ -427,6 +427,7 @@ __device__ __forceinline__ void wgrad_trans_staged2_body(const float* __restrict
                 const float av[4] = {at[a].x, at[a].y, at[a].z, at[a].w};
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
+                    if (!GLASS_MFMA_KEEP((e * 2 + a) * 4 + it)) continue;
                     const float bv[4] = {bt[it].x, bt[it].y, bt[it].z, bt[it].w};
                     acc[a][it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[a][it], 0, 0, 0);
                 }
@@ -584,6 +585,7 @@ __device__ __forceinline__ void wgrad_sl_staged2_body(const WgradSL& a, int64_t 
         for (int e = 0; e < 4; ++e)
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
+                if (!GLASS_MFMA_KEEP(e * 8 + it)) continue;
                 const float bv[4] = {bt[it].x, bt[it].y, bt[it].z, bt[it].w};
                 acc[it] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[e], acc[it], 0, 0, 0);
             }
@@ -614,6 +616,322 @@ __device__ __forceinline__ void wgrad_sl_staged2_body(const WgradSL& a, int64_t 
 #pragma unroll
         for (int r = 0; r < 4; ++r) pw[(16 * w + 4 * q + r) * (2 * H) + 16 * it + j] = acc[it][r];
     if (tid < H) part_b[(int64_t)blk * kSLOut + tid] = bsum;
+}
+
+// ---- the two staged bodies above in the split product form (hidden 64, round 6) ----------------------------------------
+// v_mfma_f32_16x16x32_bf16 sums over 32 node rows per instruction, so a stage is 32 rows: every thread loads TWO rows (2 rp,
+// 2 rp + 1) x one column quad per operand, synthesises its elements, cuts each column's row pair into three bf16 pieces
+// (split2: the pair packed in one word — exactly the unit the transposed image stores) and writes three words per column.
+// Image per operand: [piece][column][32 rows] bf16 = 64 bytes per column, NO padding (two buffers of dZ^T [128] + X^T [64]
+// = 72 KiB: two workgroups per CU stay resident); the 16-byte chunk q (rows 8 q .. 8 q + 7) of column c lies at chunk
+// q ^ ((c >> 2) & 3), so the 16 lanes of a fragment read (16 consecutive columns, one q) touch 16 different bank groups
+// 48 MFMAs of 16 cycles per 32 rows where the f32-input form runs 64 of 32.  Bias partials: the loaders sum what they
+// synthesise (lane shuffles over the row pairs, one pass through LDS over the waves).  Partial tiles as the f32 bodies write them.
+constexpr int kStg2sWordsA = 3 * 128 * 16, kStg2sWordsB = 3 * 64 * 16;   // 32-bit words of the two images of one buffer (trans pair)
+constexpr int kStg2sWords = kStg2sWordsA + kStg2sWordsB;                 // 9 216 words = 36 KiB per buffer (S / L: the same sum)
+constexpr size_t kStg2sLdsBytes = (size_t)(2 * kStg2sWords + 5 * 64) * 4;  // + the [5][64] coefficients of a derived dc
+// ... and the four columns of a quad are rotated by the quad's group ((c >> 4) & 3), so that the 64 lanes of a STORE (16 column
+// quads x 4 row pairs, one k) land in 64 different banks as well (unrotated: 16 banks, every store 4-way conflicted — with
+// eight waves per CU storing 36 words per thread and stage that, not the MFMAs, would pace the stage).
+__device__ __forceinline__ int stg2s_slot(int c) { return (c & ~3) | ((c + (c >> 4)) & 3); }
+__device__ __forceinline__ int stg2s_word(int c, int rp) { return stg2s_slot(c) * 16 + ((((rp >> 2) ^ (c >> 2)) & 3) << 2) + (rp & 3); }
+__device__ __forceinline__ int stg2s_chunk(int c, int q) { return stg2s_slot(c) * 4 + ((q ^ (c >> 2)) & 3); }
+
+#define GLASS_SPLIT6(ACC, AF, BF)                                                                                     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AF[1]), __builtin_bit_cast(bf16x8, BF[1]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AF[2]), __builtin_bit_cast(bf16x8, BF[0]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AF[0]), __builtin_bit_cast(bf16x8, BF[2]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AF[1]), __builtin_bit_cast(bf16x8, BF[0]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AF[0]), __builtin_bit_cast(bf16x8, BF[1]), ACC, 0, 0, 0); \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, AF[0]), __builtin_bit_cast(bf16x8, BF[0]), ACC, 0, 0, 0)
+
+__device__ __forceinline__ void wgrad_trans_staged2s_body(const float* __restrict__ X, int64_t ldx, int64_t N, int rows_per_slab,
+                                                          float* __restrict__ part_w, float* __restrict__ part_b,
+                                                          const WgradSynth& sy, int bx, float* lds) {
+    constexpr int H = 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rp = tid >> 4, ga = tid & 15;  // loader role: row pair rp of the stage, columns 4 ga .. 4 ga + 3
+    const int64_t r0 = (int64_t)bx * rows_per_slab;
+    const int64_t r1 = r0 + rows_per_slab < N ? r0 + rows_per_slab : N;
+    const int n_st = (int)((r1 - r0 + 31) / 32);
+    const buf_rsrc r_d = make_rsrc(sy.dsrc, N * sy.ldd * 4), r_t = make_rsrc(sy.T, N * sy.ldt * 4), r_x = make_rsrc(X, N * ldx * 4);
+    const buf_rsrc r_m = make_rsrc(sy.mask, N);
+    struct Raw {
+        float4 d[2], t1[2], t0[2], x[2];
+        unsigned mk[2];
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r = r0 + 32 * st + 2 * rp + u;
+            const bool ok = r < r1;
+            const int ri = (int)r;
+            R.d[u] = buf_load4(r_d, ok ? (int)((ri * sy.ldd + 4 * ga) * 4) : kBufOOB);
+            R.t1[u] = buf_load4(r_t, ok ? (int)((ri * sy.ldt + 4 * ga) * 4) : kBufOOB);
+            R.t0[u] = buf_load4(r_t, ok ? (int)((ri * sy.ldt + H + 4 * ga) * 4) : kBufOOB);
+            R.x[u] = buf_load4(r_x, ok ? (int)((ri * ldx + 4 * ga) * 4) : kBufOOB);
+            R.mk[u] = __builtin_amdgcn_raw_buffer_load_b8(r_m, ok ? ri : kBufOOB, 0, 0);
+        }
+    };
+    float bs1[4] = {0.f, 0.f, 0.f, 0.f}, bs0[4] = {0.f, 0.f, 0.f, 0.f};  // bias partials of outputs 4 ga + k / H + 4 ga + k over this thread's rows
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        unsigned* dz = reinterpret_cast<unsigned*>(lds) + (st & 1) * kStg2sWords;
+        unsigned* xi = dz + kStg2sWordsA;
+        float z1[2][4], z0[2][4], xv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float c1 = R.mk[u] ? sy.zr : sy.omz, c0 = R.mk[u] ? sy.omz : sy.zr;
+            const float d[4] = {R.d[u].x, R.d[u].y, R.d[u].z, R.d[u].w};
+            const float t1[4] = {R.t1[u].x, R.t1[u].y, R.t1[u].z, R.t1[u].w}, t0[4] = {R.t0[u].x, R.t0[u].y, R.t0[u].z, R.t0[u].w};
+            xv[u][0] = R.x[u].x, xv[u][1] = R.x[u].y, xv[u][2] = R.x[u].z, xv[u][3] = R.x[u].w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                z1[u][k] = d[k] * c1 * act_grad(sy.act, t1[k]);
+                z0[u][k] = d[k] * c0 * act_grad(sy.act, t0[k]);
+                bs1[k] += z1[u][k];
+                bs0[k] += z0[u][k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned hi, mid, lo;
+            const int c = 4 * ga + k;
+            split2(z1[0][k], z1[1][k], hi, mid, lo);
+            int wd = stg2s_word(c, rp);
+            dz[wd] = hi, dz[128 * 16 + wd] = mid, dz[2 * 128 * 16 + wd] = lo;
+            split2(z0[0][k], z0[1][k], hi, mid, lo);
+            wd = stg2s_word(H + c, rp);
+            dz[wd] = hi, dz[128 * 16 + wd] = mid, dz[2 * 128 * 16 + wd] = lo;
+            split2(xv[0][k], xv[1][k], hi, mid, lo);
+            wd = stg2s_word(c, rp);
+            xi[wd] = hi, xi[64 * 16 + wd] = mid, xi[2 * 64 * 16 + wd] = lo;
+        }
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    wg_f32x4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[a][it] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    D_STAMP(4, 1);
+    for (int st = 0; st < n_st; ++st) {
+        if (st == 1) D_STAMP(4, 2);
+        const uint4* dz = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(lds) + (st & 1) * kStg2sWords);
+        const uint4* xi = dz + kStg2sWordsA / 4;
+        uint4 af[2][3], bf[4][3];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) af[a][pc] = dz[pc * 128 * 4 + stg2s_chunk(16 * (2 * w + a) + j, q)];
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bf[it][pc] = xi[pc * 64 * 4 + stg2s_chunk(16 * it + j, q)];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int it = 0; it < 4; ++it) { GLASS_SPLIT6(acc[a][it], af[a], bf[it]); }
+        if (st + 1 < n_st) {
+            if (st & 1) {
+                commit(st + 1, rawA);
+                issue(st + 3, rawA);
+            } else {
+                commit(st + 1, rawB);
+                issue(st + 3, rawB);
+            }
+            lds_barrier();
+        }
+    }
+    D_STAMP(4, 3);
+    // partial tile, plain [o][i]: o = 16 (2w + a) + 4q + r, i = 16 it + j
+    float* pw = part_w + (int64_t)bx * kTile;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[(16 * (2 * w + a) + 4 * q + r) * H + 16 * it + j] = acc[a][it][r];
+    D_STAMP(4, 7);
+    if (part_b) {  // bias partial: the wave's four row-pair slots of a column by shuffles, the four waves through LDS
+        lds_barrier();  // (every wave is done reading the last stage's image)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bs1[k] += __shfl_xor(bs1[k], 16);
+            bs0[k] += __shfl_xor(bs0[k], 16);
+            bs1[k] += __shfl_xor(bs1[k], 32);
+            bs0[k] += __shfl_xor(bs0[k], 32);
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lds[w * 128 + 4 * ga + k] = bs1[k];
+                lds[w * 128 + H + 4 * ga + k] = bs0[k];
+            }
+        }
+        lds_barrier();
+        if (tid < 128) part_b[(int64_t)bx * kOT + tid] = (lds[tid] + lds[128 + tid]) + (lds[256 + tid] + lds[384 + tid]);
+    }
+}
+
+__device__ __forceinline__ void wgrad_sl_staged2s_body(const WgradSL& a, int64_t N, int blk, float* __restrict__ part_w,
+                                                       float* __restrict__ part_b, float* lds) {
+    constexpr int H = 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rp = tid >> 4, ga = tid & 15;
+    const bool lab = blk >= a.n_s;
+    int64_t r0, r_end;
+    if (!lab) {
+        r0 = (int64_t)blk * a.rows_per_slab;
+        r_end = min(N, r0 + a.rows_per_slab);
+    } else {
+        const int64_t n_lab = a.lab_count[0];
+        r0 = (int64_t)(blk - a.n_s) * 64;
+        r_end = min(n_lab, r0 + 64);
+    }
+    const int n_st = r_end > r0 ? (int)((r_end - r0 + 31) / 32) : 0;
+    int li[2][2] = {{-1, -1}, {-1, -1}};  // L tile: the rows of this thread's list positions of stages 0, 1
+    if (lab) {
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t pos = r0 + 32 * st + 2 * rp + u;
+                li[st][u] = pos < r_end ? a.lab_rows[pos] : -1;
+            }
+    }
+    const GnBwdSrc& src = a.src;
+    const bool src_on = src.acc != nullptr;
+    Drop sdrop = src.drop;
+    if (src_on && sdrop.p > 0.f) {
+        sdrop.seed = a.rng_state[0];
+        sdrop.step = a.rng_state[1];
+    }
+    float* coef_s = lds + 2 * kStg2sWords;  // [5][64] (src)
+    const buf_rsrc r_d = src_on ? make_rsrc(src.dy, N * src.lddy * 4) : make_rsrc(a.dc, N * a.ldd * 4);
+    const int64_t ld_d = src_on ? src.lddy : a.ldd;
+    const buf_rsrc r_sx = make_rsrc(src_on ? src.x : a.X, src_on ? N * src.ldx * 4 : 0);
+    const buf_rsrc r_sad = make_rsrc((src_on && src.addend) ? src.addend : a.X, (src_on && src.addend) ? N * src.ldadd * 4 : 0);
+    const buf_rsrc r_g = make_rsrc(a.X, N * a.ldx * 4), r_x = make_rsrc(a.X2, N * a.ldx2 * 4);
+    struct Raw {
+        float4 d[2], g[2], x[2], sx[2], sad[2];
+        int row[2];
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t pos = r0 + 32 * st + 2 * rp + u;
+            int row = pos < r_end ? (int)pos : -1;
+            if (lab) row = st == 0 ? li[0][u] : st == 1 ? li[1][u] : -1;
+            R.row[u] = row;
+            R.d[u] = buf_load4(r_d, row >= 0 ? (int)((row * ld_d + 4 * ga) * 4) : kBufOOB);
+            R.sx[u] = buf_load4(r_sx, row >= 0 ? (int)((row * src.ldx + 4 * ga) * 4) : kBufOOB);
+            R.sad[u] = buf_load4(r_sad, row >= 0 ? (int)((row * src.ldadd + 4 * ga) * 4) : kBufOOB);
+            R.g[u] = buf_load4(r_g, row >= 0 ? (int)((row * a.ldx + 4 * ga) * 4) : kBufOOB);
+            R.x[u] = buf_load4(r_x, row >= 0 ? (int)((row * a.ldx2 + 4 * ga) * 4) : kBufOOB);
+        }
+    };
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};  // bias partial of outputs 4 ga + k over this thread's rows
+    auto commit = [&](int buf, const Raw& R) __attribute__((always_inline)) {
+        unsigned* dcI = reinterpret_cast<unsigned*>(lds) + buf * kStg2sWords;  // dc^T: 64 columns; [g || x_]^T: 128 columns
+        unsigned* inI = dcI + kStg2sWordsB;
+        float d[2][4], g[2][4], x[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float4 dcv = R.d[u];
+            if (src_on) {
+                float sds[4] = {1.f, 1.f, 1.f, 1.f};
+                if (sdrop.p > 0.f) drop_scales<4>(sdrop, R.row[u] < 0 ? 0 : R.row[u], 4 * ga, sds);
+                dcv = gn_bwd_apply4(R.d[u], R.sx[u], R.sad[u], coef_s, 4 * ga, src.act, sds);
+                if (R.row[u] < 0) dcv = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            d[u][0] = dcv.x, d[u][1] = dcv.y, d[u][2] = dcv.z, d[u][3] = dcv.w;
+            g[u][0] = R.g[u].x, g[u][1] = R.g[u].y, g[u][2] = R.g[u].z, g[u][3] = R.g[u].w;
+            x[u][0] = R.x[u].x, x[u][1] = R.x[u].y, x[u][2] = R.x[u].z, x[u][3] = R.x[u].w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) bs[k] += d[u][k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned hi, mid, lo;
+            const int c = 4 * ga + k;
+            split2(d[0][k], d[1][k], hi, mid, lo);
+            int wd = stg2s_word(c, rp);
+            dcI[wd] = hi, dcI[64 * 16 + wd] = mid, dcI[2 * 64 * 16 + wd] = lo;
+            split2(g[0][k], g[1][k], hi, mid, lo);
+            inI[wd] = hi, inI[128 * 16 + wd] = mid, inI[2 * 128 * 16 + wd] = lo;
+            split2(x[0][k], x[1][k], hi, mid, lo);
+            wd = stg2s_word(H + c, rp);
+            inI[wd] = hi, inI[128 * 16 + wd] = mid, inI[2 * 128 * 16 + wd] = lo;
+        }
+    };
+    wg_f32x4 acc[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) acc[it] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](int buf) __attribute__((always_inline)) {
+        const uint4* dcI = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(lds) + buf * kStg2sWords);
+        const uint4* inI = dcI + kStg2sWordsB / 4;
+        uint4 af[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) af[pc] = dcI[pc * 64 * 4 + stg2s_chunk(16 * w + j, q)];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            uint4 bf[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bf[pc] = inI[pc * 128 * 4 + stg2s_chunk(16 * it + j, q)];
+            GLASS_SPLIT6(acc[it], af, bf);
+        }
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    if (src_on) {
+        gn_bwd_coef_nobarrier(src.acc, src.n_rep, N, src.saved, src.gamma, src.alpha, nullptr, nullptr, nullptr, 0, false, coef_s);
+        lds_barrier();  // coefficients before the first stage is prepared
+    }
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    D_STAMP(3, 1);
+    for (int st = 0; st < n_st; ++st) {
+        if (st == 1) D_STAMP(3, 2);
+        compute(st & 1);
+        if (st + 1 < n_st) {
+            if (st & 1) {
+                commit(0, rawA);
+                issue(st + 3, rawA);
+            } else {
+                commit(1, rawB);
+                issue(st + 3, rawB);
+            }
+            lds_barrier();
+        }
+    }
+    D_STAMP(3, 3);
+    float* pw = part_w + (int64_t)blk * kTile;
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[(16 * w + 4 * q + r) * (2 * H) + 16 * it + j] = acc[it][r];
+    D_STAMP(3, 7);
+    lds_barrier();  // (every wave is done reading the last stage's image)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        bs[k] += __shfl_xor(bs[k], 16);
+        bs[k] += __shfl_xor(bs[k], 32);
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lds[w * 64 + 4 * ga + k] = bs[k];
+    }
+    lds_barrier();
+    if (tid < H) part_b[(int64_t)blk * kSLOut + tid] = (lds[tid] + lds[64 + tid]) + (lds[128 + tid] + lds[192 + tid]);
 }
 
 template <int kStages>

@@ -211,7 +211,7 @@ def _comb_eff_bwd(dsrc, conv, mask, out, xa, xb, pending, acc, gn, labels, dsrc_
     rc = _lib.load().glass_comb_eff_bwd_f32(0 if dsrc_gn is not None else dsrc.data_ptr(), dsrc.stride(0), mask.data_ptr(), float(conv.z_ratio),
                                             conv._stack_eff["comb"][1].data_ptr(), out.data_ptr(), out.stride(0), n, H,
                                             gpart.data_ptr(), gx.data_ptr(), gx.stride(0), gsaved.data_ptr(),
-                                            galpha.data_ptr(), gact, float(gp), rng, gcall, _rep(gpart),
+                                            galpha.data_ptr(), ops.act_word(gact), float(gp), rng, gcall, _rep(gpart),
                                             xa.data_ptr(), xa.stride(0),
                                             xb.data_ptr(), xb.stride(0), ws.data_ptr(), labels.rows.data_ptr(),
                                             labels.count.data_ptr(), labels.cap, 0 if dsrc_gn is None else dsrc_gn.ptr, _stream())

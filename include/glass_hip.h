@@ -50,7 +50,9 @@ typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a k
  * environment variable is read, nothing is process-global; what a call does follows from its arguments alone, so two threads
  * on two streams with different options each get their own behaviour. */
 #define GLASS_ACT_MASK 0xff
-#define GLASS_DENSE_F32_PRODUCTS 0x100 /* hidden 128 / 256 / 512 (LDS-tiled family): form fp32 products with the f32-input MFMA
+#define GLASS_DENSE_F32_PRODUCTS 0x100 /* hidden 128 / 256 / 512 (LDS-tiled family) and, since round 6, the staged hidden-64 kernels
+                                          (trans / comb forward, both fused backward launches; also read from the gn_act word of
+                                          glass_comb_eff_fwd_f32 / _bwd_f32): form fp32 products with the f32-input MFMA
                                           (an fmaf chain, 1/16 of the bf16 matrix rate) instead of the default six bf16 partial
                                           products of 3-way split operands (glass_dense_caps.product_form).  Same operand images
                                           either way.  Differences of the default form at the edge of fp32's range: a +-Inf

@@ -81,6 +81,15 @@ def main():
             s5, l5 = t[:, :, 5][wg] - t0, (t[:, :, 6] - t[:, :, 5])[wg]
             print(f"   wgrad waves start p10/p50/p90/max {pct(s5, 10):.0f}/{pct(s5, 50):.0f}/{pct(s5, 90):.0f}/{s5.max():.0f};"
                   f" life mean {l5.mean():.0f} p90 {pct(l5, 90):.0f} max {l5.max():.0f}; last end at {t[:, :, 6][wg].max() - t0:.0f}")
+            # split-form staged bodies: 5 entry, 1 first stage in LDS, 2 first stage multiplied, 3 last stage done, 7 tile stored, 6 exit
+            prev_s = 5
+            for slot, nm in ((1, "prologue"), (2, "stage 0"), (3, "other stages"), (7, "tile store"), (6, "bias + exit")):
+                okw = wg & (t[:, :, slot] > 0) & (t[:, :, prev_s] > 0)
+                if not okw.any():
+                    continue
+                dd = (t[:, :, slot] - t[:, :, prev_s])[okw]
+                print(f"     wgrad {nm:12s} ({prev_s}->{slot}) mean {dd.mean():.0f}  p50 {pct(dd, 50):.0f}  p90 {pct(dd, 90):.0f}")
+                prev_s = slot
 
 
 if __name__ == "__main__":
