@@ -396,7 +396,8 @@ WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     int64_t rows = ceil_div(N, max_slabs);
     if (rows < 64) rows = 64;
     rows = ceil_div(rows, 8) * 8;  // whole row pairs for each of the 4 waves
-    if (N <= kFusedBwdMaxRows) rows = ceil_div(rows, 32) * 32;  // (the staged bodies of the fused launches walk 16-row stages, 32-row ones in the split form)
+    // (the staged bodies of hidden 64's fused launches — one 128 x 64 tile per slab — walk 16-row stages, 32-row ones in the split form)
+    if (N <= kFusedBwdMaxRows) rows = ceil_div(rows, tiles == 1 ? 32 : 16) * (tiles == 1 ? 32 : 16);
     g.rows_per_slab = (int)rows;
     g.n_slabs = (int)ceil_div(N, rows);
     g.ny = (int)ceil_div(I, kIT);
