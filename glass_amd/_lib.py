@@ -116,6 +116,12 @@ SIGNATURES = {
                                           c_int, c_float, _P, c_uint64, _P, _I, _P, _I, _P]),
     "glass_dual_linear_fwd_gather_supported": (c_int, [_I]),
     "glass_step_prologue_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _I, _P, _I, _P]),
+    "glass_peer_allreduce_adam_f32": (c_int, [_P, _I, _P, _P, _P, _P, c_double, c_double, c_double, c_double, _P, _P, _P, _I, _P, _P]),
+    "glass_peer_alloc": (c_int, [_I, _P]),
+    "glass_peer_free": (c_int, [_P]),
+    "glass_peer_export": (c_int, [_P, _P]),
+    "glass_peer_import": (c_int, [_P, _P]),
+    "glass_peer_close": (c_int, [_P]),
     "glass_step_head_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, c_float, _P, _P, _I, _P, _I,
                                     _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "glass_graphnorm_finalize_f32": (c_int, [_P, _I, _I, _I, _I, _P, _P, _P, c_float, _P, _P]),

@@ -327,7 +327,35 @@ class ParamArena(FlatGradBucket):
         ex = self.exchange
         return self.shard_optimizer and ex is not None and ex.has_big
 
+    def adopt_grad_storage(self, flat):
+        """Move the gradient arena into `flat` (same length and dtype; e.g. an allocation the peers of a one-shot exchange map:
+        glass_amd/peer.py): every .grad becomes a view of it.  Captured graphs hold the old addresses and are dropped."""
+        if flat.numel() != self.flat.numel() or flat.dtype != self.flat.dtype or flat.device != self.flat.device:
+            raise ValueError("adopt_grad_storage: the new buffer must match the gradient arena")
+        drop_captured_graphs(self.model)
+        for mod in self.model.modules():  # step programs hold launch arguments with the old gradient addresses
+            mod.__dict__.pop("_glass_stack_prog", None)
+        self.flat = flat
+        self._exchange = None
+        with torch.no_grad():
+            for p in self.params:
+                o = self._offsets[id(p)]
+                p.grad = self.flat[o:o + p.numel()].view_as(p)
+        # (stacked gradient views of the fused pairs point into the old buffer: rebuild what hangs on the model)
+        for mod in self.model.modules():
+            st = getattr(mod, "_stack", None)
+            if isinstance(st, dict):
+                for kind, tup in list(st.items()):
+                    W, b, dW, db = tup[:4]
+                    oW = W.data_ptr() - self.flat_param.data_ptr()
+                    ob = b.data_ptr() - self.flat_param.data_ptr()
+                    ndW = self.flat[oW // 4:oW // 4 + W.numel()].view_as(W)
+                    ndb = self.flat[ob // 4:ob // 4 + b.numel()].view_as(b)
+                    st[kind] = (W, b, ndW, ndb) + tuple(tup[4:])
+
     def all_reduce_mean(self):
+        if getattr(self, "_peer", None) is not None:
+            return  # the one-shot exchange rides in the optimizer's launch (glass_amd/peer.py)
         ex = self.exchange
         if ex is None:
             return

@@ -47,7 +47,7 @@ class _FlatAdamCore:
 
     def fusable(self):
         """The update can ride in the step program's last launch (glass_embed_norm_bwd_adam_f32): one unsharded arena."""
-        return not self.arena.sharded() and self.arena.attached()
+        return not self.arena.sharded() and self.arena.attached() and getattr(self.arena, "_peer", None) is None
 
     def fused_args(self):
         """(param, grad, exp_avg, exp_avg_sq, n, lr_dev, beta1, beta2, eps, weight_decay, step_dev) of the whole arena."""
@@ -64,6 +64,10 @@ class _FlatAdamCore:
         if not torch.cuda.is_current_stream_capturing():
             self.sync_lr()
         a = self.arena
+        peer = getattr(a, "_peer", None)
+        if peer is not None:  # one-shot peer exchange + Adam as ONE launch (glass_amd/peer.py); all_reduce_mean() was a no-op
+            peer.step(self)
+            return
 
         def launch(param, grad, m, v, counter):
             if param.numel() == 0:

@@ -611,6 +611,35 @@ int glass_step_head_f32(const float* const* src, float* const* dst, const int64_
                         int64_t n_zero_words, glass_batch_cursor* cur, int64_t n_idx, int64_t smax, int64_t y_row_bytes,
                         int64_t* pos_dst, void* y_dst, uint8_t* mask, int32_t* lab_rows, int32_t* lab_count, void* ws,
                         int64_t n_nodes, void* stream);
+/*     One-shot peer all-reduce of the gradient arena fused with Adam (the small bucket of the data-parallel exchange,
+ *     SURVEY.md 8e; replaces `all_reduce(grads) / world` + `Adam.step()` of the replicas: impl/train.py:10-16, GLASSTest.py:213).
+ *     xGMI is point to point, so every rank READS every peer's arena directly instead of walking a ring: one launch per
+ *     rank and step — publish "my gradients of step s are final" (grp->flags[rank][0] = s, system-scope release), wait for every
+ *     peer's flag (bounded spin), mean gradient = (g_0 + g_1 + ... + g_{N-1}) / N summed in RANK order (the same bits on every
+ *     rank), Adam on this rank's replica (the arithmetic of glass_adam_step_f32), publish "done reading" (flags[rank][1] = s)
+ *     and wait for the peers' done flags before the launch ends (a rank's next backward may then overwrite its arena).
+ *     grp: every rank's arena and flag block (2 x uint64, zero before the first call) as THIS process addresses them — the
+ *     own ones plain, the peers' through hipIpc mappings (glass_peer_export / _import) or peer access inside one process.
+ *     seq_dev uint64[2] = {last finished exchange, ticket} (zero before the first call; every rank advances in lock step);
+ *     status_dev int32: set non-zero (sticky) when a flag did not arrive within spin_limit polls — the launch then ends
+ *     without touching parameters, moments or step_dev: an error for the host to raise, never a hang.  mean_out (may be
+ *     NULL) receives the mean gradient.  No allocation, no host synchronisation: capturable in the step's graph.
+ *     glass_peer_alloc / _free / _export / _import / _close are SET-UP helpers (the only entries that allocate): an arena
+ *     shared over hipIpc must be a whole runtime allocation, not a slice of a framework's pooled block. */
+typedef struct glass_peer_group {
+    int32_t world, rank;
+    const float* grad[8];
+    uint64_t* flags[8];
+} glass_peer_group;
+int glass_peer_allreduce_adam_f32(const glass_peer_group* grp, int64_t n, float* param, float* exp_avg, float* exp_avg_sq,
+                                  const float* lr_dev, double beta1, double beta2, double eps, double weight_decay,
+                                  int64_t* step_dev, uint64_t* seq_dev, int32_t* status_dev, int64_t spin_limit,
+                                  float* mean_out, void* stream);
+int glass_peer_alloc(int64_t bytes, void** out);
+int glass_peer_free(void* p);
+int glass_peer_export(void* p, void* handle64);   /* handle64: 64 bytes (hipIpcMemHandle_t) */
+int glass_peer_import(const void* handle64, void** out);
+int glass_peer_close(void* p);
 /*     Exact cross-workgroup GraphNorm sums (hidden 64): the whole-graph GraphNorm (PyG GraphNorm with batch = None,
  *     impl/models.py:165,249,257,266,271) needs column sums over ALL rows between every pair of kernels of the step.
  *     Instead of per-workgroup fp64 partials + a finalize launch, the producers add their per-workgroup sums into
