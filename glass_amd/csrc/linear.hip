@@ -372,6 +372,18 @@ static int thin_blocks(int64_t N) {
 
 WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     WgradGeom g;
+    if (wgrad128_shape(N, O, I)) {
+        // one workgroup per slab covers all four tiles (wgrad128.hip): about one slab per CU, whole 32-row stages
+        int64_t rows = ceil_div(ceil_div(N, (int64_t)256), (int64_t)32) * 32;
+        if (rows < 64) rows = 64;
+        g.rows_per_slab = (int)rows;
+        g.n_slabs = (int)ceil_div(N, rows);
+        g.ny = (int)ceil_div(I, kIT);
+        g.nz = (int)ceil_div(O, kOT);
+        g.part_w_floats = (int64_t)g.n_slabs * g.ny * g.nz * kTile;
+        g.part_b_floats = (int64_t)g.n_slabs * g.nz * kOT + kWgradHeaderFloats;
+        return g;
+    }
     // Slab count: about one workgroup per CU over all (slab, input-chunk, output-chunk) triples, at most 128
     // slabs (measured on MI355X, us for 128/64 slabs vs 256: N=17 080 O=128 I=128 22 vs 31; N=50 000 O=256 I=128
     // 52 vs 80 — fewer, longer slabs amortise the pipeline fill and halve the partial traffic).
@@ -656,7 +668,11 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
     // hidden 128 (the widths of the tiled family whose graph or layer is too small for wgrad_tiled.hip): the product form of
     // that family (this call's options) applies here too — six bf16 partial products per fp32 product
     const bool split = tiled_shape_ok(H) && tiled_split_products() && ldx % 2 == 0;
-    if (split && eff)
+    if (split && !eff && X2 == nullptr && wgrad128_shape(N, O, I) && ldx % 4 == 0 && aligned16(X) &&
+        N * std::max(std::max(ldd, ldx), act != GLASS_ACT_NONE ? ldt : (int64_t)0) * 4 < (1ll << 31))
+        // rows shared through LDS, one workgroup per slab (32-bit buffer offsets: checked above)
+        launch_wgrad128_trans(X, ldx, N, g.rows_per_slab, g.n_slabs, part_w, pb_arg, header, sy, st);
+    else if (split && eff)
         hipLaunchKernelGGL((wgrad_partial_split_kernel<false, true>), grid, dim3(kBlock), 0, st, X, ldx, N, (int)O, (int)I,
                            g.rows_per_slab, part_w, pb_arg, header, sy);
     else if (split && act != GLASS_ACT_NONE)

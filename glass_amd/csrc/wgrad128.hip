@@ -1,0 +1,182 @@
+// Weight gradient of the trans pair at hidden 128 on mid-size graphs (em_user-shape: N = 50 000), rows shared through LDS
+// (round 6; reference impl/models.py:158-162 backward: dW[2H, H] = dZ^T X, dZ = mix'(dout) . act'(T)).
+//
+// The register-pipelined kernel this replaces at that shape (wgrad_partial_split_kernel, linear.hip) cuts the [256 x 128]
+// output into four 128 x 64 tiles per slab, one workgroup each, every workgroup reading its rows' gradient, pre-activation
+// half and input half straight from global memory: 5 120 B requested per row for 2 048 B of operands.  tools/wgrad_probe.py
+// put that launch at 14 us fixed + 0.65-0.75 us per 1 000 rows of REQUEST bandwidth between the CUs and L2 — sharing through
+// L1 (a paired form) did not help, fewer vector instructions did not help.  Here a slab has ONE workgroup of
+// eight waves that requests every row once: stages of 32 rows, the loaders (two rows x one column quad per thread and
+// operand) synthesise dZ, cut row pairs into bf16 pieces (split2) and write the transposed, swizzled images of
+// wgrad_common.h (stg2s_*: [piece][column][32 rows], no padding, fragment reads and stores conflict free); wave (ob, ib)
+// owns outputs 64 ob .. + 63 x inputs 64 ib .. + 63 = 16 accumulator tiles, 96 MFMAs of v_mfma_f32_16x16x32_bf16 per stage.
+// Two 72 KiB stage buffers: one workgroup per CU.  Partials: the four 128 x 64 sub-tiles in plain [o][i] order at the
+// places the batched reduce expects them (header[2] = 1), bias partials from the loaders' own sums.
+#include "common.h"
+#include "wgrad_common.h"
+#include "dense_common.h"
+
+namespace glass {
+
+constexpr int kW128Threads = 512;
+constexpr int kW128WordsA = 3 * 256 * 16, kW128WordsB = 3 * 128 * 16;   // 32-bit words of the dZ^T / X^T images of one buffer
+constexpr int kW128Words = kW128WordsA + kW128WordsB;                   // 18 432 words = 72 KiB
+constexpr size_t kW128LdsBytes = (size_t)2 * kW128Words * 4;
+
+__global__ __launch_bounds__(kW128Threads, 1) void wgrad128_trans_kernel(const float* __restrict__ X, int64_t ldx, int64_t N,
+                                                                         int rows_per_slab, int n_slabs, float* __restrict__ part_w,
+                                                                         float* __restrict__ part_b, float* __restrict__ header,
+                                                                         WgradSynth sy) {
+    extern __shared__ float lds[];
+    constexpr int H = 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rp = tid >> 5, ga = tid & 31;  // loader role: row pair rp of the stage, columns 4 ga .. 4 ga + 3
+    const int ob = w >> 1, ib = w & 1;       // this wave's 64 outputs / 64 inputs
+    const int bx = blockIdx.x;
+    if (header && bx == 0 && tid == 0) {
+        header[0] = 0.f;
+        header[1] = sy.zr;
+        header[2] = 1.f;  // tiles in plain [o][i] order
+    }
+    const int64_t r0 = (int64_t)bx * rows_per_slab;
+    const int64_t r1 = r0 + rows_per_slab < N ? r0 + rows_per_slab : N;
+    const int n_st = (int)((r1 - r0 + 31) / 32);
+    const bool has_t = sy.act != GLASS_ACT_NONE;
+    const buf_rsrc r_d = make_rsrc(sy.dsrc, N * sy.ldd * 4), r_x = make_rsrc(X, N * ldx * 4), r_m = make_rsrc(sy.mask, N);
+    const buf_rsrc r_t = make_rsrc(has_t ? sy.T : sy.dsrc, has_t ? N * sy.ldt * 4 : 0);  // no activation: reads 0, act'(0) unused
+    struct Raw {
+        float4 d[2], t1[2], t0[2], x[2];
+        unsigned mk[2];
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t r = r0 + 32 * st + 2 * rp + u;
+            const bool ok = r < r1;
+            const int ri = (int)r;
+            R.d[u] = buf_load4(r_d, ok ? (int)((ri * sy.ldd + 4 * ga) * 4) : kBufOOB);
+            R.t1[u] = buf_load4(r_t, ok ? (int)((ri * sy.ldt + 4 * ga) * 4) : kBufOOB);
+            R.t0[u] = buf_load4(r_t, ok ? (int)((ri * sy.ldt + H + 4 * ga) * 4) : kBufOOB);
+            R.x[u] = buf_load4(r_x, ok ? (int)((ri * ldx + 4 * ga) * 4) : kBufOOB);
+            R.mk[u] = __builtin_amdgcn_raw_buffer_load_b8(r_m, ok ? ri : kBufOOB, 0, 0);
+        }
+    };
+    float bs1[4] = {0.f, 0.f, 0.f, 0.f}, bs0[4] = {0.f, 0.f, 0.f, 0.f};  // bias partials of outputs 4 ga + k / H + 4 ga + k
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        unsigned* dz = reinterpret_cast<unsigned*>(lds) + (st & 1) * kW128Words;
+        unsigned* xi = dz + kW128WordsA;
+        float z1[2][4], z0[2][4], xv[2][4];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float c1 = R.mk[u] ? sy.zr : sy.omz, c0 = R.mk[u] ? sy.omz : sy.zr;
+            const float d[4] = {R.d[u].x, R.d[u].y, R.d[u].z, R.d[u].w};
+            const float t1[4] = {R.t1[u].x, R.t1[u].y, R.t1[u].z, R.t1[u].w}, t0[4] = {R.t0[u].x, R.t0[u].y, R.t0[u].z, R.t0[u].w};
+            xv[u][0] = R.x[u].x, xv[u][1] = R.x[u].y, xv[u][2] = R.x[u].z, xv[u][3] = R.x[u].w;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                z1[u][k] = d[k] * c1, z0[u][k] = d[k] * c0;
+                if (has_t) z1[u][k] *= act_grad(sy.act, t1[k]), z0[u][k] *= act_grad(sy.act, t0[k]);
+                bs1[k] += z1[u][k];
+                bs0[k] += z0[u][k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned hi, mid, lo;
+            const int c = 4 * ga + k;
+            split2(z1[0][k], z1[1][k], hi, mid, lo);
+            int wd = stg2s_word(c, rp);
+            dz[wd] = hi, dz[256 * 16 + wd] = mid, dz[2 * 256 * 16 + wd] = lo;
+            split2(z0[0][k], z0[1][k], hi, mid, lo);
+            wd = stg2s_word(H + c, rp);
+            dz[wd] = hi, dz[256 * 16 + wd] = mid, dz[2 * 256 * 16 + wd] = lo;
+            split2(xv[0][k], xv[1][k], hi, mid, lo);
+            wd = stg2s_word(c, rp);
+            xi[wd] = hi, xi[128 * 16 + wd] = mid, xi[2 * 128 * 16 + wd] = lo;
+        }
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    wg_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[a][it] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    for (int st = 0; st < n_st; ++st) {
+        const uint4* dz = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(lds) + (st & 1) * kW128Words);
+        const uint4* xi = dz + kW128WordsA / 4;
+        uint4 af[4][3];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) af[a][pc] = dz[pc * 256 * 4 + stg2s_chunk(64 * ob + 16 * a + j, q)];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            uint4 bf[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bf[pc] = xi[pc * 128 * 4 + stg2s_chunk(64 * ib + 16 * it + j, q)];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { GLASS_SPLIT6(acc[a][it], af[a], bf); }
+        }
+        if (st + 1 < n_st) {
+            if (st & 1) {
+                commit(st + 1, rawA);
+                issue(st + 3, rawA);
+            } else {
+                commit(st + 1, rawB);
+                issue(st + 3, rawB);
+            }
+            lds_barrier();
+        }
+    }
+    // the four 128 x 64 sub-tiles (z = o / 128, y = i / 64) in plain [o][i] order: o = 64 ob + 16 a + 4 q + r, i = 64 ib + 16 it + j
+    {
+        const int z = ob >> 1, y = ib;
+        float* pw = part_w + ((int64_t)(z * 2 + y) * n_slabs + bx) * kTile;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[(64 * (ob & 1) + 16 * a + 4 * q + r) * kIT + 16 * it + j] = acc[a][it][r];
+    }
+    if (part_b) {  // bias partial: the wave's two row-pair slots of a column by a shuffle, the eight waves through LDS
+        lds_barrier();  // (every wave is done reading the last stage's image)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            bs1[k] += __shfl_xor(bs1[k], 32);
+            bs0[k] += __shfl_xor(bs0[k], 32);
+        }
+        if (lane < 32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                lds[w * 256 + 4 * ga + k] = bs1[k];
+                lds[w * 256 + H + 4 * ga + k] = bs0[k];
+            }
+        }
+        lds_barrier();
+        if (tid < 256) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) s += lds[ww * 256 + tid];
+            part_b[((int64_t)(tid >> 7) * n_slabs + bx) * kOT + (tid & 127)] = s;
+        }
+    }
+}
+
+// shapes served: the trans pair of hidden 128 (O = 256, I = 128) on a graph that gives every slab a few 32-row stages
+bool wgrad128_shape(int64_t N, int64_t O, int64_t I) { return O == 256 && I == 128 && N >= 8192 && N <= kFusedBwdMaxRows * 4; }
+
+void launch_wgrad128_trans(const float* X, int64_t ldx, int64_t N, int rows_per_slab, int n_slabs, float* part_w, float* part_b,
+                           float* header, const WgradSynth& sy, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)wgrad128_trans_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kW128LdsBytes);
+    hipLaunchKernelGGL(wgrad128_trans_kernel, dim3((unsigned)n_slabs), dim3(kW128Threads), kW128LdsBytes, st, X, ldx, N, rows_per_slab,
+                       n_slabs, part_w, part_b, header, sy);
+}
+
+}  // namespace glass

@@ -27,6 +27,11 @@ struct WgradGeom {
     int64_t part_w_floats, part_b_floats;
 };
 WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I);  // linear.hip
+// wgrad128.hip: the trans pair of hidden 128 with the slab's rows shared through LDS (one workgroup per slab, all four tiles)
+bool wgrad128_shape(int64_t N, int64_t O, int64_t I);
+struct WgradSynth;
+void launch_wgrad128_trans(const float* X, int64_t ldx, int64_t N, int rows_per_slab, int n_slabs, float* part_w, float* part_b,
+                           float* header, const WgradSynth& sy, hipStream_t st);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));

@@ -691,6 +691,59 @@ def test_tiled_wgrad_eight_wave_kernel(N, H, comb, act):
         assert rc != 0 and b"2-byte" in lib.glass_last_error_string()
 
 
+@pytest.mark.parametrize("N", [8192, 50003, 70001, 100000 + 31])
+@pytest.mark.parametrize("act", [1, 2, 0])
+def test_wgrad128_rows_shared_through_lds(N, act):
+    """glass_dual_linear_wgrad_f32 for the trans pair of hidden 128 on a mid-size graph (round 6, wgrad128.hip: one workgroup per
+    slab, the slab's rows requested once and shared through LDS as swizzled bf16 images, all four 128 x 64 tiles from 16
+    accumulator tiles per wave): dW, db against the fp64 sums for ELU / ReLU / no activation, odd N (a slab that ends inside a
+    row pair, the last row labeled), strided operands; twice -> identical bits (no atomics, fixed slab order); the f32-input
+    product form of the same call (the register-pipelined kernel on the same slab geometry) against the same sums."""
+    from glass_amd import ops, _lib
+    lib = _lib.load()
+    H = 128
+    gen = torch.Generator().manual_seed(N + act)
+    zr = 0.8
+    dsrc = torch.randn(N, H, generator=gen)
+    T = torch.randn(N, 2 * H, generator=gen)
+    X = torch.randn(N, H, generator=gen)
+    mask = torch.rand(N, generator=gen) < 0.02
+    mask[-1] = True
+    c1 = torch.where(mask, zr, 1 - zr).double().reshape(-1, 1)
+    G = torch.cat((c1 * dsrc.double(), (1 - c1) * dsrc.double()), 1)
+    if act == 1:
+        G = G * torch.where(T > 0, torch.ones(()), torch.exp(T)).double()
+    elif act == 2:
+        G = G * (T > 0).double()
+    dW_ref, db_ref = G.t() @ X.double(), G.sum(0)
+    dg = torch.randn(N, H + 8, device=DEV)
+    dg[:, 4:4 + H] = dsrc.to(DEV)
+    dgv = dg[:, 4:4 + H]   # strided: ld = H + 8, 16-B aligned columns
+    Tg, Xg, mg = T.to(DEV), X.to(DEV), mask.to(DEV).to(torch.uint8)
+    ws = ops._wgrad_workspace(torch.device(DEV), N, 2 * H, H, slot=("w128", N, act))
+    prev = ops.DENSE_F32_PRODUCTS
+    try:
+        for form in (False, True):
+            ops.DENSE_F32_PRODUCTS = form
+            got = []
+            for _ in range(2):
+                dW = torch.full((2 * H, H), float("nan"), device=DEV)
+                db = torch.full((2 * H,), float("nan"), device=DEV)
+                rc = lib.glass_dual_linear_wgrad_f32(dgv.data_ptr(), dgv.stride(0), Tg.data_ptr() if act else 0, Tg.stride(0) if act else 0,
+                                                     mg.data_ptr(), zr, ops.act_word(act), Xg.data_ptr(), Xg.stride(0), 0, 0, N, H,
+                                                     dW.data_ptr(), dW.stride(0), db.data_ptr(), 0, ws.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream)
+                assert rc == 0, lib.glass_last_error_string()
+                got.append((dW.cpu(), db.cpu()))
+            e_w, e_b = rel_inf(got[0][0], dW_ref), rel_inf(got[0][1], db_ref)
+            assert e_w < TOL and e_b < TOL, (form, e_w, e_b)
+            assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+            if not form:
+                record_parity(f"kernel/wgrad128_lds_N{N}_act{act}", dW_rel_inf=e_w, db_rel_inf=e_b)
+    finally:
+        ops.DENSE_F32_PRODUCTS = prev
+
+
 @pytest.mark.parametrize("H,N,comb", [(128, 3001, False), (256, 4099, False), (256, 4099, True), (256, 70001, True),
                                       # hidden 64 (round 6: the staged forward kernels take the split form too)
                                       (64, 3001, False), (64, 17080, False), (64, 3001, True)])

@@ -10,4 +10,4 @@ for f in dense dense_tiled linear wgrad_tiled; do
 done
 /opt/rocm/bin/hipcc $FLAGS -c ../../tools/lab/lab_knobs.cpp -o ../../tools/bin/trace/lab_knobs.o || exit 1
 T=../../tools/bin/trace
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC spmm.o graphnorm.o elementwise.o labels.o embnorm.o pool.o $T/linear.o $T/wgrad_tiled.o $T/dense.o $T/dense_tiled.o dense_narrow.o head.o readout.o pairhead.o peer.o api.o $T/lab_knobs.o -o ../../tools/bin/libglass_trace.so && echo "trace lib built"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC spmm.o graphnorm.o elementwise.o labels.o embnorm.o pool.o $T/linear.o $T/wgrad_tiled.o $T/dense.o $T/dense_tiled.o dense_narrow.o head.o readout.o pairhead.o peer.o wgrad128.o api.o $T/lab_knobs.o -o ../../tools/bin/libglass_trace.so && echo "trace lib built"
