@@ -26,6 +26,8 @@ class BCEWithLogits(nn.Module):
         return nn.functional.binary_cross_entropy_with_logits(pred.flatten(), y.flatten())
 
 
+import os as _os
+PROBE_OPAQUE_LOSSES = _os.environ.get("GLASS_LOSS_PROBE", "1") != "0"   # 0: never evaluate an opaque loss callable to classify it
 _PROBE_TOL = 1e-6
 _probed = {}  # id(loss_fn) -> (weakref or None, mode or None)
 
@@ -84,6 +86,12 @@ def fusable_mode(loss_fn):
             loss_fn.ignore_index == -100 and getattr(loss_fn, "label_smoothing", 0.0) == 0.0):
         return 0
     if not callable(loss_fn):
+        return None
+    # Opt-out: the probe CALLS the loss (<= 4 times, on small synthetic CPU tensors) — a stateful callable (running statistics,
+    # logging, counters) sees those phantom calls, and one that equals CE / BCE at probe time but depends on state that changes
+    # later would be replaced by the fused kernel for good.  `loss_fn._glass_no_fuse = True` (or GLASS_LOSS_PROBE=0 in the
+    # environment) keeps such a callable on the plain path: it is then called as it is, once per step, by autograd.
+    if getattr(loss_fn, "_glass_no_fuse", False) or not PROBE_OPAQUE_LOSSES:
         return None
     hit = _probed.get(id(loss_fn))
     if hit is not None and (hit[0] is None or hit[0]() is loss_fn):

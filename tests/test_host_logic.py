@@ -330,3 +330,48 @@ def test_deepcopy_of_a_model_is_a_plain_independent_copy():
     assert not any(k in mod.__dict__ for mod in c.modules() for k in arena._RUNTIME_ATTRS)
     assert "_glass_train_steps" in m.__dict__ and m.conv.__dict__["_glass_arena"] is not None   # the original keeps its own
     assert copy.deepcopy(RuntimeCache(x=1)) == {} and isinstance(copy.deepcopy(RuntimeCache(x=1)), RuntimeCache)
+
+
+def test_opaque_loss_probe_can_be_declined():
+    """losses.fusable_mode classifies an opaque callable by CALLING it on synthetic tensors: a callable marked
+    `_glass_no_fuse` is never called by the probe and never fused; an unmarked one that computes the reference's binary loss is
+    recognised (GLASSTest.py:57-58)."""
+    import torch
+    from glass_amd import losses
+
+    calls = []
+
+    def counting_bce(x, y):
+        calls.append(1)
+        return torch.nn.BCEWithLogitsLoss()(x.flatten(), y.flatten())
+
+    assert losses.fusable_mode(counting_bce) == 1 and len(calls) > 0
+    n = len(calls)
+    assert losses.fusable_mode(counting_bce) == 1 and len(calls) == n   # cached verdict: no further calls
+
+    def stateful(x, y):
+        calls.append(2)
+        return torch.nn.BCEWithLogitsLoss()(x.flatten(), y.flatten())
+
+    stateful._glass_no_fuse = True
+    n = len(calls)
+    assert losses.fusable_mode(stateful) is None and len(calls) == n
+
+
+def test_scaling_forecast_model():
+    """dist.predict_scaling: the forecast every bench line prints — efficiency 1 at one rank, falling with the
+    ring's depth, the one-shot form flat in N and above the ring from 2 ranks on; an embedding-sized bucket that overlaps the
+    backward tail hides the small all-reduce."""
+    from glass_amd import dist
+    small = {"small_allreduce": 200_000, "big_reduce_scatter": 0, "big_all_gather": 0}
+    fc = dist.predict_scaling(small, 0.232)
+    eff = {r["world"]: r for r in fc["per_world"]}
+    assert eff[1]["ring_efficiency"] == 1.0 and eff[1]["oneshot_efficiency"] == 1.0
+    assert 1.0 > eff[2]["ring_efficiency"] > eff[4]["ring_efficiency"] > eff[8]["ring_efficiency"] > 0.8
+    assert abs(eff[8]["ring_exposed_us"] - (12.0 + 14 * 1.5 + 2 * 200_000 / 8 / (153.0 * 0.7 * 1e3))) < 1e-6
+    assert all(eff[n]["oneshot_efficiency"] > eff[n]["ring_efficiency"] for n in (2, 4, 8))
+    assert abs(eff[2]["oneshot_exposed_us"] - eff[8]["oneshot_exposed_us"]) < 1e-9
+    big = {"small_allreduce": 200_000, "big_reduce_scatter": 25_600_000, "big_all_gather": 25_600_000}
+    a = dist.predict_scaling(big, 0.6, overlaps_small=False)["per_world"][3]
+    b = dist.predict_scaling(big, 0.6, overlaps_small=True)["per_world"][3]
+    assert b["ring_exposed_us"] < a["ring_exposed_us"] and b["ring_efficiency"] > a["ring_efficiency"]
