@@ -1015,7 +1015,10 @@ __global__ __launch_bounds__(kBlock, 2) void dual_bwd_kernel(DgradArgs A, int n_
                                                             float* __restrict__ part_w, float* __restrict__ part_b,
                                                             float* __restrict__ wg_header, WgradSynth sy) {
     extern __shared__ float4 lds_w[];
-    const int b = blockIdx.x;
+    // the weight-gradient workgroups are the long ones (phase stamps: 12.6 / 16.2 us of life against 7.8 / 11.1): they take the
+    // FIRST workgroup ids, so the dispatcher starts them first; b = the id in the old order (data-gradient tiles first)
+    const int n_wg_blocks = (int)gridDim.x - n_dgrad_blocks;
+    const int b = (int)blockIdx.x < n_wg_blocks ? n_dgrad_blocks + (int)blockIdx.x : (int)blockIdx.x - n_wg_blocks;
     // trans pair at hidden 64: the slabs go through LDS in 16-row stages (wgrad_trans_staged2_body; plain [o][i] tiles)
     const bool staged2 = GLASS_TRANS_WGRAD_STAGED2 && NT == 64 && O == 128 && I == 64 && sy.X2 == nullptr && gy == 1;
     if (b == 0 && threadIdx.x == 0) {  // the partials below are in the plain form (mode header read by the reduce launch)
@@ -2305,7 +2308,10 @@ template <int H, bool SP = false>
 __global__ __launch_bounds__(kBlock, 2) void comb_bwd_eff_kernel(DgradEffArgs A, int n_dgrad_blocks, WgradSL sl, float zr,
                                                                 float* __restrict__ part_w, float* __restrict__ part_b) {
     extern __shared__ float4 lds_w[];
-    const int b = blockIdx.x;
+    // the weight-gradient workgroups are the long ones (phase stamps: 12.6 / 16.2 us of life against 7.8 / 11.1): they take the
+    // FIRST workgroup ids, so the dispatcher starts them first; b = the id in the old order (data-gradient tiles first)
+    const int n_wg_blocks = (int)gridDim.x - n_dgrad_blocks;
+    const int b = (int)blockIdx.x < n_wg_blocks ? n_dgrad_blocks + (int)blockIdx.x : (int)blockIdx.x - n_wg_blocks;
     if (b == 0 && threadIdx.x == 0) {  // mode header behind the bias partials, read by the (deferred) reduce launch
         float* header = part_b + (int64_t)(sl.n_s + sl.n_l) * kSLOut;
         header[0] = 2.f;
