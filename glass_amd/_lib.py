@@ -24,7 +24,7 @@ AGGR_MODES = {"mean": 0, "sum": 1, "gcn": 2}
 ACT_NONE, ACT_ELU, ACT_RELU = 0, 1, 2
 PLAN_HEADER_WORDS = 16
 EMBED_NORM_MAX_ROWS = 8192  # GLASS_EMBED_NORM_MAX_ROWS
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class GlassHipError(RuntimeError):

@@ -30,7 +30,7 @@ typedef struct glass_gn_bwd_src glass_gn_bwd_src;
 typedef struct glass_gn_src glass_gn_src; /* exact GraphNorm accumulators as a kernel input: defined with K5's entries */
 #endif
 
-#define GLASS_ABI_VERSION 5
+#define GLASS_ABI_VERSION 6
 
 #define GLASS_E_ARG (-1)       /* bad argument (null pointer, negative size, misaligned ld) */
 #define GLASS_E_PLAN (-2)      /* plan blob does not match the call (magic / sizes) */

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in glass_hip.h but not exported"
     assert sorted(_lib.SIGNATURES) == names, "ctypes table and header disagree"
-    assert lib.glass_version() == _lib.ABI_VERSION == 5
+    assert lib.glass_version() == _lib.ABI_VERSION == 6
 
 
 def test_header_cites_reference_lines():
