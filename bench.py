@@ -971,9 +971,9 @@ def main():
     # forms an fp32 product from six bf16 partial products (glass_dense_caps.product_form; GLASS_DENSE_SPLIT=0 opts every call out) — a sixth of the bf16 peak
     from glass_amd import _lib as _glib
     caps = _glib.dense_caps(H)
-    split_form = caps.family == 3 and caps.product_form == 1 and not ops.DENSE_F32_PRODUCTS
+    split_form = caps.product_form == 1 and not ops.DENSE_F32_PRODUCTS
     mfma_peak = MFMA_BF16_TFLOPS / 6.0 if split_form else MFMA_F32_TFLOPS
-    peak_note = ("fp32 products as six bf16 partial products of 3-way split operands (v_mfma_f32_32x32x16_bf16): peak = bf16 dense "
+    peak_note = ("fp32 products as six bf16 partial products of 3-way split operands (v_mfma_f32_32x32x16_bf16 / _16x16x32_bf16): peak = bf16 dense "
                  "peak / 6; the f32-input MFMA peak is 157.3 TFLOP/s" if split_form else "f32-input MFMA (v_mfma_f32_*_f32)")
     top = breakdown[0]
     dominant = {"kernel": top[0], "us_per_step": round(top[1], 2), "share_of_step": round(top[1] / step_breakdown["total_us"], 3)}

@@ -2632,7 +2632,8 @@ extern "C" int glass_dense_caps_query(int64_t H, glass_dense_caps* out) {
         c.stat_rows = (int32_t)glass_dual_linear_stat_rows(H);
         c.fwd_gather = glass_dual_linear_fwd_gather_supported(H);
         c.act_codes = (1 << GLASS_ACT_ELU) | (1 << GLASS_ACT_RELU);
-        c.product_form = c.family == 3 ? 1 : 0;  // the family's default; GLASS_DENSE_F32_PRODUCTS in a call's act word opts out
+        // the family's default; GLASS_DENSE_F32_PRODUCTS in a call's act word opts out (round 6: the staged hidden-64 kernels too)
+        c.product_form = (c.family == 3 || (c.family == 2 && lab_knob("GLASS_H64_SPLIT", 1) != 0)) ? 1 : 0;
     }
     c.serve_width = c.family ? (int32_t)H : (H <= 64 ? 64 : H <= 128 ? 128 : H <= 256 ? 256 : H <= 512 ? 512 : 0);
     c.gn_exact = glass_gn_exact_supported(H);
