@@ -404,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_kernel(const float* __res
 // prologue (C <= 128), workgroup 0 also writes the parameter gradients — no finalize launch.  The thread's first batch of
 // rows is requested BEFORE the fold so that both share one memory round trip (a barrier drains outstanding loads);
 // CC = 64: the barrier-free fold by four lanes per column, CC = 0: any C <= 128 through LDS.
-template <int VW, int CC>
+template <int VW, int CC, int UN = kUnroll>
 __global__ __launch_bounds__(kBlock) void gn_bwd_apply_acc_kernel(const float* __restrict__ dy, int64_t lddy,
                                                                   const float* __restrict__ x, int64_t ldx,
                                                                   float* __restrict__ dx, int64_t lddx,
@@ -425,10 +425,10 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_acc_kernel(const float* _
     const bool col_ok = c0 < C;
     const int64_t stride = (int64_t)gridDim.x * rpb;
     const int64_t r_first = (int64_t)blockIdx.x * rpb + tr;
-    F<VW> g[kUnroll], xv[kUnroll], ad[kUnroll];
+    F<VW> g[UN], xv[UN], ad[UN];
     auto load_batch = [&](int64_t r) __attribute__((always_inline)) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const int64_t rr = r + u * stride;
             if (col_ok && rr < N) {
                 g[u].load(dy + rr * lddy + c0);
@@ -473,10 +473,10 @@ __global__ __launch_bounds__(kBlock) void gn_bwd_apply_acc_kernel(const float* _
         drop.seed = rng_state[0];
         drop.step = rng_state[1];
     }
-    for (int64_t r = r_first; r < N; r += stride * kUnroll) {
+    for (int64_t r = r_first; r < N; r += stride * UN) {
         if (r != r_first) load_batch(r);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UN; ++u) {
             const int64_t rr = r + u * stride;
             if (rr >= N) continue;
             bwd_g<VW>(g[u].a, xv[u].a, scale, shift, act, drop, rr, c0);
@@ -699,7 +699,8 @@ extern "C" int glass_graphnorm_bwd_from_stats_f32(const float* dy, int64_t lddy,
         const int n_rep = (int)-nblk;  // replicas the producers used
         GLASS_REQUIRE(n_rep <= kAccRep && (n_rep == 1 || n_rep % 2 == 0), "graphnorm_bwd_from_stats: nblk = -(replicas), 2 .. 16");
         if (C == 64 && n_rep >= 2)
-            hipLaunchKernelGGL((gn_bwd_apply_acc_kernel<4, 64>), dim3(apply_blocks(n_rows, t4)), dim3(kBlock), 0, (hipStream_t)stream,
+            // 80-row tiles (five rows per thread in one round of loads): about one workgroup per CU at ppi_bp-shape
+            hipLaunchKernelGGL((gn_bwd_apply_acc_kernel<4, 64, 5>), dim3((unsigned)ceil_div(n_rows, (int64_t)t4.rpb * 5)), dim3(kBlock), 0, (hipStream_t)stream,
                                dy, lddy, x, ldx, dx, lddx, addend, ldadd, n_rows, (int)C, t4.tc_log2, saved, (const long long*)partial,
                                n_rep, gamma, alpha, dgamma, dbeta, dalpha, accumulate, act, make_drop(p_drop, call_id, C), rng_state);
         else
