@@ -101,6 +101,11 @@ class BatchLabels:
         self.cursor.copy_(desc)
         self._epoch = (pos_all, y_all, idx_batches, pos_dst, y_dst, int(n_idx), int(smax), int(yrb))
 
+    def rewind(self):
+        """The cursor back to the epoch's first batch (device-side: a fill on the current stream, outside any capture)."""
+        if self.cursor is not None:
+            self.cursor[5:6].zero_()
+
     def head_args(self):
         """The label arguments of glass_step_head_f32 (behind the prologue's)."""
         _pos_all, y_all, _idx, pos_dst, y_dst, n_idx, smax, yrb = self._epoch

@@ -170,12 +170,17 @@ class TrainStep:
         restored afterwards: the trajectory is that of a run without this check.  Returns True when the capture is trusted."""
         import torch.distributed as td
         snap = self._snapshot()
+        head = self._labels is not None and self._labels.in_head
+        if head:
+            self._labels.rewind()   # (labels in the head launch: the eager step and the replay must take the SAME batch of the cursor)
         self._fwd_bwd()
         self.bucket.all_reduce_mean()
         self.opt.step()
         torch.cuda.synchronize()
         g_eager, p_eager = self.bucket.flat.clone(), self.bucket.flat_param.clone()
         self._restore(snap)
+        if head:
+            self._labels.rewind()
         self._g_fb.replay()
         torch.cuda.synchronize()
         g_graph, p_graph = self.bucket.flat.clone(), self.bucket.flat_param.clone()

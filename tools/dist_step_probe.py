@@ -14,7 +14,7 @@ import torch
 import torch.distributed as td
 
 
-def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False, force_capture_failure=False):
+def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False, force_capture_failure=False, head=False):
     from glass_amd import synth, losses, ops, dist as gdist, step as step_mod
     step_mod.CAPTURE_COLLECTIVE = capture_collective
     from glass_amd.arena import ParamArena
@@ -38,9 +38,15 @@ def run(dist_mode, nodeid=False, capture_collective=True, force_mismatch=False, 
     step._force_verify_mismatch = force_mismatch  # the replay-vs-eager check of a captured collective reports a mismatch
     step._force_capture_failure = force_capture_failure  # the capture attempt itself fails: agreed on by all ranks, split form
     B = w.batch
-    for k in range(20):
-        b = k % 4
-        step(pos[b * B:(b + 1) * B], y[b * B:(b + 1) * B])
+    if head:  # round 6: the labels inside the step's head launch, the batch named by the device cursor (TrainStep.begin_epoch)
+        assert step.begin_epoch(pos, y, torch.arange(4 * B, device=dev).reshape(4, B), wrap=True)
+        for k in range(20):
+            step.next_step()
+        assert int(step._labels.cursor[5]) == 20, int(step._labels.cursor[5])
+    else:
+        for k in range(20):
+            b = k % 4
+            step(pos[b * B:(b + 1) * B], y[b * B:(b + 1) * B])
     torch.cuda.synchronize()
     # one small bucket: the exchange + Adam are captured with the step when RCCL allows it (else the split form);
     # with an embedding-sized bucket: two graphs + the small all-reduce beside the backward tail, collectives eager
@@ -59,8 +65,10 @@ if __name__ == "__main__":
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29577"), RANK="0", WORLD_SIZE="1")
     torch.cuda.set_device(0)
     single = {nid: run(False, nid) for nid in (False, True)}
+    head_single = run(False, False, head=True)
     td.init_process_group("nccl", device_id=torch.device("cuda", 0))
     split = {nid: run(True, nid) for nid in (False, True)}
+    head_split = {nid: run(True, nid, head=True) for nid in (False, True)}
     eager_coll = run(True, False, capture_collective=False)  # the split form, whatever the capture attempt above did
     opted_out = run(True, False, force_mismatch=True)         # capture succeeds, the check "fails": automatic opt-out
     refused = run(True, False, force_capture_failure=True)    # the capture attempt fails: outcome agreed (all-reduce MIN), split form
@@ -72,6 +80,14 @@ if __name__ == "__main__":
         ok = ok and same
         print("nodeid" if nid else "deg", "single", single[nid][0], split[nid][1], split[nid][0],
               "same" if same else "DIFFERENT", "capture_error:", split[nid][2])
+    same = single[False][0] == head_single[0]
+    ok = ok and same
+    print("deg single", single[False][0], "labels in the head launch:", head_single[0], "same" if same else "DIFFERENT")
+    for nid in (False, True):
+        same = single[nid][0] == head_split[nid][0] and head_split[nid][1] == split[nid][1]
+        ok = ok and same
+        print("nodeid" if nid else "deg", "single", single[nid][0], "head launch +", head_split[nid][1], head_split[nid][0],
+              "same" if same else "DIFFERENT", "verified:", head_split[nid][3], "capture_error:", head_split[nid][2])
     same = single[False][0] == eager_coll[0]
     ok = ok and same and eager_coll[1] == "split"
     print("deg single", single[False][0], eager_coll[1], eager_coll[0], "same" if same else "DIFFERENT")
