@@ -807,9 +807,9 @@ def main():
     # blocks of EXACTLY --steps steps, each bracketed by barrier + synchronize; the first one sizes the run (same count on
     # every rank: it is derived from the max over ranks)
     first = max_over_ranks([timed_block(args.warmup)])[0]
-    # at least --min-blocks blocks and about one second of timed region (the r04 driver run rested on 0.25 s of GPU time: too
-    # short for its 1 Hz utilisation samples to see), at most 400 blocks
-    n_blocks = int(min(max(args.min_blocks, -(-1.0 // max(first, 1e-6))), 400))
+    # at least --min-blocks blocks and about THREE seconds of timed region (the r04 driver run rested on 0.25 s of GPU time, the
+    # r05 one on 1 s: both too short for its 1 Hz utilisation samples to see the GPU phase), at most 1 200 blocks
+    n_blocks = int(min(max(args.min_blocks, -(-3.0 // max(first, 1e-6))), 1200))
     times = [first] + [timed_block(args.warmup + (1 + b) * args.steps) for b in range(n_blocks - 1)]
     times = sorted(max_over_ranks(times))
     dt = times[len(times) // 2]  # the median block
