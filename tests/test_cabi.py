@@ -204,6 +204,38 @@ def test_step_program_entry_points_validate_on_the_host():
     assert lib.glass_graphnorm_stats_exact_f32(p, 64, 16, 64, None, 16, None) == -1
 
 
+def test_round6_entry_points_validate_on_the_host():
+    """glass_step_head_f32 (prologue || labels over a device cursor) and glass_peer_allreduce_adam_f32 (one-shot exchange + Adam):
+    argument checks answer with codes before any launch — no GPU needed."""
+    import ctypes
+    from glass_amd import _lib, peer
+    lib = _lib.load()
+    x = np.zeros(64, dtype=np.float32)
+    p = x.ctypes.data
+    pro = [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0]   # an empty prologue (no pack job, no table, no zero-fill)
+    # no cursor / no label buffers
+    assert lib.glass_step_head_f32(*pro, None, 8, 7, 8, p, p, p, p, p, p, 100, None) == -1
+    assert lib.glass_step_head_f32(*pro, p, 8, 7, 8, None, p, p, p, p, p, 100, None) == -1
+    # a batch of zero rows, a target row size that is not a multiple of 4 bytes, a misaligned cursor
+    assert lib.glass_step_head_f32(*pro, p, 0, 7, 8, p, p, p, p, p, p, 100, None) == -1
+    assert lib.glass_step_head_f32(*pro, p, 8, 7, 6, p, p, p, p, p, p, 100, None) == -1
+    assert lib.glass_step_head_f32(*pro, p + 4, 8, 7, 8, p, p, p, p, p, p, 100, None) == -1
+    assert b"step_head" in lib.glass_last_error_string()
+    # one-shot exchange: world size out of range, a rank without a mapping, a zero spin limit
+    grp = peer._PeerGroupStruct()
+    grp.world, grp.rank = 9, 0
+    args = (100, p, p, p, p, 0.9, 0.999, 1e-8, 0.0, p, p, p)
+    assert lib.glass_peer_allreduce_adam_f32(ctypes.byref(grp), *args, 1000, None, None) == -1
+    grp.world, grp.rank = 2, 0
+    grp.grad[0], grp.flags[0] = p, p          # rank 1 has no arena / flag block
+    assert lib.glass_peer_allreduce_adam_f32(ctypes.byref(grp), *args, 1000, None, None) == -1
+    assert b"rank 1" in lib.glass_last_error_string()
+    grp.grad[1], grp.flags[1] = p, p
+    assert lib.glass_peer_allreduce_adam_f32(ctypes.byref(grp), *args, 0, None, None) == -1
+    assert lib.glass_peer_alloc(0, None) == -1 and lib.glass_peer_export(None, None) == -1 and lib.glass_peer_import(None, None) == -1
+    assert lib.glass_peer_free(None) == 0 and lib.glass_peer_close(None) == 0
+
+
 def test_repeatable_entry_points_refuse_instead_of_falling_back_to_float_atomics():
     """an entry point that documents bitwise repeatability never reaches a float atomicAdd — beyond the
     ordered scatter's LDS staging (and for max pooling) it returns GLASS_E_WS and names the workspace form; the one
