@@ -178,6 +178,9 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
     const bool eff = header[0] != 0.f;
     const float zr = header[1];
     const bool plain = header[2] != 0.f;  // tiles in [o][i] order (wgrad_trans_staged2_body)
+    // header[0] == 3: effective-weight form whose labeled-rows tiles are LIST tiles (wgrad128_comb_kernel): the first
+    // header[3] places of a (z >= nz / 2, y) block instead of one per slab
+    const int n_list = header[0] == 3.f ? (int)header[3] : n_slabs;
     const int zz = eff ? z % (nz / 2) : z;
     const float cs = !eff ? 1.f : (z < nz / 2 ? 1.f - zr : zr);
     const float cl = !eff ? 0.f : (z < nz / 2 ? 2.f * zr - 1.f : 1.f - 2.f * zr);
@@ -191,14 +194,15 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
             p = part_b + (int64_t)zsrc * n_slabs * kOT + (k0 - kTile);
             stride = kOT;
         }
+        const int n_here = (eff && zsrc >= nz / 2) ? n_list : n_slabs;   // tiles of this block that hold sums
         float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int b = tr; b < n_slabs; b += 64) {
+        for (int b = tr; b < n_here; b += 64) {
             float4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int bb = b + 16 * u;
-                v[u] = bb < n_slabs ? *reinterpret_cast<const float4*>(p + (int64_t)bb * stride)
-                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                v[u] = bb < n_here ? *reinterpret_cast<const float4*>(p + (int64_t)bb * stride)
+                                   : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
@@ -372,6 +376,22 @@ static int thin_blocks(int64_t N) {
 
 WgradGeom wgrad_geom(int64_t N, int64_t O, int64_t I) {
     WgradGeom g;
+    if (wgrad128_comb_shape(N, O, I)) {
+        // comb pair of hidden 128 in S / L form with list tiles (wgrad128.hip): slab workgroups + the list workgroups fill one
+        // round of the chip; the buffer keeps the effective-weight layout (an L block has room for n_slabs tiles, n_l are used)
+        int64_t room = 256 - wgrad128_comb_lists(N);
+        if (room < 64) room = 64;
+        int64_t rows = ceil_div(ceil_div(N, room), (int64_t)32) * 32;
+        if (rows < 64) rows = 64;
+        g.rows_per_slab = (int)rows;
+        g.n_slabs = (int)ceil_div(N, rows);
+        if (g.n_slabs < wgrad128_comb_lists(N)) g.n_slabs = wgrad128_comb_lists(N);  // (an L block holds n_l tiles)
+        g.ny = (int)ceil_div(I, kIT);
+        g.nz = (int)ceil_div(O, kOT);
+        g.part_w_floats = (int64_t)g.n_slabs * g.ny * g.nz * kTile;
+        g.part_b_floats = (int64_t)g.n_slabs * g.nz * kOT + kWgradHeaderFloats;
+        return g;
+    }
     if (wgrad128_shape(N, O, I)) {
         // one workgroup per slab covers all four tiles (wgrad128.hip): about one slab per CU, whole 32-row stages
         int64_t rows = ceil_div(ceil_div(N, (int64_t)256), (int64_t)32) * 32;
@@ -672,6 +692,10 @@ extern "C" int glass_dual_linear_wgrad_f32(const float* dsrc, int64_t ldd, const
         N * std::max(std::max(ldd, ldx), act != GLASS_ACT_NONE ? ldt : (int64_t)0) * 4 < (1ll << 31))
         // rows shared through LDS, one workgroup per slab (32-bit buffer offsets: checked above)
         launch_wgrad128_trans(X, ldx, N, g.rows_per_slab, g.n_slabs, part_w, pb_arg, header, sy, st);
+    else if (split && eff && wgrad128_comb_shape(N, O, I) && ldx % 4 == 0 && ldx2 % 4 == 0 && aligned16(X) && aligned16(X2) &&
+             N * std::max(std::max(ldd, ldx), ldx2) * 4 < (1ll << 31))
+        // S tile per slab with the rows shared through LDS + list tiles for the labeled rows (wgrad128.hip)
+        launch_wgrad128_comb(dsrc, ldd, X, ldx, X2, ldx2, mask, N, g.rows_per_slab, g.n_slabs, (float)z_ratio, part_w, pb_arg, header, st);
     else if (split && eff)
         hipLaunchKernelGGL((wgrad_partial_split_kernel<false, true>), grid, dim3(kBlock), 0, st, X, ldx, N, (int)O, (int)I,
                            g.rows_per_slab, part_w, pb_arg, header, sy);

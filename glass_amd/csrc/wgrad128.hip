@@ -169,8 +169,193 @@ __global__ __launch_bounds__(kW128Threads, 1) void wgrad128_trans_kernel(const f
     }
 }
 
+// ---- comb pair (effective-weight S / L form, reference impl/models.py:169-173 backward): S = sum over ALL rows of dc^T [g || x_]
+// ([128 x 256]: one tile per slab, the same eight-wave workgroup with the roles of the images swapped: A = dc^T [128 columns],
+// B = [g || x_]^T [256 columns]), L = the same sum over the LABELED rows.  The labeled rows are few (a batch's subgraph
+// nodes) and this entry point has the label bytes, not the batch's row list: n_l trailing workgroups each scan the label
+// bytes of ONE chunk of N / n_l rows (ordered compaction by wave ballots into LDS, as the register-pipelined kernel does per
+// slab), then walk their list through the same 32-row stages with gathered rows.  Partials in the effective-weight layout of
+// the batched reduce with the L tiles of a (z = 1, y) block being the first n_l of its n_slabs places (header[0] = 3,
+// header[3] = n_l): 4 n_l tiles instead of 4 n_slabs — with one L tile per slab the 224 slabs of config 4 would write and
+// re-read 29 MB of nearly empty tiles.
+constexpr int kW128ListCap = 3968;  // labeled rows one L workgroup can list (the 15.5 KiB of LDS behind the two stage buffers)
+
+__global__ __launch_bounds__(kW128Threads, 1) void wgrad128_comb_kernel(const float* __restrict__ dc, int64_t ldd,
+                                                                        const float* __restrict__ G, int64_t ldg,
+                                                                        const float* __restrict__ X, int64_t ldx,
+                                                                        const uint8_t* __restrict__ mask, int64_t N, int rows_per_slab,
+                                                                        int n_slabs, int n_l, float zr, float* __restrict__ part_w,
+                                                                        float* __restrict__ part_b, float* __restrict__ header) {
+    extern __shared__ float lds[];
+    constexpr int H = 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rp = tid >> 5, ga = tid & 31;
+    const int ob = w >> 2, ib = w & 3;       // this wave's 64 outputs (of 128) / 64 inputs (of 256)
+    const int bx = blockIdx.x;
+    if (header && bx == 0 && tid == 0) {
+        header[0] = 3.f;   // effective-weight form with n_l list tiles (wgrad_reduce_body)
+        header[1] = zr;
+        header[2] = 1.f;   // plain [o][i] tiles
+        header[3] = (float)n_l;
+    }
+    const bool lab = bx >= n_slabs;
+    int* list = reinterpret_cast<int*>(lds + 2 * kW128Words);
+    __shared__ int wave_cnt[kW128Threads / 64];
+    int64_t r0 = 0, r1 = 0;
+    int n_rows;
+    if (!lab) {
+        r0 = (int64_t)bx * rows_per_slab;
+        r1 = r0 + rows_per_slab < N ? r0 + rows_per_slab : N;
+        n_rows = (int)(r1 - r0);
+    } else {
+        // this chunk's labeled rows in row order
+        const int64_t chunk = (N + n_l - 1) / n_l;
+        const int64_t c0 = (int64_t)(bx - n_slabs) * chunk, c1 = c0 + chunk < N ? c0 + chunk : N;
+        int base = 0;
+        for (int64_t p = c0; p < c1; p += kW128Threads) {
+            const int64_t r = p + tid;
+            const bool flag = r < c1 && mask[r] != 0;
+            const unsigned long long bal = __ballot(flag);
+            if (lane == 0) wave_cnt[w] = __popcll(bal);
+            __syncthreads();
+            int off = base, total = 0;
+            for (int ww = 0; ww < kW128Threads / 64; ++ww) {
+                if (ww < w) off += wave_cnt[ww];
+                total += wave_cnt[ww];
+            }
+            if (flag) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)r;
+            base += total;
+            __syncthreads();
+        }
+        n_rows = base;
+    }
+    const int n_st = (n_rows + 31) / 32;
+    const buf_rsrc r_d = make_rsrc(dc, N * ldd * 4), r_g = make_rsrc(G, N * ldg * 4), r_x = make_rsrc(X, N * ldx * 4);
+    struct Raw {
+        float4 d[2], g[2], x[2];
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pos = 32 * st + 2 * rp + u;
+            int ri = -1;
+            if (pos < n_rows) ri = lab ? list[pos] : (int)(r0 + pos);
+            R.d[u] = buf_load4(r_d, ri >= 0 ? (int)((ri * ldd + 4 * ga) * 4) : kBufOOB);
+            R.g[u] = buf_load4(r_g, ri >= 0 ? (int)((ri * ldg + 4 * ga) * 4) : kBufOOB);
+            R.x[u] = buf_load4(r_x, ri >= 0 ? (int)((ri * ldx + 4 * ga) * 4) : kBufOOB);
+        }
+    };
+    float bs[4] = {0.f, 0.f, 0.f, 0.f};  // bias partial of outputs 4 ga + k over this thread's rows
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        unsigned* dI = reinterpret_cast<unsigned*>(lds) + (st & 1) * kW128Words;   // dc^T: 128 columns
+        unsigned* inI = dI + kW128WordsB;                                             // [g || x_]^T: 256 columns
+        const float d0[4] = {R.d[0].x, R.d[0].y, R.d[0].z, R.d[0].w}, d1[4] = {R.d[1].x, R.d[1].y, R.d[1].z, R.d[1].w};
+        const float g0[4] = {R.g[0].x, R.g[0].y, R.g[0].z, R.g[0].w}, g1[4] = {R.g[1].x, R.g[1].y, R.g[1].z, R.g[1].w};
+        const float x0[4] = {R.x[0].x, R.x[0].y, R.x[0].z, R.x[0].w}, x1[4] = {R.x[1].x, R.x[1].y, R.x[1].z, R.x[1].w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            unsigned hi, mid, lo;
+            const int c = 4 * ga + k;
+            bs[k] += d0[k] + d1[k];
+            split2(d0[k], d1[k], hi, mid, lo);
+            int wd = stg2s_word(c, rp);
+            dI[wd] = hi, dI[128 * 16 + wd] = mid, dI[2 * 128 * 16 + wd] = lo;
+            split2(g0[k], g1[k], hi, mid, lo);
+            inI[wd] = hi, inI[256 * 16 + wd] = mid, inI[2 * 256 * 16 + wd] = lo;
+            split2(x0[k], x1[k], hi, mid, lo);
+            wd = stg2s_word(H + c, rp);
+            inI[wd] = hi, inI[256 * 16 + wd] = mid, inI[2 * 256 * 16 + wd] = lo;
+        }
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    wg_f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int it = 0; it < 4; ++it) acc[a][it] = (wg_f32x4){0.f, 0.f, 0.f, 0.f};
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    for (int st = 0; st < n_st; ++st) {
+        const uint4* dI = reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned*>(lds) + (st & 1) * kW128Words);
+        const uint4* inI = dI + kW128WordsB / 4;
+        uint4 af[4][3];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) af[a][pc] = dI[pc * 128 * 4 + stg2s_chunk(64 * ob + 16 * a + j, q)];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            uint4 bf[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bf[pc] = inI[pc * 256 * 4 + stg2s_chunk(64 * ib + 16 * it + j, q)];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) { GLASS_SPLIT6(acc[a][it], af[a], bf); }
+        }
+        if (st + 1 < n_st) {
+            if (st & 1) {
+                commit(st + 1, rawA);
+                issue(st + 3, rawA);
+            } else {
+                commit(st + 1, rawB);
+                issue(st + 3, rawB);
+            }
+            lds_barrier();
+        }
+    }
+    // sub-tile (z, y = ib): z = 0 the S tile of slab bx, z = 1 the L tile of list workgroup bx - n_slabs (the first n_l places of its block)
+    {
+        const int z = lab ? 1 : 0, place = lab ? bx - n_slabs : bx;
+        float* pw = part_w + ((int64_t)(z * 4 + ib) * n_slabs + place) * kTile;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[(64 * ob + 16 * a + 4 * q + r) * kIT + 16 * it + j] = acc[a][it][r];
+    }
+    if (part_b) {
+        lds_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bs[k] += __shfl_xor(bs[k], 32);
+        if (lane < 32) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lds[w * 128 + 4 * ga + k] = bs[k];
+        }
+        lds_barrier();
+        if (tid < 128) {
+            float s = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < 8; ++ww) s += lds[ww * 128 + tid];
+            const int z = lab ? 1 : 0, place = lab ? bx - n_slabs : bx;
+            part_b[((int64_t)z * n_slabs + place) * kOT + tid] = s;
+        }
+    }
+}
+
 // shapes served: the trans pair of hidden 128 (O = 256, I = 128) on a graph that gives every slab a few 32-row stages
 bool wgrad128_shape(int64_t N, int64_t O, int64_t I) { return O == 256 && I == 128 && N >= 8192 && N <= kFusedBwdMaxRows * 4; }
+
+// ... and its comb pair (O = I = 256) in the S / L form above; n_l list workgroups so that a chunk's rows fit one list
+bool wgrad128_comb_shape(int64_t N, int64_t O, int64_t I) { return O == 256 && I == 256 && N >= 8192 && N <= kFusedBwdMaxRows * 4; }
+int wgrad128_comb_lists(int64_t N) {
+    int64_t n_l = ceil_div(N, (int64_t)kW128ListCap);
+    if (n_l < 16) n_l = 16;
+    return (int)n_l;
+}
+
+void launch_wgrad128_comb(const float* dc, int64_t ldd, const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* mask,
+                          int64_t N, int rows_per_slab, int n_slabs, float zr, float* part_w, float* part_b, float* header,
+                          hipStream_t st) {
+    const size_t lds = kW128LdsBytes + (size_t)kW128ListCap * 4;
+    (void)hipFuncSetAttribute((const void*)wgrad128_comb_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int n_l = wgrad128_comb_lists(N);
+    hipLaunchKernelGGL(wgrad128_comb_kernel, dim3((unsigned)(n_slabs + n_l)), dim3(kW128Threads), lds, st, dc, ldd, G, ldg, X, ldx, mask, N,
+                       rows_per_slab, n_slabs, n_l, zr, part_w, part_b, header);
+}
 
 void launch_wgrad128_trans(const float* X, int64_t ldx, int64_t N, int rows_per_slab, int n_slabs, float* part_w, float* part_b,
                            float* header, const WgradSynth& sy, hipStream_t st) {

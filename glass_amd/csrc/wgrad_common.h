@@ -32,6 +32,11 @@ bool wgrad128_shape(int64_t N, int64_t O, int64_t I);
 struct WgradSynth;
 void launch_wgrad128_trans(const float* X, int64_t ldx, int64_t N, int rows_per_slab, int n_slabs, float* part_w, float* part_b,
                            float* header, const WgradSynth& sy, hipStream_t st);
+bool wgrad128_comb_shape(int64_t N, int64_t O, int64_t I);
+int wgrad128_comb_lists(int64_t N);
+void launch_wgrad128_comb(const float* dc, int64_t ldd, const float* G, int64_t ldg, const float* X, int64_t ldx, const uint8_t* mask,
+                          int64_t N, int rows_per_slab, int n_slabs, float zr, float* part_w, float* part_b, float* header,
+                          hipStream_t st);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float wg_f32x4 __attribute__((ext_vector_type(4)));

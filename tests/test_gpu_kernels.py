@@ -744,6 +744,52 @@ def test_wgrad128_rows_shared_through_lds(N, act):
         ops.DENSE_F32_PRODUCTS = prev
 
 
+@pytest.mark.parametrize("N,labeled", [(8192, "few"), (50003, "few"), (50003, "none"), (9001, "all"), (100000 + 31, "dense")])
+def test_wgrad128_comb_pair_list_tiles(N, labeled):
+    """glass_dual_linear_wgrad_f32 for the COMB pair of hidden 128 on a mid-size graph (round 6, wgrad128_comb_kernel: S tile per
+    slab with the rows shared through LDS, the labeled rows as LIST tiles — n_l trailing workgroups each scan one chunk of the
+    label bytes — and the batched reduce's form 3): dW [256 x 256], db against the fp64 sums with a batch-like label density,
+    no labeled row at all, EVERY row labeled (L = S: the list workgroups walk whole chunks) and a third of the rows; odd N, the
+    last row labeled; twice -> identical bits; the f32-input product form of the same call on the same geometry."""
+    from glass_amd import ops, _lib
+    lib = _lib.load()
+    H = 128
+    gen = torch.Generator().manual_seed(N + len(labeled))
+    zr = 0.8
+    dsrc = torch.randn(N, H, generator=gen)
+    X = torch.randn(N, H, generator=gen)
+    X2 = torch.randn(N, H, generator=gen)
+    mask = {"few": torch.rand(N, generator=gen) < 0.02, "none": torch.zeros(N, dtype=torch.bool),
+            "all": torch.ones(N, dtype=torch.bool), "dense": torch.rand(N, generator=gen) < 0.33}[labeled]
+    if labeled == "few":
+        mask[-1] = True
+    c1 = torch.where(mask, zr, 1 - zr).double().reshape(-1, 1)
+    G = torch.cat((c1 * dsrc.double(), (1 - c1) * dsrc.double()), 1)
+    dW_ref, db_ref = G.t() @ torch.cat((X, X2), 1).double(), G.sum(0)
+    dg, Xg, X2g, mg = dsrc.to(DEV), X.to(DEV), X2.to(DEV), mask.to(DEV).to(torch.uint8)
+    ws = ops._wgrad_workspace(torch.device(DEV), N, 2 * H, 2 * H, slot=("w128c", N, labeled))
+    prev = ops.DENSE_F32_PRODUCTS
+    try:
+        for form in (False, True):
+            ops.DENSE_F32_PRODUCTS = form
+            got = []
+            for _ in range(2):
+                dW = torch.full((2 * H, 2 * H), float("nan"), device=DEV)
+                db = torch.full((2 * H,), float("nan"), device=DEV)
+                rc = lib.glass_dual_linear_wgrad_f32(dg.data_ptr(), dg.stride(0), 0, 0, mg.data_ptr(), zr, ops.act_word(0), Xg.data_ptr(),
+                                                     Xg.stride(0), X2g.data_ptr(), X2g.stride(0), N, H, dW.data_ptr(), dW.stride(0),
+                                                     db.data_ptr(), 0, ws.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                assert rc == 0, lib.glass_last_error_string()
+                got.append((dW.cpu(), db.cpu()))
+            e_w, e_b = rel_inf(got[0][0], dW_ref), rel_inf(got[0][1], db_ref)
+            assert e_w < TOL and e_b < TOL, (form, e_w, e_b)
+            assert torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1])
+            if not form:
+                record_parity(f"kernel/wgrad128_comb_N{N}_{labeled}", dW_rel_inf=e_w, db_rel_inf=e_b)
+    finally:
+        ops.DENSE_F32_PRODUCTS = prev
+
+
 @pytest.mark.parametrize("H,N,comb", [(128, 3001, False), (256, 4099, False), (256, 4099, True), (256, 70001, True),
                                       # hidden 64 (round 6: the staged forward kernels take the split form too)
                                       (64, 3001, False), (64, 17080, False), (64, 3001, True)])
