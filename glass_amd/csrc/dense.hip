@@ -799,12 +799,15 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
         }
     }
 }
-// The same body with a RUN-TIME number of stages ("tall" row tiles, see comb_fwd_eff3_kernel): a workgroup takes n_tiles
-// consecutive 64-row tiles, loads its weight slice and the GraphNorm statistics once and keeps the double-buffered stage
-// pipeline running across the tiles; the backward column sums of a GraphNorm are still written per 64-row tile (the partials
-// form keeps its ABI: one entry per tile), flushed every four stages.
+// The same body with a RUN-TIME number of stages ("tall" row tiles, see comb_fwd_eff3_kernel): a workgroup takes
+// `stages_per_wg` consecutive 16-row stages, loads its weight slice and the GraphNorm statistics once and keeps the
+// double-buffered stage pipeline running across them.  The split is by STAGES, not by 64-row tiles (round 6): 50 000 rows are
+// 782 tiles = 196 workgroups of 4 tiles — 60 of the 256 CUs idle, the others 16 stages deep —, but 3 125 stages = 241
+// workgroups of 13.  The backward column sums of a GraphNorm keep their ABI (one entry per 64-row tile, summed by the
+// consumer): workgroup b writes ITS sums (float per lane over four stages, double across) to entry b and zeroes the entries
+// b + grid, b + 2 grid, ... < n_tiles (grid <= n_tiles: a workgroup covers at least four stages).
 template <int H>
-__global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int tiles_per_wg) {
+__global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int stages_per_wg) {
     static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
     extern __shared__ float4 lds_w3[];
     float* lds = reinterpret_cast<float*>(lds_w3);
@@ -820,12 +823,10 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int ti
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
     const int rs = tid / (H / 4), ga = tid % (H / 4);
-    const int64_t tile0 = (int64_t)blockIdx.x * tiles_per_wg;
-    const int64_t n_tiles_all = (N + 63) / 64;
-    const int n_tiles = (int)(tile0 + tiles_per_wg <= n_tiles_all ? tiles_per_wg : n_tiles_all - tile0);
-    if (n_tiles <= 0) return;
-    const int nst = 4 * n_tiles;
-    const int64_t r0 = tile0 * 64;
+    const int64_t stage0 = (int64_t)blockIdx.x * stages_per_wg;
+    const int64_t n_stages_all = (N + 15) / 16, n_tiles_all = (N + 63) / 64;
+    const int nst = (int)(stage0 + stages_per_wg <= n_stages_all ? stages_per_wg : n_stages_all - stage0);
+    const int64_t r0 = stage0 * 16;
     const buf_rsrc r_d = make_rsrc(dsrc, N * ldd * 4), r_t = make_rsrc(A.T ? A.T : dsrc, A.T ? N * ldt * 4 : 0);
     const buf_rsrc r_m = make_rsrc(A.mask, N), r_out = make_rsrc(A.out, N * ldo * 4);
     const buf_rsrc r_add = make_rsrc(A.addend ? A.addend : dsrc, A.addend ? N * ldadd * 4 : 0);
@@ -908,24 +909,8 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int ti
     issue(2, rawA);
     lds_barrier();
     float s1 = 0.f, s2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;  // this lane's column sums: float over four stages (16 values, as the 64-row tiles had it), double across
     const int c = 16 * w + j;
-    auto flush = [&](int64_t tile) __attribute__((always_inline)) {  // this lane's column sums of one 64-row tile
-        double a = (double)s1, b2 = (double)s2;
-        a += __shfl_xor(a, 16);
-        b2 += __shfl_xor(b2, 16);
-        a += __shfl_xor(a, 32);
-        b2 += __shfl_xor(b2, 32);
-        if (q == 0) {
-            if (gs.exact) {
-                gn_acc_add(reinterpret_cast<long long*>(gs.partial), (int)(tile % gs.exact), 0, c, H, a, kAccScaleBwd);
-                gn_acc_add(reinterpret_cast<long long*>(gs.partial), (int)(tile % gs.exact), 1, c, H, b2, kAccScaleBwd);
-            } else {
-                gs.partial[((size_t)tile * 2) * H + c] = a;
-                gs.partial[((size_t)tile * 2 + 1) * H + c] = b2;
-            }
-        }
-        s1 = s2 = 0.f;
-    };
     auto stage = [&](int st, Raw& Rn) __attribute__((always_inline)) {
         const float* At = lds + (st & 1) * kBuf;
         const float* ADD = At + 16 * RA;
@@ -970,12 +955,33 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int ti
             s1 = fmaf(vl, uu[r], s1);
             s2 = fmaf(vl, xx[r], s2);
         }
-        if (gn_on && (st & 3) == 3) flush(tile0 + (st >> 2));
+        if (gn_on && (st & 3) == 3) {
+            d1 += (double)s1, d2 += (double)s2;
+            s1 = s2 = 0.f;
+        }
         if (st + 1 < nst) lds_barrier();
     };
     for (int st = 0; st < nst; st += 2) {
         stage(st, rawB);
-        stage(st + 1, rawA);  // (nst is a multiple of 4)
+        if (st + 1 < nst) stage(st + 1, rawA);
+    }
+    if (!gn_on) return;
+    d1 += (double)s1, d2 += (double)s2;
+    d1 += __shfl_xor(d1, 16);
+    d2 += __shfl_xor(d2, 16);
+    d1 += __shfl_xor(d1, 32);
+    d2 += __shfl_xor(d2, 32);
+    if (q != 0) return;
+    if (gs.exact) {
+        gn_acc_add(reinterpret_cast<long long*>(gs.partial), (int)(blockIdx.x % gs.exact), 0, c, H, d1, kAccScaleBwd);
+        gn_acc_add(reinterpret_cast<long long*>(gs.partial), (int)(blockIdx.x % gs.exact), 1, c, H, d2, kAccScaleBwd);
+        return;
+    }
+    gs.partial[((size_t)blockIdx.x * 2) * H + c] = d1;
+    gs.partial[((size_t)blockIdx.x * 2 + 1) * H + c] = d2;
+    for (int64_t e = (int64_t)blockIdx.x + gridDim.x; e < n_tiles_all; e += gridDim.x) {
+        gs.partial[((size_t)e * 2) * H + c] = 0.0;
+        gs.partial[((size_t)e * 2 + 1) * H + c] = 0.0;
     }
 }
 constexpr size_t trans_dgrad3_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 32) * sizeof(float); }
@@ -2844,10 +2850,11 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         const DgradArgs d128{dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs};
         const int64_t n_tiles = ceil_div(n_nodes, 64);
         if (lab_knob("GLASS_TRANS_DGRAD3", 1) && n_tiles > 256) {  // more than one round of 64-row tiles: tall tiles, one workgroup per CU (trans_dgrad3_kernel)
-            const int tiles_per_wg = (int)ceil_div(n_tiles, 256);
+            const int64_t n_stages = ceil_div(n_nodes, 16);
+            const int stages_per_wg = (int)ceil_div(n_stages, 256);  // >= 5 here: never more workgroups than 64-row tiles (the partials' entries)
             const size_t lds3 = trans_dgrad3_lds(128);
             allow_lds(trans_dgrad3_kernel<128>, lds3);
-            hipLaunchKernelGGL((trans_dgrad3_kernel<128>), dim3((unsigned)ceil_div(n_tiles, tiles_per_wg)), dim3(512), lds3, st, d128, tiles_per_wg);
+            hipLaunchKernelGGL((trans_dgrad3_kernel<128>), dim3((unsigned)ceil_div(n_stages, stages_per_wg)), dim3(512), lds3, st, d128, stages_per_wg);
             const int rc3 = launch_status("glass_dual_linear_dgrad_f32 (staged, tall, hidden 128)");
             return rc3 ? rc3 : wgrad_after();
         }

@@ -1027,6 +1027,50 @@ def test_dense_pack_forward_effective_weight_appendix():
         assert torch.allclose(app[off:off + 4], Weff[n, 16 * ks + 4 * q:16 * ks + 4 * q + 4], rtol=0, atol=1e-6)
 
 
+@pytest.mark.parametrize("N", [16400, 50003, 70001])
+def test_trans_dgrad_hidden128_stage_split(N):
+    """Trans pair's data gradient at hidden 128 on a graph of more than 256 row tiles (trans_dgrad3_kernel: workgroups take
+    runs of 16-row STAGES — 13 of them at N = 50 003, the last workgroup a shorter run, an odd count —): out = (mix'(dout) .
+    ELU'(T)) @ Wstack + addend against fp64, and the backward-GraphNorm column sums of its epilogue — one partials entry per
+    WORKGROUP, the remaining per-tile entries zeroed by the kernel (the buffer is handed over full of NaNs) — against fp64
+    sums; twice -> identical bits."""
+    from glass_amd import stack
+    from glass_amd.arena import ParamArena
+    from glass_amd.factory import build_glass
+    torch.manual_seed(N)
+    H, z = 128, 0.8
+    model = build_glass(H, 1, 5, 3, "mean", "sum", z).to(DEV).train()
+    ParamArena(model)
+    st = model.conv.convs[0]._stack["trans"]
+    gmod = model.conv.convs[0].gn
+    mask = (torch.rand(N, device=DEV) < 0.1).to(torch.uint8)
+    mask[-1] = 1
+    dsrc, T = torch.randn(N, H, device=DEV), torch.randn(N, 2 * H, device=DEV)
+    addend, gx = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+    saved = torch.cat([gx.mean(0), 1.0 / (gx.var(0, unbiased=False) + 1e-5).sqrt(), torch.ones(H, device=DEV),
+                       torch.zeros(H, device=DEV)]).contiguous()
+    nblk = -(-N // int(stack._lib.load().glass_dual_linear_stat_rows(H)))
+    got = []
+    for _ in range(2):
+        out = torch.full((N, H), float("nan"), device=DEV)
+        gpart = torch.full((nblk, 2, H), float("nan"), dtype=torch.float64, device=DEV)
+        stack._dual_dgrad(dsrc, T, st, mask, z, 1, H, addend, out, gn=(gpart, gx, saved, gmod.mean_scale, 0, 0.0, 0))
+        got.append((out, gpart))
+    W = st[0].double()
+    lab = mask.bool().unsqueeze(1)
+    w1 = torch.where(lab, torch.tensor(z, device=DEV, dtype=torch.float64), torch.tensor(1 - z, device=DEV, dtype=torch.float64))
+    elu_g = lambda t: torch.where(t > 0, torch.ones_like(t), torch.exp(t))
+    d = dsrc.double()
+    ref = (w1 * d * elu_g(T[:, :H].double())) @ W[:H] + ((1 - w1) * d * elu_g(T[:, H:].double())) @ W[H:] + addend.double()
+    out, gpart = got[0]
+    e_out = rel_inf(out.double(), ref)
+    xhat = (gx.double() - gmod.mean_scale.double() * saved[:H].double()) * saved[H:2 * H].double()
+    e_s1, e_s2 = rel_inf(gpart[:, 0].sum(0), ref.sum(0)), rel_inf(gpart[:, 1].sum(0), (ref * xhat).sum(0))
+    assert e_out < TOL and e_s1 < TOL and e_s2 < TOL, (e_out, e_s1, e_s2)
+    assert torch.equal(got[1][0], out) and torch.equal(got[1][1], gpart)
+    record_parity(f"kernel/trans_dgrad128_stage_split_N{N}", out_rel_inf=e_out, gn_sum_rel_inf=max(e_s1, e_s2))
+
+
 @pytest.mark.parametrize("pattern", ["none", "one_per_tile_3", "sparse", "cap3", "cap4", "cap7", "cap8", "all"])
 def test_comb_pair_effective_weight_paths(pattern):
     """Comb pair at hidden 256 on the tiled kernels: the effective-weight (one product) and two-product paths — forward
