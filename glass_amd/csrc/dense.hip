@@ -1902,6 +1902,243 @@ __global__ __launch_bounds__(kBlock * WG) void trans_fwd2_kernel(const float* __
     }
 }
 
+// ---- trans forward, stage-run form (hidden 128; round 6) ------------------------------------------------------------------
+// The LDS-tiled kernel served this pair at hidden 128 (tiled_fwd_kernel<128, false, 128>: 391 tiles of 128 rows at em_user-shape,
+// every tile re-streaming the 196 KiB cut weight image through LDS, the tiles in phase — K loops with HBM idle, then one
+// chip-wide burst of 77 MB of T and m with the matrix cores idle: 2.2 + 20.6 + 14.3 us by phase stamps, DESIGN 7 R4-a').  This is
+// comb_fwd_eff3_kernel's form for the trans pair: eight waves, wave w owns columns 16 w .. 16 w + 15 of BOTH halves (the label
+// mix needs f1 and f0 of a column in one lane) and keeps its two weight slices in registers for the whole run (K = 128: 2 x 8
+// float4, cut once into 2 x 12 uint4 in the split form); a workgroup walks rows_main rows (one round of the chip) in 16-row
+// stages, double-buffered loads two stages ahead, so loads, products and stores of different stages overlap all along the
+// launch.  Image: layout kLayoutWave16Cols ([256 outputs][128]).  xa_index: the rows are gathered from the embedding table
+// (layer 0; the index of a stage is requested two stages before its rows).  Statistics (partials form): workgroup b writes
+// entry b and zeroes entries b + grid, ... (one entry per 64 rows in the ABI; rows_main >= 64).
+template <int H, bool SP>
+__global__ __launch_bounds__(4 * H) void trans_fwd3_kernel(const float* __restrict__ xa, int64_t lda, int64_t xa_rows,
+                                                           const float* __restrict__ Wimg, const float* __restrict__ bias,
+                                                           const uint8_t* __restrict__ mask, float zr, float omz, int act,
+                                                           float* __restrict__ T, int64_t ldt, float* __restrict__ out,
+                                                           int64_t ldo, int64_t N, double* __restrict__ stats, GnPrologue pro,
+                                                           const int64_t* __restrict__ xa_index, int rows_main) {
+    static_assert(H == 128, "eight waves x 16 columns of both halves");
+    constexpr int THREADS = 4 * H, NTL = H / 16, KF4 = H / 16;  // float4 of one weight slice per lane (k = 32 q + 4 tt + e)
+    constexpr int KT = H, RS = KT + 4;
+    constexpr int RSB = KT + 8;        // SP: bf16 elements per row of a piece plane (272 B: 16 lanes' fragment reads cover the 64 banks once)
+    constexpr int kPlane = 16 * RSB;
+    __shared__ __attribute__((aligned(16))) float tile[SP ? 1 : 2][SP ? 4 : 16 * RS];
+    __shared__ __attribute__((aligned(16))) unsigned short tile_s[SP ? 2 : 1][SP ? 3 * kPlane : 8];  // [buffer][piece][row][k]
+    __shared__ __attribute__((aligned(16))) float gn_coef_s[2 * H];
+    __shared__ int rowflag_s[2][16];   // per stage buffer: row of each slot (-1 none; bit 30: labeled row)
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_main;
+    const int n_rows = (int)(r0 + rows_main <= N ? rows_main : N - r0);
+    const int nst = (n_rows + 15) / 16;
+    const buf_rsrc r_xa = make_rsrc(xa, xa_rows * lda * 4), r_out = make_rsrc(out, N * ldo * 4);
+    const buf_rsrc r_T = make_rsrc(T ? T : out, T ? N * ldt * 4 : 0);
+    const buf_rsrc r_side = make_rsrc(pro.side ? pro.side : out, pro.side ? N * pro.lds * 4 : 0);
+    const buf_rsrc r_mask = make_rsrc(mask, N);
+    const int rs = tid / (H / 4), ga = tid % (H / 4);
+    auto row_of = [&](int st) __attribute__((always_inline)) -> int {
+        const int slot = 16 * st + rs;
+        return (st < nst && slot < n_rows) ? (int)(r0 + slot) : -1;
+    };
+    // gathered operand: the index of stage s is loaded two issues before the rows of stage s (ia = index of the next stage
+    // to be issued, ib = of the one after it)
+    auto index_of = [&](int st) __attribute__((always_inline)) -> int {
+        const int r = row_of(st);
+        if (r < 0) return 0;
+        const int64_t g = xa_index[r];
+        return (int)(g < 0 ? 0 : (g >= xa_rows ? xa_rows - 1 : g));
+    };
+    int ia = 0, ib = 0;
+    if (xa_index) ia = index_of(0), ib = index_of(1);
+    struct Raw {
+        float4 a;
+        unsigned mk;
+        int row;
+    };
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int r = row_of(st);
+        int src = r;
+        if (xa_index) {
+            src = ia;
+            ia = ib;
+            ib = index_of(st + 2);
+        }
+        R.row = r;
+        R.a = buf_load4(r_xa, r >= 0 ? (int)((src * lda + 4 * ga) * 4) : kBufOOB);
+        R.mk = __builtin_amdgcn_raw_buffer_load_b8(r_mask, r >= 0 ? r : kBufOOB, 0, 0);
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    GnCoefRegs CR;
+    const bool fold_here = pro.saved != nullptr;
+    if (fold_here && pro.src.acc) gn_fwd_coef_issue<H, THREADS>(pro.src, CR);
+    const float4* img = reinterpret_cast<const float4*>(Wimg);
+    float4 bw1[KF4], bw0[KF4];
+#pragma unroll
+    for (int tt = 0; tt < KF4; ++tt) {
+        bw1[tt] = img[(((tt >> 2) * 2 * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+        bw0[tt] = img[(((tt >> 2) * 2 * NTL + NTL + w) * 4 + (tt & 3)) * 64 + lane];
+    }
+    float b1 = bias[16 * w + j], b0 = bias[H + 16 * w + j];
+    if (fold_here && pro.src.acc) {
+        gn_fwd_coef_issue_params<H>(pro.src, CR);
+        glass_pin(CR.gamma);
+        glass_pin(CR.beta);
+        glass_pin(CR.alpha);
+    }
+    glass_pin(b1);
+    glass_pin(b0);
+    Drop drop = pro.drop;
+    if (pro.saved && drop.p > 0.f) {
+        drop.seed = pro.rng_state[0];
+        drop.step = pro.rng_state[1];
+    }
+    if (fold_here) gn_fwd_coef_finish<H, THREADS>(pro.src, pro.saved, N, CR, gn_coef_s);
+    // SP: the wave's two weight slices as bf16 pieces, block b = the lane's k = 32 q + 8 b .. + 7 (bw[2b], bw[2b + 1])
+    uint4 bwc1[SP ? KF4 / 2 : 1][3], bwc0[SP ? KF4 / 2 : 1][3];
+    if constexpr (SP) {
+#pragma unroll
+        for (int b = 0; b < KF4 / 2; ++b) {
+            const Split4 s0 = split4(bw1[2 * b]), s1 = split4(bw1[2 * b + 1]);
+            bwc1[b][0] = make_uint4(s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y);
+            bwc1[b][1] = make_uint4(s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y);
+            bwc1[b][2] = make_uint4(s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y);
+            const Split4 u0 = split4(bw0[2 * b]), u1 = split4(bw0[2 * b + 1]);
+            bwc0[b][0] = make_uint4(u0.hi.x, u0.hi.y, u1.hi.x, u1.hi.y);
+            bwc0[b][1] = make_uint4(u0.mid.x, u0.mid.y, u1.mid.x, u1.mid.y);
+            bwc0[b][2] = make_uint4(u0.lo.x, u0.lo.y, u1.lo.x, u1.lo.y);
+        }
+    }
+    lds_barrier();  // coefficients
+    const bool pro_on = pro.saved != nullptr;
+    float sc[4] = {1.f, 1.f, 1.f, 1.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pro_on) {
+        const float4 s4 = *reinterpret_cast<const float4*>(gn_coef_s + 4 * ga);
+        const float4 h4 = *reinterpret_cast<const float4*>(gn_coef_s + H + 4 * ga);
+        sc[0] = s4.x, sc[1] = s4.y, sc[2] = s4.z, sc[3] = s4.w;
+        sh[0] = h4.x, sh[1] = h4.y, sh[2] = h4.z, sh[3] = h4.w;
+    }
+    const int pact = pro_on ? pro.act : GLASS_ACT_NONE;
+    const bool drop_on = pro_on && drop.p > 0.f;
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        const int r = R.row;
+        float a[4] = {R.a.x, R.a.y, R.a.z, R.a.w};
+        float ds[4] = {1.f, 1.f, 1.f, 1.f};
+        if (drop_on) drop_scales<4>(drop, r < 0 ? 0 : r, 4 * ga, ds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float h = fmaf(a[k], sc[k], sh[k]);
+            h = act_fast(pact, h);
+            a[k] = h * ds[k];
+        }
+        const float4 v = make_float4(a[0], a[1], a[2], a[3]);
+        buf_store4(r_side, (pro_on && pro.side && r >= 0) ? (int)((r * pro.lds + 4 * ga) * 4) : kBufOOB, v);
+        if constexpr (SP) {
+            const Split4 sa = split4(v);
+            unsigned short* P = tile_s[st & 1] + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = sa.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = sa.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = sa.lo;
+        } else {
+            *reinterpret_cast<float4*>(tile[SP ? 0 : (st & 1)] + rs * RS + 4 * ga) = v;
+        }
+        if (ga == 0) rowflag_s[st & 1][rs] = (r >= 0 && R.mk != 0) ? (r | (1 << 30)) : r;
+    };
+    float ssum = 0.f, ssq = 0.f;
+    double dsum = 0.0, dsq = 0.0;  // column sums: float over four stages (16 values per lane), double across
+    commit(0, rawA);
+    issue(2, rawA);
+    lds_barrier();
+    const int c = 16 * w + j;
+    auto stage = [&](int st, Raw& Rn) __attribute__((always_inline)) {
+        int rv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rv[r] = rowflag_s[st & 1][4 * q + r];
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP) {
+            // lane (j, q): row j of the stage, k = 32 q + 8 b .. + 7 of block b: one 16-byte read per piece
+            const unsigned short* P = tile_s[st & 1] + j * RSB + (KT / 4) * q;
+#pragma unroll
+            for (int b = 0; b < KF4 / 2; ++b) {
+                uint4 af[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) af[pc] = *reinterpret_cast<const uint4*>(P + pc * kPlane + 8 * b);
+#define GLASS_SMMA16(ACC, BW, pa, pb)                                                                                 \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[pa]), __builtin_bit_cast(bf16x8, BW[b][pb]), ACC, 0, 0, 0)
+                GLASS_SMMA16(acc1, bwc1, 1, 1); GLASS_SMMA16(acc0, bwc0, 1, 1);  // small terms first; the two halves' chains interleave
+                GLASS_SMMA16(acc1, bwc1, 2, 0); GLASS_SMMA16(acc0, bwc0, 2, 0);
+                GLASS_SMMA16(acc1, bwc1, 0, 2); GLASS_SMMA16(acc0, bwc0, 0, 2);
+                GLASS_SMMA16(acc1, bwc1, 1, 0); GLASS_SMMA16(acc0, bwc0, 1, 0);
+                GLASS_SMMA16(acc1, bwc1, 0, 1); GLASS_SMMA16(acc0, bwc0, 0, 1);
+                GLASS_SMMA16(acc1, bwc1, 0, 0); GLASS_SMMA16(acc0, bwc0, 0, 0);
+#undef GLASS_SMMA16
+            }
+        } else {
+            const float* A = tile[SP ? 0 : (st & 1)] + j * RS + (KT / 4) * q;
+            float4 a4[KF4];
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(A + 4 * tt);
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) {
+                const float x[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w};
+                const float y1[4] = {bw1[tt].x, bw1[tt].y, bw1[tt].z, bw1[tt].w}, y0[4] = {bw0[tt].x, bw0[tt].y, bw0[tt].z, bw0[tt].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y1[e], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y0[e], acc0, 0, 0, 0);
+                }
+            }
+        }
+        if (st + 1 < nst) {
+            commit(st + 1, Rn);
+            issue(st + 3, Rn);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0;
+            const int row = rv[r] & ((1 << 30) - 1);
+            const bool lab = (rv[r] >> 30) & 1;
+            const float w1 = lab ? zr : omz, w0 = lab ? omz : zr;
+            const float v1 = acc1[r] + b1, v0 = acc0[r] + b0;
+            buf_store1(r_T, (live && T) ? (int)((row * ldt + c) * 4) : kBufOOB, v1);
+            buf_store1(r_T, (live && T) ? (int)((row * ldt + H + c) * 4) : kBufOOB, v0);
+            float a1 = v1, a0 = v0;
+            a1 = act_fast(act, a1), a0 = act_fast(act, a0);
+            const float o = w1 * a1 + w0 * a0;
+            buf_store1(r_out, live ? (int)((row * ldo + c) * 4) : kBufOOB, o);
+            ssum += live ? o : 0.f;
+            ssq += live ? o * o : 0.f;
+        }
+        if ((st & 3) == 3) {
+            dsum += (double)ssum, dsq += (double)ssq;
+            ssum = ssq = 0.f;
+        }
+        if (st + 1 < nst) lds_barrier();
+    };
+    for (int st = 0; st < nst; st += 2) {
+        stage(st, rawB);
+        if (st + 1 < nst) stage(st + 1, rawA);
+    }
+    if (stats == nullptr) return;
+    dsum += (double)ssum, dsq += (double)ssq;
+    dsum += __shfl_xor(dsum, 16);
+    dsq += __shfl_xor(dsq, 16);
+    dsum += __shfl_xor(dsum, 32);
+    dsq += __shfl_xor(dsq, 32);
+    if (q != 0) return;
+    stats[((size_t)blockIdx.x * 2) * H + c] = dsum;
+    stats[((size_t)blockIdx.x * 2 + 1) * H + c] = dsq;
+    const int64_t n_entries = (N + 63) / 64;
+    for (int64_t e = (int64_t)blockIdx.x + gridDim.x; e < n_entries; e += gridDim.x) {
+        stats[((size_t)e * 2) * H + c] = 0.0;
+        stats[((size_t)e * 2 + 1) * H + c] = 0.0;
+    }
+}
+
 // Data gradient of the comb pair in the same form:  d[g || x_][r] = dc[r] . (w1 W1 + w0 W0): K = H instead of 2H (one
 // K pass), the mix coefficient folded into the weight.  The first H output columns are the gradient of conv.gn's output:
 // its backward column sums are accumulated by the epilogue as in dual_dgrad_body (one partial per workgroup, the extra
@@ -2667,7 +2904,7 @@ extern "C" int glass_dual_linear_layout(int64_t H) { return narrow_shape_ok(H) ?
 // ... and of the FORWARD operand image for (H, K = input width): 0 wave16, 1 paired, 5 paired + effective-weight appendix
 // (comb pair, K = 2H, at hidden 256 / 512: 1.5 x the weight's floats)
 extern "C" int glass_dual_linear_fwd_layout(int64_t H, int64_t K) {
-    if (GLASS_TRANS_FWD_V2 && wave16_shape_ok(H) && K == H) return kLayoutWave16Cols;  // trans pair at hidden 64: trans_fwd2_kernel
+    if (GLASS_TRANS_FWD_V2 && (wave16_shape_ok(H) || H == 128) && K == H) return kLayoutWave16Cols;  // trans pair at hidden 64 / 128: trans_fwd2_kernel / trans_fwd3_kernel
     if (!tiled_here(H)) return kLayoutWave16;
     return tiled_eff_fwd_shape(H, K) ? kLayoutTiledPairedEff : kLayoutTiledPaired;
 }
@@ -2726,6 +2963,23 @@ extern "C" int glass_dual_linear_fwd_f32(const float* xa, int64_t lda, const flo
     // dynamic LDS: one weight image per K-pass in flight (NT*256 bytes each; two when K needs > 1 pass and both fit)
     const size_t lds_comb = lds_bytes(2 * H, (int)(2 * H / 64)), lds_trans = lds_bytes(2 * H, (int)(H / 64));
     const GnPrologue pro{gn_saved, (int)H, gn_act, make_drop(gn_saved ? p_drop : 0.f, call_id, H), rng_state, xa_out, ldxo, esrc};
+    if (GLASS_TRANS_FWD_V2 && !comb && H == 128) {  // stage-run form (image in layout kLayoutWave16Cols: glass_dual_linear_fwd_layout)
+        const int64_t src_rows = xa_index ? xa_rows : n_nodes;
+        const int64_t ld_max = std::max(std::max(ldo, T ? ldt : (int64_t)0), gn_saved ? ldxo : (int64_t)0);
+        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31) && src_rows * lda * 4 < (1ll << 31),
+                      "dual_linear_fwd: rows * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
+        // one round of the chip; never fewer than 64 rows per workgroup (the statistics have one entry per 64 rows)
+        int64_t rows_main = ceil_div(ceil_div(n_nodes, (int64_t)256), (int64_t)16) * 16;
+        if (rows_main < 64) rows_main = 64;
+        const dim3 grid3((unsigned)ceil_div(n_nodes, rows_main));
+        if (tiled_split_products())
+            hipLaunchKernelGGL((trans_fwd3_kernel<128, true>), grid3, dim3(512), 0, st, xa, lda, src_rows, W, bias, mask, zr, omz, act, T,
+                               ldt, out, ldo, n_nodes, stats, pro, xa_index, (int)rows_main);
+        else
+            hipLaunchKernelGGL((trans_fwd3_kernel<128, false>), grid3, dim3(512), 0, st, xa, lda, src_rows, W, bias, mask, zr, omz, act, T,
+                               ldt, out, ldo, n_nodes, stats, pro, xa_index, (int)rows_main);
+        return launch_status("glass_dual_linear_fwd_f32 (stage run, hidden 128)");
+    }
     if (tiled_here(H)) {
         GnPrologue tpro = pro;
         tpro.gather = xa_index;
@@ -3247,6 +3501,7 @@ static int pack_launch(const float* const* src, float* const* dst, const int64_t
                       (long long)dst_floats[k], (long long)glass_dense_image_floats(NT[k], KT[k], transposed[k]));
         GLASS_REQUIRE(layout == kLayoutWave16 ||
                           (layout == kLayoutWave16Cols && ((NT[k] == 128 && KT[k] == 64 && !(transposed[k] & 1)) ||
+                                                           (NT[k] == 256 && KT[k] == 128 && !(transposed[k] & 1)) ||
                                                            (NT[k] == 64 && KT[k] == 128 && (transposed[k] & 1)) ||
                                                            (NT[k] == 128 && KT[k] == 256 && (transposed[k] & 1)))) ||
                           ((layout == kLayoutTiledPaired || layout == kLayoutTiledPlain) && NT[k] % 256 == 0) ||
