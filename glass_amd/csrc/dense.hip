@@ -2139,6 +2139,263 @@ __global__ __launch_bounds__(4 * H) void trans_fwd3_kernel(const float* __restri
     }
 }
 
+// ---- comb data gradient, stage-run form (hidden 128; round 6) --------------------------------------------------------------
+// d[g || x_][r] = dc[r] . W_eff(label of r)  ([N, 128] x [128, 256]; no activation, so the mix folds into the weight).  The
+// LDS-tiled kernel served this at hidden 128 (tiled_dgrad_kernel<128, 256, 128, 256>: 60.7 us at em_user-shape for ~100 MB of
+// traffic, 1.8 + 16.3 + 20.1 us by phase with the tiles in lockstep).  Here trans_fwd3_kernel's form: eight waves, wave w owns
+// columns 16 w .. + 15 of BOTH output halves (dg and dx_) and keeps the two slices of the UNLABELED effective weight in
+// registers while its workgroup walks rows_main rows in 16-row stages.  Labeled rows (a batch's subgraph nodes: a few per
+// workgroup) are skipped by that pass — the workgroup lists them up front (ordered compaction of its label bytes) — and done
+// in a second, short pass with the LABELED effective weight loaded into the same registers and the rows gathered by the
+// list.  No row list from the caller, no extra workgroups, one statistics entry per workgroup (both passes in one sum).
+// The first 128 output columns are the gradient of conv.gn's output: its backward column sums ride in the epilogue as in
+// trans_dgrad3_kernel (u and xhat . u prepared by the loader, through LDS).
+// Image: layout kLayoutWave16EffDgradCols ([256 outputs][128], unlabeled then labeled).
+constexpr int kCombDgrad3List = 4096;  // labeled rows a workgroup can list = its most rows (the host caps rows_main)
+template <int H, bool SP>
+__global__ __launch_bounds__(4 * H) void comb_dgrad3_kernel(const float* __restrict__ dsrc, int64_t ldd,
+                                                            const uint8_t* __restrict__ mask, const float* __restrict__ WT,
+                                                            const uint64_t* __restrict__ rng_state, float* __restrict__ out,
+                                                            int64_t ldo, int64_t N, GnBwdStats gs, int rows_main) {
+    static_assert(H == 128, "eight waves x 16 columns of both halves");
+    extern __shared__ float4 lds_cd3[];
+    float* lds = reinterpret_cast<float*>(lds_cd3);
+    constexpr int THREADS = 4 * H, NTL = H / 16, KF4 = H / 16;
+    constexpr int KT = H, RS = KT + 4, RP = H + 4;
+    constexpr int RSB = KT + 8, kPlane = 16 * RSB;
+    constexpr int kAFloats = SP ? (3 * kPlane) / 2 : 16 * RS;
+    constexpr int kBuf = kAFloats + 2 * 16 * RP;  // A | U | XU  (floats per stage buffer)
+    int* rowflag_s = reinterpret_cast<int*>(lds + 2 * kBuf);   // [2][16]: row of each slot (-1 none; bit 30: computed, not stored / counted)
+    int* wave_cnt = rowflag_s + 32;                             // [8]
+    int* list = wave_cnt + 8;                                   // [kCombDgrad3List]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, q = lane >> 4;
+    const int rs = tid / (H / 4), ga = tid % (H / 4);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_main;
+    const int n_rows = (int)(r0 + rows_main <= N ? rows_main : N - r0);
+    const bool gn_on = gs.partial != nullptr;
+    const buf_rsrc r_d = make_rsrc(dsrc, N * ldd * 4), r_out = make_rsrc(out, N * ldo * 4), r_m = make_rsrc(mask, N);
+    const buf_rsrc r_x = make_rsrc(gn_on ? gs.x : dsrc, gn_on ? N * gs.ldx * 4 : 0);
+    struct Raw {
+        float4 d, x;
+        unsigned mk;
+        int row;
+    };
+    int n_cur = n_rows;   // rows of the running pass
+    bool labp = false;    // second pass: the listed (labeled) rows
+    auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
+        const int slot = 16 * st + rs;
+        int r = -1;
+        if (slot < n_cur) r = labp ? list[slot] : (int)(r0 + slot);
+        R.row = r;
+        R.d = buf_load4(r_d, r >= 0 ? (int)((r * ldd + 4 * ga) * 4) : kBufOOB);
+        R.x = buf_load4(r_x, r >= 0 ? (int)((r * gs.ldx + 4 * ga) * 4) : kBufOOB);
+        R.mk = __builtin_amdgcn_raw_buffer_load_b8(r_m, r >= 0 ? r : kBufOOB, 0, 0);
+    };
+    Raw rawA, rawB;
+    issue(0, rawA);
+    issue(1, rawB);
+    // this workgroup's labeled rows, in row order
+    int n_lab = 0;
+    for (int p = 0; p < n_rows; p += THREADS) {
+        const int slot = p + tid;
+        const bool flag = slot < n_rows && mask[r0 + slot] != 0;
+        const unsigned long long bal = __ballot(flag);
+        if (lane == 0) wave_cnt[w] = __popcll(bal);
+        __syncthreads();
+        int off = n_lab, total = 0;
+#pragma unroll
+        for (int ww = 0; ww < THREADS / 64; ++ww) {
+            if (ww < w) off += wave_cnt[ww];
+            total += wave_cnt[ww];
+        }
+        if (flag) list[off + __popcll(bal & ((1ull << lane) - 1ull))] = (int)(r0 + slot);
+        n_lab += total;
+        __syncthreads();
+    }
+    const float4* img = reinterpret_cast<const float4*>(WT);
+    float4 bw1[KF4], bw0[KF4];
+    uint4 bwc1[SP ? KF4 / 2 : 1][3], bwc0[SP ? KF4 / 2 : 1][3];
+    auto load_weights = [&](int image) __attribute__((always_inline)) {
+        const float4* im = img + (size_t)image * (2 * H * KT / 4);
+#pragma unroll
+        for (int tt = 0; tt < KF4; ++tt) {
+            bw1[tt] = im[(((tt >> 2) * 2 * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+            bw0[tt] = im[(((tt >> 2) * 2 * NTL + NTL + w) * 4 + (tt & 3)) * 64 + lane];
+        }
+        if constexpr (SP) {  // block b = the lane's k = 32 q + 8 b .. + 7 (bw[2b], bw[2b + 1])
+#pragma unroll
+            for (int b = 0; b < KF4 / 2; ++b) {
+                const Split4 s0 = split4(bw1[2 * b]), s1 = split4(bw1[2 * b + 1]);
+                bwc1[b][0] = make_uint4(s0.hi.x, s0.hi.y, s1.hi.x, s1.hi.y);
+                bwc1[b][1] = make_uint4(s0.mid.x, s0.mid.y, s1.mid.x, s1.mid.y);
+                bwc1[b][2] = make_uint4(s0.lo.x, s0.lo.y, s1.lo.x, s1.lo.y);
+                const Split4 u0 = split4(bw0[2 * b]), u1 = split4(bw0[2 * b + 1]);
+                bwc0[b][0] = make_uint4(u0.hi.x, u0.hi.y, u1.hi.x, u1.hi.y);
+                bwc0[b][1] = make_uint4(u0.mid.x, u0.mid.y, u1.mid.x, u1.mid.y);
+                bwc0[b][2] = make_uint4(u0.lo.x, u0.lo.y, u1.lo.x, u1.lo.y);
+            }
+        }
+    };
+    load_weights(0);
+    const bool gdrop_on = gn_on && gs.drop.p > 0.f;
+    Drop gdrop = gs.drop;
+    if (gdrop_on) {
+        gdrop.seed = rng_state[0];
+        gdrop.step = rng_state[1];
+    }
+    float g_mu[4] = {0.f, 0.f, 0.f, 0.f}, g_rs[4] = {0.f, 0.f, 0.f, 0.f}, g_al[4] = {0.f, 0.f, 0.f, 0.f};
+    float g_sc[4] = {0.f, 0.f, 0.f, 0.f}, g_sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (gn_on) {
+        const float4 m4 = *reinterpret_cast<const float4*>(gs.saved + 4 * ga), r4 = *reinterpret_cast<const float4*>(gs.saved + H + 4 * ga);
+        const float4 s4 = *reinterpret_cast<const float4*>(gs.saved + 2 * H + 4 * ga), h4 = *reinterpret_cast<const float4*>(gs.saved + 3 * H + 4 * ga);
+        const float4 a4 = *reinterpret_cast<const float4*>(gs.alpha + 4 * ga);
+        g_mu[0] = m4.x, g_mu[1] = m4.y, g_mu[2] = m4.z, g_mu[3] = m4.w;
+        g_rs[0] = r4.x, g_rs[1] = r4.y, g_rs[2] = r4.z, g_rs[3] = r4.w;
+        g_sc[0] = s4.x, g_sc[1] = s4.y, g_sc[2] = s4.z, g_sc[3] = s4.w;
+        g_sh[0] = h4.x, g_sh[1] = h4.y, g_sh[2] = h4.z, g_sh[3] = h4.w;
+        g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
+    }
+    auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
+        float* At = lds + (st & 1) * kBuf;
+        float* U = At + kAFloats;
+        float* XU = U + 16 * RP;
+        const int r = R.row < 0 ? 0 : R.row;
+        const float xv[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
+        float gds[4] = {1.f, 1.f, 1.f, 1.f}, u[4], xu[4];
+        if (gdrop_on) drop_scales<4>(gdrop, r, 4 * ga, gds);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float uk = gds[k];
+            uk *= act_grad(gs.act, fmaf(xv[k], g_sc[k], g_sh[k]));
+            u[k] = uk;
+            xu[k] = (xv[k] - g_al[k] * g_mu[k]) * g_rs[k] * uk;
+        }
+        if constexpr (SP) {
+            const Split4 sd = split4(R.d);
+            unsigned short* P = reinterpret_cast<unsigned short*>(At) + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = sd.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = sd.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = sd.lo;
+        } else {
+            *reinterpret_cast<float4*>(At + rs * RS + 4 * ga) = R.d;
+        }
+        *reinterpret_cast<float4*>(U + rs * RP + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
+        *reinterpret_cast<float4*>(XU + rs * RP + 4 * ga) = make_float4(xu[0], xu[1], xu[2], xu[3]);
+        // first pass: a labeled row is computed with the wrong weight and dropped (the second pass owns it)
+        if (ga == 0) rowflag_s[(st & 1) * 16 + rs] = (R.row >= 0 && !labp && R.mk != 0) ? (R.row | (1 << 30)) : R.row;
+    };
+    float s1 = 0.f, s2 = 0.f;
+    double d1 = 0.0, d2 = 0.0;  // column sums: float over four stages, double across
+    const int c = 16 * w + j;
+    int nst = (n_cur + 15) / 16;
+    auto stage = [&](int st, Raw& Rn) __attribute__((always_inline)) {
+        const float* At = lds + (st & 1) * kBuf;
+        const float* U = At + kAFloats;
+        const float* XU = U + 16 * RP;
+        int rv[4];
+        float uu[4], xx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rv[r] = rowflag_s[(st & 1) * 16 + 4 * q + r];
+            uu[r] = U[(4 * q + r) * RP + c];
+            xx[r] = XU[(4 * q + r) * RP + c];
+        }
+        f32x4 acc1 = {0.f, 0.f, 0.f, 0.f}, acc0 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP) {
+            const unsigned short* P = reinterpret_cast<const unsigned short*>(At) + j * RSB + (KT / 4) * q;
+#pragma unroll
+            for (int b = 0; b < KF4 / 2; ++b) {
+                uint4 af[3];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) af[pc] = *reinterpret_cast<const uint4*>(P + pc * kPlane + 8 * b);
+#define GLASS_SMMA16(ACC, BW, pa, pb)                                                                                 \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[pa]), __builtin_bit_cast(bf16x8, BW[b][pb]), ACC, 0, 0, 0)
+                GLASS_SMMA16(acc1, bwc1, 1, 1); GLASS_SMMA16(acc0, bwc0, 1, 1);
+                GLASS_SMMA16(acc1, bwc1, 2, 0); GLASS_SMMA16(acc0, bwc0, 2, 0);
+                GLASS_SMMA16(acc1, bwc1, 0, 2); GLASS_SMMA16(acc0, bwc0, 0, 2);
+                GLASS_SMMA16(acc1, bwc1, 1, 0); GLASS_SMMA16(acc0, bwc0, 1, 0);
+                GLASS_SMMA16(acc1, bwc1, 0, 1); GLASS_SMMA16(acc0, bwc0, 0, 1);
+                GLASS_SMMA16(acc1, bwc1, 0, 0); GLASS_SMMA16(acc0, bwc0, 0, 0);
+#undef GLASS_SMMA16
+            }
+        } else {
+            const float* A = At + j * RS + (KT / 4) * q;
+            float4 a4[KF4];
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(A + 4 * tt);
+#pragma unroll
+            for (int tt = 0; tt < KF4; ++tt) {
+                const float x[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w};
+                const float y1[4] = {bw1[tt].x, bw1[tt].y, bw1[tt].z, bw1[tt].w}, y0[4] = {bw0[tt].x, bw0[tt].y, bw0[tt].z, bw0[tt].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y1[e], acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[e], y0[e], acc0, 0, 0, 0);
+                }
+            }
+        }
+        if (st + 1 < nst) {
+            commit(st + 1, Rn);
+            issue(st + 3, Rn);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool live = rv[r] >= 0 && !(rv[r] >> 30);
+            buf_store1(r_out, live ? (int)((rv[r] * ldo + c) * 4) : kBufOOB, acc1[r]);
+            buf_store1(r_out, live ? (int)((rv[r] * ldo + H + c) * 4) : kBufOOB, acc0[r]);
+            const float vl = live ? acc1[r] : 0.f;
+            s1 = fmaf(vl, uu[r], s1);
+            s2 = fmaf(vl, xx[r], s2);
+        }
+        if ((st & 3) == 3) {
+            d1 += (double)s1, d2 += (double)s2;
+            s1 = s2 = 0.f;
+        }
+        if (st + 1 < nst) lds_barrier();
+    };
+    auto run = [&]() __attribute__((always_inline)) {  // (stages 0 and 1 of the pass are requested)
+        commit(0, rawA);
+        issue(2, rawA);
+        lds_barrier();
+        for (int st = 0; st < nst; st += 2) {
+            stage(st, rawB);
+            if (st + 1 < nst) stage(st + 1, rawA);
+        }
+        d1 += (double)s1, d2 += (double)s2;
+        s1 = s2 = 0.f;
+    };
+    run();
+    if (n_lab > 0) {  // (workgroup-uniform)
+        lds_barrier();  // the first pass's last stage is read; the list is complete since the prologue
+        labp = true;
+        n_cur = n_lab;
+        nst = (n_cur + 15) / 16;
+        issue(0, rawA);
+        issue(1, rawB);
+        load_weights(1);
+        run();
+    }
+    if (!gn_on) return;
+    d1 += __shfl_xor(d1, 16);
+    d2 += __shfl_xor(d2, 16);
+    d1 += __shfl_xor(d1, 32);
+    d2 += __shfl_xor(d2, 32);
+    if (q != 0) return;
+    gs.partial[((size_t)blockIdx.x * 2) * H + c] = d1;
+    gs.partial[((size_t)blockIdx.x * 2 + 1) * H + c] = d2;
+    const int64_t n_entries = (N + 63) / 64;
+    for (int64_t e = (int64_t)blockIdx.x + gridDim.x; e < n_entries; e += gridDim.x) {
+        gs.partial[((size_t)e * 2) * H + c] = 0.0;
+        gs.partial[((size_t)e * 2 + 1) * H + c] = 0.0;
+    }
+}
+template <bool SP>
+constexpr size_t comb_dgrad3_lds() {
+    constexpr int H = 128, kA = SP ? (3 * 16 * (H + 8)) / 2 : 16 * (H + 4);
+    return (size_t)(2 * (kA + 2 * 16 * (H + 4)) + 32 + 8 + kCombDgrad3List) * sizeof(float);
+}
+
 // Data gradient of the comb pair in the same form:  d[g || x_][r] = dc[r] . (w1 W1 + w0 W0): K = H instead of 2H (one
 // K pass), the mix coefficient folded into the weight.  The first H output columns are the gradient of conv.gn's output:
 // its backward column sums are accumulated by the epilogue as in dual_dgrad_body (one partial per workgroup, the extra
@@ -2911,6 +3168,7 @@ extern "C" int glass_dual_linear_fwd_layout(int64_t H, int64_t K) {
 extern "C" int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out) {
     if (GLASS_TRANS_DGRAD_V2 && (wave16_shape_ok(H) || H == 128) && n_out == H) return kLayoutWave16Cols;  // trans pair at hidden 64 / 128: trans_dgrad2_body
     if (!tiled_here(H)) return kLayoutWave16;
+    if (GLASS_COMB_DGRAD_V2 && H == 128 && n_out == 2 * H) return kLayoutWave16EffDgradCols;  // comb pair at hidden 128: comb_dgrad3_kernel
     if (tiled_eff_dgrad_shape(H, n_out)) return kLayoutTiledPlainEff;
     return n_out % 256 == 0 ? kLayoutTiledPlain : kLayoutTiledSplit;
 }
@@ -3116,6 +3374,31 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         allow_lds(trans_dgrad2_kernel<128>, lds128);
         hipLaunchKernelGGL((trans_dgrad2_kernel<128>), dim3((unsigned)ceil_div(n_nodes, 64)), dim3(512), lds128, st, d128);
         const int rc = launch_status("glass_dual_linear_dgrad_f32 (staged, hidden 128)");
+        return rc ? rc : wgrad_after();
+    }
+    if (GLASS_COMB_DGRAD_V2 && H == 128 && n_out == 2 * H) {  // comb pair: stage-run form (image in layout kLayoutWave16EffDgradCols)
+        if (act != GLASS_ACT_NONE || addend || p_drop > 0.f) {
+            set_error("dual_linear_dgrad: at hidden 128 the 256-wide data gradient is the comb pair's (no activation, addend or dropout)");
+            return GLASS_E_UNSUPPORTED;
+        }
+        GLASS_REQUIRE(!gn_exact, "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only");
+        const int64_t ld_max = std::max(std::max(ldd, ldo), gn_partial ? gn_ldx : (int64_t)0);
+        GLASS_REQUIRE(n_nodes * ld_max * 4 < (1ll << 31), "dual_linear_dgrad: n_nodes * ld * 4 must stay below 2^31 (32-bit buffer offsets)");
+        // one round of the chip; >= 64 rows per workgroup (one statistics entry per 64 rows), <= the list a workgroup can hold
+        int64_t rows_main = ceil_div(ceil_div(n_nodes, (int64_t)256), (int64_t)16) * 16;
+        if (rows_main < 64) rows_main = 64;
+        if (rows_main > kCombDgrad3List) rows_main = kCombDgrad3List;
+        const dim3 grid3((unsigned)ceil_div(n_nodes, rows_main));
+        if (tiled_split_products()) {
+            allow_lds((comb_dgrad3_kernel<128, true>), comb_dgrad3_lds<true>());
+            hipLaunchKernelGGL((comb_dgrad3_kernel<128, true>), grid3, dim3(512), comb_dgrad3_lds<true>(), st, dsrc, ldd, mask, WT, rng_state,
+                               out, ldo, n_nodes, gs, (int)rows_main);
+        } else {
+            allow_lds((comb_dgrad3_kernel<128, false>), comb_dgrad3_lds<false>());
+            hipLaunchKernelGGL((comb_dgrad3_kernel<128, false>), grid3, dim3(512), comb_dgrad3_lds<false>(), st, dsrc, ldd, mask, WT, rng_state,
+                               out, ldo, n_nodes, gs, (int)rows_main);
+        }
+        const int rc = launch_status("glass_dual_linear_dgrad_f32 (stage run, hidden 128, comb pair)");
         return rc ? rc : wgrad_after();
     }
     if (tiled_here(H)) {

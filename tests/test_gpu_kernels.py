@@ -1071,6 +1071,63 @@ def test_trans_dgrad_hidden128_stage_split(N):
     record_parity(f"kernel/trans_dgrad128_stage_split_N{N}", out_rel_inf=e_out, gn_sum_rel_inf=max(e_s1, e_s2))
 
 
+@pytest.mark.parametrize("N,labeled", [(50003, "few"), (50003, "none"), (5000, "all"), (63, "few"), (17080, "dense"), (1100000, "few")])
+def test_comb_dgrad_hidden128_stage_run(N, labeled):
+    """Comb pair's data gradient at hidden 128 (comb_dgrad3_kernel: a workgroup walks its rows with the UNLABELED effective
+    weight, lists its labeled rows and redoes those with the LABELED one): d[g || x_] = [w1 dc | w0 dc] @ Wstack against fp64
+    for a batch-like label density, no labeled row, every row labeled (the second pass as long as the first), a graph
+    smaller than one workgroup, a third of the rows, and more than 256 x 4096 rows (the list cap bounds the rows per
+    workgroup); the backward-GraphNorm column sums of the first 128 columns — one entry per workgroup, the rest zeroed (NaN
+    prefill) — against fp64; both product forms; twice -> identical bits."""
+    from glass_amd import ops, stack
+    from glass_amd.arena import ParamArena
+    from glass_amd.factory import build_glass
+    torch.manual_seed(N + len(labeled))
+    H, z = 128, 0.8
+    model = build_glass(H, 1, 5, 3, "mean", "sum", z).to(DEV).train()
+    ParamArena(model)
+    st = model.conv.convs[0]._stack["comb"]
+    gmod = model.conv.convs[0].gn
+    mask = {"few": torch.rand(N, device=DEV) < 0.02, "none": torch.zeros(N, dtype=torch.bool, device=DEV),
+            "all": torch.ones(N, dtype=torch.bool, device=DEV), "dense": torch.rand(N, device=DEV) < 0.33}[labeled].to(torch.uint8)
+    if labeled == "few":
+        mask[-1] = 1
+        mask[0] = 1
+    dc, gx = torch.randn(N, H, device=DEV), torch.randn(N, H, device=DEV)
+    saved = torch.cat([gx.mean(0), 1.0 / (gx.var(0, unbiased=False) + 1e-5).sqrt(), torch.ones(H, device=DEV),
+                       torch.zeros(H, device=DEV)]).contiguous()
+    nblk = -(-N // int(stack._lib.load().glass_dual_linear_stat_rows(H)))
+    W = st[0].double()
+    lab = mask.bool().unsqueeze(1)
+    w1 = torch.where(lab, torch.tensor(z, device=DEV, dtype=torch.float64), torch.tensor(1 - z, device=DEV, dtype=torch.float64))
+    ref = (w1 * dc.double()) @ W[:H] + ((1 - w1) * dc.double()) @ W[H:]
+    g = ref[:, :H]
+    xhat = (gx.double() - gmod.mean_scale.double() * saved[:H].double()) * saved[H:2 * H].double()
+    prev = ops.DENSE_F32_PRODUCTS
+    try:
+        for form in (False, True):
+            ops.DENSE_F32_PRODUCTS = form
+            got = []
+            for _ in range(2):
+                din = torch.full((N, 2 * H), float("nan"), device=DEV)
+                gpart = torch.full((nblk, 2, H), float("nan"), dtype=torch.float64, device=DEV)
+                stack._dual_dgrad(dc, None, st, mask, z, 0, 2 * H, None, din, gn=(gpart, gx, saved, gmod.mean_scale, 0, 0.0, 0))
+                got.append((din, gpart))
+            din, gpart = got[0]
+            e_out = rel_inf(din.double(), ref)
+            e_s1, e_s2 = rel_inf(gpart[:, 0].sum(0), g.sum(0)), rel_inf(gpart[:, 1].sum(0), (g * xhat).sum(0))
+            assert e_out < TOL and e_s1 < TOL and e_s2 < TOL, (form, e_out, e_s1, e_s2)
+            assert torch.equal(got[1][0], din) and torch.equal(got[1][1], gpart)
+            # without the statistics epilogue: the same gradient
+            din2 = torch.full((N, 2 * H), float("nan"), device=DEV)
+            stack._dual_dgrad(dc, None, st, mask, z, 0, 2 * H, None, din2)
+            assert torch.equal(din2, din)
+            if not form:
+                record_parity(f"kernel/comb_dgrad128_stage_run_N{N}_{labeled}", out_rel_inf=e_out, gn_sum_rel_inf=max(e_s1, e_s2))
+    finally:
+        ops.DENSE_F32_PRODUCTS = prev
+
+
 @pytest.mark.parametrize("pattern", ["none", "one_per_tile_3", "sparse", "cap3", "cap4", "cap7", "cap8", "all"])
 def test_comb_pair_effective_weight_paths(pattern):
     """Comb pair at hidden 256 on the tiled kernels: the effective-weight (one product) and two-product paths — forward
