@@ -31,7 +31,10 @@ __global__ __launch_bounds__(kW128Threads, 1) void wgrad128_trans_kernel(const f
     constexpr int H = 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int rp = tid >> 5, ga = tid & 31;  // loader role: row pair rp of the stage, columns 4 ga .. 4 ga + 3
+    // loader role: row pair rp of the stage, columns 4 ga .. 4 ga + 3.  A wave takes 4 row pairs x 16 column quads (waves 0-3
+    // the low 64 columns, 4-7 the high ones): the 64 words of one of its image stores then lie in 64 different banks
+    // (stg2s_word; with 2 row pairs x 32 quads per wave every store was 2-way conflicted: 0.64 conflict cycles per active one)
+    const int rp = (tid >> 4) & 15, ga = (tid & 15) | ((tid >> 8) << 4);
     const int ob = w >> 1, ib = w & 1;       // this wave's 64 outputs / 64 inputs
     const int bx = blockIdx.x;
     if (header && bx == 0 && tid == 0) {
@@ -145,25 +148,27 @@ __global__ __launch_bounds__(kW128Threads, 1) void wgrad128_trans_kernel(const f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) pw[(64 * (ob & 1) + 16 * a + 4 * q + r) * kIT + 16 * it + j] = acc[a][it][r];
     }
-    if (part_b) {  // bias partial: the wave's two row-pair slots of a column by a shuffle, the eight waves through LDS
+    if (part_b) {  // bias partial: the wave's four row-pair slots of a column by shuffles, the four waves of a column half through LDS
         lds_barrier();  // (every wave is done reading the last stage's image)
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+            bs1[k] += __shfl_xor(bs1[k], 16);
+            bs0[k] += __shfl_xor(bs0[k], 16);
             bs1[k] += __shfl_xor(bs1[k], 32);
             bs0[k] += __shfl_xor(bs0[k], 32);
         }
-        if (lane < 32) {
+        if (lane < 16) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                lds[w * 256 + 4 * ga + k] = bs1[k];
-                lds[w * 256 + H + 4 * ga + k] = bs0[k];
+                lds[(w & 3) * 256 + 4 * ga + k] = bs1[k];
+                lds[(w & 3) * 256 + H + 4 * ga + k] = bs0[k];
             }
         }
         lds_barrier();
         if (tid < 256) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) s += lds[ww * 256 + tid];
+            for (int ww = 0; ww < 4; ++ww) s += lds[ww * 256 + tid];
             part_b[((int64_t)(tid >> 7) * n_slabs + bx) * kOT + (tid & 127)] = s;
         }
     }
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(kW128Threads, 1) void wgrad128_comb_kernel(const fl
     constexpr int H = 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, q = lane >> 4;
-    const int rp = tid >> 5, ga = tid & 31;
+    const int rp = (tid >> 4) & 15, ga = (tid & 15) | ((tid >> 8) << 4);  // (as in wgrad128_trans_kernel)
     const int ob = w >> 2, ib = w & 3;       // this wave's 64 outputs (of 128) / 64 inputs (of 256)
     const int bx = blockIdx.x;
     if (header && bx == 0 && tid == 0) {
@@ -320,16 +325,19 @@ __global__ __launch_bounds__(kW128Threads, 1) void wgrad128_comb_kernel(const fl
     if (part_b) {
         lds_barrier();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bs[k] += __shfl_xor(bs[k], 32);
-        if (lane < 32) {
+        for (int k = 0; k < 4; ++k) {
+            bs[k] += __shfl_xor(bs[k], 16);
+            bs[k] += __shfl_xor(bs[k], 32);
+        }
+        if (lane < 16) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) lds[w * 128 + 4 * ga + k] = bs[k];
+            for (int k = 0; k < 4; ++k) lds[(w & 3) * 128 + 4 * ga + k] = bs[k];
         }
         lds_barrier();
         if (tid < 128) {
             float s = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 8; ++ww) s += lds[ww * 128 + tid];
+            for (int ww = 0; ww < 4; ++ww) s += lds[ww * 128 + tid];
             const int z = lab ? 1 : 0, place = lab ? bx - n_slabs : bx;
             part_b[((int64_t)z * n_slabs + place) * kOT + tid] = s;
         }
