@@ -411,8 +411,10 @@ int glass_dual_linear_supported(int64_t H);
 /* 0: wave16 operand images (flags layout 0 for both operands); 1: tiled (forward operand layout 1, data-gradient
  * operand layout 2 — except a 128-wide output, hidden 128's trans pair, which keeps layout 0 and the wave16 kernel) */
 int glass_dual_linear_layout(int64_t H);
-/* layout code of the data-gradient operand image for (H, n_out): 0, 2, 3, 4 or 9, and of the forward operand image for
- * (H, K = input width): 0, 1, 5 or 9 (see glass_dense_pack_batch_f32) */
+/* layout code of the data-gradient operand image for (H, n_out): 0, 2, 3, 4, 9 or 10, and of the forward operand image for
+ * (H, K = input width): 0, 1, 5 or 9 (see glass_dense_pack_batch_f32).  Hidden 128 (round 6, "stage-run" kernels that keep a
+ * wave's weight slice in registers): forward of the trans pair 9, data gradient of the trans pair 9, of the comb pair 10 (its
+ * 256-wide data gradient takes no activation, addend or dropout: GLASS_E_UNSUPPORTED otherwise). */
 int glass_dual_linear_dgrad_layout(int64_t H, int64_t n_out);
 int glass_dual_linear_fwd_layout(int64_t H, int64_t K);
 /* rows covered by one workgroup of the fused kernels at hidden H = rows per `stats` / `gn_partial` entry */
@@ -556,8 +558,9 @@ int glass_spmm_reduce_rows_f32(const float* partials, float* Y, int64_t ldy, int
  *     tile — tile t holds columns 64 (t >> 2) + 16 (t & 3) .. + 15 — for the "staged" hidden-64 kernels, where a wave owns 16
  *     consecutive output columns and keeps its slice of the operand in registers: 8 = forward image of the comb pair
  *     (glass_comb_eff_fwd_layout), 10 = its data-gradient images, packed BEHIND the layout-7 pair in the same buffer
- *     (glass_comb_eff_dgrad_layout2), 9 = both operands of the trans pair (glass_dual_linear_fwd_layout(64, 64),
- *     glass_dual_linear_dgrad_layout(64, 64)).  z_ratio (may be NULL when no job has layout 4 - 8, 10): per-job label mix of
+ *     (glass_comb_eff_dgrad_layout2; alone, [256][256] transposed, as the comb pair's data-gradient operand at hidden 128:
+ *     glass_dual_linear_dgrad_layout(128, 256)), 9 = both operands of the trans pair (glass_dual_linear_fwd_layout(H, H),
+ *     glass_dual_linear_dgrad_layout(H, H), H = 64 or 128).  z_ratio (may be NULL when no job has layout 4 - 8, 10): per-job label mix of
  *     the pair.  dst[k] holds NT*KT floats otherwise.  The pointer / size arrays are HOST arrays.
  *     The staged kernels address their row operands through buffer resources (32-bit offsets): rows * ld * 4 < 2^31,
  *     checked per call; glass_comb_eff_max_rows(ld) tells the limit. */
