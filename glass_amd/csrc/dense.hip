@@ -806,14 +806,20 @@ __device__ __forceinline__ void trans_dgrad2_body(const float* __restrict__ dsrc
 // workgroups of 13.  The backward column sums of a GraphNorm keep their ABI (one entry per 64-row tile, summed by the
 // consumer): workgroup b writes ITS sums (float per lane over four stages, double across) to entry b and zeroes the entries
 // b + grid, b + 2 grid, ... < n_tiles (grid <= n_tiles: a workgroup covers at least four stages).
-template <int H>
+// SP: the product in the split form (as trans_dgrad2_body at hidden 64): the loader cuts its eight elements of dZ into three
+// bf16 planes, the wave its weight slice once (96 registers); 48 MFMAs of 16 cycles per stage and wave where the f32-input
+// form issues 64 of 32.  The GraphNorm's column constants then live in LDS and the epilogue operands are read behind the
+// products (register budget: 256).
+template <int H, bool SP = false>
 __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int stages_per_wg) {
     static_assert(H == 64 || H == 128, "H / 16 waves x 16 columns");
     extern __shared__ float4 lds_w3[];
     float* lds = reinterpret_cast<float*>(lds_w3);
     constexpr int NTL = H / 16, KF4 = (2 * H) / 16;
     constexpr int KT = 2 * H, RA = KT + 4, RP = H + 4;
-    constexpr int kBuf = 16 * RA + 4 * 16 * RP;  // A | ADD | M | U | XU  (floats per stage buffer)
+    constexpr int RSB = KT + 8, kPlane = 16 * RSB;  // SP: bf16 per row of a piece plane, per plane
+    constexpr int kAFloats = SP ? (3 * kPlane) / 2 : 16 * RA;
+    constexpr int kBuf = kAFloats + 4 * 16 * RP;  // A | ADD | M | U | XU  (floats per stage buffer)
     int* rows_s = reinterpret_cast<int*>(lds + 2 * kBuf);  // [2][16]: the rows of the stage in each buffer
     const float* __restrict__ dsrc = A.dsrc;
     const int64_t ldd = A.ldd, ldt = A.ldt, ldadd = A.ldadd, ldo = A.ldo, N = A.N;
@@ -834,13 +840,14 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int st
     struct Raw {
         float4 d, t1, t0, ad, x;
         unsigned mk;
-        int row;
+    };
+    auto row_of = [&](int st) __attribute__((always_inline)) -> int {  // this thread's row of stage st (-1: none)
+        const int64_t rr = r0 + 16 * st + rs;
+        return (st < nst && rr < N) ? (int)rr : -1;
     };
     auto issue = [&](int st, Raw& R) __attribute__((always_inline)) {
-        const int64_t rr = r0 + 16 * st + rs;
-        const bool ok = st < nst && rr < N;
-        const int r = ok ? (int)rr : -1;
-        R.row = r;
+        const int r = row_of(st);
+        const bool ok = r >= 0;
         R.d = buf_load4(r_d, ok ? (int)((r * ldd + 4 * ga) * 4) : kBufOOB);
         R.t1 = buf_load4(r_t, ok ? (int)((r * ldt + 4 * ga) * 4) : kBufOOB);
         R.t0 = buf_load4(r_t, ok ? (int)((r * ldt + H + 4 * ga) * 4) : kBufOOB);
@@ -855,6 +862,16 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int st
     float4 bw[KF4];
 #pragma unroll
     for (int tt = 0; tt < KF4; ++tt) bw[tt] = img[(((tt >> 2) * NTL + w) * 4 + (tt & 3)) * 64 + lane];
+    uint4 bwc[SP ? KF4 / 2 : 1][3];  // SP: block b = the lane's k = (KT / 4) q + 8 b .. + 7 (bw[2b], bw[2b + 1])
+    if constexpr (SP) {
+#pragma unroll
+        for (int b = 0; b < KF4 / 2; ++b) {
+            const Split4 c0 = split4(bw[2 * b]), c1 = split4(bw[2 * b + 1]);
+            bwc[b][0] = make_uint4(c0.hi.x, c0.hi.y, c1.hi.x, c1.hi.y);
+            bwc[b][1] = make_uint4(c0.mid.x, c0.mid.y, c1.mid.x, c1.mid.y);
+            bwc[b][2] = make_uint4(c0.lo.x, c0.lo.y, c1.lo.x, c1.lo.y);
+        }
+    }
     Drop drop = A.drop;
     const bool drop_on = drop.p > 0.f, gn_on = gs.partial != nullptr, gdrop_on = gn_on && gs.drop.p > 0.f;
     Drop gdrop = gs.drop;
@@ -862,9 +879,14 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int st
         drop.seed = gdrop.seed = A.rng_state[0];
         drop.step = gdrop.step = A.rng_state[1];
     }
+    // the GraphNorm's per-column constants of this thread's four columns: registers, or (SP) LDS
     float g_mu[4] = {0.f, 0.f, 0.f, 0.f}, g_rs[4] = {0.f, 0.f, 0.f, 0.f}, g_al[4] = {0.f, 0.f, 0.f, 0.f};
     float g_sc[4] = {0.f, 0.f, 0.f, 0.f}, g_sh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gn_on) {
+    float* gcol = lds + 2 * kBuf + 32;  // SP: [5][H]  mean | rstd | scale | shift | alpha  (zeros without a GraphNorm)
+    if constexpr (SP) {
+        for (int k = tid; k < 5 * H; k += 4 * H) gcol[k] = !gn_on ? 0.f : k < 4 * H ? gs.saved[k] : gs.alpha[k - 4 * H];
+        lds_barrier();  // (the first commit below reads other threads' constants)
+    } else if (gn_on) {
         const float4 m4 = *reinterpret_cast<const float4*>(gs.saved + 4 * ga), r4 = *reinterpret_cast<const float4*>(gs.saved + H + 4 * ga);
         const float4 s4 = *reinterpret_cast<const float4*>(gs.saved + 2 * H + 4 * ga), h4 = *reinterpret_cast<const float4*>(gs.saved + 3 * H + 4 * ga);
         const float4 a4 = *reinterpret_cast<const float4*>(gs.alpha + 4 * ga);
@@ -876,15 +898,26 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int st
     }
     auto commit = [&](int st, const Raw& R) __attribute__((always_inline)) {
         float* At = lds + (st & 1) * kBuf;
-        float* ADD = At + 16 * RA;
+        float* ADD = At + kAFloats;
         float* M = ADD + 16 * RP;
         float* U = M + 16 * RP;
         float* XU = U + 16 * RP;
-        const int r = R.row < 0 ? 0 : R.row;
+        const int row = row_of(st);
+        const int r = row < 0 ? 0 : row;
         const float c1 = R.mk ? zr : omz, c0 = R.mk ? omz : zr;
         const float d[4] = {R.d.x, R.d.y, R.d.z, R.d.w}, t1[4] = {R.t1.x, R.t1.y, R.t1.z, R.t1.w}, t0[4] = {R.t0.x, R.t0.y, R.t0.z, R.t0.w};
         const float xv[4] = {R.x.x, R.x.y, R.x.z, R.x.w};
         float z1[4], z0[4], m[4] = {1.f, 1.f, 1.f, 1.f}, gds[4] = {1.f, 1.f, 1.f, 1.f}, u[4], xu[4];
+        if constexpr (SP) {
+            const float4 m4 = *reinterpret_cast<const float4*>(gcol + 4 * ga), r4 = *reinterpret_cast<const float4*>(gcol + H + 4 * ga);
+            const float4 s4 = *reinterpret_cast<const float4*>(gcol + 2 * H + 4 * ga), h4 = *reinterpret_cast<const float4*>(gcol + 3 * H + 4 * ga);
+            const float4 a4 = *reinterpret_cast<const float4*>(gcol + 4 * H + 4 * ga);
+            g_mu[0] = m4.x, g_mu[1] = m4.y, g_mu[2] = m4.z, g_mu[3] = m4.w;
+            g_rs[0] = r4.x, g_rs[1] = r4.y, g_rs[2] = r4.z, g_rs[3] = r4.w;
+            g_sc[0] = s4.x, g_sc[1] = s4.y, g_sc[2] = s4.z, g_sc[3] = s4.w;
+            g_sh[0] = h4.x, g_sh[1] = h4.y, g_sh[2] = h4.z, g_sh[3] = h4.w;
+            g_al[0] = a4.x, g_al[1] = a4.y, g_al[2] = a4.z, g_al[3] = a4.w;
+        }
         if (drop_on) drop_scales<4>(drop, r, 4 * ga, m);
         if (gdrop_on) drop_scales<4>(gdrop, r, 4 * ga, gds);
 #pragma unroll
@@ -897,13 +930,24 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int st
             u[k] = uk;
             xu[k] = (xv[k] - g_al[k] * g_mu[k]) * g_rs[k] * uk;
         }
-        *reinterpret_cast<float4*>(At + rs * RA + 4 * ga) = make_float4(z1[0], z1[1], z1[2], z1[3]);
-        *reinterpret_cast<float4*>(At + rs * RA + H + 4 * ga) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        if constexpr (SP) {
+            const Split4 s1c = split4(make_float4(z1[0], z1[1], z1[2], z1[3])), s0c = split4(make_float4(z0[0], z0[1], z0[2], z0[3]));
+            unsigned short* P = reinterpret_cast<unsigned short*>(At) + rs * RSB + 4 * ga;
+            *reinterpret_cast<uint2*>(P) = s1c.hi;
+            *reinterpret_cast<uint2*>(P + kPlane) = s1c.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane) = s1c.lo;
+            *reinterpret_cast<uint2*>(P + H) = s0c.hi;
+            *reinterpret_cast<uint2*>(P + kPlane + H) = s0c.mid;
+            *reinterpret_cast<uint2*>(P + 2 * kPlane + H) = s0c.lo;
+        } else {
+            *reinterpret_cast<float4*>(At + rs * RA + 4 * ga) = make_float4(z1[0], z1[1], z1[2], z1[3]);
+            *reinterpret_cast<float4*>(At + rs * RA + H + 4 * ga) = make_float4(z0[0], z0[1], z0[2], z0[3]);
+        }
         *reinterpret_cast<float4*>(ADD + rs * RP + 4 * ga) = R.ad;
         *reinterpret_cast<float4*>(M + rs * RP + 4 * ga) = make_float4(m[0], m[1], m[2], m[3]);
         *reinterpret_cast<float4*>(U + rs * RP + 4 * ga) = make_float4(u[0], u[1], u[2], u[3]);
         *reinterpret_cast<float4*>(XU + rs * RP + 4 * ga) = make_float4(xu[0], xu[1], xu[2], xu[3]);
-        if (ga == 0) rows_s[(st & 1) * 16 + rs] = R.row;
+        if (ga == 0) rows_s[(st & 1) * 16 + rs] = row;
     };
     commit(0, rawA);
     issue(2, rawA);
@@ -913,38 +957,67 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int st
     const int c = 16 * w + j;
     auto stage = [&](int st, Raw& Rn) __attribute__((always_inline)) {
         const float* At = lds + (st & 1) * kBuf;
-        const float* ADD = At + 16 * RA;
+        const float* ADD = At + kAFloats;
         const float* M = ADD + 16 * RP;
         const float* U = M + 16 * RP;
         const float* XU = U + 16 * RP;
-        float4 a4[KF4];
+        float4 a4[SP ? 1 : KF4];
+        if constexpr (!SP) {
 #pragma unroll
-        for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(At + j * RA + (KT / 4) * q + 4 * tt);
+            for (int tt = 0; tt < KF4; ++tt) a4[tt] = *reinterpret_cast<const float4*>(At + j * RA + (KT / 4) * q + 4 * tt);
+        }
         int rv[4];
         float ad[4], mm[4], uu[4], xx[4];
+        auto epilogue_operands = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            rv[r] = rows_s[(st & 1) * 16 + 4 * q + r];
-            ad[r] = ADD[(4 * q + r) * RP + c];
-            mm[r] = M[(4 * q + r) * RP + c];
-            uu[r] = U[(4 * q + r) * RP + c];
-            xx[r] = XU[(4 * q + r) * RP + c];
-        }
+            for (int r = 0; r < 4; ++r) {
+                rv[r] = rows_s[(st & 1) * 16 + 4 * q + r];
+                ad[r] = ADD[(4 * q + r) * RP + c];
+                mm[r] = M[(4 * q + r) * RP + c];
+                uu[r] = U[(4 * q + r) * RP + c];
+                xx[r] = XU[(4 * q + r) * RP + c];
+            }
+        };
+        if constexpr (!SP) epilogue_operands();
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP) {
+            const unsigned short* P = reinterpret_cast<const unsigned short*>(At) + j * RSB + (KT / 4) * q;
 #pragma unroll
-        for (int tt = 0; tt < KF4; tt += 2) {
-            const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
-            const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
-            const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+            for (int b = 0; b < KF4 / 2; ++b) {  // two chains (even / odd K blocks), small terms first
+                uint4 af[3];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+                for (int pc = 0; pc < 3; ++pc) af[pc] = *reinterpret_cast<const uint4*>(P + pc * kPlane + 8 * b);
+#define GLASS_SMMA16(ACC, pa, pb)                                                                                     \
+    ACC = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[pa]), __builtin_bit_cast(bf16x8, bwc[b][pb]), ACC, 0, 0, 0)
+                if (b & 1) {
+                    GLASS_SMMA16(acc1, 1, 1); GLASS_SMMA16(acc1, 2, 0); GLASS_SMMA16(acc1, 0, 2);
+                    GLASS_SMMA16(acc1, 1, 0); GLASS_SMMA16(acc1, 0, 1); GLASS_SMMA16(acc1, 0, 0);
+                } else {
+                    GLASS_SMMA16(acc0, 1, 1); GLASS_SMMA16(acc0, 2, 0); GLASS_SMMA16(acc0, 0, 2);
+                    GLASS_SMMA16(acc0, 1, 0); GLASS_SMMA16(acc0, 0, 1); GLASS_SMMA16(acc0, 0, 0);
+                }
+#undef GLASS_SMMA16
+            }
+        } else {
+#pragma unroll
+            for (int tt = 0; tt < KF4; tt += 2) {
+                const float x0[4] = {a4[tt].x, a4[tt].y, a4[tt].z, a4[tt].w}, y0[4] = {bw[tt].x, bw[tt].y, bw[tt].z, bw[tt].w};
+                const float x1[4] = {a4[tt + 1].x, a4[tt + 1].y, a4[tt + 1].z, a4[tt + 1].w};
+                const float y1[4] = {bw[tt + 1].x, bw[tt + 1].y, bw[tt + 1].z, bw[tt + 1].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0[e], y0[e], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1[e], y1[e], acc1, 0, 0, 0);
+                }
             }
         }
         if (st + 1 < nst) {
             commit(st + 1, Rn);
             issue(st + 3, Rn);
+        }
+        if constexpr (SP) {  // the epilogue's operands behind the products and the next stage's cut (register budget)
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue_operands();
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -985,6 +1058,7 @@ __global__ __launch_bounds__(4 * H) void trans_dgrad3_kernel(DgradArgs A, int st
     }
 }
 constexpr size_t trans_dgrad3_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 32) * sizeof(float); }
+constexpr size_t trans_dgrad3_split_lds(int H) { return (size_t)(2 * ((3 * 16 * (2 * H + 8)) / 2 + 4 * 16 * (H + 4)) + 32 + 5 * H) * sizeof(float); }
 
 constexpr size_t trans_dgrad2_lds(int H) { return (size_t)(2 * (16 * (2 * H + 4) + 4 * 16 * (H + 4)) + 64) * sizeof(float); }
 constexpr size_t kTransDgrad2SplitLds = (size_t)(2 * ((3 * 16 * (2 * 64 + 8)) / 2 + 4 * 16 * (64 + 4)) + 64) * sizeof(float);  // SP at hidden 64
@@ -3364,6 +3438,13 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         if (lab_knob("GLASS_TRANS_DGRAD3", 1) && n_tiles > 256) {  // more than one round of 64-row tiles: tall tiles, one workgroup per CU (trans_dgrad3_kernel)
             const int64_t n_stages = ceil_div(n_nodes, 16);
             const int stages_per_wg = (int)ceil_div(n_stages, 256);  // >= 5 here: never more workgroups than 64-row tiles (the partials' entries)
+            if (tiled_split_products() && lab_knob("GLASS_TRANS_DGRAD3_SPLIT", 1)) {  // the call's product form (GLASS_DENSE_F32_PRODUCTS opts out)
+                const size_t lds3s = trans_dgrad3_split_lds(128);
+                allow_lds((trans_dgrad3_kernel<128, true>), lds3s);
+                hipLaunchKernelGGL((trans_dgrad3_kernel<128, true>), dim3((unsigned)ceil_div(n_stages, stages_per_wg)), dim3(512), lds3s, st, d128, stages_per_wg);
+                const int rc3 = launch_status("glass_dual_linear_dgrad_f32 (staged, tall, hidden 128, split products)");
+                return rc3 ? rc3 : wgrad_after();
+            }
             const size_t lds3 = trans_dgrad3_lds(128);
             allow_lds(trans_dgrad3_kernel<128>, lds3);
             hipLaunchKernelGGL((trans_dgrad3_kernel<128>), dim3((unsigned)ceil_div(n_stages, stages_per_wg)), dim3(512), lds3, st, d128, stages_per_wg);

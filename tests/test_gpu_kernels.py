@@ -1050,25 +1050,33 @@ def test_trans_dgrad_hidden128_stage_split(N):
     saved = torch.cat([gx.mean(0), 1.0 / (gx.var(0, unbiased=False) + 1e-5).sqrt(), torch.ones(H, device=DEV),
                        torch.zeros(H, device=DEV)]).contiguous()
     nblk = -(-N // int(stack._lib.load().glass_dual_linear_stat_rows(H)))
-    got = []
-    for _ in range(2):
-        out = torch.full((N, H), float("nan"), device=DEV)
-        gpart = torch.full((nblk, 2, H), float("nan"), dtype=torch.float64, device=DEV)
-        stack._dual_dgrad(dsrc, T, st, mask, z, 1, H, addend, out, gn=(gpart, gx, saved, gmod.mean_scale, 0, 0.0, 0))
-        got.append((out, gpart))
     W = st[0].double()
     lab = mask.bool().unsqueeze(1)
     w1 = torch.where(lab, torch.tensor(z, device=DEV, dtype=torch.float64), torch.tensor(1 - z, device=DEV, dtype=torch.float64))
     elu_g = lambda t: torch.where(t > 0, torch.ones_like(t), torch.exp(t))
     d = dsrc.double()
     ref = (w1 * d * elu_g(T[:, :H].double())) @ W[:H] + ((1 - w1) * d * elu_g(T[:, H:].double())) @ W[H:] + addend.double()
-    out, gpart = got[0]
-    e_out = rel_inf(out.double(), ref)
     xhat = (gx.double() - gmod.mean_scale.double() * saved[:H].double()) * saved[H:2 * H].double()
-    e_s1, e_s2 = rel_inf(gpart[:, 0].sum(0), ref.sum(0)), rel_inf(gpart[:, 1].sum(0), (ref * xhat).sum(0))
-    assert e_out < TOL and e_s1 < TOL and e_s2 < TOL, (e_out, e_s1, e_s2)
-    assert torch.equal(got[1][0], out) and torch.equal(got[1][1], gpart)
-    record_parity(f"kernel/trans_dgrad128_stage_split_N{N}", out_rel_inf=e_out, gn_sum_rel_inf=max(e_s1, e_s2))
+    from glass_amd import ops
+    prev = ops.DENSE_F32_PRODUCTS
+    try:
+        for form in (False, True):   # six bf16 partial products (default) / the f32-input MFMA
+            ops.DENSE_F32_PRODUCTS = form
+            got = []
+            for _ in range(2):
+                out = torch.full((N, H), float("nan"), device=DEV)
+                gpart = torch.full((nblk, 2, H), float("nan"), dtype=torch.float64, device=DEV)
+                stack._dual_dgrad(dsrc, T, st, mask, z, 1, H, addend, out, gn=(gpart, gx, saved, gmod.mean_scale, 0, 0.0, 0))
+                got.append((out, gpart))
+            out, gpart = got[0]
+            e_out = rel_inf(out.double(), ref)
+            e_s1, e_s2 = rel_inf(gpart[:, 0].sum(0), ref.sum(0)), rel_inf(gpart[:, 1].sum(0), (ref * xhat).sum(0))
+            assert e_out < TOL and e_s1 < TOL and e_s2 < TOL, (form, e_out, e_s1, e_s2)
+            assert torch.equal(got[1][0], out) and torch.equal(got[1][1], gpart)
+            if not form:
+                record_parity(f"kernel/trans_dgrad128_stage_split_N{N}", out_rel_inf=e_out, gn_sum_rel_inf=max(e_s1, e_s2))
+    finally:
+        ops.DENSE_F32_PRODUCTS = prev
 
 
 @pytest.mark.parametrize("N,labeled", [(50003, "few"), (50003, "none"), (5000, "all"), (63, "few"), (17080, "dense"), (1100000, "few")])
