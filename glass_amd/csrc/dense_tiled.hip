@@ -862,14 +862,9 @@ int launch_tiled_dgrad(const float* dsrc, int64_t ldd, const float* T, int64_t l
             tiled_dgrad_launch<HH, NOUT, BM, BN, SPLIT, false>(dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop, \
                                                                rng_state, out, ldo, N, gs, st);                      \
     }
-    if (H == 128 && n_out == H) {  // trans pair: the two terms of the product side by side in one 256-slot tile
-        GLASS_TDG1(128, 128, 64, 256, true)
-    } else if (H == 128 && tall128(N)) {
-        tiled_dgrad_launch<128, 256, 128, 256, false, true>(dsrc, ldd, T, ldt, mask, zr, omz, act, WTimg, addend, ldadd, drop,
-                                                            rng_state, out, ldo, N, gs, st);
-    } else if (H == 128) {
-        GLASS_TDG1(128, 256, 64, 256, false)
-    } else if (H == 256) {
+    // (hidden 128's data gradients left this family in round 6: trans_dgrad2 / trans_dgrad3 / comb_dgrad3 kernels of dense.hip,
+    //  whose operand images are in other layouts — dgrad_launch never comes here with H = 128)
+    if (H == 256) {
         if (n_out == H) GLASS_TDG1(256, 256, 128, 256, false) else GLASS_TDG1(256, 512, 128, 256, false)
     } else if (H == 512) {
         if (n_out == H) GLASS_TDG1(512, 512, 128, 256, false) else GLASS_TDG1(512, 1024, 128, 256, false)
