@@ -1079,6 +1079,67 @@ def test_trans_dgrad_hidden128_stage_split(N):
         ops.DENSE_F32_PRODUCTS = prev
 
 
+@pytest.mark.parametrize("N,gather,p_drop", [(50003, False, 0.0), (50003, True, 0.5), (1000, True, 0.0), (63, False, 0.5), (17080, False, 0.0)])
+def test_trans_fwd_hidden128_stage_run(N, gather, p_drop):
+    """Trans pair's forward at hidden 128 (trans_fwd3_kernel): GraphNorm prologue (scale / shift from `saved`, ELU, dropout) in the
+    loader with the normalised operand as side output, the operand rows optionally gathered from a 37-row table (layer 0),
+    T = h W^T + b, out = label mix of ELU(T), and the column sums of `out` — one entry per WORKGROUP, the rest of the 64-row
+    entries zeroed by the kernel (NaN prefill).  fp64 reference built on the kernel's own side output (so the dropout mask is
+    the kernel's), the side output itself against the formula where nothing is dropped; both product forms; twice -> bits."""
+    from glass_amd import ops, stack
+    from glass_amd.arena import ParamArena
+    from glass_amd.factory import build_glass
+    torch.manual_seed(N + int(gather))
+    H, z = 128, 0.8
+    model = build_glass(H, 1, 5, 3, "mean", "sum", z).to(DEV).train()
+    ParamArena(model)
+    st = model.conv.convs[0]._stack["trans"]
+    W, b = st[0].double(), st[1].double()
+    mask = (torch.rand(N, device=DEV) < 0.1).to(torch.uint8)
+    mask[-1] = 1
+    V = 37
+    src = torch.randn(V if gather else N, H, device=DEV)
+    idx = torch.randint(0, V, (N,), device=DEV, dtype=torch.int64) if gather else None
+    scale, shift = torch.rand(H, device=DEV) + 0.5, torch.randn(H, device=DEV) * 0.1
+    saved = torch.cat([torch.zeros(H, device=DEV), torch.ones(H, device=DEV), scale, shift]).contiguous()
+    nblk = -(-N // int(stack._lib.load().glass_dual_linear_stat_rows(H)))
+    rows = src[idx] if gather else src
+    h_formula = torch.nn.functional.elu(rows.double() * scale.double() + shift.double())
+    lab = mask.bool().unsqueeze(1)
+    prev = ops.DENSE_F32_PRODUCTS
+    try:
+        for form in (False, True):
+            ops.DENSE_F32_PRODUCTS = form
+            got = []
+            for _ in range(2):
+                T = torch.full((N, 2 * H), float("nan"), device=DEV)
+                out = torch.full((N, H), float("nan"), device=DEV)
+                side = torch.full((N, H), float("nan"), device=DEV)
+                cstat = torch.full((nblk, 2, H), float("nan"), dtype=torch.float64, device=DEV)
+                stack._dual_fwd(src, None, st, mask, z, 1, T, out, cstat, gn=(saved, 1, p_drop, 3, side), xa_index=idx)
+                got.append((T, out, side, cstat))
+            T, out, side, cstat = got[0]
+            if p_drop == 0.0:
+                assert rel_inf(side.double(), h_formula) < TOL
+            else:   # kept elements scaled by 1 / (1 - p), about half of them dropped
+                kept = side != 0
+                assert 0.4 < float(kept.float().mean()) < 0.6
+                assert rel_inf(side.double()[kept], (h_formula / (1 - p_drop))[kept]) < TOL
+            Tref = side.double() @ W.t() + b
+            A = torch.nn.functional.elu(Tref)
+            oref = torch.where(lab, z * A[:, :H] + (1 - z) * A[:, H:], (1 - z) * A[:, :H] + z * A[:, H:])
+            e_T, e_o = rel_inf(T.double(), Tref), rel_inf(out.double(), oref)
+            e_s, e_q = rel_inf(cstat[:, 0].sum(0), oref.sum(0)), rel_inf(cstat[:, 1].sum(0), (oref * oref).sum(0))
+            assert max(e_T, e_o, e_s, e_q) < TOL, (form, e_T, e_o, e_s, e_q)
+            for a, b2 in zip(got[0], got[1]):
+                assert torch.equal(a, b2)
+            if not form:
+                record_parity(f"kernel/trans_fwd128_stage_run_N{N}_gather{int(gather)}_p{p_drop}", T_rel_inf=e_T, out_rel_inf=e_o,
+                              stats_rel_inf=max(e_s, e_q))
+    finally:
+        ops.DENSE_F32_PRODUCTS = prev
+
+
 @pytest.mark.parametrize("N,labeled", [(50003, "few"), (50003, "none"), (5000, "all"), (63, "few"), (17080, "dense"), (1100000, "few")])
 def test_comb_dgrad_hidden128_stage_run(N, labeled):
     """Comb pair's data gradient at hidden 128 (comb_dgrad3_kernel: a workgroup walks its rows with the UNLABELED effective
