@@ -488,7 +488,8 @@ __global__ __launch_bounds__(kTThreads, (BM == 64 && !S3) ? 3 : 2) void tiled_fw
 // out[N, NOUT] = dZ[N, 2H] @ Wstack[2H, NOUT] (+ addend)(* dropout mask), dZ[n, o] = coef(n, o < H) * dsrc[n, o mod H]
 // * act'(T[n, o]) synthesised while staging; WTimg = Wstack^T packed plain-tiled: a lane holds four consecutive output
 // columns (cb = 0..3).
-// SPLIT (hidden 128, trans pair: a 128-wide output would fill only half of the 256-slot column tile): the product is
+// SPLIT — kept for reference, NOT instantiated since round 6 (hidden 128's trans pair runs trans_dgrad2 / trans_dgrad3 of dense.hip) —
+// (hidden 128, trans pair: a 128-wide output would fill only half of the 256-slot column tile): the product is
 // dZ1 @ W1 + dZ0 @ W0 with both terms [N, 128] — the two wave columns of the workgroup take one term each: the left
 // pair of waves multiplies the f1 half (its own A image) into column slots 0..127, the right pair the f0 half into slots
 // 128..255, K is H instead of 2H, and the right pair hands its accumulators to the left through LDS before the epilogue.
