@@ -3435,10 +3435,14 @@ static int dgrad_launch(const float* dsrc, int64_t ldd, const float* T, int64_t 
         GLASS_REQUIRE(!gn_exact, "dual_linear_dgrad: exact GraphNorm accumulators are served at hidden 64 only");
         const DgradArgs d128{dsrc, ldd, Tp, ldt, mask, zr, omz, act, WT, addend, ldadd, drop, rng_state, out, ldo, n_nodes, gs};
         const int64_t n_tiles = ceil_div(n_nodes, 64);
-        if (lab_knob("GLASS_TRANS_DGRAD3", 1) && n_tiles > 256) {  // more than one round of 64-row tiles: tall tiles, one workgroup per CU (trans_dgrad3_kernel)
+        const bool split3 = tiled_split_products() && lab_knob("GLASS_TRANS_DGRAD3_SPLIT", 1) != 0;  // the call's product form (GLASS_DENSE_F32_PRODUCTS opts out)
+        // more than one round of 64-row tiles: runs of stages, one workgroup per CU (trans_dgrad3_kernel); in the split form that
+        // kernel serves the smaller graphs too, one 64-row tile (four stages) per workgroup
+        if (lab_knob("GLASS_TRANS_DGRAD3", 1) && (n_tiles > 256 || split3)) {
             const int64_t n_stages = ceil_div(n_nodes, 16);
-            const int stages_per_wg = (int)ceil_div(n_stages, 256);  // >= 5 here: never more workgroups than 64-row tiles (the partials' entries)
-            if (tiled_split_products() && lab_knob("GLASS_TRANS_DGRAD3_SPLIT", 1)) {  // the call's product form (GLASS_DENSE_F32_PRODUCTS opts out)
+            int stages_per_wg = (int)ceil_div(n_stages, 256);  // never more workgroups than 64-row tiles (the partials' entries): >= 4 stages each
+            if (stages_per_wg < 4) stages_per_wg = 4;
+            if (split3) {
                 const size_t lds3s = trans_dgrad3_split_lds(128);
                 allow_lds((trans_dgrad3_kernel<128, true>), lds3s);
                 hipLaunchKernelGGL((trans_dgrad3_kernel<128, true>), dim3((unsigned)ceil_div(n_stages, stages_per_wg)), dim3(512), lds3s, st, d128, stages_per_wg);
