@@ -581,8 +581,8 @@ def test_graphnorm_scratch_reuse_stress():
 
 
 # ---------------------------------------------------------------------------------- K5 fused dense
-@pytest.mark.parametrize("H,N", [(64, 17080), (64, 77), (128, 5000), (128, 1030), (128, 50003), (128, 63), (256, 2100), (256, 33),
-                                 (256, 70001), (512, 300)])
+@pytest.mark.parametrize("H,N", [(64, 17080), (64, 77), (128, 5000), (128, 1030), (128, 50003), (128, 63), (128, 1), (128, 17),
+                                 (256, 2100), (256, 33), (256, 70001), (512, 300)])
 @pytest.mark.parametrize("comb", [False, True])
 def test_dual_linear_mix_fused(H, N, comb):
     """Fused (Linear pair + ELU + mix) MFMA kernels vs an fp64 composition of nn.Linear, ELU and the mix:
